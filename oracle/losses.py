@@ -1,0 +1,90 @@
+"""Oracle (test infrastructure): Keras / musket_core losses and metrics, PyTorch-CPU fp32.
+
+Names follow the registry at ``segmentation_pipeline/segmentation.py:15-22`` and the
+loss suggestions at ``segmentation_pipeline/schemas/segmentation.raml:12-21``; the
+composite grammar ``"binary_crossentropy+0.1*dice_loss"`` is documented at
+reference ``README.md:210-214``.  Bodies restate Keras 2.2.4 (TF backend) and
+musket_core.losses (un-vendored: PARITY UNPINNED).  All take probabilities
+(post-activation), like Keras losses do.
+"""
+import re
+
+import numpy as np
+import torch
+
+KERAS_EPSILON = np.float32(1e-7)
+
+
+def binary_crossentropy(y_true, p):
+    """Keras ``binary_crossentropy`` on probabilities, TF backend: clip to
+    [eps, 1-eps], recover logits, sigmoid-CE-with-logits, mean over all axes."""
+    eps = torch.tensor(KERAS_EPSILON)
+    one = torch.tensor(np.float32(1.0))
+    pc = torch.clamp(p, eps, one - eps)
+    z = torch.log(pc / (one - pc))
+    ce = torch.clamp(z, min=0) - z * y_true + torch.log1p(torch.exp(-torch.abs(z)))
+    return ce.mean()
+
+
+def categorical_crossentropy(y_true, p):
+    """Keras ``categorical_crossentropy`` on probabilities (last axis = classes)."""
+    eps = torch.tensor(KERAS_EPSILON)
+    p = p / p.sum(dim=-1, keepdim=True)
+    p = torch.clamp(p, eps, 1.0 - eps)
+    return (-(y_true * torch.log(p)).sum(dim=-1)).mean()
+
+
+def dice_coef(y_true, p, smooth=1.0):
+    inter = (y_true * p).sum()
+    return (2.0 * inter + smooth) / (y_true.sum() + p.sum() + smooth)
+
+
+def dice_loss(y_true, p):
+    """musket_core.losses.dice_coef_loss: 1 - soft dice over the flattened batch."""
+    return 1.0 - dice_coef(y_true, p)
+
+
+def iou_coef(y_true, p, smooth=1.0):
+    inter = (y_true * p).sum()
+    return (inter + smooth) / (y_true.sum() + p.sum() - inter + smooth)
+
+
+def iou_loss(y_true, p):
+    return 1.0 - iou_coef(y_true, p)
+
+
+def dice_metric(y_true, p):
+    """``dice`` metric: soft-dice formula on predictions thresholded at 0.5."""
+    return dice_coef(y_true, (p > 0.5).to(p.dtype))
+
+
+def binary_accuracy(y_true, p):
+    return ((p > 0.5).to(p.dtype) == y_true).to(p.dtype).mean()
+
+
+LOSSES = {
+    "binary_crossentropy": binary_crossentropy,
+    "categorical_crossentropy": categorical_crossentropy,
+    "dice_loss": dice_loss,
+    "iou_loss": iou_loss,
+}
+
+_TERM = re.compile(r"^\s*(?:([0-9.eE+-]+)\s*\*\s*)?([A-Za-z_][A-Za-z0-9_]*)\s*$")
+
+
+def parse_loss(spec):
+    """``"a+w*b"`` -> [(1.0,'a'), (w,'b')]  (reference README.md:210-214)."""
+    out = []
+    for term in spec.split("+"):
+        m = _TERM.match(term)
+        if not m:
+            raise ValueError("cannot parse loss term %r" % term)
+        out.append((float(m.group(1)) if m.group(1) else 1.0, m.group(2)))
+    return out
+
+
+def composite_loss(spec, y_true, p):
+    total = 0.0
+    for w, name in parse_loss(spec):
+        total = total + w * LOSSES[name](y_true, p)
+    return total

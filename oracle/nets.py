@@ -1,0 +1,201 @@
+"""Oracle (test infrastructure): U-Net over a pre-activation ResNet encoder, PyTorch-CPU fp32.
+
+Restates the graph that ``segmentation_pipeline/segmentation.py:113,155`` obtains from
+``segmentation_models.Unet(backbone_name='resnet34', input_shape=(H,W,3), classes=1,
+activation='sigmoid', decoder_block_type='upsampling', decoder_filters=(256,128,64,32,16),
+decoder_use_batchnorm=True)`` - kwargs/defaults from
+``segmentation_pipeline/schemas/segmentation.raml:158-178`` - i.e. segmentation_models 0.2.1
+(``requires.txt:15``) over the classification_models ResNet (``segmentation.py:5``).
+Neither package is vendored or installable here: PARITY UNPINNED (see oracle/__init__.py).
+
+Layouts exposed: activations NHWC, conv kernels HWIO (Keras), BN vectors [C].
+Internally tensors are moved to NCHW for torch.nn.functional primitives.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+STAGE_FILTERS = (64, 128, 256, 512)
+BN_EPS_ENCODER = 2e-5   # classification_models ResNet: BatchNormalization(epsilon=2e-5)
+BN_EPS_DECODER = 1e-3   # Keras BatchNormalization default
+BN_MOMENTUM = 0.99      # Keras default, used by both
+
+
+def _he_uniform(rng, shape):
+    kh, kw, ci, co = shape
+    limit = np.sqrt(6.0 / (kh * kw * ci))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+def _glorot_uniform(rng, shape):
+    kh, kw, ci, co = shape
+    limit = np.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+def _bn(P, name, c, scale=True):
+    if scale:
+        P[name + "/gamma"] = np.ones(c, np.float32)
+    P[name + "/beta"] = np.zeros(c, np.float32)
+    P[name + "/moving_mean"] = np.zeros(c, np.float32)
+    P[name + "/moving_variance"] = np.ones(c, np.float32)
+
+
+def init_unet_resnet(backbone="resnet34", in_ch=3, classes=1,
+                     decoder_filters=(256, 128, 64, 32, 16), seed=42):
+    """Random-init parameter set (he_uniform encoder, glorot_uniform decoder/head)."""
+    rng = np.random.RandomState(seed)
+    units = RESNET_UNITS[backbone]
+    P = OrderedDict()
+    _bn(P, "bn_data", in_ch, scale=False)
+    P["conv0/kernel"] = _he_uniform(rng, (7, 7, in_ch, 64))
+    _bn(P, "bn0", 64)
+    cin = 64
+    for s, (n_units, f) in enumerate(zip(units, STAGE_FILTERS), start=1):
+        for u in range(1, n_units + 1):
+            pre = "stage%d_unit%d_" % (s, u)
+            _bn(P, pre + "bn1", cin)
+            P[pre + "conv1/kernel"] = _he_uniform(rng, (3, 3, cin, f))
+            _bn(P, pre + "bn2", f)
+            P[pre + "conv2/kernel"] = _he_uniform(rng, (3, 3, f, f))
+            if u == 1:
+                P[pre + "sc/kernel"] = _he_uniform(rng, (1, 1, cin, f))
+            cin = f
+    _bn(P, "bn1", cin)
+    skip_ch = (STAGE_FILTERS[2], STAGE_FILTERS[1], STAGE_FILTERS[0], 64, 0)
+    for i, f in enumerate(decoder_filters):
+        pre = "decoder_stage%d_" % i
+        P[pre + "conv1/kernel"] = _glorot_uniform(rng, (3, 3, cin + skip_ch[i], f))
+        _bn(P, pre + "bn1", f)
+        P[pre + "conv2/kernel"] = _glorot_uniform(rng, (3, 3, f, f))
+        _bn(P, pre + "bn2", f)
+        cin = f
+    P["final_conv/kernel"] = _glorot_uniform(rng, (3, 3, cin, classes))
+    P["final_conv/bias"] = np.zeros(classes, np.float32)
+    return P
+
+
+def trainable_names(P, freeze_encoder=False):
+    """Names that receive gradients/updates.  Moving statistics never do."""
+    out = []
+    for k in P:
+        if k.endswith("moving_mean") or k.endswith("moving_variance"):
+            continue
+        if freeze_encoder and not (k.startswith("decoder_") or k.startswith("final_")):
+            continue
+        out.append(k)
+    return out
+
+
+def conv_param_count(P):
+    return int(sum(v.size for k, v in P.items() if k.endswith("/kernel")))
+
+
+class _Ctx:
+    def __init__(self, P, training, taps):
+        self.P = P
+        self.training = training
+        self.taps = taps
+        self.bn_updates = OrderedDict()
+
+    def tap(self, name, t):
+        if self.taps is not None:
+            self.taps[name] = t.permute(0, 2, 3, 1)  # NHWC view
+        return t
+
+
+def _conv(ctx, x, name, stride=1, pad=0):
+    # Keras HWIO -> torch OIHW ; explicit symmetric ZeroPadding2D + 'valid'
+    w = ctx.P[name + "/kernel"].permute(3, 2, 0, 1)
+    b = ctx.P.get(name + "/bias")
+    return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+
+def _bn_apply(ctx, x, name, eps, relu):
+    """Keras BatchNormalization.  Training phase: biased batch variance for the
+    normalisation; moving variance updated with the unbiased estimate
+    (tf.nn.fused_batch_norm behaviour), momentum 0.99."""
+    P = ctx.P
+    c = x.shape[1]
+    gamma = P.get(name + "/gamma")
+    beta = P[name + "/beta"]
+    if ctx.training:
+        mean = x.mean(dim=(0, 2, 3))
+        var = ((x - mean.view(1, c, 1, 1)) ** 2).mean(dim=(0, 2, 3))
+        n = x.numel() // c
+        with torch.no_grad():
+            mm = P[name + "/moving_mean"] * BN_MOMENTUM + mean * (1 - BN_MOMENTUM)
+            mv = P[name + "/moving_variance"] * BN_MOMENTUM + var * (n / max(n - 1, 1)) * (1 - BN_MOMENTUM)
+            ctx.bn_updates[name + "/moving_mean"] = mm.detach().clone()
+            ctx.bn_updates[name + "/moving_variance"] = mv.detach().clone()
+    else:
+        mean = P[name + "/moving_mean"]
+        var = P[name + "/moving_variance"]
+    inv = torch.rsqrt(var + eps)
+    scale = inv if gamma is None else inv * gamma
+    y = (x - mean.view(1, c, 1, 1)) * scale.view(1, c, 1, 1) + beta.view(1, c, 1, 1)
+    return F.relu(y) if relu else y
+
+
+def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
+                        decoder_filters=(256, 128, 64, 32, 16)):
+    """P: dict name -> torch tensor (Keras layouts).  x_nhwc: [N,H,W,C] float32 raw 0..255.
+    Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits)."""
+    ctx = _Ctx(P, training, taps)
+    units = RESNET_UNITS[backbone]
+    x = x_nhwc.permute(0, 3, 1, 2)
+    x = _bn_apply(ctx, x, "bn_data", BN_EPS_ENCODER, relu=False)
+    ctx.tap("bn_data", x)
+    x = _conv(ctx, x, "conv0", stride=2, pad=3)
+    ctx.tap("conv0", x)
+    x = _bn_apply(ctx, x, "bn0", BN_EPS_ENCODER, relu=True)
+    skips = {"relu0": x}
+    ctx.tap("relu0", x)
+    x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), kernel_size=3, stride=2)  # ZeroPadding2D(1) + valid pool
+    ctx.tap("pooling0", x)
+    for s, (n_units, f) in enumerate(zip(units, STAGE_FILTERS), start=1):
+        for u in range(1, n_units + 1):
+            pre = "stage%d_unit%d_" % (s, u)
+            stride = 2 if (u == 1 and s > 1) else 1
+            a = _bn_apply(ctx, x, pre + "bn1", BN_EPS_ENCODER, relu=True)
+            if u == 1:
+                skips[pre + "relu1"] = a
+                ctx.tap(pre + "relu1", a)
+                shortcut = _conv(ctx, a, pre + "sc", stride=stride, pad=0)
+            else:
+                shortcut = x
+            y = _conv(ctx, a, pre + "conv1", stride=stride, pad=1)
+            y = _bn_apply(ctx, y, pre + "bn2", BN_EPS_ENCODER, relu=True)
+            y = _conv(ctx, y, pre + "conv2", stride=1, pad=1)
+            x = y + shortcut
+            ctx.tap(pre + "out", x)
+    x = _bn_apply(ctx, x, "bn1", BN_EPS_ENCODER, relu=True)
+    ctx.tap("relu1", x)
+    skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
+    for i, f in enumerate(decoder_filters):
+        pre = "decoder_stage%d_" % i
+        x = F.interpolate(x, scale_factor=2, mode="nearest")  # UpSampling2D(2)
+        if skip_names[i] is not None:
+            x = torch.cat([x, skips[skip_names[i]]], dim=1)
+        x = _conv(ctx, x, pre + "conv1", pad=1)
+        x = _bn_apply(ctx, x, pre + "bn1", BN_EPS_DECODER, relu=True)
+        x = _conv(ctx, x, pre + "conv2", pad=1)
+        x = _bn_apply(ctx, x, pre + "bn2", BN_EPS_DECODER, relu=True)
+        ctx.tap(pre + "relu2", x)
+    x = _conv(ctx, x, "final_conv", pad=1)
+    logits = x.permute(0, 2, 3, 1).contiguous()
+    return logits, ctx.bn_updates
+
+
+def to_torch(P, requires_grad_names=()):
+    out = OrderedDict()
+    req = set(requires_grad_names)
+    for k, v in P.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)).clone()
+        if k in req:
+            t.requires_grad_(True)
+        out[k] = t
+    return out

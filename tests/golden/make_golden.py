@@ -1,0 +1,86 @@
+"""Regenerates the committed golden fixtures.  Run from the repo root:
+
+    python tests/golden/make_golden.py
+
+* ``rle_golden.json`` - inputs/outputs of the REFERENCE's own
+  ``segmentation_pipeline/impl/rle.py:10-35`` (``rle_encode`` / ``rle_decode``), imported from
+  ``/root/reference`` with a stub for the absent ``skimage`` (only ``multi_rle_encode`` uses it).
+  This is the only part of the reference that can execute in this container.
+* ``unet_resnet18_64.npz`` / ``unet_resnet34_64.npz`` - outputs of the in-repo oracle (PARITY
+  UNPINNED: the reference's Keras path is not runnable) on a seeded synthetic batch; they pin
+  the oracle against drift of itself / of the torch build.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def make_rle():
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        print("reference absent; keeping existing rle_golden.json")
+        return
+    sk = types.ModuleType("skimage")
+    skm = types.ModuleType("skimage.morphology")
+    skm.label = lambda a: a
+    sk.morphology = skm
+    sys.modules["skimage"] = sk
+    sys.modules["skimage.morphology"] = skm
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_rle", os.path.join(ref, "segmentation_pipeline/impl/rle.py"))
+    ref_rle = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_rle)
+    rng = np.random.RandomState(7)
+    cases = []
+    shapes = [(6, 6), (5, 9), (16, 16), (1, 7), (7, 1), (32, 20)]
+    for shp in shapes:
+        for dens in (0.0, 0.15, 0.5, 1.0):
+            m = (rng.uniform(size=shp) < dens).astype(np.uint8)
+            enc = ref_rle.rle_encode(m)
+            dec = ref_rle.rle_decode(enc, shp) if enc else np.zeros(shp, np.uint8).T
+            cases.append({"shape": list(shp), "mask": m.tolist(), "rle": enc,
+                          "decoded_shape": list(dec.shape), "decoded": dec.tolist()})
+    m = np.zeros((6, 6), np.uint8)
+    m[2:5, 1:3] = 1
+    cases.append({"shape": [6, 6], "mask": m.tolist(), "rle": ref_rle.rle_encode(m),
+                  "decoded_shape": [6, 6], "decoded": ref_rle.rle_decode(ref_rle.rle_encode(m), (6, 6)).tolist()})
+    with open(os.path.join(HERE, "rle_golden.json"), "w") as f:
+        json.dump({"source": "reference segmentation_pipeline/impl/rle.py:10-35", "cases": cases}, f)
+    print("rle cases", len(cases))
+
+
+def make_unet(backbone, size, n, fname):
+    from oracle import nets, step
+    P = nets.init_unet_resnet(backbone, seed=42)
+    tr = step.OracleTrainer(P, backbone=backbone, loss="binary_crossentropy+1.0*dice_loss",
+                            optimizer="adam", lr=1e-3)
+    x, y = step.synthetic_batch(n, size, size, seed=1234)
+    xf, yf = x.astype(np.float32), y.astype(np.float32)
+    o1 = tr.step(xf, yf)
+    o2 = tr.step(xf, yf)
+    names = list(o1["grads"].keys())
+    np.savez_compressed(
+        os.path.join(HERE, fname),
+        x=x, y=y, seed=42,
+        logits1=o1["logits"].astype(np.float32), logits2=o2["logits"].astype(np.float32),
+        scalars1=np.array([o1[k] for k in ("loss", "bce", "dice_loss", "dice", "binary_accuracy")], np.float64),
+        scalars2=np.array([o2[k] for k in ("loss", "bce", "dice_loss", "dice", "binary_accuracy")], np.float64),
+        grad_names=np.array(names),
+        grad_l2_step1=np.array([np.sqrt((o1["grads"][k].astype(np.float64) ** 2).sum()) for k in names]),
+        param_sum_after2=np.array([tr.P[k].astype(np.float64).sum() for k in names]),
+        param_abs_after2=np.array([np.abs(tr.P[k].astype(np.float64)).sum() for k in names]),
+    )
+    print(fname, "loss", o1["loss"], o2["loss"], "dice", o1["dice"])
+
+
+if __name__ == "__main__":
+    make_rle()
+    make_unet("resnet18", 64, 2, "unet_resnet18_64.npz")
+    make_unet("resnet34", 64, 2, "unet_resnet34_64.npz")

@@ -1,0 +1,128 @@
+"""CPU tests: the oracle against its golden vectors and against naive numpy restatements."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import losses, nets, np_ops, optim, step
+
+
+def test_conv_param_count_matches_published_unet_resnet34():
+    # ~24.4 M parameters is the publicly quoted size of Unet('resnet34').
+    P = nets.init_unet_resnet("resnet34")
+    assert nets.conv_param_count(P) == 24421456
+
+
+@pytest.mark.parametrize("backbone", ["resnet18", "resnet34"])
+def test_oracle_matches_golden(golden_dir, backbone):
+    g = np.load(os.path.join(golden_dir, "unet_%s_64.npz" % backbone))
+    P = nets.init_unet_resnet(backbone, seed=int(g["seed"]))
+    tr = step.OracleTrainer(P, backbone=backbone, loss="binary_crossentropy+1.0*dice_loss",
+                            optimizer="adam", lr=1e-3)
+    xf, yf = g["x"].astype(np.float32), g["y"].astype(np.float32)
+    o1 = tr.step(xf, yf)
+    o2 = tr.step(xf, yf)
+    keys = ("loss", "bce", "dice_loss", "dice", "binary_accuracy")
+    np.testing.assert_allclose([o1[k] for k in keys], g["scalars1"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose([o2[k] for k in keys], g["scalars2"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(o1["logits"], g["logits1"], atol=2e-4)
+    names = [str(s) for s in g["grad_names"]]
+    l2 = np.array([np.sqrt((o1["grads"][k].astype(np.float64) ** 2).sum()) for k in names])
+    np.testing.assert_allclose(l2, g["grad_l2_step1"], rtol=1e-3, atol=1e-6)
+
+
+def test_rle_golden_vectors_from_reference(golden_dir):
+    """The in-repo RLE restatement against vectors produced by the reference's own rle.py."""
+    from segmentation_pipeline.impl import rle
+    with open(os.path.join(golden_dir, "rle_golden.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 20
+    for c in cases:
+        m = np.array(c["mask"], np.uint8).reshape(c["shape"])
+        assert rle.rle_encode(m) == c["rle"]
+        if c["rle"]:
+            dec = rle.rle_decode(c["rle"], tuple(c["shape"]))
+            assert dec.shape == tuple(c["decoded_shape"])
+            np.testing.assert_array_equal(dec, np.array(c["decoded"], np.uint8))
+
+
+def test_np_conv_matches_torch():
+    rng = np.random.RandomState(0)
+    for (h, w, ci, co, k, s, p) in [(9, 11, 5, 7, 3, 1, 1), (12, 12, 4, 6, 3, 2, 1), (16, 14, 3, 8, 7, 2, 3),
+                                    (8, 8, 6, 4, 1, 2, 0)]:
+        x = rng.randn(2, h, w, ci).astype(np.float32)
+        wt = rng.randn(k, k, ci, co).astype(np.float32)
+        ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(wt).permute(3, 2, 0, 1),
+                       stride=s, padding=p).permute(0, 2, 3, 1).numpy()
+        np.testing.assert_allclose(np_ops.conv2d(x, wt, s, p), ref, atol=1e-4)
+        # gradients vs autograd
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+        wtt = torch.from_numpy(wt).permute(3, 2, 0, 1).requires_grad_(True)
+        out = F.conv2d(xt, wtt, stride=s, padding=p)
+        dy = rng.randn(*out.shape).astype(np.float32)
+        out.backward(torch.from_numpy(dy))
+        dy_nhwc = dy.transpose(0, 2, 3, 1)
+        np.testing.assert_allclose(np_ops.conv2d_dgrad(dy_nhwc, wt, (h, w), s, p),
+                                   xt.grad.permute(0, 2, 3, 1).numpy(), atol=1e-4)
+        np.testing.assert_allclose(np_ops.conv2d_wgrad(x, dy_nhwc, (k, k), s, p),
+                                   wtt.grad.permute(2, 3, 1, 0).numpy(), atol=2e-4)
+
+
+def test_np_bn_pool_upsample_match_oracle_net_ops():
+    rng = np.random.RandomState(1)
+    x = rng.randn(2, 8, 8, 6).astype(np.float32) * 3 + 1
+    gamma = rng.rand(6).astype(np.float32) + 0.5
+    beta = rng.randn(6).astype(np.float32)
+    P = {"b/gamma": torch.from_numpy(gamma), "b/beta": torch.from_numpy(beta),
+         "b/moving_mean": torch.zeros(6), "b/moving_variance": torch.ones(6)}
+    ctx = nets._Ctx(P, True, None)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+    y = nets._bn_apply(ctx, xt, "b", 1e-3, relu=False)
+    yn, mean, var = np_ops.bn_train(x, gamma, beta, 1e-3)
+    np.testing.assert_allclose(y.detach().permute(0, 2, 3, 1).numpy(), yn, atol=1e-5)
+    n = 2 * 8 * 8
+    np.testing.assert_allclose(ctx.bn_updates["b/moving_variance"].numpy(),
+                               0.99 + 0.01 * var * n / (n - 1), rtol=1e-5)
+    dy = rng.randn(2, 8, 8, 6).astype(np.float32)
+    y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    dx, dg, db = np_ops.bn_train_bwd(x, dy, gamma, 1e-3)
+    np.testing.assert_allclose(xt.grad.permute(0, 2, 3, 1).numpy(), dx, atol=1e-5)
+    np.testing.assert_allclose(P["b/gamma"].grad if P["b/gamma"].grad is not None else dg, dg)
+    # pool / upsample
+    xp = F.max_pool2d(F.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(np_ops.maxpool3x3s2(x), xp)
+    up = F.interpolate(torch.from_numpy(x).permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1).numpy()
+    np.testing.assert_array_equal(np_ops.upsample2x(x), up)
+    np.testing.assert_allclose(np_ops.upsample2x_bwd(np_ops.upsample2x(x)), 4 * x, rtol=1e-6)
+
+
+def test_keras_adam_known_answer():
+    # one parameter, g = 0.5: m=0.05, v=2.5e-4, lr_t = 1e-3*sqrt(1-.999)/(1-.9)
+    opt = optim.Adam(lr=1e-3)
+    p = {"w": np.array([1.0], np.float32)}
+    opt.step(p, {"w": np.array([0.5], np.float32)})
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    expect = 1.0 - lr_t * 0.05 / (np.sqrt(2.5e-4) + 1e-7)
+    np.testing.assert_allclose(p["w"], [expect], rtol=1e-6)
+    # SGD momentum form v = mu*v - lr*g ; p += v
+    sgd = optim.SGD(lr=0.1, momentum=0.9)
+    p = {"w": np.array([1.0], np.float32)}
+    sgd.step(p, {"w": np.array([1.0], np.float32)})
+    sgd.step(p, {"w": np.array([1.0], np.float32)})
+    np.testing.assert_allclose(p["w"], [1.0 - 0.1 - (0.09 + 0.1)], rtol=1e-6)
+
+
+def test_losses_basic_properties():
+    y = torch.tensor([[1.0, 0.0, 1.0, 0.0]])
+    p = torch.tensor([[0.9, 0.1, 0.8, 0.3]])
+    bce = losses.binary_crossentropy(y, p)
+    ref = -(np.log(0.9) + np.log(0.9) + np.log(0.8) + np.log(0.7)) / 4
+    assert abs(float(bce) - ref) < 1e-6
+    d = losses.dice_loss(y, p)
+    assert abs(float(d) - (1 - (2 * 1.7 + 1) / (2 + 2.1 + 1))) < 1e-6
+    assert losses.parse_loss("binary_crossentropy+0.1*dice_loss") == [(1.0, "binary_crossentropy"), (0.1, "dice_loss")]
+    # clipping: p == 1 exactly with y == 0 stays finite (Keras epsilon clip)
+    assert np.isfinite(float(losses.binary_crossentropy(torch.zeros(1), torch.ones(1))))
