@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: U-Net/ResNet-34 training step, 512x512x3 -> 1 class, batch 16 per GPU,
+bf16 MFMA (BASELINE.json configs[1]; configs[2] with --gpus 8 under torch.distributed.run).
+
+One "step" = on-device augmentation of the resident uint8 batch + weight compute copies + forward +
+sigmoid/BCE/Dice loss + backward + (RCCL gradient all-reduce when N > 1) + Adam.  Raw images and
+masks are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        bench.py --gpus 8 --steps 20 --warmup 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 512
+BATCH = 16
+LOSS = "binary_crossentropy+1.0*dice_loss"
+# algorithmic work per trained image (BASELINE.md 3 / SURVEY 8d): conv MACs only, 2 FLOP/MAC, 3x forward
+FLOP_PER_IMAGE = 187.94e9
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+CONV_TILES = {1: "128, 128, 2, 2", 2: "64, 256, 1, 4", 3: "32, 256, 1, 4", 4: "16, 256, 1, 4", 5: "64, 64, 2, 2", 6: "128, 64, 4, 1"}
+
+
+def wgrad_tile(cout):
+    return "16, 256, 1, 4" if cout <= 16 else "32, 256, 1, 4" if cout <= 32 else "64, 128, 1, 4" if cout <= 64 else "128, 128, 2, 2"
+
+
+def kernel_key(name, meta, dtype):
+    t = "unsigned short" if dtype == "bf16" else "float"
+    if name == "stp_conv2d":
+        c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
+        return "conv_igemm_kernel<%s, %s, %s>" % (t, CONV_TILES[meta["tile"]], c4)
+    if name == "stp_conv2d_wgrad":
+        c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
+        return "conv_wgrad_kernel<%s, %s, %s>" % (t, wgrad_tile(meta["cout"]), c4)
+    return name
+
+
+def per_kernel_profile(model, reps=3):
+    """Eager instrumented passes: every launch of the step bracketed by HIP events on the stream the
+    kernels run on (torch's current stream).  Returns {kernel: [launches, seconds, flops]} per step."""
+    p = model.plan
+    st = torch.cuda.current_stream()
+    launches = [(l, "prep") for l in p.prep] + [(l, "fwd") for l in p.fwd] + [(l, "bwd") for l in p.bwd]
+    acc = {}
+    saved = [t.clone() for t in model._mutable_state()]
+    for rep in range(reps + 1):
+        evs = []
+        for (fn, args, name, meta), _ in launches:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = fn(*args, st.cuda_stream)
+            e1.record(st)
+            if rc != 0:
+                raise RuntimeError("%s failed (%d)" % (name, rc))
+            evs.append((name, meta, e0, e1))
+        torch.cuda.synchronize()
+        if rep == 0:
+            continue  # first pass warms caches / clocks
+        for name, meta, e0, e1 in evs:
+            key = kernel_key(name, meta, model.dtype) if meta else name
+            a = acc.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += meta["flops"] if meta else 0.0
+    for t, s in zip(model._mutable_state(), saved):
+        t.copy_(s)
+    return {k: [v[0] / reps, v[1] / reps, v[2] / reps] for k, v in acc.items()}
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The in-repo CPU oracle (a PORT: the reference's Keras-CPU fit() is not installable here, see
+    BASELINE.md 2) running the same step on a bounded sample: U-Net/ResNet-34, 512x512, batch 2."""
+    from oracle import nets as onets
+    from oracle import step as ostep
+    n = 2
+    P = onets.init_unet_resnet("resnet34", seed=42)
+    tr = ostep.OracleTrainer(P, backbone="resnet34", loss=LOSS, optimizer="adam", lr=1e-3)
+    x, y = ostep.synthetic_batch(n, H, W, seed=1234)
+    xf, yf = x.astype(np.float32), y.astype(np.float32)
+    tr.step(xf, yf)  # warm-up
+    steps, t0 = 0, time.time()
+    while steps < 1 or (time.time() - t0 < seconds_budget * 0.6 and steps < 4):
+        tr.step(xf, yf)
+        steps += 1
+    dt = time.time() - t0
+    return {"value": round(n * steps / dt, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "oracle (PyTorch-CPU fp32) training step, U-Net/ResNet34 512x512x3, batch %d, %d timed steps after 1 warm-up, "
+                      "no augmentation" % (n, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph (for rocprofv3 kernel traces of the launches themselves)")
+    args = ap.parse_args()
+
+    from segmentation_training_pipeline_amd import augment, distributed, ops
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+
+    rank, local_rank, world = distributed.env_world()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...` (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    distributed.init("nccl")
+    dev = torch.device("cuda", local_rank)
+
+    model = HipSegModel("Unet", "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
+                        lr=1e-3, use_graph=not args.eager, device=str(dev))
+    if world > 1:
+        model.set_data_parallel(distributed.GradReducer(bucket_mb=32.0))
+
+    # synthetic data: uniform uint8 images, 3 random discs per mask, seed 1234 + rank
+    rng = np.random.RandomState(1234 + rank)
+    img = rng.randint(0, 256, size=(BATCH, H, W, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    msk = np.zeros((BATCH, H, W), np.uint8)
+    for i in range(BATCH):
+        for _ in range(3):
+            cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(0.08, 0.22) * H
+            msk[i] |= ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r).astype(np.uint8)
+    raw_img, raw_msk = torch.from_numpy(img).to(dev), torch.from_numpy(msk).to(dev)
+    total = args.steps + args.warmup
+    prm = np.stack([augment.sample_batch(augment.BENCH_SPEC, rng, BATCH, H, W, (H, W)) for _ in range(total)])
+    prm = torch.from_numpy(prm).to(dev)
+    in_img, in_msk = model.plan.inputs["image"].buf, model.plan.inputs["mask"].buf
+
+    def step(i):
+        ops.augment_u8(raw_img, raw_msk, in_img, in_msk, prm[i], BATCH, H, W, H, W, 3)
+        model.train_on_batch(None, None, fetch=False)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    metrics = model.metrics()
+    images_per_sec = world * BATCH * args.steps / elapsed
+
+    out = {
+        "metric": "images/sec U-Net/ResNet34 512x512 bs16 training step", "value": round(images_per_sec, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "U-Net/ResNet34 512x512x3 1-class, batch 16 per GPU, BCE+Dice, Adam, on-device augment "
+                               "(BASELINE.json configs[1]%s)" % ("; configs[2] data-parallel" if world > 1 else ""),
+                   "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                   "hipgraph": not args.eager, "loss_after_run": round(metrics["loss"], 5)},
+        "step_mfma_frac": round(images_per_sec / world * FLOP_PER_IMAGE / (PEAK_BF16_TFLOPS * 1e12), 4),
+    }
+    if rank == 0 and not args.no_kernel_profile:
+        prof = per_kernel_profile(model)
+        tot = sum(v[1] for v in prof.values())
+        gemm = {k: v for k, v in prof.items() if v[2] > 0}
+        dom = max(gemm, key=lambda k: gemm[k][1])
+        n_l, sec, fl = gemm[dom]
+        ach = fl / sec / 1e12
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
+                           "share_of_step_kernel_time": round(sec / tot, 3)}
+        top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]
+        out["kernel_time_us"] = {k: [round(v[0], 1), round(1e6 * v[1], 1), round(v[2] / v[1] / 1e12, 1) if v[2] else None] for k, v in top}
+        out["kernel_time_total_us"] = round(1e6 * tot, 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+/*
+ * stp_hip.h - C-ABI of the MI355X-native segmentation training hot path (libstp_hip.so).
+ *
+ * Boundary contract (last row): the reference has no native layer at all - its
+ * hot loop is Keras `fit_generator` over TF/cuDNN ops reached from
+ * segmentation_pipeline/segmentation.py:35 (GenericImageTaskConfig.fit) and :155
+ * (`clazz(**cleaned)` -> segmentation_models.Unet graph).  Each entry point below replaces the
+ * TF op family named in its comment; the Python host mirror that binds them with ctypes lives
+ * in segmentation_training_pipeline_amd/_lib.py, and INTEGRATION.md shows the reference-side
+ * stub.
+ *
+ * Rules for every entry point:
+ *   - plain pointers / ints / floats / hipStream_t only (passed as void*); no C++ or torch types;
+ *   - the caller owns every buffer (device memory, 16-byte aligned); nothing here allocates;
+ *   - stream-ordered, never synchronises, safe to capture into a hipGraph;
+ *   - returns 0 on success, <0 on error (STP_E_*); never throws;
+ *   - re-entrant on distinct streams/workspaces.
+ *
+ * Tensors: activations NHWC dense; dtype 0 = fp32, 1 = bf16 (storage of activations and of the
+ * compute copies of weights; accumulation is always fp32; master weights/grads/optimizer
+ * state are always fp32).
+ */
+#ifndef STP_HIP_H
+#define STP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STP_OK 0
+#define STP_E_BADARG (-1)
+#define STP_E_LAUNCH (-2)
+#define STP_E_WORKSPACE (-3)
+
+#define STP_F32 0
+#define STP_BF16 1
+
+/* How src0 is resampled into the virtual input plane of the implicit GEMM gather. */
+#define STP_SRC_DIRECT 0     /* virtual (h,w) = src (h,w)                                        */
+#define STP_SRC_NEAREST2X 1  /* UpSampling2D(2): virtual (h,w) reads src (h/2,w/2)               */
+#define STP_SRC_ZEROINS2X 2  /* zero-insertion: virtual (h,w) reads src (h/2,w/2) iff both even  */
+                             /* (data-gradient of a stride-2 convolution)                        */
+
+int stp_abi_version(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA.  Replaces keras.layers.Conv2D forward and the
+ * Conv2DBackpropInput op of its gradient (reference call site segmentation.py:155 builds the
+ * graph; schemas/segmentation.raml:158-178 names the decoder it produces).
+ *
+ * virtual input  V[n,h,w,c] = concat_c( resample(src0)[.., C0], src1[.., C1] ), h<Hv, w<Wv
+ * out[n,ho,wo,co] = sum_{kh,kw,c} V[n, ho*stride - pad + kh, wo*stride - pad + kw, c]
+ *                                 * weight[co][(kh*KW + kw)*(C0+C1) + c]
+ *                   (+ bias[co]) (+ residual[n,ho,wo,co]) (ReLU if relu)
+ * Output channels [0,Cd0) go to dst0 (row stride Cd0), [Cd0,Cout) to dst1 (row stride
+ * Cout-Cd0); each destination either overwrites or accumulates (+=).
+ * Constraints: C0, C1 multiples of 8 (bf16) / 4 (fp32), or C0 == 4 && C1 == 0 (stem, KW even);
+ * Cd0 and Cout-Cd0 multiples of 4 unless Cout < 4 is handled by padding the weight rows
+ * (Cout is then the number of valid rows; only those are stored).
+ */
+typedef struct stp_conv_params {
+  const void* src0;     /* [N,Hs0,Ws0,C0]                       */
+  const void* src1;     /* [N,Hv,Wv,C1] or NULL                 */
+  const void* weight;   /* [Cout_pad][KH*KW*(C0+C1)] dtype      */
+  const float* bias;    /* [Cout] or NULL                       */
+  const void* residual; /* [N,Ho,Wo,Cout] dtype or NULL         */
+  void* dst0;           /* [N,Ho,Wo,Cd0]                        */
+  void* dst1;           /* [N,Ho,Wo,Cout-Cd0] or NULL           */
+  int32_t N, Hs0, Ws0, Hv, Wv, C0, C1;
+  int32_t src0_mode;    /* STP_SRC_*                            */
+  int32_t KH, KW, stride, pad;
+  int32_t Ho, Wo, Cout, Cd0;
+  int32_t accumulate0, accumulate1, relu;
+  int32_t dtype;        /* STP_F32 / STP_BF16                   */
+  int32_t tile;         /* 0 = auto; else forces a tile config (testing/tuning) */
+} stp_conv_params;
+
+int stp_conv2d(const stp_conv_params* p, void* stream);
+/* tile configuration stp_conv2d would pick for p (1..6: 128x128, 64x256, 32x256, 16x256, 64x64,
+ * 128x64 = output channels x pixels per workgroup); used by bench.py's per-kernel roofline. */
+int stp_conv2d_tile_for(const stp_conv_params* p);
+
+/* ----------------------------------------------------------------------------------------------
+ * Weight gradient (Conv2DBackpropFilter).  dW[co][(kh*KW+kw)*(C0+C1)+c] =
+ *   sum_{n,ho,wo} dY[n,ho,wo,co] * V[n, ho*stride-pad+kh, wo*stride-pad+kw, c]
+ * with V gathered exactly as in stp_conv2d.  Pixels are split over `splits` slabs written to
+ * `workspace` ([splits][Cout][K] fp32) and reduced in fixed order (deterministic).
+ * dW is fp32 [Cout][K]; accumulate != 0 adds to it.
+ */
+typedef struct stp_wgrad_params {
+  const void* src0;
+  const void* src1;
+  const void* dy;       /* [N,Ho,Wo,Cout] dtype */
+  float* dw;            /* [Cout][K] fp32       */
+  int32_t N, Hs0, Ws0, Hv, Wv, C0, C1, src0_mode;
+  int32_t KH, KW, stride, pad;
+  int32_t Ho, Wo, Cout;
+  int32_t accumulate;
+  int32_t dtype;
+  int32_t splits;       /* 0 = auto */
+} stp_wgrad_params;
+
+size_t stp_conv2d_wgrad_workspace_bytes(const stp_wgrad_params* p);
+int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Compute copies of a convolution kernel from the fp32 master (layout [Cout][KH][KW][Cin]):
+ *   fwd : [Cout_pad16][KH][KWp][Cinp] dtype, zero padded (operand of stp_conv2d / layout of dW)
+ *   bwd : [Cin_pad16][KH][KW][CoutB]  dtype, spatially flipped and transposed, zero padded
+ *         (operand of the data-gradient GEMM: stp_conv2d over dY with pad' = K-1-pad)
+ * Either pointer may be NULL.  stp_weight_grad_unpad copies a padded gradient
+ * [Cout..][KH][KWp][Cinp] back to the master layout.  stp_stem_beta_grad: see loss_optim.hip.
+ */
+int stp_weight_prepare(const float* master, void* fwd, void* bwd, int32_t Cout, int32_t KH, int32_t KW,
+                       int32_t Cin, int32_t KWp, int32_t Cinp, int32_t CoutB, int32_t dtype, void* stream);
+int stp_weight_grad_unpad(const float* padded, float* grad, int32_t Cout, int32_t KH, int32_t KW,
+                          int32_t Cin, int32_t KWp, int32_t Cinp, int32_t accumulate, void* stream);
+int stp_stem_beta_grad(const float* padded_dw, const float* master, float* dbeta, int32_t Cout, int32_t KH,
+                       int32_t KW, int32_t Cin, int32_t KWp, int32_t Cinp, int32_t one_ch, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * BatchNormalization (Keras semantics: biased batch variance for the normalisation, unbiased
+ * for the moving variance, momentum on the moving stats).  Replaces keras BatchNormalization /
+ * tf.nn.fused_batch_norm + ReLU, forward and gradient.
+ *   stp_bn_stats     : per-channel mean and rstd (= 1/sqrt(var+eps)) over `rows` = N*H*W, plus the
+ *                      moving-stat update (either may be NULL).  workspace: stp_bn_workspace_bytes.
+ *   stp_bn_apply     : y = (x-mean)*rstd*gamma + beta, optional ReLU.  For uint8 input
+ *                      (xdtype = STP_U8, C <= 4, the raw image) Cy must be 4 and the padded
+ *                      channels are written as pad_value; otherwise Cy == C and xdtype == ydtype.
+ *   stp_bn_inference : same with rstd derived from the moving variance.
+ *   stp_bn_backward  : dy is the gradient w.r.t. the (post-ReLU) output; the ReLU mask is
+ *                      re-derived from x (same single-fma affine as the forward).  Produces dx
+ *                      (optionally accumulating) and the raw sums dgamma / dbeta (may be NULL).
+ * gamma and beta may be NULL (scale=False / center=False).
+ */
+#define STP_U8 2
+size_t stp_bn_workspace_bytes(int32_t C);
+int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t C, float eps, float momentum,
+                 float* mean, float* rstd, float* moving_mean, float* moving_var,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int stp_bn_apply(const void* x, int32_t xdtype, void* y, int32_t ydtype, int64_t rows, int32_t C, int32_t Cy,
+                 const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 int32_t relu, float pad_value, void* stream);
+int stp_bn_inference(const void* x, int32_t xdtype, void* y, int32_t ydtype, int64_t rows, int32_t C, int32_t Cy,
+                     const float* moving_mean, const float* moving_var, float eps,
+                     const float* gamma, const float* beta, int32_t relu, float pad_value, void* stream);
+int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t dtype, int64_t rows, int32_t C,
+                    const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    float* dgamma, float* dbeta, int32_t relu, int32_t accumulate_dx,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ZeroPadding2D(1) + MaxPooling2D(3, strides 2, 'valid') (classification_models ResNet stem).
+ * idx [N,Ho,Wo,C] uint8 records kh*3+kw of the first maximum (padded taps compete with value 0);
+ * the gradient routes dy through it (TF MaxPoolGrad behaviour). */
+int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C,
+                     int32_t dtype, void* stream);
+int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t dtype, int32_t accumulate, void* stream);
+
+/* Gradient of UpSampling2D(2): dx[n,h,w,c] (+)= sum of the 2x2 block of dy ([N,2H,2W,ldy]). */
+int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,
+                       int32_t dtype, int32_t accumulate, void* stream);
+
+/* Bias gradient: out[c] (+)= sum over rows of x[rows][C]; and the in-place tensor add used where two
+ * gradient paths meet outside a GEMM epilogue.  workspace as for stp_bn_stats. */
+int stp_channel_sum(const void* x, int32_t dtype, int64_t rows, int32_t C, float* out, int32_t accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int stp_add_inplace(void* dst, const void* src, int64_t count, int32_t dtype, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Segmentation head + loss.  logits -> sigmoid -> w_bce*binary_crossentropy + w_dice*dice_loss
+ * (Keras TF-backend BCE with the 1e-7 probability clip; musket dice_coef_loss, smooth 1), the
+ * metrics (dice at 0.5, binary_accuracy) and dL/dlogits (channel 0 of a [count][dl_channels]
+ * tensor, other channels zero, so it can feed the 8-channel-granular gather of the GEMMs).
+ * scalars (fp32[8]): loss, bce, dice_loss, dice_metric, binary_accuracy, sum_p, sum_y, sum_py.
+ * Two-stage, fixed-order reduction (deterministic).
+ */
+size_t stp_loss_workspace_bytes(void);
+int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, int64_t count, int32_t dtype,
+                         float w_bce, float w_dice, float* scalars, void* dlogits, int32_t dl_channels,
+                         float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Optimizers over a flat fp32 arena (Keras 2.2.4 update rules, schemas/segmentation.raml:77-89).
+ * `state` is a device int32[2]: [0] = iteration counter (incremented by the launch, so a captured
+ * graph advances), [1] = scratch for the bias-corrected step size.  count must be a multiple of 4.
+ * lr lives in device memory (lr[0]) so callbacks can change it without re-capturing.
+ * mask (uint8, optional) freezes elements where mask[i] == 0 (freeze_encoder).
+ * gscale (device float, optional) multiplies the gradient (clipnorm / 1/world_size).
+ */
+int stp_adam(float* param, const float* grad, float* m, float* v, int64_t count, const float* lr,
+             float beta1, float beta2, float eps, int32_t* state, const uint8_t* mask, const float* gscale,
+             float clipvalue, void* stream);
+int stp_sgd(float* param, const float* grad, float* vel, int64_t count, const float* lr, float momentum,
+            int32_t nesterov, const uint8_t* mask, const float* gscale, float clipvalue, void* stream);
+/* gscale[0] = min(1, clipnorm / ||base*grad||_2) * base  (base = 1/world_size for summed data-parallel
+ * gradients; deterministic two-stage reduction).  workspace >= 4 KiB. */
+int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, float base, float* gscale,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * On-device augmentation (replaces the imgaug worker processes, schemas/augmenters.raml:43-133).
+ * One fused pass per batch: inverse affine warp (flip/scale/translate/rotate/shear composed on
+ * the host into a 2x3 matrix per sample), bilinear for the image (constant 0 border, result
+ * rounded to uint8 like imgaug), nearest for the mask, then Add / Multiply colour ops.
+ * params per sample (float[10]): m00 m01 m02 m10 m11 m12 (output->input pixel map), add, mul, 0, 0
+ */
+int stp_augment_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out,
+                   const float* params, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+                   int32_t C, void* stream);
+
+/* Gradient-bucket helpers for the RCCL all-reduce (fp32 <-> bf16 wire format). */
+int stp_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);
+int stp_cast_bf16_to_f32(const void* src, float* dst, int64_t count, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STP_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libstp_hip.so (C-ABI declared in include/stp_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails this
+raises.  PyTorch is used by callers only for device memory, streams and process groups;
+pointers cross the boundary as plain integers (``tensor.data_ptr()``).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstp_hip.so")
+
+F32, BF16, U8 = 0, 1, 2
+SRC_DIRECT, SRC_NEAREST2X, SRC_ZEROINS2X = 0, 1, 2
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class StpError(RuntimeError):
+    pass
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("src0", vp), ("src1", vp), ("weight", vp), ("bias", vp), ("residual", vp), ("dst0", vp), ("dst1", vp),
+                ("N", i32), ("Hs0", i32), ("Ws0", i32), ("Hv", i32), ("Wv", i32), ("C0", i32), ("C1", i32),
+                ("src0_mode", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
+                ("Ho", i32), ("Wo", i32), ("Cout", i32), ("Cd0", i32),
+                ("accumulate0", i32), ("accumulate1", i32), ("relu", i32), ("dtype", i32), ("tile", i32)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [("src0", vp), ("src1", vp), ("dy", vp), ("dw", vp),
+                ("N", i32), ("Hs0", i32), ("Ws0", i32), ("Hv", i32), ("Wv", i32), ("C0", i32), ("C1", i32),
+                ("src0_mode", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
+                ("Ho", i32), ("Wo", i32), ("Cout", i32), ("accumulate", i32), ("dtype", i32), ("splits", i32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/stp_hip.h
+SIGNATURES = {
+    "stp_abi_version": (i32, []),
+    "stp_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_wgrad_workspace_bytes": (sz, [C.POINTER(WgradParams)]),
+    "stp_conv2d_wgrad": (i32, [C.POINTER(WgradParams), vp, sz, vp]),
+    "stp_weight_prepare": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_weight_grad_unpad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_stem_beta_grad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_bn_workspace_bytes": (sz, [i32]),
+    "stp_bn_stats": (i32, [vp, i32, i64, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "stp_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, vp, i32, f32, vp]),
+    "stp_bn_inference": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, f32, vp]),
+    "stp_bn_backward": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+    "stp_maxpool3x3s2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_upsample2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_channel_sum": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
+    "stp_add_inplace": (i32, [vp, vp, i64, i32, vp]),
+    "stp_loss_workspace_bytes": (sz, []),
+    "stp_sigmoid_bce_dice": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i32, f32, vp, sz, vp]),
+    "stp_sigmoid": (i32, [vp, vp, i64, i32, vp]),
+    "stp_adam": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, vp, f32, vp]),
+    "stp_sgd": (i32, [vp, vp, vp, i64, vp, f32, i32, vp, vp, f32, vp]),
+    "stp_grad_global_scale": (i32, [vp, i64, f32, f32, vp, vp, sz, vp]),
+    "stp_augment_u8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
+    "stp_cast_bf16_to_f32": (i32, [vp, vp, i64, f32, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (building is ``segmentation_training_pipeline_amd.build``).
+    Raises StpError if it is absent: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StpError("libstp_hip.so is missing (%s): build it with "
+                       "`python -m segmentation_training_pipeline_amd.build`; there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "STP_E_BADARG", -2: "STP_E_LAUNCH", -3: "STP_E_WORKSPACE"}
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise StpError("%s failed: %s (%d)" % (what or "stp call", _ERR.get(rc, "?"), rc))
+
+
+def call(name, *args):
+    """Immediate call with error check."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,302 @@
+"""Model object of the HIP backend: what ``PipelineConfig.createNet()`` hands back in place of a
+``keras.Model`` (plugin contract, SURVEY 8b: ``predict``, ``load_weights``, ``save_weights`` as used
+at reference ``segmentation_pipeline/segmentation.py:44,143,152,236``, plus ``train_on_batch``).
+
+Weights cross this boundary in Keras layouts (conv kernels HWIO, BN vectors [C]) under the
+layer names of segmentation_models / classification_models; on the device they live in one
+flat fp32 arena (kernels as OHWI) so the optimizer and the gradient all-reduce are single
+streaming launches.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import graph, nets
+
+SCALAR_NAMES = ("loss", "binary_crossentropy", "dice_loss", "dice", "binary_accuracy")
+
+
+def parse_loss(spec):
+    """``"binary_crossentropy+0.1*dice_loss"`` -> (w_bce, w_dice)  (grammar: reference README.md:210-214)."""
+    w = {"binary_crossentropy": 0.0, "dice_loss": 0.0}
+    for term in str(spec).split("+"):
+        term = term.strip()
+        if "*" in term:
+            k, name = term.split("*", 1)
+            k, name = float(k), name.strip()
+        else:
+            k, name = 1.0, term
+        if name not in w:
+            raise ValueError("loss %r is not available in the HIP backend (have: %s)" % (name, ", ".join(sorted(w))))
+        w[name] += k
+    return w["binary_crossentropy"], w["dice_loss"]
+
+
+class HipSegModel(object):
+    def __init__(self, architecture="Unet", backbone="resnet34", input_shape=(512, 512, 3), classes=1, activation="sigmoid",
+                 batch=16, dtype="bf16", loss="binary_crossentropy", optimizer="Adam", lr=1e-3, freeze_encoder=False,
+                 decoder_filters=(256, 128, 64, 32, 16), clipnorm=None, clipvalue=None, use_graph=True, device="cuda",
+                 opt_kwargs=None, seed=42):
+        if architecture != "Unet":
+            raise ValueError("Unknown architecture")
+        if backbone not in nets.RESNET_UNITS:
+            raise ValueError("Unknown backbone")
+        if classes != 1 or activation not in ("sigmoid", None):
+            raise ValueError("the HIP backend currently trains 1-class sigmoid heads")
+        self.architecture, self.backbone = architecture, backbone
+        self.H, self.W, self.in_ch = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
+        self.classes, self.batch, self.dtype = classes, int(batch), dtype
+        self.decoder_filters = tuple(decoder_filters)
+        self.loss_w = parse_loss(loss)
+        self.optimizer = optimizer.lower()
+        if self.optimizer not in ("adam", "sgd"):
+            raise ValueError("optimizer %r is not available in the HIP backend (have: Adam, SGD)" % optimizer)
+        self.opt_kwargs = dict(opt_kwargs or {})
+        self.clipnorm = float(clipnorm) if clipnorm else 0.0
+        self.clipvalue = float(clipvalue) if clipvalue else 0.0
+        self.use_graph = use_graph
+        self.device = torch.device(device)
+        self.reducer = None
+        self._graphs = None
+        self.plan = graph.Plan(self.batch, dtype, device, training=True)
+        if freeze_encoder:
+            self.plan.frozen_prefixes = nets.ENCODER_PREFIXES
+        self.plan.define(self._net(True))
+        p = self.plan
+        p.init_states()
+        p.set_trainable_mask()
+        n = p.P.numel()
+        self.lr = torch.tensor([float(lr)], dtype=torch.float32, device=self.device)
+        self.opt_state = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.ws_norm = torch.empty(1024, dtype=torch.float32, device=self.device)
+        self.m = self.v = self.vel = None
+        if self.optimizer == "adam":
+            self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        elif self.opt_kwargs.get("momentum", 0.0):
+            self.vel = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._build_opt()
+        self._infer = None
+        self.init_weights(seed)
+
+    # ------------------------------------------------------------------ construction helpers
+    def _net(self, training):
+        def fn(plan):
+            logits = nets.unet_resnet(plan, self.backbone, self.H, self.W, self.in_ch, self.classes, self.decoder_filters,
+                                      self.loss_w, with_loss=training)
+            if not training:
+                plan.sigmoid_out(logits)
+            return logits
+        return fn
+
+    def set_data_parallel(self, reducer):
+        """Attaches a gradient reducer (distributed.GradReducer): gradients are SUM-all-reduced between
+        the backward and optimizer graphs and the 1/world mean is folded into the optimizer."""
+        self.reducer = reducer
+        self.dp_scale = float(reducer.scale)
+        self.gscale.fill_(self.dp_scale)
+        self._build_opt(use_gscale=True)
+
+    def _build_opt(self, use_gscale=False):
+        """(Re)creates the optimizer launch list.  ``use_gscale``: multiply gradients by the device
+        scalar ``gscale`` (clipnorm factor and/or 1/world_size of the data-parallel mean)."""
+        p = self.plan
+        p.opt = []
+        n = p.P.numel()
+        if self.clipnorm > 0:
+            p._emit(p.opt, "stp_grad_global_scale", p.G.data_ptr(), n, self.clipnorm, getattr(self, "dp_scale", 1.0),
+                    self.gscale.data_ptr(), self.ws_norm.data_ptr(), self.ws_norm.numel() * 4)
+        gs = self.gscale.data_ptr() if (use_gscale or self.clipnorm > 0) else None
+        has_frozen = any(not i.trainable for i in p.params.values())
+        mask = p.mask.data_ptr() if has_frozen else None
+        kw = self.opt_kwargs
+        if self.optimizer == "adam":
+            p._emit(p.opt, "stp_adam", p.P.data_ptr(), p.G.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), n,
+                    self.lr.data_ptr(), float(kw.get("beta_1", 0.9)), float(kw.get("beta_2", 0.999)),
+                    float(kw.get("epsilon", 1e-7)), self.opt_state.data_ptr(), mask, gs, self.clipvalue)
+        else:
+            p._emit(p.opt, "stp_sgd", p.P.data_ptr(), p.G.data_ptr(), self.vel.data_ptr() if self.vel is not None else None, n,
+                    self.lr.data_ptr(), float(kw.get("momentum", 0.0)), int(bool(kw.get("nesterov", False))), mask, gs,
+                    self.clipvalue)
+        self._graphs = None
+
+    def _mutable_state(self):
+        p = self.plan
+        return [t for t in (p.P, p.S, self.opt_state, self.m, self.v, self.vel, self.gscale) if t is not None]
+
+    # ------------------------------------------------------------------ weights
+    def init_weights(self, seed=42):
+        """he_uniform encoder kernels, glorot_uniform decoder/head kernels, BN gamma=1 beta=0 (the
+        initialisers of classification_models / Keras Conv2D defaults)."""
+        rng = np.random.RandomState(seed)
+        w = OrderedDict()
+        for name, info in self.plan.params.items():
+            if info.kind == "kernel":
+                co, kh, kw, ci = info.shape
+                enc = any(name.startswith(pfx) for pfx in nets.ENCODER_PREFIXES)
+                limit = np.sqrt(6.0 / (kh * kw * ci)) if enc else np.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+                w[name] = rng.uniform(-limit, limit, size=(kh, kw, ci, co)).astype(np.float32)
+            elif info.kind == "gamma":
+                w[name] = np.ones(info.shape, np.float32)
+            else:
+                w[name] = np.zeros(info.shape, np.float32)
+        self.set_weights(w)
+        self.plan.init_states()
+
+    def set_weights(self, weights):
+        """weights: dict name -> numpy (Keras layouts); may include BN moving statistics."""
+        p = self.plan
+        flat = p.P.cpu().numpy()
+        st = p.S.cpu().numpy()
+        for name, a in weights.items():
+            a = np.asarray(a, np.float32)
+            if name in p.params:
+                info = p.params[name]
+                if info.kind == "kernel":
+                    if a.shape != (info.shape[1], info.shape[2], info.shape[3], info.shape[0]):
+                        raise ValueError("%s: kernel shape %s does not match %s (HWIO)" % (name, a.shape, info.shape))
+                    a = a.transpose(3, 0, 1, 2)
+                elif a.shape != info.shape:
+                    raise ValueError("%s: shape %s does not match %s" % (name, a.shape, info.shape))
+                flat[info.offset:info.offset + info.numel] = a.reshape(-1)
+            elif name in p.states:
+                off, numel, _ = p.states[name]
+                st[off:off + numel] = a.reshape(-1)
+            else:
+                raise KeyError("unknown weight %r" % name)
+        p.P.copy_(torch.from_numpy(flat))
+        p.S.copy_(torch.from_numpy(st))
+
+    def _unflatten(self, flat):
+        out = OrderedDict()
+        for name, info in self.plan.params.items():
+            a = flat[info.offset:info.offset + info.numel].reshape(info.shape)
+            out[name] = a.transpose(1, 2, 3, 0).copy() if info.kind == "kernel" else a.copy()
+        return out
+
+    def get_weights(self):
+        out = self._unflatten(self.plan.P.cpu().numpy())
+        st = self.plan.S.cpu().numpy()
+        for name, (off, numel, _) in self.plan.states.items():
+            out[name] = st[off:off + numel].copy()
+        return out
+
+    def get_gradients(self):
+        return self._unflatten(self.plan.G.cpu().numpy())
+
+    def save_weights(self, path):
+        """Checkpoint payload: safetensors of the Keras-layout tensors (Keras HDF5 cannot be
+        produced here - h5py is absent; the file naming is the reference's, README.md:382)."""
+        from safetensors.numpy import save_file
+        w = self.get_weights()
+        save_file({k: np.ascontiguousarray(v) for k, v in w.items()}, path,
+                  metadata={"format": "stp-keras-layout", "backbone": self.backbone, "architecture": self.architecture})
+
+    def load_weights(self, path):
+        from safetensors.numpy import load_file
+        self.set_weights(load_file(path))
+
+    # ------------------------------------------------------------------ stepping
+    def _ensure_graphs(self):
+        """Captures the step into two hipGraphs: 'fb' (weight copies + forward + loss + backward) and
+        'opt' (optimizer); the data-parallel all-reduce runs between them.  A warm-up pass runs
+        first on a snapshot of all mutable state (lazy code-object loading and
+        hipFuncSetAttribute must not happen under capture), then the snapshot is restored."""
+        if self._graphs is not None:
+            return
+        p = self.plan
+        saved = [t.clone() for t in self._mutable_state()]
+        p.run(p.prep); p.run(p.fwd); p.run(p.bwd); p.run(p.opt)
+        torch.cuda.synchronize()
+        for t, s in zip(self._mutable_state(), saved):
+            t.copy_(s)
+        torch.cuda.synchronize()
+        gfb, gopt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gfb):
+            p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+        with torch.cuda.graph(gopt):
+            p.run(p.opt)
+        self._graphs = {"fb": gfb, "opt": gopt}
+
+    def load_batch(self, x, y=None):
+        """Copies a uint8 image batch [N,H,W,C] (and masks [N,H,W,1] in {0,1}) into the plan's input buffers."""
+        p = self.plan
+        xi = p.inputs["image"].buf
+        x = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+        if x.dtype != torch.uint8:
+            raise TypeError("images must be uint8 (raw 0..255), as SimplePNGMaskDataSet delivers them")
+        xi.copy_(x.reshape(xi.shape), non_blocking=True)
+        if y is not None:
+            yi = p.inputs["mask"].buf
+            y = torch.from_numpy(np.ascontiguousarray(y)) if isinstance(y, np.ndarray) else y
+            yi.copy_(y.to(torch.uint8).reshape(yi.shape), non_blocking=True)
+
+    def forward_backward(self):
+        p = self.plan
+        if self.use_graph:
+            self._ensure_graphs()
+            self._graphs["fb"].replay()
+        else:
+            p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+
+    def apply_gradients(self):
+        p = self.plan
+        if self.reducer is not None:
+            self.reducer.allreduce(p.G)
+        if self.use_graph:
+            self._ensure_graphs()
+            self._graphs["opt"].replay()
+        else:
+            p.run(p.opt)
+
+    def train_on_batch(self, x=None, y=None, fetch=True):
+        """One training step.  x: uint8 [N,H,W,3], y: [N,H,W,1] in {0,1}; None = reuse the resident
+        batch.  Returns dict(loss, binary_crossentropy, dice_loss, dice, binary_accuracy) if fetch."""
+        if x is not None:
+            self.load_batch(x, y)
+        self.forward_backward()
+        self.apply_gradients()
+        return self.metrics() if fetch else None
+
+    def metrics(self):
+        s = self.plan.loss_scalars.cpu().numpy()
+        return dict(zip(SCALAR_NAMES, (float(v) for v in s[:5])))
+
+    def logits(self):
+        return self.plan.tensors["final_conv"].buf.to(torch.float32).cpu().numpy()
+
+    def activation(self, name):
+        return self.plan.tensors[name].buf.to(torch.float32).cpu().numpy()
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    def get_lr(self):
+        return float(self.lr.item())
+
+    # ------------------------------------------------------------------ inference
+    def predict(self, x):
+        """``model.predict``: x uint8 [B,H,W,C] (any B) -> float32 probabilities [B,H,W,classes].
+        Inference-phase BatchNormalization (moving statistics), weights shared with training."""
+        if self._infer is None:
+            ip = graph.Plan(self.batch, self.dtype, str(self.device), training=False)
+            ip.define(self._net(False), share=self.plan)
+            self._infer = ip
+        ip = self._infer
+        x = np.ascontiguousarray(x)
+        if x.dtype != np.uint8:
+            raise TypeError("images must be uint8 (raw 0..255)")
+        B = x.shape[0]
+        out = np.empty((B, self.H, self.W, self.classes), np.float32)
+        xi = ip.inputs["image"].buf
+        for s in range(0, B, self.batch):
+            chunk = x[s:s + self.batch]
+            n = chunk.shape[0]
+            if n < self.batch:
+                chunk = np.concatenate([chunk, np.zeros((self.batch - n,) + chunk.shape[1:], np.uint8)], axis=0)
+            xi.copy_(torch.from_numpy(chunk).reshape(xi.shape))
+            ip.run(ip.prep); ip.run(ip.fwd)
+            out[s:s + n] = ip.probs[:n].cpu().numpy()
+        return out

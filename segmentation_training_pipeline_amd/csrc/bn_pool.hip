@@ -1,0 +1,572 @@
+// BatchNormalization (training / inference phase), max-pool and upsample-gradient kernels.
+// All are HBM-bound streaming kernels: 16-byte vector access, channel constants staged in LDS,
+// two-stage fixed-order reductions (per-block partials -> finalize) so results are
+// deterministic run to run.
+#include "common.h"
+
+#define BN_MAX_BLOCKS 1024
+
+// x*scale + shift exactly as the forward computed it: the backward re-derives the ReLU mask
+// from this expression, so both sides must round identically (single fma).
+__device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return fmaf(x, scale, shift); }
+
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return load4(p); }
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) { return load4(p); }
+
+// ------------------------------------------------------------------------------------------
+// statistics: partial[block][0][c] = sum x, partial[block][1][c] = sum x^2 over the block's rows
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, int64_t rows, int C, float* partial) {
+  extern __shared__ float red[];  // [256][8] worst case handled in column tiles below
+  const int cg = C >> 2;                              // channel groups of 4
+  const int colsPerPass = cg < 256 ? cg : 256;
+  const int rowLanes = 256 / colsPerPass;             // threads along rows
+  const int tcol = threadIdx.x % colsPerPass, trow = threadIdx.x / colsPerPass;
+  const int64_t rowsPerBlock = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rowsPerBlock;
+  const int64_t r1 = r0 + rowsPerBlock < rows ? r0 + rowsPerBlock : rows;
+  for (int c0 = 0; c0 < cg; c0 += colsPerPass) {
+    const int c = c0 + tcol;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (c < cg && trow < rowLanes) {
+      for (int64_t r = r0 + trow; r < r1; r += rowLanes) {
+        const f32x4 v = ld4<T>(x + r * C + c * 4);
+        s += v;
+        q += v * v;
+      }
+    }
+    // reduce over row lanes through LDS (fixed order)
+    float* rs = red;               // [rowLanes][colsPerPass][8]
+    const int slot = (trow * colsPerPass + tcol) * 8;
+    rs[slot + 0] = s.x; rs[slot + 1] = s.y; rs[slot + 2] = s.z; rs[slot + 3] = s.w;
+    rs[slot + 4] = q.x; rs[slot + 5] = q.y; rs[slot + 6] = q.z; rs[slot + 7] = q.w;
+    __syncthreads();
+    if (trow == 0 && c < cg) {
+      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int t = 0; t < rowLanes; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += rs[(t * colsPerPass + tcol) * 8 + e];
+      float* p = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p[c * 4 + e] = a[e]; p[C + c * 4 + e] = a[4 + e]; }
+    }
+    __syncthreads();
+  }
+}
+
+// raw image input: uint8, any channel count (C = 3); one thread per (row-lane, channel)
+__global__ __launch_bounds__(256) void bn_partial_u8_kernel(const uint8_t* __restrict__ x, int64_t rows, int C, float* partial) {
+  __shared__ float rs[256 * 2];
+  const int rowLanes = 256 / C;
+  const int tcol = threadIdx.x % C, trow = threadIdx.x / C;
+  const int64_t rowsPerBlock = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rowsPerBlock;
+  const int64_t r1 = r0 + rowsPerBlock < rows ? r0 + rowsPerBlock : rows;
+  float s = 0.f, q = 0.f;
+  if (trow < rowLanes)
+    for (int64_t r = r0 + trow; r < r1; r += rowLanes) {
+      const float v = (float)x[r * C + tcol];
+      s += v;
+      q += v * v;
+    }
+  rs[threadIdx.x * 2] = s;
+  rs[threadIdx.x * 2 + 1] = q;
+  __syncthreads();
+  if (trow == 0 && threadIdx.x < C) {
+    float a = 0.f, b = 0.f;
+    for (int t = 0; t < rowLanes; ++t) { a += rs[(t * C + tcol) * 2]; b += rs[(t * C + tcol) * 2 + 1]; }
+    partial[(size_t)blockIdx.x * 2 * C + tcol] = a;
+    partial[(size_t)blockIdx.x * 2 * C + C + tcol] = b;
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* partial, int blocks, int C, double inv_rows, double unbias, float eps,
+                                   float momentum, float* mean, float* rstd, float* mm, float* mv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < blocks; ++b) { s += partial[(size_t)b * 2 * C + c]; q += partial[(size_t)b * 2 * C + C + c]; }
+  const double m = s * inv_rows;
+  double var = q * inv_rows - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (mm) mm[c] = mm[c] * momentum + (float)m * (1.f - momentum);
+  if (mv) mv[c] = mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+}
+
+extern "C" size_t stp_bn_workspace_bytes(int32_t C) { return (size_t)BN_MAX_BLOCKS * 2 * C * sizeof(float); }
+
+static int bn_blocks(int64_t rows) {
+  int64_t b = rows / 64;
+  if (b < 1) b = 1;
+  if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+  return (int)b;
+}
+
+extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t C, float eps, float momentum,
+                            float* mean, float* rstd, float* moving_mean, float* moving_var, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!x || !mean || !rstd || !workspace || rows <= 0 || C <= 0) return STP_E_BADARG;
+  if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = bn_blocks(rows);
+  float* partial = (float*)workspace;
+  if (xdtype == STP_U8) {
+    if (C > 256) return STP_E_BADARG;
+    hipLaunchKernelGGL(bn_partial_u8_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)x, rows, C, partial);
+  } else {
+    if (C & 3) return STP_E_BADARG;
+    const size_t lds = 256 * 8 * sizeof(float);
+    if (xdtype == STP_BF16)
+      hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)x, rows, C, partial);
+    else if (xdtype == STP_F32)
+      hipLaunchKernelGGL(bn_partial_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)x, rows, C, partial);
+    else
+      return STP_E_BADARG;
+  }
+  STP_LAUNCH_CHECK();
+  const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, blocks, C, 1.0 / (double)rows,
+                     unbias, eps, momentum, mean, rstd, moving_mean, moving_var);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// apply: y = relu?(x*scale + shift); scale/shift staged in LDS once per block
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x, TY* __restrict__ y, int64_t rows, int C,
+                                                       const float* mean, const float* rstd, const float* gamma,
+                                                       const float* beta, const float* mvar, float eps, int relu) {
+  extern __shared__ float ss[];  // scale[C], shift[C]
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float r = rstd ? rstd[c] : rsqrtf(mvar[c] + eps);
+    const float sc = gamma ? r * gamma[c] : r;
+    ss[c] = sc;
+    ss[C + c] = (beta ? beta[c] : 0.f) - mean[c] * sc;
+  }
+  __syncthreads();
+  const int cg = C >> 2;
+  const int64_t total = rows * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cg) * 4;
+    f32x4 v = ld4<TX>(x + i * 4);
+    v.x = bn_affine(v.x, ss[c], ss[C + c]);
+    v.y = bn_affine(v.y, ss[c + 1], ss[C + c + 1]);
+    v.z = bn_affine(v.z, ss[c + 2], ss[C + c + 2]);
+    v.w = bn_affine(v.w, ss[c + 3], ss[C + c + 3]);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    store4(y + i * 4, v);
+  }
+}
+
+// uint8 [rows][C<=4] -> TY [rows][4]; padded channels get pad_value
+template <typename TY>
+__global__ __launch_bounds__(256) void bn_apply_u8_kernel(const uint8_t* __restrict__ x, TY* __restrict__ y, int64_t rows,
+                                                          int C, const float* mean, const float* rstd, const float* gamma,
+                                                          const float* beta, const float* mvar, float eps, int relu,
+                                                          float pad_value) {
+  float sc[4], sh[4];
+  for (int c = 0; c < 4; ++c) {
+    if (c < C) {
+      const float r = rstd ? rstd[c] : rsqrtf(mvar[c] + eps);
+      sc[c] = gamma ? r * gamma[c] : r;
+      sh[c] = (beta ? beta[c] : 0.f) - mean[c] * sc[c];
+    } else { sc[c] = 0.f; sh[c] = pad_value; }
+  }
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    f32x4 v;
+    for (int c = 0; c < 4; ++c) {
+      float t = c < C ? bn_affine((float)x[r * C + c], sc[c], sh[c]) : pad_value;
+      if (relu && c < C) t = fmaxf(t, 0.f);
+      v[c] = t;
+    }
+    store4(y + r * 4, v);
+  }
+}
+
+static int grid_for(int64_t items) {
+  int64_t b = (items + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static int bn_apply_dispatch(const void* x, int xdt, void* y, int ydt, int64_t rows, int C, int Cy, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, const float* mvar, float eps,
+                             int relu, float pad_value, hipStream_t s) {
+  if (!x || !y || !mean || rows <= 0) return STP_E_BADARG;
+  if (xdt == STP_U8) {
+    if (C > 4 || Cy != 4) return STP_E_BADARG;
+    const int g = grid_for(rows);
+    if (ydt == STP_BF16)
+      hipLaunchKernelGGL(bn_apply_u8_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const uint8_t*)x, (bf16_t*)y, rows, C, mean,
+                         rstd, gamma, beta, mvar, eps, relu, pad_value);
+    else if (ydt == STP_F32)
+      hipLaunchKernelGGL(bn_apply_u8_kernel<float>, dim3(g), dim3(256), 0, s, (const uint8_t*)x, (float*)y, rows, C, mean,
+                         rstd, gamma, beta, mvar, eps, relu, pad_value);
+    else
+      return STP_E_BADARG;
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
+  if ((C & 3) || Cy != C || xdt != ydt) return STP_E_BADARG;
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  const int g = grid_for(rows * (C >> 2));
+  if (xdt == STP_BF16)
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, rows, C,
+                       mean, rstd, gamma, beta, mvar, eps, relu);
+  else if (xdt == STP_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(g), dim3(256), lds, s, (const float*)x, (float*)y, rows, C, mean,
+                       rstd, gamma, beta, mvar, eps, relu);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_bn_apply(const void* x, int32_t xdtype, void* y, int32_t ydtype, int64_t rows, int32_t C, int32_t Cy,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu,
+                            float pad_value, void* stream) {
+  if (!rstd) return STP_E_BADARG;
+  return bn_apply_dispatch(x, xdtype, y, ydtype, rows, C, Cy, mean, rstd, gamma, beta, nullptr, 0.f, relu, pad_value,
+                           (hipStream_t)stream);
+}
+
+extern "C" int stp_bn_inference(const void* x, int32_t xdtype, void* y, int32_t ydtype, int64_t rows, int32_t C, int32_t Cy,
+                                const float* moving_mean, const float* moving_var, float eps, const float* gamma,
+                                const float* beta, int32_t relu, float pad_value, void* stream) {
+  if (!moving_var) return STP_E_BADARG;
+  return bn_apply_dispatch(x, xdtype, y, ydtype, rows, C, Cy, moving_mean, nullptr, gamma, beta, moving_var, eps, relu,
+                           pad_value, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward.  g = dy * [relu ? (x*scale+shift > 0) : 1];  partial sums of g and g*xhat
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows,
+                                                             int C, const float* mean, const float* rstd,
+                                                             const float* gamma, const float* beta, int relu,
+                                                             float* partial) {
+  extern __shared__ float red[];
+  const int cg = C >> 2;
+  const int colsPerPass = cg < 256 ? cg : 256;
+  const int rowLanes = 256 / colsPerPass;
+  const int tcol = threadIdx.x % colsPerPass, trow = threadIdx.x / colsPerPass;
+  const int64_t rowsPerBlock = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rowsPerBlock;
+  const int64_t r1 = r0 + rowsPerBlock < rows ? r0 + rowsPerBlock : rows;
+  for (int c0 = 0; c0 < cg; c0 += colsPerPass) {
+    const int c = c0 + tcol;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (c < cg && trow < rowLanes) {
+      float mu[4], rs[4], sc[4], sh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mu[e] = mean[c * 4 + e];
+        rs[e] = rstd[c * 4 + e];
+        sc[e] = gamma ? rs[e] * gamma[c * 4 + e] : rs[e];
+        sh[e] = (beta ? beta[c * 4 + e] : 0.f) - mu[e] * sc[e];
+      }
+      for (int64_t r = r0 + trow; r < r1; r += rowLanes) {
+        const f32x4 xv = ld4<T>(x + r * C + c * 4);
+        f32x4 g = ld4<T>(dy + r * C + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (relu && !(bn_affine(xv[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
+          s[e] += g[e];
+          q[e] += g[e] * ((xv[e] - mu[e]) * rs[e]);
+        }
+      }
+    }
+    float* rsm = red;
+    const int slot = (trow * colsPerPass + tcol) * 8;
+    rsm[slot + 0] = s.x; rsm[slot + 1] = s.y; rsm[slot + 2] = s.z; rsm[slot + 3] = s.w;
+    rsm[slot + 4] = q.x; rsm[slot + 5] = q.y; rsm[slot + 6] = q.z; rsm[slot + 7] = q.w;
+    __syncthreads();
+    if (trow == 0 && c < cg) {
+      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int t = 0; t < rowLanes; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += rsm[(t * colsPerPass + tcol) * 8 + e];
+      float* p = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p[c * 4 + e] = a[e]; p[C + c * 4 + e] = a[4 + e]; }
+    }
+    __syncthreads();
+  }
+}
+
+// sums[0][c] = dbeta, sums[1][c] = dgamma (raw sums, also written to the grad buffers)
+__global__ void bn_bwd_finalize_kernel(const float* partial, int blocks, int C, float* sums, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < blocks; ++b) { s += partial[(size_t)b * 2 * C + c]; q += partial[(size_t)b * 2 * C + C + c]; }
+  sums[c] = (float)s;
+  sums[C + c] = (float)q;
+  if (dbeta) dbeta[c] = (float)s;
+  if (dgamma) dgamma[c] = (float)q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                           int64_t rows, int C, const float* mean, const float* rstd,
+                                                           const float* gamma, const float* beta, const float* sums,
+                                                           float inv_rows, int relu, int accumulate) {
+  extern __shared__ float ss[];  // mean, rstd, scale, shift, k1 = dbeta/M, k2 = dgamma/M   [6][C]
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float r = rstd[c], sc = gamma ? r * gamma[c] : r;
+    ss[c] = mean[c];
+    ss[C + c] = r;
+    ss[2 * C + c] = sc;
+    ss[3 * C + c] = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    ss[4 * C + c] = sums[c] * inv_rows;
+    ss[5 * C + c] = sums[C + c] * inv_rows;
+  }
+  __syncthreads();
+  const int cg = C >> 2;
+  const int64_t total = rows * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cg) * 4;
+    const f32x4 xv = ld4<T>(x + i * 4);
+    f32x4 g = ld4<T>(dy + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (relu && !(bn_affine(xv[e], ss[2 * C + c + e], ss[3 * C + c + e]) > 0.f)) g[e] = 0.f;
+      const float xh = (xv[e] - ss[c + e]) * ss[C + c + e];
+      o[e] = ss[2 * C + c + e] * (g[e] - ss[4 * C + c + e] - xh * ss[5 * C + c + e]);
+    }
+    if (accumulate) o += ld4<T>(dx + i * 4);
+    store4(dx + i * 4, o);
+  }
+}
+
+extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t dtype, int64_t rows, int32_t C,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma,
+                               float* dbeta, int32_t relu, int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (!x || !dy || !dx || !mean || !rstd || !workspace || rows <= 0 || C <= 0 || (C & 3)) return STP_E_BADARG;
+  if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = bn_blocks(rows) > BN_MAX_BLOCKS - 1 ? BN_MAX_BLOCKS - 1 : bn_blocks(rows);
+  float* partial = (float*)workspace;
+  float* sums = partial + (size_t)(BN_MAX_BLOCKS - 1) * 2 * C;  // last slab holds the finalized sums
+  const size_t lds = 256 * 8 * sizeof(float);
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy,
+                       rows, C, mean, rstd, gamma, beta, relu, partial);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)x, (const float*)dy, rows,
+                       C, mean, rstd, gamma, beta, relu, partial);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, blocks, C, sums, dgamma, dbeta);
+  STP_LAUNCH_CHECK();
+  const size_t lds2 = 6 * (size_t)C * sizeof(float);
+  const int g = grid_for(rows * (C >> 2));
+  const float inv_rows = (float)(1.0 / (double)rows);
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)dy,
+                       (bf16_t*)dx, rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g), dim3(256), lds2, s, (const float*)x, (const float*)dy, (float*)dx,
+                       rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// ZeroPadding2D(1) + MaxPooling2D(3, 2, valid).  idx[n,ho,wo,c] = kh*3+kw of the first maximum
+// (padded taps take part with value 0, as in the Keras graph).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                          int N, int H, int W, int C, int Ho, int Wo) {
+  const int cg = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cg) * 4;
+    int64_t p = i / cg;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    f32x4 best = {0.f, 0.f, 0.f, 0.f};
+    int bi[4] = {0, 0, 0, 0};
+    bool firstTap = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = ld4<T>(x + (((int64_t)n * H + h) * W + w) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (firstTap || v[e] > best[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
+        firstTap = false;
+      }
+    store4(y + i * 4, best);
+    if (idx) *reinterpret_cast<uint32_t*>(idx + i * 4) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo,
+                                                          int accumulate) {
+  const int cg = C >> 2;
+  const int64_t total = (int64_t)N * H * W * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cg) * 4;
+    int64_t p = i / cg;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    // windows (ho,wo) with 2*ho-1+kh == h  ->  kh = h+1-2*ho in [0,2]
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + 1 - kh;
+      if (hh < 0 || (hh & 1)) continue;
+      const int ho = hh >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w + 1 - kw;
+        if (ww < 0 || (ww & 1)) continue;
+        const int wo = ww >> 1;
+        if (wo >= Wo) continue;
+        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
+        const uint32_t id = *reinterpret_cast<const uint32_t*>(idx + o);
+        const f32x4 d = ld4<T>(dy + o);
+        const uint32_t me = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (((id >> (8 * e)) & 0xff) == me) g[e] += d[e];
+      }
+    }
+    if (accumulate) g += ld4<T>(dx + i * 4);
+    store4(dx + i * 4, g);
+  }
+}
+
+extern "C" int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t dtype, void* stream) {
+  if (!x || !y || (C & 3) || N <= 0) return STP_E_BADARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int g = grid_for((int64_t)N * Ho * Wo * (C >> 2));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C, Ho, Wo);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                    int32_t dtype, int32_t accumulate, void* stream) {
+  if (!idx || !dy || !dx || (C & 3) || N <= 0) return STP_E_BADARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int g = grid_for((int64_t)N * H * W * (C >> 2));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gradient of UpSampling2D(2): dy is [N,2H,2W,ldy] (first C channels used), dx [N,H,W,C]
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
+                                                             int C, int ldy, int accumulate) {
+  const int cg = C >> 2;
+  const int64_t total = (int64_t)N * H * W * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cg) * 4;
+    int64_t p = i / cg;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    const T* b = dy + (((int64_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * ldy + c;
+    f32x4 g = ld4<T>(b) + ld4<T>(b + ldy) + ld4<T>(b + (int64_t)2 * W * ldy) + ld4<T>(b + (int64_t)2 * W * ldy + ldy);
+    if (accumulate) g += ld4<T>(dx + i * 4);
+    store4(dx + i * 4, g);
+  }
+}
+
+extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,
+                                  int32_t dtype, int32_t accumulate, void* stream) {
+  if (!dy || !dx || (C & 3) || (ldy & 3) || ldy < C) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * H * W * (C >> 2));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-channel sums of a [rows][C] tensor (bias gradient) and dst += src
+__global__ void colsum_finalize_kernel(const float* partial, int blocks, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * 2 * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+extern "C" int stp_channel_sum(const void* x, int32_t dtype, int64_t rows, int32_t C, float* out, int32_t accumulate,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !out || !workspace || rows <= 0 || C <= 0 || (C & 3)) return STP_E_BADARG;
+  if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = bn_blocks(rows);
+  float* partial = (float*)workspace;
+  const size_t lds = 256 * 8 * sizeof(float);
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)x, rows, C, partial);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(bn_partial_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)x, rows, C, partial);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, blocks, C, out, accumulate);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    store4(dst + i * 4, ld4<T>(dst + i * 4) + ld4<T>(src + i * 4));
+}
+
+extern "C" int stp_add_inplace(void* dst, const void* src, int64_t count, int32_t dtype, void* stream) {
+  if (!dst || !src || count <= 0 || (count & 3)) return STP_E_BADARG;
+  const int g = grid_for(count >> 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (bf16_t*)dst, (const bf16_t*)src, count >> 2);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(g), dim3(256), 0, s, (float*)dst, (const float*)src, count >> 2);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}

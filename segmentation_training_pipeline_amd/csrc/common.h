@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, 16-byte vector access).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stp_hip.h"
+
+#define STP_LAUNCH_CHECK()                       \
+  do {                                           \
+    if (hipGetLastError() != hipSuccess) return STP_E_LAUNCH; \
+  } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rule as torch / numpy ml_dtypes bf16 casts)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16 bytes
+  static constexpr int DTYPE = STP_F32;
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VEC = 8;
+  static constexpr int DTYPE = STP_BF16;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 4 consecutive elements <-> f32x4 (8-byte access for bf16, 16-byte for fp32)
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+  u32x2 r = *reinterpret_cast<const u32x2*>(p);
+  f32x4 o;
+  o.x = __uint_as_float(r.x << 16);
+  o.y = __uint_as_float(r.x & 0xffff0000u);
+  o.z = __uint_as_float(r.y << 16);
+  o.w = __uint_as_float(r.y & 0xffff0000u);
+  return o;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  u32x2 r;
+  r.x = pack_bf16x2(v.x, v.y);
+  r.y = pack_bf16x2(v.z, v.w);
+  *reinterpret_cast<u32x2*>(p) = r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Exact unsigned 32-bit division by a runtime constant (round-up method, Granlund-Montgomery):
+// l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, q = (t + ((n - t) >> 1)) >> (l - 1), t = mulhi(m, n).
+struct FastDiv {
+  uint32_t d, magic, shift;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = 0;
+  f.shift = 0;
+  if (d > 1) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.magic = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.shift = l - 1;
+  }
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+  if (f.d <= 1) return n;
+  const uint32_t t = __umulhi(n, f.magic);
+  return (t + ((n - t) >> 1)) >> f.shift;
+}
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

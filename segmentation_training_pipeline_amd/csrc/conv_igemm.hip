@@ -1,0 +1,349 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (forward and data-gradient).
+//
+// GEMM view:  C[cout][pixel] = sum_k  W[cout][k] * V[pixel][k],   k = (kh*KW + kw)*Ctot + c
+//   A operand (MFMA rows  i) = weight rows  (K-contiguous in HBM, OHWI layout)
+//   B operand (MFMA cols  j) = im2col rows gathered on the fly from NHWC activations, with
+//     nearest-2x upsampling / zero-insertion of src0 and channel-concat of src1 folded into the
+//     gather (the upsampled / concatenated / zero-inserted tensors are never materialised).
+// With the 16x16 MFMA C layout (col = lane&15, row = (lane>>4)*4 + r) every lane ends up with 4
+// consecutive output channels of one pixel, i.e. one 8-byte (bf16) or 16-byte (fp32) NHWC store.
+//
+// Tile bytes are identical for both dtypes: every LDS row holds 128 bytes of K (64 bf16 / 32
+// fp32); a lane's 16-byte fragment read feeds one v_mfma_f32_16x16x32_bf16 or four
+// v_mfma_f32_16x16x4_f32 (exact fp32, used by the parity mode).  LDS rows are XOR-swizzled in
+// 16-byte slots (slot ^= row & 7): conflict-free for the ds_read_b128 lane groups of gfx950
+// and for the 8-lane ds_write_b128 groups.  Global->register->LDS staging, double-buffered LDS,
+// next tile's global loads in flight during the MFMAs of the current one.
+#include "common.h"
+
+struct ConvArgs {
+  const char* src0;
+  const char* src1;
+  const char* weight;
+  const char* residual;
+  const float* bias;
+  char* dst0;
+  char* dst1;
+  int N, Hs0, Ws0, Hv, Wv, C0, C1, Ctot, mode;
+  int KH, KW, stride, pad, Ho, Wo, Cout, Cd0, Cd1;
+  int acc0, acc1, relu;
+  int K, P, HoWo, wrows;
+  int ntile_m, ntile_n;
+  FastDiv divC, divKW;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // A lane holds k = 4*(lane>>4) + s, s = 0..3, of a 16-wide K chunk; step s multiplies the s-th
+  // components.  A and B use the same (lane, s) -> k map, which is all the contraction needs.
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+// BM = output-channel rows per block, BN = pixels per block, WM x WN = wave grid (4 waves).
+template <typename T, int BM, int BN, int WM, int WN, bool C4>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KE = 128 / (int)sizeof(T);  // K elements per LDS row / K-step
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int RA = (BM + 31) / 32, RB = (BN + 31) / 32;
+  constexpr int STAGE = (BM + BN) * 128;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r0 = tid >> 3, slot = tid & 7;
+
+  // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a
+  // contiguous run of pixel tiles (neighbouring tiles share their 3x3 halo rows in that L2).
+  int bid = blockIdx.x;
+  const int nblk = a.ntile_m * a.ntile_n;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int tile_m = bid % a.ntile_m;  // cout tiles innermost: they share the same pixels
+  const int tile_n = bid / a.ntile_m;
+  const int cout0 = tile_m * BM;
+  const int pix0 = tile_n * BN;
+
+  // ---- per-thread gather metadata for its pixel rows -------------------------------------
+  int hb[RB], wb[RB], nb[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int pm = pix0 + r0 + 32 * i;
+    if (pm < a.P && (r0 + 32 * i) < BN) {
+      const int n = pm / a.HoWo;
+      const int rem = pm - n * a.HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      nb[i] = n;
+      hb[i] = ho * a.stride - a.pad;
+      wb[i] = wo * a.stride - a.pad;
+    } else {
+      nb[i] = 0;
+      hb[i] = -(1 << 24);
+      wb[i] = -(1 << 24);
+    }
+  }
+
+  u32x4 ra[RA], rb[RB];
+
+  auto load_tile = [&](int kt) {
+    const int k = kt * KE + slot * VEC;
+    const bool kok = k < a.K;
+    // weights: plain rows
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int row = cout0 + r0 + 32 * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kok && row < a.wrows && (r0 + 32 * i) < BM)
+        v = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)row * a.K + k) * sizeof(T));
+      ra[i] = v;
+    }
+    // activations: im2col gather
+    if constexpr (C4) {
+      // stem: 4 (padded) channels per pixel; one 16-byte vector = two horizontally adjacent taps
+      const uint32_t pos = (uint32_t)k >> 2;
+      const int kh = (int)fdiv(pos, a.divKW);
+      const int kw = (int)pos - kh * a.KW;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int hv = hb[i] + kh, wv = wb[i] + kw;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (kok && (unsigned)hv < (unsigned)a.Hv) {
+          const char* rowp = a.src0 + ((size_t)(nb[i] * a.Hs0 + hv) * a.Ws0) * (4 * sizeof(T));
+          if ((unsigned)wv < (unsigned)a.Wv) {
+            u32x2 t = *reinterpret_cast<const u32x2*>(rowp + (size_t)wv * (4 * sizeof(T)));
+            v.x = t.x; v.y = t.y;
+          }
+          if ((unsigned)(wv + 1) < (unsigned)a.Wv) {
+            u32x2 t = *reinterpret_cast<const u32x2*>(rowp + (size_t)(wv + 1) * (4 * sizeof(T)));
+            v.z = t.x; v.w = t.y;
+          }
+        }
+        rb[i] = v;
+      }
+    } else {
+      const uint32_t pos = fdiv((uint32_t)k, a.divC);
+      int ci = k - (int)pos * a.Ctot;
+      const int kh = (int)fdiv(pos, a.divKW);
+      const int kw = (int)pos - kh * a.KW;
+      const bool first = ci < a.C0;
+      const char* base = first ? a.src0 : a.src1;
+      const int cs = first ? a.C0 : a.C1;
+      const int mode = first ? a.mode : 0;
+      const int Hs = first ? a.Hs0 : a.Hv, Ws = first ? a.Ws0 : a.Wv;
+      if (!first) ci -= a.C0;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int hv = hb[i] + kh, wv = wb[i] + kw;
+        bool ok = kok && (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+        if (mode == STP_SRC_ZEROINS2X) ok = ok && (((hv | wv) & 1) == 0);
+        const int hs = mode ? (hv >> 1) : hv, ws = mode ? (wv >> 1) : wv;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(base + (((size_t)(nb[i] * Hs + hs) * Ws + ws) * cs + ci) * sizeof(T));
+        rb[i] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int row = r0 + 32 * i;
+      if (row < BM) *reinterpret_cast<u32x4*>(sa + row * 128 + ((slot ^ (row & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = r0 + 32 * i;
+      if (row < BN) *reinterpret_cast<u32x4*>(sb + row * 128 + ((slot ^ (row & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lg = lane >> 4;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * STAGE + (wm * (BM / WM)) * 128;
+    const char* sb = smem + buf * STAGE + BM * 128 + (wn * (BN / WN)) * 128;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = i * 16 + lr;  // (wave row offset is a multiple of 16 -> row&7 unchanged)
+        fa[i] = *reinterpret_cast<const u32x4*>(sa + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = j * 16 + lr;
+        fb[j] = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  };
+
+  const int nk = (a.K + KE - 1) / KE;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    compute(cur);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, residual, ReLU, dual destination, optional accumulate -------------
+  const T* res = reinterpret_cast<const T*>(a.residual);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
+    if (pm >= a.P) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+      if (co >= a.Cout) continue;
+      f32x4 v = acc[i][j];
+      if (co + 3 < a.Cout) {
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+        if (res) v += load4(res + (size_t)pm * a.Cout + co);
+        T* d;
+        bool accum;
+        if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
+        else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
+        if (accum) v += load4(d);
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        store4(d, v);
+      } else {
+        // ragged channel tail (e.g. the 1-class head): scalar path
+        for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
+          const int c1 = co + r;
+          float x = v[r];
+          if (a.bias) x += a.bias[c1];
+          if (res) x += Elem<T>::load(res + (size_t)pm * a.Cout + c1);
+          T* d;
+          bool accum;
+          if (c1 < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + c1; accum = a.acc0; }
+          else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (c1 - a.Cd0); accum = a.acc1; }
+          if (accum) x += Elem<T>::load(d);
+          if (a.relu) x = fmaxf(x, 0.f);
+          Elem<T>::store(d, x);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool C4>
+static int launch_cfg(ConvArgs& a, hipStream_t s) {
+  a.ntile_m = ceil_div(a.Cout, BM);
+  a.ntile_n = ceil_div(a.P, BN);
+  const size_t lds = 2 * (BM + BN) * 128;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, C4>;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;  // one per template instantiation
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return STP_E_LAUNCH;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.ntile_m * a.ntile_n), dim3(256), lds, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// tile ids: 1 = 128x128, 2 = 64co x 256px, 3 = 32co x 256px, 4 = 16co x 256px, 5 = 64x64, 6 = 128co x 64px
+template <typename T, bool C4>
+static int launch_tile(ConvArgs& a, int tile, hipStream_t s) {
+  switch (tile) {
+    case 1: return launch_cfg<T, 128, 128, 2, 2, C4>(a, s);
+    case 2: return launch_cfg<T, 64, 256, 1, 4, C4>(a, s);
+    case 3: return launch_cfg<T, 32, 256, 1, 4, C4>(a, s);
+    case 4: return launch_cfg<T, 16, 256, 1, 4, C4>(a, s);
+    case 5: return launch_cfg<T, 64, 64, 2, 2, C4>(a, s);
+    case 6: return launch_cfg<T, 128, 64, 4, 1, C4>(a, s);
+    default: return STP_E_BADARG;
+  }
+}
+
+static int auto_tile(const ConvArgs& a) {
+  const int co = a.Cout;
+  if (co <= 16) return 4;
+  if (co <= 32) return 3;
+  // enough 128x128 tiles to cover the 256 CUs at least ~2x? otherwise use smaller tiles
+  if (co <= 64) return ((int64_t)a.P >= 256 * 256) ? 2 : 5;
+  const int64_t big = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 128);
+  if (big >= 384) return 1;
+  const int64_t mid = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 64);
+  if (mid >= 384) return 6;
+  return 5;
+}
+
+// Which tile configuration stp_conv2d would launch (profiling / roofline bookkeeping).
+extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
+  if (!p) return STP_E_BADARG;
+  if (p->tile) return p->tile;
+  ConvArgs a;
+  a.Cout = p->Cout;
+  a.P = (int)((int64_t)p->N * p->Ho * p->Wo);
+  return auto_tile(a);
+}
+
+extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
+  if (!p || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
+  if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
+  const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  const bool c4 = (p->dtype == STP_BF16) && p->C0 == 4 && p->C1 == 0;
+  if (c4) {
+    if ((p->KW & 1) || p->src0_mode != STP_SRC_DIRECT) return STP_E_BADARG;
+  } else if ((p->C0 % vec) || (p->C1 % vec)) {
+    return STP_E_BADARG;
+  }
+  if (p->C1 > 0 && !p->src1) return STP_E_BADARG;
+  if (p->Cd0 <= 0 || p->Cd0 > p->Cout || (p->Cd0 < p->Cout && (!p->dst1 || (p->Cd0 & 3) || ((p->Cout - p->Cd0) & 3))))
+    return STP_E_BADARG;
+  if (p->N <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->Cout <= 0 || p->KH <= 0 || p->KW <= 0 || p->stride <= 0) return STP_E_BADARG;
+  ConvArgs a;
+  a.src0 = (const char*)p->src0; a.src1 = (const char*)p->src1; a.weight = (const char*)p->weight;
+  a.residual = (const char*)p->residual; a.bias = p->bias; a.dst0 = (char*)p->dst0; a.dst1 = (char*)p->dst1;
+  a.N = p->N; a.Hs0 = p->Hs0; a.Ws0 = p->Ws0; a.Hv = p->Hv; a.Wv = p->Wv; a.C0 = p->C0; a.C1 = p->C1;
+  a.Ctot = p->C0 + p->C1; a.mode = p->src0_mode;
+  a.KH = p->KH; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.Ho = p->Ho; a.Wo = p->Wo;
+  a.Cout = p->Cout; a.Cd0 = p->Cd0; a.Cd1 = p->Cout - p->Cd0;
+  a.acc0 = p->accumulate0; a.acc1 = p->accumulate1; a.relu = p->relu;
+  a.K = p->KH * p->KW * a.Ctot;
+  const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
+  if (P >= (1ll << 31) || (int64_t)a.K * a.Ctot >= (1ll << 32)) return STP_E_BADARG;
+  a.P = (int)P; a.HoWo = p->Ho * p->Wo; a.wrows = round_up(p->Cout, 16);
+  a.divC = make_fastdiv((uint32_t)a.Ctot); a.divKW = make_fastdiv((uint32_t)a.KW);
+  const int tile = p->tile ? p->tile : auto_tile(a);
+  hipStream_t s = (hipStream_t)stream;
+  if (p->dtype == STP_BF16) return c4 ? launch_tile<bf16_t, true>(a, tile, s) : launch_tile<bf16_t, false>(a, tile, s);
+  return launch_tile<float, false>(a, tile, s);
+}

@@ -1,0 +1,418 @@
+// Segmentation loss (sigmoid + Keras BCE + musket dice), Keras optimizers over a flat fp32
+// arena, weight-layout preparation and wire-format casts.  HBM-bound streaming kernels with
+// two-stage fixed-order reductions.
+#include "common.h"
+
+#define LOSS_MAX_BLOCKS 1024
+#define LOSS_NSUM 8
+
+// ------------------------------------------------------------------------------------------
+// pass 1: per-block partial sums of
+//   0 bce_i   1 p   2 y   3 p*y   4 [p>.5]   5 [p>.5]*y   6 [(p>.5)==y]   7 unused
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// Keras/TF binary_crossentropy on probabilities: clip p to [eps, 1-eps], go back to logits,
+// sigmoid_cross_entropy_with_logits.  Returns the loss term; in_range tells whether the clip
+// was inactive (gradient flows).
+__device__ __forceinline__ float keras_bce(float p, float y, bool* in_range) {
+  const float eps = 1e-7f, hi = 1.f - 1e-7f;
+  const float pc = fminf(fmaxf(p, eps), hi);
+  *in_range = (p >= eps) && (p <= hi);
+  const float z = logf(pc / (1.f - pc));
+  return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                           int64_t count, float* partial) {
+  float a[LOSS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t per = (count + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < count ? i0 + per : count;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float z = Elem<T>::load(logits + i);
+    const float y = target[i] ? 1.f : 0.f;
+    const float p = 1.f / (1.f + expf(-z));
+    bool inr;
+    a[0] += keras_bce(p, y, &inr);
+    a[1] += p;
+    a[2] += y;
+    a[3] += p * y;
+    const float t = p > 0.5f ? 1.f : 0.f;
+    a[4] += t;
+    a[5] += t * y;
+    a[6] += (t == y) ? 1.f : 0.f;
+  }
+  __shared__ float red[4][LOSS_NSUM];
+#pragma unroll
+  for (int e = 0; e < LOSS_NSUM; ++e) a[e] = wave_sum(a[e]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < LOSS_NSUM; ++e) red[threadIdx.x >> 6][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < LOSS_NSUM)
+    partial[(size_t)blockIdx.x * LOSS_NSUM + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// scalars: 0 loss 1 bce 2 dice_loss 3 dice_metric 4 binary_accuracy 5 sum_p 6 sum_y 7 sum_py
+__global__ void loss_finalize_kernel(const float* partial, int blocks, double inv_count, float w_bce, float w_dice,
+                                     float* scalars) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s[LOSS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < blocks; ++b)
+    for (int e = 0; e < LOSS_NSUM; ++e) s[e] += partial[(size_t)b * LOSS_NSUM + e];
+  const double bce = s[0] * inv_count;
+  const double dice_l = 1.0 - (2.0 * s[3] + 1.0) / (s[2] + s[1] + 1.0);
+  const double dice_m = (2.0 * s[5] + 1.0) / (s[2] + s[4] + 1.0);
+  scalars[0] = (float)(w_bce * bce + w_dice * dice_l);
+  scalars[1] = (float)bce;
+  scalars[2] = (float)dice_l;
+  scalars[3] = (float)dice_m;
+  scalars[4] = (float)(s[6] * inv_count);
+  scalars[5] = (float)s[1];
+  scalars[6] = (float)s[2];
+  scalars[7] = (float)s[3];
+}
+
+// pass 2: dL/dlogit, written to channel 0 of a [count][dl_channels] tensor (other channels 0)
+template <typename T>
+__global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                        int64_t count, const float* scalars, float w_bce, float w_dice,
+                                                        float inv_count, float grad_scale, T* __restrict__ dl, int dlc) {
+  const float sp = scalars[5], sy = scalars[6], spy = scalars[7];
+  const float den = sy + sp + 1.f;
+  const float inv_den2 = 1.f / (den * den);
+  const float num = 2.f * spy + 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const float z = Elem<T>::load(logits + i);
+    const float y = target[i] ? 1.f : 0.f;
+    const float p = 1.f / (1.f + expf(-z));
+    const bool inr = (p >= 1e-7f) && (p <= 1.f - 1e-7f);
+    // d bce / d z = (p - y) where the probability clip is inactive
+    float g = inr ? w_bce * (p - y) * inv_count : 0.f;
+    // d dice_loss / d p = -(2 y den - num) / den^2 ;  dp/dz = p (1-p)
+    g += w_dice * (-(2.f * y * den - num) * inv_den2) * (p * (1.f - p));
+    g *= grad_scale;
+    T* o = dl + i * dlc;
+    Elem<T>::store(o, g);
+    for (int c = 1; c < dlc; ++c) Elem<T>::store(o + c, 0.f);
+  }
+}
+
+extern "C" size_t stp_loss_workspace_bytes(void) { return (size_t)LOSS_MAX_BLOCKS * LOSS_NSUM * sizeof(float); }
+
+extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, int64_t count, int32_t dtype, float w_bce,
+                                    float w_dice, float* scalars, void* dlogits, int32_t dl_channels, float grad_scale,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!logits || !target || !scalars || !workspace || count <= 0) return STP_E_BADARG;
+  if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = count / 1024;
+  if (b < 1) b = 1;
+  if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
+  const int blocks = (int)b;
+  float* partial = (float*)workspace;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(loss_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)logits, target, count, partial);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(loss_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)logits, target, count, partial);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, 1.0 / (double)count, w_bce, w_dice, scalars);
+  STP_LAUNCH_CHECK();
+  if (dlogits) {
+    if (dl_channels < 1) return STP_E_BADARG;
+    int64_t g = (count + 255) / 256;
+    if (g > 4096) g = 4096;
+    const float inv_count = (float)(1.0 / (double)count);
+    if (dtype == STP_BF16)
+      hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, target, count, scalars,
+                         w_bce, w_dice, inv_count, grad_scale, (bf16_t*)dlogits, dl_channels);
+    else
+      hipLaunchKernelGGL(loss_grad_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, target, count, scalars,
+                         w_bce, w_dice, inv_count, grad_scale, (float*)dlogits, dl_channels);
+    STP_LAUNCH_CHECK();
+  }
+  return STP_OK;
+}
+
+template <typename T>
+__global__ void sigmoid_kernel(const T* __restrict__ logits, float* __restrict__ probs, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    probs[i] = 1.f / (1.f + expf(-Elem<T>::load(logits + i)));
+}
+
+extern "C" int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, void* stream) {
+  if (!logits || !probs || count <= 0) return STP_E_BADARG;
+  int64_t g = (count + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16) hipLaunchKernelGGL(sigmoid_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, probs, count);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(sigmoid_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, probs, count);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Optimizers (Keras 2.2.4 formulas).  state[0] = iteration t (int), state[1] = lr_t (float bits)
+__global__ void adam_prep_kernel(int32_t* state, const float* lr, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int t = state[0] + 1;
+  state[0] = t;
+  const double lr_t = (double)lr[0] * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  reinterpret_cast<float*>(state)[1] = (float)lr_t;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t count, const int32_t* state, float b1,
+                                                   float b2, float eps, const uint8_t* __restrict__ mask,
+                                                   const float* gscale, float clipvalue) {
+  const float lr_t = reinterpret_cast<const float*>(state)[1];
+  const float gs = gscale ? gscale[0] : 1.f;
+  const int64_t n4 = count >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 gv = load4(g + i * 4) * gs;
+    if (clipvalue > 0.f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = fminf(fmaxf(gv[e], -clipvalue), clipvalue);
+    f32x4 mv = load4(m + i * 4), vv = load4(v + i * 4), pv = load4(p + i * 4);
+    uint32_t mk = mask ? *reinterpret_cast<const uint32_t*>(mask + i * 4) : 0x01010101u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!((mk >> (8 * e)) & 0xff)) continue;
+      const float mn = b1 * mv[e] + (1.f - b1) * gv[e];
+      const float vn = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
+      pv[e] = pv[e] - lr_t * mn / (sqrtf(vn) + eps);
+      mv[e] = mn;
+      vv[e] = vn;
+    }
+    store4(m + i * 4, mv);
+    store4(v + i * 4, vv);
+    store4(p + i * 4, pv);
+  }
+}
+
+extern "C" int stp_adam(float* param, const float* grad, float* m, float* v, int64_t count, const float* lr, float beta1,
+                        float beta2, float eps, int32_t* state, const uint8_t* mask, const float* gscale, float clipvalue,
+                        void* stream) {
+  if (!param || !grad || !m || !v || !lr || !state || count <= 0 || (count & 3)) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2);
+  STP_LAUNCH_CHECK();
+  int64_t g = ((count >> 2) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)g), dim3(256), 0, s, param, grad, m, v, count, state, beta1, beta2, eps, mask,
+                     gscale, clipvalue);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel,
+                                                  int64_t count, const float* lr, float mu, int nesterov,
+                                                  const uint8_t* __restrict__ mask, const float* gscale, float clipvalue) {
+  const float l = lr[0];
+  const float gs = gscale ? gscale[0] : 1.f;
+  const int64_t n4 = count >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 gv = load4(g + i * 4) * gs;
+    if (clipvalue > 0.f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = fminf(fmaxf(gv[e], -clipvalue), clipvalue);
+    f32x4 vv = vel ? load4(vel + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f}, pv = load4(p + i * 4);
+    uint32_t mk = mask ? *reinterpret_cast<const uint32_t*>(mask + i * 4) : 0x01010101u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!((mk >> (8 * e)) & 0xff)) continue;
+      const float vn = mu * vv[e] - l * gv[e];
+      pv[e] = nesterov ? pv[e] + mu * vn - l * gv[e] : pv[e] + vn;
+      vv[e] = vn;
+    }
+    if (vel) store4(vel + i * 4, vv);
+    store4(p + i * 4, pv);
+  }
+}
+
+extern "C" int stp_sgd(float* param, const float* grad, float* vel, int64_t count, const float* lr, float momentum,
+                       int32_t nesterov, const uint8_t* mask, const float* gscale, float clipvalue, void* stream) {
+  if (!param || !grad || !lr || count <= 0 || (count & 3)) return STP_E_BADARG;
+  int64_t g = ((count >> 2) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, param, grad, vel, count, lr, momentum,
+                     nesterov, mask, gscale, clipvalue);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ||grad||^2 partials -> gscale = min(1, clipnorm/||base*g||) * base   (base = 1/world_size)
+__global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restrict__ g, int64_t count, float* partial) {
+  float a = 0.f;
+  const int64_t per = (count + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < count ? i0 + per : count;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) a += g[i] * g[i];
+  __shared__ float red[4];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void gscale_finalize_kernel(const float* partial, int blocks, float clipnorm, float base, float* gscale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += partial[b];
+  const double norm = sqrt(s) * (double)base;  // norm of the (mean) gradient the optimizer will see
+  double k = 1.0;
+  if (clipnorm > 0.f && norm > (double)clipnorm) k = (double)clipnorm / norm;
+  gscale[0] = (float)(k * (double)base);
+}
+
+extern "C" int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, float base, float* gscale,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grad || !gscale || !workspace || count <= 0) return STP_E_BADARG;
+  if (workspace_bytes < 1024 * sizeof(float)) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = count / 4096;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(sqsum_partial_kernel, dim3((int)b), dim3(256), 0, s, grad, count, (float*)workspace);
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gscale_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, (int)b, clipnorm, base, gscale);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight compute copies.  master [Cout][KH][KW][Cin] fp32.
+//   fwd [rows_f][KH][KWp][Cinp]  (rows_f = Cout rounded up to 16; zero padded)
+//   bwd [rows_b][KH][KW][CoutB]  bwd[ci][kh][kw][co] = master[co][KH-1-kh][KW-1-kw][ci]
+//                                (rows_b = Cin rounded up to 16, CoutB >= Cout; zero padded)
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prepare_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd,
+                                                             int Cout, int KH, int KW, int Cin, int KWp, int Cinp, int CoutB,
+                                                             int rows_f, int rows_b) {
+  const int64_t nf = fwd ? (int64_t)rows_f * KH * KWp * Cinp : 0;
+  const int64_t nb = bwd ? (int64_t)rows_b * KH * KW * CoutB : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * 256) {
+    if (i < nf) {
+      int64_t r = i;
+      const int ci = (int)(r % Cinp); r /= Cinp;
+      const int kw = (int)(r % KWp); r /= KWp;
+      const int kh = (int)(r % KH);
+      const int co = (int)(r / KH);
+      float v = 0.f;
+      if (co < Cout && kw < KW && ci < Cin) v = w[(((int64_t)co * KH + kh) * KW + kw) * Cin + ci];
+      Elem<T>::store(fwd + i, v);
+    } else {
+      int64_t r = i - nf;
+      const int co = (int)(r % CoutB); r /= CoutB;
+      const int kw = (int)(r % KW); r /= KW;
+      const int kh = (int)(r % KH);
+      const int ci = (int)(r / KH);
+      float v = 0.f;
+      if (co < Cout && ci < Cin) v = w[(((int64_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+      Elem<T>::store(bwd + (i - nf), v);
+    }
+  }
+}
+
+extern "C" int stp_weight_prepare(const float* master, void* fwd, void* bwd, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
+                                  int32_t KWp, int32_t Cinp, int32_t CoutB, int32_t dtype, void* stream) {
+  if (!master || (!fwd && !bwd) || KWp < KW || Cinp < Cin || CoutB < Cout) return STP_E_BADARG;
+  const int rows_f = round_up(Cout, 16), rows_b = round_up(Cin, 16);
+  const int64_t total = (fwd ? (int64_t)rows_f * KH * KWp * Cinp : 0) + (bwd ? (int64_t)rows_b * KH * KW * CoutB : 0);
+  int64_t g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(weight_prepare_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, master, (bf16_t*)fwd, (bf16_t*)bwd, Cout, KH,
+                       KW, Cin, KWp, Cinp, CoutB, rows_f, rows_b);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(weight_prepare_kernel<float>, dim3((int)g), dim3(256), 0, s, master, (float*)fwd, (float*)bwd, Cout, KH, KW,
+                       Cin, KWp, Cinp, CoutB, rows_f, rows_b);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// padded gradient [CoutP][KH][KWp][Cinp] -> master layout [Cout][KH][KW][Cin]
+__global__ void weight_grad_unpad_kernel(const float* __restrict__ padded, float* __restrict__ grad, int Cout, int KH, int KW,
+                                         int Cin, int KWp, int Cinp, int accumulate) {
+  const int64_t n = (int64_t)Cout * KH * KW * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i;
+    const int ci = (int)(r % Cin); r /= Cin;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH);
+    const int co = (int)(r / KH);
+    const float v = padded[(((int64_t)co * KH + kh) * KWp + kw) * Cinp + ci];
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
+}
+
+extern "C" int stp_weight_grad_unpad(const float* padded, float* grad, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
+                                     int32_t KWp, int32_t Cinp, int32_t accumulate, void* stream) {
+  if (!padded || !grad) return STP_E_BADARG;
+  int64_t g = ((int64_t)Cout * KH * KW * Cin + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(weight_grad_unpad_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, padded, grad, Cout, KH, KW, Cin,
+                     KWp, Cinp, accumulate);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// Gradient of the beta of the input BatchNormalization (bn_data, scale=False) without a stem
+// data-gradient pass.  The stem input carries a constant-one 4th channel, so the padded stem
+// weight gradient holds S[co][kh][kw] = sum over valid taps of dY in channel slot `one_ch`;
+//   dbeta[c] = sum_{co,kh,kw} W[co][kh][kw][c] * S[co][kh][kw].
+__global__ void stem_beta_grad_kernel(const float* __restrict__ padded_dw, const float* __restrict__ w, float* __restrict__ dbeta,
+                                      int Cout, int KH, int KW, int Cin, int KWp, int Cinp, int one_ch) {
+  const int c = blockIdx.x;
+  float a = 0.f;
+  const int n = Cout * KH * KW;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    int r = i;
+    const int kw = r % KW; r /= KW;
+    const int kh = r % KH;
+    const int co = r / KH;
+    a += w[(((int64_t)co * KH + kh) * KW + kw) * Cin + c] * padded_dw[(((int64_t)co * KH + kh) * KWp + kw) * Cinp + one_ch];
+  }
+  a = wave_sum(a);
+  if (threadIdx.x == 0) dbeta[c] = a;
+}
+
+extern "C" int stp_stem_beta_grad(const float* padded_dw, const float* master, float* dbeta, int32_t Cout, int32_t KH,
+                                  int32_t KW, int32_t Cin, int32_t KWp, int32_t Cinp, int32_t one_ch, void* stream) {
+  if (!padded_dw || !master || !dbeta || one_ch >= Cinp) return STP_E_BADARG;
+  hipLaunchKernelGGL(stem_beta_grad_kernel, dim3(Cin), dim3(64), 0, (hipStream_t)stream, padded_dw, master, dbeta, Cout, KH, KW,
+                     Cin, KWp, Cinp, one_ch);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) dst[i] = f32_to_bf16(src[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t count, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) dst[i] = bf16_to_f32(src[i]) * scale;
+}
+extern "C" int stp_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream) {
+  if (!src || !dst || count <= 0) return STP_E_BADARG;
+  int64_t g = (count + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, count);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+extern "C" int stp_cast_bf16_to_f32(const void* src, float* dst, int64_t count, float scale, void* stream) {
+  if (!src || !dst || count <= 0) return STP_E_BADARG;
+  int64_t g = (count + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, count, scale);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_abi_version(void) { return 1; }

@@ -1,0 +1,98 @@
+"""Data-parallel training: one process per GPU, gradients averaged with RCCL over xGMI.
+
+The reference's multi-GPU mode is ``cfg.gpus = N`` (README.md:756-760: in-graph replicas via
+keras ``multi_gpu_model``, no collective library); ``--num_gpus/--gpus_per_net`` of ``musket fit``
+(README.md:45-57) choose how many devices an experiment may use.  Here every rank owns a full
+replica; after the backward graph the flat fp32 gradient arena is all-reduced in a few large
+buckets (xGMI is point-to-point: ring collectives are per-link bound, so buckets are sized in
+tens of MB, not per layer) and the 1/world mean is folded into the optimizer's gradient scale.
+BatchNormalization statistics stay per replica, as with the reference's towers.
+
+``torch.distributed`` backend "nccl" IS RCCL on ROCm; "gloo" is used by the CPU test-suite to
+exercise the same bucketing logic.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when absent."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def bucket_bounds(numel, bucket_elems, align=4):
+    """Splits [0, numel) into contiguous buckets of ~bucket_elems (multiples of ``align``)."""
+    bucket_elems = max(align, (int(bucket_elems) // align) * align)
+    out, s = [], 0
+    while s < numel:
+        e = min(numel, s + bucket_elems)
+        out.append((s, e))
+        s = e
+    return out
+
+
+class GradReducer(object):
+    """Sum-all-reduce of a flat gradient arena in buckets; the mean's 1/world factor is NOT applied
+    to the arena - read it from ``scale`` and fold it into the optimizer (HipSegModel.gscale)."""
+
+    def __init__(self, group=None, bucket_mb=32.0, wire_bf16=False, cast_fns=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.wire_bf16 = wire_bf16
+        self.cast_fns = cast_fns        # (f32->bf16, bf16->f32) device kernels when wire_bf16
+        self._wire = None
+        self._bounds = None
+
+    @property
+    def scale(self):
+        return 1.0 / self.world
+
+    def allreduce(self, flat):
+        if self.world <= 1:
+            return
+        if self._bounds is None or self._bounds[-1][1] != flat.numel():
+            self._bounds = bucket_bounds(flat.numel(), self.bucket_elems)
+        if self.wire_bf16:
+            if self._wire is None or self._wire.numel() != flat.numel():
+                self._wire = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            to_bf16, to_f32 = self.cast_fns
+            works = []
+            for s, e in self._bounds:
+                to_bf16(flat[s:e], self._wire[s:e], e - s)
+                works.append(dist.all_reduce(self._wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for (s, e), w in zip(self._bounds, works):
+                w.wait()
+                to_f32(self._wire[s:e], flat[s:e], e - s)
+            return
+        works = [dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in self._bounds]
+        for w in works:
+            w.wait()
+
+
+def shard_indices(n, rank, world, epoch, seed):
+    """Per-epoch permutation shared by all ranks (same seed), strided by rank; every rank gets
+    the same number of samples (the tail wraps around) so collectives stay aligned."""
+    g = torch.Generator()
+    g.manual_seed(int(seed) * 1000003 + int(epoch))
+    perm = torch.randperm(n, generator=g).tolist()
+    per = (n + world - 1) // world
+    perm = perm + perm[: per * world - n]
+    return perm[rank::world][:per]

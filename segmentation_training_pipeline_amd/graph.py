@@ -1,0 +1,425 @@
+"""Static training/inference plan: the host-side runtime of the HIP hot path.
+
+A network definition (``nets.py``) is executed ONCE against a :class:`Plan`; every layer call
+records the C-ABI launches of its forward, pushes a closure for its backward, and declares its
+parameters inside flat fp32 arenas (master weights ``P``, gradients ``G``, optimizer state,
+BN moving statistics ``S``).  The result is three launch lists - ``prep`` (weight compute
+copies), ``fwd`` (+loss), ``bwd`` - plus ``opt``; a step replays them on one HIP stream, eagerly or
+as a captured hipGraph.  There is no tracing compiler and no autograd: gradients meet by
+plan-time bookkeeping (first writer overwrites, later writers accumulate in the GEMM epilogue).
+
+PyTorch supplies device memory (``torch.empty``), the stream handle and - in ``distributed.py`` -
+the RCCL process group; all arithmetic happens in libstp_hip.so.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+_TD = {"bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+class StpShapeError(ValueError):
+    pass
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+class DT(object):
+    """Device tensor handle: NHWC activation + (optional) gradient buffer."""
+    __slots__ = ("name", "N", "H", "W", "C", "buf", "grad", "grad_ready", "needs_grad", "gradC", "meta")
+
+    def __init__(self, name, N, H, W, Cn, buf=None, needs_grad=False):
+        self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cn
+        self.buf, self.grad, self.grad_ready, self.needs_grad = buf, None, False, needs_grad
+        self.gradC = Cn
+        self.meta = {}
+
+    @property
+    def rows(self):
+        return self.N * self.H * self.W
+
+
+class ParamInfo(object):
+    __slots__ = ("name", "offset", "numel", "shape", "kind", "trainable")
+
+    def __init__(self, name, offset, shape, kind, trainable):
+        self.name, self.offset, self.shape, self.kind, self.trainable = name, offset, tuple(shape), kind, trainable
+        self.numel = int(np.prod(shape))
+
+
+class Plan(object):
+    def __init__(self, batch, dtype="bf16", device="cuda", training=True):
+        if dtype not in _TD:
+            raise ValueError("dtype must be 'bf16' or 'fp32'")
+        self.device = torch.device(device)
+        # A plan may be BUILT on CPU tensors (structure/shape checks in the CPU test suite);
+        # it can only RUN on the GPU: run() raises otherwise - there is no CPU compute path.
+        if self.device.type == "cuda" and not torch.cuda.is_available():
+            raise _lib.StpError("the HIP training path needs a GPU; there is no CPU fallback")
+        self.lib = _lib.load()
+        self.N = batch
+        self.dtype = dtype
+        self.tdt = _TD[dtype]
+        self.cdt = ops.BF16 if dtype == "bf16" else ops.F32
+        self.vec = 8 if dtype == "bf16" else 4
+        self.training = training
+        self.params = OrderedDict()
+        self.states = OrderedDict()
+        self._poff = 0
+        self._soff = 0
+        self.dry = True
+        self.frozen_prefixes = ()
+        self._keep = []
+        self.tensors = OrderedDict()
+        self.P = self.G = self.S = None
+        self.prep, self.fwd, self.bwd, self.opt = [], [], [], []
+        self._tape = []
+        self._wg_ws_bytes = 0
+        self._bn_ws_c = 4
+        self.bn_momentum = 0.99
+        self.loss_scalars = None
+        self.inputs = {}
+
+    # ------------------------------------------------------------------ definition driver
+    def define(self, net_fn, share=None):
+        """Runs ``net_fn(plan)`` twice: a dry pass that sizes the arenas, then the real pass.
+        ``share``: another plan of the same network whose parameter / moving-statistics arenas
+        are reused (the inference plan shares the training plan's weights)."""
+        self.dry = True
+        net_fn(self)
+        n = _rup(self._poff, 4)
+        if share is not None:
+            if [(k, v.offset, v.shape) for k, v in share.params.items()] != [(k, v.offset, v.shape) for k, v in self.params.items()] \
+                    or list(share.states.items()) != list(self.states.items()):
+                raise StpShapeError("plans that share weights must declare identical parameters")
+            self.P, self.S, self.G = share.P, share.S, None
+        else:
+            self.P = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.G = torch.zeros(n, dtype=torch.float32, device=self.device) if self.training else None
+            self.S = torch.zeros(max(_rup(self._soff, 4), 4), dtype=torch.float32, device=self.device)
+        self.mask = torch.ones(n, dtype=torch.uint8, device=self.device)
+        self.ws_wgrad = torch.empty(max(self._wg_ws_bytes // 4, 4) + 4, dtype=torch.float32, device=self.device)
+        self.ws_bn = torch.empty(ops.bn_workspace_bytes(_rup(self._bn_ws_c, 4)) // 4, dtype=torch.float32, device=self.device)
+        self.ws_loss = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
+        self.dry = False
+        self._tape = []
+        self.tensors = OrderedDict()
+        net_fn(self)
+        if self.training:
+            for back in reversed(self._tape):
+                back()
+        self._tape = []
+        return self
+
+    # ------------------------------------------------------------------ parameters / state
+    def param(self, name, shape, kind="weight"):
+        if self.dry:
+            off = _rup(self._poff, 4)
+            trainable = not any(name.startswith(p) for p in self.frozen_prefixes)
+            self.params[name] = ParamInfo(name, off, shape, kind, trainable)
+            self._poff = off + int(np.prod(shape))
+        return self.params[name]
+
+    def state(self, name, numel, init=0.0):
+        if self.dry:
+            off = _rup(self._soff, 4)
+            self.states[name] = (off, numel, init)
+            self._soff = off + numel
+        return self.states[name][0]
+
+    def _pptr(self, info):
+        return self.P.data_ptr() + 4 * info.offset
+
+    def _gptr(self, info):
+        return self.G.data_ptr() + 4 * info.offset
+
+    def _sptr(self, off):
+        return self.S.data_ptr() + 4 * off
+
+    # ------------------------------------------------------------------ buffers / launches
+    def _alloc(self, shape, dtype=None):
+        t = torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _new(self, name, H, W, Cn, needs_grad, dtype=None):
+        t = DT(name, self.N, H, W, Cn, None if self.dry else self._alloc((self.N, H, W, Cn), dtype), needs_grad)
+        self.tensors[name] = t
+        return t
+
+    def _gradbuf(self, t):
+        if t.grad is None:
+            t.grad = self._alloc((t.N, t.H, t.W, t.gradC))
+        return t.grad
+
+    # a launch record is (C function, args without the trailing stream, entry-point name, meta);
+    # meta carries the layer name and the ALGORITHMIC flops of GEMM launches for bench.py's roofline.
+    def _emit(self, lst, fname, *args):
+        lst.append((getattr(self.lib, fname), args, fname, None))
+
+    def _emit_conv(self, lst, p, meta=None):
+        self._keep.append(p)
+        lst.append((self.lib.stp_conv2d, (C.byref(p),), "stp_conv2d", meta))
+
+    def _emit_wgrad(self, lst, p, meta=None):
+        self._keep.append(p)
+        lst.append((self.lib.stp_conv2d_wgrad, (C.byref(p), self.ws_wgrad.data_ptr(), self.ws_wgrad.numel() * 4),
+                    "stp_conv2d_wgrad", meta))
+
+    # ------------------------------------------------------------------ layers
+    def input_u8(self, name, H, W, Cn):
+        t = DT(name, self.N, H, W, Cn, None if self.dry else self._alloc((self.N, H, W, Cn), torch.uint8))
+        self.inputs[name] = t
+        return t
+
+    def input_bn(self, name, x, eps):
+        """BatchNormalization(scale=False) on the raw uint8 image -> dtype tensor padded to 4
+        channels whose last channel is the constant 1 (see stp_stem_beta_grad)."""
+        if x.C > 4:
+            raise StpShapeError("input_bn handles up to 4 image channels")
+        beta = self.param(name + "/beta", (x.C,), "beta")
+        mm = self.state(name + "/moving_mean", x.C, 0.0)
+        mv = self.state(name + "/moving_variance", x.C, 1.0)
+        out = self._new(name, x.H, x.W, 4, False)
+        out.meta["real_c"] = x.C
+        out.meta["input_bn_beta"] = beta
+        if self.dry:
+            return out
+        if self.training:
+            mean, rstd = self._alloc((x.C,), torch.float32), self._alloc((x.C,), torch.float32)
+            self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), ops.U8, x.rows, x.C, eps, self.bn_momentum,
+                       mean.data_ptr(), rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(),
+                       self.ws_bn.numel() * 4)
+            self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, 4,
+                       mean.data_ptr(), rstd.data_ptr(), None, self._pptr(beta), 0, 1.0)
+        else:
+            self._emit(self.fwd, "stp_bn_inference", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, 4,
+                       self._sptr(mm), self._sptr(mv), eps, None, self._pptr(beta), 0, 1.0)
+        return out
+
+    def bn(self, name, x, eps, relu=True, scale=True):
+        Cn = x.C
+        gamma = self.param(name + "/gamma", (Cn,), "gamma") if scale else None
+        beta = self.param(name + "/beta", (Cn,), "beta")
+        mm = self.state(name + "/moving_mean", Cn, 0.0)
+        mv = self.state(name + "/moving_variance", Cn, 1.0)
+        trainable = beta.trainable
+        out = self._new(name, x.H, x.W, Cn, x.needs_grad or trainable)
+        self._bn_ws_c = max(self._bn_ws_c, Cn)
+        if self.dry:
+            return out
+        gp = self._pptr(gamma) if gamma else None
+        if not self.training:
+            self._emit(self.fwd, "stp_bn_inference", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
+                       self._sptr(mm), self._sptr(mv), eps, gp, self._pptr(beta), int(relu), 0.0)
+            return out
+        mean, rstd = self._alloc((Cn,), torch.float32), self._alloc((Cn,), torch.float32)
+        self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), self.cdt, x.rows, Cn, eps, self.bn_momentum, mean.data_ptr(),
+                   rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
+        self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
+                   mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu), 0.0)
+
+        def back():
+            if not out.needs_grad or not out.grad_ready:
+                return
+            # dx is always produced (it is cheap relative to skipping logic); frozen params are masked in the optimizer
+            dx = self._gradbuf(x) if x.needs_grad else self._alloc((x.N, x.H, x.W, Cn))
+            self._emit(self.bwd, "stp_bn_backward", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt, x.rows, Cn,
+                       mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), self._gptr(gamma) if gamma else None,
+                       self._gptr(beta), int(relu), int(x.grad_ready and x.needs_grad), self.ws_bn.data_ptr(),
+                       self.ws_bn.numel() * 4)
+            if x.needs_grad:
+                x.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
+    def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None):
+        """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
+        ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add()."""
+        real_c0 = x.meta.get("real_c", x.C)
+        stem = real_c0 != x.C
+        if stem and (src1 is not None or upsample):
+            raise StpShapeError("padded-channel input supports a plain conv only")
+        C0, C1 = x.C, (src1.C if src1 is not None else 0)
+        if not stem and (C0 % self.vec or C1 % self.vec):
+            raise StpShapeError("%s: input channels (%d,%d) must be multiples of %d for dtype %s" % (name, C0, C1, self.vec, self.dtype))
+        Hv, Wv = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
+        if src1 is not None and (src1.H, src1.W) != (Hv, Wv):
+            raise StpShapeError("%s: skip tensor is %dx%d, expected %dx%d" % (name, src1.H, src1.W, Hv, Wv))
+        Ho, Wo = (Hv + 2 * pad - k) // stride + 1, (Wv + 2 * pad - k) // stride + 1
+        KWp = k + (k & 1) if stem else k
+        Cin_master = real_c0 + C1
+        Cinp = C0 + C1
+        w = self.param(name + "/kernel", (Cout, k, k, Cin_master), "kernel")
+        b = self.param(name + "/bias", (Cout,), "bias") if bias else None
+        CoutB = _rup(Cout, self.vec)
+        x_ng = x.needs_grad
+        s_ng = src1.needs_grad if src1 is not None else False
+        out = self._new(name, Ho, Wo, Cout, x_ng or s_ng or w.trainable or (residual is not None and residual.needs_grad))
+        out.gradC = CoutB
+        # workspace sizing needs the wgrad plan: query the library (cheap, host only)
+        wp = _lib.WgradParams()
+        wp.N, wp.Hs0, wp.Ws0, wp.Hv, wp.Wv, wp.C0, wp.C1 = self.N, x.H, x.W, Hv, Wv, C0, C1
+        wp.src0_mode = ops.SRC_NEAREST2X if upsample else ops.SRC_DIRECT
+        wp.KH, wp.KW, wp.stride, wp.pad, wp.Ho, wp.Wo, wp.Cout = k, KWp, stride, pad, Ho, Wo, CoutB
+        wp.accumulate, wp.dtype, wp.splits = 0, self.cdt, 0
+        if self.training and w.trainable:
+            self._wg_ws_bytes = max(self._wg_ws_bytes, int(self.lib.stp_conv2d_wgrad_workspace_bytes(C.byref(wp))))
+        if self.dry:
+            return out
+        rows_f, rows_b = _rup(Cout, 16), _rup(Cinp, 16)
+        wf = self._alloc((rows_f * k * KWp * Cinp,))
+        need_dgrad = self.training and (x_ng or s_ng) and not stem
+        wb = self._alloc((rows_b * k * k * CoutB,)) if need_dgrad else None
+        self._emit(self.prep, "stp_weight_prepare", self._pptr(w), wf.data_ptr(), wb.data_ptr() if wb is not None else None,
+                   Cout, k, k, Cin_master, KWp, Cinp, CoutB, self.cdt)
+        p = ops.conv_params(x.buf, wf, out.buf, N=self.N, Hs0=x.H, Ws0=x.W, Hv=Hv, Wv=Wv, C0=C0, C1=C1,
+                            src1=src1.buf if src1 is not None else None,
+                            mode=ops.SRC_NEAREST2X if upsample else ops.SRC_DIRECT, KH=k, KW=KWp, stride=stride, pad=pad,
+                            Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
+        if b is not None:
+            p.bias = self._pptr(b)
+        # algorithmic work of this layer: 2 * pixels * Cout * KH*KW*Cin with the REAL (unpadded) dims
+        flops = 2.0 * self.N * Ho * Wo * Cout * k * k * Cin_master
+        self._emit_conv(self.fwd, p, {"layer": name, "pass": "fwd", "flops": flops, "tile": int(self.lib.stp_conv2d_tile_for(C.byref(p)))})
+        if not self.training:
+            return out
+
+        def back():
+            if not out.needs_grad or not out.grad_ready:
+                return
+            dy = out.grad
+            rows = out.rows
+            # residual branch: d(residual) = dY
+            if residual is not None and residual.needs_grad:
+                if not residual.grad_ready and residual.gradC == out.gradC:
+                    residual.grad = dy          # alias: dY is dead once this layer's backward has been issued
+                    residual.grad_ready = True
+                else:
+                    self._emit(self.bwd, "stp_add_inplace", self._gradbuf(residual).data_ptr(), dy.data_ptr(),
+                               rows * out.gradC, self.cdt)
+            # weight gradient
+            if w.trainable:
+                padded = stem or CoutB != Cout
+                if padded:
+                    dwp = self._alloc((CoutB * k * KWp * Cinp,), torch.float32)
+                    wp.dw = dwp.data_ptr()
+                else:
+                    wp.dw = self._gptr(w)
+                wp.src0, wp.src1, wp.dy = x.buf.data_ptr(), (src1.buf.data_ptr() if src1 is not None else None), dy.data_ptr()
+                self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB})
+                if padded:
+                    self._emit(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
+                               Cinp, 0)
+                beta = x.meta.get("input_bn_beta")
+                if stem and beta is not None and beta.trainable:
+                    self._emit(self.bwd, "stp_stem_beta_grad", dwp.data_ptr(), self._pptr(w), self._gptr(beta), Cout, k, k,
+                               real_c0, KWp, Cinp, real_c0)
+            if b is not None and b.trainable:
+                tmp = self._alloc((CoutB,), torch.float32)
+                self._emit(self.bwd, "stp_channel_sum", dy.data_ptr(), self.cdt, rows, CoutB, tmp.data_ptr(), 0,
+                           self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
+                self._emit(self.bwd, "stp_weight_grad_unpad", tmp.data_ptr(), self._gptr(b), Cout, 1, 1, 1, 1, 1, 0)
+            # data gradient
+            if need_dgrad:
+                if upsample:
+                    d0 = self._alloc((self.N, Hv, Wv, C0)) if x_ng else None
+                    acc0 = 0
+                else:
+                    d0 = self._gradbuf(x) if x_ng else None
+                    acc0 = int(x.grad_ready)
+                d1 = self._gradbuf(src1) if s_ng else None
+                acc1 = int(src1.grad_ready) if s_ng else 0
+                if d0 is None:
+                    d0 = self._alloc((self.N, Hv, Wv, C0))      # gradient not wanted: scratch sink
+                if C1 and d1 is None:
+                    d1 = self._alloc((self.N, Hv, Wv, C1))
+                q = ops.conv_params(dy, wb, d0, N=self.N, Hs0=Ho, Ws0=Wo,
+                                    Hv=(2 * Ho - 1 if stride == 2 else Ho), Wv=(2 * Wo - 1 if stride == 2 else Wo),
+                                    C0=CoutB, mode=(ops.SRC_ZEROINS2X if stride == 2 else ops.SRC_DIRECT), KH=k, KW=k, stride=1,
+                                    pad=k - 1 - pad, Ho=Hv, Wo=Wv, Cout=C0 + C1, dtype=self.cdt, dst1=d1, Cd0=C0,
+                                    accumulate0=acc0, accumulate1=acc1)
+                if stride not in (1, 2):
+                    raise StpShapeError("data gradient supports stride 1 and 2")
+                self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": flops,
+                                              "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
+                if upsample and x_ng:
+                    self._emit(self.bwd, "stp_upsample2x_bwd", d0.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W,
+                               C0, C0, self.cdt, int(x.grad_ready))
+                if x_ng:
+                    x.grad_ready = True
+                if s_ng:
+                    src1.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
+    def maxpool(self, name, x):
+        Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+        out = self._new(name, Ho, Wo, x.C, x.needs_grad)
+        if self.dry:
+            return out
+        idx = self._alloc((self.N, Ho, Wo, x.C), torch.uint8) if self.training else None
+        self._emit(self.fwd, "stp_maxpool3x3s2", x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if idx is not None else None,
+                   self.N, x.H, x.W, x.C, self.cdt)
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            self._emit(self.bwd, "stp_maxpool3x3s2_bwd", idx.data_ptr(), out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N,
+                       x.H, x.W, x.C, self.cdt, int(x.grad_ready))
+            x.grad_ready = True
+
+        if self.training:
+            self._tape.append(back)
+        return out
+
+    def sigmoid_loss(self, logits, target, w_bce, w_dice):
+        """sigmoid + w_bce*binary_crossentropy + w_dice*dice_loss; seeds the backward pass."""
+        if logits.C != 1:
+            raise StpShapeError("binary loss expects one class")
+        if self.dry:
+            return
+        self.loss_scalars = self._alloc((8,), torch.float32)
+        count = logits.rows
+        dl = self._gradbuf(logits) if self.training else None
+        self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),
+                   float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC, 1.0,
+                   self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        logits.grad_ready = self.training
+
+    def sigmoid_out(self, logits):
+        """Activation('sigmoid') of the head for inference: float32 probabilities."""
+        if self.dry:
+            return None
+        probs = self._alloc((logits.N, logits.H, logits.W, logits.C), torch.float32)
+        self._emit(self.fwd, "stp_sigmoid", logits.buf.data_ptr(), probs.data_ptr(), logits.rows * logits.C, self.cdt)
+        self.probs = probs
+        return probs
+
+    # ------------------------------------------------------------------ execution
+    def run(self, launches):
+        if self.device.type != "cuda":
+            raise _lib.StpError("plans execute on the GPU only (no CPU fallback)")
+        st = torch.cuda.current_stream().cuda_stream
+        for fn, args, name, _meta in launches:
+            rc = fn(*args, st)
+            if rc != 0:
+                _lib.check(rc, name)
+
+    def init_states(self):
+        for name, (off, numel, init) in self.states.items():
+            self.S[off:off + numel] = init
+
+    def set_trainable_mask(self):
+        self.mask.fill_(1)
+        for info in self.params.values():
+            if not info.trainable:
+                self.mask[info.offset:info.offset + info.numel] = 0

@@ -1,0 +1,197 @@
+"""GPU parity tests of the whole training step (U-Net over ResNet) against the CPU oracle and the
+committed golden fixtures.  Bars (BASELINE.json north_star): logits within 1e-3, Dice within 1e-5
+in the exact-fp32 mode; the bf16 mode (the benchmarked precision) is held to the documented
+bf16 tolerances below.  Parity is vs the in-repo oracle: the reference's Keras path cannot run.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets as onets  # noqa: E402
+from oracle import step as ostep  # noqa: E402
+
+LOSS = "binary_crossentropy+1.0*dice_loss"
+TAP_MAP = [("bn_data", "bn_data"), ("conv0", "conv0"), ("relu0", "bn0"), ("pooling0", "pooling0"),
+           ("stage1_unit1_relu1", "stage1_unit1_bn1"), ("stage1_unit1_out", "stage1_unit1_conv2"),
+           ("stage2_unit1_out", "stage2_unit1_conv2"), ("stage3_unit1_out", "stage3_unit1_conv2"),
+           ("stage4_unit1_out", "stage4_unit1_conv2"), ("relu1", "bn1"),
+           ("decoder_stage0_relu2", "decoder_stage0_bn2"), ("decoder_stage2_relu2", "decoder_stage2_bn2"),
+           ("decoder_stage4_relu2", "decoder_stage4_bn2")]
+
+
+def make(backbone, size, n, dtype, use_graph=False, **kw):
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    return HipSegModel("Unet", backbone, (size, size, 3), 1, "sigmoid", batch=n, dtype=dtype, loss=kw.pop("loss", LOSS),
+                       optimizer=kw.pop("optimizer", "Adam"), lr=kw.pop("lr", 1e-3), use_graph=use_graph, **kw)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+
+
+def first_bad_tap(model, taps, atol):
+    """Localises a mismatch: walks the network in forward order."""
+    for oname, pname in TAP_MAP:
+        if oname not in taps:
+            continue
+        ref = taps[oname].detach().numpy()
+        got = model.activation(pname)[..., :ref.shape[-1]]
+        err = np.abs(got - ref).max()
+        if not err <= atol * max(1.0, np.abs(ref).max()):
+            return "%s: max err %.3g (ref max %.3g)" % (pname, err, np.abs(ref).max())
+    return None
+
+
+@pytest.mark.parametrize("backbone", ["resnet18", "resnet34"])
+def test_fp32_step_matches_oracle(backbone):
+    n, size = 2, 64
+    P = onets.init_unet_resnet(backbone, seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=1234)
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=LOSS, optimizer="sgd", lr=0.05, opt_kwargs={"momentum": 0.9})
+    m = make(backbone, size, n, "fp32", optimizer="SGD", lr=0.05, opt_kwargs={"momentum": 0.9})
+    m.set_weights(P)
+    taps = {}
+    o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
+    met = m.train_on_batch(x, y)
+    bad = first_bad_tap(m, taps, 2e-4)
+    assert bad is None, bad
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)                 # north-star bar
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5                             # north-star bar
+    assert abs(met["dice"] - o["dice"]) < 1e-5
+    assert abs(met["loss"] - o["loss"]) < 1e-5 * max(1.0, abs(o["loss"]))
+    assert abs(met["binary_crossentropy"] - o["bce"]) < 1e-5
+    assert abs(met["binary_accuracy"] - o["binary_accuracy"]) < 1e-6
+    # Gradients.  Two fp32 implementations of a ReLU network cannot agree element-wise on the sign of
+    # pre-activations that are within rounding (~1e-6) of zero; with ~1e6 activations about one such
+    # kink flips per step, and a single flip perturbs every upstream gradient by O(1e-3) relative L2
+    # (measured: HIP's dx equals an fp64 recomputation from its own buffers to 5e-8).  So: layers after
+    # the last ReLU-BN pair must agree tightly, all others in relative L2.
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = rel_l2(g[k], ref)
+        tight = k.startswith("final_conv")          # depends only on dL/dlogits and the last activation
+        assert e <= (1e-4 if tight else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
+    w = m.get_weights()
+    for k in tr.P:
+        np.testing.assert_allclose(w[k], tr.P[k], atol=5e-5, err_msg=k)
+    # second step: re-synchronise the weights first (the kink noise above times lr would otherwise be
+    # amplified by the next forward), then the forward must again agree to the 1e-3 bar and the
+    # momentum update must carry over.
+    m.set_weights(tr.P)
+    o2 = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met2 = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o2["logits"], atol=1e-3)
+    assert abs(met2["dice_loss"] - o2["dice_loss"]) < 1e-5
+    w = m.get_weights()
+    for k in tr.P:
+        np.testing.assert_allclose(w[k], tr.P[k], atol=2e-4, err_msg=k)
+
+
+def test_fp32_adam_step_matches_golden_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_resnet34_64.npz"))
+    P = onets.init_unet_resnet("resnet34", seed=int(g["seed"]))
+    m = make("resnet34", 64, 2, "fp32")
+    m.set_weights(P)
+    met = m.train_on_batch(g["x"], g["y"])
+    np.testing.assert_allclose(m.logits(), g["logits1"], atol=1e-3)
+    loss, bce, dice_loss, dice, acc = g["scalars1"]
+    assert abs(met["dice_loss"] - dice_loss) < 1e-5 and abs(met["dice"] - dice) < 1e-5
+    assert abs(met["loss"] - loss) < 2e-5
+    names = [str(s) for s in g["grad_names"]]
+    got = m.get_gradients()
+    l2 = np.array([np.sqrt((got[k].astype(np.float64) ** 2).sum()) for k in names])
+    np.testing.assert_allclose(l2, g["grad_l2_step1"], rtol=2e-2, atol=1e-6)   # ReLU-kink noise, see above
+    # Adam's first update is lr*sign(g) wherever |g| >> eps: elements whose gradient is at rounding
+    # level legitimately differ by up to 2*lr, and the next forward amplifies that, so the second
+    # step is held to a statistical band only.
+    met2 = m.train_on_batch(g["x"], g["y"])
+    d = np.abs(m.logits() - g["logits2"])
+    assert d.mean() < 2e-2 and np.corrcoef(m.logits().ravel(), g["logits2"].ravel())[0, 1] > 0.995
+    assert abs(met2["loss"] - g["scalars2"][0]) < 2e-2
+
+
+def test_hipgraph_replay_equals_eager():
+    P = onets.init_unet_resnet("resnet18", seed=7)
+    x, y = ostep.synthetic_batch(2, 64, 64, seed=5)
+    outs = []
+    for use_graph in (False, True):
+        m = make("resnet18", 64, 2, "bf16", use_graph=use_graph)
+        m.set_weights(P)
+        r = [m.train_on_batch(x, y) for _ in range(3)]
+        outs.append((r, m.logits(), m.get_weights()))
+    assert outs[0][0] == outs[1][0]                        # bitwise: kernels are deterministic
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        np.testing.assert_array_equal(outs[0][2][k], outs[1][2][k], err_msg=k)
+
+
+def test_bf16_step_close_to_fp32_oracle():
+    """bf16 storage / bf16 MFMA inputs / fp32 accumulation, the benchmarked precision.  Every layer
+    rounds inputs, weights and outputs to 8 significant bits (2^-9 relative RMS each), which over the
+    ~40 conv+BN layers of the path compounds to ~2 % of the logit range (measured 1.8 % mean).  The
+    per-kernel bf16 tests (test_ops_gpu.py) hold each kernel to one output rounding against the oracle
+    evaluated on the same bf16-rounded inputs; this test bounds the end-to-end drift."""
+    n, size = 2, 64
+    P = onets.init_unet_resnet("resnet18", seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=1234)
+    tr = ostep.OracleTrainer(P, backbone="resnet18", loss=LOSS, optimizer="adam", lr=1e-3)
+    m = make("resnet18", size, n, "bf16")
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    ref = o["logits"]
+    err = np.abs(m.logits() - ref)
+    rng_ = np.abs(ref).max()
+    assert err.mean() < 0.03 * rng_ and err.max() < 0.25 * rng_, (err.max(), err.mean(), rng_)
+    assert np.corrcoef(m.logits().ravel(), ref.ravel())[0, 1] > 0.98
+    assert abs(met["loss"] - o["loss"]) < 2e-2
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-2
+    g = m.get_gradients()
+    cos = []
+    for k, r in o["grads"].items():
+        if r.size > 64:
+            a, b = g[k].ravel().astype(np.float64), r.ravel().astype(np.float64)
+            cos.append(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    # bf16 drift of the forward (the net is evaluated at slightly perturbed activations) decorrelates
+    # the gradient by ~1.5 % per BN/ReLU pair going backwards: 0.996 at the head, ~0.8 at the stem
+    # (fp32 mode: 0.99999 everywhere - scratch/dbg_bf16.py).
+    assert min(cos) > 0.65 and max(cos) > 0.99, (min(cos), max(cos))
+    # training makes progress in bf16
+    losses = [met["loss"]] + [m.train_on_batch(x, y)["loss"] for _ in range(8)]
+    assert losses[-1] < losses[0]
+
+
+def test_freeze_encoder_and_predict_and_checkpoint(tmp_path):
+    n, size = 2, 64
+    P = onets.init_unet_resnet("resnet18", seed=3)
+    x, y = ostep.synthetic_batch(n, size, size, seed=9)
+    m = make("resnet18", size, n, "fp32", freeze_encoder=True)
+    m.set_weights(P)
+    tr = ostep.OracleTrainer(P, backbone="resnet18", loss=LOSS, optimizer="adam", lr=1e-3, freeze_encoder=True)
+    for _ in range(2):
+        m.train_on_batch(x, y)
+        tr.step(x.astype(np.float32), y.astype(np.float32))
+    w = m.get_weights()
+    for k in P:
+        if k.startswith("decoder_") or k.startswith("final_") or "moving" in k:
+            continue
+        np.testing.assert_array_equal(w[k], P[k], err_msg=k)       # frozen encoder parameters do not move
+    assert np.abs(w["decoder_stage0_conv1/kernel"] - P["decoder_stage0_conv1/kernel"]).max() > 0
+    # inference phase (moving statistics) vs the oracle's, on 3 images (chunking + padding of the last chunk)
+    x3 = np.concatenate([x, x[:1]], axis=0)
+    tr.P.update({k: w[k] for k in w})                              # same weights on both sides
+    ref = torch.sigmoid(torch.from_numpy(tr.forward(x3.astype(np.float32), training=False))).numpy()
+    np.testing.assert_allclose(m.predict(x3), ref, atol=2e-4)
+    # checkpoint round trip
+    path = str(tmp_path / "best-0.0.weights")
+    m.save_weights(path)
+    m2 = make("resnet18", size, n, "fp32")
+    m2.load_weights(path)
+    w2 = m2.get_weights()
+    for k in w:
+        np.testing.assert_array_equal(w[k], w2[k], err_msg=k)

@@ -1,0 +1,475 @@
+"""GPU parity tests: every C-ABI entry point against the CPU oracle (oracle/np_ops.py etc.).
+
+Parity is "vs the in-repo CPU oracle" - the reference's Keras path is not executable (see
+oracle/__init__.py).  Tolerances: fp32 mode 1e-4 relative to the output scale (exact-fp32 MFMA,
+only the summation order differs); bf16 mode compares against the oracle evaluated on the same
+bf16-rounded inputs, allowing one bf16 output rounding (2^-8 relative) plus fp32 accumulation.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import augment as oaug  # noqa: E402
+from oracle import losses as olosses  # noqa: E402
+from oracle import np_ops  # noqa: E402
+from oracle import optim as ooptim  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from segmentation_training_pipeline_amd import ops as o
+    return o
+
+
+DEV = "cuda"
+TD = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def q(a, dtype):
+    """Round a numpy array through the storage dtype (so oracle and kernel see equal inputs)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(TD[dtype]).to(torch.float32).numpy()
+
+
+_KEEP = []
+
+
+def dev(a, dtype):
+    """Device copy in the storage dtype.  Params structs hold raw pointers only, so every
+    temporary is parked in _KEEP until the test ends (see the autouse fixture)."""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(TD[dtype]).to(DEV).contiguous()
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def keep(t):
+    _KEEP.append(t)
+    return t
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+def tol(ref, dtype, k=1.0):
+    s = float(np.abs(ref).max()) + 1e-6
+    return (2e-4 if dtype == "fp32" else 1.2e-2) * s * k
+
+
+def prep_weights(ops, w_hwio, dtype, KWp=None, Cinp=None, CoutB=None):
+    """HWIO numpy -> (master OHWI fp32 dev, fwd copy, bwd copy)."""
+    kh, kw, ci, co = w_hwio.shape
+    KWp = KWp or kw
+    Cinp = Cinp or ci
+    vec = 8 if dtype == "bf16" else 4
+    CoutB = CoutB or ((co + vec - 1) // vec * vec)
+    master = torch.from_numpy(np.ascontiguousarray(w_hwio.transpose(3, 0, 1, 2), dtype=np.float32)).to(DEV)
+    rows_f = (co + 15) // 16 * 16
+    rows_b = (ci + 15) // 16 * 16
+    fwd = torch.empty(rows_f * kh * KWp * Cinp, dtype=TD[dtype], device=DEV)
+    bwd = torch.empty(rows_b * kh * kw * CoutB, dtype=TD[dtype], device=DEV)
+    ops.weight_prepare(master, fwd, bwd, co, kh, kw, ci, KWp, Cinp, CoutB, ops.dt(fwd))
+    return master, fwd, bwd, CoutB
+
+
+CONV_CASES = [
+    # n, h, w, ci, co, k, stride, pad, tile
+    (2, 16, 16, 32, 128, 3, 1, 1, 1),
+    (2, 16, 16, 64, 64, 3, 1, 1, 2),
+    (1, 24, 20, 16, 32, 3, 1, 1, 3),
+    (1, 20, 24, 32, 16, 3, 1, 1, 4),
+    (2, 9, 11, 64, 64, 3, 1, 1, 5),
+    (2, 12, 12, 128, 256, 3, 2, 1, 6),
+    (2, 16, 16, 64, 128, 1, 2, 0, 0),
+    (1, 8, 8, 256, 512, 3, 1, 1, 0),
+    (3, 7, 5, 24, 40, 3, 1, 1, 0),     # ragged everything (Cout multiple of 4 only)
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_forward(ops, dtype, case):
+    n, h, w, ci, co, k, s, p, tile = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(k, k, ci, co) / np.sqrt(k * k * ci), dtype)
+    ref = np_ops.conv2d(x, wt, s, p)
+    ho, wo = ref.shape[1:3]
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    xd = dev(x, dtype)
+    y = torch.full((n, ho, wo, co), float("nan"), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(xd, fwd, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=k, KW=k, stride=s, pad=p,
+                        Ho=ho, Wo=wo, Cout=co, dtype=ops.dt(y), tile=tile)
+    ops.conv2d(P)
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv2d_epilogue_bias_residual_relu_dualdest_accumulate(ops, dtype):
+    rng = np.random.RandomState(3)
+    n, h, w, ci, co = 2, 10, 10, 32, 48
+    x = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / 17.0, dtype)
+    bias = rng.randn(co).astype(np.float32)
+    res = q(rng.randn(n, h, w, co), dtype)
+    ref = np.maximum(np_ops.conv2d(x, wt, 1, 1, bias) + res, 0)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    y = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(dev(x, dtype), fwd, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1,
+                        Ho=h, Wo=w, Cout=co, dtype=ops.dt(y), bias=keep(torch.from_numpy(bias).to(DEV)),
+                        residual=dev(res, dtype), relu=1)
+    ops.conv2d(P)
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+    # dual destination with accumulate on the second one
+    ref2 = np_ops.conv2d(x, wt, 1, 1)
+    d0 = torch.empty((n, h, w, 16), dtype=TD[dtype], device=DEV)
+    init1 = q(rng.randn(n, h, w, 32), dtype)
+    d1 = dev(init1, dtype)
+    P = ops.conv_params(dev(x, dtype), fwd, d0, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1,
+                        Ho=h, Wo=w, Cout=co, dtype=ops.dt(y), dst1=d1, Cd0=16, accumulate1=1)
+    ops.conv2d(P)
+    np.testing.assert_allclose(host(d0), ref2[..., :16], atol=tol(ref2, dtype))
+    np.testing.assert_allclose(host(d1), ref2[..., 16:] + init1, atol=tol(ref2, dtype, 2))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv2d_head_single_class_with_bias(ops, dtype):
+    rng = np.random.RandomState(4)
+    n, h, w, ci, co = 2, 12, 12, 16, 1
+    x = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / 12.0, dtype)
+    bias = np.array([0.3], np.float32)
+    ref = np_ops.conv2d(x, wt, 1, 1, bias)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    y = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(dev(x, dtype), fwd, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1,
+                        Ho=h, Wo=w, Cout=co, dtype=ops.dt(y), bias=keep(torch.from_numpy(bias).to(DEV)))
+    ops.conv2d(P)
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv2d_upsample_concat_gather(ops, dtype):
+    """decoder conv1: conv3x3(concat(UpSampling2D(2)(x), skip)) without materialising either."""
+    rng = np.random.RandomState(5)
+    n, h, w, c0, c1, co = 2, 6, 7, 32, 16, 64
+    x = q(rng.randn(n, h, w, c0), dtype)
+    skip = q(rng.randn(n, 2 * h, 2 * w, c1), dtype)
+    wt = q(rng.randn(3, 3, c0 + c1, co) / 20.0, dtype)
+    v = np.concatenate([np_ops.upsample2x(x), skip], axis=-1)
+    ref = np_ops.conv2d(v, wt, 1, 1)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    y = torch.empty((n, 2 * h, 2 * w, co), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(dev(x, dtype), fwd, y, N=n, Hs0=h, Ws0=w, Hv=2 * h, Wv=2 * w, C0=c0, C1=c1, src1=dev(skip, dtype),
+                        mode=ops.SRC_NEAREST2X, KH=3, KW=3, stride=1, pad=1, Ho=2 * h, Wo=2 * w, Cout=co, dtype=ops.dt(y))
+    ops.conv2d(P)
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("geom", [(3, 1, 1, 10, 12), (3, 2, 1, 12, 10), (1, 2, 0, 8, 8), (3, 2, 1, 9, 11)])
+def test_conv2d_data_gradient(ops, dtype, geom):
+    """dgrad = stp_conv2d over dY with the flipped/transposed weight copy (zero-insertion for stride 2)."""
+    k, s, p, h, w = geom
+    rng = np.random.RandomState(6)
+    n, ci, co = 2, 32, 64
+    wt = q(rng.randn(k, k, ci, co) / np.sqrt(k * k * co), dtype)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = q(rng.randn(n, ho, wo, co), dtype)
+    ref = np_ops.conv2d_dgrad(dy, wt, (h, w), s, p)
+    _, _, bwd, coB = prep_weights(ops, wt, dtype)
+    dx = torch.empty((n, h, w, ci), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(dev(dy, dtype), bwd, dx, N=n, Hs0=ho, Ws0=wo, Hv=(2 * ho - 1 if s == 2 else ho),
+                        Wv=(2 * wo - 1 if s == 2 else wo), C0=coB, mode=(ops.SRC_ZEROINS2X if s == 2 else ops.SRC_DIRECT),
+                        KH=k, KW=k, stride=1, pad=k - 1 - p, Ho=h, Wo=w, Cout=ci, dtype=ops.dt(dx))
+    ops.conv2d(P)
+    np.testing.assert_allclose(host(dx), ref, atol=tol(ref, dtype))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_stem_conv_7x7_s2_padded_channels(ops, dtype):
+    """conv0: 7x7/2 over a 3-channel image stored as 4 channels (4th = 1), weights padded to 7x8x4."""
+    rng = np.random.RandomState(7)
+    n, h, w, co = 2, 32, 36, 64
+    x3 = q(rng.randn(n, h, w, 3), dtype)
+    wt = q(rng.randn(7, 7, 3, co) / 12.0, dtype)
+    ref = np_ops.conv2d(x3, wt, 2, 3)
+    ho, wo = ref.shape[1:3]
+    x4 = np.concatenate([x3, np.ones((n, h, w, 1), np.float32)], axis=-1)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype, KWp=8, Cinp=4)
+    y = torch.empty((n, ho, wo, co), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(dev(x4, dtype), fwd, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=4, KH=7, KW=8, stride=2, pad=3,
+                        Ho=ho, Wo=wo, Cout=co, dtype=ops.dt(y))
+    ops.conv2d(P)
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+    # weight gradient through the same padded geometry + the bn_data beta gradient trick
+    dy = q(rng.randn(n, ho, wo, co), dtype)
+    refw = np_ops.conv2d_wgrad(x3, dy, (7, 7), 2, 3)
+    dwp = torch.zeros((co, 7, 8, 4), dtype=torch.float32, device=DEV)
+    W = ops.wgrad_params(dev(x4, dtype), dev(dy, dtype), dwp, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=4, KH=7, KW=8, stride=2,
+                         pad=3, Ho=ho, Wo=wo, Cout=co, dtype=ops.dt(y))
+    ws = torch.empty(ops.wgrad_workspace_bytes(W) // 4 + 4, dtype=torch.float32, device=DEV)
+    ops.conv2d_wgrad(W, ws)
+    g = torch.empty((co, 7, 7, 3), dtype=torch.float32, device=DEV)
+    ops.weight_grad_unpad(dwp, g, co, 7, 7, 3, 8, 4)
+    np.testing.assert_allclose(host(g).transpose(1, 2, 3, 0), refw, atol=tol(refw, dtype))
+    # d(sum over valid taps) : dbeta of an input BN with identity scale = sum_c dX[..., c]
+    refdx = np_ops.conv2d_dgrad(dy, wt, (h, w), 2, 3)
+    master = torch.from_numpy(np.ascontiguousarray(wt.transpose(3, 0, 1, 2))).to(DEV)
+    db = torch.empty(3, dtype=torch.float32, device=DEV)
+    ops.stem_beta_grad(dwp, master, db, co, 7, 7, 3, 8, 4, 3)
+    refdb = refdx.sum(axis=(0, 1, 2))
+    np.testing.assert_allclose(host(db), refdb, atol=tol(refdb, dtype, 4))
+
+
+WGRAD_CASES = [
+    # n, h, w, ci, co, k, stride, pad, splits
+    (2, 16, 16, 32, 128, 3, 1, 1, 0),
+    (2, 16, 16, 64, 64, 3, 1, 1, 3),
+    (1, 24, 20, 16, 32, 3, 1, 1, 0),
+    (1, 20, 24, 32, 16, 3, 1, 1, 5),
+    (2, 12, 12, 128, 256, 3, 2, 1, 1),
+    (2, 16, 16, 64, 128, 1, 2, 0, 0),
+    (3, 7, 5, 24, 40, 3, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv2d_weight_gradient(ops, dtype, case):
+    n, h, w, ci, co, k, s, p, splits = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = q(rng.randn(n, h, w, ci), dtype)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = q(rng.randn(n, ho, wo, co), dtype)
+    ref = np_ops.conv2d_wgrad(x, dy, (k, k), s, p)  # HWIO
+    dw = torch.full((co, k, k, ci), float("nan"), dtype=torch.float32, device=DEV)
+    W = ops.wgrad_params(dev(x, dtype), dev(dy, dtype), dw, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=k, KW=k, stride=s,
+                         pad=p, Ho=ho, Wo=wo, Cout=co, dtype=ops.dt(dev(x, dtype)), splits=splits)
+    ws = torch.empty(ops.wgrad_workspace_bytes(W) // 4 + 4, dtype=torch.float32, device=DEV)
+    ops.conv2d_wgrad(W, ws)
+    np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
+    # accumulate
+    W.accumulate = 1
+    ops.conv2d_wgrad(W, ws)
+    np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), 2 * ref, atol=tol(ref, dtype, 2))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv2d_weight_gradient_upsample_concat(ops, dtype):
+    rng = np.random.RandomState(9)
+    n, h, w, c0, c1, co = 2, 6, 7, 32, 16, 64
+    x = q(rng.randn(n, h, w, c0), dtype)
+    skip = q(rng.randn(n, 2 * h, 2 * w, c1), dtype)
+    dy = q(rng.randn(n, 2 * h, 2 * w, co), dtype)
+    v = np.concatenate([np_ops.upsample2x(x), skip], axis=-1)
+    ref = np_ops.conv2d_wgrad(v, dy, (3, 3), 1, 1)
+    dw = torch.empty((co, 3, 3, c0 + c1), dtype=torch.float32, device=DEV)
+    W = ops.wgrad_params(dev(x, dtype), dev(dy, dtype), dw, N=n, Hs0=h, Ws0=w, Hv=2 * h, Wv=2 * w, C0=c0, C1=c1,
+                         src1=dev(skip, dtype), mode=ops.SRC_NEAREST2X, KH=3, KW=3, stride=1, pad=1, Ho=2 * h, Wo=2 * w,
+                         Cout=co, dtype=ops.dt(dev(x, dtype)))
+    ws = torch.empty(ops.wgrad_workspace_bytes(W) // 4 + 4, dtype=torch.float32, device=DEV)
+    ops.conv2d_wgrad(W, ws)
+    np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C", [16, 64, 768])
+def test_batchnorm_train_forward_backward(ops, dtype, C):
+    rng = np.random.RandomState(10)
+    n, h, w = 2, 12, 10
+    rows = n * h * w
+    x = q(rng.randn(n, h, w, C) * 2 + 0.5, dtype)
+    gamma = (rng.rand(C) + 0.5).astype(np.float32)
+    beta = rng.randn(C).astype(np.float32) * 0.3
+    eps, mom = 1e-3, 0.99
+    yref, mean, var = np_ops.bn_train(x, gamma, beta, eps)
+    yref = np.maximum(yref, 0)
+    xd = dev(x, dtype)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    m, r = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    mm, mv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(C) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, C, eps, mom, m, r, mm, mv, ws)
+    np.testing.assert_allclose(host(m), mean, atol=1e-4)
+    np.testing.assert_allclose(host(r), 1 / np.sqrt(var + eps), rtol=1e-4)
+    np.testing.assert_allclose(host(mm), mean * 0.01, atol=1e-5)
+    np.testing.assert_allclose(host(mv), 0.99 + 0.01 * var * rows / (rows - 1), rtol=1e-4)
+    y = torch.empty_like(xd)
+    g, b = f(gamma), f(beta)
+    ops.bn_apply(xd, y, rows, C, C, m, r, g, b, relu=1)
+    np.testing.assert_allclose(host(y), yref, atol=tol(yref, dtype))
+    # backward through ReLU + BN
+    dy = q(rng.randn(n, h, w, C), dtype)
+    pre, _, _ = np_ops.bn_train(x, gamma, beta, eps)
+    dxr, dgr, dbr = np_ops.bn_train_bwd(x, dy * (pre > 0), gamma, eps)
+    dx = torch.empty_like(xd)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_backward(xd, dev(dy, dtype), dx, rows, C, m, r, g, b, dg, db, relu=1, accumulate_dx=0, workspace=ws)
+    np.testing.assert_allclose(host(db), dbr, atol=2e-3 * np.abs(dbr).max() + 1e-3)
+    np.testing.assert_allclose(host(dg), dgr, atol=2e-3 * np.abs(dgr).max() + 1e-3)
+    safe = np.abs(pre) > 1e-4  # a pre-activation within rounding of 0 may take either side of the ReLU
+    np.testing.assert_allclose(host(dx)[safe], dxr[safe], atol=tol(dxr, dtype, 2))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_input_batchnorm_uint8_to_padded4(ops, dtype):
+    rng = np.random.RandomState(11)
+    n, h, w = 2, 16, 18
+    x = rng.randint(0, 256, size=(n, h, w, 3)).astype(np.uint8)
+    beta = np.array([0.1, -0.2, 0.05], np.float32)
+    yref, mean, var = np_ops.bn_train(x.astype(np.float32), None, beta, 2e-5)
+    xd = torch.from_numpy(x).to(DEV)
+    m, r = torch.empty(3, device=DEV), torch.empty(3, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(4) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, n * h * w, 3, 2e-5, 0.99, m, r, None, None, ws)
+    np.testing.assert_allclose(host(m), mean, rtol=1e-5)
+    y = torch.empty((n, h, w, 4), dtype=TD[dtype], device=DEV)
+    ops.bn_apply(xd, y, n * h * w, 3, 4, m, r, None, keep(torch.from_numpy(beta).to(DEV)), relu=0, pad_value=1.0)
+    out = host(y)
+    np.testing.assert_allclose(out[..., :3], yref, atol=tol(yref, dtype))
+    np.testing.assert_array_equal(out[..., 3], 1.0)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_maxpool_and_upsample_gradients(ops, dtype):
+    rng = np.random.RandomState(12)
+    n, h, w, c = 2, 14, 12, 32
+    x = q(np.maximum(rng.randn(n, h, w, c), 0), dtype)
+    ref = np_ops.maxpool3x3s2(x)
+    ho, wo = ref.shape[1:3]
+    xd = dev(x, dtype)
+    y = torch.empty((n, ho, wo, c), dtype=TD[dtype], device=DEV)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=DEV)
+    ops.maxpool3x3s2(xd, y, idx, n, h, w, c)
+    np.testing.assert_array_equal(host(y), ref)
+    dy = q(rng.randn(n, ho, wo, c), dtype)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+    out = torch.nn.functional.max_pool2d(torch.nn.functional.pad(xt, (1, 1, 1, 1)), 3, 2)
+    out.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    dxref = xt.grad.permute(0, 2, 3, 1).numpy()
+    dx = torch.empty_like(xd)
+    ops.maxpool3x3s2_bwd(idx, dev(dy, dtype), dx, n, h, w, c)
+    # ties (zeros after ReLU) may route to a different tap; compare only where x > 0 (gradient
+    # through ReLU is zero elsewhere, which is what the network sees)
+    msk = x > 0
+    np.testing.assert_allclose(host(dx)[msk], dxref[msk], atol=tol(dxref, dtype, 2))
+    # upsample gradient
+    g = q(rng.randn(n, 2 * h, 2 * w, c), dtype)
+    dxu = torch.empty((n, h, w, c), dtype=TD[dtype], device=DEV)
+    ops.upsample2x_bwd(dev(g, dtype), dxu, n, h, w, c, c)
+    np.testing.assert_allclose(host(dxu), np_ops.upsample2x_bwd(g), atol=tol(g, dtype, 4))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
+    rng = np.random.RandomState(13)
+    count = 2 * 48 * 48
+    z = q(rng.randn(count) * 3, dtype)
+    z[:4] = q(np.array([30.0, -30.0, 17.0, -17.0]), dtype)  # exercises the probability clip
+    y = (rng.rand(count) < 0.3).astype(np.uint8)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    yt = torch.from_numpy(y.astype(np.float32))
+    p = torch.sigmoid(zt)
+    loss = olosses.composite_loss("binary_crossentropy+0.5*dice_loss", yt, p)
+    loss.backward()
+    scal = torch.empty(8, device=DEV)
+    C = 8 if dtype == "bf16" else 4
+    dl = torch.full((count, C), float("nan"), dtype=TD[dtype], device=DEV)
+    ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
+    ops.sigmoid_bce_dice(dev(z, dtype), keep(torch.from_numpy(y).to(DEV)), count, 1.0, 0.5, scal, dl, C, 1.0, ws)
+    s = host(scal)
+    assert abs(s[0] - float(loss.detach())) < 1e-5 * max(1, abs(float(loss.detach())))
+    assert abs(s[1] - float(olosses.binary_crossentropy(yt, p.detach()))) < 1e-5
+    assert abs(s[2] - float(olosses.dice_loss(yt, p.detach()))) < 1e-5      # the north-star 1e-5 Dice bar
+    assert abs(s[3] - float(olosses.dice_metric(yt, p.detach()))) < 1e-5
+    assert abs(s[4] - float(olosses.binary_accuracy(yt, p.detach()))) < 1e-6
+    g = host(dl)
+    ref = zt.grad.numpy()
+    np.testing.assert_allclose(g[:, 0], ref, atol=(1e-8 if dtype == "fp32" else 1e-2 * np.abs(ref).max()))
+    np.testing.assert_array_equal(g[:, 1:], 0)
+
+
+def test_adam_and_sgd_match_keras_rules(ops):
+    rng = np.random.RandomState(14)
+    n = 4096 + 8
+    p0 = rng.randn(n).astype(np.float32)
+    grads = [rng.randn(n).astype(np.float32) * 0.1 for _ in range(3)]
+    f = lambda a: keep(torch.from_numpy(a.copy()).to(DEV))
+    # Adam
+    oracle = ooptim.Adam(lr=1e-3)
+    P = {"w": p0.copy()}
+    p, m, v = f(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-3], device=DEV)
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for g in grads:
+        oracle.step(P, {"w": g})
+        ops.adam(p, f(g), m, v, n, lr, 0.9, 0.999, 1e-7, state)
+    np.testing.assert_allclose(host(p), P["w"], atol=2e-6)
+    assert int(state[0].item()) == 3
+    # masked (frozen) elements do not move
+    mask = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    mask[: n // 2] = 1
+    before = host(p).copy()
+    ops.adam(p, f(grads[0]), m, v, n, lr, 0.9, 0.999, 1e-7, state, mask=mask)
+    after = host(p)
+    np.testing.assert_array_equal(after[n // 2:], before[n // 2:])
+    assert np.abs(after[: n // 2] - before[: n // 2]).max() > 0
+    # SGD with momentum + nesterov
+    for nesterov in (False, True):
+        oracle = ooptim.SGD(lr=0.05, momentum=0.9, nesterov=nesterov)
+        P = {"w": p0.copy()}
+        p, vel = f(p0), torch.zeros(n, device=DEV)
+        lr = torch.tensor([0.05], device=DEV)
+        for g in grads:
+            oracle.step(P, {"w": g})
+            ops.sgd(p, f(g), vel, n, lr, 0.9, nesterov)
+        np.testing.assert_allclose(host(p), P["w"], atol=2e-6)
+    # clipnorm scale
+    g = f(grads[0])
+    gs = torch.empty(1, device=DEV)
+    ws = torch.empty(1024, device=DEV)
+    ops.grad_global_scale(g, n, 0.5, 1.0, gs, ws)
+    norm = np.sqrt((grads[0].astype(np.float64) ** 2).sum())
+    assert abs(float(gs.item()) - min(1.0, 0.5 / norm)) < 1e-6
+
+
+def test_augment_fixed_point_warp_bit_exact(ops):
+    rng = np.random.RandomState(15)
+    n, h, w = 3, 40, 52
+    img = rng.randint(0, 256, size=(n, h, w, 3)).astype(np.uint8)
+    mask = (rng.rand(n, h, w) < 0.3).astype(np.uint8)
+    mats = [oaug.affine_matrix(h, w, 1.2, (0.1, -0.05), 13.0, -7.0, True, False, (32, 48)),
+            oaug.affine_matrix(h, w, 0.8, (-0.2, 0.2), -16.0, 16.0, False, True, (32, 48)),
+            oaug.affine_matrix(h, w, out_hw=(32, 48))]
+    prm = oaug.pack_params(mats, [12, -20, 0], [1.15, 0.8, 1.0])
+    ri, rm = oaug.warp_u8(img, mask, prm, (32, 48))
+    io = torch.empty((n, 32, 48, 3), dtype=torch.uint8, device=DEV)
+    mo = torch.empty((n, 32, 48), dtype=torch.uint8, device=DEV)
+    ops.augment_u8(keep(torch.from_numpy(img).to(DEV)), keep(torch.from_numpy(mask).to(DEV)), io, mo, keep(torch.from_numpy(prm).to(DEV)),
+                   n, h, w, 32, 48, 3)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(io.cpu().numpy(), ri)   # byte work: bit-exact
+    np.testing.assert_array_equal(mo.cpu().numpy(), rm)
+
+
+def test_bf16_wire_casts(ops):
+    x = torch.randn(10007, device=DEV)
+    b = torch.empty(10007, dtype=torch.bfloat16, device=DEV)
+    ops.cast_f32_to_bf16(x, b, x.numel())
+    torch.cuda.synchronize()
+    assert torch.equal(b, x.to(torch.bfloat16))
+    y = torch.empty_like(x)
+    ops.cast_bf16_to_f32(b, y, x.numel(), 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(y, b.to(torch.float32) * 0.5)
