@@ -1,0 +1,107 @@
+"""Dataset classes under the reference's import path (reference ``segmentation_pipeline/impl/datasets.py:1``
+re-exports ``musket_core.datasets``; usage README.md:121-125, 313-340, 417-427).
+
+Contract reproduced here: a dataset is any object with ``__len__`` and ``__getitem__(i) ->
+PredictionItem(id, x, y)`` where ``x`` is an H x W x 3 uint8 image (0..255) and ``y`` an H x W x 1 mask in
+{0,1}; ``isPositive(i)`` is optional (``negatives:`` balancing).  Images are decoded on the host with
+Pillow; everything after decoding (resize, augmentation, normalisation) happens on the GPU.
+"""
+import os
+
+import numpy as np
+
+AUGMENTER_QUEUE_LIMIT = 50   # kept for source compatibility (FAQ.md:15-22); the HIP path has no worker queue
+
+_IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".gif", ".tif", ".tiff")
+
+
+class PredictionItem(object):
+    def __init__(self, path, x, y):
+        self.x = x
+        self.y = y
+        self.id = path
+
+    def original(self):
+        return self
+
+    def rootItem(self):
+        return self
+
+
+class DataSet(object):
+    def __len__(self):
+        raise NotImplementedError
+
+    def __getitem__(self, item):
+        raise NotImplementedError
+
+    def isPositive(self, item):
+        return True
+
+
+def _imread_rgb(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+
+def _imread_mask(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im)
+    if a.ndim == 3:
+        a = a.astype(np.int32).sum(axis=2)
+    return (a != 0).astype(np.uint8)[:, :, None]
+
+
+class SimplePNGMaskDataSet(DataSet):
+    """Folder of images + folder of same-named PNG masks (README.md:116-125)."""
+
+    def __init__(self, path, mask, in_ext="jpg", out_ext="png", generate=False):
+        self.path, self.mask = path, mask
+        self.in_ext, self.out_ext = in_ext, out_ext
+        names = sorted(f for f in os.listdir(path) if f.lower().endswith(_IMG_EXT))
+        self.files = {os.path.splitext(f)[0]: f for f in names}
+        self.ids = sorted(self.files)
+        self.name = os.path.basename(os.path.normpath(path))
+
+    def __len__(self):
+        return len(self.ids)
+
+    def _mask_path(self, ident):
+        for ext in (self.out_ext, "png", "PNG"):
+            p = os.path.join(self.mask, ident + "." + ext)
+            if os.path.exists(p):
+                return p
+        raise FileNotFoundError("no mask for %r in %s" % (ident, self.mask))
+
+    def __getitem__(self, item):
+        ident = self.ids[item]
+        x = _imread_rgb(os.path.join(self.path, self.files[ident]))
+        y = _imread_mask(self._mask_path(ident))
+        return PredictionItem(ident, x, y)
+
+    def isPositive(self, item):
+        return True
+
+
+class NotzeroSimplePNGMaskDataSet(SimplePNGMaskDataSet):
+    """Variant whose ``isPositive`` looks at the mask (FAQ.md:100-106 uses this name for extra data)."""
+
+    def isPositive(self, item):
+        return bool(_imread_mask(self._mask_path(self.ids[item])).any())
+
+
+class DirectoryDataSet(DataSet):
+    """Images of a folder without masks (prediction input)."""
+
+    def __init__(self, path):
+        self.path = path
+        self.ids = sorted(f for f in os.listdir(path) if f.lower().endswith(_IMG_EXT))
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, item):
+        f = self.ids[item]
+        return PredictionItem(f, _imread_rgb(os.path.join(self.path, f)), None)

@@ -82,14 +82,24 @@ class HipSegModel(object):
         self.init_weights(seed)
 
     # ------------------------------------------------------------------ construction helpers
-    def _net(self, training):
+    def _net(self, training, with_loss=None):
+        with_loss = training if with_loss is None else with_loss
+
         def fn(plan):
             logits = nets.unet_resnet(plan, self.backbone, self.H, self.W, self.in_ch, self.classes, self.decoder_filters,
-                                      self.loss_w, with_loss=training)
-            if not training:
+                                      self.loss_w, with_loss=with_loss)
+            if not with_loss:
                 plan.sigmoid_out(logits)
             return logits
         return fn
+
+    def eval_plan(self):
+        """Inference-phase plan WITH the loss/metric reduction (validation pass of fit()); shares weights."""
+        if getattr(self, "_eval", None) is None:
+            ep = graph.Plan(self.batch, self.dtype, str(self.device), training=False)
+            ep.define(self._net(False, with_loss=True), share=self.plan)
+            self._eval = ep
+        return self._eval
 
     def set_data_parallel(self, reducer):
         """Attaches a gradient reducer (distributed.GradReducer): gradients are SUM-all-reduced between

@@ -81,14 +81,44 @@ __global__ __launch_bounds__(256) void bn_partial_u8_kernel(const uint8_t* __res
   }
 }
 
-__global__ void bn_finalize_kernel(const float* partial, int blocks, int C, double inv_rows, double unbias, float eps,
-                                   float momentum, float* mean, float* rstd, float* mm, float* mv) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// Sums partial[b][which][c] over b for 4 consecutive channels per workgroup: 64 strided lanes per
+// channel (independent loads in flight), then a fixed-shape LDS tree -> deterministic.
+// Returns the totals (valid on lane 0 of each channel column) for `which` = 0 and 1.
+struct Sum2 { double s, q; };
+__device__ __forceinline__ Sum2 reduce_partials(const float* partial, int blocks, int C, int c, bool want_q) {
+  __shared__ double sh[2][64][4];
+  const int cc = threadIdx.x & 3, lane = threadIdx.x >> 2;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < blocks; ++b) { s += partial[(size_t)b * 2 * C + c]; q += partial[(size_t)b * 2 * C + C + c]; }
-  const double m = s * inv_rows;
-  double var = q * inv_rows - m * m;
+  if (c < C)
+    for (int b = lane; b < blocks; b += 64) {
+      s += (double)partial[(size_t)b * 2 * C + c];
+      if (want_q) q += (double)partial[(size_t)b * 2 * C + C + c];
+    }
+  sh[0][lane][cc] = s;
+  sh[1][lane][cc] = q;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (lane < w) {
+      sh[0][lane][cc] += sh[0][lane + w][cc];
+      sh[1][lane][cc] += sh[1][lane + w][cc];
+    }
+    __syncthreads();
+  }
+  Sum2 r;
+  r.s = sh[0][0][cc];
+  r.q = sh[1][0][cc];
+  return r;
+}
+
+// launch: grid = ceil(C/4), block = 256
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int blocks, int C, double inv_rows, double unbias,
+                                                          float eps, float momentum, float* mean, float* rstd, float* mm,
+                                                          float* mv) {
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+  const Sum2 t = reduce_partials(partial, blocks, C, c, true);
+  if ((threadIdx.x >> 2) != 0 || c >= C) return;
+  const double m = t.s * inv_rows;
+  double var = t.q * inv_rows - m * m;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -128,7 +158,7 @@ extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t
   }
   STP_LAUNCH_CHECK();
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, blocks, C, 1.0 / (double)rows,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, blocks, C, 1.0 / (double)rows,
                      unbias, eps, momentum, mean, rstd, moving_mean, moving_var);
   STP_LAUNCH_CHECK();
   return STP_OK;
@@ -300,15 +330,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 }
 
 // sums[0][c] = dbeta, sums[1][c] = dgamma (raw sums, also written to the grad buffers)
-__global__ void bn_bwd_finalize_kernel(const float* partial, int blocks, int C, float* sums, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < blocks; ++b) { s += partial[(size_t)b * 2 * C + c]; q += partial[(size_t)b * 2 * C + C + c]; }
-  sums[c] = (float)s;
-  sums[C + c] = (float)q;
-  if (dbeta) dbeta[c] = (float)s;
-  if (dgamma) dgamma[c] = (float)q;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int blocks, int C, float* sums,
+                                                              float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+  const Sum2 t = reduce_partials(partial, blocks, C, c, true);
+  if ((threadIdx.x >> 2) != 0 || c >= C) return;
+  sums[c] = (float)t.s;
+  sums[C + c] = (float)t.q;
+  if (dbeta) dbeta[c] = (float)t.s;
+  if (dgamma) dgamma[c] = (float)t.q;
 }
 
 template <typename T>
@@ -365,7 +395,7 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, blocks, C, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, blocks, C, sums, dgamma, dbeta);
   STP_LAUNCH_CHECK();
   const size_t lds2 = 6 * (size_t)C * sizeof(float);
   const int g = grid_for(rows * (C >> 2));
@@ -523,12 +553,12 @@ extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H
 
 // ------------------------------------------------------------------------------------------
 // per-channel sums of a [rows][C] tensor (bias gradient) and dst += src
-__global__ void colsum_finalize_kernel(const float* partial, int blocks, int C, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * 2 * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* partial, int blocks, int C, float* out,
+                                                              int accumulate) {
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+  const Sum2 t = reduce_partials(partial, blocks, C, c, false);
+  if ((threadIdx.x >> 2) != 0 || c >= C) return;
+  out[c] = accumulate ? out[c] + (float)t.s : (float)t.s;
 }
 
 extern "C" int stp_channel_sum(const void* x, int32_t dtype, int64_t rows, int32_t C, float* out, int32_t accumulate,
@@ -546,7 +576,7 @@ extern "C" int stp_channel_sum(const void* x, int32_t dtype, int64_t rows, int32
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, blocks, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, blocks, C, out, accumulate);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }

@@ -250,13 +250,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* slabs, float* dw, int64_t count, int splits, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dw[i] (+)= sum_k slabs[k][i], 4 floats per thread (count is a multiple of 4: Cout*K with K % 4 == 0)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int64_t count,
+                                                           int splits, int accumulate) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= count) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * count + i];
-  if (accumulate) s += dw[i];
-  dw[i] = s;
+  f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+  for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * count + i);
+  if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i);
+  *reinterpret_cast<f32x4*>(dw + i) = s;
 }
 
 struct WgradPlan {
@@ -358,7 +360,7 @@ extern "C" int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size
   else rc = launch_wgrad_tile<float, false>(a, w, s);
   if (rc != STP_OK) return rc;
   const int64_t count = (int64_t)p->Cout * a.K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, s, (const float*)workspace, p->dw,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 1024)), dim3(256), 0, s, (const float*)workspace, p->dw,
                      count, w.splits, p->accumulate);
   STP_LAUNCH_CHECK();
   return STP_OK;

@@ -55,12 +55,21 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__
 }
 
 // scalars: 0 loss 1 bce 2 dice_loss 3 dice_metric 4 binary_accuracy 5 sum_p 6 sum_y 7 sum_py
-__global__ void loss_finalize_kernel(const float* partial, int blocks, double inv_count, float w_bce, float w_dice,
-                                     float* scalars) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s[LOSS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < blocks; ++b)
-    for (int e = 0; e < LOSS_NSUM; ++e) s[e] += partial[(size_t)b * LOSS_NSUM + e];
+// one workgroup: 8 sums x 32 strided lanes, then a fixed-shape LDS tree (deterministic)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial, int blocks, double inv_count, float w_bce,
+                                                            float w_dice, float* scalars) {
+  __shared__ double sh[32][LOSS_NSUM];
+  const int e = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  double a = 0.0;
+  for (int b = lane; b < blocks; b += 32) a += (double)partial[(size_t)b * LOSS_NSUM + e];
+  sh[lane][e] = a;
+  __syncthreads();
+  for (int w = 16; w > 0; w >>= 1) {
+    if (lane < w) sh[lane][e] += sh[lane + w][e];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double* s = sh[0];
   const double bce = s[0] * inv_count;
   const double dice_l = 1.0 - (2.0 * s[3] + 1.0) / (s[2] + s[1] + 1.0);
   const double dice_m = (2.0 * s[5] + 1.0) / (s[2] + s[4] + 1.0);
@@ -119,7 +128,7 @@ extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, i
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, 1.0 / (double)count, w_bce, w_dice, scalars);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)count, w_bce, w_dice, scalars);
   STP_LAUNCH_CHECK();
   if (dlogits) {
     if (dl_channels < 1) return STP_E_BADARG;
@@ -257,11 +266,19 @@ __global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void gscale_finalize_kernel(const float* partial, int blocks, float clipnorm, float base, float* gscale) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partial[b];
-  const double norm = sqrt(s) * (double)base;  // norm of the (mean) gradient the optimizer will see
+__global__ __launch_bounds__(256) void gscale_finalize_kernel(const float* partial, int blocks, float clipnorm, float base,
+                                                              float* gscale) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 256) a += (double)partial[b];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double norm = sqrt(sh[0]) * (double)base;  // norm of the (mean) gradient the optimizer will see
   double k = 1.0;
   if (clipnorm > 0.f && norm > (double)clipnorm) k = (double)clipnorm / norm;
   gscale[0] = (float)(k * (double)base);
@@ -277,7 +294,7 @@ extern "C" int stp_grad_global_scale(const float* grad, int64_t count, float cli
   if (b > 1024) b = 1024;
   hipLaunchKernelGGL(sqsum_partial_kernel, dim3((int)b), dim3(256), 0, s, grad, count, (float*)workspace);
   STP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gscale_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, (int)b, clipnorm, base, gscale);
+  hipLaunchKernelGGL(gscale_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, (int)b, clipnorm, base, gscale);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }

@@ -1,0 +1,88 @@
+"""Architecture factories with the constructor signatures the reference resolves by name.
+
+``PipelineConfig.createNet1`` (reference ``segmentation_pipeline/segmentation.py:96-155``) looks the
+``architecture`` up in ``custom_models`` / ``segmentation_models`` and calls it with every non-pipeline
+YAML key (after alias renaming) that appears in ``inspect.signature`` of the constructor.  The
+functions below carry the segmentation_models 0.2.1 keyword names and the defaults of
+``schemas/segmentation.raml:158-178`` so that filtering behaves the same; they return a
+:class:`SegModel`, which plays the role of the ``keras.Model`` (``compile`` / ``predict`` /
+``load_weights`` / ``save_weights`` / ``train_on_batch``) and is backed by the HIP plan.
+"""
+import os
+import warnings
+
+from . import nets
+from .backend import HipSegModel
+
+
+class SegModel(object):
+    """Uncompiled model description; ``compile`` builds the HIP training plan."""
+
+    def __init__(self, architecture, backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder,
+                 decoder_filters):
+        if input_shape is None or input_shape[0] is None or input_shape[1] is None:
+            raise ValueError("the HIP backend builds static plans: give `shape: [H, W, C]` in the experiment YAML")
+        self.architecture, self.backbone_name = architecture, backbone_name
+        self.input_shape = tuple(int(v) for v in input_shape)
+        self.classes, self.activation = int(classes), activation
+        self.encoder_weights, self.freeze_encoder = encoder_weights, bool(freeze_encoder)
+        self.decoder_filters = tuple(decoder_filters)
+        self.impl = None
+        self._pending_weights = None
+
+    def compile(self, optimizer="Adam", loss="binary_crossentropy", lr=1e-3, batch=16, dtype="bf16", clipnorm=None,
+                clipvalue=None, metrics=None, device="cuda", use_graph=True, opt_kwargs=None):
+        self.impl = HipSegModel(self.architecture, self.backbone_name, self.input_shape, self.classes, self.activation,
+                                batch=batch, dtype=dtype, loss=loss, optimizer=optimizer, lr=lr,
+                                freeze_encoder=self.freeze_encoder, decoder_filters=self.decoder_filters, clipnorm=clipnorm,
+                                clipvalue=clipvalue, use_graph=use_graph, device=device, opt_kwargs=opt_kwargs)
+        ew = self.encoder_weights
+        if ew:
+            if os.path.exists(str(ew)):
+                self.impl.load_weights(str(ew))
+            else:
+                warnings.warn("encoder_weights=%r: no pretrained file is available offline; the encoder starts from "
+                              "he_uniform initialisation (pass a path to a .weights file to load one)" % (ew,))
+        if self._pending_weights is not None:
+            self.impl.load_weights(self._pending_weights)
+            self._pending_weights = None
+        return self
+
+    def _need(self):
+        if self.impl is None:
+            self.compile()
+        return self.impl
+
+    def predict(self, x):
+        return self._need().predict(x)
+
+    def train_on_batch(self, x, y):
+        return self._need().train_on_batch(x, y)
+
+    def load_weights(self, path):
+        if self.impl is None:
+            self._pending_weights = path
+        else:
+            self.impl.load_weights(path)
+
+    def save_weights(self, path):
+        self._need().save_weights(path)
+
+
+def Unet(backbone_name="vgg16", input_shape=(None, None, 3), classes=1, activation="sigmoid", encoder_weights="imagenet",
+         freeze_encoder=False, decoder_block_type="upsampling", decoder_filters=(256, 128, 64, 32, 16),
+         decoder_use_batchnorm=True, n_upsample_blocks=5, upsample_rates=(2, 2, 2, 2, 2)):
+    """segmentation_models.Unet keyword surface (schemas/segmentation.raml:158-178)."""
+    if backbone_name not in nets.RESNET_UNITS:
+        raise ValueError("Unknown backbone")
+    if decoder_block_type != "upsampling" or not decoder_use_batchnorm or int(n_upsample_blocks) != 5 \
+            or tuple(upsample_rates) != (2, 2, 2, 2, 2):
+        raise ValueError("the HIP Unet implements the default decoder (upsampling blocks with BatchNorm, 5 x2 stages)")
+    return SegModel("Unet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, decoder_filters)
+
+
+ARCHITECTURES = {"Unet": Unet}
+
+
+def known_backbones():
+    return nets.known_backbones()

@@ -1,0 +1,457 @@
+"""Host-side training engine behind ``cfg.fit()``: the counterpart of the un-vendored
+``musket_core.generic_config.GenericImageTaskConfig`` whose methods the reference calls at
+``segmentation_pipeline/segmentation.py:35-47,65,131,151,159-169`` and documents in README.md
+(folds ``:172-175``, ``testSplit`` ``:196``, stages ``:353-383``, negatives ``:385-427``, freeze /
+unfreeze ``:281-299``, callbacks ``:721-743``, resume ``:651-660``, ``cfg.gpus`` ``:756-760``).
+
+What runs where: this module only schedules - k-fold split, stage loop, epoch loop, callbacks,
+checkpoints and metric files (paths next to the YAML, README.md:173-174, ``weights/best-<fold>.<stage>.weights``
+README.md:382).  Every pixel and every FLOP is handled by the HIP plan (``backend.HipSegModel``): images
+are uploaded as raw uint8, resized/augmented by ``stp_augment_u8`` and trained by the captured graph.
+"""
+import csv
+import os
+import time
+
+import numpy as np
+import torch
+import yaml
+
+from . import augment, distributed, ops
+
+# YAML keys flagged (meta.custom) in schemas/segmentation.raml:26-120 (+ the keys used by the examples that
+# the RAML does not list): consumed by the pipeline, never forwarded to the model constructor.
+CUSTOM_KEYS = {
+    "architecture", "crops", "augmentation", "transforms", "optimizer", "lr", "clipnorm", "clipvalue", "loss", "batch",
+    "metrics", "primary_metric", "primary_metric_mode", "callbacks", "stages", "folds_count", "random_state",
+    "extra_train_data", "dataset_augmenter", "classifier", "classifier_lr", "testSplit", "dataset", "datasets", "fit_with",
+    "imports", "import_tasks", "run_tasks", "copyWeights", "dtype", "gpus", "inference_batch", "testTimeAugmentation",
+    "compressPredictionsAsInts", "compressScale", "showDataExamples", "bgr", "stratified", "validationSplit",
+}
+# (meta.alias) renames, schemas/segmentation.raml:50-51,67-68,175-176
+ALIASES = {"backbone": "backbone_name", "shape": "input_shape", "use_batchnorm": "decoder_use_batchnorm"}
+
+
+def load_yaml(path):
+    with open(path) as f:
+        return yaml.safe_load(f) or {}
+
+
+def aug_list(spec):
+    """``augmentation:`` may be a mapping (README.md:130-133) or a list of single-key mappings."""
+    if spec is None:
+        return []
+    if isinstance(spec, dict):
+        return [{k: v} for k, v in spec.items()]
+    return list(spec)
+
+
+def metric_mode(name, mode="auto"):
+    if mode in ("min", "max"):
+        return mode
+    return "min" if "loss" in name else "max"
+
+
+# ------------------------------------------------------------------------------------------ callbacks
+class EarlyStopping(object):
+    """keras.callbacks.EarlyStopping subset (schemas/callbacks.raml:8-23)."""
+
+    def __init__(self, patience=0, monitor="val_loss", mode="auto", verbose=0, min_delta=0.0):
+        self.patience, self.monitor, self.mode = int(patience), monitor, metric_mode(monitor, mode)
+        self.best, self.wait, self.stop = None, 0, False
+
+    def on_epoch_end(self, trainer, epoch, logs):
+        v = logs.get(self.monitor)
+        if v is None:
+            return
+        if self.best is None or (v < self.best if self.mode == "min" else v > self.best):
+            self.best, self.wait = v, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                self.stop = True
+
+
+class ReduceLROnPlateau(object):
+    """keras.callbacks.ReduceLROnPlateau subset (schemas/callbacks.raml:24-33)."""
+
+    def __init__(self, patience=10, factor=0.1, monitor="val_loss", mode="auto", cooldown=0, verbose=0, min_lr=0.0):
+        self.patience, self.factor, self.monitor = int(patience), float(factor), monitor
+        self.mode, self.cooldown, self.min_lr = metric_mode(monitor, mode), int(cooldown), float(min_lr)
+        self.best, self.wait, self.cool = None, 0, 0
+        self.stop = False
+
+    def on_epoch_end(self, trainer, epoch, logs):
+        v = logs.get(self.monitor)
+        if v is None:
+            return
+        if self.cool > 0:
+            self.cool -= 1
+            self.wait = 0
+        if self.best is None or (v < self.best if self.mode == "min" else v > self.best):
+            self.best, self.wait = v, 0
+        elif self.cool <= 0:
+            self.wait += 1
+            if self.wait >= self.patience:
+                old = trainer.model.get_lr()
+                if old > self.min_lr:
+                    trainer.model.set_lr(max(old * self.factor, self.min_lr))
+                    self.cool, self.wait = self.cooldown, 0
+
+
+class CyclicLR(object):
+    """bckenstler CLR (schemas/callbacks.raml:34-48, README.md:433-452): per-batch triangular policy."""
+
+    def __init__(self, base_lr=0.001, max_lr=0.006, step_size=2000.0, mode="triangular", gamma=1.0):
+        self.base_lr, self.max_lr, self.step_size, self.mode, self.gamma = float(base_lr), float(max_lr), float(step_size), mode, float(gamma)
+        self.it = 0
+        self.stop = False
+
+    def lr(self):
+        cycle = np.floor(1 + self.it / (2 * self.step_size))
+        x = abs(self.it / self.step_size - 2 * cycle + 1)
+        scale = 1.0 if self.mode == "triangular" else (1 / (2.0 ** (cycle - 1)) if self.mode == "triangular2" else self.gamma ** self.it)
+        return self.base_lr + (self.max_lr - self.base_lr) * max(0.0, 1 - x) * scale
+
+    def on_batch_end(self, trainer):
+        self.it += 1
+        trainer.model.set_lr(self.lr())
+
+    def on_epoch_end(self, trainer, epoch, logs):
+        pass
+
+
+CALLBACKS = {"EarlyStopping": EarlyStopping, "ReduceLROnPlateau": ReduceLROnPlateau, "CyclicLR": CyclicLR}
+
+
+def make_callbacks(spec):
+    out = []
+    for item in aug_list(spec):
+        (name, args), = item.items()
+        if name not in CALLBACKS:
+            raise ValueError("callback %r is not available (have: %s)" % (name, ", ".join(sorted(CALLBACKS))))
+        out.append(CALLBACKS[name](**(args or {})))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ folds
+class KFoldedDataSet(object):
+    """Train/validation index sets per fold from a fixed seed (README.md:172-175); optional hold-out
+    ``testSplit`` (README.md:196).  ``negatives`` handling follows README.md:385-427."""
+
+    def __init__(self, ds, indexes, folds_count=5, random_state=33, test_split=0.0):
+        self.ds = ds
+        idx = np.array(list(indexes), dtype=np.int64)
+        rng = np.random.RandomState(random_state)
+        perm = rng.permutation(len(idx))
+        idx = idx[perm]
+        self.test_indexes = np.array([], np.int64)
+        if test_split and test_split > 0:
+            n_test = int(round(len(idx) * float(test_split)))
+            self.test_indexes, idx = idx[:n_test], idx[n_test:]
+        self.folds = []
+        if folds_count <= 1 or len(idx) < 2:
+            n_val = max(1, len(idx) // 5) if len(idx) > 1 else 0
+            self.folds.append((idx[n_val:], idx[:n_val]))
+        else:
+            parts = np.array_split(idx, folds_count)
+            for f in range(folds_count):
+                val = parts[f]
+                train = np.concatenate([parts[j] for j in range(folds_count) if j != f]) if folds_count > 1 else idx
+                self.folds.append((train, val))
+
+    def sampledIndexes(self, fold, isTrain, negatives="all"):
+        idx = self.folds[fold][0 if isTrain else 1]
+        if negatives in ("all", "real", None):
+            return idx
+        pos = [i for i in idx if self.ds.isPositive(int(i))]
+        if negatives == "none":
+            return np.array(pos, np.int64)
+        neg = [i for i in idx if not self.ds.isPositive(int(i))]
+        k = int(negatives) * len(pos)
+        return np.array(pos + neg[:k], np.int64)
+
+
+# ------------------------------------------------------------------------------------------ device feeding
+class DeviceFeeder(object):
+    """uint8 items -> the plan's input buffers.  One async H2D copy of the raw pixels per item and one
+    ``stp_augment_u8`` launch that resizes to the network shape (and augments when training)."""
+
+    def __init__(self, device, out_hw, spec, seed):
+        self.device, self.out_hw, self.spec = device, out_hw, spec
+        self.rng = np.random.RandomState(seed)
+        self._keep = []
+
+    def feed(self, plan, items, training):
+        self._keep = []
+        img_buf, msk_buf = plan.inputs["image"].buf, plan.inputs["mask"].buf
+        n = img_buf.shape[0]
+        oh, ow = self.out_hw
+        for i in range(n):
+            it = items[i % len(items)]             # a short last batch wraps around (static plan batch)
+            x = np.ascontiguousarray(it.x[:, :, :3], dtype=np.uint8)
+            h, w = x.shape[:2]
+            y = it.y if it.y is not None else np.zeros((h, w, 1), np.uint8)
+            y = np.ascontiguousarray((np.asarray(y).reshape(h, w, -1)[:, :, 0] != 0).astype(np.uint8))
+            prm = augment.sample_batch(self.spec if training else [], self.rng, 1, h, w, (oh, ow))
+            xd = torch.from_numpy(x).to(self.device, non_blocking=True)
+            yd = torch.from_numpy(y).to(self.device, non_blocking=True)
+            pd = torch.from_numpy(prm).to(self.device, non_blocking=True)
+            self._keep += [xd, yd, pd]
+            ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, 3)
+
+
+def derived_metrics(scal):
+    """scal: the 8 loss scalars of stp_sigmoid_bce_dice -> Keras-style log entries."""
+    loss, bce, dice_l, dice_m, acc, sp, sy, spy = (float(v) for v in scal)
+    return {"loss": loss, "binary_crossentropy": bce, "dice_loss": dice_l, "dice": dice_m, "binary_accuracy": acc,
+            "iou": (spy + 1.0) / (sy + sp - spy + 1.0)}
+
+
+class Trainer(object):
+    def __init__(self, model, feeder, ds, callbacks, rank=0, world=1):
+        self.model, self.feeder, self.ds, self.callbacks = model, feeder, ds, callbacks
+        self.rank, self.world = rank, world
+
+    def _batches(self, indexes, batch):
+        for s in range(0, len(indexes), batch):
+            yield [self.ds[int(i)] for i in indexes[s:s + batch]]
+
+    def run_epoch(self, indexes, training):
+        m = self.model
+        plan = m.plan if training else m.eval_plan()
+        agg, nb = {}, 0
+        for items in self._batches(indexes, m.batch):
+            self.feeder.feed(plan, items, training)
+            if training:
+                m.train_on_batch(None, None, fetch=False)
+                scal = plan.loss_scalars.cpu().numpy()
+                for cb in self.callbacks:
+                    if hasattr(cb, "on_batch_end"):
+                        cb.on_batch_end(self)
+            else:
+                plan.run(plan.prep); plan.run(plan.fwd)
+                scal = plan.loss_scalars.cpu().numpy()
+            for k, v in derived_metrics(scal).items():
+                agg[k] = agg.get(k, 0.0) + v
+            nb += 1
+        return {k: v / max(nb, 1) for k, v in agg.items()}
+
+
+# ------------------------------------------------------------------------------------------ config
+class Stage(object):
+    def __init__(self, dict_, cfg):
+        self.dict, self.cfg = dict(dict_ or {}), cfg
+        d = self.dict
+        self.epochs = int(d.get("epochs", 1))
+        self.lr = d.get("lr")
+        self.loss = d.get("loss")
+        self.negatives = d.get("negatives", "real")
+        self.validation_negatives = d.get("validation_negatives", self.negatives)
+        self.initial_weights = d.get("initial_weights")
+        self.unfreeze_encoder = bool(d.get("unfreeze_encoder", False))
+
+    def callbacks(self):
+        if "callbacks" in self.dict:
+            return make_callbacks(self.dict["callbacks"])
+        return make_callbacks(self.cfg.all.get("callbacks")) + make_callbacks(self.dict.get("extra_callbacks"))
+
+    def unfreeze(self, model):
+        model.freeze_encoder = False
+
+
+class GenericTaskConfig(object):
+    """Attribute surface of the parsed experiment (``self.all`` keeps the raw YAML, read by createNet1)."""
+
+    def __init__(self, **atrs):
+        self.all = dict(atrs)
+        a = self.all
+        self.path = None
+        self.architecture = a.get("architecture")
+        self.backbone = a.get("backbone")
+        self.encoder_weights = a.get("encoder_weights")
+        self.classes = int(a.get("classes", 1))
+        self.shape = a.get("shape")
+        self.crops = a.get("crops")
+        self.batch = int(a.get("batch", 16))
+        self.optimizer = a.get("optimizer", "Adam")
+        self.lr = float(a.get("lr", 0.001))
+        self.clipnorm, self.clipvalue = a.get("clipnorm"), a.get("clipvalue")
+        self.loss = a.get("loss", "binary_crossentropy")
+        self.metrics = list(a.get("metrics", []) or [])
+        self.primary_metric = a.get("primary_metric", "val_loss")
+        self.primary_metric_mode = a.get("primary_metric_mode", "auto")
+        self.folds_count = int(a.get("folds_count", 5))
+        self.random_state = int(a.get("random_state", 33))
+        self.testSplit = float(a.get("testSplit", 0.0) or 0.0)
+        self.freeze_encoder = bool(a.get("freeze_encoder", False))
+        self.augmentation = aug_list(a.get("augmentation"))
+        self.transforms = aug_list(a.get("transforms"))
+        self.dtype = a.get("dtype", "bf16")
+        self.gpus = int(a.get("gpus", 1))
+        self.inference_batch = int(a.get("inference_batch", self.batch))
+        self.showDataExamples = False
+        self.resume = False
+        self.stages = [self.createStage(s) for s in (a.get("stages") or [{"epochs": 1}])]
+        self.dataset_clazz = KFoldedDataSet
+
+    # --- hooks the subclass provides (reference segmentation.py:49-50,93-155)
+    def createStage(self, x):
+        return Stage(x, self)
+
+    def createNet(self):
+        raise NotImplementedError
+
+    def setAllowResume(self, v):
+        self.resume = bool(v)
+
+    def clean(self, cleaned):
+        cleaned.pop("datasets", None)
+        return cleaned
+
+    # --- paths (next to the YAML)
+    def _dir(self, name):
+        d = os.path.join(os.path.dirname(os.path.abspath(self.path)), name)
+        os.makedirs(d, exist_ok=True)
+        return d
+
+    def weightsPath(self, fold, stage):
+        return os.path.join(self._dir("weights"), "best-%d.%d.weights" % (fold, stage))
+
+    def metricsPath(self, fold, stage):
+        return os.path.join(self._dir("metrics"), "metrics-%d.%d.csv" % (fold, stage))
+
+    def kfold(self, ds, indexes=None):
+        if indexes is None:
+            indexes = range(len(ds))
+        return self.dataset_clazz(ds, indexes, self.folds_count, self.random_state, self.testSplit)
+
+    # --- model lifecycle
+    def _compiled(self, stage=None, use_graph=True):
+        model = self.createNet()
+        loss = (stage.loss if stage is not None and stage.loss else self.loss)
+        lr = float(stage.lr) if stage is not None and stage.lr is not None else self.lr
+        if stage is not None and stage.unfreeze_encoder:
+            stage.unfreeze(model)
+        rank, local_rank, world = distributed.env_world()
+        device = "cuda:%d" % local_rank
+        model.compile(optimizer=self.optimizer, loss=loss, lr=lr, batch=self.batch, dtype=self.dtype, clipnorm=self.clipnorm,
+                      clipvalue=self.clipvalue, metrics=self.metrics, device=device, use_graph=use_graph)
+        return model
+
+    def load_model(self, fold=0, stage=-1):
+        if stage < 0:
+            stage = len(self.stages) + stage
+        model = self._compiled(self.stages[stage])
+        model.load_weights(self.weightsPath(fold, stage))
+        return model
+
+    def fit(self, dataset=None, subsample=1.0, foldsToExecute=None, start_from_stage=0):
+        """Trains one model per fold and stage; returns the list of per-(fold, stage) summaries."""
+        if dataset is None:
+            dataset = self._dataset_from_yaml()
+        rank, local_rank, world = distributed.init() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 0, 1)
+        indexes = list(range(len(dataset)))
+        if subsample < 1.0:
+            indexes = indexes[: max(1, int(len(indexes) * subsample))]
+        kf = self.kfold(dataset, indexes)
+        folds = range(len(kf.folds)) if foldsToExecute is None else foldsToExecute
+        summaries = []
+        for fold in folds:
+            prev = None
+            for si, stage in enumerate(self.stages):
+                if si < start_from_stage:
+                    continue
+                wp = self.weightsPath(fold, si)
+                if self.resume and os.path.exists(wp) and self._stage_done(fold, si, stage):
+                    prev = wp
+                    continue
+                summaries.append(self._run_stage(kf, dataset, fold, si, stage, prev, rank, world))
+                prev = wp
+        if rank == 0:
+            with open(os.path.join(os.path.dirname(os.path.abspath(self.path)), "summary.yaml"), "w") as f:
+                yaml.safe_dump({"primary_metric": self.primary_metric, "stages": summaries}, f)
+        return summaries
+
+    def _stage_done(self, fold, si, stage):
+        mp = self.metricsPath(fold, si)
+        if not os.path.exists(mp):
+            return False
+        with open(mp) as f:
+            return sum(1 for _ in f) - 1 >= stage.epochs
+
+    def _run_stage(self, kf, ds, fold, si, stage, prev_weights, rank, world):
+        model = self._compiled(stage)
+        impl = model.impl
+        init = stage.initial_weights or prev_weights
+        if init:
+            impl.load_weights(os.path.join(os.path.dirname(os.path.abspath(self.path)), init) if not os.path.isabs(init) else init)
+        if world > 1:
+            impl.set_data_parallel(distributed.GradReducer())
+        H, W = int(self.shape[0]), int(self.shape[1])
+        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state * 7919 + fold * 101 + si)
+        cbs = stage.callbacks()
+        trainer = Trainer(impl, feeder, ds, cbs, rank, world)
+        train_idx = kf.sampledIndexes(fold, True, stage.negatives)
+        val_idx = kf.sampledIndexes(fold, False, stage.validation_negatives)
+        mode = metric_mode(self.primary_metric, self.primary_metric_mode)
+        best, best_epoch, rows = None, -1, []
+        t0 = time.time()
+        for epoch in range(stage.epochs):
+            order = np.array(train_idx)[distributed.shard_indices(len(train_idx), rank, world, epoch, self.random_state + fold)] \
+                if len(train_idx) else np.array([], np.int64)
+            logs = trainer.run_epoch(order, True)
+            if len(val_idx):
+                logs.update({"val_" + k: v for k, v in trainer.run_epoch(val_idx, False).items()})
+            logs["lr"] = impl.get_lr()
+            rows.append(dict(epoch=epoch, **logs))
+            cur = logs.get(self.primary_metric, logs.get("loss"))
+            if best is None or (cur < best if mode == "min" else cur > best):
+                best, best_epoch = cur, epoch
+                if rank == 0:
+                    impl.save_weights(self.weightsPath(fold, si))
+            stop = False
+            for cb in cbs:
+                cb.on_epoch_end(trainer, epoch, logs)
+                stop = stop or getattr(cb, "stop", False)
+            if rank == 0:
+                self._write_metrics(fold, si, rows)
+            if stop:
+                break
+        return {"fold": int(fold), "stage": int(si), "epochs_run": len(rows), "best_epoch": int(best_epoch),
+                self.primary_metric: float(best) if best is not None else None, "seconds": round(time.time() - t0, 3)}
+
+    def _write_metrics(self, fold, si, rows):
+        keys = ["epoch"] + sorted(k for k in rows[0] if k != "epoch")
+        with open(self.metricsPath(fold, si), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=keys)
+            w.writeheader()
+            for r in rows:
+                w.writerow({k: r.get(k) for k in keys})
+
+    def info(self, metric=None):
+        """Primary metric per fold/stage from the metrics files (README.md:711-718)."""
+        metric = metric or self.primary_metric
+        mode = metric_mode(metric, self.primary_metric_mode)
+        out = []
+        mdir = self._dir("metrics")
+        for fn in sorted(os.listdir(mdir)):
+            if not fn.startswith("metrics-"):
+                continue
+            fold, stage = (int(v) for v in fn[len("metrics-"):-4].split("."))
+            with open(os.path.join(mdir, fn)) as f:
+                vals = [float(r[metric]) for r in csv.DictReader(f) if r.get(metric) not in (None, "")]
+            if vals:
+                out.append({"fold": fold, "stage": stage, metric: (min(vals) if mode == "min" else max(vals))})
+        return out
+
+    def _dataset_from_yaml(self):
+        """``fit_with: name`` + ``datasets: {name: {input_path, output_path}}`` (examples/people/ds_1.yaml:33-38)."""
+        from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+        name = self.all.get("fit_with")
+        dss = self.all.get("datasets") or {}
+        if name and name in dss and "input_path" in dss[name]:
+            base = os.path.dirname(os.path.abspath(self.path))
+            d = dss[name]
+            return SimplePNGMaskDataSet(os.path.join(base, d["input_path"]), os.path.join(base, d["output_path"]))
+        raise ValueError("fit() needs a dataset: pass one or declare `fit_with` + `datasets` in the YAML")

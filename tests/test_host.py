@@ -1,0 +1,189 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU compute)."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from oracle import augment as oaug
+from segmentation_pipeline import segmentation
+from segmentation_pipeline.impl import datasets
+from segmentation_training_pipeline_amd import augment, distributed, graph, nets, pipeline
+from segmentation_training_pipeline_amd.backend import parse_loss
+
+BASE = {"architecture": "Unet", "backbone": "ResNet34", "classes": 1, "activation": "sigmoid", "shape": [64, 64, 3],
+        "optimizer": "Adam", "batch": 2, "loss": "binary_crossentropy+0.1*dice_loss", "stages": [{"epochs": 1}],
+        "augmentation": {"Fliplr": 0.5, "Flipud": 0.5}, "metrics": ["binary_accuracy", "iou"],
+        "primary_metric": "val_binary_accuracy", "freeze_encoder": True,
+        "callbacks": {"EarlyStopping": {"patience": 3, "monitor": "val_binary_accuracy"},
+                      "ReduceLROnPlateau": {"patience": 2, "factor": 0.5, "monitor": "val_binary_accuracy", "cooldown": 1}}}
+
+
+def write_cfg(tmp_path, **over):
+    c = dict(BASE)
+    c.update(over)
+    p = str(tmp_path / "config.yaml")
+    with open(p, "w") as f:
+        yaml.safe_dump(c, f)
+    return p
+
+
+def test_parse_sets_path_and_createnet_kwarg_rules(tmp_path):
+    cfg = segmentation.parse(write_cfg(tmp_path))
+    assert cfg.path.endswith("config.yaml") and cfg.batch == 2 and cfg.folds_count == 5
+    m = cfg.createNet()
+    # alias renaming + lower-casing + pipeline-level keys filtered out (reference segmentation.py:119-129)
+    assert m.backbone_name == "resnet34" and m.input_shape == (64, 64, 3) and m.freeze_encoder is True
+    assert cfg.all["backbone"] == "resnet34"
+    cfg2 = segmentation.parse(write_cfg(tmp_path, activation="none"))
+    assert cfg2.createNet().activation is None                       # reference :97-101
+    cfg3 = segmentation.parse(write_cfg(tmp_path, crops=2))
+    assert cfg3.createNet().input_shape == (32, 32, 3)               # reference :135-136
+
+
+def test_unknown_names_raise_the_reference_errors(tmp_path, capsys):
+    with pytest.raises(ValueError, match="Unknown architecture"):
+        segmentation.parse(write_cfg(tmp_path, architecture="Nope")).createNet()
+    with pytest.raises(ValueError, match="Unknown backbone"):
+        segmentation.parse(write_cfg(tmp_path, backbone="vgg11")).createNet()
+    assert "Known backbones" in capsys.readouterr().out
+
+
+def test_custom_models_registry_takes_precedence(tmp_path):
+    seen = {}
+
+    def mine(backbone_name="x", input_shape=None, classes=1):
+        seen.update(backbone_name=backbone_name, input_shape=input_shape, classes=classes)
+        return "model"
+    segmentation.custom_models["Mine"] = mine
+    try:
+        assert segmentation.parse(write_cfg(tmp_path, architecture="Mine")).createNet() == "model"
+        assert seen == {"backbone_name": "resnet34", "input_shape": [64, 64, 3], "classes": 1}
+    finally:
+        del segmentation.custom_models["Mine"]
+
+
+def test_stages_and_unfreeze(tmp_path):
+    cfg = segmentation.parse(write_cfg(tmp_path, stages=[{"epochs": 2}, {"epochs": 3, "unfreeze_encoder": True, "lr": 1e-4,
+                                                                       "loss": "dice_loss", "negatives": "none"}]))
+    assert [s.epochs for s in cfg.stages] == [2, 3]
+    assert isinstance(cfg.stages[0], segmentation.SegmentationStage)
+    m = cfg.createNet()
+    cfg.stages[1].unfreeze(m)
+    assert m.freeze_encoder is False and cfg.stages[1].negatives == "none"
+    assert cfg.weightsPath(0, 1).endswith(os.path.join("weights", "best-0.1.weights"))
+
+
+def test_loss_grammar():
+    assert parse_loss("binary_crossentropy+0.1*dice_loss") == (1.0, 0.1)
+    assert parse_loss("dice_loss") == (0.0, 1.0)
+    with pytest.raises(ValueError):
+        parse_loss("lovasz_loss")
+
+
+def test_kfold_is_deterministic_disjoint_and_respects_test_split():
+    class DS:
+        def __len__(self): return 23
+        def isPositive(self, i): return i % 3 != 0
+    a = pipeline.KFoldedDataSet(DS(), range(23), 5, 33, 0.2)
+    b = pipeline.KFoldedDataSet(DS(), range(23), 5, 33, 0.2)
+    assert len(a.test_indexes) == 5
+    allv = np.concatenate([v for _, v in a.folds])
+    assert sorted(allv.tolist() + a.test_indexes.tolist()) == list(range(23))
+    for (t1, v1), (t2, v2) in zip(a.folds, b.folds):
+        assert t1.tolist() == t2.tolist() and v1.tolist() == v2.tolist() and not set(t1) & set(v1)
+    pos = a.sampledIndexes(0, True, "none")
+    assert all(i % 3 != 0 for i in pos)
+    one = a.sampledIndexes(0, True, 1)
+    assert len(one) <= 2 * len(pos)
+
+
+def test_callbacks_lr_policies():
+    class M:
+        lr = 1.0
+        def get_lr(self): return self.lr
+        def set_lr(self, v): self.lr = v
+    class T:
+        model = M()
+    t = T()
+    es = pipeline.EarlyStopping(patience=2, monitor="val_loss")
+    for v in (1.0, 0.9, 0.95, 0.96):
+        es.on_epoch_end(t, 0, {"val_loss": v})
+    assert es.stop
+    rl = pipeline.ReduceLROnPlateau(patience=1, factor=0.5, monitor="val_acc", cooldown=0)
+    for v in (0.5, 0.4, 0.3):
+        rl.on_epoch_end(t, 0, {"val_acc": v})
+    assert t.model.lr == 0.25
+    c = pipeline.CyclicLR(base_lr=0.1, max_lr=0.5, step_size=4)
+    lrs = []
+    for _ in range(8):
+        c.on_batch_end(t)
+        lrs.append(t.model.lr)
+    assert abs(max(lrs) - 0.5) < 1e-9 and abs(lrs[-1] - 0.1) < 1e-9
+    with pytest.raises(ValueError):
+        pipeline.make_callbacks({"TensorBoard": {}})
+
+
+def test_augment_matrices_match_the_oracle_and_reject_unknown():
+    rng = np.random.RandomState(0)
+    spec = [{"Fliplr": 1.0}, {"Affine": {"scale": 1.3, "translate_percent": {"x": 0.1, "y": -0.05}, "rotate": 12, "shear": -7}},
+            {"Add": 7}, {"Multiply": 1.1}]
+    prm = augment.sample_batch(spec, rng, 1, 40, 52, (32, 48))
+    ref = oaug.affine_matrix(40, 52, 1.3, (0.1, -0.05), 12.0, -7.0, True, False, (32, 48))
+    np.testing.assert_allclose(prm[0, :6].reshape(2, 3), ref[:2], rtol=1e-6, atol=1e-5)
+    assert prm[0, 6] == 7 and abs(prm[0, 7] - 1.1) < 1e-6
+    ident = augment.identity_batch(2, 64, 64, (64, 64))
+    np.testing.assert_allclose(ident[0, :6], [1, 0, 0, 0, 1, 0], atol=1e-12)
+    with pytest.raises(ValueError, match="GaussianBlur"):
+        augment.sample_batch([{"GaussianBlur": 1.0}], rng, 1, 8, 8, (8, 8))
+    assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
+
+
+def test_plan_structure_matches_unet_resnet34():
+    plan = graph.Plan(2, "bf16", "cpu", training=True)
+    plan.define(lambda p: nets.unet_resnet(p, "resnet34", 64, 64))
+    kernels = sum(i.numel for i in plan.params.values() if i.kind == "kernel")
+    assert kernels == 24421456                                         # same count as the oracle graph
+    names = [n for _, _, n, _ in plan.fwd]
+    assert names.count("stp_conv2d") == 48 and names.count("stp_bn_stats") == 45
+    bnames = [n for _, _, n, _ in plan.bwd]
+    assert bnames.count("stp_conv2d_wgrad") == 48 and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
+    assert "stp_add_inplace" not in bnames                             # every residual gradient aliases
+    fl = sum(m["flops"] for _, _, _, m in plan.fwd if m)
+    assert abs(fl / 2 / (2 * 1e6) - 31323 * (64 * 64) / (512 * 512)) < 2.0   # 31.3 GMAC/img at 512^2
+    frozen = graph.Plan(2, "fp32", "cpu", training=True)
+    frozen.frozen_prefixes = nets.ENCODER_PREFIXES
+    frozen.define(lambda p: nets.unet_resnet(p, "resnet18", 64, 64))
+    fb = [m["layer"] for _, _, n, m in frozen.bwd if n == "stp_conv2d_wgrad"]
+    assert fb and all(l.startswith("decoder_") or l.startswith("final_") for l in fb)
+
+
+def test_simple_png_mask_dataset(tmp_path):
+    from PIL import Image
+    img_dir, msk_dir = tmp_path / "img", tmp_path / "msk"
+    img_dir.mkdir(); msk_dir.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 256, (20, 24, 3)).astype(np.uint8)).save(str(img_dir / ("im%d.jpg" % i)))
+        m = np.zeros((20, 24), np.uint8); m[5:10, 3:9] = 255
+        Image.fromarray(m).save(str(msk_dir / ("im%d.png" % i)))
+    ds = datasets.SimplePNGMaskDataSet(str(img_dir), str(msk_dir))
+    assert len(ds) == 3
+    it = ds[1]
+    assert isinstance(it, datasets.PredictionItem) and it.id == "im1"
+    assert it.x.shape == (20, 24, 3) and it.x.dtype == np.uint8
+    assert it.y.shape == (20, 24, 1) and set(np.unique(it.y)) == {0, 1} and it.y.sum() == 30
+    assert ds.isPositive(0) and datasets.AUGMENTER_QUEUE_LIMIT == 50
+
+
+def test_bucketing_and_sharding():
+    b = distributed.bucket_bounds(1003, 256)
+    assert b[0] == (0, 256) and b[-1][1] == 1003 and all(s % 4 == 0 for s, _ in b)
+    seen = []
+    for r in range(4):
+        idx = distributed.shard_indices(10, r, 4, epoch=3, seed=1)
+        assert len(idx) == 3
+        seen += idx
+    assert set(seen) == set(range(10))
+    assert distributed.shard_indices(10, 0, 4, 3, 1) == distributed.shard_indices(10, 0, 4, 3, 1)
+    assert distributed.shard_indices(10, 0, 4, 4, 1) != distributed.shard_indices(10, 0, 4, 3, 1)

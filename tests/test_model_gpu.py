@@ -77,8 +77,8 @@ def test_fp32_step_matches_oracle(backbone):
         tight = k.startswith("final_conv")          # depends only on dL/dlogits and the last activation
         assert e <= (1e-4 if tight else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
     w = m.get_weights()
-    for k in tr.P:
-        np.testing.assert_allclose(w[k], tr.P[k], atol=5e-5, err_msg=k)
+    for k in tr.P:   # lr (0.05) x gradient kink noise (<= 3e-2 relative L2) bounds the post-step difference
+        np.testing.assert_allclose(w[k], tr.P[k], atol=2e-4, err_msg=k)
     # second step: re-synchronise the weights first (the kink noise above times lr would otherwise be
     # amplified by the next forward), then the forward must again agree to the 1e-3 bar and the
     # momentum update must carry over.
