@@ -41,8 +41,11 @@ def wgrad_tile(cout):
 def kernel_key(name, meta, dtype):
     t = "unsigned short" if dtype == "bf16" else "float"
     if name == "stp_conv2d":
+        tile = meta["tile"]
+        if tile >= 64:   # uniform-tap buffer-DMA kernel: tile = 32*STAGES + base tile
+            return "conv_igemm_ut_kernel<%s, %s, %d>" % (t, CONV_TILES[tile % 32], tile // 32)
         c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
-        return "conv_igemm_kernel<%s, %s, %s>" % (t, CONV_TILES[meta["tile"]], c4)
+        return "conv_igemm_kernel<%s, %s, %s>" % (t, CONV_TILES[tile], c4)
     if name == "stp_conv2d_wgrad":
         c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
         return "conv_wgrad_kernel<%s, %s, %s>" % (t, wgrad_tile(meta["cout"]), c4)

@@ -1,0 +1,37 @@
+"""Per-launch timing table of the full-size step (eager, HIP events)."""
+import sys, json, numpy as np, torch
+sys.path.insert(0, ".")
+from segmentation_training_pipeline_amd.backend import HipSegModel
+dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+m = HipSegModel("Unet", "resnet34", (512, 512, 3), 1, "sigmoid", batch=16, dtype=dt, loss="binary_crossentropy+1.0*dice_loss", use_graph=False)
+p = m.plan
+rng = np.random.RandomState(0)
+m.load_batch(rng.randint(0, 256, (16, 512, 512, 3)).astype(np.uint8), (rng.rand(16, 512, 512, 1) < 0.2).astype(np.uint8))
+st = torch.cuda.current_stream()
+launches = p.prep + p.fwd + p.bwd + p.opt
+reps = 3
+tot = {}
+for rep in range(reps + 1):
+    evs = []
+    for fn, args, name, meta in launches:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st); rc = fn(*args, st.cuda_stream); e1.record(st)
+        assert rc == 0, name
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    if rep:
+        for i, (e0, e1) in enumerate(evs):
+            tot[i] = tot.get(i, 0.0) + e0.elapsed_time(e1) * 1e3 / reps
+rows = []
+for i, (fn, args, name, meta) in enumerate(launches):
+    rows.append((tot[i], name, meta))
+print("total us", sum(tot.values()))
+agg = {}
+for us, name, meta in rows:
+    agg[name] = agg.get(name, 0) + us
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
+    print("%-28s %9.1f us" % (k, v))
+print("---- GEMM launches")
+for us, name, meta in rows:
+    if meta:
+        print("%-28s %-6s tile=%-3s %8.1f us %7.1f TF" % (meta["layer"], meta["pass"], meta.get("tile", meta.get("cout")), us, meta["flops"] / us / 1e6))

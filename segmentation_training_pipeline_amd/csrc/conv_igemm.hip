@@ -11,9 +11,18 @@
 // Tile bytes are identical for both dtypes: every LDS row holds 128 bytes of K (64 bf16 / 32
 // fp32); a lane's 16-byte fragment read feeds one v_mfma_f32_16x16x32_bf16 or four
 // v_mfma_f32_16x16x4_f32 (exact fp32, used by the parity mode).  LDS rows are XOR-swizzled in
-// 16-byte slots (slot ^= row & 7): conflict-free for the ds_read_b128 lane groups of gfx950
-// and for the 8-lane ds_write_b128 groups.  Global->register->LDS staging, double-buffered LDS,
-// next tile's global loads in flight during the MFMAs of the current one.
+// 16-byte slots (slot ^= row & 7): conflict-free for the ds_read_b128 lane groups of gfx950.
+//
+// Two kernels share the MFMA loop and the epilogue:
+//  * conv_igemm_ut_kernel ("uniform tap"): when Ctot and C0 are multiples of the K-step, all 8 slots
+//    of a K-tile belong to ONE filter tap and ONE source, so the tap decomposition is scalar (SALU) and
+//    every 16-byte vector is fetched with `buffer_load_dwordx4 ... offen lds` straight into LDS: 32-bit
+//    offsets, hardware out-of-range -> 0 for padding, no VGPR staging, no ds_write.  The LDS image of
+//    an LDS-DMA is lane-linear, so the swizzle is applied to the SOURCE (the thread owning physical
+//    slot s of row r fetches logical slot s ^ (r&7)).  STAGES-deep LDS ring, counted s_waitcnt vmcnt(N)
+//    + bare s_barrier (never a drain inside the loop).
+//  * conv_igemm_kernel (general): per-lane tap decomposition, global -> VGPR -> ds_write double buffer;
+//    handles the 4-channel stem (C4), 16/32-channel layers and ragged shapes.
 #include "common.h"
 
 struct ConvArgs {
@@ -29,6 +38,7 @@ struct ConvArgs {
   int acc0, acc1, relu;
   int K, P, HoWo, wrows;
   int ntile_m, ntile_n;
+  uint32_t bytes0, bytes1, bytesw;
   FastDiv divC, divKW;
 };
 
@@ -49,7 +59,212 @@ template <> struct Mma<float> {
   }
 };
 
-// BM = output-channel rows per block, BN = pixels per block, WM x WN = wave grid (4 waves).
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a
+// contiguous run of pixel tiles (neighbouring tiles share their 3x3 halo rows in that L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// One K-tile of MFMAs for this wave: TM x TN fragments of 16x16, two 64-byte chunks per 128-byte row.
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void compute_tile(const char* stage, int wm, int wn, int lr, int lg,
+                                             f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  const char* sa = stage + (wm * (BM / WM)) * 128;
+  const char* sb = stage + BM * 128 + (wn * (BN / WN)) * 128;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    u32x4 fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = i * 16 + lr;  // (wave row offset is a multiple of 16 -> row&7 unchanged)
+      fa[i] = *reinterpret_cast<const u32x4*>(sa + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = j * 16 + lr;
+      fb[j] = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+  }
+}
+
+// bias, residual, ReLU, dual destination, optional accumulate
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0, int wm, int wn, int lr, int lg,
+                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  const T* res = reinterpret_cast<const T*>(a.residual);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
+    if (pm >= a.P) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+      if (co >= a.Cout) continue;
+      f32x4 v = acc[i][j];
+      if (co + 3 < a.Cout) {
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+        if (res) v += load4(res + (size_t)pm * a.Cout + co);
+        T* d;
+        bool accum;
+        if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
+        else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
+        if (accum) v += load4(d);
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        store4(d, v);
+      } else {
+        // ragged channel tail (e.g. the 1-class head): scalar path
+        for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
+          const int c1 = co + r;
+          float x = v[r];
+          if (a.bias) x += a.bias[c1];
+          if (res) x += Elem<T>::load(res + (size_t)pm * a.Cout + c1);
+          T* d;
+          bool accum;
+          if (c1 < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + c1; accum = a.acc0; }
+          else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (c1 - a.Cd0); accum = a.acc1; }
+          if (accum) x += Elem<T>::load(d);
+          if (a.relu) x = fmaxf(x, 0.f);
+          Elem<T>::store(d, x);
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// uniform-tap buffer-DMA kernel
+// ================================================================================================
+#define STP_OOB 0x80000000u  // voffset beyond any descriptor: the buffer load returns 0 (conv padding)
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
+  static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0 && STAGES >= 2, "config");
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KE = 128 / SZ;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int L = RA + RB;  // VMEM instructions per wave per K-tile
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r0 = tid >> 3;
+  const int lslot = (tid & 7) ^ (r0 & 7);  // logical 16-byte slot fetched by this thread (row&7 == r0&7 for all passes)
+
+  const int bid = xcd_remap(blockIdx.x, a.ntile_m * a.ntile_n);
+  const int tile_m = bid % a.ntile_m, tile_n = bid / a.ntile_m;
+  const int cout0 = tile_m * BM, pix0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, a.bytesw, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.bytes1 : 0u, 0x00020000);
+
+  // per-thread pixel rows: image offsets (elements) in both sources and the top-left tap coordinate
+  int hb[RB], wb[RB];
+  uint32_t nof0[RB], nof1[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int pm = pix0 + r0 + 32 * i;
+    if (pm < a.P) {
+      const int n = pm / a.HoWo;
+      const int rem = pm - n * a.HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      hb[i] = ho * a.stride - a.pad;
+      wb[i] = wo * a.stride - a.pad;
+      nof0[i] = (uint32_t)n * (uint32_t)(a.Hs0 * a.Ws0 * a.C0);
+      nof1[i] = (uint32_t)n * (uint32_t)(a.Hv * a.Wv * a.C1);
+    } else {
+      hb[i] = wb[i] = -(1 << 24);
+      nof0[i] = nof1[i] = 0;
+    }
+  }
+  // weight rows: byte offset of (row, logical slot); rows past the allocation fall out of the descriptor
+  uint32_t wof[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) wof[i] = ((uint32_t)(cout0 + r0 + 32 * i) * (uint32_t)a.K + (uint32_t)lslot * VEC) * SZ;
+
+  auto issue_tile = [&](int kt, int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + BM * 128;
+    const uint32_t k0 = (uint32_t)kt * KE;  // wave-uniform from here: scalar tap decomposition
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sa + (i * 32 + wave * 8) * 128), 16,
+                                               wof[i] + k0 * SZ, 0, 0, 0);
+    const uint32_t pos = fdiv(k0, a.divC);
+    const int cb = (int)(k0 - pos * (uint32_t)a.Ctot);
+    const int kh = (int)fdiv(pos, a.divKW);
+    const int kw = (int)pos - kh * a.KW;
+    if (cb < a.C0) {
+      const int sh = a.mode ? 1 : 0;
+      const uint32_t ci = (uint32_t)(cb + lslot * VEC);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int hv = hb[i] + kh, wv = wb[i] + kw;
+        bool ok = (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+        if (a.mode == STP_SRC_ZEROINS2X) ok = ok && (((hv | wv) & 1) == 0);
+        const uint32_t off = nof0[i] + (uint32_t)((hv >> sh) * a.Ws0 + (wv >> sh)) * (uint32_t)a.C0 + ci;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(sb + (i * 32 + wave * 8) * 128), 16,
+                                                 ok ? off * SZ : STP_OOB, 0, 0, 0);
+      }
+    } else {
+      const uint32_t ci = (uint32_t)(cb - a.C0 + lslot * VEC);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int hv = hb[i] + kh, wv = wb[i] + kw;
+        const bool ok = (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+        const uint32_t off = nof1[i] + (uint32_t)(hv * a.Wv + wv) * (uint32_t)a.C1 + ci;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(sb + (i * 32 + wave * 8) * 128), 16,
+                                                 ok ? off * SZ : STP_OOB, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int nk = a.K / KE;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue_tile(s, s);
+  int buf = 0, nbuf = STAGES - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt must have landed; up to STAGES-2 younger tiles stay in flight across the barrier
+    const int ahead = nk - 1 - kt;
+    if (STAGES >= 3 && ahead >= STAGES - 2) wait_vmcnt<(STAGES >= 3 ? (STAGES - 2) : 0) * L>();
+    else if (STAGES >= 4 && ahead == 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // tile kt visible to every wave; the buffer of tile kt-1 is free
+    if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1, nbuf);
+    compute_tile<T, BM, BN, WM, WN>(smem + buf * STAGE, wm, wn, lr, lg, acc);
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
+  }
+  epilogue<T, BM, BN, WM, WN>(a, cout0, pix0, wm, wn, lr, lg, acc);
+#endif
+}
+
+// ================================================================================================
+// general register-staged kernel
+// ================================================================================================
 template <typename T, int BM, int BN, int WM, int WN, bool C4>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves");
@@ -67,14 +282,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int r0 = tid >> 3, slot = tid & 7;
 
-  // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a
-  // contiguous run of pixel tiles (neighbouring tiles share their 3x3 halo rows in that L2).
-  int bid = blockIdx.x;
-  const int nblk = a.ntile_m * a.ntile_n;
-  {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-  }
+  const int bid = xcd_remap(blockIdx.x, a.ntile_m * a.ntile_n);
   const int tile_m = bid % a.ntile_m;  // cout tiles innermost: they share the same pixels
   const int tile_n = bid / a.ntile_m;
   const int cout0 = tile_m * BM;
@@ -183,29 +391,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lr = lane & 15, lg = lane >> 4;
-  auto compute = [&](int buf) {
-    const char* sa = smem + buf * STAGE + (wm * (BM / WM)) * 128;
-    const char* sb = smem + buf * STAGE + BM * 128 + (wn * (BN / WN)) * 128;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      u32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = i * 16 + lr;  // (wave row offset is a multiple of 16 -> row&7 unchanged)
-        fa[i] = *reinterpret_cast<const u32x4*>(sa + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = j * 16 + lr;
-        fb[j] = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-    }
-  };
-
   const int nk = (a.K + KE - 1) / KE;
   load_tile(0);
   store_tile(0);
@@ -213,112 +398,108 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    compute(cur);
+    compute_tile<T, BM, BN, WM, WN>(smem + cur * STAGE, wm, wn, lr, lg, acc);
     if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
   }
-
-  // ---- epilogue: bias, residual, ReLU, dual destination, optional accumulate -------------
-  const T* res = reinterpret_cast<const T*>(a.residual);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
-    if (pm >= a.P) continue;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
-      if (co >= a.Cout) continue;
-      f32x4 v = acc[i][j];
-      if (co + 3 < a.Cout) {
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
-        if (res) v += load4(res + (size_t)pm * a.Cout + co);
-        T* d;
-        bool accum;
-        if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
-        else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
-        if (accum) v += load4(d);
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        store4(d, v);
-      } else {
-        // ragged channel tail (e.g. the 1-class head): scalar path
-        for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
-          const int c1 = co + r;
-          float x = v[r];
-          if (a.bias) x += a.bias[c1];
-          if (res) x += Elem<T>::load(res + (size_t)pm * a.Cout + c1);
-          T* d;
-          bool accum;
-          if (c1 < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + c1; accum = a.acc0; }
-          else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (c1 - a.Cd0); accum = a.acc1; }
-          if (accum) x += Elem<T>::load(d);
-          if (a.relu) x = fmaxf(x, 0.f);
-          Elem<T>::store(d, x);
-        }
-      }
-    }
-  }
+  epilogue<T, BM, BN, WM, WN>(a, cout0, pix0, wm, wn, lr, lg, acc);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool C4>
-static int launch_cfg(ConvArgs& a, hipStream_t s) {
-  a.ntile_m = ceil_div(a.Cout, BM);
-  a.ntile_n = ceil_div(a.P, BN);
-  const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, C4>;
-  if (lds > 64 * 1024) {
-    static bool attr_set = false;  // one per template instantiation
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return STP_E_LAUNCH;
-      attr_set = true;
-    }
+// ================================================================================================
+// host side
+// ================================================================================================
+template <typename K>
+static int launch_kernel(K kern, ConvArgs& a, size_t lds, bool& attr_set, hipStream_t s) {
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.ntile_m * a.ntile_n), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
 
-// tile ids: 1 = 128x128, 2 = 64co x 256px, 3 = 32co x 256px, 4 = 16co x 256px, 5 = 64x64, 6 = 128co x 64px
+template <typename T, int BM, int BN, int WM, int WN, bool C4>
+static int launch_gen(ConvArgs& a, hipStream_t s) {
+  static bool attr_set = false;  // one per template instantiation
+  a.ntile_m = ceil_div(a.Cout, BM);
+  a.ntile_n = ceil_div(a.P, BN);
+  return launch_kernel(conv_igemm_kernel<T, BM, BN, WM, WN, C4>, a, (size_t)2 * (BM + BN) * 128, attr_set, s);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_ut(ConvArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  a.ntile_m = ceil_div(a.Cout, BM);
+  a.ntile_n = ceil_div(a.P, BN);
+  return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES>, a, (size_t)STAGES * (BM + BN) * 128, attr_set, s);
+}
+
+// Tile ids (output channels x pixels per workgroup):
+//   general kernel   1: 128x128   2: 64x256   3: 32x256   4: 16x256   5: 64x64   6: 128x64
+//   uniform-tap DMA  32*STAGES + {1, 2, 5, 6} (STAGES = 2, 3; 4 for the two small tiles)
 template <typename T, bool C4>
-static int launch_tile(ConvArgs& a, int tile, hipStream_t s) {
-  switch (tile) {
-    case 1: return launch_cfg<T, 128, 128, 2, 2, C4>(a, s);
-    case 2: return launch_cfg<T, 64, 256, 1, 4, C4>(a, s);
-    case 3: return launch_cfg<T, 32, 256, 1, 4, C4>(a, s);
-    case 4: return launch_cfg<T, 16, 256, 1, 4, C4>(a, s);
-    case 5: return launch_cfg<T, 64, 64, 2, 2, C4>(a, s);
-    case 6: return launch_cfg<T, 128, 64, 4, 1, C4>(a, s);
-    default: return STP_E_BADARG;
+static int launch_tile(ConvArgs& a, int tile, bool ut_ok, hipStream_t s) {
+  if constexpr (C4) {
+    switch (tile) {
+      case 2: return launch_gen<T, 64, 256, 1, 4, true>(a, s);
+      case 5: return launch_gen<T, 64, 64, 2, 2, true>(a, s);
+      default: return STP_E_BADARG;
+    }
+  } else {
+    if (tile >= 64 && !ut_ok) return STP_E_BADARG;
+    switch (tile) {
+      case 1: return launch_gen<T, 128, 128, 2, 2, false>(a, s);
+      case 2: return launch_gen<T, 64, 256, 1, 4, false>(a, s);
+      case 3: return launch_gen<T, 32, 256, 1, 4, false>(a, s);
+      case 4: return launch_gen<T, 16, 256, 1, 4, false>(a, s);
+      case 5: return launch_gen<T, 64, 64, 2, 2, false>(a, s);
+      case 6: return launch_gen<T, 128, 64, 4, 1, false>(a, s);
+      case 64 + 1: return launch_ut<T, 128, 128, 2, 2, 2>(a, s);
+      case 64 + 2: return launch_ut<T, 64, 256, 1, 4, 2>(a, s);
+      case 64 + 5: return launch_ut<T, 64, 64, 2, 2, 2>(a, s);
+      case 64 + 6: return launch_ut<T, 128, 64, 4, 1, 2>(a, s);
+      case 96 + 1: return launch_ut<T, 128, 128, 2, 2, 3>(a, s);
+      case 96 + 2: return launch_ut<T, 64, 256, 1, 4, 3>(a, s);
+      case 96 + 5: return launch_ut<T, 64, 64, 2, 2, 3>(a, s);
+      case 96 + 6: return launch_ut<T, 128, 64, 4, 1, 3>(a, s);
+      case 128 + 5: return launch_ut<T, 64, 64, 2, 2, 4>(a, s);
+      case 128 + 6: return launch_ut<T, 128, 64, 4, 1, 4>(a, s);
+      default: return STP_E_BADARG;
+    }
   }
 }
 
-static int auto_tile(const ConvArgs& a) {
+// Heuristics from scratch/conv_bench.py on MI355X (bf16): the kernel is latency- rather than MFMA-bound, so
+// 2-stage rings that let 2+ workgroups share a CU beat deeper rings at 1 workgroup/CU, and tiles are
+// shrunk until the grid covers the 256 CUs at least ~1.5x.
+static int auto_tile(const ConvArgs& a, bool ut_ok) {
   const int co = a.Cout;
   if (co <= 16) return 4;
   if (co <= 32) return 3;
-  // enough 128x128 tiles to cover the 256 CUs at least ~2x? otherwise use smaller tiles
-  if (co <= 64) return ((int64_t)a.P >= 256 * 256) ? 2 : 5;
+  if (co <= 64) {
+    if (ut_ok) return 64 + 5;
+    return ((int64_t)a.P >= 256 * 256) ? 2 : 5;
+  }
   const int64_t big = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 128);
-  if (big >= 384) return 1;
   const int64_t mid = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 64);
+  if (ut_ok) {
+    if (big >= 384) return 64 + 1;
+    if (mid >= 384) return 64 + 6;
+    return 128 + 5;
+  }
+  if (big >= 384) return 1;
   if (mid >= 384) return 6;
   return 5;
 }
 
-// Which tile configuration stp_conv2d would launch (profiling / roofline bookkeeping).
-extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
-  if (!p) return STP_E_BADARG;
-  if (p->tile) return p->tile;
-  ConvArgs a;
-  a.Cout = p->Cout;
-  a.P = (int)((int64_t)p->N * p->Ho * p->Wo);
-  return auto_tile(a);
-}
-
-extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
+static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, bool* ut_out) {
   if (!p || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
   if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
   const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  const int sz = p->dtype == STP_BF16 ? 2 : 4;
+  const int ke = 128 / sz;
   const bool c4 = (p->dtype == STP_BF16) && p->C0 == 4 && p->C1 == 0;
   if (c4) {
     if ((p->KW & 1) || p->src0_mode != STP_SRC_DIRECT) return STP_E_BADARG;
@@ -329,7 +510,6 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (p->Cd0 <= 0 || p->Cd0 > p->Cout || (p->Cd0 < p->Cout && (!p->dst1 || (p->Cd0 & 3) || ((p->Cout - p->Cd0) & 3))))
     return STP_E_BADARG;
   if (p->N <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->Cout <= 0 || p->KH <= 0 || p->KW <= 0 || p->stride <= 0) return STP_E_BADARG;
-  ConvArgs a;
   a.src0 = (const char*)p->src0; a.src1 = (const char*)p->src1; a.weight = (const char*)p->weight;
   a.residual = (const char*)p->residual; a.bias = p->bias; a.dst0 = (char*)p->dst0; a.dst1 = (char*)p->dst1;
   a.N = p->N; a.Hs0 = p->Hs0; a.Ws0 = p->Ws0; a.Hv = p->Hv; a.Wv = p->Wv; a.C0 = p->C0; a.C1 = p->C1;
@@ -339,11 +519,39 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   a.acc0 = p->accumulate0; a.acc1 = p->accumulate1; a.relu = p->relu;
   a.K = p->KH * p->KW * a.Ctot;
   const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
-  if (P >= (1ll << 31) || (int64_t)a.K * a.Ctot >= (1ll << 32)) return STP_E_BADARG;
+  if (P >= (1ll << 31)) return STP_E_BADARG;
   a.P = (int)P; a.HoWo = p->Ho * p->Wo; a.wrows = round_up(p->Cout, 16);
   a.divC = make_fastdiv((uint32_t)a.Ctot); a.divKW = make_fastdiv((uint32_t)a.KW);
-  const int tile = p->tile ? p->tile : auto_tile(a);
+  const int64_t lim = 1ll << 31;
+  const int64_t b0 = (int64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * sz;
+  const int64_t b1 = (int64_t)p->N * p->Hv * p->Wv * p->C1 * sz;
+  const int64_t bw = (int64_t)a.wrows * a.K * sz;
+  a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
+  a.ntile_m = a.ntile_n = 0;
+  *c4_out = c4;
+  *ut_out = !c4 && (a.Ctot % ke == 0) && (a.C0 % ke == 0) && b0 < lim && b1 < lim && bw < lim;
+  return STP_OK;
+}
+
+// Which tile configuration stp_conv2d would launch (profiling / roofline bookkeeping).
+extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
+  ConvArgs a;
+  bool c4, ut;
+  const int rc = fill_args(p, a, &c4, &ut);
+  if (rc != STP_OK) return rc;
+  int tile = p->tile ? p->tile : auto_tile(a, ut);
+  if (c4 && tile != 2 && tile != 5) tile = 2;
+  return tile;
+}
+
+extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
+  ConvArgs a;
+  bool c4, ut;
+  const int rc = fill_args(p, a, &c4, &ut);
+  if (rc != STP_OK) return rc;
+  int tile = p->tile ? p->tile : auto_tile(a, ut);
+  if (c4 && tile != 2 && tile != 5) tile = 2;
   hipStream_t s = (hipStream_t)stream;
-  if (p->dtype == STP_BF16) return c4 ? launch_tile<bf16_t, true>(a, tile, s) : launch_tile<bf16_t, false>(a, tile, s);
-  return launch_tile<float, false>(a, tile, s);
+  if (p->dtype == STP_BF16) return c4 ? launch_tile<bf16_t, true>(a, tile, ut, s) : launch_tile<bf16_t, false>(a, tile, ut, s);
+  return launch_tile<float, false>(a, tile, ut, s);
 }

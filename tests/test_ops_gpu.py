@@ -93,6 +93,12 @@ CONV_CASES = [
     (2, 16, 16, 64, 128, 1, 2, 0, 0),
     (1, 8, 8, 256, 512, 3, 1, 1, 0),
     (3, 7, 5, 24, 40, 3, 1, 1, 0),     # ragged everything (Cout multiple of 4 only)
+    # uniform-tap buffer-DMA kernel (Cin multiple of the 128-byte K-step): tile = 32*STAGES + base tile
+    (2, 16, 16, 64, 128, 3, 1, 1, 65), (2, 16, 16, 64, 128, 3, 1, 1, 97),
+    (2, 16, 16, 64, 64, 3, 1, 1, 66), (2, 16, 16, 64, 64, 3, 1, 1, 98),
+    (2, 9, 11, 128, 64, 3, 1, 1, 69), (2, 9, 11, 128, 64, 3, 1, 1, 101), (2, 9, 11, 128, 64, 3, 1, 1, 133),
+    (2, 12, 12, 128, 256, 3, 2, 1, 70), (2, 12, 12, 128, 256, 3, 2, 1, 102), (1, 13, 9, 192, 136, 3, 1, 1, 134),
+    (2, 16, 16, 64, 128, 1, 2, 0, 70),
 ]
 
 
