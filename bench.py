@@ -42,13 +42,18 @@ def kernel_key(name, meta, dtype):
     t = "unsigned short" if dtype == "bf16" else "float"
     if name == "stp_conv2d":
         tile = meta["tile"]
+        if tile >= 256:  # buffer-DMA kernel, per-lane tap (small channel counts), 2 stages
+            return "conv_igemm_ut_kernel<%s, %s, 2, false>" % (t, CONV_TILES[tile - 256])
         if tile >= 64:   # uniform-tap buffer-DMA kernel: tile = 32*STAGES + base tile
-            return "conv_igemm_ut_kernel<%s, %s, %d>" % (t, CONV_TILES[tile % 32], tile // 32)
+            return "conv_igemm_ut_kernel<%s, %s, %d, true>" % (t, CONV_TILES[tile % 32], tile // 32)
         c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
         return "conv_igemm_kernel<%s, %s, %s>" % (t, CONV_TILES[tile], c4)
     if name == "stp_conv2d_wgrad":
-        c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
-        return "conv_wgrad_kernel<%s, %s, %s>" % (t, wgrad_tile(meta["cout"]), c4)
+        if dtype == "bf16" and meta["layer"] == "conv0":
+            return "conv_wgrad_kernel<%s, %s, true>" % (t, wgrad_tile(meta["cout"]))
+        if dtype == "fp32" and meta["cout"] <= 32:
+            return "conv_wgrad_kernel<%s, %s, false>" % (t, wgrad_tile(meta["cout"]))
+        return "conv_wgrad_dma_kernel<%s, %s, 2>" % (t, wgrad_tile(meta["cout"]))
     return name
 
 

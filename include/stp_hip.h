@@ -105,6 +105,10 @@ typedef struct stp_wgrad_params {
 
 size_t stp_conv2d_wgrad_workspace_bytes(const stp_wgrad_params* p);
 int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, void* stream);
+/* The two phases of stp_conv2d_wgrad as separate launches (so that a profiler / the plan can time them
+ * individually).  variant: 0 = auto, 1 = register-staged kernel, 2 / 3 = buffer-DMA ring with 2 / 3 stages. */
+int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, int32_t variant, void* stream);
+int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Compute copies of a convolution kernel from the fp32 master (layout [Cout][KH][KW][Cin]):

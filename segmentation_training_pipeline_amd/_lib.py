@@ -42,6 +42,8 @@ SIGNATURES = {
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_wgrad_workspace_bytes": (sz, [C.POINTER(WgradParams)]),
     "stp_conv2d_wgrad": (i32, [C.POINTER(WgradParams), vp, sz, vp]),
+    "stp_conv2d_wgrad_partial": (i32, [C.POINTER(WgradParams), vp, sz, i32, vp]),
+    "stp_conv2d_wgrad_reduce": (i32, [C.POINTER(WgradParams), vp, vp]),
     "stp_weight_prepare": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_weight_grad_unpad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_stem_beta_grad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

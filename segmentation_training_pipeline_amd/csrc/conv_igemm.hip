@@ -145,17 +145,21 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
 // ================================================================================================
 #define STP_OOB 0x80000000u  // voffset beyond any descriptor: the buffer load returns 0 (conv padding)
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+// UNI = true : Ctot % KE == 0 and C0 % KE == 0 -> one tap and one source per K-tile (scalar decomposition)
+// UNI = false: KE % Ctot == 0 and C1 == 0 (16/32-channel layers): a K-tile spans KE/Ctot taps, the tap is a
+//              per-lane constant offset from a scalar base, still no per-load division
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool UNI>
 __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
-  static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0 && STAGES >= 2, "config");
+  static_assert(WM * WN == 4 && BM % 16 == 0 && BN % 32 == 0 && STAGES >= 2, "config");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
   constexpr int SZ = (int)sizeof(T);
   constexpr int VEC = Elem<T>::VEC;
   constexpr int KE = 128 / SZ;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int RA = (BM + 31) / 32, RB = BN / 32;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int L = RA + RB;  // VMEM instructions per wave per K-tile
+  constexpr int DUMP = STAGES * STAGE;  // 4 KiB sink: keeps every wave at L loads per tile when BM < 32
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,6 +196,9 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
       nof0[i] = nof1[i] = 0;
     }
   }
+  // !UNI: this lane's tap offset inside a K-tile and its channel offset inside the tap
+  const uint32_t lane_dpos = UNI ? 0u : fdiv((uint32_t)(lslot * VEC), a.divC);
+  const uint32_t lane_ci = UNI ? 0u : (uint32_t)(lslot * VEC) - lane_dpos * (uint32_t)a.Ctot;
   // weight rows: byte offset of (row, logical slot); rows past the allocation fall out of the descriptor
   uint32_t wof[RA];
 #pragma unroll
@@ -202,9 +209,30 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     char* sb = sa + BM * 128;
     const uint32_t k0 = (uint32_t)kt * KE;  // wave-uniform from here: scalar tap decomposition
 #pragma unroll
-    for (int i = 0; i < RA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(sa + (i * 32 + wave * 8) * 128), 16,
-                                               wof[i] + k0 * SZ, 0, 0, 0);
+    for (int i = 0; i < RA; ++i) {
+      const bool act = (i * 32 + wave * 8) < BM;  // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsw, (__attribute__((address_space(3))) void*)(act ? sa + (i * 32 + wave * 8) * 128 : smem + DUMP + wave * 1024), 16,
+          (act && (UNI || (int)(k0 + lslot * VEC) < a.K)) ? wof[i] + k0 * SZ : STP_OOB, 0, 0, 0);
+    }
+    if constexpr (!UNI) {
+      // several taps per K-tile: tap = k0/Ctot + (this lane's constant tap offset); single source
+      const uint32_t pos = fdiv(k0, a.divC) + lane_dpos;
+      const int kh = (int)fdiv(pos, a.divKW);
+      const int kw = (int)pos - kh * a.KW;
+      const bool kok = pos < (uint32_t)(a.KH * a.KW);
+      const int sh = a.mode ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int hv = hb[i] + kh, wv = wb[i] + kw;
+        bool ok = kok && (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+        if (a.mode == STP_SRC_ZEROINS2X) ok = ok && (((hv | wv) & 1) == 0);
+        const uint32_t off = nof0[i] + (uint32_t)((hv >> sh) * a.Ws0 + (wv >> sh)) * (uint32_t)a.C0 + lane_ci;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(sb + (i * 32 + wave * 8) * 128), 16,
+                                                 ok ? off * SZ : STP_OOB, 0, 0, 0);
+      }
+      return;
+    }
     const uint32_t pos = fdiv(k0, a.divC);
     const int cb = (int)(k0 - pos * (uint32_t)a.Ctot);
     const int kh = (int)fdiv(pos, a.divKW);
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int lr = lane & 15, lg = lane >> 4;
 
-  const int nk = a.K / KE;
+  const int nk = (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue_tile(s, s);
@@ -428,19 +456,20 @@ static int launch_gen(ConvArgs& a, hipStream_t s) {
   return launch_kernel(conv_igemm_kernel<T, BM, BN, WM, WN, C4>, a, (size_t)2 * (BM + BN) * 128, attr_set, s);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool UNI = true>
 static int launch_ut(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = ceil_div(a.P, BN);
-  return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES>, a, (size_t)STAGES * (BM + BN) * 128, attr_set, s);
+  return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI>, a, (size_t)STAGES * (BM + BN) * 128 + 4096, attr_set, s);
 }
 
 // Tile ids (output channels x pixels per workgroup):
 //   general kernel   1: 128x128   2: 64x256   3: 32x256   4: 16x256   5: 64x64   6: 128x64
 //   uniform-tap DMA  32*STAGES + {1, 2, 5, 6} (STAGES = 2, 3; 4 for the two small tiles)
+// ut_ok: 0 = general kernel only, 1 = uniform-tap DMA eligible, 2 = per-lane-tap DMA eligible (small Ctot)
 template <typename T, bool C4>
-static int launch_tile(ConvArgs& a, int tile, bool ut_ok, hipStream_t s) {
+static int launch_tile(ConvArgs& a, int tile, int ut_ok, hipStream_t s) {
   if constexpr (C4) {
     switch (tile) {
       case 2: return launch_gen<T, 64, 256, 1, 4, true>(a, s);
@@ -448,7 +477,7 @@ static int launch_tile(ConvArgs& a, int tile, bool ut_ok, hipStream_t s) {
       default: return STP_E_BADARG;
     }
   } else {
-    if (tile >= 64 && !ut_ok) return STP_E_BADARG;
+    if (tile >= 256 ? ut_ok != 2 : (tile >= 64 && ut_ok != 1)) return STP_E_BADARG;
     switch (tile) {
       case 1: return launch_gen<T, 128, 128, 2, 2, false>(a, s);
       case 2: return launch_gen<T, 64, 256, 1, 4, false>(a, s);
@@ -466,6 +495,12 @@ static int launch_tile(ConvArgs& a, int tile, bool ut_ok, hipStream_t s) {
       case 96 + 6: return launch_ut<T, 128, 64, 4, 1, 3>(a, s);
       case 128 + 5: return launch_ut<T, 64, 64, 2, 2, 4>(a, s);
       case 128 + 6: return launch_ut<T, 128, 64, 4, 1, 4>(a, s);
+      case 64 + 3: return launch_ut<T, 32, 256, 1, 4, 2>(a, s);
+      case 64 + 4: return launch_ut<T, 16, 256, 1, 4, 2>(a, s);
+      // per-lane-tap variants for 8/16/32-channel inputs (ut_ok == 2)
+      case 256 + 2: return launch_ut<T, 64, 256, 1, 4, 2, false>(a, s);
+      case 256 + 3: return launch_ut<T, 32, 256, 1, 4, 2, false>(a, s);
+      case 256 + 4: return launch_ut<T, 16, 256, 1, 4, 2, false>(a, s);
       default: return STP_E_BADARG;
     }
   }
@@ -474,17 +509,18 @@ static int launch_tile(ConvArgs& a, int tile, bool ut_ok, hipStream_t s) {
 // Heuristics from scratch/conv_bench.py on MI355X (bf16): the kernel is latency- rather than MFMA-bound, so
 // 2-stage rings that let 2+ workgroups share a CU beat deeper rings at 1 workgroup/CU, and tiles are
 // shrunk until the grid covers the 256 CUs at least ~1.5x.
-static int auto_tile(const ConvArgs& a, bool ut_ok) {
+static int auto_tile(const ConvArgs& a, int ut_ok) {
   const int co = a.Cout;
-  if (co <= 16) return 4;
-  if (co <= 32) return 3;
+  if (co <= 16) return ut_ok == 2 ? 256 + 4 : ut_ok == 1 ? 64 + 4 : 4;
+  if (co <= 32) return ut_ok == 2 ? 256 + 3 : ut_ok == 1 ? 64 + 3 : 3;
   if (co <= 64) {
-    if (ut_ok) return 64 + 5;
+    if (ut_ok == 2) return 256 + 2;
+    if (ut_ok == 1) return 64 + 5;
     return ((int64_t)a.P >= 256 * 256) ? 2 : 5;
   }
   const int64_t big = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 128);
   const int64_t mid = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 64);
-  if (ut_ok) {
+  if (ut_ok == 1) {
     if (big >= 384) return 64 + 1;
     if (mid >= 384) return 64 + 6;
     return 128 + 5;
@@ -494,7 +530,7 @@ static int auto_tile(const ConvArgs& a, bool ut_ok) {
   return 5;
 }
 
-static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, bool* ut_out) {
+static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* ut_out) {
   if (!p || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
   if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
   const int vec = p->dtype == STP_BF16 ? 8 : 4;
@@ -529,14 +565,19 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, bool* 
   a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
   a.ntile_m = a.ntile_n = 0;
   *c4_out = c4;
-  *ut_out = !c4 && (a.Ctot % ke == 0) && (a.C0 % ke == 0) && b0 < lim && b1 < lim && bw < lim;
+  *ut_out = 0;
+  if (!c4 && b0 < lim && b1 < lim && bw < lim) {
+    if ((a.Ctot % ke == 0) && (a.C0 % ke == 0)) *ut_out = 1;
+    else if (a.C1 == 0 && (ke % a.Ctot == 0)) *ut_out = 2;
+  }
   return STP_OK;
 }
 
 // Which tile configuration stp_conv2d would launch (profiling / roofline bookkeeping).
 extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
   ConvArgs a;
-  bool c4, ut;
+  bool c4;
+  int ut;
   const int rc = fill_args(p, a, &c4, &ut);
   if (rc != STP_OK) return rc;
   int tile = p->tile ? p->tile : auto_tile(a, ut);
@@ -546,7 +587,8 @@ extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
 
 extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   ConvArgs a;
-  bool c4, ut;
+  bool c4;
+  int ut;
   const int rc = fill_args(p, a, &c4, &ut);
   if (rc != STP_OK) return rc;
   int tile = p->tile ? p->tile : auto_tile(a, ut);

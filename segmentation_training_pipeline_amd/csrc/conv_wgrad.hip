@@ -27,8 +27,12 @@ struct WgradArgs {
   int KH, KW, stride, pad, Ho, Wo, Cout;
   int K, P, HoWo;
   int ntile_m, ntile_n, steps_per_split, nsteps;
+  uint32_t bytes0, bytes1, bytesdy;
   FastDiv divC, divKW, divHoWo, divWo;
 };
+
+#define STP_OOB 0x80000000u  // buffer voffset beyond any descriptor -> the load returns 0
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // byte address of (row, byte-in-row) in a pixel-major tile whose rows are ROWB bytes
 template <int ROWB> __device__ __forceinline__ int tile_addr(int row, int byte) {
@@ -37,6 +41,91 @@ template <int ROWB> __device__ __forceinline__ int tile_addr(int row, int byte) 
   constexpr int M = (U >= 8 ? 8 : U) - 1;
   const int s = (row / R) & M;
   return row * ROWB + (byte ^ (s << 5));
+}
+
+// One pixel-step of MFMAs for this wave (transpose reads for bf16, scalar reads for fp32).
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void wgrad_compute(const char* sa, int wm, int wn, int lr, int lg,
+                                              f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int PK = 128 / SZ;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int ROWA = BM * SZ, ROWB = BN * SZ;
+    const char* sb = sa + PK * ROWA;
+    const int ca = (wm * (BM / WM)) * SZ, cb = (wn * (BN / WN)) * SZ;  // wave column origin, bytes
+    if constexpr (sizeof(T) == 2) {
+      // 64 pixels per step = 2 MFMA k-steps of 32 pixels.  Lane group g owns pixels
+      // {4g..4g+3} and {16+4g..16+4g+3} of the 32: two transpose reads of a [4][16] block.
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 fa[TM], fb[TN];
+        const int prow = c * 32 + lg * 4 + (lr >> 2);
+        const int qb = (lr & 3) * 8;  // this lane's 8-byte quad inside the 32-byte block
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int byte = ca + i * 32 + qb;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prow, byte)));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prow + 16, byte)));
+          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int byte = cb + j * 32 + qb;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(prow, byte)));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(prow + 16, byte)));
+          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          fb[j] = u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // fp32: 32 pixels per step = 8 MFMA k-steps of 4 pixels; lane group g owns pixel 4s+g.
+#pragma unroll
+      for (int s = 0; s < PK / 4; ++s) {
+        const int prow = s * 4 + lg;
+        float fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[i] = *reinterpret_cast<const float*>(sa + tile_addr<ROWA>(prow, ca + (i * 16 + lr) * 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[j] = *reinterpret_cast<const float*>(sb + tile_addr<ROWB>(prow, cb + (j * 16 + lr) * 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void wgrad_write_slab(const WgradArgs& a, int split, int cout0, int k0, int wm, int wn, int lr, int lg,
+                                                 f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  float* out = a.out + (size_t)split * a.Cout * a.K;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int kc = k0 + wn * (BN / WN) + j * 16 + lr;
+      const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+      if (kc >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < a.Cout) out[(size_t)(co + r) * a.K + kc] = acc[i][j][r];
+    }
+  }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool C4>
@@ -161,65 +250,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lr = lane & 15, lg = lane >> 4;
-  auto compute = [&](int buf) {
-    const char* sa = smem + buf * STAGE;
-    const char* sb = sa + PK * ROWA;
-    const int ca = (wm * (BM / WM)) * SZ, cb = (wn * (BN / WN)) * SZ;  // wave column origin, bytes
-    if constexpr (sizeof(T) == 2) {
-      // 64 pixels per step = 2 MFMA k-steps of 32 pixels.  Lane group g owns pixels
-      // {4g..4g+3} and {16+4g..16+4g+3} of the 32: two transpose reads of a [4][16] block.
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        u32x4 fa[TM], fb[TN];
-        const int prow = c * 32 + lg * 4 + (lr >> 2);
-        const int qb = (lr & 3) * 8;  // this lane's 8-byte quad inside the 32-byte block
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int byte = ca + i * 32 + qb;
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prow, byte)));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prow + 16, byte)));
-          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int byte = cb + j * 32 + qb;
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(prow, byte)));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(prow + 16, byte)));
-          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          fb[j] = u32x4{l2.x, l2.y, h2.x, h2.y};
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-      }
-    } else {
-      // fp32: 32 pixels per step = 8 MFMA k-steps of 4 pixels; lane group g owns pixel 4s+g.
-#pragma unroll
-      for (int s = 0; s < PK / 4; ++s) {
-        const int prow = s * 4 + lg;
-        float fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const float*>(sa + tile_addr<ROWA>(prow, ca + (i * 16 + lr) * 4));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const float*>(sb + tile_addr<ROWB>(prow, cb + (j * 16 + lr) * 4));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    }
-  };
+  auto compute = [&](int buf) { wgrad_compute<T, BM, BN, WM, WN>(smem + buf * STAGE, wm, wn, lr, lg, acc); };
 
   if (step0 < step1) {
     load_tile(step0);
@@ -234,20 +265,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
   }
 
-  // ---- write the fp32 slab (zeros if this split had no pixels) ---------------------------
-  float* out = a.out + (size_t)split * a.Cout * a.K;
+  wgrad_write_slab<BM, BN, WM, WN>(a, split, cout0, k0, wm, wn, lr, lg, acc);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant: every 16-byte vector of both tiles is fetched with `buffer_load_dwordx4 ... lds`
+// (32-bit offsets, out-of-range -> 0 for padding / tails), STAGES-deep ring with counted vmcnt.  The LDS
+// image of an LDS-DMA is lane-linear, so the 32-byte-unit XOR swizzle is applied to the SOURCE column:
+// a thread owns a fixed PHYSICAL 16-byte slot and fetches the logical column that lives there (the
+// swizzle key only depends on row&7 and every pass advances the row by a multiple of 8).
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) {
+  static_assert(WM * WN == 4 && STAGES >= 2, "config");
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int PK = 128 / SZ;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int ROWA = BM * SZ, ROWB = BN * SZ;
+  constexpr int VPRA = ROWA / 16, VPRB = ROWB / 16;
+  constexpr int RPA = 256 / VPRA, RPB = 256 / VPRB;            // rows per pass
+  constexpr int NVA = (PK + RPA - 1) / RPA, NVB = (PK + RPB - 1) / RPB;
+  static_assert((NVA == 1 || RPA % 8 == 0) && (NVB == 1 || RPB % 8 == 0), "swizzle key must not change between passes");
+  constexpr int STAGE = PK * (ROWA + ROWB);
+  constexpr int L = NVA + NVB;
+  constexpr int DUMP = STAGES * STAGE;  // 4 KiB sink for the lane groups that have no row in a pass
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles = a.ntile_m * a.ntile_n;
+  const int split = blockIdx.x / tiles;
+  const int t = blockIdx.x - split * tiles;
+  const int tile_m = t % a.ntile_m, tile_n = t / a.ntile_m;
+  const int cout0 = tile_m * BM, k0 = tile_n * BN;
+  const int step0 = split * a.steps_per_split;
+  const int step1 = min(step0 + a.steps_per_split, a.nsteps);
+
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.bytesdy, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.bytes1 : 0u, 0x00020000);
+
+  // fixed per-thread columns (logical column stored at this thread's physical slot)
+  const int rowA0 = tid / VPRA, rowB0 = tid / VPRB;
+  const int colA = (tile_addr<ROWA>(rowA0, (tid % VPRA) * 16) - rowA0 * ROWA) / SZ;
+  const int colB = (tile_addr<ROWB>(rowB0, (tid % VPRB) * 16) - rowB0 * ROWB) / SZ;
+  const bool coA_ok = (cout0 + colA) < a.Cout;
+  const int kB = k0 + colB;
+  const bool kB_ok = kB < a.K;
+  const uint32_t pos = fdiv((uint32_t)kB, a.divC);
+  int ci = kB - (int)pos * a.Ctot;
+  const int kh = (int)fdiv(pos, a.divKW);
+  const int kw = (int)pos - kh * a.KW;
+  const bool first = ci < a.C0;
+  if (!first) ci -= a.C0;
+  const int cs = first ? a.C0 : a.C1;
+  const int sh = (first && a.mode) ? 1 : 0;
+  const bool zins = first && a.mode == STP_SRC_ZEROINS2X;
+  const int Hs = first ? a.Hs0 : a.Hv, Ws = first ? a.Ws0 : a.Wv;
+
+  auto issue_tile = [&](int step, int buf) {
+    const int p0 = step * PK;
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + PK * ROWA;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int kc = k0 + wn * (BN / WN) + j * 16 + lr;
-      const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
-      if (kc >= a.K) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (co + r < a.Cout) out[(size_t)(co + r) * a.K + kc] = acc[i][j][r];
+    for (int i = 0; i < NVA; ++i) {
+      const int row = rowA0 + i * RPA;
+      const int p = p0 + row;
+      const bool act = (i * 256 + wave * 64) / VPRA < PK;   // wave-uniform: does this pass have rows for this wave?
+      const uint32_t off = (coA_ok && row < PK && p < a.P) ? ((uint32_t)p * (uint32_t)a.Cout + (uint32_t)(cout0 + colA)) * SZ : STP_OOB;
+      char* dst = act ? sa + (i * 256 + wave * 64) * 16 : smem + DUMP + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int row = rowB0 + i * RPB;
+      const int p = p0 + row;
+      const bool act = (i * 256 + wave * 64) / VPRB < PK;
+      uint32_t off = STP_OOB;
+      if (kB_ok && row < PK && p < a.P) {
+        const uint32_t n = fdiv((uint32_t)p, a.divHoWo);
+        const uint32_t rem = (uint32_t)p - n * (uint32_t)a.HoWo;
+        const uint32_t ho = fdiv(rem, a.divWo);
+        const uint32_t wo = rem - ho * (uint32_t)a.Wo;
+        const int hv = (int)ho * a.stride - a.pad + kh;
+        const int wv = (int)wo * a.stride - a.pad + kw;
+        bool ok = (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+        if (zins) ok = ok && (((hv | wv) & 1) == 0);
+        if (ok) off = ((n * (uint32_t)Hs + (uint32_t)(hv >> sh)) * (uint32_t)Ws + (uint32_t)(wv >> sh)) * (uint32_t)cs * SZ + (uint32_t)ci * SZ;
+      }
+      char* dst = act ? sb + (i * 256 + wave * 64) * 16 : smem + DUMP + wave * 1024;
+      if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int nst = step1 - step0;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nst) issue_tile(step0 + s, s);
+  int buf = 0, nbuf = STAGES - 1;
+  for (int st = 0; st < nst; ++st) {
+    const int ahead = nst - 1 - st;
+    if (STAGES >= 3 && ahead >= STAGES - 2) wait_vmcnt<(STAGES >= 3 ? (STAGES - 2) : 0) * L>();
+    else if (STAGES >= 4 && ahead == 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (st + STAGES - 1 < nst) issue_tile(step0 + st + STAGES - 1, nbuf);
+    wgrad_compute<T, BM, BN, WM, WN>(smem + buf * STAGE, wm, wn, lr, lg, acc);
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }
+  wgrad_write_slab<BM, BN, WM, WN>(a, split, cout0, k0, wm, wn, lr, lg, acc);
+#endif
 }
 
 // dw[i] (+)= sum_k slabs[k][i], 4 floats per thread (count is a multiple of 4: Cout*K with K % 4 == 0)
@@ -280,7 +419,9 @@ static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
   const int tiles = w.ntile_m * w.ntile_n;
   int splits = p->splits;
   if (splits <= 0) {
-    splits = ceil_div(1024, tiles);                   // ~4 blocks per CU
+    // ~2 workgroups per CU; every extra split costs a slab write + read of Cout*K floats, so large
+    // weight matrices (stage 3/4) get few splits and the huge-pixel layers many
+    splits = ceil_div(512, tiles);
     const int max_by_steps = w.nsteps / 8 > 0 ? w.nsteps / 8 : 1;  // keep >= 8 steps per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > 256) splits = 256;
@@ -299,39 +440,85 @@ extern "C" size_t stp_conv2d_wgrad_workspace_bytes(const stp_wgrad_params* p) {
   return (size_t)w.splits * p->Cout * K * sizeof(float);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool C4>
-static int launch_wgrad(WgradArgs& a, int splits, hipStream_t s) {
-  constexpr int PK = 128 / (int)sizeof(T);
-  const size_t lds = 2 * PK * (BM + BN) * sizeof(T);
-  auto kern = conv_wgrad_kernel<T, BM, BN, WM, WN, C4>;
-  if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return STP_E_LAUNCH;
-      attr_set = true;
-    }
+template <typename K>
+static int launch_wg(K kern, WgradArgs& a, size_t lds, int splits, bool& attr_set, hipStream_t s) {
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.ntile_m * a.ntile_n * splits), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
 
+template <typename T, int BM, int BN, int WM, int WN, bool C4>
+static int launch_wgrad(WgradArgs& a, int splits, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int PK = 128 / (int)sizeof(T);
+  return launch_wg(conv_wgrad_kernel<T, BM, BN, WM, WN, C4>, a, (size_t)2 * PK * (BM + BN) * sizeof(T), splits, attr_set, s);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_wgrad_dma(WgradArgs& a, int splits, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int PK = 128 / (int)sizeof(T);
+  return launch_wg(conv_wgrad_dma_kernel<T, BM, BN, WM, WN, STAGES>, a, (size_t)STAGES * PK * (BM + BN) * sizeof(T) + 4096, splits,
+                   attr_set, s);
+}
+
+// variant: 0 = auto, 1 = legacy register-staged, 2/3 = DMA ring with that many stages
 template <typename T, bool C4>
-static int launch_wgrad_tile(WgradArgs& a, const WgradPlan& w, hipStream_t s) {
-  switch (w.tile) {
-    case 1: return launch_wgrad<T, 128, 128, 2, 2, C4>(a, w.splits, s);
-    case 2: return launch_wgrad<T, 64, 128, 1, 4, C4>(a, w.splits, s);
-    case 3: return launch_wgrad<T, 32, 256, 1, 4, C4>(a, w.splits, s);
-    case 4: return launch_wgrad<T, 16, 256, 1, 4, C4>(a, w.splits, s);
-    default: return STP_E_BADARG;
+static int launch_wgrad_tile(WgradArgs& a, const WgradPlan& w, bool dma_ok, int variant, hipStream_t s) {
+  if constexpr (C4) {
+    switch (w.tile) {
+      case 2: return launch_wgrad<T, 64, 128, 1, 4, true>(a, w.splits, s);
+      default: return STP_E_BADARG;
+    }
+  } else {
+    const bool f32 = sizeof(T) == 4;
+    int v = variant;
+    if (v == 0) v = dma_ok ? 2 : 1;
+    if (v >= 2 && (!dma_ok || (f32 && w.tile >= 3))) v = 1;  // fp32 256-column tiles: swizzle key varies per pass
+    if (v == 1) {
+      switch (w.tile) {
+        case 1: return launch_wgrad<T, 128, 128, 2, 2, false>(a, w.splits, s);
+        case 2: return launch_wgrad<T, 64, 128, 1, 4, false>(a, w.splits, s);
+        case 3: return launch_wgrad<T, 32, 256, 1, 4, false>(a, w.splits, s);
+        case 4: return launch_wgrad<T, 16, 256, 1, 4, false>(a, w.splits, s);
+        default: return STP_E_BADARG;
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      switch (w.tile * 4 + v) {
+        case 1 * 4 + 2: return launch_wgrad_dma<T, 128, 128, 2, 2, 2>(a, w.splits, s);
+        case 1 * 4 + 3: return launch_wgrad_dma<T, 128, 128, 2, 2, 3>(a, w.splits, s);
+        case 2 * 4 + 2: return launch_wgrad_dma<T, 64, 128, 1, 4, 2>(a, w.splits, s);
+        case 2 * 4 + 3: return launch_wgrad_dma<T, 64, 128, 1, 4, 3>(a, w.splits, s);
+        case 3 * 4 + 2: return launch_wgrad_dma<T, 32, 256, 1, 4, 2>(a, w.splits, s);
+        case 3 * 4 + 3: return launch_wgrad_dma<T, 32, 256, 1, 4, 3>(a, w.splits, s);
+        case 4 * 4 + 2: return launch_wgrad_dma<T, 16, 256, 1, 4, 2>(a, w.splits, s);
+        case 4 * 4 + 3: return launch_wgrad_dma<T, 16, 256, 1, 4, 3>(a, w.splits, s);
+        default: return STP_E_BADARG;
+      }
+    } else {
+      switch (w.tile * 4 + v) {
+        case 1 * 4 + 2: return launch_wgrad_dma<T, 128, 128, 2, 2, 2>(a, w.splits, s);
+        case 1 * 4 + 3: return launch_wgrad_dma<T, 128, 128, 2, 2, 3>(a, w.splits, s);
+        case 2 * 4 + 2: return launch_wgrad_dma<T, 64, 128, 1, 4, 2>(a, w.splits, s);
+        case 2 * 4 + 3: return launch_wgrad_dma<T, 64, 128, 1, 4, 3>(a, w.splits, s);
+        default: return STP_E_BADARG;
+      }
+    }
   }
 }
 
-extern "C" int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, void* stream) {
+static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, WgradArgs& a, WgradPlan& w, bool* c4_out,
+                      bool* dma_out) {
   if (!p || !p->src0 || !p->dy || !p->dw || !workspace) return STP_E_BADARG;
   if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
   const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  const int sz = p->dtype == STP_BF16 ? 2 : 4;
   const bool c4 = (p->dtype == STP_BF16) && p->C0 == 4 && p->C1 == 0;
   if (c4) {
     if ((p->KW & 1) || p->src0_mode != STP_SRC_DIRECT) return STP_E_BADARG;
@@ -341,8 +528,7 @@ extern "C" int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size
   if (p->Cout % vec) return STP_E_BADARG;
   if (p->C1 > 0 && !p->src1) return STP_E_BADARG;
   if (stp_conv2d_wgrad_workspace_bytes(p) > workspace_bytes) return STP_E_WORKSPACE;
-  const WgradPlan w = plan_wgrad(p);
-  WgradArgs a;
+  w = plan_wgrad(p);
   a.src0 = (const char*)p->src0; a.src1 = (const char*)p->src1; a.dy = (const char*)p->dy; a.out = (float*)workspace;
   a.N = p->N; a.Hs0 = p->Hs0; a.Ws0 = p->Ws0; a.Hv = p->Hv; a.Wv = p->Wv; a.C0 = p->C0; a.C1 = p->C1;
   a.Ctot = p->C0 + p->C1; a.mode = p->src0_mode;
@@ -354,14 +540,42 @@ extern "C" int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size
   a.ntile_m = w.ntile_m; a.ntile_n = w.ntile_n; a.steps_per_split = w.steps_per_split; a.nsteps = w.nsteps;
   a.divC = make_fastdiv((uint32_t)a.Ctot); a.divKW = make_fastdiv((uint32_t)a.KW);
   a.divHoWo = make_fastdiv((uint32_t)a.HoWo); a.divWo = make_fastdiv((uint32_t)a.Wo);
-  hipStream_t s = (hipStream_t)stream;
-  int rc;
-  if (p->dtype == STP_BF16) rc = c4 ? launch_wgrad_tile<bf16_t, true>(a, w, s) : launch_wgrad_tile<bf16_t, false>(a, w, s);
-  else rc = launch_wgrad_tile<float, false>(a, w, s);
+  const int64_t lim = 1ll << 31;
+  const int64_t b0 = (int64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * sz, b1 = (int64_t)p->N * p->Hv * p->Wv * p->C1 * sz;
+  const int64_t bd = P * p->Cout * sz;
+  a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesdy = (uint32_t)(bd < lim ? bd : 0);
+  *c4_out = c4;
+  *dma_out = !c4 && b0 < lim && b1 < lim && bd < lim;
+  return STP_OK;
+}
+
+// Phase 1: per-split partial sums into the workspace slabs.  `variant` as in launch_wgrad_tile.
+extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, int32_t variant,
+                                        void* stream) {
+  WgradArgs a;
+  WgradPlan w;
+  bool c4, dma;
+  const int rc = wgrad_fill(p, workspace, workspace_bytes, a, w, &c4, &dma);
   if (rc != STP_OK) return rc;
-  const int64_t count = (int64_t)p->Cout * a.K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 1024)), dim3(256), 0, s, (const float*)workspace, p->dw,
-                     count, w.splits, p->accumulate);
+  hipStream_t s = (hipStream_t)stream;
+  if (p->dtype == STP_BF16)
+    return c4 ? launch_wgrad_tile<bf16_t, true>(a, w, dma, variant, s) : launch_wgrad_tile<bf16_t, false>(a, w, dma, variant, s);
+  return launch_wgrad_tile<float, false>(a, w, dma, variant, s);
+}
+
+// Phase 2: dw (+)= sum over slabs, fixed order.
+extern "C" int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, void* stream) {
+  if (!p || !p->dw || !workspace) return STP_E_BADARG;
+  const WgradPlan w = plan_wgrad(p);
+  const int64_t count = (int64_t)p->Cout * p->KH * p->KW * (p->C0 + p->C1);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 1024)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                     p->dw, count, w.splits, p->accumulate);
   STP_LAUNCH_CHECK();
   return STP_OK;
+}
+
+extern "C" int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, void* stream) {
+  const int rc = stp_conv2d_wgrad_partial(p, workspace, workspace_bytes, 0, stream);
+  if (rc != STP_OK) return rc;
+  return stp_conv2d_wgrad_reduce(p, workspace, stream);
 }

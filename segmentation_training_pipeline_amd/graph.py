@@ -168,9 +168,12 @@ class Plan(object):
         lst.append((self.lib.stp_conv2d, (C.byref(p),), "stp_conv2d", meta))
 
     def _emit_wgrad(self, lst, p, meta=None):
+        """Weight gradient = split partial sums + fixed-order reduce: two launch records so that each
+        kernel can be timed on its own (bench.py) - same arithmetic as stp_conv2d_wgrad."""
         self._keep.append(p)
-        lst.append((self.lib.stp_conv2d_wgrad, (C.byref(p), self.ws_wgrad.data_ptr(), self.ws_wgrad.numel() * 4),
+        lst.append((self.lib.stp_conv2d_wgrad_partial, (C.byref(p), self.ws_wgrad.data_ptr(), self.ws_wgrad.numel() * 4, 0),
                     "stp_conv2d_wgrad", meta))
+        lst.append((self.lib.stp_conv2d_wgrad_reduce, (C.byref(p), self.ws_wgrad.data_ptr()), "stp_conv2d_wgrad_reduce", None))
 
     # ------------------------------------------------------------------ layers
     def input_u8(self, name, H, W, Cn):

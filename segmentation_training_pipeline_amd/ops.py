@@ -67,6 +67,15 @@ def conv2d_wgrad(p, workspace, st=None):
                                             stream() if st is None else st), "stp_conv2d_wgrad")
 
 
+def conv2d_wgrad_partial(p, workspace, variant=0):
+    _lib.check(_lib.load().stp_conv2d_wgrad_partial(C.byref(p), ptr(workspace), workspace.numel() * workspace.element_size(),
+                                                    variant, stream()), "stp_conv2d_wgrad_partial")
+
+
+def conv2d_wgrad_reduce(p, workspace):
+    _lib.check(_lib.load().stp_conv2d_wgrad_reduce(C.byref(p), ptr(workspace), stream()), "stp_conv2d_wgrad_reduce")
+
+
 def weight_prepare(master, fwd, bwd, Cout, KH, KW, Cin, KWp, Cinp, CoutB, dtype):
     _lib.call("stp_weight_prepare", ptr(master), ptr(fwd), ptr(bwd), Cout, KH, KW, Cin, KWp, Cinp, CoutB, dtype, stream())
 

@@ -148,6 +148,7 @@ def test_plan_structure_matches_unet_resnet34():
     assert names.count("stp_conv2d") == 48 and names.count("stp_bn_stats") == 45
     bnames = [n for _, _, n, _ in plan.bwd]
     assert bnames.count("stp_conv2d_wgrad") == 48 and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
+    assert bnames.count("stp_conv2d_wgrad_reduce") == 48
     assert "stp_add_inplace" not in bnames                             # every residual gradient aliases
     fl = sum(m["flops"] for _, _, _, m in plan.fwd if m)
     assert abs(fl / 2 / (2 * 1e6) - 31323 * (64 * 64) / (512 * 512)) < 2.0   # 31.3 GMAC/img at 512^2
