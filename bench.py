@@ -42,6 +42,8 @@ def kernel_key(name, meta, dtype):
     t = "unsigned short" if dtype == "bf16" else "float"
     if name == "stp_conv2d":
         tile = meta["tile"]
+        if tile == 512:
+            return "conv_sc_kernel<%s>" % t
         if tile >= 256:  # buffer-DMA kernel, per-lane tap (small channel counts), 2 stages
             return "conv_igemm_ut_kernel<%s, %s, 2, false>" % (t, CONV_TILES[tile - 256])
         if tile >= 64:   # uniform-tap buffer-DMA kernel: tile = 32*STAGES + base tile
@@ -49,6 +51,8 @@ def kernel_key(name, meta, dtype):
         c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
         return "conv_igemm_kernel<%s, %s, %s>" % (t, CONV_TILES[tile], c4)
     if name == "stp_conv2d_wgrad":
+        if meta.get("sc"):
+            return "conv_sc_wgrad_kernel<%s>" % t
         if dtype == "bf16" and meta["layer"] == "conv0":
             return "conv_wgrad_kernel<%s, %s, true>" % (t, wgrad_tile(meta["cout"]))
         if dtype == "fp32" and meta["cout"] <= 32:
@@ -129,13 +133,14 @@ def main():
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...` (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
-    distributed.init("nccl")
+    force_dp = os.environ.get("STP_FORCE_DP") == "1"      # single-GPU exercise of the RCCL path
+    distributed.init("nccl", force=force_dp)
     dev = torch.device("cuda", local_rank)
 
     model = HipSegModel("Unet", "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
                         lr=1e-3, use_graph=not args.eager, device=str(dev))
-    if world > 1:
-        model.set_data_parallel(distributed.GradReducer(bucket_mb=32.0))
+    if world > 1 or force_dp:
+        model.set_data_parallel(distributed.GradReducer(bucket_mb=32.0, force=force_dp))
 
     # synthetic data: uniform uint8 images, 3 random discs per mask, seed 1234 + rank
     rng = np.random.RandomState(1234 + rank)
@@ -203,7 +208,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -79,9 +79,14 @@ typedef struct stp_conv_params {
 } stp_conv_params;
 
 int stp_conv2d(const stp_conv_params* p, void* stream);
-/* tile configuration stp_conv2d would pick for p (1..6: 128x128, 64x256, 32x256, 16x256, 64x64,
- * 128x64 = output channels x pixels per workgroup); used by bench.py's per-kernel roofline. */
+/* tile configuration stp_conv2d would pick for p (see conv_igemm.hip: 1..6 register-staged tiles, 32*STAGES+t
+ * uniform-tap DMA tiles, 256+t per-lane-tap DMA tiles, 512 small-channel kernel); used by bench.py. */
 int stp_conv2d_tile_for(const stp_conv_params* p);
+/* Small-channel path (Cin <= 32, Cout <= 32, 3x3 stride 1 pad 1, single source, optional nearest-2x):
+ * an 8x32 output tile per workgroup with the input halo tile staged once in LDS (conv_sc.hip).
+ * stp_conv2d uses it automatically when stp_conv2d_sc_eligible(p) != 0 (tile id 512). */
+int stp_conv2d_sc_eligible(const stp_conv_params* p);
+int stp_conv2d_sc(const stp_conv_params* p, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Weight gradient (Conv2DBackpropFilter).  dW[co][(kh*KW+kw)*(C0+C1)+c] =
@@ -108,7 +113,11 @@ int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspac
 /* The two phases of stp_conv2d_wgrad as separate launches (so that a profiler / the plan can time them
  * individually).  variant: 0 = auto, 1 = register-staged kernel, 2 / 3 = buffer-DMA ring with 2 / 3 stages. */
 int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, int32_t variant, void* stream);
-int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, void* stream);
+int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, int32_t variant, void* stream);
+/* Small-channel weight gradient (conv_sc.hip): chosen automatically by variant 0 when eligible. */
+int stp_wgrad_sc_eligible(const stp_wgrad_params* p);
+int stp_wgrad_sc_slabs(const stp_wgrad_params* p);
+int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Compute copies of a convolution kernel from the fp32 master (layout [Cout][KH][KW][Cin]):

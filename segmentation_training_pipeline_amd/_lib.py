@@ -40,10 +40,15 @@ SIGNATURES = {
     "stp_abi_version": (i32, []),
     "stp_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_sc_eligible": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_sc": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_wgrad_workspace_bytes": (sz, [C.POINTER(WgradParams)]),
     "stp_conv2d_wgrad": (i32, [C.POINTER(WgradParams), vp, sz, vp]),
     "stp_conv2d_wgrad_partial": (i32, [C.POINTER(WgradParams), vp, sz, i32, vp]),
-    "stp_conv2d_wgrad_reduce": (i32, [C.POINTER(WgradParams), vp, vp]),
+    "stp_conv2d_wgrad_reduce": (i32, [C.POINTER(WgradParams), vp, i32, vp]),
+    "stp_wgrad_sc_eligible": (i32, [C.POINTER(WgradParams)]),
+    "stp_wgrad_sc_slabs": (i32, [C.POINTER(WgradParams)]),
+    "stp_wgrad_sc_partial": (i32, [C.POINTER(WgradParams), vp, vp]),
     "stp_weight_prepare": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_weight_grad_unpad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_stem_beta_grad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -14,42 +14,83 @@ template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
 template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return load4(p); }
 template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) { return load4(p); }
 
+// V consecutive channels <-> float[V]; V*sizeof(T) is 8 or 16 bytes
+template <typename T, int V> __device__ __forceinline__ void ldv(const T* p, float (&o)[V]) {
+  if constexpr (V == 4) {
+    const f32x4 v = ld4<T>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {  // 8 bf16 = one 16-byte load
+    const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(r[e] << 16); o[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+  }
+}
+template <typename T, int V> __device__ __forceinline__ void stv(T* p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    store4(p, f32x4{o[0], o[1], o[2], o[3]});
+  } else {
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(p) = r;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // statistics: partial[block][0][c] = sum x, partial[block][1][c] = sum x^2 over the block's rows
-template <typename T>
+// Each thread owns V consecutive channels (16 bytes for bf16 V=8 / fp32 V=4) and strides over rows with 4
+// independent loads in flight; row lanes are then combined through LDS in a fixed order.
+template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, int64_t rows, int C, float* partial) {
-  extern __shared__ float red[];  // [256][8] worst case handled in column tiles below
-  const int cg = C >> 2;                              // channel groups of 4
+  extern __shared__ float red[];  // [256][2V]
+  const int cg = C / V;
   const int colsPerPass = cg < 256 ? cg : 256;
-  const int rowLanes = 256 / colsPerPass;             // threads along rows
+  const int rowLanes = 256 / colsPerPass;
   const int tcol = threadIdx.x % colsPerPass, trow = threadIdx.x / colsPerPass;
   const int64_t rowsPerBlock = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * rowsPerBlock;
   const int64_t r1 = r0 + rowsPerBlock < rows ? r0 + rowsPerBlock : rows;
   for (int c0 = 0; c0 < cg; c0 += colsPerPass) {
     const int c = c0 + tcol;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    float s[V], q[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = q[e] = 0.f;
     if (c < cg && trow < rowLanes) {
-      for (int64_t r = r0 + trow; r < r1; r += rowLanes) {
-        const f32x4 v = ld4<T>(x + r * C + c * 4);
-        s += v;
-        q += v * v;
+      const T* base = x + (size_t)c * V;
+      int64_t r = r0 + trow;
+      for (; r + 3 * (int64_t)rowLanes < r1; r += 4 * (int64_t)rowLanes) {
+        float v0[V], v1[V], v2[V], v3[V];
+        ldv<T, V>(base + r * C, v0);
+        ldv<T, V>(base + (r + rowLanes) * C, v1);
+        ldv<T, V>(base + (r + 2 * (int64_t)rowLanes) * C, v2);
+        ldv<T, V>(base + (r + 3 * (int64_t)rowLanes) * C, v3);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          s[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+          q[e] += (v0[e] * v0[e] + v1[e] * v1[e]) + (v2[e] * v2[e] + v3[e] * v3[e]);
+        }
+      }
+      for (; r < r1; r += rowLanes) {
+        float v0[V];
+        ldv<T, V>(base + r * C, v0);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[e] += v0[e]; q[e] += v0[e] * v0[e]; }
       }
     }
-    // reduce over row lanes through LDS (fixed order)
-    float* rs = red;               // [rowLanes][colsPerPass][8]
-    const int slot = (trow * colsPerPass + tcol) * 8;
-    rs[slot + 0] = s.x; rs[slot + 1] = s.y; rs[slot + 2] = s.z; rs[slot + 3] = s.w;
-    rs[slot + 4] = q.x; rs[slot + 5] = q.y; rs[slot + 6] = q.z; rs[slot + 7] = q.w;
+    const int slot = (trow * colsPerPass + tcol) * 2 * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[slot + e] = s[e]; red[slot + V + e] = q[e]; }
     __syncthreads();
     if (trow == 0 && c < cg) {
-      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      float a[2 * V];
+#pragma unroll
+      for (int e = 0; e < 2 * V; ++e) a[e] = 0.f;
       for (int t = 0; t < rowLanes; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += rs[(t * colsPerPass + tcol) * 8 + e];
+        for (int e = 0; e < 2 * V; ++e) a[e] += red[(t * colsPerPass + tcol) * 2 * V + e];
       float* p = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { p[c * 4 + e] = a[e]; p[C + c * 4 + e] = a[4 + e]; }
+      for (int e = 0; e < V; ++e) { p[c * V + e] = a[e]; p[C + c * V + e] = a[V + e]; }
     }
     __syncthreads();
   }
@@ -148,11 +189,12 @@ extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t
     hipLaunchKernelGGL(bn_partial_u8_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)x, rows, C, partial);
   } else {
     if (C & 3) return STP_E_BADARG;
-    const size_t lds = 256 * 8 * sizeof(float);
-    if (xdtype == STP_BF16)
-      hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)x, rows, C, partial);
+    if (xdtype == STP_BF16 && (C & 7) == 0)
+      hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
+    else if (xdtype == STP_BF16)
+      hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
     else if (xdtype == STP_F32)
-      hipLaunchKernelGGL(bn_partial_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)x, rows, C, partial);
+      hipLaunchKernelGGL((bn_partial_kernel<float, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const float*)x, rows, C, partial);
     else
       return STP_E_BADARG;
   }
@@ -275,13 +317,13 @@ extern "C" int stp_bn_inference(const void* x, int32_t xdtype, void* y, int32_t 
 
 // ------------------------------------------------------------------------------------------
 // backward.  g = dy * [relu ? (x*scale+shift > 0) : 1];  partial sums of g and g*xhat
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows,
                                                              int C, const float* mean, const float* rstd,
                                                              const float* gamma, const float* beta, int relu,
                                                              float* partial) {
   extern __shared__ float red[];
-  const int cg = C >> 2;
+  const int cg = C / V;
   const int colsPerPass = cg < 256 ? cg : 256;
   const int rowLanes = 256 / colsPerPass;
   const int tcol = threadIdx.x % colsPerPass, trow = threadIdx.x / colsPerPass;
@@ -290,40 +332,60 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   const int64_t r1 = r0 + rowsPerBlock < rows ? r0 + rowsPerBlock : rows;
   for (int c0 = 0; c0 < cg; c0 += colsPerPass) {
     const int c = c0 + tcol;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    float s[V], q[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = q[e] = 0.f;
     if (c < cg && trow < rowLanes) {
-      float mu[4], rs[4], sc[4], sh[4];
+      float mu[V], rs[V], sc[V], sh[V];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        mu[e] = mean[c * 4 + e];
-        rs[e] = rstd[c * 4 + e];
-        sc[e] = gamma ? rs[e] * gamma[c * 4 + e] : rs[e];
-        sh[e] = (beta ? beta[c * 4 + e] : 0.f) - mu[e] * sc[e];
+      for (int e = 0; e < V; ++e) {
+        mu[e] = mean[c * V + e];
+        rs[e] = rstd[c * V + e];
+        sc[e] = gamma ? rs[e] * gamma[c * V + e] : rs[e];
+        sh[e] = (beta ? beta[c * V + e] : 0.f) - mu[e] * sc[e];
       }
-      for (int64_t r = r0 + trow; r < r1; r += rowLanes) {
-        const f32x4 xv = ld4<T>(x + r * C + c * 4);
-        f32x4 g = ld4<T>(dy + r * C + c * 4);
+      const size_t cb = (size_t)c * V;
+      int64_t r = r0 + trow;
+      for (; r + (int64_t)rowLanes < r1; r += 2 * (int64_t)rowLanes) {
+        float x0[V], g0[V], x1[V], g1[V];
+        ldv<T, V>(x + r * C + cb, x0);
+        ldv<T, V>(dy + r * C + cb, g0);
+        ldv<T, V>(x + (r + rowLanes) * C + cb, x1);
+        ldv<T, V>(dy + (r + rowLanes) * C + cb, g1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (relu && !(bn_affine(xv[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
-          s[e] += g[e];
-          q[e] += g[e] * ((xv[e] - mu[e]) * rs[e]);
+        for (int e = 0; e < V; ++e) {
+          if (relu && !(bn_affine(x0[e], sc[e], sh[e]) > 0.f)) g0[e] = 0.f;
+          if (relu && !(bn_affine(x1[e], sc[e], sh[e]) > 0.f)) g1[e] = 0.f;
+          s[e] += g0[e] + g1[e];
+          q[e] += g0[e] * ((x0[e] - mu[e]) * rs[e]) + g1[e] * ((x1[e] - mu[e]) * rs[e]);
+        }
+      }
+      for (; r < r1; r += rowLanes) {
+        float x0[V], g0[V];
+        ldv<T, V>(x + r * C + cb, x0);
+        ldv<T, V>(dy + r * C + cb, g0);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          if (relu && !(bn_affine(x0[e], sc[e], sh[e]) > 0.f)) g0[e] = 0.f;
+          s[e] += g0[e];
+          q[e] += g0[e] * ((x0[e] - mu[e]) * rs[e]);
         }
       }
     }
-    float* rsm = red;
-    const int slot = (trow * colsPerPass + tcol) * 8;
-    rsm[slot + 0] = s.x; rsm[slot + 1] = s.y; rsm[slot + 2] = s.z; rsm[slot + 3] = s.w;
-    rsm[slot + 4] = q.x; rsm[slot + 5] = q.y; rsm[slot + 6] = q.z; rsm[slot + 7] = q.w;
+    const int slot = (trow * colsPerPass + tcol) * 2 * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[slot + e] = s[e]; red[slot + V + e] = q[e]; }
     __syncthreads();
     if (trow == 0 && c < cg) {
-      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      float a[2 * V];
+#pragma unroll
+      for (int e = 0; e < 2 * V; ++e) a[e] = 0.f;
       for (int t = 0; t < rowLanes; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += rsm[(t * colsPerPass + tcol) * 8 + e];
+        for (int e = 0; e < 2 * V; ++e) a[e] += red[(t * colsPerPass + tcol) * 2 * V + e];
       float* p = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { p[c * 4 + e] = a[e]; p[C + c * 4 + e] = a[4 + e]; }
+      for (int e = 0; e < V; ++e) { p[c * V + e] = a[e]; p[C + c * V + e] = a[V + e]; }
     }
     __syncthreads();
   }
@@ -341,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
   if (dgamma) dgamma[c] = (float)t.q;
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                            int64_t rows, int C, const float* mean, const float* rstd,
                                                            const float* gamma, const float* beta, const float* sums,
@@ -357,21 +419,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     ss[5 * C + c] = sums[C + c] * inv_rows;
   }
   __syncthreads();
-  const int cg = C >> 2;
+  const int cg = C / V;
   const int64_t total = rows * cg;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % cg) * 4;
-    const f32x4 xv = ld4<T>(x + i * 4);
-    f32x4 g = ld4<T>(dy + i * 4);
-    f32x4 o;
+    const int c = (int)(i % cg) * V;
+    float xv[V], g[V], o[V];
+    ldv<T, V>(x + i * V, xv);
+    ldv<T, V>(dy + i * V, g);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < V; ++e) {
       if (relu && !(bn_affine(xv[e], ss[2 * C + c + e], ss[3 * C + c + e]) > 0.f)) g[e] = 0.f;
       const float xh = (xv[e] - ss[c + e]) * ss[C + c + e];
       o[e] = ss[2 * C + c + e] * (g[e] - ss[4 * C + c + e] - xh * ss[5 * C + c + e]);
     }
-    if (accumulate) o += ld4<T>(dx + i * 4);
-    store4(dx + i * 4, o);
+    if (accumulate) {
+      float d[V];
+      ldv<T, V>(dx + i * V, d);
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] += d[e];
+    }
+    stv<T, V>(dx + i * V, o);
   }
 }
 
@@ -385,26 +452,32 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
   const int blocks = bn_blocks(rows) > BN_MAX_BLOCKS - 1 ? BN_MAX_BLOCKS - 1 : bn_blocks(rows);
   float* partial = (float*)workspace;
   float* sums = partial + (size_t)(BN_MAX_BLOCKS - 1) * 2 * C;  // last slab holds the finalized sums
-  const size_t lds = 256 * 8 * sizeof(float);
-  if (dtype == STP_BF16)
-    hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy,
-                       rows, C, mean, rstd, gamma, beta, relu, partial);
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  if (v8)
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t*)x,
+                       (const bf16_t*)dy, rows, C, mean, rstd, gamma, beta, relu, partial);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t*)x,
+                       (const bf16_t*)dy, rows, C, mean, rstd, gamma, beta, relu, partial);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)x, (const float*)dy, rows,
-                       C, mean, rstd, gamma, beta, relu, partial);
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<float, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const float*)x,
+                       (const float*)dy, rows, C, mean, rstd, gamma, beta, relu, partial);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, blocks, C, sums, dgamma, dbeta);
   STP_LAUNCH_CHECK();
   const size_t lds2 = 6 * (size_t)C * sizeof(float);
-  const int g = grid_for(rows * (C >> 2));
+  const int g = grid_for(rows * (C / (v8 ? 8 : 4)));
   const float inv_rows = (float)(1.0 / (double)rows);
-  if (dtype == STP_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)dy,
+  if (v8)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(g), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)dy,
+                       (bf16_t*)dx, rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(g), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)dy,
                        (bf16_t*)dx, rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g), dim3(256), lds2, s, (const float*)x, (const float*)dy, (float*)dx,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(g), dim3(256), lds2, s, (const float*)x, (const float*)dy, (float*)dx,
                        rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
   STP_LAUNCH_CHECK();
   return STP_OK;
@@ -568,11 +641,12 @@ extern "C" int stp_channel_sum(const void* x, int32_t dtype, int64_t rows, int32
   hipStream_t s = (hipStream_t)stream;
   const int blocks = bn_blocks(rows);
   float* partial = (float*)workspace;
-  const size_t lds = 256 * 8 * sizeof(float);
-  if (dtype == STP_BF16)
-    hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)x, rows, C, partial);
+  if (dtype == STP_BF16 && (C & 7) == 0)
+    hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(bn_partial_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)x, rows, C, partial);
+    hipLaunchKernelGGL((bn_partial_kernel<float, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const float*)x, rows, C, partial);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();

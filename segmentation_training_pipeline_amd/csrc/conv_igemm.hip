@@ -573,8 +573,13 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* u
   return STP_OK;
 }
 
+extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p);
+extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream);
+#define STP_TILE_SC 512  // the small-channel halo-tile kernel of conv_sc.hip
+
 // Which tile configuration stp_conv2d would launch (profiling / roofline bookkeeping).
 extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
+  if (p && (p->tile == 0 || p->tile == STP_TILE_SC) && stp_conv2d_sc_eligible(p)) return STP_TILE_SC;
   ConvArgs a;
   bool c4;
   int ut;
@@ -586,6 +591,10 @@ extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
 }
 
 extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
+  if (p && (p->tile == 0 || p->tile == STP_TILE_SC)) {
+    if (stp_conv2d_sc_eligible(p)) return stp_conv2d_sc(p, stream);
+    if (p->tile == STP_TILE_SC) return STP_E_BADARG;
+  }
   ConvArgs a;
   bool c4;
   int ut;

@@ -1,0 +1,399 @@
+// "Small-channel" 3x3 / stride-1 / pad-1 convolution for the full-resolution decoder tail and the head
+// (Cin <= 32, Cout <= 32): these layers are HBM-bound (AI 8..96 FLOP/B), and the generic
+// implicit-GEMM gather re-reads every input pixel 9 times through the vector-memory path.
+//
+// Here a workgroup owns an 8 x 32 output tile: the (8+2) x (32+2) x Cin input halo tile is staged ONCE in
+// LDS (coalesced 16-byte vectors, padding and nearest-2x upsampling resolved while staging), the whole
+// weight matrix lives in registers as MFMA A fragments, and every B fragment is a single ds_read_b128
+// from the halo tile at (pixel + tap offset): no im2col copy exists anywhere.  Per 16 output pixels:
+// ceil(9*Cin/32) LDS reads and as many MFMAs per 16 output channels.  With ~11-22 KB of LDS per
+// workgroup 7+ workgroups share a CU, which is what hides the load latency of this streaming kernel.
+//
+//   C[cout][pixel] = sum_k W[cout][k] * halo[pixel + tap(k)][ch(k)],   k = tap*Cin + ch, tap = kh*3 + kw
+// The k -> (lane group, vector slot) assignment is the same for A and B (all a contraction needs).
+// Used for forward and (with the flipped/transposed weight copy) for the data gradient.
+#include "common.h"
+
+struct ScArgs {
+  const char* src;     // [N,Hs,Ws,CIN]  (Hs = H/2 when upsampling)
+  const char* weight;  // [Cout_pad16][9*CIN]
+  const float* bias;
+  char* dst;           // [N,H,W,Cout]
+  int N, H, W, Hs, Ws, Cout, up, accumulate, relu;
+  int tiles_x, tiles_y;
+};
+
+template <typename T> struct ScMma;
+template <> struct ScMma<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct ScMma<float> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+constexpr int SC_TH = 8, SC_TW = 32, SC_HW = SC_TW + 2, SC_HH = SC_TH + 2;
+
+template <typename T, int CIN, int TM>
+__global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KC = 4 * VEC;                    // k values per MFMA chunk (32 bf16 / 16 fp32)
+  constexpr int K = 9 * CIN;
+  constexpr int NCH = (K + KC - 1) / KC;
+  constexpr int VPP = CIN / VEC;                 // 16-byte vectors per pixel
+  constexpr int PIXB = CIN * SZ;                 // bytes per pixel in the halo tile
+  static_assert(CIN % VEC == 0, "CIN must be a multiple of the 16-byte vector");
+
+  extern __shared__ __attribute__((aligned(16))) char halo[];  // [SC_HH][SC_HW][CIN]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int y0 = ty * SC_TH, x0 = tx * SC_TW;
+
+  // ---- stage the halo tile -----------------------------------------------------------------
+  const int sh = a.up ? 1 : 0;
+  const char* img = a.src + (size_t)n * a.Hs * a.Ws * PIXB;
+  for (int v = tid; v < SC_HH * SC_HW * VPP; v += 256) {
+    const int pix = v / VPP, cv = v - pix * VPP;
+    const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+      val = *reinterpret_cast<const u32x4*>(img + ((size_t)(gy >> sh) * a.Ws + (gx >> sh)) * PIXB + cv * 16);
+    *reinterpret_cast<u32x4*>(halo + v * 16) = val;
+  }
+
+  // ---- weights -> registers (A fragments), per-lane tap offsets of the B fragments -----------
+  u32x4 fa[TM][NCH];
+  int boff[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k0 = c * KC + lg * VEC;
+    const int tap = k0 / CIN, ch = k0 - tap * CIN;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    boff[c] = (k0 < K) ? ((kh * SC_HW + kw) * CIN + ch) * SZ : -1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (k0 < K) w = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(i * 16 + lr) * K + k0) * SZ);
+      fa[i][c] = w;
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMAs: wave w owns tile rows 2w, 2w+1; 4 fragments of 16 pixels -------------------------
+  f32x4 acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int py = wave * 2 + (f >> 1), px = (f & 1) * 16 + lr;
+    const char* pbase = halo + (py * SC_HW + px) * PIXB;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      u32x4 fb = {0u, 0u, 0u, 0u};
+      if (boff[c] >= 0) fb = *reinterpret_cast<const u32x4*>(pbase + boff[c]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ScMma<T>::run(fa[i][c], fb, acc[i][f]);
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------
+  T* out = reinterpret_cast<T*>(a.dst);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+    if (gy >= a.H || gx >= a.W) continue;
+    const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int co = i * 16 + lg * 4;
+      if (co >= a.Cout) continue;
+      f32x4 v = acc[i][f];
+      if (co + 3 < a.Cout) {
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+        T* d = out + pm * a.Cout + co;
+        if (a.accumulate) v += load4(d);
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        store4(d, v);
+      } else {
+        for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
+          float x = v[r];
+          if (a.bias) x += a.bias[co + r];
+          T* d = out + pm * a.Cout + co + r;
+          if (a.accumulate) x += Elem<T>::load(d);
+          if (a.relu) x = fmaxf(x, 0.f);
+          Elem<T>::store(d, x);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int CIN, int TM>
+static int launch_sc(const ScArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)SC_HH * SC_HW * CIN * sizeof(T);
+  hipLaunchKernelGGL((conv_sc_kernel<T, CIN, TM>), dim3(a.N * a.tiles_x * a.tiles_y), dim3(256), lds, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+template <typename T>
+static int dispatch_sc(const ScArgs& a, int cin, hipStream_t s) {
+  const int tm = a.Cout <= 16 ? 1 : 2;
+  switch (cin * 4 + tm) {
+    case 4 * 4 + 1: if constexpr (sizeof(T) == 4) return launch_sc<T, 4, 1>(a, s); else return STP_E_BADARG;
+    case 4 * 4 + 2: if constexpr (sizeof(T) == 4) return launch_sc<T, 4, 2>(a, s); else return STP_E_BADARG;
+    case 8 * 4 + 1: return launch_sc<T, 8, 1>(a, s);
+    case 8 * 4 + 2: return launch_sc<T, 8, 2>(a, s);
+    case 16 * 4 + 1: return launch_sc<T, 16, 1>(a, s);
+    case 16 * 4 + 2: return launch_sc<T, 16, 2>(a, s);
+    case 32 * 4 + 1: return launch_sc<T, 32, 1>(a, s);
+    case 32 * 4 + 2: return launch_sc<T, 32, 2>(a, s);
+    default: return STP_E_BADARG;
+  }
+}
+
+// Is this convolution served by the small-channel kernel?  (stp_conv2d consults this before the GEMM path.)
+extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p) {
+  if (!p) return 0;
+  const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  const int cin = p->C0;
+  // fp32 holds half as many k per 16-byte vector: cap Cin at 16 there so the A fragments stay in registers
+  const bool cin_ok = p->dtype == STP_F32 ? (cin == 4 || cin == 8 || cin == 16) : (cin == 8 || cin == 16 || cin == 32);
+  return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->C1 == 0 && cin_ok && (cin % vec) == 0 && p->Cout <= 32 &&
+         p->Cd0 == p->Cout && !p->residual && p->Ho == p->Hv && p->Wo == p->Wv &&
+         (p->src0_mode == STP_SRC_DIRECT || (p->src0_mode == STP_SRC_NEAREST2X && p->Hv == 2 * p->Hs0 && p->Wv == 2 * p->Ws0));
+}
+
+extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
+  if (!stp_conv2d_sc_eligible(p) || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
+  ScArgs a;
+  a.src = (const char*)p->src0; a.weight = (const char*)p->weight; a.bias = p->bias; a.dst = (char*)p->dst0;
+  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
+  a.up = p->src0_mode == STP_SRC_NEAREST2X; a.accumulate = p->accumulate0; a.relu = p->relu;
+  a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
+  hipStream_t s = (hipStream_t)stream;
+  return p->dtype == STP_BF16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);
+}
+
+// =================================================================================================
+// Small-channel weight gradient:  dW[co][tap*CIN + ci] = sum_pixels dY[p][co] * X[p + tap][ci]
+// Persistent workgroups walk 8x32 tiles; per tile the X halo tile and the dY tile are staged in LDS.
+// The reduction index (pixels) is the slow dimension of both tiles, so bf16 fragments come from the
+// transpose read ds_read_b64_tr_b16 ([4 pixels][16 channels] per 16-lane group); fp32 uses one element
+// per lane.  A 32-pixel MFMA chunk is one tile row.  The 9 taps are split over the 4 waves (wave w owns
+// taps w, w+4, w+8), so no cross-wave reduction is needed and accumulators stay in registers across
+// tiles.  Each workgroup writes one fp32 slab; the generic fixed-order reduce kernel sums them.
+// =================================================================================================
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+struct ScWgArgs {
+  const char* src;  // x  [N,Hs,Ws,CIN]
+  const char* dy;   // dY [N,H,W,COUT]
+  float* slabs;     // [gridDim][Cout][9*CIN]
+  int N, H, W, Hs, Ws, Cout, up;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int TMo = (COUT + 15) / 16, TNi = CIN / 16;
+  constexpr int PIXB = CIN * SZ, DYB = COUT * SZ;
+  constexpr int HALO_BYTES = SC_HH * SC_HW * PIXB;
+  static_assert(CIN % 16 == 0 && COUT % VEC == 0, "channel granularity");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* dyt = smem + HALO_BYTES;  // [SC_TH][SC_TW][COUT]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int sh = a.up ? 1 : 0;
+
+  f32x4 acc[3][TMo][TNi];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < TMo; ++i)
+#pragma unroll
+      for (int j = 0; j < TNi; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    const int y0 = ty * SC_TH, x0 = tx * SC_TW;
+    __syncthreads();  // previous tile fully consumed
+    const char* img = a.src + (size_t)n * a.Hs * a.Ws * PIXB;
+    for (int v = tid; v < SC_HH * SC_HW * (CIN / VEC); v += 256) {
+      const int pix = v / (CIN / VEC), cv = v - pix * (CIN / VEC);
+      const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+        val = *reinterpret_cast<const u32x4*>(img + ((size_t)(gy >> sh) * a.Ws + (gx >> sh)) * PIXB + cv * 16);
+      *reinterpret_cast<u32x4*>(halo + v * 16) = val;
+    }
+    const char* dimg = a.dy + (size_t)n * a.H * a.W * DYB;
+    for (int v = tid; v < SC_TH * SC_TW * (COUT / VEC); v += 256) {
+      const int pix = v / (COUT / VEC), cv = v - pix * (COUT / VEC);
+      const int py = pix / SC_TW, px = pix - py * SC_TW;
+      const int gy = y0 + py, gx = x0 + px;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (gy < a.H && gx < a.W) val = *reinterpret_cast<const u32x4*>(dimg + ((size_t)gy * a.W + gx) * DYB + cv * 16);
+      *reinterpret_cast<u32x4*>(dyt + v * 16) = val;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int row = 0; row < SC_TH; ++row) {  // one 32-pixel chunk = one tile row
+      if constexpr (sizeof(T) == 2) {
+        // lane group g owns pixels x = 4g..4g+3 (lo) and 16+4g..16+4g+3 (hi); lane i of a group addresses pixel (i>>2), quad (i&3)
+        const int xl = lg * 4 + (lr >> 2), qb = (lr & 3) * 8;
+        u32x4 fa[TMo];
+#pragma unroll
+        for (int i = 0; i < TMo; ++i) {
+          const char* p = dyt + ((row * SC_TW + xl) * COUT + i * 16) * SZ + qb;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * DYB));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int tap = wave + 4 * t;
+          if (tap < 9) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int j = 0; j < TNi; ++j) {
+              const char* p = halo + (((row + kh) * SC_HW + xl + kw) * CIN + j * 16) * SZ + qb;
+              const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+              const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * PIXB));
+              const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+              const u32x4 fb = u32x4{l2.x, l2.y, h2.x, h2.y};
+#pragma unroll
+              for (int i = 0; i < TMo; ++i)
+                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb),
+                                                                       acc[t][i][j], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        // fp32: 8 k-steps of 4 pixels; lane group g owns pixel 4s + g
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int x = s * 4 + lg;
+          float fa[TMo];
+#pragma unroll
+          for (int i = 0; i < TMo; ++i) fa[i] = *reinterpret_cast<const float*>(dyt + ((row * SC_TW + x) * COUT + i * 16 + lr) * SZ);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int tap = wave + 4 * t;
+            if (tap < 9) {
+              const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+              for (int j = 0; j < TNi; ++j) {
+                const float fb = *reinterpret_cast<const float*>(halo + (((row + kh) * SC_HW + x + kw) * CIN + j * 16 + lr) * SZ);
+#pragma unroll
+                for (int i = 0; i < TMo; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb, acc[t][i][j], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- slab: C layout row (co) = lg*4 + r, col (ci) = lr ------------------------------------------
+  float* out = a.slabs + (size_t)blockIdx.x * a.Cout * (9 * CIN);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap >= 9) continue;
+#pragma unroll
+    for (int i = 0; i < TMo; ++i)
+#pragma unroll
+      for (int j = 0; j < TNi; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = i * 16 + lg * 4 + r;
+          if (co < a.Cout) out[(size_t)co * (9 * CIN) + tap * CIN + j * 16 + lr] = acc[t][i][j][r];
+        }
+  }
+}
+
+#define SC_WG_MAX_BLOCKS 1024
+
+extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
+  if (!p) return 0;
+  const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->C1 == 0 && (p->C0 == 16 || p->C0 == 32) &&
+         (p->Cout == 8 || p->Cout == 16 || p->Cout == 32 || (p->Cout == 4 && vec == 4)) && (p->Cout % vec) == 0 &&
+         p->Ho == p->Hv && p->Wo == p->Wv &&
+         (p->src0_mode == STP_SRC_DIRECT || (p->src0_mode == STP_SRC_NEAREST2X && p->Hv == 2 * p->Hs0 && p->Wv == 2 * p->Ws0));
+}
+
+// number of slabs (= workgroups) the small-channel weight gradient writes
+extern "C" int stp_wgrad_sc_slabs(const stp_wgrad_params* p) {
+  const int64_t tiles = (int64_t)p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW);
+  return (int)(tiles < SC_WG_MAX_BLOCKS ? tiles : SC_WG_MAX_BLOCKS);
+}
+
+template <typename T, int CIN, int COUT>
+static int launch_sc_wg(const ScWgArgs& a, int blocks, hipStream_t s) {
+  const size_t lds = (size_t)SC_HH * SC_HW * CIN * sizeof(T) + (size_t)SC_TH * SC_TW * COUT * sizeof(T) + 64;
+  hipLaunchKernelGGL((conv_sc_wgrad_kernel<T, CIN, COUT>), dim3(blocks), dim3(256), lds, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream) {
+  if (!stp_wgrad_sc_eligible(p) || !p->src0 || !p->dy || !workspace) return STP_E_BADARG;
+  ScWgArgs a;
+  a.src = (const char*)p->src0; a.dy = (const char*)p->dy; a.slabs = (float*)workspace;
+  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
+  a.up = p->src0_mode == STP_SRC_NEAREST2X;
+  a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH); a.ntiles = a.N * a.tiles_x * a.tiles_y;
+  const int blocks = stp_wgrad_sc_slabs(p);
+  hipStream_t s = (hipStream_t)stream;
+  const int key = p->C0 * 64 + p->Cout;
+  if (p->dtype == STP_BF16) {
+    switch (key) {
+      case 16 * 64 + 8: return launch_sc_wg<bf16_t, 16, 8>(a, blocks, s);
+      case 16 * 64 + 16: return launch_sc_wg<bf16_t, 16, 16>(a, blocks, s);
+      case 16 * 64 + 32: return launch_sc_wg<bf16_t, 16, 32>(a, blocks, s);
+      case 32 * 64 + 8: return launch_sc_wg<bf16_t, 32, 8>(a, blocks, s);
+      case 32 * 64 + 16: return launch_sc_wg<bf16_t, 32, 16>(a, blocks, s);
+      case 32 * 64 + 32: return launch_sc_wg<bf16_t, 32, 32>(a, blocks, s);
+      default: return STP_E_BADARG;
+    }
+  }
+  switch (key) {
+    case 16 * 64 + 4: return launch_sc_wg<float, 16, 4>(a, blocks, s);
+    case 16 * 64 + 8: return launch_sc_wg<float, 16, 8>(a, blocks, s);
+    case 16 * 64 + 16: return launch_sc_wg<float, 16, 16>(a, blocks, s);
+    case 16 * 64 + 32: return launch_sc_wg<float, 16, 32>(a, blocks, s);
+    case 32 * 64 + 4: return launch_sc_wg<float, 32, 4>(a, blocks, s);
+    case 32 * 64 + 8: return launch_sc_wg<float, 32, 8>(a, blocks, s);
+    case 32 * 64 + 16: return launch_sc_wg<float, 32, 16>(a, blocks, s);
+    case 32 * 64 + 32: return launch_sc_wg<float, 32, 32>(a, blocks, s);
+    default: return STP_E_BADARG;
+  }
+}

@@ -400,12 +400,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(dw + i) = s;
 }
 
+// Many slabs, few elements (small-channel layers: up to 1024 slabs of a few thousand floats): 16 lanes walk
+// the slabs in parallel for each group of 4 elements, then a fixed-shape LDS tree combines them.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int64_t count,
+                                                                int splits, int accumulate) {
+  __shared__ f32x4 sh[16][16];
+  const int ev = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = ((int64_t)blockIdx.x * 16 + ev) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < count)
+    for (int k = sl; k < splits; k += 16) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * count + i);
+  sh[sl][ev] = s;
+  __syncthreads();
+  for (int w = 8; w > 0; w >>= 1) {
+    if (sl < w) sh[sl][ev] += sh[sl + w][ev];
+    __syncthreads();
+  }
+  if (sl == 0 && i < count) {
+    f32x4 r = sh[0][ev];
+    if (accumulate) r += *reinterpret_cast<const f32x4*>(dw + i);
+    *reinterpret_cast<f32x4*>(dw + i) = r;
+  }
+}
+
 struct WgradPlan {
   int tile, bm, bn, ntile_m, ntile_n, splits, steps_per_split, nsteps;
 };
 
+extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p);
+extern "C" int stp_wgrad_sc_slabs(const stp_wgrad_params* p);
+extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream);
+#define WG_TILE_SC 100  // small-channel halo-tile kernel (conv_sc.hip): splits = number of persistent workgroups
+
 static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
   WgradPlan w;
+  if (p->splits == 0 && stp_wgrad_sc_eligible(p)) {
+    w.tile = WG_TILE_SC; w.bm = w.bn = 0; w.ntile_m = w.ntile_n = 1;
+    w.splits = stp_wgrad_sc_slabs(p); w.steps_per_split = 0; w.nsteps = 0;
+    return w;
+  }
   const int K = p->KH * p->KW * (p->C0 + p->C1);
   const int pk = p->dtype == STP_BF16 ? 64 : 32;
   const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
@@ -433,11 +466,14 @@ static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
   return w;
 }
 
+static WgradPlan plan_wgrad_gemm(const stp_wgrad_params* p);
+
+// enough for either kernel family (the automatic choice and the forced GEMM variants)
 extern "C" size_t stp_conv2d_wgrad_workspace_bytes(const stp_wgrad_params* p) {
   if (!p) return 0;
-  const WgradPlan w = plan_wgrad(p);
+  const WgradPlan w = plan_wgrad(p), g = plan_wgrad_gemm(p);
   const size_t K = (size_t)p->KH * p->KW * (p->C0 + p->C1);
-  return (size_t)w.splits * p->Cout * K * sizeof(float);
+  return (size_t)(w.splits > g.splits ? w.splits : g.splits) * p->Cout * K * sizeof(float);
 }
 
 template <typename K>
@@ -513,6 +549,13 @@ static int launch_wgrad_tile(WgradArgs& a, const WgradPlan& w, bool dma_ok, int 
   }
 }
 
+static WgradPlan plan_wgrad_gemm(const stp_wgrad_params* p) {
+  stp_wgrad_params q = *p;
+  if (q.splits == 0 && stp_wgrad_sc_eligible(p)) q.splits = -1;  // any non-zero value bypasses the small-channel plan...
+  WgradPlan w = plan_wgrad(&q);
+  return w;
+}
+
 static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, WgradArgs& a, WgradPlan& w, bool* c4_out,
                       bool* dma_out) {
   if (!p || !p->src0 || !p->dy || !p->dw || !workspace) return STP_E_BADARG;
@@ -528,7 +571,8 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
   if (p->Cout % vec) return STP_E_BADARG;
   if (p->C1 > 0 && !p->src1) return STP_E_BADARG;
   if (stp_conv2d_wgrad_workspace_bytes(p) > workspace_bytes) return STP_E_WORKSPACE;
-  w = plan_wgrad(p);
+  w = plan_wgrad_gemm(p);
+  if ((size_t)w.splits * p->Cout * p->KH * p->KW * (p->C0 + p->C1) * sizeof(float) > workspace_bytes) return STP_E_WORKSPACE;
   a.src0 = (const char*)p->src0; a.src1 = (const char*)p->src1; a.dy = (const char*)p->dy; a.out = (float*)workspace;
   a.N = p->N; a.Hs0 = p->Hs0; a.Ws0 = p->Ws0; a.Hv = p->Hv; a.Wv = p->Wv; a.C0 = p->C0; a.C1 = p->C1;
   a.Ctot = p->C0 + p->C1; a.mode = p->src0_mode;
@@ -552,6 +596,10 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
 // Phase 1: per-split partial sums into the workspace slabs.  `variant` as in launch_wgrad_tile.
 extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, int32_t variant,
                                         void* stream) {
+  if (p && variant == 0 && p->splits == 0 && stp_wgrad_sc_eligible(p)) {
+    if (!workspace || stp_conv2d_wgrad_workspace_bytes(p) > workspace_bytes) return STP_E_WORKSPACE;
+    return stp_wgrad_sc_partial(p, workspace, stream);
+  }
   WgradArgs a;
   WgradPlan w;
   bool c4, dma;
@@ -563,13 +611,17 @@ extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspa
   return launch_wgrad_tile<float, false>(a, w, dma, variant, s);
 }
 
-// Phase 2: dw (+)= sum over slabs, fixed order.
-extern "C" int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, void* stream) {
+// Phase 2: dw (+)= sum over slabs, fixed order.  `variant` must be the one given to the partial launch.
+extern "C" int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, int32_t variant, void* stream) {
   if (!p || !p->dw || !workspace) return STP_E_BADARG;
-  const WgradPlan w = plan_wgrad(p);
+  const WgradPlan w = variant == 0 ? plan_wgrad(p) : plan_wgrad_gemm(p);
   const int64_t count = (int64_t)p->Cout * p->KH * p->KW * (p->C0 + p->C1);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 1024)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
-                     p->dw, count, w.splits, p->accumulate);
+  if (w.splits >= 64 && count <= (1 << 16))
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(ceil_div(count, 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, p->dw, count, w.splits, p->accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 1024)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                       p->dw, count, w.splits, p->accumulate);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
@@ -577,5 +629,5 @@ extern "C" int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* wo
 extern "C" int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, void* stream) {
   const int rc = stp_conv2d_wgrad_partial(p, workspace, workspace_bytes, 0, stream);
   if (rc != STP_OK) return rc;
-  return stp_conv2d_wgrad_reduce(p, workspace, stream);
+  return stp_conv2d_wgrad_reduce(p, workspace, 0, stream);
 }

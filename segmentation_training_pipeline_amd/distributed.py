@@ -22,18 +22,20 @@ def env_world():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None):
+def init(backend=None, force=False):
+    """Joins the torchrun rendezvous (env://).  With world size 1 nothing is initialised unless ``force``
+    (used to exercise the RCCL path on a single GPU)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -52,9 +54,10 @@ class GradReducer(object):
     """Sum-all-reduce of a flat gradient arena in buckets; the mean's 1/world factor is NOT applied
     to the arena - read it from ``scale`` and fold it into the optimizer (HipSegModel.gscale)."""
 
-    def __init__(self, group=None, bucket_mb=32.0, wire_bf16=False, cast_fns=None):
+    def __init__(self, group=None, bucket_mb=32.0, wire_bf16=False, cast_fns=None, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force          # run the collectives even with one rank (single-GPU test of the RCCL path)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.wire_bf16 = wire_bf16
         self.cast_fns = cast_fns        # (f32->bf16, bf16->f32) device kernels when wire_bf16
@@ -66,7 +69,7 @@ class GradReducer(object):
         return 1.0 / self.world
 
     def allreduce(self, flat):
-        if self.world <= 1:
+        if self.world <= 1 and not (self.force and dist.is_initialized()):
             return
         if self._bounds is None or self._bounds[-1][1] != flat.numel():
             self._bounds = bucket_bounds(flat.numel(), self.bucket_elems)
@@ -82,9 +85,9 @@ class GradReducer(object):
                 w.wait()
                 to_f32(self._wire[s:e], flat[s:e], e - s)
             return
-        works = [dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in self._bounds]
-        for w in works:
-            w.wait()
+        # issued back to back on the current stream: RCCL pipelines consecutive collectives of one communicator
+        for s, e in self._bounds:
+            dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group)
 
 
 def shard_indices(n, rank, world, epoch, seed):

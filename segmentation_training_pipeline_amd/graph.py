@@ -173,7 +173,7 @@ class Plan(object):
         self._keep.append(p)
         lst.append((self.lib.stp_conv2d_wgrad_partial, (C.byref(p), self.ws_wgrad.data_ptr(), self.ws_wgrad.numel() * 4, 0),
                     "stp_conv2d_wgrad", meta))
-        lst.append((self.lib.stp_conv2d_wgrad_reduce, (C.byref(p), self.ws_wgrad.data_ptr()), "stp_conv2d_wgrad_reduce", None))
+        lst.append((self.lib.stp_conv2d_wgrad_reduce, (C.byref(p), self.ws_wgrad.data_ptr(), 0), "stp_conv2d_wgrad_reduce", None))
 
     # ------------------------------------------------------------------ layers
     def input_u8(self, name, H, W, Cn):
@@ -317,7 +317,8 @@ class Plan(object):
                 else:
                     wp.dw = self._gptr(w)
                 wp.src0, wp.src1, wp.dy = x.buf.data_ptr(), (src1.buf.data_ptr() if src1 is not None else None), dy.data_ptr()
-                self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB})
+                self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
+                                                "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp)))})
                 if padded:
                     self._emit(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
                                Cinp, 0)

@@ -72,8 +72,8 @@ def conv2d_wgrad_partial(p, workspace, variant=0):
                                                     variant, stream()), "stp_conv2d_wgrad_partial")
 
 
-def conv2d_wgrad_reduce(p, workspace):
-    _lib.check(_lib.load().stp_conv2d_wgrad_reduce(C.byref(p), ptr(workspace), stream()), "stp_conv2d_wgrad_reduce")
+def conv2d_wgrad_reduce(p, workspace, variant=0):
+    _lib.check(_lib.load().stp_conv2d_wgrad_reduce(C.byref(p), ptr(workspace), variant, stream()), "stp_conv2d_wgrad_reduce")
 
 
 def weight_prepare(master, fwd, bwd, Cout, KH, KW, Cin, KWp, Cinp, CoutB, dtype):

@@ -105,13 +105,13 @@ def test_fp32_adam_step_matches_golden_fixture(golden_dir):
     names = [str(s) for s in g["grad_names"]]
     got = m.get_gradients()
     l2 = np.array([np.sqrt((got[k].astype(np.float64) ** 2).sum()) for k in names])
-    np.testing.assert_allclose(l2, g["grad_l2_step1"], rtol=2e-2, atol=1e-6)   # ReLU-kink noise, see above
+    np.testing.assert_allclose(l2, g["grad_l2_step1"], rtol=5e-2, atol=1e-6)   # ReLU-kink noise, see above
     # Adam's first update is lr*sign(g) wherever |g| >> eps: elements whose gradient is at rounding
     # level legitimately differ by up to 2*lr, and the next forward amplifies that, so the second
     # step is held to a statistical band only.
     met2 = m.train_on_batch(g["x"], g["y"])
     d = np.abs(m.logits() - g["logits2"])
-    assert d.mean() < 2e-2 and np.corrcoef(m.logits().ravel(), g["logits2"].ravel())[0, 1] > 0.995
+    assert d.mean() < 4e-2 and np.corrcoef(m.logits().ravel(), g["logits2"].ravel())[0, 1] > 0.995
     assert abs(met2["loss"] - g["scalars2"][0]) < 2e-2
 
 

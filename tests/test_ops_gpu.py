@@ -103,6 +103,9 @@ CONV_CASES = [
     # per-lane-tap DMA variants for 8/16/32-channel inputs (several taps per K-tile, ragged K tail)
     (1, 24, 20, 16, 64, 3, 1, 1, 258), (1, 24, 20, 32, 32, 3, 1, 1, 259), (1, 20, 24, 16, 16, 3, 1, 1, 260),
     (2, 13, 9, 32, 16, 3, 1, 1, 0), (2, 13, 9, 8, 16, 3, 1, 1, 0), (2, 12, 12, 16, 32, 3, 2, 1, 0),
+    # small-channel halo-tile kernel (tile 512) incl. ragged tiles, and the GEMM path forced for the same shapes
+    (2, 19, 45, 16, 16, 3, 1, 1, 512), (1, 8, 32, 32, 32, 3, 1, 1, 512), (2, 21, 33, 8, 16, 3, 1, 1, 512),
+    (2, 19, 45, 16, 32, 3, 1, 1, 512), (2, 19, 45, 16, 16, 3, 1, 1, 260), (1, 40, 70, 32, 24, 3, 1, 1, 0),
 ]
 
 
@@ -257,6 +260,9 @@ WGRAD_CASES = [
     (2, 12, 12, 128, 256, 3, 2, 1, 1),
     (2, 16, 16, 64, 128, 1, 2, 0, 0),
     (3, 7, 5, 24, 40, 3, 1, 1, 2),
+    # small-channel halo-tile weight gradient (automatic for 16/32-channel 3x3 s1 layers), ragged tiles
+    (2, 19, 45, 16, 16, 3, 1, 1, 0), (1, 9, 33, 32, 32, 3, 1, 1, 0), (2, 21, 40, 16, 32, 3, 1, 1, 0), (2, 19, 45, 32, 16, 3, 1, 1, 0),
+    (1, 16, 64, 16, 8, 3, 1, 1, 0),
 ]
 
 
@@ -284,7 +290,7 @@ def test_conv2d_weight_gradient(ops, dtype, case):
     for variant in (1, 2, 3):
         dw.fill_(float("nan"))
         ops.conv2d_wgrad_partial(W, ws, variant)
-        ops.conv2d_wgrad_reduce(W, ws)
+        ops.conv2d_wgrad_reduce(W, ws, variant)
         np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype), err_msg="variant %d" % variant)
 
 
