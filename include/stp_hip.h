@@ -129,6 +129,13 @@ int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* strea
  */
 int stp_weight_prepare(const float* master, void* fwd, void* bwd, int32_t Cout, int32_t KH, int32_t KW,
                        int32_t Cin, int32_t KWp, int32_t Cinp, int32_t CoutB, int32_t dtype, void* stream);
+/* All layers of a network in ONE launch: the caller fills a host array of opaque descriptors
+ * (stp_weight_prepare_desc_bytes() each) with stp_weight_prepare_desc_fill - `start` = running sum of the
+ * returned element counts - uploads it, and replays stp_weight_prepare_batched every step. */
+size_t stp_weight_prepare_desc_bytes(void);
+int64_t stp_weight_prepare_desc_fill(void* desc_host, int32_t index, int64_t start, const float* master, void* fwd, void* bwd,
+                                     int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, int32_t KWp, int32_t Cinp, int32_t CoutB);
+int stp_weight_prepare_batched(const void* desc_dev, int32_t nlayers, int64_t total, int32_t dtype, void* stream);
 int stp_weight_grad_unpad(const float* padded, float* grad, int32_t Cout, int32_t KH, int32_t KW,
                           int32_t Cin, int32_t KWp, int32_t Cinp, int32_t accumulate, void* stream);
 int stp_stem_beta_grad(const float* padded_dw, const float* master, float* dbeta, int32_t Cout, int32_t KH,

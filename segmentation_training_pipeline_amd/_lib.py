@@ -50,6 +50,9 @@ SIGNATURES = {
     "stp_wgrad_sc_slabs": (i32, [C.POINTER(WgradParams)]),
     "stp_wgrad_sc_partial": (i32, [C.POINTER(WgradParams), vp, vp]),
     "stp_weight_prepare": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_weight_prepare_desc_bytes": (sz, []),
+    "stp_weight_prepare_desc_fill": (i64, [vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
+    "stp_weight_prepare_batched": (i32, [vp, i32, i64, i32, vp]),
     "stp_weight_grad_unpad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_stem_beta_grad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_bn_workspace_bytes": (sz, [i32]),

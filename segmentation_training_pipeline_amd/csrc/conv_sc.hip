@@ -207,6 +207,7 @@ struct ScWgArgs {
   float* slabs;     // [gridDim][Cout][9*CIN]
   int N, H, W, Hs, Ws, Cout, up;
   int tiles_x, tiles_y, ntiles;
+  int ctot, coff;   // this source occupies channels [coff, coff+CIN) of the Ctot-channel concatenated input
 };
 
 template <typename T, int CIN, int COUT>
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
   }
 
   // ---- slab: C layout row (co) = lg*4 + r, col (ci) = lr ------------------------------------------
-  float* out = a.slabs + (size_t)blockIdx.x * a.Cout * (9 * CIN);
+  float* out = a.slabs + (size_t)blockIdx.x * a.Cout * (9 * a.ctot);
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int tap = wave + 4 * t;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = i * 16 + lg * 4 + r;
-          if (co < a.Cout) out[(size_t)co * (9 * CIN) + tap * CIN + j * 16 + lr] = acc[t][i][j][r];
+          if (co < a.Cout) out[(size_t)co * (9 * a.ctot) + tap * a.ctot + a.coff + j * 16 + lr] = acc[t][i][j][r];
         }
   }
 }
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
 extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
   if (!p) return 0;
   const int vec = p->dtype == STP_BF16 ? 8 : 4;
-  return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->C1 == 0 && (p->C0 == 16 || p->C0 == 32) &&
+  const bool c0ok = p->C0 == 16 || p->C0 == 32 || (p->C0 == 64 && vec == 8);
+  const bool c1ok = p->C1 == 0 || p->C1 == 16 || p->C1 == 32 || (p->C1 == 64 && vec == 8);   // (shape-only: no pointers here)
+  return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && c0ok && c1ok &&
          (p->Cout == 8 || p->Cout == 16 || p->Cout == 32 || (p->Cout == 4 && vec == 4)) && (p->Cout % vec) == 0 &&
          p->Ho == p->Hv && p->Wo == p->Wv &&
          (p->src0_mode == STP_SRC_DIRECT || (p->src0_mode == STP_SRC_NEAREST2X && p->Hv == 2 * p->Hs0 && p->Wv == 2 * p->Ws0));
@@ -364,36 +367,50 @@ static int launch_sc_wg(const ScWgArgs& a, int blocks, hipStream_t s) {
   return STP_OK;
 }
 
-extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream) {
-  if (!stp_wgrad_sc_eligible(p) || !p->src0 || !p->dy || !workspace) return STP_E_BADARG;
-  ScWgArgs a;
-  a.src = (const char*)p->src0; a.dy = (const char*)p->dy; a.slabs = (float*)workspace;
-  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
-  a.up = p->src0_mode == STP_SRC_NEAREST2X;
-  a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH); a.ntiles = a.N * a.tiles_x * a.tiles_y;
-  const int blocks = stp_wgrad_sc_slabs(p);
-  hipStream_t s = (hipStream_t)stream;
-  const int key = p->C0 * 64 + p->Cout;
-  if (p->dtype == STP_BF16) {
+template <typename T>
+static int sc_wg_dispatch(const ScWgArgs& a, int cin, int cout, int blocks, hipStream_t s) {
+  const int key = cin * 64 + cout;
+  if constexpr (sizeof(T) == 2) {
     switch (key) {
-      case 16 * 64 + 8: return launch_sc_wg<bf16_t, 16, 8>(a, blocks, s);
-      case 16 * 64 + 16: return launch_sc_wg<bf16_t, 16, 16>(a, blocks, s);
-      case 16 * 64 + 32: return launch_sc_wg<bf16_t, 16, 32>(a, blocks, s);
-      case 32 * 64 + 8: return launch_sc_wg<bf16_t, 32, 8>(a, blocks, s);
-      case 32 * 64 + 16: return launch_sc_wg<bf16_t, 32, 16>(a, blocks, s);
-      case 32 * 64 + 32: return launch_sc_wg<bf16_t, 32, 32>(a, blocks, s);
+      case 16 * 64 + 8: return launch_sc_wg<T, 16, 8>(a, blocks, s);
+      case 16 * 64 + 16: return launch_sc_wg<T, 16, 16>(a, blocks, s);
+      case 16 * 64 + 32: return launch_sc_wg<T, 16, 32>(a, blocks, s);
+      case 32 * 64 + 8: return launch_sc_wg<T, 32, 8>(a, blocks, s);
+      case 32 * 64 + 16: return launch_sc_wg<T, 32, 16>(a, blocks, s);
+      case 32 * 64 + 32: return launch_sc_wg<T, 32, 32>(a, blocks, s);
+      case 64 * 64 + 8: return launch_sc_wg<T, 64, 8>(a, blocks, s);
+      case 64 * 64 + 16: return launch_sc_wg<T, 64, 16>(a, blocks, s);
+      case 64 * 64 + 32: return launch_sc_wg<T, 64, 32>(a, blocks, s);
+      default: return STP_E_BADARG;
+    }
+  } else {
+    switch (key) {
+      case 16 * 64 + 4: return launch_sc_wg<T, 16, 4>(a, blocks, s);
+      case 16 * 64 + 8: return launch_sc_wg<T, 16, 8>(a, blocks, s);
+      case 16 * 64 + 16: return launch_sc_wg<T, 16, 16>(a, blocks, s);
+      case 16 * 64 + 32: return launch_sc_wg<T, 16, 32>(a, blocks, s);
+      case 32 * 64 + 4: return launch_sc_wg<T, 32, 4>(a, blocks, s);
+      case 32 * 64 + 8: return launch_sc_wg<T, 32, 8>(a, blocks, s);
+      case 32 * 64 + 16: return launch_sc_wg<T, 32, 16>(a, blocks, s);
+      case 32 * 64 + 32: return launch_sc_wg<T, 32, 32>(a, blocks, s);
       default: return STP_E_BADARG;
     }
   }
-  switch (key) {
-    case 16 * 64 + 4: return launch_sc_wg<float, 16, 4>(a, blocks, s);
-    case 16 * 64 + 8: return launch_sc_wg<float, 16, 8>(a, blocks, s);
-    case 16 * 64 + 16: return launch_sc_wg<float, 16, 16>(a, blocks, s);
-    case 16 * 64 + 32: return launch_sc_wg<float, 16, 32>(a, blocks, s);
-    case 32 * 64 + 4: return launch_sc_wg<float, 32, 4>(a, blocks, s);
-    case 32 * 64 + 8: return launch_sc_wg<float, 32, 8>(a, blocks, s);
-    case 32 * 64 + 16: return launch_sc_wg<float, 32, 16>(a, blocks, s);
-    case 32 * 64 + 32: return launch_sc_wg<float, 32, 32>(a, blocks, s);
-    default: return STP_E_BADARG;
-  }
+}
+
+// One launch per source of the concatenated input; both write disjoint column ranges of the same slabs.
+extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream) {
+  if (!stp_wgrad_sc_eligible(p) || !p->src0 || !p->dy || !workspace || (p->C1 > 0 && !p->src1)) return STP_E_BADARG;
+  ScWgArgs a;
+  a.dy = (const char*)p->dy; a.slabs = (float*)workspace;
+  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Cout = p->Cout;
+  a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH); a.ntiles = a.N * a.tiles_x * a.tiles_y;
+  a.ctot = p->C0 + p->C1;
+  const int blocks = stp_wgrad_sc_slabs(p);
+  hipStream_t s = (hipStream_t)stream;
+  a.src = (const char*)p->src0; a.Hs = p->Hs0; a.Ws = p->Ws0; a.up = p->src0_mode == STP_SRC_NEAREST2X; a.coff = 0;
+  int rc = p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C0, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C0, p->Cout, blocks, s);
+  if (rc != STP_OK || p->C1 == 0) return rc;
+  a.src = (const char*)p->src1; a.Hs = p->Hv; a.Ws = p->Wv; a.up = 0; a.coff = p->C0;
+  return p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C1, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C1, p->Cout, blocks, s);
 }

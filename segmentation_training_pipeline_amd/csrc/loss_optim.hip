@@ -353,6 +353,78 @@ extern "C" int stp_weight_prepare(const float* master, void* fwd, void* bwd, int
   return STP_OK;
 }
 
+// All layers in one launch: desc[l] describes layer l, `start` is the running element count (fwd then bwd
+// elements of every layer); a thread finds its layer by binary search.  Same arithmetic as the
+// per-layer kernel above, 1 launch instead of ~50 per step.
+struct WeightPrepDesc {
+  const float* master;
+  void* fwd;
+  void* bwd;
+  int64_t start;      // first global element index of this layer
+  int32_t Cout, KH, KW, Cin, KWp, Cinp, CoutB, rows_f, rows_b, pad_;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prepare_batched_kernel(const WeightPrepDesc* __restrict__ desc, int nlayers, int64_t total) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = nlayers - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (desc[mid].start <= g) lo = mid; else hi = mid - 1;
+    }
+    const WeightPrepDesc d = desc[lo];
+    const int64_t i = g - d.start;
+    const int64_t nf = d.fwd ? (int64_t)d.rows_f * d.KH * d.KWp * d.Cinp : 0;
+    if (i < nf) {
+      int64_t r = i;
+      const int ci = (int)(r % d.Cinp); r /= d.Cinp;
+      const int kw = (int)(r % d.KWp); r /= d.KWp;
+      const int kh = (int)(r % d.KH);
+      const int co = (int)(r / d.KH);
+      float v = 0.f;
+      if (co < d.Cout && kw < d.KW && ci < d.Cin) v = d.master[(((int64_t)co * d.KH + kh) * d.KW + kw) * d.Cin + ci];
+      Elem<T>::store(reinterpret_cast<T*>(d.fwd) + i, v);
+    } else {
+      int64_t r = i - nf;
+      const int co = (int)(r % d.CoutB); r /= d.CoutB;
+      const int kw = (int)(r % d.KW); r /= d.KW;
+      const int kh = (int)(r % d.KH);
+      const int ci = (int)(r / d.KH);
+      float v = 0.f;
+      if (co < d.Cout && ci < d.Cin) v = d.master[(((int64_t)co * d.KH + (d.KH - 1 - kh)) * d.KW + (d.KW - 1 - kw)) * d.Cin + ci];
+      Elem<T>::store(reinterpret_cast<T*>(d.bwd) + (i - nf), v);
+    }
+  }
+}
+
+extern "C" size_t stp_weight_prepare_desc_bytes(void) { return sizeof(WeightPrepDesc); }
+
+// Fills one host-side descriptor (the caller uploads the array to the device); returns the element count.
+extern "C" int64_t stp_weight_prepare_desc_fill(void* desc_host, int32_t index, int64_t start, const float* master, void* fwd,
+                                                void* bwd, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, int32_t KWp,
+                                                int32_t Cinp, int32_t CoutB) {
+  WeightPrepDesc* d = reinterpret_cast<WeightPrepDesc*>(desc_host) + index;
+  d->master = master; d->fwd = fwd; d->bwd = bwd; d->start = start;
+  d->Cout = Cout; d->KH = KH; d->KW = KW; d->Cin = Cin; d->KWp = KWp; d->Cinp = Cinp; d->CoutB = CoutB;
+  d->rows_f = round_up(Cout, 16); d->rows_b = round_up(Cin, 16); d->pad_ = 0;
+  return (fwd ? (int64_t)d->rows_f * KH * KWp * Cinp : 0) + (bwd ? (int64_t)d->rows_b * KH * KW * CoutB : 0);
+}
+
+extern "C" int stp_weight_prepare_batched(const void* desc_dev, int32_t nlayers, int64_t total, int32_t dtype, void* stream) {
+  if (!desc_dev || nlayers <= 0 || total <= 0) return STP_E_BADARG;
+  int64_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(weight_prepare_batched_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(weight_prepare_batched_kernel<float>, dim3((int)g), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // padded gradient [CoutP][KH][KWp][Cinp] -> master layout [Cout][KH][KW][Cin]
 __global__ void weight_grad_unpad_kernel(const float* __restrict__ padded, float* __restrict__ grad, int Cout, int KH, int KW,
                                          int Cin, int KWp, int Cinp, int accumulate) {

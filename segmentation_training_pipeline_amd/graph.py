@@ -80,6 +80,7 @@ class Plan(object):
         self.P = self.G = self.S = None
         self.prep, self.fwd, self.bwd, self.opt = [], [], [], []
         self._tape = []
+        self._prep_layers = []
         self._wg_ws_bytes = 0
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
@@ -109,13 +110,29 @@ class Plan(object):
         self.ws_loss = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
         self.dry = False
         self._tape = []
+        self._prep_layers = []
         self.tensors = OrderedDict()
         net_fn(self)
+        self._finish_prep()
         if self.training:
             for back in reversed(self._tape):
                 back()
         self._tape = []
         return self
+
+    def _finish_prep(self):
+        """One batched weight-preparation launch for all conv layers (descriptor table lives on the device)."""
+        n = len(self._prep_layers)
+        if not n:
+            return
+        dsz = int(self.lib.stp_weight_prepare_desc_bytes())
+        host = (C.c_char * (dsz * n))()
+        total = 0
+        for i, lay in enumerate(self._prep_layers):
+            total += int(self.lib.stp_weight_prepare_desc_fill(C.cast(host, C.c_void_p), i, total, *lay))
+        dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
+        self._keep.append(dev)
+        self._emit(self.prep, "stp_weight_prepare_batched", dev.data_ptr(), n, total, self.cdt)
 
     # ------------------------------------------------------------------ parameters / state
     def param(self, name, shape, kind="weight"):
@@ -281,8 +298,9 @@ class Plan(object):
         wf = self._alloc((rows_f * k * KWp * Cinp,))
         need_dgrad = self.training and (x_ng or s_ng) and not stem
         wb = self._alloc((rows_b * k * k * CoutB,)) if need_dgrad else None
-        self._emit(self.prep, "stp_weight_prepare", self._pptr(w), wf.data_ptr(), wb.data_ptr() if wb is not None else None,
-                   Cout, k, k, Cin_master, KWp, Cinp, CoutB, self.cdt)
+        # collected here, issued as ONE batched launch per step (see _finish_prep)
+        self._prep_layers.append((self._pptr(w), wf.data_ptr(), wb.data_ptr() if wb is not None else None,
+                                  Cout, k, k, Cin_master, KWp, Cinp, CoutB))
         p = ops.conv_params(x.buf, wf, out.buf, N=self.N, Hs0=x.H, Ws0=x.W, Hv=Hv, Wv=Wv, C0=C0, C1=C1,
                             src1=src1.buf if src1 is not None else None,
                             mode=ops.SRC_NEAREST2X if upsample else ops.SRC_DIRECT, KH=k, KW=KWp, stride=stride, pad=pad,

@@ -295,9 +295,11 @@ def test_conv2d_weight_gradient(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_conv2d_weight_gradient_upsample_concat(ops, dtype):
+@pytest.mark.parametrize("chans", [(32, 16, 64), (64, 64, 32), (32, 16, 16)])
+def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
     rng = np.random.RandomState(9)
-    n, h, w, c0, c1, co = 2, 6, 7, 32, 16, 64
+    n, h, w = 2, 6, 7
+    c0, c1, co = chans            # (64, 64, 32) = decoder_stage3_conv1: the small-channel kernel, one launch per source
     x = q(rng.randn(n, h, w, c0), dtype)
     skip = q(rng.randn(n, 2 * h, 2 * w, c1), dtype)
     dy = q(rng.randn(n, 2 * h, 2 * w, co), dtype)
