@@ -76,9 +76,15 @@ typedef struct stp_conv_params {
   int32_t accumulate0, accumulate1, relu;
   int32_t dtype;        /* STP_F32 / STP_BF16                   */
   int32_t tile;         /* 0 = auto; else forces a tile config (testing/tuning) */
+  int32_t stats_tiles;  /* OUT (written by stp_conv2d when stats_partial != NULL): number of pixel tiles */
+  float* stats_partial; /* optional [2][Cout][pixel tiles] fp32: per-tile sum / sum of squares of the stored
+                           output per channel (fused BatchNormalization statistics, finalize with
+                           stp_bn_finalize); capacity >= stp_conv2d_stats_floats(p) floats */
 } stp_conv_params;
 
 int stp_conv2d(const stp_conv_params* p, void* stream);
+/* floats needed by stats_partial for this shape (tile choice included) */
+size_t stp_conv2d_stats_floats(const stp_conv_params* p);
 /* tile configuration stp_conv2d would pick for p (see conv_igemm.hip: 1..6 register-staged tiles, 32*STAGES+t
  * uniform-tap DMA tiles, 256+t per-lane-tap DMA tiles, 512 small-channel kernel); used by bench.py. */
 int stp_conv2d_tile_for(const stp_conv_params* p);
@@ -161,6 +167,9 @@ size_t stp_bn_workspace_bytes(int32_t C);
 int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t C, float eps, float momentum,
                  float* mean, float* rstd, float* moving_mean, float* moving_var,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* second half of stp_bn_stats for statistics produced by a convolution epilogue (stats_partial) */
+int stp_bn_finalize(const float* partial, int32_t tiles, int64_t rows, int32_t C, float eps, float momentum,
+                    float* mean, float* rstd, float* moving_mean, float* moving_var, void* stream);
 int stp_bn_apply(const void* x, int32_t xdtype, void* y, int32_t ydtype, int64_t rows, int32_t C, int32_t Cy,
                  const float* mean, const float* rstd, const float* gamma, const float* beta,
                  int32_t relu, float pad_value, void* stream);

@@ -25,7 +25,8 @@ class ConvParams(C.Structure):
                 ("N", i32), ("Hs0", i32), ("Ws0", i32), ("Hv", i32), ("Wv", i32), ("C0", i32), ("C1", i32),
                 ("src0_mode", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("Cd0", i32),
-                ("accumulate0", i32), ("accumulate1", i32), ("relu", i32), ("dtype", i32), ("tile", i32)]
+                ("accumulate0", i32), ("accumulate1", i32), ("relu", i32), ("dtype", i32), ("tile", i32),
+                ("stats_tiles", i32), ("stats_partial", vp)]
 
 
 class WgradParams(C.Structure):
@@ -39,6 +40,7 @@ class WgradParams(C.Structure):
 SIGNATURES = {
     "stp_abi_version": (i32, []),
     "stp_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "stp_conv2d_stats_floats": (sz, [C.POINTER(ConvParams)]),
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc": (i32, [C.POINTER(ConvParams), vp]),
@@ -57,6 +59,7 @@ SIGNATURES = {
     "stp_stem_beta_grad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_bn_workspace_bytes": (sz, [i32]),
     "stp_bn_stats": (i32, [vp, i32, i64, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "stp_bn_finalize": (i32, [vp, i32, i64, i32, f32, f32, vp, vp, vp, vp, vp]),
     "stp_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, vp, i32, f32, vp]),
     "stp_bn_inference": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, f32, vp]),
     "stp_bn_backward": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),

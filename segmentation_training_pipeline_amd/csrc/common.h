@@ -67,6 +67,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sum over each aligned group of 16 lanes (a DPP "row") with 4 v_add_f32 row_shr: the total lands in lane 15
+// of the row (other lanes hold partial prefix sums).  No LDS traffic (unlike __shfl_xor -> ds_bpermute).
+__device__ __forceinline__ float row_sum16_to_lane15(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+  return v;
+}
+
 // Exact unsigned 32-bit division by a runtime constant (round-up method, Granlund-Montgomery):
 // l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, q = (t + ((n - t) >> 1)) >> (l - 1), t = mulhi(m, n).
 struct FastDiv {

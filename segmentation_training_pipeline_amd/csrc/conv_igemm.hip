@@ -39,6 +39,7 @@ struct ConvArgs {
   int K, P, HoWo, wrows;
   int ntile_m, ntile_n;
   uint32_t bytes0, bytes1, bytesw;
+  float* stats;  // optional [2][Cout][ntile_n]
   FastDiv divC, divKW;
 };
 
@@ -95,47 +96,91 @@ __device__ __forceinline__ void compute_tile(const char* stage, int wm, int wn, 
   }
 }
 
-// bias, residual, ReLU, dual destination, optional accumulate
+// value as it will be read back from memory (the BatchNorm that follows normalises the STORED tensor)
+__device__ __forceinline__ f32x4 stored(f32x4 v, const float*) { return v; }
+__device__ __forceinline__ f32x4 stored(f32x4 v, const bf16_t*) {
+  const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+}
+
+// bias, residual, ReLU, dual destination, optional accumulate, optional fused BatchNormalization statistics.
+//
+// Statistics: per-channel sum and sum of squares (of the values as STORED) over this workgroup's pixels.  The
+// 16 lanes of a DPP row hold 16 different pixels of the same 4 channels -> row reduction with DPP adds, then
+// the WN waves that share the channels are combined through LDS in a fixed order.  Layout written:
+// stats[stat][channel][tile] (tile index contiguous, so the finalize reads coalesced).  The channel-tile loop
+// is the OUTER loop so that only one pair of accumulators is live at a time (register pressure).
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0, int wm, int wn, int lr, int lg,
-                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int tile_n) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   const T* res = reinterpret_cast<const T*>(a.residual);
+  float* red = reinterpret_cast<float*>(smem);  // [WN][BM][2], valid after the barrier below
+  if (a.stats) __syncthreads();                 // the K-loop's LDS tiles are dead from here on
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
-    if (pm >= a.P) continue;
+  for (int i = 0; i < TM; ++i) {
+    const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+    f32x4 ss = {0.f, 0.f, 0.f, 0.f}, qq = {0.f, 0.f, 0.f, 0.f};
+    if (co < a.Cout) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
-      if (co >= a.Cout) continue;
-      f32x4 v = acc[i][j];
-      if (co + 3 < a.Cout) {
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
-        if (res) v += load4(res + (size_t)pm * a.Cout + co);
-        T* d;
-        bool accum;
-        if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
-        else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
-        if (accum) v += load4(d);
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        store4(d, v);
-      } else {
-        // ragged channel tail (e.g. the 1-class head): scalar path
-        for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
-          const int c1 = co + r;
-          float x = v[r];
-          if (a.bias) x += a.bias[c1];
-          if (res) x += Elem<T>::load(res + (size_t)pm * a.Cout + c1);
+      for (int j = 0; j < TN; ++j) {
+        const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
+        if (pm >= a.P) continue;
+        f32x4 v = acc[i][j];
+        if (co + 3 < a.Cout) {
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+          if (res) v += load4(res + (size_t)pm * a.Cout + co);
           T* d;
           bool accum;
-          if (c1 < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + c1; accum = a.acc0; }
-          else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (c1 - a.Cd0); accum = a.acc1; }
-          if (accum) x += Elem<T>::load(d);
-          if (a.relu) x = fmaxf(x, 0.f);
-          Elem<T>::store(d, x);
+          if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
+          else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
+          if (accum) v += load4(d);
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          store4(d, v);
+          if (a.stats) {
+            const f32x4 sv = stored(v, (const T*)nullptr);
+            ss += sv;
+            qq += sv * sv;
+          }
+        } else {
+          // ragged channel tail (e.g. the 1-class head): scalar path
+          for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
+            const int c1 = co + r;
+            float x = v[r];
+            if (a.bias) x += a.bias[c1];
+            if (res) x += Elem<T>::load(res + (size_t)pm * a.Cout + c1);
+            T* d;
+            bool accum;
+            if (c1 < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + c1; accum = a.acc0; }
+            else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (c1 - a.Cd0); accum = a.acc1; }
+            if (accum) x += Elem<T>::load(d);
+            if (a.relu) x = fmaxf(x, 0.f);
+            Elem<T>::store(d, x);
+          }
         }
       }
+    }
+    if (a.stats) {  // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = row_sum16_to_lane15(ss[e]), q = row_sum16_to_lane15(qq[e]);
+        if (lr == 15) {
+          const int cl = wm * (BM / WM) + i * 16 + lg * 4 + e;
+          red[(wn * BM + cl) * 2] = s;
+          red[(wn * BM + cl) * 2 + 1] = q;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < BM; c += 256) {
+      if (cout0 + c >= a.Cout) continue;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) { s += red[(w * BM + c) * 2]; q += red[(w * BM + c) * 2 + 1]; }
+      a.stats[(size_t)(cout0 + c) * a.ntile_n + tile_n] = s;
+      a.stats[((size_t)a.Cout + cout0 + c) * a.ntile_n + tile_n] = q;
     }
   }
 }
@@ -286,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }
-  epilogue<T, BM, BN, WM, WN>(a, cout0, pix0, wm, wn, lr, lg, acc);
+  epilogue<T, BM, BN, WM, WN>(a, cout0, pix0, wm, wn, lr, lg, acc, smem, tile_n);
 #endif
 }
 
@@ -430,7 +475,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
   }
-  epilogue<T, BM, BN, WM, WN>(a, cout0, pix0, wm, wn, lr, lg, acc);
+  epilogue<T, BM, BN, WM, WN>(a, cout0, pix0, wm, wn, lr, lg, acc, smem, tile_n);
 }
 
 // ================================================================================================
@@ -564,6 +609,8 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* u
   const int64_t bw = (int64_t)a.wrows * a.K * sz;
   a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
   a.ntile_m = a.ntile_n = 0;
+  a.stats = p->stats_partial;
+  if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;
   *c4_out = c4;
   *ut_out = 0;
   if (!c4 && b0 < lim && b1 < lim && bw < lim) {
@@ -571,6 +618,12 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* u
     else if (a.C1 == 0 && (ke % a.Ctot == 0)) *ut_out = 2;
   }
   return STP_OK;
+}
+
+static int tile_pixels(int tile) {
+  if (tile == 512) return 256;
+  const int t = tile >= 256 ? tile - 256 : tile % 32;
+  return (t == 2 || t == 3 || t == 4) ? 256 : (t == 1 ? 128 : 64);
 }
 
 extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p);
@@ -590,6 +643,13 @@ extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
   return tile;
 }
 
+extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
+  const int tile = stp_conv2d_tile_for(p);
+  if (tile < 0) return 0;
+  if (tile == STP_TILE_SC) return (size_t)p->N * ceil_div(p->Hv, 8) * ceil_div(p->Wv, 32) * 2 * p->Cout;
+  return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
+}
+
 extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SC)) {
     if (stp_conv2d_sc_eligible(p)) return stp_conv2d_sc(p, stream);
@@ -603,6 +663,7 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   int tile = p->tile ? p->tile : auto_tile(a, ut);
   if (c4 && tile != 2 && tile != 5) tile = 2;
   hipStream_t s = (hipStream_t)stream;
+  const_cast<stp_conv_params*>(p)->stats_tiles = ceil_div(a.P, tile_pixels(tile));
   if (p->dtype == STP_BF16) return c4 ? launch_tile<bf16_t, true>(a, tile, ut, s) : launch_tile<bf16_t, false>(a, tile, ut, s);
   return launch_tile<float, false>(a, tile, ut, s);
 }

@@ -21,7 +21,14 @@ struct ScArgs {
   char* dst;           // [N,H,W,Cout]
   int N, H, W, Hs, Ws, Cout, up, accumulate, relu;
   int tiles_x, tiles_y;
+  float* stats;        // optional fused BatchNorm statistics [2][Cout][tiles]
 };
+
+__device__ __forceinline__ f32x4 sc_stored(f32x4 v, const float*) { return v; }
+__device__ __forceinline__ f32x4 sc_stored(f32x4 v, const bf16_t*) {
+  const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+}
 
 template <typename T> struct ScMma;
 template <> struct ScMma<bf16_t> {
@@ -113,6 +120,9 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
 
   // ---- epilogue -----------------------------------------------------------------------------------
   T* out = reinterpret_cast<T*>(a.dst);
+  f32x4 ss[TM], qq[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
@@ -129,6 +139,11 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
         if (a.accumulate) v += load4(d);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         store4(d, v);
+        if (a.stats) {
+          const f32x4 sv = sc_stored(v, (const T*)nullptr);
+          ss[i] += sv;
+          qq[i] += sv * sv;
+        }
       } else {
         for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
           float x = v[r];
@@ -139,6 +154,30 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
           Elem<T>::store(d, x);
         }
       }
+    }
+  }
+  if (a.stats) {
+    // butterfly over the 16 pixel lanes, then the 4 waves (same channels, different rows) through LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(halo);  // [4][TM*16][2]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = row_sum16_to_lane15(ss[i][e]), qv = row_sum16_to_lane15(qq[i][e]);
+        if (lr == 15) {
+          const int cl = i * 16 + lg * 4 + e;
+          red[(wave * TM * 16 + cl) * 2] = sv;
+          red[(wave * TM * 16 + cl) * 2 + 1] = qv;
+        }
+      }
+    __syncthreads();
+    if (tid < TM * 16 && tid < a.Cout) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { sv += red[(w * TM * 16 + tid) * 2]; qv += red[(w * TM * 16 + tid) * 2 + 1]; }
+      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][tile]
+      a.stats[((size_t)a.Cout + tid) * gridDim.x + blockIdx.x] = qv;
     }
   }
 }
@@ -186,6 +225,9 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
   a.up = p->src0_mode == STP_SRC_NEAREST2X; a.accumulate = p->accumulate0; a.relu = p->relu;
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
+  a.stats = p->stats_partial;
+  if (a.stats && (p->Cout & 3)) return STP_E_BADARG;
+  const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
   hipStream_t s = (hipStream_t)stream;
   return p->dtype == STP_BF16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);
 }

@@ -240,8 +240,15 @@ class Plan(object):
                        self._sptr(mm), self._sptr(mv), eps, gp, self._pptr(beta), int(relu), 0.0)
             return out
         mean, rstd = self._alloc((Cn,), torch.float32), self._alloc((Cn,), torch.float32)
-        self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), self.cdt, x.rows, Cn, eps, self.bn_momentum, mean.data_ptr(),
-                   rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
+        fused = x.meta.get("stats")
+        if fused is not None:
+            st, cp = fused
+            tiles = int(self.lib.stp_conv2d_stats_floats(C.byref(cp))) // (2 * Cn)
+            self._emit(self.fwd, "stp_bn_finalize", st.data_ptr(), tiles, x.rows, Cn, eps, self.bn_momentum, mean.data_ptr(),
+                       rstd.data_ptr(), self._sptr(mm), self._sptr(mv))
+        else:
+            self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), self.cdt, x.rows, Cn, eps, self.bn_momentum, mean.data_ptr(),
+                       rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
         self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
                    mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu), 0.0)
 
@@ -260,7 +267,7 @@ class Plan(object):
         self._tape.append(back)
         return out
 
-    def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None):
+    def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False):
         """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
         ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add()."""
         real_c0 = x.meta.get("real_c", x.C)
@@ -307,6 +314,12 @@ class Plan(object):
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
         if b is not None:
             p.bias = self._pptr(b)
+        if bn_stats and self.training:
+            # the BatchNormalization that follows takes its batch statistics from this conv's epilogue
+            nfl = int(self.lib.stp_conv2d_stats_floats(C.byref(p)))
+            st = self._alloc((max(nfl, 4),), torch.float32)
+            p.stats_partial = st.data_ptr()
+            out.meta["stats"] = (st, p)
         # algorithmic work of this layer: 2 * pixels * Cout * KH*KW*Cin with the REAL (unpadded) dims
         flops = 2.0 * self.N * Ho * Wo * Cout * k * k * Cin_master
         self._emit_conv(self.fwd, p, {"layer": name, "pass": "fwd", "flops": flops, "tile": int(self.lib.stp_conv2d_tile_for(C.byref(p)))})

@@ -10,6 +10,7 @@ Fusions expressed here (none changes the arithmetic of the Keras graph):
   * ZeroPadding2D + 'valid' conv            -> conv with symmetric pad
   * Add() after conv2                        -> residual operand of the conv epilogue
   * UpSampling2D(2) + Concatenate + conv     -> one conv with a two-source gather
+  * batch statistics of a BatchNormalization -> reduced in the epilogue of the conv that feeds it (bn_stats=True)
 """
 
 RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
@@ -32,7 +33,7 @@ def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 
     units = RESNET_UNITS[backbone]
     img = plan.input_u8("image", H, W, in_ch)
     x = plan.input_bn("bn_data", img, BN_EPS_ENCODER)
-    x = plan.conv("conv0", x, 64, 7, stride=2, pad=3)
+    x = plan.conv("conv0", x, 64, 7, stride=2, pad=3, bn_stats=True)
     relu0 = x = plan.bn("bn0", x, BN_EPS_ENCODER, relu=True)
     x = plan.maxpool("pooling0", x)
     taps = {}
@@ -46,16 +47,16 @@ def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 
                 shortcut = plan.conv(pre + "sc", a, f, 1, stride=stride, pad=0)
             else:
                 shortcut = x
-            y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1)
+            y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1, bn_stats=True)
             y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
-            x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut)
+            x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut, bn_stats=True)
     x = plan.bn("bn1", x, BN_EPS_ENCODER, relu=True)
     skips = (taps[4], taps[3], taps[2], relu0, None)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
-        x = plan.conv(pre + "conv1", x, f, 3, pad=1, src1=skips[i], upsample=True)
+        x = plan.conv(pre + "conv1", x, f, 3, pad=1, src1=skips[i], upsample=True, bn_stats=True)
         x = plan.bn(pre + "bn1", x, BN_EPS_DECODER, relu=True)
-        x = plan.conv(pre + "conv2", x, f, 3, pad=1)
+        x = plan.conv(pre + "conv2", x, f, 3, pad=1, bn_stats=True)
         x = plan.bn(pre + "bn2", x, BN_EPS_DECODER, relu=True)
     logits = plan.conv("final_conv", x, classes, 3, pad=1, bias=True)
     if with_loss:

@@ -145,7 +145,9 @@ def test_plan_structure_matches_unet_resnet34():
     kernels = sum(i.numel for i in plan.params.values() if i.kind == "kernel")
     assert kernels == 24421456                                         # same count as the oracle graph
     names = [n for _, _, n, _ in plan.fwd]
-    assert names.count("stp_conv2d") == 48 and names.count("stp_bn_stats") == 45
+    # the raw-image BN and the BN after the max-pool reduce on their own; the other 43 take their batch
+    # statistics from the epilogue of the conv that produces their input
+    assert names.count("stp_conv2d") == 48 and names.count("stp_bn_stats") == 2 and names.count("stp_bn_finalize") == 43
     bnames = [n for _, _, n, _ in plan.bwd]
     assert bnames.count("stp_conv2d_wgrad") == 48 and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
     assert bnames.count("stp_conv2d_wgrad_reduce") == 48
