@@ -208,19 +208,25 @@ extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t
 
 // Finalize for statistics produced by a convolution epilogue: partial is [2][C][tiles] (tile contiguous).
 // One wave per channel: coalesced strided walk + wave reduction, fixed order.
-__global__ __launch_bounds__(64) void bn_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, double inv_rows,
-                                                               double unbias, float eps, float momentum, float* mean, float* rstd,
-                                                               float* mm, float* mv) {
+__global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, double inv_rows,
+                                                                double unbias, float eps, float momentum, float* mean, float* rstd,
+                                                                float* mm, float* mv) {
+  __shared__ double sh[2][256];
   const int c = blockIdx.x;
   const float* ps = partial + (size_t)c * tiles;
   const float* pq = partial + ((size_t)C + c) * tiles;
   double s = 0.0, q = 0.0;
-  for (int t = threadIdx.x; t < tiles; t += 64) { s += (double)ps[t]; q += (double)pq[t]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  for (int t = threadIdx.x; t < tiles; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
+    __syncthreads();
+  }
   if (threadIdx.x != 0) return;
-  const double m = s * inv_rows;
-  double var = q * inv_rows - m * m;
+  const double m = sh[0][0] * inv_rows;
+  double var = sh[1][0] * inv_rows - m * m;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -232,7 +238,7 @@ extern "C" int stp_bn_finalize(const float* partial, int32_t tiles, int64_t rows
                                float* rstd, float* moving_mean, float* moving_var, void* stream) {
   if (!partial || !mean || !rstd || tiles <= 0 || rows <= 0 || C <= 0) return STP_E_BADARG;
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, tiles, C, 1.0 / (double)rows,
+  hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, tiles, C, 1.0 / (double)rows,
                      unbias, eps, momentum, mean, rstd, moving_mean, moving_var);
   STP_LAUNCH_CHECK();
   return STP_OK;

@@ -82,7 +82,7 @@ __device__ __forceinline__ float row_sum16_to_lane15(float v) {
 struct FastDiv {
   uint32_t d, magic, shift;
 };
-static inline FastDiv make_fastdiv(uint32_t d) {
+__host__ __device__ static inline FastDiv make_fastdiv(uint32_t d) {
   FastDiv f;
   f.d = d;
   f.magic = 0;

@@ -546,6 +546,9 @@ static int launch_tile(ConvArgs& a, int tile, int ut_ok, hipStream_t s) {
       case 256 + 2: return launch_ut<T, 64, 256, 1, 4, 2, false>(a, s);
       case 256 + 3: return launch_ut<T, 32, 256, 1, 4, 2, false>(a, s);
       case 256 + 4: return launch_ut<T, 16, 256, 1, 4, 2, false>(a, s);
+      case 256 + 1: return launch_ut<T, 128, 128, 2, 2, 2, false>(a, s);
+      case 256 + 5: return launch_ut<T, 64, 64, 2, 2, 2, false>(a, s);
+      case 256 + 6: return launch_ut<T, 128, 64, 4, 1, 2, false>(a, s);
       default: return STP_E_BADARG;
     }
   }
@@ -569,6 +572,11 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
     if (big >= 384) return 64 + 1;
     if (mid >= 384) return 64 + 6;
     return 128 + 5;
+  }
+  if (ut_ok == 2) {
+    if (big >= 384) return 256 + 1;
+    if (mid >= 384) return 256 + 6;
+    return 256 + 5;
   }
   if (big >= 384) return 1;
   if (mid >= 384) return 6;

@@ -364,32 +364,33 @@ struct WeightPrepDesc {
   int32_t Cout, KH, KW, Cin, KWp, Cinp, CoutB, rows_f, rows_b, pad_;
 };
 
+// grid.y = layer, grid.x strides over that layer's elements.  The fwd copy is a row-wise copy with padding
+// (consecutive threads -> consecutive output elements -> coalesced reads of the master for Cinp == Cin);
+// the bwd copy is a transpose, done through the same index arithmetic (its reads are strided but the whole
+// master arena is only ~100 MB and L2/MALL resident).
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prepare_batched_kernel(const WeightPrepDesc* __restrict__ desc, int nlayers, int64_t total) {
-  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
-    int lo = 0, hi = nlayers - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (desc[mid].start <= g) lo = mid; else hi = mid - 1;
-    }
-    const WeightPrepDesc d = desc[lo];
-    const int64_t i = g - d.start;
-    const int64_t nf = d.fwd ? (int64_t)d.rows_f * d.KH * d.KWp * d.Cinp : 0;
+  const WeightPrepDesc d = desc[blockIdx.y];
+  const int64_t nf = d.fwd ? (int64_t)d.rows_f * d.KH * d.KWp * d.Cinp : 0;
+  const int64_t nb = d.bwd ? (int64_t)d.rows_b * d.KH * d.KW * d.CoutB : 0;
+  const FastDiv dCinp = make_fastdiv((uint32_t)d.Cinp), dKWp = make_fastdiv((uint32_t)d.KWp), dKH = make_fastdiv((uint32_t)d.KH);
+  const FastDiv dCoutB = make_fastdiv((uint32_t)d.CoutB), dKW = make_fastdiv((uint32_t)d.KW);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * 256) {
     if (i < nf) {
-      int64_t r = i;
-      const int ci = (int)(r % d.Cinp); r /= d.Cinp;
-      const int kw = (int)(r % d.KWp); r /= d.KWp;
-      const int kh = (int)(r % d.KH);
-      const int co = (int)(r / d.KH);
+      uint32_t r = (uint32_t)i, t;
+      t = fdiv(r, dCinp); const int ci = (int)(r - t * d.Cinp); r = t;
+      t = fdiv(r, dKWp); const int kw = (int)(r - t * d.KWp); r = t;
+      t = fdiv(r, dKH); const int kh = (int)(r - t * d.KH);
+      const int co = (int)t;
       float v = 0.f;
       if (co < d.Cout && kw < d.KW && ci < d.Cin) v = d.master[(((int64_t)co * d.KH + kh) * d.KW + kw) * d.Cin + ci];
       Elem<T>::store(reinterpret_cast<T*>(d.fwd) + i, v);
     } else {
-      int64_t r = i - nf;
-      const int co = (int)(r % d.CoutB); r /= d.CoutB;
-      const int kw = (int)(r % d.KW); r /= d.KW;
-      const int kh = (int)(r % d.KH);
-      const int ci = (int)(r / d.KH);
+      uint32_t r = (uint32_t)(i - nf), t;
+      t = fdiv(r, dCoutB); const int co = (int)(r - t * d.CoutB); r = t;
+      t = fdiv(r, dKW); const int kw = (int)(r - t * d.KW); r = t;
+      t = fdiv(r, dKH); const int kh = (int)(r - t * d.KH);
+      const int ci = (int)t;
       float v = 0.f;
       if (co < d.Cout && ci < d.Cin) v = d.master[(((int64_t)co * d.KH + (d.KH - 1 - kh)) * d.KW + (d.KW - 1 - kw)) * d.Cin + ci];
       Elem<T>::store(reinterpret_cast<T*>(d.bwd) + (i - nf), v);
@@ -412,13 +413,12 @@ extern "C" int64_t stp_weight_prepare_desc_fill(void* desc_host, int32_t index, 
 
 extern "C" int stp_weight_prepare_batched(const void* desc_dev, int32_t nlayers, int64_t total, int32_t dtype, void* stream) {
   if (!desc_dev || nlayers <= 0 || total <= 0) return STP_E_BADARG;
-  int64_t g = (total + 255) / 256;
-  if (g > 8192) g = 8192;
+  // 64 workgroups per layer: the big layers (9.4 MB) grid-stride, the small ones finish at once
   hipStream_t s = (hipStream_t)stream;
   if (dtype == STP_BF16)
-    hipLaunchKernelGGL(weight_prepare_batched_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
+    hipLaunchKernelGGL(weight_prepare_batched_kernel<bf16_t>, dim3(64, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(weight_prepare_batched_kernel<float>, dim3((int)g), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
+    hipLaunchKernelGGL(weight_prepare_batched_kernel<float>, dim3(64, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();

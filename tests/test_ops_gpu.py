@@ -106,6 +106,7 @@ CONV_CASES = [
     # small-channel halo-tile kernel (tile 512) incl. ragged tiles, and the GEMM path forced for the same shapes
     (2, 19, 45, 16, 16, 3, 1, 1, 512), (1, 8, 32, 32, 32, 3, 1, 1, 512), (2, 21, 33, 8, 16, 3, 1, 1, 512),
     (2, 19, 45, 16, 32, 3, 1, 1, 512), (2, 19, 45, 16, 16, 3, 1, 1, 260), (1, 40, 70, 32, 24, 3, 1, 1, 0),
+    (2, 16, 16, 32, 128, 3, 1, 1, 257), (2, 16, 16, 32, 128, 3, 1, 1, 262), (2, 9, 11, 16, 64, 3, 1, 1, 261),
 ]
 
 
