@@ -80,6 +80,17 @@ typedef struct stp_conv_params {
   float* stats_partial; /* optional [2][Cout][pixel tiles] fp32: per-tile sum / sum of squares of the stored
                            output per channel (fused BatchNormalization statistics, finalize with
                            stp_bn_finalize); capacity >= stp_conv2d_stats_floats(p) floats */
+  /* BatchNormalization-backward fusion for a data-gradient convolution whose destination is dY of a BN(+ReLU)
+   * output with this convolution as its only consumer: with bnb_x != NULL (the BN INPUT, [N,Ho,Wo,Cout] dtype)
+   * the epilogue stores g = dY * [bn(x) > 0] (g = dY when bnb_relu == 0) instead of dY and writes
+   * stats_partial = per-tile sum(g) / sum(g * xhat) per channel; finish with stp_bn_backward_fused.  Requires
+   * stats_partial, Cd0 == Cout, Cout % 4 == 0, no accumulate / relu / residual. */
+  const void* bnb_x;
+  const float* bnb_mean;
+  const float* bnb_rstd;
+  const float* bnb_gamma; /* NULL: scale=False */
+  const float* bnb_beta;  /* NULL: center=False */
+  int32_t bnb_relu;
 } stp_conv_params;
 
 int stp_conv2d(const stp_conv_params* p, void* stream);
@@ -164,6 +175,12 @@ int stp_stem_beta_grad(const float* padded_dw, const float* master, float* dbeta
  */
 #define STP_U8 2
 size_t stp_bn_workspace_bytes(int32_t C);
+/* second half of stp_bn_backward when the partial sums came from a convolution epilogue (stp_conv_params.bnb_x):
+ * g is the masked gradient that epilogue stored, partial its [2][C][tiles] sums. */
+int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C,
+                          const float* mean, const float* rstd, const float* gamma, const float* partial, int32_t tiles,
+                          float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
+                          void* stream);
 int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t C, float eps, float momentum,
                  float* mean, float* rstd, float* moving_mean, float* moving_var,
                  void* workspace, size_t workspace_bytes, void* stream);

@@ -26,7 +26,8 @@ class ConvParams(C.Structure):
                 ("src0_mode", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("Cd0", i32),
                 ("accumulate0", i32), ("accumulate1", i32), ("relu", i32), ("dtype", i32), ("tile", i32),
-                ("stats_tiles", i32), ("stats_partial", vp)]
+                ("stats_tiles", i32), ("stats_partial", vp),
+                ("bnb_x", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_gamma", vp), ("bnb_beta", vp), ("bnb_relu", i32)]
 
 
 class WgradParams(C.Structure):
@@ -63,6 +64,7 @@ SIGNATURES = {
     "stp_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, vp, i32, f32, vp]),
     "stp_bn_inference": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, f32, vp]),
     "stp_bn_backward": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+    "stp_bn_backward_fused": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "stp_maxpool3x3s2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_upsample2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

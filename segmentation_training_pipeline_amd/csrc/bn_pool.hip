@@ -6,9 +6,6 @@
 
 #define BN_MAX_BLOCKS 1024
 
-// x*scale + shift exactly as the forward computed it: the backward re-derives the ReLU mask
-// from this expression, so both sides must round identically (single fma).
-__device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return fmaf(x, scale, shift); }
 
 template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
 template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return load4(p); }
@@ -517,6 +514,59 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(g), dim3(256), lds2, s, (const float*)x, (const float*)dy, (float*)dx,
                        rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// [2][C][tiles] epilogue partials -> sums (same contract as bn_bwd_finalize_kernel); one workgroup per channel
+__global__ __launch_bounds__(256) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, float* sums,
+                                                                    float* dgamma, float* dbeta) {
+  __shared__ double sh[2][256];
+  const int c = blockIdx.x;
+  const float* ps = partial + (size_t)c * tiles;
+  const float* pq = partial + ((size_t)C + c) * tiles;
+  double s = 0.0, q = 0.0;
+  for (int t = threadIdx.x; t < tiles; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  sums[c] = (float)sh[0][0];
+  sums[C + c] = (float)sh[1][0];
+  if (dbeta) dbeta[c] = (float)sh[0][0];
+  if (dgamma) dgamma[c] = (float)sh[1][0];
+}
+
+extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C,
+                                     const float* mean, const float* rstd, const float* gamma, const float* partial,
+                                     int32_t tiles, float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (!x || !g || !dx || !mean || !rstd || !partial || !workspace || rows <= 0 || C <= 0 || (C & 3) || tiles <= 0) return STP_E_BADARG;
+  if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* sums = (float*)workspace + (size_t)(BN_MAX_BLOCKS - 1) * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(C), dim3(256), 0, s, partial, tiles, C, sums, dgamma, dbeta);
+  STP_LAUNCH_CHECK();
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const size_t lds2 = 6 * (size_t)C * sizeof(float);
+  const int gr = grid_for(rows * (C / (v8 ? 8 : 4)));
+  const float inv_rows = (float)(1.0 / (double)rows);
+  // the ReLU mask is already folded into g
+  if (v8)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g,
+                       (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g,
+                       (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(gr), dim3(256), lds2, s, (const float*)x, (const float*)g, (float*)dx,
+                       rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
+  else
+    return STP_E_BADARG;
   STP_LAUNCH_CHECK();
   return STP_OK;
 }

@@ -103,3 +103,42 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// x*scale + shift exactly as the BatchNormalization forward computed it: the backward passes re-derive the
+// ReLU mask from this expression, so every user must round identically (single fma).
+__device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return fmaf(x, scale, shift); }
+
+// BatchNormalization-backward partial sums fused into the epilogue of the data-gradient convolution that
+// produces dY of the BN output:  g = dY * [relu mask],  sum(g) and sum(g * xhat) per channel, g stored in
+// place of dY (see stp_conv_params.bnb_x).
+struct BnBack {
+  const char* x;  // BN input, same [pixels][C] layout and dtype as the convolution's destination
+  const float *mean, *rstd, *gamma, *beta;
+  int relu;
+};
+struct BnBackCh {  // per-lane constants of 4 consecutive channels
+  f32x4 sc, sh, mu, rs;
+};
+__device__ __forceinline__ BnBackCh bnback_load(const BnBack& b, int c) {
+  BnBackCh k;
+  k.mu = *reinterpret_cast<const f32x4*>(b.mean + c);
+  k.rs = *reinterpret_cast<const f32x4*>(b.rstd + c);
+  k.sc = b.gamma ? k.rs * *reinterpret_cast<const f32x4*>(b.gamma + c) : k.rs;
+  const f32x4 be = b.beta ? *reinterpret_cast<const f32x4*>(b.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) k.sh[e] = be[e] - k.mu[e] * k.sc[e];
+  return k;
+}
+// dy (as stored) -> masked g; accumulates the two sums
+__device__ __forceinline__ f32x4 bnback_apply(const BnBackCh& k, int relu, const f32x4& xv, const f32x4& dy, f32x4& ss, f32x4& qq) {
+  f32x4 g;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool on = !relu || bn_affine(xv[e], k.sc[e], k.sh[e]) > 0.f;
+    g[e] = on ? dy[e] : 0.f;
+    ss[e] += g[e];
+    qq[e] += g[e] * ((xv[e] - k.mu[e]) * k.rs[e]);
+  }
+  return g;
+}
+

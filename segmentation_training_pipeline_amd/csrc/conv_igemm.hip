@@ -40,6 +40,7 @@ struct ConvArgs {
   int ntile_m, ntile_n;
   uint32_t bytes0, bytes1, bytesw;
   float* stats;  // optional [2][Cout][ntile_n]
+  BnBack bnb;    // bnb.x != NULL: stats are the BatchNormalization-backward sums and dst receives the masked gradient
   FastDiv divC, divKW;
 };
 
@@ -122,6 +123,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
     const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
     f32x4 ss = {0.f, 0.f, 0.f, 0.f}, qq = {0.f, 0.f, 0.f, 0.f};
     if (co < a.Cout) {
+      BnBackCh bk;
+      if (a.bnb.x) bk = bnback_load(a.bnb, co);  // Cout % 4 == 0 in this mode
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
@@ -136,8 +139,12 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
           else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
           if (accum) v += load4(d);
           if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (a.bnb.x) {
+            const f32x4 xv = load4(reinterpret_cast<const T*>(a.bnb.x) + (size_t)pm * a.Cout + co);
+            v = bnback_apply(bk, a.bnb.relu, xv, stored(v, (const T*)nullptr), ss, qq);
+          }
           store4(d, v);
-          if (a.stats) {
+          if (a.stats && !a.bnb.x) {
             const f32x4 sv = stored(v, (const T*)nullptr);
             ss += sv;
             qq += sv * sv;
@@ -619,6 +626,8 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* u
   a.ntile_m = a.ntile_n = 0;
   a.stats = p->stats_partial;
   if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;
+  a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
+  a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
   *c4_out = c4;
   *ut_out = 0;
   if (!c4 && b0 < lim && b1 < lim && bw < lim) {
@@ -668,6 +677,8 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   int ut;
   const int rc = fill_args(p, a, &c4, &ut);
   if (rc != STP_OK) return rc;
+  // (checked here, not in fill_args: the sizing queries run before stats_partial is allocated)
+  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->accumulate0 || p->relu || p->residual)) return STP_E_BADARG;
   int tile = p->tile ? p->tile : auto_tile(a, ut);
   if (c4 && tile != 2 && tile != 5) tile = 2;
   hipStream_t s = (hipStream_t)stream;

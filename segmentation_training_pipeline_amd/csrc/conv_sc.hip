@@ -22,6 +22,7 @@ struct ScArgs {
   int N, H, W, Hs, Ws, Cout, up, accumulate, relu;
   int tiles_x, tiles_y;
   float* stats;        // optional fused BatchNorm statistics [2][Cout][tiles]
+  BnBack bnb;          // see stp_conv_params.bnb_x
 };
 
 __device__ __forceinline__ f32x4 sc_stored(f32x4 v, const float*) { return v; }
@@ -138,8 +139,13 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
         T* d = out + pm * a.Cout + co;
         if (a.accumulate) v += load4(d);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.bnb.x) {
+          const BnBackCh bk = bnback_load(a.bnb, co);
+          const f32x4 xv = load4(reinterpret_cast<const T*>(a.bnb.x) + pm * a.Cout + co);
+          v = bnback_apply(bk, a.bnb.relu, xv, sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
+        }
         store4(d, v);
-        if (a.stats) {
+        if (a.stats && !a.bnb.x) {
           const f32x4 sv = sc_stored(v, (const T*)nullptr);
           ss[i] += sv;
           qq[i] += sv * sv;
@@ -227,6 +233,9 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
   a.stats = p->stats_partial;
   if (a.stats && (p->Cout & 3)) return STP_E_BADARG;
+  a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
+  a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
+  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->accumulate0 || p->relu)) return STP_E_BADARG;
   const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
   hipStream_t s = (hipStream_t)stream;
   return p->dtype == STP_BF16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);

@@ -11,6 +11,7 @@ plan-time bookkeeping (first writer overwrites, later writers accumulate in the 
 PyTorch supplies device memory (``torch.empty``), the stream handle and - in ``distributed.py`` -
 the RCCL process group; all arithmetic happens in libstp_hip.so.
 """
+import os
 import ctypes as C
 from collections import OrderedDict
 
@@ -84,6 +85,7 @@ class Plan(object):
         self._wg_ws_bytes = 0
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
+        self.fuse_bn_backward = os.environ.get("STP_FUSE_BN_BACKWARD", "1") != "0"
         self.loss_scalars = None
         self.inputs = {}
 
@@ -175,6 +177,14 @@ class Plan(object):
             t.grad = self._alloc((t.N, t.H, t.W, t.gradC))
         return t.grad
 
+    @staticmethod
+    def _use(*ts):
+        """Counts the consumers of a tensor: a BatchNormalization output read by exactly one convolution gets its
+        backward partial sums from that convolution's data-gradient epilogue (stp_conv_params.bnb_x)."""
+        for t in ts:
+            if t is not None:
+                t.meta["uses"] = t.meta.get("uses", 0) + 1
+
     # a launch record is (C function, args without the trailing stream, entry-point name, meta);
     # meta carries the layer name and the ALGORITHMIC flops of GEMM launches for bench.py's roofline.
     def _emit(self, lst, fname, *args):
@@ -232,6 +242,7 @@ class Plan(object):
         trainable = beta.trainable
         out = self._new(name, x.H, x.W, Cn, x.needs_grad or trainable)
         self._bn_ws_c = max(self._bn_ws_c, Cn)
+        self._use(x)
         if self.dry:
             return out
         gp = self._pptr(gamma) if gamma else None
@@ -251,12 +262,25 @@ class Plan(object):
                        rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
         self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
                    mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu), 0.0)
+        out.meta["bn"] = (x.buf.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu))
 
         def back():
             if not out.needs_grad or not out.grad_ready:
                 return
             # dx is always produced (it is cheap relative to skipping logic); frozen params are masked in the optimizer
             dx = self._gradbuf(x) if x.needs_grad else self._alloc((x.N, x.H, x.W, Cn))
+            fused_b = out.meta.get("bnb")
+            if fused_b is not None:
+                # the only consumer's data-gradient epilogue already masked dY and reduced the per-tile sums
+                st, q = fused_b
+                tiles = int(self.lib.stp_conv2d_stats_floats(C.byref(q))) // (2 * Cn)
+                self._emit(self.bwd, "stp_bn_backward_fused", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt,
+                           x.rows, Cn, mean.data_ptr(), rstd.data_ptr(), gp, st.data_ptr(), tiles,
+                           self._gptr(gamma) if gamma else None, self._gptr(beta), int(x.grad_ready and x.needs_grad),
+                           self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
+                if x.needs_grad:
+                    x.grad_ready = True
+                return
             self._emit(self.bwd, "stp_bn_backward", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt, x.rows, Cn,
                        mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), self._gptr(gamma) if gamma else None,
                        self._gptr(beta), int(relu), int(x.grad_ready and x.needs_grad), self.ws_bn.data_ptr(),
@@ -291,6 +315,7 @@ class Plan(object):
         s_ng = src1.needs_grad if src1 is not None else False
         out = self._new(name, Ho, Wo, Cout, x_ng or s_ng or w.trainable or (residual is not None and residual.needs_grad))
         out.gradC = CoutB
+        self._use(x, src1, residual)
         # workspace sizing needs the wgrad plan: query the library (cheap, host only)
         wp = _lib.WgradParams()
         wp.N, wp.Hs0, wp.Ws0, wp.Hv, wp.Wv, wp.C0, wp.C1 = self.N, x.H, x.W, Hv, Wv, C0, C1
@@ -383,6 +408,14 @@ class Plan(object):
                                     accumulate0=acc0, accumulate1=acc1)
                 if stride not in (1, 2):
                     raise StpShapeError("data gradient supports stride 1 and 2")
+                bnm = x.meta.get("bn")
+                if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses") == 1 and not upsample and C1 == 0
+                        and x_ng and not acc0 and C0 % 4 == 0):
+                    q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
+                    nfl = int(self.lib.stp_conv2d_stats_floats(C.byref(q)))
+                    st = self._alloc((max(nfl, 4),), torch.float32)
+                    q.stats_partial = st.data_ptr()
+                    x.meta["bnb"] = (st, q)
                 self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": flops,
                                               "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
                 if upsample and x_ng:
@@ -399,6 +432,7 @@ class Plan(object):
     def maxpool(self, name, x):
         Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
         out = self._new(name, Ho, Wo, x.C, x.needs_grad)
+        self._use(x)
         if self.dry:
             return out
         idx = self._alloc((self.N, Ho, Wo, x.C), torch.uint8) if self.training else None

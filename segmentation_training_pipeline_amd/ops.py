@@ -48,6 +48,10 @@ def conv2d(p, st=None):
     _lib.check(_lib.load().stp_conv2d(C.byref(p), stream() if st is None else st), "stp_conv2d")
 
 
+def conv2d_stats_floats(p):
+    return int(_lib.load().stp_conv2d_stats_floats(C.byref(p)))
+
+
 def wgrad_params(src0, dy, dw, *, N, Hs0, Ws0, Hv, Wv, C0, KH, KW, stride, pad, Ho, Wo, Cout, dtype,
                  src1=None, C1=0, mode=SRC_DIRECT, accumulate=0, splits=0):
     p = _lib.WgradParams()
@@ -110,6 +114,12 @@ def bn_inference(x, y, rows, Cn, Cy, mm, mv, eps, gamma, beta, relu, pad_value=0
 def bn_backward(x, dy, dx, rows, Cn, mean, rstd, gamma, beta, dgamma, dbeta, relu, accumulate_dx, workspace):
     _lib.call("stp_bn_backward", ptr(x), ptr(dy), ptr(dx), dt(x), rows, Cn, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
               ptr(dgamma), ptr(dbeta), int(relu), int(accumulate_dx), ptr(workspace),
+              workspace.numel() * workspace.element_size(), stream())
+
+
+def bn_backward_fused(x, g, dx, rows, Cn, mean, rstd, gamma, partial, tiles, dgamma, dbeta, accumulate_dx, workspace):
+    _lib.call("stp_bn_backward_fused", ptr(x), ptr(g), ptr(dx), dt(x), rows, Cn, ptr(mean), ptr(rstd), ptr(gamma), ptr(partial),
+              int(tiles), ptr(dgamma), ptr(dbeta), int(accumulate_dx), ptr(workspace),
               workspace.numel() * workspace.element_size(), stream())
 
 

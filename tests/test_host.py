@@ -151,6 +151,10 @@ def test_plan_structure_matches_unet_resnet34():
     bnames = [n for _, _, n, _ in plan.bwd]
     assert bnames.count("stp_conv2d_wgrad") == 48 and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
     assert bnames.count("stp_conv2d_wgrad_reduce") == 48
+    # BatchNormalization outputs read by exactly one convolution get their backward sums from that convolution's
+    # data-gradient epilogue: 16 bn2 + 12 bn1 of the non-first units + 5 decoder bn1 + the last decoder bn2
+    assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward") == 44
+    assert bnames.count("stp_bn_backward_fused") == 34
     assert "stp_add_inplace" not in bnames                             # every residual gradient aliases
     fl = sum(m["flops"] for _, _, _, m in plan.fwd if m)
     assert abs(fl / 2 / (2 * 1e6) - 31323 * (64 * 64) / (512 * 512)) < 2.0   # 31.3 GMAC/img at 512^2

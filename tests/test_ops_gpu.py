@@ -355,6 +355,59 @@ def test_batchnorm_train_forward_backward(ops, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0), (2, 9, 11, 128, 64, 5), (2, 19, 45, 16, 16, 512), (2, 19, 45, 16, 32, 512),
+                                  (1, 24, 20, 16, 64, 258), (2, 13, 9, 64, 24, 0), (1, 20, 24, 128, 16, 68)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_batchnorm_backward_sums_fused_in_conv_epilogue(ops, dtype, case, relu):
+    """stp_conv_params.bnb_x: the convolution that produces dY of a BN(+ReLU) output masks it and reduces the
+    BatchNormalization-backward sums in its epilogue; stp_bn_backward_fused must then equal conv + stp_bn_backward."""
+    n, h, w, ci, co, tile = case
+    rng = np.random.RandomState(77)
+    rows = n * h * w
+    src = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    x = q(rng.randn(n, h, w, co) * 1.5 + 0.3, dtype)          # the BN input
+    gamma = (rng.rand(co) + 0.5).astype(np.float32)
+    beta = (rng.randn(co) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd, g, b = dev(x, dtype), f(gamma), f(beta)
+    m, r = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(co) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, co, 1e-3, 0.99, m, r, None, None, ws)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    sd = dev(src, dtype)
+    mk = lambda dst: ops.conv_params(sd, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
+                                     Cout=co, dtype=ops.dt(dst), tile=tile)
+    # unfused reference on the device
+    dy = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
+    ops.conv2d(mk(dy))
+    dx0 = torch.empty_like(dy)
+    dg0, db0 = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ops.bn_backward(xd, dy, dx0, rows, co, m, r, g, b, dg0, db0, relu=relu, accumulate_dx=0, workspace=ws)
+    # fused
+    gbuf = torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+    P = mk(gbuf)
+    P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), relu
+    st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    tiles = ops.conv2d_stats_floats(P) // (2 * co)
+    assert tiles == P.stats_tiles
+    dx1 = torch.empty_like(dy)
+    dg1, db1 = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ops.bn_backward_fused(xd, gbuf, dx1, rows, co, m, r, g, st, tiles, dg1, db1, accumulate_dx=0, workspace=ws)
+    # the stored gradient is dY under the ReLU mask, bit for bit
+    pre = host(xd) * (host(r) * gamma) + (beta - host(m) * host(r) * gamma)
+    safe = np.abs(pre) > 1e-3
+    want = host(dy) * ((pre > 0) if relu else 1.0)
+    np.testing.assert_array_equal(host(gbuf)[safe], want[safe])
+    scale = lambda a: 2e-4 * np.abs(a).max() + 1e-4
+    np.testing.assert_allclose(host(db1), host(db0), atol=scale(host(db0)) * 5)
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=scale(host(dg0)) * 5)
+    np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_input_batchnorm_uint8_to_padded4(ops, dtype):
     rng = np.random.RandomState(11)
     n, h, w = 2, 16, 18
