@@ -333,8 +333,12 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     else if (STAGES >= 4 && ahead == 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // tile kt visible to every wave; the buffer of tile kt-1 is free
+#if !defined(STP_EXP) || STP_EXP != 2  // (what-if builds of scratch/exp_build.sh: 1 = no MFMA work, 2 = no loads in the loop)
     if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1, nbuf);
+#endif
+#if !defined(STP_EXP) || STP_EXP != 1
     compute_tile<T, BM, BN, WM, WN>(smem + buf * STAGE, wm, wn, lr, lg, acc);
+#endif
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }

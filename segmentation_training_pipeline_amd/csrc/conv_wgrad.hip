@@ -27,6 +27,7 @@ struct WgradArgs {
   int KH, KW, stride, pad, Ho, Wo, Cout;
   int K, P, HoWo;
   int ntile_m, ntile_n, steps_per_split, nsteps;
+  int rowu;  // every pixel step lies inside one image and starts on an output-row boundary pattern (see ROWU)
   uint32_t bytes0, bytes1, bytesdy;
   FastDiv divC, divKW, divHoWo, divWo;
 };
@@ -275,7 +276,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // image of an LDS-DMA is lane-linear, so the 32-byte-unit XOR swizzle is applied to the SOURCE column:
 // a thread owns a fixed PHYSICAL 16-byte slot and fetches the logical column that lives there (the
 // swizzle key only depends on row&7 and every pass advances the row by a multiple of 8).
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+//
+// ROWU ("uniform rows"): when Wo % PK == 0, or PK % Wo == 0 and Ho*Wo % PK == 0 (every power-of-two feature map), the
+// PK pixels of a step are (ho0 + r / Wo, wo0 + r % Wo) of ONE image with wave-uniform (n, ho0, wo0): the two
+// divisions per gathered row become per-thread constants plus scalar arithmetic - the address VALU work was
+// what bounded this kernel (scratch/whatif_bench.py: loads-only took 80% of the full time).
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool ROWU>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) {
   static_assert(WM * WN == 4 && STAGES >= 2, "config");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -326,10 +332,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
   const bool zins = first && a.mode == STP_SRC_ZEROINS2X;
   const int Hs = first ? a.Hs0 : a.Hv, Ws = first ? a.Ws0 : a.Wv;
 
+  // ROWU: per-thread constants of its rows
+  int hc[NVB], wc[NVB];
+  uint32_t rowa[NVA];
+  const uint32_t pixb = (uint32_t)cs * SZ, imgb = (uint32_t)Hs * (uint32_t)Ws * pixb, cib = (uint32_t)ci * SZ;
+  if constexpr (ROWU) {
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int row = rowB0 + i * RPB;
+      const int dho = a.Wo >= PK ? 0 : row / a.Wo;
+      const int dwo = a.Wo >= PK ? row : row - dho * a.Wo;
+      hc[i] = dho * a.stride - a.pad + kh;
+      wc[i] = dwo * a.stride - a.pad + kw;
+    }
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) rowa[i] = ((uint32_t)(rowA0 + i * RPA) * (uint32_t)a.Cout + (uint32_t)(cout0 + colA)) * SZ;
+  }
+
   auto issue_tile = [&](int step, int buf) {
     const int p0 = step * PK;
     char* sa = smem + buf * STAGE;
     char* sb = sa + PK * ROWA;
+    if constexpr (ROWU) {
+      // wave-uniform decomposition of the step's first pixel (P % PK == 0 here: no ragged tail)
+      const uint32_t n = fdiv((uint32_t)p0, a.divHoWo);
+      const uint32_t rem = (uint32_t)p0 - n * (uint32_t)a.HoWo;
+      const uint32_t ho0 = fdiv(rem, a.divWo);
+      const uint32_t wo0 = rem - ho0 * (uint32_t)a.Wo;
+      const int hs = (int)ho0 * a.stride, wsb = (int)wo0 * a.stride;
+      const uint32_t abase = (uint32_t)p0 * (uint32_t)a.Cout * SZ;
+      const uint32_t nb = n * imgb + cib;
+#pragma unroll
+      for (int i = 0; i < NVA; ++i) {
+        const bool act = (i * 256 + wave * 64) / VPRA < PK;
+        const bool rok = NVA * RPA == PK || (rowA0 + i * RPA) < PK;
+        char* dst = act ? sa + (i * 256 + wave * 64) * 16 : smem + DUMP + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)dst, 16,
+                                                 (coA_ok && rok) ? abase + rowa[i] : STP_OOB, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NVB; ++i) {
+        const bool act = (i * 256 + wave * 64) / VPRB < PK;
+        const bool rok = NVB * RPB == PK || (rowB0 + i * RPB) < PK;
+        const int hv = hs + hc[i], wv = wsb + wc[i];
+        bool ok = kB_ok && rok && (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+        if (zins) ok = ok && (((hv | wv) & 1) == 0);
+        const uint32_t off = nb + ((uint32_t)(hv >> sh) * (uint32_t)Ws + (uint32_t)(wv >> sh)) * pixb;
+        char* dst = act ? sb + (i * 256 + wave * 64) * 16 : smem + DUMP + wave * 1024;
+        if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dst, 16, ok ? off : STP_OOB, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dst, 16, ok ? off : STP_OOB, 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int row = rowA0 + i * RPA;
@@ -380,8 +434,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
     else if (STAGES >= 4 && ahead == 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+#if !defined(STP_EXP) || STP_EXP != 2  // what-if builds (scratch/exp_build.sh): 1 = no MFMA work, 2 = no loads in the loop
     if (st + STAGES - 1 < nst) issue_tile(step0 + st + STAGES - 1, nbuf);
+#endif
+#if !defined(STP_EXP) || STP_EXP != 1
     wgrad_compute<T, BM, BN, WM, WN>(smem + buf * STAGE, wm, wn, lr, lg, acc);
+#endif
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }
@@ -499,8 +557,10 @@ template <typename T, int BM, int BN, int WM, int WN, int STAGES>
 static int launch_wgrad_dma(WgradArgs& a, int splits, hipStream_t s) {
   static bool attr_set = false;
   constexpr int PK = 128 / (int)sizeof(T);
-  return launch_wg(conv_wgrad_dma_kernel<T, BM, BN, WM, WN, STAGES>, a, (size_t)STAGES * PK * (BM + BN) * sizeof(T) + 4096, splits,
-                   attr_set, s);
+  static bool attr_set_u = false;
+  const size_t lds = (size_t)STAGES * PK * (BM + BN) * sizeof(T) + 4096;
+  if (a.rowu) return launch_wg(conv_wgrad_dma_kernel<T, BM, BN, WM, WN, STAGES, true>, a, lds, splits, attr_set_u, s);
+  return launch_wg(conv_wgrad_dma_kernel<T, BM, BN, WM, WN, STAGES, false>, a, lds, splits, attr_set, s);
 }
 
 // variant: 0 = auto, 1 = legacy register-staged, 2/3 = DMA ring with that many stages
@@ -582,6 +642,10 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
   if (P >= (1ll << 31)) return STP_E_BADARG;
   a.P = (int)P; a.HoWo = p->Ho * p->Wo;
   a.ntile_m = w.ntile_m; a.ntile_n = w.ntile_n; a.steps_per_split = w.steps_per_split; a.nsteps = w.nsteps;
+  {
+    const int pk = 128 / sz;
+    a.rowu = (p->Wo % pk == 0) || (pk % p->Wo == 0 && a.HoWo % pk == 0);
+  }
   a.divC = make_fastdiv((uint32_t)a.Ctot); a.divKW = make_fastdiv((uint32_t)a.KW);
   a.divHoWo = make_fastdiv((uint32_t)a.HoWo); a.divWo = make_fastdiv((uint32_t)a.Wo);
   const int64_t lim = 1ll << 31;

@@ -264,6 +264,8 @@ WGRAD_CASES = [
     # small-channel halo-tile weight gradient (automatic for 16/32-channel 3x3 s1 layers), ragged tiles
     (2, 19, 45, 16, 16, 3, 1, 1, 0), (1, 9, 33, 32, 32, 3, 1, 1, 0), (2, 21, 40, 16, 32, 3, 1, 1, 0), (2, 19, 45, 32, 16, 3, 1, 1, 0),
     (1, 16, 64, 16, 8, 3, 1, 1, 0),
+    # power-of-two feature maps: the DMA kernel's uniform-row addressing (one image row / whole rows per pixel step)
+    (1, 2, 128, 64, 64, 3, 1, 1, 0), (2, 16, 32, 64, 64, 3, 2, 1, 0), (1, 8, 64, 128, 136, 3, 1, 1, 2), (3, 8, 8, 64, 192, 3, 1, 1, 0),
 ]
 
 
@@ -296,10 +298,13 @@ def test_conv2d_weight_gradient(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("chans", [(32, 16, 64), (64, 64, 32), (32, 16, 16)])
+@pytest.mark.parametrize("chans", [(32, 16, 64), (64, 64, 32), (32, 16, 16), (128, 64, 64, 8, 8), (64, 64, 128, 4, 32)])
 def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
     rng = np.random.RandomState(9)
     n, h, w = 2, 6, 7
+    if len(chans) == 5:           # power-of-two maps: uniform-row addressing with two sources
+        h, w = chans[3:]
+        chans = chans[:3]
     c0, c1, co = chans            # (64, 64, 32) = decoder_stage3_conv1: the small-channel kernel, one launch per source
     x = q(rng.randn(n, h, w, c0), dtype)
     skip = q(rng.randn(n, 2 * h, 2 * w, c1), dtype)
