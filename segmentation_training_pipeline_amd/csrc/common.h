@@ -104,6 +104,14 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// XCD-aware work order: consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2), so map
+// them onto 8 contiguous runs of the logical tile order - neighbouring tiles (shared 3x3 halo rows, or the
+// same pixel range of a weight-gradient split) then meet in one L2.  Bijective for any nblk.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 // x*scale + shift exactly as the BatchNormalization forward computed it: the backward passes re-derive the
 // ReLU mask from this expression, so every user must round identically (single fma).
 __device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return fmaf(x, scale, shift); }

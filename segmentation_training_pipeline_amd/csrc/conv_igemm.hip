@@ -63,12 +63,6 @@ template <> struct Mma<float> {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a
-// contiguous run of pixel tiles (neighbouring tiles share their 3x3 halo rows in that L2).
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
 
 // One K-tile of MFMAs for this wave: TM x TN fragments of 16x16, two 64-byte chunks per 128-byte row.
 template <typename T, int BM, int BN, int WM, int WN>

@@ -27,6 +27,7 @@ struct WgradArgs {
   int KH, KW, stride, pad, Ho, Wo, Cout;
   int K, P, HoWo;
   int ntile_m, ntile_n, steps_per_split, nsteps;
+  int xcd;   // XCD-contiguous block order
   int rowu;  // every pixel step lies inside one image and starts on an output-row boundary pattern (see ROWU)
   uint32_t bytes0, bytes1, bytesdy;
   FastDiv divC, divKW, divHoWo, divWo;
@@ -146,8 +147,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int wm = wave / WN, wn = wave % WN;
 
   const int tiles = a.ntile_m * a.ntile_n;
-  const int split = blockIdx.x / tiles;
-  const int t = blockIdx.x - split * tiles;
+  const int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // the tiles of one split (same pixels) share an XCD's L2
+  const int split = bid / tiles;
+  const int t = bid - split * tiles;
   const int tile_m = t % a.ntile_m, tile_n = t / a.ntile_m;
   const int cout0 = tile_m * BM, k0 = tile_n * BN;
   const int step0 = split * a.steps_per_split;
@@ -303,8 +305,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
   const int wm = wave / WN, wn = wave % WN;
 
   const int tiles = a.ntile_m * a.ntile_n;
-  const int split = blockIdx.x / tiles;
-  const int t = blockIdx.x - split * tiles;
+  const int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // the tiles of one split (same pixels) share an XCD's L2
+  const int split = bid / tiles;
+  const int t = bid - split * tiles;
   const int tile_m = t % a.ntile_m, tile_n = t / a.ntile_m;
   const int cout0 = tile_m * BM, k0 = tile_n * BN;
   const int step0 = split * a.steps_per_split;
@@ -642,6 +645,9 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
   if (P >= (1ll << 31)) return STP_E_BADARG;
   a.P = (int)P; a.HoWo = p->Ho * p->Wo;
   a.ntile_m = w.ntile_m; a.ntile_n = w.ntile_n; a.steps_per_split = w.steps_per_split; a.nsteps = w.nsteps;
+  // measured per layer (scratch/launch_table.py with and without): the XCD-contiguous order gains 5-10% when one
+  // Cout tile covers the layer (Cout <= 128), is neutral for Cout = 512 and loses 35% for Cout = 256
+  a.xcd = w.ntile_m == 1;
   {
     const int pk = 128 / sz;
     a.rowu = (p->Wo % pk == 0) || (pk % p->Wo == 0 && a.HoWo % pk == 0);
