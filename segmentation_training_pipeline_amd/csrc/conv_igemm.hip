@@ -71,24 +71,30 @@ __device__ __forceinline__ void compute_tile(const char* stage, int wm, int wn, 
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   const char* sa = stage + (wm * (BM / WM)) * 128;
   const char* sb = stage + BM * 128 + (wn * (BN / WN)) * 128;
+  // all fragment reads of the K-tile are issued before its first MFMA (the compiler would otherwise sink them
+  // next to their users to save registers, exposing one LDS round trip per four MFMAs); the s_waitcnt counters
+  // it inserts then release the first 64-byte chunk while the second is still in flight
+  u32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    u32x4 fa[TM], fb[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = i * 16 + lr;  // (wave row offset is a multiple of 16 -> row&7 unchanged)
-      fa[i] = *reinterpret_cast<const u32x4*>(sa + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+      fa[c][i] = *reinterpret_cast<const u32x4*>(sa + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = j * 16 + lr;
-      fb[j] = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+      fb[c][j] = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-  }
+      for (int j = 0; j < TN; ++j) Mma<T>::run(fa[c][i], fb[c][j], acc[i][j]);
 }
 
 // value as it will be read back from memory (the BatchNorm that follows normalises the STORED tensor)
@@ -535,10 +541,13 @@ static int launch_tile(ConvArgs& a, int tile, int ut_ok, hipStream_t s) {
       case 4: return launch_gen<T, 16, 256, 1, 4, false>(a, s);
       case 5: return launch_gen<T, 64, 64, 2, 2, false>(a, s);
       case 6: return launch_gen<T, 128, 64, 4, 1, false>(a, s);
+      case 7: return launch_gen<T, 64, 128, 2, 2, false>(a, s);
       case 64 + 1: return launch_ut<T, 128, 128, 2, 2, 2>(a, s);
       case 64 + 2: return launch_ut<T, 64, 256, 1, 4, 2>(a, s);
       case 64 + 5: return launch_ut<T, 64, 64, 2, 2, 2>(a, s);
       case 64 + 6: return launch_ut<T, 128, 64, 4, 1, 2>(a, s);
+      case 64 + 7: return launch_ut<T, 64, 128, 2, 2, 2>(a, s);
+      case 96 + 7: return launch_ut<T, 64, 128, 2, 2, 3>(a, s);
       case 96 + 1: return launch_ut<T, 128, 128, 2, 2, 3>(a, s);
       case 96 + 2: return launch_ut<T, 64, 256, 1, 4, 3>(a, s);
       case 96 + 5: return launch_ut<T, 64, 64, 2, 2, 3>(a, s);
@@ -568,7 +577,7 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
   if (co <= 32) return ut_ok == 2 ? 256 + 3 : ut_ok == 1 ? 64 + 3 : 3;
   if (co <= 64) {
     if (ut_ok == 2) return 256 + 2;
-    if (ut_ok == 1) return 64 + 5;
+    if (ut_ok == 1) return ceil_div(a.P, 128) >= 384 ? 64 + 7 : 64 + 5;
     return ((int64_t)a.P >= 256 * 256) ? 2 : 5;
   }
   const int64_t big = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 128);
@@ -638,7 +647,7 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* u
 static int tile_pixels(int tile) {
   if (tile == 512) return 256;
   const int t = tile >= 256 ? tile - 256 : tile % 32;
-  return (t == 2 || t == 3 || t == 4) ? 256 : (t == 1 ? 128 : 64);
+  return (t == 2 || t == 3 || t == 4) ? 256 : ((t == 1 || t == 7) ? 128 : 64);
 }
 
 extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p);

@@ -364,37 +364,45 @@ struct WeightPrepDesc {
   int32_t Cout, KH, KW, Cin, KWp, Cinp, CoutB, rows_f, rows_b, pad_;
 };
 
-// grid.y = layer, grid.x strides over that layer's elements.  The fwd copy is a row-wise copy with padding
-// (consecutive threads -> consecutive output elements -> coalesced reads of the master for Cinp == Cin);
-// the bwd copy is a transpose, done through the same index arithmetic (its reads are strided but the whole
-// master arena is only ~100 MB and L2/MALL resident).
+// grid.y = layer; the workgroups of a layer stride over its (tap, 32-cout, 32-cin) units.  A unit is read once
+// from the fp32 master (cin fastest: coalesced), held in LDS, and written twice: the forward copy in the same
+// orientation and the data-gradient copy transposed (cout fastest) with the taps flipped - both coalesced.
+// Padding (Cinp > Cin, KWp > KW, row padding to 16, CoutB > Cout) is written as zeros.
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prepare_batched_kernel(const WeightPrepDesc* __restrict__ desc, int nlayers, int64_t total) {
+  __shared__ float tile[32][33];
   const WeightPrepDesc d = desc[blockIdx.y];
-  const int64_t nf = d.fwd ? (int64_t)d.rows_f * d.KH * d.KWp * d.Cinp : 0;
-  const int64_t nb = d.bwd ? (int64_t)d.rows_b * d.KH * d.KW * d.CoutB : 0;
-  const FastDiv dCinp = make_fastdiv((uint32_t)d.Cinp), dKWp = make_fastdiv((uint32_t)d.KWp), dKH = make_fastdiv((uint32_t)d.KH);
-  const FastDiv dCoutB = make_fastdiv((uint32_t)d.CoutB), dKW = make_fastdiv((uint32_t)d.KW);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * 256) {
-    if (i < nf) {
-      uint32_t r = (uint32_t)i, t;
-      t = fdiv(r, dCinp); const int ci = (int)(r - t * d.Cinp); r = t;
-      t = fdiv(r, dKWp); const int kw = (int)(r - t * d.KWp); r = t;
-      t = fdiv(r, dKH); const int kh = (int)(r - t * d.KH);
-      const int co = (int)t;
+  const int co_ext = d.bwd ? (d.rows_f > d.CoutB ? d.rows_f : d.CoutB) : d.rows_f;
+  const int ci_ext = d.bwd ? (d.Cinp > d.rows_b ? d.Cinp : d.rows_b) : d.Cinp;
+  const int CT = (co_ext + 31) >> 5, IT = (ci_ext + 31) >> 5, taps = d.KH * d.KWp;
+  const int units = taps * CT * IT;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  T* fwd = reinterpret_cast<T*>(d.fwd);
+  T* bwd = reinterpret_cast<T*>(d.bwd);
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int it = u % IT;
+    const int ct = (u / IT) % CT;
+    const int tap = u / (IT * CT);
+    const int kh = tap / d.KWp, kw = tap - kh * d.KWp;
+    const int co0 = ct * 32, ci0 = it * 32;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int co = co0 + ty + 8 * p, ci = ci0 + tx;
       float v = 0.f;
       if (co < d.Cout && kw < d.KW && ci < d.Cin) v = d.master[(((int64_t)co * d.KH + kh) * d.KW + kw) * d.Cin + ci];
-      Elem<T>::store(reinterpret_cast<T*>(d.fwd) + i, v);
-    } else {
-      uint32_t r = (uint32_t)(i - nf), t;
-      t = fdiv(r, dCoutB); const int co = (int)(r - t * d.CoutB); r = t;
-      t = fdiv(r, dKW); const int kw = (int)(r - t * d.KW); r = t;
-      t = fdiv(r, dKH); const int kh = (int)(r - t * d.KH);
-      const int ci = (int)t;
-      float v = 0.f;
-      if (co < d.Cout && ci < d.Cin) v = d.master[(((int64_t)co * d.KH + (d.KH - 1 - kh)) * d.KW + (d.KW - 1 - kw)) * d.Cin + ci];
-      Elem<T>::store(reinterpret_cast<T*>(d.bwd) + (i - nf), v);
+      tile[ty + 8 * p][tx] = v;
+      if (fwd && co < d.rows_f && ci < d.Cinp) Elem<T>::store(fwd + (((int64_t)co * d.KH + kh) * d.KWp + kw) * d.Cinp + ci, v);
     }
+    __syncthreads();
+    if (bwd && kw < d.KW) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int ci = ci0 + ty + 8 * p, co = co0 + tx;
+        if (ci < d.rows_b && co < d.CoutB)
+          Elem<T>::store(bwd + (((int64_t)ci * d.KH + (d.KH - 1 - kh)) * d.KW + (d.KW - 1 - kw)) * d.CoutB + co, tile[tx][ty + 8 * p]);
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -553,6 +553,42 @@ def test_augment_fixed_point_warp_bit_exact(ops):
     np.testing.assert_array_equal(mo.cpu().numpy(), rm)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batched_weight_prepare_equals_per_layer(ops, dtype):
+    """The once-per-step batched launch (LDS tile transpose) must write exactly what stp_weight_prepare writes
+    layer by layer: forward copies with channel/tap padding, flipped + transposed data-gradient copies."""
+    import ctypes as C
+    from segmentation_training_pipeline_amd import _lib
+    lib = _lib.load()
+    vec = 8 if dtype == "bf16" else 4
+    rng = np.random.RandomState(3)
+    # Cout, KH, KW, Cin(master), KWp, Cinp, want_bwd
+    layers = [(64, 7, 7, 3, 8, 4, False), (64, 3, 3, 64, 3, 64, True), (40, 3, 3, 24, 3, 24, True), (1, 3, 3, 16, 3, 16, True),
+              (136, 1, 1, 72, 1, 72, True), (16, 3, 3, 48, 3, 48, False)]
+    dsz = int(lib.stp_weight_prepare_desc_bytes())
+    hostbuf = (C.c_char * (dsz * len(layers)))()
+    total, outs = 0, []
+    for i, (co, kh, kw, ci, kwp, cinp, want_bwd) in enumerate(layers):
+        coutb = (co + vec - 1) // vec * vec
+        master = keep(torch.from_numpy(rng.randn(co, kh, kw, ci).astype(np.float32)).to(DEV))
+        rows_f, rows_b = (co + 15) // 16 * 16, (cinp + 15) // 16 * 16
+        mk = lambda n: torch.full((n,), float("nan"), dtype=TD[dtype], device=DEV)
+        f1, f2 = mk(rows_f * kh * kwp * cinp), mk(rows_f * kh * kwp * cinp)
+        b1 = b2 = None
+        if want_bwd:
+            b1, b2 = mk(rows_b * kh * kw * coutb), mk(rows_b * kh * kw * coutb)
+        ops.weight_prepare(master, f1, b1, co, kh, kw, ci, kwp, cinp, coutb, ops.dt(f1))
+        total += int(lib.stp_weight_prepare_desc_fill(C.cast(hostbuf, C.c_void_p), i, total, ops.ptr(master), ops.ptr(f2), ops.ptr(b2),
+                                                      co, kh, kw, ci, kwp, cinp, coutb))
+        outs.append((f1, f2, b1, b2))
+    dev_desc = keep(torch.frombuffer(bytearray(bytes(hostbuf)), dtype=torch.uint8).to(DEV))
+    _lib.call("stp_weight_prepare_batched", dev_desc.data_ptr(), len(layers), total, ops.dt(outs[0][0]), ops.stream())
+    for f1, f2, b1, b2 in outs:
+        np.testing.assert_array_equal(host(f2), host(f1))
+        if b1 is not None:
+            np.testing.assert_array_equal(host(b2), host(b1))
+
+
 def test_bf16_wire_casts(ops):
     x = torch.randn(10007, device=DEV)
     b = torch.empty(10007, dtype=torch.bfloat16, device=DEV)
