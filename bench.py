@@ -31,7 +31,8 @@ FLOP_PER_IMAGE = 187.94e9
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
-CONV_TILES = {1: "128, 128, 2, 2", 2: "64, 256, 1, 4", 3: "32, 256, 1, 4", 4: "16, 256, 1, 4", 5: "64, 64, 2, 2", 6: "128, 64, 4, 1"}
+CONV_TILES = {1: "128, 128, 2, 2", 2: "64, 256, 1, 4", 3: "32, 256, 1, 4", 4: "16, 256, 1, 4", 5: "64, 64, 2, 2", 6: "128, 64, 4, 1",
+              7: "64, 128, 2, 2"}
 
 
 def wgrad_tile(cout):
@@ -57,7 +58,8 @@ def kernel_key(name, meta, dtype):
             return "conv_wgrad_kernel<%s, %s, true>" % (t, wgrad_tile(meta["cout"]))
         if dtype == "fp32" and meta["cout"] <= 32:
             return "conv_wgrad_kernel<%s, %s, false>" % (t, wgrad_tile(meta["cout"]))
-        return "conv_wgrad_dma_kernel<%s, %s, 2>" % (t, wgrad_tile(meta["cout"]))
+        # (..., STAGES = 2, ROWU = true: every feature map of this workload is a power of two)
+        return "conv_wgrad_dma_kernel<%s, %s, 2, true>" % (t, wgrad_tile(meta["cout"]))
     return name
 
 
@@ -91,6 +93,21 @@ def per_kernel_profile(model, reps=3):
     for t, s in zip(model._mutable_state(), saved):
         t.copy_(s)
     return {k: [v[0] / reps, v[1] / reps, v[2] / reps] for k, v in acc.items()}
+
+
+def pmc_traffic(kernel):
+    """L2-miss bytes per launch of ``kernel`` (read + write) from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
+    that kernel was not in the measured build."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None, None
+    if not k:
+        return None, None
+    return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], "profiles/r01b_pmc_traffic.json"
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -197,8 +214,10 @@ def main():
         dom = max(gemm, key=lambda k: gemm[k][1])
         n_l, sec, fl = gemm[dom]
         ach = fl / sec / 1e12
+        traffic, traffic_src = pmc_traffic(dom)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                           "traffic_source": traffic_src,
                            "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
                            "share_of_step_kernel_time": round(sec / tot, 3)}
         top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]
