@@ -12,7 +12,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import graph, nets
+from . import distributed, graph, nets
 
 SCALAR_NAMES = ("loss", "binary_crossentropy", "dice_loss", "dice", "binary_accuracy")
 
@@ -58,6 +58,9 @@ class HipSegModel(object):
         self.use_graph = use_graph
         self.device = torch.device(device)
         self.reducer = None
+        self.dp_overlap = False
+        self._segments = None
+        self._works = []
         self._graphs = None
         self.plan = graph.Plan(self.batch, dtype, device, training=True)
         if freeze_encoder:
@@ -101,10 +104,20 @@ class HipSegModel(object):
             self._eval = ep
         return self._eval
 
-    def set_data_parallel(self, reducer):
+    def set_data_parallel(self, reducer, overlap=True):
         """Attaches a gradient reducer (distributed.GradReducer): gradients are SUM-all-reduced between
-        the backward and optimizer graphs and the 1/world mean is folded into the optimizer."""
+        the backward and optimizer graphs and the 1/world mean is folded into the optimizer.
+
+        ``overlap``: the backward is cut into segments after which a range of the gradient arena is final (the arena
+        is written from its tail towards its head, Plan.bwd_marks); the all-reduce of that range is issued
+        asynchronously as soon as its segment has been launched, so RCCL runs under the remaining backward GEMMs.
+        ``overlap=True`` uses distributed.two_phase_bounds; ``overlap="buckets"`` keeps the reducer's own buckets."""
         self.reducer = reducer
+        self.dp_overlap = bool(overlap) and not reducer.wire_bf16 and self.plan.bwd_monotone
+        if self.dp_overlap and overlap != "buckets":
+            reducer.set_bounds(distributed.two_phase_bounds(self.plan.bwd_marks, self.plan.G.numel()))
+        self._segments = None
+        self._works = []
         self.dp_scale = float(reducer.scale)
         self.gscale.fill_(self.dp_scale)
         self._build_opt(use_gscale=True)
@@ -223,12 +236,36 @@ class HipSegModel(object):
         for t, s in zip(self._mutable_state(), saved):
             t.copy_(s)
         torch.cuda.synchronize()
-        gfb, gopt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gfb):
-            p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+        gopt = torch.cuda.CUDAGraph()
+        segs = self._dp_segments()
+        if segs is None:
+            gfb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gfb):
+                p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+            self._graphs = {"fb": gfb, "opt": gopt}
+        else:
+            # one graph per backward segment; the first also holds the weight copies, the forward and the loss
+            gs, a = [], 0
+            for i, (b, _) in enumerate(segs):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    if i == 0:
+                        p.run(p.prep); p.run(p.fwd)
+                    p.run(p.bwd[a:b])
+                gs.append(g)
+                a = b
+            self._graphs = {"segs": gs, "opt": gopt}
         with torch.cuda.graph(gopt):
             p.run(p.opt)
-        self._graphs = {"fb": gfb, "opt": gopt}
+
+    def _dp_segments(self):
+        """[(end launch index, [(s, e) gradient ranges final after it])] or None when the all-reduce is not overlapped."""
+        if self.reducer is None or not getattr(self, "dp_overlap", False) or not self.reducer.active:
+            return None
+        if self._segments is None:
+            p = self.plan
+            self._segments = distributed.overlap_schedule(p.bwd_marks, self.reducer.bounds(p.G.numel()), len(p.bwd))
+        return self._segments
 
     def load_batch(self, x, y=None):
         """Copies a uint8 image batch [N,H,W,C] (and masks [N,H,W,1] in {0,1}) into the plan's input buffers."""
@@ -245,15 +282,35 @@ class HipSegModel(object):
 
     def forward_backward(self):
         p = self.plan
+        segs = self._dp_segments()
         if self.use_graph:
             self._ensure_graphs()
-            self._graphs["fb"].replay()
-        else:
-            p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+        if segs is None:
+            if self.use_graph:
+                self._graphs["fb"].replay()
+            else:
+                p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+            return
+        self._works, a = [], 0
+        for i, (b, ranges) in enumerate(segs):
+            if self.use_graph:
+                self._graphs["segs"][i].replay()
+            else:
+                if i == 0:
+                    p.run(p.prep); p.run(p.fwd)
+                p.run(p.bwd[a:b])
+            a = b
+            for s, e in ranges:
+                self._works.append(self.reducer.allreduce_range(p.G, s, e))
 
     def apply_gradients(self):
         p = self.plan
-        if self.reducer is not None:
+        if self._dp_segments() is not None:
+            for w in self._works:
+                if w is not None:
+                    w.wait()
+            self._works = []
+        elif self.reducer is not None:
             self.reducer.allreduce(p.G)
         if self.use_graph:
             self._ensure_graphs()

@@ -50,6 +50,52 @@ def bucket_bounds(numel, bucket_elems, align=4):
     return out
 
 
+def overlap_schedule(marks, bounds, n_launches):
+    """Cuts a backward launch list into segments after which gradient buckets are final.
+
+    ``marks``: [(launches issued so far, lowest gradient offset written so far)] per backward layer (Plan.bwd_marks;
+    the arena fills from its tail).  ``bounds``: ascending [(s, e)] buckets.  Returns [(end launch index, [(s, e), ...])]
+    with strictly increasing ends, the last one == n_launches, every bucket exactly once; a bucket is attached to the
+    first segment end at which ``lowest offset <= s``; the head bucket (and whatever the backward never reaches, e.g.
+    a frozen encoder) goes with the last segment."""
+    segs, pending = [], list(reversed(bounds))
+    for end, low in marks:
+        ready = []
+        while len(pending) > 1 and pending[0][0] >= low:
+            ready.append(pending.pop(0))
+        if not ready:
+            continue
+        if segs and segs[-1][0] == end:
+            segs[-1][1].extend(ready)
+        else:
+            segs.append((end, ready))
+    if segs and segs[-1][0] == n_launches:
+        segs[-1][1].extend(pending)
+    else:
+        segs.append((n_launches, pending))
+    return segs
+
+
+def two_phase_bounds(marks, numel, frac=0.7, align=4):
+    """Two gradient ranges for the overlapped reducer: the arena's tail, final once ``frac`` of the backward launches
+    have been issued (for U-Net/ResNet: decoder + stages 4-3, > 90 % of the bytes), is all-reduced under the rest of
+    the backward (the high-resolution stage-1/2 and stem layers: few parameters, a third of the time); the small
+    head follows after the last launch.  xGMI rings are per-link bound, so one large message beats many buckets, and
+    every extra backward segment costs a graph launch (~0.07 ms measured) - hence two phases, not N buckets."""
+    if not marks:
+        return [(0, numel)]
+    total = marks[-1][0]
+    low = numel
+    for end, lo in marks:
+        low = lo
+        if end >= frac * total:
+            break
+    low = (low // align) * align
+    if low <= 0 or low >= numel:
+        return [(0, numel)]
+    return [(0, low), (low, numel)]
+
+
 class GradReducer(object):
     """Sum-all-reduce of a flat gradient arena in buckets; the mean's 1/world factor is NOT applied
     to the arena - read it from ``scale`` and fold it into the optimizer (HipSegModel.gscale)."""
@@ -67,6 +113,26 @@ class GradReducer(object):
     @property
     def scale(self):
         return 1.0 / self.world
+
+    @property
+    def active(self):
+        return self.world > 1 or (self.force and dist.is_initialized())
+
+    def bounds(self, numel):
+        if self._bounds is None or self._bounds[-1][1] != numel:
+            self._bounds = bucket_bounds(numel, self.bucket_elems)
+        return self._bounds
+
+    def set_bounds(self, bounds):
+        """Replaces the uniform buckets (e.g. with two_phase_bounds for the overlapped schedule)."""
+        self._bounds = list(bounds)
+
+    def allreduce_range(self, flat, s, e):
+        """Asynchronous SUM-all-reduce of flat[s:e] ordered after the work already on the current stream; returns
+        the work handle (``wait()`` orders the current stream after the collective) or None when inactive."""
+        if not self.active or os.environ.get("STP_DP_NOCOMM") == "1":   # (NOCOMM: measure the segmentation cost alone)
+            return None
+        return dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def allreduce(self, flat):
         if self.world <= 1 and not (self.force and dist.is_initialized()):

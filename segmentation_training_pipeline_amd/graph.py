@@ -81,6 +81,8 @@ class Plan(object):
         self.P = self.G = self.S = None
         self.prep, self.fwd, self.bwd, self.opt = [], [], [], []
         self._tape = []
+        self._goffs = []
+        self.bwd_marks, self.bwd_monotone = [], True
         self._prep_layers = []
         self._wg_ws_bytes = 0
         self._bn_ws_c = 4
@@ -117,8 +119,20 @@ class Plan(object):
         net_fn(self)
         self._finish_prep()
         if self.training:
+            # bwd_marks[i] = (launches issued after the i-th backward closure, lowest gradient offset written so far):
+            # gradients at or above that offset are final from that launch on, PROVIDED layers finish in descending
+            # arena order (true when parameters are declared in call order); otherwise bwd_monotone is cleared and
+            # the reducer falls back to one all-reduce after the whole backward
+            self.bwd_marks, self.bwd_monotone = [], True
+            low = self.G.numel() if self.G is not None else 0
             for back in reversed(self._tape):
+                self._goffs = []
                 back()
+                if self._goffs:
+                    if max(e for _, e in self._goffs) > low:
+                        self.bwd_monotone = False
+                    low = min(low, min(o for o, _ in self._goffs))
+                self.bwd_marks.append((len(self.bwd), low))
         self._tape = []
         return self
 
@@ -156,6 +170,9 @@ class Plan(object):
         return self.P.data_ptr() + 4 * info.offset
 
     def _gptr(self, info):
+        # the backward closures ask for gradient addresses in backward order: the running minimum tells the
+        # data-parallel reducer which tail of the arena is final after each layer (bwd_marks)
+        self._goffs.append((info.offset, info.offset + int(np.prod(info.shape))))
         return self.G.data_ptr() + 4 * info.offset
 
     def _sptr(self, off):

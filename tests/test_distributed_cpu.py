@@ -33,6 +33,13 @@ def _worker(rank, world, port, q):
                                    cast_fns=(lambda s, d, c: d.copy_(s.to(torch.bfloat16)), lambda s, d, c: d.copy_(s.to(torch.float32))))
     red2.allreduce(g2)
     ok = ok and torch.equal(g2, torch.ones(1024) * 3)
+    # overlapped form: asynchronous per-bucket reductions issued in backward (tail-first) order, waited before the optimizer
+    g3 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red3 = distributed.GradReducer(bucket_mb=0.05)
+    works = [red3.allreduce_range(g3, s, e) for s, e in reversed(red3.bounds(n))]
+    for wk in works:
+        wk.wait()
+    ok = ok and torch.equal(g3, expect)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -49,3 +56,34 @@ def test_gloo_world2_bucketed_allreduce():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_overlap_schedule_covers_every_bucket_once_in_backward_order():
+    """distributed.overlap_schedule on the real plan of U-Net/ResNet34: segments end at increasing launch indices,
+    each bucket appears once, and a bucket is only released when no later backward launch can write into it."""
+    from segmentation_training_pipeline_amd import distributed, graph, nets
+    plan = graph.Plan(batch=2, dtype="bf16", device="cpu")
+    plan.define(lambda p: nets.unet_resnet(p, "resnet34", 64, 64))
+    assert plan.bwd_monotone
+    ends = [e for e, _ in plan.bwd_marks]
+    lows = [l for _, l in plan.bwd_marks]
+    assert ends == sorted(ends) and ends[-1] == len(plan.bwd) and lows == sorted(lows, reverse=True) and lows[-1] == 0
+    n = plan.G.numel()
+    bounds = distributed.bucket_bounds(n, 4 * (1 << 20))      # 16 MB buckets -> 6 buckets
+    segs = distributed.overlap_schedule(plan.bwd_marks, bounds, len(plan.bwd))
+    assert [e for e, _ in segs] == sorted(set(e for e, _ in segs)) and segs[-1][0] == len(plan.bwd)
+    seen = [r for _, rs in segs for r in rs]
+    assert sorted(seen) == bounds and len(segs) >= 4
+    for end, rs in segs[:-1]:
+        low_at_end = [l for e, l in plan.bwd_marks if e == end][-1]
+        assert all(s >= low_at_end for s, _ in rs)
+    assert (0, bounds[0][1]) in segs[-1][1]
+    # default schedule: two phases, the tail (> 90 % of the bytes) final at 70 % of the launches
+    two = distributed.two_phase_bounds(plan.bwd_marks, n)
+    assert len(two) == 2 and two[0][0] == 0 and two[1][1] == n and two[0][1] == two[1][0] and two[0][1] < 0.1 * n
+    s2 = distributed.overlap_schedule(plan.bwd_marks, two, len(plan.bwd))
+    assert len(s2) == 2 and 0.6 * len(plan.bwd) < s2[0][0] < 0.85 * len(plan.bwd) and s2[1][0] == len(plan.bwd)
+    # a frozen encoder never reaches the head of the arena: everything left goes with the last segment
+    short = [(e, max(l, n // 2)) for e, l in plan.bwd_marks]
+    segs2 = distributed.overlap_schedule(short, bounds, len(plan.bwd))
+    assert sorted(r for _, rs in segs2 for r in rs) == bounds and segs2[-1][0] == len(plan.bwd)

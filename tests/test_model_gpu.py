@@ -130,6 +130,42 @@ def test_hipgraph_replay_equals_eager():
         np.testing.assert_array_equal(outs[0][2][k], outs[1][2][k], err_msg=k)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_overlapped_rccl_allreduce_equals_plain_step(use_graph):
+    """Data-parallel path on one GPU (world size 1 over RCCL, GradReducer(force=True)): the backward cut into
+    per-bucket segments with asynchronous all-reduces must leave exactly the weights of the plain step."""
+    import socket
+    import torch.distributed as dist
+    from segmentation_training_pipeline_amd import distributed
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    x, y = ostep.synthetic_batch(2, 64, 64, seed=11)
+    ref = make("resnet18", 64, 2, "bf16", use_graph=use_graph)
+    ref.init_weights(seed=5)
+    for _ in range(3):
+        ref.train_on_batch(x, y)
+    want = ref.get_weights()
+    distributed.init("nccl", force=True)
+    try:
+        m = make("resnet18", 64, 2, "bf16", use_graph=use_graph)
+        m.init_weights(seed=5)
+        if use_graph:
+            m.set_data_parallel(distributed.GradReducer(bucket_mb=8.0, force=True), overlap="buckets")   # 14.3M params -> 7 buckets
+            segs = m._dp_segments()
+            assert segs is not None and len(segs) >= 3 and sum(len(r) for _, r in segs) == 7
+        else:
+            m.set_data_parallel(distributed.GradReducer(force=True))                   # default: two phases
+            segs = m._dp_segments()
+            assert len(segs) == 2 and segs[0][1][0][1] == m.plan.G.numel() and segs[1][1][0][0] == 0
+        for _ in range(3):
+            m.train_on_batch(x, y)
+        got = m.get_weights()
+    finally:
+        dist.destroy_process_group()
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
 def test_bf16_step_close_to_fp32_oracle():
     """bf16 storage / bf16 MFMA inputs / fp32 accumulation, the benchmarked precision.  Every layer
     rounds inputs, weights and outputs to 8 significant bits (2^-9 relative RMS each), which over the
