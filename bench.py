@@ -74,6 +74,8 @@ def per_kernel_profile(model, reps=3):
     for rep in range(reps + 1):
         evs = []
         for (fn, args, name, meta), _ in launches:
+            if fn is None:
+                continue  # fork/join markers of the side-stream weight-gradient chain: this pass is single-stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             rc = fn(*args, st.cuda_stream)
@@ -85,11 +87,11 @@ def per_kernel_profile(model, reps=3):
         if rep == 0:
             continue  # first pass warms caches / clocks
         for name, meta, e0, e1 in evs:
-            key = kernel_key(name, meta, model.dtype) if meta else name
+            key = kernel_key(name, meta, model.dtype) if (meta and "flops" in meta) else name
             a = acc.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += meta["flops"] if meta else 0.0
+            a[2] += meta["flops"] if (meta and "flops" in meta) else 0.0
     for t, s in zip(model._mutable_state(), saved):
         t.copy_(s)
     return {k: [v[0] / reps, v[1] / reps, v[2] / reps] for k, v in acc.items()}

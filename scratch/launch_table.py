@@ -8,7 +8,7 @@ p = m.plan
 rng = np.random.RandomState(0)
 m.load_batch(rng.randint(0, 256, (16, 512, 512, 3)).astype(np.uint8), (rng.rand(16, 512, 512, 1) < 0.2).astype(np.uint8))
 st = torch.cuda.current_stream()
-launches = p.prep + p.fwd + p.bwd + p.opt
+launches = [l for l in p.prep + p.fwd + p.bwd + p.opt if l[0] is not None]
 reps = 3
 tot = {}
 for rep in range(reps + 1):
@@ -33,5 +33,5 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
     print("%-28s %9.1f us" % (k, v))
 print("---- GEMM launches")
 for us, name, meta in rows:
-    if meta:
+    if meta and 'flops' in meta:
         print("%-28s %-6s tile=%-3s %8.1f us %7.1f TF" % (meta["layer"], meta["pass"], meta.get("tile", meta.get("cout")), us, meta["flops"] / us / 1e6))

@@ -88,6 +88,11 @@ class Plan(object):
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
         self.fuse_bn_backward = os.environ.get("STP_FUSE_BN_BACKWARD", "1") != "0"
+        # weight gradients (needed only by the optimizer / all-reduce) run on a second stream next to the data-gradient
+        # + BatchNormalization-backward chain of the same layer: the small latency-bound kernels of one chain fill the
+        # tails of the other's GEMMs (captured into the same hipGraph as a fork/join)
+        self.side_stream_wgrad = os.environ.get("STP_SIDE_STREAM_WGRAD", "1") != "0"
+        self._side = None
         self.loss_scalars = None
         self.inputs = {}
 
@@ -207,6 +212,13 @@ class Plan(object):
     def _emit(self, lst, fname, *args):
         lst.append((getattr(self.lib, fname), args, fname, None))
 
+    def _emit_side(self, lst, fname, *args):
+        lst.append((getattr(self.lib, fname), args, fname, {"stream": 1}))
+
+    @staticmethod
+    def _mark(lst, what):
+        lst.append((None, (), what, None))
+
     def _emit_conv(self, lst, p, meta=None):
         self._keep.append(p)
         lst.append((self.lib.stp_conv2d, (C.byref(p),), "stp_conv2d", meta))
@@ -215,9 +227,11 @@ class Plan(object):
         """Weight gradient = split partial sums + fixed-order reduce: two launch records so that each
         kernel can be timed on its own (bench.py) - same arithmetic as stp_conv2d_wgrad."""
         self._keep.append(p)
+        meta = dict(meta or {}, stream=1)
         lst.append((self.lib.stp_conv2d_wgrad_partial, (C.byref(p), self.ws_wgrad.data_ptr(), self.ws_wgrad.numel() * 4, 0),
                     "stp_conv2d_wgrad", meta))
-        lst.append((self.lib.stp_conv2d_wgrad_reduce, (C.byref(p), self.ws_wgrad.data_ptr(), 0), "stp_conv2d_wgrad_reduce", None))
+        lst.append((self.lib.stp_conv2d_wgrad_reduce, (C.byref(p), self.ws_wgrad.data_ptr(), 0), "stp_conv2d_wgrad_reduce",
+                    {"stream": 1}))
 
     # ------------------------------------------------------------------ layers
     def input_u8(self, name, H, W, Cn):
@@ -373,6 +387,9 @@ class Plan(object):
                 return
             dy = out.grad
             rows = out.rows
+            # the previous layer's weight-gradient chain (side stream) must be done before this layer's main-stream
+            # kernels: they may accumulate into a buffer it reads (dY aliased as a residual gradient two layers up)
+            self._mark(self.bwd, "join")
             # residual branch: d(residual) = dY
             if residual is not None and residual.needs_grad:
                 if not residual.grad_ready and residual.gradC == out.gradC:
@@ -381,8 +398,9 @@ class Plan(object):
                 else:
                     self._emit(self.bwd, "stp_add_inplace", self._gradbuf(residual).data_ptr(), dy.data_ptr(),
                                rows * out.gradC, self.cdt)
-            # weight gradient
+            # weight gradient: on the side stream, forked here (dY is final), joined at the next convolution's backward
             if w.trainable:
+                self._mark(self.bwd, "fork")
                 padded = stem or CoutB != Cout
                 if padded:
                     dwp = self._alloc((CoutB * k * KWp * Cinp,), torch.float32)
@@ -393,11 +411,11 @@ class Plan(object):
                 self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
                                                 "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp)))})
                 if padded:
-                    self._emit(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
-                               Cinp, 0)
+                    self._emit_side(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
+                                    Cinp, 0)
                 beta = x.meta.get("input_bn_beta")
                 if stem and beta is not None and beta.trainable:
-                    self._emit(self.bwd, "stp_stem_beta_grad", dwp.data_ptr(), self._pptr(w), self._gptr(beta), Cout, k, k,
+                    self._emit_side(self.bwd, "stp_stem_beta_grad", dwp.data_ptr(), self._pptr(w), self._gptr(beta), Cout, k, k,
                                real_c0, KWp, Cinp, real_c0)
             if b is not None and b.trainable:
                 tmp = self._alloc((CoutB,), torch.float32)
@@ -494,11 +512,36 @@ class Plan(object):
     def run(self, launches):
         if self.device.type != "cuda":
             raise _lib.StpError("plans execute on the GPU only (no CPU fallback)")
-        st = torch.cuda.current_stream().cuda_stream
-        for fn, args, name, _meta in launches:
-            rc = fn(*args, st)
+        main = torch.cuda.current_stream()
+        st = main.cuda_stream
+        side, forked = None, False
+        for fn, args, name, meta in launches:
+            if fn is None:                      # stream markers of the weight-gradient side chain
+                if name == "fork" and self.side_stream_wgrad:
+                    side = self._side_stream()
+                    side.wait_stream(main)      # everything issued so far (dY of this layer) is visible to the side chain
+                    forked = True
+                elif name == "join" and forked:
+                    main.wait_stream(side)
+                    forked = False
+                continue
+            s = st
+            if meta is not None and meta.get("stream") and self.side_stream_wgrad:
+                if not forked:                  # a launch list cut between fork and its side launches (graph segments)
+                    side = self._side_stream()
+                    side.wait_stream(main)
+                    forked = True
+                s = side.cuda_stream
+            rc = fn(*args, s)
             if rc != 0:
                 _lib.check(rc, name)
+        if forked:
+            main.wait_stream(side)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def init_states(self):
         for name, (off, numel, init) in self.states.items():
