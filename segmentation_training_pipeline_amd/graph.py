@@ -93,6 +93,7 @@ class Plan(object):
         # tails of the other's GEMMs (captured into the same hipGraph as a fork/join)
         self.side_stream_wgrad = os.environ.get("STP_SIDE_STREAM_WGRAD", "1") != "0"
         self._side = None
+        self._side_reads = set()
         self.loss_scalars = None
         self.inputs = {}
 
@@ -195,8 +196,13 @@ class Plan(object):
         return t
 
     def _gradbuf(self, t):
+        """Gradient buffer of ``t`` for a main-stream kernel that is about to WRITE it.  If a weight-gradient chain
+        still in flight on the side stream reads that buffer (a dY aliased as a residual gradient), join first."""
         if t.grad is None:
             t.grad = self._alloc((t.N, t.H, t.W, t.gradC))
+        if self._side_reads and t.grad.data_ptr() in self._side_reads:
+            self._mark(self.bwd, "join")
+            self._side_reads.clear()
         return t.grad
 
     @staticmethod
@@ -387,9 +393,11 @@ class Plan(object):
                 return
             dy = out.grad
             rows = out.rows
-            # the previous layer's weight-gradient chain (side stream) must be done before this layer's main-stream
-            # kernels: they may accumulate into a buffer it reads (dY aliased as a residual gradient two layers up)
+            # lag-1 join: the previous convolution's weight-gradient chain finishes before this layer's kernels start.
+            # (Letting the side chain fall further behind - joining only on a buffer hazard, see _gradbuf - measured
+            # SLOWER, 11.15 vs 10.88 ms/step: the chain then reads dY / x long after the main chain left them in L2.)
             self._mark(self.bwd, "join")
+            self._side_reads.clear()
             # residual branch: d(residual) = dY
             if residual is not None and residual.needs_grad:
                 if not residual.grad_ready and residual.gradC == out.gradC:
@@ -398,9 +406,11 @@ class Plan(object):
                 else:
                     self._emit(self.bwd, "stp_add_inplace", self._gradbuf(residual).data_ptr(), dy.data_ptr(),
                                rows * out.gradC, self.cdt)
-            # weight gradient: on the side stream, forked here (dY is final), joined at the next convolution's backward
+            # weight gradient: on the side stream, forked here (dY is final); joined before any kernel rewrites dY (_gradbuf)
+            # and at the end of the launch list
             if w.trainable:
                 self._mark(self.bwd, "fork")
+                self._side_reads.add(dy.data_ptr())     # see _gradbuf: the only buffer of the chain that is ever rewritten
                 padded = stem or CoutB != Cout
                 if padded:
                     dwp = self._alloc((CoutB * k * KWp * Cinp,), torch.float32)
