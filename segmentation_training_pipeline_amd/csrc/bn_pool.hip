@@ -574,87 +574,104 @@ extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int
 // ------------------------------------------------------------------------------------------
 // ZeroPadding2D(1) + MaxPooling2D(3, 2, valid).  idx[n,ho,wo,c] = kh*3+kw of the first maximum
 // (padded taps take part with value 0, as in the Keras graph).
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
                                                           int N, int H, int W, int C, int Ho, int Wo) {
-  const int cg = C >> 2;
-  const int64_t total = (int64_t)N * Ho * Wo * cg;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % cg) * 4;
-    int64_t p = i / cg;
-    const int wo = (int)(p % Wo); p /= Wo;
-    const int ho = (int)(p % Ho);
-    const int n = (int)(p / Ho);
-    f32x4 best = {0.f, 0.f, 0.f, 0.f};
-    int bi[4] = {0, 0, 0, 0};
-    bool firstTap = true;
+  const int cg = C / V;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cg) return;
+  const int wo = t / cg, c = (t - wo * cg) * V;
+  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  float best[V];
+  uint8_t bi[V];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+  for (int e = 0; e < V; ++e) { best[e] = 0.f; bi[e] = 0; }
+  bool firstTap = true;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = ld4<T>(x + (((int64_t)n * H + h) * W + w) * C + c);
+  for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (firstTap || v[e] > best[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
-        firstTap = false;
-      }
-    store4(y + i * 4, best);
-    if (idx) *reinterpret_cast<uint32_t*>(idx + i * 4) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    for (int kw = 0; kw < 3; ++kw) {
+      const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
+      float v[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = 0.f;      // padded taps take part with value 0, as in the Keras graph
+      if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ldv<T, V>(x + (((size_t)n * H + h) * W + w) * C + c, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+        if (firstTap || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)(kh * 3 + kw); }
+      firstTap = false;
+    }
+  const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+  stv<T, V>(y + o, best);
+  if (idx) {
+    if constexpr (V == 8) *reinterpret_cast<uint2*>(idx + o) = *reinterpret_cast<const uint2*>(bi);
+    else *reinterpret_cast<uint32_t*>(idx + o) = *reinterpret_cast<const uint32_t*>(bi);
   }
 }
 
-template <typename T>
+// One workgroup row per input row (blockIdx.y = n*H + h): 32-bit index arithmetic only, V channels per thread
+// (16 bytes of bf16), each input pixel gathers from the <= 4 windows that contain it.
+template <typename T, int V>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
                                                           T* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo,
                                                           int accumulate) {
-  const int cg = C >> 2;
-  const int64_t total = (int64_t)N * H * W * cg;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % cg) * 4;
-    int64_t p = i / cg;
-    const int w = (int)(p % W); p /= W;
-    const int h = (int)(p % H);
-    const int n = (int)(p / H);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    // windows (ho,wo) with 2*ho-1+kh == h  ->  kh = h+1-2*ho in [0,2]
+  const int cg = C / V;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cg) return;
+  const int w = t / cg, c = (t - w * cg) * V;
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  float g[V];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int hh = h + 1 - kh;
-      if (hh < 0 || (hh & 1)) continue;
-      const int ho = hh >> 1;
-      if (ho >= Ho) continue;
+  for (int e = 0; e < V; ++e) g[e] = 0.f;
+  // windows (ho,wo) with 2*ho-1+kh == h  ->  kh = h+1-2*ho in [0,2]
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ww = w + 1 - kw;
-        if (ww < 0 || (ww & 1)) continue;
-        const int wo = ww >> 1;
-        if (wo >= Wo) continue;
-        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
-        const uint32_t id = *reinterpret_cast<const uint32_t*>(idx + o);
-        const f32x4 d = ld4<T>(dy + o);
-        const uint32_t me = (uint32_t)(kh * 3 + kw);
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hh = h + 1 - kh;
+    if (hh < 0 || (hh & 1)) continue;
+    const int ho = hh >> 1;
+    if (ho >= Ho) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (((id >> (8 * e)) & 0xff) == me) g[e] += d[e];
-      }
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = w + 1 - kw;
+      if (ww < 0 || (ww & 1)) continue;
+      const int wo = ww >> 1;
+      if (wo >= Wo) continue;
+      const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+      uint8_t id[V];
+      if constexpr (V == 8) *reinterpret_cast<uint2*>(id) = *reinterpret_cast<const uint2*>(idx + o);
+      else *reinterpret_cast<uint32_t*>(id) = *reinterpret_cast<const uint32_t*>(idx + o);
+      float d[V];
+      ldv<T, V>(dy + o, d);
+      const uint8_t me = (uint8_t)(kh * 3 + kw);
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+        if (id[e] == me) g[e] += d[e];
     }
-    if (accumulate) g += ld4<T>(dx + i * 4);
-    store4(dx + i * 4, g);
   }
+  T* out = dx + (((size_t)n * H + h) * W + w) * C + c;
+  if (accumulate) {
+    float o[V];
+    ldv<T, V>(out, o);
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] += o[e];
+  }
+  stv<T, V>(out, g);
 }
 
 extern "C" int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C,
                                 int32_t dtype, void* stream) {
   if (!x || !y || (C & 3) || N <= 0) return STP_E_BADARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int g = grid_for((int64_t)N * Ho * Wo * (C >> 2));
+  if ((int64_t)N * Ho > 65535) return STP_E_BADARG;  // gridDim.y
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const dim3 grid(ceil_div(Wo * (C / (v8 ? 8 : 4)), 256), N * Ho);
+  if (v8)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C, Ho, Wo);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -665,12 +682,16 @@ extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx
                                     int32_t dtype, int32_t accumulate, void* stream) {
   if (!idx || !dy || !dx || (C & 3) || N <= 0) return STP_E_BADARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int g = grid_for((int64_t)N * H * W * (C >> 2));
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
+  if ((int64_t)N * H > 65535) return STP_E_BADARG;  // gridDim.y
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
+  if (v8)
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), grid, dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -679,33 +700,44 @@ extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx
 
 // ------------------------------------------------------------------------------------------
 // gradient of UpSampling2D(2): dy is [N,2H,2W,ldy] (first C channels used), dx [N,H,W,C]
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
                                                              int C, int ldy, int accumulate) {
-  const int cg = C >> 2;
-  const int64_t total = (int64_t)N * H * W * cg;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % cg) * 4;
-    int64_t p = i / cg;
-    const int w = (int)(p % W); p /= W;
-    const int h = (int)(p % H);
-    const int n = (int)(p / H);
-    const T* b = dy + (((int64_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * ldy + c;
-    f32x4 g = ld4<T>(b) + ld4<T>(b + ldy) + ld4<T>(b + (int64_t)2 * W * ldy) + ld4<T>(b + (int64_t)2 * W * ldy + ldy);
-    if (accumulate) g += ld4<T>(dx + i * 4);
-    store4(dx + i * 4, g);
+  const int cg = C / V;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cg) return;
+  const int w = t / cg, c = (t - w * cg) * V;
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  const T* b = dy + (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * ldy + c;
+  float g[V], a1[V], a2[V], a3[V];
+  ldv<T, V>(b, g);
+  ldv<T, V>(b + ldy, a1);
+  ldv<T, V>(b + (size_t)2 * W * ldy, a2);
+  ldv<T, V>(b + (size_t)2 * W * ldy + ldy, a3);
+#pragma unroll
+  for (int e = 0; e < V; ++e) g[e] = ((g[e] + a1[e]) + a2[e]) + a3[e];
+  T* out = dx + (((size_t)n * H + h) * W + w) * C + c;
+  if (accumulate) {
+    float o[V];
+    ldv<T, V>(out, o);
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] += o[e];
   }
+  stv<T, V>(out, g);
 }
 
 extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,
                                   int32_t dtype, int32_t accumulate, void* stream) {
-  if (!dy || !dx || (C & 3) || (ldy & 3) || ldy < C) return STP_E_BADARG;
-  const int g = grid_for((int64_t)N * H * W * (C >> 2));
+  if (!dy || !dx || (C & 3) || (ldy & 3) || ldy < C || (int64_t)N * H > 65535) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16)
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate);
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0 && (ldy & 7) == 0;
+  const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
+  if (v8)
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate);
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
