@@ -91,6 +91,11 @@ typedef struct stp_conv_params {
   const float* bnb_gamma; /* NULL: scale=False */
   const float* bnb_beta;  /* NULL: center=False */
   int32_t bnb_relu;
+  /* Gradient of UpSampling2D(2) folded into the epilogue of the data-gradient convolution whose (virtual) destination
+   * is the upsampled tensor: with dst_sum2x2 != 0, dst0 is [N,Ho/2,Wo/2,Cout] and receives the sum of each 2x2 block
+   * (the hi-res gradient is never written); bnb_x / stats_partial / accumulate0 then refer to that low-resolution
+   * tensor.  Small-channel kernel only (stp_conv2d_sc_eligible), Ho and Wo even, no bias / relu. */
+  int32_t dst_sum2x2;
 } stp_conv_params;
 
 int stp_conv2d(const stp_conv_params* p, void* stream);

@@ -27,7 +27,8 @@ class ConvParams(C.Structure):
                 ("Ho", i32), ("Wo", i32), ("Cout", i32), ("Cd0", i32),
                 ("accumulate0", i32), ("accumulate1", i32), ("relu", i32), ("dtype", i32), ("tile", i32),
                 ("stats_tiles", i32), ("stats_partial", vp),
-                ("bnb_x", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_gamma", vp), ("bnb_beta", vp), ("bnb_relu", i32)]
+                ("bnb_x", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_gamma", vp), ("bnb_beta", vp), ("bnb_relu", i32),
+                ("dst_sum2x2", i32)]
 
 
 class WgradParams(C.Structure):

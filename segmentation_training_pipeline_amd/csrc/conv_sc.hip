@@ -23,6 +23,7 @@ struct ScArgs {
   int tiles_x, tiles_y;
   float* stats;        // optional fused BatchNorm statistics [2][Cout][tiles]
   BnBack bnb;          // see stp_conv_params.bnb_x
+  int sum2;            // see stp_conv_params.dst_sum2x2: dst is [N,H/2,W/2,Cout]
 };
 
 __device__ __forceinline__ f32x4 sc_stored(f32x4 v, const float*) { return v; }
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
     }
   }
   __syncthreads();
+  float* red = reinterpret_cast<float*>(halo + SC_HH * SC_HW * PIXB);  // [4][TM*16][2] behind the halo tile
+  // (A variant that looped over 16-channel passes of the same halo tile to cut registers - 5 instead of 3 waves/SIMD for
+  //  Cout = 32 - measured slower: the weights then load after the barrier instead of under the halo staging.)
+  constexpr int cb = 0;
 
   // ---- MFMAs: wave w owns tile rows 2w, 2w+1; 4 fragments of 16 pixels -------------------------
   f32x4 acc[TM][4];
@@ -124,6 +129,42 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
   f32x4 ss[TM], qq[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // per-channel BatchNormalization constants of this lane's channels: fetched once, not per fragment.  (Prefetching
+  // the x values themselves at kernel start was tried and lost 20-30 %: the extra registers cost occupancy, which is
+  // what hides latency in these single-shot workgroups.)
+  BnBackCh bks[TM];
+  if (a.bnb.x) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      if (cb + i * 16 + lg * 4 < a.Cout) bks[i] = bnback_load(a.bnb, cb + i * 16 + lg * 4);
+  }
+  if (a.sum2) {
+    // gradient of UpSampling2D(2): the wave's two tile rows are one output row (fragments f and f+2, same lane), lanes
+    // lr and lr^1 one output column (quad_perm DPP); even lanes own the low-resolution pixel
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int gy = y0 + wave * 2, gx = x0 + h2 * 16 + lr;
+      const bool own = !(lr & 1) && gy < a.H && gx < a.W;
+      const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int co = cb + i * 16 + lg * 4;
+        f32x4 v = acc[i][h2] + acc[i][h2 + 2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+        if (!own || co >= a.Cout) continue;
+        T* d = out + pm * a.Cout + co;
+        if (a.accumulate) v += load4(d);
+        if (a.bnb.x) {
+          const f32x4 xv = load4(reinterpret_cast<const T*>(a.bnb.x) + pm * a.Cout + co);
+          v = bnback_apply(bks[i], a.bnb.relu, xv, sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
+        }
+        store4(d, v);
+      }
+    }
+  } else
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
@@ -131,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
     const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int co = i * 16 + lg * 4;
+      const int co = cb + i * 16 + lg * 4;
       if (co >= a.Cout) continue;
       f32x4 v = acc[i][f];
       if (co + 3 < a.Cout) {
@@ -140,9 +181,8 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
         if (a.accumulate) v += load4(d);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (a.bnb.x) {
-          const BnBackCh bk = bnback_load(a.bnb, co);
           const f32x4 xv = load4(reinterpret_cast<const T*>(a.bnb.x) + pm * a.Cout + co);
-          v = bnback_apply(bk, a.bnb.relu, xv, sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
+          v = bnback_apply(bks[i], a.bnb.relu, xv, sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
         }
         store4(d, v);
         if (a.stats && !a.bnb.x) {
@@ -164,8 +204,6 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
   }
   if (a.stats) {
     // butterfly over the 16 pixel lanes, then the 4 waves (same channels, different rows) through LDS
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(halo);  // [4][TM*16][2]
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -178,19 +216,19 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
         }
       }
     __syncthreads();
-    if (tid < TM * 16 && tid < a.Cout) {
+    if (tid < TM * 16 && cb + tid < a.Cout) {
       float sv = 0.f, qv = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { sv += red[(w * TM * 16 + tid) * 2]; qv += red[(w * TM * 16 + tid) * 2 + 1]; }
-      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][tile]
-      a.stats[((size_t)a.Cout + tid) * gridDim.x + blockIdx.x] = qv;
+      a.stats[(size_t)(cb + tid) * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][tile]
+      a.stats[((size_t)a.Cout + cb + tid) * gridDim.x + blockIdx.x] = qv;
     }
   }
 }
 
 template <typename T, int CIN, int TM>
 static int launch_sc(const ScArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)SC_HH * SC_HW * CIN * sizeof(T);
+  const size_t lds = (size_t)SC_HH * SC_HW * CIN * sizeof(T) + 4 * TM * 16 * 2 * sizeof(float);
   hipLaunchKernelGGL((conv_sc_kernel<T, CIN, TM>), dim3(a.N * a.tiles_x * a.tiles_y), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
@@ -235,7 +273,9 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   if (a.stats && (p->Cout & 3)) return STP_E_BADARG;
   a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
   a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
-  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->accumulate0 || p->relu)) return STP_E_BADARG;
+  a.sum2 = p->dst_sum2x2;
+  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || (p->accumulate0 && !a.sum2) || p->relu)) return STP_E_BADARG;
+  if (a.sum2 && ((p->Cout & 3) || (a.H & 1) || (a.W & 1) || p->bias || p->relu || (a.stats && !a.bnb.x))) return STP_E_BADARG;
   const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
   hipStream_t s = (hipStream_t)stream;
   return p->dtype == STP_BF16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);

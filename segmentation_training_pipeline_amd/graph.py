@@ -92,6 +92,7 @@ class Plan(object):
         # + BatchNormalization-backward chain of the same layer: the small latency-bound kernels of one chain fill the
         # tails of the other's GEMMs (captured into the same hipGraph as a fork/join)
         self.side_stream_wgrad = os.environ.get("STP_SIDE_STREAM_WGRAD", "1") != "0"
+        self.fold_upsample_grad = os.environ.get("STP_FOLD_UPSAMPLE_GRAD", "1") != "0"
         self._side = None
         self._side_reads = set()
         self.loss_scalars = None
@@ -454,8 +455,19 @@ class Plan(object):
                 if stride not in (1, 2):
                     raise StpShapeError("data gradient supports stride 1 and 2")
                 bnm = x.meta.get("bn")
-                if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses") == 1 and not upsample and C1 == 0
-                        and x_ng and not acc0 and C0 % 4 == 0):
+                folded_up = False
+                if upsample and x_ng and C1 == 0 and self.fold_upsample_grad:
+                    # the small-channel kernel sums each 2x2 block in its epilogue: the hi-res gradient of the upsampled
+                    # tensor is never written and stp_upsample2x_bwd disappears
+                    q.dst_sum2x2 = 1
+                    if self.lib.stp_conv2d_sc_eligible(C.byref(q)) and C0 % 4 == 0:
+                        folded_up = True
+                        q.dst0 = self._gradbuf(x).data_ptr()
+                        q.accumulate0 = int(x.grad_ready)
+                    else:
+                        q.dst_sum2x2 = 0
+                if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses") == 1 and (folded_up or not upsample) and C1 == 0
+                        and x_ng and not q.accumulate0 and C0 % 4 == 0):
                     q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
                     nfl = int(self.lib.stp_conv2d_stats_floats(C.byref(q)))
                     st = self._alloc((max(nfl, 4),), torch.float32)
@@ -463,7 +475,7 @@ class Plan(object):
                     x.meta["bnb"] = (st, q)
                 self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": flops,
                                               "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
-                if upsample and x_ng:
+                if upsample and x_ng and not folded_up:
                     self._emit(self.bwd, "stp_upsample2x_bwd", d0.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W,
                                C0, C0, self.cdt, int(x.grad_ready))
                 if x_ng:

@@ -413,6 +413,58 @@ def test_batchnorm_backward_sums_fused_in_conv_epilogue(ops, dtype, case, relu):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
+def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
+    """stp_conv_params.dst_sum2x2: the data-gradient convolution of an UpSampling2D(2) input writes the 2x2 block sums
+    at low resolution; must equal convolution at high resolution followed by stp_upsample2x_bwd (and, with bnb_x, by the
+    unfused BatchNormalization backward)."""
+    n, h, w, ci, co = 2, 18, 44, 16, 32          # virtual (upsampled) size; ragged 8x32 tiles
+    rng = np.random.RandomState(21)
+    src = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    sd = dev(src, dtype)
+    mk = lambda dst: ops.conv_params(sd, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
+                                     Cout=co, dtype=ops.dt(dst), tile=512)
+    hi = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
+    ops.conv2d(mk(hi))
+    base = q(rng.randn(n, h // 2, w // 2, co), dtype)
+    want = dev(base, dtype) if mode == "accumulate" else torch.empty((n, h // 2, w // 2, co), dtype=TD[dtype], device=DEV)
+    ops.upsample2x_bwd(hi, want, n, h // 2, w // 2, co, co, accumulate=int(mode == "accumulate"))
+    got = dev(base, dtype) if mode == "accumulate" else torch.full((n, h // 2, w // 2, co), float("nan"), dtype=TD[dtype], device=DEV)
+    P = mk(got)
+    P.dst_sum2x2 = 1
+    P.accumulate0 = int(mode == "accumulate")
+    if mode != "bn_backward":
+        ops.conv2d(P)
+        # bf16: the unfused path rounds the hi-res gradient to bf16 before summing, the fused one sums in fp32
+        np.testing.assert_allclose(host(got), host(want), atol=tol(host(want), dtype, 1.0 if dtype == "bf16" else 0.05))
+        return
+    rows = n * (h // 2) * (w // 2)
+    x = dev(q(rng.randn(n, h // 2, w // 2, co) + 0.2, dtype), dtype)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    g, b = f(rng.rand(co) + 0.5), f(rng.randn(co) * 0.3)
+    m, r = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(co) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(x, rows, co, 1e-3, 0.99, m, r, None, None, ws)
+    dx0, dg0, db0 = torch.empty_like(want), torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ops.bn_backward(x, want, dx0, rows, co, m, r, g, b, dg0, db0, relu=1, accumulate_dx=0, workspace=ws)
+    P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(x), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1
+    st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    tiles = ops.conv2d_stats_floats(P) // (2 * co)
+    dx1, dg1, db1 = torch.empty_like(want), torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ops.bn_backward_fused(x, got, dx1, rows, co, m, r, g, st, tiles, dg1, db1, accumulate_dx=0, workspace=ws)
+    k = 1.0 if dtype == "bf16" else 0.05
+    np.testing.assert_allclose(host(db1), host(db0), atol=(2e-2 if dtype == "bf16" else 1e-3) * np.abs(host(db0)).max() + 1e-3)
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=(2e-2 if dtype == "bf16" else 1e-3) * np.abs(host(dg0)).max() + 1e-3)
+    pre = host(x) * (host(r) * host(g)) + (host(b) - host(m) * host(r) * host(g))
+    safe = np.abs(pre) > 1e-3
+    np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, k))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_input_batchnorm_uint8_to_padded4(ops, dtype):
     rng = np.random.RandomState(11)
     n, h, w = 2, 16, 18
