@@ -152,9 +152,13 @@ def test_plan_structure_matches_unet_resnet34():
     assert bnames.count("stp_conv2d_wgrad") == 48 and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
     assert bnames.count("stp_conv2d_wgrad_reduce") == 48
     # BatchNormalization outputs read by exactly one convolution get their backward sums from that convolution's
-    # data-gradient epilogue: 16 bn2 + 12 bn1 of the non-first units + 5 decoder bn1 + the last decoder bn2
+    # data-gradient epilogue: 16 bn2 + 12 bn1 of the non-first units + 5 decoder bn1 + the last decoder bn2, plus
+    # decoder_stage3_bn2 whose consumer's data-gradient folds the UpSampling2D gradient (dst_sum2x2, small-channel kernel)
     assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward") == 44
-    assert bnames.count("stp_bn_backward_fused") == 34
+    assert bnames.count("stp_bn_backward_fused") == 35
+    assert bnames.count("stp_upsample2x_bwd") == 4          # 5 decoder stages, one folded
+    # weight-gradient chains run on the side stream: one fork per trainable convolution, joins at the next one
+    assert bnames.count("fork") == 48 and bnames.count("join") == 48
     assert "stp_add_inplace" not in bnames                             # every residual gradient aliases
     fl = sum(m["flops"] for _, _, _, m in plan.fwd if m)
     assert abs(fl / 2 / (2 * 1e6) - 31323 * (64 * 64) / (512 * 512)) < 2.0   # 31.3 GMAC/img at 512^2
