@@ -14,6 +14,10 @@ import torch
 
 from . import distributed, graph, nets
 
+# hipGraph capture must not be invalidated by HIP calls of OTHER threads (the RCCL watchdog of torch.distributed polls
+# events while a rank captures its step): thread-local capture mode
+CAPTURE_MODE = "thread_local"
+
 SCALAR_NAMES = ("loss", "binary_crossentropy", "dice_loss", "dice", "binary_accuracy")
 
 
@@ -240,7 +244,7 @@ class HipSegModel(object):
         segs = self._dp_segments()
         if segs is None:
             gfb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gfb):
+            with torch.cuda.graph(gfb, capture_error_mode=CAPTURE_MODE):
                 p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
             self._graphs = {"fb": gfb, "opt": gopt}
         else:
@@ -248,14 +252,14 @@ class HipSegModel(object):
             gs, a = [], 0
             for i, (b, _) in enumerate(segs):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     if i == 0:
                         p.run(p.prep); p.run(p.fwd)
                     p.run(p.bwd[a:b])
                 gs.append(g)
                 a = b
             self._graphs = {"segs": gs, "opt": gopt}
-        with torch.cuda.graph(gopt):
+        with torch.cuda.graph(gopt, capture_error_mode=CAPTURE_MODE):
             p.run(p.opt)
 
     def _dp_segments(self):
