@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 C=segmentation_training_pipeline_amd/csrc
-for n in 1 2; do
+for n in ${EXPS:-1 2 3}; do
   for f in conv_igemm conv_wgrad; do
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Iinclude -DSTP_EXP=$n -c $C/$f.hip -o scratch/_exp/${f}_exp$n.o &
   done

@@ -75,6 +75,16 @@ __device__ __forceinline__ void compute_tile(const char* stage, int wm, int wn, 
   // next to their users to save registers, exposing one LDS round trip per four MFMAs); the s_waitcnt counters
   // it inserts then release the first 64-byte chunk while the second is still in flight
   u32x4 fa[2][TM], fb[2][TN];
+#if defined(STP_EXP) && STP_EXP == 3  // what-if: no LDS fragment reads either (pure MFMA issue rate)
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[c][i] = u32x4{(uint32_t)lr, (uint32_t)lg, (uint32_t)c, (uint32_t)i};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[c][j] = u32x4{(uint32_t)lg, (uint32_t)lr, (uint32_t)j, (uint32_t)c};
+  }
+  asm volatile("" ::: "memory");
+#else
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -88,6 +98,7 @@ __device__ __forceinline__ void compute_tile(const char* stage, int wm, int wn, 
       fb[c][j] = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
     }
   }
+#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     else if (STAGES >= 4 && ahead == 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // tile kt visible to every wave; the buffer of tile kt-1 is free
-#if !defined(STP_EXP) || STP_EXP != 2  // (what-if builds of scratch/exp_build.sh: 1 = no MFMA work, 2 = no loads in the loop)
+#if !defined(STP_EXP) || (STP_EXP != 2 && STP_EXP != 3)  // (what-if builds of scratch/exp_build.sh: 1 = no MFMA work, 2 = no loads in the loop, 3 = 2 + no LDS reads)
     if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1, nbuf);
 #endif
 #if !defined(STP_EXP) || STP_EXP != 1
