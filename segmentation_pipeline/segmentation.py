@@ -112,51 +112,110 @@ class PipelineConfig(generic.GenericTaskConfig):
     def get_eval_batch(self):
         return self.inference_batch
 
-    # ---------------------------------------------------------------- inference to disk (reference :62-79)
-    def predict_on_directory(self, spath, fold=0, stage=0, limit=-1, batch_size=32, ttflips=False):
-        from segmentation_pipeline.impl.datasets import DirectoryDataSet
+    # ---------------------------------------------------------------- inference (reference :62-91, :158-191)
+    def _models(self, fold, stage):
+        folds = fold if isinstance(fold, (list, tuple)) else [fold]
+        return [self.load_model(f, stage) for f in folds]
+
+    def _resize_to_net(self, impl, images):
+        """uint8 HxWx3 images of any size -> uint8 [n, H, W, 3] at the network shape (stp_augment_u8, identity + resize)."""
         from segmentation_training_pipeline_amd import ops
         import torch
-        folds = fold if isinstance(fold, (list, tuple)) else [fold]
-        nets_ = [self.load_model(f, stage) for f in folds]
+        H, W = int(self.shape[0]), int(self.shape[1])
+        xs = np.zeros((len(images), H, W, 3), np.uint8)
+        for i, img in enumerate(images):
+            h, w = img.shape[:2]
+            prm = torch.from_numpy(generic.augment.identity_batch(1, h, w, (H, W))).to(impl.device)
+            src = torch.from_numpy(np.ascontiguousarray(img)).to(impl.device)
+            dst = torch.empty((1, H, W, 3), dtype=torch.uint8, device=impl.device)
+            ops.augment_u8(src, None, dst, None, prm, 1, h, w, H, W, 3)
+            xs[i] = dst[0].cpu().numpy()
+        return xs
+
+    def predict_on_batch(self, models, ttflips, xs):
+        """Mean of the fold models' probabilities, optionally with flip test-time augmentation (README.md:519-534).
+        ``models``: one model or a list; ``xs``: uint8 [n, H, W, 3] at the network shape, n <= inference batch."""
+        models = models if isinstance(models, (list, tuple)) else [models]
+        acc = np.zeros((len(xs),) + tuple(int(v) for v in self.shape[:2]) + (self.classes,), np.float32)
+        k = 0
+        for m in models:
+            acc += m.predict(xs); k += 1
+            if ttflips:
+                acc += m.predict(xs[:, :, ::-1])[:, :, ::-1]; k += 1
+                acc += m.predict(xs[:, ::-1])[:, ::-1]; k += 1
+        return acc / k
+
+    @staticmethod
+    def _scale_back(p, h, w):
+        """Prediction at the network shape -> original image size (nearest, like the reference's Scale of a map)."""
+        yy = (np.arange(h) * p.shape[0] // h)[:, None]
+        xx = (np.arange(w) * p.shape[1] // w)[None, :]
+        return p[yy, xx]
+
+    def predict_on_directory(self, spath, fold=0, stage=0, limit=-1, batch_size=32, ttflips=False):
+        from segmentation_pipeline.impl.datasets import DirectoryDataSet
+        nets_ = self._models(fold, stage)
         ds = DirectoryDataSet(spath)
         n = len(ds) if limit < 0 else min(limit, len(ds))
-        H, W = int(self.shape[0]), int(self.shape[1])
         impl0 = nets_[0].impl
         B = impl0.batch
         for s in range(0, n, B):
             items = [ds[i] for i in range(s, min(s + B, n))]
-            xs = np.zeros((len(items), H, W, 3), np.uint8)
-            for i, it in enumerate(items):          # Resize to the network shape on the device
-                h, w = it.x.shape[:2]
-                prm = torch.from_numpy(generic.augment.identity_batch(1, h, w, (H, W))).to(impl0.device)
-                src = torch.from_numpy(np.ascontiguousarray(it.x)).to(impl0.device)
-                dst = torch.empty((1, H, W, 3), dtype=torch.uint8, device=impl0.device)
-                ops.augment_u8(src, None, dst, None, prm, 1, h, w, H, W, 3)
-                xs[i] = dst[0].cpu().numpy()
-            acc = np.zeros((len(items), H, W, self.classes), np.float32)
-            k = 0
-            for m in nets_:
-                acc += m.predict(xs); k += 1
-                if ttflips:                          # flip test-time augmentation (README.md:534)
-                    acc += m.predict(xs[:, :, ::-1])[:, :, ::-1]; k += 1
-                    acc += m.predict(xs[:, ::-1])[:, ::-1]; k += 1
-            yield items, acc / k
+            xs = self._resize_to_net(impl0, [it.x for it in items])
+            yield items, self.predict_on_batch(nets_, ttflips, xs)
 
     def predict_to_directory(self, spath, tpath, fold=0, stage=0, limit=-1, batchSize=32, binaryArray=False, ttflips=False):
         os.makedirs(tpath, exist_ok=True)
         from PIL import Image
         for items, probs in self.predict_on_directory(spath, fold=fold, stage=stage, limit=limit, batch_size=batchSize, ttflips=ttflips):
             for it, p in zip(items, probs):
-                h, w = it.x.shape[:2]
-                yy = (np.arange(h) * p.shape[0] // h)[:, None]
-                xx = (np.arange(w) * p.shape[1] // w)[None, :]
-                scaled = p[yy, xx]                    # back to the original image size
+                scaled = self._scale_back(p, *it.x.shape[:2])
                 stem = it.id[0:it.id.index(".")] if "." in it.id else it.id
                 if binaryArray:
                     np.save(os.path.join(tpath, stem), scaled)
                 else:
                     Image.fromarray((scaled[:, :, 0] * 255).astype(np.uint8)).save(os.path.join(tpath, stem + ".png"))
+
+    def predict_in_directory(self, spath, fold, stage, cb=None, data=None, limit=-1, batchSize=32, ttflips=False):
+        """Calls ``cb(file_name, map, data)`` per image with ``map.arr`` = probabilities at the ORIGINAL image size
+        (reference :81-91; README.md:498-527).  ``fold`` may be a list (ensemble).  The README's ensembling example
+        omits ``stage`` (``predict_in_directory(path, folds, cb, data)``): that call shape is accepted too."""
+        if callable(stage):
+            stage, cb, data = 0, stage, cb
+        for items, probs in self.predict_on_directory(spath, fold=fold, stage=stage, limit=limit, batch_size=batchSize, ttflips=ttflips):
+            for it, p in zip(items, probs):
+                cb(it.id, PredictedMap(self._scale_back(p, *it.x.shape[:2])), data)
+
+    def evaluateAll(self, ds, fold, stage=-1, negatives="real", ttflips=None):
+        """Iterator over validation batches of ``fold`` (reference :158-191): each carries the original ``images``,
+        ``data`` (ids), ``segmentation_maps`` (ground truth) and ``predicted_maps_aug`` (probabilities, original size)."""
+        folds = self.kfold(ds, range(0, len(ds)))
+        indexes = [int(i) for i in folds.sampledIndexes(fold, False, negatives)]
+        m = self.load_model(fold, stage)
+        B = m.impl.batch
+        for s in range(0, len(indexes), B):
+            items = [ds[i] for i in indexes[s:s + B]]
+            xs = self._resize_to_net(m.impl, [it.x for it in items])
+            probs = self.predict_on_batch(m, ttflips, xs)
+            yield EvalBatch(images=[it.x for it in items], data=[it.id for it in items],
+                            segmentation_maps=[PredictedMap(np.asarray(it.y)) for it in items],
+                            predicted_maps_aug=[PredictedMap(self._scale_back(p, *it.x.shape[:2])) for it, p in zip(items, probs)])
+
+
+class PredictedMap(object):
+    """What callbacks receive in place of imgaug's SegmentationMapOnImage: ``.arr`` is the HxWxC array."""
+
+    def __init__(self, arr):
+        self.arr = arr
+        self.shape = arr.shape
+
+
+class EvalBatch(object):
+    """Stand-in for imgaug.Batch as produced by evaluateAll (reference :184-186)."""
+
+    def __init__(self, images, data, segmentation_maps, predicted_maps_aug):
+        self.images, self.data = images, data
+        self.segmentation_maps, self.predicted_maps_aug = segmentation_maps, predicted_maps_aug
 
 
 def parse(path) -> PipelineConfig:

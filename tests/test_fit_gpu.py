@@ -64,3 +64,22 @@ def test_parse_fit_predict_end_to_end(tmp_path):
     assert p.shape == (128, 128) and p.dtype == np.uint8
     m = np.asarray(Image.open(os.path.join(msk_dir, "s00.png"))) > 0
     assert p[m].mean() > p[~m].mean()                                       # foreground scores higher than background
+    # callback form + fold ensembling + flip TTA (README.md:498-534); probabilities arrive at the original size
+    seen = {}
+    cfg.predict_in_directory(img_dir, [0], 1, lambda name, mp, data: data.__setitem__(name, mp.arr), seen, ttflips=True)
+    assert sorted(seen) == sorted(os.listdir(img_dir)) and seen["s00.png"].shape == (128, 128, 1)
+    assert seen["s00.png"][m].mean() > seen["s00.png"][~m].mean()
+    plain = {}
+    cfg.predict_in_directory(img_dir, 0, lambda name, mp, data: data.__setitem__(name, mp.arr), plain)    # README call shape (no stage)
+    assert sorted(plain) == sorted(seen)
+    # evaluateAll: validation batches of the fold with ground truth and predictions (reference :158-191)
+    from segmentation_pipeline.impl.rle import rle_encode, rle_decode
+    n_val, dices = 0, []
+    for b in cfg.evaluateAll(ds, 0, stage=1):
+        assert len(b.images) == len(b.data) == len(b.segmentation_maps) == len(b.predicted_maps_aug)
+        for gt, pr in zip(b.segmentation_maps, b.predicted_maps_aug):
+            g, p1 = gt.arr.reshape(128, 128) > 0, pr.arr[:, :, 0] > 0.5
+            dices.append(2.0 * (g & p1).sum() / max(1, g.sum() + p1.sum()))
+            assert np.array_equal(rle_decode(rle_encode(p1), (128, 128)) > 0, p1)     # the submission helper round-trips
+            n_val += 1
+    assert n_val == 4 and np.mean(dices) > 0.2      # 8 epochs on 4 images: plumbing, not accuracy
