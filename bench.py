@@ -97,6 +97,11 @@ def per_kernel_profile(model, reps=3):
     return {k: [v[0] / reps, v[1] / reps, v[2] / reps] for k, v in acc.items()}
 
 
+def flop_per_image(model):
+    fwd = sum(m["flops"] for _, _, _, m in model.plan.fwd if m and "flops" in m)
+    return 3.0 * fwd / model.batch
+
+
 def pmc_traffic(kernel):
     """L2-miss bytes per launch of ``kernel`` (read + write) from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
@@ -141,6 +146,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet"],
+                    help="Unet = BASELINE.json's headline workload; Linknet = SURVEY 8f N1 on the same kernels (not the headline metric)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (for rocprofv3 kernel traces of the launches themselves)")
     args = ap.parse_args()
 
@@ -156,7 +163,7 @@ def main():
     distributed.init("nccl", force=force_dp)
     dev = torch.device("cuda", local_rank)
 
-    model = HipSegModel("Unet", "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
+    model = HipSegModel(args.architecture, "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
                         lr=1e-3, use_graph=not args.eager, device=str(dev))
     if world > 1 or force_dp:
         model.set_data_parallel(distributed.GradReducer(bucket_mb=float(os.environ.get("STP_DP_BUCKET_MB", "32")), force=force_dp), overlap={"0": False, "1": True}.get(os.environ.get("STP_DP_OVERLAP", "1"), "buckets"))
@@ -200,14 +207,16 @@ def main():
     images_per_sec = world * BATCH * args.steps / elapsed
 
     out = {
-        "metric": "images/sec U-Net/ResNet34 512x512 bs16 training step", "value": round(images_per_sec, 2), "unit": "images/sec",
+        "metric": "images/sec %s/ResNet34 512x512 bs16 training step" % ("U-Net" if args.architecture == "Unet" else args.architecture), "value": round(images_per_sec, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "U-Net/ResNet34 512x512x3 1-class, batch 16 per GPU, BCE+Dice, Adam, on-device augment "
-                               "(BASELINE.json configs[1]%s)" % ("; configs[2] data-parallel" if world > 1 else ""),
+        "config": {"workload": ("U-Net" if args.architecture == "Unet" else args.architecture) + "/ResNet34 512x512x3 1-class, batch 16 per GPU, BCE+Dice, Adam, on-device augment "
+                               "(%s%s)" % ("BASELINE.json configs[1]" if args.architecture == "Unet" else "SURVEY 8f N1 workload, not the headline metric",
+                                           "; configs[2] data-parallel" if world > 1 else ""),
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "hipgraph": not args.eager, "loss_after_run": round(metrics["loss"], 5)},
-        "step_mfma_frac": round(images_per_sec / world * FLOP_PER_IMAGE / (PEAK_BF16_TFLOPS * 1e12), 4),
+        # algorithmic FLOP per trained image = 3 x the forward conv FLOP the plan recorded (187.94 GFLOP for the U-Net)
+        "step_mfma_frac": round(images_per_sec / world * flop_per_image(model) / (PEAK_BF16_TFLOPS * 1e12), 4),
     }
     if rank == 0 and not args.no_kernel_profile:
         prof = per_kernel_profile(model)

@@ -78,6 +78,29 @@ def init_unet_resnet(backbone="resnet34", in_ch=3, classes=1,
     return P
 
 
+def init_linknet_resnet(backbone="resnet34", in_ch=3, classes=1, decoder_filters=(None, None, None, None, 16), seed=42):
+    """Linknet over the same encoder (segmentation_models 0.2.1 ``Linknet(decoder_block_type='upsampling',
+    decoder_use_batchnorm=True)``, kwargs/defaults ``schemas/segmentation.raml:180-203``).  Decoder block i
+    (``decoder_stage{i}``): 1x1 conv to in/4 -> BN -> ReLU -> UpSampling2D(2) -> 3x3 conv in/4 -> BN -> ReLU -> 1x1 conv to
+    the skip's channel count (or ``decoder_filters[i]`` without a skip) -> BN -> ReLU -> Add(skip)."""
+    full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
+    P = OrderedDict((k, v) for k, v in full.items() if not (k.startswith("decoder_") or k.startswith("final_")))
+    rng = np.random.RandomState(seed + 1)
+    cin = STAGE_FILTERS[3]
+    skip_ch = (STAGE_FILTERS[2], STAGE_FILTERS[1], STAGE_FILTERS[0], 64, None)
+    for i in range(5):
+        pre = "decoder_stage%d_" % i
+        mid = cin // 4
+        out = skip_ch[i] if skip_ch[i] is not None else decoder_filters[i]
+        for j, (k, ci, co) in enumerate(((1, cin, mid), (3, mid, mid), (1, mid, out)), start=1):
+            P[pre + "conv%d/kernel" % j] = _glorot_uniform(rng, (k, k, ci, co))
+            _bn(P, pre + "bn%d" % j, co)
+        cin = out
+    P["final_conv/kernel"] = _glorot_uniform(rng, (3, 3, cin, classes))
+    P["final_conv/bias"] = np.zeros(classes, np.float32)
+    return P
+
+
 def trainable_names(P, freeze_encoder=False):
     """Names that receive gradients/updates.  Moving statistics never do."""
     out = []
@@ -140,11 +163,8 @@ def _bn_apply(ctx, x, name, eps, relu):
     return F.relu(y) if relu else y
 
 
-def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
-                        decoder_filters=(256, 128, 64, 32, 16)):
-    """P: dict name -> torch tensor (Keras layouts).  x_nhwc: [N,H,W,C] float32 raw 0..255.
-    Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits)."""
-    ctx = _Ctx(P, training, taps)
+def _resnet_encoder(ctx, x_nhwc, backbone):
+    """Pre-activation ResNet of classification_models up to the final bn1+relu; returns (x, skip tensors by layer name)."""
     units = RESNET_UNITS[backbone]
     x = x_nhwc.permute(0, 3, 1, 2)
     x = _bn_apply(ctx, x, "bn_data", BN_EPS_ENCODER, relu=False)
@@ -174,6 +194,33 @@ def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None
             ctx.tap(pre + "out", x)
     x = _bn_apply(ctx, x, "bn1", BN_EPS_ENCODER, relu=True)
     ctx.tap("relu1", x)
+    return x, skips
+
+
+def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None):
+    """Linknet (see init_linknet_resnet).  Returns (logits_nhwc, bn_updates)."""
+    ctx = _Ctx(P, training, taps)
+    x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
+    skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
+    for i in range(5):
+        pre = "decoder_stage%d_" % i
+        x = _bn_apply(ctx, _conv(ctx, x, pre + "conv1"), pre + "bn1", BN_EPS_DECODER, relu=True)
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        x = _bn_apply(ctx, _conv(ctx, x, pre + "conv2", pad=1), pre + "bn2", BN_EPS_DECODER, relu=True)
+        x = _bn_apply(ctx, _conv(ctx, x, pre + "conv3"), pre + "bn3", BN_EPS_DECODER, relu=True)
+        if skip_names[i] is not None:
+            x = x + skips[skip_names[i]]
+        ctx.tap(pre + "out", x)
+    x = _conv(ctx, x, "final_conv", pad=1)
+    return x.permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+
+
+def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
+                        decoder_filters=(256, 128, 64, 32, 16)):
+    """P: dict name -> torch tensor (Keras layouts).  x_nhwc: [N,H,W,C] float32 raw 0..255.
+    Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits)."""
+    ctx = _Ctx(P, training, taps)
+    x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
     skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i

@@ -31,7 +31,7 @@ class OracleTrainer:
 
     def __init__(self, params, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss",
                  optimizer="adam", lr=1e-3, freeze_encoder=False, clipnorm=None, clipvalue=None,
-                 decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None):
+                 decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None, architecture="Unet"):
         self.P = OrderedDict((k, v.copy()) for k, v in params.items())
         self.backbone = backbone
         self.loss_spec = loss
@@ -39,13 +39,17 @@ class OracleTrainer:
         self.trainable = nets.trainable_names(self.P, freeze_encoder)
         self.clipnorm, self.clipvalue = clipnorm, clipvalue
         self.decoder_filters = tuple(decoder_filters)
+        self.architecture = architecture
+
+    def _forward(self, P, x, training, taps):
+        if self.architecture == "Linknet":
+            return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
+        return nets.unet_resnet_forward(P, x, self.backbone, training=training, taps=taps, decoder_filters=self.decoder_filters)
 
     def forward(self, x_nhwc, training=False, taps=None):
         with torch.no_grad():
             P = nets.to_torch(self.P)
-            logits, _ = nets.unet_resnet_forward(P, torch.from_numpy(x_nhwc.astype(np.float32)),
-                                                 self.backbone, training=training, taps=taps,
-                                                 decoder_filters=self.decoder_filters)
+            logits, _ = self._forward(P, torch.from_numpy(x_nhwc.astype(np.float32)), training, taps)
         return logits.numpy()
 
     def step(self, x_nhwc, y_nhwc, taps=None, apply=True):
@@ -54,8 +58,7 @@ class OracleTrainer:
         P = nets.to_torch(self.P, self.trainable)
         x = torch.from_numpy(np.ascontiguousarray(x_nhwc, dtype=np.float32))
         y = torch.from_numpy(np.ascontiguousarray(y_nhwc, dtype=np.float32))
-        logits, bn_updates = nets.unet_resnet_forward(P, x, self.backbone, training=True, taps=taps,
-                                                      decoder_filters=self.decoder_filters)
+        logits, bn_updates = self._forward(P, x, True, taps)
         p = torch.sigmoid(logits)
         loss = losses.composite_loss(self.loss_spec, y, p)
         loss.backward()

@@ -42,7 +42,7 @@ class HipSegModel(object):
                  batch=16, dtype="bf16", loss="binary_crossentropy", optimizer="Adam", lr=1e-3, freeze_encoder=False,
                  decoder_filters=(256, 128, 64, 32, 16), clipnorm=None, clipvalue=None, use_graph=True, device="cuda",
                  opt_kwargs=None, seed=42):
-        if architecture != "Unet":
+        if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
         if backbone not in nets.RESNET_UNITS:
             raise ValueError("Unknown backbone")
@@ -93,8 +93,8 @@ class HipSegModel(object):
         with_loss = training if with_loss is None else with_loss
 
         def fn(plan):
-            logits = nets.unet_resnet(plan, self.backbone, self.H, self.W, self.in_ch, self.classes, self.decoder_filters,
-                                      self.loss_w, with_loss=with_loss)
+            logits = nets.NETWORKS[self.architecture](plan, self.backbone, self.H, self.W, self.in_ch, self.classes,
+                                                      self.decoder_filters, self.loss_w, with_loss=with_loss)
             if not with_loss:
                 plan.sigmoid_out(logits)
             return logits

@@ -486,6 +486,37 @@ class Plan(object):
         self._tape.append(back)
         return out
 
+    def add(self, name, y, skip):
+        """Keras ``Add()([y, skip])`` computed in place on y's buffer (y must have no other consumer): Linknet's
+        decoder adds the encoder feature AFTER BatchNormalization + ReLU, so it cannot ride in a conv epilogue."""
+        if (y.H, y.W, y.C) != (skip.H, skip.W, skip.C):
+            raise StpShapeError("%s: cannot add %dx%dx%d and %dx%dx%d" % (name, y.H, y.W, y.C, skip.H, skip.W, skip.C))
+        out = DT(name, self.N, y.H, y.W, y.C, y.buf, y.needs_grad or skip.needs_grad)
+        out.gradC = y.gradC
+        self.tensors[name] = out
+        self._use(y, skip)
+        if self.dry:
+            return out
+        self._emit(self.fwd, "stp_add_inplace", y.buf.data_ptr(), skip.buf.data_ptr(), y.rows * y.C, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not out.needs_grad or not out.grad_ready:
+                return
+            dy = out.grad
+            if y.needs_grad:
+                y.grad, y.grad_ready = dy, True          # alias: read by y's backward, issued before any later writer below
+            if skip.needs_grad:
+                if not skip.grad_ready and skip.gradC == out.gradC:
+                    skip.grad, skip.grad_ready = dy, True   # first gradient of the skip tensor: alias, later writers accumulate
+                else:
+                    self._emit(self.bwd, "stp_add_inplace", self._gradbuf(skip).data_ptr(), dy.data_ptr(), y.rows * out.gradC,
+                               self.cdt)
+
+        self._tape.append(back)
+        return out
+
     def maxpool(self, name, x):
         Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
         out = self._new(name, Ho, Wo, x.C, x.needs_grad)

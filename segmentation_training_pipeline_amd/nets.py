@@ -25,11 +25,10 @@ def known_backbones():
     return sorted(RESNET_UNITS)
 
 
-def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 128, 64, 32, 16),
-                loss=(1.0, 1.0), with_loss=True):
-    """Declares inputs 'image' (uint8 NHWC) and 'mask' (uint8 NHW1); returns the logits tensor."""
+def _resnet_encoder(plan, backbone, H, W, in_ch):
+    """Pre-activation ResNet-18/34 of classification_models; returns (bn1+relu output, relu0, {stage: unit-1 relu1})."""
     if H % 32 or W % 32:
-        raise ValueError("U-Net input height/width must be divisible by 32")
+        raise ValueError("input height/width must be divisible by 32")
     units = RESNET_UNITS[backbone]
     img = plan.input_u8("image", H, W, in_ch)
     x = plan.input_bn("bn_data", img, BN_EPS_ENCODER)
@@ -51,6 +50,21 @@ def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 
             y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
             x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut, bn_stats=True)
     x = plan.bn("bn1", x, BN_EPS_ENCODER, relu=True)
+    return x, relu0, taps
+
+
+def _head(plan, x, H, W, classes, loss, with_loss):
+    logits = plan.conv("final_conv", x, classes, 3, pad=1, bias=True)
+    if with_loss:
+        target = plan.input_u8("mask", H, W, 1)
+        plan.sigmoid_loss(logits, target, loss[0], loss[1])
+    return logits
+
+
+def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 128, 64, 32, 16),
+                loss=(1.0, 1.0), with_loss=True):
+    """Declares inputs 'image' (uint8 NHWC) and 'mask' (uint8 NHW1); returns the logits tensor."""
+    x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
     skips = (taps[4], taps[3], taps[2], relu0, None)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
@@ -58,8 +72,26 @@ def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 
         x = plan.bn(pre + "bn1", x, BN_EPS_DECODER, relu=True)
         x = plan.conv(pre + "conv2", x, f, 3, pad=1, bn_stats=True)
         x = plan.bn(pre + "bn2", x, BN_EPS_DECODER, relu=True)
-    logits = plan.conv("final_conv", x, classes, 3, pad=1, bias=True)
-    if with_loss:
-        target = plan.input_u8("mask", H, W, 1)
-        plan.sigmoid_loss(logits, target, loss[0], loss[1])
-    return logits
+    return _head(plan, x, H, W, classes, loss, with_loss)
+
+
+def linknet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(None, None, None, None, 16),
+                   loss=(1.0, 1.0), with_loss=True):
+    """segmentation_models 0.2.1 ``Linknet(decoder_block_type='upsampling', decoder_use_batchnorm=True)``
+    (``schemas/segmentation.raml:180-203``): per decoder stage 1x1 conv to in/4, UpSampling2D(2) folded into the 3x3
+    conv's gather, 1x1 conv to the skip's channels, each followed by BN+ReLU, then Add(skip)."""
+    x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
+    skips = (taps[4], taps[3], taps[2], relu0, None)
+    for i in range(5):
+        pre = "decoder_stage%d_" % i
+        mid = x.C // 4
+        out = skips[i].C if skips[i] is not None else int(decoder_filters[i])
+        x = plan.bn(pre + "bn1", plan.conv(pre + "conv1", x, mid, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
+        x = plan.bn(pre + "bn2", plan.conv(pre + "conv2", x, mid, 3, pad=1, upsample=True, bn_stats=True), BN_EPS_DECODER, relu=True)
+        x = plan.bn(pre + "bn3", plan.conv(pre + "conv3", x, out, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
+        if skips[i] is not None:
+            x = plan.add(pre + "add", x, skips[i])
+    return _head(plan, x, H, W, classes, loss, with_loss)
+
+
+NETWORKS = {"Unet": unet_resnet, "Linknet": linknet_resnet}

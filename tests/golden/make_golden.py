@@ -6,7 +6,7 @@
   ``segmentation_pipeline/impl/rle.py:10-35`` (``rle_encode`` / ``rle_decode``), imported from
   ``/root/reference`` with a stub for the absent ``skimage`` (only ``multi_rle_encode`` uses it).
   This is the only part of the reference that can execute in this container.
-* ``unet_resnet18_64.npz`` / ``unet_resnet34_64.npz`` - outputs of the in-repo oracle (PARITY
+* ``unet_resnet18_64.npz`` / ``unet_resnet34_64.npz`` / ``linknet_resnet18_64.npz`` - outputs of the in-repo oracle (PARITY
   UNPINNED: the reference's Keras path is not runnable) on a seeded synthetic batch; they pin
   the oracle against drift of itself / of the torch build.
 """
@@ -56,11 +56,11 @@ def make_rle():
     print("rle cases", len(cases))
 
 
-def make_unet(backbone, size, n, fname):
+def make_unet(backbone, size, n, fname, arch="Unet"):
     from oracle import nets, step
-    P = nets.init_unet_resnet(backbone, seed=42)
+    P = (nets.init_unet_resnet if arch == "Unet" else nets.init_linknet_resnet)(backbone, seed=42)
     tr = step.OracleTrainer(P, backbone=backbone, loss="binary_crossentropy+1.0*dice_loss",
-                            optimizer="adam", lr=1e-3)
+                            optimizer="adam", lr=1e-3, architecture=arch)
     x, y = step.synthetic_batch(n, size, size, seed=1234)
     xf, yf = x.astype(np.float32), y.astype(np.float32)
     o1 = tr.step(xf, yf)
@@ -84,3 +84,4 @@ if __name__ == "__main__":
     make_rle()
     make_unet("resnet18", 64, 2, "unet_resnet18_64.npz")
     make_unet("resnet34", 64, 2, "unet_resnet34_64.npz")
+    make_unet("resnet18", 64, 2, "linknet_resnet18_64.npz", arch="Linknet")

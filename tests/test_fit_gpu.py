@@ -83,3 +83,24 @@ def test_parse_fit_predict_end_to_end(tmp_path):
             assert np.array_equal(rle_decode(rle_encode(p1), (128, 128)) > 0, p1)     # the submission helper round-trips
             n_val += 1
     assert n_val == 4 and np.mean(dices) > 0.2      # 8 epochs on 4 images: plumbing, not accuracy
+
+
+def test_linknet_yaml_fits(tmp_path):
+    """`architecture: Linknet` resolves to the HIP Linknet (same encoder, 1x1/3x3/1x1 decoder blocks + Add)."""
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    img_dir, msk_dir = make_dataset(str(tmp_path))
+    cfg_path = str(tmp_path / "linknet.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Linknet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid",
+                        "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.002, "batch": 4, "folds_count": 2,
+                        "loss": "binary_crossentropy+1.0*dice_loss", "metrics": ["binary_accuracy", "dice"],
+                        "primary_metric": "val_dice", "stages": [{"epochs": 5}]}, f)
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
+    assert [(s["fold"], s["stage"]) for s in out] == [(0, 0)]
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        losses = [float(r["loss"]) for r in csv.DictReader(f)]
+    assert len(losses) == 5 and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    m = cfg.load_model(0, 0)
+    assert m.impl.architecture == "Linknet" and any(k.startswith("decoder_stage0_conv3") for k in m.impl.get_weights())

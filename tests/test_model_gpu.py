@@ -25,7 +25,7 @@ TAP_MAP = [("bn_data", "bn_data"), ("conv0", "conv0"), ("relu0", "bn0"), ("pooli
 
 def make(backbone, size, n, dtype, use_graph=False, **kw):
     from segmentation_training_pipeline_amd.backend import HipSegModel
-    return HipSegModel("Unet", backbone, (size, size, 3), 1, "sigmoid", batch=n, dtype=dtype, loss=kw.pop("loss", LOSS),
+    return HipSegModel(kw.pop("architecture", "Unet"), backbone, (size, size, 3), 1, "sigmoid", batch=n, dtype=dtype, loss=kw.pop("loss", LOSS),
                        optimizer=kw.pop("optimizer", "Adam"), lr=kw.pop("lr", 1e-3), use_graph=use_graph, **kw)
 
 
@@ -47,13 +47,14 @@ def first_bad_tap(model, taps, atol):
     return None
 
 
-@pytest.mark.parametrize("backbone", ["resnet18", "resnet34"])
-def test_fp32_step_matches_oracle(backbone):
+@pytest.mark.parametrize("arch,backbone", [("Unet", "resnet18"), ("Unet", "resnet34"), ("Linknet", "resnet18"), ("Linknet", "resnet34")])
+def test_fp32_step_matches_oracle(arch, backbone):
     n, size = 2, 64
-    P = onets.init_unet_resnet(backbone, seed=42)
+    P = (onets.init_unet_resnet if arch == "Unet" else onets.init_linknet_resnet)(backbone, seed=42)
     x, y = ostep.synthetic_batch(n, size, size, seed=1234)
-    tr = ostep.OracleTrainer(P, backbone=backbone, loss=LOSS, optimizer="sgd", lr=0.05, opt_kwargs={"momentum": 0.9})
-    m = make(backbone, size, n, "fp32", optimizer="SGD", lr=0.05, opt_kwargs={"momentum": 0.9})
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=LOSS, optimizer="sgd", lr=0.05, opt_kwargs={"momentum": 0.9}, architecture=arch)
+    m = make(backbone, size, n, "fp32", optimizer="SGD", lr=0.05, opt_kwargs={"momentum": 0.9}, architecture=arch)
+    assert sorted(m.get_weights()) == sorted(P)            # same parameter names and shapes as the oracle's Keras layout
     m.set_weights(P)
     taps = {}
     o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
@@ -92,10 +93,11 @@ def test_fp32_step_matches_oracle(backbone):
         np.testing.assert_allclose(w[k], tr.P[k], atol=2e-4, err_msg=k)
 
 
-def test_fp32_adam_step_matches_golden_fixture(golden_dir):
-    g = np.load(os.path.join(golden_dir, "unet_resnet34_64.npz"))
-    P = onets.init_unet_resnet("resnet34", seed=int(g["seed"]))
-    m = make("resnet34", 64, 2, "fp32")
+@pytest.mark.parametrize("arch,backbone", [("Unet", "resnet34"), ("Linknet", "resnet18")])
+def test_fp32_adam_step_matches_golden_fixture(golden_dir, arch, backbone):
+    g = np.load(os.path.join(golden_dir, "%s_%s_64.npz" % (arch.lower(), backbone)))
+    P = (onets.init_unet_resnet if arch == "Unet" else onets.init_linknet_resnet)(backbone, seed=int(g["seed"]))
+    m = make(backbone, 64, 2, "fp32", architecture=arch)
     m.set_weights(P)
     met = m.train_on_batch(g["x"], g["y"])
     np.testing.assert_allclose(m.logits(), g["logits1"], atol=1e-3)
@@ -115,12 +117,13 @@ def test_fp32_adam_step_matches_golden_fixture(golden_dir):
     assert abs(met2["loss"] - g["scalars2"][0]) < 2e-2
 
 
-def test_hipgraph_replay_equals_eager():
-    P = onets.init_unet_resnet("resnet18", seed=7)
+@pytest.mark.parametrize("arch", ["Unet", "Linknet"])
+def test_hipgraph_replay_equals_eager(arch):
+    P = (onets.init_unet_resnet if arch == "Unet" else onets.init_linknet_resnet)("resnet18", seed=7)
     x, y = ostep.synthetic_batch(2, 64, 64, seed=5)
     outs = []
     for use_graph in (False, True):
-        m = make("resnet18", 64, 2, "bf16", use_graph=use_graph)
+        m = make("resnet18", 64, 2, "bf16", use_graph=use_graph, architecture=arch)
         m.set_weights(P)
         r = [m.train_on_batch(x, y) for _ in range(3)]
         outs.append((r, m.logits(), m.get_weights()))

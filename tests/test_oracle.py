@@ -16,12 +16,12 @@ def test_conv_param_count_matches_published_unet_resnet34():
     assert nets.conv_param_count(P) == 24421456
 
 
-@pytest.mark.parametrize("backbone", ["resnet18", "resnet34"])
-def test_oracle_matches_golden(golden_dir, backbone):
-    g = np.load(os.path.join(golden_dir, "unet_%s_64.npz" % backbone))
-    P = nets.init_unet_resnet(backbone, seed=int(g["seed"]))
+@pytest.mark.parametrize("arch,backbone", [("Unet", "resnet18"), ("Unet", "resnet34"), ("Linknet", "resnet18")])
+def test_oracle_matches_golden(golden_dir, arch, backbone):
+    g = np.load(os.path.join(golden_dir, "%s_%s_64.npz" % (arch.lower(), backbone)))
+    P = (nets.init_unet_resnet if arch == "Unet" else nets.init_linknet_resnet)(backbone, seed=int(g["seed"]))
     tr = step.OracleTrainer(P, backbone=backbone, loss="binary_crossentropy+1.0*dice_loss",
-                            optimizer="adam", lr=1e-3)
+                            optimizer="adam", lr=1e-3, architecture=arch)
     xf, yf = g["x"].astype(np.float32), g["y"].astype(np.float32)
     o1 = tr.step(xf, yf)
     o2 = tr.step(xf, yf)
