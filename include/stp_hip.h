@@ -248,6 +248,15 @@ int stp_adam(float* param, const float* grad, float* m, float* v, int64_t count,
              float clipvalue, void* stream);
 int stp_sgd(float* param, const float* grad, float* vel, int64_t count, const float* lr, float momentum,
             int32_t nesterov, const uint8_t* mask, const float* gscale, float clipvalue, void* stream);
+/* RMSprop (Keras 2.2.4): a <- rho a + (1-rho) g^2 ; p <- p - lr g / (sqrt(a) + eps).  Same mask / gscale / clipvalue
+ * conventions as stp_adam. */
+int stp_rmsprop(float* param, const float* grad, float* acc, int64_t count, const float* lr, float rho, float eps,
+                const uint8_t* mask, const float* gscale, float clipvalue, void* stream);
+/* Nadam (Keras 2.2.4, schedule_decay form; lr default 0.002).  state: int32[2] as stp_adam (state[0] = iteration);
+ * fstate: float[8] device scratch whose element 0 is m_schedule and MUST be initialised to 1.0. */
+int stp_nadam(float* param, const float* grad, float* m, float* v, int64_t count, const float* lr, float beta1, float beta2,
+              float eps, float schedule_decay, int32_t* state, float* fstate, const uint8_t* mask, const float* gscale,
+              float clipvalue, void* stream);
 /* gscale[0] = min(1, clipnorm / ||base*grad||_2) * base  (base = 1/world_size for summed data-parallel
  * gradients; deterministic two-stage reduction).  workspace >= 4 KiB. */
 int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, float base, float* gscale,

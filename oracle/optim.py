@@ -85,7 +85,38 @@ class RMSprop:
         return params
 
 
-OPTIMIZERS = {"adam": Adam, "sgd": SGD, "rmsprop": RMSprop}
+class Nadam:
+    """keras/optimizers.py (2.2.4) Nadam: Nesterov Adam with the momentum schedule mu_t = beta_1 (1 - 0.5 * 0.96^(t * decay))."""
+
+    def __init__(self, lr=0.002, beta_1=0.9, beta_2=0.999, epsilon=1e-7, schedule_decay=0.004):
+        self.lr, self.b1, self.b2, self.eps, self.sd = lr, beta_1, beta_2, epsilon, schedule_decay
+        self.t = 0
+        self.m_schedule = 1.0
+        self.m, self.v = {}, {}
+
+    def step(self, params, grads):
+        self.t += 1
+        t = self.t
+        mu_t = self.b1 * (1.0 - 0.5 * 0.96 ** (t * self.sd))
+        mu_t1 = self.b1 * (1.0 - 0.5 * 0.96 ** ((t + 1) * self.sd))
+        ms_new = self.m_schedule * mu_t
+        ms_next = ms_new * mu_t1
+        self.m_schedule = ms_new
+        for k, g in grads.items():
+            m = self.m.get(k, np.zeros_like(g))
+            v = self.v.get(k, np.zeros_like(g))
+            g_prime = g / f32(1.0 - ms_new)
+            m = (f32(self.b1) * m + f32(1.0 - self.b1) * g).astype(f32)
+            m_prime = m / f32(1.0 - ms_next)
+            v = (f32(self.b2) * v + f32(1.0 - self.b2) * g * g).astype(f32)
+            v_prime = v / f32(1.0 - self.b2 ** t)
+            m_bar = f32(1.0 - mu_t) * g_prime + f32(mu_t1) * m_prime
+            params[k] = (params[k] - f32(self.lr) * m_bar / (np.sqrt(v_prime) + f32(self.eps))).astype(f32)
+            self.m[k], self.v[k] = m, v
+        return params
+
+
+OPTIMIZERS = {"adam": Adam, "sgd": SGD, "rmsprop": RMSprop, "nadam": Nadam}
 
 
 def make(name, lr=None, **kw):

@@ -54,8 +54,8 @@ class HipSegModel(object):
         self.decoder_filters = tuple(decoder_filters)
         self.loss_w = parse_loss(loss)
         self.optimizer = optimizer.lower()
-        if self.optimizer not in ("adam", "sgd"):
-            raise ValueError("optimizer %r is not available in the HIP backend (have: Adam, SGD)" % optimizer)
+        if self.optimizer not in ("adam", "sgd", "rmsprop", "nadam"):
+            raise ValueError("optimizer %r is not available in the HIP backend (have: SGD, Adam, RMSprop, Nadam)" % optimizer)
         self.opt_kwargs = dict(opt_kwargs or {})
         self.clipnorm = float(clipnorm) if clipnorm else 0.0
         self.clipvalue = float(clipvalue) if clipvalue else 0.0
@@ -78,10 +78,15 @@ class HipSegModel(object):
         self.opt_state = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.gscale = torch.ones(1, dtype=torch.float32, device=self.device)
         self.ws_norm = torch.empty(1024, dtype=torch.float32, device=self.device)
-        self.m = self.v = self.vel = None
-        if self.optimizer == "adam":
+        self.m = self.v = self.vel = self.opt_fstate = None
+        if self.optimizer in ("adam", "nadam"):
             self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
             self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
+            if self.optimizer == "nadam":
+                self.opt_fstate = torch.zeros(8, dtype=torch.float32, device=self.device)
+                self.opt_fstate[0] = 1.0      # m_schedule
+        elif self.optimizer == "rmsprop":
+            self.m = torch.zeros(n, dtype=torch.float32, device=self.device)   # the squared-gradient accumulator
         elif self.opt_kwargs.get("momentum", 0.0):
             self.vel = torch.zeros(n, dtype=torch.float32, device=self.device)
         self._build_opt()
@@ -143,6 +148,14 @@ class HipSegModel(object):
             p._emit(p.opt, "stp_adam", p.P.data_ptr(), p.G.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), n,
                     self.lr.data_ptr(), float(kw.get("beta_1", 0.9)), float(kw.get("beta_2", 0.999)),
                     float(kw.get("epsilon", 1e-7)), self.opt_state.data_ptr(), mask, gs, self.clipvalue)
+        elif self.optimizer == "nadam":
+            p._emit(p.opt, "stp_nadam", p.P.data_ptr(), p.G.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), n,
+                    self.lr.data_ptr(), float(kw.get("beta_1", 0.9)), float(kw.get("beta_2", 0.999)),
+                    float(kw.get("epsilon", 1e-7)), float(kw.get("schedule_decay", 0.004)), self.opt_state.data_ptr(),
+                    self.opt_fstate.data_ptr(), mask, gs, self.clipvalue)
+        elif self.optimizer == "rmsprop":
+            p._emit(p.opt, "stp_rmsprop", p.P.data_ptr(), p.G.data_ptr(), self.m.data_ptr(), n, self.lr.data_ptr(),
+                    float(kw.get("rho", 0.9)), float(kw.get("epsilon", 1e-7)), mask, gs, self.clipvalue)
         else:
             p._emit(p.opt, "stp_sgd", p.P.data_ptr(), p.G.data_ptr(), self.vel.data_ptr() if self.vel is not None else None, n,
                     self.lr.data_ptr(), float(kw.get("momentum", 0.0)), int(bool(kw.get("nesterov", False))), mask, gs,
@@ -151,7 +164,7 @@ class HipSegModel(object):
 
     def _mutable_state(self):
         p = self.plan
-        return [t for t in (p.P, p.S, self.opt_state, self.m, self.v, self.vel, self.gscale) if t is not None]
+        return [t for t in (p.P, p.S, self.opt_state, self.opt_fstate, self.m, self.v, self.vel, self.gscale) if t is not None]
 
     # ------------------------------------------------------------------ weights
     def init_weights(self, seed=42):

@@ -218,6 +218,107 @@ extern "C" int stp_adam(float* param, const float* grad, float* m, float* v, int
   return STP_OK;
 }
 
+// RMSprop (keras/optimizers.py 2.2.4): a <- rho a + (1-rho) g^2 ; p <- p - lr g / (sqrt(a) + eps)
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc,
+                                                      int64_t count, const float* lr, float rho, float eps,
+                                                      const uint8_t* __restrict__ mask, const float* gscale, float clipvalue) {
+  const float l = lr[0];
+  const float gs = gscale ? gscale[0] : 1.f;
+  const int64_t n4 = count >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 gv = load4(g + i * 4) * gs;
+    if (clipvalue > 0.f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = fminf(fmaxf(gv[e], -clipvalue), clipvalue);
+    f32x4 av = load4(acc + i * 4), pv = load4(p + i * 4);
+    uint32_t mk = mask ? *reinterpret_cast<const uint32_t*>(mask + i * 4) : 0x01010101u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!((mk >> (8 * e)) & 0xff)) continue;
+      const float an = rho * av[e] + (1.f - rho) * gv[e] * gv[e];
+      pv[e] = pv[e] - l * gv[e] / (sqrtf(an) + eps);
+      av[e] = an;
+    }
+    store4(acc + i * 4, av);
+    store4(p + i * 4, pv);
+  }
+}
+
+extern "C" int stp_rmsprop(float* param, const float* grad, float* acc, int64_t count, const float* lr, float rho, float eps,
+                           const uint8_t* mask, const float* gscale, float clipvalue, void* stream) {
+  if (!param || !grad || !acc || !lr || count <= 0 || (count & 3)) return STP_E_BADARG;
+  int64_t g = ((count >> 2) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, param, grad, acc, count, lr, rho, eps, mask,
+                     gscale, clipvalue);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// Nadam (keras/optimizers.py 2.2.4, schedule_decay form).  state[0] = iteration t, fstate[0] = m_schedule (starts at 1),
+// fstate[1..5] = this step's scalars {1/(1-m_schedule_new), 1/(1-m_schedule_next), 1/(1-beta2^t), 1-mu_t, mu_{t+1}}
+__global__ void nadam_prep_kernel(int32_t* state, float* fstate, float beta1, float beta2, float schedule_decay) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int t = state[0] + 1;
+  state[0] = t;
+  const double mu_t = (double)beta1 * (1.0 - 0.5 * pow(0.96, (double)t * (double)schedule_decay));
+  const double mu_t1 = (double)beta1 * (1.0 - 0.5 * pow(0.96, (double)(t + 1) * (double)schedule_decay));
+  const double ms_new = (double)fstate[0] * mu_t;
+  const double ms_next = ms_new * mu_t1;
+  fstate[0] = (float)ms_new;
+  fstate[1] = (float)(1.0 / (1.0 - ms_new));
+  fstate[2] = (float)(1.0 / (1.0 - ms_next));
+  fstate[3] = (float)(1.0 / (1.0 - pow((double)beta2, (double)t)));
+  fstate[4] = (float)(1.0 - mu_t);
+  fstate[5] = (float)mu_t1;
+}
+
+__global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t count, const float* lr, const float* fstate,
+                                                    float b1, float b2, float eps, const uint8_t* __restrict__ mask,
+                                                    const float* gscale, float clipvalue) {
+  const float l = lr[0];
+  const float ig = fstate[1], im = fstate[2], iv = fstate[3], cg = fstate[4], cm = fstate[5];
+  const float gs = gscale ? gscale[0] : 1.f;
+  const int64_t n4 = count >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 gv = load4(g + i * 4) * gs;
+    if (clipvalue > 0.f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = fminf(fmaxf(gv[e], -clipvalue), clipvalue);
+    f32x4 mv = load4(m + i * 4), vv = load4(v + i * 4), pv = load4(p + i * 4);
+    uint32_t mk = mask ? *reinterpret_cast<const uint32_t*>(mask + i * 4) : 0x01010101u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!((mk >> (8 * e)) & 0xff)) continue;
+      const float mn = b1 * mv[e] + (1.f - b1) * gv[e];
+      const float vn = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
+      const float mbar = cg * (gv[e] * ig) + cm * (mn * im);
+      pv[e] = pv[e] - l * mbar / (sqrtf(vn * iv) + eps);
+      mv[e] = mn;
+      vv[e] = vn;
+    }
+    store4(m + i * 4, mv);
+    store4(v + i * 4, vv);
+    store4(p + i * 4, pv);
+  }
+}
+
+extern "C" int stp_nadam(float* param, const float* grad, float* m, float* v, int64_t count, const float* lr, float beta1,
+                         float beta2, float eps, float schedule_decay, int32_t* state, float* fstate, const uint8_t* mask,
+                         const float* gscale, float clipvalue, void* stream) {
+  if (!param || !grad || !m || !v || !lr || !state || !fstate || count <= 0 || (count & 3)) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nadam_prep_kernel, dim3(1), dim3(64), 0, s, state, fstate, beta1, beta2, schedule_decay);
+  STP_LAUNCH_CHECK();
+  int64_t g = ((count >> 2) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(nadam_kernel, dim3((int)g), dim3(256), 0, s, param, grad, m, v, count, lr, fstate, beta1, beta2, eps, mask,
+                     gscale, clipvalue);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel,
                                                   int64_t count, const float* lr, float mu, int nesterov,
                                                   const uint8_t* __restrict__ mask, const float* gscale, float clipvalue) {

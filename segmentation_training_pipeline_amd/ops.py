@@ -163,6 +163,15 @@ def adam(param, grad, m, v, count, lr, b1, b2, eps, state, mask=None, gscale=Non
               ptr(gscale), float(clipvalue), stream())
 
 
+def rmsprop(p, g, acc, n, lr, rho, eps, mask=None, gscale=None, clipvalue=0.0):
+    _lib.call("stp_rmsprop", ptr(p), ptr(g), ptr(acc), n, ptr(lr), rho, eps, ptr(mask), ptr(gscale), clipvalue, stream())
+
+
+def nadam(p, g, m, v, n, lr, b1, b2, eps, schedule_decay, state, fstate, mask=None, gscale=None, clipvalue=0.0):
+    _lib.call("stp_nadam", ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(lr), b1, b2, eps, schedule_decay, ptr(state), ptr(fstate),
+              ptr(mask), ptr(gscale), clipvalue, stream())
+
+
 def sgd(param, grad, vel, count, lr, momentum, nesterov, mask=None, gscale=None, clipvalue=0.0):
     _lib.call("stp_sgd", ptr(param), ptr(grad), ptr(vel), count, ptr(lr), momentum, int(nesterov), ptr(mask), ptr(gscale),
               float(clipvalue), stream())

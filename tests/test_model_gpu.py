@@ -117,6 +117,30 @@ def test_fp32_adam_step_matches_golden_fixture(golden_dir, arch, backbone):
     assert abs(met2["loss"] - g["scalars2"][0]) < 2e-2
 
 
+@pytest.mark.parametrize("opt,lr", [("RMSprop", 1e-3), ("Nadam", 2e-3)])
+def test_rmsprop_and_nadam_steps_match_oracle(opt, lr):
+    """the remaining Keras optimizers through the whole step (fp32, hipGraph replay: Nadam's momentum
+    schedule is device state).  Weights after 2 steps vs the oracle, re-synchronised between steps (ReLU-kink noise)."""
+    P = onets.init_unet_resnet("resnet18", seed=3)
+    x, y = ostep.synthetic_batch(2, 64, 64, seed=9)
+    tr = ostep.OracleTrainer(P, backbone="resnet18", loss=LOSS, optimizer=opt.lower(), lr=lr)
+    m = make("resnet18", 64, 2, "fp32", optimizer=opt, lr=lr, use_graph=True)
+    m.set_weights(P)
+    for step_no in range(2):
+        o = tr.step(x.astype(np.float32), y.astype(np.float32))
+        met = m.train_on_batch(x, y)
+        assert abs(met["loss"] - o["loss"]) < 2e-5 * max(1.0, abs(o["loss"]))
+        w = m.get_weights()
+        # both optimizers normalise by sqrt(v): the first update is ~ lr*sign(g) (x 3.16 for RMSprop's rho = 0.9), so an
+        # element whose gradient is at rounding level may move the other way; compare the bulk (99 %) tightly and bound
+        # the rest by two full-size steps
+        for k in tr.P:
+            d = np.abs(w[k] - tr.P[k]).ravel()
+            bad = int((d > 2e-5 + 0.05 * lr).sum())
+            assert bad <= max(3, 0.02 * d.size) and d.max() <= 7.0 * lr + 1e-5, (k, bad, d.size, d.max())
+        m.set_weights(tr.P)
+
+
 @pytest.mark.parametrize("arch", ["Unet", "Linknet"])
 def test_hipgraph_replay_equals_eager(arch):
     P = (onets.init_unet_resnet if arch == "Unet" else onets.init_linknet_resnet)("resnet18", seed=7)

@@ -577,6 +577,27 @@ def test_adam_and_sgd_match_keras_rules(ops):
             oracle.step(P, {"w": g})
             ops.sgd(p, f(g), vel, n, lr, 0.9, nesterov)
         np.testing.assert_allclose(host(p), P["w"], atol=2e-6)
+    # RMSprop and Nadam (Keras 2.2.4 forms; Nadam's momentum schedule lives on the device: graph-replayable)
+    oracle = ooptim.RMSprop(lr=1e-3)
+    P = {"w": p0.copy()}
+    p, acc = f(p0), torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-3], device=DEV)
+    for g in grads:
+        oracle.step(P, {"w": g})
+        ops.rmsprop(p, f(g), acc, n, lr, 0.9, 1e-7)
+    np.testing.assert_allclose(host(p), P["w"], atol=2e-6)
+    oracle = ooptim.Nadam(lr=2e-3)
+    P = {"w": p0.copy()}
+    p, m, v = f(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lr = torch.tensor([2e-3], device=DEV)
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    fstate = torch.zeros(8, device=DEV)
+    fstate[0] = 1.0
+    for g in grads + grads:
+        oracle.step(P, {"w": g})
+        ops.nadam(p, f(g), m, v, n, lr, 0.9, 0.999, 1e-7, 0.004, state, fstate)
+    np.testing.assert_allclose(host(p), P["w"], atol=5e-6)
+    assert int(state[0].item()) == 6 and abs(float(fstate[0].item()) - oracle.m_schedule) < 1e-6
     # clipnorm scale
     g = f(grads[0])
     gs = torch.empty(1, device=DEV)

@@ -126,3 +126,22 @@ def test_losses_basic_properties():
     assert losses.parse_loss("binary_crossentropy+0.1*dice_loss") == [(1.0, "binary_crossentropy"), (0.1, "dice_loss")]
     # clipping: p == 1 exactly with y == 0 stays finite (Keras epsilon clip)
     assert np.isfinite(float(losses.binary_crossentropy(torch.zeros(1), torch.ones(1))))
+
+
+def test_nadam_and_rmsprop_first_steps_by_hand():
+    """Keras 2.2.4 update rules written out for one scalar: guards the oracle the HIP optimizers are held to."""
+    from oracle import optim
+    g = np.array([0.5], np.float32)
+    P = {"w": np.array([1.0], np.float32)}
+    optim.RMSprop(lr=1e-3).step(P, {"w": g})
+    a = 0.1 * 0.25
+    assert abs(P["w"][0] - (1.0 - 1e-3 * 0.5 / (np.sqrt(a) + 1e-7))) < 1e-7
+    P = {"w": np.array([1.0], np.float32)}
+    o = optim.Nadam(lr=2e-3)
+    o.step(P, {"w": g})
+    mu1 = 0.9 * (1 - 0.5 * 0.96 ** 0.004)
+    mu2 = 0.9 * (1 - 0.5 * 0.96 ** 0.008)
+    m, v = 0.1 * 0.5, 0.001 * 0.25
+    m_bar = (1 - mu1) * 0.5 / (1 - mu1) + mu2 * m / (1 - mu1 * mu2)
+    want = 1.0 - 2e-3 * m_bar / (np.sqrt(v / (1 - 0.999)) + 1e-7)
+    assert abs(P["w"][0] - want) < 1e-6 and abs(o.m_schedule - mu1) < 1e-12
