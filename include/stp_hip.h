@@ -226,7 +226,8 @@ int stp_add_inplace(void* dst, const void* src, int64_t count, int32_t dtype, vo
  * (Keras TF-backend BCE with the 1e-7 probability clip; musket dice_coef_loss, smooth 1), the
  * metrics (dice at 0.5, binary_accuracy) and dL/dlogits (channel 0 of a [count][dl_channels]
  * tensor, other channels zero, so it can feed the 8-channel-granular gather of the GEMMs).
- * scalars (fp32[8]): loss, bce, dice_loss, dice_metric, binary_accuracy, sum_p, sum_y, sum_py.
+ * scalars (fp32[10]): loss, bce, dice_loss, dice_metric, binary_accuracy, sum_p, sum_y, sum_py, iou, iot
+ *   (iou = (sum_py+1)/(sum_y+sum_p-sum_py+1); iot = the same with p thresholded at 0.5).
  * Two-stage, fixed-order reduction (deterministic).
  */
 size_t stp_loss_workspace_bytes(void);

@@ -58,6 +58,11 @@ def dice_metric(y_true, p):
     return dice_coef(y_true, (p > 0.5).to(p.dtype))
 
 
+def iot_metric(y_true, p):
+    """``iot`` metric ("at 0.5 threshold", schemas/segmentation.raml:105): iou_coef on thresholded predictions."""
+    return iou_coef(y_true, (p > 0.5).to(p.dtype))
+
+
 def binary_accuracy(y_true, p):
     return ((p > 0.5).to(p.dtype) == y_true).to(p.dtype).mean()
 

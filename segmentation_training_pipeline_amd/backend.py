@@ -346,7 +346,9 @@ class HipSegModel(object):
 
     def metrics(self):
         s = self.plan.loss_scalars.cpu().numpy()
-        return dict(zip(SCALAR_NAMES, (float(v) for v in s[:5])))
+        out = dict(zip(SCALAR_NAMES, (float(v) for v in s[:5])))
+        out["iou"], out["iot"] = float(s[8]), float(s[9])
+        return out
 
     def logits(self):
         return self.plan.tensors["final_conv"].buf.to(torch.float32).cpu().numpy()

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial
   scalars[5] = (float)s[1];
   scalars[6] = (float)s[2];
   scalars[7] = (float)s[3];
+  scalars[8] = (float)((s[3] + 1.0) / (s[2] + s[1] - s[3] + 1.0));   // iou: musket iou_coef, smooth 1
+  scalars[9] = (float)((s[5] + 1.0) / (s[2] + s[4] - s[5] + 1.0));   // iot: the same on predictions thresholded at 0.5
 }
 
 // pass 2: dL/dlogit, written to channel 0 of a [count][dl_channels] tensor (other channels 0)

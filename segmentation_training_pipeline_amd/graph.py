@@ -544,7 +544,7 @@ class Plan(object):
             raise StpShapeError("binary loss expects one class")
         if self.dry:
             return
-        self.loss_scalars = self._alloc((8,), torch.float32)
+        self.loss_scalars = self._alloc((12,), torch.float32)
         count = logits.rows
         dl = self._gradbuf(logits) if self.training else None
         self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),

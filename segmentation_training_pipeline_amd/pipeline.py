@@ -202,10 +202,11 @@ class DeviceFeeder(object):
 
 
 def derived_metrics(scal):
-    """scal: the 8 loss scalars of stp_sigmoid_bce_dice -> Keras-style log entries."""
-    loss, bce, dice_l, dice_m, acc, sp, sy, spy = (float(v) for v in scal)
+    """scal: the loss scalars of stp_sigmoid_bce_dice -> Keras-style log entries (metric names of
+    schemas/segmentation.raml:98-105: binary_accuracy, dice, iou, iot)."""
+    loss, bce, dice_l, dice_m, acc, _sp, _sy, _spy, iou, iot = (float(v) for v in scal[:10])
     return {"loss": loss, "binary_crossentropy": bce, "dice_loss": dice_l, "dice": dice_m, "binary_accuracy": acc,
-            "iou": (spy + 1.0) / (sy + sp - spy + 1.0)}
+            "iou": iou, "iot": iot}
 
 
 class Trainer(object):

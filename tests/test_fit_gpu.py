@@ -35,7 +35,7 @@ def test_parse_fit_predict_end_to_end(tmp_path):
     with open(cfg_path, "w") as f:
         yaml.safe_dump({"architecture": "Unet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid",
                         "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.002, "batch": 4, "folds_count": 2,
-                        "loss": "binary_crossentropy+1.0*dice_loss", "metrics": ["binary_accuracy", "dice"],
+                        "loss": "binary_crossentropy+1.0*dice_loss", "metrics": ["binary_accuracy", "dice", "iou", "iot"],
                         "primary_metric": "val_dice", "augmentation": {"Fliplr": 0.5, "Flipud": 0.5},
                         "callbacks": {"ReduceLROnPlateau": {"patience": 50, "factor": 0.5, "monitor": "val_loss"}},
                         "stages": [{"epochs": 6}, {"epochs": 2, "lr": 0.0005}]}, f)
@@ -47,7 +47,7 @@ def test_parse_fit_predict_end_to_end(tmp_path):
         assert os.path.exists(os.path.join(str(tmp_path), "weights", "best-0.%d.weights" % st))
     with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
         rows = list(csv.DictReader(f))
-    assert len(rows) == 6 and {"loss", "val_loss", "binary_accuracy", "val_dice", "lr"} <= set(rows[0])
+    assert len(rows) == 6 and {"loss", "val_loss", "binary_accuracy", "val_dice", "iou", "val_iot", "lr"} <= set(rows[0])
     losses = [float(r["loss"]) for r in rows]
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]           # it learns the bright ellipses
     assert os.path.exists(os.path.join(str(tmp_path), "summary.yaml"))

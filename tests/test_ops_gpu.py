@@ -525,7 +525,7 @@ def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     p = torch.sigmoid(zt)
     loss = olosses.composite_loss("binary_crossentropy+0.5*dice_loss", yt, p)
     loss.backward()
-    scal = torch.empty(8, device=DEV)
+    scal = torch.empty(10, device=DEV)
     C = 8 if dtype == "bf16" else 4
     dl = torch.full((count, C), float("nan"), dtype=TD[dtype], device=DEV)
     ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
@@ -536,6 +536,7 @@ def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     assert abs(s[2] - float(olosses.dice_loss(yt, p.detach()))) < 1e-5      # the north-star 1e-5 Dice bar
     assert abs(s[3] - float(olosses.dice_metric(yt, p.detach()))) < 1e-5
     assert abs(s[4] - float(olosses.binary_accuracy(yt, p.detach()))) < 1e-6
+    assert abs(s[8] - float(olosses.iou_coef(yt, p.detach()))) < 1e-5 and abs(s[9] - float(olosses.iot_metric(yt, p.detach()))) < 1e-5
     g = host(dl)
     ref = zt.grad.numpy()
     np.testing.assert_allclose(g[:, 0], ref, atol=(1e-8 if dtype == "fp32" else 1e-2 * np.abs(ref).max()))
