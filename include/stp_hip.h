@@ -235,6 +235,15 @@ int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, int64_t coun
                          float w_bce, float w_dice, float* scalars, void* dlogits, int32_t dl_channels,
                          float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
 int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, void* stream);
+/* Multi-class head (activation: softmax, loss: categorical_crossentropy[+w*dice_loss]; schemas/segmentation.raml:12-21,
+ * 62-63): channel softmax over the first `classes` (2..32) channels of logits [pixels][ldc], target = uint8 class index
+ * per pixel.  scalars as stp_sigmoid_bce_dice with [1] = categorical_crossentropy and the sums taken over every
+ * (pixel, class) element of the one-hot target; dlogits [pixels][dl_channels] gets classes gradients + zero padding. */
+int stp_softmax_cce_dice(const void* logits, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc,
+                         int32_t dtype, float w_cce, float w_dice, float* scalars, void* dlogits, int32_t dl_channels,
+                         float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* probs [pixels][classes] fp32 = softmax of the first `classes` channels */
+int stp_softmax(const void* logits, float* probs, int64_t pixels, int32_t classes, int32_t ldc, int32_t dtype, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Optimizers over a flat fp32 arena (Keras 2.2.4 update rules, schemas/segmentation.raml:77-89).

@@ -31,7 +31,7 @@ class OracleTrainer:
 
     def __init__(self, params, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss",
                  optimizer="adam", lr=1e-3, freeze_encoder=False, clipnorm=None, clipvalue=None,
-                 decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None, architecture="Unet"):
+                 decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None, architecture="Unet", activation="sigmoid"):
         self.P = OrderedDict((k, v.copy()) for k, v in params.items())
         self.backbone = backbone
         self.loss_spec = loss
@@ -40,6 +40,7 @@ class OracleTrainer:
         self.clipnorm, self.clipvalue = clipnorm, clipvalue
         self.decoder_filters = tuple(decoder_filters)
         self.architecture = architecture
+        self.activation = activation     # "sigmoid": y [N,H,W,1] in {0,1};  "softmax": y [N,H,W,1] class index -> one-hot
 
     def _forward(self, P, x, training, taps):
         if self.architecture == "Linknet":
@@ -59,14 +60,18 @@ class OracleTrainer:
         x = torch.from_numpy(np.ascontiguousarray(x_nhwc, dtype=np.float32))
         y = torch.from_numpy(np.ascontiguousarray(y_nhwc, dtype=np.float32))
         logits, bn_updates = self._forward(P, x, True, taps)
-        p = torch.sigmoid(logits)
+        if self.activation == "softmax":
+            p = torch.softmax(logits, dim=-1)
+            y = torch.nn.functional.one_hot(y[..., 0].long(), logits.shape[-1]).to(torch.float32)
+        else:
+            p = torch.sigmoid(logits)
         loss = losses.composite_loss(self.loss_spec, y, p)
         loss.backward()
         grads = OrderedDict((k, P[k].grad.numpy().copy()) for k in self.trainable)
         out = {
             "logits": logits.detach().numpy().copy(),
             "loss": float(loss.detach()),
-            "bce": float(losses.binary_crossentropy(y, p.detach())),
+            "bce": float((losses.categorical_crossentropy if self.activation == "softmax" else losses.binary_crossentropy)(y, p.detach())),
             "dice_loss": float(losses.dice_loss(y, p.detach())),
             "dice": float(losses.dice_metric(y, p.detach())),
             "binary_accuracy": float(losses.binary_accuracy(y, p.detach())),

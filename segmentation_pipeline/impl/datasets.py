@@ -49,9 +49,13 @@ def _imread_mask(path):
     from PIL import Image
     with Image.open(path) as im:
         a = np.asarray(im)
-    if a.ndim == 3:
-        a = a.astype(np.int32).sum(axis=2)
-    return (a != 0).astype(np.uint8)[:, :, None]
+    if a.ndim == 3:                      # colour-coded binary mask: any non-zero channel is foreground
+        return (a.astype(np.int32).sum(axis=2) != 0).astype(np.uint8)[:, :, None]
+    # single-channel PNG: the usual 0/255 (or 0/1) binary mask -> {0,1}; a label image whose values are small class
+    # indices (<= 32, `classes` > 1 experiments) keeps them - the training feeder binarises for the 1-class head anyway
+    if a.max(initial=0) > 32:
+        return (a != 0).astype(np.uint8)[:, :, None]
+    return a.astype(np.uint8)[:, :, None]
 
 
 class SimplePNGMaskDataSet(DataSet):

@@ -74,6 +74,8 @@ SIGNATURES = {
     "stp_loss_workspace_bytes": (sz, []),
     "stp_sigmoid_bce_dice": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i32, f32, vp, sz, vp]),
     "stp_sigmoid": (i32, [vp, vp, i64, i32, vp]),
+    "stp_softmax_cce_dice": (i32, [vp, vp, i64, i32, i32, i32, f32, f32, vp, vp, i32, f32, vp, sz, vp]),
+    "stp_softmax": (i32, [vp, vp, i64, i32, i32, i32, vp]),
     "stp_adam": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, vp, f32, vp]),
     "stp_sgd": (i32, [vp, vp, vp, i64, vp, f32, i32, vp, vp, f32, vp]),
     "stp_rmsprop": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, f32, vp]),

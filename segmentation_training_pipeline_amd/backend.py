@@ -21,9 +21,12 @@ CAPTURE_MODE = "thread_local"
 SCALAR_NAMES = ("loss", "binary_crossentropy", "dice_loss", "dice", "binary_accuracy")
 
 
-def parse_loss(spec):
-    """``"binary_crossentropy+0.1*dice_loss"`` -> (w_bce, w_dice)  (grammar: reference README.md:210-214)."""
-    w = {"binary_crossentropy": 0.0, "dice_loss": 0.0}
+def parse_loss(spec, classes=1):
+    """``"binary_crossentropy+0.1*dice_loss"`` -> (w_ce, w_dice)  (grammar: reference README.md:210-214).  The
+    cross-entropy term is ``binary_crossentropy`` for the 1-class sigmoid head and ``categorical_crossentropy`` for the
+    softmax head (schemas/segmentation.raml:12-21)."""
+    ce = "binary_crossentropy" if classes == 1 else "categorical_crossentropy"
+    w = {ce: 0.0, "dice_loss": 0.0}
     for term in str(spec).split("+"):
         term = term.strip()
         if "*" in term:
@@ -34,7 +37,7 @@ def parse_loss(spec):
         if name not in w:
             raise ValueError("loss %r is not available in the HIP backend (have: %s)" % (name, ", ".join(sorted(w))))
         w[name] += k
-    return w["binary_crossentropy"], w["dice_loss"]
+    return w[ce], w["dice_loss"]
 
 
 class HipSegModel(object):
@@ -46,13 +49,13 @@ class HipSegModel(object):
             raise ValueError("Unknown architecture")
         if backbone not in nets.RESNET_UNITS:
             raise ValueError("Unknown backbone")
-        if classes != 1 or activation not in ("sigmoid", None):
-            raise ValueError("the HIP backend currently trains 1-class sigmoid heads")
+        if not ((classes == 1 and activation in ("sigmoid", None)) or (2 <= classes <= 32 and activation == "softmax")):
+            raise ValueError("the HIP backend trains 1-class sigmoid heads and 2..32-class softmax heads")
         self.architecture, self.backbone = architecture, backbone
         self.H, self.W, self.in_ch = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
         self.classes, self.batch, self.dtype = classes, int(batch), dtype
         self.decoder_filters = tuple(decoder_filters)
-        self.loss_w = parse_loss(loss)
+        self.loss_w = parse_loss(loss, classes)
         self.optimizer = optimizer.lower()
         if self.optimizer not in ("adam", "sgd", "rmsprop", "nadam"):
             raise ValueError("optimizer %r is not available in the HIP backend (have: SGD, Adam, RMSprop, Nadam)" % optimizer)
@@ -101,7 +104,7 @@ class HipSegModel(object):
             logits = nets.NETWORKS[self.architecture](plan, self.backbone, self.H, self.W, self.in_ch, self.classes,
                                                       self.decoder_filters, self.loss_w, with_loss=with_loss)
             if not with_loss:
-                plan.sigmoid_out(logits)
+                (plan.sigmoid_out if self.classes == 1 else plan.softmax_out)(logits)
             return logits
         return fn
 
@@ -347,6 +350,8 @@ class HipSegModel(object):
     def metrics(self):
         s = self.plan.loss_scalars.cpu().numpy()
         out = dict(zip(SCALAR_NAMES, (float(v) for v in s[:5])))
+        if self.classes > 1:
+            out["categorical_crossentropy"] = out.pop("binary_crossentropy")
         out["iou"], out["iot"] = float(s[8]), float(s[9])
         return out
 

@@ -148,6 +148,173 @@ extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, i
   return STP_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Multi-class head: channel softmax + Keras categorical_crossentropy (+ w * musket dice over all class maps).
+// One thread per pixel; logits [pixels][ldc] (first `classes` channels), target = class index per pixel.
+// The seven sums have the binary kernel's meaning, taken over every (pixel, class) element of the one-hot target;
+// sum 0 is the per-pixel cross-entropy.
+#define STP_MAX_CLASSES 32
+
+template <typename T>
+__device__ __forceinline__ void softmax_row(const T* z, int classes, float (&p)[STP_MAX_CLASSES]) {
+  float m = -3.4e38f;
+  for (int c = 0; c < classes; ++c) { p[c] = Elem<T>::load(z + c); m = fmaxf(m, p[c]); }
+  float sum = 0.f;
+  for (int c = 0; c < classes; ++c) { p[c] = expf(p[c] - m); sum += p[c]; }
+  const float inv = 1.f / sum;
+  for (int c = 0; c < classes; ++c) p[c] *= inv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_loss_partial_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                                   int64_t pixels, int classes, int ldc, float* partial) {
+  float a[LOSS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t per = (pixels + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < pixels ? i0 + per : pixels;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    float p[STP_MAX_CLASSES];
+    softmax_row(logits + i * ldc, classes, p);
+    const int t = target[i] < classes ? target[i] : classes - 1;
+    // Keras: p <- p / sum(p) (a no-op on a softmax up to rounding), clip to [eps, 1-eps], -sum(y log p)
+    a[0] += -logf(fminf(fmaxf(p[t], 1e-7f), 1.f - 1e-7f));
+    for (int c = 0; c < classes; ++c) {
+      const float y = c == t ? 1.f : 0.f, th = p[c] > 0.5f ? 1.f : 0.f;
+      a[1] += p[c];
+      a[2] += y;
+      a[3] += p[c] * y;
+      a[4] += th;
+      a[5] += th * y;
+      a[6] += (th == y) ? 1.f : 0.f;
+    }
+  }
+  __shared__ float red[4][LOSS_NSUM];
+#pragma unroll
+  for (int e = 0; e < LOSS_NSUM; ++e) a[e] = wave_sum(a[e]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < LOSS_NSUM; ++e) red[threadIdx.x >> 6][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < LOSS_NSUM)
+    partial[(size_t)blockIdx.x * LOSS_NSUM + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// scalars as in the binary case, with scalars[1] = categorical_crossentropy and scalars[4] the element-wise accuracy
+__global__ __launch_bounds__(256) void softmax_loss_finalize_kernel(const float* partial, int blocks, double inv_pixels,
+                                                                    double inv_elems, float w_cce, float w_dice, float* scalars) {
+  __shared__ double sh[32][LOSS_NSUM];
+  const int e = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  double a = 0.0;
+  for (int b = lane; b < blocks; b += 32) a += (double)partial[(size_t)b * LOSS_NSUM + e];
+  sh[lane][e] = a;
+  __syncthreads();
+  for (int w = 16; w > 0; w >>= 1) {
+    if (lane < w) sh[lane][e] += sh[lane + w][e];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double* s = sh[0];
+  const double cce = s[0] * inv_pixels;
+  const double dice_l = 1.0 - (2.0 * s[3] + 1.0) / (s[2] + s[1] + 1.0);
+  scalars[0] = (float)(w_cce * cce + w_dice * dice_l);
+  scalars[1] = (float)cce;
+  scalars[2] = (float)dice_l;
+  scalars[3] = (float)((2.0 * s[5] + 1.0) / (s[2] + s[4] + 1.0));
+  scalars[4] = (float)(s[6] * inv_elems);
+  scalars[5] = (float)s[1];
+  scalars[6] = (float)s[2];
+  scalars[7] = (float)s[3];
+  scalars[8] = (float)((s[3] + 1.0) / (s[2] + s[1] - s[3] + 1.0));
+  scalars[9] = (float)((s[5] + 1.0) / (s[2] + s[4] - s[5] + 1.0));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_loss_grad_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                                int64_t pixels, int classes, int ldc, const float* scalars,
+                                                                float w_cce, float w_dice, float inv_pixels, float grad_scale,
+                                                                T* __restrict__ dl, int dlc) {
+  const float sp = scalars[5], sy = scalars[6], spy = scalars[7];
+  const float den = sy + sp + 1.f;
+  const float inv_den2 = 1.f / (den * den);
+  const float num = 2.f * spy + 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * 256) {
+    float p[STP_MAX_CLASSES];
+    softmax_row(logits + i * ldc, classes, p);
+    const int t = target[i] < classes ? target[i] : classes - 1;
+    const bool inr = p[t] >= 1e-7f && p[t] <= 1.f - 1e-7f;   // the clip passes no gradient outside
+    // dice: G_c = d dice_loss / d p_c = -(2 y_c den - num) / den^2 ; dz_k = p_k (G_k - sum_c G_c p_c)
+    float gp = 0.f;
+    for (int c = 0; c < classes; ++c) gp += (-(2.f * (c == t ? 1.f : 0.f) * den - num) * inv_den2) * p[c];
+    T* o = dl + i * dlc;
+    for (int c = 0; c < classes; ++c) {
+      const float y = c == t ? 1.f : 0.f;
+      float g = inr ? w_cce * (p[c] - y) * inv_pixels : 0.f;
+      g += w_dice * p[c] * ((-(2.f * y * den - num) * inv_den2) - gp);
+      Elem<T>::store(o + c, g * grad_scale);
+    }
+    for (int c = classes; c < dlc; ++c) Elem<T>::store(o + c, 0.f);
+  }
+}
+
+extern "C" int stp_softmax_cce_dice(const void* logits, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc,
+                                    int32_t dtype, float w_cce, float w_dice, float* scalars, void* dlogits, int32_t dl_channels,
+                                    float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!logits || !target || !scalars || !workspace || pixels <= 0 || classes < 2 || classes > STP_MAX_CLASSES || ldc < classes)
+    return STP_E_BADARG;
+  if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = pixels / 1024;
+  if (b < 1) b = 1;
+  if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
+  const int blocks = (int)b;
+  float* partial = (float*)workspace;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(softmax_loss_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)logits, target, pixels, classes, ldc, partial);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL(softmax_loss_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)logits, target, pixels, classes, ldc, partial);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(softmax_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)pixels,
+                     1.0 / ((double)pixels * classes), w_cce, w_dice, scalars);
+  STP_LAUNCH_CHECK();
+  if (dlogits) {
+    if (dl_channels < classes) return STP_E_BADARG;
+    int64_t g = (pixels + 255) / 256;
+    if (g > 4096) g = 4096;
+    const float inv_pixels = (float)(1.0 / (double)pixels);
+    if (dtype == STP_BF16)
+      hipLaunchKernelGGL(softmax_loss_grad_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, target, pixels, classes,
+                         ldc, scalars, w_cce, w_dice, inv_pixels, grad_scale, (bf16_t*)dlogits, dl_channels);
+    else
+      hipLaunchKernelGGL(softmax_loss_grad_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, target, pixels, classes,
+                         ldc, scalars, w_cce, w_dice, inv_pixels, grad_scale, (float*)dlogits, dl_channels);
+    STP_LAUNCH_CHECK();
+  }
+  return STP_OK;
+}
+
+template <typename T>
+__global__ void softmax_kernel(const T* __restrict__ logits, float* __restrict__ probs, int64_t pixels, int classes, int ldc) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * 256) {
+    float p[STP_MAX_CLASSES];
+    softmax_row(logits + i * ldc, classes, p);
+    for (int c = 0; c < classes; ++c) probs[i * classes + c] = p[c];
+  }
+}
+
+extern "C" int stp_softmax(const void* logits, float* probs, int64_t pixels, int32_t classes, int32_t ldc, int32_t dtype, void* stream) {
+  if (!logits || !probs || pixels <= 0 || classes < 1 || classes > STP_MAX_CLASSES || ldc < classes) return STP_E_BADARG;
+  int64_t g = (pixels + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16) hipLaunchKernelGGL(softmax_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, probs, pixels, classes, ldc);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(softmax_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, probs, pixels, classes, ldc);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 template <typename T>
 __global__ void sigmoid_kernel(const T* __restrict__ logits, float* __restrict__ probs, int64_t count) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)

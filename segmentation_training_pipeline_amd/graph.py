@@ -552,6 +552,28 @@ class Plan(object):
                    self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
         logits.grad_ready = self.training
 
+    def softmax_loss(self, logits, target, w_cce, w_dice):
+        """channel softmax + w_cce*categorical_crossentropy + w_dice*dice_loss (target = class index per pixel)."""
+        if logits.C < 2:
+            raise StpShapeError("categorical loss expects at least two classes")
+        if self.dry:
+            return
+        self.loss_scalars = self._alloc((12,), torch.float32)
+        dl = self._gradbuf(logits) if self.training else None
+        self._emit(self.fwd, "stp_softmax_cce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), logits.rows, logits.C, logits.C,
+                   self.cdt, float(w_cce), float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None,
+                   logits.gradC, 1.0, self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        logits.grad_ready = self.training
+
+    def softmax_out(self, logits):
+        """Activation('softmax') of the head for inference: float32 probabilities."""
+        if self.dry:
+            return None
+        probs = self._alloc((logits.N, logits.H, logits.W, logits.C), torch.float32)
+        self._emit(self.fwd, "stp_softmax", logits.buf.data_ptr(), probs.data_ptr(), logits.rows, logits.C, logits.C, self.cdt)
+        self.probs = probs
+        return probs
+
     def sigmoid_out(self, logits):
         """Activation('sigmoid') of the head for inference: float32 probabilities."""
         if self.dry:

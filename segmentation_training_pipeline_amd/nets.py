@@ -56,8 +56,11 @@ def _resnet_encoder(plan, backbone, H, W, in_ch):
 def _head(plan, x, H, W, classes, loss, with_loss):
     logits = plan.conv("final_conv", x, classes, 3, pad=1, bias=True)
     if with_loss:
-        target = plan.input_u8("mask", H, W, 1)
-        plan.sigmoid_loss(logits, target, loss[0], loss[1])
+        target = plan.input_u8("mask", H, W, 1)       # {0,1} for the sigmoid head, class index for the softmax head
+        if classes == 1:
+            plan.sigmoid_loss(logits, target, loss[0], loss[1])
+        else:
+            plan.softmax_loss(logits, target, loss[0], loss[1])
     return logits
 
 

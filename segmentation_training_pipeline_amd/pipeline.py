@@ -177,8 +177,8 @@ class DeviceFeeder(object):
     """uint8 items -> the plan's input buffers.  One async H2D copy of the raw pixels per item and one
     ``stp_augment_u8`` launch that resizes to the network shape (and augments when training)."""
 
-    def __init__(self, device, out_hw, spec, seed):
-        self.device, self.out_hw, self.spec = device, out_hw, spec
+    def __init__(self, device, out_hw, spec, seed, classes=1):
+        self.device, self.out_hw, self.spec, self.classes = device, out_hw, spec, int(classes)
         self.rng = np.random.RandomState(seed)
         self._keep = []
 
@@ -192,7 +192,13 @@ class DeviceFeeder(object):
             x = np.ascontiguousarray(it.x[:, :, :3], dtype=np.uint8)
             h, w = x.shape[:2]
             y = it.y if it.y is not None else np.zeros((h, w, 1), np.uint8)
-            y = np.ascontiguousarray((np.asarray(y).reshape(h, w, -1)[:, :, 0] != 0).astype(np.uint8))
+            y = np.asarray(y).reshape(h, w, -1)
+            if self.classes == 1:
+                y = np.ascontiguousarray((y[:, :, 0] != 0).astype(np.uint8))
+            elif y.shape[2] == self.classes:       # one-hot maps (what a Keras softmax head is fed) -> class index
+                y = np.ascontiguousarray(y.argmax(axis=2).astype(np.uint8))
+            else:                                  # label image
+                y = np.ascontiguousarray(np.minimum(y[:, :, 0], self.classes - 1).astype(np.uint8))
             prm = augment.sample_batch(self.spec if training else [], self.rng, 1, h, w, (oh, ow))
             xd = torch.from_numpy(x).to(self.device, non_blocking=True)
             yd = torch.from_numpy(y).to(self.device, non_blocking=True)
@@ -201,12 +207,12 @@ class DeviceFeeder(object):
             ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, 3)
 
 
-def derived_metrics(scal):
+def derived_metrics(scal, classes=1):
     """scal: the loss scalars of stp_sigmoid_bce_dice -> Keras-style log entries (metric names of
     schemas/segmentation.raml:98-105: binary_accuracy, dice, iou, iot)."""
     loss, bce, dice_l, dice_m, acc, _sp, _sy, _spy, iou, iot = (float(v) for v in scal[:10])
-    return {"loss": loss, "binary_crossentropy": bce, "dice_loss": dice_l, "dice": dice_m, "binary_accuracy": acc,
-            "iou": iou, "iot": iot}
+    return {"loss": loss, ("binary_crossentropy" if classes == 1 else "categorical_crossentropy"): bce, "dice_loss": dice_l,
+            "dice": dice_m, "binary_accuracy": acc, "iou": iou, "iot": iot}
 
 
 class Trainer(object):
@@ -233,7 +239,7 @@ class Trainer(object):
             else:
                 plan.run(plan.prep); plan.run(plan.fwd)
                 scal = plan.loss_scalars.cpu().numpy()
-            for k, v in derived_metrics(scal).items():
+            for k, v in derived_metrics(scal, getattr(m, "classes", 1)).items():
                 agg[k] = agg.get(k, 0.0) + v
             nb += 1
         return {k: v / max(nb, 1) for k, v in agg.items()}
@@ -390,7 +396,8 @@ class GenericTaskConfig(object):
         if world > 1:
             impl.set_data_parallel(distributed.GradReducer())
         H, W = int(self.shape[0]), int(self.shape[1])
-        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state * 7919 + fold * 101 + si)
+        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state * 7919 + fold * 101 + si,
+                              classes=self.classes)
         cbs = stage.callbacks()
         trainer = Trainer(impl, feeder, ds, cbs, rank, world)
         train_idx = kf.sampledIndexes(fold, True, stage.negatives)

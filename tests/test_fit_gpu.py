@@ -104,3 +104,44 @@ def test_linknet_yaml_fits(tmp_path):
     assert len(losses) == 5 and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
     m = cfg.load_model(0, 0)
     assert m.impl.architecture == "Linknet" and any(k.startswith("decoder_stage0_conv3") for k in m.impl.get_weights())
+
+
+def test_three_class_softmax_yaml_fits(tmp_path):
+    """`classes: 3`, `activation: softmax`, `loss: categorical_crossentropy` (schemas/segmentation.raml:12-21, 62-63) with
+    label-image masks (pixel value = class index)."""
+    from PIL import Image
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    img_dir, msk_dir = os.path.join(str(tmp_path), "img"), os.path.join(str(tmp_path), "msk")
+    os.makedirs(img_dir); os.makedirs(msk_dir)
+    rng = np.random.RandomState(1)
+    for i in range(8):
+        lab = np.zeros((128, 128), np.uint8)
+        a, b = rng.randint(20, 100, 2)
+        lab[a:, :] = 1
+        lab[:, b:] = 2
+        img = rng.randint(0, 40, (128, 128, 3)).astype(np.uint8)
+        img[..., 0] += ((lab == 1) * 150).astype(np.uint8)      # class 1 is red, class 2 is blue
+        img[..., 2] += ((lab == 2) * 150).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(img_dir, "m%02d.png" % i))
+        Image.fromarray(lab).save(os.path.join(msk_dir, "m%02d.png" % i))
+    cfg_path = str(tmp_path / "mc.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Unet", "backbone": "resnet18", "classes": 3, "activation": "softmax",
+                        "shape": [128, 128, 3], "optimizer": "Nadam", "lr": 0.002, "batch": 4, "folds_count": 2,
+                        "loss": "categorical_crossentropy+0.5*dice_loss", "metrics": ["dice", "iou"],
+                        "primary_metric": "val_loss", "primary_metric_mode": "min", "stages": [{"epochs": 8}]}, f)
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir, in_ext="png"), foldsToExecute=[0])
+    assert len(out) == 1
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        rows = list(csv.DictReader(f))
+    losses = [float(r["loss"]) for r in rows]
+    assert len(rows) == 8 and "categorical_crossentropy" in rows[0] and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    m = cfg.load_model(0, 0)
+    x = np.stack([np.asarray(Image.open(os.path.join(img_dir, "m00.png")))])
+    pr = m.predict(x)
+    assert pr.shape == (1, 128, 128, 3) and np.allclose(pr.sum(-1), 1.0, atol=1e-4)
+    # (no accuracy bar on predict(): after 8 optimizer steps the BatchNormalization moving statistics, momentum 0.99,
+    #  are still ~92 % initial values - inference-phase outputs of so short a run are not meaningful, as in Keras)
+    assert float(rows[-1]["iou"]) > float(rows[0]["iou"])       # the training-phase metric improves

@@ -117,6 +117,38 @@ def test_fp32_adam_step_matches_golden_fixture(golden_dir, arch, backbone):
     assert abs(met2["loss"] - g["scalars2"][0]) < 2e-2
 
 
+def test_fp32_softmax_head_step_matches_oracle():
+    """`classes: 3, activation: softmax, loss: categorical_crossentropy+dice_loss` through the whole
+    step (3-channel head conv, channel softmax, class-index masks) at the binary head's bars."""
+    n, size, classes = 2, 64, 3
+    P = onets.init_unet_resnet("resnet18", classes=classes, seed=42)
+    x, _ = ostep.synthetic_batch(n, size, size, seed=77)
+    yy, xx = np.mgrid[0:size, 0:size]
+    y = ((yy // 16 + xx // 24) % classes).astype(np.uint8)[None, :, :, None].repeat(n, axis=0)      # label image
+    spec = "categorical_crossentropy+1.0*dice_loss"
+    tr = ostep.OracleTrainer(P, backbone="resnet18", loss=spec, optimizer="sgd", lr=0.05, activation="softmax")
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    m = HipSegModel("Unet", "resnet18", (size, size, 3), classes, "softmax", batch=n, dtype="fp32", loss=spec, optimizer="SGD",
+                    lr=0.05, use_graph=False)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["dice"] - o["dice"]) < 1e-5
+    assert abs(met["categorical_crossentropy"] - o["bce"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = rel_l2(g[k], ref)
+        assert e <= (1e-4 if k.startswith("final_conv") else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
+    # inference: softmax probabilities, rows sum to one
+    m.set_weights(tr.P)
+    pr = m.predict(x)
+    ref = torch.softmax(torch.from_numpy(tr.forward(x.astype(np.float32))), dim=-1).numpy()
+    assert pr.shape == (n, size, size, classes)
+    np.testing.assert_allclose(pr.sum(axis=-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(pr, ref, atol=1e-3)
+
+
 @pytest.mark.parametrize("opt,lr", [("RMSprop", 1e-3), ("Nadam", 2e-3)])
 def test_rmsprop_and_nadam_steps_match_oracle(opt, lr):
     """the remaining Keras optimizers through the whole step (fp32, hipGraph replay: Nadam's momentum

@@ -543,6 +543,48 @@ def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     np.testing.assert_array_equal(g[:, 1:], 0)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("classes,ldc", [(3, 3), (5, 8), (21, 24)])
+def test_softmax_categorical_crossentropy_dice_loss_and_gradient(ops, dtype, classes, ldc):
+    """stp_softmax_cce_dice / stp_softmax against the oracle's Keras categorical_crossentropy (+ musket dice over all class
+    maps) through torch autograd; logits rows carry ldc >= classes channels (padded rows of the head conv)."""
+    import ctypes as C
+    from segmentation_training_pipeline_amd import _lib
+    rng = np.random.RandomState(31)
+    pixels = 2 * 24 * 24
+    z = q(rng.randn(pixels, ldc) * 3, dtype)
+    z[0, :classes] = q(np.array([40.0] + [-40.0] * (classes - 1)), dtype)       # exercises the probability clip
+    t = rng.randint(0, classes, size=pixels).astype(np.uint8)
+    t[0] = 1
+    zt = torch.from_numpy(z[:, :classes].copy()).requires_grad_(True)
+    yt = torch.nn.functional.one_hot(torch.from_numpy(t.astype(np.int64)), classes).to(torch.float32)
+    p = torch.softmax(zt, dim=-1)
+    loss = olosses.composite_loss("categorical_crossentropy+0.5*dice_loss", yt, p)
+    loss.backward()
+    scal = torch.empty(10, device=DEV)
+    dlc = 8 * ((classes + 7) // 8)
+    dl = torch.full((pixels, dlc), float("nan"), dtype=TD[dtype], device=DEV)
+    ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
+    zd, td = dev(z, dtype), keep(torch.from_numpy(t).to(DEV))
+    _lib.call("stp_softmax_cce_dice", ops.ptr(zd), ops.ptr(td), pixels, classes, ldc, ops.dt(zd), 1.0, 0.5, ops.ptr(scal), ops.ptr(dl), dlc,
+              1.0, ops.ptr(ws), ws.numel() * 4, ops.stream())
+    s = host(scal)
+    pd = p.detach()
+    assert abs(s[0] - float(loss.detach())) < 2e-5 * max(1, abs(float(loss.detach())))
+    assert abs(s[1] - float(olosses.categorical_crossentropy(yt, pd))) < 2e-5
+    assert abs(s[2] - float(olosses.dice_loss(yt, pd))) < 1e-5
+    assert abs(s[3] - float(olosses.dice_metric(yt, pd))) < 1e-5
+    assert abs(s[4] - float(olosses.binary_accuracy(yt, pd))) < 1e-6
+    assert abs(s[8] - float(olosses.iou_coef(yt, pd))) < 1e-5 and abs(s[9] - float(olosses.iot_metric(yt, pd))) < 1e-5
+    g = host(dl)
+    ref = zt.grad.numpy()
+    np.testing.assert_allclose(g[:, :classes], ref, atol=(2e-8 if dtype == "fp32" else 1e-2 * np.abs(ref).max()))
+    np.testing.assert_array_equal(g[:, classes:], 0)
+    probs = torch.empty((pixels, classes), device=DEV)
+    _lib.call("stp_softmax", ops.ptr(zd), ops.ptr(probs), pixels, classes, ldc, ops.dt(zd), ops.stream())
+    np.testing.assert_allclose(host(probs), pd.numpy(), atol=2e-6)
+
+
 def test_adam_and_sgd_match_keras_rules(ops):
     rng = np.random.RandomState(14)
     n = 4096 + 8
