@@ -274,11 +274,19 @@ int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, floa
 
 /* ----------------------------------------------------------------------------------------------
  * On-device augmentation (replaces the imgaug worker processes, schemas/augmenters.raml:43-133).
- * One fused pass per batch: inverse affine warp (flip/scale/translate/rotate/shear composed on
- * the host into a 2x3 matrix per sample), bilinear for the image (constant 0 border, result
- * rounded to uint8 like imgaug), nearest for the mask, then Add / Multiply colour ops.
- * params per sample (float[10]): m00 m01 m02 m10 m11 m12 (output->input pixel map), add, mul, 0, 0
+ * One fused pass per batch: inverse affine warp (flips, Affine, crop / pad augmenters and the final Resize composed on
+ * the host into a 2x3 matrix per sample), bilinear for the image (constant 0 border, result rounded to uint8 like
+ * imgaug), nearest for the mask, then the point operations in the fixed order Add, Multiply, MultiplyElementwise,
+ * AddElementwise, AdditiveGaussianNoise, Dropout, Grayscale, Invert (integer / single-rounded float arithmetic: the
+ * numpy oracle reproduces them bit for bit; per-pixel randomness is a counter-based hash of seed, pixel, channel, op).
+ * params per sample: float[STP_AUG_RECORD] (integers stored as exactly representable floats)
+ *   0-5 m00 m01 m02 m10 m11 m12 (output->input pixel map)   6-8 Add per channel   9-11 Multiply per channel
+ *   12 flags (1 Invert, 2 noise per channel, 4 dropout per channel, 8 AddElementwise per channel,
+ *             16 MultiplyElementwise per channel, 32 AddElementwise on, 64 MultiplyElementwise on)
+ *   13 Grayscale alpha * 256   14 noise k = rint(sigma * 65536 / 147.8)   15 dropout threshold rint(p * 2^24)
+ *   16-17 AddElementwise [lo, hi] (int)   18-19 MultiplyElementwise [lo, hi]   20 seed (integer < 2^24)   21-23 zero
  */
+#define STP_AUG_RECORD 24
 int stp_augment_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out,
                    const float* params, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
                    int32_t C, void* stream);

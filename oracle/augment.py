@@ -41,20 +41,144 @@ def affine_matrix(h, w, scale=1.0, translate_percent=(0.0, 0.0), rotate=0.0, she
     return inv
 
 
-def pack_params(mats, adds, muls):
-    """float32 [N,10] rows: m00 m01 m02 m10 m11 m12 add mul 0 0 (the kernel's per-sample record)."""
+AUG_RECORD = 24          # floats per sample, layout in include/stp_hip.h (stp_augment_u8)
+F_INVERT, F_NOISE_PC, F_DROP_PC, F_ADDE_PC, F_MULE_PC, F_ADDE, F_MULE = 1, 2, 4, 8, 16, 32, 64
+IRWIN_HALL_STD = 147.8   # std of the sum of 4 uniform bytes: sqrt(4 * (256^2 - 1) / 12)
+
+
+def pack_params(mats, adds, muls, **point):
+    """float32 [N,24] rows (the kernel's per-sample record).  ``adds`` / ``muls``: scalar or 3 per sample.  Optional
+    per-sample lists in ``point``: invert, gray_alpha, noise_sigma, noise_per_channel, dropout_p, dropout_per_channel,
+    add_elem (lo, hi), add_elem_per_channel, mul_elem (lo, hi), mul_elem_per_channel, seed."""
     n = len(mats)
-    out = np.zeros((n, 10), np.float32)
+    out = np.zeros((n, AUG_RECORD), np.float32)
+    g = lambda k, i, d: (point[k][i] if k in point and point[k] is not None else d)
     for i in range(n):
         out[i, 0:3] = mats[i][0]
         out[i, 3:6] = mats[i][1]
-        out[i, 6] = adds[i]
-        out[i, 7] = muls[i]
+        out[i, 6:9] = adds[i]
+        out[i, 9:12] = muls[i]
+        flags = 0
+        if g("invert", i, False):
+            flags |= F_INVERT
+        out[i, 13] = int(round(float(g("gray_alpha", i, 0.0)) * 256))
+        sig = float(g("noise_sigma", i, 0.0))
+        out[i, 14] = int(round(sig * 65536.0 / IRWIN_HALL_STD))
+        if g("noise_per_channel", i, False):
+            flags |= F_NOISE_PC
+        out[i, 15] = int(round(float(g("dropout_p", i, 0.0)) * (1 << 24)))
+        if g("dropout_per_channel", i, False):
+            flags |= F_DROP_PC
+        ae = g("add_elem", i, None)
+        if ae is not None:
+            flags |= F_ADDE | (F_ADDE_PC if g("add_elem_per_channel", i, False) else 0)
+            out[i, 16], out[i, 17] = int(ae[0]), int(ae[1])
+        me = g("mul_elem", i, None)
+        if me is not None:
+            flags |= F_MULE | (F_MULE_PC if g("mul_elem_per_channel", i, False) else 0)
+            out[i, 18], out[i, 19] = me[0], me[1]
+        out[i, 12] = flags
+        out[i, 20] = int(g("seed", i, 0)) & 0xffffff
     return out
 
 
+def aug_hash(seed, pix, ch, op):
+    """The kernel's counter-based hash in uint32 arithmetic (pix, ch: arrays)."""
+    with np.errstate(over="ignore"):
+        h = (np.uint32(seed) ^ (pix.astype(np.uint32) * np.uint32(0x9E3779B1)) ^ (ch.astype(np.uint32) * np.uint32(0x85EBCA77))
+             ^ np.uint32((op * 0xC2B2AE3D) & 0xffffffff))
+        h ^= h >> np.uint32(16); h = h * np.uint32(0x7feb352d)
+        h ^= h >> np.uint32(15); h = h * np.uint32(0x846ca68b)
+        h ^= h >> np.uint32(16)
+    return h
+
+
+def point_ops(v, rec):
+    """v: int64 [H,W,C] after the warp; rec: one float32[24] record -> uint8 [H,W,C] (bit-exact restatement)."""
+    oh, ow, c = v.shape
+    flags = int(rec[12])
+    seed = int(rec[20])
+    pix = (np.arange(oh, dtype=np.uint32)[:, None] * np.uint32(ow) + np.arange(ow, dtype=np.uint32)[None, :])[..., None]
+    pix = np.broadcast_to(pix, (oh, ow, c))
+    chan = np.broadcast_to(np.arange(c, dtype=np.uint32)[None, None, :], (oh, ow, c))
+    zero = np.zeros_like(chan)
+    cc = np.minimum(np.arange(c), 2)
+    v = np.clip(v + rec[6:9].astype(np.int64)[cc][None, None, :], 0, 255)
+    mul = rec[9:12][cc]
+    for k in range(c):
+        if mul[k] != np.float32(1.0):
+            v[..., k] = np.clip(np.rint(v[..., k].astype(np.float32) * mul[k]).astype(np.int64), 0, 255)
+    if flags & F_MULE:
+        h = aug_hash(seed, pix, chan if flags & F_MULE_PC else zero, 1)
+        u = (h >> np.uint32(8)).astype(np.float32) * np.float32(5.9604644775390625e-8)
+        m = rec[18] + (rec[19] - rec[18]) * u                      # float32, one rounding per operation
+        v = np.clip(np.rint(v.astype(np.float32) * m).astype(np.int64), 0, 255)
+    if flags & F_ADDE:
+        lo, nvals = int(rec[16]), int(rec[17]) - int(rec[16]) + 1
+        h = aug_hash(seed, pix, chan if flags & F_ADDE_PC else zero, 2)
+        v = np.clip(v + lo + (h % np.uint32(nvals)).astype(np.int64), 0, 255)
+    k = int(rec[14])
+    if k:
+        h = aug_hash(seed, pix, chan if flags & F_NOISE_PC else zero, 3).astype(np.int64)
+        ssum = (h & 255) + ((h >> 8) & 255) + ((h >> 16) & 255) + (h >> 24)
+        v = np.clip(v + (((ssum - 510) * k + 32768) >> 16), 0, 255)
+    t = int(rec[15])
+    if t:
+        h = aug_hash(seed, pix, chan if flags & F_DROP_PC else zero, 4)
+        v = np.where((h >> np.uint32(8)).astype(np.int64) < t, 0, v)
+    gq = int(rec[13])
+    if gq and c == 3:
+        gray = (v[..., 0] * 4899 + v[..., 1] * 9617 + v[..., 2] * 1868 + 8192) >> 14
+        v = (gq * gray[..., None] + (256 - gq) * v + 128) >> 8
+    if flags & F_INVERT:
+        v = 255 - v
+    return v.astype(np.uint8)
+
+
+# ---- sequential geometric composition (imgaug Sequential applies the augmenters in the listed order) -------------
+class Canvas(object):
+    """Tracks the current canvas size and the 3x3 map from current-canvas pixel coords to ORIGINAL input pixel coords."""
+
+    def __init__(self, h, w):
+        self.h, self.w = float(h), float(w)
+        self.M = np.eye(3)
+
+    def _push(self, cur_to_prev):
+        self.M = self.M @ cur_to_prev
+
+    def fliplr(self):
+        self._push(np.array([[-1, 0, self.w - 1], [0, 1, 0], [0, 0, 1]], np.float64))
+
+    def flipud(self):
+        self._push(np.array([[1, 0, 0], [0, -1, self.h - 1], [0, 0, 1]], np.float64))
+
+    def affine(self, scale=1.0, translate_percent=(0.0, 0.0), rotate=0.0, shear=0.0):
+        self._push(affine_matrix(self.h, self.w, scale, translate_percent, rotate, shear))
+
+    def crop(self, top, left, new_h, new_w):
+        """Keep the window [top, top+new_h) x [left, left+new_w): negative offsets pad with the constant border."""
+        self._push(np.array([[1, 0, left], [0, 1, top], [0, 0, 1]], np.float64))
+        self.h, self.w = float(new_h), float(new_w)
+
+    def resize(self, new_h, new_w):
+        sy, sx = self.h / new_h, self.w / new_w
+        self._push(np.array([[sx, 0, 0.5 * sx - 0.5], [0, sy, 0.5 * sy - 0.5], [0, 0, 1]], np.float64))
+        self.h, self.w = float(new_h), float(new_w)
+
+
+def compose(h, w, steps, out_hw):
+    """steps: [("fliplr",), ("flipud",), ("affine", scale, (tx, ty), rotate, shear), ("crop", top, left, nh, nw),
+    ("resize", nh, nw)] applied in order, then the trailing Resize to ``out_hw``.  Returns the 3x3 output->input map."""
+    c = Canvas(h, w)
+    for st in steps:
+        getattr(c, st[0])(*st[1:])
+    if (int(c.h), int(c.w)) != tuple(out_hw):
+        c.resize(*out_hw)
+    return c.M
+
+
 def warp_u8(img, mask, params, out_hw):
-    """img [N,H,W,C] u8, mask [N,H,W] u8 or None, params float32 [N,10] -> (img_out, mask_out)."""
+    """img [N,H,W,C] u8, mask [N,H,W] u8 or None, params float32 [N,24] -> (img_out, mask_out)."""
     n, h, w, c = img.shape
     oh, ow = out_hw
     xo = np.arange(ow, dtype=np.float64)[None, :]
@@ -63,7 +187,6 @@ def warp_u8(img, mask, params, out_hw):
     mask_out = None if mask is None else np.zeros((n, oh, ow), np.uint8)
     for i in range(n):
         m = params[i, :6].astype(np.float64)
-        add, mul = int(params[i, 6]), np.float32(params[i, 7])
         X0 = np.rint(m[0] * xo * 1024.0).astype(np.int64) + np.rint((m[1] * yo + m[2]) * 1024.0).astype(np.int64)
         Y0 = np.rint(m[3] * xo * 1024.0).astype(np.int64) + np.rint((m[4] * yo + m[5]) * 1024.0).astype(np.int64)
         X, Y = (X0 + 16) >> 5, (Y0 + 16) >> 5
@@ -78,10 +201,7 @@ def warp_u8(img, mask, params, out_hw):
 
         v = (w00[..., None] * tap(iy, ix) + w01[..., None] * tap(iy, ix + 1) +
              w10[..., None] * tap(iy + 1, ix) + w11[..., None] * tap(iy + 1, ix + 1) + 512) >> 10
-        v = np.clip(v + add, 0, 255)
-        if mul != np.float32(1.0):
-            v = np.clip(np.rint(v.astype(np.float32) * mul).astype(np.int64), 0, 255)
-        img_out[i] = v.astype(np.uint8)
+        img_out[i] = point_ops(v, params[i])
         if mask is not None:
             mx, my = (X0 + 512) >> 10, (Y0 + 512) >> 10
             ok = (mx >= 0) & (mx < w) & (my >= 0) & (my < h)

@@ -3,22 +3,32 @@
 The reference feeds the network from imgaug worker processes (``augmentation:`` YAML list, catalogue
 ``segmentation_pipeline/schemas/augmenters.raml:43-133``, semantics README.md:247-268: a
 ``Sequential`` of augmenters applied jointly to image and mask, followed by a resize to ``shape``).
-Here the host only SAMPLES the per-image parameters (a few floats) and folds all geometric
-augmenters + the final resize into one 2x3 output->input matrix per image; the pixels are moved
-by one HIP kernel (``stp_augment_u8``), so no CPU worker touches image data.
+Here the host only SAMPLES the per-image parameters (a 24-float record) and folds every geometric
+augmenter + the final resize, in the listed order, into one 2x3 output->input matrix per image; the pixels
+are moved by one HIP kernel (``stp_augment_u8``), so no CPU worker touches image data.
 
 Supported augmenters (YAML name -> effect):
-  Fliplr(p), Flipud(p), Affine{scale, translate_percent, rotate, shear}, Add(value), Multiply(mul),
-  Sequential / Sometimes(p, then_list) containers.
-Anything else raises ``ValueError`` naming the augmenter (no silent skipping).
+  geometry (composed into the matrix): Fliplr(p), Flipud(p), Affine{scale, translate_percent, rotate, shear},
+    CropToFixedSize{width,height}, PadToFixedSize{width,height}, Pad{px}, CropAndPad{percent} (the last two keep the size,
+    imgaug's default ``keep_size=True``);
+  point operations (the kernel's fixed order, see include/stp_hip.h): Add, Multiply (value or range, ``per_channel``),
+    AddElementwise, MultiplyElementwise, AdditiveGaussianNoise{scale, per_channel}, Dropout{p, per_channel},
+    Grayscale{alpha}, Invert(p);
+  containers: Sequential, Sometimes{p, then_list}, OneOf.
+Neighbourhood filters (GaussianBlur, AverageBlur, MedianBlur, Sharpen, Emboss, EdgeDetect), PiecewiseAffine,
+ElasticTransformation and BackgroundReplacer raise ``ValueError`` naming the augmenter (no silent skipping).
 """
 import math
 
 import numpy as np
 
+AUG_RECORD = 24
+F_INVERT, F_NOISE_PC, F_DROP_PC, F_ADDE_PC, F_MULE_PC, F_ADDE, F_MULE = 1, 2, 4, 8, 16, 32, 64
+IRWIN_HALL_STD = 147.8   # std of the sum of 4 uniform bytes (the kernel's Gaussian-noise generator)
+
 
 def _rng_range(rng, v, default):
-    """imgaug-style stochastic parameter: scalar, (lo, hi) tuple/list or {'x':..,'y':..} handled by caller."""
+    """imgaug-style stochastic parameter: scalar or (lo, hi)."""
     if v is None:
         return default
     if isinstance(v, (list, tuple)):
@@ -26,87 +36,180 @@ def _rng_range(rng, v, default):
     return float(v)
 
 
-class SampleParams(object):
-    __slots__ = ("fliplr", "flipud", "scale", "tx", "ty", "rotate", "shear", "add", "mul")
+def _arg(args, key, default=None):
+    """YAML gives either a scalar/list (positional form, README.md:266-268) or a mapping."""
+    if isinstance(args, dict):
+        return args.get(key, default)
+    return args if args is not None else default
 
-    def __init__(self):
-        self.fliplr = self.flipud = False
-        self.scale, self.tx, self.ty, self.rotate, self.shear = 1.0, 0.0, 0.0, 0.0, 0.0
-        self.add, self.mul = 0, 1.0
+
+class SampleParams(object):
+    """One image's sampled pipeline: the canvas transform so far plus the point-operation parameters."""
+
+    def __init__(self, h, w):
+        self.h, self.w = float(h), float(w)        # current canvas
+        self.M = np.eye(3)                          # current-canvas pixel -> original input pixel
+        self.add = np.zeros(3)
+        self.mul = np.ones(3)
+        self.flags = 0
+        self.gray, self.noise, self.drop = 0.0, 0.0, 0.0
+        self.adde, self.mule = None, None
+
+    # ---- geometry: every op appends the map from the NEW canvas to the PREVIOUS one
+    def push(self, cur_to_prev):
+        self.M = self.M @ cur_to_prev
+
+    def affine(self, scale, tx, ty, rotate, shear):
+        rot, sh = math.radians(rotate), math.radians(shear)
+        cx, cy = self.w / 2.0 - 0.5, self.h / 2.0 - 0.5
+        a = np.array([[scale * math.cos(rot), -scale * math.sin(rot + sh), tx * self.w],
+                      [scale * math.sin(rot), scale * math.cos(rot + sh), ty * self.h], [0.0, 0.0, 1.0]])
+        t0 = np.array([[1.0, 0.0, -cx], [0.0, 1.0, -cy], [0.0, 0.0, 1.0]])
+        t1 = np.array([[1.0, 0.0, cx], [0.0, 1.0, cy], [0.0, 0.0, 1.0]])
+        self.push(np.linalg.inv(t1 @ a @ t0))
+
+    def window(self, top, left, new_h, new_w):
+        """Crop (positive offsets) / pad with the constant border (negative offsets) to a new canvas."""
+        self.push(np.array([[1.0, 0.0, left], [0.0, 1.0, top], [0.0, 0.0, 1.0]]))
+        self.h, self.w = float(new_h), float(new_w)
+
+    def resize(self, new_h, new_w):
+        sy, sx = self.h / new_h, self.w / new_w
+        self.push(np.array([[sx, 0.0, 0.5 * sx - 0.5], [0.0, sy, 0.5 * sy - 0.5], [0.0, 0.0, 1.0]]))
+        self.h, self.w = float(new_h), float(new_w)
+
+
+def _per_channel(rng, args):
+    pc = _arg(args, "per_channel", False) if isinstance(args, dict) else False
+    return bool(pc) if not isinstance(pc, float) else rng.uniform() < pc
+
+
+def _children(args):
+    return args if isinstance(args, list) else (args or {}).get("children", (args or {}).get("then_list", []))
 
 
 def _apply(spec, rng, sp):
-    """spec: list of {Name: args} (the YAML form).  Later geometric augmenters compose onto earlier ones
-    in the order given; one Affine is supported per pipeline (the README's example shape)."""
+    """spec: list of {Name: args} (the YAML form), applied in the listed order like imgaug's Sequential."""
     for item in spec or []:
         if isinstance(item, str):
             name, args = item, None
         else:
             (name, args), = item.items()
-        if name in ("Fliplr", "Flipud"):
+        if name in ("Fliplr", "Flipud", "Invert"):
             p = float(args) if args is not None and not isinstance(args, dict) else float((args or {}).get("p", 1.0))
             if rng.uniform() < p:
                 if name == "Fliplr":
-                    sp.fliplr = not sp.fliplr
+                    sp.push(np.array([[-1.0, 0.0, sp.w - 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]))
+                elif name == "Flipud":
+                    sp.push(np.array([[1.0, 0.0, 0.0], [0.0, -1.0, sp.h - 1.0], [0.0, 0.0, 1.0]]))
                 else:
-                    sp.flipud = not sp.flipud
+                    sp.flags ^= F_INVERT
         elif name == "Affine":
             a = args or {}
-            sp.scale *= _rng_range(rng, a.get("scale"), 1.0)
+            scale = _rng_range(rng, a.get("scale"), 1.0)
             tp = a.get("translate_percent")
             if isinstance(tp, dict):
-                sp.tx += _rng_range(rng, tp.get("x"), 0.0)
-                sp.ty += _rng_range(rng, tp.get("y"), 0.0)
+                tx, ty = _rng_range(rng, tp.get("x"), 0.0), _rng_range(rng, tp.get("y"), 0.0)
             elif tp is not None:
-                sp.tx += _rng_range(rng, tp, 0.0)
-                sp.ty += _rng_range(rng, tp, 0.0)
-            sp.rotate += _rng_range(rng, a.get("rotate"), 0.0)
-            sp.shear += _rng_range(rng, a.get("shear"), 0.0)
-        elif name == "Add":
-            v = args.get("value") if isinstance(args, dict) else args
-            sp.add += int(round(_rng_range(rng, v, 0.0)))
-        elif name == "Multiply":
-            v = args.get("mul") if isinstance(args, dict) else args
-            sp.mul *= _rng_range(rng, v, 1.0)
+                tx, ty = _rng_range(rng, tp, 0.0), _rng_range(rng, tp, 0.0)
+            else:
+                tx = ty = 0.0
+            sp.affine(scale, tx, ty, _rng_range(rng, a.get("rotate"), 0.0), _rng_range(rng, a.get("shear"), 0.0))
+        elif name == "CropToFixedSize":
+            tw, th = int(_arg(args, "width")), int(_arg(args, "height"))
+            nh, nw = min(sp.h, th), min(sp.w, tw)
+            top, left = rng.randint(0, int(sp.h - nh) + 1), rng.randint(0, int(sp.w - nw) + 1)     # position='uniform'
+            sp.window(top, left, nh, nw)
+        elif name == "PadToFixedSize":
+            tw, th = int(_arg(args, "width")), int(_arg(args, "height"))
+            nh, nw = max(sp.h, th), max(sp.w, tw)
+            top, left = rng.randint(0, int(nh - sp.h) + 1), rng.randint(0, int(nw - sp.w) + 1)
+            sp.window(-top, -left, nh, nw)
+        elif name in ("Pad", "CropAndPad"):
+            h0, w0 = sp.h, sp.w
+            if name == "Pad":
+                px = _arg(args, "px", 0)
+                side = lambda: (int(px) if not isinstance(px, (list, tuple)) else int(rng.randint(int(px[0]), int(px[1]) + 1)))
+                if isinstance(px, (list, tuple)) and len(px) == 4:
+                    t, r, b, l = (int(v) for v in px)
+                else:
+                    t, r, b, l = side(), side(), side(), side()
+            else:
+                pc = _arg(args, "percent", 0.0)
+                side = lambda: _rng_range(rng, pc, 0.0)
+                t, r, b, l = (int(round(side() * h0)), int(round(side() * w0)), int(round(side() * h0)), int(round(side() * w0)))
+            nh, nw = max(1.0, h0 + t + b), max(1.0, w0 + l + r)                       # negative = crop
+            sp.window(-t, -l, nh, nw)
+            sp.resize(h0, w0)                                                         # keep_size=True (imgaug default)
+        elif name in ("Add", "Multiply"):
+            v = _arg(args, "value" if name == "Add" else "mul")
+            pc = _per_channel(rng, args)
+            vals = [_rng_range(rng, v, 0.0 if name == "Add" else 1.0) for _ in range(3 if pc else 1)] * (1 if pc else 3)
+            if name == "Add":
+                sp.add += np.round(vals)
+            else:
+                sp.mul *= vals
+        elif name in ("AddElementwise", "MultiplyElementwise"):
+            v = _arg(args, "value" if name == "AddElementwise" else "mul")
+            lo, hi = (v[0], v[1]) if isinstance(v, (list, tuple)) else (v, v)
+            pc = _per_channel(rng, args)
+            if name == "AddElementwise":
+                sp.adde = (int(round(lo)), int(round(hi)))
+                sp.flags |= F_ADDE | (F_ADDE_PC if pc else 0)
+            else:
+                sp.mule = (float(lo), float(hi))
+                sp.flags |= F_MULE | (F_MULE_PC if pc else 0)
+        elif name == "AdditiveGaussianNoise":
+            sp.noise = _rng_range(rng, _arg(args, "scale", 0.0), 0.0)
+            if _per_channel(rng, args):
+                sp.flags |= F_NOISE_PC
+        elif name == "Dropout":
+            sp.drop = _rng_range(rng, _arg(args, "p", 0.0), 0.0)
+            if _per_channel(rng, args):
+                sp.flags |= F_DROP_PC
+        elif name == "Grayscale":
+            sp.gray = _rng_range(rng, _arg(args, "alpha", 1.0), 1.0)
         elif name == "Sequential":
-            _apply(args if isinstance(args, list) else (args or {}).get("children", []), rng, sp)
+            _apply(_children(args), rng, sp)
         elif name == "Sometimes":
             a = args or {}
             if rng.uniform() < float(a.get("p", 0.5)):
                 _apply(a.get("then_list", []), rng, sp)
+        elif name == "OneOf":
+            ch = _children(args)
+            if ch:
+                _apply([ch[rng.randint(0, len(ch))]], rng, sp)
         else:
             raise ValueError("augmenter %r is not available in the HIP augmentation stage" % name)
 
 
-def matrix(sp, h, w, out_hw):
-    """2x3 OUTPUT->INPUT pixel map: inverse of (flip o affine-about-centre), then the final resize."""
-    rot, sh = math.radians(sp.rotate), math.radians(sp.shear)
-    cx, cy = w / 2.0 - 0.5, h / 2.0 - 0.5
-    a = np.array([[sp.scale * math.cos(rot), -sp.scale * math.sin(rot + sh), sp.tx * w],
-                  [sp.scale * math.sin(rot), sp.scale * math.cos(rot + sh), sp.ty * h],
-                  [0.0, 0.0, 1.0]])
-    t0 = np.array([[1.0, 0.0, -cx], [0.0, 1.0, -cy], [0.0, 0.0, 1.0]])
-    t1 = np.array([[1.0, 0.0, cx], [0.0, 1.0, cy], [0.0, 0.0, 1.0]])
-    fwd = t1 @ a @ t0
-    if sp.fliplr:
-        fwd = np.array([[-1.0, 0.0, w - 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]) @ fwd
-    if sp.flipud:
-        fwd = np.array([[1.0, 0.0, 0.0], [0.0, -1.0, h - 1.0], [0.0, 0.0, 1.0]]) @ fwd
-    inv = np.linalg.inv(fwd)
+def record(sp, out_hw, seed):
+    """float32[24] record of ``stp_augment_u8`` (layout: include/stp_hip.h) for one sampled pipeline."""
     oh, ow = out_hw
-    if (oh, ow) != (h, w):
-        inv = inv @ np.array([[w / ow, 0.0, 0.5 * w / ow - 0.5], [0.0, h / oh, 0.5 * h / oh - 0.5], [0.0, 0.0, 1.0]])
-    return inv[:2]
+    if (sp.h, sp.w) != (float(oh), float(ow)):
+        sp.resize(oh, ow)                      # the trailing Resize to the network shape
+    r = np.zeros(AUG_RECORD, np.float32)
+    r[0:6] = sp.M[:2].reshape(-1)
+    r[6:9], r[9:12] = sp.add, sp.mul
+    r[12] = sp.flags
+    r[13] = int(round(min(max(sp.gray, 0.0), 1.0) * 256))
+    r[14] = int(round(sp.noise * 65536.0 / IRWIN_HALL_STD))
+    r[15] = int(round(min(max(sp.drop, 0.0), 1.0) * (1 << 24)))
+    if sp.adde is not None:
+        r[16], r[17] = sp.adde
+    if sp.mule is not None:
+        r[18], r[19] = sp.mule
+    r[20] = seed & 0xffffff
+    return r
 
 
 def sample_batch(spec, rng, n, h, w, out_hw):
-    """float32 [n,10] parameter records for ``stp_augment_u8`` (m00 m01 m02 m10 m11 m12 add mul 0 0)."""
-    out = np.zeros((n, 10), np.float32)
+    """float32 [n,24] parameter records for ``stp_augment_u8``."""
+    out = np.zeros((n, AUG_RECORD), np.float32)
     for i in range(n):
-        sp = SampleParams()
+        sp = SampleParams(h, w)
         _apply(spec, rng, sp)
-        out[i, :6] = matrix(sp, h, w, out_hw).reshape(-1)
-        out[i, 6], out[i, 7] = sp.add, sp.mul
+        out[i] = record(sp, out_hw, int(rng.randint(0, 1 << 24)) if sp.flags or sp.noise or sp.drop else 0)
     return out
 
 

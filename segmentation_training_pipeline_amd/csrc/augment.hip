@@ -5,14 +5,38 @@
 // the host into ONE 2x3 matrix per sample that maps output pixel centres to input pixel
 // coordinates.  Sampling uses cv2.warpAffine-style fixed point so that results are integer-exact
 // and reproducible on any device: coordinates carry 10 fractional bits, bilinear weights 5 bits
-// per axis, border = constant 0.  Masks use nearest neighbour.  Colour ops Add (integer) and
-// Multiply (float, round-half-even) follow on the uint8 result, saturating like imgaug.
+// per axis, border = constant 0.  Masks use nearest neighbour.  The point operations of the catalogue (Add, Multiply,
+// their Elementwise forms, AdditiveGaussianNoise, Dropout, Grayscale, Invert) follow on the uint8 result, saturating
+// like imgaug; crop / pad augmenters are part of the matrix.
 #include "common.h"
 
+// Per-sample record, STP_AUG_RECORD = 24 floats (integers are stored as exactly representable floats):
+//   0-5   2x3 output->input matrix
+//   6-8   Add per channel (int)            9-11  Multiply per channel (float)
+//   12    flags: 1 Invert | 2 noise per channel | 4 dropout per channel | 8 AddElementwise per channel |
+//                16 MultiplyElementwise per channel | 32 AddElementwise on | 64 MultiplyElementwise on
+//   13    Grayscale alpha in 1/256 (0..256)
+//   14    AdditiveGaussianNoise: k = rint(sigma * 65536 / 147.8) (sigma in 8-bit units; noise = Irwin-Hall sum of 4 bytes)
+//   15    Dropout: threshold on 24 random bits, rint(p * 2^24)
+//   16-17 AddElementwise integer range [lo, hi]     18-19 MultiplyElementwise range [lo, hi]
+//   20    seed (integer < 2^24)                      21-23 reserved
+// Point operations run in this fixed order after the warp: Add, Multiply, MultiplyElementwise, AddElementwise,
+// AdditiveGaussianNoise, Dropout, Grayscale, Invert - all in integer / single-rounded float arithmetic, so the numpy
+// oracle (oracle/augment.py) reproduces them bit for bit; randomness is a counter-based hash of (seed, pixel, channel, op).
 struct AugSample {
   float m[6];
-  float add, mul, r0, r1;
+  float add[3], mul[3];
+  float flags, gray_q, noise_k, drop_t;
+  float adde_lo, adde_hi, mule_lo, mule_hi;
+  float seed, r0, r1, r2;
 };
+
+__device__ __forceinline__ uint32_t aug_hash(uint32_t seed, uint32_t pix, uint32_t ch, uint32_t op) {
+  uint32_t h = seed ^ (pix * 0x9E3779B1u) ^ (ch * 0x85EBCA77u) ^ (op * 0xC2B2AE3Du);
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 
 __device__ __forceinline__ int64_t fix10(double v) { return (int64_t)__double2ll_rn(v); }
 
@@ -39,16 +63,44 @@ __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict_
     const bool x0ok = ix >= 0 && ix < Win, x1ok = ix + 1 >= 0 && ix + 1 < Win;
     const bool y0ok = iy >= 0 && iy < Hin, y1ok = iy + 1 >= 0 && iy + 1 < Hin;
     const uint8_t* b = img + (int64_t)n * Hin * Win * C;
-    const int addi = (int)s.add;
+    const uint32_t flags = (uint32_t)s.flags, seed = (uint32_t)s.seed, pix = (uint32_t)(yo * Wout + xo);
+    const int noise_k = (int)s.noise_k;
+    const uint32_t drop_t = (uint32_t)s.drop_t;
+    const int ae_lo = (int)s.adde_lo, ae_n = (int)s.adde_hi - ae_lo + 1;
+    int px[4] = {0, 0, 0, 0};
     for (int c = 0; c < C; ++c) {
       const int v00 = (x0ok && y0ok) ? b[(iy * Win + ix) * C + c] : 0;
       const int v01 = (x1ok && y0ok) ? b[(iy * Win + ix + 1) * C + c] : 0;
       const int v10 = (x0ok && y1ok) ? b[((iy + 1) * Win + ix) * C + c] : 0;
       const int v11 = (x1ok && y1ok) ? b[((iy + 1) * Win + ix + 1) * C + c] : 0;
       int v = (w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11 + 512) >> 10;
-      v = min(max(v + addi, 0), 255);
-      if (s.mul != 1.f) v = min(max((int)rintf((float)v * s.mul), 0), 255);
-      img_out[i * C + c] = (uint8_t)v;
+      const int cc = c < 3 ? c : 2;
+      v = clip255(v + (int)s.add[cc]);
+      if (s.mul[cc] != 1.f) v = clip255((int)rintf(__fmul_rn((float)v, s.mul[cc])));
+      if (flags & 64u) {
+        const float u = __fmul_rn((float)(aug_hash(seed, pix, (flags & 16u) ? c : 0, 1u) >> 8), 5.9604644775390625e-8f);
+        const float m = __fadd_rn(s.mule_lo, __fmul_rn(__fsub_rn(s.mule_hi, s.mule_lo), u));
+        v = clip255((int)rintf(__fmul_rn((float)v, m)));
+      }
+      if (flags & 32u) v = clip255(v + ae_lo + (int)(aug_hash(seed, pix, (flags & 8u) ? c : 0, 2u) % (uint32_t)ae_n));
+      if (noise_k) {
+        const uint32_t h = aug_hash(seed, pix, (flags & 2u) ? c : 0, 3u);
+        const int sum = (int)(h & 255u) + (int)((h >> 8) & 255u) + (int)((h >> 16) & 255u) + (int)(h >> 24);
+        v = clip255(v + (((sum - 510) * noise_k + 32768) >> 16));
+      }
+      if (drop_t && (aug_hash(seed, pix, (flags & 4u) ? c : 0, 4u) >> 8) < drop_t) v = 0;
+      if (c < 4) px[c] = v;
+      if (C != 3) img_out[i * C + c] = (uint8_t)((flags & 1u) ? 255 - v : v);
+    }
+    if (C == 3) {
+      const int gq = (int)s.gray_q;
+      if (gq) {  // cv2 RGB2GRAY fixed point, blended with alpha = gq/256
+        const int gray = (px[0] * 4899 + px[1] * 9617 + px[2] * 1868 + 8192) >> 14;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px[c] = (gq * gray + (256 - gq) * px[c] + 128) >> 8;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) img_out[i * 3 + c] = (uint8_t)((flags & 1u) ? 255 - px[c] : px[c]);
     }
     if (mask) {
       const int64_t mx = (X0 + 512) >> 10, my = (Y0 + 512) >> 10;

@@ -126,16 +126,38 @@ def test_callbacks_lr_policies():
 
 def test_augment_matrices_match_the_oracle_and_reject_unknown():
     rng = np.random.RandomState(0)
+    # augmenters compose in the listed order (imgaug Sequential): flip first, then the affine about the centre
     spec = [{"Fliplr": 1.0}, {"Affine": {"scale": 1.3, "translate_percent": {"x": 0.1, "y": -0.05}, "rotate": 12, "shear": -7}},
             {"Add": 7}, {"Multiply": 1.1}]
     prm = augment.sample_batch(spec, rng, 1, 40, 52, (32, 48))
-    ref = oaug.affine_matrix(40, 52, 1.3, (0.1, -0.05), 12.0, -7.0, True, False, (32, 48))
+    assert prm.shape == (1, augment.AUG_RECORD) == (1, oaug.AUG_RECORD)
+    ref = oaug.compose(40, 52, [("fliplr",), ("affine", 1.3, (0.1, -0.05), 12.0, -7.0)], (32, 48))
     np.testing.assert_allclose(prm[0, :6].reshape(2, 3), ref[:2], rtol=1e-6, atol=1e-5)
-    assert prm[0, 6] == 7 and abs(prm[0, 7] - 1.1) < 1e-6
+    assert list(prm[0, 6:9]) == [7, 7, 7] and np.allclose(prm[0, 9:12], 1.1, atol=1e-6) and prm[0, 12] == 0
     ident = augment.identity_batch(2, 64, 64, (64, 64))
     np.testing.assert_allclose(ident[0, :6], [1, 0, 0, 0, 1, 0], atol=1e-12)
-    with pytest.raises(ValueError, match="GaussianBlur"):
-        augment.sample_batch([{"GaussianBlur": 1.0}], rng, 1, 8, 8, (8, 8))
+    # crop / pad family: deterministic cases against the oracle's canvas algebra
+    prm = augment.sample_batch([{"CropToFixedSize": {"width": 52, "height": 40}}, {"PadToFixedSize": {"width": 52, "height": 40}},
+                                {"Pad": {"px": [3, 1, 2, 4]}}, {"Flipud": 1.0}], rng, 1, 40, 52, (20, 26))
+    ref = oaug.compose(40, 52, [("crop", -3, -4, 45, 57), ("resize", 40, 52), ("flipud",)], (20, 26))
+    np.testing.assert_allclose(prm[0, :6].reshape(2, 3), ref[:2], rtol=1e-6, atol=1e-5)
+    prm = augment.sample_batch([{"CropAndPad": {"percent": -0.1}}], rng, 1, 40, 50, (40, 50))      # crop 10 % per side, keep size
+    ref = oaug.compose(40, 50, [("crop", 4, 5, 32, 40), ("resize", 40, 50)], (40, 50))
+    np.testing.assert_allclose(prm[0, :6].reshape(2, 3), ref[:2], rtol=1e-6, atol=1e-5)
+    # point operations land in the record (include/stp_hip.h layout)
+    prm = augment.sample_batch([{"Invert": 1.0}, {"Grayscale": {"alpha": 0.5}}, {"AdditiveGaussianNoise": {"scale": 12.75, "per_channel": True}},
+                                {"Dropout": {"p": 0.25}}, {"AddElementwise": [-10, 10]}, {"MultiplyElementwise": {"mul": [0.9, 1.1], "per_channel": True}},
+                                {"Add": {"value": [-5, 5], "per_channel": True}}], rng, 1, 8, 8, (8, 8))[0]
+    F = augment
+    assert int(prm[12]) == F.F_INVERT | F.F_NOISE_PC | F.F_ADDE | F.F_MULE | F.F_MULE_PC
+    assert prm[13] == 128 and prm[14] == round(12.75 * 65536 / 147.8) and prm[15] == (1 << 22)
+    assert (prm[16], prm[17]) == (-10, 10) and np.allclose(prm[18:20], [0.9, 1.1]) and 0 <= prm[20] < (1 << 24)
+    assert len(set(prm[6:9])) > 1                                   # per-channel Add drew three values
+    picks = {int(augment.sample_batch([{"OneOf": [{"Invert": 1.0}, {"Dropout": 0.5}]}], rng, 1, 8, 8, (8, 8))[0, 12]) for _ in range(20)}
+    assert picks == {0, 1}                                          # OneOf takes exactly one child
+    for bad in ("GaussianBlur", "ElasticTransformation", "Sharpen"):
+        with pytest.raises(ValueError, match=bad):
+            augment.sample_batch([{bad: 1.0}], rng, 1, 8, 8, (8, 8))
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
 
 

@@ -669,6 +669,48 @@ def test_augment_fixed_point_warp_bit_exact(ops):
     np.testing.assert_array_equal(mo.cpu().numpy(), rm)
 
 
+@pytest.mark.parametrize("channels", [3, 1])
+def test_augment_point_operations_bit_exact(ops, channels):
+    """Every point operation of the catalogue (per-channel Add/Multiply, Multiply/AddElementwise, AdditiveGaussianNoise,
+    Dropout, Grayscale, Invert) and the crop/pad canvas algebra against the numpy oracle: bytes must be identical."""
+    rng = np.random.RandomState(16)
+    n, h, w, oh, ow = 6, 36, 44, 32, 40
+    img = rng.randint(0, 256, size=(n, h, w, channels)).astype(np.uint8)
+    mask = rng.randint(0, 3, size=(n, h, w)).astype(np.uint8)
+    mats = [oaug.compose(h, w, [("fliplr",), ("affine", 1.1, (0.05, 0.0), 8.0, 3.0)], (oh, ow)),
+            oaug.compose(h, w, [("crop", 4, 6, 24, 30)], (oh, ow)),                 # CropToFixedSize
+            oaug.compose(h, w, [("crop", -5, -3, 50, 52)], (oh, ow)),               # PadToFixedSize
+            oaug.compose(h, w, [("crop", -2, -4, 41, 50), ("resize", h, w), ("flipud",)], (oh, ow)),   # Pad (keep size) + flip
+            oaug.compose(h, w, [], (oh, ow)), oaug.compose(h, w, [], (oh, ow))]
+    prm = oaug.pack_params(
+        mats, [[3, -4, 5], 0, 0, 10, 0, -7], [[1.1, 0.9, 1.0], 1.0, 1.05, 1.0, 1.0, 1.0],
+        invert=[False, True, False, False, True, False], gray_alpha=[0.0, 0.0, 1.0, 0.4, 0.0, 0.0],
+        noise_sigma=[0.0, 8.0, 0.0, 12.75, 0.0, 25.0], noise_per_channel=[False, True, False, False, False, True],
+        dropout_p=[0.0, 0.0, 0.2, 0.0, 0.1, 0.0], dropout_per_channel=[False, False, True, False, False, False],
+        add_elem=[None, (-10, 10), None, (-3, 7), None, (0, 0)], add_elem_per_channel=[False, True, False, False, False, False],
+        mul_elem=[None, None, (0.8, 1.2), None, (0.9, 1.1), None], mul_elem_per_channel=[False, False, True, False, False, False],
+        seed=[0, 12345, 999, 77, 0xABCDE, 5])
+    ri, rm = oaug.warp_u8(img, mask, prm, (oh, ow))
+    io = torch.empty((n, oh, ow, channels), dtype=torch.uint8, device=DEV)
+    mo = torch.empty((n, oh, ow), dtype=torch.uint8, device=DEV)
+    ops.augment_u8(keep(torch.from_numpy(img).to(DEV)), keep(torch.from_numpy(mask).to(DEV)), io, mo, keep(torch.from_numpy(prm).to(DEV)),
+                   n, h, w, oh, ow, channels)
+    torch.cuda.synchronize()
+    got = io.cpu().numpy()
+    for i in range(n):
+        np.testing.assert_array_equal(got[i], ri[i], err_msg="sample %d" % i)
+    np.testing.assert_array_equal(mo.cpu().numpy(), rm)
+    # the generators do what their names say: noise ~ N(0, sigma), dropout rate ~ p
+    flat = np.full((1, 64, 64, 3), 128, np.uint8)
+    one = oaug.pack_params([oaug.compose(64, 64, [], (64, 64))], [0], [1.0], noise_sigma=[10.0], noise_per_channel=[True], seed=[42])
+    o, _ = oaug.warp_u8(flat, None, one, (64, 64))
+    d = o.astype(np.float64) - 128
+    assert abs(d.mean()) < 0.5 and 9.0 < d.std() < 11.0
+    one = oaug.pack_params([oaug.compose(64, 64, [], (64, 64))], [0], [1.0], dropout_p=[0.3], seed=[43])
+    o, _ = oaug.warp_u8(flat, None, one, (64, 64))
+    assert 0.25 < (o[..., 0] == 0).mean() < 0.35 and np.array_equal(o[..., 0] == 0, o[..., 2] == 0)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_batched_weight_prepare_equals_per_layer(ops, dtype):
     """The once-per-step batched launch (LDS tile transpose) must write exactly what stp_weight_prepare writes
