@@ -290,6 +290,13 @@ int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, floa
 int stp_augment_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out,
                    const float* params, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
                    int32_t C, void* stream);
+/* Neighbourhood filters of the augmenter catalogue on a uint8 batch [N,H,W,C] (src != dst): per image an
+ * int32[STP_FILTER_RECORD] record = K (odd <= 13; 0 = copy), mode (0 = linear K x K filter, 1 = median), 0, 0, K*K weights
+ * in 1/16384 units.  Reflect-101 border, integer arithmetic (bit-exact against the oracle).  GaussianBlur, AverageBlur,
+ * Sharpen, Emboss and EdgeDetect are linear filters whose weights the host derives; MedianBlur is mode 1. */
+#define STP_FILTER_RECORD 173
+int stp_filter_u8(const uint8_t* src, uint8_t* dst, const int32_t* params, int32_t N, int32_t H, int32_t W, int32_t C,
+                  void* stream);
 
 /* Gradient-bucket helpers for the RCCL all-reduce (fp32 <-> bf16 wire format). */
 int stp_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);

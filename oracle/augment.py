@@ -207,3 +207,26 @@ def warp_u8(img, mask, params, out_hw):
             ok = (mx >= 0) & (mx < w) & (my >= 0) & (my < h)
             mask_out[i] = mask[i][np.clip(my, 0, h - 1), np.clip(mx, 0, w - 1)] * ok
     return img_out, mask_out
+
+
+FILTER_RECORD = 173      # int32 per image: K, mode, 0, 0, 13*13 weights (include/stp_hip.h, stp_filter_u8)
+
+
+def filter_u8(img, recs):
+    """img [N,H,W,C] u8, recs int32 [N,173] -> filtered copy; bit-exact restatement of stp_filter_u8."""
+    out = img.copy()
+    n, h, w, c = img.shape
+    for i in range(n):
+        K, mode = int(recs[i, 0]), int(recs[i, 1])
+        if K <= 0:
+            continue
+        r = K // 2
+        pad = np.pad(img[i].astype(np.int64), ((r, r), (r, r), (0, 0)), mode="reflect")    # numpy's reflect == reflect-101
+        win = np.stack([pad[ky:ky + h, kx:kx + w] for ky in range(K) for kx in range(K)], axis=0)   # [K*K,H,W,C]
+        if mode == 0:
+            wts = recs[i, 4:4 + K * K].astype(np.int64)
+            acc = (win * wts[:, None, None, None]).sum(axis=0)
+            out[i] = np.clip((acc + 8192) >> 14, 0, 255).astype(np.uint8)
+        else:
+            out[i] = np.sort(win, axis=0)[(K * K) // 2].astype(np.uint8)
+    return out

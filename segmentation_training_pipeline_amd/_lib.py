@@ -82,6 +82,7 @@ SIGNATURES = {
     "stp_nadam": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, vp, vp, f32, vp]),
     "stp_grad_global_scale": (i32, [vp, i64, f32, f32, vp, vp, sz, vp]),
     "stp_augment_u8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_filter_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "stp_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "stp_cast_bf16_to_f32": (i32, [vp, vp, i64, f32, vp]),
 }

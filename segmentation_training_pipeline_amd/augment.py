@@ -15,8 +15,11 @@ Supported augmenters (YAML name -> effect):
     AddElementwise, MultiplyElementwise, AdditiveGaussianNoise{scale, per_channel}, Dropout{p, per_channel},
     Grayscale{alpha}, Invert(p);
   containers: Sequential, Sometimes{p, then_list}, OneOf.
-Neighbourhood filters (GaussianBlur, AverageBlur, MedianBlur, Sharpen, Emboss, EdgeDetect), PiecewiseAffine,
-ElasticTransformation and BackgroundReplacer raise ``ValueError`` naming the augmenter (no silent skipping).
+  neighbourhood filters (a second kernel, ``stp_filter_u8``, on the augmented batch at the network resolution, after the
+    point operations; up to MAX_FILTERS per image, in the listed order): GaussianBlur{sigma}, AverageBlur{k},
+    MedianBlur{k}, Sharpen{alpha, lightness}, Emboss{alpha, strength}, EdgeDetect{alpha}.
+PiecewiseAffine, ElasticTransformation, DirectedEdgeDetect and BackgroundReplacer raise ``ValueError`` naming the
+augmenter (no silent skipping).
 """
 import math
 
@@ -25,6 +28,7 @@ import numpy as np
 AUG_RECORD = 24
 F_INVERT, F_NOISE_PC, F_DROP_PC, F_ADDE_PC, F_MULE_PC, F_ADDE, F_MULE = 1, 2, 4, 8, 16, 32, 64
 IRWIN_HALL_STD = 147.8   # std of the sum of 4 uniform bytes (the kernel's Gaussian-noise generator)
+FILTER_RECORD, FILTER_KMAX, MAX_FILTERS = 173, 13, 2
 
 
 def _rng_range(rng, v, default):
@@ -54,6 +58,7 @@ class SampleParams(object):
         self.flags = 0
         self.gray, self.noise, self.drop = 0.0, 0.0, 0.0
         self.adde, self.mule = None, None
+        self.filters = []                           # [(K, mode, weights K*K float or None)]
 
     # ---- geometry: every op appends the map from the NEW canvas to the PREVIOUS one
     def push(self, cur_to_prev):
@@ -169,6 +174,12 @@ def _apply(spec, rng, sp):
                 sp.flags |= F_DROP_PC
         elif name == "Grayscale":
             sp.gray = _rng_range(rng, _arg(args, "alpha", 1.0), 1.0)
+        elif name in ("GaussianBlur", "AverageBlur", "MedianBlur", "Sharpen", "Emboss", "EdgeDetect"):
+            f = _filter(name, args, rng)
+            if f is not None:
+                if len(sp.filters) >= MAX_FILTERS:
+                    raise ValueError("more than %d neighbourhood filters in one augmentation pipeline" % MAX_FILTERS)
+                sp.filters.append(f)
         elif name == "Sequential":
             _apply(_children(args), rng, sp)
         elif name == "Sometimes":
@@ -181,6 +192,66 @@ def _apply(spec, rng, sp):
                 _apply([ch[rng.randint(0, len(ch))]], rng, sp)
         else:
             raise ValueError("augmenter %r is not available in the HIP augmentation stage" % name)
+
+
+def _odd_k(rng, k):
+    k = int(round(_rng_range(rng, k, 3)))
+    return k
+
+
+def _filter(name, args, rng):
+    """(K, mode, weights) of one neighbourhood augmenter; None when it samples to the identity."""
+    if name == "GaussianBlur":
+        sigma = _rng_range(rng, _arg(args, "sigma", 0.0), 0.0)
+        if sigma < 1e-3:
+            return None
+        K = min(FILTER_KMAX, 2 * int(math.ceil(3.0 * sigma)) + 1)          # +-3 sigma, truncated at radius 6 (sigma > 2)
+        x = np.arange(K) - K // 2
+        g = np.exp(-0.5 * (x / sigma) ** 2)
+        g /= g.sum()
+        return K, 0, np.outer(g, g)
+    if name in ("AverageBlur", "MedianBlur"):
+        k = _odd_k(rng, _arg(args, "k", 3))
+        if name == "MedianBlur" and k % 2 == 0:
+            k += 1                                                            # imgaug: even sizes are incremented
+        if k <= 1:
+            return None
+        k = min(k, FILTER_KMAX)
+        if name == "MedianBlur":
+            return k, 1, None
+        K = k if k % 2 else k + 1                                             # an even box sits in an odd window (anchor like cv2.blur)
+        wts = np.zeros((K, K))
+        wts[:k, :k] = 1.0 / (k * k)
+        return K, 0, wts
+    alpha = _rng_range(rng, _arg(args, "alpha", 1.0) if isinstance(args, dict) else args, 1.0)
+    ident = np.zeros((3, 3)); ident[1, 1] = 1.0
+    if name == "Sharpen":
+        l = _rng_range(rng, _arg(args, "lightness", 1.0) if isinstance(args, dict) else None, 1.0)
+        eff = np.array([[-1, -1, -1], [-1, 8 + l, -1], [-1, -1, -1]], np.float64)
+    elif name == "Emboss":
+        st = _rng_range(rng, _arg(args, "strength", 1.0) if isinstance(args, dict) else None, 1.0)
+        eff = np.array([[-1 - st, 0 - st, 0], [0 - st, 1, 0 + st], [0, 0 + st, 1 + st]], np.float64)
+    else:
+        eff = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], np.float64)
+    if alpha <= 0:
+        return None
+    return 3, 0, (1.0 - alpha) * ident + alpha * eff
+
+
+def filter_records(filters_per_image):
+    """[[(K, mode, weights), ...] per image] -> None (no filter anywhere) or int32 [passes, n, 173] for stp_filter_u8."""
+    passes = max((len(f) for f in filters_per_image), default=0)
+    if passes == 0:
+        return None
+    out = np.zeros((passes, len(filters_per_image), FILTER_RECORD), np.int32)
+    for i, fl in enumerate(filters_per_image):
+        for ps, (K, mode, wts) in enumerate(fl):
+            out[ps, i, 0], out[ps, i, 1] = K, mode
+            if wts is not None:
+                q = np.rint(np.asarray(wts, np.float64) * 16384.0).astype(np.int64).reshape(-1)
+                q[(K * K) // 2 if q[(K * K) // 2] else int(np.argmax(np.abs(q)))] += int(round(float(np.sum(wts)) * 16384.0)) - int(q.sum())
+                out[ps, i, 4:4 + K * K] = q                     # the quantised weights keep the filter's exact DC gain
+    return out
 
 
 def record(sp, out_hw, seed):
@@ -203,13 +274,23 @@ def record(sp, out_hw, seed):
     return r
 
 
-def sample_batch(spec, rng, n, h, w, out_hw):
-    """float32 [n,24] parameter records for ``stp_augment_u8``."""
+def sample_batch_ex(spec, rng, n, h, w, out_hw):
+    """(float32 [n,24] records for ``stp_augment_u8``, None or int32 [passes,n,173] records for ``stp_filter_u8``)."""
     out = np.zeros((n, AUG_RECORD), np.float32)
+    filt = []
     for i in range(n):
         sp = SampleParams(h, w)
         _apply(spec, rng, sp)
         out[i] = record(sp, out_hw, int(rng.randint(0, 1 << 24)) if sp.flags or sp.noise or sp.drop else 0)
+        filt.append(sp.filters)
+    return out, filter_records(filt)
+
+
+def sample_batch(spec, rng, n, h, w, out_hw):
+    """float32 [n,24] parameter records for ``stp_augment_u8`` (pipelines without neighbourhood filters)."""
+    out, filt = sample_batch_ex(spec, rng, n, h, w, out_hw)
+    if filt is not None:
+        raise ValueError("this pipeline contains neighbourhood filters: use sample_batch_ex")
     return out
 
 

@@ -121,3 +121,65 @@ extern "C" int stp_augment_u8(const uint8_t* img, const uint8_t* mask, uint8_t* 
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Neighbourhood filters of the catalogue (GaussianBlur, AverageBlur, Sharpen, Emboss, EdgeDetect = a K x K linear
+// filter; MedianBlur = rank selection) on the augmented uint8 batch, one per-image record:
+//   int32[STP_FILTER_RECORD = 4 + 13*13]: K (odd, 0 = copy, <= 13), mode (0 linear, 1 median), 0, 0, then K*K weights
+//   in 1/16384 (row-major; ignored for the median).  Border: reflect-101 (cv2.filter2D / cv2.blur default).
+// Integer arithmetic throughout -> bit-exact against the numpy oracle.  Masks are not filtered (as in imgaug).
+#define STP_FILTER_RECORD 173
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void filter_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                        const int32_t* __restrict__ prm, int N, int H, int W, int C) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int x = (int)((i / C) % W);
+    const int y = (int)((i / ((int64_t)C * W)) % H);
+    const int n = (int)(i / ((int64_t)C * W * H));
+    const int32_t* r = prm + (size_t)n * STP_FILTER_RECORD;
+    const int K = r[0];
+    if (K <= 0) { dst[i] = src[i]; continue; }
+    const int rad = K >> 1;
+    const uint8_t* b = src + (int64_t)n * H * W * C + c;
+    if (r[1] == 0) {
+      int acc = 0;
+      for (int ky = 0; ky < K; ++ky) {
+        const int yy = reflect101(y + ky - rad, H);
+        for (int kx = 0; kx < K; ++kx) acc += r[4 + ky * K + kx] * (int)b[((int64_t)yy * W + reflect101(x + kx - rad, W)) * C];
+      }
+      dst[i] = (uint8_t)min(max((acc + 8192) >> 14, 0), 255);
+    } else {
+      // median of K*K bytes by counting: the smallest value v with #(values <= v) > K*K/2
+      int hist_lo = 0, lo = 0, hi = 255;
+      const int need = (K * K) / 2 + 1;
+      while (lo < hi) {            // binary search over the value range, one pass over the window per step
+        const int mid = (lo + hi) >> 1;
+        int cnt = 0;
+        for (int ky = 0; ky < K; ++ky) {
+          const int yy = reflect101(y + ky - rad, H);
+          for (int kx = 0; kx < K; ++kx) cnt += (int)b[((int64_t)yy * W + reflect101(x + kx - rad, W)) * C] <= mid;
+        }
+        if (cnt >= need) hi = mid; else lo = mid + 1;
+      }
+      (void)hist_lo;
+      dst[i] = (uint8_t)lo;
+    }
+  }
+}
+
+extern "C" int stp_filter_u8(const uint8_t* src, uint8_t* dst, const int32_t* params, int32_t N, int32_t H, int32_t W, int32_t C,
+                             void* stream) {
+  if (!src || !dst || !params || src == dst || N <= 0 || H <= 0 || W <= 0 || C <= 0) return STP_E_BADARG;
+  int64_t g = ((int64_t)N * H * W * C + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(filter_u8_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, src, dst, params, N, H, W, C);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}

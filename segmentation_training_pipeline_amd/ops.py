@@ -187,6 +187,10 @@ def augment_u8(img, mask, img_out, mask_out, params, N, Hin, Win, Hout, Wout, Cn
               stream())
 
 
+def filter_u8(src, dst, params, N, H, W, Cn):
+    _lib.call("stp_filter_u8", ptr(src), ptr(dst), ptr(params), N, H, W, Cn, stream())
+
+
 def cast_f32_to_bf16(src, dst, count):
     _lib.call("stp_cast_f32_to_bf16", ptr(src), ptr(dst), count, stream())
 

@@ -199,12 +199,25 @@ class DeviceFeeder(object):
                 y = np.ascontiguousarray(y.argmax(axis=2).astype(np.uint8))
             else:                                  # label image
                 y = np.ascontiguousarray(np.minimum(y[:, :, 0], self.classes - 1).astype(np.uint8))
-            prm = augment.sample_batch(self.spec if training else [], self.rng, 1, h, w, (oh, ow))
+            prm, filt = augment.sample_batch_ex(self.spec if training else [], self.rng, 1, h, w, (oh, ow))
             xd = torch.from_numpy(x).to(self.device, non_blocking=True)
             yd = torch.from_numpy(y).to(self.device, non_blocking=True)
             pd = torch.from_numpy(prm).to(self.device, non_blocking=True)
             self._keep += [xd, yd, pd]
-            ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, 3)
+            if filt is None:
+                ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, 3)
+                continue
+            # neighbourhood filters: augment into a staging image, then one stp_filter_u8 pass per filter (ping-pong),
+            # the last one writing the plan's input buffer
+            fd = torch.from_numpy(filt).to(self.device, non_blocking=True)
+            bufs = [torch.empty((oh, ow, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self._keep += [fd] + bufs
+            ops.augment_u8(xd, yd, bufs[0], msk_buf[i], pd, 1, h, w, oh, ow, 3)
+            src = 0
+            for ps in range(filt.shape[0]):
+                dst = img_buf[i] if ps == filt.shape[0] - 1 else bufs[1 - src]
+                ops.filter_u8(bufs[src], dst, fd[ps], 1, oh, ow, 3)
+                src = 1 - src
 
 
 def derived_metrics(scal, classes=1):

@@ -95,7 +95,13 @@ def test_linknet_yaml_fits(tmp_path):
         yaml.safe_dump({"architecture": "Linknet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid",
                         "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.002, "batch": 4, "folds_count": 2,
                         "loss": "binary_crossentropy+1.0*dice_loss", "metrics": ["binary_accuracy", "dice"],
-                        "primary_metric": "val_dice", "stages": [{"epochs": 5}]}, f)
+                        "primary_metric": "val_dice", "stages": [{"epochs": 5}],
+                        # the wider augmenter catalogue through the device feeder: crop/pad in the matrix, point operations,
+                        # and a neighbourhood filter pass (stp_filter_u8) chosen by OneOf
+                        "augmentation": {"Fliplr": 0.5, "CropAndPad": {"percent": [-0.05, 0.05]},
+                                         "OneOf": [{"GaussianBlur": {"sigma": [0.0, 1.0]}}, {"AverageBlur": {"k": 3}},
+                                                   {"MedianBlur": {"k": 3}}],
+                                         "AdditiveGaussianNoise": {"scale": [0, 8]}, "Multiply": {"mul": [0.9, 1.1], "per_channel": True}}}, f)
     cfg = segmentation.parse(cfg_path)
     out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
     assert [(s["fold"], s["stage"]) for s in out] == [(0, 0)]

@@ -155,9 +155,17 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     assert len(set(prm[6:9])) > 1                                   # per-channel Add drew three values
     picks = {int(augment.sample_batch([{"OneOf": [{"Invert": 1.0}, {"Dropout": 0.5}]}], rng, 1, 8, 8, (8, 8))[0, 12]) for _ in range(20)}
     assert picks == {0, 1}                                          # OneOf takes exactly one child
-    for bad in ("GaussianBlur", "ElasticTransformation", "Sharpen"):
+    for bad in ("PiecewiseAffine", "ElasticTransformation", "BackgroundReplacer"):
         with pytest.raises(ValueError, match=bad):
             augment.sample_batch([{bad: 1.0}], rng, 1, 8, 8, (8, 8))
+    # neighbourhood filters come back as a second record set (stp_filter_u8), at most MAX_FILTERS per image
+    prm, filt = augment.sample_batch_ex([{"OneOf": [{"GaussianBlur": {"sigma": [0.5, 1.0]}}, {"MedianBlur": {"k": 3}}]}, {"Sharpen": 0.5}],
+                                        rng, 3, 8, 8, (8, 8))
+    assert prm.shape == (3, 24) and filt.shape == (2, 3, augment.FILTER_RECORD) and set(filt[1, :, 0]) == {3}
+    with pytest.raises(ValueError, match="use sample_batch_ex"):
+        augment.sample_batch([{"AverageBlur": 3}], rng, 1, 8, 8, (8, 8))
+    with pytest.raises(ValueError, match="more than 2"):
+        augment.sample_batch_ex([{"AverageBlur": 3}] * 3, rng, 1, 8, 8, (8, 8))
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
 
 

@@ -711,6 +711,45 @@ def test_augment_point_operations_bit_exact(ops, channels):
     assert 0.25 < (o[..., 0] == 0).mean() < 0.35 and np.array_equal(o[..., 0] == 0, o[..., 2] == 0)
 
 
+def test_neighbourhood_filters_bit_exact(ops):
+    """stp_filter_u8 (GaussianBlur / AverageBlur / Sharpen / Emboss / EdgeDetect as K x K linear filters, MedianBlur as rank
+    selection; reflect-101 border) against the numpy oracle, records produced by the host sampler."""
+    from segmentation_training_pipeline_amd import augment
+    rng = np.random.RandomState(17)
+    specs = [[{"GaussianBlur": {"sigma": 1.2}}], [{"AverageBlur": {"k": 3}}], [{"AverageBlur": 4}], [{"MedianBlur": {"k": 5}}],
+             [{"Sharpen": {"alpha": 0.6, "lightness": 1.3}}], [{"Emboss": {"alpha": 0.5, "strength": 1.5}}], [{"EdgeDetect": 0.4}],
+             [{"GaussianBlur": 2.5}, {"Sharpen": {"alpha": 1.0, "lightness": 0.8}}], [], [{"MedianBlur": 3}]]
+    per_image = []
+    for sp_ in specs:
+        _, f = augment.sample_batch_ex(sp_, rng, 1, 8, 8, (8, 8))
+        per_image.append(f)
+    passes = max(0 if f is None else f.shape[0] for f in per_image)
+    recs = np.zeros((passes, len(specs), augment.FILTER_RECORD), np.int32)
+    for i, f in enumerate(per_image):
+        if f is not None:
+            recs[:f.shape[0], i] = f[:, 0]
+    assert passes == 2 and recs[0, 0, 0] == 9 and recs[0, 7, 0] == 13 and recs[1, 7, 0] == 3 and recs[0, 8, 0] == 0
+    assert recs[0, 0, 4:4 + 81].sum() == 16384 and recs[0, 2, 0] == 5 and recs[0, 3, 1] == 1     # unit DC gain; even box in odd window
+    for (h, w, c) in [(21, 30, 3), (5, 4, 1)]:
+        img = rng.randint(0, 256, size=(len(specs), h, w, c)).astype(np.uint8)
+        cur = keep(torch.from_numpy(img).to(DEV))
+        ref = img
+        for ps in range(passes):
+            nxt = torch.empty_like(cur)
+            ops.filter_u8(cur, nxt, keep(torch.from_numpy(recs[ps]).to(DEV)), len(specs), h, w, c)
+            ref = oaug.filter_u8(ref, recs[ps])
+            cur = keep(nxt)
+        got = cur.cpu().numpy()
+        for i in range(len(specs)):
+            np.testing.assert_array_equal(got[i], ref[i], err_msg="spec %d at %dx%dx%d" % (i, h, w, c))
+        np.testing.assert_array_equal(got[8], img[8])                         # no filter: copied through
+    flat = np.full((1, 9, 9, 3), 77, np.uint8)
+    for ps in range(passes):                                                  # constant images stay constant (DC gain exactly 1)
+        for i in range(len(specs)):
+            if recs[ps, i, 0] and (recs[ps, i, 1] == 1 or recs[ps, i, 4:].sum() == 16384):
+                np.testing.assert_array_equal(oaug.filter_u8(flat, recs[ps, i:i + 1]), flat)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_batched_weight_prepare_equals_per_layer(ops, dtype):
     """The once-per-step batched launch (LDS tile transpose) must write exactly what stp_weight_prepare writes
