@@ -26,7 +26,7 @@ CUSTOM_KEYS = {
     "metrics", "primary_metric", "primary_metric_mode", "callbacks", "stages", "folds_count", "random_state",
     "extra_train_data", "dataset_augmenter", "classifier", "classifier_lr", "testSplit", "dataset", "datasets", "fit_with",
     "imports", "import_tasks", "run_tasks", "copyWeights", "dtype", "gpus", "inference_batch", "testTimeAugmentation",
-    "compressPredictionsAsInts", "compressScale", "showDataExamples", "bgr", "stratified", "validationSplit",
+    "compressPredictionsAsInts", "compressScale", "showDataExamples", "bgr", "stratified", "validationSplit", "draw_examples",
 }
 # (meta.alias) renames, schemas/segmentation.raml:50-51,67-68,175-176
 ALIASES = {"backbone": "backbone_name", "shape": "input_shape", "use_batchnorm": "decoder_use_batchnorm"}
@@ -122,6 +122,58 @@ class CyclicLR(object):
 
 
 CALLBACKS = {"EarlyStopping": EarlyStopping, "ReduceLROnPlateau": ReduceLROnPlateau, "CyclicLR": CyclicLR}
+
+
+class DrawResults(object):
+    """Per-epoch example sheets (reference segmentation.py:216-247, 251-257): up to ``limit`` samples of the fold's
+    validation set (or, with ``train=True`` = ``cfg.showDataExamples``, augmented training samples) go through
+    ``model.predict``; image | ground truth | prediction > 0.5 are written side by side to
+    ``examples/<stage>/<fold>/t_epoch_<epoch>.<n>.jpg`` (``t_epoch_train<epoch>.<n>.jpg`` for the training variant)."""
+
+    def __init__(self, cfg, ds, indexes, fold, stage, limit=16, train=False, drawingFunction=None):
+        self.cfg, self.ds, self.fold, self.stage, self.train = cfg, ds, fold, stage, train
+        self.indexes = [int(i) for i in list(indexes)[:limit]]
+        self.drawingFunction = drawingFunction or draw_test_batch
+        self.stop = False
+
+    def on_epoch_end(self, trainer, epoch, logs=None):
+        if trainer.rank != 0 or not self.indexes:
+            return
+        m = trainer.model
+        items = [self.ds[i] for i in self.indexes]
+        B = m.batch
+        dr = os.path.join(os.path.dirname(os.path.abspath(self.cfg.path)), "examples", str(self.stage), str(self.fold))
+        os.makedirs(dr, exist_ok=True)
+        for num, s in enumerate(range(0, len(items), B)):
+            chunk = items[s:s + B]
+            ip = m.eval_plan()
+            trainer.feeder.feed(ip, chunk, training=self.train)       # resize only, or the training augmentation
+            xs = ip.inputs["image"].buf[:len(chunk)].cpu().numpy()
+            ys = ip.inputs["mask"].buf[:len(chunk)].cpu().numpy()
+            pred = m.predict(xs)
+            name = ("t_epoch_train" if self.train else "t_epoch_") + str(epoch) + "." + str(num) + ".jpg"
+            self.drawingFunction(EvalSheet(xs, ys, pred > 0.5), os.path.join(dr, name))
+
+
+class EvalSheet(object):
+    """What a drawing function receives: network-shape ``images_aug`` (uint8), ``segmentation_maps_aug`` (ground truth) and
+    ``heatmaps_aug`` (thresholded predictions), the attribute names of the imgaug batch the reference passes."""
+
+    def __init__(self, images, masks, heat):
+        self.images_aug, self.segmentation_maps_aug, self.heatmaps_aug = images, masks, heat
+
+
+def draw_test_batch(batch, path):
+    """Default drawing function: one row per sample, image | ground truth | prediction (class maps scaled to 0..255)."""
+    from PIL import Image
+    rows = []
+    for x, y, p in zip(batch.images_aug, batch.segmentation_maps_aug, batch.heatmaps_aug):
+        y = np.asarray(y).reshape(x.shape[0], x.shape[1], -1)
+        p = np.asarray(p).reshape(x.shape[0], x.shape[1], -1)
+        gt = (y[:, :, 0].astype(np.float32) * (255.0 / max(1, int(y.max())))).astype(np.uint8)
+        pr = ((p.argmax(axis=2) * (255 // max(1, p.shape[2] - 1))) if p.shape[2] > 1 else p[:, :, 0] * 255).astype(np.uint8)
+        rows.append(np.concatenate([x[:, :, :3], np.repeat(gt[:, :, None], 3, 2), np.repeat(pr[:, :, None], 3, 2)], axis=1))
+    Image.fromarray(np.concatenate(rows, axis=0)).save(path, quality=90)
 
 
 def make_callbacks(spec):
@@ -311,6 +363,10 @@ class GenericTaskConfig(object):
         self.gpus = int(a.get("gpus", 1))
         self.inference_batch = int(a.get("inference_batch", self.batch))
         self.showDataExamples = False
+        self.drawingFunction = None
+        # the reference always draws validation examples each epoch; `draw_examples: false` in the YAML (a key of this
+        # backend) switches the per-epoch JPG sheets off for throughput runs
+        self.draw_examples = bool(a.get("draw_examples", True))
         self.resume = False
         self.stages = [self.createStage(s) for s in (a.get("stages") or [{"epochs": 1}])]
         self.dataset_clazz = KFoldedDataSet
@@ -415,6 +471,11 @@ class GenericTaskConfig(object):
         trainer = Trainer(impl, feeder, ds, cbs, rank, world)
         train_idx = kf.sampledIndexes(fold, True, stage.negatives)
         val_idx = kf.sampledIndexes(fold, False, stage.validation_negatives)
+        if self.draw_examples:
+            # SegmentationStage.add_visualization_callbacks (reference segmentation.py:251-257)
+            cbs.append(DrawResults(self, ds, val_idx, fold, si, drawingFunction=self.drawingFunction))
+            if self.showDataExamples:
+                cbs.append(DrawResults(self, ds, train_idx, fold, si, train=True, drawingFunction=self.drawingFunction))
         mode = metric_mode(self.primary_metric, self.primary_metric_mode)
         best, best_epoch, rows = None, -1, []
         t0 = time.time()

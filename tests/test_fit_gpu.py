@@ -51,6 +51,11 @@ def test_parse_fit_predict_end_to_end(tmp_path):
     losses = [float(r["loss"]) for r in rows]
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]           # it learns the bright ellipses
     assert os.path.exists(os.path.join(str(tmp_path), "summary.yaml"))
+    # per-epoch example sheets (reference segmentation.py:233-247): examples/<stage>/<fold>/t_epoch_<e>.<n>.jpg
+    from PIL import Image as _Im
+    sheet = _Im.open(os.path.join(str(tmp_path), "examples", "0", "0", "t_epoch_5.0.jpg"))
+    assert sheet.size == (3 * 128, 4 * 128)                                 # 4 validation samples: image | truth | prediction
+    assert os.path.exists(os.path.join(str(tmp_path), "examples", "1", "0", "t_epoch_1.0.jpg"))
     info = cfg.info()
     assert {(i["fold"], i["stage"]) for i in info} == {(0, 0), (0, 1)}
     # resume: nothing left to do for this fold
