@@ -8,7 +8,7 @@ augmenter + the final resize, in the listed order, into one 2x3 output->input ma
 are moved by one HIP kernel (``stp_augment_u8``), so no CPU worker touches image data.
 
 Supported augmenters (YAML name -> effect):
-  geometry (composed into the matrix): Fliplr(p), Flipud(p), Affine{scale, translate_percent, rotate, shear},
+  geometry (composed into the matrix): Fliplr(p), Flipud(p), Rotate90, Affine{scale, translate_percent, rotate, shear},
     CropToFixedSize{width,height}, PadToFixedSize{width,height}, Pad{px}, CropAndPad{percent} (the last two keep the size,
     imgaug's default ``keep_size=True``);
   point operations (the kernel's fixed order, see include/stp_hip.h): Add, Multiply (value or range, ``per_channel``),
@@ -109,6 +109,13 @@ def _apply(spec, rng, sp):
                     sp.push(np.array([[1.0, 0.0, 0.0], [0.0, -1.0, sp.h - 1.0], [0.0, 0.0, 1.0]]))
                 else:
                     sp.flags ^= F_INVERT
+        elif name == "Rotate90":
+            # musket's quarter-turn augmenter as the reference YAMLs use it (examples/people/ds_1.yaml:6): a random number
+            # of counter-clockwise 90 degree turns (np.rot90 convention); the canvas swaps its sides on odd counts
+            if args is None or args is True or (isinstance(args, (int, float)) and rng.uniform() < float(args)):
+                for _ in range(int(rng.randint(0, 4))):
+                    sp.push(np.array([[0.0, -1.0, sp.w - 1.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]))
+                    sp.h, sp.w = sp.w, sp.h
         elif name == "Affine":
             a = args or {}
             scale = _rng_range(rng, a.get("scale"), 1.0)

@@ -52,6 +52,19 @@ def metric_mode(name, mode="auto"):
     return "min" if "loss" in name else "max"
 
 
+# Keras logs a metric under the NAME OF ITS FUNCTION: the registry of segmentation.py:15-22 maps `iou` -> iou_coef,
+# `iot` -> iot_coef, `dice_loss` -> dice_coef_loss, so reference YAMLs monitor e.g. `val_iou_coef`
+# (examples/people/ds_1.yaml:19-27).  Both spellings resolve to the same log entry.
+LOG_ALIASES = {"iou_coef": "iou", "iot_coef": "iot", "dice_coef_loss": "dice_loss", "iou_coef_loss": "iou_loss", "acc": "binary_accuracy"}
+
+
+def log_value(logs, name):
+    if name in logs:
+        return logs[name]
+    pre, base = ("val_", name[4:]) if name.startswith("val_") else ("", name)
+    return logs.get(pre + LOG_ALIASES.get(base, base))
+
+
 # ------------------------------------------------------------------------------------------ callbacks
 class EarlyStopping(object):
     """keras.callbacks.EarlyStopping subset (schemas/callbacks.raml:8-23)."""
@@ -61,7 +74,7 @@ class EarlyStopping(object):
         self.best, self.wait, self.stop = None, 0, False
 
     def on_epoch_end(self, trainer, epoch, logs):
-        v = logs.get(self.monitor)
+        v = log_value(logs, self.monitor)
         if v is None:
             return
         if self.best is None or (v < self.best if self.mode == "min" else v > self.best):
@@ -82,7 +95,7 @@ class ReduceLROnPlateau(object):
         self.stop = False
 
     def on_epoch_end(self, trainer, epoch, logs):
-        v = logs.get(self.monitor)
+        v = log_value(logs, self.monitor)
         if v is None:
             return
         if self.cool > 0:
@@ -487,7 +500,9 @@ class GenericTaskConfig(object):
                 logs.update({"val_" + k: v for k, v in trainer.run_epoch(val_idx, False).items()})
             logs["lr"] = impl.get_lr()
             rows.append(dict(epoch=epoch, **logs))
-            cur = logs.get(self.primary_metric, logs.get("loss"))
+            cur = log_value(logs, self.primary_metric)
+            if cur is None:
+                cur = logs.get("loss")
             if best is None or (cur < best if mode == "min" else cur > best):
                 best, best_epoch = cur, epoch
                 if rank == 0:

@@ -144,6 +144,19 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     prm = augment.sample_batch([{"CropAndPad": {"percent": -0.1}}], rng, 1, 40, 50, (40, 50))      # crop 10 % per side, keep size
     ref = oaug.compose(40, 50, [("crop", 4, 5, 32, 40), ("resize", 40, 50)], (40, 50))
     np.testing.assert_allclose(prm[0, :6].reshape(2, 3), ref[:2], rtol=1e-6, atol=1e-5)
+    # Rotate90 (examples/people/ds_1.yaml:6): exactly the four quarter turns of np.rot90
+    sq = np.random.RandomState(1).randint(0, 256, (1, 8, 8, 3)).astype(np.uint8)
+    turns = set()
+    for sd in range(24):
+        m = augment.sample_batch([{"Rotate90": True}], np.random.RandomState(sd), 1, 8, 8, (8, 8))
+        out, _ = oaug.warp_u8(sq, None, m, (8, 8))
+        ks = [k for k in range(4) if np.array_equal(out[0], np.rot90(sq[0], k))]
+        assert len(ks) == 1
+        turns.add(ks[0])
+    assert turns == {0, 1, 2, 3}
+    # callbacks may monitor Keras' function-name spelling of a metric (examples/people/ds_1.yaml:19-27)
+    assert pipeline.log_value({"val_iou": 0.5, "loss": 1.0}, "val_iou_coef") == 0.5 and pipeline.log_value({"loss": 1.0}, "loss") == 1.0
+    assert pipeline.log_value({"dice_loss": 0.25}, "dice_coef_loss") == 0.25 and pipeline.log_value({}, "val_iou_coef") is None
     # point operations land in the record (include/stp_hip.h layout)
     prm = augment.sample_batch([{"Invert": 1.0}, {"Grayscale": {"alpha": 0.5}}, {"AdditiveGaussianNoise": {"scale": 12.75, "per_channel": True}},
                                 {"Dropout": {"p": 0.25}}, {"AddElementwise": [-10, 10]}, {"MultiplyElementwise": {"mul": [0.9, 1.1], "per_channel": True}},
