@@ -106,15 +106,16 @@ def pmc_traffic(kernel):
     """L2-miss bytes per launch of ``kernel`` (read + write) from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
     that kernel was not in the measured build."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"].get(kernel)
-    except (OSError, ValueError, KeyError):
-        return None, None
-    if not k:
-        return None, None
-    return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], "profiles/r01b_pmc_traffic.json"
+    for name in ("r01c_pmc_traffic.json", "r01b_pmc_traffic.json"):      # newest measurement that knows this kernel
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"].get(kernel)
+        except (OSError, ValueError, KeyError):
+            continue
+        if k:
+            return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], "profiles/" + name
+    return None, None
 
 
 def cpu_baseline(seconds_budget=25.0):
