@@ -17,7 +17,13 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3),
+                "resnet152": (3, 8, 36, 3)}
+BOTTLENECK = ("resnet50", "resnet101", "resnet152")   # classification_models residual_bottleneck_block: 1x1 f, 3x3 f (stride), 1x1 4f
+
+
+def expansion(backbone):
+    return 4 if backbone in BOTTLENECK else 1
 STAGE_FILTERS = (64, 128, 256, 512)
 BN_EPS_ENCODER = 2e-5   # classification_models ResNet: BatchNormalization(epsilon=2e-5)
 BN_EPS_DECODER = 1e-3   # Keras BatchNormalization default
@@ -54,18 +60,26 @@ def init_unet_resnet(backbone="resnet34", in_ch=3, classes=1,
     P["conv0/kernel"] = _he_uniform(rng, (7, 7, in_ch, 64))
     _bn(P, "bn0", 64)
     cin = 64
+    ex = expansion(backbone)
     for s, (n_units, f) in enumerate(zip(units, STAGE_FILTERS), start=1):
         for u in range(1, n_units + 1):
             pre = "stage%d_unit%d_" % (s, u)
             _bn(P, pre + "bn1", cin)
-            P[pre + "conv1/kernel"] = _he_uniform(rng, (3, 3, cin, f))
-            _bn(P, pre + "bn2", f)
-            P[pre + "conv2/kernel"] = _he_uniform(rng, (3, 3, f, f))
+            if ex == 1:
+                P[pre + "conv1/kernel"] = _he_uniform(rng, (3, 3, cin, f))
+                _bn(P, pre + "bn2", f)
+                P[pre + "conv2/kernel"] = _he_uniform(rng, (3, 3, f, f))
+            else:
+                P[pre + "conv1/kernel"] = _he_uniform(rng, (1, 1, cin, f))
+                _bn(P, pre + "bn2", f)
+                P[pre + "conv2/kernel"] = _he_uniform(rng, (3, 3, f, f))
+                _bn(P, pre + "bn3", f)
+                P[pre + "conv3/kernel"] = _he_uniform(rng, (1, 1, f, f * ex))
             if u == 1:
-                P[pre + "sc/kernel"] = _he_uniform(rng, (1, 1, cin, f))
-            cin = f
+                P[pre + "sc/kernel"] = _he_uniform(rng, (1, 1, cin, f * ex))
+            cin = f * ex
     _bn(P, "bn1", cin)
-    skip_ch = (STAGE_FILTERS[2], STAGE_FILTERS[1], STAGE_FILTERS[0], 64, 0)
+    skip_ch = (STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex, 64, 0)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
         P[pre + "conv1/kernel"] = _glorot_uniform(rng, (3, 3, cin + skip_ch[i], f))
@@ -86,8 +100,9 @@ def init_linknet_resnet(backbone="resnet34", in_ch=3, classes=1, decoder_filters
     full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
     P = OrderedDict((k, v) for k, v in full.items() if not (k.startswith("decoder_") or k.startswith("final_")))
     rng = np.random.RandomState(seed + 1)
-    cin = STAGE_FILTERS[3]
-    skip_ch = (STAGE_FILTERS[2], STAGE_FILTERS[1], STAGE_FILTERS[0], 64, None)
+    ex = expansion(backbone)
+    cin = STAGE_FILTERS[3] * ex
+    skip_ch = (STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex, 64, None)
     for i in range(5):
         pre = "decoder_stage%d_" % i
         mid = cin // 4
@@ -187,9 +202,16 @@ def _resnet_encoder(ctx, x_nhwc, backbone):
                 shortcut = _conv(ctx, a, pre + "sc", stride=stride, pad=0)
             else:
                 shortcut = x
-            y = _conv(ctx, a, pre + "conv1", stride=stride, pad=1)
-            y = _bn_apply(ctx, y, pre + "bn2", BN_EPS_ENCODER, relu=True)
-            y = _conv(ctx, y, pre + "conv2", stride=1, pad=1)
+            if expansion(backbone) == 1:
+                y = _conv(ctx, a, pre + "conv1", stride=stride, pad=1)
+                y = _bn_apply(ctx, y, pre + "bn2", BN_EPS_ENCODER, relu=True)
+                y = _conv(ctx, y, pre + "conv2", stride=1, pad=1)
+            else:   # bottleneck: the stride sits on the 3x3 convolution
+                y = _conv(ctx, a, pre + "conv1")
+                y = _bn_apply(ctx, y, pre + "bn2", BN_EPS_ENCODER, relu=True)
+                y = _conv(ctx, y, pre + "conv2", stride=stride, pad=1)
+                y = _bn_apply(ctx, y, pre + "bn3", BN_EPS_ENCODER, relu=True)
+                y = _conv(ctx, y, pre + "conv3")
             x = y + shortcut
             ctx.tap(pre + "out", x)
     x = _bn_apply(ctx, x, "bn1", BN_EPS_ENCODER, relu=True)

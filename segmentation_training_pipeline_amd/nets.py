@@ -13,7 +13,9 @@ Fusions expressed here (none changes the arithmetic of the Keras graph):
   * batch statistics of a BatchNormalization -> reduced in the epilogue of the conv that feeds it (bn_stats=True)
 """
 
-RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3),
+                "resnet152": (3, 8, 36, 3)}
+BOTTLENECK = ("resnet50", "resnet101", "resnet152")   # residual_bottleneck_block: 1x1 f, 3x3 f (carries the stride), 1x1 4f
 STAGE_FILTERS = (64, 128, 256, 512)
 BN_EPS_ENCODER = 2e-5
 BN_EPS_DECODER = 1e-3
@@ -30,6 +32,7 @@ def _resnet_encoder(plan, backbone, H, W, in_ch):
     if H % 32 or W % 32:
         raise ValueError("input height/width must be divisible by 32")
     units = RESNET_UNITS[backbone]
+    ex = 4 if backbone in BOTTLENECK else 1
     img = plan.input_u8("image", H, W, in_ch)
     x = plan.input_bn("bn_data", img, BN_EPS_ENCODER)
     x = plan.conv("conv0", x, 64, 7, stride=2, pad=3, bn_stats=True)
@@ -43,12 +46,19 @@ def _resnet_encoder(plan, backbone, H, W, in_ch):
             a = plan.bn(pre + "bn1", x, BN_EPS_ENCODER, relu=True)
             if u == 1:
                 taps[s] = a
-                shortcut = plan.conv(pre + "sc", a, f, 1, stride=stride, pad=0)
+                shortcut = plan.conv(pre + "sc", a, f * ex, 1, stride=stride, pad=0)
             else:
                 shortcut = x
-            y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1, bn_stats=True)
-            y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
-            x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut, bn_stats=True)
+            if ex == 1:
+                y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1, bn_stats=True)
+                y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
+                x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut, bn_stats=True)
+            else:
+                y = plan.conv(pre + "conv1", a, f, 1, bn_stats=True)
+                y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
+                y = plan.conv(pre + "conv2", y, f, 3, stride=stride, pad=1, bn_stats=True)
+                y = plan.bn(pre + "bn3", y, BN_EPS_ENCODER, relu=True)
+                x = plan.conv(pre + "conv3", y, f * ex, 1, residual=shortcut, bn_stats=True)
     x = plan.bn("bn1", x, BN_EPS_ENCODER, relu=True)
     return x, relu0, taps
 
