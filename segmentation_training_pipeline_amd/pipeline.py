@@ -238,13 +238,105 @@ class KFoldedDataSet(object):
 
 
 # ------------------------------------------------------------------------------------------ device feeding
+class HostItem(object):
+    """A dataset item prepared for the device: raw uint8 pixels and the label plane in PINNED host memory."""
+    __slots__ = ("id", "x", "y", "h", "w", "src")
+
+    def __init__(self, ident, x, y, h, w, src):
+        self.id, self.x, self.y, self.h, self.w, self.src = ident, x, y, h, w, src
+
+
+def prepare_item(it, classes, pin):
+    """PredictionItem -> HostItem: RGB uint8 [h,w,3] and label uint8 [h,w] ({0,1} for the sigmoid head, class index for the
+    softmax head; one-hot maps are arg-maxed).  This is the CPU work per sample; everything else happens on the GPU."""
+    x = np.ascontiguousarray(np.asarray(it.x)[:, :, :3], dtype=np.uint8)
+    h, w = x.shape[:2]
+    y = it.y if it.y is not None else np.zeros((h, w, 1), np.uint8)
+    y = np.asarray(y).reshape(h, w, -1)
+    if classes == 1:
+        y = (y[:, :, 0] != 0).astype(np.uint8)
+    elif y.shape[2] == classes:            # one-hot maps (what a Keras softmax head is fed) -> class index
+        y = y.argmax(axis=2).astype(np.uint8)
+    else:                                  # label image
+        y = np.minimum(y[:, :, 0], classes - 1).astype(np.uint8)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(np.ascontiguousarray(y))
+    if pin:
+        xt, yt = xt.pin_memory(), yt.pin_memory()
+    return HostItem(it.id, xt, yt, h, w, it)
+
+
+class HostBatch(object):
+    """A full plan batch of equally sized items, already wrapped around to the plan's batch size: pinned pixel / label
+    blocks and the sampled augmentation records - one H2D copy and one kernel launch per block on the device side."""
+    __slots__ = ("items", "X", "Y", "prm", "filt", "h", "w")
+
+    def __init__(self, items, X, Y, prm, filt, h, w):
+        self.items, self.X, self.Y, self.prm, self.filt, self.h, self.w = items, X, Y, prm, filt, h, w
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        return iter(self.items)
+
+
+class HostPrefetcher(object):
+    """Background thread that reads (decodes) the next batches from the dataset and stages them in pinned memory while the
+    GPU trains on the current one - the replacement of the reference's imgaug worker processes + bounded queue
+    (FAQ.md:15-22; ``AUGMENTER_QUEUE_LIMIT``), minus the augmentation itself, which runs on the device."""
+
+    def __init__(self, ds, indexes, batch, classes, pin, depth=2, sampler=None):
+        """``sampler(n, h, w) -> (records, filter records)``: when given and a batch's items share one size, the thread also
+        packs the batch into two pinned blocks and samples its augmentation records (HostBatch)."""
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self._err = None
+
+        def pack(items):
+            h, w = items[0].h, items[0].w
+            if sampler is None or any((it.h, it.w) != (h, w) for it in items):
+                return items
+            X = torch.empty((batch, h, w, 3), dtype=torch.uint8, pin_memory=pin)
+            Y = torch.empty((batch, h, w), dtype=torch.uint8, pin_memory=pin)
+            xv, yv = X.numpy(), Y.numpy()
+            for i in range(batch):                      # a short last batch wraps around (static plan batch)
+                xv[i], yv[i] = items[i % len(items)].x.numpy(), items[i % len(items)].y.numpy()
+            prm, filt = sampler(batch, h, w)
+            return HostBatch(items, X, Y, prm, filt, h, w)
+
+        def work():
+            try:
+                for s in range(0, len(indexes), batch):
+                    self.q.put(pack([prepare_item(ds[int(i)], classes, False if sampler is not None else pin)
+                                     for i in indexes[s:s + batch]]))
+            except BaseException as e:      # surfaced on the consumer side
+                self._err = e
+            self.q.put(None)
+
+        self.t = threading.Thread(target=work, daemon=True)
+        self.t.start()
+
+    def __iter__(self):
+        while True:
+            b = self.q.get()
+            if b is None:
+                if self._err is not None:
+                    raise self._err
+                return
+            yield b
+
+
 class DeviceFeeder(object):
-    """uint8 items -> the plan's input buffers.  One async H2D copy of the raw pixels per item and one
-    ``stp_augment_u8`` launch that resizes to the network shape (and augments when training)."""
+    """HostItems -> the plan's input buffers: asynchronous H2D copies of the raw pixels from pinned memory on a COPY
+    stream (they overlap the previous step's kernels), then one ``stp_augment_u8`` launch per item on the compute stream
+    that resizes to the network shape and augments when training (+ ``stp_filter_u8`` passes for neighbourhood filters)."""
 
     def __init__(self, device, out_hw, spec, seed, classes=1):
-        self.device, self.out_hw, self.spec, self.classes = device, out_hw, spec, int(classes)
+        self.device, self.out_hw, self.spec, self.classes = torch.device(device), out_hw, spec, int(classes)
         self.rng = np.random.RandomState(seed)
+        self.pin = self.device.type == "cuda"
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.pin else None
         self._keep = []
 
     def feed(self, plan, items, training):
@@ -252,23 +344,26 @@ class DeviceFeeder(object):
         img_buf, msk_buf = plan.inputs["image"].buf, plan.inputs["mask"].buf
         n = img_buf.shape[0]
         oh, ow = self.out_hw
-        for i in range(n):
-            it = items[i % len(items)]             # a short last batch wraps around (static plan batch)
-            x = np.ascontiguousarray(it.x[:, :, :3], dtype=np.uint8)
-            h, w = x.shape[:2]
-            y = it.y if it.y is not None else np.zeros((h, w, 1), np.uint8)
-            y = np.asarray(y).reshape(h, w, -1)
-            if self.classes == 1:
-                y = np.ascontiguousarray((y[:, :, 0] != 0).astype(np.uint8))
-            elif y.shape[2] == self.classes:       # one-hot maps (what a Keras softmax head is fed) -> class index
-                y = np.ascontiguousarray(y.argmax(axis=2).astype(np.uint8))
-            else:                                  # label image
-                y = np.ascontiguousarray(np.minimum(y[:, :, 0], self.classes - 1).astype(np.uint8))
+        if isinstance(items, HostBatch) and items.X.shape[0] == n:
+            return self._feed_block(plan, items)
+        items = [it if isinstance(it, HostItem) else prepare_item(it, self.classes, self.pin) for it in items]
+        main = torch.cuda.current_stream()
+        staged = []
+        with torch.cuda.stream(self.copy_stream):
+            for i in range(n):
+                it = items[i % len(items)]             # a short last batch wraps around (static plan batch)
+                xd = torch.empty((it.h, it.w, 3), dtype=torch.uint8, device=self.device)
+                yd = torch.empty((it.h, it.w), dtype=torch.uint8, device=self.device)
+                xd.copy_(it.x, non_blocking=True)
+                yd.copy_(it.y, non_blocking=True)
+                xd.record_stream(main); yd.record_stream(main)     # consumed by kernels of the compute stream
+                staged.append((it, xd, yd))
+        main.wait_stream(self.copy_stream)
+        for i, (it, xd, yd) in enumerate(staged):
+            h, w = it.h, it.w
             prm, filt = augment.sample_batch_ex(self.spec if training else [], self.rng, 1, h, w, (oh, ow))
-            xd = torch.from_numpy(x).to(self.device, non_blocking=True)
-            yd = torch.from_numpy(y).to(self.device, non_blocking=True)
             pd = torch.from_numpy(prm).to(self.device, non_blocking=True)
-            self._keep += [xd, yd, pd]
+            self._keep += [xd, yd, pd, it]
             if filt is None:
                 ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, 3)
                 continue
@@ -285,6 +380,39 @@ class DeviceFeeder(object):
                 src = 1 - src
 
 
+def _feed_block(self, plan, hb):
+    """Equal-size batch: two H2D copies (pixels, labels) on the copy stream, one ``stp_augment_u8`` launch for the batch."""
+    img_buf, msk_buf = plan.inputs["image"].buf, plan.inputs["mask"].buf
+    n = img_buf.shape[0]
+    oh, ow = self.out_hw
+    main = torch.cuda.current_stream()
+    with torch.cuda.stream(self.copy_stream):
+        xd = torch.empty(hb.X.shape, dtype=torch.uint8, device=self.device)
+        yd = torch.empty(hb.Y.shape, dtype=torch.uint8, device=self.device)
+        xd.copy_(hb.X, non_blocking=True)
+        yd.copy_(hb.Y, non_blocking=True)
+        pd = torch.from_numpy(hb.prm).to(self.device, non_blocking=True)
+        fd = torch.from_numpy(hb.filt).to(self.device, non_blocking=True) if hb.filt is not None else None
+        for t in (xd, yd, pd) + ((fd,) if fd is not None else ()):
+            t.record_stream(main)
+    main.wait_stream(self.copy_stream)
+    self._keep += [xd, yd, pd, hb]
+    if fd is None:
+        ops.augment_u8(xd, yd, img_buf, msk_buf, pd, n, hb.h, hb.w, oh, ow, 3)
+        return
+    bufs = [torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
+    self._keep += [fd] + bufs
+    ops.augment_u8(xd, yd, bufs[0], msk_buf, pd, n, hb.h, hb.w, oh, ow, 3)
+    src = 0
+    for ps in range(hb.filt.shape[0]):
+        dst = img_buf if ps == hb.filt.shape[0] - 1 else bufs[1 - src]
+        ops.filter_u8(bufs[src], dst, fd[ps], n, oh, ow, 3)
+        src = 1 - src
+
+
+DeviceFeeder._feed_block = _feed_block
+
+
 def derived_metrics(scal, classes=1):
     """scal: the loss scalars of stp_sigmoid_bce_dice -> Keras-style log entries (metric names of
     schemas/segmentation.raml:98-105: binary_accuracy, dice, iou, iot)."""
@@ -298,29 +426,33 @@ class Trainer(object):
         self.model, self.feeder, self.ds, self.callbacks = model, feeder, ds, callbacks
         self.rank, self.world = rank, world
 
-    def _batches(self, indexes, batch):
-        for s in range(0, len(indexes), batch):
-            yield [self.ds[int(i)] for i in indexes[s:s + batch]]
+    def _batches(self, indexes, batch, training):
+        f = self.feeder
+        oh_ow = f.out_hw
+        sampler = lambda n, h, w: augment.sample_batch_ex(f.spec if training else [], f.rng, n, h, w, oh_ow)
+        return HostPrefetcher(self.ds, [int(i) for i in indexes], batch, f.classes, f.pin, sampler=sampler)
 
     def run_epoch(self, indexes, training):
         m = self.model
         plan = m.plan if training else m.eval_plan()
-        agg, nb = {}, 0
-        for items in self._batches(indexes, m.batch):
+        agg, snaps = {}, []
+        for items in self._batches(indexes, m.batch, training):
             self.feeder.feed(plan, items, training)
             if training:
                 m.train_on_batch(None, None, fetch=False)
-                scal = plan.loss_scalars.cpu().numpy()
                 for cb in self.callbacks:
                     if hasattr(cb, "on_batch_end"):
                         cb.on_batch_end(self)
             else:
                 plan.run(plan.prep); plan.run(plan.fwd)
-                scal = plan.loss_scalars.cpu().numpy()
-            for k, v in derived_metrics(scal, getattr(m, "classes", 1)).items():
-                agg[k] = agg.get(k, 0.0) + v
-            nb += 1
-        return {k: v / max(nb, 1) for k, v in agg.items()}
+            # the step's scalars stay on the device (no host sync per batch: the host keeps running ahead, so the next
+            # batch's H2D copies overlap this step); they are fetched once per epoch
+            snaps.append(plan.loss_scalars.clone())
+        if snaps:
+            for scal in torch.stack(snaps).cpu().numpy():
+                for k, v in derived_metrics(scal, getattr(m, "classes", 1)).items():
+                    agg[k] = agg.get(k, 0.0) + v
+        return {k: v / max(len(snaps), 1) for k, v in agg.items()}
 
 
 # ------------------------------------------------------------------------------------------ config

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import torch
 import pytest
 import yaml
 
@@ -180,6 +181,40 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     with pytest.raises(ValueError, match="more than 2"):
         augment.sample_batch_ex([{"AverageBlur": 3}] * 3, rng, 1, 8, 8, (8, 8))
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
+
+
+def test_host_prefetcher_prepares_batches_in_order_and_reports_errors():
+    """The loader thread that replaces the reference's augmentation worker processes: items come out batched, in order,
+    labels reduced to one uint8 plane (binary / class index / arg-max of one-hot); a failing dataset raises in the consumer."""
+    class DS(object):
+        def __init__(self, n, fail_at=None):
+            self.n, self.fail_at = n, fail_at
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            if i == self.fail_at:
+                raise IOError("broken file %d" % i)
+            x = np.full((6, 5, 4), i, np.uint8)                       # RGBA: the alpha plane is dropped
+            y = np.zeros((6, 5, 3), np.uint8); y[:, :, i % 3] = 1     # one-hot maps
+            from segmentation_pipeline.impl.datasets import PredictionItem
+            return PredictionItem("id%d" % i, x, y)
+
+    got = list(pipeline.HostPrefetcher(DS(7), list(range(7)), 3, classes=3, pin=False))
+    assert [len(b) for b in got] == [3, 3, 1] and [it.id for b in got for it in b] == ["id%d" % i for i in range(7)]
+    it = got[1][2]
+    assert tuple(it.x.shape) == (6, 5, 3) and it.x.dtype == torch.uint8 and int(it.x[0, 0, 0]) == 5
+    assert tuple(it.y.shape) == (6, 5) and int(it.y[0, 0]) == 5 % 3
+    # equal-size batches are packed into two blocks (wrapped around to the plan's batch) with the sampled records
+    smp = lambda n, h, w: augment.sample_batch_ex([{"Fliplr": 0.5}], np.random.RandomState(0), n, h, w, (8, 8))
+    hb = list(pipeline.HostPrefetcher(DS(5), list(range(5)), 4, classes=3, pin=False, sampler=smp))
+    assert isinstance(hb[0], pipeline.HostBatch) and tuple(hb[1].X.shape) == (4, 6, 5, 3) and len(hb[1]) == 1
+    assert [int(v) for v in hb[1].X[:, 0, 0, 0]] == [4, 4, 4, 4] and hb[0].prm.shape == (4, 24) and hb[0].filt is None
+    b = pipeline.prepare_item(DS(1)[0], 1, False)                     # 1-class head: any non-zero label is foreground
+    assert set(np.unique(b.y.numpy())) == {1}
+    with pytest.raises(IOError, match="broken file 4"):
+        list(pipeline.HostPrefetcher(DS(7, fail_at=4), list(range(7)), 3, classes=1, pin=False))
 
 
 def test_plan_structure_matches_unet_resnet34():
