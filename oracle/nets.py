@@ -51,7 +51,7 @@ def _bn(P, name, c, scale=True):
 
 
 def init_unet_resnet(backbone="resnet34", in_ch=3, classes=1,
-                     decoder_filters=(256, 128, 64, 32, 16), seed=42):
+                     decoder_filters=(256, 128, 64, 32, 16), seed=42, decoder_block_type="upsampling"):
     """Random-init parameter set (he_uniform encoder, glorot_uniform decoder/head)."""
     rng = np.random.RandomState(seed)
     units = RESNET_UNITS[backbone]
@@ -82,6 +82,15 @@ def init_unet_resnet(backbone="resnet34", in_ch=3, classes=1,
     skip_ch = (STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex, 64, 0)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
+        if decoder_block_type == "transpose":
+            # Transpose2D_block: Conv2DTranspose(f, 4x4, strides 2, 'same') kernel (kh, kw, out, in), BN, ReLU, concat, conv3x3
+            lim = np.sqrt(6.0 / (16 * cin + 16 * f))
+            P[pre + "upsample/kernel"] = rng.uniform(-lim, lim, size=(4, 4, f, cin)).astype(np.float32)
+            _bn(P, pre + "bn1", f)
+            P[pre + "conv2/kernel"] = _glorot_uniform(rng, (3, 3, f + skip_ch[i], f))
+            _bn(P, pre + "bn2", f)
+            cin = f
+            continue
         P[pre + "conv1/kernel"] = _glorot_uniform(rng, (3, 3, cin + skip_ch[i], f))
         _bn(P, pre + "bn1", f)
         P[pre + "conv2/kernel"] = _glorot_uniform(rng, (3, 3, f, f))
@@ -246,6 +255,17 @@ def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None
     skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
+        if pre + "upsample/kernel" in P:
+            # Conv2DTranspose(4x4, strides 2, padding='same'): the gradient of a stride-2 'same' conv = torch padding 1
+            wt = P[pre + "upsample/kernel"].permute(3, 2, 0, 1)           # (kh,kw,out,in) -> (in,out,kh,kw)
+            x = F.conv_transpose2d(x, wt, stride=2, padding=1)
+            x = _bn_apply(ctx, x, pre + "bn1", BN_EPS_DECODER, relu=True)
+            if skip_names[i] is not None:
+                x = torch.cat([x, skips[skip_names[i]]], dim=1)
+            x = _conv(ctx, x, pre + "conv2", pad=1)
+            x = _bn_apply(ctx, x, pre + "bn2", BN_EPS_DECODER, relu=True)
+            ctx.tap(pre + "relu2", x)
+            continue
         x = F.interpolate(x, scale_factor=2, mode="nearest")  # UpSampling2D(2)
         if skip_names[i] is not None:
             x = torch.cat([x, skips[skip_names[i]]], dim=1)

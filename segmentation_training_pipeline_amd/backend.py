@@ -44,7 +44,7 @@ class HipSegModel(object):
     def __init__(self, architecture="Unet", backbone="resnet34", input_shape=(512, 512, 3), classes=1, activation="sigmoid",
                  batch=16, dtype="bf16", loss="binary_crossentropy", optimizer="Adam", lr=1e-3, freeze_encoder=False,
                  decoder_filters=(256, 128, 64, 32, 16), clipnorm=None, clipvalue=None, use_graph=True, device="cuda",
-                 opt_kwargs=None, seed=42):
+                 opt_kwargs=None, seed=42, decoder_block_type="upsampling"):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
         if backbone not in nets.RESNET_UNITS:
@@ -55,6 +55,9 @@ class HipSegModel(object):
         self.H, self.W, self.in_ch = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
         self.classes, self.batch, self.dtype = classes, int(batch), dtype
         self.decoder_filters = tuple(decoder_filters)
+        if decoder_block_type not in ("upsampling", "transpose") or (decoder_block_type == "transpose" and architecture != "Unet"):
+            raise ValueError("decoder_block_type %r is not available for %s" % (decoder_block_type, architecture))
+        self.decoder_block_type = decoder_block_type
         self.loss_w = parse_loss(loss, classes)
         self.optimizer = optimizer.lower()
         if self.optimizer not in ("adam", "sgd", "rmsprop", "nadam"):
@@ -101,8 +104,9 @@ class HipSegModel(object):
         with_loss = training if with_loss is None else with_loss
 
         def fn(plan):
+            kw = {"decoder_block_type": self.decoder_block_type} if self.architecture == "Unet" else {}
             logits = nets.NETWORKS[self.architecture](plan, self.backbone, self.H, self.W, self.in_ch, self.classes,
-                                                      self.decoder_filters, self.loss_w, with_loss=with_loss)
+                                                      self.decoder_filters, self.loss_w, with_loss=with_loss, **kw)
             if not with_loss:
                 (plan.sigmoid_out if self.classes == 1 else plan.softmax_out)(logits)
             return logits
@@ -176,11 +180,11 @@ class HipSegModel(object):
         rng = np.random.RandomState(seed)
         w = OrderedDict()
         for name, info in self.plan.params.items():
-            if info.kind == "kernel":
+            if info.kind in ("kernel", "tkernel"):
                 co, kh, kw, ci = info.shape
                 enc = any(name.startswith(pfx) for pfx in nets.ENCODER_PREFIXES)
                 limit = np.sqrt(6.0 / (kh * kw * ci)) if enc else np.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
-                w[name] = rng.uniform(-limit, limit, size=(kh, kw, ci, co)).astype(np.float32)
+                w[name] = rng.uniform(-limit, limit, size=(kh, kw, ci, co) if info.kind == "kernel" else (kh, kw, co, ci)).astype(np.float32)
             elif info.kind == "gamma":
                 w[name] = np.ones(info.shape, np.float32)
             else:
@@ -201,6 +205,10 @@ class HipSegModel(object):
                     if a.shape != (info.shape[1], info.shape[2], info.shape[3], info.shape[0]):
                         raise ValueError("%s: kernel shape %s does not match %s (HWIO)" % (name, a.shape, info.shape))
                     a = a.transpose(3, 0, 1, 2)
+                elif info.kind == "tkernel":      # Conv2DTranspose: Keras (kh, kw, out, in) -> spatially flipped OHWI
+                    if a.shape != (info.shape[1], info.shape[2], info.shape[0], info.shape[3]):
+                        raise ValueError("%s: kernel shape %s does not match %s (kh,kw,out,in)" % (name, a.shape, info.shape))
+                    a = a[::-1, ::-1].transpose(2, 0, 1, 3)
                 elif a.shape != info.shape:
                     raise ValueError("%s: shape %s does not match %s" % (name, a.shape, info.shape))
                 flat[info.offset:info.offset + info.numel] = a.reshape(-1)
@@ -216,7 +224,12 @@ class HipSegModel(object):
         out = OrderedDict()
         for name, info in self.plan.params.items():
             a = flat[info.offset:info.offset + info.numel].reshape(info.shape)
-            out[name] = a.transpose(1, 2, 3, 0).copy() if info.kind == "kernel" else a.copy()
+            if info.kind == "kernel":
+                out[name] = a.transpose(1, 2, 3, 0).copy()
+            elif info.kind == "tkernel":
+                out[name] = a.transpose(1, 2, 0, 3)[::-1, ::-1].copy()
+            else:
+                out[name] = a.copy()
         return out
 
     def get_weights(self):

@@ -329,9 +329,20 @@ class Plan(object):
         self._tape.append(back)
         return out
 
-    def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False):
+    def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False,
+             transpose=False):
         """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
-        ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add()."""
+        ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add().
+
+        ``transpose``: Keras ``Conv2DTranspose(Cout, k, strides=2, padding='same')`` (k even, 4 in segmentation_models'
+        transpose decoder blocks).  TF pads the equivalent forward convolution by k/2-1 on each side, so the transposed
+        convolution is a stride-1 convolution over the ZERO-INSERTED input (2H-1 x 2W-1) with pad k-1-(k/2-1) and the
+        spatially flipped kernel - the zero-insertion gather that the stride-2 data-gradients already use.  The master
+        parameter holds the flipped OHWI kernel (kind "tkernel"; set/get_weights convert from Keras' (kh,kw,out,in))."""
+        if transpose:
+            if stride != 1 or upsample or src1 is not None or residual is not None or k % 2:
+                raise StpShapeError("transpose=True is the plain stride-2 'same' Conv2DTranspose with an even kernel")
+            pad = k - 1 - (k // 2 - 1)
         real_c0 = x.meta.get("real_c", x.C)
         stem = real_c0 != x.C
         if stem and (src1 is not None or upsample):
@@ -339,14 +350,14 @@ class Plan(object):
         C0, C1 = x.C, (src1.C if src1 is not None else 0)
         if not stem and (C0 % self.vec or C1 % self.vec):
             raise StpShapeError("%s: input channels (%d,%d) must be multiples of %d for dtype %s" % (name, C0, C1, self.vec, self.dtype))
-        Hv, Wv = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
+        Hv, Wv = (2 * x.H, 2 * x.W) if upsample else ((2 * x.H - 1, 2 * x.W - 1) if transpose else (x.H, x.W))
         if src1 is not None and (src1.H, src1.W) != (Hv, Wv):
             raise StpShapeError("%s: skip tensor is %dx%d, expected %dx%d" % (name, src1.H, src1.W, Hv, Wv))
         Ho, Wo = (Hv + 2 * pad - k) // stride + 1, (Wv + 2 * pad - k) // stride + 1
         KWp = k + (k & 1) if stem else k
         Cin_master = real_c0 + C1
         Cinp = C0 + C1
-        w = self.param(name + "/kernel", (Cout, k, k, Cin_master), "kernel")
+        w = self.param(name + "/kernel", (Cout, k, k, Cin_master), "tkernel" if transpose else "kernel")
         b = self.param(name + "/bias", (Cout,), "bias") if bias else None
         CoutB = _rup(Cout, self.vec)
         x_ng = x.needs_grad
@@ -357,7 +368,8 @@ class Plan(object):
         # workspace sizing needs the wgrad plan: query the library (cheap, host only)
         wp = _lib.WgradParams()
         wp.N, wp.Hs0, wp.Ws0, wp.Hv, wp.Wv, wp.C0, wp.C1 = self.N, x.H, x.W, Hv, Wv, C0, C1
-        wp.src0_mode = ops.SRC_NEAREST2X if upsample else ops.SRC_DIRECT
+        src_mode = ops.SRC_NEAREST2X if upsample else (ops.SRC_ZEROINS2X if transpose else ops.SRC_DIRECT)
+        wp.src0_mode = src_mode
         wp.KH, wp.KW, wp.stride, wp.pad, wp.Ho, wp.Wo, wp.Cout = k, KWp, stride, pad, Ho, Wo, CoutB
         wp.accumulate, wp.dtype, wp.splits = 0, self.cdt, 0
         if self.training and w.trainable:
@@ -373,7 +385,7 @@ class Plan(object):
                                   Cout, k, k, Cin_master, KWp, Cinp, CoutB))
         p = ops.conv_params(x.buf, wf, out.buf, N=self.N, Hs0=x.H, Ws0=x.W, Hv=Hv, Wv=Wv, C0=C0, C1=C1,
                             src1=src1.buf if src1 is not None else None,
-                            mode=ops.SRC_NEAREST2X if upsample else ops.SRC_DIRECT, KH=k, KW=KWp, stride=stride, pad=pad,
+                            mode=src_mode, KH=k, KW=KWp, stride=stride, pad=pad,
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
         if b is not None:
             p.bias = self._pptr(b)
@@ -384,7 +396,7 @@ class Plan(object):
             p.stats_partial = st.data_ptr()
             out.meta["stats"] = (st, p)
         # algorithmic work of this layer: 2 * pixels * Cout * KH*KW*Cin with the REAL (unpadded) dims
-        flops = 2.0 * self.N * Ho * Wo * Cout * k * k * Cin_master
+        flops = 2.0 * self.N * Ho * Wo * Cout * k * k * Cin_master / (4.0 if transpose else 1.0)   # zero-inserted taps are not work
         self._emit_conv(self.fwd, p, {"layer": name, "pass": "fwd", "flops": flops, "tile": int(self.lib.stp_conv2d_tile_for(C.byref(p)))})
         if not self.training:
             return out
@@ -447,11 +459,16 @@ class Plan(object):
                     d0 = self._alloc((self.N, Hv, Wv, C0))      # gradient not wanted: scratch sink
                 if C1 and d1 is None:
                     d1 = self._alloc((self.N, Hv, Wv, C1))
-                q = ops.conv_params(dy, wb, d0, N=self.N, Hs0=Ho, Ws0=Wo,
-                                    Hv=(2 * Ho - 1 if stride == 2 else Ho), Wv=(2 * Wo - 1 if stride == 2 else Wo),
-                                    C0=CoutB, mode=(ops.SRC_ZEROINS2X if stride == 2 else ops.SRC_DIRECT), KH=k, KW=k, stride=1,
-                                    pad=k - 1 - pad, Ho=Hv, Wo=Wv, Cout=C0 + C1, dtype=self.cdt, dst1=d1, Cd0=C0,
-                                    accumulate0=acc0, accumulate1=acc1)
+                if transpose:
+                    # gradient of the zero-inserted input at its even positions only = a plain stride-2 convolution of dY
+                    q = ops.conv_params(dy, wb, d0, N=self.N, Hs0=Ho, Ws0=Wo, Hv=Ho, Wv=Wo, C0=CoutB, mode=ops.SRC_DIRECT, KH=k, KW=k,
+                                        stride=2, pad=k - 1 - pad, Ho=x.H, Wo=x.W, Cout=C0, dtype=self.cdt, accumulate0=acc0)
+                else:
+                    q = ops.conv_params(dy, wb, d0, N=self.N, Hs0=Ho, Ws0=Wo,
+                                        Hv=(2 * Ho - 1 if stride == 2 else Ho), Wv=(2 * Wo - 1 if stride == 2 else Wo),
+                                        C0=CoutB, mode=(ops.SRC_ZEROINS2X if stride == 2 else ops.SRC_DIRECT), KH=k, KW=k, stride=1,
+                                        pad=k - 1 - pad, Ho=Hv, Wo=Wv, Cout=C0 + C1, dtype=self.cdt, dst1=d1, Cd0=C0,
+                                        accumulate0=acc0, accumulate1=acc1)
                 if stride not in (1, 2):
                     raise StpShapeError("data gradient supports stride 1 and 2")
                 bnm = x.meta.get("bn")

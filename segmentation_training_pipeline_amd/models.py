@@ -33,6 +33,7 @@ class SegModel(object):
     def compile(self, optimizer="Adam", loss="binary_crossentropy", lr=1e-3, batch=16, dtype="bf16", clipnorm=None,
                 clipvalue=None, metrics=None, device="cuda", use_graph=True, opt_kwargs=None):
         self.impl = HipSegModel(self.architecture, self.backbone_name, self.input_shape, self.classes, self.activation,
+                                decoder_block_type=getattr(self, "decoder_block_type", "upsampling"),
                                 batch=batch, dtype=dtype, loss=loss, optimizer=optimizer, lr=lr,
                                 freeze_encoder=self.freeze_encoder, decoder_filters=self.decoder_filters, clipnorm=clipnorm,
                                 clipvalue=clipvalue, use_graph=use_graph, device=device, opt_kwargs=opt_kwargs)
@@ -75,10 +76,12 @@ def Unet(backbone_name="vgg16", input_shape=(None, None, 3), classes=1, activati
     """segmentation_models.Unet keyword surface (schemas/segmentation.raml:158-178)."""
     if backbone_name not in nets.RESNET_UNITS:
         raise ValueError("Unknown backbone")
-    if decoder_block_type != "upsampling" or not decoder_use_batchnorm or int(n_upsample_blocks) != 5 \
+    if decoder_block_type not in ("upsampling", "transpose") or not decoder_use_batchnorm or int(n_upsample_blocks) != 5 \
             or tuple(upsample_rates) != (2, 2, 2, 2, 2):
-        raise ValueError("the HIP Unet implements the default decoder (upsampling blocks with BatchNorm, 5 x2 stages)")
-    return SegModel("Unet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, decoder_filters)
+        raise ValueError("the HIP Unet implements the upsampling and transpose decoder blocks with BatchNorm, 5 x2 stages")
+    m = SegModel("Unet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, decoder_filters)
+    m.decoder_block_type = decoder_block_type
+    return m
 
 
 def Linknet(backbone_name="vgg16", input_shape=(None, None, 3), classes=1, activation="sigmoid", encoder_weights="imagenet",

@@ -75,12 +75,20 @@ def _head(plan, x, H, W, classes, loss, with_loss):
 
 
 def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 128, 64, 32, 16),
-                loss=(1.0, 1.0), with_loss=True):
-    """Declares inputs 'image' (uint8 NHWC) and 'mask' (uint8 NHW1); returns the logits tensor."""
+                loss=(1.0, 1.0), with_loss=True, decoder_block_type="upsampling"):
+    """Declares inputs 'image' (uint8 NHWC) and 'mask' (uint8 NHW1); returns the logits tensor.
+    ``decoder_block_type``: 'upsampling' (UpSampling2D + concat + 2 x conv3x3) or 'transpose' (Conv2DTranspose 4x4 s2 ->
+    BN -> ReLU -> concat -> conv3x3; segmentation_models' Transpose2D_block, schemas/segmentation.raml:166-169)."""
     x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
     skips = (taps[4], taps[3], taps[2], relu0, None)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
+        if decoder_block_type == "transpose":
+            x = plan.conv(pre + "upsample", x, f, 4, transpose=True, bn_stats=True)
+            x = plan.bn(pre + "bn1", x, BN_EPS_DECODER, relu=True)
+            x = plan.conv(pre + "conv2", x, f, 3, pad=1, src1=skips[i], bn_stats=True)
+            x = plan.bn(pre + "bn2", x, BN_EPS_DECODER, relu=True)
+            continue
         x = plan.conv(pre + "conv1", x, f, 3, pad=1, src1=skips[i], upsample=True, bn_stats=True)
         x = plan.bn(pre + "bn1", x, BN_EPS_DECODER, relu=True)
         x = plan.conv(pre + "conv2", x, f, 3, pad=1, bn_stats=True)

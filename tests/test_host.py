@@ -43,6 +43,10 @@ def test_parse_sets_path_and_createnet_kwarg_rules(tmp_path):
 
 
 def test_unknown_names_raise_the_reference_errors(tmp_path, capsys):
+    cfg4 = segmentation.parse(write_cfg(tmp_path, architecture="Linknet", backbone="resnet50"))
+    assert cfg4.createNet().architecture == "Linknet" and cfg4.createNet().backbone_name == "resnet50"
+    cfg5 = segmentation.parse(write_cfg(tmp_path, decoder_block_type="transpose"))         # schemas/segmentation.raml:166-169
+    assert cfg5.createNet().decoder_block_type == "transpose"
     with pytest.raises(ValueError, match="Unknown architecture"):
         segmentation.parse(write_cfg(tmp_path, architecture="Nope")).createNet()
     with pytest.raises(ValueError, match="Unknown backbone"):

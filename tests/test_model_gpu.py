@@ -129,6 +129,39 @@ def test_fp32_adam_step_matches_golden_fixture(golden_dir, arch, backbone):
     assert abs(met2["loss"] - g["scalars2"][0]) < 2e-2
 
 
+def test_fp32_transpose_decoder_step_matches_oracle():
+    """`decoder_block_type: transpose` (Conv2DTranspose 4x4 s2 'same' -> BN -> ReLU -> concat -> conv3x3): the transposed
+    convolution runs as the zero-insertion gather with the flipped kernel, its gradients as a stride-2 convolution and a
+    zero-insertion weight-gradient; checked against torch's conv_transpose2d in the oracle at the usual bars."""
+    n, size = 2, 64
+    P = onets.init_unet_resnet("resnet18", seed=42, decoder_block_type="transpose")
+    x, y = ostep.synthetic_batch(n, size, size, seed=1234)
+    tr = ostep.OracleTrainer(P, backbone="resnet18", loss=LOSS, optimizer="sgd", lr=0.05, opt_kwargs={"momentum": 0.9})
+    m = make("resnet18", size, n, "fp32", optimizer="SGD", lr=0.05, opt_kwargs={"momentum": 0.9}, decoder_block_type="transpose")
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    for k, v in m.get_weights().items():                       # Keras (kh,kw,out,in) layout survives the round trip
+        np.testing.assert_array_equal(v, P[k], err_msg=k)
+    taps = {}
+    o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
+    met = m.train_on_batch(x, y)
+    bad = first_bad_tap(m, taps, 2e-4)
+    assert bad is None, bad
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 1e-5 * max(1.0, abs(o["loss"]))
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = rel_l2(g[k], ref)
+        assert e <= (1e-4 if k.startswith("final_conv") else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
+    # bf16 + hipGraph: runs and learns
+    mb = make("resnet18", size, n, "bf16", use_graph=True, decoder_block_type="transpose")
+    mb.set_weights(P)
+    l0 = mb.train_on_batch(x, y)["loss"]
+    for _ in range(10):
+        l1 = mb.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0
+
+
 def test_fp32_softmax_head_step_matches_oracle():
     """`classes: 3, activation: softmax, loss: categorical_crossentropy+dice_loss` through the whole
     step (3-channel head conv, channel softmax, class-index masks) at the binary head's bars."""
