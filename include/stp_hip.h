@@ -210,6 +210,12 @@ int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H,
                      int32_t dtype, void* stream);
 int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                          int32_t dtype, int32_t accumulate, void* stream);
+/* MaxPooling2D(2, 2), no padding (keras.applications VGG blocks; H and W even).  idx = 2*dy+dx of the first maximum. */
+int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int stp_maxpool2x2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                       int32_t accumulate, void* stream);
+/* dy <- dy * [y > 0] in place (gradient of a ReLU fused into a convolution epilogue); count % 4 == 0 */
+int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* stream);
 
 /* Gradient of UpSampling2D(2): dx[n,h,w,c] (+)= sum of the 2x2 block of dy ([N,2H,2W,ldy]). */
 int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,

@@ -22,6 +22,10 @@ RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": 
 BOTTLENECK = ("resnet50", "resnet101", "resnet152")   # classification_models residual_bottleneck_block: 1x1 f, 3x3 f (stride), 1x1 4f
 
 
+VGG_BLOCKS = {"vgg16": (2, 2, 3, 3, 3), "vgg19": (2, 2, 4, 4, 4)}
+VGG_FILTERS = (64, 128, 256, 512, 512)
+
+
 def expansion(backbone):
     return 4 if backbone in BOTTLENECK else 1
 STAGE_FILTERS = (64, 128, 256, 512)
@@ -54,6 +58,8 @@ def init_unet_resnet(backbone="resnet34", in_ch=3, classes=1,
                      decoder_filters=(256, 128, 64, 32, 16), seed=42, decoder_block_type="upsampling"):
     """Random-init parameter set (he_uniform encoder, glorot_uniform decoder/head)."""
     rng = np.random.RandomState(seed)
+    if backbone in VGG_BLOCKS:
+        return _init_unet_vgg(rng, backbone, in_ch, classes, decoder_filters, decoder_block_type)
     units = RESNET_UNITS[backbone]
     P = OrderedDict()
     _bn(P, "bn_data", in_ch, scale=False)
@@ -101,6 +107,44 @@ def init_unet_resnet(backbone="resnet34", in_ch=3, classes=1,
     return P
 
 
+def _init_unet_vgg(rng, backbone, in_ch, classes, decoder_filters, decoder_block_type):
+    """U-Net over keras.applications VGG16/19 (Conv2D 3x3 'same' + bias + ReLU, MaxPooling2D(2)); segmentation_models takes
+    the last convolution of every block as skip and block5_pool as the decoder input (schemas/segmentation.raml:158-178
+    defaults, backbone names README.md:587-589)."""
+    if decoder_block_type != "upsampling":
+        raise ValueError("VGG oracle: upsampling decoder only")
+    P = OrderedDict()
+    cin = in_ch
+    for b, (n_conv, f) in enumerate(zip(VGG_BLOCKS[backbone], VGG_FILTERS), start=1):
+        for c in range(1, n_conv + 1):
+            P["block%d_conv%d/kernel" % (b, c)] = _glorot_uniform(rng, (3, 3, cin, f))
+            P["block%d_conv%d/bias" % (b, c)] = np.zeros(f, np.float32)
+            cin = f
+    skip_ch = VGG_FILTERS[::-1]
+    for i, f in enumerate(decoder_filters):
+        pre = "decoder_stage%d_" % i
+        P[pre + "conv1/kernel"] = _glorot_uniform(rng, (3, 3, cin + skip_ch[i], f))
+        _bn(P, pre + "bn1", f)
+        P[pre + "conv2/kernel"] = _glorot_uniform(rng, (3, 3, f, f))
+        _bn(P, pre + "bn2", f)
+        cin = f
+    P["final_conv/kernel"] = _glorot_uniform(rng, (3, 3, cin, classes))
+    P["final_conv/bias"] = np.zeros(classes, np.float32)
+    return P
+
+
+def _vgg_encoder(ctx, x_nhwc, backbone):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    skips = []
+    for b, n_conv in enumerate(VGG_BLOCKS[backbone], start=1):
+        for c in range(1, n_conv + 1):
+            x = F.relu(_conv(ctx, x, "block%d_conv%d" % (b, c), pad=1))
+        ctx.tap("block%d_out" % b, x)
+        skips.append(x)
+        x = F.max_pool2d(x, kernel_size=2, stride=2)
+    return x, skips[::-1]
+
+
 def init_linknet_resnet(backbone="resnet34", in_ch=3, classes=1, decoder_filters=(None, None, None, None, 16), seed=42):
     """Linknet over the same encoder (segmentation_models 0.2.1 ``Linknet(decoder_block_type='upsampling',
     decoder_use_batchnorm=True)``, kwargs/defaults ``schemas/segmentation.raml:180-203``).  Decoder block i
@@ -131,7 +175,7 @@ def trainable_names(P, freeze_encoder=False):
     for k in P:
         if k.endswith("moving_mean") or k.endswith("moving_variance"):
             continue
-        if freeze_encoder and not (k.startswith("decoder_") or k.startswith("final_")):
+        if freeze_encoder and not (k.startswith("decoder_") or k.startswith("final_")):   # everything else is encoder (incl. VGG blocks)
             continue
         out.append(k)
     return out
@@ -251,8 +295,13 @@ def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None
     """P: dict name -> torch tensor (Keras layouts).  x_nhwc: [N,H,W,C] float32 raw 0..255.
     Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits)."""
     ctx = _Ctx(P, training, taps)
-    x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
-    skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
+    if backbone in VGG_BLOCKS:
+        x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
+        skips = {"s%d" % i: t for i, t in enumerate(sk)}
+        skip_names = ("s0", "s1", "s2", "s3", "s4")
+    else:
+        x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
+        skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
         if pre + "upsample/kernel" in P:

@@ -68,6 +68,9 @@ SIGNATURES = {
     "stp_bn_backward_fused": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "stp_maxpool3x3s2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_maxpool2x2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "stp_maxpool2x2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_relu_bwd": (i32, [vp, vp, i64, i32, vp]),
     "stp_upsample2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_channel_sum": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
     "stp_add_inplace": (i32, [vp, vp, i64, i32, vp]),

@@ -47,7 +47,7 @@ class HipSegModel(object):
                  opt_kwargs=None, seed=42, decoder_block_type="upsampling"):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
-        if backbone not in nets.RESNET_UNITS:
+        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet"):
             raise ValueError("Unknown backbone")
         if not ((classes == 1 and activation in ("sigmoid", None)) or (2 <= classes <= 32 and activation == "softmax")):
             raise ValueError("the HIP backend trains 1-class sigmoid heads and 2..32-class softmax heads")

@@ -699,6 +699,112 @@ extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx
 }
 
 // ------------------------------------------------------------------------------------------
+// MaxPooling2D(2, 2) without padding (keras.applications VGG blocks).  idx[n,ho,wo,c] = 2*dy+dx of the first maximum;
+// every input pixel belongs to exactly one window, so the gradient is a masked copy.  H and W even.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                           int N, int H, int W, int C) {
+  const int cg = C / V, Ho = H >> 1, Wo = W >> 1;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cg) return;
+  const int wo = t / cg, c = (t - wo * cg) * V;
+  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  float best[V];
+  uint8_t bi[V];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v[V];
+    ldv<T, V>(x + (((size_t)n * H + 2 * ho + (k >> 1)) * W + 2 * wo + (k & 1)) * C + c, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      if (k == 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)k; }
+  }
+  const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+  stv<T, V>(y + o, best);
+  if (idx) {
+    if constexpr (V == 8) *reinterpret_cast<uint2*>(idx + o) = *reinterpret_cast<const uint2*>(bi);
+    else *reinterpret_cast<uint32_t*>(idx + o) = *reinterpret_cast<const uint32_t*>(bi);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy, T* __restrict__ dx,
+                                                           int N, int H, int W, int C, int accumulate) {
+  const int cg = C / V, Ho = H >> 1, Wo = W >> 1;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cg) return;
+  const int w = t / cg, c = (t - w * cg) * V;
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  const size_t o = (((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c;
+  uint8_t id[V];
+  if constexpr (V == 8) *reinterpret_cast<uint2*>(id) = *reinterpret_cast<const uint2*>(idx + o);
+  else *reinterpret_cast<uint32_t*>(id) = *reinterpret_cast<const uint32_t*>(idx + o);
+  float d[V], g[V];
+  ldv<T, V>(dy + o, d);
+  const uint8_t me = (uint8_t)(((h & 1) << 1) | (w & 1));
+#pragma unroll
+  for (int e = 0; e < V; ++e) g[e] = id[e] == me ? d[e] : 0.f;
+  T* out = dx + (((size_t)n * H + h) * W + w) * C + c;
+  if (accumulate) {
+    float a[V];
+    ldv<T, V>(out, a);
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] += a[e];
+  }
+  stv<T, V>(out, g);
+}
+
+extern "C" int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                              void* stream) {
+  if (!x || !y || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * (H >> 1) > 65535) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const dim3 grid(ceil_div((W >> 1) * (C / (v8 ? 8 : 4)), 256), N * (H >> 1));
+  if (v8) hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C);
+  else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C);
+  else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool2_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_maxpool2x2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                  int32_t dtype, int32_t accumulate, void* stream) {
+  if (!idx || !dy || !dx || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * H > 65535) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
+  if (v8) hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
+  else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
+  else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float, 4>), grid, dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, accumulate);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// dY <- dY * [y > 0] in place: the gradient of a ReLU fused into a convolution epilogue (VGG: Conv2D(activation='relu'))
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ y, T* __restrict__ dy, int64_t count4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 a = ld4<T>(y + i * 4);
+    f32x4 g = ld4<T>(dy + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+    store4(dy + i * 4, g);
+  }
+}
+
+extern "C" int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* stream) {
+  if (!y || !dy || count <= 0 || (count & 3)) return STP_E_BADARG;
+  const int g = grid_for(count >> 2);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)dy, count >> 2);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)dy, count >> 2);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // gradient of UpSampling2D(2): dy is [N,2H,2W,ldy] (first C channels used), dx [N,H,W,C]
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,

@@ -271,6 +271,22 @@ class Plan(object):
                        self._sptr(mm), self._sptr(mv), eps, None, self._pptr(beta), 0, 1.0)
         return out
 
+    def input_cast(self, name, x):
+        """Raw uint8 image -> dtype tensor padded to 4 channels (zeros), no normalisation: the input of the keras.applications
+        VGG encoders, which segmentation_models feeds with raw pixels (no in-graph preprocessing)."""
+        if x.C > 4:
+            raise StpShapeError("input_cast handles up to 4 image channels")
+        out = self._new(name, x.H, x.W, 4, False)
+        out.meta["real_c"] = x.C
+        if self.dry:
+            return out
+        zero, one = self._alloc((4,), torch.float32), self._alloc((4,), torch.float32)
+        zero.zero_(); one.fill_(1.0)
+        # y = x * 1 + 0 through the uint8 BatchNorm-apply kernel (mean 0, rstd 1, no gamma/beta), padded channel = 0
+        self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, 4,
+                   zero.data_ptr(), one.data_ptr(), None, None, 0, 0.0)
+        return out
+
     def bn(self, name, x, eps, relu=True, scale=True):
         Cn = x.C
         gamma = self.param(name + "/gamma", (Cn,), "gamma") if scale else None
@@ -330,7 +346,7 @@ class Plan(object):
         return out
 
     def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False,
-             transpose=False):
+             transpose=False, relu=False):
         """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
         ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add().
 
@@ -364,6 +380,8 @@ class Plan(object):
         s_ng = src1.needs_grad if src1 is not None else False
         out = self._new(name, Ho, Wo, Cout, x_ng or s_ng or w.trainable or (residual is not None and residual.needs_grad))
         out.gradC = CoutB
+        if bias:
+            self._bn_ws_c = max(self._bn_ws_c, CoutB)      # the bias gradient (stp_channel_sum) shares the BN workspace
         self._use(x, src1, residual)
         # workspace sizing needs the wgrad plan: query the library (cheap, host only)
         wp = _lib.WgradParams()
@@ -389,6 +407,10 @@ class Plan(object):
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
         if b is not None:
             p.bias = self._pptr(b)
+        if relu:
+            if CoutB != Cout:
+                raise StpShapeError("%s: a fused ReLU needs Cout to be a multiple of %d" % (name, self.vec))
+            p.relu = 1        # Conv2D(activation='relu'): fused into the epilogue; its gradient masks dY first (stp_relu_bwd)
         if bn_stats and self.training:
             # the BatchNormalization that follows takes its batch statistics from this conv's epilogue
             nfl = int(self.lib.stp_conv2d_stats_floats(C.byref(p)))
@@ -406,6 +428,8 @@ class Plan(object):
                 return
             dy = out.grad
             rows = out.rows
+            if relu:
+                self._emit(self.bwd, "stp_relu_bwd", out.buf.data_ptr(), dy.data_ptr(), rows * out.gradC, self.cdt)
             # lag-1 join: the previous convolution's weight-gradient chain finishes before this layer's kernels start.
             # (Letting the side chain fall further behind - joining only on a buffer hazard, see _gradbuf - measured
             # SLOWER, 11.15 vs 10.88 ms/step: the chain then reads dY / x long after the main chain left them in L2.)
@@ -532,6 +556,29 @@ class Plan(object):
                                self.cdt)
 
         self._tape.append(back)
+        return out
+
+    def maxpool2(self, name, x):
+        """MaxPooling2D(2, 2) without padding (VGG blocks)."""
+        if x.H % 2 or x.W % 2:
+            raise StpShapeError("%s: 2x2 pooling needs even height/width" % name)
+        out = self._new(name, x.H // 2, x.W // 2, x.C, x.needs_grad)
+        self._use(x)
+        if self.dry:
+            return out
+        idx = self._alloc((self.N, x.H // 2, x.W // 2, x.C), torch.uint8) if self.training else None
+        self._emit(self.fwd, "stp_maxpool2x2", x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if idx is not None else None,
+                   self.N, x.H, x.W, x.C, self.cdt)
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            self._emit(self.bwd, "stp_maxpool2x2_bwd", idx.data_ptr(), out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N,
+                       x.H, x.W, x.C, self.cdt, int(x.grad_ready))
+            x.grad_ready = True
+
+        if self.training:
+            self._tape.append(back)
         return out
 
     def maxpool(self, name, x):

@@ -74,7 +74,7 @@ def Unet(backbone_name="vgg16", input_shape=(None, None, 3), classes=1, activati
          freeze_encoder=False, decoder_block_type="upsampling", decoder_filters=(256, 128, 64, 32, 16),
          decoder_use_batchnorm=True, n_upsample_blocks=5, upsample_rates=(2, 2, 2, 2, 2)):
     """segmentation_models.Unet keyword surface (schemas/segmentation.raml:158-178)."""
-    if backbone_name not in nets.RESNET_UNITS:
+    if backbone_name not in nets.known_backbones():
         raise ValueError("Unknown backbone")
     if decoder_block_type not in ("upsampling", "transpose") or not decoder_use_batchnorm or int(n_upsample_blocks) != 5 \
             or tuple(upsample_rates) != (2, 2, 2, 2, 2):

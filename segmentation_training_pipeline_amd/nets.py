@@ -20,11 +20,13 @@ STAGE_FILTERS = (64, 128, 256, 512)
 BN_EPS_ENCODER = 2e-5
 BN_EPS_DECODER = 1e-3
 
-ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1")
+ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1", "block")
+VGG_BLOCKS = {"vgg16": (2, 2, 3, 3, 3), "vgg19": (2, 2, 4, 4, 4)}      # keras.applications: 3x3 'same' convs + ReLU per block
+VGG_FILTERS = (64, 128, 256, 512, 512)
 
 
 def known_backbones():
-    return sorted(RESNET_UNITS)
+    return sorted(RESNET_UNITS) + sorted(VGG_BLOCKS)
 
 
 def _resnet_encoder(plan, backbone, H, W, in_ch):
@@ -63,6 +65,22 @@ def _resnet_encoder(plan, backbone, H, W, in_ch):
     return x, relu0, taps
 
 
+def _vgg_encoder(plan, backbone, H, W, in_ch):
+    """keras.applications VGG16/VGG19 (include_top=False) fed with raw pixels; returns (block5_pool, the last conv of each
+    block = segmentation_models' skip layers block5_conv3 ... block1_conv2, deepest first)."""
+    if H % 32 or W % 32:
+        raise ValueError("input height/width must be divisible by 32")
+    img = plan.input_u8("image", H, W, in_ch)
+    x = plan.input_cast("input_cast", img)
+    skips = []
+    for b, (n_conv, f) in enumerate(zip(VGG_BLOCKS[backbone], VGG_FILTERS), start=1):
+        for c in range(1, n_conv + 1):
+            x = plan.conv("block%d_conv%d" % (b, c), x, f, 3, pad=1, bias=True, relu=True)
+        skips.append(x)
+        x = plan.maxpool2("block%d_pool" % b, x)
+    return x, skips[::-1]
+
+
 def _head(plan, x, H, W, classes, loss, with_loss):
     logits = plan.conv("final_conv", x, classes, 3, pad=1, bias=True)
     if with_loss:
@@ -79,8 +97,11 @@ def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 
     """Declares inputs 'image' (uint8 NHWC) and 'mask' (uint8 NHW1); returns the logits tensor.
     ``decoder_block_type``: 'upsampling' (UpSampling2D + concat + 2 x conv3x3) or 'transpose' (Conv2DTranspose 4x4 s2 ->
     BN -> ReLU -> concat -> conv3x3; segmentation_models' Transpose2D_block, schemas/segmentation.raml:166-169)."""
-    x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
-    skips = (taps[4], taps[3], taps[2], relu0, None)
+    if backbone in VGG_BLOCKS:
+        x, skips = _vgg_encoder(plan, backbone, H, W, in_ch)        # five skips: every decoder stage concatenates one
+    else:
+        x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
+        skips = (taps[4], taps[3], taps[2], relu0, None)
     for i, f in enumerate(decoder_filters):
         pre = "decoder_stage%d_" % i
         if decoder_block_type == "transpose":

@@ -20,7 +20,9 @@ TAP_MAP = [("bn_data", "bn_data"), ("conv0", "conv0"), ("relu0", "bn0"), ("pooli
            ("stage2_unit1_out", "stage2_unit1_conv2"), ("stage3_unit1_out", "stage3_unit1_conv2"),
            ("stage4_unit1_out", "stage4_unit1_conv2"), ("relu1", "bn1"),
            ("decoder_stage0_relu2", "decoder_stage0_bn2"), ("decoder_stage2_relu2", "decoder_stage2_bn2"),
-           ("decoder_stage4_relu2", "decoder_stage4_bn2")]
+           ("decoder_stage4_relu2", "decoder_stage4_bn2"),
+           ("block1_out", "block1_conv2"), ("block2_out", "block2_conv2"), ("block3_out", "block3_conv3"),
+           ("block4_out", "block4_conv3"), ("block5_out", "block5_conv3")]
 
 
 def make(backbone, size, n, dtype, use_graph=False, **kw):
@@ -127,6 +129,35 @@ def test_fp32_adam_step_matches_golden_fixture(golden_dir, arch, backbone):
     d = np.abs(m.logits() - g["logits2"])
     assert d.mean() < 4e-2 and np.corrcoef(m.logits().ravel(), g["logits2"].ravel())[0, 1] > 0.995
     assert abs(met2["loss"] - g["scalars2"][0]) < 2e-2
+
+
+def test_fp32_vgg16_unet_step_matches_oracle():
+    """U-Net over keras.applications VGG16: biased 3x3 convolutions with the ReLU fused into the epilogue
+    (gradient through stp_relu_bwd), 2x2 max-pooling, raw-pixel input without normalisation, five skip connections."""
+    n, size = 2, 64
+    P = onets.init_unet_resnet("vgg16", seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=1234)
+    tr = ostep.OracleTrainer(P, backbone="vgg16", loss=LOSS, optimizer="sgd", lr=1e-3)
+    m = make("vgg16", size, n, "fp32", optimizer="SGD", lr=1e-3)
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    taps = {}
+    o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
+    met = m.train_on_batch(x, y)
+    bad = first_bad_tap(m, taps, 2e-4)
+    assert bad is None, bad
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 1e-5 * max(1.0, abs(o["loss"]))
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = rel_l2(g[k], ref)
+        assert e <= (1e-4 if k.startswith("final_conv") else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
+    mb = make("vgg16", size, n, "bf16", use_graph=True, optimizer="Adam", lr=1e-4)     # bf16 + hipGraph: runs and learns
+    mb.set_weights(P)
+    l0 = mb.train_on_batch(x, y)["loss"]
+    for _ in range(10):
+        l1 = mb.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0
 
 
 def test_fp32_transpose_decoder_step_matches_oracle():
