@@ -250,6 +250,8 @@ def prepare_item(it, classes, pin):
     """PredictionItem -> HostItem: RGB uint8 [h,w,3] and label uint8 [h,w] ({0,1} for the sigmoid head, class index for the
     softmax head; one-hot maps are arg-maxed).  This is the CPU work per sample; everything else happens on the GPU."""
     x = np.ascontiguousarray(np.asarray(it.x)[:, :, :3], dtype=np.uint8)
+    if not x.flags.writeable:              # PIL-backed arrays are read-only; torch.from_numpy wants a writable buffer
+        x = x.copy()
     h, w = x.shape[:2]
     y = it.y if it.y is not None else np.zeros((h, w, 1), np.uint8)
     y = np.asarray(y).reshape(h, w, -1)
