@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet"],
+    ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet", "FPN"],
                     help="Unet = BASELINE.json's headline workload; Linknet = SURVEY 8f N1 on the same kernels (not the headline metric)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (for rocprofv3 kernel traces of the launches themselves)")
     args = ap.parse_args()

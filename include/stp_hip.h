@@ -220,6 +220,15 @@ int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* st
 /* Gradient of UpSampling2D(2): dx[n,h,w,c] (+)= sum of the 2x2 block of dy ([N,2H,2W,ldy]). */
 int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,
                        int32_t dtype, int32_t accumulate, void* stream);
+/* x[n,2h+i,2w+j,c] += m[n,h,w,c] in place (FPN: Add()([lateral, UpSampling2D(2)(m)])); H, W = size of x, even. */
+int stp_upsample2x_add(void* x, const void* m, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* tf.image.resize_bilinear(align_corners=False) of TF 1.x by an integer factor (src = dst / factor, no half-pixel offset) -
+ * Keras 2.2.4's K.resize_images(interpolation='bilinear').  x [N,H,W,C] -> channels [coff, coff+C) of y [N,H*f,W*f,ldo]
+ * (Concatenate of resized maps without a copy; factor 1 = strided copy).  The gradient is a fixed-order gather. */
+int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
+                        int32_t coff, int32_t dtype, void* stream);
+int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
+                            int32_t coff, int32_t dtype, int32_t accumulate, void* stream);
 
 /* Bias gradient: out[c] (+)= sum over rows of x[rows][C]; and the in-place tensor add used where two
  * gradient paths meet outside a GEMM epilogue.  workspace as for stp_bn_stats. */

@@ -169,13 +169,81 @@ def init_linknet_resnet(backbone="resnet34", in_ch=3, classes=1, decoder_filters
     return P
 
 
+def init_fpn_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, pyramid_filters=256, segmentation_filters=128):
+    """FPN over the same encoder: segmentation_models 0.2.1 ``FPN(upsample_rates=(2,2,2), last_upsample=4,
+    interpolation='bilinear', use_batchnorm=True)`` (``schemas/segmentation.raml:180-203``); see fpn_resnet_forward."""
+    full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
+    P = OrderedDict((k, v) for k, v in full.items() if not (k.startswith("decoder_") or k.startswith("final_")))
+    rng = np.random.RandomState(seed + 2)
+    ex = expansion(backbone)
+    level_ch = (STAGE_FILTERS[3] * ex, STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex)
+    for i, c in enumerate(level_ch):
+        pre = "fpn_stage%d_" % i
+        P[pre + "lateral/kernel"] = _glorot_uniform(rng, (1, 1, c, pyramid_filters))
+        P[pre + "lateral/bias"] = (rng.randn(pyramid_filters) * 0.01).astype(np.float32)
+        P[pre + "segm1/kernel"] = _glorot_uniform(rng, (3, 3, pyramid_filters, segmentation_filters))
+        _bn(P, pre + "segm1_bn", segmentation_filters)
+        P[pre + "segm2/kernel"] = _glorot_uniform(rng, (3, 3, segmentation_filters, segmentation_filters))
+        _bn(P, pre + "segm2_bn", segmentation_filters)
+    P["fpn_final/kernel"] = _glorot_uniform(rng, (3, 3, 4 * segmentation_filters, 4 * segmentation_filters))
+    _bn(P, "fpn_final_bn", 4 * segmentation_filters)
+    P["final_conv/kernel"] = _glorot_uniform(rng, (3, 3, 4 * segmentation_filters, classes))
+    P["final_conv/bias"] = np.zeros(classes, np.float32)
+    return P
+
+
+def resize_bilinear_tf1(x, f):
+    """tf.image.resize_bilinear(align_corners=False) of TF 1.x by an integer factor on NCHW: src = dst / f, x0 = floor(src),
+    x1 = min(x0 + 1, in - 1) - no half-pixel offset (torch's F.interpolate uses half-pixel centres and is NOT this).
+    TF's lerp order: along x first (top, bottom), then along y."""
+    if f == 1:
+        return x
+    n, c, h, w = x.shape
+    yo, xo = torch.arange(h * f), torch.arange(w * f)
+    y0, x0 = yo // f, xo // f
+    fy = ((yo - y0 * f).to(x.dtype) / f).view(1, 1, -1, 1)
+    fx = ((xo - x0 * f).to(x.dtype) / f).view(1, 1, 1, -1)
+    y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
+    r0, r1 = x[:, :, y0], x[:, :, y1]
+    top = r0[:, :, :, x0] + (r0[:, :, :, x1] - r0[:, :, :, x0]) * fx
+    bot = r1[:, :, :, x0] + (r1[:, :, :, x1] - r1[:, :, :, x0]) * fx
+    return top + (bot - top) * fy
+
+
+def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None):
+    """Pyramid over [encoder output, stage4/3/2 unit-1 relu1]: lateral Conv2D 1x1 (bias) + UpSampling2D(2) of the level above,
+    two (Conv2D 3x3 no bias, BN, ReLU) per level; the maps resized to 1/4 resolution, concatenated finest first,
+    Conv 3x3 + BN + ReLU (4 x 128 filters), Conv2D 3x3 to the classes, bilinear x4.  Returns (logits_nhwc, bn_updates)."""
+    ctx = _Ctx(P, training, taps)
+    x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
+    levels = (x, skips["stage4_unit1_relu1"], skips["stage3_unit1_relu1"], skips["stage2_unit1_relu1"])
+    m, pyramid = None, []
+    for i, c in enumerate(levels):
+        pre = "fpn_stage%d_" % i
+        lat = _conv(ctx, c, pre + "lateral")
+        if m is not None:
+            lat = lat + F.interpolate(m, scale_factor=2, mode="nearest")
+        p = _bn_apply(ctx, _conv(ctx, lat, pre + "segm1", pad=1), pre + "segm1_bn", BN_EPS_DECODER, relu=True)
+        p = _bn_apply(ctx, _conv(ctx, p, pre + "segm2", pad=1), pre + "segm2_bn", BN_EPS_DECODER, relu=True)
+        ctx.tap(pre + "out", p)
+        m = lat
+        pyramid.append(p)
+    cat = torch.cat([resize_bilinear_tf1(p, f) for p, f in zip(pyramid[::-1], (1, 2, 4, 8))], dim=1)
+    y = _bn_apply(ctx, _conv(ctx, cat, "fpn_final", pad=1), "fpn_final_bn", BN_EPS_DECODER, relu=True)
+    lo = _conv(ctx, y, "final_conv", pad=1)
+    return resize_bilinear_tf1(lo, 4).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+
+
+ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1/", "block")
+
+
 def trainable_names(P, freeze_encoder=False):
     """Names that receive gradients/updates.  Moving statistics never do."""
     out = []
     for k in P:
         if k.endswith("moving_mean") or k.endswith("moving_variance"):
             continue
-        if freeze_encoder and not (k.startswith("decoder_") or k.startswith("final_")):   # everything else is encoder (incl. VGG blocks)
+        if freeze_encoder and k.startswith(ENCODER_PREFIXES):
             continue
         out.append(k)
     return out

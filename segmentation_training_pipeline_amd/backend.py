@@ -47,7 +47,7 @@ class HipSegModel(object):
                  opt_kwargs=None, seed=42, decoder_block_type="upsampling"):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
-        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet"):
+        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet"):   # VGG: U-Net only
             raise ValueError("Unknown backbone")
         if not ((classes == 1 and activation in ("sigmoid", None)) or (2 <= classes <= 32 and activation == "softmax")):
             raise ValueError("the HIP backend trains 1-class sigmoid heads and 2..32-class softmax heads")
@@ -369,7 +369,8 @@ class HipSegModel(object):
         return out
 
     def logits(self):
-        return self.plan.tensors["final_conv"].buf.to(torch.float32).cpu().numpy()
+        t = self.plan.tensors.get("logits", self.plan.tensors["final_conv"])      # FPN: the head conv is resized x4
+        return t.buf.to(torch.float32).cpu().numpy()
 
     def activation(self, name):
         return self.plan.tensors[name].buf.to(torch.float32).cpu().numpy()

@@ -851,6 +851,120 @@ extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H
 }
 
 // ------------------------------------------------------------------------------------------
+// FPN pieces.  (a) x[n,2h+i,2w+j,c] += m[n,h,w,c]: Add()([lateral, UpSampling2D(2)(m)]) in place on the lateral tensor.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(T* __restrict__ x, const T* __restrict__ m, int N, int H, int W, int C) {
+  const int cg = C / V;                       // H, W: size of x (even)
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cg) return;
+  const int w = t / cg, c = (t - w * cg) * V;
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  float a[V], b[V];
+  T* px = x + (((size_t)n * H + h) * W + w) * C + c;
+  ldv<T, V>(px, a);
+  ldv<T, V>(m + (((size_t)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * C + c, b);
+#pragma unroll
+  for (int e = 0; e < V; ++e) a[e] += b[e];
+  stv<T, V>(px, a);
+}
+
+extern "C" int stp_upsample2x_add(void* x, const void* m, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+  if (!x || !m || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * H > 65535) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
+  if (v8) hipLaunchKernelGGL((upsample2x_add_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)m, N, H, W, C);
+  else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_add_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)m, N, H, W, C);
+  else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_add_kernel<float, 4>), grid, dim3(256), 0, s, (float*)x, (const float*)m, N, H, W, C);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// (b) tf.image.resize_bilinear(align_corners=False) of TF 1.x (what Keras 2.2.4 K.resize_images(interpolation='bilinear')
+// calls) by an integer factor f: src = dst / f, x0 = floor(src), x1 = min(x0 + 1, in - 1), no half-pixel offset.
+// The output may be a channel slice of a wider tensor (ldo / coff: Concatenate of the resized pyramid levels); f = 1 copies.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                                              int f, int ldo, int coff) {
+  const int Ho = H * f, Wo = W * f;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const float inv = 1.f / (float)f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int xo = (int)((i / C) % Wo);
+    const int yo = (int)((i / ((int64_t)C * Wo)) % Ho);
+    const int n = (int)(i / ((int64_t)C * Wo * Ho));
+    const int x0 = xo / f, y0 = yo / f;
+    const float fx = (float)(xo - x0 * f) * inv, fy = (float)(yo - y0 * f) * inv;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const T* b = x + (int64_t)n * H * W * C + c;
+    const float v00 = Elem<T>::load(b + ((int64_t)y0 * W + x0) * C), v01 = Elem<T>::load(b + ((int64_t)y0 * W + x1) * C);
+    const float v10 = Elem<T>::load(b + ((int64_t)y1 * W + x0) * C), v11 = Elem<T>::load(b + ((int64_t)y1 * W + x1) * C);
+    const float top = v00 + (v01 - v00) * fx, bot = v10 + (v11 - v10) * fx;      // TF's lerp order
+    Elem<T>::store(y + (((int64_t)n * Ho + yo) * Wo + xo) * ldo + coff + c, top + (bot - top) * fy);
+  }
+}
+
+// gradient: dx[n,h,w,c] (+)= sum over the outputs that read this input pixel, in a fixed order (deterministic gather)
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
+                                                                  int C, int f, int ldo, int coff, int accumulate) {
+  const int Ho = H * f, Wo = W * f;
+  const int64_t total = (int64_t)N * H * W * C;
+  const float inv = 1.f / (float)f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int w = (int)((i / C) % W);
+    const int h = (int)((i / ((int64_t)C * W)) % H);
+    const int n = (int)(i / ((int64_t)C * W * H));
+    const T* b = dy + (int64_t)n * Ho * Wo * ldo + coff + c;
+    float acc = 0.f;
+    // rows yo with y0 == h contribute (1 - fy) [all of it when h is the last row: y1 clamps to h]; rows with y0 == h - 1 contribute fy
+    for (int yo = max((h - 1) * f, 0); yo < (h + 1) * f; ++yo) {
+      const int y0 = yo / f;
+      const float fy = (float)(yo - y0 * f) * inv;
+      float wy = 0.f;
+      if (y0 == h) wy += 1.f - fy;
+      if (min(y0 + 1, H - 1) == h) wy += fy;
+      if (wy == 0.f) continue;
+      for (int xo = max((w - 1) * f, 0); xo < (w + 1) * f; ++xo) {
+        const int x0 = xo / f;
+        const float fx = (float)(xo - x0 * f) * inv;
+        float wx = 0.f;
+        if (x0 == w) wx += 1.f - fx;
+        if (min(x0 + 1, W - 1) == w) wx += fx;
+        if (wx != 0.f) acc += wy * wx * Elem<T>::load(b + ((int64_t)yo * Wo + xo) * ldo);
+      }
+    }
+    if (accumulate) acc += Elem<T>::load(dx + i);
+    Elem<T>::store(dx + i, acc);
+  }
+}
+
+extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
+                                   int32_t coff, int32_t dtype, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * H * factor * W * factor * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_bilinear_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(resize_bilinear_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, factor, ldo, coff);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor,
+                                       int32_t ldo, int32_t coff, int32_t dtype, int32_t accumulate, void* stream) {
+  if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * H * W * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_bilinear_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(resize_bilinear_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, factor, ldo, coff, accumulate);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // per-channel sums of a [rows][C] tensor (bias gradient) and dst += src
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* partial, int blocks, int C, float* out,
                                                               int accumulate) {

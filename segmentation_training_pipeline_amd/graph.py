@@ -558,6 +558,87 @@ class Plan(object):
         self._tape.append(back)
         return out
 
+    def upsample_add(self, name, x, m):
+        """FPN top-down step ``Add()([x, UpSampling2D(2)(m)])`` in place on x's buffer (x must have no other consumer yet)."""
+        if (x.H, x.W, x.C) != (2 * m.H, 2 * m.W, m.C):
+            raise StpShapeError("%s: %dx%dx%d cannot take the 2x upsampling of %dx%dx%d" % (name, x.H, x.W, x.C, m.H, m.W, m.C))
+        out = DT(name, self.N, x.H, x.W, x.C, x.buf, x.needs_grad or m.needs_grad)
+        out.gradC = x.gradC
+        self.tensors[name] = out
+        self._use(x, m)
+        if self.dry:
+            return out
+        self._emit(self.fwd, "stp_upsample2x_add", x.buf.data_ptr(), m.buf.data_ptr(), self.N, x.H, x.W, x.C, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not out.needs_grad or not out.grad_ready:
+                return
+            dy = out.grad
+            if m.needs_grad:
+                self._emit(self.bwd, "stp_upsample2x_bwd", dy.data_ptr(), self._gradbuf(m).data_ptr(), self.N, m.H, m.W, m.C, out.gradC,
+                           self.cdt, int(m.grad_ready))
+                m.grad_ready = True
+            if x.needs_grad:
+                x.grad, x.grad_ready = dy, True
+
+        self._tape.append(back)
+        return out
+
+    def concat_resize(self, name, parts):
+        """``Concatenate()([ResizeImage(f_i, 'bilinear')(t_i) ...])``: every part is resized (TF 1.x bilinear, integer
+        factor; 1 = copy) straight into its channel slice of the output."""
+        Ho, Wo = parts[0][0].H * parts[0][1], parts[0][0].W * parts[0][1]
+        if any((t.H * f, t.W * f) != (Ho, Wo) for t, f in parts):
+            raise StpShapeError("%s: resized parts differ in size" % name)
+        Ct = sum(t.C for t, _ in parts)
+        out = self._new(name, Ho, Wo, Ct, any(t.needs_grad for t, _ in parts))
+        self._use(*[t for t, _ in parts])
+        if self.dry:
+            return out
+        off = 0
+        for t, f in parts:
+            self._emit(self.fwd, "stp_resize_bilinear", t.buf.data_ptr(), out.buf.data_ptr(), self.N, t.H, t.W, t.C, f, Ct, off, self.cdt)
+            off += t.C
+        if not self.training:
+            return out
+
+        def back():
+            if not out.needs_grad or not out.grad_ready:
+                return
+            o = 0
+            for t, f in parts:
+                if t.needs_grad:
+                    self._emit(self.bwd, "stp_resize_bilinear_bwd", out.grad.data_ptr(), self._gradbuf(t).data_ptr(), self.N, t.H, t.W,
+                               t.C, f, out.gradC, o, self.cdt, int(t.grad_ready))
+                    t.grad_ready = True
+                o += t.C
+
+        self._tape.append(back)
+        return out
+
+    def resize(self, name, x, factor):
+        """``ResizeImage(factor, 'bilinear')`` of a tensor whose gradient carries padded channels (the class logits)."""
+        out = self._new(name, x.H * factor, x.W * factor, x.C, x.needs_grad)
+        out.gradC = x.gradC
+        self._use(x)
+        if self.dry:
+            return out
+        self._emit(self.fwd, "stp_resize_bilinear", x.buf.data_ptr(), out.buf.data_ptr(), self.N, x.H, x.W, x.C, factor, x.C, 0, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            self._emit(self.bwd, "stp_resize_bilinear_bwd", out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.gradC,
+                       factor, x.gradC, 0, self.cdt, int(x.grad_ready))
+            x.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
     def maxpool2(self, name, x):
         """MaxPooling2D(2, 2) without padding (VGG blocks)."""
         if x.H % 2 or x.W % 2:

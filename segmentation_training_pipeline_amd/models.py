@@ -96,7 +96,19 @@ def Linknet(backbone_name="vgg16", input_shape=(None, None, 3), classes=1, activ
     return SegModel("Linknet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, decoder_filters)
 
 
-ARCHITECTURES = {"Unet": Unet, "Linknet": Linknet}
+def FPN(backbone_name="vgg16", input_shape=(None, None, 3), classes=21, activation="softmax", encoder_weights="imagenet",
+        freeze_encoder=False, fpn_layers="default", pyramid_block_filters=256, segmentation_block_filters=128,
+        upsample_rates=(2, 2, 2), last_upsample=4, interpolation="bilinear", use_batchnorm=True, dropout=None):
+    """segmentation_models.FPN keyword surface (schemas/segmentation.raml:180-203)."""
+    if backbone_name not in nets.RESNET_UNITS:
+        raise ValueError("Unknown backbone")
+    if fpn_layers != "default" or tuple(upsample_rates) != (2, 2, 2) or int(last_upsample) != 4 or interpolation != "bilinear" \
+            or not use_batchnorm or dropout or int(pyramid_block_filters) != 256 or int(segmentation_block_filters) != 128:
+        raise ValueError("the HIP FPN implements the default pyramid (256/128 filters, x2 rates, bilinear, BatchNorm, no dropout)")
+    return SegModel("FPN", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+
+
+ARCHITECTURES = {"Unet": Unet, "Linknet": Linknet, "FPN": FPN}
 
 
 def known_backbones():

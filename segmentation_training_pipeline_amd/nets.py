@@ -136,4 +136,34 @@ def linknet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(No
     return _head(plan, x, H, W, classes, loss, with_loss)
 
 
-NETWORKS = {"Unet": unet_resnet, "Linknet": linknet_resnet}
+def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True,
+               pyramid_block_filters=256, segmentation_block_filters=128, last_upsample=4):
+    """segmentation_models 0.2.1 ``FPN(..., upsample_rates=(2,2,2), interpolation='bilinear', use_batchnorm=True)``
+    (``schemas/segmentation.raml:180-203``).  Pyramid over [encoder output, stage4/3/2 unit1 relu1]: 1x1 lateral conv (+ the
+    2x nearest upsampling of the level above), two conv3x3+BN+ReLU segmentation convs per level; the four maps are resized
+    to 1/4 resolution (TF 1.x bilinear) and concatenated, conv3x3+BN+ReLU, conv3x3 to the classes, bilinear x4."""
+    if last_upsample != 4:
+        raise ValueError("the HIP FPN pyramid ends at 1/4 resolution: last_upsample must be 4")
+    x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
+    pf, sf = int(pyramid_block_filters), int(segmentation_block_filters)
+    m, pyramid = None, []
+    for i, c in enumerate((x, taps[4], taps[3], taps[2])):
+        pre = "fpn_stage%d_" % i
+        lat = plan.conv(pre + "lateral", c, pf, 1, bias=True)
+        if m is not None:
+            lat = plan.upsample_add(pre + "add", lat, m)
+        p = plan.bn(pre + "segm1_bn", plan.conv(pre + "segm1", lat, sf, 3, pad=1, bn_stats=True), BN_EPS_DECODER, relu=True)
+        p = plan.bn(pre + "segm2_bn", plan.conv(pre + "segm2", p, sf, 3, pad=1, bn_stats=True), BN_EPS_DECODER, relu=True)
+        m = lat
+        pyramid.append(p)
+    cat = plan.concat_resize("fpn_concat", [(pyramid[3], 1), (pyramid[2], 2), (pyramid[1], 4), (pyramid[0], 8)])
+    y = plan.bn("fpn_final_bn", plan.conv("fpn_final", cat, sf * 4, 3, pad=1, bn_stats=True), BN_EPS_DECODER, relu=True)
+    lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
+    logits = plan.resize("logits", lo, 4)
+    if with_loss:
+        target = plan.input_u8("mask", H, W, 1)
+        (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, loss[0], loss[1])
+    return logits
+
+
+NETWORKS = {"Unet": unet_resnet, "Linknet": linknet_resnet, "FPN": fpn_resnet}

@@ -21,6 +21,8 @@ TAP_MAP = [("bn_data", "bn_data"), ("conv0", "conv0"), ("relu0", "bn0"), ("pooli
            ("stage4_unit1_out", "stage4_unit1_conv2"), ("relu1", "bn1"),
            ("decoder_stage0_relu2", "decoder_stage0_bn2"), ("decoder_stage2_relu2", "decoder_stage2_bn2"),
            ("decoder_stage4_relu2", "decoder_stage4_bn2"),
+           ("fpn_stage0_out", "fpn_stage0_segm2_bn"), ("fpn_stage1_out", "fpn_stage1_segm2_bn"),
+           ("fpn_stage2_out", "fpn_stage2_segm2_bn"), ("fpn_stage3_out", "fpn_stage3_segm2_bn"),
            ("block1_out", "block1_conv2"), ("block2_out", "block2_conv2"), ("block3_out", "block3_conv3"),
            ("block4_out", "block4_conv3"), ("block5_out", "block5_conv3")]
 
@@ -52,12 +54,13 @@ def first_bad_tap(model, taps, atol):
 
 
 @pytest.mark.parametrize("arch,backbone", [("Unet", "resnet18"), ("Unet", "resnet34"), ("Linknet", "resnet18"), ("Linknet", "resnet34"),
-                                           ("Unet", "resnet50"), ("Linknet", "resnet50")])      # bottleneck encoders: 1x1 / 3x3 / 1x1
+                                           ("Unet", "resnet50"), ("Linknet", "resnet50"),      # bottleneck encoders: 1x1 / 3x3 / 1x1
+                                           ("FPN", "resnet18"), ("FPN", "resnet50")])         # BASELINE configs[3] family
 def test_fp32_step_matches_oracle(arch, backbone):
     # (the 2048-channel bottleneck encoders get 128 px: at 64 px their last BatchNormalization sees 8 values per channel
     #  and the fp32 round-off of the two implementations, amplified by 1/sigma, exceeds the per-tap debugging tolerance)
     n, size = 2, (128 if backbone == "resnet50" else 64)
-    P = (onets.init_unet_resnet if arch == "Unet" else onets.init_linknet_resnet)(backbone, seed=42)
+    P = {"Unet": onets.init_unet_resnet, "Linknet": onets.init_linknet_resnet, "FPN": onets.init_fpn_resnet}[arch](backbone, seed=42)
     x, y = ostep.synthetic_batch(n, size, size, seed=1234)
     tr = ostep.OracleTrainer(P, backbone=backbone, loss=LOSS, optimizer="sgd", lr=0.05, opt_kwargs={"momentum": 0.9}, architecture=arch)
     m = make(backbone, size, n, "fp32", optimizer="SGD", lr=0.05, opt_kwargs={"momentum": 0.9}, architecture=arch)
@@ -70,7 +73,7 @@ def test_fp32_step_matches_oracle(arch, backbone):
     assert bad is None, bad
     # north-star bar 1e-3 (stated for U-Net/ResNet34).  Linknet over the 2048-channel encoder - 3 x (conv, BN over as few as
     # 128 values) per decoder stage on top of 50 layers - lands at 1.3e-3 between two fp32 summation orders: 2e-3 there.
-    latol = 2e-3 if (arch, backbone) == ("Linknet", "resnet50") else 1e-3
+    latol = 2e-3 if (arch, backbone) in (("Linknet", "resnet50"), ("FPN", "resnet50")) else 1e-3
     np.testing.assert_allclose(m.logits(), o["logits"], atol=latol)
     assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5                             # north-star bar
     # `dice` is the THRESHOLDED metric: a pixel whose probability is within the logit tolerance of 0.5 may fall on either
@@ -223,6 +226,28 @@ def test_fp32_softmax_head_step_matches_oracle():
     assert pr.shape == (n, size, size, classes)
     np.testing.assert_allclose(pr.sum(axis=-1), 1.0, atol=1e-5)
     np.testing.assert_allclose(pr, ref, atol=1e-3)
+
+
+def test_fp32_fpn_resnet50_three_class_matches_oracle():
+    """BASELINE.json configs[3] as a parity case (FPN / ResNet50, 3-class softmax), at a size the oracle finishes in seconds."""
+    n, size, classes = 1, 128, 3
+    P = onets.init_fpn_resnet("resnet50", classes=classes, seed=42)
+    x, _ = ostep.synthetic_batch(n, size, size, seed=5)
+    yy, xx = np.mgrid[0:size, 0:size]
+    y = ((yy // 32 + xx // 48) % classes).astype(np.uint8)[None, :, :, None].repeat(n, axis=0)
+    spec = "categorical_crossentropy+0.5*dice_loss"
+    tr = ostep.OracleTrainer(P, backbone="resnet50", loss=spec, optimizer="sgd", lr=0.01, architecture="FPN", activation="softmax")
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    m = HipSegModel("FPN", "resnet50", (size, size, 3), classes, "softmax", batch=n, dtype="fp32", loss=spec, optimizer="SGD", lr=0.01,
+                    use_graph=False)
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=2e-3)          # deep bottleneck encoder, batch of one: see above
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+    pr = m.predict(x)
+    assert pr.shape == (n, size, size, classes) and np.allclose(pr.sum(-1), 1.0, atol=1e-5)
 
 
 @pytest.mark.parametrize("opt,lr", [("RMSprop", 1e-3), ("Nadam", 2e-3)])

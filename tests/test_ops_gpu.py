@@ -514,6 +514,39 @@ def test_maxpool_and_upsample_gradients(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("factor", [1, 2, 4, 8])
+def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor):
+    """stp_resize_bilinear(_bwd): TF 1.x resize_bilinear(align_corners=False) by an integer factor, written into a channel
+    slice of a wider tensor (FPN's Concatenate), against the oracle's index formulation and torch autograd."""
+    from oracle import nets as onets
+    from segmentation_training_pipeline_amd import _lib
+    rng = np.random.RandomState(41)
+    n, h, w, c, ldo, coff = 2, 5, 7, 8, 24, 8
+    x = q(rng.randn(n, h, w, c), dtype)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = onets.resize_bilinear_tf1(xt, factor)
+    gy = q(rng.randn(n, h * factor, w * factor, ldo), dtype)
+    ref.backward(torch.from_numpy(gy[..., coff:coff + c]).permute(0, 3, 1, 2))
+    y = torch.full((n, h * factor, w * factor, ldo), 7.0, dtype=TD[dtype], device=DEV)
+    xd = dev(x, dtype)
+    _lib.call("stp_resize_bilinear", ops.ptr(xd), ops.ptr(y), n, h, w, c, factor, ldo, coff, ops.dt(xd), ops.stream())
+    got = host(y)
+    np.testing.assert_allclose(got[..., coff:coff + c], ref.detach().permute(0, 2, 3, 1).numpy(), atol=tol(x, dtype, 0.5))
+    assert np.all(got[..., :coff] == 7.0) and np.all(got[..., coff + c:] == 7.0)          # neighbours' slices untouched
+    for acc in (0, 1):
+        base = q(rng.randn(n, h, w, c), dtype)
+        dx = dev(base, dtype)
+        _lib.call("stp_resize_bilinear_bwd", ops.ptr(dev(gy, dtype)), ops.ptr(dx), n, h, w, c, factor, ldo, coff, ops.dt(dx), acc, ops.stream())
+        want = xt.grad.permute(0, 2, 3, 1).numpy() + (base if acc else 0)
+        np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
+    # FPN top-down add: x += nearest-2x(m)
+    xa, ma = q(rng.randn(n, 6, 8, 16), dtype), q(rng.randn(n, 3, 4, 16), dtype)
+    xd2 = dev(xa, dtype)
+    _lib.call("stp_upsample2x_add", ops.ptr(xd2), ops.ptr(dev(ma, dtype)), n, 6, 8, 16, ops.dt(xd2), ops.stream())
+    np.testing.assert_allclose(host(xd2), xa + np_ops.upsample2x(ma), atol=tol(xa, dtype, 1.0))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     rng = np.random.RandomState(13)
     count = 2 * 48 * 48
