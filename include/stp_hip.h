@@ -214,6 +214,10 @@ int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N
 int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 int stp_maxpool2x2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
                        int32_t accumulate, void* stream);
+/* AveragePooling2D(pool = strides = k), H % k == W % k == 0 (PSPNet pyramid pooling) and its gradient dx = dy / k^2. */
+int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* stream);
+int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
+                    int32_t accumulate, void* stream);
 /* dy <- dy * [y > 0] in place (gradient of a ReLU fused into a convolution epilogue); count % 4 == 0 */
 int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* stream);
 

@@ -234,6 +234,43 @@ def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None)
     return resize_bilinear_tf1(lo, 4).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
+def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_filters=512):
+    """PSPNet (segmentation_models 0.2.1 defaults, ``schemas/segmentation.raml:225-249``): only the encoder up to
+    stage3_unit1_relu1 (1/8 resolution) exists; see pspnet_resnet_forward."""
+    full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
+    keep = ("bn_data", "conv0", "bn0", "stage1_", "stage2_", "stage3_unit1_bn1")
+    P = OrderedDict((k, v) for k, v in full.items() if k.startswith(keep))
+    rng = np.random.RandomState(seed + 3)
+    c = STAGE_FILTERS[1] * expansion(backbone)
+    for level in (1, 2, 3, 6):
+        P["psp_level%d_conv/kernel" % level] = _glorot_uniform(rng, (1, 1, c, conv_filters))
+        _bn(P, "psp_level%d_bn" % level, conv_filters)
+    P["psp_final/kernel"] = _glorot_uniform(rng, (1, 1, c + 4 * conv_filters, 512))
+    _bn(P, "psp_final_bn", 512)
+    P["final_conv/kernel"] = _glorot_uniform(rng, (3, 3, 512, classes))
+    P["final_conv/bias"] = np.zeros(classes, np.float32)
+    return P
+
+
+def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None):
+    """feature = stage3_unit1_relu1; for level in 1, 2, 3, 6: AveragePooling2D(size / level) -> Conv 1x1 (no bias) -> BN ->
+    ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
+    classes; bilinear x8.  Returns (logits_nhwc, bn_updates)."""
+    ctx = _Ctx(P, training, taps)
+    _, skips = _resnet_encoder(ctx, x_nhwc, backbone, stop_at="stage3_unit1_relu1")
+    f = skips["stage3_unit1_relu1"]
+    parts = [f]
+    for level in (1, 2, 3, 6):
+        k = f.shape[2] // level
+        p = F.avg_pool2d(f, kernel_size=k, stride=k)
+        p = _bn_apply(ctx, _conv(ctx, p, "psp_level%d_conv" % level), "psp_level%d_bn" % level, BN_EPS_DECODER, relu=True)
+        ctx.tap("psp_level%d_out" % level, p)
+        parts.append(resize_bilinear_tf1(p, k))
+    y = _bn_apply(ctx, _conv(ctx, torch.cat(parts, dim=1), "psp_final"), "psp_final_bn", BN_EPS_DECODER, relu=True)
+    lo = _conv(ctx, y, "final_conv", pad=1)
+    return resize_bilinear_tf1(lo, 8).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+
+
 ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1/", "block")
 
 
@@ -299,7 +336,7 @@ def _bn_apply(ctx, x, name, eps, relu):
     return F.relu(y) if relu else y
 
 
-def _resnet_encoder(ctx, x_nhwc, backbone):
+def _resnet_encoder(ctx, x_nhwc, backbone, stop_at=None):
     """Pre-activation ResNet of classification_models up to the final bn1+relu; returns (x, skip tensors by layer name)."""
     units = RESNET_UNITS[backbone]
     x = x_nhwc.permute(0, 3, 1, 2)
@@ -320,6 +357,8 @@ def _resnet_encoder(ctx, x_nhwc, backbone):
             if u == 1:
                 skips[pre + "relu1"] = a
                 ctx.tap(pre + "relu1", a)
+                if stop_at == pre + "relu1":
+                    return None, skips
                 shortcut = _conv(ctx, a, pre + "sc", stride=stride, pad=0)
             else:
                 shortcut = x

@@ -45,6 +45,8 @@ class OracleTrainer:
     def _forward(self, P, x, training, taps):
         if self.architecture == "Linknet":
             return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
+        if self.architecture == "PSPNet":
+            return nets.pspnet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
         if self.architecture == "FPN":
             return nets.fpn_resnet_forward(P, x, self.backbone, training=training, taps=taps)
         return nets.unet_resnet_forward(P, x, self.backbone, training=training, taps=taps, decoder_filters=self.decoder_filters)

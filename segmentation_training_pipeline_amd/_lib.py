@@ -70,6 +70,8 @@ SIGNATURES = {
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool2x2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool2x2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_relu_bwd": (i32, [vp, vp, i64, i32, vp]),
     "stp_upsample2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_upsample2x_add": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -851,6 +851,65 @@ extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H
 }
 
 // ------------------------------------------------------------------------------------------
+// AveragePooling2D(pool = strides = k) with H % k == W % k == 0 (PSPNet's pyramid pooling levels) and its gradient
+// (every input pixel belongs to exactly one window: dx = dy / k^2).
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int k) {
+  const int Ho = H / k, Wo = W / k;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const float inv = 1.f / (float)(k * k);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int wo = (int)((i / C) % Wo);
+    const int ho = (int)((i / ((int64_t)C * Wo)) % Ho);
+    const int n = (int)(i / ((int64_t)C * Wo * Ho));
+    const T* b = x + (((int64_t)n * H + (int64_t)ho * k) * W + (int64_t)wo * k) * C + c;
+    float acc = 0.f;
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) acc += Elem<T>::load(b + ((int64_t)dy * W + dx) * C);
+    Elem<T>::store(y + i, acc * inv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int k,
+                                                          int accumulate) {
+  const int Ho = H / k, Wo = W / k;
+  const int64_t total = (int64_t)N * H * W * C;
+  const float inv = 1.f / (float)(k * k);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int w = (int)((i / C) % W);
+    const int h = (int)((i / ((int64_t)C * W)) % H);
+    const int n = (int)(i / ((int64_t)C * W * H));
+    float g = Elem<T>::load(dy + (((int64_t)n * Ho + h / k) * Wo + w / k) * C + c) * inv;
+    if (accumulate) g += Elem<T>::load(dx + i);
+    Elem<T>::store(dx + i, g);
+  }
+}
+
+extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * (H / k) * (W / k) * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, k);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(avgpool_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, k);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
+                               int32_t accumulate, void* stream) {
+  if (!dy || !dx || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * H * W * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, k, accumulate);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // FPN pieces.  (a) x[n,2h+i,2w+j,c] += m[n,h,w,c]: Add()([lateral, UpSampling2D(2)(m)]) in place on the lateral tensor.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2x_add_kernel(T* __restrict__ x, const T* __restrict__ m, int N, int H, int W, int C) {

@@ -639,6 +639,28 @@ class Plan(object):
         self._tape.append(back)
         return out
 
+    def avgpool(self, name, x, k):
+        """AveragePooling2D(pool_size = strides = k) with exact division (PSPNet pyramid levels)."""
+        if x.H % k or x.W % k:
+            raise StpShapeError("%s: %dx%d is not divisible by the pooling size %d" % (name, x.H, x.W, k))
+        out = self._new(name, x.H // k, x.W // k, x.C, x.needs_grad)
+        self._use(x)
+        if self.dry:
+            return out
+        self._emit(self.fwd, "stp_avgpool", x.buf.data_ptr(), out.buf.data_ptr(), self.N, x.H, x.W, x.C, k, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            self._emit(self.bwd, "stp_avgpool_bwd", out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.C, k, self.cdt,
+                       int(x.grad_ready))
+            x.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
     def maxpool2(self, name, x):
         """MaxPooling2D(2, 2) without padding (VGG blocks)."""
         if x.H % 2 or x.W % 2:

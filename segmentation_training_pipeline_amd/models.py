@@ -108,7 +108,19 @@ def FPN(backbone_name="vgg16", input_shape=(None, None, 3), classes=21, activati
     return SegModel("FPN", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
 
 
-ARCHITECTURES = {"Unet": Unet, "Linknet": Linknet, "FPN": FPN}
+def PSPNet(backbone_name="vgg16", input_shape=(384, 384, 3), classes=21, activation="softmax", encoder_weights="imagenet",
+           freeze_encoder=False, downsample_factor=8, psp_conv_filters=512, psp_pooling_type="avg", use_batchnorm=True, dropout=None,
+           final_interpolation="bilinear"):
+    """segmentation_models.PSPNet keyword surface (schemas/segmentation.raml:225-249)."""
+    if backbone_name not in nets.RESNET_UNITS:
+        raise ValueError("Unknown backbone")
+    if int(downsample_factor) != 8 or int(psp_conv_filters) != 512 or psp_pooling_type != "avg" or not use_batchnorm or dropout \
+            or final_interpolation != "bilinear":
+        raise ValueError("the HIP PSPNet implements the default module (1/8 feature, 512 filters, avg pooling, BatchNorm, bilinear)")
+    return SegModel("PSPNet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+
+
+ARCHITECTURES = {"Unet": Unet, "Linknet": Linknet, "FPN": FPN, "PSPNet": PSPNet}
 
 
 def known_backbones():

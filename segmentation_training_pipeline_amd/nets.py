@@ -29,9 +29,10 @@ def known_backbones():
     return sorted(RESNET_UNITS) + sorted(VGG_BLOCKS)
 
 
-def _resnet_encoder(plan, backbone, H, W, in_ch):
-    """Pre-activation ResNet-18/34 of classification_models; returns (bn1+relu output, relu0, {stage: unit-1 relu1})."""
-    if H % 32 or W % 32:
+def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
+    """Pre-activation ResNet of classification_models; returns (bn1+relu output, relu0, {stage: unit-1 relu1}).
+    ``stop_stage``: build only up to that stage's unit-1 relu1 (PSPNet cuts the backbone there); the first value is None."""
+    if (H % 32 or W % 32) and stop_stage is None:
         raise ValueError("input height/width must be divisible by 32")
     units = RESNET_UNITS[backbone]
     ex = 4 if backbone in BOTTLENECK else 1
@@ -48,6 +49,8 @@ def _resnet_encoder(plan, backbone, H, W, in_ch):
             a = plan.bn(pre + "bn1", x, BN_EPS_ENCODER, relu=True)
             if u == 1:
                 taps[s] = a
+                if s == stop_stage:
+                    return None, relu0, taps
                 shortcut = plan.conv(pre + "sc", a, f * ex, 1, stride=stride, pad=0)
             else:
                 shortcut = x
@@ -166,4 +169,33 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
     return logits
 
 
-NETWORKS = {"Unet": unet_resnet, "Linknet": linknet_resnet, "FPN": fpn_resnet}
+def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True,
+                  downsample_factor=8, psp_conv_filters=512):
+    """segmentation_models 0.2.1 ``PSPNet(downsample_factor=8, psp_conv_filters=512, psp_pooling_type='avg', use_batchnorm=True,
+    final_interpolation='bilinear')`` (``schemas/segmentation.raml:225-249``): the backbone is cut at the 1/8 feature
+    (stage3_unit1_relu1; 1/4: stage2, 1/16: stage4); pyramid pooling levels 1, 2, 3, 6 = AveragePooling2D(size/level) ->
+    Conv 1x1 + BN + ReLU -> bilinear resize back, concatenated with the feature; Conv 1x1 + BN + ReLU; Conv 3x3 to the classes;
+    bilinear x downsample_factor."""
+    stage = {4: 2, 8: 3, 16: 4}[int(downsample_factor)]
+    _, _, taps = _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=stage)
+    f = taps[stage]
+    if f.H != f.W or f.H % 6:
+        raise ValueError("PSPNet needs a square input whose 1/%d feature map is divisible by 6 (got %dx%d)" % (downsample_factor, f.H, f.W))
+    parts = [(f, 1)]
+    for level in (1, 2, 3, 6):
+        k = f.H // level
+        pre = "psp_level%d_" % level
+        p = plan.avgpool(pre + "pool", f, k)
+        p = plan.bn(pre + "bn", plan.conv(pre + "conv", p, int(psp_conv_filters), 1, bn_stats=True), BN_EPS_DECODER, relu=True)
+        parts.append((p, k))
+    cat = plan.concat_resize("psp_concat", parts)
+    y = plan.bn("psp_final_bn", plan.conv("psp_final", cat, 512, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
+    lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
+    logits = plan.resize("logits", lo, int(downsample_factor))
+    if with_loss:
+        target = plan.input_u8("mask", H, W, 1)
+        (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, loss[0], loss[1])
+    return logits
+
+
+NETWORKS = {"Unet": unet_resnet, "Linknet": linknet_resnet, "FPN": fpn_resnet, "PSPNet": pspnet_resnet}

@@ -47,6 +47,8 @@ def test_unknown_names_raise_the_reference_errors(tmp_path, capsys):
     assert cfg4.createNet().architecture == "Linknet" and cfg4.createNet().backbone_name == "resnet50"
     cfg6 = segmentation.parse(write_cfg(tmp_path, architecture="FPN", backbone="resnet50", classes=3, activation="softmax"))
     assert cfg6.createNet().architecture == "FPN" and cfg6.createNet().classes == 3
+    cfg7 = segmentation.parse(write_cfg(tmp_path, architecture="PSPNet", backbone="resnet101", classes=20, activation="softmax", shape=[96, 96, 3]))
+    assert cfg7.createNet().architecture == "PSPNet" and cfg7.createNet().input_shape == (96, 96, 3)
     cfg5 = segmentation.parse(write_cfg(tmp_path, decoder_block_type="transpose"))         # schemas/segmentation.raml:166-169
     assert cfg5.createNet().decoder_block_type == "transpose"
     with pytest.raises(ValueError, match="Unknown architecture"):

@@ -228,6 +228,45 @@ def test_fp32_softmax_head_step_matches_oracle():
     np.testing.assert_allclose(pr, ref, atol=1e-3)
 
 
+@pytest.mark.parametrize("backbone,classes", [("resnet18", 1), ("resnet50", 5)])
+def test_fp32_pspnet_step_matches_oracle(backbone, classes):
+    """PSPNet (BASELINE.json configs[4] family): backbone cut at the 1/8 feature, pyramid pooling levels 1/2/3/6 through
+    stp_avgpool -> 1x1 conv + BN + ReLU -> TF1 bilinear resize into the concatenated tensor, x8 resize of the logits.
+    96 px = 12x12 feature map (divisible by 6); BatchNormalization at level 1 sees only `batch` values per channel."""
+    n, size = 2, 96
+    P = onets.init_pspnet_resnet(backbone, classes=classes, seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=8)
+    act = "sigmoid" if classes == 1 else "softmax"
+    if classes > 1:
+        yy, xx = np.mgrid[0:size, 0:size]
+        y = ((yy // 16 + xx // 24) % classes).astype(np.uint8)[None, :, :, None].repeat(n, axis=0)
+    spec = LOSS if classes == 1 else "categorical_crossentropy+1.0*dice_loss"
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=spec, optimizer="sgd", lr=0.02, architecture="PSPNet", activation=act)
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    m = HipSegModel("PSPNet", backbone, (size, size, 3), classes, act, batch=n, dtype="fp32", loss=spec, optimizer="SGD", lr=0.02,
+                    use_graph=False)
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    taps = {}
+    o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
+    met = m.train_on_batch(x, y)
+    for lvl in (1, 2, 3, 6):
+        ref = taps["psp_level%d_out" % lvl].detach().numpy()
+        np.testing.assert_allclose(m.activation("psp_level%d_bn" % lvl), ref, atol=5e-4 * max(1.0, np.abs(ref).max()), err_msg="level %d" % lvl)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = rel_l2(g[k], ref)
+        assert e <= (1e-4 if k.startswith("final_conv") else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
+    mb = HipSegModel("PSPNet", backbone, (size, size, 3), classes, act, batch=n, dtype="bf16", loss=spec, optimizer="Adam", lr=1e-3)
+    mb.set_weights(P)
+    l0 = mb.train_on_batch(x, y)["loss"]
+    for _ in range(10):
+        l1 = mb.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0                                   # bf16 + hipGraph: runs and learns
+
+
 def test_fp32_fpn_resnet50_three_class_matches_oracle():
     """BASELINE.json configs[3] as a parity case (FPN / ResNet50, 3-class softmax), at a size the oracle finishes in seconds."""
     n, size, classes = 1, 128, 3

@@ -539,6 +539,18 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
         _lib.call("stp_resize_bilinear_bwd", ops.ptr(dev(gy, dtype)), ops.ptr(dx), n, h, w, c, factor, ldo, coff, ops.dt(dx), acc, ops.stream())
         want = xt.grad.permute(0, 2, 3, 1).numpy() + (base if acc else 0)
         np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
+    # PSPNet pyramid pooling: AveragePooling2D(k, k) and its gradient
+    xp = q(rng.randn(n, 6, 6, 8), dtype)
+    xpt = torch.from_numpy(xp).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    pr = torch.nn.functional.avg_pool2d(xpt, 3, 3)
+    gyp = q(rng.randn(n, 2, 2, 8), dtype)
+    pr.backward(torch.from_numpy(gyp).permute(0, 3, 1, 2))
+    yp, dxp = torch.empty((n, 2, 2, 8), dtype=TD[dtype], device=DEV), torch.empty((n, 6, 6, 8), dtype=TD[dtype], device=DEV)
+    xpd = dev(xp, dtype)
+    _lib.call("stp_avgpool", ops.ptr(xpd), ops.ptr(yp), n, 6, 6, 8, 3, ops.dt(xpd), ops.stream())
+    _lib.call("stp_avgpool_bwd", ops.ptr(dev(gyp, dtype)), ops.ptr(dxp), n, 6, 6, 8, 3, ops.dt(xpd), 0, ops.stream())
+    np.testing.assert_allclose(host(yp), pr.detach().permute(0, 2, 3, 1).numpy(), atol=tol(xp, dtype, 0.5))
+    np.testing.assert_allclose(host(dxp), xpt.grad.permute(0, 2, 3, 1).numpy(), atol=tol(gyp, dtype, 0.5))
     # FPN top-down add: x += nearest-2x(m)
     xa, ma = q(rng.randn(n, 6, 8, 16), dtype), q(rng.randn(n, 3, 4, 16), dtype)
     xd2 = dev(xa, dtype)
