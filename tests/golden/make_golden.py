@@ -6,7 +6,8 @@
   ``segmentation_pipeline/impl/rle.py:10-35`` (``rle_encode`` / ``rle_decode``), imported from
   ``/root/reference`` with a stub for the absent ``skimage`` (only ``multi_rle_encode`` uses it).
   This is the only part of the reference that can execute in this container.
-* ``unet_resnet18_64.npz`` / ``unet_resnet34_64.npz`` / ``linknet_resnet18_64.npz`` - outputs of the in-repo oracle (PARITY
+* ``unet_resnet18_64.npz`` / ``unet_resnet34_64.npz`` / ``linknet_resnet18_64.npz`` / ``fpn_resnet18_64.npz`` /
+  ``pspnet_resnet18_96.npz`` - outputs of the in-repo oracle (PARITY
   UNPINNED: the reference's Keras path is not runnable) on a seeded synthetic batch; they pin
   the oracle against drift of itself / of the torch build.
 """
@@ -58,7 +59,8 @@ def make_rle():
 
 def make_unet(backbone, size, n, fname, arch="Unet"):
     from oracle import nets, step
-    P = (nets.init_unet_resnet if arch == "Unet" else nets.init_linknet_resnet)(backbone, seed=42)
+    P = {"Unet": nets.init_unet_resnet, "Linknet": nets.init_linknet_resnet, "FPN": nets.init_fpn_resnet,
+         "PSPNet": nets.init_pspnet_resnet}[arch](backbone, seed=42)
     tr = step.OracleTrainer(P, backbone=backbone, loss="binary_crossentropy+1.0*dice_loss",
                             optimizer="adam", lr=1e-3, architecture=arch)
     x, y = step.synthetic_batch(n, size, size, seed=1234)
@@ -85,3 +87,5 @@ if __name__ == "__main__":
     make_unet("resnet18", 64, 2, "unet_resnet18_64.npz")
     make_unet("resnet34", 64, 2, "unet_resnet34_64.npz")
     make_unet("resnet18", 64, 2, "linknet_resnet18_64.npz", arch="Linknet")
+    make_unet("resnet18", 64, 2, "fpn_resnet18_64.npz", arch="FPN")
+    make_unet("resnet18", 96, 2, "pspnet_resnet18_96.npz", arch="PSPNet")

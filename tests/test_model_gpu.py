@@ -110,11 +110,13 @@ def test_fp32_step_matches_oracle(arch, backbone):
         np.testing.assert_allclose(w[k], tr.P[k], atol=watol, err_msg=k)
 
 
-@pytest.mark.parametrize("arch,backbone", [("Unet", "resnet34"), ("Linknet", "resnet18")])
-def test_fp32_adam_step_matches_golden_fixture(golden_dir, arch, backbone):
-    g = np.load(os.path.join(golden_dir, "%s_%s_64.npz" % (arch.lower(), backbone)))
-    P = (onets.init_unet_resnet if arch == "Unet" else onets.init_linknet_resnet)(backbone, seed=int(g["seed"]))
-    m = make(backbone, 64, 2, "fp32", architecture=arch)
+@pytest.mark.parametrize("arch,backbone,size", [("Unet", "resnet34", 64), ("Linknet", "resnet18", 64), ("FPN", "resnet18", 64),
+                                                ("PSPNet", "resnet18", 96)])
+def test_fp32_adam_step_matches_golden_fixture(golden_dir, arch, backbone, size):
+    g = np.load(os.path.join(golden_dir, "%s_%s_%d.npz" % (arch.lower(), backbone, size)))
+    P = {"Unet": onets.init_unet_resnet, "Linknet": onets.init_linknet_resnet, "FPN": onets.init_fpn_resnet,
+         "PSPNet": onets.init_pspnet_resnet}[arch](backbone, seed=int(g["seed"]))
+    m = make(backbone, size, 2, "fp32", architecture=arch)
     m.set_weights(P)
     met = m.train_on_batch(g["x"], g["y"])
     np.testing.assert_allclose(m.logits(), g["logits1"], atol=1e-3)

@@ -16,10 +16,12 @@ def test_conv_param_count_matches_published_unet_resnet34():
     assert nets.conv_param_count(P) == 24421456
 
 
-@pytest.mark.parametrize("arch,backbone", [("Unet", "resnet18"), ("Unet", "resnet34"), ("Linknet", "resnet18")])
-def test_oracle_matches_golden(golden_dir, arch, backbone):
-    g = np.load(os.path.join(golden_dir, "%s_%s_64.npz" % (arch.lower(), backbone)))
-    P = (nets.init_unet_resnet if arch == "Unet" else nets.init_linknet_resnet)(backbone, seed=int(g["seed"]))
+@pytest.mark.parametrize("arch,backbone,size", [("Unet", "resnet18", 64), ("Unet", "resnet34", 64), ("Linknet", "resnet18", 64),
+                                                ("FPN", "resnet18", 64), ("PSPNet", "resnet18", 96)])
+def test_oracle_matches_golden(golden_dir, arch, backbone, size):
+    g = np.load(os.path.join(golden_dir, "%s_%s_%d.npz" % (arch.lower(), backbone, size)))
+    P = {"Unet": nets.init_unet_resnet, "Linknet": nets.init_linknet_resnet, "FPN": nets.init_fpn_resnet,
+         "PSPNet": nets.init_pspnet_resnet}[arch](backbone, seed=int(g["seed"]))
     tr = step.OracleTrainer(P, backbone=backbone, loss="binary_crossentropy+1.0*dice_loss",
                             optimizer="adam", lr=1e-3, architecture=arch)
     xf, yf = g["x"].astype(np.float32), g["y"].astype(np.float32)
