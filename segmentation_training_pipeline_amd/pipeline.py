@@ -137,6 +137,44 @@ class CyclicLR(object):
 CALLBACKS = {"EarlyStopping": EarlyStopping, "ReduceLROnPlateau": ReduceLROnPlateau, "CyclicLR": CyclicLR}
 
 
+class LRFinder(object):
+    """Result of ``cfg.lr_find`` with the accessors of keras_lr_finder (README.md:461-468): ``lrs`` / ``losses`` per batch,
+    ``plot_loss`` and ``plot_loss_change`` (matplotlib, imported on use), ``get_derivatives``."""
+
+    def __init__(self, start_lr, end_lr, num_batches):
+        self.lrs, self.losses = [], []
+        self.best_loss = 1e9
+        self.mult = (end_lr / start_lr) ** (1.0 / max(1, num_batches))
+
+    def record(self, lr, loss):
+        """Appends one batch; True = stop (loss diverged: NaN or > 4x the best so far)."""
+        self.lrs.append(lr)
+        self.losses.append(loss)
+        if not np.isfinite(loss) or loss > self.best_loss * 4:
+            return True
+        self.best_loss = min(self.best_loss, loss)
+        return False
+
+    def get_derivatives(self, sma=1):
+        d = [0.0] * sma
+        for i in range(sma, len(self.lrs)):
+            d.append((self.losses[i] - self.losses[i - sma]) / sma)
+        return d
+
+    def plot_loss(self, n_skip_beginning=10, n_skip_end=5, x_scale="log"):
+        import matplotlib.pyplot as plt
+        plt.ylabel("loss"); plt.xlabel("learning rate (log scale)")
+        plt.plot(self.lrs[n_skip_beginning:len(self.lrs) - n_skip_end], self.losses[n_skip_beginning:len(self.losses) - n_skip_end])
+        plt.xscale(x_scale)
+
+    def plot_loss_change(self, sma=1, n_skip_beginning=10, n_skip_end=5, y_lim=(-0.01, 0.01)):
+        import matplotlib.pyplot as plt
+        d = self.get_derivatives(sma)[n_skip_beginning:len(self.lrs) - n_skip_end]
+        plt.ylabel("rate of loss change"); plt.xlabel("learning rate (log scale)")
+        plt.plot(self.lrs[n_skip_beginning:len(self.lrs) - n_skip_end], d)
+        plt.xscale("log"); plt.ylim(y_lim)
+
+
 class DrawResults(object):
     """Per-epoch example sheets (reference segmentation.py:216-247, 251-257): up to ``limit`` samples of the fold's
     validation set (or, with ``train=True`` = ``cfg.showDataExamples``, augmented training samples) go through
@@ -659,6 +697,38 @@ class GenericTaskConfig(object):
             w.writeheader()
             for r in rows:
                 w.writerow({k: r.get(k) for k in keys})
+
+    def lr_find(self, d=None, foldsToExecute=None, stage=0, subsample=1.0, start_lr=0.00001, end_lr=1.0, epochs=5):
+        """Learning-rate range test (README.md:455-470, the keras_lr_finder procedure): trains fold 0's training set for
+        ``epochs`` epochs while multiplying the learning rate after every batch so that it sweeps ``start_lr -> end_lr``
+        geometrically; records the loss per batch and stops early once it exceeds 4x the best one.  No weights are saved."""
+        if d is None:
+            d = self._dataset_from_yaml()
+        fold = (foldsToExecute or [0])[0]
+        kf = self.kfold(d, range(len(d)))
+        idx = [int(i) for i in kf.sampledIndexes(fold, True, "all")]
+        idx = idx[: max(1, int(len(idx) * subsample))]
+        st = self.stages[stage]
+        model = self._compiled(st)
+        impl = model.impl
+        H, W = int(self.shape[0]), int(self.shape[1])
+        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state, classes=self.classes)
+        trainer = Trainer(impl, feeder, d, [], 0, 1)
+        nb = max(1, -(-len(idx) // impl.batch)) * int(epochs)
+        finder = LRFinder(float(start_lr), float(end_lr), nb)
+        lr = float(start_lr)
+        impl.set_lr(lr)
+        rng = np.random.RandomState(self.random_state)
+        for _ in range(int(epochs)):
+            order = [idx[i] for i in rng.permutation(len(idx))]
+            for items in trainer._batches(order, impl.batch, True):
+                feeder.feed(impl.plan, items, True)
+                loss = impl.train_on_batch(None, None)["loss"]
+                if finder.record(lr, loss):
+                    return finder
+                lr *= finder.mult
+                impl.set_lr(lr)
+        return finder
 
     def info(self, metric=None):
         """Primary metric per fold/stage from the metrics files (README.md:711-718)."""

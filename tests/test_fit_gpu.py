@@ -69,6 +69,9 @@ def test_parse_fit_predict_end_to_end(tmp_path):
     assert p.shape == (128, 128) and p.dtype == np.uint8
     m = np.asarray(Image.open(os.path.join(msk_dir, "s00.png"))) > 0
     assert p[m].mean() > p[~m].mean()                                       # foreground scores higher than background
+    # learning-rate range test (README.md:455-470)
+    finder = cfg.lr_find(ds, start_lr=1e-5, end_lr=1.0, epochs=3)
+    assert 1 <= len(finder.lrs) == len(finder.losses) <= 3 and finder.lrs[0] == 1e-5 and np.isfinite(finder.losses[0])
     # callback form + fold ensembling + flip TTA (README.md:498-534); probabilities arrive at the original size
     seen = {}
     cfg.predict_in_directory(img_dir, [0], 1, lambda name, mp, data: data.__setitem__(name, mp.arr), seen, ttflips=True)

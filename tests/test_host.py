@@ -191,6 +191,17 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
 
 
+def test_lr_finder_schedule_and_stop_rule():
+    f = pipeline.LRFinder(1e-5, 1.0, 100)
+    assert abs(1e-5 * f.mult ** 100 - 1.0) < 1e-9                       # geometric sweep start_lr -> end_lr over the batches
+    lr = 1e-5
+    for loss in (2.0, 1.5, 1.0, 1.2, 3.9):
+        assert not f.record(lr, loss); lr *= f.mult
+    assert f.record(lr, 4.1) and len(f.lrs) == len(f.losses) == 6        # > 4 x best (1.0): stop
+    assert pipeline.LRFinder(1e-5, 1.0, 10).record(1e-5, float("nan"))
+    assert f.get_derivatives(2)[:2] == [0.0, 0.0] and abs(f.get_derivatives(2)[2] - (1.0 - 2.0) / 2) < 1e-12
+
+
 def test_host_prefetcher_prepares_batches_in_order_and_reports_errors():
     """The loader thread that replaces the reference's augmentation worker processes: items come out batched, in order,
     labels reduced to one uint8 plane (binary / class index / arg-max of one-hot); a failing dataset raises in the consumer."""
