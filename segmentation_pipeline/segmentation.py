@@ -121,7 +121,7 @@ class PipelineConfig(generic.GenericTaskConfig):
         """uint8 HxWx3 images of any size -> uint8 [n, H, W, 3] at the network shape (stp_augment_u8, identity + resize)."""
         from segmentation_training_pipeline_amd import ops
         import torch
-        H, W = int(self.shape[0]), int(self.shape[1])
+        H, W = impl.H, impl.W
         xs = np.zeros((len(images), H, W, 3), np.uint8)
         for i, img in enumerate(images):
             h, w = img.shape[:2]
@@ -136,7 +136,7 @@ class PipelineConfig(generic.GenericTaskConfig):
         """Mean of the fold models' probabilities, optionally with flip test-time augmentation (README.md:519-534).
         ``models``: one model or a list; ``xs``: uint8 [n, H, W, 3] at the network shape, n <= inference batch."""
         models = models if isinstance(models, (list, tuple)) else [models]
-        acc = np.zeros((len(xs),) + tuple(int(v) for v in self.shape[:2]) + (self.classes,), np.float32)
+        acc = np.zeros((len(xs),) + tuple(xs.shape[1:3]) + (self.classes,), np.float32)
         k = 0
         for m in models:
             acc += m.predict(xs); k += 1
@@ -161,8 +161,29 @@ class PipelineConfig(generic.GenericTaskConfig):
         B = impl0.batch
         for s in range(0, n, B):
             items = [ds[i] for i in range(s, min(s + B, n))]
+            if self.crops:
+                yield items, [self._predict_cells(nets_, ttflips, it.x) for it in items]
+                continue
             xs = self._resize_to_net(impl0, [it.x for it in items])
             yield items, self.predict_on_batch(nets_, ttflips, xs)
+
+    def _predict_cells(self, models, ttflips, img):
+        """``crops: N`` at prediction time (README.md:488-491): the image is split into the N x N cells the model was trained
+        on, every cell is predicted, scaled back to its own size and the map is assembled - invisible to the caller."""
+        from segmentation_training_pipeline_amd.pipeline import crop_bounds
+        c = int(self.crops)
+        h, w = img.shape[:2]
+        ys, xs_ = crop_bounds(h, c), crop_bounds(w, c)
+        cells = [img[ys[r]:ys[r + 1], xs_[q]:xs_[q + 1]] for r in range(c) for q in range(c)]
+        impl0 = models[0].impl
+        out = np.zeros((h, w, self.classes), np.float32)
+        for s in range(0, len(cells), impl0.batch):
+            chunk = cells[s:s + impl0.batch]
+            probs = self.predict_on_batch(models, ttflips, self._resize_to_net(impl0, chunk))
+            for k, (cell, p) in enumerate(zip(chunk, probs), start=s):
+                r, q = divmod(k, c)
+                out[ys[r]:ys[r + 1], xs_[q]:xs_[q + 1]] = self._scale_back(p, *cell.shape[:2])
+        return out
 
     def predict_to_directory(self, spath, tpath, fold=0, stage=0, limit=-1, batchSize=32, binaryArray=False, ttflips=False):
         os.makedirs(tpath, exist_ok=True)
@@ -195,8 +216,10 @@ class PipelineConfig(generic.GenericTaskConfig):
         B = m.impl.batch
         for s in range(0, len(indexes), B):
             items = [ds[i] for i in indexes[s:s + B]]
-            xs = self._resize_to_net(m.impl, [it.x for it in items])
-            probs = self.predict_on_batch(m, ttflips, xs)
+            if self.crops:
+                probs = [self._predict_cells([m], ttflips, it.x) for it in items]
+            else:
+                probs = self.predict_on_batch(m, ttflips, self._resize_to_net(m.impl, [it.x for it in items]))
             yield EvalBatch(images=[it.x for it in items], data=[it.id for it in items],
                             segmentation_maps=[PredictedMap(np.asarray(it.y)) for it in items],
                             predicted_maps_aug=[PredictedMap(self._scale_back(p, *it.x.shape[:2])) for it, p in zip(items, probs)])

@@ -275,6 +275,41 @@ class KFoldedDataSet(object):
         return np.array(pos + neg[:k], np.int64)
 
 
+def crop_bounds(size, crops):
+    """Cell boundaries along one axis for ``crops`` cells (README.md:476-491): floor(k * size / crops)."""
+    return [(k * size) // crops for k in range(crops + 1)]
+
+
+class CropsDataSet(object):
+    """``crops: N`` (README.md:476-491): every image / mask is split into N x N cells and the model trains on the cells
+    (augmentations run per cell).  Item i is cell ``i % N^2`` (row-major) of base item ``i // N^2``."""
+
+    def __init__(self, ds, crops):
+        self.ds, self.crops = ds, int(crops)
+        self.name = getattr(ds, "name", "")
+
+    def __len__(self):
+        return len(self.ds) * self.crops * self.crops
+
+    def _cell(self, a, k):
+        if a is None:
+            return None
+        a = np.asarray(a)
+        ys, xs = crop_bounds(a.shape[0], self.crops), crop_bounds(a.shape[1], self.crops)
+        r, c = divmod(k, self.crops)
+        return a[ys[r]:ys[r + 1], xs[c]:xs[c + 1]]
+
+    def __getitem__(self, i):
+        from segmentation_pipeline.impl.datasets import PredictionItem
+        base, k = divmod(int(i), self.crops * self.crops)
+        it = self.ds[base]
+        return PredictionItem("%s.%d" % (it.id, k), self._cell(it.x, k), self._cell(it.y, k))
+
+    def isPositive(self, i):
+        y = self[i].y
+        return bool(np.asarray(y).any()) if y is not None else True
+
+
 # ------------------------------------------------------------------------------------------ device feeding
 class HostItem(object):
     """A dataset item prepared for the device: raw uint8 pixels and the label plane in PINNED host memory."""
@@ -612,6 +647,8 @@ class GenericTaskConfig(object):
         if dataset is None:
             dataset = self._dataset_from_yaml()
         rank, local_rank, world = distributed.init() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 0, 1)
+        if self.crops:
+            dataset = CropsDataSet(dataset, self.crops)       # the network is built for shape / crops (createNet1)
         indexes = list(range(len(dataset)))
         if subsample < 1.0:
             indexes = indexes[: max(1, int(len(indexes) * subsample))]
@@ -649,7 +686,7 @@ class GenericTaskConfig(object):
             impl.load_weights(os.path.join(os.path.dirname(os.path.abspath(self.path)), init) if not os.path.isabs(init) else init)
         if world > 1:
             impl.set_data_parallel(distributed.GradReducer())
-        H, W = int(self.shape[0]), int(self.shape[1])
+        H, W = impl.H, impl.W                                  # = shape, or shape / crops
         feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state * 7919 + fold * 101 + si,
                               classes=self.classes)
         cbs = stage.callbacks()

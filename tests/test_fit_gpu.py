@@ -159,3 +159,32 @@ def test_three_class_softmax_yaml_fits(tmp_path):
     # (no accuracy bar on predict(): after 8 optimizer steps the BatchNormalization moving statistics, momentum 0.99,
     #  are still ~92 % initial values - inference-phase outputs of so short a run are not meaningful, as in Keras)
     assert float(rows[-1]["iou"]) > float(rows[0]["iou"])       # the training-phase metric improves
+
+
+def test_crops_yaml_trains_on_cells_and_assembles_predictions(tmp_path):
+    """`crops: 2` (README.md:476-491): the network is built for shape / 2, trains on the 4 cells of every image, and
+    prediction splits, predicts and re-assembles transparently at the original size."""
+    from PIL import Image
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    img_dir, msk_dir = make_dataset(str(tmp_path))
+    cfg_path = str(tmp_path / "crops.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Unet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid", "crops": 2,
+                        "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.002, "batch": 4, "folds_count": 2,
+                        "loss": "binary_crossentropy+1.0*dice_loss", "metrics": ["dice"], "primary_metric": "val_dice",
+                        "stages": [{"epochs": 3}]}, f)
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
+    assert len(out) == 1
+    m = cfg.load_model(0, 0)
+    assert (m.impl.H, m.impl.W) == (64, 64)
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        rows = list(csv.DictReader(f))
+    assert len(rows) == 3 and np.isfinite(float(rows[-1]["loss"]))
+    dst = str(tmp_path / "pred")
+    cfg.predict_to_directory(img_dir, dst, fold=0, stage=0)
+    p = np.asarray(Image.open(os.path.join(dst, "s03.png")))
+    assert p.shape == (128, 128) and p.dtype == np.uint8
+    sheet = Image.open(os.path.join(str(tmp_path), "examples", "0", "0", "t_epoch_2.0.jpg"))
+    assert sheet.size[0] == 3 * 64                                   # example sheets show the cells the model sees

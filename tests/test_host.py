@@ -191,6 +191,28 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
 
 
+def test_crops_dataset_splits_items_into_cells():
+    """`crops: N` (README.md:476-491): N x N cells per item, row-major, boundaries floor(k * size / N); the cells tile the image."""
+    from segmentation_pipeline.impl.datasets import PredictionItem
+
+    class DS(object):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            x = np.arange(7 * 10 * 3, dtype=np.uint8).reshape(7, 10, 3) + i
+            y = np.zeros((7, 10, 1), np.uint8); y[5:, 7:] = 1
+            return PredictionItem("im%d" % i, x, y)
+
+    cd = pipeline.CropsDataSet(DS(), 3)
+    assert len(cd) == 18 and pipeline.crop_bounds(7, 3) == [0, 2, 4, 7] and pipeline.crop_bounds(10, 3) == [0, 3, 6, 10]
+    it = cd[9 + 5]                                                   # base item 1, cell (row 1, col 2)
+    assert it.id == "im1.5" and it.x.shape == (2, 4, 3) and np.array_equal(it.x, DS()[1].x[2:4, 6:10]) and it.y.shape == (2, 4, 1)
+    rows = [np.concatenate([cd[r * 3 + c].x for c in range(3)], axis=1) for r in range(3)]
+    assert np.array_equal(np.concatenate(rows, axis=0), DS()[0].x)
+    assert [cd.isPositive(k) for k in range(9)] == [False] * 8 + [True]
+
+
 def test_lr_finder_schedule_and_stop_rule():
     f = pipeline.LRFinder(1e-5, 1.0, 100)
     assert abs(1e-5 * f.mult ** 100 - 1.0) < 1e-9                       # geometric sweep start_lr -> end_lr over the batches
