@@ -292,6 +292,42 @@ int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, floa
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * DeepLabV3+ (the in-tree model, segmentation_pipeline/impl/deeplab/model.py) - the ops nothing else needs.
+ *
+ * Depthwise convolution (DepthwiseConv2D, model.py:136, 255-259): x [N,H,W,C] dtype, w fp32 [k][k][C] (Keras'
+ * (kh,kw,C,1) kernel as stored), explicit top/left padding (TF 'same' is bottom/right heavy), dilation; C % 4 == 0.
+ * The weight gradient needs stp_dwconv_wgrad_workspace_bytes(C, k) of workspace (two-stage fixed-order reduction). */
+int stp_dwconv(const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+               int32_t pad_t, int32_t pad_l, int32_t dilation, int32_t Ho, int32_t Wo, int32_t dtype, void* stream);
+int stp_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
+                     int32_t stride, int32_t pad_t, int32_t pad_l, int32_t dilation, int32_t Ho, int32_t Wo, int32_t dtype,
+                     int32_t accumulate, void* stream);
+size_t stp_dwconv_wgrad_workspace_bytes(int32_t C, int32_t k);
+int stp_dwconv_wgrad(const void* x, const void* dy, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
+                     int32_t stride, int32_t pad_t, int32_t pad_l, int32_t dilation, int32_t Ho, int32_t Wo, int32_t dtype,
+                     int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* tf.image.resize_bilinear(align_corners=True) to any output size (BilinearUpsampling, model.py:94-100) and its gradient
+ * (fixed-order gather).  Dense [N,H,W,C] tensors, any C. */
+int stp_resize_bilinear_ac(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                           int32_t dtype, void* stream);
+int stp_resize_bilinear_ac_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                               int32_t dtype, int32_t accumulate, void* stream);
+/* Inverted dropout (model.py:461): y = mask * x / (1 - rate), mask = counter-based hash of (state[0], salt, index) - the same
+ * call with dy gives the gradient; stp_counter_tick advances state[0] (int32 on the device) once per step, so a hipGraph
+ * replay draws a fresh mask.  x == y allowed. */
+int stp_counter_tick(int32_t* state, void* stream);
+int stp_dropout(const void* x, void* y, int64_t count, float rate, const int32_t* state, uint32_t salt, int32_t dtype, void* stream);
+/* Activation('sigmoid') carried by the last convolution (model.py:485) as a tensor op on the first `channels` columns of
+ * [rows][ld] tensors, and dz = dp * p * (1 - p) over [rows][ldg] gradients (padding columns written as 0). */
+int stp_sigmoid_act(const void* z, void* p, int64_t rows, int32_t channels, int32_t ldz, int32_t ldp, int32_t dtype, void* stream);
+int stp_sigmoid_act_bwd(const void* p, const void* dp, void* dz, int64_t rows, int32_t channels, int32_t ldp, int32_t ldg,
+                        int32_t dtype, void* stream);
+/* Loss on PROBABILITIES (the model upsamples sigmoid outputs, model.py:485-486): same scalars as stp_sigmoid_bce_dice,
+ * gradient w.r.t. the probabilities into column 0 of dprobs [count][dl_channels].  workspace >= stp_loss_workspace_bytes(). */
+int stp_prob_bce_dice(const void* probs, const uint8_t* target, int64_t count, int32_t dtype, float w_bce, float w_dice,
+                      float* scalars, void* dprobs, int32_t dl_channels, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * On-device augmentation (replaces the imgaug worker processes, schemas/augmenters.raml:43-133).
  * One fused pass per batch: inverse affine warp (flips, Affine, crop / pad augmenters and the final Resize composed on
  * the host into a 2x3 matrix per sample), bilinear for the image (constant 0 border, result rounded to uint8 like

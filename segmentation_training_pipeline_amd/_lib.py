@@ -89,6 +89,17 @@ SIGNATURES = {
     "stp_rmsprop": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, f32, vp]),
     "stp_nadam": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, vp, vp, f32, vp]),
     "stp_grad_global_scale": (i32, [vp, i64, f32, f32, vp, vp, sz, vp]),
+    "stp_dwconv": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_dwconv_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_dwconv_wgrad_workspace_bytes": (sz, [i32, i32]),
+    "stp_dwconv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "stp_resize_bilinear_ac": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_resize_bilinear_ac_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_counter_tick": (i32, [vp, vp]),
+    "stp_dropout": (i32, [vp, vp, i64, f32, vp, C.c_uint32, i32, vp]),
+    "stp_sigmoid_act": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
+    "stp_sigmoid_act_bwd": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "stp_prob_bce_dice": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i32, vp, sz, vp]),
     "stp_augment_u8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_filter_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "stp_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
     v.y = bn_affine(v.y, ss[c + 1], ss[C + c + 1]);
     v.z = bn_affine(v.z, ss[c + 2], ss[C + c + 2]);
     v.w = bn_affine(v.w, ss[c + 3], ss[C + c + 3]);
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (relu) { v.x = bn_act(v.x, relu); v.y = bn_act(v.y, relu); v.z = bn_act(v.z, relu); v.w = bn_act(v.w, relu); }
     store4(y + i * 4, v);
   }
 }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_apply_u8_kernel(const uint8_t* __restr
     f32x4 v;
     for (int c = 0; c < 4; ++c) {
       float t = c < C ? bn_affine((float)x[r * C + c], sc[c], sh[c]) : pad_value;
-      if (relu && c < C) t = fmaxf(t, 0.f);
+      if (relu && c < C) t = bn_act(t, relu);
       v[c] = t;
     }
     store4(y + r * 4, v);
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
         ldv<T, V>(dy + (r + rowLanes) * C + cb, g1);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          if (relu && !(bn_affine(x0[e], sc[e], sh[e]) > 0.f)) g0[e] = 0.f;
-          if (relu && !(bn_affine(x1[e], sc[e], sh[e]) > 0.f)) g1[e] = 0.f;
+          if (!bn_act_on(bn_affine(x0[e], sc[e], sh[e]), relu)) g0[e] = 0.f;
+          if (!bn_act_on(bn_affine(x1[e], sc[e], sh[e]), relu)) g1[e] = 0.f;
           s[e] += g0[e] + g1[e];
           q[e] += g0[e] * ((x0[e] - mu[e]) * rs[e]) + g1[e] * ((x1[e] - mu[e]) * rs[e]);
         }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
         ldv<T, V>(dy + r * C + cb, g0);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          if (relu && !(bn_affine(x0[e], sc[e], sh[e]) > 0.f)) g0[e] = 0.f;
+          if (!bn_act_on(bn_affine(x0[e], sc[e], sh[e]), relu)) g0[e] = 0.f;
           s[e] += g0[e];
           q[e] += g0[e] * ((x0[e] - mu[e]) * rs[e]);
         }
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     ldv<T, V>(dy + i * V, g);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      if (relu && !(bn_affine(xv[e], ss[2 * C + c + e], ss[3 * C + c + e]) > 0.f)) g[e] = 0.f;
+      if (!bn_act_on(bn_affine(xv[e], ss[2 * C + c + e], ss[3 * C + c + e]), relu)) g[e] = 0.f;
       const float xh = (xv[e] - ss[c + e]) * ss[C + c + e];
       o[e] = ss[2 * C + c + e] * (g[e] - ss[4 * C + c + e] - xh * ss[5 * C + c + e]);
     }

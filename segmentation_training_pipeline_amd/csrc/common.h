@@ -115,6 +115,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // x*scale + shift exactly as the BatchNormalization forward computed it: the backward passes re-derive the
 // ReLU mask from this expression, so every user must round identically (single fma).
 __device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return fmaf(x, scale, shift); }
+// activation fused behind a BatchNormalization: 0 none, 1 ReLU, 2 ReLU6 (K.relu(x, max_value=6): MobileNetV2 blocks).
+// bn_act_on = "the gradient passes" (strictly inside the linear range, as TF's relu6 gradient does)
+__device__ __forceinline__ float bn_act(float v, int relu) { return relu == 0 ? v : (relu == 1 ? fmaxf(v, 0.f) : fminf(fmaxf(v, 0.f), 6.f)); }
+__device__ __forceinline__ bool bn_act_on(float v, int relu) { return relu == 0 || (v > 0.f && (relu == 1 || v < 6.f)); }
 
 // BatchNormalization-backward partial sums fused into the epilogue of the data-gradient convolution that
 // produces dY of the BN output:  g = dY * [relu mask],  sum(g) and sum(g * xhat) per channel, g stored in
@@ -142,7 +146,7 @@ __device__ __forceinline__ f32x4 bnback_apply(const BnBackCh& k, int relu, const
   f32x4 g;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const bool on = !relu || bn_affine(xv[e], k.sc[e], k.sh[e]) > 0.f;
+    const bool on = bn_act_on(bn_affine(xv[e], k.sc[e], k.sh[e]), relu);
     g[e] = on ? dy[e] : 0.f;
     ss[e] += g[e];
     qq[e] += g[e] * ((xv[e] - k.mu[e]) * k.rs[e]);

@@ -559,6 +559,116 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("geom", [(3, 1, 1, 1, 1), (3, 2, 0, 0, 1), (3, 1, 2, 2, 2), (3, 1, 4, 4, 4), (3, 2, 1, 1, 1)])
+def test_depthwise_convolution_forward_and_gradients(ops, dtype, geom):
+    """stp_dwconv / _dgrad / _wgrad (DeepLab model.py:136, 255-259): stride, dilation and explicit top/left padding (TF 'same'
+    with stride 2 pads bottom/right only) against torch's grouped convolution and autograd."""
+    from segmentation_training_pipeline_amd import _lib
+    k, stride, pt, pl, dil = geom
+    rng = np.random.RandomState(51)
+    n, h, w, c = 2, 12, 10, 24
+    keff = (k - 1) * dil + 1
+    ho, wo = -(-h // stride), -(-w // stride)                               # 'same'
+    pb, pr = max((ho - 1) * stride + keff - h - pt, 0), max((wo - 1) * stride + keff - w - pl, 0)
+    x = q(rng.randn(n, h, w, c), dtype)
+    wt = rng.randn(k, k, c).astype(np.float32) / 3
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wtt = torch.from_numpy(wt).permute(2, 0, 1)[:, None].clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, (pl, pr, pt, pb)), wtt, stride=stride, dilation=dil, groups=c)
+    assert ref.shape[2:] == (ho, wo)
+    gy = q(rng.randn(n, ho, wo, c), dtype)
+    ref.backward(torch.from_numpy(gy).permute(0, 3, 1, 2))
+    xd, wd, gyd = dev(x, dtype), keep(torch.from_numpy(wt).to(DEV)), dev(gy, dtype)
+    y = torch.empty((n, ho, wo, c), dtype=TD[dtype], device=DEV)
+    geo = (n, h, w, c, k, stride, pt, pl, dil, ho, wo, ops.dt(xd))
+    _lib.call("stp_dwconv", ops.ptr(xd), ops.ptr(wd), ops.ptr(y), *geo, ops.stream())
+    np.testing.assert_allclose(host(y), ref.detach().permute(0, 2, 3, 1).numpy(), atol=tol(host(y), dtype, 1.0))
+    dx = torch.empty_like(xd)
+    _lib.call("stp_dwconv_dgrad", ops.ptr(gyd), ops.ptr(wd), ops.ptr(dx), *geo, 0, ops.stream())
+    np.testing.assert_allclose(host(dx), xt.grad.permute(0, 2, 3, 1).numpy(), atol=tol(xt.grad.numpy(), dtype, 1.0))
+    dw = torch.full((k, k, c), float("nan"), device=DEV)
+    ws = torch.empty(int(_lib.load().stp_dwconv_wgrad_workspace_bytes(c, k)) // 4, device=DEV)
+    _lib.call("stp_dwconv_wgrad", ops.ptr(xd), ops.ptr(gyd), ops.ptr(dw), *geo, 0, ops.ptr(ws), ws.numel() * 4, ops.stream())
+    refw = wtt.grad[:, 0].permute(1, 2, 0).numpy()
+    np.testing.assert_allclose(host(dw), refw, atol=(2e-4 if dtype == "fp32" else 2e-3) * np.abs(refw).max() + 1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("sizes", [((5, 7), (40, 56)), ((1, 1), (6, 9)), ((6, 6), (6, 6)), ((4, 3), (9, 5))])
+def test_align_corners_bilinear_dropout_sigmoid_and_probability_loss(ops, dtype, sizes):
+    """The remaining DeepLab ops: resize_bilinear(align_corners=True) fwd/bwd vs torch, inverted dropout (mask reproducible,
+    forward == backward map, fresh per tick), sigmoid activation + gradient, and the loss on probabilities."""
+    from segmentation_training_pipeline_amd import _lib
+    (h, w), (ho, wo) = sizes
+    rng = np.random.RandomState(52)
+    n, c = 2, 5
+    x = q(rng.randn(n, h, w, c), dtype)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(xt, size=(ho, wo), mode="bilinear", align_corners=True)
+    gy = q(rng.randn(n, ho, wo, c), dtype)
+    ref.backward(torch.from_numpy(gy).permute(0, 3, 1, 2))
+    xd = dev(x, dtype)
+    y = torch.empty((n, ho, wo, c), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_resize_bilinear_ac", ops.ptr(xd), ops.ptr(y), n, h, w, c, ho, wo, ops.dt(xd), ops.stream())
+    np.testing.assert_allclose(host(y), ref.detach().permute(0, 2, 3, 1).numpy(), atol=tol(x, dtype, 0.5))
+    dx = torch.empty_like(xd)
+    _lib.call("stp_resize_bilinear_ac_bwd", ops.ptr(dev(gy, dtype)), ops.ptr(dx), n, h, w, c, ho, wo, ops.dt(xd), 0, ops.stream())
+    want = xt.grad.permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
+    # dropout
+    cnt = n * ho * wo * c
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    yd = dev(gy, dtype)
+    o1, o2 = torch.empty_like(yd), torch.empty_like(yd)
+    _lib.call("stp_dropout", ops.ptr(yd), ops.ptr(o1), cnt, 0.25, ops.ptr(state), 7, ops.dt(yd), ops.stream())
+    _lib.call("stp_dropout", ops.ptr(yd), ops.ptr(o2), cnt, 0.25, ops.ptr(state), 7, ops.dt(yd), ops.stream())
+    a1 = host(o1)
+    np.testing.assert_array_equal(a1, host(o2))                                # same step, same salt: same mask
+    kept = a1 != 0
+    np.testing.assert_allclose(a1[kept], (gy / 0.75)[kept], rtol=1e-2 if dtype == "bf16" else 1e-6)
+    _lib.call("stp_counter_tick", ops.ptr(state), ops.stream())
+    _lib.call("stp_dropout", ops.ptr(yd), ops.ptr(o2), cnt, 0.25, ops.ptr(state), 7, ops.dt(yd), ops.stream())
+    assert int(state[0].item()) == 1 and (cnt < 200 or not np.array_equal(host(o2) != 0, kept))
+    if cnt > 2000:
+        assert 0.18 < 1 - kept.mean() < 0.32
+    # sigmoid activation on column 0 of a padded tensor and its gradient
+    rows = n * ho * wo
+    z = q(rng.randn(rows, 8), dtype)
+    p = torch.zeros((rows, 1), dtype=TD[dtype], device=DEV)
+    zd = dev(z, dtype)
+    _lib.call("stp_sigmoid_act", ops.ptr(zd), ops.ptr(p), rows, 1, 8, 1, ops.dt(zd), ops.stream())
+    pr = 1 / (1 + np.exp(-z[:, :1].astype(np.float64)))
+    np.testing.assert_allclose(host(p), pr, atol=1e-6 if dtype == "fp32" else 4e-3)
+    dp = q(rng.randn(rows, 8), dtype)
+    dz = torch.empty((rows, 8), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_sigmoid_act_bwd", ops.ptr(p), ops.ptr(dev(dp, dtype)), ops.ptr(dz), rows, 1, 1, 8, ops.dt(zd), ops.stream())
+    got = host(dz)
+    np.testing.assert_allclose(got[:, 0], dp[:, 0] * host(p)[:, 0] * (1 - host(p)[:, 0]), atol=tol(dp, dtype, 0.5))
+    np.testing.assert_array_equal(got[:, 1:], 0)
+    # loss on probabilities
+    pp = q(np.clip(rng.rand(rows), 0.0, 1.0), dtype)
+    pp[:3] = q(np.array([0.0, 1.0, 0.4]), dtype)     # (not exactly 0.5: torch's max(z,0)/|z| formulation has a kink at z = 0)
+    yy = (rng.rand(rows) < 0.3).astype(np.uint8)
+    pt = torch.from_numpy(pp.astype(np.float32)).requires_grad_(True)
+    yt = torch.from_numpy(yy.astype(np.float32))
+    loss = olosses.composite_loss("binary_crossentropy+0.5*dice_loss", yt, pt)
+    loss.backward()
+    scal = torch.empty(10, device=DEV)
+    dl = torch.full((rows, 8), float("nan"), dtype=TD[dtype], device=DEV)
+    ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
+    _lib.call("stp_prob_bce_dice", ops.ptr(dev(pp, dtype)), ops.ptr(keep(torch.from_numpy(yy).to(DEV))), rows, ops.dt(zd), 1.0, 0.5,
+              ops.ptr(scal), ops.ptr(dl), 8, ops.ptr(ws), ws.numel() * 4, ops.stream())
+    sc = host(scal)
+    assert abs(sc[0] - float(loss.detach())) < 2e-5 * max(1.0, abs(float(loss.detach())))
+    assert abs(sc[2] - float(olosses.dice_loss(yt, pt.detach()))) < 1e-5
+    g = host(dl)
+    refg = pt.grad.numpy()
+    inr = (pp >= 1e-7) & (pp <= 1 - 1e-7) & (pp != 0.5)       # bf16 rounds some samples onto the kink as well
+    np.testing.assert_allclose(g[inr, 0], refg[inr], rtol=2e-2 if dtype == "bf16" else 2e-4, atol=1e-6)
+    np.testing.assert_array_equal(g[:, 1:], 0)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     rng = np.random.RandomState(13)
     count = 2 * 48 * 48
