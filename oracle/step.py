@@ -40,9 +40,13 @@ class OracleTrainer:
         self.clipnorm, self.clipvalue = clipnorm, clipvalue
         self.decoder_filters = tuple(decoder_filters)
         self.architecture = architecture
+        self.steps_done = 0              # mirrors the device step counter that seeds DeepLab's dropout mask
         self.activation = activation     # "sigmoid": y [N,H,W,1] in {0,1};  "softmax": y [N,H,W,1] class index -> one-hot
 
     def _forward(self, P, x, training, taps):
+        if self.architecture == "DeepLabV3":      # returns PROBABILITIES (the activation is inside the model, deeplab.py)
+            from . import deeplab
+            return deeplab.deeplab_forward(P, x, training=training, taps=taps, step=self.steps_done + 1)
         if self.architecture == "Linknet":
             return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
         if self.architecture == "PSPNet":
@@ -64,7 +68,9 @@ class OracleTrainer:
         x = torch.from_numpy(np.ascontiguousarray(x_nhwc, dtype=np.float32))
         y = torch.from_numpy(np.ascontiguousarray(y_nhwc, dtype=np.float32))
         logits, bn_updates = self._forward(P, x, True, taps)
-        if self.activation == "softmax":
+        if self.architecture == "DeepLabV3":
+            p = logits
+        elif self.activation == "softmax":
             p = torch.softmax(logits, dim=-1)
             y = torch.nn.functional.one_hot(y[..., 0].long(), logits.shape[-1]).to(torch.float32)
         else:
@@ -81,6 +87,7 @@ class OracleTrainer:
             "binary_accuracy": float(losses.binary_accuracy(y, p.detach())),
             "grads": grads,
         }
+        self.steps_done += 1
         if apply:
             g = optim.clip_grads(grads, self.clipnorm, self.clipvalue)
             self.opt.step(self.P, g)

@@ -32,7 +32,9 @@ unsupported_objects = ("iot", "lovasz_loss", "iou_loss", "jaccard_loss", "focal_
 extra_train = {}
 dataset_augmenters = {}
 
-custom_models = {}          # user-registered: name -> fn(**arch_kwargs) -> model  (reference :31-33, README.md:636-643)
+# name -> fn(**arch_kwargs) -> model; the reference ships one entry, its in-tree DeepLabV3+ (reference :31-33), and lets users
+# add more (README.md:636-643)
+custom_models = {"DeepLabV3": _models.Deeplabv3}
 
 
 def ansemblePredictions(sourceFolder, folders, cb, data, weights=None):

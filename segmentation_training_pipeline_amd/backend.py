@@ -47,7 +47,8 @@ class HipSegModel(object):
                  opt_kwargs=None, seed=42, decoder_block_type="upsampling"):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
-        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet"):   # VGG: U-Net only
+        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet") \
+                or ((backbone == "mobilenetv2") != (architecture == "DeepLabV3")):     # VGG: U-Net only; MobileNetV2: DeepLabV3 only
             raise ValueError("Unknown backbone")
         if not ((classes == 1 and activation in ("sigmoid", None)) or (2 <= classes <= 32 and activation == "softmax")):
             raise ValueError("the HIP backend trains 1-class sigmoid heads and 2..32-class softmax heads")
@@ -107,7 +108,7 @@ class HipSegModel(object):
             kw = {"decoder_block_type": self.decoder_block_type} if self.architecture == "Unet" else {}
             logits = nets.NETWORKS[self.architecture](plan, self.backbone, self.H, self.W, self.in_ch, self.classes,
                                                       self.decoder_filters, self.loss_w, with_loss=with_loss, **kw)
-            if not with_loss:
+            if not with_loss and self.architecture != "DeepLabV3":      # (DeepLab's graph ends in probabilities itself)
                 (plan.sigmoid_out if self.classes == 1 else plan.softmax_out)(logits)
             return logits
         return fn
@@ -171,7 +172,7 @@ class HipSegModel(object):
 
     def _mutable_state(self):
         p = self.plan
-        return [t for t in (p.P, p.S, self.opt_state, self.opt_fstate, self.m, self.v, self.vel, self.gscale) if t is not None]
+        return [t for t in (p.P, p.S, self.opt_state, self.opt_fstate, self.m, self.v, self.vel, self.gscale, p.step_state) if t is not None]
 
     # ------------------------------------------------------------------ weights
     def init_weights(self, seed=42):
@@ -185,6 +186,10 @@ class HipSegModel(object):
                 enc = any(name.startswith(pfx) for pfx in nets.ENCODER_PREFIXES)
                 limit = np.sqrt(6.0 / (kh * kw * ci)) if enc else np.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
                 w[name] = rng.uniform(-limit, limit, size=(kh, kw, ci, co) if info.kind == "kernel" else (kh, kw, co, ci)).astype(np.float32)
+            elif info.kind == "dw":
+                k, _, cch = info.shape
+                lim = np.sqrt(6.0 / (k * k * cch + k * k))
+                w[name] = rng.uniform(-lim, lim, size=info.shape + (1,)).astype(np.float32)
             elif info.kind == "gamma":
                 w[name] = np.ones(info.shape, np.float32)
             else:
@@ -205,6 +210,10 @@ class HipSegModel(object):
                     if a.shape != (info.shape[1], info.shape[2], info.shape[3], info.shape[0]):
                         raise ValueError("%s: kernel shape %s does not match %s (HWIO)" % (name, a.shape, info.shape))
                     a = a.transpose(3, 0, 1, 2)
+                elif info.kind == "dw":           # DepthwiseConv2D: Keras (kh, kw, C, 1) == the stored [kh][kw][C]
+                    if a.shape not in (info.shape, info.shape + (1,)):
+                        raise ValueError("%s: depthwise kernel shape %s does not match %s" % (name, a.shape, info.shape + (1,)))
+                    a = a.reshape(info.shape)
                 elif info.kind == "tkernel":      # Conv2DTranspose: Keras (kh, kw, out, in) -> spatially flipped OHWI
                     if a.shape != (info.shape[1], info.shape[2], info.shape[0], info.shape[3]):
                         raise ValueError("%s: kernel shape %s does not match %s (kh,kw,out,in)" % (name, a.shape, info.shape))
@@ -228,6 +237,8 @@ class HipSegModel(object):
                 out[name] = a.transpose(1, 2, 3, 0).copy()
             elif info.kind == "tkernel":
                 out[name] = a.transpose(1, 2, 0, 3)[::-1, ::-1].copy()
+            elif info.kind == "dw":
+                out[name] = a.reshape(info.shape + (1,)).copy()
             else:
                 out[name] = a.copy()
         return out
@@ -369,7 +380,8 @@ class HipSegModel(object):
         return out
 
     def logits(self):
-        t = self.plan.tensors.get("logits", self.plan.tensors["final_conv"])      # FPN: the head conv is resized x4
+        ts = self.plan.tensors                     # FPN / PSPNet / DeepLab: the head output is a resized tensor named "logits"
+        t = ts["logits"] if "logits" in ts else ts["final_conv"]
         return t.buf.to(torch.float32).cpu().numpy()
 
     def activation(self, name):

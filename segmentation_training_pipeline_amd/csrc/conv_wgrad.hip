@@ -571,7 +571,10 @@ template <typename T, bool C4>
 static int launch_wgrad_tile(WgradArgs& a, const WgradPlan& w, bool dma_ok, int variant, hipStream_t s) {
   if constexpr (C4) {
     switch (w.tile) {
+      case 1: return launch_wgrad<T, 128, 128, 2, 2, true>(a, w.splits, s);
       case 2: return launch_wgrad<T, 64, 128, 1, 4, true>(a, w.splits, s);
+      case 3: return launch_wgrad<T, 32, 256, 1, 4, true>(a, w.splits, s);
+      case 4: return launch_wgrad<T, 16, 256, 1, 4, true>(a, w.splits, s);
       default: return STP_E_BADARG;
     }
   } else {

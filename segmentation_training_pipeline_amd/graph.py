@@ -95,6 +95,8 @@ class Plan(object):
         self.fold_upsample_grad = os.environ.get("STP_FOLD_UPSAMPLE_GRAD", "1") != "0"
         self._side = None
         self._side_reads = set()
+        self._dw_ws_bytes = 0
+        self.step_state = None
         self.loss_scalars = None
         self.inputs = {}
 
@@ -119,6 +121,7 @@ class Plan(object):
         self.ws_wgrad = torch.empty(max(self._wg_ws_bytes // 4, 4) + 4, dtype=torch.float32, device=self.device)
         self.ws_bn = torch.empty(ops.bn_workspace_bytes(_rup(self._bn_ws_c, 4)) // 4, dtype=torch.float32, device=self.device)
         self.ws_loss = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
+        self.ws_dw = torch.empty(max(self._dw_ws_bytes // 4, 4), dtype=torch.float32, device=self.device)
         self.dry = False
         self._tape = []
         self._prep_layers = []
@@ -287,8 +290,11 @@ class Plan(object):
                    zero.data_ptr(), one.data_ptr(), None, None, 0, 0.0)
         return out
 
-    def bn(self, name, x, eps, relu=True, scale=True):
+    def bn(self, name, x, eps, relu=True, scale=True, momentum=None):
+        """``relu``: False/0 none, True/1 ReLU, 2 ReLU6 (MobileNetV2).  ``momentum``: Keras BatchNormalization momentum (0.99)."""
         Cn = x.C
+        relu = int(relu)
+        momentum = self.bn_momentum if momentum is None else float(momentum)
         gamma = self.param(name + "/gamma", (Cn,), "gamma") if scale else None
         beta = self.param(name + "/beta", (Cn,), "beta")
         mm = self.state(name + "/moving_mean", Cn, 0.0)
@@ -309,10 +315,10 @@ class Plan(object):
         if fused is not None:
             st, cp = fused
             tiles = int(self.lib.stp_conv2d_stats_floats(C.byref(cp))) // (2 * Cn)
-            self._emit(self.fwd, "stp_bn_finalize", st.data_ptr(), tiles, x.rows, Cn, eps, self.bn_momentum, mean.data_ptr(),
+            self._emit(self.fwd, "stp_bn_finalize", st.data_ptr(), tiles, x.rows, Cn, eps, momentum, mean.data_ptr(),
                        rstd.data_ptr(), self._sptr(mm), self._sptr(mv))
         else:
-            self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), self.cdt, x.rows, Cn, eps, self.bn_momentum, mean.data_ptr(),
+            self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), self.cdt, x.rows, Cn, eps, momentum, mean.data_ptr(),
                        rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
         self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
                    mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu), 0.0)
@@ -346,7 +352,7 @@ class Plan(object):
         return out
 
     def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False,
-             transpose=False, relu=False):
+             transpose=False, relu=False, same_tf=False):
         """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
         ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add().
 
@@ -370,6 +376,13 @@ class Plan(object):
         if src1 is not None and (src1.H, src1.W) != (Hv, Wv):
             raise StpShapeError("%s: skip tensor is %dx%d, expected %dx%d" % (name, src1.H, src1.W, Hv, Wv))
         Ho, Wo = (Hv + 2 * pad - k) // stride + 1, (Wv + 2 * pad - k) // stride + 1
+        if same_tf:
+            # TF / Keras padding='same': ceil(size / stride) outputs, the odd padding pixel goes to the bottom / right.  The
+            # kernels take the top/left padding and the output size; taps past the far edge are out of bounds = zero.
+            Ho, Wo = -(-Hv // stride), -(-Wv // stride)
+            pad = max((Ho - 1) * stride + k - Hv, 0) // 2
+            if max((Wo - 1) * stride + k - Wv, 0) // 2 != pad:
+                raise StpShapeError("%s: 'same' padding differs between height and width" % name)
         KWp = k + (k & 1) if stem else k
         Cin_master = real_c0 + C1
         Cinp = C0 + C1
@@ -638,6 +651,135 @@ class Plan(object):
 
         self._tape.append(back)
         return out
+
+    def dwconv(self, name, x, k=3, stride=1, dilation=1):
+        """Keras ``DepthwiseConv2D(k, strides, padding='same', dilation_rate, use_bias=False)`` (DeepLab model.py:136, 255-259).
+        The fp32 master kernel [k][k][C] is read directly by the kernels (kind "dw": Keras' (kh,kw,C,1) layout as stored)."""
+        Cn = x.C
+        if Cn % 4:
+            raise StpShapeError("%s: depthwise convolution needs a multiple of 4 channels" % name)
+        keff = (k - 1) * dilation + 1
+        Ho, Wo = -(-x.H // stride), -(-x.W // stride)
+        pt, pl = max((Ho - 1) * stride + keff - x.H, 0) // 2, max((Wo - 1) * stride + keff - x.W, 0) // 2
+        w = self.param(name + "/depthwise_kernel", (k, k, Cn), "dw")
+        out = self._new(name, Ho, Wo, Cn, x.needs_grad or w.trainable)
+        self._use(x)
+        self._dw_ws_bytes = max(self._dw_ws_bytes, int(self.lib.stp_dwconv_wgrad_workspace_bytes(Cn, k)))
+        if self.dry:
+            return out
+        geo = (self.N, x.H, x.W, Cn, k, stride, pt, pl, dilation, Ho, Wo, self.cdt)
+        self._emit(self.fwd, "stp_dwconv", x.buf.data_ptr(), self._pptr(w), out.buf.data_ptr(), *geo)
+        if not self.training:
+            return out
+
+        def back():
+            if not out.needs_grad or not out.grad_ready:
+                return
+            if w.trainable:
+                self._emit(self.bwd, "stp_dwconv_wgrad", x.buf.data_ptr(), out.grad.data_ptr(), self._gptr(w), *geo, 0,
+                           self.ws_dw.data_ptr(), self.ws_dw.numel() * 4)
+            if x.needs_grad:
+                self._emit(self.bwd, "stp_dwconv_dgrad", out.grad.data_ptr(), self._pptr(w), self._gradbuf(x).data_ptr(), *geo,
+                           int(x.grad_ready))
+                x.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
+    def dropout(self, name, x, rate, salt):
+        """Keras ``Dropout(rate)``: training = inverted dropout in place (mask = hash of the device step counter, which the
+        first dropout of the plan ticks once per forward); inference = identity."""
+        if not self.training:
+            return x
+        out = DT(name, self.N, x.H, x.W, x.C, x.buf, x.needs_grad)
+        out.gradC = x.gradC
+        self.tensors[name] = out
+        self._use(x)
+        if self.dry:
+            return out
+        if self.step_state is None:
+            self.step_state = torch.zeros(2, dtype=torch.int32, device=self.device)
+            self._keep.append(self.step_state)
+            self._emit(self.fwd, "stp_counter_tick", self.step_state.data_ptr())
+        cnt = x.rows * x.C
+        self._emit(self.fwd, "stp_dropout", x.buf.data_ptr(), x.buf.data_ptr(), cnt, float(rate), self.step_state.data_ptr(), int(salt), self.cdt)
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            dy = out.grad
+            self._emit(self.bwd, "stp_dropout", dy.data_ptr(), dy.data_ptr(), x.rows * out.gradC, float(rate), self.step_state.data_ptr(),
+                       int(salt), self.cdt)
+            x.grad, x.grad_ready = dy, True
+
+        self._tape.append(back)
+        return out
+
+    def resize_ac(self, name, x, Ho, Wo):
+        """``BilinearUpsampling`` (DeepLab model.py:56-100): tf.image.resize_bilinear(align_corners=True) to (Ho, Wo)."""
+        out = self._new(name, Ho, Wo, x.C, x.needs_grad)
+        out.gradC = x.gradC
+        self._use(x)
+        if self.dry:
+            return out
+        self._emit(self.fwd, "stp_resize_bilinear_ac", x.buf.data_ptr(), out.buf.data_ptr(), self.N, x.H, x.W, x.C, Ho, Wo, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            self._emit(self.bwd, "stp_resize_bilinear_ac_bwd", out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.gradC,
+                       Ho, Wo, self.cdt, int(x.grad_ready))
+            x.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
+    def sigmoid_act(self, name, z):
+        """Activation('sigmoid') as a layer (DeepLab's last convolution carries it, model.py:485)."""
+        out = self._new(name, z.H, z.W, z.C, z.needs_grad)
+        out.gradC = z.gradC
+        self._use(z)
+        if self.dry:
+            return out
+        self._emit(self.fwd, "stp_sigmoid_act", z.buf.data_ptr(), out.buf.data_ptr(), z.rows, z.C, z.C, z.C, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not (z.needs_grad and out.grad_ready):
+                return
+            self._emit(self.bwd, "stp_sigmoid_act_bwd", out.buf.data_ptr(), out.grad.data_ptr(), self._gradbuf(z).data_ptr(), z.rows, z.C,
+                       z.C, z.gradC, self.cdt)
+            z.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
+    def prob_loss(self, probs, target, w_bce, w_dice):
+        """w_bce*binary_crossentropy + w_dice*dice_loss on probabilities (1 class); seeds the backward pass."""
+        if probs.C != 1:
+            raise StpShapeError("the probability loss expects one class")
+        if self.dry:
+            return
+        self.loss_scalars = self._alloc((12,), torch.float32)
+        dp = self._gradbuf(probs) if self.training else None
+        self._emit(self.fwd, "stp_prob_bce_dice", probs.buf.data_ptr(), target.buf.data_ptr(), probs.rows, self.cdt, float(w_bce),
+                   float(w_dice), self.loss_scalars.data_ptr(), dp.data_ptr() if dp is not None else None, probs.gradC,
+                   self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        probs.grad_ready = self.training
+
+    def probs_out(self, probs):
+        """Inference output when the model itself ends in probabilities: float32 copy."""
+        if self.dry:
+            return None
+        if self.tdt == torch.float32:
+            self.probs = probs.buf                      # already float32
+            return self.probs
+        self.probs = self._alloc((probs.N, probs.H, probs.W, probs.C), torch.float32)
+        self._emit(self.fwd, "stp_cast_bf16_to_f32", probs.buf.data_ptr(), self.probs.data_ptr(), probs.rows * probs.C, 1.0)
+        return self.probs
 
     def avgpool(self, name, x, k):
         """AveragePooling2D(pool_size = strides = k) with exact division (PSPNet pyramid levels)."""

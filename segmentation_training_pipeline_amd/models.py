@@ -120,6 +120,22 @@ def PSPNet(backbone_name="vgg16", input_shape=(384, 384, 3), classes=21, activat
     return SegModel("PSPNet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
 
 
+def Deeplabv3(encoder_weights="pascal_voc", input_tensor=None, input_shape=(512, 512, 3), classes=21, backbone_name="mobilenetv2", OS=16,
+              alpha=1.0, activation=None, freeze_encoder=False):
+    """The reference's in-tree constructor (segmentation_pipeline/impl/deeplab/model.py:281; registered in
+    ``custom_models`` as ``DeepLabV3``, segmentation.py:31-33), with its own argument checks (:317-328)."""
+    if encoder_weights not in ("pascal_voc", None) and not os.path.exists(str(encoder_weights)):
+        raise ValueError("The `encoder_weights` argument should be either `None` (random initialization) or `pascal_voc` "
+                         "(pre-trained on PASCAL VOC)")
+    if backbone_name not in ("xception", "mobilenetv2"):
+        raise ValueError("The `backbone_name` argument should be either `xception`  or `mobilenetv2` ")
+    if backbone_name != "mobilenetv2" or float(alpha) != 1.0:
+        raise ValueError("the HIP DeepLabV3 implements the mobilenetv2 branch with alpha = 1")
+    if activation != "sigmoid" or int(classes) != 1:
+        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head")
+    return SegModel("DeepLabV3", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+
+
 ARCHITECTURES = {"Unet": Unet, "Linknet": Linknet, "FPN": FPN, "PSPNet": PSPNet}
 
 

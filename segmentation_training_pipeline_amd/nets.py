@@ -20,13 +20,13 @@ STAGE_FILTERS = (64, 128, 256, 512)
 BN_EPS_ENCODER = 2e-5
 BN_EPS_DECODER = 1e-3
 
-ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1", "block")
+ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1", "block", "Conv", "expanded_conv")
 VGG_BLOCKS = {"vgg16": (2, 2, 3, 3, 3), "vgg19": (2, 2, 4, 4, 4)}      # keras.applications: 3x3 'same' convs + ReLU per block
 VGG_FILTERS = (64, 128, 256, 512, 512)
 
 
 def known_backbones():
-    return sorted(RESNET_UNITS) + sorted(VGG_BLOCKS)
+    return sorted(RESNET_UNITS) + sorted(VGG_BLOCKS) + ["mobilenetv2"]
 
 
 def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
@@ -198,4 +198,58 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
     return logits
 
 
-NETWORKS = {"Unet": unet_resnet, "Linknet": linknet_resnet, "FPN": fpn_resnet, "PSPNet": pspnet_resnet}
+# (filters, stride, expansion, block_id, skip_connection, rate): segmentation_pipeline/impl/deeplab/model.py:395-431
+MOBILENETV2_BLOCKS = [(16, 1, 1, 0, False, 1), (24, 2, 6, 1, False, 1), (24, 1, 6, 2, True, 1), (32, 2, 6, 3, False, 1), (32, 1, 6, 4, True, 1),
+                      (32, 1, 6, 5, True, 1), (64, 1, 6, 6, False, 1), (64, 1, 6, 7, True, 2), (64, 1, 6, 8, True, 2), (64, 1, 6, 9, True, 2),
+                      (96, 1, 6, 10, False, 2), (96, 1, 6, 11, True, 2), (96, 1, 6, 12, True, 2), (160, 1, 6, 13, False, 2),
+                      (160, 1, 6, 14, True, 4), (160, 1, 6, 15, True, 4), (320, 1, 6, 16, False, 4)]
+DEEPLAB_DROPOUT_SALT = 0x0D0D
+
+
+def deeplab_mobilenetv2(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True):
+    """The reference's in-tree DeepLabV3+ (``segmentation_pipeline/impl/deeplab/model.py:281-519``, registered as
+    ``DeepLabV3`` at ``segmentation.py:31-33``), MobileNetV2 branch (alpha 1, output stride 8):
+    Conv 3x3 s2 + BN + ReLU6 (:383-390); 17 inverted residual blocks = 1x1 expand, depthwise 3x3 (stride / atrous rate), 1x1
+    project, each with BN(eps 1e-3, momentum 0.999) and ReLU6 except after the projection, optional Add (:236-279, :392-431);
+    ASPP: image pooling branch (global average -> 1x1 -> BN -> ReLU -> bilinear back) and 1x1 branch (:438-450), concat, 1x1
+    projection + BN + ReLU + Dropout(0.1) (:456-461); 1x1 convolution to the classes WITH the activation, then align-corners
+    bilinear upsampling of the probabilities to the input size (:485-486).  The loss therefore works on probabilities."""
+    if backbone != "mobilenetv2":
+        raise ValueError("Unknown backbone")        # (the xception branch is not built)
+    if classes != 1:
+        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head")
+    if H % 8 or W % 8 or H != W:
+        raise ValueError("DeepLabV3 (output stride 8) needs a square input divisible by 8")
+    mob = dict(momentum=0.999)
+    img = plan.input_u8("image", H, W, in_ch)
+    x = plan.input_cast("input_cast", img)
+    x = plan.bn("Conv_BN", plan.conv("Conv", x, 32, 3, stride=2, same_tf=True, bn_stats=True), 1e-3, relu=2, **mob)
+    for filters, stride, exp, bid, skip, rate in MOBILENETV2_BLOCKS:
+        pre = "expanded_conv_%d_" % bid if bid else "expanded_conv_"
+        inp = x
+        if bid:
+            x = plan.bn(pre + "expand_BN", plan.conv(pre + "expand", x, exp * x.C, 1, bn_stats=True), 1e-3, relu=2, **mob)
+        x = plan.bn(pre + "depthwise_BN", plan.dwconv(pre + "depthwise", x, 3, stride=stride, dilation=rate), 1e-3, relu=2, **mob)
+        x = plan.bn(pre + "project_BN", plan.conv(pre + "project", x, filters, 1, bn_stats=True), 1e-3, relu=0, **mob)
+        if skip:
+            x = plan.add(pre + "add", x, inp)
+    b4 = plan.avgpool("image_pooling_pool", x, x.H)
+    b4 = plan.bn("image_pooling_BN", plan.conv("image_pooling", b4, 256, 1, bn_stats=True), 1e-5, relu=1)
+    b0 = plan.bn("aspp0_BN", plan.conv("aspp0", x, 256, 1, bn_stats=True), 1e-5, relu=1)
+    # BilinearUpsampling of the 1x1 map is a broadcast under either bilinear convention: the integer-factor resize writes it
+    # straight into its half of the Concatenate
+    cat = plan.concat_resize("aspp_concat", [(b4, x.H), (b0, 1)])
+    y = plan.bn("concat_projection_BN", plan.conv("concat_projection", cat, 256, 1, bn_stats=True), 1e-5, relu=1)
+    y = plan.dropout("dropout", y, 0.1, DEEPLAB_DROPOUT_SALT)
+    z = plan.conv("custom_logits_semantic", y, classes, 1, bias=True)
+    p_lo = plan.sigmoid_act("probs_lo", z)
+    probs = plan.resize_ac("logits", p_lo, H, W)          # named like the other heads' output tensor; holds PROBABILITIES
+    if with_loss:
+        target = plan.input_u8("mask", H, W, 1)
+        plan.prob_loss(probs, target, loss[0], loss[1])
+    else:
+        plan.probs_out(probs)
+    return probs
+
+
+NETWORKS = {"DeepLabV3": deeplab_mobilenetv2, "Unet": unet_resnet, "Linknet": linknet_resnet, "FPN": fpn_resnet, "PSPNet": pspnet_resnet}

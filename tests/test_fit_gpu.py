@@ -188,3 +188,34 @@ def test_crops_yaml_trains_on_cells_and_assembles_predictions(tmp_path):
     assert p.shape == (128, 128) and p.dtype == np.uint8
     sheet = Image.open(os.path.join(str(tmp_path), "examples", "0", "0", "t_epoch_2.0.jpg"))
     assert sheet.size[0] == 3 * 64                                   # example sheets show the cells the model sees
+
+
+def test_reference_example_experiment_deeplabv3_mobilenetv2(tmp_path):
+    """The reference's own example experiment (examples/people/ds_1.yaml: DeepLabV3 / mobilenetv2, Fliplr + Flipud + Rotate90,
+    binary_crossentropy, EarlyStopping / ReduceLROnPlateau monitoring val_iou_coef, YAML-declared dataset) at a test size."""
+    from segmentation_pipeline import segmentation
+    img_dir, msk_dir = make_dataset(str(tmp_path))
+    cfg_path = str(tmp_path / "ds_1.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"backbone": "mobilenetv2", "architecture": "DeepLabV3",
+                        "augmentation": {"Fliplr": 0.5, "Flipud": 0.5, "Rotate90": True},
+                        "classes": 1, "activation": "sigmoid", "encoder_weights": "pascal_voc", "shape": [128, 128, 3],
+                        "optimizer": "Adam", "batch": 4, "folds_count": 2, "metrics": ["binary_accuracy", "iou"],
+                        "primary_metric": "val_binary_accuracy",
+                        "callbacks": {"EarlyStopping": {"patience": 15, "monitor": "val_iou_coef", "verbose": 1},
+                                      "ReduceLROnPlateau": {"patience": 4, "factor": 0.5, "monitor": "val_iou_coef", "mode": "auto",
+                                                            "cooldown": 5, "verbose": 1}},
+                        "loss": "binary_crossentropy", "stages": [{"epochs": 4}], "fit_with": "simple",
+                        "datasets": {"simple": {"input_path": img_dir, "output_path": msk_dir}}}, f)
+    cfg = segmentation.parse(cfg_path)
+    with pytest.warns(UserWarning, match="pascal_voc"):
+        out = cfg.fit(foldsToExecute=[0])
+    assert [(s["fold"], s["stage"]) for s in out] == [(0, 0)]
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        rows = list(csv.DictReader(f))
+    losses = [float(r["loss"]) for r in rows]
+    assert len(rows) == 4 and {"val_iou", "val_binary_accuracy"} <= set(rows[0]) and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    m = cfg.load_model(0, 0)
+    assert m.impl.architecture == "DeepLabV3" and "expanded_conv_16_depthwise/depthwise_kernel" in m.impl.get_weights()
+    pr = m.predict(np.zeros((1, 128, 128, 3), np.uint8))
+    assert pr.shape == (1, 128, 128, 1) and 0.0 <= pr.min() and pr.max() <= 1.0

@@ -230,6 +230,55 @@ def test_fp32_softmax_head_step_matches_oracle():
     np.testing.assert_allclose(pr, ref, atol=1e-3)
 
 
+def test_fp32_deeplabv3_mobilenetv2_step_matches_oracle():
+    """The reference's IN-TREE model (segmentation_pipeline/impl/deeplab/model.py, `architecture: DeepLabV3`, the example
+    experiment examples/people/ds_1.yaml): MobileNetV2 inverted residuals with depthwise / atrous convolutions and ReLU6,
+    ASPP image pooling, Dropout with the reproducible device mask, sigmoid inside the model and align-corners upsampling of
+    the PROBABILITIES, loss on probabilities.  Two steps (the second draws a different dropout mask)."""
+    from oracle import deeplab as odl
+    n, size = 2, 64
+    P = odl.init_deeplab_mobilenetv2(seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=21)
+    tr = ostep.OracleTrainer(P, backbone="mobilenetv2", loss=LOSS, optimizer="sgd", lr=0.02, architecture="DeepLabV3")
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    m = HipSegModel("DeepLabV3", "mobilenetv2", (size, size, 3), 1, "sigmoid", batch=n, dtype="fp32", loss=LOSS, optimizer="SGD", lr=0.02,
+                    use_graph=False)
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    for k, v in m.get_weights().items():
+        np.testing.assert_array_equal(v, P[k], err_msg=k)                      # depthwise kernels keep Keras' (kh,kw,C,1) layout
+    for step_no in range(2):
+        taps = {}
+        o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
+        met = m.train_on_batch(x, y)
+        if step_no == 0:
+            for oname, pname in (("Conv", "Conv_BN"), ("block0", "expanded_conv_project_BN"), ("block2", "expanded_conv_2_add"),
+                                 ("block9", "expanded_conv_9_add"), ("block16", "expanded_conv_16_project_BN")):
+                ref = taps[oname].detach().numpy()
+                np.testing.assert_allclose(m.activation(pname), ref, atol=3e-4 * max(1.0, np.abs(ref).max()), err_msg=pname)
+        np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-4)          # probabilities: 1e-3 on logits ~ 2.5e-4 on p
+        assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+        g = m.get_gradients()
+        for k, ref in o["grads"].items():
+            # a projection BN's beta feeds a 1x1 convolution + batch-statistics BN with no non-linearity in between: the loss
+            # does not depend on it and both gradients are round-off around zero - hence the absolute floor
+            e = np.linalg.norm(g[k].astype(np.float64) - ref) / (np.linalg.norm(ref.astype(np.float64)) + 1e-3)
+            assert e <= (1e-4 if k.startswith("custom_logits") else 6e-2), "step %d grad %s: rel L2 %.3g" % (step_no, k, e)
+        m.set_weights(tr.P)
+    # inference: Dropout off, moving statistics
+    pr = m.predict(x)
+    ref = tr.forward(x.astype(np.float32))
+    assert pr.shape == (n, size, size, 1)
+    np.testing.assert_allclose(pr, ref, atol=2e-4)
+    # bf16 + hipGraph: runs, draws a fresh mask per replay, learns
+    mb = HipSegModel("DeepLabV3", "mobilenetv2", (size, size, 3), 1, "sigmoid", batch=n, dtype="bf16", loss=LOSS, optimizer="Adam", lr=1e-3)
+    mb.set_weights(P)
+    l0 = mb.train_on_batch(x, y)["loss"]
+    for _ in range(15):
+        l1 = mb.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0 and int(mb.plan.step_state[0].item()) == 16
+
+
 @pytest.mark.parametrize("backbone,classes", [("resnet18", 1), ("resnet50", 5)])
 def test_fp32_pspnet_step_matches_oracle(backbone, classes):
     """PSPNet (BASELINE.json configs[4] family): backbone cut at the 1/8 feature, pyramid pooling levels 1/2/3/6 through
