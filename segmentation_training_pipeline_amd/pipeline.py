@@ -643,7 +643,18 @@ class GenericTaskConfig(object):
         return model
 
     def fit(self, dataset=None, subsample=1.0, foldsToExecute=None, start_from_stage=0):
-        """Trains one model per fold and stage; returns the list of per-(fold, stage) summaries."""
+        """Trains one model per fold and stage; returns the list of per-(fold, stage) summaries.
+
+        ``cfg.gpus = N`` (README.md:756-760) in a process that was not started by torchrun: the reference replicates the graph
+        inside the process; here the experiment is re-launched as N ranks through the fit launcher (one process per GPU).
+        That needs the dataset to be declared in the YAML (``fit_with`` / ``datasets``) - a live Python dataset object cannot be
+        handed to other processes - otherwise a RuntimeError says how to launch."""
+        if int(getattr(self, "gpus", 1)) > 1 and "WORLD_SIZE" not in os.environ:
+            if dataset is not None:
+                raise RuntimeError("cfg.gpus = %d: start the script with `python -m torch.distributed.run --nproc-per-node %d ...` "
+                                   "(one process per GPU), or declare the dataset in the YAML (fit_with / datasets) so that "
+                                   "fit() can launch the ranks itself" % (self.gpus, self.gpus))
+            return self._fit_multi_gpu(foldsToExecute)
         if dataset is None:
             dataset = self._dataset_from_yaml()
         rank, local_rank, world = distributed.init() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 0, 1)
@@ -670,6 +681,18 @@ class GenericTaskConfig(object):
             with open(os.path.join(os.path.dirname(os.path.abspath(self.path)), "summary.yaml"), "w") as f:
                 yaml.safe_dump({"primary_metric": self.primary_metric, "stages": summaries}, f)
         return summaries
+
+    def _fit_multi_gpu(self, folds):
+        import subprocess
+        from . import fit as launcher
+        job = {"name": os.path.basename(self.path), "config": os.path.abspath(self.path), "nproc": int(self.gpus), "port": 29500 + os.getpid() % 2000,
+               "devices": list(range(int(self.gpus)))}
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        rc = subprocess.call(launcher.command(job, allow_resume=self.resume, folds=folds), env=env)
+        if rc:
+            raise RuntimeError("multi-GPU fit failed (exit %d)" % rc)
+        with open(os.path.join(os.path.dirname(os.path.abspath(self.path)), "summary.yaml")) as f:
+            return yaml.safe_load(f)["stages"]
 
     def _stage_done(self, fold, si, stage):
         mp = self.metricsPath(fold, si)

@@ -191,6 +191,14 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
 
 
+def test_cfg_gpus_without_torchrun_explains_how_to_launch(tmp_path, monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    cfg = segmentation.parse(write_cfg(tmp_path))
+    cfg.gpus = 4
+    with pytest.raises(RuntimeError, match="nproc-per-node 4"):
+        cfg.fit(object())                     # a live dataset object cannot be shipped to the ranks
+
+
 def test_crops_dataset_splits_items_into_cells():
     """`crops: N` (README.md:476-491): N x N cells per item, row-major, boundaries floor(k * size / N); the cells tile the image."""
     from segmentation_pipeline.impl.datasets import PredictionItem
