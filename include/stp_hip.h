@@ -96,6 +96,11 @@ typedef struct stp_conv_params {
    * (the hi-res gradient is never written); bnb_x / stats_partial / accumulate0 then refer to that low-resolution
    * tensor.  Small-channel kernel only (stp_conv2d_sc_eligible), Ho and Wo even, no bias / relu. */
   int32_t dst_sum2x2;
+  /* stats_slots > 0 (a power of two <= 64): stats_partial points to PRE-ZEROED int64 fixed-point slots [2][Cout][stats_slots]
+   * (2^-24 units) and every pixel tile ADDS its sums atomically into slot (tile % stats_slots) - integer addition, hence
+   * order-independent and deterministic - instead of writing a per-tile partial: no finalize kernel; the consumer
+   * (stp_bn_apply_slots / stp_bn_backward_slots) sums the few slots of each channel in its prologue. */
+  int32_t stats_slots;
 } stp_conv_params;
 
 int stp_conv2d(const stp_conv_params* p, void* stream);
@@ -180,6 +185,16 @@ int stp_stem_beta_grad(const float* padded_dw, const float* master, float* dbeta
  */
 #define STP_U8 2
 size_t stp_bn_workspace_bytes(int32_t C);
+/* The slot forms (stp_conv_params.stats_slots): statistics -> mean / rstd (published for the backward pass), moving statistics
+ * and the normalisation + activation in ONE kernel; and the BatchNormalization backward from bnb slots in ONE kernel. */
+int stp_bn_apply_slots(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C, const int64_t* slots, int32_t nslots,
+                       float eps, float momentum, float* mean, float* rstd, float* moving_mean, float* moving_var,
+                       const float* gamma, const float* beta, int32_t relu, void* stream);
+int stp_bn_backward_slots(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C, const float* mean,
+                          const float* rstd, const float* gamma, const int64_t* slots, int32_t nslots, float* dgamma,
+                          float* dbeta, int32_t accumulate_dx, void* stream);
+/* zero-fill (the slot arena, once per step); p and bytes 16-byte aligned */
+int stp_zero_bytes(void* p, int64_t bytes, void* stream);
 /* second half of stp_bn_backward when the partial sums came from a convolution epilogue (stp_conv_params.bnb_x):
  * g is the masked gradient that epilogue stored, partial its [2][C][tiles] sums. */
 int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C,

@@ -28,7 +28,7 @@ class ConvParams(C.Structure):
                 ("accumulate0", i32), ("accumulate1", i32), ("relu", i32), ("dtype", i32), ("tile", i32),
                 ("stats_tiles", i32), ("stats_partial", vp),
                 ("bnb_x", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_gamma", vp), ("bnb_beta", vp), ("bnb_relu", i32),
-                ("dst_sum2x2", i32)]
+                ("dst_sum2x2", i32), ("stats_slots", i32)]
 
 
 class WgradParams(C.Structure):
@@ -65,6 +65,9 @@ SIGNATURES = {
     "stp_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, vp, i32, f32, vp]),
     "stp_bn_inference": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, f32, vp]),
     "stp_bn_backward": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+    "stp_bn_apply_slots": (i32, [vp, vp, i32, i64, i32, vp, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "stp_bn_backward_slots": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
+    "stp_zero_bytes": (i32, [vp, i64, vp]),
     "stp_bn_backward_fused": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "stp_maxpool3x3s2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

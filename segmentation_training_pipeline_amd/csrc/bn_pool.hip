@@ -246,13 +246,34 @@ extern "C" int stp_bn_finalize(const float* partial, int32_t tiles, int64_t rows
 template <typename TX, typename TY>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x, TY* __restrict__ y, int64_t rows, int C,
                                                        const float* mean, const float* rstd, const float* gamma,
-                                                       const float* beta, const float* mvar, float eps, int relu) {
+                                                       const float* beta, const float* mvar, float eps, int relu,
+                                                       const long long* slots = nullptr, int nslots = 0, double inv_rows = 0.0,
+                                                       double unbias = 0.0, float momentum = 0.f, float* mean_out = nullptr,
+                                                       float* rstd_out = nullptr, float* mm = nullptr, float* mv = nullptr) {
   extern __shared__ float ss[];  // scale[C], shift[C]
   for (int c = threadIdx.x; c < C; c += 256) {
-    const float r = rstd ? rstd[c] : rsqrtf(mvar[c] + eps);
+    float m, r;
+    if (slots) {
+      // batch statistics straight from the producing convolution's fixed-point slots (every workgroup derives the same
+      // numbers; workgroup 0 publishes them for the backward pass and updates the moving statistics)
+      const double md = slot_sum(slots, nslots, c) * inv_rows;
+      double var = slot_sum(slots, nslots, C + c) * inv_rows - md * md;
+      if (var < 0.0) var = 0.0;
+      m = (float)md;
+      r = (float)(1.0 / sqrt(var + (double)eps));
+      if (blockIdx.x == 0) {
+        mean_out[c] = m;
+        rstd_out[c] = r;
+        if (mm) mm[c] = mm[c] * momentum + m * (1.f - momentum);
+        if (mv) mv[c] = mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+      }
+    } else {
+      m = mean[c];
+      r = rstd ? rstd[c] : rsqrtf(mvar[c] + eps);
+    }
     const float sc = gamma ? r * gamma[c] : r;
     ss[c] = sc;
-    ss[C + c] = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    ss[C + c] = (beta ? beta[c] : 0.f) - m * sc;
   }
   __syncthreads();
   const int cg = C >> 2;
@@ -340,6 +361,38 @@ extern "C" int stp_bn_apply(const void* x, int32_t xdtype, void* y, int32_t ydty
   if (!rstd) return STP_E_BADARG;
   return bn_apply_dispatch(x, xdtype, y, ydtype, rows, C, Cy, mean, rstd, gamma, beta, nullptr, 0.f, relu, pad_value,
                            (hipStream_t)stream);
+}
+
+extern "C" int stp_bn_apply_slots(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C, const int64_t* slots, int32_t nslots,
+                                  float eps, float momentum, float* mean, float* rstd, float* moving_mean, float* moving_var,
+                                  const float* gamma, const float* beta, int32_t relu, void* stream) {
+  if (!x || !y || !slots || !mean || !rstd || rows <= 0 || C <= 0 || (C & 3) || nslots < 1 || (nslots & (nslots - 1))) return STP_E_BADARG;
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  const int g = grid_for(rows * (C >> 2));
+  const double inv_rows = 1.0 / (double)rows, unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, rows, C, (const float*)nullptr,
+                       (const float*)nullptr, gamma, beta, (const float*)nullptr, eps, relu, (const long long*)slots, nslots, inv_rows, unbias,
+                       momentum, mean, rstd, moving_mean, moving_var);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(g), dim3(256), lds, s, (const float*)x, (float*)y, rows, C, (const float*)nullptr,
+                       (const float*)nullptr, gamma, beta, (const float*)nullptr, eps, relu, (const long long*)slots, nslots, inv_rows, unbias,
+                       momentum, mean, rstd, moving_mean, moving_var);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+__global__ __launch_bounds__(256) void zero_kernel(uint4* p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+extern "C" int stp_zero_bytes(void* p, int64_t bytes, void* stream) {
+  if (!p || bytes <= 0 || (bytes & 15) || ((uintptr_t)p & 15)) return STP_E_BADARG;
+  hipLaunchKernelGGL(zero_kernel, dim3(grid_for(bytes >> 4)), dim3(256), 0, (hipStream_t)stream, (uint4*)p, bytes >> 4);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
 }
 
 extern "C" int stp_bn_inference(const void* x, int32_t xdtype, void* y, int32_t ydtype, int64_t rows, int32_t C, int32_t Cy,
@@ -442,7 +495,8 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                            int64_t rows, int C, const float* mean, const float* rstd,
                                                            const float* gamma, const float* beta, const float* sums,
-                                                           float inv_rows, int relu, int accumulate) {
+                                                           float inv_rows, int relu, int accumulate, const long long* slots = nullptr,
+                                                           int nslots = 0, float* dgamma = nullptr, float* dbeta = nullptr) {
   extern __shared__ float ss[];  // mean, rstd, scale, shift, k1 = dbeta/M, k2 = dgamma/M   [6][C]
   for (int c = threadIdx.x; c < C; c += 256) {
     const float r = rstd[c], sc = gamma ? r * gamma[c] : r;
@@ -450,8 +504,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     ss[C + c] = r;
     ss[2 * C + c] = sc;
     ss[3 * C + c] = (beta ? beta[c] : 0.f) - mean[c] * sc;
-    ss[4 * C + c] = sums[c] * inv_rows;
-    ss[5 * C + c] = sums[C + c] * inv_rows;
+    float sb, sg;
+    if (slots) {    // sums from the data-gradient convolution's fixed-point slots; workgroup 0 publishes the parameter gradients
+      sb = (float)slot_sum(slots, nslots, c);
+      sg = (float)slot_sum(slots, nslots, C + c);
+      if (blockIdx.x == 0) {
+        if (dbeta) dbeta[c] = sb;
+        if (dgamma) dgamma[c] = sg;
+      }
+    } else {
+      sb = sums[c];
+      sg = sums[C + c];
+    }
+    ss[4 * C + c] = sb * inv_rows;
+    ss[5 * C + c] = sg * inv_rows;
   }
   __syncthreads();
   const int cg = C / V;
@@ -539,6 +605,31 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_tiles_kernel(const float*
   sums[C + c] = (float)sh[1][0];
   if (dbeta) dbeta[c] = (float)sh[0][0];
   if (dgamma) dgamma[c] = (float)sh[1][0];
+}
+
+extern "C" int stp_bn_backward_slots(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C, const float* mean,
+                                     const float* rstd, const float* gamma, const int64_t* slots, int32_t nslots, float* dgamma,
+                                     float* dbeta, int32_t accumulate_dx, void* stream) {
+  if (!x || !g || !dx || !mean || !rstd || !slots || rows <= 0 || C <= 0 || (C & 3) || nslots < 1 || (nslots & (nslots - 1))) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const size_t lds2 = 6 * (size_t)C * sizeof(float);
+  const int gr = grid_for(rows * (C / (v8 ? 8 : 4)));
+  const float inv_rows = (float)(1.0 / (double)rows);
+  const long long* sl = (const long long*)slots;
+  if (v8)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, rows, C,
+                       mean, rstd, gamma, (const float*)nullptr, (const float*)nullptr, inv_rows, 0, accumulate_dx, sl, nslots, dgamma, dbeta);
+  else if (dtype == STP_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, rows, C,
+                       mean, rstd, gamma, (const float*)nullptr, (const float*)nullptr, inv_rows, 0, accumulate_dx, sl, nslots, dgamma, dbeta);
+  else if (dtype == STP_F32)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(gr), dim3(256), lds2, s, (const float*)x, (const float*)g, (float*)dx, rows, C,
+                       mean, rstd, gamma, (const float*)nullptr, (const float*)nullptr, inv_rows, 0, accumulate_dx, sl, nslots, dgamma, dbeta);
+  else
+    return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
 }
 
 extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C,

@@ -120,6 +120,21 @@ __device__ __forceinline__ float bn_affine(float x, float scale, float shift) { 
 __device__ __forceinline__ float bn_act(float v, int relu) { return relu == 0 ? v : (relu == 1 ? fmaxf(v, 0.f) : fminf(fmaxf(v, 0.f), 6.f)); }
 __device__ __forceinline__ bool bn_act_on(float v, int relu) { return relu == 0 || (v > 0.f && (relu == 1 || v < 6.f)); }
 
+// Fused BatchNormalization sums, "slot" form: instead of one partial per pixel tile (reduced by a finalize kernel), the
+// epilogue adds its tile's sum into one of a few int64 FIXED-POINT slots per channel (2^-24 units).  Integer addition is
+// associative, so the result does not depend on the order in which workgroups arrive: deterministic without a second
+// kernel; the consumer (BN apply / BN-backward apply) sums the <= 16 slots of each channel in its prologue.
+#define STP_SLOT_SCALE 16777216.0
+__device__ __forceinline__ void slot_add(long long* slots, int nslots, int channel, int tile, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(slots) + (size_t)channel * nslots + (tile & (nslots - 1)),
+            (unsigned long long)__double2ll_rn((double)v * STP_SLOT_SCALE));
+}
+__device__ __forceinline__ double slot_sum(const long long* slots, int nslots, int channel) {
+  long long s = 0;
+  for (int k = 0; k < nslots; ++k) s += slots[(size_t)channel * nslots + k];
+  return (double)s * (1.0 / STP_SLOT_SCALE);
+}
+
 // BatchNormalization-backward partial sums fused into the epilogue of the data-gradient convolution that
 // produces dY of the BN output:  g = dY * [relu mask],  sum(g) and sum(g * xhat) per channel, g stored in
 // place of dY (see stp_conv_params.bnb_x).

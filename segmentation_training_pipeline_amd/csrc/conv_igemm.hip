@@ -39,7 +39,8 @@ struct ConvArgs {
   int K, P, HoWo, wrows;
   int ntile_m, ntile_n;
   uint32_t bytes0, bytes1, bytesw;
-  float* stats;  // optional [2][Cout][ntile_n]
+  float* stats;  // optional [2][Cout][ntile_n] floats, or (stat_slots > 0) int64 fixed-point slots [2][Cout][stat_slots]
+  int stat_slots;
   BnBack bnb;    // bnb.x != NULL: stats are the BatchNormalization-backward sums and dst receives the masked gradient
   FastDiv divC, divKW;
 };
@@ -197,6 +198,12 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < WN; ++w) { s += red[(w * BM + c) * 2]; q += red[(w * BM + c) * 2 + 1]; }
+      if (a.stat_slots) {
+        long long* sl = reinterpret_cast<long long*>(a.stats);
+        slot_add(sl, a.stat_slots, cout0 + c, tile_n, s);
+        slot_add(sl, a.stat_slots, a.Cout + cout0 + c, tile_n, q);
+        continue;
+      }
       a.stats[(size_t)(cout0 + c) * a.ntile_n + tile_n] = s;
       a.stats[((size_t)a.Cout + cout0 + c) * a.ntile_n + tile_n] = q;
     }
@@ -643,7 +650,9 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* u
   a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
   a.ntile_m = a.ntile_n = 0;
   a.stats = p->stats_partial;
+  a.stat_slots = p->stats_slots;
   if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;
+  if (a.stat_slots && (!a.stats || (a.stat_slots & (a.stat_slots - 1)) || a.stat_slots > 64)) return STP_E_BADARG;
   a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
   a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
   *c4_out = c4;

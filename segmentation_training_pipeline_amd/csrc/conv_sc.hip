@@ -21,7 +21,8 @@ struct ScArgs {
   char* dst;           // [N,H,W,Cout]
   int N, H, W, Hs, Ws, Cout, up, accumulate, relu;
   int tiles_x, tiles_y;
-  float* stats;        // optional fused BatchNorm statistics [2][Cout][tiles]
+  float* stats;        // optional fused BatchNorm statistics [2][Cout][tiles] (or int64 slots, see stat_slots)
+  int stat_slots;
   BnBack bnb;          // see stp_conv_params.bnb_x
   int sum2;            // see stp_conv_params.dst_sum2x2: dst is [N,H/2,W/2,Cout]
 };
@@ -220,8 +221,14 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
       float sv = 0.f, qv = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { sv += red[(w * TM * 16 + tid) * 2]; qv += red[(w * TM * 16 + tid) * 2 + 1]; }
-      a.stats[(size_t)(cb + tid) * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][tile]
-      a.stats[((size_t)a.Cout + cb + tid) * gridDim.x + blockIdx.x] = qv;
+      if (a.stat_slots) {
+        long long* sl = reinterpret_cast<long long*>(a.stats);
+        slot_add(sl, a.stat_slots, cb + tid, (int)blockIdx.x, sv);
+        slot_add(sl, a.stat_slots, a.Cout + cb + tid, (int)blockIdx.x, qv);
+      } else {
+        a.stats[(size_t)(cb + tid) * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][tile]
+        a.stats[((size_t)a.Cout + cb + tid) * gridDim.x + blockIdx.x] = qv;
+      }
     }
   }
 }
@@ -270,7 +277,9 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.up = p->src0_mode == STP_SRC_NEAREST2X; a.accumulate = p->accumulate0; a.relu = p->relu;
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
   a.stats = p->stats_partial;
+  a.stat_slots = p->stats_slots;
   if (a.stats && (p->Cout & 3)) return STP_E_BADARG;
+  if (a.stat_slots && (!a.stats || (a.stat_slots & (a.stat_slots - 1)) || a.stat_slots > 64)) return STP_E_BADARG;
   a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
   a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
   a.sum2 = p->dst_sum2x2;

@@ -97,6 +97,12 @@ class Plan(object):
         self._side_reads = set()
         self._dw_ws_bytes = 0
         self.step_state = None
+        # fused BatchNormalization sums in fixed-point slots (stp_conv_params.stats_slots): no finalize kernels
+        self.bn_slots = os.environ.get("STP_BN_SLOTS", "0") == "1"   # measured: no gain over the finalize kernels, kept opt-in
+        self.bn_slots_max_rows = int(os.environ.get("STP_BN_SLOTS_MAXROWS", "1073741824"))
+        self._slot_need = 0          # int64 elements, counted in the dry pass
+        self._slot_used = 0
+        self.slot_arena = None
         self.loss_scalars = None
         self.inputs = {}
 
@@ -122,6 +128,8 @@ class Plan(object):
         self.ws_bn = torch.empty(ops.bn_workspace_bytes(_rup(self._bn_ws_c, 4)) // 4, dtype=torch.float32, device=self.device)
         self.ws_loss = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=self.device)
         self.ws_dw = torch.empty(max(self._dw_ws_bytes // 4, 4), dtype=torch.float32, device=self.device)
+        if self.training and self.bn_slots and self._slot_need:
+            self.slot_arena = torch.zeros(_rup(self._slot_need, 2), dtype=torch.int64, device=self.device)
         self.dry = False
         self._tape = []
         self._prep_layers = []
@@ -146,8 +154,27 @@ class Plan(object):
         self._tape = []
         return self
 
+    @staticmethod
+    def _nslots(Cn):
+        """Slots per channel: as many as keep 2 * C * slots int64 reads in the consumer's prologue small (<= 16)."""
+        n = 16
+        while n > 1 and n * Cn > 1024:
+            n //= 2
+        return n
+
+    def _slots(self, Cn):
+        """(device pointer, slots per channel) of a zero-initialised [2][Cn][n] slice of the slot arena."""
+        n = self._nslots(Cn)
+        off = self._slot_used
+        self._slot_used += 2 * Cn * n
+        if self._slot_used > self.slot_arena.numel():
+            raise StpShapeError("slot arena exhausted")
+        return self.slot_arena.data_ptr() + 8 * off, n
+
     def _finish_prep(self):
         """One batched weight-preparation launch for all conv layers (descriptor table lives on the device)."""
+        if self.slot_arena is not None:
+            self._emit(self.prep, "stp_zero_bytes", self.slot_arena.data_ptr(), self.slot_arena.numel() * 8)
         n = len(self._prep_layers)
         if not n:
             return
@@ -304,6 +331,7 @@ class Plan(object):
         self._bn_ws_c = max(self._bn_ws_c, Cn)
         self._use(x)
         if self.dry:
+            self._slot_need += 4 * Cn * self._nslots(Cn)       # forward statistics + backward sums
             return out
         gp = self._pptr(gamma) if gamma else None
         if not self.training:
@@ -312,7 +340,12 @@ class Plan(object):
             return out
         mean, rstd = self._alloc((Cn,), torch.float32), self._alloc((Cn,), torch.float32)
         fused = x.meta.get("stats")
-        if fused is not None:
+        slots = x.meta.get("stats_slots")
+        if slots is not None:
+            # statistics from the producing convolution's fixed-point slots: finalize + normalise + activation in one kernel
+            self._emit(self.fwd, "stp_bn_apply_slots", x.buf.data_ptr(), out.buf.data_ptr(), self.cdt, x.rows, Cn, slots[0], slots[1], eps,
+                       momentum, mean.data_ptr(), rstd.data_ptr(), self._sptr(mm), self._sptr(mv), gp, self._pptr(beta), int(relu))
+        elif fused is not None:
             st, cp = fused
             tiles = int(self.lib.stp_conv2d_stats_floats(C.byref(cp))) // (2 * Cn)
             self._emit(self.fwd, "stp_bn_finalize", st.data_ptr(), tiles, x.rows, Cn, eps, momentum, mean.data_ptr(),
@@ -320,8 +353,9 @@ class Plan(object):
         else:
             self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), self.cdt, x.rows, Cn, eps, momentum, mean.data_ptr(),
                        rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
-        self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
-                   mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu), 0.0)
+        if slots is None:
+            self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
+                       mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu), 0.0)
         out.meta["bn"] = (x.buf.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu))
 
         def back():
@@ -329,6 +363,14 @@ class Plan(object):
                 return
             # dx is always produced (it is cheap relative to skipping logic); frozen params are masked in the optimizer
             dx = self._gradbuf(x) if x.needs_grad else self._alloc((x.N, x.H, x.W, Cn))
+            bslots = out.meta.get("bnb_slots")
+            if bslots is not None:
+                self._emit(self.bwd, "stp_bn_backward_slots", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt, x.rows, Cn,
+                           mean.data_ptr(), rstd.data_ptr(), gp, bslots[0], bslots[1], self._gptr(gamma) if gamma else None,
+                           self._gptr(beta), int(x.grad_ready and x.needs_grad))
+                if x.needs_grad:
+                    x.grad_ready = True
+                return
             fused_b = out.meta.get("bnb")
             if fused_b is not None:
                 # the only consumer's data-gradient epilogue already masked dY and reduced the per-tile sums
@@ -424,7 +466,11 @@ class Plan(object):
             if CoutB != Cout:
                 raise StpShapeError("%s: a fused ReLU needs Cout to be a multiple of %d" % (name, self.vec))
             p.relu = 1        # Conv2D(activation='relu'): fused into the epilogue; its gradient masks dY first (stp_relu_bwd)
-        if bn_stats and self.training:
+        if bn_stats and self.training and self.slot_arena is not None and self.N * Ho * Wo <= self.bn_slots_max_rows:
+            sp, sn = self._slots(Cout)
+            p.stats_partial, p.stats_slots = sp, sn
+            out.meta["stats_slots"] = (sp, sn)
+        elif bn_stats and self.training:
             # the BatchNormalization that follows takes its batch statistics from this conv's epilogue
             nfl = int(self.lib.stp_conv2d_stats_floats(C.byref(p)))
             st = self._alloc((max(nfl, 4),), torch.float32)
@@ -523,10 +569,15 @@ class Plan(object):
                 if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses") == 1 and (folded_up or not upsample) and C1 == 0
                         and x_ng and not q.accumulate0 and C0 % 4 == 0):
                     q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
-                    nfl = int(self.lib.stp_conv2d_stats_floats(C.byref(q)))
-                    st = self._alloc((max(nfl, 4),), torch.float32)
-                    q.stats_partial = st.data_ptr()
-                    x.meta["bnb"] = (st, q)
+                    if self.slot_arena is not None and self.N * Hv * Wv <= self.bn_slots_max_rows:
+                        sp, sn = self._slots(C0)
+                        q.stats_partial, q.stats_slots = sp, sn
+                        x.meta["bnb_slots"] = (sp, sn)
+                    else:
+                        nfl = int(self.lib.stp_conv2d_stats_floats(C.byref(q)))
+                        st = self._alloc((max(nfl, 4),), torch.float32)
+                        q.stats_partial = st.data_ptr()
+                        x.meta["bnb"] = (st, q)
                 self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": flops,
                                               "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
                 if upsample and x_ng and not folded_up:

@@ -380,6 +380,35 @@ def test_hipgraph_replay_equals_eager(arch):
         np.testing.assert_array_equal(outs[0][2][k], outs[1][2][k], err_msg=k)
 
 
+def test_fixed_point_slot_sums_step_equals_finalize_step(monkeypatch):
+    """STP_BN_SLOTS=1 (BatchNormalization sums accumulated in the conv epilogues' int64 slots, no finalize launches) is an opt-in
+    schedule of the same arithmetic: fp32 steps agree with the default schedule to summation-order noise, and replay is bitwise."""
+    P = onets.init_unet_resnet("resnet18", seed=7)
+    x, y = ostep.synthetic_batch(2, 64, 64, seed=5)
+    res = {}
+    for slots, use_graph in ((0, False), (1, False), (1, True)):
+        monkeypatch.setenv("STP_BN_SLOTS", str(slots))
+        m = make("resnet18", 64, 2, "fp32", use_graph=use_graph)
+        names = [l[2] for l in m.plan.fwd + m.plan.bwd]
+        assert ("stp_bn_apply_slots" in names) == bool(slots) and ("stp_bn_backward_slots" in names) == bool(slots)
+        m.set_weights(P)
+        r1 = m.train_on_batch(x, y)
+        first, w1 = m.logits(), m.get_weights()              # forward of step 1: same weights in every schedule
+        r2 = m.train_on_batch(x, y)
+        res[(slots, use_graph)] = ((r1, r2), m.logits(), m.get_weights(), first, w1)
+    a, b, c = res[(0, False)], res[(1, False)], res[(1, True)]
+    assert b[0] == c[0]
+    np.testing.assert_array_equal(b[1], c[1])
+    for k in b[2]:
+        np.testing.assert_array_equal(b[2][k], c[2][k], err_msg=k)
+    np.testing.assert_allclose(b[3], a[3], atol=1e-4 * max(1.0, np.abs(a[3]).max()))
+    for k in ("loss", "dice"):
+        assert abs(b[0][0][k] - a[0][0][k]) < 1e-5, k
+    # the first Adam step moves every weight by lr * sign(g): only weights whose gradient is rounding noise may differ
+    diff = sum(int((np.abs(b[4][k] - a[4][k]) > 1e-4).sum()) for k in a[4])
+    assert diff < 0.02 * sum(v.size for v in a[4].values()), diff
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_overlapped_rccl_allreduce_equals_plain_step(use_graph):
     """Data-parallel path on one GPU (world size 1 over RCCL, GradReducer(force=True)): the backward cut into

@@ -413,6 +413,75 @@ def test_batchnorm_backward_sums_fused_in_conv_epilogue(ops, dtype, case, relu):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0), (2, 19, 45, 16, 16, 512), (2, 13, 9, 64, 24, 0), (3, 32, 32, 64, 512, 0)])
+def test_batchnorm_sums_in_fixed_point_slots(ops, dtype, case):
+    """stp_conv_params.stats_slots: the epilogue adds its tile sums atomically into int64 fixed-point slots (order-independent,
+    so deterministic); stp_bn_apply_slots must equal stp_bn_stats + stp_bn_apply on the stored conv output, and
+    stp_bn_backward_slots must equal conv + stp_bn_backward.  Two runs give bit-identical results."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co, tile = case
+    rng = np.random.RandomState(91)
+    rows = n * h * w
+    src, wt = q(rng.randn(n, h, w, ci), dtype), q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    gamma, beta = (rng.rand(co) + 0.5).astype(np.float32), (rng.randn(co) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    g, b = f(gamma), f(beta)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    sd = dev(src, dtype)
+    mk = lambda dst: ops.conv_params(sd, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
+                                     Cout=co, dtype=ops.dt(dst), tile=tile)
+    nslots = 16 if co * 16 <= 1024 else max(1, 1024 // co)
+    ws = torch.empty(ops.bn_workspace_bytes(co) // 4, dtype=torch.float32, device=DEV)
+    outs = []
+    for rep in range(2):
+        y = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
+        slots = torch.zeros(2 * co * nslots, dtype=torch.int64, device=DEV)
+        P = mk(y)
+        P.stats_partial, P.stats_slots = ops.ptr(slots), nslots
+        ops.conv2d(P)
+        m1, r1 = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+        mm1, mv1 = torch.zeros(co, device=DEV), torch.ones(co, device=DEV)
+        a1 = torch.empty_like(y)
+        _lib.call("stp_bn_apply_slots", ops.ptr(y), ops.ptr(a1), ops.dt(y), rows, co, ops.ptr(slots), nslots, 1e-3, 0.99, ops.ptr(m1), ops.ptr(r1),
+                  ops.ptr(mm1), ops.ptr(mv1), ops.ptr(g), ops.ptr(b), 1, ops.stream())
+        outs.append((host(a1), host(m1), host(r1), host(mm1), host(mv1)))
+    for u, v in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(u, v)                                  # atomics in integer arithmetic: run-to-run identical
+    m0, r0 = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    mm0, mv0 = torch.zeros(co, device=DEV), torch.ones(co, device=DEV)
+    ops.bn_stats(y, rows, co, 1e-3, 0.99, m0, r0, mm0, mv0, ws)
+    a0 = torch.empty_like(y)
+    ops.bn_apply(y, a0, rows, co, co, m0, r0, g, b, relu=1)
+    np.testing.assert_allclose(outs[0][1], host(m0), atol=2e-6 * max(1.0, np.abs(host(m0)).max()))
+    np.testing.assert_allclose(outs[0][2], host(r0), rtol=2e-5)
+    np.testing.assert_allclose(outs[0][3], host(mm0), atol=1e-6)
+    np.testing.assert_allclose(outs[0][4], host(mv0), rtol=2e-5)
+    np.testing.assert_allclose(outs[0][0], host(a0), atol=tol(host(a0), dtype, 0.5))
+    # backward sums through slots
+    x = dev(q(rng.randn(n, h, w, co) * 1.5 + 0.3, dtype), dtype)
+    ops.bn_stats(x, rows, co, 1e-3, 0.99, m0, r0, None, None, ws)
+    dy = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
+    ops.conv2d(mk(dy))
+    dx0, dg0, db0 = torch.empty_like(dy), torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ops.bn_backward(x, dy, dx0, rows, co, m0, r0, g, b, dg0, db0, relu=1, accumulate_dx=0, workspace=ws)
+    gbuf = torch.empty_like(dy)
+    slots = torch.zeros(2 * co * nslots, dtype=torch.int64, device=DEV)
+    P = mk(gbuf)
+    P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(x), ops.ptr(m0), ops.ptr(r0), ops.ptr(g), ops.ptr(b), 1
+    P.stats_partial, P.stats_slots = ops.ptr(slots), nslots
+    ops.conv2d(P)
+    dx1, dg1, db1 = torch.empty_like(dy), torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    _lib.call("stp_bn_backward_slots", ops.ptr(x), ops.ptr(gbuf), ops.ptr(dx1), ops.dt(x), rows, co, ops.ptr(m0), ops.ptr(r0), ops.ptr(g),
+              ops.ptr(slots), nslots, ops.ptr(dg1), ops.ptr(db1), 0, ops.stream())
+    sc = lambda a: 1e-3 * np.abs(a).max() + 1e-4
+    np.testing.assert_allclose(host(db1), host(db0), atol=sc(host(db0)))
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=sc(host(dg0)))
+    pre = host(x) * (host(r0) * gamma) + (beta - host(m0) * host(r0) * gamma)
+    safe = np.abs(pre) > 1e-3
+    np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
 def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
     """stp_conv_params.dst_sum2x2: the data-gradient convolution of an UpSampling2D(2) input writes the 2x2 block sums
