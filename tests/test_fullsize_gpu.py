@@ -1,0 +1,199 @@
+"""BASELINE.json's FULL sizes (configs[1], [3], [4]) on the GPU.  The CPU oracle needs minutes per step at these sizes, so
+the checks are the size-independent ones the task statement asks for:
+
+* every kind of layer of the headline step (U-Net/ResNet34, 16x512x512, bf16) recomputed ON THE DEVICE in fp32 from the
+  very buffers the HIP kernels read (conv forward through each tile family, BatchNormalization forward, weight gradients,
+  data gradient + fused BatchNormalization backward incl. the folded upsampling gradient) - plain torch ops are the checker
+  here, never the product path;
+* hipGraph replay == eager launches, bit for bit, and the loss of a fixed batch falls;
+* FPN/ResNet50 1024x1024 3-class bs4 and PSPNet/ResNet101 768x768 20-class bs8 run, stay finite, replay bit-identically.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+LOSS = "binary_crossentropy+1.0*dice_loss"
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1)
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.fixture(scope="module")
+def headline():
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    from oracle import step as ostep
+    m = HipSegModel("Unet", "resnet34", (512, 512, 3), 1, "sigmoid", batch=16, dtype="bf16", loss=LOSS, optimizer="Adam", lr=1e-3,
+                    use_graph=False)
+    x, y = ostep.synthetic_batch(16, 512, 512, seed=1234)
+    m.load_batch(x, y)
+    m.forward_backward()
+    torch.cuda.synchronize()
+    w = {k: torch.from_numpy(v).cuda() for k, v in m.get_weights().items()}
+    g = {k: torch.from_numpy(v).cuda() for k, v in m.get_gradients().items()}
+    yield m, w, g
+    del m
+
+
+def kernel(w, name):
+    """Keras HWIO -> torch OIHW, rounded to the bf16 compute copy the kernels read."""
+    return bf16r(w[name + "/kernel"].permute(3, 2, 0, 1).contiguous())
+
+
+def conv_ref(a, k, stride, pad):
+    return nhwc(F.conv2d(a, k, stride=stride, padding=pad))
+
+
+FWD_LAYERS = [
+    # layer, input builder, stride, pad          (tile family exercised at full size)
+    ("stage1_unit2_conv1", "stage1_unit2_bn1", 1, 1),          # 64 -> 64 @128^2
+    ("stage2_unit1_conv1", "stage2_unit1_bn1", 2, 1),          # stride 2
+    ("stage2_unit3_conv1", "stage2_unit3_bn1", 1, 1),
+    ("stage3_unit1_sc", "stage3_unit1_bn1", 2, 0),             # 1x1 stride-2 shortcut
+    ("stage3_unit4_conv1", "stage3_unit4_bn1", 1, 1),
+    ("stage4_unit2_conv1", "stage4_unit2_bn1", 1, 1),
+    ("decoder_stage3_conv2", "decoder_stage3_bn1", 1, 1),      # small-channel halo kernel
+    ("decoder_stage4_conv2", "decoder_stage4_bn1", 1, 1),
+]
+
+
+@pytest.mark.parametrize("layer,src,stride,pad", FWD_LAYERS)
+def test_headline_conv_forward_layers(headline, layer, src, stride, pad):
+    m, w, _ = headline
+    ts = m.plan.tensors
+    ref = conv_ref(nchw(ts[src].buf), kernel(w, layer), stride, pad)
+    got = ts[layer].buf.float()
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < 3e-3                                            # one bf16 rounding of the output
+    assert float((got - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+
+
+def test_headline_stem_residual_concat_and_head(headline):
+    m, w, _ = headline
+    ts = m.plan.tensors
+    # stem: 7x7 stride 2 over the 3 image channels of bn_data (the 4th channel carries the constant of stp_stem_beta_grad)
+    ref = conv_ref(nchw(ts["bn_data"].buf[..., :3]), kernel(w, "conv0"), 2, 3)
+    assert rel_l2(ts["conv0"].buf.float(), ref) < 3e-3
+    # residual add fused into the epilogue
+    ref = conv_ref(nchw(ts["stage3_unit2_bn2"].buf), kernel(w, "stage3_unit2_conv2"), 1, 1) + ts["stage3_unit1_conv2"].buf.float()
+    assert rel_l2(ts["stage3_unit2_conv2"].buf.float(), ref) < 3e-3
+    # decoder: nearest 2x upsampling and the skip concat resolved inside the operand gather
+    up = F.interpolate(nchw(ts["decoder_stage1_bn2"].buf), scale_factor=2, mode="nearest")
+    a = torch.cat([up, nchw(ts["stage2_unit1_bn1"].buf)], dim=1)
+    ref = conv_ref(a, kernel(w, "decoder_stage2_conv1"), 1, 1)
+    assert rel_l2(ts["decoder_stage2_conv1"].buf.float(), ref) < 3e-3
+    up = F.interpolate(nchw(ts["decoder_stage3_bn2"].buf), scale_factor=2, mode="nearest")
+    ref = conv_ref(up, kernel(w, "decoder_stage4_conv1"), 1, 1)
+    assert rel_l2(ts["decoder_stage4_conv1"].buf.float(), ref) < 3e-3
+    # head: biased 3x3 conv -> logits (channel 0 of the padded tensor)
+    ref = conv_ref(nchw(ts["decoder_stage4_bn2"].buf), kernel(w, "final_conv"), 1, 1) + w["final_conv/bias"].float()
+    got = ts["final_conv"].buf.float()[..., :1]
+    assert rel_l2(got, ref) < 3e-3
+
+
+@pytest.mark.parametrize("bn,src,eps", [("stage3_unit2_bn1", "stage3_unit1_conv2", 2e-5), ("bn0", "conv0", 2e-5),
+                                        ("decoder_stage3_bn1", "decoder_stage3_conv1", 1e-3), ("decoder_stage4_bn2", "decoder_stage4_conv2", 1e-3)])
+def test_headline_batchnorm_forward_layers(headline, bn, src, eps):
+    """Training-phase statistics over all 16*H*W positions (taken from the conv epilogue in the product), affine + ReLU."""
+    m, w, _ = headline
+    ts = m.plan.tensors
+    x = ts[src].buf.float()
+    mean = x.double().mean(dim=(0, 1, 2))
+    var = (x.double() - mean).pow(2).mean(dim=(0, 1, 2))
+    ref = torch.relu(((x.double() - mean) / torch.sqrt(var + eps) * w[bn + "/gamma"].double() + w[bn + "/beta"].double())).float()
+    got = ts[bn].buf.float()
+    assert rel_l2(got, ref) < 3e-3
+    assert float((got - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("layer,src,stride,pad", [l for l in FWD_LAYERS if not l[0].endswith("_sc")] + [("stage3_unit1_sc", "stage3_unit1_bn1", 2, 0)])
+def test_headline_weight_gradient_layers(headline, layer, src, stride, pad):
+    """dW = sum over 16*Ho*Wo pixels of dY (x) X: split-K slabs + fixed-order reduce (DMA kernel / small-channel kernel)."""
+    m, w, g = headline
+    ts = m.plan.tensors
+    a = nchw(ts[src].buf)
+    dy = nchw(ts[layer].grad)
+    k = kernel(w, layer).requires_grad_(True)
+    F.conv2d(a, k, stride=stride, padding=pad).backward(dy)
+    got = g[layer + "/kernel"].permute(3, 2, 0, 1)
+    assert rel_l2(got, k.grad) < 2e-3
+
+
+def _bn_relu(x, gamma, beta, eps):
+    mean = x.mean(dim=(0, 2, 3), keepdim=True)
+    var = (x - mean).pow(2).mean(dim=(0, 2, 3), keepdim=True)
+    return torch.relu((x - mean) * torch.rsqrt(var + eps) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+
+
+@pytest.mark.parametrize("conv_in,bn,conv_out,up", [("decoder_stage1_conv1", "decoder_stage1_bn1", "decoder_stage1_conv2", False),
+                                                     ("decoder_stage4_conv1", "decoder_stage4_bn1", "decoder_stage4_conv2", False),
+                                                     ("decoder_stage3_conv2", "decoder_stage3_bn2", "decoder_stage4_conv1", True)])
+def test_headline_data_gradient_through_batchnorm(headline, conv_in, bn, conv_out, up):
+    """dL/d(conv_in output) = BatchNormalization-backward(ReLU mask * conv_out's data gradient): the data-gradient GEMM with the
+    backward sums in its epilogue (and, for `up`, the 2x2 fold of the upsampling gradient) against autograd in fp32.  Decoder
+    layers only: an encoder unit's dY buffer is handed on as the residual gradient and accumulated into, so it no longer
+    holds dY when the step ends (the encoder's data-gradient GEMMs are the same kernels, covered at op level)."""
+    m, w, g = headline
+    ts = m.plan.tensors
+    eps = 1e-3 if bn.startswith("decoder") else 2e-5
+    x = nchw(ts[conv_in].buf).clone().requires_grad_(True)
+    gam = w[bn + "/gamma"].float().clone().requires_grad_(True)
+    bet = w[bn + "/beta"].float().clone().requires_grad_(True)
+    a = _bn_relu(x, gam, bet, eps)
+    if up:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    F.conv2d(a, kernel(w, conv_out), padding=1).backward(nchw(ts[conv_out].grad))
+    assert rel_l2(nchw(ts[conv_in].grad), x.grad) < 1.5e-2      # dY and activations are stored in bf16; ReLU kinks at rounding distance
+    assert rel_l2(g[bn + "/beta"], bet.grad) < 1e-2              # the parameter gradients come from the same epilogue sums
+    assert rel_l2(g[bn + "/gamma"], gam.grad) < 1e-2
+
+
+def _run_steps(arch, backbone, size, batch, classes, use_graph, steps, seed=3):
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    act = "sigmoid" if classes == 1 else "softmax"
+    spec = LOSS if classes == 1 else "categorical_crossentropy+1.0*dice_loss"
+    m = HipSegModel(arch, backbone, (size, size, 3), classes, act, batch=batch, dtype="bf16", loss=spec, optimizer="Adam", lr=1e-3,
+                    use_graph=use_graph)
+    rng = np.random.RandomState(seed)
+    x = rng.randint(0, 256, (batch, size, size, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size]
+    if classes == 1:
+        y = (((yy // 64 + xx // 96) % 3) == 0).astype(np.uint8)[None, :, :, None].repeat(batch, axis=0)
+    else:
+        y = ((yy // 64 + xx // 96) % classes).astype(np.uint8)[None, :, :, None].repeat(batch, axis=0)
+    hist = [m.train_on_batch(x, y) for _ in range(steps)]
+    out = (hist, m.logits(), m.get_weights())
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
+FULL = [("Unet", "resnet34", 512, 16, 1), ("FPN", "resnet50", 1024, 4, 3), ("PSPNet", "resnet101", 768, 8, 20)]
+
+
+@pytest.mark.parametrize("arch,backbone,size,batch,classes", FULL)
+def test_full_size_graph_replay_is_bitwise_and_the_loss_falls(arch, backbone, size, batch, classes):
+    e = _run_steps(arch, backbone, size, batch, classes, False, 6)
+    g = _run_steps(arch, backbone, size, batch, classes, True, 6)
+    assert e[0] == g[0]
+    assert torch.equal(torch.from_numpy(e[1]), torch.from_numpy(g[1]))
+    for k in e[2]:
+        assert np.array_equal(e[2][k], g[2][k]), k
+    losses = [h["loss"] for h in e[0]]
+    assert all(np.isfinite(v) for v in losses), losses
+    assert min(losses[3:]) < losses[0], losses                    # a fixed batch is being fitted
