@@ -229,8 +229,12 @@ int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N
 int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 int stp_maxpool2x2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
                        int32_t accumulate, void* stream);
-/* AveragePooling2D(pool = strides = k), H % k == W % k == 0 (PSPNet pyramid pooling) and its gradient dx = dy / k^2. */
-int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* stream);
+/* AveragePooling2D(pool = strides = k), H % k == W % k == 0 (PSPNet pyramid pooling) and its gradient dx = dy / k^2.
+ * Large windows over few outputs are reduced in two fixed-order stages through `workspace` (fp32 partials; size from the
+ * query, 0 = not needed); without it the single-stage kernel runs. */
+size_t stp_avgpool_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k);
+int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* workspace,
+                size_t workspace_bytes, void* stream);
 int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
                     int32_t accumulate, void* stream);
 /* dy <- dy * [y > 0] in place (gradient of a ReLU fused into a convolution epilogue); count % 4 == 0 */
@@ -243,11 +247,14 @@ int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W
 int stp_upsample2x_add(void* x, const void* m, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 /* tf.image.resize_bilinear(align_corners=False) of TF 1.x by an integer factor (src = dst / factor, no half-pixel offset) -
  * Keras 2.2.4's K.resize_images(interpolation='bilinear').  x [N,H,W,C] -> channels [coff, coff+C) of y [N,H*f,W*f,ldo]
- * (Concatenate of resized maps without a copy; factor 1 = strided copy).  The gradient is a fixed-order gather. */
+ * (Concatenate of resized maps without a copy; factor 1 = strided copy).  The gradient is a fixed-order gather: one
+ * workgroup per input pixel over the (2f)^2 outputs that may read it, split further through `workspace` (fp32 partials,
+ * size from the query, 0 = not needed) when a few pixels collect a whole map (PSPNet level 1: 1x1 -> 96x96). */
 int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
                         int32_t coff, int32_t dtype, void* stream);
+size_t stp_resize_bilinear_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor);
 int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
-                            int32_t coff, int32_t dtype, int32_t accumulate, void* stream);
+                            int32_t coff, int32_t dtype, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Bias gradient: out[c] (+)= sum over rows of x[rows][C]; and the in-place tensor add used where two
  * gradient paths meet outside a GEMM epilogue.  workspace as for stp_bn_stats. */

@@ -3,10 +3,12 @@ import sys, json, numpy as np, torch
 sys.path.insert(0, ".")
 from segmentation_training_pipeline_amd.backend import HipSegModel
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
-m = HipSegModel("Unet", "resnet34", (512, 512, 3), 1, "sigmoid", batch=16, dtype=dt, loss="binary_crossentropy+1.0*dice_loss", use_graph=False)
+arch, bb, size, batch, classes = (sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else ("Unet", "resnet34", 512, 16, 1)
+m = HipSegModel(arch, bb, (size, size, 3), classes, "sigmoid" if classes == 1 else "softmax", batch=batch, dtype=dt,
+                loss="binary_crossentropy+1.0*dice_loss" if classes == 1 else "categorical_crossentropy+1.0*dice_loss", use_graph=False)
 p = m.plan
 rng = np.random.RandomState(0)
-m.load_batch(rng.randint(0, 256, (16, 512, 512, 3)).astype(np.uint8), (rng.rand(16, 512, 512, 1) < 0.2).astype(np.uint8))
+m.load_batch(rng.randint(0, 256, (batch, size, size, 3)).astype(np.uint8), (rng.rand(batch, size, size, 1) < 0.2).astype(np.uint8))
 st = torch.cuda.current_stream()
 launches = [l for l in p.prep + p.fwd + p.bwd + p.opt if l[0] is not None]
 reps = 3
@@ -31,6 +33,9 @@ for us, name, meta in rows:
     agg[name] = agg.get(name, 0) + us
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
     print("%-28s %9.1f us" % (k, v))
+print("---- slowest launches")
+for us, name, meta in sorted(rows, key=lambda r: -r[0])[:25]:
+    print("%-28s %-28s %8.1f us" % (name, (meta or {}).get("layer", ""), us))
 print("---- GEMM launches")
 for us, name, meta in rows:
     if meta and 'flops' in meta:

@@ -73,13 +73,15 @@ SIGNATURES = {
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool2x2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool2x2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "stp_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_avgpool_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "stp_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "stp_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_relu_bwd": (i32, [vp, vp, i64, i32, vp]),
     "stp_upsample2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_upsample2x_add": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "stp_resize_bilinear_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_resize_bilinear_bwd_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "stp_resize_bilinear_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "stp_channel_sum": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
     "stp_add_inplace": (i32, [vp, vp, i64, i32, vp]),
     "stp_loss_workspace_bytes": (sz, []),

@@ -3,6 +3,7 @@
 // two-stage fixed-order reductions (per-block partials -> finalize) so results are
 // deterministic run to run.
 #include "common.h"
+#include <algorithm>
 
 #define BN_MAX_BLOCKS 1024
 
@@ -979,8 +980,140 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
-extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* stream) {
+// Large windows (PSPNet: 96x96 .. 16x16 pixels per output): one workgroup per (window, channel chunk).  VL vector lanes x
+// PL pixel lanes stride over the window with 16-byte loads; the pixel lanes are combined through LDS in a fixed order.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void avgpool_win_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int k, int VL,
+                                                          int rps, float* __restrict__ part) {
+  extern __shared__ float red[];  // [PL][VL*V]
+  const int PL = 256 / VL;
+  const int vl = threadIdx.x % VL, pl = threadIdx.x / VL;
+  const int Ho = H / k, Wo = W / k;
+  int b = blockIdx.x;
+  const int wo = b % Wo; b /= Wo;
+  const int ho = b % Ho;
+  const int n = b / Ho;
+  const int c = (blockIdx.y * VL + vl) * V;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  if (c < C && pl < PL) {
+    const T* base = x + (((int64_t)n * H + (int64_t)ho * k) * W + (int64_t)wo * k) * C + c;
+    const int r0 = blockIdx.z * rps, r1 = min(k, r0 + rps);      // window rows of this split (all of them without a workspace)
+    for (int p = r0 * k + pl; p < r1 * k; p += PL) {
+      const int dy = p / k, dx = p - dy * k;
+      float v[V];
+      ldv<T, V>(base + ((int64_t)dy * W + dx) * C, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += v[e];
+    }
+  }
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[(pl * VL + vl) * V + e] = acc[e];
+  }
+  __syncthreads();
+  const int t = threadIdx.x, cc = blockIdx.y * VL * V + t;
+  if (t < VL * V && cc < C) {
+    float sum = 0.f;
+    for (int l = 0; l < PL; ++l) sum += red[l * VL * V + t];
+    if (part) part[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * C + cc] = sum;
+    else Elem<T>::store(y + (((int64_t)n * Ho + ho) * Wo + wo) * C + cc, sum / (float)(k * k));
+  }
+}
+
+// second stage of a split reduction: dst[i] (+)= scale * sum_s part[s][i], s in ascending order
+template <typename T>
+__global__ __launch_bounds__(256) void split_combine_kernel(const float* __restrict__ part, int S, int64_t n, float scale, T* __restrict__ dst,
+                                                            int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float sum = 0.f;
+  for (int q = 0; q < S; ++q) sum += part[(int64_t)q * n + i];
+  sum *= scale;
+  if (accumulate) sum += Elem<T>::load(dst + i);
+  Elem<T>::store(dst + i, sum);
+}
+
+// rows-per-split of a reduction over `rows` x `cols` taps done by `blocks` workgroups: split until >= 1024 workgroups exist
+static int split_rows(int64_t blocks, int rows, int cols) {
+  if (blocks >= 1024 || (int64_t)rows * cols < 1024) return rows;
+  const int want = (int)ceil_div((int64_t)1024, blocks);
+  const int rps = (int)ceil_div(rows, want < rows ? want : rows);
+  return rps < 1 ? 1 : rps;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void avgpool_bwd_vec_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int C, int k,
+                                                              int accumulate) {
+  const int cg = C / V;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cg) return;
+  const int w = t / cg, c = (t - w * cg) * V;
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  const float inv = 1.f / (float)(k * k);
+  float g[V], o[V];
+  ldv<T, V>(dy + (((int64_t)n * (H / k) + h / k) * (W / k) + w / k) * C + c, g);
+  T* d = dx + (((int64_t)n * H + h) * W + w) * C + c;
+#pragma unroll
+  for (int e = 0; e < V; ++e) o[e] = g[e] * inv;
+  if (accumulate) {
+    ldv<T, V>(d, g);
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] += g[e];
+  }
+  stv<T, V>(d, o);
+}
+
+// vector width shared by the pooling / resize kernels: 16-byte (bf16 x8, fp32 x4) or 8-byte (bf16 x4) channel groups
+static int vec_for(int dtype, int a, int b, int c) {
+  const int m = a | b | c;
+  if (dtype == STP_BF16 && !(m & 7)) return 8;
+  return (m & 3) ? 1 : 4;
+}
+
+static int pool_vl(int cg) { return cg < 8 ? cg : 8; }   // 8 vector lanes = 128 contiguous bytes per pixel and workgroup
+
+extern "C" size_t stp_avgpool_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k) {
+  if (N <= 0 || C <= 0 || k < 1 || H % k || W % k) return 0;
+  const int64_t nwin = (int64_t)N * (H / k) * (W / k);
+  size_t need = 0;
+  for (int V = 4; V <= 8; V += 4) {                      // either vector width the launch may pick
+    const int cg = ceil_div(C, V);
+    const int rps = split_rows(nwin * ceil_div(cg, pool_vl(cg)), k, k);
+    if (rps < k) need = std::max(need, (size_t)ceil_div(k, rps) * nwin * C * sizeof(float));
+  }
+  return need;
+}
+
+extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
+  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  const int V = vec_for(dtype, C, 0, 0);
+  if (V > 1 && k * k >= 32) {
+    const int cg = C / V, VL = pool_vl(cg);
+    const int64_t nwin = (int64_t)N * (H / k) * (W / k);
+    int rps = split_rows(nwin * ceil_div(cg, VL), k, k);
+    int S = ceil_div(k, rps);
+    if (S > 1 && (!workspace || workspace_bytes < (size_t)S * nwin * C * sizeof(float))) { rps = k; S = 1; }   // no workspace: one pass
+    float* part = S > 1 ? (float*)workspace : nullptr;
+    const dim3 grid((unsigned)nwin, ceil_div(cg, VL), S);
+    const size_t lds = (size_t)(256 / VL) * VL * V * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 8) hipLaunchKernelGGL((avgpool_win_kernel<bf16_t, 8>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, k, VL, rps, part);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((avgpool_win_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, k, VL, rps, part);
+    else hipLaunchKernelGGL((avgpool_win_kernel<float, 4>), grid, dim3(256), lds, s, (const float*)x, (float*)y, H, W, C, k, VL, rps, part);
+    STP_LAUNCH_CHECK();
+    if (S > 1) {
+      const int64_t ne = nwin * C;
+      const float sc = 1.f / (float)(k * k);
+      if (dtype == STP_BF16) hipLaunchKernelGGL(split_combine_kernel<bf16_t>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, sc, (bf16_t*)y, 0);
+      else hipLaunchKernelGGL(split_combine_kernel<float>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, sc, (float*)y, 0);
+      STP_LAUNCH_CHECK();
+    }
+    return STP_OK;
+  }
   const int g = grid_for((int64_t)N * (H / k) * (W / k) * C);
   if (dtype == STP_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, k);
   else if (dtype == STP_F32) hipLaunchKernelGGL(avgpool_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, k);
@@ -992,6 +1125,17 @@ extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t
 extern "C" int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
                                int32_t accumulate, void* stream) {
   if (!dy || !dx || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
+  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  const int V = vec_for(dtype, C, 0, 0);
+  if (V > 1 && (int64_t)N * H <= 65535) {
+    const dim3 grid(ceil_div(W * (C / V), 256), N * H);
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 8) hipLaunchKernelGGL((avgpool_bwd_vec_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, k, accumulate);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((avgpool_bwd_vec_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, k, accumulate);
+    else hipLaunchKernelGGL((avgpool_bwd_vec_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)dy, (float*)dx, H, W, C, k, accumulate);
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
   const int g = grid_for((int64_t)N * H * W * C);
   if (dtype == STP_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, k, accumulate);
@@ -1092,9 +1236,109 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const T* __res
   }
 }
 
+// 16-byte channel groups: one thread per (output pixel, channel group), the same lerp order as the scalar kernel
+template <typename T, int V>
+__global__ __launch_bounds__(256) void resize_bilinear_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int f,
+                                                                  int ldo, int coff) {
+  const int cg = C / V, Ho = H * f, Wo = W * f;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cg) return;
+  const int xo = t / cg, c = (t - xo * cg) * V;
+  const int n = blockIdx.y / Ho, yo = blockIdx.y - n * Ho;
+  const float inv = 1.f / (float)f;
+  const int x0 = xo / f, y0 = yo / f;
+  const float fx = (float)(xo - x0 * f) * inv, fy = (float)(yo - y0 * f) * inv;
+  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  const T* b = x + (int64_t)n * H * W * C + c;
+  float v00[V], v01[V], v10[V], v11[V], o[V];
+  ldv<T, V>(b + ((int64_t)y0 * W + x0) * C, v00);
+  ldv<T, V>(b + ((int64_t)y0 * W + x1) * C, v01);
+  ldv<T, V>(b + ((int64_t)y1 * W + x0) * C, v10);
+  ldv<T, V>(b + ((int64_t)y1 * W + x1) * C, v11);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float top = v00[e] + (v01[e] - v00[e]) * fx, bot = v10[e] + (v11[e] - v10[e]) * fx;
+    o[e] = top + (bot - top) * fy;
+  }
+  stv<T, V>(y + (((int64_t)n * Ho + yo) * Wo + xo) * ldo + coff + c, o);
+}
+
+// gradient, one workgroup per (input pixel, channel chunk): the (2f)^2 outputs that may read the pixel are spread over TL tap
+// lanes (VL vector lanes each), tap-lane partials are combined through LDS in a fixed order - deterministic, and parallel
+// even when a whole 96x96 map is the gradient of a single pooled pixel (PSPNet level 1)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_blk_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int C,
+                                                                      int f, int ldo, int coff, int accumulate, int VL, int rps,
+                                                                      float* __restrict__ part) {
+  extern __shared__ float red[];  // [TL][VL*V]
+  const int TL = 256 / VL;
+  const int vl = threadIdx.x % VL, tl = threadIdx.x / VL;
+  const int Ho = H * f, Wo = W * f;
+  int b = blockIdx.x;
+  const int w = b % W; b /= W;
+  const int h = b % H;
+  const int n = b / H;
+  const int c = (blockIdx.y * VL + vl) * V;
+  const float inv = 1.f / (float)f;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  if (c < C && tl < TL) {
+    const T* src = dy + (int64_t)n * Ho * Wo * ldo + coff + c;
+    const int span = 2 * f;
+    const int r0 = blockIdx.z * rps, r1 = min(span, r0 + rps);   // tap rows of this split
+    for (int t = r0 * span + tl; t < r1 * span; t += TL) {
+      const int ty = t / span, tx = t - ty * span;
+      const int yo = (h - 1) * f + ty, xo = (w - 1) * f + tx;
+      if (yo < 0 || xo < 0) continue;
+      const int y0 = yo / f, x0 = xo / f;
+      const float fy = (float)(yo - y0 * f) * inv, fx = (float)(xo - x0 * f) * inv;
+      float wy = 0.f, wx = 0.f;
+      if (y0 == h) wy += 1.f - fy;
+      if (min(y0 + 1, H - 1) == h) wy += fy;
+      if (x0 == w) wx += 1.f - fx;
+      if (min(x0 + 1, W - 1) == w) wx += fx;
+      const float wgt = wy * wx;
+      if (wgt == 0.f) continue;
+      float v[V];
+      ldv<T, V>(src + ((int64_t)yo * Wo + xo) * ldo, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += wgt * v[e];
+    }
+  }
+  if (tl < TL) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[(tl * VL + vl) * V + e] = acc[e];
+  }
+  __syncthreads();
+  const int t = threadIdx.x, cc = blockIdx.y * VL * V + t;
+  if (t < VL * V && cc < C) {
+    float sum = 0.f;
+    for (int l = 0; l < TL; ++l) sum += red[l * VL * V + t];
+    if (part) {
+      part[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * C + cc] = sum;
+    } else {
+      T* d = dx + (((int64_t)n * H + h) * W + w) * C + cc;
+      if (accumulate) sum += Elem<T>::load(d);
+      Elem<T>::store(d, sum);
+    }
+  }
+}
+
 extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
                                    int32_t coff, int32_t dtype, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
+  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  const int V = vec_for(dtype, C, ldo, coff);
+  if (V > 1 && (int64_t)N * H * factor <= 65535) {
+    const dim3 grid(ceil_div(W * factor * (C / V), 256), N * H * factor);
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 8) hipLaunchKernelGGL((resize_bilinear_vec_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, factor, ldo, coff);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((resize_bilinear_vec_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, factor, ldo, coff);
+    else hipLaunchKernelGGL((resize_bilinear_vec_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, H, W, C, factor, ldo, coff);
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
   const int g = grid_for((int64_t)N * H * factor * W * factor * C);
   if (dtype == STP_BF16) hipLaunchKernelGGL(resize_bilinear_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_bilinear_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, factor, ldo, coff);
@@ -1103,9 +1347,49 @@ extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H,
   return STP_OK;
 }
 
+extern "C" size_t stp_resize_bilinear_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 2) return 0;
+  const int64_t npix = (int64_t)N * H * W;
+  const int span = 2 * factor;
+  size_t need = 0;
+  for (int V = 4; V <= 8; V += 4) {
+    const int cg = ceil_div(C, V);
+    const int rps = split_rows(npix * ceil_div(cg, pool_vl(cg)), span, span);
+    if (rps < span) need = std::max(need, (size_t)ceil_div(span, rps) * npix * C * sizeof(float));
+  }
+  return need;
+}
+
 extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor,
-                                       int32_t ldo, int32_t coff, int32_t dtype, int32_t accumulate, void* stream) {
+                                       int32_t ldo, int32_t coff, int32_t dtype, int32_t accumulate, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
+  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  const int V = vec_for(dtype, C, ldo, coff);
+  if (V > 1 && factor >= 2) {
+    const int cg = C / V, span = 2 * factor;
+    const int64_t npix = (int64_t)N * H * W;
+    // few taps per pixel: wide channel chunks keep the tap lanes busy; many taps: 128-byte chunks and more workgroups
+    const int VL = span * span >= 256 ? pool_vl(cg) : (cg < 32 ? cg : 32);
+    int rps = VL == pool_vl(cg) ? split_rows(npix * ceil_div(cg, VL), span, span) : span;
+    int S = ceil_div(span, rps);
+    if (S > 1 && (!workspace || workspace_bytes < (size_t)S * npix * C * sizeof(float))) { rps = span; S = 1; }
+    float* part = S > 1 ? (float*)workspace : nullptr;
+    const dim3 grid((unsigned)npix, ceil_div(cg, VL), S);
+    const size_t lds = (size_t)(256 / VL) * VL * V * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 8) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 8>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part);
+    else hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<float, 4>), grid, dim3(256), lds, s, (const float*)dy, (float*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part);
+    STP_LAUNCH_CHECK();
+    if (S > 1) {
+      const int64_t ne = npix * C;
+      if (dtype == STP_BF16) hipLaunchKernelGGL(split_combine_kernel<bf16_t>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, 1.f, (bf16_t*)dx, accumulate);
+      else hipLaunchKernelGGL(split_combine_kernel<float>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, 1.f, (float*)dx, accumulate);
+      STP_LAUNCH_CHECK();
+    }
+    return STP_OK;
+  }
   const int g = grid_for((int64_t)N * H * W * C);
   if (dtype == STP_BF16) hipLaunchKernelGGL(resize_bilinear_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_bilinear_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, factor, ldo, coff, accumulate);

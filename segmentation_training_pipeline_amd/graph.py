@@ -249,6 +249,14 @@ class Plan(object):
     def _emit(self, lst, fname, *args):
         lst.append((getattr(self.lib, fname), args, fname, None))
 
+    def _scratch(self, nbytes):
+        """(pointer, bytes) of a plan-time fp32 scratch buffer for a two-stage reduction; (None, 0) if the op needs none."""
+        nbytes = int(nbytes)
+        if nbytes <= 0:
+            return None, 0
+        buf = self._alloc((nbytes // 4,), torch.float32)
+        return buf.data_ptr(), nbytes
+
     def _emit_side(self, lst, fname, *args):
         lst.append((getattr(self.lib, fname), args, fname, {"stream": 1}))
 
@@ -674,8 +682,9 @@ class Plan(object):
             o = 0
             for t, f in parts:
                 if t.needs_grad:
+                    wp, wb = self._scratch(self.lib.stp_resize_bilinear_bwd_workspace_bytes(self.N, t.H, t.W, t.C, f))
                     self._emit(self.bwd, "stp_resize_bilinear_bwd", out.grad.data_ptr(), self._gradbuf(t).data_ptr(), self.N, t.H, t.W,
-                               t.C, f, out.gradC, o, self.cdt, int(t.grad_ready))
+                               t.C, f, out.gradC, o, self.cdt, int(t.grad_ready), wp, wb)
                     t.grad_ready = True
                 o += t.C
 
@@ -696,8 +705,9 @@ class Plan(object):
         def back():
             if not (x.needs_grad and out.grad_ready):
                 return
+            wp, wb = self._scratch(self.lib.stp_resize_bilinear_bwd_workspace_bytes(self.N, x.H, x.W, x.gradC, factor))
             self._emit(self.bwd, "stp_resize_bilinear_bwd", out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.gradC,
-                       factor, x.gradC, 0, self.cdt, int(x.grad_ready))
+                       factor, x.gradC, 0, self.cdt, int(x.grad_ready), wp, wb)
             x.grad_ready = True
 
         self._tape.append(back)
@@ -840,7 +850,8 @@ class Plan(object):
         self._use(x)
         if self.dry:
             return out
-        self._emit(self.fwd, "stp_avgpool", x.buf.data_ptr(), out.buf.data_ptr(), self.N, x.H, x.W, x.C, k, self.cdt)
+        wp, wb = self._scratch(self.lib.stp_avgpool_workspace_bytes(self.N, x.H, x.W, x.C, k))
+        self._emit(self.fwd, "stp_avgpool", x.buf.data_ptr(), out.buf.data_ptr(), self.N, x.H, x.W, x.C, k, self.cdt, wp, wb)
         if not self.training:
             return out
 

@@ -605,7 +605,7 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
     for acc in (0, 1):
         base = q(rng.randn(n, h, w, c), dtype)
         dx = dev(base, dtype)
-        _lib.call("stp_resize_bilinear_bwd", ops.ptr(dev(gy, dtype)), ops.ptr(dx), n, h, w, c, factor, ldo, coff, ops.dt(dx), acc, ops.stream())
+        _lib.call("stp_resize_bilinear_bwd", ops.ptr(dev(gy, dtype)), ops.ptr(dx), n, h, w, c, factor, ldo, coff, ops.dt(dx), acc, None, 0, ops.stream())
         want = xt.grad.permute(0, 2, 3, 1).numpy() + (base if acc else 0)
         np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
     # PSPNet pyramid pooling: AveragePooling2D(k, k) and its gradient
@@ -616,7 +616,7 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
     pr.backward(torch.from_numpy(gyp).permute(0, 3, 1, 2))
     yp, dxp = torch.empty((n, 2, 2, 8), dtype=TD[dtype], device=DEV), torch.empty((n, 6, 6, 8), dtype=TD[dtype], device=DEV)
     xpd = dev(xp, dtype)
-    _lib.call("stp_avgpool", ops.ptr(xpd), ops.ptr(yp), n, 6, 6, 8, 3, ops.dt(xpd), ops.stream())
+    _lib.call("stp_avgpool", ops.ptr(xpd), ops.ptr(yp), n, 6, 6, 8, 3, ops.dt(xpd), None, 0, ops.stream())
     _lib.call("stp_avgpool_bwd", ops.ptr(dev(gyp, dtype)), ops.ptr(dxp), n, 6, 6, 8, 3, ops.dt(xpd), 0, ops.stream())
     np.testing.assert_allclose(host(yp), pr.detach().permute(0, 2, 3, 1).numpy(), atol=tol(xp, dtype, 0.5))
     np.testing.assert_allclose(host(dxp), xpt.grad.permute(0, 2, 3, 1).numpy(), atol=tol(gyp, dtype, 0.5))
@@ -625,6 +625,59 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
     xd2 = dev(xa, dtype)
     _lib.call("stp_upsample2x_add", ops.ptr(xd2), ops.ptr(dev(ma, dtype)), n, 6, 8, 16, ops.dt(xd2), ops.stream())
     np.testing.assert_allclose(host(xd2), xa + np_ops.upsample2x(ma), atol=tol(xa, dtype, 1.0))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("geom", [(1, 1, 24, 320), (2, 2, 12, 72), (3, 3, 8, 40), (6, 6, 4, 24), (5, 7, 8, 20), (3, 2, 6, 3), (12, 12, 8, 24)])
+def test_pyramid_pooling_geometry_resize_and_pool(ops, dtype, geom):
+    """PSPNet's pyramid at its real aspect: a (H x W) pooled map blown up by a large factor (level 1 is a single pixel whose
+    gradient sums a whole feature map), channel counts that take the 16-byte (x8), 8-byte (x4) and scalar paths, and the
+    window-per-workgroup average pooling with k*k >= 32."""
+    from oracle import nets as onets
+    from segmentation_training_pipeline_amd import _lib
+    h, w, f, c = geom
+    n = 2
+    rng = np.random.RandomState(43)
+    x = q(rng.randn(n, h, w, c), dtype)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = onets.resize_bilinear_tf1(xt, f)
+    gy = q(rng.randn(n, h * f, w * f, c), dtype)
+    ref.backward(torch.from_numpy(gy).permute(0, 3, 1, 2))
+    xd = dev(x, dtype)
+    y = torch.empty((n, h * f, w * f, c), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_resize_bilinear", ops.ptr(xd), ops.ptr(y), n, h, w, c, f, c, 0, ops.dt(xd), ops.stream())
+    np.testing.assert_allclose(host(y), ref.detach().permute(0, 2, 3, 1).numpy(), atol=tol(x, dtype, 0.5))
+    wsb = int(_lib.load().stp_resize_bilinear_bwd_workspace_bytes(n, h, w, c, f))
+    assert wsb > 0 or 4 * f * f < 1024                       # the large-factor cases do take the split path
+    ws = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=DEV)
+    for acc, use_ws in ((0, True), (1, True), (0, False), (1, False)):
+        base = q(rng.randn(n, h, w, c) * f, dtype)
+        dx = dev(base, dtype)
+        _lib.call("stp_resize_bilinear_bwd", ops.ptr(dev(gy, dtype)), ops.ptr(dx), n, h, w, c, f, c, 0, ops.dt(dx), acc,
+                  ops.ptr(ws) if use_ws and wsb else None, wsb if use_ws else 0, ops.stream())
+        want = xt.grad.permute(0, 2, 3, 1).numpy() + (base if acc else 0)
+        np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
+    # the pooling that produced such a map: window f x f over the (h*f, w*f) feature
+    feat = q(rng.randn(n, h * f, w * f, c), dtype)
+    ft = torch.from_numpy(feat).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    pr = torch.nn.functional.avg_pool2d(ft, f, f)
+    gp = q(rng.randn(n, h, w, c), dtype)
+    pr.backward(torch.from_numpy(gp).permute(0, 3, 1, 2))
+    fd = dev(feat, dtype)
+    yp = torch.empty((n, h, w, c), dtype=TD[dtype], device=DEV)
+    wsp = int(_lib.load().stp_avgpool_workspace_bytes(n, h * f, w * f, c, f))
+    wp = torch.empty(max(wsp, 4) // 4, dtype=torch.float32, device=DEV)
+    for use_ws in (True, False):
+        yp.fill_(9.0)
+        _lib.call("stp_avgpool", ops.ptr(fd), ops.ptr(yp), n, h * f, w * f, c, f, ops.dt(fd), ops.ptr(wp) if use_ws and wsp else None,
+                  wsp if use_ws else 0, ops.stream())
+        np.testing.assert_allclose(host(yp), pr.detach().permute(0, 2, 3, 1).numpy(), atol=tol(feat, dtype, 0.1))
+    for acc in (0, 1):
+        base = q(rng.randn(n, h * f, w * f, c), dtype)
+        dxp = dev(base, dtype)
+        _lib.call("stp_avgpool_bwd", ops.ptr(dev(gp, dtype)), ops.ptr(dxp), n, h * f, w * f, c, f, ops.dt(fd), acc, ops.stream())
+        want = ft.grad.permute(0, 2, 3, 1).numpy() + (base if acc else 0)
+        np.testing.assert_allclose(host(dxp), want, atol=tol(want, dtype, 1.0))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
