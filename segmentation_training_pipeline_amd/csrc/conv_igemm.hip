@@ -123,9 +123,16 @@ __device__ __forceinline__ f32x4 stored(f32x4 v, const bf16_t*) {
 // the WN waves that share the channels are combined through LDS in a fixed order.  Layout written:
 // stats[stat][channel][tile] (tile index contiguous, so the finalize reads coalesced).  The channel-tile loop
 // is the OUTER loop so that only one pair of accumulators is live at a time (register pressure).
-template <typename T, int BM, int BN, int WM, int WN>
+// PRE: the residual / BatchNormalization-backward x values of this lane's outputs were fetched before the K loop (bf16,
+// buffer-DMA kernel) - the epilogue's own loads sit behind per-fragment branches and would be latency-serialised.
+__device__ __forceinline__ f32x4 unpack_bf16x4(const u32x2 r) {
+  return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool PRE = false>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0, int wm, int wn, int lr, int lg,
-                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int tile_n) {
+                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int tile_n,
+                                         const u32x2 (*pre)[BN / WN / 16] = nullptr) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   const T* res = reinterpret_cast<const T*>(a.residual);
   float* red = reinterpret_cast<float*>(smem);  // [WN][BM][2], valid after the barrier below
@@ -144,7 +151,10 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
         f32x4 v = acc[i][j];
         if (co + 3 < a.Cout) {
           if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
-          if (res) v += load4(res + (size_t)pm * a.Cout + co);
+          if (res) {
+            if constexpr (PRE) v += unpack_bf16x4(pre[i][j]);
+            else v += load4(res + (size_t)pm * a.Cout + co);
+          }
           T* d;
           bool accum;
           if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
@@ -152,7 +162,9 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
           if (accum) v += load4(d);
           if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           if (a.bnb.x) {
-            const f32x4 xv = load4(reinterpret_cast<const T*>(a.bnb.x) + (size_t)pm * a.Cout + co);
+            f32x4 xv;
+            if constexpr (PRE) xv = unpack_bf16x4(pre[i][j]);
+            else xv = load4(reinterpret_cast<const T*>(a.bnb.x) + (size_t)pm * a.Cout + co);
             v = bnback_apply(bk, a.bnb.relu, xv, stored(v, (const T*)nullptr), ss, qq);
           }
           store4(d, v);
@@ -340,6 +352,25 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   const int lr = lane & 15, lg = lane >> 4;
 
   const int nk = (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
+  // epilogue operands (residual or the BatchNormalization-backward x; never both) fetched now: the loads are OLDER than every
+  // tile load, so the counted vmcnt waits of the K loop also cover them, and their latency hides under the whole loop
+  constexpr bool PRE = SZ == 2;
+  u32x2 pre[PRE ? TM : 1][TN];
+  if constexpr (PRE) {
+    const T* ps = a.residual ? reinterpret_cast<const T*>(a.residual) : reinterpret_cast<const T*>(a.bnb.x);
+    if (ps) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
+          const bool ok = co + 3 < a.Cout && pm < a.P;                       // others are never read; clamp keeps the load in bounds
+          pre[i][j] = *reinterpret_cast<const u32x2*>(ps + (ok ? (size_t)pm * a.Cout + co : (size_t)0));
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue_tile(s, s);
@@ -360,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }
-  epilogue<T, BM, BN, WM, WN>(a, cout0, pix0, wm, wn, lr, lg, acc, smem, tile_n);
+  epilogue<T, BM, BN, WM, WN, PRE>(a, cout0, pix0, wm, wn, lr, lg, acc, smem, tile_n, pre);
 #endif
 }
 
