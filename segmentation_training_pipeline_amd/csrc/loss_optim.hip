@@ -155,30 +155,57 @@ extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, i
 // sum 0 is the per-pixel cross-entropy.
 #define STP_MAX_CLASSES 32
 
-template <typename T>
-__device__ __forceinline__ void softmax_row(const T* z, int classes, float (&p)[STP_MAX_CLASSES]) {
+// Rows are held in registers: the class loops are unrolled to a compile-time bound CM (4, 8, 16, 24 or 32 >= classes) and
+// predicated, rows whose stride allows it are read / written as 16-byte vectors.
+template <typename T, int CM>
+__device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, float (&p)[CM]) {
+  constexpr int V = Elem<T>::VEC;
+  if (vec) {
+#pragma unroll
+    for (int v = 0; v < CM / V; ++v) {
+      if (v * V < classes) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(z + v * V);
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { p[v * V + 2 * e] = __uint_as_float(r[e] << 16); p[v * V + 2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[v * V + e] = __uint_as_float(r[e]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CM; ++c) p[c] = c < classes ? Elem<T>::load(z + c) : 0.f;
+  }
   float m = -3.4e38f;
-  for (int c = 0; c < classes; ++c) { p[c] = Elem<T>::load(z + c); m = fmaxf(m, p[c]); }
+#pragma unroll
+  for (int c = 0; c < CM; ++c) if (c < classes) m = fmaxf(m, p[c]);
   float sum = 0.f;
-  for (int c = 0; c < classes; ++c) { p[c] = expf(p[c] - m); sum += p[c]; }
+#pragma unroll
+  for (int c = 0; c < CM; ++c) { p[c] = c < classes ? expf(p[c] - m) : 0.f; sum += p[c]; }
   const float inv = 1.f / sum;
-  for (int c = 0; c < classes; ++c) p[c] *= inv;
+#pragma unroll
+  for (int c = 0; c < CM; ++c) p[c] *= inv;
 }
 
-template <typename T>
+template <typename T, int CM>
 __global__ __launch_bounds__(256) void softmax_loss_partial_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
                                                                    int64_t pixels, int classes, int ldc, float* partial) {
   float a[LOSS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int64_t per = (pixels + gridDim.x - 1) / gridDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < pixels ? i0 + per : pixels;
+  const bool vec = (ldc % Elem<T>::VEC) == 0 && CM % Elem<T>::VEC == 0;
   for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    float p[STP_MAX_CLASSES];
-    softmax_row(logits + i * ldc, classes, p);
+    float p[CM];
+    softmax_row<T, CM>(logits + i * ldc, classes, vec, p);
     const int t = target[i] < classes ? target[i] : classes - 1;
-    // Keras: p <- p / sum(p) (a no-op on a softmax up to rounding), clip to [eps, 1-eps], -sum(y log p)
-    a[0] += -logf(fminf(fmaxf(p[t], 1e-7f), 1.f - 1e-7f));
-    for (int c = 0; c < classes; ++c) {
+    float pt = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+      if (c >= classes) continue;
       const float y = c == t ? 1.f : 0.f, th = p[c] > 0.5f ? 1.f : 0.f;
+      pt = c == t ? p[c] : pt;
       a[1] += p[c];
       a[2] += y;
       a[3] += p[c] * y;
@@ -186,6 +213,8 @@ __global__ __launch_bounds__(256) void softmax_loss_partial_kernel(const T* __re
       a[5] += th * y;
       a[6] += (th == y) ? 1.f : 0.f;
     }
+    // Keras: p <- p / sum(p) (a no-op on a softmax up to rounding), clip to [eps, 1-eps], -sum(y log p)
+    a[0] += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
   }
   __shared__ float red[4][LOSS_NSUM];
 #pragma unroll
@@ -228,32 +257,85 @@ __global__ __launch_bounds__(256) void softmax_loss_finalize_kernel(const float*
   scalars[9] = (float)((s[5] + 1.0) / (s[2] + s[4] - s[5] + 1.0));
 }
 
-template <typename T>
+template <typename T, int CM>
 __global__ __launch_bounds__(256) void softmax_loss_grad_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
                                                                 int64_t pixels, int classes, int ldc, const float* scalars,
                                                                 float w_cce, float w_dice, float inv_pixels, float grad_scale,
                                                                 T* __restrict__ dl, int dlc) {
+  constexpr int V = Elem<T>::VEC;
   const float sp = scalars[5], sy = scalars[6], spy = scalars[7];
   const float den = sy + sp + 1.f;
   const float inv_den2 = 1.f / (den * den);
   const float num = 2.f * spy + 1.f;
+  const bool vec = (ldc % V) == 0 && CM % V == 0, vout = (dlc % V) == 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * 256) {
-    float p[STP_MAX_CLASSES];
-    softmax_row(logits + i * ldc, classes, p);
+    float p[CM];
+    softmax_row<T, CM>(logits + i * ldc, classes, vec, p);
     const int t = target[i] < classes ? target[i] : classes - 1;
-    const bool inr = p[t] >= 1e-7f && p[t] <= 1.f - 1e-7f;   // the clip passes no gradient outside
+    float pt = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) pt = c == t ? p[c] : pt;
+    const bool inr = pt >= 1e-7f && pt <= 1.f - 1e-7f;   // the clip passes no gradient outside
     // dice: G_c = d dice_loss / d p_c = -(2 y_c den - num) / den^2 ; dz_k = p_k (G_k - sum_c G_c p_c)
     float gp = 0.f;
-    for (int c = 0; c < classes; ++c) gp += (-(2.f * (c == t ? 1.f : 0.f) * den - num) * inv_den2) * p[c];
-    T* o = dl + i * dlc;
-    for (int c = 0; c < classes; ++c) {
+#pragma unroll
+    for (int c = 0; c < CM; ++c) gp += (-(2.f * (c == t ? 1.f : 0.f) * den - num) * inv_den2) * p[c];   // p[c] = 0 beyond classes
+    float g[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
       const float y = c == t ? 1.f : 0.f;
-      float g = inr ? w_cce * (p[c] - y) * inv_pixels : 0.f;
-      g += w_dice * p[c] * ((-(2.f * y * den - num) * inv_den2) - gp);
-      Elem<T>::store(o + c, g * grad_scale);
+      float v = inr ? w_cce * (p[c] - y) * inv_pixels : 0.f;
+      v += w_dice * p[c] * ((-(2.f * y * den - num) * inv_den2) - gp);
+      g[c] = c < classes ? v * grad_scale : 0.f;
     }
-    for (int c = classes; c < dlc; ++c) Elem<T>::store(o + c, 0.f);
+    T* o = dl + i * dlc;
+    if (vout) {
+#pragma unroll
+      for (int v = 0; v < 32 / V; ++v) {
+        if (v * V >= dlc) break;
+        u32x4 r = {0u, 0u, 0u, 0u};
+        auto gv = [&](int idx) { return idx < CM ? g[idx % CM] : 0.f; };      // channels past the class bucket are padding
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = pack_bf16x2(gv(v * V + 2 * e), gv(v * V + 2 * e + 1));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = __float_as_uint(gv(v * V + e));
+        }
+        *reinterpret_cast<u32x4*>(o + v * V) = r;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CM; ++c) if (c < classes) Elem<T>::store(o + c, g[c]);
+      for (int c = classes; c < dlc; ++c) Elem<T>::store(o + c, 0.f);
+    }
   }
+}
+
+template <typename T, int CM>
+static void launch_softmax_loss(const T* logits, const uint8_t* target, int64_t pixels, int classes, int ldc, float w_cce, float w_dice,
+                                float* scalars, T* dl, int dlc, float grad_scale, float* partial, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((softmax_loss_partial_kernel<T, CM>), dim3(blocks), dim3(256), 0, s, logits, target, pixels, classes, ldc, partial);
+  hipLaunchKernelGGL(softmax_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)pixels,
+                     1.0 / ((double)pixels * classes), w_cce, w_dice, scalars);
+  if (dl) {
+    int64_t g = (pixels + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL((softmax_loss_grad_kernel<T, CM>), dim3((int)g), dim3(256), 0, s, logits, target, pixels, classes, ldc, scalars, w_cce,
+                       w_dice, (float)(1.0 / (double)pixels), grad_scale, dl, dlc);
+  }
+}
+
+template <typename T>
+static void dispatch_softmax_loss(const T* logits, const uint8_t* target, int64_t pixels, int classes, int ldc, float w_cce, float w_dice,
+                                  float* scalars, T* dl, int dlc, float grad_scale, float* partial, int blocks, hipStream_t s) {
+#define STP_SM(CM) launch_softmax_loss<T, CM>(logits, target, pixels, classes, ldc, w_cce, w_dice, scalars, dl, dlc, grad_scale, partial, blocks, s)
+  if (classes <= 4) STP_SM(4);
+  else if (classes <= 8) STP_SM(8);
+  else if (classes <= 16) STP_SM(16);
+  else if (classes <= 24) STP_SM(24);
+  else STP_SM(32);
+#undef STP_SM
 }
 
 extern "C" int stp_softmax_cce_dice(const void* logits, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc,
@@ -268,29 +350,16 @@ extern "C" int stp_softmax_cce_dice(const void* logits, const uint8_t* target, i
   if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
   const int blocks = (int)b;
   float* partial = (float*)workspace;
+  if (dlogits && dl_channels < classes) return STP_E_BADARG;
   if (dtype == STP_BF16)
-    hipLaunchKernelGGL(softmax_loss_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)logits, target, pixels, classes, ldc, partial);
+    dispatch_softmax_loss<bf16_t>((const bf16_t*)logits, target, pixels, classes, ldc, w_cce, w_dice, scalars, (bf16_t*)dlogits, dl_channels,
+                                  grad_scale, partial, blocks, s);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(softmax_loss_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)logits, target, pixels, classes, ldc, partial);
+    dispatch_softmax_loss<float>((const float*)logits, target, pixels, classes, ldc, w_cce, w_dice, scalars, (float*)dlogits, dl_channels,
+                                 grad_scale, partial, blocks, s);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(softmax_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)pixels,
-                     1.0 / ((double)pixels * classes), w_cce, w_dice, scalars);
-  STP_LAUNCH_CHECK();
-  if (dlogits) {
-    if (dl_channels < classes) return STP_E_BADARG;
-    int64_t g = (pixels + 255) / 256;
-    if (g > 4096) g = 4096;
-    const float inv_pixels = (float)(1.0 / (double)pixels);
-    if (dtype == STP_BF16)
-      hipLaunchKernelGGL(softmax_loss_grad_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, target, pixels, classes,
-                         ldc, scalars, w_cce, w_dice, inv_pixels, grad_scale, (bf16_t*)dlogits, dl_channels);
-    else
-      hipLaunchKernelGGL(softmax_loss_grad_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, target, pixels, classes,
-                         ldc, scalars, w_cce, w_dice, inv_pixels, grad_scale, (float*)dlogits, dl_channels);
-    STP_LAUNCH_CHECK();
-  }
   return STP_OK;
 }
 
@@ -298,8 +367,10 @@ template <typename T>
 __global__ void softmax_kernel(const T* __restrict__ logits, float* __restrict__ probs, int64_t pixels, int classes, int ldc) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * 256) {
     float p[STP_MAX_CLASSES];
-    softmax_row(logits + i * ldc, classes, p);
-    for (int c = 0; c < classes; ++c) probs[i * classes + c] = p[c];
+    softmax_row<T, STP_MAX_CLASSES>(logits + i * ldc, classes, (ldc % Elem<T>::VEC) == 0, p);
+#pragma unroll
+    for (int c = 0; c < STP_MAX_CLASSES; ++c)
+      if (c < classes) probs[i * classes + c] = p[c];
   }
 }
 
