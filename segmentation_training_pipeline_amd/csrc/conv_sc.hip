@@ -48,6 +48,21 @@ template <> struct ScMma<float> {
   }
 };
 
+// 4 channels as fetched (8 bytes of bf16 stay packed until they are used: prefetched epilogue operands cost half the registers)
+template <typename T> struct ScRaw4;
+template <> struct ScRaw4<float> {
+  f32x4 v;
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+  __device__ __forceinline__ f32x4 get() const { return v; }
+};
+template <> struct ScRaw4<bf16_t> {
+  u32x2 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x2*>(p); }
+  __device__ __forceinline__ f32x4 get() const {
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+  }
+};
+
 constexpr int SC_TH = 8, SC_TW = 32, SC_HW = SC_TW + 2, SC_HH = SC_TH + 2;
 
 template <typename T, int CIN, int TM>
@@ -143,6 +158,20 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
     // gradient of UpSampling2D(2): the wave's two tile rows are one output row (fragments f and f+2, same lane), lanes
     // lr and lr^1 one output column (quad_perm DPP); even lanes own the low-resolution pixel
     const int H2 = a.H >> 1, W2 = a.W >> 1;
+    ScRaw4<T> xpre[TM][2];
+    if (a.bnb.x) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int gy = y0 + wave * 2, gx = x0 + h2 * 16 + lr;
+        const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int co = cb + i * 16 + lg * 4;
+          const bool ok = !(lr & 1) && gy < a.H && gx < a.W && co < a.Cout;
+          xpre[i][h2].load(reinterpret_cast<const T*>(a.bnb.x) + (ok ? pm * a.Cout + co : (size_t)0));
+        }
+      }
+    }
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const int gy = y0 + wave * 2, gx = x0 + h2 * 16 + lr;
@@ -158,14 +187,27 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
         if (!own || co >= a.Cout) continue;
         T* d = out + pm * a.Cout + co;
         if (a.accumulate) v += load4(d);
-        if (a.bnb.x) {
-          const f32x4 xv = load4(reinterpret_cast<const T*>(a.bnb.x) + pm * a.Cout + co);
-          v = bnback_apply(bks[i], a.bnb.relu, xv, sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
-        }
+        if (a.bnb.x) v = bnback_apply(bks[i], a.bnb.relu, xpre[i][h2].get(), sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
         store4(d, v);
       }
     }
-  } else
+  } else {
+  // the x values of the fused BatchNormalization backward for all of this lane's outputs, issued together (clamped
+  // addresses, no control flow between them): one latency instead of one per fragment, in registers the weights just freed
+  ScRaw4<T> xpre[TM][4];
+  if (a.bnb.x) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+      const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int co = cb + i * 16 + lg * 4;
+        const bool ok = gy < a.H && gx < a.W && co + 3 < a.Cout;
+        xpre[i][f].load(reinterpret_cast<const T*>(a.bnb.x) + (ok ? pm * a.Cout + co : (size_t)0));
+      }
+    }
+  }
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
@@ -181,10 +223,7 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
         T* d = out + pm * a.Cout + co;
         if (a.accumulate) v += load4(d);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.bnb.x) {
-          const f32x4 xv = load4(reinterpret_cast<const T*>(a.bnb.x) + pm * a.Cout + co);
-          v = bnback_apply(bks[i], a.bnb.relu, xv, sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
-        }
+        if (a.bnb.x) v = bnback_apply(bks[i], a.bnb.relu, xpre[i][f].get(), sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
         store4(d, v);
         if (a.stats && !a.bnb.x) {
           const f32x4 sv = sc_stored(v, (const T*)nullptr);
@@ -202,6 +241,7 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
         }
       }
     }
+  }
   }
   if (a.stats) {
     // butterfly over the 16 pixel lanes, then the 4 waves (same channels, different rows) through LDS
