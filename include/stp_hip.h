@@ -101,6 +101,15 @@ typedef struct stp_conv_params {
    * order-independent and deterministic - instead of writing a per-tile partial: no finalize kernel; the consumer
    * (stp_bn_apply_slots / stp_bn_backward_slots) sums the few slots of each channel in its prologue. */
   int32_t stats_slots;
+  /* Fused PRODUCER BatchNormalization (small-channel kernel only): src_bn_mean != NULL means src0 holds the tensor BEFORE a
+   * training-phase BatchNormalization (+ activation src_bn_relu: 0 none, 1 ReLU, 2 ReLU6).  The kernel normalises it while
+   * staging its halo tile, with the arithmetic and rounding of stp_bn_apply, so the result equals the unfused pair bit for
+   * bit and the normalised tensor is never written to HBM.  Padding stays zero (it pads the NORMALISED tensor). */
+  const float* src_bn_mean;
+  const float* src_bn_rstd;
+  const float* src_bn_gamma; /* may be NULL */
+  const float* src_bn_beta;  /* may be NULL */
+  int32_t src_bn_relu;
 } stp_conv_params;
 
 int stp_conv2d(const stp_conv_params* p, void* stream);
@@ -133,6 +142,12 @@ typedef struct stp_wgrad_params {
   int32_t accumulate;
   int32_t dtype;
   int32_t splits;       /* 0 = auto */
+  /* as stp_conv_params.src_bn_*: src0 is the pre-normalisation tensor (small-channel weight gradient, C1 == 0 only) */
+  const float* src_bn_mean;
+  const float* src_bn_rstd;
+  const float* src_bn_gamma;
+  const float* src_bn_beta;
+  int32_t src_bn_relu;
 } stp_wgrad_params;
 
 size_t stp_conv2d_wgrad_workspace_bytes(const stp_wgrad_params* p);

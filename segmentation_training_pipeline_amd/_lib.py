@@ -28,14 +28,16 @@ class ConvParams(C.Structure):
                 ("accumulate0", i32), ("accumulate1", i32), ("relu", i32), ("dtype", i32), ("tile", i32),
                 ("stats_tiles", i32), ("stats_partial", vp),
                 ("bnb_x", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_gamma", vp), ("bnb_beta", vp), ("bnb_relu", i32),
-                ("dst_sum2x2", i32), ("stats_slots", i32)]
+                ("dst_sum2x2", i32), ("stats_slots", i32),
+                ("src_bn_mean", vp), ("src_bn_rstd", vp), ("src_bn_gamma", vp), ("src_bn_beta", vp), ("src_bn_relu", i32)]
 
 
 class WgradParams(C.Structure):
     _fields_ = [("src0", vp), ("src1", vp), ("dy", vp), ("dw", vp),
                 ("N", i32), ("Hs0", i32), ("Ws0", i32), ("Hv", i32), ("Wv", i32), ("C0", i32), ("C1", i32),
                 ("src0_mode", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
-                ("Ho", i32), ("Wo", i32), ("Cout", i32), ("accumulate", i32), ("dtype", i32), ("splits", i32)]
+                ("Ho", i32), ("Wo", i32), ("Cout", i32), ("accumulate", i32), ("dtype", i32), ("splits", i32),
+                ("src_bn_mean", vp), ("src_bn_rstd", vp), ("src_bn_gamma", vp), ("src_bn_beta", vp), ("src_bn_relu", i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/stp_hip.h

@@ -385,7 +385,7 @@ class HipSegModel(object):
         return t.buf.to(torch.float32).cpu().numpy()
 
     def activation(self, name):
-        return self.plan.tensors[name].buf.to(torch.float32).cpu().numpy()
+        return self.plan.tensor(name).buf.to(torch.float32).cpu().numpy()
 
     def set_lr(self, lr):
         self.lr.fill_(float(lr))

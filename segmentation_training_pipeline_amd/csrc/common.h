@@ -117,7 +117,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 __device__ __forceinline__ float bn_affine(float x, float scale, float shift) { return fmaf(x, scale, shift); }
 // activation fused behind a BatchNormalization: 0 none, 1 ReLU, 2 ReLU6 (K.relu(x, max_value=6): MobileNetV2 blocks).
 // bn_act_on = "the gradient passes" (strictly inside the linear range, as TF's relu6 gradient does)
-__device__ __forceinline__ float bn_act(float v, int relu) { return relu == 0 ? v : (relu == 1 ? fmaxf(v, 0.f) : fminf(fmaxf(v, 0.f), 6.f)); }
+// (one v_med3_f32 against bounds that depend only on the mode: -inf..inf, 0..inf, 0..6)
+__device__ __forceinline__ float bn_act(float v, int relu) {
+  const float lo = relu ? 0.f : -__builtin_inff(), hi = relu == 2 ? 6.f : __builtin_inff();
+  return __builtin_amdgcn_fmed3f(v, lo, hi);
+}
 __device__ __forceinline__ bool bn_act_on(float v, int relu) { return relu == 0 || (v > 0.f && (relu == 1 || v < 6.f)); }
 
 // Fused BatchNormalization sums, "slot" form: instead of one partial per pixel tile (reduced by a finalize kernel), the

@@ -25,6 +25,39 @@ struct ScArgs {
   int stat_slots;
   BnBack bnb;          // see stp_conv_params.bnb_x
   int sum2;            // see stp_conv_params.dst_sum2x2: dst is [N,H/2,W/2,Cout]
+  BnBack pbn;          // see stp_conv_params.src_bn_mean: src is normalised while it is staged (pbn.x unused)
+};
+
+// BatchNormalization (+activation) of one staged 16-byte vector: V consecutive channels with per-lane constants.  Same fma,
+// activation and bf16 rounding as bn_apply_kernel, so the staged tile equals what stp_bn_apply would have stored.
+template <typename T> struct ScStageBn;
+template <> struct ScStageBn<float> {
+  f32x4 sc, sh;
+  __device__ __forceinline__ void load(const BnBack& b, int c) { const BnBackCh k = bnback_load(b, c); sc = k.sc; sh = k.sh; }
+  __device__ __forceinline__ u32x4 apply(const u32x4& r, int relu) const {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(bn_act(bn_affine(__uint_as_float(r[e]), sc[e], sh[e]), relu));
+    return o;
+  }
+};
+template <> struct ScStageBn<bf16_t> {
+  f32x2 sc[4], sh[4];   // channel pairs: one v_pk_fma_f32 each
+  __device__ __forceinline__ void load(const BnBack& b, int c) {
+    const BnBackCh k0 = bnback_load(b, c), k1 = bnback_load(b, c + 4);
+    sc[0] = f32x2{k0.sc[0], k0.sc[1]}; sc[1] = f32x2{k0.sc[2], k0.sc[3]}; sc[2] = f32x2{k1.sc[0], k1.sc[1]}; sc[3] = f32x2{k1.sc[2], k1.sc[3]};
+    sh[0] = f32x2{k0.sh[0], k0.sh[1]}; sh[1] = f32x2{k0.sh[2], k0.sh[3]}; sh[2] = f32x2{k1.sh[0], k1.sh[1]}; sh[3] = f32x2{k1.sh[2], k1.sh[3]};
+  }
+  __device__ __forceinline__ u32x4 apply(const u32x4& r, int relu) const {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f32x2 v = {__uint_as_float(r[e] << 16), __uint_as_float(r[e] & 0xffff0000u)};
+      v = __builtin_elementwise_fma(v, sc[e], sh[e]);               // = bn_affine per element (single rounding)
+      o[e] = pack_bf16x2(bn_act(v.x, relu), bn_act(v.y, relu));
+    }
+    return o;
+  }
 };
 
 __device__ __forceinline__ f32x4 sc_stored(f32x4 v, const float*) { return v; }
@@ -89,13 +122,19 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
   // ---- stage the halo tile -----------------------------------------------------------------
   const int sh = a.up ? 1 : 0;
   const char* img = a.src + (size_t)n * a.Hs * a.Ws * PIXB;
+  static_assert(256 % VPP == 0, "a thread stages the same channel vector in every pass");
+  const bool pbn = a.pbn.mean != nullptr;
+  ScStageBn<T> sbn;
+  if (pbn) sbn.load(a.pbn, (tid % VPP) * VEC);
   for (int v = tid; v < SC_HH * SC_HW * VPP; v += 256) {
     const int pix = v / VPP, cv = v - pix * VPP;
     const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     u32x4 val = {0u, 0u, 0u, 0u};
-    if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+    if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
       val = *reinterpret_cast<const u32x4*>(img + ((size_t)(gy >> sh) * a.Ws + (gx >> sh)) * PIXB + cv * 16);
+      if (pbn) val = sbn.apply(val, a.pbn.relu);
+    }
     *reinterpret_cast<u32x4*>(halo + v * 16) = val;
   }
 
@@ -323,6 +362,9 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
   a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
   a.sum2 = p->dst_sum2x2;
+  a.pbn.x = nullptr; a.pbn.mean = p->src_bn_mean; a.pbn.rstd = p->src_bn_rstd; a.pbn.gamma = p->src_bn_gamma; a.pbn.beta = p->src_bn_beta;
+  a.pbn.relu = p->src_bn_relu;
+  if (a.pbn.mean && !a.pbn.rstd) return STP_E_BADARG;
   if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || (p->accumulate0 && !a.sum2) || p->relu)) return STP_E_BADARG;
   if (a.sum2 && ((p->Cout & 3) || (a.H & 1) || (a.W & 1) || p->bias || p->relu || (a.stats && !a.bnb.x))) return STP_E_BADARG;
   const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
@@ -348,6 +390,7 @@ struct ScWgArgs {
   int N, H, W, Hs, Ws, Cout, up;
   int tiles_x, tiles_y, ntiles;
   int ctot, coff;   // this source occupies channels [coff, coff+CIN) of the Ctot-channel concatenated input
+  BnBack pbn;       // see stp_wgrad_params.src_bn_mean
 };
 
 template <typename T, int CIN, int COUT>
@@ -366,6 +409,11 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int sh = a.up ? 1 : 0;
+
+  static_assert(256 % (CIN / VEC) == 0, "a thread stages the same channel vector in every pass");
+  const bool pbn = a.pbn.mean != nullptr;
+  ScStageBn<T> sbn;
+  if (pbn) sbn.load(a.pbn, (tid % (CIN / VEC)) * VEC);
 
   f32x4 acc[3][TMo][TNi];
 #pragma unroll
@@ -388,8 +436,10 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
       const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       u32x4 val = {0u, 0u, 0u, 0u};
-      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
         val = *reinterpret_cast<const u32x4*>(img + ((size_t)(gy >> sh) * a.Ws + (gx >> sh)) * PIXB + cv * 16);
+        if (pbn) val = sbn.apply(val, a.pbn.relu);
+      }
       *reinterpret_cast<u32x4*>(halo + v * 16) = val;
     }
     const char* dimg = a.dy + (size_t)n * a.H * a.W * DYB;
@@ -546,11 +596,15 @@ extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, 
   a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Cout = p->Cout;
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH); a.ntiles = a.N * a.tiles_x * a.tiles_y;
   a.ctot = p->C0 + p->C1;
+  a.pbn.x = nullptr; a.pbn.mean = p->src_bn_mean; a.pbn.rstd = p->src_bn_rstd; a.pbn.gamma = p->src_bn_gamma; a.pbn.beta = p->src_bn_beta;
+  a.pbn.relu = p->src_bn_relu;
+  if (a.pbn.mean && (!a.pbn.rstd || p->C1 > 0)) return STP_E_BADARG;
   const int blocks = stp_wgrad_sc_slabs(p);
   hipStream_t s = (hipStream_t)stream;
   a.src = (const char*)p->src0; a.Hs = p->Hs0; a.Ws = p->Ws0; a.up = p->src0_mode == STP_SRC_NEAREST2X; a.coff = 0;
   int rc = p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C0, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C0, p->Cout, blocks, s);
   if (rc != STP_OK || p->C1 == 0) return rc;
+  a.pbn.mean = nullptr;
   a.src = (const char*)p->src1; a.Hs = p->Hv; a.Ws = p->Wv; a.up = 0; a.coff = p->C0;
   return p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C1, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C1, p->Cout, blocks, s);
 }

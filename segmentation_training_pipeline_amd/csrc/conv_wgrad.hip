@@ -673,6 +673,7 @@ extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspa
     if (!workspace || stp_conv2d_wgrad_workspace_bytes(p) > workspace_bytes) return STP_E_WORKSPACE;
     return stp_wgrad_sc_partial(p, workspace, stream);
   }
+  if (p && p->src_bn_mean) return STP_E_BADARG;   // fused producer BatchNormalization: small-channel kernel only
   WgradArgs a;
   WgradPlan w;
   bool c4, dma;

@@ -99,6 +99,9 @@ class Plan(object):
         self.step_state = None
         # fused BatchNormalization sums in fixed-point slots (stp_conv_params.stats_slots): no finalize kernels
         self.bn_slots = os.environ.get("STP_BN_SLOTS", "0") == "1"   # measured: no gain over the finalize kernels, kept opt-in
+        # BatchNormalization whose only consumers are small-channel convolutions: normalised inside their halo staging
+        # (stp_conv_params.src_bn_mean), the normalised tensor is never written
+        self.fuse_bn_sc = os.environ.get("STP_FUSE_BN_SC", "1") != "0"
         self.bn_slots_max_rows = int(os.environ.get("STP_BN_SLOTS_MAXROWS", "1073741824"))
         self._slot_need = 0          # int64 elements, counted in the dry pass
         self._slot_used = 0
@@ -135,6 +138,7 @@ class Plan(object):
         self._prep_layers = []
         self.tensors = OrderedDict()
         net_fn(self)
+        self._fuse_bn_into_consumers()
         self._finish_prep()
         if self.training:
             # bwd_marks[i] = (launches issued after the i-th backward closure, lowest gradient offset written so far):
@@ -248,6 +252,38 @@ class Plan(object):
     # meta carries the layer name and the ALGORITHMIC flops of GEMM launches for bench.py's roofline.
     def _emit(self, lst, fname, *args):
         lst.append((getattr(self.lib, fname), args, fname, None))
+
+    def _fuse_bn_into_consumers(self):
+        """Drops the stp_bn_apply launch of every BatchNormalization all of whose consumers are small-channel convolutions
+        (forward and weight gradient read the pre-normalisation tensor and normalise it while staging; the data gradient and
+        the BatchNormalization backward never read the normalised tensor).  ``tensor(name)`` still materialises it on demand."""
+        drop = set()
+        for t in self.tensors.values():
+            rec, cons = t.meta.get("apply_rec"), t.meta.get("sc_consumers")
+            if rec is None or not cons or len(cons) != t.meta.get("uses", 0):
+                continue
+            pre, mean, rstd, gp, beta, relu = t.meta["bn"]
+            for cp, wp in cons:
+                cp.src0 = pre
+                cp.src_bn_mean, cp.src_bn_rstd, cp.src_bn_gamma, cp.src_bn_beta, cp.src_bn_relu = mean, rstd, gp, beta, relu
+                wp.src_bn_mean, wp.src_bn_rstd, wp.src_bn_gamma, wp.src_bn_beta, wp.src_bn_relu = mean, rstd, gp, beta, relu
+            t.meta["deferred"] = rec
+            t.meta["src_override"] = pre
+            drop.add(id(rec))
+        if drop:
+            self.fwd = [r for r in self.fwd if id(r) not in drop]
+
+    def tensor(self, name):
+        """The named tensor with its buffer valid: a normalised tensor that only exists inside its consumers' staging is
+        computed here with the launch the plan dropped (inspection / tests; not part of the step)."""
+        t = self.tensors[name]
+        rec = t.meta.get("deferred")
+        if rec is not None:
+            fn, args = rec[0], rec[1]
+            rc = fn(*args, torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise _lib.StpError("%s failed with %d" % (rec[2], rc))
+        return t
 
     def _scratch(self, nbytes):
         """(pointer, bytes) of a plan-time fp32 scratch buffer for a two-stage reduction; (None, 0) if the op needs none."""
@@ -365,6 +401,9 @@ class Plan(object):
             self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn,
                        mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu), 0.0)
         out.meta["bn"] = (x.buf.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gp, self._pptr(beta), int(relu))
+        if self.fuse_bn_sc and slots is None:
+            out.meta["apply_rec"] = self.fwd[-1]
+            out.meta["sc_consumers"] = []
 
         def back():
             if not out.needs_grad or not out.grad_ready:
@@ -468,6 +507,9 @@ class Plan(object):
                             src1=src1.buf if src1 is not None else None,
                             mode=src_mode, KH=k, KW=KWp, stride=stride, pad=pad,
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
+        if (self.training and x.meta.get("apply_rec") is not None and src1 is None and residual is None and not transpose and not stem
+                and self.lib.stp_conv2d_sc_eligible(C.byref(p)) and (not w.trainable or self.lib.stp_wgrad_sc_eligible(C.byref(wp)))):
+            x.meta["sc_consumers"].append((p, wp))       # see _fuse_bn_into_consumers
         if b is not None:
             p.bias = self._pptr(b)
         if relu:
@@ -521,7 +563,7 @@ class Plan(object):
                     wp.dw = dwp.data_ptr()
                 else:
                     wp.dw = self._gptr(w)
-                wp.src0, wp.src1, wp.dy = x.buf.data_ptr(), (src1.buf.data_ptr() if src1 is not None else None), dy.data_ptr()
+                wp.src0, wp.src1, wp.dy = x.meta.get("src_override") or x.buf.data_ptr(), (src1.buf.data_ptr() if src1 is not None else None), dy.data_ptr()
                 self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
                                                 "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp)))})
                 if padded:

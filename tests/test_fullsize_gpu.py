@@ -50,6 +50,16 @@ def headline():
     del m
 
 
+class _Tensors:
+    """plan.tensors with every buffer valid (a BatchNormalization output fused into its consumers is materialised on demand)."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __getitem__(self, name):
+        return self.plan.tensor(name)
+
+
 def kernel(w, name):
     """Keras HWIO -> torch OIHW, rounded to the bf16 compute copy the kernels read."""
     return bf16r(w[name + "/kernel"].permute(3, 2, 0, 1).contiguous())
@@ -75,7 +85,7 @@ FWD_LAYERS = [
 @pytest.mark.parametrize("layer,src,stride,pad", FWD_LAYERS)
 def test_headline_conv_forward_layers(headline, layer, src, stride, pad):
     m, w, _ = headline
-    ts = m.plan.tensors
+    ts = _Tensors(m.plan)
     ref = conv_ref(nchw(ts[src].buf), kernel(w, layer), stride, pad)
     got = ts[layer].buf.float()
     assert got.shape == ref.shape
@@ -85,7 +95,7 @@ def test_headline_conv_forward_layers(headline, layer, src, stride, pad):
 
 def test_headline_stem_residual_concat_and_head(headline):
     m, w, _ = headline
-    ts = m.plan.tensors
+    ts = _Tensors(m.plan)
     # stem: 7x7 stride 2 over the 3 image channels of bn_data (the 4th channel carries the constant of stp_stem_beta_grad)
     ref = conv_ref(nchw(ts["bn_data"].buf[..., :3]), kernel(w, "conv0"), 2, 3)
     assert rel_l2(ts["conv0"].buf.float(), ref) < 3e-3
@@ -111,7 +121,7 @@ def test_headline_stem_residual_concat_and_head(headline):
 def test_headline_batchnorm_forward_layers(headline, bn, src, eps):
     """Training-phase statistics over all 16*H*W positions (taken from the conv epilogue in the product), affine + ReLU."""
     m, w, _ = headline
-    ts = m.plan.tensors
+    ts = _Tensors(m.plan)
     x = ts[src].buf.float()
     mean = x.double().mean(dim=(0, 1, 2))
     var = (x.double() - mean).pow(2).mean(dim=(0, 1, 2))
@@ -125,7 +135,7 @@ def test_headline_batchnorm_forward_layers(headline, bn, src, eps):
 def test_headline_weight_gradient_layers(headline, layer, src, stride, pad):
     """dW = sum over 16*Ho*Wo pixels of dY (x) X: split-K slabs + fixed-order reduce (DMA kernel / small-channel kernel)."""
     m, w, g = headline
-    ts = m.plan.tensors
+    ts = _Tensors(m.plan)
     a = nchw(ts[src].buf)
     dy = nchw(ts[layer].grad)
     k = kernel(w, layer).requires_grad_(True)
@@ -149,7 +159,7 @@ def test_headline_data_gradient_through_batchnorm(headline, conv_in, bn, conv_ou
     layers only: an encoder unit's dY buffer is handed on as the residual gradient and accumulated into, so it no longer
     holds dY when the step ends (the encoder's data-gradient GEMMs are the same kernels, covered at op level)."""
     m, w, g = headline
-    ts = m.plan.tensors
+    ts = _Tensors(m.plan)
     eps = 1e-3 if bn.startswith("decoder") else 2e-5
     x = nchw(ts[conv_in].buf).clone().requires_grad_(True)
     gam = w[bn + "/gamma"].float().clone().requires_grad_(True)

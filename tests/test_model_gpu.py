@@ -68,8 +68,13 @@ def test_fp32_step_matches_oracle(arch, backbone):
     m.set_weights(P)
     taps = {}
     o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
-    met = m.train_on_batch(x, y)
+    # forward + backward, taps, THEN the optimizer: a BatchNormalization output that lives only inside its consumers' staging
+    # is materialised on demand with the current gamma / beta (graph.Plan.tensor), so it must be read before they move
+    m.load_batch(x, y)
+    m.forward_backward()
     bad = first_bad_tap(m, taps, 2e-4)
+    m.apply_gradients()
+    met = m.metrics()
     assert bad is None, bad
     # north-star bar 1e-3 (stated for U-Net/ResNet34).  Linknet over the 2048-channel encoder - 3 x (conv, BN over as few as
     # 128 values) per decoder stage on top of 50 layers - lands at 1.3e-3 between two fp32 summation orders: 2e-3 there.
@@ -148,8 +153,13 @@ def test_fp32_vgg16_unet_step_matches_oracle():
     m.set_weights(P)
     taps = {}
     o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
-    met = m.train_on_batch(x, y)
+    # forward + backward, taps, THEN the optimizer: a BatchNormalization output that lives only inside its consumers' staging
+    # is materialised on demand with the current gamma / beta (graph.Plan.tensor), so it must be read before they move
+    m.load_batch(x, y)
+    m.forward_backward()
     bad = first_bad_tap(m, taps, 2e-4)
+    m.apply_gradients()
+    met = m.metrics()
     assert bad is None, bad
     np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
     assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 1e-5 * max(1.0, abs(o["loss"]))
@@ -180,8 +190,13 @@ def test_fp32_transpose_decoder_step_matches_oracle():
         np.testing.assert_array_equal(v, P[k], err_msg=k)
     taps = {}
     o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
-    met = m.train_on_batch(x, y)
+    # forward + backward, taps, THEN the optimizer: a BatchNormalization output that lives only inside its consumers' staging
+    # is materialised on demand with the current gamma / beta (graph.Plan.tensor), so it must be read before they move
+    m.load_batch(x, y)
+    m.forward_backward()
     bad = first_bad_tap(m, taps, 2e-4)
+    m.apply_gradients()
+    met = m.metrics()
     assert bad is None, bad
     np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
     assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 1e-5 * max(1.0, abs(o["loss"]))

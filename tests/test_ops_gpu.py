@@ -482,6 +482,66 @@ def test_batchnorm_sums_in_fixed_point_slots(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 19, 45, 16, 16, 0, 1), (2, 20, 34, 16, 8, 1, 1), (1, 12, 40, 8, 16, 0, 0), (2, 16, 32, 32, 16, 1, 2)])
+def test_producer_batchnorm_fused_into_small_channel_staging(ops, dtype, case):
+    """stp_conv_params.src_bn_* / stp_wgrad_params.src_bn_*: the small-channel forward and weight-gradient kernels normalise the
+    pre-BatchNormalization tensor while staging it.  Bit-identical to stp_bn_apply followed by the plain kernels (same fma,
+    activation and rounding), with and without nearest-2x upsampling; the generic kernels refuse the fields."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co, up, relu = case
+    if dtype == "fp32" and ci > 16:
+        pytest.skip("fp32 small-channel kernel: Cin <= 16")
+    rng = np.random.RandomState(77)
+    rows = n * h * w
+    ypre = q(rng.randn(n, h, w, ci) * 2 + 0.5, dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    mean, rstd = f(ypre.reshape(-1, ci).mean(0)), f(1.0 / np.sqrt(ypre.reshape(-1, ci).var(0) + 1e-3))
+    gamma, beta = f(rng.rand(ci) + 0.5), f(rng.randn(ci) * 0.3)
+    yd = dev(ypre, dtype)
+    act = torch.empty_like(yd)
+    ops.bn_apply(yd, act, rows, ci, ci, mean, rstd, gamma, beta, relu=relu)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    H, W = (2 * h, 2 * w) if up else (h, w)
+    mk = lambda src, dst: ops.conv_params(src, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=H, Wv=W, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=H, Wo=W,
+                                          Cout=co, dtype=ops.dt(dst), mode=(ops.SRC_NEAREST2X if up else ops.SRC_DIRECT))
+    ref, got = torch.empty((n, H, W, co), dtype=TD[dtype], device=DEV), torch.empty((n, H, W, co), dtype=TD[dtype], device=DEV)
+    P0 = mk(act, ref)
+    assert _lib.load().stp_conv2d_sc_eligible(P0)
+    ops.conv2d(P0)
+    P1 = mk(yd, got)
+    P1.src_bn_mean, P1.src_bn_rstd, P1.src_bn_gamma, P1.src_bn_beta, P1.src_bn_relu = ops.ptr(mean), ops.ptr(rstd), ops.ptr(gamma), ops.ptr(beta), relu
+    ops.conv2d(P1)
+    np.testing.assert_array_equal(host(got), host(ref))
+    P1.tile = 5                                                            # a GEMM tile: the generic kernel must refuse
+    assert _lib.load().stp_conv2d(P1, ops.stream()) == -1
+    # weight gradient
+    dy = dev(q(rng.randn(n, H, W, co), dtype), dtype)
+    def wgrad(src, fused):
+        wp = _lib.WgradParams()
+        wp.src0, wp.dy = ops.ptr(src), ops.ptr(dy)
+        wp.N, wp.Hs0, wp.Ws0, wp.Hv, wp.Wv, wp.C0, wp.C1 = n, h, w, H, W, ci, 0
+        wp.src0_mode = ops.SRC_NEAREST2X if up else ops.SRC_DIRECT
+        wp.KH, wp.KW, wp.stride, wp.pad, wp.Ho, wp.Wo, wp.Cout = 3, 3, 1, 1, H, W, co
+        wp.accumulate, wp.dtype, wp.splits = 0, ops.dt(src), 0
+        if fused:
+            wp.src_bn_mean, wp.src_bn_rstd, wp.src_bn_gamma, wp.src_bn_beta, wp.src_bn_relu = ops.ptr(mean), ops.ptr(rstd), ops.ptr(gamma), ops.ptr(beta), relu
+        dw = torch.zeros(co * 9 * ci, dtype=torch.float32, device=DEV)
+        wp.dw = ops.ptr(dw)
+        nb = int(_lib.load().stp_conv2d_wgrad_workspace_bytes(wp))
+        ws = torch.empty(max(nb, 4) // 4 + 4, dtype=torch.float32, device=DEV)
+        rc = _lib.load().stp_conv2d_wgrad(wp, ops.ptr(ws), ws.numel() * 4, ops.stream())
+        return rc, host(dw), wp, ws
+    if _lib.load().stp_wgrad_sc_eligible(wgrad(act, False)[2]):
+        rc0, d0, _, _ = wgrad(act, False)
+        rc1, d1, wp1, ws1 = wgrad(yd, True)
+        assert rc0 == 0 and rc1 == 0
+        np.testing.assert_array_equal(d1, d0)
+        wp1.splits = 2                                                     # forces the GEMM plan, which has no fused producer BN
+        assert _lib.load().stp_conv2d_wgrad_partial(wp1, ops.ptr(ws1), ws1.numel() * 4, 1, ops.stream()) == -1
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
 def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
     """stp_conv_params.dst_sum2x2: the data-gradient convolution of an UpSampling2D(2) input writes the 2x2 block sums
