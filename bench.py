@@ -45,6 +45,8 @@ def kernel_key(name, meta, dtype):
         tile = meta["tile"]
         if tile == 512:
             return "conv_sc_kernel<%s>" % t
+        if tile == 768:
+            return "conv_stem_kernel"
         if tile >= 256:  # buffer-DMA kernel, per-lane tap (small channel counts), 2 stages
             return "conv_igemm_ut_kernel<%s, %s, 2, false>" % (t, CONV_TILES[tile - 256])
         if tile >= 64:   # uniform-tap buffer-DMA kernel: tile = 32*STAGES + base tile

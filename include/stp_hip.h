@@ -123,6 +123,10 @@ int stp_conv2d_tile_for(const stp_conv_params* p);
  * stp_conv2d uses it automatically when stp_conv2d_sc_eligible(p) != 0 (tile id 512). */
 int stp_conv2d_sc_eligible(const stp_conv_params* p);
 int stp_conv2d_sc(const stp_conv_params* p, void* stream);
+/* The ResNet stem (classification_models conv0: 7x7 / stride 2 / pad 3, 3+1 input channels -> 64, bf16): halo-tile kernel,
+ * used by stp_conv2d automatically when eligible (tile id 768); optional fused BatchNormalization sums (stats_partial). */
+int stp_conv2d_stem_eligible(const stp_conv_params* p);
+int stp_conv2d_stem(const stp_conv_params* p, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Weight gradient (Conv2DBackpropFilter).  dW[co][(kh*KW+kw)*(C0+C1)+c] =

@@ -48,6 +48,8 @@ SIGNATURES = {
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc": (i32, [C.POINTER(ConvParams), vp]),
+    "stp_conv2d_stem_eligible": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_stem": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_wgrad_workspace_bytes": (sz, [C.POINTER(WgradParams)]),
     "stp_conv2d_wgrad": (i32, [C.POINTER(WgradParams), vp, sz, vp]),
     "stp_conv2d_wgrad_partial": (i32, [C.POINTER(WgradParams), vp, sz, i32, vp]),

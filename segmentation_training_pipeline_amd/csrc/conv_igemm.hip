@@ -703,11 +703,15 @@ static int tile_pixels(int tile) {
 
 extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream);
+extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p);
+extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream);
 #define STP_TILE_SC 512  // the small-channel halo-tile kernel of conv_sc.hip
+#define STP_TILE_STEM 768  // the 7x7 / stride-2 stem kernel of conv_sc.hip
 
 // Which tile configuration stp_conv2d would launch (profiling / roofline bookkeeping).
 extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SC) && stp_conv2d_sc_eligible(p)) return STP_TILE_SC;
+  if (p && (p->tile == 0 || p->tile == STP_TILE_STEM) && stp_conv2d_stem_eligible(p)) return STP_TILE_STEM;
   ConvArgs a;
   bool c4;
   int ut;
@@ -722,6 +726,7 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   const int tile = stp_conv2d_tile_for(p);
   if (tile < 0) return 0;
   if (tile == STP_TILE_SC) return (size_t)p->N * ceil_div(p->Hv, 8) * ceil_div(p->Wv, 32) * 2 * p->Cout;
+  if (tile == STP_TILE_STEM) return (size_t)p->N * ceil_div(p->Ho, 8) * ceil_div(p->Wo, 32) * 2 * p->Cout;
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
 }
 
@@ -729,6 +734,10 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SC)) {
     if (stp_conv2d_sc_eligible(p)) return stp_conv2d_sc(p, stream);
     if (p->tile == STP_TILE_SC) return STP_E_BADARG;
+  }
+  if (p && (p->tile == 0 || p->tile == STP_TILE_STEM)) {
+    if (stp_conv2d_stem_eligible(p)) return stp_conv2d_stem(p, stream);
+    if (p->tile == STP_TILE_STEM) return STP_E_BADARG;
   }
   ConvArgs a;
   bool c4;

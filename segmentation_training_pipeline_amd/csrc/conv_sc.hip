@@ -373,6 +373,136 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
 }
 
 // =================================================================================================
+// Stem: 7x7 / stride 2 / pad 3 convolution of the 4-channel (3 image channels + 1) bf16 input to 64 channels (ResNet conv0).
+// The generic implicit GEMM gathers 49 taps of 8 bytes per output pixel through the vector-memory path; this layer is
+// HBM-bound (33 MB in, 134 MB out at 16x512x512), so the same halo-tile scheme as above is used: the (2*8+5) x (2*32+5)
+// input patch of an 8 x 32 output tile is staged once (rows padded to 70 pixels = a 16-byte multiple) next to the weights
+// [64][7][8][4] (kw padded to 8 by the prepare kernel: K = 224 = 7 MFMA chunks, chunk = kh; LDS rows padded to 464 bytes =
+// an odd number of 16-byte units, conflict-free for the 16 rows of an A fragment), and a B fragment is ONE ds_read_b128:
+// lane group g of chunk kh reads taps kw = 2g, 2g+1 (2 pixels x 4 channels, contiguous).  (Weights in registers - 112 VGPRs -
+// leave one wave per SIMD; from LDS the kernel runs 4.)
+// =================================================================================================
+constexpr int ST_HH = (SC_TH - 1) * 2 + 7, ST_HW = 70, ST_WROW = 464, ST_HALO = ST_HH * ST_HW * 8, ST_WBYTES = 64 * ST_WROW;
+
+struct StemArgs {
+  const char* src;     // [N,H,W,4] bf16
+  const char* weight;  // [64][7][8][4] bf16
+  char* dst;           // [N,Ho,Wo,64] bf16
+  int N, H, W, Ho, Wo, tiles_x, tiles_y;
+  float* stats;        // optional fused BatchNorm statistics [2][64][tiles]
+};
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs a) {
+  constexpr int TM = 4, NCH = 7, K = 224, COUT = 64;
+  extern __shared__ __attribute__((aligned(16))) char halo[];  // [ST_HH][ST_HW] pixels of 8 bytes, then the stats scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int y0 = ty * SC_TH, x0 = tx * SC_TW;
+  const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;
+
+  const char* img = a.src + (size_t)n * a.H * a.W * 8;
+  for (int v = tid; v < ST_HH * ST_HW; v += 256) {
+    const int hy = v / ST_HW, hx = v - hy * ST_HW;
+    const int gy = iy0 + hy, gx = ix0 + hx;
+    u32x2 val = {0u, 0u};
+    if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) val = *reinterpret_cast<const u32x2*>(img + ((size_t)gy * a.W + gx) * 8);
+    *reinterpret_cast<u32x2*>(halo + v * 8) = val;
+  }
+  char* wl = halo + ST_HALO;  // [64][ST_WROW]
+  for (int v = tid; v < COUT * (K / 8); v += 256) {
+    const int row = v / (K / 8), q = v - row * (K / 8);
+    *reinterpret_cast<u32x4*>(wl + row * ST_WROW + q * 16) = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)row * K + q * 8) * 2);
+  }
+  __syncthreads();
+
+  f32x4 acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1   // (unrolled, the compiler hoists all 28 A fragments: 112 VGPRs and one wave per SIMD)
+  for (int c = 0; c < NCH; ++c) {
+    u32x4 fa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(wl + (i * 16 + lr) * ST_WROW + c * 64 + lg * 16);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int py = wave * 2 + (f >> 1), px = (f & 1) * 16 + lr;
+      const u32x4 fb = *reinterpret_cast<const u32x4*>(halo + ((2 * py + c) * ST_HW + 2 * px + 2 * lg) * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ScMma<bf16_t>::run(fa[i], fb, acc[i][f]);
+    }
+  }
+  __syncthreads();   // the stats scratch below reuses the weight region
+
+  // channel tile OUTER: one pair of statistics accumulators live at a time (register pressure decides the occupancy here)
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.dst);
+  float* red = reinterpret_cast<float*>(halo + ST_HALO);  // [4][64][2], over the (dead) weights
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    f32x4 ss = {0.f, 0.f, 0.f, 0.f}, qq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+      if (gy >= a.Ho || gx >= a.Wo) continue;
+      const size_t pm = ((size_t)n * a.Ho + gy) * a.Wo + gx;
+      const f32x4 v = acc[i][f];
+      store4(out + pm * COUT + i * 16 + lg * 4, v);
+      const f32x4 sv = sc_stored(v, (const bf16_t*)nullptr);
+      ss += sv;
+      qq += sv * sv;
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = row_sum16_to_lane15(ss[e]), qv = row_sum16_to_lane15(qq[e]);
+        if (lr == 15) {
+          const int cl = i * 16 + lg * 4 + e;
+          red[(wave * COUT + cl) * 2] = sv;
+          red[(wave * COUT + cl) * 2 + 1] = qv;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    if (tid < COUT) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { sv += red[(w * COUT + tid) * 2]; qv += red[(w * COUT + tid) * 2 + 1]; }
+      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][tile]
+      a.stats[((size_t)COUT + tid) * gridDim.x + blockIdx.x] = qv;
+    }
+  }
+}
+
+extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p) {
+  if (!p) return 0;
+  return p->dtype == STP_BF16 && p->C0 == 4 && p->C1 == 0 && p->KH == 7 && p->KW == 8 && p->stride == 2 && p->pad == 3 && p->Cout == 64 &&
+         p->Cd0 == 64 && p->src0_mode == STP_SRC_DIRECT && p->Hs0 == p->Hv && p->Ws0 == p->Wv && p->Ho == (p->Hv - 1) / 2 + 1 &&
+         p->Wo == (p->Wv - 1) / 2 + 1 && !p->bias && !p->residual && !p->relu && !p->accumulate0 && !p->bnb_x && !p->dst_sum2x2 &&
+         !p->stats_slots && !p->src_bn_mean;
+}
+
+extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream) {
+  if (!stp_conv2d_stem_eligible(p) || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
+  StemArgs a;
+  a.src = (const char*)p->src0; a.weight = (const char*)p->weight; a.dst = (char*)p->dst0;
+  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Ho = p->Ho; a.Wo = p->Wo;
+  a.tiles_x = ceil_div(a.Wo, SC_TW); a.tiles_y = ceil_div(a.Ho, SC_TH);
+  a.stats = p->stats_partial;
+  const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
+  const size_t lds = (size_t)ST_HALO + ST_WBYTES;
+  hipLaunchKernelGGL(conv_stem_kernel, dim3(a.N * a.tiles_x * a.tiles_y), dim3(256), lds, (hipStream_t)stream, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// =================================================================================================
 // Small-channel weight gradient:  dW[co][tap*CIN + ci] = sum_pixels dY[p][co] * X[p + tap][ci]
 // Persistent workgroups walk 8x32 tiles; per tile the X halo tile and the dY tile are staged in LDS.
 // The reduction index (pixels) is the slow dimension of both tiles, so bf16 fragments come from the

@@ -216,6 +216,44 @@ def test_conv2d_data_gradient(ops, dtype, geom):
     np.testing.assert_allclose(host(dx), ref, atol=tol(ref, dtype))
 
 
+@pytest.mark.parametrize("size", [(32, 36), (64, 64), (37, 70)])
+def test_stem_halo_kernel_with_fused_statistics(ops, size):
+    """conv_stem_kernel (bf16, tile id 768): the ResNet conv0 through the halo-tile kernel at even, tile-aligned and ragged / odd
+    sizes, against the naive oracle and the generic implicit GEMM (tile 2) on the same buffers; its fused BatchNormalization
+    sums through stp_bn_finalize against stp_bn_stats of the stored output."""
+    from segmentation_training_pipeline_amd import _lib
+    h, w = size
+    n, co, dtype = 2, 64, "bf16"
+    rng = np.random.RandomState(9)
+    x3 = q(rng.randn(n, h, w, 3), dtype)
+    wt = q(rng.randn(7, 7, 3, co) / 12.0, dtype)
+    ref = np_ops.conv2d(x3, wt, 2, 3)
+    ho, wo = ref.shape[1:3]
+    x4 = np.concatenate([x3, np.ones((n, h, w, 1), np.float32)], axis=-1)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype, KWp=8, Cinp=4)
+    xd = dev(x4, dtype)
+    mk = lambda dst, tile: ops.conv_params(xd, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=4, KH=7, KW=8, stride=2, pad=3, Ho=ho, Wo=wo,
+                                           Cout=co, dtype=ops.dt(dst), tile=tile)
+    y, y2 = torch.empty((n, ho, wo, co), dtype=TD[dtype], device=DEV), torch.empty((n, ho, wo, co), dtype=TD[dtype], device=DEV)
+    P = mk(y, 0)
+    assert _lib.load().stp_conv2d_stem_eligible(P) and _lib.load().stp_conv2d_tile_for(P) == 768
+    st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    ops.conv2d(mk(y2, 2))
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+    np.testing.assert_allclose(host(y), host(y2), atol=tol(ref, dtype))          # two summation orders, one output rounding each
+    tiles = ops.conv2d_stats_floats(P) // (2 * co)
+    assert tiles == P.stats_tiles == n * -(-ho // 8) * -(-wo // 32)
+    rows = n * ho * wo
+    m1, r1, m0, r0 = (torch.empty(co, device=DEV) for _ in range(4))
+    _lib.call("stp_bn_finalize", ops.ptr(st), tiles, rows, co, 2e-5, 0.99, ops.ptr(m1), ops.ptr(r1), None, None, ops.stream())
+    ws = torch.empty(ops.bn_workspace_bytes(co) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(y, rows, co, 2e-5, 0.99, m0, r0, None, None, ws)
+    np.testing.assert_allclose(host(m1), host(m0), atol=2e-6 * max(1.0, np.abs(host(m0)).max()))
+    np.testing.assert_allclose(host(r1), host(r0), rtol=2e-5)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_stem_conv_7x7_s2_padded_channels(ops, dtype):
     """conv0: 7x7/2 over a 3-channel image stored as 4 channels (4th = 1), weights padded to 7x8x4."""
