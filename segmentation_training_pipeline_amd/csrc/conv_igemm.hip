@@ -42,7 +42,7 @@ struct ConvArgs {
   float* stats;  // optional [2][Cout][ntile_n] floats, or (stat_slots > 0) int64 fixed-point slots [2][Cout][stat_slots]
   int stat_slots;
   BnBack bnb;    // bnb.x != NULL: stats are the BatchNormalization-backward sums and dst receives the masked gradient
-  FastDiv divC, divKW;
+  FastDiv divC, divKW, divHoWo, divWo, divNtm;   // magic-number division: a runtime integer divide costs ~30 VALU instructions
 };
 
 template <typename T> struct Mma;
@@ -167,6 +167,9 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
             else xv = load4(reinterpret_cast<const T*>(a.bnb.x) + (size_t)pm * a.Cout + co);
             v = bnback_apply(bk, a.bnb.relu, xv, stored(v, (const T*)nullptr), ss, qq);
           }
+#if defined(STP_EXP) && STP_EXP == 4   // what-if: no output stores (the branch is never taken, the values stay live)
+          if (a.P < 0)
+#endif
           store4(d, v);
           if (a.stats && !a.bnb.x) {
             const f32x4 sv = stored(v, (const T*)nullptr);
@@ -250,8 +253,11 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   const int r0 = tid >> 3;
   const int lslot = (tid & 7) ^ (r0 & 7);  // logical 16-byte slot fetched by this thread (row&7 == r0&7 for all passes)
 
+#if defined(STP_EXP) && STP_EXP == 5   // what-if: empty workgroups (launch + dispatch cost of the grid)
+  if (a.P >= 0) return;
+#endif
   const int bid = xcd_remap(blockIdx.x, a.ntile_m * a.ntile_n);
-  const int tile_m = bid % a.ntile_m, tile_n = bid / a.ntile_m;
+  const int tile_n = (int)fdiv((uint32_t)bid, a.divNtm), tile_m = bid - tile_n * a.ntile_m;
   const int cout0 = tile_m * BM, pix0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, a.bytesw, 0x00020000);
@@ -265,9 +271,9 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   for (int i = 0; i < RB; ++i) {
     const int pm = pix0 + r0 + 32 * i;
     if (pm < a.P) {
-      const int n = pm / a.HoWo;
+      const int n = (int)fdiv((uint32_t)pm, a.divHoWo);
       const int rem = pm - n * a.HoWo;
-      const int ho = rem / a.Wo;
+      const int ho = (int)fdiv((uint32_t)rem, a.divWo);
       const int wo = rem - ho * a.Wo;
       hb[i] = ho * a.stride - a.pad;
       wb[i] = wo * a.stride - a.pad;
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int r0 = tid >> 3, slot = tid & 7;
 
   const int bid = xcd_remap(blockIdx.x, a.ntile_m * a.ntile_n);
-  const int tile_m = bid % a.ntile_m;  // cout tiles innermost: they share the same pixels
-  const int tile_n = bid / a.ntile_m;
+  const int tile_n = (int)fdiv((uint32_t)bid, a.divNtm);
+  const int tile_m = bid - tile_n * a.ntile_m;  // cout tiles innermost: they share the same pixels
   const int cout0 = tile_m * BM;
   const int pix0 = tile_n * BN;
 
@@ -427,9 +433,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   for (int i = 0; i < RB; ++i) {
     const int pm = pix0 + r0 + 32 * i;
     if (pm < a.P && (r0 + 32 * i) < BN) {
-      const int n = pm / a.HoWo;
+      const int n = (int)fdiv((uint32_t)pm, a.divHoWo);
       const int rem = pm - n * a.HoWo;
-      const int ho = rem / a.Wo;
+      const int ho = (int)fdiv((uint32_t)rem, a.divWo);
       const int wo = rem - ho * a.Wo;
       nb[i] = n;
       hb[i] = ho * a.stride - a.pad;
@@ -558,6 +564,7 @@ static int launch_gen(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;  // one per template instantiation
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = ceil_div(a.P, BN);
+  a.divNtm = make_fastdiv((uint32_t)a.ntile_m);
   return launch_kernel(conv_igemm_kernel<T, BM, BN, WM, WN, C4>, a, (size_t)2 * (BM + BN) * 128, attr_set, s);
 }
 
@@ -566,6 +573,7 @@ static int launch_ut(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = ceil_div(a.P, BN);
+  a.divNtm = make_fastdiv((uint32_t)a.ntile_m);
   return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI>, a, (size_t)STAGES * (BM + BN) * 128 + 4096, attr_set, s);
 }
 
@@ -632,6 +640,9 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
   const int64_t big = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 128);
   const int64_t mid = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 64);
   if (ut_ok == 1) {
+    // one or two K steps (1x1 bottleneck convolutions): nothing to pipeline, the narrower pixel tile's extra workgroups hide
+    // more of the per-workgroup latency (scratch/conv1x1_bench.py: 64->256 @ 4x256^2 65 -> 57 us)
+    if (a.K <= 128 && mid >= 384) return 64 + 6;
     if (big >= 384) return 64 + 1;
     if (mid >= 384) return 64 + 6;
     return 128 + 5;
@@ -674,6 +685,7 @@ static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* u
   if (P >= (1ll << 31)) return STP_E_BADARG;
   a.P = (int)P; a.HoWo = p->Ho * p->Wo; a.wrows = round_up(p->Cout, 16);
   a.divC = make_fastdiv((uint32_t)a.Ctot); a.divKW = make_fastdiv((uint32_t)a.KW);
+  a.divHoWo = make_fastdiv((uint32_t)(p->Ho * p->Wo)); a.divWo = make_fastdiv((uint32_t)p->Wo);
   const int64_t lim = 1ll << 31;
   const int64_t b0 = (int64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * sz;
   const int64_t b1 = (int64_t)p->N * p->Hv * p->Wv * p->C1 * sz;

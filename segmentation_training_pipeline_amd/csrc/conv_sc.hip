@@ -21,6 +21,7 @@ struct ScArgs {
   char* dst;           // [N,H,W,Cout]
   int N, H, W, Hs, Ws, Cout, up, accumulate, relu;
   int tiles_x, tiles_y;
+  FastDiv divTx, divTy;
   float* stats;        // optional fused BatchNorm statistics [2][Cout][tiles] (or int64 slots, see stat_slots)
   int stat_slots;
   BnBack bnb;          // see stp_conv_params.bnb_x
@@ -114,9 +115,10 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
   const int lr = lane & 15, lg = lane >> 4;
 
   int b = blockIdx.x;
-  const int tx = b % a.tiles_x; b /= a.tiles_x;
-  const int ty = b % a.tiles_y;
-  const int n = b / a.tiles_y;
+  const int bq = (int)fdiv((uint32_t)b, a.divTx);
+  const int tx = b - bq * a.tiles_x;
+  const int n = (int)fdiv((uint32_t)bq, a.divTy);
+  const int ty = bq - n * a.tiles_y;
   const int y0 = ty * SC_TH, x0 = tx * SC_TW;
 
   // ---- stage the halo tile -----------------------------------------------------------------
@@ -355,6 +357,7 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
   a.up = p->src0_mode == STP_SRC_NEAREST2X; a.accumulate = p->accumulate0; a.relu = p->relu;
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
+  a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
   a.stats = p->stats_partial;
   a.stat_slots = p->stats_slots;
   if (a.stats && (p->Cout & 3)) return STP_E_BADARG;
@@ -389,6 +392,7 @@ struct StemArgs {
   const char* weight;  // [64][7][8][4] bf16
   char* dst;           // [N,Ho,Wo,64] bf16
   int N, H, W, Ho, Wo, tiles_x, tiles_y;
+  FastDiv divTx, divTy;
   float* stats;        // optional fused BatchNorm statistics [2][64][tiles]
 };
 
@@ -398,9 +402,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   int b = blockIdx.x;
-  const int tx = b % a.tiles_x; b /= a.tiles_x;
-  const int ty = b % a.tiles_y;
-  const int n = b / a.tiles_y;
+  const int bq = (int)fdiv((uint32_t)b, a.divTx);
+  const int tx = b - bq * a.tiles_x;
+  const int n = (int)fdiv((uint32_t)bq, a.divTy);
+  const int ty = bq - n * a.tiles_y;
   const int y0 = ty * SC_TH, x0 = tx * SC_TW;
   const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;
 
@@ -494,6 +499,7 @@ extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream) {
   a.src = (const char*)p->src0; a.weight = (const char*)p->weight; a.dst = (char*)p->dst0;
   a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Ho = p->Ho; a.Wo = p->Wo;
   a.tiles_x = ceil_div(a.Wo, SC_TW); a.tiles_y = ceil_div(a.Ho, SC_TH);
+  a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
   a.stats = p->stats_partial;
   const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
   const size_t lds = (size_t)ST_HALO + ST_WBYTES;
