@@ -81,10 +81,11 @@ typedef struct stp_conv_params {
                            output per channel (fused BatchNormalization statistics, finalize with
                            stp_bn_finalize); capacity >= stp_conv2d_stats_floats(p) floats */
   /* BatchNormalization-backward fusion for a data-gradient convolution whose destination is dY of a BN(+ReLU)
-   * output with this convolution as its only consumer: with bnb_x != NULL (the BN INPUT, [N,Ho,Wo,Cout] dtype)
+   * output and which COMPLETES that gradient - the only consumer of the BN output, or the last one to contribute
+   * (accumulate0 = 1 on top of what the other consumers wrote): with bnb_x != NULL (the BN INPUT, [N,Ho,Wo,Cout] dtype)
    * the epilogue stores g = dY * [bn(x) > 0] (g = dY when bnb_relu == 0) instead of dY and writes
    * stats_partial = per-tile sum(g) / sum(g * xhat) per channel; finish with stp_bn_backward_fused.  Requires
-   * stats_partial, Cd0 == Cout, Cout % 4 == 0, no accumulate / relu / residual. */
+   * stats_partial, Cd0 == Cout, Cout % 4 == 0, no relu / residual. */
   const void* bnb_x;
   const float* bnb_mean;
   const float* bnb_rstd;

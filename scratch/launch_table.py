@@ -36,6 +36,19 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
 print("---- slowest launches")
 for us, name, meta in sorted(rows, key=lambda r: -r[0])[:25]:
     print("%-28s %-28s %8.1f us" % (name, (meta or {}).get("layer", ""), us))
+print("---- BatchNormalization launches (bytes = passes x rows x C x 2)")
+for us, name, meta in rows:
+    pass
+for i, (fn, args, name, meta) in enumerate(launches):
+    if name in ("stp_bn_backward_fused", "stp_bn_backward", "stp_bn_apply"):
+        if name == "stp_bn_apply":
+            r, c, passes = args[4], args[5], 2
+        elif name == "stp_bn_backward_fused":
+            r, c, passes = args[4], args[5], 3
+        else:
+            r, c, passes = args[4], args[5], 5
+        byt = passes * r * c * 2
+        print("%-24s rows %8d C %4d  %7.1f us  %6.2f TB/s" % (name, r, c, tot[i], byt / tot[i] / 1e6))
 print("---- GEMM launches")
 for us, name, meta in rows:
     if meta and 'flops' in meta:

@@ -758,7 +758,7 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (rc != STP_OK) return rc;
   if (p->dst_sum2x2 || p->src_bn_mean) return STP_E_BADARG;  // folded upsample gradient / fused producer BN: small-channel kernel only
   // (checked here, not in fill_args: the sizing queries run before stats_partial is allocated)
-  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->accumulate0 || p->relu || p->residual)) return STP_E_BADARG;
+  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->relu || p->residual)) return STP_E_BADARG;
   int tile = p->tile ? p->tile : auto_tile(a, ut);
   if (c4 && tile != 2 && tile != 5) tile = 2;
   hipStream_t s = (hipStream_t)stream;

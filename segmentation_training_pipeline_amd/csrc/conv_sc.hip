@@ -368,7 +368,7 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.pbn.x = nullptr; a.pbn.mean = p->src_bn_mean; a.pbn.rstd = p->src_bn_rstd; a.pbn.gamma = p->src_bn_gamma; a.pbn.beta = p->src_bn_beta;
   a.pbn.relu = p->src_bn_relu;
   if (a.pbn.mean && !a.pbn.rstd) return STP_E_BADARG;
-  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || (p->accumulate0 && !a.sum2) || p->relu)) return STP_E_BADARG;
+  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->relu)) return STP_E_BADARG;
   if (a.sum2 && ((p->Cout & 3) || (a.H & 1) || (a.W & 1) || p->bias || p->relu || (a.stats && !a.bnb.x))) return STP_E_BADARG;
   const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
   hipStream_t s = (hipStream_t)stream;

@@ -33,13 +33,26 @@ def _rup(a, b):
 
 class DT(object):
     """Device tensor handle: NHWC activation + (optional) gradient buffer."""
-    __slots__ = ("name", "N", "H", "W", "C", "buf", "grad", "grad_ready", "needs_grad", "gradC", "meta")
+    __slots__ = ("name", "N", "H", "W", "C", "buf", "grad", "_grad_ready", "grad_writes", "needs_grad", "gradC", "meta")
 
     def __init__(self, name, N, H, W, Cn, buf=None, needs_grad=False):
         self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cn
-        self.buf, self.grad, self.grad_ready, self.needs_grad = buf, None, False, needs_grad
+        self.buf, self.grad, self._grad_ready, self.needs_grad = buf, None, False, needs_grad
+        self.grad_writes = 0
         self.gradC = Cn
         self.meta = {}
+
+    @property
+    def grad_ready(self):
+        return self._grad_ready
+
+    @grad_ready.setter
+    def grad_ready(self, v):
+        """Set by every consumer's backward after it wrote / accumulated its contribution: ``grad_writes`` counts them, so the
+        consumer that finds ``grad_writes == uses - 1`` knows it completes the gradient (BatchNormalization-backward fusion)."""
+        self._grad_ready = bool(v)
+        if v:
+            self.grad_writes += 1
 
     @property
     def rows(self):
@@ -88,6 +101,7 @@ class Plan(object):
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
         self.fuse_bn_backward = os.environ.get("STP_FUSE_BN_BACKWARD", "1") != "0"
+        self.fuse_bn_backward_last = os.environ.get("STP_FUSE_BN_BACKWARD_LAST", "1") != "0"
         # weight gradients (needed only by the optimizer / all-reduce) run on a second stream next to the data-gradient
         # + BatchNormalization-backward chain of the same layer: the small latency-bound kernels of one chain fill the
         # tails of the other's GEMMs (captured into the same hipGraph as a fork/join)
@@ -616,8 +630,13 @@ class Plan(object):
                         q.accumulate0 = int(x.grad_ready)
                     else:
                         q.dst_sum2x2 = 0
-                if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses") == 1 and (folded_up or not upsample) and C1 == 0
-                        and x_ng and not q.accumulate0 and C0 % 4 == 0):
+                uses = x.meta.get("uses", 0)
+                # the only consumer, or the LAST of several (every other consumer has already written or accumulated its
+                # share, this data gradient accumulates on top): its epilogue sees the complete gradient of the BN output
+                sole = uses == 1 and not q.accumulate0
+                last = self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and q.accumulate0 and not upsample
+                if (self.fuse_bn_backward and bnm is not None and (sole or last) and (folded_up or not upsample) and C1 == 0
+                        and x_ng and C0 % 4 == 0):
                     q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
                     if self.slot_arena is not None and self.N * Hv * Wv <= self.bn_slots_max_rows:
                         sp, sn = self._slots(C0)

@@ -302,9 +302,11 @@ def test_plan_structure_matches_unet_resnet34():
     assert bnames.count("stp_conv2d_wgrad_reduce") == 48
     # BatchNormalization outputs read by exactly one convolution get their backward sums from that convolution's
     # data-gradient epilogue: 16 bn2 + 12 bn1 of the non-first units + 5 decoder bn1 + the last decoder bn2, plus
-    # decoder_stage3_bn2 whose consumer's data-gradient folds the UpSampling2D gradient (dst_sum2x2, small-channel kernel)
+    # decoder_stage3_bn2 whose consumer's data-gradient folds the UpSampling2D gradient (dst_sum2x2, small-channel kernel);
+    # and the bn1 of the four stage-first units (read by the shortcut, conv1 and - stages 2..4 - a decoder concat): the last
+    # data gradient to arrive accumulates on top of the others and reduces the sums of the complete gradient
     assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward") == 44
-    assert bnames.count("stp_bn_backward_fused") == 35
+    assert bnames.count("stp_bn_backward_fused") == 39
     assert bnames.count("stp_upsample2x_bwd") == 4          # 5 decoder stages, one folded
     # weight-gradient chains run on the side stream: one fork per trainable convolution, joins at the next one
     assert bnames.count("fork") == 48 and bnames.count("join") == 48

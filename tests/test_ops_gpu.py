@@ -400,16 +400,19 @@ def test_batchnorm_train_forward_backward(ops, dtype, C):
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0), (2, 9, 11, 128, 64, 5), (2, 19, 45, 16, 16, 512), (2, 19, 45, 16, 32, 512),
                                   (1, 24, 20, 16, 64, 258), (2, 13, 9, 64, 24, 0), (1, 20, 24, 128, 16, 68)])
-@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("relu", [1, 0, 3])
 def test_batchnorm_backward_sums_fused_in_conv_epilogue(ops, dtype, case, relu):
     """stp_conv_params.bnb_x: the convolution that produces dY of a BN(+ReLU) output masks it and reduces the
     BatchNormalization-backward sums in its epilogue; stp_bn_backward_fused must then equal conv + stp_bn_backward."""
     n, h, w, ci, co, tile = case
+    last = relu == 3            # relu 3 = ReLU with this convolution as the LAST of several consumers: accumulate0 on top of theirs
+    relu = 1 if last else relu
     rng = np.random.RandomState(77)
     rows = n * h * w
     src = q(rng.randn(n, h, w, ci), dtype)
     wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
     x = q(rng.randn(n, h, w, co) * 1.5 + 0.3, dtype)          # the BN input
+    others = q(rng.randn(n, h, w, co), dtype)                  # what the other consumers already wrote into dY
     gamma = (rng.rand(co) + 0.5).astype(np.float32)
     beta = (rng.randn(co) * 0.3).astype(np.float32)
     f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
@@ -420,15 +423,15 @@ def test_batchnorm_backward_sums_fused_in_conv_epilogue(ops, dtype, case, relu):
     _, fwd, _, _ = prep_weights(ops, wt, dtype)
     sd = dev(src, dtype)
     mk = lambda dst: ops.conv_params(sd, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
-                                     Cout=co, dtype=ops.dt(dst), tile=tile)
+                                     Cout=co, dtype=ops.dt(dst), tile=tile, accumulate0=int(last))
     # unfused reference on the device
-    dy = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
+    dy = dev(others, dtype) if last else torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV)
     ops.conv2d(mk(dy))
     dx0 = torch.empty_like(dy)
     dg0, db0 = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
     ops.bn_backward(xd, dy, dx0, rows, co, m, r, g, b, dg0, db0, relu=relu, accumulate_dx=0, workspace=ws)
     # fused
-    gbuf = torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+    gbuf = dev(others, dtype) if last else torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
     P = mk(gbuf)
     P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), relu
     st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
