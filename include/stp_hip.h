@@ -263,6 +263,13 @@ int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* st
 /* Gradient of UpSampling2D(2): dx[n,h,w,c] (+)= sum of the 2x2 block of dy ([N,2H,2W,ldy]). */
 int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,
                        int32_t dtype, int32_t accumulate, void* stream);
+/* The same when dx is the gradient of a BatchNormalization(+activation) output that this launch completes: the stored value
+ * is masked with the activation re-derived from the BN input bn_x and `partial` ([2][C][tiles], tiles from the query; 0 =
+ * channel count not supported) receives the sums stp_bn_backward_fused consumes - see stp_conv_params.bnb_x. */
+int stp_upsample2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype);
+int stp_upsample2x_bwd_bn(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,
+                          int32_t accumulate, const void* bn_x, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int32_t relu, float* partial, void* stream);
 /* x[n,2h+i,2w+j,c] += m[n,h,w,c] in place (FPN: Add()([lateral, UpSampling2D(2)(m)])); H, W = size of x, even. */
 int stp_upsample2x_add(void* x, const void* m, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 /* tf.image.resize_bilinear(align_corners=False) of TF 1.x by an integer factor (src = dst / factor, no half-pixel offset) -

@@ -897,49 +897,128 @@ extern "C" int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtyp
 }
 
 // ------------------------------------------------------------------------------------------
-// gradient of UpSampling2D(2): dy is [N,2H,2W,ldy] (first C channels used), dx [N,H,W,C]
-template <typename T, int V>
+// gradient of UpSampling2D(2): dy is [N,2H,2W,ldy] (first C channels used), dx [N,H,W,C].
+// BNB: dx is the gradient of a BatchNormalization(+activation) output that this launch completes - the value is masked with the
+// activation re-derived from the BN input x and the workgroup writes its partial sums of g and g * xhat ([2][C][workgroups],
+// the layout stp_bn_backward_fused reduces), exactly as the convolution epilogues do (stp_conv_params.bnb_x).
+__device__ __forceinline__ f32x4 stored4(f32x4 v, const float*) { return v; }   // the value as the destination dtype holds it
+__device__ __forceinline__ f32x4 stored4(f32x4 v, const bf16_t*) {
+  const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+}
+
+template <typename T, int V, bool BNB>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
-                                                             int C, int ldy, int accumulate) {
+                                                             int C, int ldy, int accumulate, BnBack bnb, float* __restrict__ partial) {
   const int cg = C / V;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= W * cg) return;
-  const int w = t / cg, c = (t - w * cg) * V;
+  const bool on = t < W * cg;
+  const int w = on ? t / cg : 0, c = on ? (t - w * cg) * V : 0;
   const int n = blockIdx.y / H, h = blockIdx.y - n * H;
-  const T* b = dy + (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * ldy + c;
-  float g[V], a1[V], a2[V], a3[V];
-  ldv<T, V>(b, g);
-  ldv<T, V>(b + ldy, a1);
-  ldv<T, V>(b + (size_t)2 * W * ldy, a2);
-  ldv<T, V>(b + (size_t)2 * W * ldy + ldy, a3);
+  float g[V];
 #pragma unroll
-  for (int e = 0; e < V; ++e) g[e] = ((g[e] + a1[e]) + a2[e]) + a3[e];
-  T* out = dx + (((size_t)n * H + h) * W + w) * C + c;
-  if (accumulate) {
-    float o[V];
-    ldv<T, V>(out, o);
+  for (int e = 0; e < V; ++e) g[e] = 0.f;
+  float sg[V], sq[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) g[e] += o[e];
+  for (int e = 0; e < V; ++e) { sg[e] = 0.f; sq[e] = 0.f; }
+  if (on) {
+    const T* b = dy + (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * ldy + c;
+    float a1[V], a2[V], a3[V];
+    ldv<T, V>(b, g);
+    ldv<T, V>(b + ldy, a1);
+    ldv<T, V>(b + (size_t)2 * W * ldy, a2);
+    ldv<T, V>(b + (size_t)2 * W * ldy + ldy, a3);
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] = ((g[e] + a1[e]) + a2[e]) + a3[e];
+    const size_t o = (((size_t)n * H + h) * W + w) * C + c;
+    T* out = dx + o;
+    if (accumulate) {
+      float p[V];
+      ldv<T, V>(out, p);
+#pragma unroll
+      for (int e = 0; e < V; ++e) g[e] += p[e];
+    }
+    if constexpr (BNB) {
+      float xv[V];
+      ldv<T, V>(reinterpret_cast<const T*>(bnb.x) + o, xv);
+#pragma unroll
+      for (int q = 0; q < V / 4; ++q) {
+        const BnBackCh k = bnback_load(bnb, c + 4 * q);
+        const f32x4 st = stored4(f32x4{g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]}, (const T*)nullptr);
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 m = bnback_apply(k, bnb.relu, f32x4{xv[4 * q], xv[4 * q + 1], xv[4 * q + 2], xv[4 * q + 3]}, st, s4, q4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[4 * q + e] = m[e]; sg[4 * q + e] = s4[e]; sq[4 * q + e] = q4[e]; }
+      }
+    }
+    stv<T, V>(out, g);
   }
-  stv<T, V>(out, g);
+  if constexpr (BNB) {
+    // threads t and t + cg own the same channels: fixed-order combine over the workgroup's 256 / cg pixels (cg divides 256)
+    extern __shared__ float red[];  // [256][2V]
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[threadIdx.x * 2 * V + e] = sg[e]; red[threadIdx.x * 2 * V + V + e] = sq[e]; }
+    __syncthreads();
+    const int cl = cg < 256 ? cg : 256;               // channel groups present in this workgroup
+    for (int idx = threadIdx.x; idx < cl * V; idx += 256) {     // cl * V = min(C, 256 * V) channels
+      const int gq = idx / V, e = idx - gq * V;
+      const int t0 = blockIdx.x * 256;                // first (w, channel group) item of the workgroup
+      const int cg0 = (t0 + gq) % cg;                 // channel group of local thread gq
+      float s = 0.f, q2 = 0.f;
+      for (int l = gq; l < 256; l += cl) { s += red[l * 2 * V + e]; q2 += red[l * 2 * V + V + e]; }
+      const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+      const int ch = cg0 * V + e;
+      partial[(size_t)ch * nblk + blk] = s;
+      partial[((size_t)C + ch) * nblk + blk] = q2;
+    }
+  }
+}
+
+static int upsample2x_bwd_launch(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,
+                                 int32_t accumulate, const BnBack* bnb, float* partial, hipStream_t s) {
+  if (!dy || !dx || (C & 3) || (ldy & 3) || ldy < C || (int64_t)N * H > 65535) return STP_E_BADARG;
+  const bool v8 = dtype == STP_BF16 && (C & 7) == 0 && (ldy & 7) == 0;
+  const int V = v8 ? 8 : 4;
+  const dim3 grid(ceil_div(W * (C / V), 256), N * H);
+  BnBack none;
+  none.x = nullptr; none.mean = none.rstd = none.gamma = none.beta = nullptr; none.relu = 0;
+  if (bnb) {
+    if (256 % (C / V) != 0 || !partial) return STP_E_BADARG;       // each workgroup must hold whole pixels of all its channel groups
+    const size_t lds = 256 * 2 * V * sizeof(float);
+    if (v8) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8, true>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, true>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
+    else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4, true>), grid, dim3(256), lds, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
+    else return STP_E_BADARG;
+  } else {
+    if (v8) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
+    else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4, false>), grid, dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
+    else return STP_E_BADARG;
+  }
+  STP_LAUNCH_CHECK();
+  return STP_OK;
 }
 
 extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,
                                   int32_t dtype, int32_t accumulate, void* stream) {
-  if (!dy || !dx || (C & 3) || (ldy & 3) || ldy < C || (int64_t)N * H > 65535) return STP_E_BADARG;
-  hipStream_t s = (hipStream_t)stream;
+  return upsample2x_bwd_launch(dy, dx, N, H, W, C, ldy, dtype, accumulate, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// number of workgroups (= partial-sum tiles per channel) of stp_upsample2x_bwd_bn
+extern "C" int stp_upsample2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype) {
   const bool v8 = dtype == STP_BF16 && (C & 7) == 0 && (ldy & 7) == 0;
-  const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
-  if (v8)
-    hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate);
-  else if (dtype == STP_BF16)
-    hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate);
-  else if (dtype == STP_F32)
-    hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate);
-  else
-    return STP_E_BADARG;
-  STP_LAUNCH_CHECK();
-  return STP_OK;
+  const int V = v8 ? 8 : 4;
+  if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;          // 0: not supported for this channel count
+  return ceil_div(W * (C / V), 256) * N * H;
+}
+
+extern "C" int stp_upsample2x_bwd_bn(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,
+                                     int32_t accumulate, const void* bn_x, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, int32_t relu, float* partial, void* stream) {
+  if (!bn_x || !mean || !rstd || !partial) return STP_E_BADARG;
+  BnBack b;
+  b.x = (const char*)bn_x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.relu = relu;
+  return upsample2x_bwd_launch(dy, dx, N, H, W, C, ldy, dtype, accumulate, &b, partial, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------

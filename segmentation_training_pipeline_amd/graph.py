@@ -436,7 +436,7 @@ class Plan(object):
             if fused_b is not None:
                 # the only consumer's data-gradient epilogue already masked dY and reduced the per-tile sums
                 st, q = fused_b
-                tiles = int(self.lib.stp_conv2d_stats_floats(C.byref(q))) // (2 * Cn)
+                tiles = q if isinstance(q, int) else int(self.lib.stp_conv2d_stats_floats(C.byref(q))) // (2 * Cn)
                 self._emit(self.bwd, "stp_bn_backward_fused", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt,
                            x.rows, Cn, mean.data_ptr(), rstd.data_ptr(), gp, st.data_ptr(), tiles,
                            self._gptr(gamma) if gamma else None, self._gptr(beta), int(x.grad_ready and x.needs_grad),
@@ -650,8 +650,19 @@ class Plan(object):
                 self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": flops,
                                               "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
                 if upsample and x_ng and not folded_up:
-                    self._emit(self.bwd, "stp_upsample2x_bwd", d0.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W,
-                               C0, C0, self.cdt, int(x.grad_ready))
+                    acc_up = int(x.grad_ready)
+                    done = (uses == 1 and not acc_up) or (self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and acc_up)
+                    ntl = int(self.lib.stp_upsample2x_bwd_bn_tiles(self.N, x.H, x.W, C0, C0, self.cdt)) if (
+                        self.fuse_bn_backward and bnm is not None and done and self.slot_arena is None) else 0
+                    if ntl > 0:
+                        # the upsampling gradient completes dY of a BatchNormalization output: mask + backward sums in the same pass
+                        st = self._alloc((2 * C0 * ntl,), torch.float32)
+                        self._emit(self.bwd, "stp_upsample2x_bwd_bn", d0.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W,
+                                   C0, C0, self.cdt, acc_up, bnm[0], bnm[1], bnm[2], bnm[3], bnm[4], bnm[5], st.data_ptr())
+                        x.meta["bnb"] = (st, ntl)
+                    else:
+                        self._emit(self.bwd, "stp_upsample2x_bwd", d0.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W,
+                                   C0, C0, self.cdt, acc_up)
                 if x_ng:
                     x.grad_ready = True
                 if s_ng:

@@ -306,8 +306,11 @@ def test_plan_structure_matches_unet_resnet34():
     # and the bn1 of the four stage-first units (read by the shortcut, conv1 and - stages 2..4 - a decoder concat): the last
     # data gradient to arrive accumulates on top of the others and reduces the sums of the complete gradient
     assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward") == 44
-    assert bnames.count("stp_bn_backward_fused") == 39
-    assert bnames.count("stp_upsample2x_bwd") == 4          # 5 decoder stages, one folded
+    # ... and the four BN outputs whose gradient is completed by an UpSampling2D gradient (bn1, decoder_stage0..2_bn2: their
+    # consumer concatenates a skip, so the fold does not apply): stp_upsample2x_bwd_bn masks and reduces in the same pass.
+    # Only bn0 (completed by the max-pool gradient) keeps the two-pass stp_bn_backward.
+    assert bnames.count("stp_bn_backward_fused") == 43
+    assert bnames.count("stp_upsample2x_bwd_bn") == 4 and bnames.count("stp_upsample2x_bwd") == 0    # 5 decoder stages, one folded
     # weight-gradient chains run on the side stream: one fork per trainable convolution, joins at the next one
     assert bnames.count("fork") == 48 and bnames.count("join") == 48
     assert "stp_add_inplace" not in bnames                             # every residual gradient aliases

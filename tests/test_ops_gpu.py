@@ -729,6 +729,49 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 6, 10, 64, 0), (2, 5, 7, 512, 1), (1, 8, 16, 128, 1), (2, 4, 4, 32, 0), (1, 3, 5, 256, 1)])
+def test_upsample_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
+    """stp_upsample2x_bwd_bn: the 2x2 fold that completes the gradient of a BatchNormalization(+ReLU) output (optionally on top of
+    what other consumers accumulated) masks it and reduces the backward sums in the same pass; followed by
+    stp_bn_backward_fused it must equal stp_upsample2x_bwd + stp_bn_backward."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c, acc = case
+    rng = np.random.RandomState(5)
+    rows = n * h * w
+    hi = dev(q(rng.randn(n, 2 * h, 2 * w, c), dtype), dtype)
+    x = q(rng.randn(n, h, w, c) * 1.5 + 0.3, dtype)
+    prior = q(rng.randn(n, h, w, c), dtype)
+    gamma, beta = (rng.rand(c) + 0.5).astype(np.float32), (rng.randn(c) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd, g, b = dev(x, dtype), f(gamma), f(beta)
+    m, r = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(c) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, c, 1e-3, 0.99, m, r, None, None, ws)
+    # reference: plain fold, then the two-pass backward
+    dy0 = dev(prior, dtype)
+    ops.upsample2x_bwd(hi, dy0, n, h, w, c, c, accumulate=acc)
+    dx0, dg0, db0 = torch.empty_like(dy0), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.bn_backward(xd, dy0, dx0, rows, c, m, r, g, b, dg0, db0, relu=1, accumulate_dx=0, workspace=ws)
+    # fused
+    tiles = int(_lib.load().stp_upsample2x_bwd_bn_tiles(n, h, w, c, c, ops.dt(xd)))
+    assert tiles > 0
+    st = torch.full((2 * c * tiles,), float("nan"), dtype=torch.float32, device=DEV)
+    gbuf = dev(prior, dtype)
+    _lib.call("stp_upsample2x_bwd_bn", ops.ptr(hi), ops.ptr(gbuf), n, h, w, c, c, ops.dt(xd), acc, ops.ptr(xd), ops.ptr(m), ops.ptr(r),
+              ops.ptr(g), ops.ptr(b), 1, ops.ptr(st), ops.stream())
+    assert not np.isnan(host(st)).any()
+    dx1, dg1, db1 = torch.empty_like(dy0), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.bn_backward_fused(xd, gbuf, dx1, rows, c, m, r, g, st, tiles, dg1, db1, accumulate_dx=0, workspace=ws)
+    pre = host(xd) * (host(r) * gamma) + (beta - host(m) * host(r) * gamma)
+    safe = np.abs(pre) > 1e-3
+    np.testing.assert_array_equal(host(gbuf)[safe], (host(dy0) * (pre > 0))[safe])       # dY under the ReLU mask, bit for bit
+    scale = lambda a: 2e-4 * np.abs(a).max() + 1e-4
+    np.testing.assert_allclose(host(db1), host(db0), atol=scale(host(db0)) * 5)
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=scale(host(dg0)) * 5)
+    np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("geom", [(1, 1, 24, 320), (2, 2, 12, 72), (3, 3, 8, 40), (6, 6, 4, 24), (5, 7, 8, 20), (3, 2, 6, 3), (12, 12, 8, 24)])
 def test_pyramid_pooling_geometry_resize_and_pool(ops, dtype, geom):
     """PSPNet's pyramid at its real aspect: a (H x W) pooled map blown up by a large factor (level 1 is a single pixel whose
