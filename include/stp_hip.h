@@ -245,6 +245,12 @@ int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H,
                      int32_t dtype, void* stream);
 int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                          int32_t dtype, int32_t accumulate, void* stream);
+/* The same when dx is the gradient of a BatchNormalization(+activation) output that this launch completes (bn0 of the ResNet
+ * stem: pooled, and read by a decoder skip): mask + partial sums for stp_bn_backward_fused, as stp_upsample2x_bwd_bn. */
+int stp_maxpool3x3s2_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype);
+int stp_maxpool3x3s2_bwd_bn(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                            int32_t accumulate, const void* bn_x, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, int32_t relu, float* partial, void* stream);
 /* MaxPooling2D(2, 2), no padding (keras.applications VGG blocks; H and W even).  idx = 2*dy+dx of the first maximum. */
 int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 int stp_maxpool2x2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,

@@ -701,53 +701,115 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Shared tail of the gradient kernels that COMPLETE the gradient of a BatchNormalization(+activation) output (the 2x2 fold of
+// UpSampling2D, the max-pool gather): the thread's V values are masked with the activation re-derived from the BN input x,
+// stored, and the workgroup reduces sum(g) / sum(g * xhat) per channel into partial[2][C][workgroups] - the layout
+// stp_bn_backward_fused consumes, exactly what the convolution epilogues write (stp_conv_params.bnb_x).
+// Thread layout of the callers: t = blockIdx.x * 256 + threadIdx.x = pixel * cg + channel group, cg = C / V dividing 256.
+__device__ __forceinline__ f32x4 stored4(f32x4 v, const float*) { return v; }   // the value as the destination dtype holds it
+__device__ __forceinline__ f32x4 stored4(f32x4 v, const bf16_t*) {
+  const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+}
+
+#define BNB_ROWS 8   // image rows per workgroup of the *_bn gradient kernels: fewer, larger partial-sum tiles
+
+template <typename T, int V>
+__device__ __forceinline__ void bnb_mask_store(float (&g)[V], size_t o, int c, const BnBack& bnb, T* __restrict__ dx, float (&sg)[V],
+                                               float (&sq)[V]) {
+  float xv[V];
+  ldv<T, V>(reinterpret_cast<const T*>(bnb.x) + o, xv);
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    const BnBackCh k = bnback_load(bnb, c + 4 * q);
+    const f32x4 st = stored4(f32x4{g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]}, (const T*)nullptr);
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 m = bnback_apply(k, bnb.relu, f32x4{xv[4 * q], xv[4 * q + 1], xv[4 * q + 2], xv[4 * q + 3]}, st, s4, q4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[4 * q + e] = m[e]; sg[4 * q + e] += s4[e]; sq[4 * q + e] += q4[e]; }
+  }
+  stv<T, V>(dx + o, g);
+}
+
+// threads t and t + cg own the same channels: fixed-order combine over the workgroup's 256 / cg pixel columns
+template <int V>
+__device__ __forceinline__ void bnb_reduce(const float (&sg)[V], const float (&sq)[V], int cg, int C, float* __restrict__ partial) {
+  extern __shared__ float red[];  // [256][2V]
+#pragma unroll
+  for (int e = 0; e < V; ++e) { red[threadIdx.x * 2 * V + e] = sg[e]; red[threadIdx.x * 2 * V + V + e] = sq[e]; }
+  __syncthreads();
+  const int cl = cg < 256 ? cg : 256;               // channel groups present in this workgroup
+  for (int idx = threadIdx.x; idx < cl * V; idx += 256) {
+    const int gq = idx / V, e = idx - gq * V;
+    const int cg0 = (blockIdx.x * 256 + gq) % cg;   // channel group of local thread gq
+    float s = 0.f, q2 = 0.f;
+    for (int l = gq; l < 256; l += cl) { s += red[l * 2 * V + e]; q2 += red[l * 2 * V + V + e]; }
+    const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int ch = cg0 * V + e;
+    partial[(size_t)ch * nblk + blk] = s;
+    partial[((size_t)C + ch) * nblk + blk] = q2;
+  }
+}
+
 // One workgroup row per input row (blockIdx.y = n*H + h): 32-bit index arithmetic only, V channels per thread
 // (16 bytes of bf16), each input pixel gathers from the <= 4 windows that contain it.
-template <typename T, int V>
+template <typename T, int V, bool BNB>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
                                                           T* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo,
-                                                          int accumulate) {
+                                                          int accumulate, BnBack bnb, float* __restrict__ partial) {
   const int cg = C / V;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= W * cg) return;
-  const int w = t / cg, c = (t - w * cg) * V;
-  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
-  float g[V];
+  const bool on = t < W * cg;
+  if (!BNB && !on) return;
+  const int w = on ? t / cg : 0, c = on ? (t - w * cg) * V : 0;
+  constexpr int ROWS = BNB ? BNB_ROWS : 1;
+  float sg[V], sq[V];
 #pragma unroll
-  for (int e = 0; e < V; ++e) g[e] = 0.f;
-  // windows (ho,wo) with 2*ho-1+kh == h  ->  kh = h+1-2*ho in [0,2]
+  for (int e = 0; e < V; ++e) { sg[e] = 0.f; sq[e] = 0.f; }
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int row = blockIdx.y * ROWS + rr;
+    if (row >= N * H || !on) break;
+    const int n = row / H, h = row - n * H;
+    float g[V];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    const int hh = h + 1 - kh;
-    if (hh < 0 || (hh & 1)) continue;
-    const int ho = hh >> 1;
-    if (ho >= Ho) continue;
+    for (int e = 0; e < V; ++e) g[e] = 0.f;
+    const size_t oo = (((size_t)n * H + h) * W + w) * C + c;
+    // windows (ho,wo) with 2*ho-1+kh == h  ->  kh = h+1-2*ho in [0,2]
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int ww = w + 1 - kw;
-      if (ww < 0 || (ww & 1)) continue;
-      const int wo = ww >> 1;
-      if (wo >= Wo) continue;
-      const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
-      uint8_t id[V];
-      if constexpr (V == 8) *reinterpret_cast<uint2*>(id) = *reinterpret_cast<const uint2*>(idx + o);
-      else *reinterpret_cast<uint32_t*>(id) = *reinterpret_cast<const uint32_t*>(idx + o);
-      float d[V];
-      ldv<T, V>(dy + o, d);
-      const uint8_t me = (uint8_t)(kh * 3 + kw);
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + 1 - kh;
+      if (hh < 0 || (hh & 1)) continue;
+      const int ho = hh >> 1;
+      if (ho >= Ho) continue;
 #pragma unroll
-      for (int e = 0; e < V; ++e)
-        if (id[e] == me) g[e] += d[e];
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w + 1 - kw;
+        if (ww < 0 || (ww & 1)) continue;
+        const int wo = ww >> 1;
+        if (wo >= Wo) continue;
+        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+        uint8_t id[V];
+        if constexpr (V == 8) *reinterpret_cast<uint2*>(id) = *reinterpret_cast<const uint2*>(idx + o);
+        else *reinterpret_cast<uint32_t*>(id) = *reinterpret_cast<const uint32_t*>(idx + o);
+        float d[V];
+        ldv<T, V>(dy + o, d);
+        const uint8_t me = (uint8_t)(kh * 3 + kw);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (id[e] == me) g[e] += d[e];
+      }
     }
-  }
-  T* out = dx + (((size_t)n * H + h) * W + w) * C + c;
-  if (accumulate) {
-    float o[V];
-    ldv<T, V>(out, o);
+    if (accumulate) {
+      float o[V];
+      ldv<T, V>(dx + oo, o);
 #pragma unroll
-    for (int e = 0; e < V; ++e) g[e] += o[e];
+      for (int e = 0; e < V; ++e) g[e] += o[e];
+    }
+    if constexpr (BNB) bnb_mask_store<T, V>(g, oo, c, bnb, dx, sg, sq);
+    else stv<T, V>(dx + oo, g);
   }
-  stv<T, V>(out, g);
+  if constexpr (BNB) bnb_reduce<V>(sg, sq, cg, C, partial);
 }
 
 extern "C" int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C,
@@ -770,24 +832,53 @@ extern "C" int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N,
   return STP_OK;
 }
 
-extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
-                                    int32_t dtype, int32_t accumulate, void* stream) {
+static int maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                              int32_t accumulate, const BnBack* bnb, float* partial, hipStream_t s) {
   if (!idx || !dy || !dx || (C & 3) || N <= 0) return STP_E_BADARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipStream_t s = (hipStream_t)stream;
   if ((int64_t)N * H > 65535) return STP_E_BADARG;  // gridDim.y
   const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
-  const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
-  if (v8)
-    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
-  else if (dtype == STP_BF16)
-    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
-  else if (dtype == STP_F32)
-    hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), grid, dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate);
-  else
-    return STP_E_BADARG;
+  const int V = v8 ? 8 : 4;
+  const dim3 grid(ceil_div(W * (C / V), 256), N * H);
+  BnBack none;
+  none.x = nullptr; none.mean = none.rstd = none.gamma = none.beta = nullptr; none.relu = 0;
+  if (bnb) {
+    if (256 % (C / V) != 0 || !partial) return STP_E_BADARG;
+    const size_t lds = 256 * 2 * V * sizeof(float);
+    const dim3 gridb(grid.x, ceil_div(N * H, BNB_ROWS));
+    if (v8) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, true>), gridb, dim3(256), lds, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4, true>), gridb, dim3(256), lds, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
+    else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4, true>), gridb, dim3(256), lds, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
+    else return STP_E_BADARG;
+  } else {
+    if (v8) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
+    else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4, false>), grid, dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
+    else return STP_E_BADARG;
+  }
   STP_LAUNCH_CHECK();
   return STP_OK;
+}
+
+extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                    int32_t dtype, int32_t accumulate, void* stream) {
+  return maxpool_bwd_launch(idx, dy, dx, N, H, W, C, dtype, accumulate, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// Same tile count rule as stp_upsample2x_bwd_bn_tiles (H, W = the pool INPUT size): workgroups of the launch, 0 = unsupported C.
+extern "C" int stp_maxpool3x3s2_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype) {
+  const int V = (dtype == STP_BF16 && (C & 7) == 0) ? 8 : 4;
+  if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;
+  return ceil_div(W * (C / V), 256) * ceil_div(N * H, BNB_ROWS);
+}
+
+extern "C" int stp_maxpool3x3s2_bwd_bn(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                       int32_t dtype, int32_t accumulate, const void* bn_x, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, int32_t relu, float* partial, void* stream) {
+  if (!bn_x || !mean || !rstd || !partial) return STP_E_BADARG;
+  BnBack b;
+  b.x = (const char*)bn_x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.relu = relu;
+  return maxpool_bwd_launch(idx, dy, dx, N, H, W, C, dtype, accumulate, &b, partial, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -901,77 +992,41 @@ extern "C" int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtyp
 // BNB: dx is the gradient of a BatchNormalization(+activation) output that this launch completes - the value is masked with the
 // activation re-derived from the BN input x and the workgroup writes its partial sums of g and g * xhat ([2][C][workgroups],
 // the layout stp_bn_backward_fused reduces), exactly as the convolution epilogues do (stp_conv_params.bnb_x).
-__device__ __forceinline__ f32x4 stored4(f32x4 v, const float*) { return v; }   // the value as the destination dtype holds it
-__device__ __forceinline__ f32x4 stored4(f32x4 v, const bf16_t*) {
-  const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
-  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
-}
-
 template <typename T, int V, bool BNB>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
                                                              int C, int ldy, int accumulate, BnBack bnb, float* __restrict__ partial) {
   const int cg = C / V;
   const int t = blockIdx.x * 256 + threadIdx.x;
   const bool on = t < W * cg;
+  if (!BNB && !on) return;
   const int w = on ? t / cg : 0, c = on ? (t - w * cg) * V : 0;
-  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
-  float g[V];
-#pragma unroll
-  for (int e = 0; e < V; ++e) g[e] = 0.f;
+  constexpr int ROWS = BNB ? BNB_ROWS : 1;
   float sg[V], sq[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { sg[e] = 0.f; sq[e] = 0.f; }
-  if (on) {
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int row = blockIdx.y * ROWS + rr;
+    if (row >= N * H || !on) break;
+    const int n = row / H, h = row - n * H;
+    const size_t o = (((size_t)n * H + h) * W + w) * C + c;
     const T* b = dy + (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * ldy + c;
-    float a1[V], a2[V], a3[V];
+    float g[V], a1[V], a2[V], a3[V];
     ldv<T, V>(b, g);
     ldv<T, V>(b + ldy, a1);
     ldv<T, V>(b + (size_t)2 * W * ldy, a2);
     ldv<T, V>(b + (size_t)2 * W * ldy + ldy, a3);
 #pragma unroll
     for (int e = 0; e < V; ++e) g[e] = ((g[e] + a1[e]) + a2[e]) + a3[e];
-    const size_t o = (((size_t)n * H + h) * W + w) * C + c;
-    T* out = dx + o;
     if (accumulate) {
       float p[V];
-      ldv<T, V>(out, p);
+      ldv<T, V>(dx + o, p);
 #pragma unroll
       for (int e = 0; e < V; ++e) g[e] += p[e];
     }
-    if constexpr (BNB) {
-      float xv[V];
-      ldv<T, V>(reinterpret_cast<const T*>(bnb.x) + o, xv);
-#pragma unroll
-      for (int q = 0; q < V / 4; ++q) {
-        const BnBackCh k = bnback_load(bnb, c + 4 * q);
-        const f32x4 st = stored4(f32x4{g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]}, (const T*)nullptr);
-        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 m = bnback_apply(k, bnb.relu, f32x4{xv[4 * q], xv[4 * q + 1], xv[4 * q + 2], xv[4 * q + 3]}, st, s4, q4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { g[4 * q + e] = m[e]; sg[4 * q + e] = s4[e]; sq[4 * q + e] = q4[e]; }
-      }
-    }
-    stv<T, V>(out, g);
+    if constexpr (BNB) bnb_mask_store<T, V>(g, o, c, bnb, dx, sg, sq);
+    else stv<T, V>(dx + o, g);
   }
-  if constexpr (BNB) {
-    // threads t and t + cg own the same channels: fixed-order combine over the workgroup's 256 / cg pixels (cg divides 256)
-    extern __shared__ float red[];  // [256][2V]
-#pragma unroll
-    for (int e = 0; e < V; ++e) { red[threadIdx.x * 2 * V + e] = sg[e]; red[threadIdx.x * 2 * V + V + e] = sq[e]; }
-    __syncthreads();
-    const int cl = cg < 256 ? cg : 256;               // channel groups present in this workgroup
-    for (int idx = threadIdx.x; idx < cl * V; idx += 256) {     // cl * V = min(C, 256 * V) channels
-      const int gq = idx / V, e = idx - gq * V;
-      const int t0 = blockIdx.x * 256;                // first (w, channel group) item of the workgroup
-      const int cg0 = (t0 + gq) % cg;                 // channel group of local thread gq
-      float s = 0.f, q2 = 0.f;
-      for (int l = gq; l < 256; l += cl) { s += red[l * 2 * V + e]; q2 += red[l * 2 * V + V + e]; }
-      const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-      const int ch = cg0 * V + e;
-      partial[(size_t)ch * nblk + blk] = s;
-      partial[((size_t)C + ch) * nblk + blk] = q2;
-    }
-  }
+  if constexpr (BNB) bnb_reduce<V>(sg, sq, cg, C, partial);
 }
 
 static int upsample2x_bwd_launch(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,
@@ -985,9 +1040,10 @@ static int upsample2x_bwd_launch(const void* dy, void* dx, int32_t N, int32_t H,
   if (bnb) {
     if (256 % (C / V) != 0 || !partial) return STP_E_BADARG;       // each workgroup must hold whole pixels of all its channel groups
     const size_t lds = 256 * 2 * V * sizeof(float);
-    if (v8) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8, true>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, true>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
-    else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4, true>), grid, dim3(256), lds, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
+    const dim3 gridb(grid.x, ceil_div(N * H, BNB_ROWS));
+    if (v8) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8, true>), gridb, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, true>), gridb, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
+    else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4, true>), gridb, dim3(256), lds, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
     else return STP_E_BADARG;
   } else {
     if (v8) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
@@ -1009,7 +1065,7 @@ extern "C" int stp_upsample2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int3
   const bool v8 = dtype == STP_BF16 && (C & 7) == 0 && (ldy & 7) == 0;
   const int V = v8 ? 8 : 4;
   if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;          // 0: not supported for this channel count
-  return ceil_div(W * (C / V), 256) * N * H;
+  return ceil_div(W * (C / V), 256) * ceil_div(N * H, BNB_ROWS);
 }
 
 extern "C" int stp_upsample2x_bwd_bn(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,

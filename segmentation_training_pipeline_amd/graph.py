@@ -973,8 +973,20 @@ class Plan(object):
         def back():
             if not (x.needs_grad and out.grad_ready):
                 return
-            self._emit(self.bwd, "stp_maxpool3x3s2_bwd", idx.data_ptr(), out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N,
-                       x.H, x.W, x.C, self.cdt, int(x.grad_ready))
+            acc = int(x.grad_ready)
+            bnm, uses = x.meta.get("bn"), x.meta.get("uses", 0)
+            done = (uses == 1 and not acc) or (self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and acc)
+            ntl = int(self.lib.stp_maxpool3x3s2_bwd_bn_tiles(self.N, x.H, x.W, x.C, self.cdt)) if (
+                self.fuse_bn_backward and bnm is not None and done and self.slot_arena is None) else 0
+            if ntl > 0:
+                # the pool gradient completes dY of a BatchNormalization output (bn0: the other consumer is a decoder skip)
+                st = self._alloc((2 * x.C * ntl,), torch.float32)
+                self._emit(self.bwd, "stp_maxpool3x3s2_bwd_bn", idx.data_ptr(), out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N,
+                           x.H, x.W, x.C, self.cdt, acc, bnm[0], bnm[1], bnm[2], bnm[3], bnm[4], bnm[5], st.data_ptr())
+                x.meta["bnb"] = (st, ntl)
+            else:
+                self._emit(self.bwd, "stp_maxpool3x3s2_bwd", idx.data_ptr(), out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N,
+                           x.H, x.W, x.C, self.cdt, acc)
             x.grad_ready = True
 
         if self.training:

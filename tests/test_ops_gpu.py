@@ -729,6 +729,52 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 14, 12, 64, 1), (1, 9, 21, 64, 0), (2, 8, 8, 32, 1)])
+def test_maxpool_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
+    """stp_maxpool3x3s2_bwd_bn (bn0 of the stem: its gradient = the pool gradient on top of a decoder skip's): must equal
+    stp_maxpool3x3s2_bwd + stp_bn_backward."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c, acc = case
+    rng = np.random.RandomState(6)
+    rows = n * h * w
+    x = q(rng.randn(n, h, w, c) * 1.5 + 0.3, dtype)                    # BN input
+    gamma, beta = (rng.rand(c) + 0.5).astype(np.float32), (rng.randn(c) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd, g, b = dev(x, dtype), f(gamma), f(beta)
+    m, r = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(c) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, c, 1e-3, 0.99, m, r, None, None, ws)
+    act = torch.empty_like(xd)
+    ops.bn_apply(xd, act, rows, c, c, m, r, g, b, relu=1)
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = torch.empty((n, ho, wo, c), dtype=TD[dtype], device=DEV)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=DEV)
+    ops.maxpool3x3s2(act, y, idx, n, h, w, c)
+    dyp = dev(q(rng.randn(n, ho, wo, c), dtype), dtype)
+    prior = q(rng.randn(n, h, w, c), dtype)
+    dy0 = dev(prior, dtype)
+    _lib.call("stp_maxpool3x3s2_bwd", ops.ptr(idx), ops.ptr(dyp), ops.ptr(dy0), n, h, w, c, ops.dt(xd), acc, ops.stream())
+    dx0, dg0, db0 = torch.empty_like(dy0), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.bn_backward(xd, dy0, dx0, rows, c, m, r, g, b, dg0, db0, relu=1, accumulate_dx=0, workspace=ws)
+    tiles = int(_lib.load().stp_maxpool3x3s2_bwd_bn_tiles(n, h, w, c, ops.dt(xd)))
+    assert tiles > 0
+    st = torch.full((2 * c * tiles,), float("nan"), dtype=torch.float32, device=DEV)
+    gbuf = dev(prior, dtype)
+    _lib.call("stp_maxpool3x3s2_bwd_bn", ops.ptr(idx), ops.ptr(dyp), ops.ptr(gbuf), n, h, w, c, ops.dt(xd), acc, ops.ptr(xd), ops.ptr(m),
+              ops.ptr(r), ops.ptr(g), ops.ptr(b), 1, ops.ptr(st), ops.stream())
+    assert not np.isnan(host(st)).any()
+    dx1, dg1, db1 = torch.empty_like(dy0), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.bn_backward_fused(xd, gbuf, dx1, rows, c, m, r, g, st, tiles, dg1, db1, accumulate_dx=0, workspace=ws)
+    pre = host(xd) * (host(r) * gamma) + (beta - host(m) * host(r) * gamma)
+    safe = np.abs(pre) > 1e-3
+    np.testing.assert_array_equal(host(gbuf)[safe], (host(dy0) * (pre > 0))[safe])
+    scale = lambda a: 2e-4 * np.abs(a).max() + 1e-4
+    np.testing.assert_allclose(host(db1), host(db0), atol=scale(host(db0)) * 5)
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=scale(host(dg0)) * 5)
+    np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 6, 10, 64, 0), (2, 5, 7, 512, 1), (1, 8, 16, 128, 1), (2, 4, 4, 32, 0), (1, 3, 5, 256, 1)])
 def test_upsample_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
     """stp_upsample2x_bwd_bn: the 2x2 fold that completes the gradient of a BatchNormalization(+ReLU) output (optionally on top of
