@@ -142,6 +142,11 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): libraries that print to the C-level stdout (RCCL's version banner, MIOpen) are
+    # moved to stderr for the lifetime of the process, the result is written to the original descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -240,7 +245,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
