@@ -15,6 +15,7 @@
 // zero-insert / concat folded in).  Pixels are partitioned over `splits` slabs (split-K) that
 // a second kernel sums in fixed order: deterministic, no atomics.
 #include "common.h"
+#include <cstdlib>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -515,7 +516,8 @@ static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
   if (splits <= 0) {
     // ~2 workgroups per CU; every extra split costs a slab write + read of Cout*K floats, so large
     // weight matrices (stage 3/4) get few splits and the huge-pixel layers many
-    splits = ceil_div(512, tiles);
+    static const int target = getenv("STP_WGRAD_BLOCKS") ? atoi(getenv("STP_WGRAD_BLOCKS")) : 512;
+    splits = ceil_div(target, tiles);
     const int max_by_steps = w.nsteps / 8 > 0 ? w.nsteps / 8 : 1;  // keep >= 8 steps per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > 256) splits = 256;

@@ -2,6 +2,7 @@
 // arena, weight-layout preparation and wire-format casts.  HBM-bound streaming kernels with
 // two-stage fixed-order reductions.
 #include "common.h"
+#include <cstdlib>
 
 #define LOSS_MAX_BLOCKS 1024
 #define LOSS_NSUM 8
@@ -762,12 +763,14 @@ extern "C" int64_t stp_weight_prepare_desc_fill(void* desc_host, int32_t index, 
 
 extern "C" int stp_weight_prepare_batched(const void* desc_dev, int32_t nlayers, int64_t total, int32_t dtype, void* stream) {
   if (!desc_dev || nlayers <= 0 || total <= 0) return STP_E_BADARG;
-  // 64 workgroups per layer: the big layers (9.4 MB) grid-stride, the small ones finish at once
+  // grid.x workgroups per layer: the big layers (9.4 MB, 2304 units) grid-stride over them, the surplus workgroups of the small
+  // layers exit at once (64 -> 256: the launch lasts as long as its largest layer, 130 -> see DESIGN)
   hipStream_t s = (hipStream_t)stream;
+  static const int per_layer = getenv("STP_PREP_BLOCKS") ? atoi(getenv("STP_PREP_BLOCKS")) : 512;
   if (dtype == STP_BF16)
-    hipLaunchKernelGGL(weight_prepare_batched_kernel<bf16_t>, dim3(64, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
+    hipLaunchKernelGGL(weight_prepare_batched_kernel<bf16_t>, dim3(per_layer, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
   else if (dtype == STP_F32)
-    hipLaunchKernelGGL(weight_prepare_batched_kernel<float>, dim3(64, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
+    hipLaunchKernelGGL(weight_prepare_batched_kernel<float>, dim3(per_layer, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
