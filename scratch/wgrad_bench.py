@@ -12,11 +12,11 @@ for name, n, h, w, ci, co, k in LAYERS:
     dy = torch.randn(n, h, w, co, device=DEV).to(torch.bfloat16)
     dw = torch.empty(co, k, k, ci, device=DEV)
     ref = None
-    for splits in (0,):
+    for splits in (0, 4, 8, 16, 32):
         W = ops.wgrad_params(x, dy, dw, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=k, KW=k, stride=1, pad=1, Ho=h, Wo=w, Cout=co,
                              dtype=ops.BF16, splits=splits)
         ws = torch.empty(ops.wgrad_workspace_bytes(W) // 4 + 4, dtype=torch.float32, device=DEV)
-        for variant in (0, 2):
+        for variant in (2, 3):
             ops.conv2d_wgrad_partial(W, ws, variant); ops.conv2d_wgrad_reduce(W, ws, variant); torch.cuda.synchronize()
             if ref is None: ref = dw.clone()
             err = (dw - ref).abs().max().item()
@@ -28,4 +28,4 @@ for name, n, h, w, ci, co, k in LAYERS:
                 e1.record(); torch.cuda.synchronize()
                 t.append(e0.elapsed_time(e1) * 1e3 / 20)
             fl = 2.0 * n * h * w * co * k * k * ci
-            print("%-22s variant %d: partial %8.1f us %7.1f TF  reduce %6.1f us  ws %6.1f MB  maxdiff %.3g" % (name, variant, t[0], fl / t[0] / 1e6, t[1], ws.numel() * 4 / 1e6, err))
+            print("%-22s splits %2d variant %d: partial %8.1f us %7.1f TF  reduce %6.1f us  ws %6.1f MB  maxdiff %.3g" % (name, splits, variant, t[0], fl / t[0] / 1e6, t[1], ws.numel() * 4 / 1e6, err))

@@ -494,6 +494,13 @@ extern "C" int stp_wgrad_sc_slabs(const stp_wgrad_params* p);
 extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream);
 #define WG_TILE_SC 100  // small-channel halo-tile kernel (conv_sc.hip): splits = number of persistent workgroups
 
+static int device_cu_count() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+    n = 256;   // MI355X (also the answer on a build host without a GPU: plan sizes must not depend on where they are computed)
+  return n;
+}
+
 static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
   WgradPlan w;
   if (p->splits == 0 && stp_wgrad_sc_eligible(p)) {
@@ -514,10 +521,15 @@ static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
   const int tiles = w.ntile_m * w.ntile_n;
   int splits = p->splits;
   if (splits <= 0) {
-    // ~2 workgroups per CU; every extra split costs a slab write + read of Cout*K floats, so large
-    // weight matrices (stage 3/4) get few splits and the huge-pixel layers many
-    static const int target = getenv("STP_WGRAD_BLOCKS") ? atoi(getenv("STP_WGRAD_BLOCKS")) : 512;
-    splits = ceil_div(target, tiles);
+    // Fill the machine EXACTLY once: workgroup slots = CUs x co-resident workgroups (LDS-limited: 2 for the 128x128 tile,
+    // 3 for 64x128), splits = floor(slots / tiles).  One workgroup more than the slots costs a whole extra round
+    // (scratch/wgrad_split_sweep.py: 128->128 @64x64, 9 tiles: 57 splits = 513 workgroups 49 us, 56 splits = 504 workgroups 33 us);
+    // every split also costs a slab write + read of Cout*K floats, so fewer is better at equal fill.
+    static const int cus = device_cu_count();
+    static const int target = getenv("STP_WGRAD_BLOCKS") ? atoi(getenv("STP_WGRAD_BLOCKS")) : 0;
+    const int slots = target > 0 ? target : cus * (w.bm == 64 ? 3 : 2);
+    splits = slots / tiles;
+    if (splits < 1) splits = 1;
     const int max_by_steps = w.nsteps / 8 > 0 ? w.nsteps / 8 : 1;  // keep >= 8 steps per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > 256) splits = 256;
