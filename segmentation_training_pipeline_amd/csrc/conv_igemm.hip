@@ -640,6 +640,10 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
   const int64_t big = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 128);
   const int64_t mid = (int64_t)ceil_div(co, 128) * ceil_div(a.P, 64);
   if (ut_ok == 1) {
+    // the last 128-channel tile at most half full (Cout = 192: a data gradient into two concatenated sources): 64-channel tiles
+    // waste nothing (scratch/tile_sweep.py: decoder_stage2_conv1 dgrad 120 -> 104 us)
+    const int tail = co % 128;
+    if (tail > 0 && tail <= 64 && ceil_div(a.P, 128) >= 384) return 64 + 7;
     // one or two K steps (1x1 bottleneck convolutions): nothing to pipeline, the narrower pixel tile's extra workgroups hide
     // more of the per-workgroup latency (scratch/conv1x1_bench.py: 64->256 @ 4x256^2 65 -> 57 us)
     if (a.K <= 128 && mid >= 384) return 64 + 6;

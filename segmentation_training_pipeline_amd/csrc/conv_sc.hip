@@ -13,6 +13,7 @@
 // The k -> (lane group, vector slot) assignment is the same for A and B (all a contraction needs).
 // Used for forward and (with the flipped/transposed weight copy) for the data gradient.
 #include "common.h"
+#include <cstdlib>
 
 struct ScArgs {
   const char* src;     // [N,Hs,Ws,CIN]  (Hs = H/2 when upsampling)
@@ -682,7 +683,8 @@ extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
 // number of slabs (= workgroups) the small-channel weight gradient writes
 extern "C" int stp_wgrad_sc_slabs(const stp_wgrad_params* p) {
   const int64_t tiles = (int64_t)p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW);
-  return (int)(tiles < SC_WG_MAX_BLOCKS ? tiles : SC_WG_MAX_BLOCKS);
+  static const int max_blocks = getenv("STP_SC_WG_BLOCKS") ? atoi(getenv("STP_SC_WG_BLOCKS")) : SC_WG_MAX_BLOCKS;
+  return (int)(tiles < max_blocks ? tiles : max_blocks);
 }
 
 template <typename T, int CIN, int COUT>
