@@ -1404,12 +1404,16 @@ __global__ __launch_bounds__(256) void resize_bilinear_vec_kernel(const T* __res
 template <typename T, int V>
 __global__ __launch_bounds__(256) void resize_bilinear_bwd_blk_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int C,
                                                                       int f, int ldo, int coff, int accumulate, int VL, int rps,
-                                                                      float* __restrict__ part) {
-  extern __shared__ float red[];  // [TL][VL*V]
-  const int TL = 256 / VL;
-  const int vl = threadIdx.x % VL, tl = threadIdx.x / VL;
+                                                                      float* __restrict__ part, int TLp, int PPB, int npix) {
+  // 256 threads = PPB input pixels x TLp tap lanes x VL vector lanes (few taps and few channels - the x4 resize of 3-class
+  // logits - would leave most of a one-pixel workgroup idle)
+  extern __shared__ float red[];  // [PPB][TLp][VL*V]
+  const int vl = threadIdx.x % VL, q = threadIdx.x / VL;
+  const int pl = q / TLp, tl = q - pl * TLp;
   const int Ho = H * f, Wo = W * f;
-  int b = blockIdx.x;
+  const int pix = blockIdx.x * PPB + pl;
+  const bool pon = pl < PPB && pix < npix;
+  int b = pon ? pix : 0;
   const int w = b % W; b /= W;
   const int h = b % H;
   const int n = b / H;
@@ -1418,11 +1422,11 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_blk_kernel(const T* _
   float acc[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) acc[e] = 0.f;
-  if (c < C && tl < TL) {
+  if (c < C && pon) {
     const T* src = dy + (int64_t)n * Ho * Wo * ldo + coff + c;
     const int span = 2 * f;
     const int r0 = blockIdx.z * rps, r1 = min(span, r0 + rps);   // tap rows of this split
-    for (int t = r0 * span + tl; t < r1 * span; t += TL) {
+    for (int t = r0 * span + tl; t < r1 * span; t += TLp) {
       const int ty = t / span, tx = t - ty * span;
       const int yo = (h - 1) * f + ty, xo = (w - 1) * f + tx;
       if (yo < 0 || xo < 0) continue;
@@ -1441,19 +1445,22 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_blk_kernel(const T* _
       for (int e = 0; e < V; ++e) acc[e] += wgt * v[e];
     }
   }
-  if (tl < TL) {
+  if (pl < PPB) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) red[(tl * VL + vl) * V + e] = acc[e];
+    for (int e = 0; e < V; ++e) red[((pl * TLp + tl) * VL + vl) * V + e] = acc[e];
   }
   __syncthreads();
-  const int t = threadIdx.x, cc = blockIdx.y * VL * V + t;
-  if (t < VL * V && cc < C) {
+  const int CW = VL * V;                               // channels of this workgroup's chunk
+  for (int t = threadIdx.x; t < PPB * CW; t += 256) {
+    const int p2 = t / CW, ch = t - p2 * CW;
+    const int cc = blockIdx.y * CW + ch, px = blockIdx.x * PPB + p2;
+    if (cc >= C || px >= npix) continue;
     float sum = 0.f;
-    for (int l = 0; l < TL; ++l) sum += red[l * VL * V + t];
+    for (int l = 0; l < TLp; ++l) sum += red[(p2 * TLp + l) * CW + ch];
     if (part) {
-      part[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * C + cc] = sum;
+      part[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * C + cc] = sum;      // (splits: PPB == 1)
     } else {
-      T* d = dx + (((int64_t)n * H + h) * W + w) * C + cc;
+      T* d = dx + (int64_t)px * C + cc;
       if (accumulate) sum += Elem<T>::load(d);
       Elem<T>::store(d, sum);
     }
@@ -1510,12 +1517,17 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
     int S = ceil_div(span, rps);
     if (S > 1 && (!workspace || workspace_bytes < (size_t)S * npix * C * sizeof(float))) { rps = span; S = 1; }
     float* part = S > 1 ? (float*)workspace : nullptr;
-    const dim3 grid((unsigned)npix, ceil_div(cg, VL), S);
+    // tap lanes per pixel: the largest power of two that the taps can keep busy; the rest of the workgroup takes more pixels
+    int TLp = 1;
+    while (TLp * 2 <= 256 / VL && TLp * 2 <= span * span) TLp *= 2;
+    int PPB = (256 / VL) / TLp;
+    if (S > 1 || PPB < 1) { PPB = 1; TLp = 256 / VL; }
+    const dim3 grid((unsigned)ceil_div(npix, PPB), ceil_div(cg, VL), S);
     const size_t lds = (size_t)(256 / VL) * VL * V * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    if (V == 8) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 8>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part);
-    else hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<float, 4>), grid, dim3(256), lds, s, (const float*)dy, (float*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part);
+    if (V == 8) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 8>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part, TLp, PPB, (int)npix);
+    else if (dtype == STP_BF16) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part, TLp, PPB, (int)npix);
+    else hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<float, 4>), grid, dim3(256), lds, s, (const float*)dy, (float*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part, TLp, PPB, (int)npix);
     STP_LAUNCH_CHECK();
     if (S > 1) {
       const int64_t ne = npix * C;

@@ -818,7 +818,8 @@ def test_upsample_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("geom", [(1, 1, 24, 320), (2, 2, 12, 72), (3, 3, 8, 40), (6, 6, 4, 24), (5, 7, 8, 20), (3, 2, 6, 3), (12, 12, 8, 24)])
+@pytest.mark.parametrize("geom", [(1, 1, 24, 320), (2, 2, 12, 72), (3, 3, 8, 40), (6, 6, 4, 24), (5, 7, 8, 20), (3, 2, 6, 3), (12, 12, 8, 24), (16, 16, 4, 8),
+                                  (5, 7, 2, 8), (9, 3, 3, 16)])
 def test_pyramid_pooling_geometry_resize_and_pool(ops, dtype, geom):
     """PSPNet's pyramid at its real aspect: a (H x W) pooled map blown up by a large factor (level 1 is a single pixel whose
     gradient sums a whole feature map), channel counts that take the 16-byte (x8), 8-byte (x4) and scalar paths, and the
