@@ -812,21 +812,25 @@ __global__ void stem_beta_grad_kernel(const float* __restrict__ padded_dw, const
   const int c = blockIdx.x;
   float a = 0.f;
   const int n = Cout * KH * KW;
-  for (int i = threadIdx.x; i < n; i += 64) {
+  for (int i = threadIdx.x; i < n; i += 256) {
     int r = i;
     const int kw = r % KW; r /= KW;
     const int kh = r % KH;
     const int co = r / KH;
     a += w[(((int64_t)co * KH + kh) * KW + kw) * Cin + c] * padded_dw[(((int64_t)co * KH + kh) * KWp + kw) * Cinp + one_ch];
   }
+  // 4 waves (the kernel is the tail of the backward pass: 3136 products per channel, latency-bound at 64 threads)
+  __shared__ float red[4];
   a = wave_sum(a);
-  if (threadIdx.x == 0) dbeta[c] = a;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) dbeta[c] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 extern "C" int stp_stem_beta_grad(const float* padded_dw, const float* master, float* dbeta, int32_t Cout, int32_t KH,
                                   int32_t KW, int32_t Cin, int32_t KWp, int32_t Cinp, int32_t one_ch, void* stream) {
   if (!padded_dw || !master || !dbeta || one_ch >= Cinp) return STP_E_BADARG;
-  hipLaunchKernelGGL(stem_beta_grad_kernel, dim3(Cin), dim3(64), 0, (hipStream_t)stream, padded_dw, master, dbeta, Cout, KH, KW,
+  hipLaunchKernelGGL(stem_beta_grad_kernel, dim3(Cin), dim3(256), 0, (hipStream_t)stream, padded_dw, master, dbeta, Cout, KH, KW,
                      Cin, KWp, Cinp, one_ch);
   STP_LAUNCH_CHECK();
   return STP_OK;
