@@ -977,7 +977,9 @@ class Plan(object):
             bnm, uses = x.meta.get("bn"), x.meta.get("uses", 0)
             done = (uses == 1 and not acc) or (self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and acc)
             ntl = int(self.lib.stp_maxpool3x3s2_bwd_bn_tiles(self.N, x.H, x.W, x.C, self.cdt)) if (
-                self.fuse_bn_backward and bnm is not None and done and self.slot_arena is None) else 0
+                self.fuse_bn_backward and bnm is not None and done and self.slot_arena is None
+                and os.environ.get("STP_FUSE_POOL_BN", "0") == "1") else 0   # measured: 10.06 -> 10.14 ms when on (the gather + x read +
+            #                                                                    reduce in one kernel runs at half the rate of the pair)
             if ntl > 0:
                 # the pool gradient completes dY of a BatchNormalization output (bn0: the other consumer is a decoder skip)
                 st = self._alloc((2 * x.C * ntl,), torch.float32)
