@@ -653,7 +653,8 @@ class Plan(object):
                     acc_up = int(x.grad_ready)
                     done = (uses == 1 and not acc_up) or (self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and acc_up)
                     ntl = int(self.lib.stp_upsample2x_bwd_bn_tiles(self.N, x.H, x.W, C0, C0, self.cdt)) if (
-                        self.fuse_bn_backward and bnm is not None and done and self.slot_arena is None) else 0
+                        self.fuse_bn_backward and bnm is not None and done and self.slot_arena is None
+                        and os.environ.get("STP_FUSE_UP_BN", "1") != "0") else 0
                     if ntl > 0:
                         # the upsampling gradient completes dY of a BatchNormalization output: mask + backward sums in the same pass
                         st = self._alloc((2 * C0 * ntl,), torch.float32)
