@@ -108,7 +108,7 @@ def pmc_traffic(kernel):
     """L2-miss bytes per launch of ``kernel`` (read + write) from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
     that kernel was not in the measured build."""
-    for name in ("r01f_pmc_traffic.json", "r01e_pmc_traffic.json", "r01d_pmc_traffic.json", "r01c_pmc_traffic.json", "r01b_pmc_traffic.json"):      # newest measurement that knows this kernel
+    for name in ("r01g_pmc_traffic.json", "r01f_pmc_traffic.json", "r01e_pmc_traffic.json", "r01d_pmc_traffic.json", "r01c_pmc_traffic.json", "r01b_pmc_traffic.json"):      # newest measurement that knows this kernel
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01f
+O=$R/gpurun_out/r01g
 mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
