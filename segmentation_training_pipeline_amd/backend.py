@@ -253,17 +253,39 @@ class HipSegModel(object):
     def get_gradients(self):
         return self._unflatten(self.plan.G.cpu().numpy())
 
+    def broadcast_state(self, src=0):
+        """Data-parallel start of a stage: every replica takes rank ``src``'s parameters, BatchNormalization moving
+        statistics and optimizer state (after a checkpoint load only rank 0 read the file)."""
+        distributed.broadcast_tensors(self._mutable_state(), src=src)
+
     def save_weights(self, path):
         """Checkpoint payload: safetensors of the Keras-layout tensors (Keras HDF5 cannot be
-        produced here - h5py is absent; the file naming is the reference's, README.md:382)."""
+        produced here - h5py is absent; the file naming is the reference's, README.md:382).  Written to a temporary
+        file and renamed, so a reader never sees a partial checkpoint."""
+        import os
         from safetensors.numpy import save_file
         w = self.get_weights()
-        save_file({k: np.ascontiguousarray(v) for k, v in w.items()}, path,
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        save_file({k: np.ascontiguousarray(v) for k, v in w.items()}, tmp,
                   metadata={"format": "stp-keras-layout", "backbone": self.backbone, "architecture": self.architecture})
+        os.replace(tmp, path)
 
-    def load_weights(self, path):
+    def load_weights(self, path, strict=True):
+        """Loads a checkpoint written by save_weights (``strict=False``: tensors the plan does not have are skipped -
+        an encoder-only pretrained file, or a classifier head left in it).  The reference stores Keras HDF5 under the same file name
+        (model.save_weights, README.md:382): such a file is recognised by its signature and rejected with a message that
+        says what to do, instead of a parser error."""
         from safetensors.numpy import load_file
-        self.set_weights(load_file(path))
+        with open(path, "rb") as f:
+            head = f.read(8)
+        if head == b"\x89HDF\r\n\x1a\n":
+            raise ValueError("%s is a Keras HDF5 checkpoint written by the reference pipeline; this backend stores safetensors "
+                             "with Keras-layout tensors under the same name. Export the Keras weights to a {layer/weight: array} "
+                             "dict (model.get_weights with layer names) and pass it to set_weights(), then save_weights()." % path)
+        w = load_file(path)
+        if not strict:
+            w = {k: v for k, v in w.items() if k in self.plan.params or k in self.plan.states}
+        self.set_weights(w)
 
     # ------------------------------------------------------------------ stepping
     def _ensure_graphs(self):

@@ -1,0 +1,205 @@
+// Shared pieces of the MFMA convolution kernels (conv_igemm.hip: per-tap operand tiles; conv_halo.hip: halo-resident
+// activation slabs): argument block, MFMA wrappers, the fused epilogue.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+  const char* src0;
+  const char* src1;
+  const char* weight;
+  const char* residual;
+  const float* bias;
+  char* dst0;
+  char* dst1;
+  int N, Hs0, Ws0, Hv, Wv, C0, C1, Ctot, mode;
+  int KH, KW, stride, pad, Ho, Wo, Cout, Cd0, Cd1;
+  int acc0, acc1, relu;
+  int K, P, HoWo, wrows;
+  int ntile_m, ntile_n;
+  uint32_t bytes0, bytes1, bytesw;
+  float* stats;  // optional [2][Cout][ntile_n] floats, or (stat_slots > 0) int64 fixed-point slots [2][Cout][stat_slots]
+  int stat_slots;
+  BnBack bnb;    // bnb.x != NULL: stats are the BatchNormalization-backward sums and dst receives the masked gradient
+  FastDiv divC, divKW, divHoWo, divWo, divNtm;   // magic-number division: a runtime integer divide costs ~30 VALU instructions
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // A lane holds k = 4*(lane>>4) + s, s = 0..3, of a 16-wide K chunk; step s multiplies the s-th
+  // components.  A and B use the same (lane, s) -> k map, which is all the contraction needs.
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+
+// One K-tile of MFMAs for this wave: TM x TN fragments of 16x16, two 64-byte chunks per 128-byte row.
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void compute_tile(const char* stage, int wm, int wn, int lr, int lg,
+                                             f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  const char* sa = stage + (wm * (BM / WM)) * 128;
+  const char* sb = stage + BM * 128 + (wn * (BN / WN)) * 128;
+  // all fragment reads of the K-tile are issued before its first MFMA (the compiler would otherwise sink them
+  // next to their users to save registers, exposing one LDS round trip per four MFMAs); the s_waitcnt counters
+  // it inserts then release the first 64-byte chunk while the second is still in flight
+  u32x4 fa[2][TM], fb[2][TN];
+#if defined(STP_EXP) && STP_EXP == 3  // what-if: no LDS fragment reads either (pure MFMA issue rate)
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[c][i] = u32x4{(uint32_t)lr, (uint32_t)lg, (uint32_t)c, (uint32_t)i};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[c][j] = u32x4{(uint32_t)lg, (uint32_t)lr, (uint32_t)j, (uint32_t)c};
+  }
+  asm volatile("" ::: "memory");
+#else
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = i * 16 + lr;  // (wave row offset is a multiple of 16 -> row&7 unchanged)
+      fa[c][i] = *reinterpret_cast<const u32x4*>(sa + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = j * 16 + lr;
+      fb[c][j] = *reinterpret_cast<const u32x4*>(sb + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
+    }
+  }
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) Mma<T>::run(fa[c][i], fb[c][j], acc[i][j]);
+}
+
+// value as it will be read back from memory (the BatchNorm that follows normalises the STORED tensor)
+__device__ __forceinline__ f32x4 stored(f32x4 v, const float*) { return v; }
+__device__ __forceinline__ f32x4 stored(f32x4 v, const bf16_t*) {
+  const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+}
+
+// bias, residual, ReLU, dual destination, optional accumulate, optional fused BatchNormalization statistics.
+//
+// Statistics: per-channel sum and sum of squares (of the values as STORED) over this workgroup's pixels.  The
+// 16 lanes of a DPP row hold 16 different pixels of the same 4 channels -> row reduction with DPP adds, then
+// the WN waves that share the channels are combined through LDS in a fixed order.  Layout written:
+// stats[stat][channel][tile] (tile index contiguous, so the finalize reads coalesced).  The channel-tile loop
+// is the OUTER loop so that only one pair of accumulators is live at a time (register pressure).
+// PRE: the residual / BatchNormalization-backward x values of this lane's outputs were fetched before the K loop (bf16,
+// buffer-DMA kernel) - the epilogue's own loads sit behind per-fragment branches and would be latency-serialised.
+__device__ __forceinline__ f32x4 unpack_bf16x4(const u32x2 r) {
+  return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool PRE = false>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0, int wm, int wn, int lr, int lg,
+                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int tile_n,
+                                         const u32x2 (*pre)[BN / WN / 16] = nullptr) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  const T* res = reinterpret_cast<const T*>(a.residual);
+  float* red = reinterpret_cast<float*>(smem);  // [WN][BM][2], valid after the barrier below
+  if (a.stats) __syncthreads();                 // the K-loop's LDS tiles are dead from here on
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+    f32x4 ss = {0.f, 0.f, 0.f, 0.f}, qq = {0.f, 0.f, 0.f, 0.f};
+    if (co < a.Cout) {
+      BnBackCh bk;
+      if (a.bnb.x) bk = bnback_load(a.bnb, co);  // Cout % 4 == 0 in this mode
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
+        if (pm >= a.P) continue;
+        f32x4 v = acc[i][j];
+        if (co + 3 < a.Cout) {
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+          if (res) {
+            if constexpr (PRE) v += unpack_bf16x4(pre[i][j]);
+            else v += load4(res + (size_t)pm * a.Cout + co);
+          }
+          T* d;
+          bool accum;
+          if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
+          else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
+          if (accum) v += load4(d);
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (a.bnb.x) {
+            f32x4 xv;
+            if constexpr (PRE) xv = unpack_bf16x4(pre[i][j]);
+            else xv = load4(reinterpret_cast<const T*>(a.bnb.x) + (size_t)pm * a.Cout + co);
+            v = bnback_apply(bk, a.bnb.relu, xv, stored(v, (const T*)nullptr), ss, qq);
+          }
+#if defined(STP_EXP) && STP_EXP == 4   // what-if: no output stores (the branch is never taken, the values stay live)
+          if (a.P < 0)
+#endif
+          store4(d, v);
+          if (a.stats && !a.bnb.x) {
+            const f32x4 sv = stored(v, (const T*)nullptr);
+            ss += sv;
+            qq += sv * sv;
+          }
+        } else {
+          // ragged channel tail (e.g. the 1-class head): scalar path
+          for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
+            const int c1 = co + r;
+            float x = v[r];
+            if (a.bias) x += a.bias[c1];
+            if (res) x += Elem<T>::load(res + (size_t)pm * a.Cout + c1);
+            T* d;
+            bool accum;
+            if (c1 < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + c1; accum = a.acc0; }
+            else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (c1 - a.Cd0); accum = a.acc1; }
+            if (accum) x += Elem<T>::load(d);
+            if (a.relu) x = fmaxf(x, 0.f);
+            Elem<T>::store(d, x);
+          }
+        }
+      }
+    }
+    if (a.stats) {  // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = row_sum16_to_lane15(ss[e]), q = row_sum16_to_lane15(qq[e]);
+        if (lr == 15) {
+          const int cl = wm * (BM / WM) + i * 16 + lg * 4 + e;
+          red[(wn * BM + cl) * 2] = s;
+          red[(wn * BM + cl) * 2 + 1] = q;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < BM; c += 256) {
+      if (cout0 + c >= a.Cout) continue;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) { s += red[(w * BM + c) * 2]; q += red[(w * BM + c) * 2 + 1]; }
+      if (a.stat_slots) {
+        long long* sl = reinterpret_cast<long long*>(a.stats);
+        slot_add(sl, a.stat_slots, cout0 + c, tile_n, s);
+        slot_add(sl, a.stat_slots, a.Cout + cout0 + c, tile_n, q);
+        continue;
+      }
+      a.stats[(size_t)(cout0 + c) * a.ntile_n + tile_n] = s;
+      a.stats[((size_t)a.Cout + cout0 + c) * a.ntile_n + tile_n] = q;
+    }
+  }
+}
+

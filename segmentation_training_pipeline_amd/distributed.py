@@ -22,6 +22,12 @@ def env_world():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def device_index(local_rank):
+    """GPU of a local rank: its own device, wrapped around when the node exposes fewer devices than ranks (tests)."""
+    n = torch.cuda.device_count()
+    return local_rank % n if n else 0
+
+
 def init(backend=None, force=False):
     """Joins the torchrun rendezvous (env://).  With world size 1 nothing is initialised unless ``force``
     (used to exercise the RCCL path on a single GPU)."""
@@ -32,9 +38,10 @@ def init(backend=None, force=False):
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            # STP_DIST_BACKEND=gloo: several ranks sharing ONE GPU (RCCL refuses duplicate devices) - the 2-rank tests
+            backend = os.environ.get("STP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device_index(local_rank))
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -154,6 +161,67 @@ class GradReducer(object):
         # issued back to back on the current stream: RCCL pipelines consecutive collectives of one communicator
         for s, e in self._bounds:
             dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group)
+
+
+def active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def barrier():
+    if active():
+        dist.barrier()
+
+
+def broadcast_tensors(tensors, src=0):
+    """Rank ``src``'s values of every tensor replace the others' (parameters, BatchNormalization statistics, optimizer
+    state after a checkpoint load: the replicas must start a stage bit-identical, nothing re-synchronises them later)."""
+    if not active():
+        return
+    for t in tensors:
+        if t is not None:
+            dist.broadcast(t, src=src)
+
+
+def average_tensor(t):
+    """In-place mean over the ranks (BatchNormalization moving statistics at the end of an epoch)."""
+    if active() and t is not None and t.numel():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.mul_(1.0 / dist.get_world_size())
+
+
+def allreduce_sums(vec):
+    """SUM over the ranks of a small float64 vector (epoch scalars: weighted metric sums + sample counts).  Every rank
+    receives the same bits, so decisions derived from the result (best checkpoint, EarlyStopping, ReduceLROnPlateau) are
+    identical on all ranks by construction.  Goes through a CPU tensor with gloo, a device tensor with RCCL."""
+    import numpy as np
+    v = np.asarray(vec, np.float64)
+    if not active():
+        return v
+    t = torch.from_numpy(v.copy())
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def replicas_equal(t):
+    """True when every rank holds the same bits in ``t`` (exact integer checksum of the raw words, MAX-reduced with its
+    negation): the data-parallel replicas must never drift - nothing re-synchronises them inside a stage."""
+    if not active():
+        return True
+    words = t.detach().reshape(-1).view(torch.int32).to(torch.int64)
+    c = int((words * (torch.arange(words.numel(), device=words.device, dtype=torch.int64) % 8191 + 1)).sum().item())
+    v = torch.tensor([c, -c], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        v = v.cuda()
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    return int(v[0].item()) == -int(v[1].item())
+
+
+def shard_list(indexes, rank, world):
+    """Strided shard WITHOUT wrap-around (validation: no collective per batch, so the shards may differ by one sample;
+    every sample is evaluated exactly once across the ranks)."""
+    return list(indexes)[rank::world] if world > 1 else list(indexes)
 
 
 def shard_indices(n, rank, world, epoch, seed):

@@ -1071,6 +1071,24 @@ class Plan(object):
         if forked:
             main.wait_stream(side)
 
+    LOSS_LAUNCHES = ("stp_sigmoid_bce_dice", "stp_softmax_cce_dice", "stp_prob_bce_dice")
+
+    def rerun_loss(self, n_valid):
+        """Re-evaluates the loss / metric reduction over the first ``n_valid`` samples only (an evaluation batch whose tail
+        was filled by wrapping around: the duplicates must not enter val_loss / dice - Keras evaluates a short last batch
+        as it is).  Samples are the slowest dimension of every tensor, so the real ones are a prefix of the element range."""
+        n_valid = int(n_valid)
+        if not 0 < n_valid <= self.N:
+            raise ValueError("n_valid out of range")
+        st = torch.cuda.current_stream().cuda_stream
+        for fn, args, name, _meta in self.fwd:
+            if name in self.LOSS_LAUNCHES:
+                a = list(args)
+                a[2] = args[2] // self.N * n_valid        # element / pixel count: [N, ...] -> [n_valid, ...]
+                _lib.check(fn(*a, st), name)
+                return
+        raise _lib.StpError("the plan has no loss launch")
+
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)

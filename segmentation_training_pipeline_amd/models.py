@@ -15,6 +15,20 @@ from . import nets
 from .backend import HipSegModel
 
 
+def pretrained_path(name, backbone):
+    root = os.environ.get("STP_PRETRAINED_DIR", os.path.join(os.path.expanduser("~"), ".stp", "pretrained"))
+    return os.path.join(root, "%s_%s.weights" % (backbone, name))
+
+
+def resolve_pretrained(name, backbone):
+    """``encoder_weights`` -> checkpoint path or None: an existing file path is taken as is; a name (`imagenet`,
+    `pascal_voc`) is looked up as ``$STP_PRETRAINED_DIR/<backbone>_<name>.weights``."""
+    if os.path.exists(str(name)):
+        return str(name)
+    p = pretrained_path(name, backbone)
+    return p if os.path.exists(p) else None
+
+
 class SegModel(object):
     """Uncompiled model description; ``compile`` builds the HIP training plan."""
 
@@ -39,11 +53,20 @@ class SegModel(object):
                                 clipvalue=clipvalue, use_graph=use_graph, device=device, opt_kwargs=opt_kwargs)
         ew = self.encoder_weights
         if ew:
-            if os.path.exists(str(ew)):
-                self.impl.load_weights(str(ew))
+            path = resolve_pretrained(ew, self.backbone_name)
+            if path is not None:
+                self.impl.load_weights(path, strict=False)
+            elif os.environ.get("STP_ALLOW_RANDOM_ENCODER") == "1" or getattr(self, "allow_random_encoder_init", False):
+                warnings.warn("encoder_weights=%r: no pretrained file found; the encoder starts from he_uniform "
+                              "initialisation (STP_ALLOW_RANDOM_ENCODER=1)" % (ew,))
             else:
-                warnings.warn("encoder_weights=%r: no pretrained file is available offline; the encoder starts from "
-                              "he_uniform initialisation (pass a path to a .weights file to load one)" % (ew,))
+                # the reference downloads these weights; a silent random start would train something else under the same YAML
+                raise RuntimeError(
+                    "encoder_weights=%r: no pretrained weights for %r are available offline. Put a checkpoint at %s "
+                    "(safetensors with Keras-layout tensors under the classification_models layer names - convert a Keras "
+                    "model with {w.name: value} -> safetensors), or pass a path as encoder_weights, or set `encoder_weights: null` "
+                    "in the YAML, or export STP_ALLOW_RANDOM_ENCODER=1 to train from random initialisation knowingly."
+                    % (ew, self.backbone_name, pretrained_path(ew, self.backbone_name)))
         if self._pending_weights is not None:
             self.impl.load_weights(self._pending_weights)
             self._pending_weights = None

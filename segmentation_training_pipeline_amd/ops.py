@@ -183,6 +183,12 @@ def grad_global_scale(grad, count, clipnorm, base, gscale, workspace):
 
 
 def augment_u8(img, mask, img_out, mask_out, params, N, Hin, Win, Hout, Wout, Cn):
+    # the C entry point takes raw pointers: a destination smaller than N x Hout x Wout (x Cn) would be written past its end
+    if img_out.numel() < N * Hout * Wout * Cn or img.numel() < N * Hin * Win * Cn:
+        raise ValueError("augment_u8: image buffers are smaller than N x H x W x C (%d < %d or %d < %d)" % (
+            img_out.numel(), N * Hout * Wout * Cn, img.numel(), N * Hin * Win * Cn))
+    if mask is not None and mask_out is not None and (mask_out.numel() < N * Hout * Wout or mask.numel() < N * Hin * Win):
+        raise ValueError("augment_u8: mask buffers are smaller than N x H x W")
     _lib.call("stp_augment_u8", ptr(img), ptr(mask), ptr(img_out), ptr(mask_out), ptr(params), N, Hin, Win, Hout, Wout, Cn,
               stream())
 

@@ -504,14 +504,22 @@ class Trainer(object):
     def _batches(self, indexes, batch, training):
         f = self.feeder
         oh_ow = f.out_hw
-        sampler = lambda n, h, w: augment.sample_batch_ex(f.spec if training else [], f.rng, n, h, w, oh_ow)
+        # the loader thread samples the augmentation records: it gets its OWN generator (seeded from the feeder's), so the
+        # training thread's draws (per-item path of DeviceFeeder.feed, DrawResults) never interleave with it
+        rng = np.random.RandomState(f.rng.randint(0, 2 ** 31 - 1))
+        sampler = lambda n, h, w: augment.sample_batch_ex(f.spec if training else [], rng, n, h, w, oh_ow)
         return HostPrefetcher(self.ds, [int(i) for i in indexes], batch, f.classes, f.pin, sampler=sampler)
 
-    def run_epoch(self, indexes, training):
+    def run_epoch_sums(self, indexes, training):
+        """One pass over ``indexes`` -> ({log name: sum over batches of value * real samples of the batch}, real samples).
+        Keras weights a batch's metric value by the batch's size; a short last batch is padded by wrapping around (static plan
+        batch), so for EVALUATION the loss / metric reduction is repeated over the real samples only (Plan.rerun_loss) -
+        the duplicates never reach val_loss, the best-checkpoint choice or the callbacks."""
         m = self.model
         plan = m.plan if training else m.eval_plan()
-        agg, snaps = {}, []
+        snaps, counts = [], []
         for items in self._batches(indexes, m.batch, training):
+            n_real = min(len(items), m.batch)
             self.feeder.feed(plan, items, training)
             if training:
                 m.train_on_batch(None, None, fetch=False)
@@ -520,14 +528,39 @@ class Trainer(object):
                         cb.on_batch_end(self)
             else:
                 plan.run(plan.prep); plan.run(plan.fwd)
+                if n_real < m.batch:
+                    plan.rerun_loss(n_real)
             # the step's scalars stay on the device (no host sync per batch: the host keeps running ahead, so the next
             # batch's H2D copies overlap this step); they are fetched once per epoch
             snaps.append(plan.loss_scalars.clone())
+            counts.append(n_real)
+        sums = {}
         if snaps:
-            for scal in torch.stack(snaps).cpu().numpy():
+            for scal, n in zip(torch.stack(snaps).cpu().numpy(), counts):
                 for k, v in derived_metrics(scal, getattr(m, "classes", 1)).items():
-                    agg[k] = agg.get(k, 0.0) + v
-        return {k: v / max(len(snaps), 1) for k, v in agg.items()}
+                    sums[k] = sums.get(k, 0.0) + v * n
+        return sums, int(sum(counts))
+
+    def run_epoch(self, indexes, training):
+        """Sample-weighted epoch means, combined over all ranks (one small SUM-all-reduce per call): every rank returns
+        the same values bit for bit."""
+        sums, n = self.run_epoch_sums(indexes, training)
+        return reduce_epoch_sums(sums, n, getattr(self.model, "classes", 1))
+
+
+def epoch_log_names(classes=1):
+    return sorted(derived_metrics(np.zeros(12, np.float32), classes))
+
+
+def reduce_epoch_sums(sums, n, classes=1):
+    """{name: weighted sum}, samples -> {name: mean over the samples of ALL ranks}.  The vector layout is fixed by the
+    metric names (not by what a rank happened to see), so a rank with an empty shard still takes part in the collective."""
+    names = epoch_log_names(classes)
+    vec = distributed.allreduce_sums([sums.get(k, 0.0) for k in names] + [float(n)])
+    total = vec[-1]
+    if total <= 0:
+        return {}
+    return {k: float(vec[i] / total) for i, k in enumerate(names)}
 
 
 # ------------------------------------------------------------------------------------------ config
@@ -630,7 +663,7 @@ class GenericTaskConfig(object):
         if stage is not None and stage.unfreeze_encoder:
             stage.unfreeze(model)
         rank, local_rank, world = distributed.env_world()
-        device = "cuda:%d" % local_rank
+        device = "cuda:%d" % distributed.device_index(local_rank)
         model.compile(optimizer=self.optimizer, loss=loss, lr=lr, batch=self.batch, dtype=self.dtype, clipnorm=self.clipnorm,
                       clipvalue=self.clipvalue, metrics=self.metrics, device=device, use_graph=use_graph)
         return model
@@ -705,9 +738,12 @@ class GenericTaskConfig(object):
         model = self._compiled(stage)
         impl = model.impl
         init = stage.initial_weights or prev_weights
-        if init:
+        if init and rank == 0:
+            # only rank 0 touches the file (it is the rank that wrote it); the others receive the tensors below
             impl.load_weights(os.path.join(os.path.dirname(os.path.abspath(self.path)), init) if not os.path.isabs(init) else init)
         if world > 1:
+            # replicas start the stage bit-identical: parameters, BatchNormalization statistics and optimizer state of rank 0
+            impl.broadcast_state(src=0)
             impl.set_data_parallel(distributed.GradReducer())
         H, W = impl.H, impl.W                                  # = shape, or shape / crops
         feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state * 7919 + fold * 101 + si,
@@ -727,9 +763,15 @@ class GenericTaskConfig(object):
         for epoch in range(stage.epochs):
             order = np.array(train_idx)[distributed.shard_indices(len(train_idx), rank, world, epoch, self.random_state + fold)] \
                 if len(train_idx) else np.array([], np.int64)
+            # Multi-GPU: every quantity a decision depends on is reduced over the ranks first (run_epoch ends in one small
+            # SUM-all-reduce), so `best`, EarlyStopping and ReduceLROnPlateau see the same numbers on every rank and no rank
+            # can leave the epoch loop or change its learning rate alone.  The validation set is sharded by rank (each sample
+            # evaluated once) and the replicas' BatchNormalization moving statistics are averaged before it.
             logs = trainer.run_epoch(order, True)
+            if world > 1:
+                distributed.average_tensor(impl.plan.S)
             if len(val_idx):
-                logs.update({"val_" + k: v for k, v in trainer.run_epoch(val_idx, False).items()})
+                logs.update({"val_" + k: v for k, v in trainer.run_epoch(distributed.shard_list(val_idx, rank, world), False).items()})
             logs["lr"] = impl.get_lr()
             rows.append(dict(epoch=epoch, **logs))
             cur = log_value(logs, self.primary_metric)
@@ -745,8 +787,18 @@ class GenericTaskConfig(object):
                 stop = stop or getattr(cb, "stop", False)
             if rank == 0:
                 self._write_metrics(fold, si, rows)
+            if world > 1:
+                # belt and braces: the decisions were taken on identical inputs; rank 0's learning rate and the OR of the stop
+                # flags are made authoritative anyway, so a replica can neither drift nor wait alone in a collective
+                v = distributed.allreduce_sums([1.0 if stop else 0.0, impl.get_lr() if rank == 0 else 0.0])
+                stop = bool(v[0] > 0)
+                if abs(float(v[1]) - impl.get_lr()) > 0:
+                    impl.set_lr(float(v[1]))
             if stop:
                 break
+        if world > 1 and not distributed.replicas_equal(impl.plan.P):
+            raise RuntimeError("data-parallel replicas diverged during fold %d stage %d (parameter checksums differ)" % (fold, si))
+        distributed.barrier()        # rank 0's checkpoint of this stage is complete before any rank moves on
         return {"fold": int(fold), "stage": int(si), "epochs_run": len(rows), "best_epoch": int(best_epoch),
                 self.primary_metric: float(best) if best is not None else None, "seconds": round(time.time() - t0, 3)}
 
@@ -764,6 +816,8 @@ class GenericTaskConfig(object):
         geometrically; records the loss per batch and stops early once it exceeds 4x the best one.  No weights are saved."""
         if d is None:
             d = self._dataset_from_yaml()
+        if self.crops:
+            d = CropsDataSet(d, self.crops)       # as fit(): the network is built for shape / crops (createNet1)
         fold = (foldsToExecute or [0])[0]
         kf = self.kfold(d, range(len(d)))
         idx = [int(i) for i in kf.sampledIndexes(fold, True, "all")]
@@ -771,7 +825,7 @@ class GenericTaskConfig(object):
         st = self.stages[stage]
         model = self._compiled(st)
         impl = model.impl
-        H, W = int(self.shape[0]), int(self.shape[1])
+        H, W = impl.H, impl.W                                  # = shape, or shape / crops: the size of the plan's input buffers
         feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state, classes=self.classes)
         trainer = Trainer(impl, feeder, d, [], 0, 1)
         nb = max(1, -(-len(idx) // impl.batch)) * int(epochs)

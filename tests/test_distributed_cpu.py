@@ -87,3 +87,54 @@ def test_overlap_schedule_covers_every_bucket_once_in_backward_order():
     short = [(e, max(l, n // 2)) for e, l in plan.bwd_marks]
     segs2 = distributed.overlap_schedule(short, bounds, len(plan.bwd))
     assert sorted(r for _, rs in segs2 for r in rs) == bounds and segs2[-1][0] == len(plan.bwd)
+
+
+def _epoch_worker(rank, world, port, q):
+    """Rank-consistent epoch bookkeeping (pipeline.reduce_epoch_sums / distributed.allreduce_sums / broadcast_tensors): the
+    ranks feed DIFFERENT shard sums and must come out with the SAME logs bit for bit - which is what makes the best-checkpoint
+    choice, EarlyStopping and ReduceLROnPlateau identical on every rank (ranks could stop alone and hang)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from segmentation_training_pipeline_amd import distributed, pipeline
+    distributed.init("gloo")
+    names = pipeline.epoch_log_names(1)
+    # rank 0 saw 5 samples, rank 1 saw 3 (validation shards differ by design); rank-specific metric sums
+    n = 5 if rank == 0 else 3
+    sums = {k: (i + 1) * 0.37 * n * (1.0 + 0.1 * rank) for i, k in enumerate(names)}
+    logs = pipeline.reduce_epoch_sums(sums, n, 1)
+    expect = {k: ((i + 1) * 0.37 * 5 * 1.0 + (i + 1) * 0.37 * 3 * 1.1) / 8.0 for i, k in enumerate(names)}
+    ok = all(abs(logs[k] - expect[k]) < 1e-12 for k in names)
+    # an empty shard still takes part in the collective (fixed vector layout)
+    logs2 = pipeline.reduce_epoch_sums({} if rank == 1 else {k: 2.0 * 4 for k in names}, 0 if rank == 1 else 4, 1)
+    ok = ok and all(abs(logs2[k] - 2.0) < 1e-12 for k in names)
+    # callbacks driven by the reduced logs take the same decision everywhere
+    es = pipeline.EarlyStopping(patience=1, monitor="val_loss")
+    for ep, v in enumerate((1.0, 0.9, 0.95)):
+        es.on_epoch_end(None, ep, {"val_loss": pipeline.reduce_epoch_sums({"loss": v * n * (1 + rank)}, n, 1)["loss"]})
+    # parameter broadcast: rank 1 starts from garbage and ends with rank 0's tensors
+    t = torch.arange(1000, dtype=torch.float32) if rank == 0 else torch.full((1000,), -7.0)
+    s = torch.ones(10) * (3.0 if rank == 0 else 9.0)
+    distributed.broadcast_tensors([t, None, s], src=0)
+    ok = ok and torch.equal(t, torch.arange(1000, dtype=torch.float32)) and torch.equal(s, torch.ones(10) * 3.0)
+    avg = torch.ones(4) * (rank + 1)
+    distributed.average_tensor(avg)
+    ok = ok and torch.equal(avg, torch.ones(4) * 1.5)
+    sh = distributed.shard_list(list(range(7)), rank, world)
+    q.put((rank, bool(ok), tuple(sorted(logs.items())), es.stop, tuple(sh)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_epoch_scalars_and_decisions_are_rank_consistent():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[:2] for r in res] == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2]                       # identical logs, bit for bit
+    assert res[0][3] == res[1][3] is True                # the same stop decision
+    assert sorted(res[0][4] + res[1][4]) == list(range(7))   # validation shards partition the set
