@@ -107,25 +107,26 @@ __device__ __forceinline__ f32x4 unpack_bf16x4(const u32x2 r) {
   return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool PRE = false>
-__device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0, int wm, int wn, int lr, int lg,
-                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int tile_n,
-                                         const u32x2 (*pre)[BN / WN / 16] = nullptr) {
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+// pixf(j) -> the flattened output pixel (n*Ho*Wo + ho*Wo + wo) of this lane's j-th fragment column, or < 0 to skip it.
+// TM x TN fragments per wave, `cw` = the wave's first output channel inside the BM-channel tile, WNN waves share those
+// channels (different pixels), NT threads per workgroup.
+template <typename T, int TM, int TN, int BM, int WNN, int NT, bool PRE, typename PixF>
+__device__ __forceinline__ void epilogue_px(const ConvArgs& a, int cout0, int cw, int wn, int lr, int lg, f32x4 (&acc)[TM][TN], char* smem,
+                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf) {
   const T* res = reinterpret_cast<const T*>(a.residual);
   float* red = reinterpret_cast<float*>(smem);  // [WN][BM][2], valid after the barrier below
   if (a.stats) __syncthreads();                 // the K-loop's LDS tiles are dead from here on
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+    const int co = cout0 + cw + i * 16 + lg * 4;
     f32x4 ss = {0.f, 0.f, 0.f, 0.f}, qq = {0.f, 0.f, 0.f, 0.f};
     if (co < a.Cout) {
       BnBackCh bk;
       if (a.bnb.x) bk = bnback_load(a.bnb, co);  // Cout % 4 == 0 in this mode
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
-        if (pm >= a.P) continue;
+        const int pm = pixf(j);
+        if (pm < 0) continue;
         f32x4 v = acc[i][j];
         if (co + 3 < a.Cout) {
           if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
@@ -177,7 +178,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
       for (int e = 0; e < 4; ++e) {
         const float s = row_sum16_to_lane15(ss[e]), q = row_sum16_to_lane15(qq[e]);
         if (lr == 15) {
-          const int cl = wm * (BM / WM) + i * 16 + lg * 4 + e;
+          const int cl = cw + i * 16 + lg * 4 + e;
           red[(wn * BM + cl) * 2] = s;
           red[(wn * BM + cl) * 2 + 1] = q;
         }
@@ -186,11 +187,11 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
   }
   if (a.stats) {
     __syncthreads();
-    for (int c = threadIdx.x; c < BM; c += 256) {
+    for (int c = threadIdx.x; c < BM; c += NT) {
       if (cout0 + c >= a.Cout) continue;
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < WN; ++w) { s += red[(w * BM + c) * 2]; q += red[(w * BM + c) * 2 + 1]; }
+      for (int w = 0; w < WNN; ++w) { s += red[(w * BM + c) * 2]; q += red[(w * BM + c) * 2 + 1]; }
       if (a.stat_slots) {
         long long* sl = reinterpret_cast<long long*>(a.stats);
         slot_add(sl, a.stat_slots, cout0 + c, tile_n, s);
@@ -201,5 +202,66 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
       a.stats[((size_t)a.Cout + cout0 + c) * a.ntile_n + tile_n] = q;
     }
   }
+}
+
+// linear pixel tiles (conv_igemm.hip): the BN pixels of a tile are consecutive flattened pixels
+template <typename T, int BM, int BN, int WM, int WN, bool PRE = false>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0, int wm, int wn, int lr, int lg,
+                                         f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int tile_n,
+                                         const u32x2 (*pre)[BN / WN / 16] = nullptr) {
+  const int pb = pix0 + wn * (BN / WN) + lr, P = a.P;
+  epilogue_px<T, BM / WM / 16, BN / WN / 16, BM, WN, 256, PRE>(a, cout0, wm * (BM / WM), wn, lr, lg, acc, smem, tile_n, pre,
+                                                               [pb, P](int j) { const int pm = pb + j * 16; return pm < P ? pm : -1; });
+}
+
+// stp_conv_params -> ConvArgs (validation shared by every MFMA convolution kernel)
+static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* ut_out) {
+  if (!p || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
+  if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
+  const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  const int sz = p->dtype == STP_BF16 ? 2 : 4;
+  const int ke = 128 / sz;
+  const bool c4 = (p->dtype == STP_BF16) && p->C0 == 4 && p->C1 == 0;
+  if (c4) {
+    if ((p->KW & 1) || p->src0_mode != STP_SRC_DIRECT) return STP_E_BADARG;
+  } else if ((p->C0 % vec) || (p->C1 % vec)) {
+    return STP_E_BADARG;
+  }
+  if (p->C1 > 0 && !p->src1) return STP_E_BADARG;
+  if (p->Cd0 <= 0 || p->Cd0 > p->Cout || (p->Cd0 < p->Cout && (!p->dst1 || (p->Cd0 & 3) || ((p->Cout - p->Cd0) & 3))))
+    return STP_E_BADARG;
+  if (p->N <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->Cout <= 0 || p->KH <= 0 || p->KW <= 0 || p->stride <= 0) return STP_E_BADARG;
+  a.src0 = (const char*)p->src0; a.src1 = (const char*)p->src1; a.weight = (const char*)p->weight;
+  a.residual = (const char*)p->residual; a.bias = p->bias; a.dst0 = (char*)p->dst0; a.dst1 = (char*)p->dst1;
+  a.N = p->N; a.Hs0 = p->Hs0; a.Ws0 = p->Ws0; a.Hv = p->Hv; a.Wv = p->Wv; a.C0 = p->C0; a.C1 = p->C1;
+  a.Ctot = p->C0 + p->C1; a.mode = p->src0_mode;
+  a.KH = p->KH; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.Ho = p->Ho; a.Wo = p->Wo;
+  a.Cout = p->Cout; a.Cd0 = p->Cd0; a.Cd1 = p->Cout - p->Cd0;
+  a.acc0 = p->accumulate0; a.acc1 = p->accumulate1; a.relu = p->relu;
+  a.K = p->KH * p->KW * a.Ctot;
+  const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
+  if (P >= (1ll << 31)) return STP_E_BADARG;
+  a.P = (int)P; a.HoWo = p->Ho * p->Wo; a.wrows = round_up(p->Cout, 16);
+  a.divC = make_fastdiv((uint32_t)a.Ctot); a.divKW = make_fastdiv((uint32_t)a.KW);
+  a.divHoWo = make_fastdiv((uint32_t)(p->Ho * p->Wo)); a.divWo = make_fastdiv((uint32_t)p->Wo);
+  const int64_t lim = 1ll << 31;
+  const int64_t b0 = (int64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * sz;
+  const int64_t b1 = (int64_t)p->N * p->Hv * p->Wv * p->C1 * sz;
+  const int64_t bw = (int64_t)a.wrows * a.K * sz;
+  a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
+  a.ntile_m = a.ntile_n = 0;
+  a.stats = p->stats_partial;
+  a.stat_slots = p->stats_slots;
+  if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;
+  if (a.stat_slots && (!a.stats || (a.stat_slots & (a.stat_slots - 1)) || a.stat_slots > 64)) return STP_E_BADARG;
+  a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
+  a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
+  *c4_out = c4;
+  *ut_out = 0;
+  if (!c4 && b0 < lim && b1 < lim && bw < lim) {
+    if ((a.Ctot % ke == 0) && (a.C0 % ke == 0)) *ut_out = 1;
+    else if (a.C1 == 0 && (ke % a.Ctot == 0)) *ut_out = 2;
+  }
+  return STP_OK;
 }
 

@@ -24,6 +24,7 @@
 //  * conv_igemm_kernel (general): per-lane tap decomposition, global -> VGPR -> ds_write double buffer;
 //    handles the 4-channel stem (C4), 16/32-channel layers and ragged shapes.
 #include "conv_common.h"
+#include <cstdlib>
 
 // ================================================================================================
 // uniform-tap buffer-DMA kernel
@@ -461,56 +462,6 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
   return 5;
 }
 
-static int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* ut_out) {
-  if (!p || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
-  if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
-  const int vec = p->dtype == STP_BF16 ? 8 : 4;
-  const int sz = p->dtype == STP_BF16 ? 2 : 4;
-  const int ke = 128 / sz;
-  const bool c4 = (p->dtype == STP_BF16) && p->C0 == 4 && p->C1 == 0;
-  if (c4) {
-    if ((p->KW & 1) || p->src0_mode != STP_SRC_DIRECT) return STP_E_BADARG;
-  } else if ((p->C0 % vec) || (p->C1 % vec)) {
-    return STP_E_BADARG;
-  }
-  if (p->C1 > 0 && !p->src1) return STP_E_BADARG;
-  if (p->Cd0 <= 0 || p->Cd0 > p->Cout || (p->Cd0 < p->Cout && (!p->dst1 || (p->Cd0 & 3) || ((p->Cout - p->Cd0) & 3))))
-    return STP_E_BADARG;
-  if (p->N <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->Cout <= 0 || p->KH <= 0 || p->KW <= 0 || p->stride <= 0) return STP_E_BADARG;
-  a.src0 = (const char*)p->src0; a.src1 = (const char*)p->src1; a.weight = (const char*)p->weight;
-  a.residual = (const char*)p->residual; a.bias = p->bias; a.dst0 = (char*)p->dst0; a.dst1 = (char*)p->dst1;
-  a.N = p->N; a.Hs0 = p->Hs0; a.Ws0 = p->Ws0; a.Hv = p->Hv; a.Wv = p->Wv; a.C0 = p->C0; a.C1 = p->C1;
-  a.Ctot = p->C0 + p->C1; a.mode = p->src0_mode;
-  a.KH = p->KH; a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.Ho = p->Ho; a.Wo = p->Wo;
-  a.Cout = p->Cout; a.Cd0 = p->Cd0; a.Cd1 = p->Cout - p->Cd0;
-  a.acc0 = p->accumulate0; a.acc1 = p->accumulate1; a.relu = p->relu;
-  a.K = p->KH * p->KW * a.Ctot;
-  const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
-  if (P >= (1ll << 31)) return STP_E_BADARG;
-  a.P = (int)P; a.HoWo = p->Ho * p->Wo; a.wrows = round_up(p->Cout, 16);
-  a.divC = make_fastdiv((uint32_t)a.Ctot); a.divKW = make_fastdiv((uint32_t)a.KW);
-  a.divHoWo = make_fastdiv((uint32_t)(p->Ho * p->Wo)); a.divWo = make_fastdiv((uint32_t)p->Wo);
-  const int64_t lim = 1ll << 31;
-  const int64_t b0 = (int64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * sz;
-  const int64_t b1 = (int64_t)p->N * p->Hv * p->Wv * p->C1 * sz;
-  const int64_t bw = (int64_t)a.wrows * a.K * sz;
-  a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
-  a.ntile_m = a.ntile_n = 0;
-  a.stats = p->stats_partial;
-  a.stat_slots = p->stats_slots;
-  if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;
-  if (a.stat_slots && (!a.stats || (a.stat_slots & (a.stat_slots - 1)) || a.stat_slots > 64)) return STP_E_BADARG;
-  a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
-  a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
-  *c4_out = c4;
-  *ut_out = 0;
-  if (!c4 && b0 < lim && b1 < lim && bw < lim) {
-    if ((a.Ctot % ke == 0) && (a.C0 % ke == 0)) *ut_out = 1;
-    else if (a.C1 == 0 && (ke % a.Ctot == 0)) *ut_out = 2;
-  }
-  return STP_OK;
-}
-
 static int tile_pixels(int tile) {
   if (tile == 512) return 256;
   const int t = tile >= 256 ? tile - 256 : tile % 32;
@@ -521,6 +472,19 @@ extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream);
 extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream);
+extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p);
+extern "C" int stp_conv2d_halo_tiles(const stp_conv_params* p, int variant);
+extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stream);
+#define STP_TILE_HALO 1024  // + variant: the halo-resident 3x3 kernel of conv_halo.hip
+// automatic use of the halo kernel (an explicit tile id always works): STP_HALO=0 switches it off for A/B runs
+static bool halo_auto_enabled() {
+  static const bool on = !(getenv("STP_HALO") && atoi(getenv("STP_HALO")) == 0);
+  return on;
+}
+static int halo_variant_for(const stp_conv_params* p) {
+  if (!p || (p->tile == 0 && !halo_auto_enabled())) return -1;
+  return stp_conv2d_halo_variant(p);
+}
 #define STP_TILE_SC 512  // the small-channel halo-tile kernel of conv_sc.hip
 #define STP_TILE_STEM 768  // the 7x7 / stride-2 stem kernel of conv_sc.hip
 
@@ -528,6 +492,11 @@ extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream);
 extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SC) && stp_conv2d_sc_eligible(p)) return STP_TILE_SC;
   if (p && (p->tile == 0 || p->tile == STP_TILE_STEM) && stp_conv2d_stem_eligible(p)) return STP_TILE_STEM;
+  {
+    const int hv = halo_variant_for(p);
+    if (hv >= 0) return STP_TILE_HALO + hv;
+    if (p && p->tile >= STP_TILE_HALO) return STP_E_BADARG;
+  }
   ConvArgs a;
   bool c4;
   int ut;
@@ -543,6 +512,7 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   if (tile < 0) return 0;
   if (tile == STP_TILE_SC) return (size_t)p->N * ceil_div(p->Hv, 8) * ceil_div(p->Wv, 32) * 2 * p->Cout;
   if (tile == STP_TILE_STEM) return (size_t)p->N * ceil_div(p->Ho, 8) * ceil_div(p->Wo, 32) * 2 * p->Cout;
+  if (tile >= STP_TILE_HALO) return (size_t)stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO) * 2 * p->Cout;
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
 }
 
@@ -554,6 +524,11 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_STEM)) {
     if (stp_conv2d_stem_eligible(p)) return stp_conv2d_stem(p, stream);
     if (p->tile == STP_TILE_STEM) return STP_E_BADARG;
+  }
+  {
+    const int hv = halo_variant_for(p);
+    if (hv >= 0) return stp_conv2d_halo(p, hv, stream);
+    if (p && p->tile >= STP_TILE_HALO) return STP_E_BADARG;
   }
   ConvArgs a;
   bool c4;

@@ -254,6 +254,104 @@ def test_stem_halo_kernel_with_fused_statistics(ops, size):
     np.testing.assert_allclose(host(r1), host(r0), rtol=2e-5)
 
 
+HALO_CASES = [
+    # n, h, w, ci, co, variant (conv_halo.hip: 0 = 16x16 px x 128 ch, 1 = 8x16 x 128, 2 = 16x16 x 64, 3 = 8x16 x 64)
+    (2, 16, 32, 128, 128, 0), (1, 32, 16, 64, 192, 0), (1, 16, 16, 256, 128, 0),
+    (2, 8, 16, 128, 256, 1), (1, 24, 32, 64, 80, 1),
+    (1, 32, 16, 64, 64, 2), (2, 16, 16, 192, 64, 2),
+    (2, 8, 32, 128, 64, 3), (1, 24, 16, 512, 64, 3),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_kernel_forward_statistics_residual(ops, case):
+    """conv_halo_kernel (bf16, tile id 1024 + variant): 3x3 / stride 1 through halo-resident activation slabs against the naive
+    oracle and the per-tap DMA kernel on the same buffers; fused BatchNormalization sums against stp_bn_stats of the stored output;
+    residual + ReLU epilogue; image borders (zero padding through out-of-range buffer offsets) on every side of every tile."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co, var = case
+    dtype = "bf16"
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    ref = np_ops.conv2d(x, wt, 1, 1)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    xd = dev(x, dtype)
+    mk = lambda dst, tile, **kw: ops.conv_params(xd, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
+                                                 Cout=co, dtype=ops.dt(dst), tile=tile, **kw)
+    y = torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+    y2 = torch.empty_like(y)
+    P = mk(y, 1024 + var)
+    assert _lib.load().stp_conv2d_tile_for(P) == 1024 + var
+    st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    ops.conv2d(mk(y2, 69))                                                   # per-tap DMA kernel, 64x64 tile
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+    np.testing.assert_allclose(host(y), host(y2), atol=tol(ref, dtype))
+    th = 16 if var in (0, 2) else 8
+    tiles = ops.conv2d_stats_floats(P) // (2 * co)
+    assert tiles == P.stats_tiles == n * (h // th) * (w // 16)
+    rows = n * h * w
+    m1, r1, m0, r0 = (torch.empty(co, device=DEV) for _ in range(4))
+    _lib.call("stp_bn_finalize", ops.ptr(st), tiles, rows, co, 1e-3, 0.99, ops.ptr(m1), ops.ptr(r1), None, None, ops.stream())
+    ws = torch.empty(ops.bn_workspace_bytes(co) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(y, rows, co, 1e-3, 0.99, m0, r0, None, None, ws)
+    np.testing.assert_allclose(host(m1), host(m0), atol=2e-6 * max(1.0, np.abs(host(m0)).max()))
+    np.testing.assert_allclose(host(r1), host(r0), rtol=2e-5)
+    # residual + ReLU (prefetched epilogue operand)
+    res = q(rng.randn(n, h, w, co), dtype)
+    y3 = torch.empty_like(y)
+    ops.conv2d(mk(y3, 1024 + var, residual=dev(res, dtype), relu=1))
+    ref3 = np.maximum(ref + res, 0)
+    np.testing.assert_allclose(host(y3), ref3, atol=tol(ref3, dtype))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 0), (2, 8, 16, 64, 256, 1), (1, 32, 16, 128, 64, 2), (2, 8, 32, 64, 64, 3)])
+@pytest.mark.parametrize("relu", [1, 0, 3])
+def test_conv_halo_kernel_batchnorm_backward_sums(ops, case, relu):
+    """bnb_x epilogue of the halo kernel == the same epilogue of the per-tap DMA kernel (masked gradient bit for bit where the
+    two accumulation orders round alike, sums to rounding), incl. accumulate0 as the LAST consumer."""
+    n, h, w, ci, co, var = case
+    dtype = "bf16"
+    last = relu == 3
+    relu = 1 if last else relu
+    rng = np.random.RandomState(78)
+    rows = n * h * w
+    src = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    x = q(rng.randn(n, h, w, co) * 1.5 + 0.3, dtype)
+    others = q(rng.randn(n, h, w, co), dtype)
+    gamma, beta = (rng.rand(co) + 0.5).astype(np.float32), (rng.randn(co) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd, g, b = dev(x, dtype), f(gamma), f(beta)
+    m, r = torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(co) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, co, 1e-3, 0.99, m, r, None, None, ws)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    sd = dev(src, dtype)
+    outs = []
+    for tile in (69, 1024 + var):
+        gbuf = dev(others, dtype) if last else torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+        P = ops.conv_params(sd, fwd, gbuf, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co,
+                            dtype=ops.dt(gbuf), tile=tile, accumulate0=int(last))
+        P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), relu
+        st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+        P.stats_partial = ops.ptr(st)
+        ops.conv2d(P)
+        tiles = ops.conv2d_stats_floats(P) // (2 * co)
+        assert tiles == P.stats_tiles
+        dx, dg, db = torch.empty_like(gbuf), torch.empty(co, device=DEV), torch.empty(co, device=DEV)
+        ops.bn_backward_fused(xd, gbuf, dx, rows, co, m, r, g, st, tiles, dg, db, accumulate_dx=0, workspace=ws)
+        outs.append((host(gbuf), host(dx), host(dg), host(db)))
+    (g0, dx0, dg0, db0), (g1, dx1, dg1, db1) = outs
+    np.testing.assert_allclose(g1, g0, atol=tol(g0, dtype))
+    sc = lambda a: 1e-3 * np.abs(a).max() + 1e-4
+    np.testing.assert_allclose(db1, db0, atol=sc(db0) * 5)
+    np.testing.assert_allclose(dg1, dg0, atol=sc(dg0) * 5)
+    np.testing.assert_allclose(dx1, dx0, atol=tol(dx0, dtype))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_stem_conv_7x7_s2_padded_channels(ops, dtype):
     """conv0: 7x7/2 over a 3-channel image stored as 4 channels (4th = 1), weights padded to 7x8x4."""
