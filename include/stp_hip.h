@@ -102,7 +102,7 @@ typedef struct stp_conv_params {
    * order-independent and deterministic - instead of writing a per-tile partial: no finalize kernel; the consumer
    * (stp_bn_apply_slots / stp_bn_backward_slots) sums the few slots of each channel in its prologue. */
   int32_t stats_slots;
-  /* Fused PRODUCER BatchNormalization (small-channel kernel only): src_bn_mean != NULL means src0 holds the tensor BEFORE a
+  /* Fused PRODUCER BatchNormalization (small-channel kernel and halo kernel only): src_bn_mean != NULL means src0 holds the tensor BEFORE a
    * training-phase BatchNormalization (+ activation src_bn_relu: 0 none, 1 ReLU, 2 ReLU6).  The kernel normalises it while
    * staging its halo tile, with the arithmetic and rounding of stp_bn_apply, so the result equals the unfused pair bit for
    * bit and the normalised tensor is never written to HBM.  Padding stays zero (it pads the NORMALISED tensor). */
@@ -117,7 +117,7 @@ int stp_conv2d(const stp_conv_params* p, void* stream);
 /* floats needed by stats_partial for this shape (tile choice included) */
 size_t stp_conv2d_stats_floats(const stp_conv_params* p);
 /* tile configuration stp_conv2d would pick for p (see conv_igemm.hip: 1..6 register-staged tiles, 32*STAGES+t
- * uniform-tap DMA tiles, 256+t per-lane-tap DMA tiles, 512 small-channel kernel); used by bench.py. */
+ * uniform-tap DMA tiles, 256+t per-lane-tap DMA tiles, 512 small-channel kernel, 768 stem kernel, 1024+v halo kernel); used by bench.py. */
 int stp_conv2d_tile_for(const stp_conv_params* p);
 /* Small-channel path (Cin <= 32, Cout <= 32, 3x3 stride 1 pad 1, single source, optional nearest-2x):
  * an 8x32 output tile per workgroup with the input halo tile staged once in LDS (conv_sc.hip).
@@ -128,6 +128,16 @@ int stp_conv2d_sc(const stp_conv_params* p, void* stream);
  * used by stp_conv2d automatically when eligible (tile id 768); optional fused BatchNormalization sums (stats_partial). */
 int stp_conv2d_stem_eligible(const stp_conv_params* p);
 int stp_conv2d_stem(const stp_conv_params* p, void* stream);
+/* Halo-resident 3x3 kernel (conv_halo.hip; bf16, stride 1, pad 1, one direct source, Cin % 64 == 0, Cout % 16 == 0, Wo % 16 == 0,
+ * Ho % 8 == 0): a workgroup keeps the (TH+2) x 18 input pixels of its TH x 16 output block resident in LDS per 64-channel slab and
+ * streams only the weights.  Tile ids 1024 + variant (0: 16x16 px x 128 channels, 1: 8x16 x 128, 2: 16x16 x 64, 3: 8x16 x 64);
+ * stp_conv2d picks it automatically where it measured faster (stp_conv2d_halo_variant(p) >= 0 with p->tile == 0; the environment
+ * variable STP_HALO=0 disables the automatic choice).  It is the one GEMM-class kernel that honours src_bn_*: the producer
+ * BatchNormalization (+activation) is applied in LDS, bit-identical to stp_bn_apply.  stp_conv2d_halo_tiles = pixel tiles
+ * (= stats_partial columns) of a variant. */
+int stp_conv2d_halo_variant(const stp_conv_params* p);
+int stp_conv2d_halo_tiles(const stp_conv_params* p, int variant);
+int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Weight gradient (Conv2DBackpropFilter).  dW[co][(kh*KW+kw)*(C0+C1)+c] =

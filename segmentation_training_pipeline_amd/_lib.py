@@ -50,6 +50,9 @@ SIGNATURES = {
     "stp_conv2d_sc": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_stem_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stem": (i32, [C.POINTER(ConvParams), vp]),
+    "stp_conv2d_halo_variant": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_halo_tiles": (i32, [C.POINTER(ConvParams), i32]),
+    "stp_conv2d_halo": (i32, [C.POINTER(ConvParams), i32, vp]),
     "stp_conv2d_wgrad_workspace_bytes": (sz, [C.POINTER(WgradParams)]),
     "stp_conv2d_wgrad": (i32, [C.POINTER(WgradParams), vp, sz, vp]),
     "stp_conv2d_wgrad_partial": (i32, [C.POINTER(WgradParams), vp, sz, i32, vp]),

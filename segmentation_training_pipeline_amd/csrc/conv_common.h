@@ -20,6 +20,7 @@ struct ConvArgs {
   float* stats;  // optional [2][Cout][ntile_n] floats, or (stat_slots > 0) int64 fixed-point slots [2][Cout][stat_slots]
   int stat_slots;
   BnBack bnb;    // bnb.x != NULL: stats are the BatchNormalization-backward sums and dst receives the masked gradient
+  BnBack pbn;    // pbn.mean != NULL (halo kernel): src0 is the tensor BEFORE a BatchNormalization(+activation), normalised in LDS
   FastDiv divC, divKW, divHoWo, divWo, divNtm;   // magic-number division: a runtime integer divide costs ~30 VALU instructions
 };
 
@@ -256,6 +257,8 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   if (a.stat_slots && (!a.stats || (a.stat_slots & (a.stat_slots - 1)) || a.stat_slots > 64)) return STP_E_BADARG;
   a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
   a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
+  a.pbn.x = nullptr; a.pbn.mean = p->src_bn_mean; a.pbn.rstd = p->src_bn_rstd; a.pbn.gamma = p->src_bn_gamma; a.pbn.beta = p->src_bn_beta;
+  a.pbn.relu = p->src_bn_relu;
   *c4_out = c4;
   *ut_out = 0;
   if (!c4 && b0 < lim && b1 < lim && bw < lim) {

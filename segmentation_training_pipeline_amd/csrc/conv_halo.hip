@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   typedef bf16_t T;
   constexpr int TW = 16, HWD = TW + 2, HH = TH + 2, NHP = HH * HWD;
   constexpr int NPASS = (NHP + 63) / 64;         // 64 halo pixels (8 per wave) per pass of the 512 threads
-  static_assert(NPASS <= 7, "the next slab must be complete two K-steps before its first tap");
+  static_assert(NPASS <= 6, "the next slab must have landed (own pieces) when the K-step of tap 8 begins");
   constexpr int SROWS = (NHP + 7) / 8 * 8;       // slab rows kept in LDS (8 per wave instruction; rows >= NHP are never read)
   constexpr int SLAB = SROWS * 128;
   constexpr int NWST = HALO_NWST;                // weight ring stages
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   constexpr int LW = BM / 64;                    // weight LDS-DMA instructions per thread per K-step
   constexpr int L = LW + 1;                      // + one slab pass (or sink)
   constexpr int TM = 4, RW = TH / WN, TN = RW;
-  constexpr int OFF_W = 2 * SLAB, OFF_DUMP = OFF_W + NWST * WSTAGE;
+  constexpr int OFF_W = 2 * SLAB, OFF_DUMP = OFF_W + NWST * WSTAGE, OFF_TAB = OFF_DUMP + 8 * 1024;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -114,6 +114,35 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
     else so = STP_OOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(on ? smem + (s & 1) * SLAB + (p * 64 + wave * 8) * 128 : sink),
                                              16, so, 0, 0, 0);
+  };
+
+  // ---- fused PRODUCER BatchNormalization (+activation): src0 holds the convolution output x that the BatchNormalization reads;
+  // y = act(fma(x, scale, shift)) is computed IN LDS on the slab, once per slab (9 K-steps), by the thread that DMA'd the 16 bytes
+  // (own data: only its own vmcnt orders the read-modify-write, the K-step barrier publishes it).  Same fma / activation / bf16
+  // rounding as stp_bn_apply -> bit-identical operands; pixels outside the image stay 0 (the padding applies to y, not x).
+  const bool fuse_bn = a.pbn.mean != nullptr;
+  float* const tab = reinterpret_cast<float*>(smem + OFF_TAB);      // scale[C0], shift[C0]
+  auto transform_slab = [&](int s_) {
+    char* sb = smem + (s_ & 1) * SLAB;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      if ((i * 64 + wave * 8) >= SROWS) continue;                    // wave-uniform: rows that went to the sink
+      const int hp = i * 64 + prow;
+      if (soff[i] == STP_OOB) continue;
+      u32x4* vp = reinterpret_cast<u32x4*>(sb + hp * 128 + pslot * 16);
+      const int ch = s_ * 64 + ((pslot ^ (hp & 7)) << 3);
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(tab + ch), sc1 = *reinterpret_cast<const f32x4*>(tab + ch + 4);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(tab + a.C0 + ch), sh1 = *reinterpret_cast<const f32x4*>(tab + a.C0 + ch + 4);
+      const u32x4 v = *vp;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bn_act(bn_affine(__uint_as_float(v[e] << 16), e < 2 ? sc0[2 * e] : sc1[2 * e - 4], e < 2 ? sh0[2 * e] : sh1[2 * e - 4]), a.pbn.relu);
+        const float hi = bn_act(bn_affine(__uint_as_float(v[e] & 0xffff0000u), e < 2 ? sc0[2 * e + 1] : sc1[2 * e - 3], e < 2 ? sh0[2 * e + 1] : sh1[2 * e - 3]), a.pbn.relu);
+        o[e] = pack_bf16x2(lo, hi);
+      }
+      *vp = o;
+    }
   };
 
   // ---- epilogue operands (residual or BatchNormalization-backward x) first: older than every tile load ---------------
@@ -191,6 +220,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if (fuse_bn) {
+    for (int c = tid; c < a.C0; c += 512) {
+      const float r = a.pbn.rstd[c], sc = a.pbn.gamma ? r * a.pbn.gamma[c] : r;
+      tab[c] = sc;
+      tab[a.C0 + c] = (a.pbn.beta ? a.pbn.beta[c] : 0.f) - a.pbn.mean[c] * sc;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // the table is visible (every wave executes this: fuse_bn is uniform)
+  }
   STP_STAMP(1);
 #if defined(STP_HALO_SCHED) && STP_HALO_SCHED == 2
   // Software pipeline over the two 32-deep halves of a K-step: the fragment reads of half h+1 are in flight under the MFMAs
@@ -270,11 +308,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
     u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     const bool grp_b = wave >= 4;          // wave-uniform
     wait_vmcnt<2 * L>();                   // slab 0 and W(0)
+    if (fuse_bn) {
+      transform_slab(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (grp_b) __builtin_amdgcn_s_barrier();
     int s = 0, t = 0;          // K-step k
     int s3 = 0, t3 = 3;        // K-step k + 3
     for (int k = 0; k < nk; ++k) {
+      // slab s+1: its passes were issued in MMA(9s .. 9s+NPASS-1) and this wave's own pieces landed before MEM(9s+7) ended
+      if (fuse_bn && t == 8 && s + 1 < nslab) transform_slab(s + 1);
       read_chunk(0, s, t, k % NWST, fa0, fb0);
       read_chunk(1, s, t, k % NWST, fa1, fb1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -326,12 +370,12 @@ template <int TH, int BM, int WM, int WN>
 static int launch_halo(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
-  const size_t lds = (size_t)2 * SROWS * 128 + HALO_NWST * BM * 128 + 8 * 1024;
+  const size_t lds = (size_t)2 * SROWS * 128 + HALO_NWST * BM * 128 + 8 * 1024 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
   auto kern = conv_halo_kernel<TH, BM, WM, WN>;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return STP_E_LAUNCH;
     attr_set = true;
   }
@@ -343,8 +387,8 @@ static int launch_halo(ConvArgs& a, hipStream_t s) {
 static bool halo_shape_ok(const stp_conv_params* p) {
   return p && p->dtype == STP_BF16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->src0_mode == STP_SRC_DIRECT &&
          p->C1 == 0 && p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv && p->Hs0 == p->Hv && p->Ws0 == p->Wv &&
-         (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->dst_sum2x2 && !p->src_bn_mean &&
-         !p->stats_slots;
+         (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->dst_sum2x2 && !p->stats_slots &&
+         (!p->src_bn_mean || (p->src_bn_rstd && p->C0 <= 512));
 }
 
 // variant for a shape: -1 = not eligible / not faster.  Measured on MI355X against the per-tap DMA kernel (scratch/halo_bench.py,

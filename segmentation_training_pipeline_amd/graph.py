@@ -116,6 +116,11 @@ class Plan(object):
         # BatchNormalization whose only consumers are small-channel convolutions: normalised inside their halo staging
         # (stp_conv_params.src_bn_mean), the normalised tensor is never written
         self.fuse_bn_sc = os.environ.get("STP_FUSE_BN_SC", "1") != "0"
+        # producer BatchNormalization applied in LDS by the halo kernel (needs its automatic selection: STP_HALO != 0).  OFF by
+        # default: measured (MI355X, U-Net/ResNet34 bs16) 9.91 ms/step without, 10.09-10.61 ms with - the weight gradient still
+        # reads the normalised tensor, so stp_bn_apply only MOVES to the side stream, and concurrent kernels buy nothing on this
+        # step (no side stream at all: 9.98 ms).  The fusion pays once the weight gradient normalises its operand as well.
+        self.fuse_bn_halo = os.environ.get("STP_FUSE_BN_HALO", "0") != "0" and os.environ.get("STP_HALO", "1") != "0"
         self.bn_slots_max_rows = int(os.environ.get("STP_BN_SLOTS_MAXROWS", "1073741824"))
         self._slot_need = 0          # int64 elements, counted in the dry pass
         self._slot_used = 0
@@ -268,24 +273,58 @@ class Plan(object):
         lst.append((getattr(self.lib, fname), args, fname, None))
 
     def _fuse_bn_into_consumers(self):
-        """Drops the stp_bn_apply launch of every BatchNormalization all of whose consumers are small-channel convolutions
-        (forward and weight gradient read the pre-normalisation tensor and normalise it while staging; the data gradient and
-        the BatchNormalization backward never read the normalised tensor).  ``tensor(name)`` still materialises it on demand."""
-        drop = set()
+        """BatchNormalization(+activation) outputs that only convolutions with a fused-producer path read:
+
+        * every consumer is a small-channel convolution (conv_sc.hip: forward AND weight gradient normalise the pre-BN tensor
+          while staging it): the stp_bn_apply launch is dropped; ``tensor(name)`` still materialises the tensor on demand;
+        * some consumers are halo-kernel convolutions (conv_halo.hip: the forward normalises the slab in LDS, but their
+          weight gradient reads the normalised tensor): the stp_bn_apply launch stays and moves to the SIDE stream - off the
+          forward's critical chain conv -> finalize -> apply -> conv; its only readers are the weight-gradient chains, which run
+          on that stream in the backward pass.
+
+        The data gradient and the BatchNormalization backward never read the normalised tensor."""
+        drop, side = set(), set()
         for t in self.tensors.values():
-            rec, cons = t.meta.get("apply_rec"), t.meta.get("sc_consumers")
-            if rec is None or not cons or len(cons) != t.meta.get("uses", 0):
+            rec, sc, halo = t.meta.get("apply_rec"), t.meta.get("sc_consumers") or [], t.meta.get("halo_consumers") or []
+            if rec is None or not (sc or halo) or len(sc) + len(halo) != t.meta.get("uses", 0):
                 continue
             pre, mean, rstd, gp, beta, relu = t.meta["bn"]
-            for cp, wp in cons:
+            for cp, wp in sc:
                 cp.src0 = pre
                 cp.src_bn_mean, cp.src_bn_rstd, cp.src_bn_gamma, cp.src_bn_beta, cp.src_bn_relu = mean, rstd, gp, beta, relu
-                wp.src_bn_mean, wp.src_bn_rstd, wp.src_bn_gamma, wp.src_bn_beta, wp.src_bn_relu = mean, rstd, gp, beta, relu
-            t.meta["deferred"] = rec
-            t.meta["src_override"] = pre
-            drop.add(id(rec))
-        if drop:
-            self.fwd = [r for r in self.fwd if id(r) not in drop]
+                if not halo:       # (with halo consumers the normalised tensor exists anyway: the weight gradient reads it)
+                    wp.src_bn_mean, wp.src_bn_rstd, wp.src_bn_gamma, wp.src_bn_beta, wp.src_bn_relu = mean, rstd, gp, beta, relu
+            for cp in halo:
+                cp.src0 = pre
+                cp.src_bn_mean, cp.src_bn_rstd, cp.src_bn_gamma, cp.src_bn_beta, cp.src_bn_relu = mean, rstd, gp, beta, relu
+            if halo:
+                side.add(id(rec))
+            else:
+                t.meta["deferred"] = rec
+                t.meta["src_override"] = pre
+                drop.add(id(rec))
+        if drop or side:
+            # every cross-stream edge of the step graph costs a queue hand-off: the deferred launches are issued in batches
+            # behind ONE fork (their only readers run in the backward pass, so any point of the forward is early enough)
+            batch = int(os.environ.get("STP_BN_SIDE_BATCH", "8"))
+            out, pending = [], []
+
+            def flush():
+                if pending:
+                    out.append((None, (), "fork", None))                      # the side stream waits for the statistics
+                    out.extend(pending)
+                    del pending[:]
+            for r in self.fwd:
+                if id(r) in drop:
+                    continue
+                if id(r) in side:
+                    pending.append((r[0], r[1], r[2], dict(r[3] or {}, stream=1)))
+                    if len(pending) >= batch:
+                        flush()
+                    continue
+                out.append(r)
+            flush()
+            self.fwd = out
 
     def tensor(self, name):
         """The named tensor with its buffer valid: a normalised tensor that only exists inside its consumers' staging is
@@ -418,6 +457,7 @@ class Plan(object):
         if self.fuse_bn_sc and slots is None:
             out.meta["apply_rec"] = self.fwd[-1]
             out.meta["sc_consumers"] = []
+            out.meta["halo_consumers"] = []
 
         def back():
             if not out.needs_grad or not out.grad_ready:
@@ -524,6 +564,9 @@ class Plan(object):
         if (self.training and x.meta.get("apply_rec") is not None and src1 is None and residual is None and not transpose and not stem
                 and self.lib.stp_conv2d_sc_eligible(C.byref(p)) and (not w.trainable or self.lib.stp_wgrad_sc_eligible(C.byref(wp)))):
             x.meta["sc_consumers"].append((p, wp))       # see _fuse_bn_into_consumers
+        elif (self.training and self.fuse_bn_halo and x.meta.get("apply_rec") is not None and src1 is None and not transpose and not stem
+                and not upsample and self.lib.stp_conv2d_halo_variant(C.byref(p)) >= 0):
+            x.meta["halo_consumers"].append(p)
         if b is not None:
             p.bias = self._pptr(b)
         if relu:

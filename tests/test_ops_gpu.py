@@ -307,6 +307,43 @@ def test_conv_halo_kernel_forward_statistics_residual(ops, case):
     np.testing.assert_allclose(host(y3), ref3, atol=tol(ref3, dtype))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 0, 1), (1, 32, 16, 256, 64, 0, 0), (2, 8, 16, 192, 128, 1, 1), (1, 16, 16, 64, 64, 2, 1),
+                                  (2, 8, 32, 512, 64, 3, 2)])
+def test_conv_halo_kernel_fused_producer_batchnorm(ops, case):
+    """stp_conv_params.src_bn_* on the halo kernel: the pre-BatchNormalization tensor is normalised (+ activation) IN LDS, once
+    per slab, by the thread that staged it.  Bit-identical to stp_bn_apply followed by the same kernel (same fma, activation and
+    bf16 rounding; padding pixels stay zero), incl. the fused statistics of the output."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co, var, relu = case
+    dtype = "bf16"
+    rng = np.random.RandomState(79)
+    rows = n * h * w
+    ypre = q(rng.randn(n, h, w, ci) * 2 + 0.5, dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    mean, rstd = f(ypre.reshape(-1, ci).mean(0)), f(1.0 / np.sqrt(ypre.reshape(-1, ci).var(0) + 1e-3))
+    gamma, beta = f(rng.rand(ci) + 0.5), f(rng.randn(ci) * 0.3 + 0.2)      # beta > 0 on average: act(shift) != 0 where padding must be 0
+    yd = dev(ypre, dtype)
+    act = torch.empty_like(yd)
+    ops.bn_apply(yd, act, rows, ci, ci, mean, rstd, gamma, beta, relu=relu)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    mk = lambda src, dst: ops.conv_params(src, fwd, dst, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
+                                          Cout=co, dtype=ops.dt(dst), tile=1024 + var)
+    ref, got = torch.empty((n, h, w, co), dtype=TD[dtype], device=DEV), torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+    P0, P1 = mk(act, ref), mk(yd, got)
+    P1.src_bn_mean, P1.src_bn_rstd, P1.src_bn_gamma, P1.src_bn_beta, P1.src_bn_relu = ops.ptr(mean), ops.ptr(rstd), ops.ptr(gamma), ops.ptr(beta), relu
+    st0 = torch.zeros((max(4, ops.conv2d_stats_floats(P0)),), dtype=torch.float32, device=DEV)
+    st1 = torch.full_like(st0, float("nan"))
+    P0.stats_partial, P1.stats_partial = ops.ptr(st0), ops.ptr(st1)
+    ops.conv2d(P0)
+    ops.conv2d(P1)
+    np.testing.assert_array_equal(host(got), host(ref))
+    np.testing.assert_array_equal(host(st1), host(st0))
+    np.testing.assert_allclose(host(ref), np_ops.conv2d(host(act), wt, 1, 1), atol=tol(host(ref), dtype))
+    P1.tile = 69                                                           # the per-tap kernel must refuse the fields
+    assert _lib.load().stp_conv2d(P1, ops.stream()) == -1
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 0), (2, 8, 16, 64, 256, 1), (1, 32, 16, 128, 64, 2), (2, 8, 32, 64, 64, 3)])
 @pytest.mark.parametrize("relu", [1, 0, 3])
 def test_conv_halo_kernel_batchnorm_backward_sums(ops, case, relu):
