@@ -109,17 +109,19 @@ __device__ __forceinline__ f32x4 unpack_bf16x4(const u32x2 r) {
 }
 
 // pixf(j) -> the flattened output pixel (n*Ho*Wo + ho*Wo + wo) of this lane's j-th fragment column, or < 0 to skip it.
-// TM x TN fragments per wave, `cw` = the wave's first output channel inside the BM-channel tile, WNN waves share those
-// channels (different pixels), NT threads per workgroup.
-template <typename T, int TM, int TN, int BM, int WNN, int NT, bool PRE, typename PixF>
-__device__ __forceinline__ void epilogue_px(const ConvArgs& a, int cout0, int cw, int wn, int lr, int lg, f32x4 (&acc)[TM][TN], char* smem,
-                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf) {
+// cof(i)  -> first of the 4 consecutive output channels (relative to the BM-channel tile) of this lane's i-th fragment row.
+// A lane's accumulators are viewed as TM x TN fragments of 4 channels x 1 pixel; the 16 lanes of a DPP row hold 16 different
+// pixels of the same channels.  `vn` of WNN = which of the WNN groups of DPP rows that share this lane's channels (waves along
+// the pixel dimension, times the pixel halves inside a 32x32 MFMA tile), NT threads per workgroup.
+template <typename T, int TM, int TN, int BM, int WNN, int NT, bool PRE, typename PixF, typename CoF>
+__device__ __forceinline__ void epilogue_cf(const ConvArgs& a, int cout0, int vn, int lr, f32x4 (&acc)[TM][TN], char* smem,
+                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf, CoF cof) {
   const T* res = reinterpret_cast<const T*>(a.residual);
   float* red = reinterpret_cast<float*>(smem);  // [WN][BM][2], valid after the barrier below
   if (a.stats) __syncthreads();                 // the K-loop's LDS tiles are dead from here on
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int co = cout0 + cw + i * 16 + lg * 4;
+    const int co = cout0 + cof(i);
     f32x4 ss = {0.f, 0.f, 0.f, 0.f}, qq = {0.f, 0.f, 0.f, 0.f};
     if (co < a.Cout) {
       BnBackCh bk;
@@ -179,9 +181,9 @@ __device__ __forceinline__ void epilogue_px(const ConvArgs& a, int cout0, int cw
       for (int e = 0; e < 4; ++e) {
         const float s = row_sum16_to_lane15(ss[e]), q = row_sum16_to_lane15(qq[e]);
         if (lr == 15) {
-          const int cl = cw + i * 16 + lg * 4 + e;
-          red[(wn * BM + cl) * 2] = s;
-          red[(wn * BM + cl) * 2 + 1] = q;
+          const int cl = cof(i) + e;
+          red[(vn * BM + cl) * 2] = s;
+          red[(vn * BM + cl) * 2 + 1] = q;
         }
       }
     }
@@ -203,6 +205,13 @@ __device__ __forceinline__ void epilogue_px(const ConvArgs& a, int cout0, int cw
       a.stats[((size_t)a.Cout + cout0 + c) * a.ntile_n + tile_n] = q;
     }
   }
+}
+
+// 16x16 MFMA fragments: row i = channels cw + i*16 + (lane>>4)*4 .. +3, the wave index along pixels selects the reduction slot
+template <typename T, int TM, int TN, int BM, int WNN, int NT, bool PRE, typename PixF>
+__device__ __forceinline__ void epilogue_px(const ConvArgs& a, int cout0, int cw, int wn, int lr, int lg, f32x4 (&acc)[TM][TN], char* smem,
+                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf) {
+  epilogue_cf<T, TM, TN, BM, WNN, NT, PRE>(a, cout0, wn, lr, acc, smem, tile_n, pre, pixf, [cw, lg](int i) { return cw + i * 16 + lg * 4; });
 }
 
 // linear pixel tiles (conv_igemm.hip): the BN pixels of a tile are consecutive flattened pixels

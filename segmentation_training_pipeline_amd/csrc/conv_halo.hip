@@ -1,35 +1,236 @@
 // 3x3 / stride-1 convolution on MFMA with HALO-RESIDENT activation slabs (gfx950, bf16) - forward and data-gradient
-// of the ResNet / decoder 3x3 layers with 64..512 channels.
+// of the ResNet / decoder 3x3 layers with 128..512 channels.
 //
 // conv_igemm.hip stages one [pixels][64 channels] operand tile PER FILTER TAP: every activation byte travels L2 -> LDS
 // nine times, and with the weights that is (BM + BN) * 128 bytes of LDS-DMA per K-step - the launches of the 256/512-channel
 // layers are bound by that path (what-if build without MFMA work: 23-35 us of a 40-46 us launch, ~18 TB/s of L2 -> LDS).
 // Here a workgroup owns a TH x 16 block of output pixels of ONE image and keeps, per 64-channel chunk ("slab"), the
 // (TH+2) x 18 input pixels that the nine taps of the block touch resident in LDS: a tap is just a different LDS row
-// offset of the same slab (pixel rows are 128 bytes = 64 channels, 16-byte slots XOR-swizzled by row & 7 exactly as in
-// conv_igemm.hip; the swizzle is conflict-free for ANY starting row, so tap-shifted fragment reads stay conflict-free).
-// Only the weights stream: BM x 64 per K-step.  L2 -> LDS bytes per workgroup K-step drop from (BM + BN) * 128 to
-// BM * 128 + slab / 9, LDS-DMA instructions per wave from 8 to 3.
+// offset of the same slab.  Only the weights stream: BM x 64 per K-step.
 //
 // K order: slab-major, tap-minor (k = slab * 9 + tap; the matching weight column is tap * Cin + slab * 64), so the first
-// nine K-steps need only slab 0 and slab s+1 streams in (one 64-pixel pass per K-step) under the taps of slab s.
-// 512 threads = 8 waves (2 per SIMD) as WM (channels) x WN (pixel rows); a wave computes 64 channels x RW rows of 16 pixels.
-// Ring: 2 slabs + 3 weight stages; one counted s_waitcnt vmcnt + one s_barrier per K-step, every K-step issues the same
-// number of LDS-DMA instructions per wave (missing ones go to a sink) so the count is a compile-time constant.
+// nine K-steps need only slab 0, and slab s+1 streams in (one 64-pixel pass per K-step) under the taps of slab s.
+// 512 threads = 8 waves (2 per SIMD) as WM (channels) x WN (pixel rows); a wave computes CW = BM / WM channels x RW = TH / WN
+// rows of 16 pixels with v_mfma_f32_32x32x16_bf16 (measured 17 % more FLOP per cycle than the 16x16x32 form): the 32
+// columns of an MFMA tile are TWO image rows of 16 pixels.
+//
+// What the measurements of the first versions said (scratch/halo_timing.py, scratch/pmc_halo.sh; 128->128 @ 16x64x64):
+//  * a K-step cost ~650 cycles + 5.2 cycles per 16x16x32 MFMA regardless of the barrier schedule; the 650 were ISSUE
+//    overhead: 120 VALU + 106 SALU instructions per 32 MFMAs (fragment addresses, tap decomposition, sink selection).
+//    -> the nine taps are unrolled: tap offsets are instruction immediates, the swizzle key depends on the pixel COLUMN only
+//       (18 pixels per halo row is even, so the bank half of a row is the parity of its column), 16 lane-constant address
+//       registers serve every fragment read, LDS-DMA offsets are (per-thread constant) + (scalar soffset);
+//  * with one barrier per K-step all 8 waves read fragments, then all issue MFMAs: nothing overlaps.
+//    -> PING-PONG: waves 0-3 and 4-7 (one of each per SIMD) run the same loop half a K-step apart, one group reads its 16
+//       fragments while the other issues its MFMAs, swapping at a barrier;
+//  * LDS-DMA instructions cost 100-180 issue cycles when they open a phase and ~60 between MFMAs -> they are issued
+//    inside the MFMA phase.
+//
+//   MEM(k): read the fragments of K-step k; lgkmcnt(0); vmcnt(youngest group) (own pieces of every older group have landed)
+//   MMA(k): MFMAs, interleaved with group(k) = { W(k+3) -> stage (k+3)%4, pass t_k of slab s_k + 1 }
+//   A:  MEM(0) | MMA(0) | MEM(1) | MMA(1) | ...          B:  -- | MEM(0) | MMA(0) | MEM(1) | ...      ( | = s_barrier )
+// RAW: W(k+1) is group(k-2), covered by the vmcnt that ends MEM(k) of BOTH groups, and a barrier separates those from
+//      either group's MEM(k+1).  WAR: group(k) overwrites W(k-1) / slab s_k - 1, last read in MEM(k-1) of both groups, which
+//      ended (lgkmcnt(0)) at least one barrier before either group's MMA(k).
+// LDS image: rows of 128 bytes (64 channels), 16-byte slots XOR-swizzled by ((row or column) >> 1) & 7: with the row / column
+// parity selecting the 128-byte half of a bank line this is conflict-free for the 16-lane groups of ds_read_b128 when a 32-row
+// MFMA operand is 32 consecutive weight rows, or 2 x 16 consecutive pixels (any start).
 // Epilogue (bias, residual, ReLU, dual destination, accumulate, BatchNormalization statistics, BatchNormalization-backward
 // sums): conv_common.h, shared with conv_igemm.hip.
 #include "conv_common.h"
 
 #define STP_OOB 0x80000000u
-#if defined(STP_HALO_SCHED) && (STP_HALO_SCHED == 1 || STP_HALO_SCHED == 2)
-#define HALO_NWST 3
-#else
 #define HALO_NWST 4
-#endif
 
-template <int TH, int BM, int WM, int WN>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// counted wait with a count that is a constant only after loop unrolling
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+  switch (n) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<1>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    default: wait_vmcnt<5>(); break;
+  }
+}
+
+// Row-major epilogue.  In the MFMA C layout a lane owns 4 channels of one pixel: its 8-byte stores / residual loads touch 64
+// different 256-byte pixel rows per instruction, and the per-channel BatchNormalization sums need a DPP row reduction per
+// fragment (measured on 128->128 @ 16x64x64: 5.4 us of a 24.6 us launch plain, 8.8 us with the statistics, 14 us with the
+// BatchNormalization-backward sums).  Instead the workgroup's fp32 tile is written to LDS as [pixel][BM channels] (row stride
+// padded by 16 bytes: conflict-free 16-byte writes) and read back so that a thread owns 8 CONSECUTIVE channels of a pixel:
+// 16-byte coalesced loads (residual / accumulate / BatchNormalization input) and stores, 16 lanes per 256-byte pixel row, and
+// the per-channel sums are plain register adds over the thread's pixels followed by ONE fixed-order reduction per workgroup.
+// The tile has 32K outputs per CU, so the epilogue is VALU-bound once the layout is right: EP selects the variant at compile
+// time (no per-element branches) and the arithmetic is written on float pairs (v_pk_* instructions).
+//   EP 0: bias / residual / accumulate / ReLU                      EP 1: EP 0 + sum, sum of squares of the stored values
+//   EP 2: (accumulate) + BatchNormalization-backward: store g = dY under the activation mask, reduce sum g and sum g * xhat
+// Same arithmetic per element as conv_common.h's epilogue (sum g * xhat is accumulated as sum g * x and centred once per channel).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// LDS-only workgroup barrier: __syncthreads() also fences global memory, i.e. waits for every outstanding global load AND store
+// (vmcnt counts stores on CDNA) - in the epilogue that would serialise the operand prefetch, the output stores and the reduction
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ f32x2v unpack_bf16x2(uint32_t w) { return f32x2v{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+
+template <int TH, int BM, int WM, int WN, int EP>
+__device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][TH / WN / 2], char* smem, int n, int y0, int x0,
+                                            int cout0, int tile_n, int wm, int wn, int lane, int tid, int wave) {
+  typedef bf16_t T;
+  constexpr int CW = BM / WM, RW = TH / WN, TM = CW / 32, TN = RW / 2;
+  constexpr int NPX = TH * 16, RS = BM * 4 + 16;          // staged row: BM floats + 16 bytes of padding
+  constexpr int CG = BM / 8, PP = 512 / CG, NP = NPX / PP;   // channel groups of 8, pixels per pass, passes
+  static_assert(NPX % PP == 0, "tile pixels per pass");
+  const int l15 = lane & 15, l4b = (lane >> 4) & 1, l5 = lane >> 5;
+  const int c8 = tid % CG, p0 = tid / CG;
+  const int co = cout0 + c8 * 8;
+  const bool cok = co < a.Cout;                               // Cout % 8 == 0: a group is valid as a whole
+  const bool first = co < a.Cd0;
+  T* const dbase = first ? reinterpret_cast<T*>(a.dst0) + co : reinterpret_cast<T*>(a.dst1) + (co - a.Cd0);
+  const int dC = first ? a.Cd0 : a.Cd1;
+  const bool accum = first ? a.acc0 : a.acc1;
+  const T* res = EP == 2 ? reinterpret_cast<const T*>(a.bnb.x) : reinterpret_cast<const T*>(a.residual);
+
+  // global operands of this thread's NP pixels: issued before the staging so their latency hides under it
+  int pm[NP];
+  u32x4 opr[NP], opa[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int px = p0 + k * PP;
+    pm[k] = n * a.HoWo + (y0 + (px >> 4)) * a.Wo + x0 + (px & 15);
+  }
+  if (cok) {
+    if (res) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) opr[k] = *reinterpret_cast<const u32x4*>(res + (size_t)pm[k] * a.Cout + co);
+    }
+    if (accum) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) opa[k] = *reinterpret_cast<const u32x4*>(dbase + (size_t)pm[k] * dC);
+    }
+  }
+  lds_barrier();                                            // every wave has left the K loop: the ring and the slabs are dead
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int px = (wn * RW + 2 * j + l4b) * 16 + l15;
+        const int c = wm * CW + i * 32 + 8 * g + 4 * l5;
+        *reinterpret_cast<f32x4*>(smem + px * RS + c * 4) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+      }
+  lds_barrier();
+
+  f32x2v ss[4], qq[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ss[e] = qq[e] = f32x2v{0.f, 0.f};
+  if (cok) {
+    // per-channel constants of the thread's 8 channels, as pairs
+    f32x2v bias2[4], ksc[4], ksh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias2[e] = ksc[e] = ksh[e] = f32x2v{0.f, 0.f};
+    if (EP != 2 && a.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias2[e] = *reinterpret_cast<const f32x2v*>(a.bias + co + 2 * e);
+    }
+    if (EP == 2) {
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co + 4);
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co + 4);
+      f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (a.bnb.gamma) { g0 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + co); g1 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + co + 4); }
+      if (a.bnb.beta) { b0 = *reinterpret_cast<const f32x4*>(a.bnb.beta + co); b1 = *reinterpret_cast<const f32x4*>(a.bnb.beta + co + 4); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float r = e < 4 ? r0[e & 3] : r1[e & 3], mu = e < 4 ? m0[e & 3] : m1[e & 3];
+        const float sc = a.bnb.gamma ? r * (e < 4 ? g0[e & 3] : g1[e & 3]) : r;
+        ksc[e >> 1][e & 1] = sc;
+        ksh[e >> 1][e & 1] = (e < 4 ? b0[e & 3] : b1[e & 3]) - mu * sc;
+      }
+    }
+    const bool relu = a.relu != 0;
+    // activation window of the fused BatchNormalization (the gradient passes strictly inside it): t is "on" iff it equals its
+    // clamp to [smallest positive number, below the upper bound] - one v_med3 + one compare instead of two compares + mask logic
+    const float alo = a.bnb.relu ? __uint_as_float(1u) : -__builtin_inff();
+    const float ahi = a.bnb.relu == 2 ? __uint_as_float(0x40bfffffu) : __builtin_inff();      // largest float below 6
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int px = p0 + k * PP;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
+      f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (EP != 2) {
+          v[e] += bias2[e];
+          if (res) v[e] += unpack_bf16x2(opr[k][e]);
+        }
+        if (accum) v[e] += unpack_bf16x2(opa[k][e]);
+        if (EP != 2 && relu) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
+        o[e] = pack_bf16x2(v[e].x, v[e].y);
+        if (EP == 1) {
+          const f32x2v sv = unpack_bf16x2(o[e]);
+          ss[e] += sv;
+          qq[e] += sv * sv;
+        }
+        if (EP == 2) {
+          // dY as stored -> masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma)
+          const f32x2v xv = unpack_bf16x2(opr[k][e]), dy = unpack_bf16x2(o[e]);
+          const f32x2v tt = xv * ksc[e] + ksh[e];
+          const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+          ss[e] += g;
+          qq[e] += g * xv;
+          o[e] = pack_bf16x2(g.x, g.y);
+        }
+      }
+      *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
+    }
+  }
+  if (EP >= 1) {
+    if (EP == 2 && cok) {   // sum g * xhat = rstd * (sum g * x - mean * sum g), per thread (linear, so the partition does not matter)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float mu = a.bnb.mean[co + e], rs = a.bnb.rstd[co + e];
+        qq[e >> 1][e & 1] = rs * (qq[e >> 1][e & 1] - mu * ss[e >> 1][e & 1]);
+      }
+    }
+    // threads with the same channel group: lanes c8 + CG*m of every wave -> butterfly inside the wave, then the 8 waves through LDS
+#pragma unroll
+    for (int off = CG; off < 64; off <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ss[e].x += __shfl_xor(ss[e].x, off, 64); ss[e].y += __shfl_xor(ss[e].y, off, 64);
+        qq[e].x += __shfl_xor(qq[e].x, off, 64); qq[e].y += __shfl_xor(qq[e].y, off, 64);
+      }
+    lds_barrier();                                          // the staged tile is dead
+    float* red = reinterpret_cast<float*>(smem);              // [8 waves][BM][2]
+    if (lane < CG) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * BM + c8 * 8 + e) * 2] = ss[e >> 1][e & 1];
+        red[(wave * BM + c8 * 8 + e) * 2 + 1] = qq[e >> 1][e & 1];
+      }
+    }
+    lds_barrier();
+    for (int c = tid; c < BM; c += 512) {
+      if (cout0 + c >= a.Cout) continue;
+      float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { s_ += red[(w * BM + c) * 2]; q_ += red[(w * BM + c) * 2 + 1]; }
+      a.stats[(size_t)(cout0 + c) * a.ntile_n + tile_n] = s_;
+      a.stats[((size_t)a.Cout + cout0 + c) * a.ntile_n + tile_n] = q_;
+    }
+  }
+}
+
+template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
-  static_assert(WM * WN == 8 && BM % (WM * 64) == 0 && BM / WM == 64 && TH % WN == 0, "config");
+  static_assert(WM * WN == 8 && BM % (WM * 32) == 0 && TH % (WN * 2) == 0, "config");
 #if defined(__HIP_DEVICE_COMPILE__)
 #if defined(STP_TIMING)   // scratch build: `bias` carries a u64[4 * workgroups] buffer of shader-clock stamps (scratch/halo_timing.py)
   ConvArgs a = a_in;
@@ -51,15 +252,16 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   constexpr int NWST = HALO_NWST;                // weight ring stages
   constexpr int WSTAGE = BM * 128;
   constexpr int LW = BM / 64;                    // weight LDS-DMA instructions per thread per K-step
-  constexpr int L = LW + 1;                      // + one slab pass (or sink)
-  constexpr int TM = 4, RW = TH / WN, TN = RW;
+  constexpr int CW = BM / WM, RW = TH / WN;      // channels / pixel rows per wave
+  constexpr int TM = CW / 32, TN = RW / 2;       // 32x32 MFMA tiles per wave
+  static_assert(LW + 1 <= TM * TN * 4, "one LDS-DMA instruction per MFMA at most");
   constexpr int OFF_W = 2 * SLAB, OFF_DUMP = OFF_W + NWST * WSTAGE, OFF_TAB = OFF_DUMP + 8 * 1024;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int lr = lane & 15, lg = lane >> 4;
+  const int l15 = lane & 15, l31 = lane & 31, l4b = (lane >> 4) & 1, l5 = lane >> 5;
 
   const int bid = xcd_remap(blockIdx.x, a.ntile_m * a.ntile_n);
   const int tile_n = bid / a.ntile_m, tile_m = bid - tile_n * a.ntile_m;   // channel tiles innermost: they share the slabs in L2
@@ -71,8 +273,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, a.bytesw, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
 
-  // ---- per-thread source offsets -----------------------------------------------------------------------------------
-  // slab pass i: halo pixel hp = i*64 + tid/8 at physical slot tid&7, which holds logical slot (tid&7) ^ (hp&7)
+  // ---- per-thread LDS-DMA source offsets ------------------------------------------------------------------------------
+  // slab pass i: halo pixel hp = i*64 + tid/8 (column hx) at physical slot tid&7, which holds logical slot (tid&7) ^ ((hx>>1)&7)
   const int prow = tid >> 3, pslot = tid & 7;
   uint32_t soff[NPASS];
 #pragma unroll
@@ -81,39 +283,28 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
     const int hy = hp / HWD, hx = hp - hy * HWD;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = hp < NHP && (unsigned)y < (unsigned)a.Hv && (unsigned)x < (unsigned)a.Wv;
-    soff[i] = ok ? (((uint32_t)(n * a.Hv + y) * (uint32_t)a.Wv + (uint32_t)x) * (uint32_t)a.C0 + (uint32_t)((pslot ^ (hp & 7)) * 8)) * 2u : STP_OOB;
+    soff[i] = ok ? (((uint32_t)(n * a.Hv + y) * (uint32_t)a.Wv + (uint32_t)x) * (uint32_t)a.C0 + (uint32_t)((pslot ^ ((hx >> 1) & 7)) * 8)) * 2u : STP_OOB;
   }
-  // weight instruction i: row i*64 + tid/8 of the channel tile, logical slot (tid&7) ^ (row&7)   (row&7 == prow&7)
+  // weight instruction i: row i*64 + tid/8 of the channel tile, logical slot (tid&7) ^ ((row>>1)&7)
   uint32_t woff[LW];
 #pragma unroll
   for (int i = 0; i < LW; ++i)
-    woff[i] = ((uint32_t)(cout0 + i * 64 + prow) * (uint32_t)a.K + (uint32_t)((pslot ^ (prow & 7)) * 8)) * 2u;
+    woff[i] = ((uint32_t)(cout0 + i * 64 + prow) * (uint32_t)a.K + (uint32_t)((pslot ^ ((prow >> 1) & 7)) * 8)) * 2u;
 
   const int nslab = a.C0 >> 6;
-  const int nk = nslab * 9;
   char* const sink = smem + OFF_DUMP + wave * 1024;
+  const uint32_t tapb = (uint32_t)a.C0 * 2u;     // bytes between the weight columns of consecutive taps
 
-  auto issue_weight_piece = [&](int i, int k, int s, int t) {   // piece i of K-step k = (slab s, tap t) -> ring stage k % NWST
-    char* dst = smem + OFF_W + (k % NWST) * WSTAGE;
-    const uint32_t kb = (uint32_t)(t * a.C0 + s * 64) * 2u;
-    const bool on = k < nk;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(on ? dst + (i * 64 + wave * 8) * 128 : sink), 16,
-                                             on ? woff[i] + kb : STP_OOB, 0, 0, 0);
+  // piece i of the weights of K-step (slab s, tap t) -> ring stage st; the column offset travels in the scalar soffset
+  auto issue_weight_piece = [&](int i, int st, int s, int t) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + OFF_W + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
+                                             woff[i], (uint32_t)t * tapb + (uint32_t)s * 128u, 0, 0);
   };
-  auto issue_weights = [&](int k, int s, int t) {
-#pragma unroll
-    for (int i = 0; i < LW; ++i) issue_weight_piece(i, k, s, t);
-  };
-  auto issue_slab_pass = [&](int s, int p) {        // pass p of slab s (no-op -> sink when out of range)
-    const bool on = s < nslab && p < NPASS && (p * 64 + wave * 8) < SROWS;
-    uint32_t so = STP_OOB;
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i)
-      if (i == p) so = soff[i];
-    if (on && so != STP_OOB) so += (uint32_t)s * 128u;
-    else so = STP_OOB;
+  // pass p (compile-time) of slab s; `live` false (no next slab) or rows past the slab -> the sink
+  auto issue_slab_pass = [&](int s, int p, bool live) {
+    const bool on = live && (p * 64 + wave * 8) < SROWS;   // wave-uniform
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(on ? smem + (s & 1) * SLAB + (p * 64 + wave * 8) * 128 : sink),
-                                             16, so, 0, 0, 0);
+                                             16, on ? soff[p] : STP_OOB, (uint32_t)s * 128u, 0, 0);
   };
 
   // ---- fused PRODUCER BatchNormalization (+activation): src0 holds the convolution output x that the BatchNormalization reads;
@@ -129,8 +320,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
       if ((i * 64 + wave * 8) >= SROWS) continue;                    // wave-uniform: rows that went to the sink
       const int hp = i * 64 + prow;
       if (soff[i] == STP_OOB) continue;
+      const int hx = hp % HWD;
       u32x4* vp = reinterpret_cast<u32x4*>(sb + hp * 128 + pslot * 16);
-      const int ch = s_ * 64 + ((pslot ^ (hp & 7)) << 3);
+      const int ch = s_ * 64 + ((pslot ^ ((hx >> 1) & 7)) << 3);
       const f32x4 sc0 = *reinterpret_cast<const f32x4*>(tab + ch), sc1 = *reinterpret_cast<const f32x4*>(tab + ch + 4);
       const f32x4 sh0 = *reinterpret_cast<const f32x4*>(tab + a.C0 + ch), sh1 = *reinterpret_cast<const f32x4*>(tab + a.C0 + ch + 4);
       const u32x4 v = *vp;
@@ -145,80 +337,35 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
     }
   };
 
-  // ---- epilogue operands (residual or BatchNormalization-backward x) first: older than every tile load ---------------
-  const int pixb = n * a.HoWo + (y0 + wn * RW) * a.Wo + x0 + lr;     // + j * Wo for fragment column j
-  u32x2 pre[TM][TN];
-  {
-    const T* ps = a.residual ? reinterpret_cast<const T*>(a.residual) : reinterpret_cast<const T*>(a.bnb.x);
-    if (ps) {
+  // ---- lane-constant fragment addresses ---------------------------------------------------------------------------------
+  // A (weights): row wm*CW + I*32 + l31 of the stage, 16-byte slot kc*2 + l5 of the K-step's 8 -> + stage offset + I*4096
+  // B (pixels) : halo pixel (wn*RW + 2J + l4b + dy) * 18 + l15 + dx of the slab           -> + (2J + dy) * 2304 (immediate)
+  uint32_t a_lane[4], b_lane[3][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int co = cout0 + wm * 64 + i * 16 + lg * 4;
+  for (int kc = 0; kc < 4; ++kc) {
+    a_lane[kc] = (uint32_t)(OFF_W + (wm * CW + l31) * 128 + (((kc * 2 + l5) ^ ((l31 >> 1) & 7)) << 4));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int pm = pixb + j * a.Wo;
-          pre[i][j] = *reinterpret_cast<const u32x2*>(ps + (co + 3 < a.Cout ? (size_t)pm * a.Cout + co : (size_t)0));
-        }
-      }
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hx = l15 + dx;
+      b_lane[dx][kc] = (uint32_t)(((wn * RW + l4b) * HWD + hx) * 128 + (((kc * 2 + l5) ^ ((hx >> 1) & 7)) << 4));
     }
   }
 
-  f32x4 acc[TM][TN];
-  // ---- fragment reads of one 32-deep half ("chunk" c) of K-step (slab s_, tap t_), weight ring stage st_ ------------
-  auto read_chunk = [&](int c, int s_, int t_, int st_, u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
-    const int dy = t_ / 3, dx = t_ - dy * 3;
-    const char* wa = smem + OFF_W + st_ * WSTAGE + (wm * 64) * 128;
-    const char* sb = smem + (s_ & 1) * SLAB;
-    const int hpb = (wn * RW + dy) * HWD + lr + dx;
-#if defined(STP_HX) && STP_HX == 2   // what-if: no LDS fragment reads
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = u32x4{(uint32_t)hpb, (uint32_t)j, (uint32_t)c, (uint32_t)lg};
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = u32x4{(uint32_t)st_, (uint32_t)i, (uint32_t)c, (uint32_t)lr};
-    asm volatile("" ::: "memory");
-    return;
-#endif
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int hp = hpb + j * HWD;
-      fb[j] = *reinterpret_cast<const u32x4*>(sb + hp * 128 + (((c * 4 + lg) ^ (hp & 7)) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row = i * 16 + lr;
-      fa[i] = *reinterpret_cast<const u32x4*>(wa + row * 128 + (((c * 4 + lg) ^ (row & 7)) << 4));
-    }
-  };
-  auto mma_chunk = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN]) {
-#if defined(STP_HX) && STP_HX == 1   // what-if: no MFMA work (the fragments stay live)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-  };
-
-  // ---- prologue: slab 0, then the groups { W(0), sink } and { W(1), sink } --------------------------------------------
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) issue_slab_pass(0, p);
-  issue_weights(0, 0, 0);
-  issue_slab_pass(nslab, 0);
-  issue_weights(1, 0, 1);
-  issue_slab_pass(nslab, 0);
-#if HALO_NWST == 4
-  issue_weights(2, 0, 2);
-  issue_slab_pass(nslab, 0);
-#endif
-
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- prologue: slab 0, then W(0), W(1), W(2) --------------------------------------------------------------------------
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) issue_slab_pass(0, p, true);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < LW; ++i) issue_weight_piece(i, t, 0, t);
 
   if (fuse_bn) {
     for (int c = tid; c < a.C0; c += 512) {
@@ -230,126 +377,93 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
     __builtin_amdgcn_s_barrier();          // the table is visible (every wave executes this: fuse_bn is uniform)
   }
   STP_STAMP(1);
-#if defined(STP_HALO_SCHED) && STP_HALO_SCHED == 2
-  // Software pipeline over the two 32-deep halves of a K-step: the fragment reads of half h+1 are in flight under the MFMAs
-  // of half h; the K-step boundary (counted vmcnt + barrier + the next LDS-DMA group) sits BETWEEN the two MFMA halves, so
-  // after the barrier every wave has 16 MFMAs queued behind its 8 reads and the LDS burst of the 8 waves hides under them.
-  //   group(j), issued right after barrier(j): { W(j+2) -> stage (j+2)%3, pass t_j of slab s_j + 1 }
-  //   barrier(j) follows vmcnt(L): only group(j-1) is in flight, so W(j) and every pass of slab s_j have landed for all waves;
-  //   before the barrier lgkmcnt(0): this wave's reads of stage j%3... (j-1)%3 and of the previous slab are complete, so the
-  //   DMA of group(j) may overwrite them.
-  u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  wait_vmcnt<L>();
-  __builtin_amdgcn_s_barrier();
-  issue_weights(2, 0, 2);
-  issue_slab_pass(1, 0);
-  read_chunk(0, 0, 0, 0, fa0, fb0);
-  int s = 0, t = 0;          // K-step k
-  int s1 = 0, t1 = 1;        // K-step k + 1
-  int s3 = 0, t3 = 3;        // K-step k + 3
-  for (int k = 0; k < nk; ++k) {
-    read_chunk(1, s, t, k % NWST, fa1, fb1);
-    mma_chunk(fa0, fb0);
-    if (k + 1 < nk) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_vmcnt<L>();
-      __builtin_amdgcn_s_barrier();
-      issue_weights(k + 3, s3, t3);
-      issue_slab_pass(s1 + 1, t1);
-      read_chunk(0, s1, t1, (k + 1) % NWST, fa0, fb0);
-    }
-    mma_chunk(fa1, fb1);
-    s = s1; t = t1;
-    if (++t1 == 9) { t1 = 0; ++s1; }
-    if (++t3 == 9) { t3 = 0; ++s3; }
-  }
-#elif defined(STP_HALO_SCHED) && STP_HALO_SCHED == 1
-  // One counted wait + one barrier per K-step, then the LDS-DMA group of K-step k+2, the 16 fragment reads and the 32 MFMAs.
-  //   group(j), issued right after barrier(j): { W(j+2) -> stage (j+2)%3, pass t_j of slab s_j + 1 }
-  //   barrier(j) follows vmcnt(L): only group(j-1) is in flight, so W(j) and every pass of slab s_j have landed for all waves,
-  //   and every wave has consumed (MFMA operands) the fragments of K-step j-1: stage (j+2)%3 and slab slot (s_j+1)&1 are free.
+
   {
-    u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    int s = 0, t = 0;          // K-step k
-    int s2 = 0, t2 = 2;        // K-step k + 2
-    for (int k = 0; k < nk; ++k) {
-      wait_vmcnt<L>();
-#if !defined(STP_HX) || STP_HX != 4   // what-if 4: no barrier in the loop
-      __builtin_amdgcn_s_barrier();
-#endif
-#if !defined(STP_HX) || STP_HX != 3   // what-if 3: no LDS-DMA in the loop
-      issue_weights(k + 2, s2, t2);
-      issue_slab_pass(s + 1, t);
-#endif
-      read_chunk(0, s, t, k % NWST, fa0, fb0);
-      read_chunk(1, s, t, k % NWST, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_chunk(fa0, fb0);
-      mma_chunk(fa1, fb1);
-      if (++t == 9) { t = 0; ++s; }
-      if (++t2 == 9) { t2 = 0; ++s2; }
-    }
-  }
-#else
-  // PING-PONG schedule.  The 8 waves form two groups (waves 0-3 = A, 4-7 = B: one wave of each per SIMD) that run the same
-  // loop half a K-step apart: while one group issues its 32 MFMAs the other reads its 16 fragments, then they swap at a
-  // barrier - the matrix pipe of every SIMD always has a wave feeding it.  Measured (scratch/halo_timing.py): in the lock-step
-  // schedule the memory part of a K-step is a ~1000-cycle LATENCY chain per wave (3 LDS-DMA instructions cost 100-180 issue
-  // cycles each when they open a phase, then 16 ds_read_b128 and their wait), which nothing overlapped.  So the LDS-DMA
-  // instructions are issued BETWEEN the MFMAs of the compute phase (where they cost ~60 cycles) and the memory phase is
-  // fragment reads only.
-  //   MEM(k): read the fragments of K-step k; lgkmcnt(0); vmcnt(L) (own pieces of every group but the youngest have landed)
-  //   MMA(k): 32 MFMAs, interleaved with group(k) = { W(k+3) -> stage (k+3)%4, pass t_k of slab s_k + 1 }
-  //   A:  MEM(0) | MMA(0) | MEM(1) | MMA(1) | ...          B:  -- | MEM(0) | MMA(0) | MEM(1) | ...      ( | = s_barrier )
-  // RAW: W(k+1) is group(k-2), covered by the vmcnt(L) that ends MEM(k) of BOTH groups, and a barrier separates those from
-  //      either group's MEM(k+1).  WAR: group(k) overwrites W(k-1) / slab s_k - 1, last read in MEM(k-1) of both groups, which
-  //      ended (lgkmcnt(0)) at least one barrier before either group's MMA(k).
-  {
-    u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     const bool grp_b = wave >= 4;          // wave-uniform
-    wait_vmcnt<2 * L>();                   // slab 0 and W(0)
+    wait_vmcnt<2 * LW>();                  // slab 0 and W(0): everything but W(1), W(2)
     if (fuse_bn) {
       transform_slab(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (grp_b) __builtin_amdgcn_s_barrier();
-    int s = 0, t = 0;          // K-step k
-    int s3 = 0, t3 = 3;        // K-step k + 3
-    for (int k = 0; k < nk; ++k) {
-      // slab s+1: its passes were issued in MMA(9s .. 9s+NPASS-1) and this wave's own pieces landed before MEM(9s+7) ended
-      if (fuse_bn && t == 8 && s + 1 < nslab) transform_slab(s + 1);
-      read_chunk(0, s, t, k % NWST, fa0, fb0);
-      read_chunk(1, s, t, k % NWST, fa1, fb1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_vmcnt<L>();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+
+    u32x4 fa[4][TM], fb[4][TN];
+    int wst = 0;                           // ring stage of the current K-step = k % 4
+    for (int s = 0; s < nslab; ++s) {
+      const bool last = s + 1 == nslab;    // no slab to prefetch, and the weights of the next "slab" do not exist
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t - dy * 3;             // compile-time after unrolling
+        // ---------------- MEM(k)
+        if (fuse_bn && t == 8 && !last) transform_slab(s + 1);   // its passes landed (own pieces) before MEM(9s+7) ended
+        {
+          const uint32_t so = (uint32_t)(wst * WSTAGE);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(fa0[i], fb0[j], acc[i][j]);
+          for (int kc = 0; kc < 4; ++kc) {
+            const uint32_t ab = a_lane[kc] + so;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[kc][j] = *reinterpret_cast<const u32x4*>(smem + b_lane[dx][kc] + (2 * j + dy) * (HWD * 128));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[kc][i] = *reinterpret_cast<const u32x4*>(smem + ab + i * 4096);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // leave the youngest group (issued in MMA(k-1)) in flight: LW weight pieces unless that K-step had none left to
+        // prefetch, plus its slab pass
+        if (t == 0) {
+          wait_vmcnt_n(LW);                                 // previous K-step = tap 8 (never of the last slab): no pass
+        } else if (last && t - 1 >= 6) {
+          wait_vmcnt_n((t - 1) < NPASS ? 1 : 0);
+        } else {
+          wait_vmcnt_n(LW + ((t - 1) < NPASS ? 1 : 0));
+        }
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (i < LW) issue_weight_piece(i, k + 3, s3, t3);
-        else if (i == LW) issue_slab_pass(s + 1, t);
+        // ---------------- MMA(k) + group(k)
+        __builtin_amdgcn_s_setprio(1);
+        {
+          const int st3 = (wst + 3) & 3;
+          const int t3 = t + 3 < 9 ? t + 3 : t - 6, s3 = t + 3 < 9 ? s : s + 1;
+          const bool wlive = !(last && t >= 6);
+          int piece = 0;
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kc][i]), __builtin_bit_cast(bf16x8, fb[kc][j]),
+                                                                    acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (piece < LW) {
+                  if (wlive) issue_weight_piece(piece, st3, s3, t3);
+                } else if (piece == LW && t < NPASS) {
+                  issue_slab_pass(s + 1, t, !last);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ++piece;
+              }
+        }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        wst = (wst + 1) & 3;
       }
-      mma_chunk(fa1, fb1);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      if (++t == 9) { t = 0; ++s; }
-      if (++t3 == 9) { t3 = 0; ++s3; }
+      // the fragment addresses follow the slab: slot (s+1) & 1
+      const uint32_t d = (s & 1) ? (uint32_t)(-SLAB) : (uint32_t)SLAB;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) b_lane[dx][kc] += d;
     }
     if (!grp_b) __builtin_amdgcn_s_barrier();
   }
-#endif
-  wait_vmcnt<0>();                         // the sink loads of the last two groups
+  wait_vmcnt<0>();                         // sink loads
   STP_STAMP(2);
-  const int Wo = a.Wo;
-  epilogue_px<T, TM, TN, BM, WN, 512, true>(a, cout0, wm * 64, wn, lr, lg, acc, smem, tile_n, pre,
-                                            [pixb, Wo](int j) { return pixb + j * Wo; });
+
+  // ---- epilogue: the fp32 tile goes through LDS into [pixel][channel] order (see epilogue_rm) ----------------------------
+  epilogue_rm<TH, BM, WM, WN, EP>(a, acc, smem, n, y0, x0, cout0, tile_n, wm, wn, lane, tid, wave);
 #if defined(STP_TIMING)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STP_STAMP(3);
@@ -366,14 +480,16 @@ static const HaloCfg HALO_CFGS[] = {{16, 128}, {8, 128}, {16, 64}, {8, 64}};
 #define STP_TILE_HALO 1024
 #define HALO_NCFG 4
 
-template <int TH, int BM, int WM, int WN>
-static int launch_halo(ConvArgs& a, hipStream_t s) {
+template <int TH, int BM, int WM, int WN, int EP>
+static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
-  const size_t lds = (size_t)2 * SROWS * 128 + HALO_NWST * BM * 128 + 8 * 1024 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
+  size_t lds = (size_t)2 * SROWS * 128 + HALO_NWST * BM * 128 + 8 * 1024 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
+  const size_t lds_ep = (size_t)TH * 16 * (BM * 4 + 16);   // the epilogue's staged fp32 tile
+  if (lds < lds_ep) lds = lds_ep;
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
-  auto kern = conv_halo_kernel<TH, BM, WM, WN>;
+  auto kern = conv_halo_kernel<TH, BM, WM, WN, EP>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return STP_E_LAUNCH;
@@ -384,17 +500,24 @@ static int launch_halo(ConvArgs& a, hipStream_t s) {
   return STP_OK;
 }
 
+template <int TH, int BM, int WM, int WN>
+static int launch_halo(ConvArgs& a, hipStream_t s) {
+  if (a.bnb.x) return launch_halo_ep<TH, BM, WM, WN, 2>(a, s);
+  if (a.stats) return launch_halo_ep<TH, BM, WM, WN, 1>(a, s);
+  return launch_halo_ep<TH, BM, WM, WN, 0>(a, s);
+}
+
 static bool halo_shape_ok(const stp_conv_params* p) {
   return p && p->dtype == STP_BF16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->src0_mode == STP_SRC_DIRECT &&
          p->C1 == 0 && p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv && p->Hs0 == p->Hv && p->Ws0 == p->Wv &&
          (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->dst_sum2x2 && !p->stats_slots &&
+         (p->Cd0 % 8) == 0 &&
          (!p->src_bn_mean || (p->src_bn_rstd && p->C0 <= 512));
 }
 
 // variant for a shape: -1 = not eligible / not faster.  Measured on MI355X against the per-tap DMA kernel (scratch/halo_bench.py,
-// bs16 U-Net/ResNet34 shapes): 128ch@64^2 30.2 -> 26.9 us (variant 0), 256ch@32^2 32.5 -> 27.4 (1), 512ch@16^2 42.7 -> 36.4 (3),
-// 128->384@64^2 78.0 -> 70.8 (0); 64-channel INPUTS (one slab, nine K-steps: nothing to amortise the slab over) are slower
-// (42 -> 47 us) and stay on the per-tap kernel.  One 8-wave workgroup per CU (100-158 KB of LDS), so the grid should cover the CUs.
+// bs16 U-Net/ResNet34 shapes); 64-channel INPUTS (one slab, nine K-steps: nothing to amortise the slab over) stay on the per-tap
+// kernel.  One 8-wave workgroup per CU (100-158 KB of LDS), so the grid should cover the CUs.
 static int halo_auto(const stp_conv_params* p) {
   if (!halo_shape_ok(p) || p->C0 < 128) return -1;
   const int64_t px16 = (p->Ho % 16) == 0 ? (int64_t)p->N * (p->Ho / 16) * (p->Wo / 16) : 0;
@@ -433,10 +556,10 @@ extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stre
   const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_halo_tiles(p, variant);
   hipStream_t s = (hipStream_t)stream;
   switch (variant) {
-    case 0: return launch_halo<16, 128, 2, 4>(a, s);
-    case 1: return launch_halo<8, 128, 2, 4>(a, s);
-    case 2: return launch_halo<16, 64, 1, 8>(a, s);
-    case 3: return launch_halo<8, 64, 1, 8>(a, s);
+    case 0: return launch_halo<16, 128, 2, 4>(a, s);   // wave: 64 channels x 4 rows
+    case 1: return launch_halo<8, 128, 2, 4>(a, s);    // wave: 64 channels x 2 rows
+    case 2: return launch_halo<16, 64, 1, 8>(a, s);    // wave: 64 channels x 2 rows
+    case 3: return launch_halo<8, 64, 2, 4>(a, s);     // wave: 32 channels x 2 rows
     default: return STP_E_BADARG;
   }
 }
