@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   constexpr int CW = BM / WM, RW = TH / WN;      // channels / pixel rows per wave
   constexpr int TM = CW / 32, TN = RW / 2;       // 32x32 MFMA tiles per wave
   static_assert(LW + 1 <= TM * TN * 4, "one LDS-DMA instruction per MFMA at most");
-  constexpr int OFF_W = 2 * SLAB, OFF_DUMP = OFF_W + NWST * WSTAGE, OFF_TAB = OFF_DUMP + 8 * 1024;
+  // LDS: [slab 0][slab 1 unless Cin == 64][NWST weight stages][scale/shift table of a fused producer BatchNormalization]
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -292,19 +292,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
     woff[i] = ((uint32_t)(cout0 + i * 64 + prow) * (uint32_t)a.K + (uint32_t)((pslot ^ ((prow >> 1) & 7)) * 8)) * 2u;
 
   const int nslab = a.C0 >> 6;
-  char* const sink = smem + OFF_DUMP + wave * 1024;
+  const int off_w = (nslab > 1 ? 2 : 1) * SLAB;   // one slab buffer is enough for a 64-channel input: two workgroups share a CU
   const uint32_t tapb = (uint32_t)a.C0 * 2u;     // bytes between the weight columns of consecutive taps
 
   // piece i of the weights of K-step (slab s, tap t) -> ring stage st; the column offset travels in the scalar soffset
   auto issue_weight_piece = [&](int i, int st, int s, int t) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + OFF_W + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + off_w + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
                                              woff[i], (uint32_t)t * tapb + (uint32_t)s * 128u, 0, 0);
   };
-  // pass p (compile-time) of slab s; `live` false (no next slab) or rows past the slab -> the sink
-  auto issue_slab_pass = [&](int s, int p, bool live) {
-    const bool on = live && (p * 64 + wave * 8) < SROWS;   // wave-uniform
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(on ? smem + (s & 1) * SLAB + (p * 64 + wave * 8) * 128 : sink),
-                                             16, on ? soff[p] : STP_OOB, (uint32_t)s * 128u, 0, 0);
+  // pass p (compile-time) of slab s.  A wave whose 8 rows lie past the slab issues nothing: pass_on() enters the vmcnt counts
+  auto pass_on = [&](int p) { return (p * 64 + wave * 8) < SROWS; };   // wave-uniform
+  auto issue_slab_pass = [&](int s, int p) {
+    if (pass_on(p))
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(smem + (s & 1) * SLAB + (p * 64 + wave * 8) * 128), 16, soff[p],
+                                               (uint32_t)s * 128u, 0, 0);
   };
 
   // ---- fused PRODUCER BatchNormalization (+activation): src0 holds the convolution output x that the BatchNormalization reads;
@@ -312,12 +313,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   // (own data: only its own vmcnt orders the read-modify-write, the K-step barrier publishes it).  Same fma / activation / bf16
   // rounding as stp_bn_apply -> bit-identical operands; pixels outside the image stay 0 (the padding applies to y, not x).
   const bool fuse_bn = a.pbn.mean != nullptr;
-  float* const tab = reinterpret_cast<float*>(smem + OFF_TAB);      // scale[C0], shift[C0]
+  float* const tab = reinterpret_cast<float*>(smem + off_w + NWST * WSTAGE);      // scale[C0], shift[C0]
   auto transform_slab = [&](int s_) {
     char* sb = smem + (s_ & 1) * SLAB;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      if ((i * 64 + wave * 8) >= SROWS) continue;                    // wave-uniform: rows that went to the sink
+      if ((i * 64 + wave * 8) >= SROWS) continue;                    // wave-uniform: rows past the slab were never fetched
       const int hp = i * 64 + prow;
       if (soff[i] == STP_OOB) continue;
       const int hx = hp % HWD;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   uint32_t a_lane[4], b_lane[3][4];
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
-    a_lane[kc] = (uint32_t)(OFF_W + (wm * CW + l31) * 128 + (((kc * 2 + l5) ^ ((l31 >> 1) & 7)) << 4));
+    a_lane[kc] = (uint32_t)(off_w + (wm * CW + l31) * 128 + (((kc * 2 + l5) ^ ((l31 >> 1) & 7)) << 4));
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int hx = l15 + dx;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
 
   // ---- prologue: slab 0, then W(0), W(1), W(2) --------------------------------------------------------------------------
 #pragma unroll
-  for (int p = 0; p < NPASS; ++p) issue_slab_pass(0, p, true);
+  for (int p = 0; p < NPASS; ++p) issue_slab_pass(0, p);
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -410,13 +411,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // leave the youngest group (issued in MMA(k-1)) in flight: LW weight pieces unless that K-step had none left to
-        // prefetch, plus its slab pass
+        // prefetch, plus its slab pass if there is a next slab and this wave has rows in that pass
         if (t == 0) {
           wait_vmcnt_n(LW);                                 // previous K-step = tap 8 (never of the last slab): no pass
-        } else if (last && t - 1 >= 6) {
-          wait_vmcnt_n((t - 1) < NPASS ? 1 : 0);
         } else {
-          wait_vmcnt_n(LW + ((t - 1) < NPASS ? 1 : 0));
+          const int np = ((t - 1) < NPASS && !last && pass_on(t - 1)) ? 1 : 0;
+          wait_vmcnt_n(((last && t - 1 >= 6) ? 0 : LW) + np);
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
                 if (piece < LW) {
                   if (wlive) issue_weight_piece(piece, st3, s3, t3);
                 } else if (piece == LW && t < NPASS) {
-                  issue_slab_pass(s + 1, t, !last);
+                  if (!last) issue_slab_pass(s + 1, t);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 ++piece;
@@ -459,7 +459,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
     }
     if (!grp_b) __builtin_amdgcn_s_barrier();
   }
-  wait_vmcnt<0>();                         // sink loads
   STP_STAMP(2);
 
   // ---- epilogue: the fp32 tile goes through LDS into [pixel][channel] order (see epilogue_rm) ----------------------------
@@ -484,7 +483,7 @@ template <int TH, int BM, int WM, int WN, int EP>
 static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
-  size_t lds = (size_t)2 * SROWS * 128 + HALO_NWST * BM * 128 + 8 * 1024 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
+  size_t lds = (size_t)(a.C0 > 64 ? 2 : 1) * SROWS * 128 + HALO_NWST * BM * 128 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
   const size_t lds_ep = (size_t)TH * 16 * (BM * 4 + 16);   // the epilogue's staged fp32 tile
   if (lds < lds_ep) lds = lds_ep;
   a.ntile_m = ceil_div(a.Cout, BM);
@@ -516,12 +515,17 @@ static bool halo_shape_ok(const stp_conv_params* p) {
 }
 
 // variant for a shape: -1 = not eligible / not faster.  Measured on MI355X against the per-tap DMA kernel (scratch/halo_bench.py,
-// bs16 U-Net/ResNet34 shapes); 64-channel INPUTS (one slab, nine K-steps: nothing to amortise the slab over) stay on the per-tap
-// kernel.  One 8-wave workgroup per CU (100-158 KB of LDS), so the grid should cover the CUs.
+// bs16 U-Net/ResNet34 shapes).  One 8-wave workgroup per CU (100-150 KB of LDS) for inputs of 128+ channels, so the grid should
+// cover the CUs.
 static int halo_auto(const stp_conv_params* p) {
-  if (!halo_shape_ok(p) || p->C0 < 128) return -1;
+  if (!halo_shape_ok(p)) return -1;
   const int64_t px16 = (p->Ho % 16) == 0 ? (int64_t)p->N * (p->Ho / 16) * (p->Wo / 16) : 0;
   const int64_t px8 = (int64_t)p->N * (p->Ho / 8) * (p->Wo / 16);
+  if (p->C0 == 64) {   // one slab, nine K-steps: the 64-channel tiles keep one slab + the ring under 80 KB, two workgroups per CU
+    if (px16 * ceil_div(p->Cout, 64) >= 512) return 2;
+    if (px8 * ceil_div(p->Cout, 64) >= 512) return 3;
+    return -1;
+  }
   const int ct = ceil_div(p->Cout, 128);
   if (p->Cout > 64 && px16 * ct >= 256) return 0;
   if (p->Cout > 64 && px8 * ct >= 192) return 1;
