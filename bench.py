@@ -110,8 +110,10 @@ def pmc_traffic(kernel):
     """L2-miss bytes per launch of ``kernel`` (read + write) from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
     that kernel was not in the measured build."""
-    for name in ("r01g_pmc_traffic.json", "r01f_pmc_traffic.json", "r01e_pmc_traffic.json", "r01d_pmc_traffic.json", "r01c_pmc_traffic.json", "r01b_pmc_traffic.json"):      # newest measurement that knows this kernel
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    names = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")), reverse=True) if os.path.isdir(pdir) else []
+    for name in names:      # newest measurement that knows this kernel
+        path = os.path.join(pdir, name)
         try:
             with open(path) as f:
                 k = json.load(f)["kernels"].get(kernel)
@@ -122,25 +124,55 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def pmc_mfma_util(kernel):
+    """MFMA pipe utilisation of ``kernel`` from the committed SQ counter pass (profiles/*_pmc_sq.json, scratch/pmc_aggregate_sq.py):
+    SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles); None when that kernel was not measured."""
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    names = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_sq.json")), reverse=True) if os.path.isdir(pdir) else []
+    for name in names:
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                k = json.load(f)["kernels"].get(kernel)
+        except (OSError, ValueError, KeyError):
+            continue
+        if k and k.get("mfma_util") is not None:
+            return k["mfma_util"], "profiles/" + name
+    return None, None
+
+
 def cpu_baseline(seconds_budget=25.0):
-    """The in-repo CPU oracle (a PORT: the reference's Keras-CPU fit() is not installable here, see
-    BASELINE.md 2) running the same step on a bounded sample: U-Net/ResNet-34, 512x512, batch 2."""
+    """The in-repo CPU oracle (a PORT: the reference's Keras-CPU fit() is not installable here) running the
+    same step - CPU augmentation (oracle/augment.py, the S1 pipeline of BASELINE.md 4) + forward + Dice/BCE + backward + Adam - on
+    a bounded sample: U-Net/ResNet-34, 512x512, batch 2 (BASELINE.md 4's batch-16, 3 warm-up / 10 timed protocol does not fit
+    the bench's time budget on the CPU, so: 1 warm-up, then as many timed steps as fit in ``seconds_budget`` (>= 3, <= 10),
+    MEDIAN step time; the value is batch / median)."""
+    from oracle import augment as oaug
     from oracle import nets as onets
     from oracle import step as ostep
+    from segmentation_training_pipeline_amd import augment
     n = 2
     P = onets.init_unet_resnet("resnet34", seed=42)
     tr = ostep.OracleTrainer(P, backbone="resnet34", loss=LOSS, optimizer="adam", lr=1e-3)
     x, y = ostep.synthetic_batch(n, H, W, seed=1234)
-    xf, yf = x.astype(np.float32), y.astype(np.float32)
-    tr.step(xf, yf)  # warm-up
-    steps, t0 = 0, time.time()
-    while steps < 1 or (time.time() - t0 < seconds_budget * 0.6 and steps < 4):
-        tr.step(xf, yf)
-        steps += 1
-    dt = time.time() - t0
-    return {"value": round(n * steps / dt, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "oracle (PyTorch-CPU fp32) training step, U-Net/ResNet34 512x512x3, batch %d, %d timed steps after 1 warm-up, "
-                      "no augmentation" % (n, steps)}
+    x8, y8 = x.astype(np.uint8), (y.reshape(n, H, W) > 0).astype(np.uint8)
+    rng = np.random.RandomState(1234)
+
+    def one_step():
+        prm = augment.sample_batch(augment.BENCH_SPEC, rng, n, H, W, (H, W))
+        xa, ya = oaug.warp_u8(x8, y8, prm, (H, W))
+        tr.step(xa.astype(np.float32), ya.reshape(n, H, W, 1).astype(np.float32))
+
+    one_step()  # warm-up
+    times, t_all = [], time.time()
+    while len(times) < 3 or (time.time() - t_all < seconds_budget and len(times) < 10):
+        t0 = time.time()
+        one_step()
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": round(n / med, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "oracle (numpy augmentation + PyTorch-CPU fp32) training step incl. the S1 augmentation, U-Net/ResNet34 512x512x3, "
+                      "batch %d, median of %d timed steps after 1 warm-up (BASELINE.md 4 protocol shortened to fit the bench budget)"
+                      % (n, len(times))}
 
 
 def main():
@@ -236,14 +268,17 @@ def main():
         n_l, sec, fl = gemm[dom]
         ach = fl / sec / 1e12
         traffic, traffic_src = pmc_traffic(dom)
+        mu, mu_src = pmc_mfma_util(dom)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
-                           "traffic_source": traffic_src,
+                           "traffic_source": traffic_src, "mfma_util": mu, "mfma_util_source": mu_src,
                            "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
                            "share_of_step_kernel_time": round(sec / tot, 3)}
-        top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]
+        top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:16]
         out["kernel_time_us"] = {k: [round(v[0], 1), round(1e6 * v[1], 1), round(v[2] / v[1] / 1e12, 1) if v[2] else None] for k, v in top}
         out["kernel_time_total_us"] = round(1e6 * tot, 1)
+        out["gemm_time_us"] = round(1e6 * sum(v[1] for v in gemm.values()), 1)
+        out["non_gemm_time_us"] = round(1e6 * (tot - sum(v[1] for v in gemm.values())), 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
