@@ -23,13 +23,13 @@ from segmentation_training_pipeline_amd.pipeline import ALIASES, CUSTOM_KEYS
 
 # name -> what the HIP loss/metric kernel provides (reference :15-22 registers these names with Keras)
 custom_objects = {
-    "dice": "dice", "iou": "iou", "dice_loss": "dice_loss", "binary_crossentropy": "binary_crossentropy",
-    "binary_accuracy": "binary_accuracy",
+    "dice": "dice", "iou": "iou", "iot": "iot", "dice_loss": "dice_loss", "binary_crossentropy": "binary_crossentropy",
+    "categorical_crossentropy": "categorical_crossentropy", "binary_accuracy": "binary_accuracy",
 }
 # registered by the reference but outside the first hot-path bar: named so the error is explicit
-unsupported_objects = ("iot", "lovasz_loss", "iou_loss", "jaccard_loss", "focal_loss")
+unsupported_objects = ("lovasz_loss", "iou_loss", "jaccard_loss", "focal_loss")
 
-extra_train = {}
+extra_train = generic.extra_train     # name -> dataset added to every fold's training indexes (reference :29, README.md:698-709)
 dataset_augmenters = {}
 
 # name -> fn(**arch_kwargs) -> model; the reference ships one entry, its in-tree DeepLabV3+ (reference :31-33), and lets users

@@ -237,6 +237,31 @@ def make_callbacks(spec):
     return out
 
 
+# name -> dataset whose samples are added to the TRAINING indexes of every fold and never to validation
+# (README.md:698-709: ``segmentation.extra_train["people"] = ds`` + ``extra_train_data: people`` in the YAML)
+extra_train = {}
+
+
+class ConcatDataSet(object):
+    """Items of ``a`` followed by the items of ``b`` (the fold split runs over ``a`` only; see extra_train)."""
+
+    def __init__(self, a, b):
+        self.a, self.b, self.na = a, b, len(a)
+        self.name = getattr(a, "name", "")
+
+    def __len__(self):
+        return self.na + len(self.b)
+
+    def __getitem__(self, i):
+        i = int(i)
+        return self.a[i] if i < self.na else self.b[i - self.na]
+
+    def isPositive(self, i):
+        i = int(i)
+        d, j = (self.a, i) if i < self.na else (self.b, i - self.na)
+        return d.isPositive(j) if hasattr(d, "isPositive") else True
+
+
 # ------------------------------------------------------------------------------------------ folds
 class KFoldedDataSet(object):
     """Train/validation index sets per fold from a fixed seed (README.md:172-175); optional hold-out
@@ -263,8 +288,12 @@ class KFoldedDataSet(object):
                 train = np.concatenate([parts[j] for j in range(folds_count) if j != f]) if folds_count > 1 else idx
                 self.folds.append((train, val))
 
+    extra_train_indexes = ()     # appended to the training indexes of every fold (extra_train_data)
+
     def sampledIndexes(self, fold, isTrain, negatives="all"):
         idx = self.folds[fold][0 if isTrain else 1]
+        if isTrain and len(self.extra_train_indexes):
+            idx = np.concatenate([idx, np.asarray(self.extra_train_indexes, np.int64)])
         if negatives in ("all", "real", None):
             return idx
         pos = [i for i in idx if self.ds.isPositive(int(i))]
@@ -696,7 +725,17 @@ class GenericTaskConfig(object):
         indexes = list(range(len(dataset)))
         if subsample < 1.0:
             indexes = indexes[: max(1, int(len(indexes) * subsample))]
+        extra_name = self.all.get("extra_train_data")
+        extra_idx = ()
+        if extra_name:
+            if extra_name not in extra_train:
+                raise ValueError("extra_train_data: %r is not registered; set segmentation.extra_train[%r] = dataset before fit() "
+                                 "(registered: %s)" % (extra_name, extra_name, ", ".join(sorted(extra_train)) or "none"))
+            extra = CropsDataSet(extra_train[extra_name], self.crops) if self.crops else extra_train[extra_name]
+            extra_idx = range(len(dataset), len(dataset) + len(extra))
+            dataset = ConcatDataSet(dataset, extra)           # folds are drawn from the original indexes only
         kf = self.kfold(dataset, indexes)
+        kf.extra_train_indexes = extra_idx
         folds = range(len(kf.folds)) if foldsToExecute is None else foldsToExecute
         summaries = []
         for fold in folds:
