@@ -1,7 +1,8 @@
 """GPU plumbing test = BASELINE.json configs[0]: a few synthetic 128x128 PNG pairs through
 SimplePNGMaskDataSet -> segmentation.parse() -> cfg.fit() -> predict_to_directory(), all on the HIP
-backend (configs[0] names U-Net/VGG11; neither the reference - README.md:587-589 offers vgg16/vgg19 only -
-nor this backend has VGG11, so the smallest available encoder, resnet18, stands in)."""
+backend.  configs[0] names U-Net/VGG11; the reference offers vgg16 / vgg19 only (README.md:587-589), so
+`test_configs0_unet_vgg16_plumbing` runs configs[0] as "4x synthetic 128x128 1-class, U-Net/VGG16, 1 epoch"; the
+longer end-to-end test uses resnet18."""
 import csv
 import os
 
@@ -91,6 +92,34 @@ def test_parse_fit_predict_end_to_end(tmp_path):
             assert np.array_equal(rle_decode(rle_encode(p1), (128, 128)) > 0, p1)     # the submission helper round-trips
             n_val += 1
     assert n_val == 4 and np.mean(dices) > 0.2      # 8 epochs on 4 images: plumbing, not accuracy
+
+
+def test_configs0_unet_vgg16_plumbing(tmp_path):
+    """BASELINE.json configs[0]: SimplePNGMaskDataSet 4x synthetic 128x128 1-class, U-Net over the VGG encoder the reference
+    has (vgg16, README.md:587-589), cfg.fit() 1 epoch, then predict_to_directory."""
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    img_dir, msk_dir = make_dataset(str(tmp_path), n=4)
+    cfg_path = str(tmp_path / "config.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Unet", "backbone": "vgg16", "classes": 1, "activation": "sigmoid", "encoder_weights": None,
+                        "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.001, "batch": 2, "folds_count": 2,
+                        "loss": "binary_crossentropy", "metrics": ["binary_accuracy", "dice"], "primary_metric": "val_binary_accuracy",
+                        "stages": [{"epochs": 1}]}, f)
+    ds = SimplePNGMaskDataSet(img_dir, msk_dir)
+    assert len(ds) == 4
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(ds, foldsToExecute=[0])
+    assert [(s["fold"], s["stage"]) for s in out] == [(0, 0)]
+    assert os.path.exists(os.path.join(str(tmp_path), "weights", "best-0.0.weights"))
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        rows = list(csv.DictReader(f))
+    assert len(rows) == 1 and np.isfinite(float(rows[0]["loss"])) and np.isfinite(float(rows[0]["val_loss"]))
+    dst = str(tmp_path / "pred")
+    cfg.predict_to_directory(img_dir, dst, fold=0, stage=0, batchSize=2)
+    from PIL import Image
+    assert sorted(os.listdir(dst)) == ["s00.png", "s01.png", "s02.png", "s03.png"]
+    assert np.asarray(Image.open(os.path.join(dst, "s00.png"))).shape == (128, 128)
 
 
 def test_linknet_yaml_fits(tmp_path):

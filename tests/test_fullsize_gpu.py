@@ -207,3 +207,51 @@ def test_full_size_graph_replay_is_bitwise_and_the_loss_falls(arch, backbone, si
     losses = [h["loss"] for h in e[0]]
     assert all(np.isfinite(v) for v in losses), losses
     assert min(losses[3:]) < losses[0], losses                    # a fixed batch is being fitted
+
+
+HEAVY_AUG = [{"Fliplr": 0.5},
+             {"Affine": {"scale": [0.8, 1.25], "translate_percent": {"x": [-0.1, 0.1], "y": [-0.1, 0.1]}, "rotate": [-20, 20], "shear": [-8, 8]}},
+             {"CropAndPad": {"percent": [-0.1, 0.1]}},
+             {"GaussianBlur": {"sigma": [0.0, 1.5]}},
+             {"AdditiveGaussianNoise": {"scale": [0, 12.75]}},
+             {"Multiply": [0.8, 1.2]}]
+
+
+def test_configs4_pspnet_resnet101_with_the_heavy_augmentation_in_the_loop():
+    """BASELINE.json configs[4] on one GPU as named: PSPNet/ResNet101, 768x768, 20 classes, batch 8, with a heavy imgaug pipeline
+    (Affine + CropAndPad + GaussianBlur + AdditiveGaussianNoise + Multiply, schemas/augmenters.raml) running ON THE DEVICE in
+    the training loop: host items -> pinned prefetch -> copy stream -> augment / filter kernels -> hipGraph step
+    (the path of cfg.fit(): pipeline.Trainer.run_epoch)."""
+    from segmentation_pipeline.impl.datasets import PredictionItem
+    from segmentation_training_pipeline_amd import pipeline
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    size, batch, classes, n = 768, 8, 20, 16
+    rng = np.random.RandomState(5)
+    yy, xx = np.mgrid[0:size, 0:size]
+    lab = ((yy // 64 + xx // 96) % classes).astype(np.uint8)
+    imgs = [np.clip(lab[:, :, None] * 12 + rng.randint(0, 16, (size, size, 3)), 0, 255).astype(np.uint8) for _ in range(n)]   # learnable: colour = class
+    msks = [lab[:, :, None].copy() for _ in range(n)]
+
+    class DS(object):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return PredictionItem("s%d" % i, imgs[i], msks[i])
+
+    m = HipSegModel("PSPNet", "resnet101", (size, size, 3), classes, "softmax", batch=batch, dtype="bf16",
+                    loss="categorical_crossentropy+1.0*dice_loss", optimizer="Adam", lr=1e-3, use_graph=True)
+    feeder = pipeline.DeviceFeeder(m.device, (size, size), HEAVY_AUG, seed=1, classes=classes)
+    tr = pipeline.Trainer(m, feeder, DS(), [], 0, 1)
+    idx = list(range(n))
+    first = tr.run_epoch(idx, True)
+    # the augmented batch the step consumed differs from the raw items (the pipeline ran) and the masks are still class ids
+    aug_img = m.plan.inputs["image"].buf.cpu().numpy().reshape(batch, size, size, 3)
+    aug_msk = m.plan.inputs["mask"].buf.cpu().numpy().reshape(batch, size, size)
+    assert not any(np.array_equal(aug_img[0], im) for im in imgs)
+    assert aug_msk.max() < classes and len(np.unique(aug_msk)) > 2
+    for _ in range(4):
+        last = tr.run_epoch(idx, True)
+    assert np.isfinite(first["loss"]) and np.isfinite(last["loss"]) and last["loss"] < first["loss"], (first, last)
+    del m, tr, feeder
+    torch.cuda.empty_cache()
