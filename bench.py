@@ -58,6 +58,8 @@ def kernel_key(name, meta, dtype):
     if name == "stp_conv2d_wgrad":
         if meta.get("sc"):
             return "conv_sc_wgrad_kernel<%s>" % t
+        if meta.get("kernel_id") in (2, 3):   # row-of-taps kernel (conv_wgrad.hip): <output channels per workgroup, waves over channels x columns>
+            return "conv_wgrad_row_kernel<%s>" % ("128, 2, 2" if meta["kernel_id"] == 2 else "64, 1, 4")
         if dtype == "bf16" and meta["layer"] == "conv0":
             return "conv_wgrad_kernel<%s, %s, true>" % (t, wgrad_tile(meta["cout"]))
         if dtype == "fp32" and meta["cout"] <= 32:

@@ -168,13 +168,18 @@ typedef struct stp_wgrad_params {
 size_t stp_conv2d_wgrad_workspace_bytes(const stp_wgrad_params* p);
 int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, void* stream);
 /* The two phases of stp_conv2d_wgrad as separate launches (so that a profiler / the plan can time them
- * individually).  variant: 0 = auto, 1 = register-staged kernel, 2 / 3 = buffer-DMA ring with 2 / 3 stages. */
+ * individually).  variant: 0 = auto, 1 = register-staged kernel, 2 / 3 = buffer-DMA ring with 2 / 3 stages,
+ * 4 = row-of-taps kernel (bf16, 3x3 / stride 1 / pad 1, C0 % 64 == 0 and C1 % 64 == 0, src0 direct or nearest-2x, Wo a multiple
+ * of 64 or a power of two >= 16 with Ho * Wo % 64 == 0; STP_E_BADARG otherwise). */
 int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, int32_t variant, void* stream);
 int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, int32_t variant, void* stream);
 /* Small-channel weight gradient (conv_sc.hip): chosen automatically by variant 0 when eligible. */
 int stp_wgrad_sc_eligible(const stp_wgrad_params* p);
 int stp_wgrad_sc_slabs(const stp_wgrad_params* p);
 int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream);
+/* Which kernel family variant 0 launches for p: 0 = pixel-reduction GEMM (conv_wgrad_kernel / conv_wgrad_dma_kernel),
+ * 1 = small-channel halo kernel, 2 / 3 = row-of-taps kernel with 128 / 64 output channels per workgroup. */
+int stp_conv2d_wgrad_kernel_id(const stp_wgrad_params* p);
 
 /* ----------------------------------------------------------------------------------------------
  * Compute copies of a convolution kernel from the fp32 master (layout [Cout][KH][KW][Cin]):

@@ -60,6 +60,7 @@ SIGNATURES = {
     "stp_wgrad_sc_eligible": (i32, [C.POINTER(WgradParams)]),
     "stp_wgrad_sc_slabs": (i32, [C.POINTER(WgradParams)]),
     "stp_wgrad_sc_partial": (i32, [C.POINTER(WgradParams), vp, vp]),
+    "stp_conv2d_wgrad_kernel_id": (i32, [C.POINTER(WgradParams)]),
     "stp_weight_prepare": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_weight_prepare_desc_bytes": (sz, []),
     "stp_weight_prepare_desc_fill": (i64, [vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),

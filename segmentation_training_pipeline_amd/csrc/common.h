@@ -61,6 +61,14 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   *reinterpret_cast<u32x2*>(p) = r;
 }
 
+// LDS-only workgroup barrier: __syncthreads() also fences global memory, i.e. waits for every outstanding global load AND store
+// (vmcnt counts stores on CDNA) - in the epilogue that would serialise the operand prefetch, the output stores and the reduction
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

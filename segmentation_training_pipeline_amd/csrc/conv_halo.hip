@@ -69,13 +69,6 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 //   EP 2: (accumulate) + BatchNormalization-backward: store g = dY under the activation mask, reduce sum g and sum g * xhat
 // Same arithmetic per element as conv_common.h's epilogue (sum g * xhat is accumulated as sum g * x and centred once per channel).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
-// LDS-only workgroup barrier: __syncthreads() also fences global memory, i.e. waits for every outstanding global load AND store
-// (vmcnt counts stores on CDNA) - in the epilogue that would serialise the operand prefetch, the output stores and the reduction
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 __device__ __forceinline__ f32x2v unpack_bf16x2(uint32_t w) { return f32x2v{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
 
 template <int TH, int BM, int WM, int WN, int EP>

@@ -14,6 +14,7 @@
 // Used for forward and (with the flipped/transposed weight copy) for the data gradient.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 struct ScArgs {
   const char* src;     // [N,Hs,Ws,CIN]  (Hs = H/2 when upsampling)
@@ -27,6 +28,7 @@ struct ScArgs {
   int stat_slots;
   BnBack bnb;          // see stp_conv_params.bnb_x
   int sum2;            // see stp_conv_params.dst_sum2x2: dst is [N,H/2,W/2,Cout]
+  uint32_t src_bytes;  // size of src (buffer descriptor of the streaming kernel's LDS-DMA)
   BnBack pbn;          // see stp_conv_params.src_bn_mean: src is normalised while it is staged (pbn.x unused)
 };
 
@@ -36,6 +38,9 @@ template <typename T> struct ScStageBn;
 template <> struct ScStageBn<float> {
   f32x4 sc, sh;
   __device__ __forceinline__ void load(const BnBack& b, int c) { const BnBackCh k = bnback_load(b, c); sc = k.sc; sh = k.sh; }
+  __device__ __forceinline__ void load_tab(const float* tsc, const float* tsh, int c) {
+    sc = *reinterpret_cast<const f32x4*>(tsc + c); sh = *reinterpret_cast<const f32x4*>(tsh + c);
+  }
   __device__ __forceinline__ u32x4 apply(const u32x4& r, int relu) const {
     u32x4 o;
 #pragma unroll
@@ -49,6 +54,10 @@ template <> struct ScStageBn<bf16_t> {
     const BnBackCh k0 = bnback_load(b, c), k1 = bnback_load(b, c + 4);
     sc[0] = f32x2{k0.sc[0], k0.sc[1]}; sc[1] = f32x2{k0.sc[2], k0.sc[3]}; sc[2] = f32x2{k1.sc[0], k1.sc[1]}; sc[3] = f32x2{k1.sc[2], k1.sc[3]};
     sh[0] = f32x2{k0.sh[0], k0.sh[1]}; sh[1] = f32x2{k0.sh[2], k0.sh[3]}; sh[2] = f32x2{k1.sh[0], k1.sh[1]}; sh[3] = f32x2{k1.sh[2], k1.sh[3]};
+  }
+  __device__ __forceinline__ void load_tab(const float* tsc, const float* tsh, int c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[e] = *reinterpret_cast<const f32x2*>(tsc + c + 2 * e); sh[e] = *reinterpret_cast<const f32x2*>(tsh + c + 2 * e); }
   }
   __device__ __forceinline__ u32x4 apply(const u32x4& r, int relu) const {
     u32x4 o;
@@ -99,6 +108,186 @@ template <> struct ScRaw4<bf16_t> {
 };
 
 constexpr int SC_TH = 8, SC_TW = 32, SC_HW = SC_TW + 2, SC_HH = SC_TH + 2;
+
+// Epilogue of the small-channel kernels, shared by the single-shot and the streaming form.  prefetch() issues the global
+// operands of the fused BatchNormalization backward (the BN input x of every output this lane owns: clamped addresses, no
+// control flow between the loads, one latency) - the streaming kernel calls it BEFORE it starts the next tile's LDS-DMA, so
+// the vmcnt wait that releases these registers does not also wait for that tile; finish() does the arithmetic and the stores.
+// LDSK: the per-channel constants of the fused BatchNormalization backward live in an LDS table [4][32] (scale, shift, mean,
+// rstd; filled once per persistent workgroup) and are read where they are used instead of occupying 16 registers per 16 channels.
+template <typename T, int TM, bool LDSK = false>
+struct ScEpilogue {
+  ScRaw4<T> xpre[TM][4];
+  BnBackCh bks[LDSK ? 1 : TM];
+  const float* ktab;
+
+  __device__ __forceinline__ void load_constants(const ScArgs& a, int lg) {
+    if (a.bnb.x) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        if (i * 16 + lg * 4 < a.Cout) bks[i] = bnback_load(a.bnb, i * 16 + lg * 4);
+    }
+  }
+  // (all 256 threads) fill the LDS table; the caller's next barrier publishes it
+  __device__ __forceinline__ void fill_table(const ScArgs& a, float* tab, int tid) {
+    ktab = tab;
+    if (a.bnb.x && tid < 32) {
+      float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+      if (tid < a.Cout) {
+        mu = a.bnb.mean[tid]; rs = a.bnb.rstd[tid];
+        sc = a.bnb.gamma ? rs * a.bnb.gamma[tid] : rs;
+        sh = (a.bnb.beta ? a.bnb.beta[tid] : 0.f) - mu * sc;
+      }
+      tab[tid] = sc; tab[32 + tid] = sh; tab[64 + tid] = mu; tab[96 + tid] = rs;
+    }
+  }
+  __device__ __forceinline__ BnBackCh bk(int i, int lg) const {
+    if constexpr (LDSK) {
+      BnBackCh k;
+      const int c = i * 16 + lg * 4;
+      k.sc = *reinterpret_cast<const f32x4*>(ktab + c); k.sh = *reinterpret_cast<const f32x4*>(ktab + 32 + c);
+      k.mu = *reinterpret_cast<const f32x4*>(ktab + 64 + c); k.rs = *reinterpret_cast<const f32x4*>(ktab + 96 + c);
+      return k;
+    } else {
+      return bks[i];
+    }
+  }
+
+  __device__ __forceinline__ void prefetch(const ScArgs& a, int n, int y0, int x0, int wave, int lr, int lg) {
+    if (!a.bnb.x) return;
+    if (a.sum2) {
+      const int H2 = a.H >> 1, W2 = a.W >> 1;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int gy = y0 + wave * 2, gx = x0 + h2 * 16 + lr;
+        const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int co = i * 16 + lg * 4;
+          const bool ok = !(lr & 1) && gy < a.H && gx < a.W && co < a.Cout;
+          xpre[i][h2].load(reinterpret_cast<const T*>(a.bnb.x) + (ok ? pm * a.Cout + co : (size_t)0));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+        const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int co = i * 16 + lg * 4;
+          const bool ok = gy < a.H && gx < a.W && co + 3 < a.Cout;
+          xpre[i][f].load(reinterpret_cast<const T*>(a.bnb.x) + (ok ? pm * a.Cout + co : (size_t)0));
+        }
+      }
+    }
+  }
+
+  // tile / ntiles: column of this tile in the [stat][channel][tile] partial sums
+  __device__ __forceinline__ void finish(const ScArgs& a, f32x4 (&acc)[TM][4], float* red, int n, int y0, int x0, int tile, int ntiles, int tid,
+                                         int wave, int lr, int lg) {
+    T* out = reinterpret_cast<T*>(a.dst);
+    f32x4 ss[TM], qq[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (a.sum2) {
+      // gradient of UpSampling2D(2): the wave's two tile rows are one output row (fragments f and f+2, same lane), lanes
+      // lr and lr^1 one output column (quad_perm DPP); even lanes own the low-resolution pixel
+      const int H2 = a.H >> 1, W2 = a.W >> 1;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int gy = y0 + wave * 2, gx = x0 + h2 * 16 + lr;
+        const bool own = !(lr & 1) && gy < a.H && gx < a.W;
+        const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int co = i * 16 + lg * 4;
+          f32x4 v = acc[i][h2] + acc[i][h2 + 2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+          if (!own || co >= a.Cout) continue;
+          T* d = out + pm * a.Cout + co;
+          if (a.accumulate) v += load4(d);
+          if (a.bnb.x) v = bnback_apply(bk(i, lg), a.bnb.relu, xpre[i][h2].get(), sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
+#if defined(STP_EXP) && STP_EXP == 11
+          if (a.N < 0)
+#endif
+          store4(d, v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+        if (gy >= a.H || gx >= a.W) continue;
+        const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int co = i * 16 + lg * 4;
+          if (co >= a.Cout) continue;
+          f32x4 v = acc[i][f];
+          if (co + 3 < a.Cout) {
+            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+            T* d = out + pm * a.Cout + co;
+            if (a.accumulate) v += load4(d);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (a.bnb.x) v = bnback_apply(bk(i, lg), a.bnb.relu, xpre[i][f].get(), sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
+#if defined(STP_EXP) && STP_EXP == 11
+            if (a.N < 0)
+#endif
+            store4(d, v);
+            if (a.stats && !a.bnb.x) {
+              const f32x4 sv = sc_stored(v, (const T*)nullptr);
+              ss[i] += sv;
+              qq[i] += sv * sv;
+            }
+          } else {
+            for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
+              float x = v[r];
+              if (a.bias) x += a.bias[co + r];
+              T* d = out + pm * a.Cout + co + r;
+              if (a.accumulate) x += Elem<T>::load(d);
+              if (a.relu) x = fmaxf(x, 0.f);
+#if defined(STP_EXP) && STP_EXP == 11
+              if (a.N < 0)
+#endif
+              Elem<T>::store(d, x);
+            }
+          }
+        }
+      }
+    }
+    if (a.stats) {
+      // butterfly over the 16 pixel lanes, then the 4 waves (same channels, different rows) through LDS
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sv = row_sum16_to_lane15(ss[i][e]), qv = row_sum16_to_lane15(qq[i][e]);
+          if (lr == 15) {
+            const int cl = i * 16 + lg * 4 + e;
+            red[(wave * TM * 16 + cl) * 2] = sv;
+            red[(wave * TM * 16 + cl) * 2 + 1] = qv;
+          }
+        }
+      lds_barrier();
+      if (tid < TM * 16 && tid < a.Cout) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sv += red[(w * TM * 16 + tid) * 2]; qv += red[(w * TM * 16 + tid) * 2 + 1]; }
+        if (a.stat_slots) {
+          long long* sl = reinterpret_cast<long long*>(a.stats);
+          slot_add(sl, a.stat_slots, tid, tile, sv);
+          slot_add(sl, a.stat_slots, a.Cout + tid, tile, qv);
+        } else {
+          a.stats[(size_t)tid * ntiles + tile] = sv;                     // [stat][channel][tile]
+          a.stats[((size_t)a.Cout + tid) * ntiles + tile] = qv;
+        }
+      }
+    }
+  }
+};
 
 template <typename T, int CIN, int TM>
 __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
@@ -161,7 +350,6 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
   float* red = reinterpret_cast<float*>(halo + SC_HH * SC_HW * PIXB);  // [4][TM*16][2] behind the halo tile
   // (A variant that looped over 16-channel passes of the same halo tile to cut registers - 5 instead of 3 waves/SIMD for
   //  Cout = 32 - measured slower: the weights then load after the barrier instead of under the halo staging.)
-  constexpr int cb = 0;
 
   // ---- MFMAs: wave w owns tile rows 2w, 2w+1; 4 fragments of 16 pixels -------------------------
   f32x4 acc[TM][4];
@@ -183,142 +371,205 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------
-  T* out = reinterpret_cast<T*>(a.dst);
-  f32x4 ss[TM], qq[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // per-channel BatchNormalization constants of this lane's channels: fetched once, not per fragment.  (Prefetching
-  // the x values themselves at kernel start was tried and lost 20-30 %: the extra registers cost occupancy, which is
-  // what hides latency in these single-shot workgroups.)
-  BnBackCh bks[TM];
-  if (a.bnb.x) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      if (cb + i * 16 + lg * 4 < a.Cout) bks[i] = bnback_load(a.bnb, cb + i * 16 + lg * 4);
-  }
-  if (a.sum2) {
-    // gradient of UpSampling2D(2): the wave's two tile rows are one output row (fragments f and f+2, same lane), lanes
-    // lr and lr^1 one output column (quad_perm DPP); even lanes own the low-resolution pixel
-    const int H2 = a.H >> 1, W2 = a.W >> 1;
-    ScRaw4<T> xpre[TM][2];
-    if (a.bnb.x) {
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const int gy = y0 + wave * 2, gx = x0 + h2 * 16 + lr;
-        const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int co = cb + i * 16 + lg * 4;
-          const bool ok = !(lr & 1) && gy < a.H && gx < a.W && co < a.Cout;
-          xpre[i][h2].load(reinterpret_cast<const T*>(a.bnb.x) + (ok ? pm * a.Cout + co : (size_t)0));
-        }
-      }
-    }
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const int gy = y0 + wave * 2, gx = x0 + h2 * 16 + lr;
-      const bool own = !(lr & 1) && gy < a.H && gx < a.W;
-      const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int co = cb + i * 16 + lg * 4;
-        f32x4 v = acc[i][h2] + acc[i][h2 + 2];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-        if (!own || co >= a.Cout) continue;
-        T* d = out + pm * a.Cout + co;
-        if (a.accumulate) v += load4(d);
-        if (a.bnb.x) v = bnback_apply(bks[i], a.bnb.relu, xpre[i][h2].get(), sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
-        store4(d, v);
-      }
-    }
+  ScEpilogue<T, TM> ep;
+  ep.load_constants(a, lg);
+  ep.prefetch(a, n, y0, x0, wave, lr, lg);
+  ep.finish(a, acc, red, n, y0, x0, (int)blockIdx.x, (int)gridDim.x, tid, wave, lr, lg);
+}
+
+// =================================================================================================
+// STREAMING form of the kernel above (the one stp_conv2d_sc launches; the single-shot form stays for A/B runs, STP_SC_STREAM=0).
+// The single-shot workgroup loads its halo tile through registers (2-6 dependent global-load round trips, the trip count is
+// not a compile-time constant), synchronises, computes, stores and retires: measured 85-150 us on the 16x512x512 layers whose
+// tensors take 30-55 us at HBM speed.  Here workgroups are PERSISTENT (a few per CU), the weights' A fragments and the fused
+// BatchNormalization constants are fetched once per workgroup, and the halo tile of the NEXT tile is written straight into the
+// other half of a double buffer by LDS-DMA (buffer_load ... lds, 16 bytes per lane, out-of-image pixels = out-of-range offset =
+// zeros) while the current tile is multiplied and stored.  Per tile:
+//   vmcnt(0) (own pieces of this tile, issued one tile ago) | producer BatchNormalization of the own pieces, in LDS | barrier |
+//   epilogue operand prefetch | LDS-DMA of the next tile | MFMAs | epilogue (vmcnt leaves the DMA in flight) | stores
+// Tiles are walked XCD by XCD: workgroup b (XCD b & 7) owns every (gridDim/8)-th tile of the b&7-th eighth of the tile list, so
+// the halo rows shared by neighbouring tiles meet in one L2.  Same MFMA order, same epilogue arithmetic: results are bit-identical
+// to the single-shot kernel.
+// =================================================================================================
+// (second launch bound = waves per SIMD = workgroups per CU the register allocation must leave room for)
+template <typename T, int CIN, int TM>
+__global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? 4 : 3) : 2)) void conv_sc_stream_kernel(const ScArgs a) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KC = 4 * VEC;
+  constexpr int K = 9 * CIN;
+  constexpr int NCH = (K + KC - 1) / KC;
+  constexpr int VPP = CIN / VEC;
+  constexpr int PIXB = CIN * SZ;
+  constexpr int NV = SC_HH * SC_HW * VPP;          // 16-byte vectors of a halo tile
+  constexpr int NPASS = (NV + 255) / 256;          // LDS-DMA instructions per thread per tile
+  constexpr int BUF = NPASS * 4096;                // one half of the double buffer (whole 1 KB wave pieces)
+  static_assert(CIN % VEC == 0 && 256 % VPP == 0, "a thread stages the same channel vector in every pass");
+
+  // LDS: [2][BUF] halo tiles | statistics scratch [4][TM*16][2] | BN-backward table [4][32] | producer-BN table [2][32]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + 2 * BUF);
+  float* ktab = red + 4 * TM * 16 * 2;
+  float* ptab = ktab + 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int sh = a.up ? 1 : 0;
+
+  // ---- tiles of this workgroup ------------------------------------------------------------------
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
   } else {
-  // the x values of the fused BatchNormalization backward for all of this lane's outputs, issued together (clamped
-  // addresses, no control flow between them): one latency instead of one per fragment, in registers the weights just freed
-  ScRaw4<T> xpre[TM][4];
-  if (a.bnb.x) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
-      const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int co = cb + i * 16 + lg * 4;
-        const bool ok = gy < a.H && gx < a.W && co + 3 < a.Cout;
-        xpre[i][f].load(reinterpret_cast<const T*>(a.bnb.x) + (ok ? pm * a.Cout + co : (size_t)0));
-      }
-    }
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = ntiles;
   }
+  if (t_first >= t_end) return;
+
+  // ---- per-thread constants of the staging: halo coordinates of the vector of every pass ------------
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  int hyx[NPASS];            // hy << 16 | hx ; -1 past the tile
+  const int cvb = (tid % VPP) * 16;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
-    if (gy >= a.H || gx >= a.W) continue;
-    const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
+  for (int p = 0; p < NPASS; ++p) {
+    const int v = p * 256 + tid, pix = v / VPP;
+    const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+    hyx[p] = v < NV ? (hy << 16 | hx) : -1;
+  }
+  const bool pbn = a.pbn.mean != nullptr;
+
+  auto decode = [&](int tile, int& n, int& y0, int& x0) {
+    const int bq = (int)fdiv((uint32_t)tile, a.divTx);
+    const int tx = tile - bq * a.tiles_x;
+    n = (int)fdiv((uint32_t)bq, a.divTy);
+    const int ty = bq - n * a.tiles_y;
+    y0 = ty * SC_TH; x0 = tx * SC_TW;
+  };
+  // LDS-DMA of a tile into buffer half b; returns the mask of passes whose vector lies inside the image
+  auto issue_tile = [&](int tile, int b) -> uint32_t {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    uint32_t inside = 0;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int gy = y0 - 1 + (hyx[p] >> 16), gx = x0 - 1 + (hyx[p] & 0xffff);
+      const bool ok = hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const uint32_t off = ok ? (uint32_t)((n * a.Hs + (gy >> sh)) * a.Ws + (gx >> sh)) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
+      inside |= ok ? (1u << p) : 0u;
+#if !defined(STP_EXP) || STP_EXP != 12   // (what-if builds of scratch/sc_exp_build.sh: 11 = no output stores, 12 = no halo loads, 13 = no LDS reads / MFMAs)
+      if (p * 256 + wave * 64 < NV)    // wave-uniform: a wave whose 64 vectors all lie past the tile issues nothing
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
+#endif
+    }
+    return inside;
+  };
+
+  uint32_t inside_cur = issue_tile(t_first, 0);
+
+  // ---- once per workgroup: weights -> registers (A fragments), lane addresses of the B fragments, constant tables -> LDS ----
+  u32x4 fa[TM][NCH];
+  uint32_t bl[NCH];            // LDS address of fragment chunk c for tile row 2*wave, column lr (buffer half 0); ~0 = chunk past K
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k0 = c * KC + lg * VEC;
+    const int tap = k0 / CIN, ch = k0 - tap * CIN;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    bl[c] = (k0 < K) ? (uint32_t)((((wave * 2 + kh) * SC_HW + kw + lr) * CIN + ch) * SZ) : 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int co = cb + i * 16 + lg * 4;
-      if (co >= a.Cout) continue;
-      f32x4 v = acc[i][f];
-      if (co + 3 < a.Cout) {
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
-        T* d = out + pm * a.Cout + co;
-        if (a.accumulate) v += load4(d);
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.bnb.x) v = bnback_apply(bks[i], a.bnb.relu, xpre[i][f].get(), sc_stored(v, (const T*)nullptr), ss[i], qq[i]);
-        store4(d, v);
-        if (a.stats && !a.bnb.x) {
-          const f32x4 sv = sc_stored(v, (const T*)nullptr);
-          ss[i] += sv;
-          qq[i] += sv * sv;
-        }
-      } else {
-        for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
-          float x = v[r];
-          if (a.bias) x += a.bias[co + r];
-          T* d = out + pm * a.Cout + co + r;
-          if (a.accumulate) x += Elem<T>::load(d);
-          if (a.relu) x = fmaxf(x, 0.f);
-          Elem<T>::store(d, x);
-        }
-      }
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (k0 < K) w = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(i * 16 + lr) * K + k0) * SZ);
+      fa[i][c] = w;
     }
   }
+  ScEpilogue<T, TM, true> ep;
+  ep.fill_table(a, ktab, tid);
+  if (pbn && tid < CIN) {
+    const float r = a.pbn.rstd[tid], sc = a.pbn.gamma ? r * a.pbn.gamma[tid] : r;
+    ptab[tid] = sc;
+    ptab[32 + tid] = (a.pbn.beta ? a.pbn.beta[tid] : 0.f) - a.pbn.mean[tid] * sc;
   }
-  if (a.stats) {
-    // butterfly over the 16 pixel lanes, then the 4 waves (same channels, different rows) through LDS
+  lds_barrier();               // the tables are visible
+
+  auto body = [&](int tile, auto curc) {
+    constexpr int CUR = decltype(curc)::value;
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's pieces (own) have landed; the previous tile's stores are out
+    if (pbn) {
+      ScStageBn<T> sbn;
+      sbn.load_tab(ptab, ptab + 32, (tid % VPP) * VEC);
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p)
+        if (inside_cur & (1u << p)) {     // padding applies to the NORMALISED tensor: out-of-image vectors stay zero
+          u32x4* vp = reinterpret_cast<u32x4*>(smem + CUR * BUF + (p * 256 + tid) * 16);
+          *vp = sbn.apply(*vp, a.pbn.relu);
+        }
+    }
+    lds_barrier();
+    ep.prefetch(a, n, y0, x0, wave, lr, lg);
+    const int next = tile + t_step;
+    if (next < t_end) inside_cur = issue_tile(next, CUR ^ 1);
+
+    f32x4 acc[TM][4];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sv = row_sum16_to_lane15(ss[i][e]), qv = row_sum16_to_lane15(qq[i][e]);
-        if (lr == 15) {
-          const int cl = i * 16 + lg * 4 + e;
-          red[(wave * TM * 16 + cl) * 2] = sv;
-          red[(wave * TM * 16 + cl) * 2 + 1] = qv;
-        }
-      }
-    __syncthreads();
-    if (tid < TM * 16 && cb + tid < a.Cout) {
-      float sv = 0.f, qv = 0.f;
+      for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { sv += red[(w * TM * 16 + tid) * 2]; qv += red[(w * TM * 16 + tid) * 2 + 1]; }
-      if (a.stat_slots) {
-        long long* sl = reinterpret_cast<long long*>(a.stats);
-        slot_add(sl, a.stat_slots, cb + tid, (int)blockIdx.x, sv);
-        slot_add(sl, a.stat_slots, a.Cout + cb + tid, (int)blockIdx.x, qv);
-      } else {
-        a.stats[(size_t)(cb + tid) * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][tile]
-        a.stats[((size_t)a.Cout + cb + tid) * gridDim.x + blockIdx.x] = qv;
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        u32x4 fb = {0u, 0u, 0u, 0u};
+        // the fragment's tile row / column half and the buffer half are instruction offsets
+#if !defined(STP_EXP) || STP_EXP != 13
+        if (bl[c] != 0xffffffffu) fb = *reinterpret_cast<const u32x4*>(smem + bl[c] + (CUR * BUF + ((f >> 1) * SC_HW + (f & 1) * 16) * PIXB));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ScMma<T>::run(fa[i][c], fb, acc[i][f]);
+#else
+        if (a.N < 0) acc[0][f][0] += __uint_as_float(fa[0][c][0] + bl[c]);
+#endif
       }
     }
+    ep.finish(a, acc, red, n, y0, x0, tile, ntiles, tid, wave, lr, lg);
+  };
+
+  for (int tile = t_first; tile < t_end; tile += 2 * t_step) {
+    body(tile, std::integral_constant<int, 0>{});
+    if (tile + t_step < t_end) body(tile + t_step, std::integral_constant<int, 1>{});
   }
+}
+
+// workgroups per CU of a streaming instantiation (registers and LDS decide), asked once
+template <typename T, int CIN, int TM>
+static int sc_stream_blocks_per_cu(size_t lds) {
+  static int cached = 0;
+  if (!cached) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_sc_stream_kernel<T, CIN, TM>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    cached = nb > 8 ? 8 : nb;
+  }
+  return cached;
 }
 
 template <typename T, int CIN, int TM>
 static int launch_sc(const ScArgs& a, hipStream_t s) {
+  static const bool stream_on = !(getenv("STP_SC_STREAM") && atoi(getenv("STP_SC_STREAM")) == 0);
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  if (stream_on) {
+    constexpr int NV = SC_HH * SC_HW * (CIN / Elem<T>::VEC), NPASS = (NV + 255) / 256;
+    const size_t lds = (size_t)2 * NPASS * 4096 + (4 * TM * 16 * 2 + 128 + 64) * sizeof(float);
+    static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+    int blocks = cus * sc_stream_blocks_per_cu<T, CIN, TM>(lds);      // a multiple of 8 on this machine: XCD-contiguous tile walk
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL((conv_sc_stream_kernel<T, CIN, TM>), dim3(blocks), dim3(256), lds, s, a);
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
   const size_t lds = (size_t)SC_HH * SC_HW * CIN * sizeof(T) + 4 * TM * 16 * 2 * sizeof(float);
-  hipLaunchKernelGGL((conv_sc_kernel<T, CIN, TM>), dim3(a.N * a.tiles_x * a.tiles_y), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_sc_kernel<T, CIN, TM>), dim3(ntiles), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
@@ -357,6 +608,11 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.src = (const char*)p->src0; a.weight = (const char*)p->weight; a.bias = p->bias; a.dst = (char*)p->dst0;
   a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
   a.up = p->src0_mode == STP_SRC_NEAREST2X; a.accumulate = p->accumulate0; a.relu = p->relu;
+  {
+    const uint64_t sb = (uint64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * (p->dtype == STP_BF16 ? 2 : 4);
+    if (sb >= 0x80000000ull) return STP_E_BADARG;   // 32-bit LDS-DMA offsets
+    a.src_bytes = (uint32_t)sb;
+  }
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
   a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
   a.stats = p->stats_partial;

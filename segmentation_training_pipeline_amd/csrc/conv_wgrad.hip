@@ -451,6 +451,236 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// ROW-OF-TAPS variant (bf16, 3x3 / stride 1 / pad 1, source channel counts multiples of 64, uniform-row feature maps).
+// The DMA kernel above is bound by the L2 -> LDS path (what-if build: loads only = 80 % of the launch; 64 FLOP per staged
+// byte): every k-tile re-stages dY, and the im2col columns of the three taps of a kernel row are three copies of the same
+// pixels shifted by one.  Here a workgroup's k-tile is ONE KERNEL ROW of a 64-channel input block - 192 columns
+// (kw = 0..2) x (ci 0..63) - and the operand tile of a 64-pixel step is the step's input pixels WITH THEIR HALO: rows x
+// (seg + 2) pixels of 128 bytes (seg = min(64, Wo) pixels of `rows` image rows).  The B fragment of tap kw is the same LDS
+// block read one pixel row further: 28 KB staged per 2 x 128 x 192 x 64 FLOP = 112 FLOP per byte, 7 LDS-DMA instructions
+// per thread per 48 MFMAs (8 per 32 above).  LDS rows keep the 32-byte-unit XOR swizzle of tile_addr<> (a transpose read
+// touches 8 consecutive pixel rows from any start: conflict-free for every kw).
+//   tile: BM output channels x 192 columns of kernel row kh, input-channel block cib   (tile_n = kh * (C0 / 64) + cib)
+//   dW column of (kw, ci): (kh * 3 + kw) * Ctot + cib * 64 + ci.  Two concatenated sources (each a multiple of 64 channels, the first optionally
+//   nearest-2x upsampled: the decoder's UpSampling2D + Concatenate) are handled per 64-channel block: a block lies in one source.
+template <int BM, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) {
+  static_assert(WM * WN == 4, "4 waves");
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef bf16_t T;
+  constexpr int SZ = 2, PK = 64, BN = 192;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int ROWA = BM * SZ, ROWB = 128;                    // LDS row bytes: dY pixel / halo pixel (64 input channels)
+  constexpr int VPRA = ROWA / 16, RPA = 256 / VPRA, NVA = PK / RPA;
+  constexpr int HROWS = 72, NVB = 3;                           // halo rows: rows x (seg + 2) <= 72; passes of 32 rows, the third has 8
+  constexpr int STAGE = PK * ROWA + HROWS * ROWB;
+  constexpr int L = NVA + NVB;                                 // LDS-DMA instructions per stage: wave 0 (waves 1-3 skip the third halo pass)
+  static_assert(NVA * RPA == PK && (NVA == 1 || RPA % 8 == 0), "A passes");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int tiles = a.ntile_m * a.ntile_n;
+  const int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int split = bid / tiles;
+  const int t = bid - split * tiles;
+  const int tile_m = t % a.ntile_m, tile_n = t / a.ntile_m;
+  const int ncib = a.Ctot >> 6;
+  const int kh = tile_n / ncib, cib = tile_n - kh * ncib;       // cib: 64-channel block of the CONCATENATED input
+  const bool first = cib * 64 < a.C0;                            // wave-uniform: which source holds this block
+  const int cs = first ? a.C0 : a.C1, cb_src = first ? cib : cib - (a.C0 >> 6);
+  const int sh = (first && a.mode == STP_SRC_NEAREST2X) ? 1 : 0;  // UpSampling2D(2) folded into the gather: source pixel = (h >> 1, w >> 1)
+  const int Hs = first ? a.Hs0 : a.Hv, Ws = first ? a.Ws0 : a.Wv;
+  const int cout0 = tile_m * BM;
+  const int step0 = split * a.steps_per_split;
+  const int step1 = min(step0 + a.steps_per_split, a.nsteps);
+
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.bytesdy, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? a.src0 : a.src1), 0, first ? a.bytes0 : a.bytes1, 0x00020000);
+
+  // geometry of a step: `rows` image rows of `seg` pixels (wave-uniform)
+  const int seg = a.Wo >= PK ? PK : a.Wo, rows = PK / seg, hw = seg + 2;
+
+  // ---- LDS-DMA constants.  A (dY): as in the DMA kernel.  B: halo row h = pass * 32 + tid / 8, physical slot tid & 7 -------
+  const int rowA0 = tid / VPRA;
+  const int colA = (tile_addr<ROWA>(rowA0, (tid % VPRA) * 16) - rowA0 * ROWA) / SZ;
+  const bool coA_ok = (cout0 + colA) < a.Cout;
+  uint32_t rowa[NVA];
+#pragma unroll
+  for (int i = 0; i < NVA; ++i) rowa[i] = ((uint32_t)(rowA0 + i * RPA) * (uint32_t)a.Cout + (uint32_t)(cout0 + colA)) * SZ;
+  const int hb0 = tid >> 3;
+  const uint32_t colB = (uint32_t)(tile_addr<ROWB>(hb0, (tid & 7) * 16) - hb0 * ROWB);   // logical byte column held by this slot
+  int hr[NVB], hx[NVB];          // image row / column of the halo pixel relative to the step's first pixel (-1 = unused row)
+#pragma unroll
+  for (int i = 0; i < NVB; ++i) {
+    const int h = hb0 + i * 32;
+    const int r = h / hw;
+    hr[i] = r < rows ? r + kh - 1 : -0x4000;
+    hx[i] = h - r * hw - 1;
+  }
+  const uint32_t pixb = (uint32_t)cs * SZ, imgb = (uint32_t)Hs * (uint32_t)Ws * pixb, cbyte = (uint32_t)cb_src * 128u + colB;
+
+  auto issue_tile = [&](int step, int buf) {
+    const int p0 = step * PK;
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + PK * ROWA;
+    const uint32_t n = fdiv((uint32_t)p0, a.divHoWo);
+    const uint32_t rem = (uint32_t)p0 - n * (uint32_t)a.HoWo;
+    const uint32_t ho0 = fdiv(rem, a.divWo);
+    const uint32_t wo0 = rem - ho0 * (uint32_t)a.Wo;
+    const uint32_t abase = (uint32_t)p0 * (uint32_t)a.Cout * SZ;
+    const uint32_t nb = n * imgb + cbyte;
+#pragma unroll
+    for (int i = 0; i < NVA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sa + (i * 256 + wave * 64) * 16), 16,
+                                               coA_ok ? abase + rowa[i] : STP_OOB, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int hv = (int)ho0 + hr[i], wv = (int)wo0 + hx[i];
+      const bool ok = (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+      const uint32_t off = nb + ((uint32_t)(hv >> sh) * (uint32_t)Ws + (uint32_t)(wv >> sh)) * pixb;
+      if (i * 32 + wave * 8 < HROWS)     // wave-uniform: rows 72.. of the third pass do not exist
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(sb + (i * 256 + wave * 64) * 16), 16,
+                                                 ok ? off : STP_OOB, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses.  Pixel q of the step = image row q / seg, column q % seg -> halo row (q / seg) * hw + q % seg + kw.
+  // A 16-lane group reads 4 consecutive pixels (seg >= 16: they share an image row); lane: pixel (lr >> 2), quad (lr & 3).
+  const int qb = (lr & 3) * 8;
+  int prowA[4], hrowB[4];      // [chunk * 2 + half]: dY row / halo row (kw = 0) of this lane's pixel
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = e * 16 + lg * 4 + (lr >> 2);
+    prowA[e] = q;
+    const int r = q / seg;
+    hrowB[e] = r * hw + (q - r * seg);
+  }
+  int kwB[TN], cbB[TN];        // tap and byte column (64-channel block) of this wave's column blocks
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / WN) + j * 16;
+    kwB[j] = col >> 6;
+    cbB[j] = (col & 63) * SZ + qb;
+  }
+  const int ca = (wm * (BM / WM)) * SZ + qb;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const char* sa) {
+    const char* sb = sa + PK * ROWA;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prowA[2 * c], ca + i * 32)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prowA[2 * c + 1], ca + i * 32)));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(hrowB[2 * c] + kwB[j], cbB[j])));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(hrowB[2 * c + 1] + kwB[j], cbB[j])));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        fb[j] = u32x4{l2.x, l2.y, h2.x, h2.y};
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // STAGES-deep ring, one barrier per step: tile st+STAGES-1 is issued after the barrier of step st (every wave has left
+  // compute(st-1), the last reader of that slot); the wait leaves the STAGES-2 younger tiles in flight
+  const int nst = step1 - step0;
+#pragma unroll
+  for (int q = 0; q < STAGES - 1; ++q)
+    if (q < nst) issue_tile(step0 + q, q);
+  int buf = 0, nbuf = STAGES - 1;
+  for (int st = 0; st < nst; ++st) {
+    const int ahead = nst - 1 - st;      // tiles after this one
+    if (STAGES >= 3 && ahead >= STAGES - 2) {
+      if (wave == 0) wait_vmcnt<(STAGES - 2) * L>(); else wait_vmcnt<(STAGES - 2) * (L - 1)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+#if !defined(STP_EXP) || STP_EXP != 2
+    if (st + STAGES - 1 < nst) issue_tile(step0 + st + STAGES - 1, nbuf);
+#endif
+#if !defined(STP_EXP) || STP_EXP != 1
+    compute(smem + buf * STAGE);
+#endif
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
+  }
+
+  // ---- slab, FRAGMENT-MAJOR: [split][tile][wave][i][j][lane] float4 (the lane's 4 output channels of one column) - every store is
+  // a 16-byte lane-contiguous vector (1 KB per wave instruction) instead of 4-byte stores K floats apart (measured: the scattered
+  // slab write was a third of the launch); wgrad_reduce_row_kernel sums the splits in this order and scatters into dW once
+  f32x4* out = reinterpret_cast<f32x4*>(a.out) + ((size_t)(split * tiles + t) * 4 + wave) * (TM * TN * 64) + lane;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) out[(i * TN + j) * 64] = acc[i][j];
+#endif
+}
+
+// Reduction of the row-of-taps kernel's fragment-major slabs: element e = ((tile * 4 + wave) * TM*TN + i*TN + j) * 64 + lane.
+// SL lanes walk the splits of an element in parallel (fixed assignment, fixed-shape LDS tree: deterministic), then the 4 floats
+// go to dW[co + r][(kh*3 + kw) * C0 + cib*64 + ci].
+template <int BM, int WM, int WN, int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_row_kernel(const f32x4* __restrict__ slabs, float* __restrict__ dw, int64_t per_split,
+                                                               int splits, int accumulate, int ntile_m, int C0, int Cout, int K) {
+  constexpr int TM = BM / WM / 16, TN = 192 / WN / 16, EPB = 256 / SL;
+  __shared__ f32x4 sh[SL][EPB];
+  const int ev = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+  const int64_t e = (int64_t)blockIdx.x * EPB + ev;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e < per_split)
+    for (int k = sl; k < splits; k += SL) s += slabs[(size_t)k * per_split + e];
+  if (SL > 1) {
+    sh[sl][ev] = s;
+    __syncthreads();
+#pragma unroll
+    for (int w = SL / 2; w > 0; w >>= 1) {
+      if (sl < w) sh[sl][ev] += sh[sl + w][ev];
+      __syncthreads();
+    }
+    s = sh[0][ev];
+  }
+  if (sl != 0 || e >= per_split) return;
+  const int lane = (int)(e & 63), lr = lane & 15, lg = lane >> 4;
+  int q = (int)(e >> 6);
+  const int ij = q % (TM * TN); q /= (TM * TN);
+  const int wave = q & 3, t = q >> 2;
+  const int i = ij / TN, j = ij - i * TN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = t % ntile_m, tile_n = t / ntile_m;
+  const int ncib = C0 >> 6, kh = tile_n / ncib, cib = tile_n - kh * ncib;
+  const int col = wn * (192 / WN) + j * 16 + lr;
+  const int kc = (kh * 3 + (col >> 6)) * C0 + cib * 64 + (col & 63);
+  const int co = tile_m * BM + wm * (BM / WM) + i * 16 + lg * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (co + r < Cout) {
+      float* d = dw + (size_t)(co + r) * K + kc;
+      *d = accumulate ? *d + s[r] : s[r];
+    }
+}
+
 // dw[i] (+)= sum_k slabs[k][i], 4 floats per thread (count is a multiple of 4: Cout*K with K % 4 == 0)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int64_t count,
                                                            int splits, int accumulate) {
@@ -543,12 +773,63 @@ static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
 
 static WgradPlan plan_wgrad_gemm(const stp_wgrad_params* p);
 
+// ---- row-of-taps kernel (conv_wgrad_row_kernel): eligibility and plan ------------------------------------------------------
+#define WG_TILE_ROW128 5
+#define WG_TILE_ROW64 6
+static bool wgrad_row_eligible(const stp_wgrad_params* p) {
+  if (!p || p->dtype != STP_BF16 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || (p->C0 & 63) || (p->C1 & 63) ||
+      p->Ho != p->Hv || p->Wo != p->Wv || (p->Cout & 7) || p->src_bn_mean)
+    return false;
+  if (p->src0_mode == STP_SRC_DIRECT ? (p->Hs0 != p->Hv || p->Ws0 != p->Wv)
+                                     : (p->src0_mode != STP_SRC_NEAREST2X || p->Hv != 2 * p->Hs0 || p->Wv != 2 * p->Ws0))
+    return false;
+  const int hw = p->Ho * p->Wo;
+  return (p->Wo % 64 == 0) || (p->Wo >= 16 && 64 % p->Wo == 0 && hw % 64 == 0);
+}
+static bool wgrad_row_auto(const stp_wgrad_params* p) {
+  static const bool on = !(getenv("STP_WGRAD_ROW") && atoi(getenv("STP_WGRAD_ROW")) == 0);
+  return on && p->splits == 0 && wgrad_row_eligible(p);
+}
+static WgradPlan plan_wgrad_row(const stp_wgrad_params* p) {
+  WgradPlan w;
+  w.bm = p->Cout <= 64 ? 64 : 128; w.bn = 192;
+  w.tile = w.bm == 64 ? WG_TILE_ROW64 : WG_TILE_ROW128;
+  w.ntile_m = ceil_div(p->Cout, w.bm);
+  w.ntile_n = 3 * ((p->C0 + p->C1) / 64);
+  const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
+  w.nsteps = (int)(P / 64);
+  const int tiles = w.ntile_m * w.ntile_n;
+  int splits = p->splits;
+  if (splits <= 0) {
+    static const int cus = device_cu_count();
+    static const int target = getenv("STP_WGRAD_ROW_BLOCKS") ? atoi(getenv("STP_WGRAD_ROW_BLOCKS")) : 0;
+    const int slots = target > 0 ? target : cus * (w.bm == 64 ? 3 : 2);   // co-resident workgroups (LDS: 40 / 56 KB each)
+    splits = slots / tiles;
+    if (splits < 1) splits = 1;
+    const int max_by_steps = w.nsteps / 8 > 0 ? w.nsteps / 8 : 1;
+    if (splits > max_by_steps) splits = max_by_steps;
+    if (splits > 512) splits = 512;
+  }
+  if (splits > w.nsteps) splits = w.nsteps;
+  if (splits < 1) splits = 1;
+  w.steps_per_split = ceil_div(w.nsteps, splits);
+  w.splits = ceil_div(w.nsteps, w.steps_per_split);
+  return w;
+}
+
 // enough for either kernel family (the automatic choice and the forced GEMM variants)
 extern "C" size_t stp_conv2d_wgrad_workspace_bytes(const stp_wgrad_params* p) {
   if (!p) return 0;
   const WgradPlan w = plan_wgrad(p), g = plan_wgrad_gemm(p);
   const size_t K = (size_t)p->KH * p->KW * (p->C0 + p->C1);
-  return (size_t)(w.splits > g.splits ? w.splits : g.splits) * p->Cout * K * sizeof(float);
+  int splits = w.splits > g.splits ? w.splits : g.splits;
+  size_t bytes = (size_t)splits * p->Cout * K * sizeof(float);
+  if (wgrad_row_eligible(p)) {
+    const WgradPlan r = plan_wgrad_row(p);
+    const size_t rb = (size_t)r.splits * r.ntile_m * r.ntile_n * r.bm * 192 * sizeof(float);   // fragment-major, whole tiles
+    if (rb > bytes) bytes = rb;
+  }
+  return bytes;
 }
 
 template <typename K>
@@ -680,6 +961,13 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
   return STP_OK;
 }
 
+extern "C" int stp_conv2d_wgrad_kernel_id(const stp_wgrad_params* p) {
+  if (!p) return 0;
+  if (p->splits == 0 && stp_wgrad_sc_eligible(p)) return 1;
+  if (wgrad_row_auto(p)) return p->Cout <= 64 ? 3 : 2;
+  return 0;
+}
+
 // Phase 1: per-split partial sums into the workspace slabs.  `variant` as in launch_wgrad_tile.
 extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, int32_t variant,
                                         void* stream) {
@@ -694,6 +982,21 @@ extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspa
   const int rc = wgrad_fill(p, workspace, workspace_bytes, a, w, &c4, &dma);
   if (rc != STP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (variant == 4 || (variant == 0 && wgrad_row_auto(p))) {   // row-of-taps kernel
+    if (!wgrad_row_eligible(p) || !dma) return STP_E_BADARG;
+    w = plan_wgrad_row(p);
+    a.ntile_m = w.ntile_m; a.ntile_n = w.ntile_n; a.steps_per_split = w.steps_per_split; a.nsteps = w.nsteps;
+    a.xcd = w.ntile_m == 1;
+    static const int stages = getenv("STP_WGRAD_ROW_STAGES") ? atoi(getenv("STP_WGRAD_ROW_STAGES")) : 3;
+    const size_t lds = (size_t)(stages == 2 ? 2 : 3) * (64 * w.bm * 2 + 72 * 128);    // 25 / 17 KB per stage
+    static bool attr128 = false, attr64 = false, attr_dummy = true;
+    if (stages == 2) {
+      if (w.tile == WG_TILE_ROW128) return launch_wg(conv_wgrad_row_kernel<128, 2, 2, 2>, a, lds, w.splits, attr_dummy, s);
+      return launch_wg(conv_wgrad_row_kernel<64, 1, 4, 2>, a, lds, w.splits, attr_dummy, s);
+    }
+    if (w.tile == WG_TILE_ROW128) return launch_wg(conv_wgrad_row_kernel<128, 2, 2, 3>, a, lds, w.splits, attr128, s);
+    return launch_wg(conv_wgrad_row_kernel<64, 1, 4, 3>, a, lds, w.splits, attr64, s);
+  }
   if (p->dtype == STP_BF16)
     return c4 ? launch_wgrad_tile<bf16_t, true>(a, w, dma, variant, s) : launch_wgrad_tile<bf16_t, false>(a, w, dma, variant, s);
   return launch_wgrad_tile<float, false>(a, w, dma, variant, s);
@@ -702,9 +1005,27 @@ extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspa
 // Phase 2: dw (+)= sum over slabs, fixed order.  `variant` must be the one given to the partial launch.
 extern "C" int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* workspace, int32_t variant, void* stream) {
   if (!p || !p->dw || !workspace) return STP_E_BADARG;
+  if (variant == 4 || (variant == 0 && wgrad_row_auto(p) && !stp_wgrad_sc_eligible(p))) {
+    if (!wgrad_row_eligible(p)) return STP_E_BADARG;
+    const WgradPlan r = plan_wgrad_row(p);
+    const int64_t per_split = (int64_t)r.ntile_m * r.ntile_n * r.bm * 192 / 4;   // float4 elements
+    const int K = 9 * (p->C0 + p->C1);
+    const int sl = r.splits >= 32 ? 16 : r.splits >= 8 ? 4 : 1;
+    const dim3 grid(ceil_div(per_split, 256 / sl));
+    hipStream_t s = (hipStream_t)stream;
+    const f32x4* slabs = (const f32x4*)workspace;
+#define STP_ROW_REDUCE(BM_, WM_, WN_, SL_) \
+    hipLaunchKernelGGL((wgrad_reduce_row_kernel<BM_, WM_, WN_, SL_>), grid, dim3(256), 0, s, slabs, p->dw, per_split, r.splits, p->accumulate, \
+                       r.ntile_m, p->C0 + p->C1, p->Cout, K)
+    if (r.bm == 128) { if (sl == 16) STP_ROW_REDUCE(128, 2, 2, 16); else if (sl == 4) STP_ROW_REDUCE(128, 2, 2, 4); else STP_ROW_REDUCE(128, 2, 2, 1); }
+    else { if (sl == 16) STP_ROW_REDUCE(64, 1, 4, 16); else if (sl == 4) STP_ROW_REDUCE(64, 1, 4, 4); else STP_ROW_REDUCE(64, 1, 4, 1); }
+#undef STP_ROW_REDUCE
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
   const WgradPlan w = variant == 0 ? plan_wgrad(p) : plan_wgrad_gemm(p);
   const int64_t count = (int64_t)p->Cout * p->KH * p->KW * (p->C0 + p->C1);
-  if (w.splits >= 64 && count <= (1 << 16))
+  if ((w.splits >= 64 && count <= (1 << 16)) || (w.splits >= 32 && count <= (1 << 19)))
     hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(ceil_div(count, 64)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, p->dw, count, w.splits, p->accumulate);
   else

@@ -622,7 +622,8 @@ class Plan(object):
                     wp.dw = self._gptr(w)
                 wp.src0, wp.src1, wp.dy = x.meta.get("src_override") or x.buf.data_ptr(), (src1.buf.data_ptr() if src1 is not None else None), dy.data_ptr()
                 self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
-                                                "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp)))})
+                                                "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp))),
+                                                "kernel_id": int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp)))})
                 if padded:
                     self._emit_side(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
                                     Cinp, 0)

@@ -439,6 +439,9 @@ WGRAD_CASES = [
     (1, 16, 64, 16, 8, 3, 1, 1, 0),
     # power-of-two feature maps: the DMA kernel's uniform-row addressing (one image row / whole rows per pixel step)
     (1, 2, 128, 64, 64, 3, 1, 1, 0), (2, 16, 32, 64, 64, 3, 2, 1, 0), (1, 8, 64, 128, 136, 3, 1, 1, 2), (3, 8, 8, 64, 192, 3, 1, 1, 0),
+    # row-of-taps kernel (variant 4; automatic for bf16 when eligible): whole rows / row segments per pixel step, channel tails, splits
+    (2, 32, 32, 128, 128, 3, 1, 1, 0), (1, 16, 64, 256, 72, 3, 1, 1, 0), (2, 4, 16, 64, 40, 3, 1, 1, 0), (1, 4, 192, 64, 64, 3, 1, 1, 3),
+    (3, 16, 16, 192, 200, 3, 1, 1, 0),
 ]
 
 
@@ -468,10 +471,23 @@ def test_conv2d_weight_gradient(ops, dtype, case):
         ops.conv2d_wgrad_partial(W, ws, variant)
         ops.conv2d_wgrad_reduce(W, ws, variant)
         np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype), err_msg="variant %d" % variant)
+    # variant 4 = row-of-taps kernel: runs on its shapes (bf16), refuses the others
+    row_ok = (dtype == "bf16" and k == 3 and s == 1 and p == 1 and ci % 64 == 0 and co % 8 == 0 and
+              (w % 64 == 0 or (w >= 16 and 64 % w == 0 and (h * w) % 64 == 0)))
+    dw.fill_(float("nan"))
+    if row_ok:
+        ops.conv2d_wgrad_partial(W, ws, 4)
+        ops.conv2d_wgrad_reduce(W, ws, 4)
+        np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype), err_msg="variant 4")
+        assert ops._lib.load().stp_conv2d_wgrad_kernel_id(ops.C.byref(W)) == ((3 if co <= 64 else 2) if splits == 0 else 0)
+    else:
+        with pytest.raises(Exception):
+            ops.conv2d_wgrad_partial(W, ws, 4)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("chans", [(32, 16, 64), (64, 64, 32), (32, 16, 16), (128, 64, 64, 8, 8), (64, 64, 128, 4, 32)])
+@pytest.mark.parametrize("chans", [(32, 16, 64), (64, 64, 32), (32, 16, 16), (128, 64, 64, 8, 8), (64, 64, 128, 4, 32), (128, 128, 136, 8, 16),
+                                   (64, 192, 72, 16, 64)])
 def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
     rng = np.random.RandomState(9)
     n, h, w = 2, 6, 7
@@ -491,6 +507,15 @@ def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
     ws = torch.empty(ops.wgrad_workspace_bytes(W) // 4 + 4, dtype=torch.float32, device=DEV)
     ops.conv2d_wgrad(W, ws)
     np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
+    # the 64-channel-block shapes on power-of-two maps take the row-of-taps kernel in bf16 (two sources, the first upsampled)
+    wo, howo = 2 * w, 4 * h * w
+    row = dtype == "bf16" and c0 % 64 == 0 and c1 % 64 == 0 and (wo % 64 == 0 or (wo >= 16 and 64 % wo == 0 and howo % 64 == 0))
+    lib = ops._lib.load()
+    assert lib.stp_conv2d_wgrad_kernel_id(ops.C.byref(W)) == (1 if lib.stp_wgrad_sc_eligible(ops.C.byref(W)) else (3 if co <= 64 else 2) if row else 0)
+    if row:
+        dw.fill_(float("nan"))
+        ops.conv2d_wgrad_partial(W, ws, 2); ops.conv2d_wgrad_reduce(W, ws, 2)      # the pixel-reduction GEMM on the same shape
+        np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
