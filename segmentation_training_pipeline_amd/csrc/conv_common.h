@@ -22,7 +22,28 @@ struct ConvArgs {
   BnBack bnb;    // bnb.x != NULL: stats are the BatchNormalization-backward sums and dst receives the masked gradient
   BnBack pbn;    // pbn.mean != NULL (halo kernel): src0 is the tensor BEFORE a BatchNormalization(+activation), normalised in LDS
   FastDiv divC, divKW, divHoWo, divWo, divNtm;   // magic-number division: a runtime integer divide costs ~30 VALU instructions
+  // zperm (uniform-tap buffer-DMA kernel, zero-inserted source = data gradient of a stride-2 convolution): the logical pixel order
+  // is PARITY-CLASS major - class c = (ho & 1) * 2 + (wo & 1), then (n, ho >> 1, wo >> 1) - so every pixel of a tile meets the
+  // zero-inserted grid the same way and the K loop visits only the taps that hit real samples (1, 2, 2 or 4 of 9; 1 or 0 of 1)
+  int zperm, zPc, zH2W2, zW2, zcpt;              // pixels per class, (Ho/2)*(Wo/2), Wo/2, K-tiles per tap
+  FastDiv divPc, divH2W2, divW2, divCpt;
 };
+
+// logical (parity-class major) pixel -> n, ho, wo
+__device__ __forceinline__ void zperm_decode(const ConvArgs& a, int pl, int& n, int& ho, int& wo) {
+  const int c = (int)fdiv((uint32_t)pl, a.divPc);
+  const int q = pl - c * a.zPc;
+  n = (int)fdiv((uint32_t)q, a.divH2W2);
+  const int rem = q - n * a.zH2W2;
+  const int y2 = (int)fdiv((uint32_t)rem, a.divW2);
+  ho = 2 * y2 + (c >> 1);
+  wo = 2 * (rem - y2 * a.zW2) + (c & 1);
+}
+__device__ __forceinline__ int zperm_pixel(const ConvArgs& a, int pl) {
+  int n, ho, wo;
+  zperm_decode(a, pl, n, ho, wo);
+  return (n * a.Ho + ho) * a.Wo + wo;
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -260,6 +281,7 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   const int64_t bw = (int64_t)a.wrows * a.K * sz;
   a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
   a.ntile_m = a.ntile_n = 0;
+  a.zperm = 0;
   a.stats = p->stats_partial;
   a.stat_slots = p->stats_slots;
   if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;

@@ -65,6 +65,18 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.bytes1 : 0u, 0x00020000);
 
+  // zperm: this tile's parity class fixes the taps that meet real samples of the zero-inserted source (all scalar)
+  const bool zp = UNI && a.zperm;
+  int zkh0 = 0, zkw0 = 0, znkw = 1, znk = 0;
+  if (zp) {
+    const int zc = (int)fdiv((uint32_t)pix0, a.divPc);
+    zkh0 = ((zc >> 1) + a.pad) & 1;                  // ho - pad + kh even  <=>  kh = zkh0 (mod 2)
+    zkw0 = ((zc & 1) + a.pad) & 1;
+    const int znkh = (a.KH - zkh0 + 1) >> 1;
+    znkw = (a.KW - zkw0 + 1) >> 1;
+    znk = znkh * znkw * a.zcpt;
+  }
+
   // per-thread pixel rows: image offsets (elements) in both sources and the top-left tap coordinate
   int hb[RB], wb[RB];
   uint32_t nof0[RB], nof1[RB];
@@ -72,10 +84,15 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   for (int i = 0; i < RB; ++i) {
     const int pm = pix0 + r0 + 32 * i;
     if (pm < a.P) {
-      const int n = (int)fdiv((uint32_t)pm, a.divHoWo);
-      const int rem = pm - n * a.HoWo;
-      const int ho = (int)fdiv((uint32_t)rem, a.divWo);
-      const int wo = rem - ho * a.Wo;
+      int n, ho, wo;
+      if (zp) {
+        zperm_decode(a, pm, n, ho, wo);
+      } else {
+        n = (int)fdiv((uint32_t)pm, a.divHoWo);
+        const int rem = pm - n * a.HoWo;
+        ho = (int)fdiv((uint32_t)rem, a.divWo);
+        wo = rem - ho * a.Wo;
+      }
       hb[i] = ho * a.stride - a.pad;
       wb[i] = wo * a.stride - a.pad;
       nof0[i] = (uint32_t)n * (uint32_t)(a.Hs0 * a.Ws0 * a.C0);
@@ -96,7 +113,12 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   auto issue_tile = [&](int kt, int buf) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + BM * 128;
-    const uint32_t k0 = (uint32_t)kt * KE;  // wave-uniform from here: scalar tap decomposition
+    uint32_t k0 = (uint32_t)kt * KE;  // wave-uniform from here: scalar tap decomposition
+    if (zp) {   // kt-th K-tile of the class: (live tap, 64-channel chunk)
+      const int tix = (int)fdiv((uint32_t)kt, a.divCpt), ch = kt - tix * a.zcpt;
+      const int ta = znkw == 2 ? tix >> 1 : tix, tb = znkw == 2 ? tix & 1 : 0;
+      k0 = (uint32_t)(((zkh0 + 2 * ta) * a.KW + zkw0 + 2 * tb) * a.Ctot + ch * KE);
+    }
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const bool act = (i * 32 + wave * 8) < BM;  // wave-uniform
@@ -158,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int lr = lane & 15, lg = lane >> 4;
 
-  const int nk = (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
+  const int nk = zp ? znk : (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
   // epilogue operands (residual or the BatchNormalization-backward x; never both) fetched now: the loads are OLDER than every
   // tile load, so the counted vmcnt waits of the K loop also cover them, and their latency hides under the whole loop
   constexpr bool PRE = SZ == 2;
@@ -171,7 +193,8 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
         const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
+          int pm = pix0 + wn * (BN / WN) + j * 16 + lr;
+          if (zp) pm = zperm_pixel(a, pm);                                      // (P is a multiple of the tile in this mode)
           const bool ok = co + 3 < a.Cout && pm < a.P;                       // others are never read; clamp keeps the load in bounds
           pre[i][j] = *reinterpret_cast<const u32x2*>(ps + (ok ? (size_t)pm * a.Cout + co : (size_t)0));
         }
@@ -198,7 +221,13 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }
-  epilogue<T, BM, BN, WM, WN, PRE>(a, cout0, pix0, wm, wn, lr, lg, acc, smem, tile_n, pre);
+  if (zp) {
+    const int pb = pix0 + wn * (BN / WN) + lr;
+    epilogue_px<T, TM, TN, BM, WN, 256, PRE>(a, cout0, wm * (BM / WM), wn, lr, lg, acc, smem, tile_n, pre,
+                                              [pb, &a](int j) { return zperm_pixel(a, pb + j * 16); });
+  } else {
+    epilogue<T, BM, BN, WM, WN, PRE>(a, cout0, pix0, wm, wn, lr, lg, acc, smem, tile_n, pre);
+  }
 #endif
 }
 
@@ -542,6 +571,19 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (c4 && tile != 2 && tile != 5) tile = 2;
   hipStream_t s = (hipStream_t)stream;
   const_cast<stp_conv_params*>(p)->stats_tiles = ceil_div(a.P, tile_pixels(tile));
+  {
+    // data gradient of a stride-2 convolution through the uniform-tap kernel: parity-class pixel order (see ConvArgs::zperm)
+    static const bool zperm_on = !(getenv("STP_ZPERM") && atoi(getenv("STP_ZPERM")) == 0);
+    const int ke = p->dtype == STP_BF16 ? 64 : 32;
+    const bool uni_tile = tile >= 64 && tile < 256;
+    if (zperm_on && a.mode == STP_SRC_ZEROINS2X && ut == 1 && uni_tile && a.stride == 1 && a.KH <= 3 && a.KW <= 3 && !(a.Ho & 1) && !(a.Wo & 1) &&
+        a.C1 == 0 && ((a.P / 4) % tile_pixels(tile)) == 0) {
+      a.zperm = 1;
+      a.zPc = a.P / 4; a.zH2W2 = (a.Ho / 2) * (a.Wo / 2); a.zW2 = a.Wo / 2; a.zcpt = a.Ctot / ke;
+      a.divPc = make_fastdiv((uint32_t)a.zPc); a.divH2W2 = make_fastdiv((uint32_t)a.zH2W2); a.divW2 = make_fastdiv((uint32_t)a.zW2);
+      a.divCpt = make_fastdiv((uint32_t)a.zcpt);
+    }
+  }
   if (p->dtype == STP_BF16) return c4 ? launch_tile<bf16_t, true>(a, tile, ut, s) : launch_tile<bf16_t, false>(a, tile, ut, s);
   return launch_tile<float, false>(a, tile, ut, s);
 }

@@ -216,6 +216,57 @@ def test_conv2d_data_gradient(ops, dtype, geom):
     np.testing.assert_allclose(host(dx), ref, atol=tol(ref, dtype))
 
 
+@pytest.mark.parametrize("geom", [(3, 1, 32, 32, 128, 64), (1, 0, 16, 64, 128, 128), (3, 1, 16, 32, 64, 256), (3, 1, 64, 16, 256, 64)])
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
+def test_stride2_data_gradient_in_parity_class_order(ops, geom, mode):
+    """Data gradient of a stride-2 convolution through the uniform-tap kernel (bf16, dY channels % 64 == 0, even maps whose quarter
+    is a multiple of the pixel tile): pixels are ordered by parity class so that the K loop visits only the taps that meet real
+    samples of the zero-inserted dY (ConvArgs::zperm).  Same results as the numpy data gradient; the epilogue (accumulate, fused
+    BatchNormalization-backward sums) must address the REAL pixel of every logical one."""
+    dtype = "bf16"
+    k, p, h, w, co, ci = geom
+    rng = np.random.RandomState(16)
+    n = 2
+    wt = q(rng.randn(k, k, ci, co) / np.sqrt(k * k * co), dtype)
+    ho, wo = (h + 2 * p - k) // 2 + 1, (w + 2 * p - k) // 2 + 1
+    dy = q(rng.randn(n, ho, wo, co), dtype)
+    ref = np_ops.conv2d_dgrad(dy, wt, (h, w), 2, p)
+    _, _, bwd, coB = prep_weights(ops, wt, dtype)
+    prev = q(rng.randn(n, h, w, ci), dtype)
+    dx = dev(prev, dtype) if mode != "plain" else torch.full((n, h, w, ci), float("nan"), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(dev(dy, dtype), bwd, dx, N=n, Hs0=ho, Ws0=wo, Hv=2 * ho - 1, Wv=2 * wo - 1, C0=coB, mode=ops.SRC_ZEROINS2X,
+                        KH=k, KW=k, stride=1, pad=k - 1 - p, Ho=h, Wo=w, Cout=ci, dtype=ops.dt(dx), accumulate0=int(mode != "plain"))
+    assert 64 <= ops._lib.load().stp_conv2d_tile_for(ops.C.byref(P)) < 256          # the uniform-tap buffer-DMA kernel
+    want = ref + (prev if mode != "plain" else 0.0)
+    if mode != "bn_backward":
+        ops.conv2d(P)
+        np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype))
+        return
+    # this data gradient completes the gradient of a BatchNormalization(+ReLU) output: masked store + the two backward sums
+    rows = n * h * w
+    x = q(rng.randn(n, h, w, ci) * 1.5 + 0.3, dtype)
+    gamma, beta = (rng.rand(ci) + 0.5).astype(np.float32), (rng.randn(ci) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd, g, b = dev(x, dtype), f(gamma), f(beta)
+    m, r = torch.empty(ci, device=DEV), torch.empty(ci, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(ci) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, ci, 1e-3, 0.99, m, r, None, None, ws)
+    P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1
+    st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    tiles = ops.conv2d_stats_floats(P) // (2 * ci)
+    pre = host(xd) * (host(r) * gamma) + (beta - host(m) * host(r) * gamma)
+    safe = np.abs(pre) > 1e-3
+    gm = want * (pre > 0)                                                       # dY under the ReLU mask
+    np.testing.assert_allclose(host(dx)[safe], gm[safe], atol=tol(want, dtype))
+    part = host(st).reshape(2, ci, tiles).sum(axis=2)
+    gs = host(dx).astype(np.float64)                                            # the sums are those of the STORED gradient
+    xhat = (host(xd).astype(np.float64) - host(m)) * host(r)
+    np.testing.assert_allclose(part[0], gs.reshape(-1, ci).sum(0), atol=2e-4 * np.abs(gs).sum(axis=(0, 1, 2)).max() + 1e-3)
+    np.testing.assert_allclose(part[1], (gs * xhat).reshape(-1, ci).sum(0), atol=2e-4 * np.abs(gs * xhat).sum(axis=(0, 1, 2)).max() + 1e-3)
+
+
 @pytest.mark.parametrize("size", [(32, 36), (64, 64), (37, 70)])
 def test_stem_halo_kernel_with_fused_statistics(ops, size):
     """conv_stem_kernel (bf16, tile id 768): the ResNet conv0 through the halo-tile kernel at even, tile-aligned and ragged / odd
