@@ -123,6 +123,9 @@ int stp_conv2d_tile_for(const stp_conv_params* p);
  * an 8x32 output tile per workgroup with the input halo tile staged once in LDS (conv_sc.hip).
  * stp_conv2d uses it automatically when stp_conv2d_sc_eligible(p) != 0 (tile id 512). */
 int stp_conv2d_sc_eligible(const stp_conv_params* p);
+/* Columns of the [stat][channel][column] partial sums the small-channel kernel writes for p (what stats_tiles will report):
+ * one per 8x32 tile, or one per persistent workgroup in the streaming form. */
+int stp_conv2d_sc_stats_tiles(const stp_conv_params* p);
 int stp_conv2d_sc(const stp_conv_params* p, void* stream);
 /* The ResNet stem (classification_models conv0: 7x7 / stride 2 / pad 3, 3+1 input channels -> 64, bf16): halo-tile kernel,
  * used by stp_conv2d automatically when eligible (tile id 768); optional fused BatchNormalization sums (stats_partial). */

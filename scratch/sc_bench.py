@@ -31,3 +31,23 @@ for name, n, h, w, ci, co, up in LAYERS:
     us = timeit(lambda: ops.conv2d(P))
     mb = (x.numel() + y.numel()) * 2 / 1e6
     print("EXP=%s %-26s %8.1f us  %6.1f MB  %5.2f TB/s" % (exp, name, us, mb, mb / us))
+# feature cost on the 16->16 @512 layer: fused producer BatchNormalization (src_bn_*), fused statistics, BN-backward epilogue
+import ctypes as C
+n, h, w, ci, co = 16, 512, 512, 16, 16
+x = torch.randn(n, h, w, ci, device=DEV).to(torch.bfloat16)
+wt = (torch.randn(16, 3, 3, ci, device=DEV) / 12).to(torch.bfloat16)
+y = torch.empty(n, h, w, co, device=DEV, dtype=torch.bfloat16)
+xb = torch.randn(n, h, w, co, device=DEV).to(torch.bfloat16)
+f32 = lambda k: torch.rand(k, device=DEV) + 0.5
+m, r, g, b = f32(16), f32(16), f32(16), f32(16)
+for feat in ("plain", "pbn", "stats", "pbn+stats", "bnb", "pbn+bnb"):
+    P = ops.conv_params(x, wt, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.BF16)
+    if "pbn" in feat:
+        P.src_bn_mean, P.src_bn_rstd, P.src_bn_gamma, P.src_bn_beta, P.src_bn_relu = ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1
+    if "stats" in feat or "bnb" in feat:
+        st = torch.empty(max(4, ops.conv2d_stats_floats(P)), device=DEV)
+        P.stats_partial = ops.ptr(st)
+    if "bnb" in feat:
+        P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(xb), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1
+    us = timeit(lambda: ops.conv2d(P))
+    print("EXP=%s 16->16 @512 %-10s %8.1f us" % (exp, feat, us))

@@ -48,6 +48,7 @@ SIGNATURES = {
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc": (i32, [C.POINTER(ConvParams), vp]),
+    "stp_conv2d_sc_stats_tiles": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stem_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stem": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_halo_variant": (i32, [C.POINTER(ConvParams)]),

@@ -499,6 +499,7 @@ static int tile_pixels(int tile) {
 
 extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream);
+extern "C" int stp_conv2d_sc_stats_tiles(const stp_conv_params* p);
 extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream);
 extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p);
@@ -539,7 +540,7 @@ extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
 extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   const int tile = stp_conv2d_tile_for(p);
   if (tile < 0) return 0;
-  if (tile == STP_TILE_SC) return (size_t)p->N * ceil_div(p->Hv, 8) * ceil_div(p->Wv, 32) * 2 * p->Cout;
+  if (tile == STP_TILE_SC) return (size_t)stp_conv2d_sc_stats_tiles(p) * 2 * p->Cout;
   if (tile == STP_TILE_STEM) return (size_t)p->N * ceil_div(p->Ho, 8) * ceil_div(p->Wo, 32) * 2 * p->Cout;
   if (tile >= STP_TILE_HALO) return (size_t)stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO) * 2 * p->Cout;
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;

@@ -120,6 +120,13 @@ struct ScEpilogue {
   ScRaw4<T> xpre[TM][4];
   BnBackCh bks[LDSK ? 1 : TM];
   const float* ktab;
+  // LDSK (persistent workgroup): the fused sums run over ALL tiles of the workgroup in these registers and are reduced once
+  // (flush_stats) into column `workgroup` of [stat][channel][workgroups]; the slot form still adds per tile
+  f32x4 ssp[LDSK ? TM : 1], qqp[LDSK ? TM : 1];
+  __device__ __forceinline__ void reset_stats() {
+#pragma unroll
+    for (int i = 0; i < (LDSK ? TM : 1); ++i) { ssp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qqp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
 
   __device__ __forceinline__ void load_constants(const ScArgs& a, int lg) {
     if (a.bnb.x) {
@@ -258,6 +265,25 @@ struct ScEpilogue {
         }
       }
     }
+    if constexpr (LDSK) {
+      if (a.stats && !a.stat_slots) {     // keep summing; flush_stats() reduces once per workgroup
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ssp[i] += ss[i]; qqp[i] += qq[i]; }
+        return;
+      }
+    }
+    reduce_stats(a, ss, qq, red, tile, ntiles, tid, wave, lr, lg);
+  }
+
+  __device__ __forceinline__ void flush_stats(const ScArgs& a, float* red, int column, int columns, int tid, int wave, int lr, int lg) {
+    if constexpr (LDSK) {
+      if (a.stats && !a.stat_slots) reduce_stats(a, ssp, qqp, red, column, columns, tid, wave, lr, lg);
+    }
+  }
+
+  template <int NS>
+  __device__ __forceinline__ void reduce_stats(const ScArgs& a, f32x4 (&ss)[NS], f32x4 (&qq)[NS], float* red, int tile, int ntiles, int tid,
+                                               int wave, int lr, int lg) {
     if (a.stats) {
       // butterfly over the 16 pixel lanes, then the 4 waves (same channels, different rows) through LDS
 #pragma unroll
@@ -393,7 +419,12 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
 // =================================================================================================
 // (second launch bound = waves per SIMD = workgroups per CU the register allocation must leave room for)
 template <typename T, int CIN, int TM>
-__global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? 4 : 3) : 2)) void conv_sc_stream_kernel(const ScArgs a) {
+#if defined(STP_EXP) && STP_EXP == 21   // what-if: 3 workgroups per CU for the 16-channel bf16 instantiations (no spill at 168 registers)
+#define SC_WPE_SMALL 3
+#else
+#define SC_WPE_SMALL 4
+#endif
+__global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? SC_WPE_SMALL : 3) : 2)) void conv_sc_stream_kernel(const ScArgs a) {
   constexpr int SZ = (int)sizeof(T);
   constexpr int VEC = Elem<T>::VEC;
   constexpr int KC = 4 * VEC;
@@ -536,34 +567,46 @@ __global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? 4 : 
     ep.finish(a, acc, red, n, y0, x0, tile, ntiles, tid, wave, lr, lg);
   };
 
+  ep.reset_stats();
   for (int tile = t_first; tile < t_end; tile += 2 * t_step) {
     body(tile, std::integral_constant<int, 0>{});
     if (tile + t_step < t_end) body(tile + t_step, std::integral_constant<int, 1>{});
   }
+  ep.flush_stats(a, red, (int)blockIdx.x, (int)gridDim.x, tid, wave, lr, lg);
 }
 
-// workgroups per CU of a streaming instantiation (registers and LDS decide), asked once
-template <typename T, int CIN, int TM>
-static int sc_stream_blocks_per_cu(size_t lds) {
-  static int cached = 0;
-  if (!cached) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_sc_stream_kernel<T, CIN, TM>, 256, lds) != hipSuccess || nb < 1) nb = 1;
-    cached = nb > 8 ? 8 : nb;
-  }
-  return cached;
+static bool sc_stream_on() {
+  static const bool on = !(getenv("STP_SC_STREAM") && atoi(getenv("STP_SC_STREAM")) == 0);
+  return on;
+}
+static int sc_cu_count() {
+  static const int cus = [] {
+    int d = 0, n = 0;
+    if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    return n;      // MI355X (also the answer on a build host without a GPU: plan sizes must not depend on where they are computed)
+  }();
+  return cus;
+}
+// workgroups of the streaming kernel: CUs x the co-resident workgroups its launch bound leaves room for, at most one per tile
+static int sc_stream_blocks(int dtype, int cin, int cout, int ntiles) {
+  const int per_cu = cout <= 16 ? (dtype == STP_BF16 && cin <= 16 ? SC_WPE_SMALL : 3) : 2;
+  const int64_t b = (int64_t)sc_cu_count() * per_cu;
+  return (int)(b < ntiles ? b : ntiles);
 }
 
 template <typename T, int CIN, int TM>
 static int launch_sc(const ScArgs& a, hipStream_t s) {
-  static const bool stream_on = !(getenv("STP_SC_STREAM") && atoi(getenv("STP_SC_STREAM")) == 0);
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
-  if (stream_on) {
+  if (sc_stream_on()) {
     constexpr int NV = SC_HH * SC_HW * (CIN / Elem<T>::VEC), NPASS = (NV + 255) / 256;
     const size_t lds = (size_t)2 * NPASS * 4096 + (4 * TM * 16 * 2 + 128 + 64) * sizeof(float);
-    static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-    int blocks = cus * sc_stream_blocks_per_cu<T, CIN, TM>(lds);      // a multiple of 8 on this machine: XCD-contiguous tile walk
-    if (blocks > ntiles) blocks = ntiles;
+    const int blocks = sc_stream_blocks(Elem<T>::DTYPE, CIN, TM * 16, ntiles);      // a multiple of 8 on this machine: XCD-contiguous tile walk
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_stream_kernel<T, CIN, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return STP_E_LAUNCH;
+      attr_set = true;
+    }
     hipLaunchKernelGGL((conv_sc_stream_kernel<T, CIN, TM>), dim3(blocks), dim3(256), lds, s, a);
     STP_LAUNCH_CHECK();
     return STP_OK;
@@ -572,6 +615,13 @@ static int launch_sc(const ScArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((conv_sc_kernel<T, CIN, TM>), dim3(ntiles), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
+}
+
+// columns of the [stat][channel][column] partial sums this kernel writes for p (one per tile; one per workgroup in streaming form)
+extern "C" int stp_conv2d_sc_stats_tiles(const stp_conv_params* p) {
+  const int ntiles = p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW);
+  if (!sc_stream_on() || p->stats_slots) return ntiles;
+  return sc_stream_blocks(p->dtype, p->C0, p->Cout <= 16 ? 16 : 32, ntiles);
 }
 
 template <typename T>
@@ -627,7 +677,7 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   if (a.pbn.mean && !a.pbn.rstd) return STP_E_BADARG;
   if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->relu)) return STP_E_BADARG;
   if (a.sum2 && ((p->Cout & 3) || (a.H & 1) || (a.W & 1) || p->bias || p->relu || (a.stats && !a.bnb.x))) return STP_E_BADARG;
-  const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
+  const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_sc_stats_tiles(p);
   hipStream_t s = (hipStream_t)stream;
   return p->dtype == STP_BF16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);
 }
