@@ -48,7 +48,7 @@ def kernel_key(name, meta, dtype):
         if tile == 768:
             return "conv_stem_kernel"
         if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows>
-            return "conv_halo_kernel<%s>" % ("16, 128, 2, 4", "8, 128, 2, 4", "16, 64, 1, 8", "8, 64, 1, 8")[tile - 1024]
+            return "conv_halo_kernel<%s>" % ("16, 128, 2, 4", "8, 128, 2, 4", "16, 64, 1, 8", "8, 64, 2, 4", "32, 64, 1, 8")[tile - 1024]
         if tile >= 256:  # buffer-DMA kernel, per-lane tap (small channel counts), 2 stages
             return "conv_igemm_ut_kernel<%s, %s, 2, false>" % (t, CONV_TILES[tile - 256])
         if tile >= 64:   # uniform-tap buffer-DMA kernel: tile = 32*STAGES + base tile

@@ -4,13 +4,13 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from segmentation_training_pipeline_amd import ops
 DEV = "cuda"
 # name, n, h, w, ci, co, [old tile ids], [halo variants]
-LAYERS = [("stage1 64->64 @128", 16, 128, 128, 64, 64, [71], [2, 3]),
+LAYERS = [("stage1 64->64 @128", 16, 128, 128, 64, 64, [71], [2, 3, 4]),
           ("stage2 128->128 @64", 16, 64, 64, 128, 128, [65], [0, 1]),
           ("stage3 256->256 @32", 16, 32, 32, 256, 256, [70], [0, 1]),
           ("stage4 512->512 @16", 16, 16, 16, 512, 512, [133], [1, 3]),
           ("dec0c2 256->256 @32", 16, 32, 32, 256, 256, [70], [1]),
           ("dec1c1d 128->384 @64", 16, 64, 64, 128, 384, [65], [0, 1]),
-          ("dec2c1d 64->192 @128", 16, 128, 128, 64, 192, [71], [0, 1, 2])]
+          ("dec2c1d 64->192 @128", 16, 128, 128, 64, 192, [71], [0, 1, 2, 4])]
 def timeit(fn, n=30):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

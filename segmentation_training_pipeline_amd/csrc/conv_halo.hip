@@ -38,6 +38,7 @@
 // Epilogue (bias, residual, ReLU, dual destination, accumulate, BatchNormalization statistics, BatchNormalization-backward
 // sums): conv_common.h, shared with conv_igemm.hip.
 #include "conv_common.h"
+#include <cstdlib>
 
 #define STP_OOB 0x80000000u
 #define HALO_NWST 4
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   typedef bf16_t T;
   constexpr int TW = 16, HWD = TW + 2, HH = TH + 2, NHP = HH * HWD;
   constexpr int NPASS = (NHP + 63) / 64;         // 64 halo pixels (8 per wave) per pass of the 512 threads
-  static_assert(NPASS <= 6, "the next slab must have landed (own pieces) when the K-step of tap 8 begins");
+  static_assert(NPASS <= 6 || TH == 32, "the next slab must have landed (own pieces) when the K-step of tap 8 begins (TH = 32: one-slab inputs only)");
   constexpr int SROWS = (NHP + 7) / 8 * 8;       // slab rows kept in LDS (8 per wave instruction; rows >= NHP are never read)
   constexpr int SLAB = SROWS * 128;
   constexpr int NWST = HALO_NWST;                // weight ring stages
@@ -468,9 +469,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
 // ================================================================================================ host side
 struct HaloCfg { int th, bm; };
 // variant ids (stp_conv_params.tile = STP_TILE_HALO + id)
-static const HaloCfg HALO_CFGS[] = {{16, 128}, {8, 128}, {16, 64}, {8, 64}};
+static const HaloCfg HALO_CFGS[] = {{16, 128}, {8, 128}, {16, 64}, {8, 64}, {32, 64}};
 #define STP_TILE_HALO 1024
-#define HALO_NCFG 4
+#define HALO_NCFG 5
 
 template <int TH, int BM, int WM, int WN, int EP>
 static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
@@ -515,6 +516,9 @@ static int halo_auto(const stp_conv_params* p) {
   const int64_t px16 = (p->Ho % 16) == 0 ? (int64_t)p->N * (p->Ho / 16) * (p->Wo / 16) : 0;
   const int64_t px8 = (int64_t)p->N * (p->Ho / 8) * (p->Wo / 16);
   if (p->C0 == 64) {   // one slab, nine K-steps: the 64-channel tiles keep one slab + the ring under 80 KB, two workgroups per CU
+    // several channel tiles over the same pixels (a data gradient into concatenated sources: 64 -> 192): 32 x 16 pixel tiles halve
+    // the weight stream per pixel (scratch/halo_bench.py: 89 -> 81 us); one channel tile: no gain (35 us either way)
+    if (p->Cout > 64 && (p->Ho % 32) == 0 && (int64_t)p->N * (p->Ho / 32) * (p->Wo / 16) * ceil_div(p->Cout, 64) >= 512) return 4;
     if (px16 * ceil_div(p->Cout, 64) >= 512) return 2;
     if (px8 * ceil_div(p->Cout, 64) >= 512) return 3;
     return -1;
@@ -530,7 +534,7 @@ extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p) {
   if (!p) return -1;
   if (p->tile >= STP_TILE_HALO && p->tile < STP_TILE_HALO + HALO_NCFG) {
     const int v = p->tile - STP_TILE_HALO;
-    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th)) return -1;
+    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && p->C0 != 64)) return -1;
     return v;
   }
   return p->tile == 0 ? halo_auto(p) : -1;
@@ -542,7 +546,7 @@ extern "C" int stp_conv2d_halo_tiles(const stp_conv_params* p, int variant) {
 }
 
 extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stream) {
-  if (variant < 0 || variant >= HALO_NCFG || !halo_shape_ok(p) || (p->Ho % HALO_CFGS[variant].th)) return STP_E_BADARG;
+  if (variant < 0 || variant >= HALO_NCFG || !halo_shape_ok(p) || (p->Ho % HALO_CFGS[variant].th) || (variant == 4 && p->C0 != 64)) return STP_E_BADARG;
   ConvArgs a;
   bool c4;
   int ut;
@@ -557,6 +561,7 @@ extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stre
     case 1: return launch_halo<8, 128, 2, 4>(a, s);    // wave: 64 channels x 2 rows
     case 2: return launch_halo<16, 64, 1, 8>(a, s);    // wave: 64 channels x 2 rows
     case 3: return launch_halo<8, 64, 2, 4>(a, s);     // wave: 32 channels x 2 rows
+    case 4: return launch_halo<32, 64, 1, 8>(a, s);    // wave: 64 channels x 4 rows; 64-channel inputs: the weights stream once per 512 pixels
     default: return STP_E_BADARG;
   }
 }

@@ -306,11 +306,12 @@ def test_stem_halo_kernel_with_fused_statistics(ops, size):
 
 
 HALO_CASES = [
-    # n, h, w, ci, co, variant (conv_halo.hip: 0 = 16x16 px x 128 ch, 1 = 8x16 x 128, 2 = 16x16 x 64, 3 = 8x16 x 64)
+    # n, h, w, ci, co, variant (conv_halo.hip: 0 = 16x16 px x 128 ch, 1 = 8x16 x 128, 2 = 16x16 x 64, 3 = 8x16 x 64, 4 = 32x16 x 64)
     (2, 16, 32, 128, 128, 0), (1, 32, 16, 64, 192, 0), (1, 16, 16, 256, 128, 0),
     (2, 8, 16, 128, 256, 1), (1, 24, 32, 64, 80, 1),
     (1, 32, 16, 64, 64, 2), (2, 16, 16, 192, 64, 2),
     (2, 8, 32, 128, 64, 3), (1, 24, 16, 512, 64, 3),
+    (1, 32, 32, 64, 64, 4), (2, 64, 16, 64, 80, 4),           # 32x16 pixels x 64 channels: 64-channel inputs only
 ]
 
 
@@ -340,7 +341,7 @@ def test_conv_halo_kernel_forward_statistics_residual(ops, case):
     ops.conv2d(mk(y2, 69))                                                   # per-tap DMA kernel, 64x64 tile
     np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
     np.testing.assert_allclose(host(y), host(y2), atol=tol(ref, dtype))
-    th = 16 if var in (0, 2) else 8
+    th = {0: 16, 1: 8, 2: 16, 3: 8, 4: 32}[var]
     tiles = ops.conv2d_stats_floats(P) // (2 * co)
     assert tiles == P.stats_tiles == n * (h // th) * (w // 16)
     rows = n * h * w
