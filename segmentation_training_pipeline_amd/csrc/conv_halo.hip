@@ -513,6 +513,10 @@ static bool halo_shape_ok(const stp_conv_params* p) {
 // cover the CUs.
 static int halo_auto(const stp_conv_params* p) {
   if (!halo_shape_ok(p)) return -1;
+  {   // experiment switch: STP_HALO_FORCE=<variant> uses that variant wherever its shape rules allow (co-residency studies)
+    static const int force = getenv("STP_HALO_FORCE") ? atoi(getenv("STP_HALO_FORCE")) : -1;
+    if (force >= 0 && force < 4 && (p->Ho % (force == 0 || force == 2 ? 16 : 8)) == 0) return force;
+  }
   const int64_t px16 = (p->Ho % 16) == 0 ? (int64_t)p->N * (p->Ho / 16) * (p->Wo / 16) : 0;
   const int64_t px8 = (int64_t)p->N * (p->Ho / 8) * (p->Wo / 16);
   if (p->C0 == 64) {   // one slab, nine K-steps: the 64-channel tiles keep one slab + the ring under 80 KB, two workgroups per CU

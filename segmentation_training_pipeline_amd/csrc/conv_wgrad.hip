@@ -32,6 +32,7 @@ struct WgradArgs {
   int rowu;  // every pixel step lies inside one image and starts on an output-row boundary pattern (see ROWU)
   uint32_t bytes0, bytes1, bytesdy;
   FastDiv divC, divKW, divHoWo, divWo;
+  BnBack pbn;   // row-of-taps kernel: src0 is the tensor BEFORE a BatchNormalization(+activation), normalised in LDS (pbn.x unused)
 };
 
 #define STP_OOB 0x80000000u  // buffer voffset beyond any descriptor -> the load returns 0
@@ -523,6 +524,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) 
     hx[i] = h - r * hw - 1;
   }
   const uint32_t pixb = (uint32_t)cs * SZ, imgb = (uint32_t)Hs * (uint32_t)Ws * pixb, cbyte = (uint32_t)cb_src * 128u + colB;
+  // fused PRODUCER BatchNormalization (+activation): the thread that DMA'd a 16-byte vector of the halo tile normalises it in LDS
+  // once it has landed (own data: its vmcnt orders the read-modify-write, the step's barrier publishes it) - same fma, activation
+  // and bf16 rounding as stp_bn_apply, so the operand equals the tensor that launch would have stored; padding stays zero
+  const bool pbn = a.pbn.mean != nullptr;
+  f32x2 psc[4], psh[4];
+  if (pbn) {
+    const int c0 = cb_src * 64 + (int)(colB >> 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float r = a.pbn.rstd[c0 + e], k = a.pbn.gamma ? r * a.pbn.gamma[c0 + e] : r;
+      psc[e >> 1][e & 1] = k;
+      psh[e >> 1][e & 1] = (a.pbn.beta ? a.pbn.beta[c0 + e] : 0.f) - a.pbn.mean[c0 + e] * k;
+    }
+  }
+  auto transform_tile = [&](int step, int buf) {
+    char* sb = smem + buf * STAGE + PK * ROWA;
+    const int p0 = step * PK;
+    const uint32_t n = fdiv((uint32_t)p0, a.divHoWo);
+    const uint32_t rem = (uint32_t)p0 - n * (uint32_t)a.HoWo;
+    const uint32_t ho0 = fdiv(rem, a.divWo);
+    const uint32_t wo0 = rem - ho0 * (uint32_t)a.Wo;
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      if (i * 32 + wave * 8 >= HROWS) continue;                 // wave-uniform
+      const int hv = (int)ho0 + hr[i], wv = (int)wo0 + hx[i];
+      if (!((unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv)) continue;
+      u32x4* vp = reinterpret_cast<u32x4*>(sb + (i * 256 + tid) * 16);
+      const u32x4 v = *vp;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f32x2 t = {__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u)};
+        t = __builtin_elementwise_fma(t, psc[e], psh[e]);
+        o[e] = pack_bf16x2(bn_act(t.x, a.pbn.relu), bn_act(t.y, a.pbn.relu));
+      }
+      *vp = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
 
   auto issue_tile = [&](int step, int buf) {
     const int p0 = step * PK;
@@ -616,6 +656,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) 
     } else {
       wait_vmcnt<0>();
     }
+    if (pbn) transform_tile(step0 + st, buf);
     __builtin_amdgcn_s_barrier();
 #if !defined(STP_EXP) || STP_EXP != 2
     if (st + STAGES - 1 < nst) issue_tile(step0 + st + STAGES - 1, nbuf);
@@ -778,8 +819,9 @@ static WgradPlan plan_wgrad_gemm(const stp_wgrad_params* p);
 #define WG_TILE_ROW64 6
 static bool wgrad_row_eligible(const stp_wgrad_params* p) {
   if (!p || p->dtype != STP_BF16 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || (p->C0 & 63) || (p->C1 & 63) ||
-      p->Ho != p->Hv || p->Wo != p->Wv || (p->Cout & 7) || p->src_bn_mean)
+      p->Ho != p->Hv || p->Wo != p->Wv || (p->Cout & 7))
     return false;
+  if (p->src_bn_mean && (!p->src_bn_rstd || p->C1 != 0 || p->src0_mode != STP_SRC_DIRECT)) return false;
   if (p->src0_mode == STP_SRC_DIRECT ? (p->Hs0 != p->Hv || p->Ws0 != p->Wv)
                                      : (p->src0_mode != STP_SRC_NEAREST2X || p->Hv != 2 * p->Hs0 || p->Wv != 2 * p->Ws0))
     return false;
@@ -958,6 +1000,8 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
   a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesdy = (uint32_t)(bd < lim ? bd : 0);
   *c4_out = c4;
   *dma_out = !c4 && b0 < lim && b1 < lim && bd < lim;
+  a.pbn.x = nullptr; a.pbn.mean = p->src_bn_mean; a.pbn.rstd = p->src_bn_rstd; a.pbn.gamma = p->src_bn_gamma; a.pbn.beta = p->src_bn_beta;
+  a.pbn.relu = p->src_bn_relu;
   return STP_OK;
 }
 
@@ -975,8 +1019,8 @@ extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspa
     if (!workspace || stp_conv2d_wgrad_workspace_bytes(p) > workspace_bytes) return STP_E_WORKSPACE;
     return stp_wgrad_sc_partial(p, workspace, stream);
   }
-  if (p && p->src_bn_mean) return STP_E_BADARG;   // fused producer BatchNormalization: small-channel kernel only
-  WgradArgs a;
+  if (p && p->src_bn_mean && !(variant == 4 || (variant == 0 && wgrad_row_auto(p)))) return STP_E_BADARG;   // fused producer BatchNormalization:
+  WgradArgs a;                                                                                              // small-channel and row-of-taps kernels only
   WgradPlan w;
   bool c4, dma;
   const int rc = wgrad_fill(p, workspace, workspace_bytes, a, w, &c4, &dma);

@@ -277,10 +277,10 @@ class Plan(object):
 
         * every consumer is a small-channel convolution (conv_sc.hip: forward AND weight gradient normalise the pre-BN tensor
           while staging it): the stp_bn_apply launch is dropped; ``tensor(name)`` still materialises the tensor on demand;
-        * some consumers are halo-kernel convolutions (conv_halo.hip: the forward normalises the slab in LDS, but their
-          weight gradient reads the normalised tensor): the stp_bn_apply launch stays and moves to the SIDE stream - off the
-          forward's critical chain conv -> finalize -> apply -> conv; its only readers are the weight-gradient chains, which run
-          on that stream in the backward pass.
+        * some consumers are halo-kernel convolutions (conv_halo.hip: the forward normalises the slab in LDS): when every one of
+          their weight gradients runs on the row-of-taps kernel (conv_wgrad.hip normalises its halo tile the same way) the launch
+          is dropped as well; otherwise a weight gradient still reads the normalised tensor, the stp_bn_apply launch stays and
+          moves to the SIDE stream - off the forward's critical chain conv -> finalize -> apply -> conv.
 
         The data gradient and the BatchNormalization backward never read the normalised tensor."""
         drop, side = set(), set()
@@ -294,10 +294,16 @@ class Plan(object):
                 cp.src_bn_mean, cp.src_bn_rstd, cp.src_bn_gamma, cp.src_bn_beta, cp.src_bn_relu = mean, rstd, gp, beta, relu
                 if not halo:       # (with halo consumers the normalised tensor exists anyway: the weight gradient reads it)
                     wp.src_bn_mean, wp.src_bn_rstd, wp.src_bn_gamma, wp.src_bn_beta, wp.src_bn_relu = mean, rstd, gp, beta, relu
-            for cp in halo:
+            halo_full = bool(halo) and all(ok for _, _, ok in halo)      # every weight gradient fuses the BatchNormalization too
+            for cp, wp, _ in halo:
                 cp.src0 = pre
                 cp.src_bn_mean, cp.src_bn_rstd, cp.src_bn_gamma, cp.src_bn_beta, cp.src_bn_relu = mean, rstd, gp, beta, relu
-            if halo:
+                if halo_full:
+                    wp.src_bn_mean, wp.src_bn_rstd, wp.src_bn_gamma, wp.src_bn_beta, wp.src_bn_relu = mean, rstd, gp, beta, relu
+            if halo_full:
+                for cp, wp in sc:
+                    wp.src_bn_mean, wp.src_bn_rstd, wp.src_bn_gamma, wp.src_bn_beta, wp.src_bn_relu = mean, rstd, gp, beta, relu
+            if halo and not halo_full:
                 side.add(id(rec))
             else:
                 t.meta["deferred"] = rec
@@ -566,7 +572,8 @@ class Plan(object):
             x.meta["sc_consumers"].append((p, wp))       # see _fuse_bn_into_consumers
         elif (self.training and self.fuse_bn_halo and x.meta.get("apply_rec") is not None and src1 is None and not transpose and not stem
                 and not upsample and self.lib.stp_conv2d_halo_variant(C.byref(p)) >= 0):
-            x.meta["halo_consumers"].append(p)
+            # (p, wp, can the weight gradient normalise its operand itself: row-of-taps kernel - or no weight gradient at all)
+            x.meta["halo_consumers"].append((p, wp, (not w.trainable) or int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp))) in (2, 3)))
         if b is not None:
             p.bias = self._pptr(b)
         if relu:

@@ -794,6 +794,46 @@ def test_producer_batchnorm_fused_into_small_channel_staging(ops, dtype, case):
         assert _lib.load().stp_conv2d_wgrad_partial(wp1, ops.ptr(ws1), ws1.numel() * 4, 1, ops.stream()) == -1
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 1), (1, 8, 64, 64, 72, 0), (2, 32, 16, 192, 64, 2), (1, 4, 128, 64, 136, 1)])
+def test_producer_batchnorm_fused_into_row_of_taps_weight_gradient(ops, case):
+    """stp_wgrad_params.src_bn_* on the row-of-taps kernel (variant 4 / automatic): the halo tile of every pixel step is normalised
+    in LDS by the thread that fetched it.  Bit-identical to stp_bn_apply followed by the same kernel on the normalised tensor
+    (same fma, activation, rounding; padding stays zero); the pixel-reduction GEMM variants refuse the fields."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co, relu = case
+    dtype = "bf16"
+    rng = np.random.RandomState(78)
+    rows = n * h * w
+    ypre = q(rng.randn(n, h, w, ci) * 2 + 0.5, dtype)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    mean, rstd = f(ypre.reshape(-1, ci).mean(0)), f(1.0 / np.sqrt(ypre.reshape(-1, ci).var(0) + 1e-3))
+    gamma, beta = f(rng.rand(ci) + 0.5), f(rng.randn(ci) * 0.3)
+    yd = dev(ypre, dtype)
+    act = torch.empty_like(yd)
+    ops.bn_apply(yd, act, rows, ci, ci, mean, rstd, gamma, beta, relu=relu)
+    dy = dev(q(rng.randn(n, h, w, co), dtype), dtype)
+
+    def wgrad(src, fused, variant):
+        dw = torch.full((co, 3, 3, ci), float("nan"), dtype=torch.float32, device=DEV)
+        W = ops.wgrad_params(src, dy, dw, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.dt(src))
+        if fused:
+            W.src_bn_mean, W.src_bn_rstd, W.src_bn_gamma, W.src_bn_beta, W.src_bn_relu = ops.ptr(mean), ops.ptr(rstd), ops.ptr(gamma), ops.ptr(beta), relu
+        ws = torch.empty(ops.wgrad_workspace_bytes(W) // 4 + 4, dtype=torch.float32, device=DEV)
+        rc = _lib.load().stp_conv2d_wgrad_partial(ops.C.byref(W), ops.ptr(ws), ws.numel() * 4, variant, ops.stream())
+        if rc == 0:
+            ops.conv2d_wgrad_reduce(W, ws, variant)
+        return rc, host(dw), W
+
+    rc0, d0, W0 = wgrad(act, False, 4)
+    assert rc0 == 0 and _lib.load().stp_conv2d_wgrad_kernel_id(ops.C.byref(W0)) in (2, 3)
+    np.testing.assert_allclose(d0.transpose(1, 2, 3, 0), np_ops.conv2d_wgrad(host(act), host(dy), (3, 3), 1, 1), atol=tol(d0, dtype))
+    for variant in (4, 0):
+        rc1, d1, _ = wgrad(yd, True, variant)
+        assert rc1 == 0
+        np.testing.assert_array_equal(d1, d0)
+    assert wgrad(yd, True, 2)[0] == -1                                      # the GEMM variants have no fused producer BN
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
 def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
