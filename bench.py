@@ -47,7 +47,7 @@ def kernel_key(name, meta, dtype):
             return "conv_sc_kernel<%s>" % t
         if tile == 768:
             return "conv_stem_kernel"
-        if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows>
+        if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows> (the profiler's name carries the epilogue variant as a 5th argument)
             return "conv_halo_kernel<%s>" % ("16, 128, 2, 4", "8, 128, 2, 4", "16, 64, 1, 8", "8, 64, 2, 4", "32, 64, 1, 8")[tile - 1024]
         if tile >= 256:  # buffer-DMA kernel, per-lane tap (small channel counts), 2 stages
             return "conv_igemm_ut_kernel<%s, %s, 2, false>" % (t, CONV_TILES[tile - 256])
@@ -59,7 +59,7 @@ def kernel_key(name, meta, dtype):
         if meta.get("sc"):
             return "conv_sc_wgrad_kernel<%s>" % t
         if meta.get("kernel_id") in (2, 3):   # row-of-taps kernel (conv_wgrad.hip): <output channels per workgroup, waves over channels x columns>
-            return "conv_wgrad_row_kernel<%s>" % ("128, 2, 2" if meta["kernel_id"] == 2 else "64, 1, 4")
+            return "conv_wgrad_row_kernel<%s, %s>" % ("128, 2, 2" if meta["kernel_id"] == 2 else "64, 1, 4", os.environ.get("STP_WGRAD_ROW_STAGES", "3"))
         if dtype == "bf16" and meta["layer"] == "conv0":
             return "conv_wgrad_kernel<%s, %s, true>" % (t, wgrad_tile(meta["cout"]))
         if dtype == "fp32" and meta["cout"] <= 32:
