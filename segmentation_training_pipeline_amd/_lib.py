@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libstp_hip.so")
+LIB_PATH = os.environ.get("STP_LIB") or os.path.join(HERE, "libstp_hip.so")   # STP_LIB: another build of the same library (A/B and what-if runs)
 
 F32, BF16, U8 = 0, 1, 2
 SRC_DIRECT, SRC_NEAREST2X, SRC_ZEROINS2X = 0, 1, 2

@@ -297,19 +297,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
 __global__ __launch_bounds__(256) void bn_apply_v8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int C,
                                                           const float* mean, const float* rstd, const float* gamma, const float* beta,
                                                           int relu) {
-  extern __shared__ float ss[];  // scale[C], shift[C]: computed once per block, then copied to this thread's registers
-  for (int cc = threadIdx.x; cc < C; cc += 256) {
-    const float r = rstd[cc], k = gamma ? r * gamma[cc] : r;
-    ss[cc] = k;
-    ss[C + cc] = (beta ? beta[cc] : 0.f) - mean[cc] * k;
-  }
-  __syncthreads();
+  // the thread fetches the constants of ITS 8 channels itself (eight 16-byte loads that hit L2, issued with the first data vectors):
+  // no LDS table, no barrier - on the 4-17 MB tensors a thread handles a few vectors and the table prologue was most of its life
   const int cg = C >> 3;
   const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;   // stride % cg == 0 (host)
   const int c = (int)(t0 % cg) * 8;
   float sc[8], sh[8];
+  {
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + c), m1 = *reinterpret_cast<const f32x4*>(mean + c + 4);
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rstd + c), r1 = *reinterpret_cast<const f32x4*>(rstd + c + 4);
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (gamma) { g0 = *reinterpret_cast<const f32x4*>(gamma + c); g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4); }
+    if (beta) { b0 = *reinterpret_cast<const f32x4*>(beta + c); b1 = *reinterpret_cast<const f32x4*>(beta + c + 4); }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = ss[c + e]; sh[e] = ss[C + c + e]; }
+    for (int e = 0; e < 8; ++e) {
+      const float r = e < 4 ? r0[e & 3] : r1[e & 3], k = gamma ? r * (e < 4 ? g0[e & 3] : g1[e & 3]) : r;
+      sc[e] = k;
+      sh[e] = (e < 4 ? b0[e & 3] : b1[e & 3]) - (e < 4 ? m0[e & 3] : m1[e & 3]) * k;
+    }
+  }
   const int64_t total = rows * cg;
   auto one = [&](const u32x4 r) {
     u32x4 o;
@@ -379,6 +385,16 @@ static int grid_for(int64_t items) {
   if (b < 1) b = 1;
   return (int)b;
 }
+// elementwise BatchNormalization passes with per-thread channel constants: at least `per_thread` vectors per thread once every CU
+// has two workgroups, so the constant set-up is amortised (a thread with one vector spends most of its life fetching constants)
+static int grid_for_amortised(int64_t items, int per_thread) {
+  int64_t b = (items + 255) / 256;
+  const int64_t lean = (items + 256 * (int64_t)per_thread - 1) / (256 * (int64_t)per_thread);
+  if (b > 512) b = lean > 512 ? lean : 512;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
 
 static int bn_apply_dispatch(const void* x, int xdt, void* y, int ydt, int64_t rows, int C, int Cy, const float* mean,
                              const float* rstd, const float* gamma, const float* beta, const float* mvar, float eps,
@@ -400,9 +416,9 @@ static int bn_apply_dispatch(const void* x, int xdt, void* y, int ydt, int64_t r
   }
   if ((C & 3) || Cy != C || xdt != ydt) return STP_E_BADARG;
   if (xdt == STP_BF16 && (C & 7) == 0 && rstd && !mvar) {
-    const int gv = grid_multiple_of(grid_for(rows * (C >> 3) / 2), C >> 3);   // ~2+ rows per thread
+    const int gv = grid_multiple_of(grid_for_amortised(rows * (C >> 3), 8), C >> 3);   // 8 vectors per thread once the CUs are covered
     if (gv > 0) {
-      hipLaunchKernelGGL(bn_apply_v8_kernel, dim3(gv), dim3(256), 2 * (size_t)C * sizeof(float), s, (const bf16_t*)x, (bf16_t*)y, rows, C, mean, rstd, gamma, beta, relu);
+      hipLaunchKernelGGL(bn_apply_v8_kernel, dim3(gv), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C, mean, rstd, gamma, beta, relu);
       STP_LAUNCH_CHECK();
       return STP_OK;
     }
@@ -564,6 +580,64 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            float inv_rows, int relu, int accumulate, const long long* slots = nullptr,
                                                            int nslots = 0, float* dgamma = nullptr, float* dbeta = nullptr) {
   extern __shared__ float ss[];  // mean, rstd, scale, shift, k1 = dbeta/M, k2 = dgamma/M   [6][C]
+  if (!slots && V == 8 && ((int64_t)gridDim.x * 256) % (C / V) == 0) {
+    // The thread keeps its 8 channels for the whole launch and fetches their constants ITSELF (twelve 16-byte loads that hit L2, one
+    // latency, issued together with the first data vectors): no LDS table, no barrier.  The table prologue - C x 6 values through
+    // LDS per workgroup, then 48 conflicting LDS reads per thread - was most of the launch on the 4-17 MB tensors of stages 2-4,
+    // where a thread handles one or two vectors (rocprofv3: 22 us for an 8 MB tensor; launch_table: 0.7-1.1 TB/s).
+    const int cg8 = C / 8;
+    const int c = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cg8) * 8;
+    float mu[8], rs[8], sc[8], sh[8], k1[8], k2[8];
+    {
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + c), m1 = *reinterpret_cast<const f32x4*>(mean + c + 4);
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(rstd + c), r1 = *reinterpret_cast<const f32x4*>(rstd + c + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + c + 4);
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(sums + C + c), q1 = *reinterpret_cast<const f32x4*>(sums + C + c + 4);
+      f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (gamma) { g0 = *reinterpret_cast<const f32x4*>(gamma + c); g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4); }
+      if (beta) { b0 = *reinterpret_cast<const f32x4*>(beta + c); b1 = *reinterpret_cast<const f32x4*>(beta + c + 4); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float m = e < 4 ? m0[e & 3] : m1[e & 3], r = e < 4 ? r0[e & 3] : r1[e & 3];
+        const float k = gamma ? r * (e < 4 ? g0[e & 3] : g1[e & 3]) : r;
+        mu[e] = m; rs[e] = r; sc[e] = k;
+        sh[e] = (e < 4 ? b0[e & 3] : b1[e & 3]) - m * k;
+        k1[e] = (e < 4 ? s0[e & 3] : s1[e & 3]) * inv_rows;
+        k2[e] = (e < 4 ? q0[e & 3] : q1[e & 3]) * inv_rows;
+      }
+    }
+    const int64_t total8 = rows * cg8, stride8 = (int64_t)gridDim.x * 256;
+    auto one8 = [&](int64_t i, const float (&xv)[V], float (&g)[V], const float (&d)[V]) {
+      float o[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        if (!bn_act_on(bn_affine(xv[e], sc[e], sh[e]), relu)) g[e] = 0.f;
+        const float xh = (xv[e] - mu[e]) * rs[e];
+        o[e] = sc[e] * (g[e] - k1[e] - xh * k2[e]);
+        if (accumulate) o[e] += d[e];
+      }
+      stv<T, V>(dx + i * V, o);
+    };
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride8 < total8; i += 2 * stride8) {          // two rows in flight per thread
+      float x0[V], g0[V], d0[V], x1[V], g1[V], d1[V];
+      ldv<T, V>(x + i * V, x0);
+      ldv<T, V>(x + (i + stride8) * V, x1);
+      ldv<T, V>(dy + i * V, g0);
+      ldv<T, V>(dy + (i + stride8) * V, g1);
+      if (accumulate) { ldv<T, V>(dx + i * V, d0); ldv<T, V>(dx + (i + stride8) * V, d1); }
+      one8(i, x0, g0, d0);
+      one8(i + stride8, x1, g1, d1);
+    }
+    for (; i < total8; i += stride8) {
+      float x0[V], g0[V], d0[V];
+      ldv<T, V>(x + i * V, x0);
+      ldv<T, V>(dy + i * V, g0);
+      if (accumulate) ldv<T, V>(dx + i * V, d0);
+      one8(i, x0, g0, d0);
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     const float r = rstd[c], sc = gamma ? r * gamma[c] : r;
     ss[c] = mean[c];
@@ -677,7 +751,7 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, blocks, C, sums, dgamma, dbeta);
   STP_LAUNCH_CHECK();
   const size_t lds2 = 6 * (size_t)C * sizeof(float);
-  const int g = grid_fixed_channels(grid_for(rows * (C / (v8 ? 8 : 4))), C / (v8 ? 8 : 4));
+  const int g = grid_fixed_channels(grid_for_amortised(rows * (C / (v8 ? 8 : 4)), 8), C / (v8 ? 8 : 4));
   const float inv_rows = (float)(1.0 / (double)rows);
   if (v8)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(g), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)dy,
@@ -722,7 +796,7 @@ extern "C" int stp_bn_backward_slots(const void* x, const void* g, void* dx, int
   hipStream_t s = (hipStream_t)stream;
   const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
   const size_t lds2 = 6 * (size_t)C * sizeof(float);
-  const int gr = grid_fixed_channels(grid_for(rows * (C / (v8 ? 8 : 4))), C / (v8 ? 8 : 4));
+  const int gr = grid_fixed_channels(grid_for_amortised(rows * (C / (v8 ? 8 : 4)), 8), C / (v8 ? 8 : 4));
   const float inv_rows = (float)(1.0 / (double)rows);
   const long long* sl = (const long long*)slots;
   if (v8)
@@ -752,7 +826,7 @@ extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int
   STP_LAUNCH_CHECK();
   const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
   const size_t lds2 = 6 * (size_t)C * sizeof(float);
-  const int gr = grid_fixed_channels(grid_for(rows * (C / (v8 ? 8 : 4))), C / (v8 ? 8 : 4));
+  const int gr = grid_fixed_channels(grid_for_amortised(rows * (C / (v8 ? 8 : 4)), 8), C / (v8 ? 8 : 4));
   const float inv_rows = (float)(1.0 / (double)rows);
   // the ReLU mask is already folded into g
   if (v8)
