@@ -833,8 +833,189 @@ struct ScWgArgs {
   int N, H, W, Hs, Ws, Cout, up;
   int tiles_x, tiles_y, ntiles;
   int ctot, coff;   // this source occupies channels [coff, coff+CIN) of the Ctot-channel concatenated input
+  uint32_t src_bytes, dy_bytes;   // buffer descriptors of the streaming kernel's LDS-DMA
   BnBack pbn;       // see stp_wgrad_params.src_bn_mean
 };
+
+// STREAMING form of conv_sc_wgrad_kernel below (the one stp_wgrad_sc_partial launches; the register-staged form stays for A/B runs,
+// STP_SC_STREAM=0): the X halo tile and the dY tile of the NEXT tile are written into the other half of a double buffer by LDS-DMA
+// (out-of-image pixels = out-of-range offset = zeros) while the current tile is multiplied; the fused producer BatchNormalization
+// normalises the staged halo vectors in LDS (same fma / activation / rounding).  Same MFMA order: bit-identical slabs.
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_sc_wgrad_stream_kernel(const ScWgArgs a) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int TMo = (COUT + 15) / 16, TNi = CIN / 16;
+  constexpr int PIXB = CIN * SZ, DYB = COUT * SZ;
+  constexpr int HALO_BYTES = SC_HH * SC_HW * PIXB;
+  static_assert(CIN % 16 == 0 && COUT % VEC == 0, "channel granularity");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][halo tile | dY tile], each padded to whole 1 KB wave pieces
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int sh = a.up ? 1 : 0;
+
+  static_assert(256 % (CIN / VEC) == 0, "a thread stages the same channel vector in every pass");
+  const bool pbn = a.pbn.mean != nullptr;
+  ScStageBn<T> sbn;
+  if (pbn) sbn.load(a.pbn, (tid % (CIN / VEC)) * VEC);
+
+  f32x4 acc[3][TMo][TNi];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < TMo; ++i)
+#pragma unroll
+      for (int j = 0; j < TNi; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: LDS-DMA into a double buffer; the tile of the NEXT iteration streams in while this one is multiplied --------
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  constexpr int VPPX = CIN / VEC, VPPD = COUT / VEC;
+  constexpr int NVX = SC_HH * SC_HW * VPPX, NPX = (NVX + 255) / 256;      // halo vectors / passes
+  constexpr int NVD = SC_TH * SC_TW * VPPD, NPD = (NVD + 255) / 256;      // dY vectors / passes
+  constexpr int XBUF = NPX * 4096, DBUF = NPD * 4096, BUF = XBUF + DBUF;  // whole 1 KB wave pieces
+  int hyx[NPX], pyx[NPD];
+#pragma unroll
+  for (int p = 0; p < NPX; ++p) {
+    const int v = p * 256 + tid, pix = v / VPPX;
+    const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+    hyx[p] = v < NVX ? (hy << 16 | hx) : -1;
+  }
+#pragma unroll
+  for (int p = 0; p < NPD; ++p) {
+    const int v = p * 256 + tid, pix = v / VPPD;
+    pyx[p] = v < NVD ? ((pix / SC_TW) << 16 | (pix % SC_TW)) : -1;
+  }
+  const uint32_t cvx = (uint32_t)(tid % VPPX) * 16u, cvd = (uint32_t)(tid % VPPD) * 16u;
+  auto decode = [&](int tile, int& n, int& y0, int& x0) {
+    int b = tile;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    n = b / a.tiles_y;
+    y0 = ty * SC_TH; x0 = tx * SC_TW;
+  };
+  auto issue_tile = [&](int tile, int bsel) -> uint32_t {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    uint32_t inside = 0;
+    char* xb = smem + bsel * BUF;
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) {
+      const int gy = y0 - 1 + (hyx[p] >> 16), gx = x0 - 1 + (hyx[p] & 0xffff);
+      const bool ok = hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const uint32_t off = ok ? (uint32_t)((n * a.Hs + (gy >> sh)) * a.Ws + (gx >> sh)) * (uint32_t)PIXB + cvx : 0x80000000u;
+      inside |= ok ? (1u << p) : 0u;
+      if (p * 256 + wave * 64 < NVX)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xb + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < NPD; ++p) {
+      const int gy = y0 + (pyx[p] >> 16), gx = x0 + (pyx[p] & 0xffff);
+      const bool ok = pyx[p] >= 0 && gy < a.H && gx < a.W;
+      const uint32_t off = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)DYB + cvd : 0x80000000u;
+      if (p * 256 + wave * 64 < NVD)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(xb + XBUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
+    }
+    return inside;
+  };
+
+  int cur = 0;
+  uint32_t inside_cur = (int)blockIdx.x < a.ntiles ? issue_tile((int)blockIdx.x, 0) : 0u;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    char* halo = smem + cur * BUF;
+    char* dyt = halo + XBUF;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own pieces of this tile have landed
+    if (pbn) {
+#pragma unroll
+      for (int p = 0; p < NPX; ++p)
+        if (inside_cur & (1u << p)) {                      // padding applies to the NORMALISED tensor
+          u32x4* vp = reinterpret_cast<u32x4*>(halo + (p * 256 + tid) * 16);
+          *vp = sbn.apply(*vp, a.pbn.relu);
+        }
+    }
+    lds_barrier();                                          // tile visible; every wave has left the previous tile's buffer
+    if (tile + (int)gridDim.x < a.ntiles) inside_cur = issue_tile(tile + (int)gridDim.x, cur ^ 1);
+    cur ^= 1;
+
+#pragma unroll 1
+    for (int row = 0; row < SC_TH; ++row) {  // one 32-pixel chunk = one tile row
+      if constexpr (sizeof(T) == 2) {
+        // lane group g owns pixels x = 4g..4g+3 (lo) and 16+4g..16+4g+3 (hi); lane i of a group addresses pixel (i>>2), quad (i&3)
+        const int xl = lg * 4 + (lr >> 2), qb = (lr & 3) * 8;
+        u32x4 fa[TMo];
+#pragma unroll
+        for (int i = 0; i < TMo; ++i) {
+          const char* p = dyt + ((row * SC_TW + xl) * COUT + i * 16) * SZ + qb;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * DYB));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int tap = wave + 4 * t;
+          if (tap < 9) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int j = 0; j < TNi; ++j) {
+              const char* p = halo + (((row + kh) * SC_HW + xl + kw) * CIN + j * 16) * SZ + qb;
+              const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+              const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * PIXB));
+              const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+              const u32x4 fb = u32x4{l2.x, l2.y, h2.x, h2.y};
+#pragma unroll
+              for (int i = 0; i < TMo; ++i)
+                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb),
+                                                                       acc[t][i][j], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        // fp32: 8 k-steps of 4 pixels; lane group g owns pixel 4s + g
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int x = s * 4 + lg;
+          float fa[TMo];
+#pragma unroll
+          for (int i = 0; i < TMo; ++i) fa[i] = *reinterpret_cast<const float*>(dyt + ((row * SC_TW + x) * COUT + i * 16 + lr) * SZ);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int tap = wave + 4 * t;
+            if (tap < 9) {
+              const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+              for (int j = 0; j < TNi; ++j) {
+                const float fb = *reinterpret_cast<const float*>(halo + (((row + kh) * SC_HW + x + kw) * CIN + j * 16 + lr) * SZ);
+#pragma unroll
+                for (int i = 0; i < TMo; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb, acc[t][i][j], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- slab: C layout row (co) = lg*4 + r, col (ci) = lr ------------------------------------------
+  float* out = a.slabs + (size_t)blockIdx.x * a.Cout * (9 * a.ctot);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap >= 9) continue;
+#pragma unroll
+    for (int i = 0; i < TMo; ++i)
+#pragma unroll
+      for (int j = 0; j < TNi; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = i * 16 + lg * 4 + r;
+          if (co < a.Cout) out[(size_t)co * (9 * a.ctot) + tap * a.ctot + a.coff + j * 16 + lr] = acc[t][i][j][r];
+        }
+  }
+}
+
 
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
@@ -995,6 +1176,20 @@ extern "C" int stp_wgrad_sc_slabs(const stp_wgrad_params* p) {
 
 template <typename T, int CIN, int COUT>
 static int launch_sc_wg(const ScWgArgs& a, int blocks, hipStream_t s) {
+  if (sc_stream_on() && a.src_bytes && a.dy_bytes) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int NPX = (SC_HH * SC_HW * (CIN / VEC) + 255) / 256, NPD = (SC_TH * SC_TW * (COUT / VEC) + 255) / 256;
+    const size_t lds = (size_t)2 * (NPX + NPD) * 4096;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_wgrad_stream_kernel<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return STP_E_LAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_sc_wgrad_stream_kernel<T, CIN, COUT>), dim3(blocks), dim3(256), lds, s, a);
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
   const size_t lds = (size_t)SC_HH * SC_HW * CIN * sizeof(T) + (size_t)SC_TH * SC_TW * COUT * sizeof(T) + 64;
   hipLaunchKernelGGL((conv_sc_wgrad_kernel<T, CIN, COUT>), dim3(blocks), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
@@ -1045,10 +1240,16 @@ extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, 
   if (a.pbn.mean && (!a.pbn.rstd || p->C1 > 0)) return STP_E_BADARG;
   const int blocks = stp_wgrad_sc_slabs(p);
   hipStream_t s = (hipStream_t)stream;
+  const uint64_t szb = p->dtype == STP_BF16 ? 2 : 4, lim = 0x80000000ull;
+  const uint64_t dyb = (uint64_t)p->N * p->Hv * p->Wv * p->Cout * szb, b0 = (uint64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * szb;
+  const uint64_t b1 = (uint64_t)p->N * p->Hv * p->Wv * p->C1 * szb;
+  a.dy_bytes = dyb < lim ? (uint32_t)dyb : 0u;      // (0 = beyond 32-bit LDS-DMA offsets: the register-staged kernel runs)
+  a.src_bytes = b0 < lim ? (uint32_t)b0 : 0u;
   a.src = (const char*)p->src0; a.Hs = p->Hs0; a.Ws = p->Ws0; a.up = p->src0_mode == STP_SRC_NEAREST2X; a.coff = 0;
   int rc = p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C0, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C0, p->Cout, blocks, s);
   if (rc != STP_OK || p->C1 == 0) return rc;
   a.pbn.mean = nullptr;
   a.src = (const char*)p->src1; a.Hs = p->Hv; a.Ws = p->Wv; a.up = 0; a.coff = p->C0;
+  a.src_bytes = b1 < lim ? (uint32_t)b1 : 0u;
   return p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C1, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C1, p->Cout, blocks, s);
 }
