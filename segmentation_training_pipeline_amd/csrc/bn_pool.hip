@@ -209,22 +209,22 @@ extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t
 __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, double inv_rows,
                                                                 double unbias, float eps, float momentum, float* mean, float* rstd,
                                                                 float* mm, float* mv) {
-  __shared__ double sh[2][256];
+  // 256 threads per channel: strided fp64 accumulation, a butterfly inside each wave, then the 4 waves through LDS (ONE barrier;
+  // the 8-round LDS tree this replaces spent the launch in barriers)
+  __shared__ double sh[2][4];
   const int c = blockIdx.x;
   const float* ps = partial + (size_t)c * tiles;
   const float* pq = partial + ((size_t)C + c) * tiles;
   double s = 0.0, q = 0.0;
   for (int t = threadIdx.x; t < tiles; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
-  sh[0][threadIdx.x] = s;
-  sh[1][threadIdx.x] = q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
-    __syncthreads();
-  }
   if (threadIdx.x != 0) return;
-  const double m = sh[0][0] * inv_rows;
-  double var = sh[1][0] * inv_rows - m * m;
+  const double S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), Q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  const double m = S * inv_rows;
+  double var = Q * inv_rows - m * m;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -769,24 +769,24 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
 // [2][C][tiles] epilogue partials -> sums (same contract as bn_bwd_finalize_kernel); one workgroup per channel
 __global__ __launch_bounds__(256) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, float* sums,
                                                                     float* dgamma, float* dbeta) {
-  __shared__ double sh[2][256];
+  // 256 threads per channel: strided fp64 accumulation, a butterfly inside each wave, then the 4 waves through LDS (ONE barrier;
+  // the 8-round LDS tree this replaces spent the launch in barriers)
+  __shared__ double sh[2][4];
   const int c = blockIdx.x;
   const float* ps = partial + (size_t)c * tiles;
   const float* pq = partial + ((size_t)C + c) * tiles;
   double s = 0.0, q = 0.0;
   for (int t = threadIdx.x; t < tiles; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
-  sh[0][threadIdx.x] = s;
-  sh[1][threadIdx.x] = q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
-    __syncthreads();
-  }
   if (threadIdx.x != 0) return;
-  sums[c] = (float)sh[0][0];
-  sums[C + c] = (float)sh[1][0];
-  if (dbeta) dbeta[c] = (float)sh[0][0];
-  if (dgamma) dgamma[c] = (float)sh[1][0];
+  const double S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), Q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  sums[c] = (float)S;
+  sums[C + c] = (float)Q;
+  if (dbeta) dbeta[c] = (float)S;
+  if (dgamma) dgamma[c] = (float)Q;
 }
 
 extern "C" int stp_bn_backward_slots(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C, const float* mean,
