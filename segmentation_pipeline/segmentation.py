@@ -98,7 +98,14 @@ class PipelineConfig(generic.GenericTaskConfig):
             s = cleaned["input_shape"]
             cleaned["input_shape"] = (s[0] // self.crops, s[1] // self.crops, s[2])
         if "input_shape" in cleaned and cleaned["input_shape"][2] > 3:
-            raise ValueError("more than 3 input channels is not available in the HIP backend yet")
+            # reference :135-153: with encoder_weights an N-channel model is built from the 3-channel pretrained one (adaptNet
+            # copies the first convolution's kernels into the wider one); without them the N-channel model is simply built.
+            # Here: 4..7 channels train from random initialisation; the pretrained-weight adaptation is not available.
+            if cleaned.get("encoder_weights"):
+                raise ValueError("encoder_weights with more than 3 input channels (N-channel weight adaptation) is not available in "
+                                 "the HIP backend: set encoder_weights: null")
+            if cleaned["input_shape"][2] > 7:
+                raise ValueError("the HIP backend takes images of up to 7 channels")
         return clazz(**cleaned)
 
     def load_model(self, fold=0, stage=-1):
@@ -120,17 +127,25 @@ class PipelineConfig(generic.GenericTaskConfig):
         return [self.load_model(f, stage) for f in folds]
 
     def _resize_to_net(self, impl, images):
-        """uint8 HxWx3 images of any size -> uint8 [n, H, W, 3] at the network shape (stp_augment_u8, identity + resize)."""
+        """uint8 HxWxC images of any size -> uint8 [n, H, W, C] at the network shape (stp_augment_u8, identity + resize)."""
         from segmentation_training_pipeline_amd import ops
         import torch
-        H, W = impl.H, impl.W
-        xs = np.zeros((len(images), H, W, 3), np.uint8)
+        H, W, ch = impl.H, impl.W, impl.in_ch
+        xs = np.zeros((len(images), H, W, ch), np.uint8)
         for i, img in enumerate(images):
+            img = np.asarray(img)
+            if img.ndim == 2:
+                img = img[:, :, None]
+            if img.shape[2] < ch:
+                if img.shape[2] != 1:
+                    raise ValueError("image has %d channels, the network expects %d" % (img.shape[2], ch))
+                img = np.repeat(img, ch, axis=2)
+            img = np.ascontiguousarray(img[:, :, :ch], dtype=np.uint8)
             h, w = img.shape[:2]
             prm = torch.from_numpy(generic.augment.identity_batch(1, h, w, (H, W))).to(impl.device)
-            src = torch.from_numpy(np.ascontiguousarray(img)).to(impl.device)
-            dst = torch.empty((1, H, W, 3), dtype=torch.uint8, device=impl.device)
-            ops.augment_u8(src, None, dst, None, prm, 1, h, w, H, W, 3)
+            src = torch.from_numpy(img).to(impl.device)
+            dst = torch.empty((1, H, W, ch), dtype=torch.uint8, device=impl.device)
+            ops.augment_u8(src, None, dst, None, prm, 1, h, w, H, W, ch)
             xs[i] = dst[0].cpu().numpy()
         return xs
 

@@ -354,14 +354,15 @@ static int grid_multiple_of(int want, int groups) {
   return g >= 1 ? g : 0;
 }
 
-// uint8 [rows][C<=4] -> TY [rows][4]; padded channels get pad_value
-template <typename TY>
+// uint8 [rows][C <= CY] -> TY [rows][CY] (CY = 4, or 8 for images of 4..7 channels); padded channels get pad_value
+template <typename TY, int CY>
 __global__ __launch_bounds__(256) void bn_apply_u8_kernel(const uint8_t* __restrict__ x, TY* __restrict__ y, int64_t rows,
                                                           int C, const float* mean, const float* rstd, const float* gamma,
                                                           const float* beta, const float* mvar, float eps, int relu,
                                                           float pad_value) {
-  float sc[4], sh[4];
-  for (int c = 0; c < 4; ++c) {
+  float sc[CY], sh[CY];
+#pragma unroll
+  for (int c = 0; c < CY; ++c) {
     if (c < C) {
       const float r = rstd ? rstd[c] : rsqrtf(mvar[c] + eps);
       sc[c] = gamma ? r * gamma[c] : r;
@@ -369,13 +370,18 @@ __global__ __launch_bounds__(256) void bn_apply_u8_kernel(const uint8_t* __restr
     } else { sc[c] = 0.f; sh[c] = pad_value; }
   }
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
-    f32x4 v;
-    for (int c = 0; c < 4; ++c) {
-      float t = c < C ? bn_affine((float)x[r * C + c], sc[c], sh[c]) : pad_value;
-      if (relu && c < C) t = bn_act(t, relu);
-      v[c] = t;
+#pragma unroll
+    for (int h = 0; h < CY / 4; ++h) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = h * 4 + e;
+        float t = c < C ? bn_affine((float)x[r * C + c], sc[c], sh[c]) : pad_value;
+        if (relu && c < C) t = bn_act(t, relu);
+        v[e] = t;
+      }
+      store4(y + r * CY + h * 4, v);
     }
-    store4(y + r * 4, v);
   }
 }
 
@@ -401,16 +407,15 @@ static int bn_apply_dispatch(const void* x, int xdt, void* y, int ydt, int64_t r
                              int relu, float pad_value, hipStream_t s) {
   if (!x || !y || !mean || rows <= 0) return STP_E_BADARG;
   if (xdt == STP_U8) {
-    if (C > 4 || Cy != 4) return STP_E_BADARG;
+    if ((Cy != 4 && Cy != 8) || C > Cy) return STP_E_BADARG;
     const int g = grid_for(rows);
-    if (ydt == STP_BF16)
-      hipLaunchKernelGGL(bn_apply_u8_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const uint8_t*)x, (bf16_t*)y, rows, C, mean,
-                         rstd, gamma, beta, mvar, eps, relu, pad_value);
-    else if (ydt == STP_F32)
-      hipLaunchKernelGGL(bn_apply_u8_kernel<float>, dim3(g), dim3(256), 0, s, (const uint8_t*)x, (float*)y, rows, C, mean,
-                         rstd, gamma, beta, mvar, eps, relu, pad_value);
-    else
-      return STP_E_BADARG;
+#define STP_APPLY_U8(TY_, CY_) \
+    hipLaunchKernelGGL((bn_apply_u8_kernel<TY_, CY_>), dim3(g), dim3(256), 0, s, (const uint8_t*)x, (TY_*)y, rows, C, mean, rstd, gamma, beta, mvar, eps, \
+                       relu, pad_value)
+    if (ydt == STP_BF16) { if (Cy == 4) STP_APPLY_U8(bf16_t, 4); else STP_APPLY_U8(bf16_t, 8); }
+    else if (ydt == STP_F32) { if (Cy == 4) STP_APPLY_U8(float, 4); else STP_APPLY_U8(float, 8); }
+    else return STP_E_BADARG;
+#undef STP_APPLY_U8
     STP_LAUNCH_CHECK();
     return STP_OK;
   }

@@ -380,14 +380,16 @@ class Plan(object):
         return t
 
     def input_bn(self, name, x, eps):
-        """BatchNormalization(scale=False) on the raw uint8 image -> dtype tensor padded to 4
-        channels whose last channel is the constant 1 (see stp_stem_beta_grad)."""
-        if x.C > 4:
-            raise StpShapeError("input_bn handles up to 4 image channels")
+        """BatchNormalization(scale=False) on the raw uint8 image -> dtype tensor padded to 4 channels (8 for images of 4..7
+        channels, reference segmentation.py:135-155 builds N-channel models) whose channel x.C is the constant 1 (see
+        stp_stem_beta_grad) and whose remaining channels are also 1 (their stem weights are zero: the unpadding drops their gradient)."""
+        if x.C > 7:
+            raise StpShapeError("input_bn handles up to 7 image channels")
+        Cp = 4 if x.C <= 3 else 8
         beta = self.param(name + "/beta", (x.C,), "beta")
         mm = self.state(name + "/moving_mean", x.C, 0.0)
         mv = self.state(name + "/moving_variance", x.C, 1.0)
-        out = self._new(name, x.H, x.W, 4, False)
+        out = self._new(name, x.H, x.W, Cp, False)
         out.meta["real_c"] = x.C
         out.meta["input_bn_beta"] = beta
         if self.dry:
@@ -397,26 +399,27 @@ class Plan(object):
             self._emit(self.fwd, "stp_bn_stats", x.buf.data_ptr(), ops.U8, x.rows, x.C, eps, self.bn_momentum,
                        mean.data_ptr(), rstd.data_ptr(), self._sptr(mm), self._sptr(mv), self.ws_bn.data_ptr(),
                        self.ws_bn.numel() * 4)
-            self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, 4,
+            self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, Cp,
                        mean.data_ptr(), rstd.data_ptr(), None, self._pptr(beta), 0, 1.0)
         else:
-            self._emit(self.fwd, "stp_bn_inference", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, 4,
+            self._emit(self.fwd, "stp_bn_inference", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, Cp,
                        self._sptr(mm), self._sptr(mv), eps, None, self._pptr(beta), 0, 1.0)
         return out
 
     def input_cast(self, name, x):
         """Raw uint8 image -> dtype tensor padded to 4 channels (zeros), no normalisation: the input of the keras.applications
         VGG encoders, which segmentation_models feeds with raw pixels (no in-graph preprocessing)."""
-        if x.C > 4:
-            raise StpShapeError("input_cast handles up to 4 image channels")
-        out = self._new(name, x.H, x.W, 4, False)
+        if x.C > 7:
+            raise StpShapeError("input_cast handles up to 7 image channels")
+        Cp = 4 if x.C <= 3 else 8
+        out = self._new(name, x.H, x.W, Cp, False)
         out.meta["real_c"] = x.C
         if self.dry:
             return out
-        zero, one = self._alloc((4,), torch.float32), self._alloc((4,), torch.float32)
+        zero, one = self._alloc((8,), torch.float32), self._alloc((8,), torch.float32)
         zero.zero_(); one.fill_(1.0)
         # y = x * 1 + 0 through the uint8 BatchNorm-apply kernel (mean 0, rstd 1, no gamma/beta), padded channel = 0
-        self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, 4,
+        self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), ops.U8, out.buf.data_ptr(), self.cdt, x.rows, x.C, Cp,
                    zero.data_ptr(), one.data_ptr(), None, None, 0, 0.0)
         return out
 
@@ -532,7 +535,7 @@ class Plan(object):
             pad = max((Ho - 1) * stride + k - Hv, 0) // 2
             if max((Wo - 1) * stride + k - Wv, 0) // 2 != pad:
                 raise StpShapeError("%s: 'same' padding differs between height and width" % name)
-        KWp = k + (k & 1) if stem else k
+        KWp = k + (k & 1) if (stem and x.C == 4) else k      # 4 padded channels: one 16-byte vector = two horizontally adjacent taps
         Cin_master = real_c0 + C1
         Cinp = C0 + C1
         w = self.param(name + "/kernel", (Cout, k, k, Cin_master), "tkernel" if transpose else "kernel")

@@ -348,10 +348,18 @@ class HostItem(object):
         self.id, self.x, self.y, self.h, self.w, self.src = ident, x, y, h, w, src
 
 
-def prepare_item(it, classes, pin):
-    """PredictionItem -> HostItem: RGB uint8 [h,w,3] and label uint8 [h,w] ({0,1} for the sigmoid head, class index for the
-    softmax head; one-hot maps are arg-maxed).  This is the CPU work per sample; everything else happens on the GPU."""
-    x = np.ascontiguousarray(np.asarray(it.x)[:, :, :3], dtype=np.uint8)
+def prepare_item(it, classes, pin, channels=3):
+    """PredictionItem -> HostItem: uint8 pixels [h,w,channels] (RGB, or the first ``channels`` <= 7 bands of an N-channel image:
+    ``shape: [H, W, C]`` in the YAML, reference segmentation.py:135-155) and label uint8 [h,w] ({0,1} for the sigmoid head, class
+    index for the softmax head; one-hot maps are arg-maxed).  This is the CPU work per sample; everything else happens on the GPU."""
+    x = np.asarray(it.x)
+    if x.ndim == 2:
+        x = x[:, :, None]
+    if x.shape[2] < channels:
+        if x.shape[2] != 1:
+            raise ValueError("item %r has %d channels, the network expects %d" % (it.id, x.shape[2], channels))
+        x = np.repeat(x, channels, axis=2)     # grey image for a multi-channel network
+    x = np.ascontiguousarray(x[:, :, :channels], dtype=np.uint8)
     if not x.flags.writeable:              # PIL-backed arrays are read-only; torch.from_numpy wants a writable buffer
         x = x.copy()
     h, w = x.shape[:2]
@@ -389,7 +397,7 @@ class HostPrefetcher(object):
     GPU trains on the current one - the replacement of the reference's imgaug worker processes + bounded queue
     (FAQ.md:15-22; ``AUGMENTER_QUEUE_LIMIT``), minus the augmentation itself, which runs on the device."""
 
-    def __init__(self, ds, indexes, batch, classes, pin, depth=2, sampler=None):
+    def __init__(self, ds, indexes, batch, classes, pin, depth=2, sampler=None, channels=3):
         """``sampler(n, h, w) -> (records, filter records)``: when given and a batch's items share one size, the thread also
         packs the batch into two pinned blocks and samples its augmentation records (HostBatch)."""
         import queue
@@ -401,7 +409,7 @@ class HostPrefetcher(object):
             h, w = items[0].h, items[0].w
             if sampler is None or any((it.h, it.w) != (h, w) for it in items):
                 return items
-            X = torch.empty((batch, h, w, 3), dtype=torch.uint8, pin_memory=pin)
+            X = torch.empty((batch, h, w, channels), dtype=torch.uint8, pin_memory=pin)
             Y = torch.empty((batch, h, w), dtype=torch.uint8, pin_memory=pin)
             xv, yv = X.numpy(), Y.numpy()
             for i in range(batch):                      # a short last batch wraps around (static plan batch)
@@ -412,7 +420,7 @@ class HostPrefetcher(object):
         def work():
             try:
                 for s in range(0, len(indexes), batch):
-                    self.q.put(pack([prepare_item(ds[int(i)], classes, False if sampler is not None else pin)
+                    self.q.put(pack([prepare_item(ds[int(i)], classes, False if sampler is not None else pin, channels)
                                      for i in indexes[s:s + batch]]))
             except BaseException as e:      # surfaced on the consumer side
                 self._err = e
@@ -436,8 +444,9 @@ class DeviceFeeder(object):
     stream (they overlap the previous step's kernels), then one ``stp_augment_u8`` launch per item on the compute stream
     that resizes to the network shape and augments when training (+ ``stp_filter_u8`` passes for neighbourhood filters)."""
 
-    def __init__(self, device, out_hw, spec, seed, classes=1):
+    def __init__(self, device, out_hw, spec, seed, classes=1, channels=3):
         self.device, self.out_hw, self.spec, self.classes = torch.device(device), out_hw, spec, int(classes)
+        self.channels = int(channels)          # image channels of the network input (3, or 4..7 for N-channel models)
         self.rng = np.random.RandomState(seed)
         self.pin = self.device.type == "cuda"
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.pin else None
@@ -450,13 +459,14 @@ class DeviceFeeder(object):
         oh, ow = self.out_hw
         if isinstance(items, HostBatch) and items.X.shape[0] == n:
             return self._feed_block(plan, items)
-        items = [it if isinstance(it, HostItem) else prepare_item(it, self.classes, self.pin) for it in items]
+        items = [it if isinstance(it, HostItem) else prepare_item(it, self.classes, self.pin, self.channels) for it in items]
+        ch = self.channels
         main = torch.cuda.current_stream()
         staged = []
         with torch.cuda.stream(self.copy_stream):
             for i in range(n):
                 it = items[i % len(items)]             # a short last batch wraps around (static plan batch)
-                xd = torch.empty((it.h, it.w, 3), dtype=torch.uint8, device=self.device)
+                xd = torch.empty((it.h, it.w, ch), dtype=torch.uint8, device=self.device)
                 yd = torch.empty((it.h, it.w), dtype=torch.uint8, device=self.device)
                 xd.copy_(it.x, non_blocking=True)
                 yd.copy_(it.y, non_blocking=True)
@@ -469,18 +479,18 @@ class DeviceFeeder(object):
             pd = torch.from_numpy(prm).to(self.device, non_blocking=True)
             self._keep += [xd, yd, pd, it]
             if filt is None:
-                ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, 3)
+                ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, ch)
                 continue
             # neighbourhood filters: augment into a staging image, then one stp_filter_u8 pass per filter (ping-pong),
             # the last one writing the plan's input buffer
             fd = torch.from_numpy(filt).to(self.device, non_blocking=True)
-            bufs = [torch.empty((oh, ow, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            bufs = [torch.empty((oh, ow, ch), dtype=torch.uint8, device=self.device) for _ in range(2)]
             self._keep += [fd] + bufs
-            ops.augment_u8(xd, yd, bufs[0], msk_buf[i], pd, 1, h, w, oh, ow, 3)
+            ops.augment_u8(xd, yd, bufs[0], msk_buf[i], pd, 1, h, w, oh, ow, ch)
             src = 0
             for ps in range(filt.shape[0]):
                 dst = img_buf[i] if ps == filt.shape[0] - 1 else bufs[1 - src]
-                ops.filter_u8(bufs[src], dst, fd[ps], 1, oh, ow, 3)
+                ops.filter_u8(bufs[src], dst, fd[ps], 1, oh, ow, ch)
                 src = 1 - src
 
 
@@ -489,6 +499,7 @@ def _feed_block(self, plan, hb):
     img_buf, msk_buf = plan.inputs["image"].buf, plan.inputs["mask"].buf
     n = img_buf.shape[0]
     oh, ow = self.out_hw
+    ch = self.channels
     main = torch.cuda.current_stream()
     with torch.cuda.stream(self.copy_stream):
         xd = torch.empty(hb.X.shape, dtype=torch.uint8, device=self.device)
@@ -502,15 +513,15 @@ def _feed_block(self, plan, hb):
     main.wait_stream(self.copy_stream)
     self._keep += [xd, yd, pd, hb]
     if fd is None:
-        ops.augment_u8(xd, yd, img_buf, msk_buf, pd, n, hb.h, hb.w, oh, ow, 3)
+        ops.augment_u8(xd, yd, img_buf, msk_buf, pd, n, hb.h, hb.w, oh, ow, ch)
         return
-    bufs = [torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
+    bufs = [torch.empty((n, oh, ow, ch), dtype=torch.uint8, device=self.device) for _ in range(2)]
     self._keep += [fd] + bufs
-    ops.augment_u8(xd, yd, bufs[0], msk_buf, pd, n, hb.h, hb.w, oh, ow, 3)
+    ops.augment_u8(xd, yd, bufs[0], msk_buf, pd, n, hb.h, hb.w, oh, ow, ch)
     src = 0
     for ps in range(hb.filt.shape[0]):
         dst = img_buf if ps == hb.filt.shape[0] - 1 else bufs[1 - src]
-        ops.filter_u8(bufs[src], dst, fd[ps], n, oh, ow, 3)
+        ops.filter_u8(bufs[src], dst, fd[ps], n, oh, ow, ch)
         src = 1 - src
 
 
@@ -537,7 +548,7 @@ class Trainer(object):
         # training thread's draws (per-item path of DeviceFeeder.feed, DrawResults) never interleave with it
         rng = np.random.RandomState(f.rng.randint(0, 2 ** 31 - 1))
         sampler = lambda n, h, w: augment.sample_batch_ex(f.spec if training else [], rng, n, h, w, oh_ow)
-        return HostPrefetcher(self.ds, [int(i) for i in indexes], batch, f.classes, f.pin, sampler=sampler)
+        return HostPrefetcher(self.ds, [int(i) for i in indexes], batch, f.classes, f.pin, sampler=sampler, channels=f.channels)
 
     def run_epoch_sums(self, indexes, training):
         """One pass over ``indexes`` -> ({log name: sum over batches of value * real samples of the batch}, real samples).
@@ -786,7 +797,7 @@ class GenericTaskConfig(object):
             impl.set_data_parallel(distributed.GradReducer())
         H, W = impl.H, impl.W                                  # = shape, or shape / crops
         feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state * 7919 + fold * 101 + si,
-                              classes=self.classes)
+                              classes=self.classes, channels=impl.in_ch)
         cbs = stage.callbacks()
         trainer = Trainer(impl, feeder, ds, cbs, rank, world)
         train_idx = kf.sampledIndexes(fold, True, stage.negatives)
@@ -865,7 +876,7 @@ class GenericTaskConfig(object):
         model = self._compiled(st)
         impl = model.impl
         H, W = impl.H, impl.W                                  # = shape, or shape / crops: the size of the plan's input buffers
-        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state, classes=self.classes)
+        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state, classes=self.classes, channels=impl.in_ch)
         trainer = Trainer(impl, feeder, d, [], 0, 1)
         nb = max(1, -(-len(idx) // impl.batch)) * int(epochs)
         finder = LRFinder(float(start_lr), float(end_lr), nb)

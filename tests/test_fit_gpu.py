@@ -248,3 +248,57 @@ def test_reference_example_experiment_deeplabv3_mobilenetv2(tmp_path):
     assert m.impl.architecture == "DeepLabV3" and "expanded_conv_16_depthwise/depthwise_kernel" in m.impl.get_weights()
     pr = m.predict(np.zeros((1, 128, 128, 3), np.uint8))
     assert pr.shape == (1, 128, 128, 1) and 0.0 <= pr.min() and pr.max() <= 1.0
+
+
+def test_four_channel_images_fit_and_predict(tmp_path):
+    """``shape: [64, 64, 4]`` with ``encoder_weights: null`` (reference segmentation.py:135-155: without pretrained weights an
+    N-channel model is simply built): 4-band items train and predict; with encoder_weights the N-channel weight adaptation is
+    refused with a clear message."""
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import PredictionItem
+    rng = np.random.RandomState(3)
+    yy, xx = np.mgrid[0:64, 0:64]
+    items = []
+    for i in range(6):
+        m = (((yy - rng.uniform(20, 44)) / rng.uniform(8, 18)) ** 2 + ((xx - rng.uniform(20, 44)) / rng.uniform(8, 18)) ** 2 <= 1)
+        img = rng.randint(0, 60, (64, 64, 4)).astype(np.uint8)
+        img[:, :, 3][m] += 180                                                   # the signal lives in the FOURTH band only
+        items.append(PredictionItem("s%d" % i, img, m[:, :, None].astype(np.uint8)))
+
+    class DS(object):
+        def __len__(self):
+            return len(items)
+
+        def __getitem__(self, i):
+            return items[i]
+
+    base = {"architecture": "Unet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid", "encoder_weights": None,
+            "shape": [64, 64, 4], "optimizer": "Adam", "lr": 0.01, "batch": 2, "folds_count": 2, "loss": "binary_crossentropy",
+            "metrics": ["binary_accuracy", "dice"], "primary_metric": "val_loss", "draw_examples": False,
+            "augmentation": {"Fliplr": 0.5}, "stages": [{"epochs": 8}]}
+    cfg_path = str(tmp_path / "config.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(base, f)
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(DS(), foldsToExecute=[0])
+    assert len(out) == 1
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        rows = list(csv.DictReader(f))
+    assert float(rows[-1]["loss"]) < float(rows[0]["loss"])
+    model = cfg.load_model(0, 0)
+    xs = cfg._resize_to_net(model.impl, [items[0].x])
+    assert xs.shape == (1, 64, 64, 4)
+    p = cfg.predict_on_batch(model, False, xs)
+    assert p.shape == (1, 64, 64, 1) and np.all(np.isfinite(p))
+    logits = lambda: model.impl._infer.tensors["final_conv"].buf.float().cpu().numpy().copy()
+    l0 = logits()
+    blind = xs.copy()
+    blind[..., 3] = 0
+    cfg.predict_on_batch(model, False, blind)
+    assert np.abs(logits() - l0).max() > 1e-3                                        # the fourth band reaches the network
+    # (16 optimizer steps: the moving statistics the inference plan normalises with have barely moved, so the maps themselves
+    #  are not asserted; tests/test_model_gpu.py::test_n_channel_inputs_match_the_oracle pins the arithmetic)
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(dict(base, encoder_weights="imagenet"), f)
+    with pytest.raises(ValueError, match="N-channel"):
+        segmentation.parse(cfg_path).createNet()

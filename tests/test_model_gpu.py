@@ -525,3 +525,40 @@ def test_freeze_encoder_and_predict_and_checkpoint(tmp_path):
     w2 = m2.get_weights()
     for k in w:
         np.testing.assert_array_equal(w[k], w2[k], err_msg=k)
+
+
+@pytest.mark.parametrize("backbone,in_ch", [("resnet18", 5), ("vgg16", 4), ("resnet18", 1)])
+def test_n_channel_inputs_match_the_oracle(backbone, in_ch):
+    """``shape: [H, W, C]`` with C != 3 (reference segmentation.py:135-155 builds N-channel models; without encoder_weights the model
+    is simply built on C channels): the raw image is padded to 4 / 8 channels behind the input BatchNormalization (ResNet) or
+    cast (VGG), the stem convolution's master kernel keeps its real (k, k, C, 64) shape.  fp32 step against the oracle at the
+    north-star bars; the bf16 mode trains."""
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    n, size = 2, 64
+    P = onets.init_unet_resnet(backbone, in_ch=in_ch, seed=42)
+    rng = np.random.RandomState(5)
+    x = rng.randint(0, 256, size=(n, size, size, in_ch)).astype(np.uint8)
+    _, y = ostep.synthetic_batch(n, size, size, seed=1234)
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=LOSS, optimizer="sgd", lr=0.05, opt_kwargs={"momentum": 0.9})
+    mk = lambda dt, g: HipSegModel("Unet", backbone, (size, size, in_ch), 1, "sigmoid", batch=n, dtype=dt, loss=LOSS, optimizer="SGD", lr=0.05,
+                                   opt_kwargs={"momentum": 0.9}, use_graph=g)
+    m = mk("fp32", False)
+    assert sorted(m.get_weights()) == sorted(P)
+    k0 = "conv0/kernel" if backbone.startswith("resnet") else "block1_conv1/kernel"
+    assert m.get_weights()[k0].shape[2] == in_ch
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5
+    g = m.get_gradients()
+    assert rel_l2(g["final_conv/kernel"], o["grads"]["final_conv/kernel"]) < 1e-4
+    assert rel_l2(g[k0], o["grads"][k0]) < 5e-2                                 # the stem's weight gradient, all C channels
+    if backbone.startswith("resnet"):
+        assert rel_l2(g["bn_data/beta"], o["grads"]["bn_data/beta"]) < 5e-2   # through the constant-1 channel of the padded input
+    mb = mk("bf16", True)
+    mb.set_weights(P)
+    l0 = mb.train_on_batch(x, y)["loss"]
+    for _ in range(5):
+        l1 = mb.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0, (l0, l1)

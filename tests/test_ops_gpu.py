@@ -887,6 +887,30 @@ def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C,Cy", [(5, 8), (4, 8), (7, 8), (1, 4)])
+def test_input_batchnorm_uint8_to_padded_channels(ops, dtype, C, Cy):
+    """uint8 images of C channels -> BatchNormalization -> dtype tensor padded to 4 / 8 channels, padding = the constant 1."""
+    rng = np.random.RandomState(21)
+    n, h, w = 2, 9, 7
+    rows = n * h * w
+    x = rng.randint(0, 256, (n, h, w, C)).astype(np.uint8)
+    beta = rng.randn(C).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd = keep(torch.from_numpy(x).to(DEV))
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(8) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, C, 2e-5, 0.99, mean, rstd, None, None, ws)
+    xf = x.reshape(-1, C).astype(np.float64)
+    np.testing.assert_allclose(host(mean), xf.mean(0), rtol=1e-5)
+    np.testing.assert_allclose(host(rstd), 1.0 / np.sqrt(xf.var(0) + 2e-5), rtol=1e-5)
+    y = torch.full((n, h, w, Cy), float("nan"), dtype=TD[dtype], device=DEV)
+    ops.bn_apply(xd, y, rows, C, Cy, mean, rstd, None, f(beta), relu=0, pad_value=1.0)
+    want = np.ones((rows, Cy))
+    want[:, :C] = (xf - xf.mean(0)) / np.sqrt(xf.var(0) + 2e-5) + beta
+    np.testing.assert_allclose(host(y).reshape(rows, Cy), want, atol=tol(want, dtype))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_input_batchnorm_uint8_to_padded4(ops, dtype):
     rng = np.random.RandomState(11)
     n, h, w = 2, 16, 18
