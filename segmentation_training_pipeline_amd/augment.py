@@ -3,9 +3,18 @@
 The reference feeds the network from imgaug worker processes (``augmentation:`` YAML list, catalogue
 ``segmentation_pipeline/schemas/augmenters.raml:43-133``, semantics README.md:247-268: a
 ``Sequential`` of augmenters applied jointly to image and mask, followed by a resize to ``shape``).
-Here the host only SAMPLES the per-image parameters (a 24-float record) and folds every geometric
-augmenter + the final resize, in the listed order, into one 2x3 output->input matrix per image; the pixels
-are moved by one HIP kernel (``stp_augment_u8``), so no CPU worker touches image data.
+Here the host only SAMPLES the per-image parameters (a 24-float record per device pass) and folds runs of geometric
+augmenters (+ the final resize) into one 2x3 output->input matrix; the pixels are moved by HIP kernels
+(``stp_augment_u8``, ``stp_filter_u8``), so no CPU worker touches image data.
+
+LISTED ORDER (imgaug ``Sequential``): a device pass is [warp, point operations in the kernel's fixed order, filters].  The
+sampler (``sample_staged``) walks the YAML list and opens a NEW pass whenever the next augmenter could not run after the
+previous ones inside the current pass (a geometric augmenter after a point operation or filter, a point operation that the
+kernel applies before one already used, a repeated point operation, a third filter); the trailing Resize to ``shape`` is
+folded into the last pass only when that pass is pure geometry, otherwise it is a pass of its own.  The common pipelines
+(geometry first, then colour, then blur, item size = network size) stay ONE pass; others cost one extra elementwise pass per
+boundary at the item's resolution.  ``sample_batch`` / ``sample_batch_ex`` (bench.py, record-layout tests) keep the merged
+single-pass form.
 
 Supported augmenters (YAML name -> effect):
   geometry (composed into the matrix): Fliplr(p), Flipud(p), Rotate90, Affine{scale, translate_percent, rotate, shear},
@@ -84,6 +93,46 @@ class SampleParams(object):
         self.h, self.w = float(new_h), float(new_w)
 
 
+# rank of an augmenter inside one device pass (the kernel's order: warp, add, mul, mul-elementwise, add-elementwise, noise,
+# dropout, grayscale, invert; then the filter kernel)
+R_GEO, R_ADD, R_MUL, R_MULE, R_ADDE, R_NOISE, R_DROP, R_GRAY, R_INVERT, R_FILTER = range(10)
+
+
+class Pipeline(object):
+    """The sampled pipeline of one image as a list of device passes.  ``strict``: honour the listed order by opening a new
+    pass where one pass cannot (module docstring); otherwise everything merges into one pass (kernel order)."""
+
+    def __init__(self, h, w, strict):
+        self.stages, self.ranks, self.strict = [SampleParams(h, w)], [R_GEO], bool(strict)
+
+    @property
+    def cur(self):
+        return self.stages[-1]
+
+    def _new(self):
+        prev = self.cur
+        self.stages.append(SampleParams(prev.h, prev.w))
+        self.ranks.append(R_GEO)
+        return self.cur
+
+    def geo(self):
+        if self.strict and self.ranks[-1] > R_GEO:
+            self._new()
+        return self.cur
+
+    def point(self, rank):
+        if self.strict and self.ranks[-1] >= rank:
+            self._new()
+        self.ranks[-1] = max(self.ranks[-1], rank)
+        return self.cur
+
+    def filt(self):
+        if self.strict and len(self.cur.filters) >= MAX_FILTERS:
+            self._new()
+        self.ranks[-1] = R_FILTER
+        return self.cur
+
+
 def _per_channel(rng, args):
     pc = _arg(args, "per_channel", False) if isinstance(args, dict) else False
     return bool(pc) if not isinstance(pc, float) else rng.uniform() < pc
@@ -93,8 +142,8 @@ def _children(args):
     return args if isinstance(args, list) else (args or {}).get("children", (args or {}).get("then_list", []))
 
 
-def _apply(spec, rng, sp):
-    """spec: list of {Name: args} (the YAML form), applied in the listed order like imgaug's Sequential."""
+def _apply(spec, rng, pl):
+    """spec: list of {Name: args} (the YAML form), applied in the listed order like imgaug's Sequential; pl: Pipeline."""
     for item in spec or []:
         if isinstance(item, str):
             name, args = item, None
@@ -104,16 +153,19 @@ def _apply(spec, rng, sp):
             p = float(args) if args is not None and not isinstance(args, dict) else float((args or {}).get("p", 1.0))
             if rng.uniform() < p:
                 if name == "Fliplr":
+                    sp = pl.geo()
                     sp.push(np.array([[-1.0, 0.0, sp.w - 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]))
                 elif name == "Flipud":
+                    sp = pl.geo()
                     sp.push(np.array([[1.0, 0.0, 0.0], [0.0, -1.0, sp.h - 1.0], [0.0, 0.0, 1.0]]))
                 else:
-                    sp.flags ^= F_INVERT
+                    pl.point(R_INVERT).flags ^= F_INVERT
         elif name == "Rotate90":
             # musket's quarter-turn augmenter as the reference YAMLs use it (examples/people/ds_1.yaml:6): a random number
             # of counter-clockwise 90 degree turns (np.rot90 convention); the canvas swaps its sides on odd counts
             if args is None or args is True or (isinstance(args, (int, float)) and rng.uniform() < float(args)):
                 for _ in range(int(rng.randint(0, 4))):
+                    sp = pl.geo()
                     sp.push(np.array([[0.0, -1.0, sp.w - 1.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]))
                     sp.h, sp.w = sp.w, sp.h
         elif name == "Affine":
@@ -126,18 +178,21 @@ def _apply(spec, rng, sp):
                 tx, ty = _rng_range(rng, tp, 0.0), _rng_range(rng, tp, 0.0)
             else:
                 tx = ty = 0.0
-            sp.affine(scale, tx, ty, _rng_range(rng, a.get("rotate"), 0.0), _rng_range(rng, a.get("shear"), 0.0))
+            pl.geo().affine(scale, tx, ty, _rng_range(rng, a.get("rotate"), 0.0), _rng_range(rng, a.get("shear"), 0.0))
         elif name == "CropToFixedSize":
+            sp = pl.geo()
             tw, th = int(_arg(args, "width")), int(_arg(args, "height"))
             nh, nw = min(sp.h, th), min(sp.w, tw)
             top, left = rng.randint(0, int(sp.h - nh) + 1), rng.randint(0, int(sp.w - nw) + 1)     # position='uniform'
             sp.window(top, left, nh, nw)
         elif name == "PadToFixedSize":
+            sp = pl.geo()
             tw, th = int(_arg(args, "width")), int(_arg(args, "height"))
             nh, nw = max(sp.h, th), max(sp.w, tw)
             top, left = rng.randint(0, int(nh - sp.h) + 1), rng.randint(0, int(nw - sp.w) + 1)
             sp.window(-top, -left, nh, nw)
         elif name in ("Pad", "CropAndPad"):
+            sp = pl.geo()
             h0, w0 = sp.h, sp.w
             if name == "Pad":
                 px = _arg(args, "px", 0)
@@ -158,45 +213,49 @@ def _apply(spec, rng, sp):
             pc = _per_channel(rng, args)
             vals = [_rng_range(rng, v, 0.0 if name == "Add" else 1.0) for _ in range(3 if pc else 1)] * (1 if pc else 3)
             if name == "Add":
-                sp.add += np.round(vals)
+                pl.point(R_ADD).add += np.round(vals)
             else:
-                sp.mul *= vals
+                pl.point(R_MUL).mul *= vals
         elif name in ("AddElementwise", "MultiplyElementwise"):
             v = _arg(args, "value" if name == "AddElementwise" else "mul")
             lo, hi = (v[0], v[1]) if isinstance(v, (list, tuple)) else (v, v)
             pc = _per_channel(rng, args)
             if name == "AddElementwise":
+                sp = pl.point(R_ADDE)
                 sp.adde = (int(round(lo)), int(round(hi)))
                 sp.flags |= F_ADDE | (F_ADDE_PC if pc else 0)
             else:
+                sp = pl.point(R_MULE)
                 sp.mule = (float(lo), float(hi))
                 sp.flags |= F_MULE | (F_MULE_PC if pc else 0)
         elif name == "AdditiveGaussianNoise":
+            sp = pl.point(R_NOISE)
             sp.noise = _rng_range(rng, _arg(args, "scale", 0.0), 0.0)
             if _per_channel(rng, args):
                 sp.flags |= F_NOISE_PC
         elif name == "Dropout":
+            sp = pl.point(R_DROP)
             sp.drop = _rng_range(rng, _arg(args, "p", 0.0), 0.0)
             if _per_channel(rng, args):
                 sp.flags |= F_DROP_PC
         elif name == "Grayscale":
-            sp.gray = _rng_range(rng, _arg(args, "alpha", 1.0), 1.0)
+            pl.point(R_GRAY).gray = _rng_range(rng, _arg(args, "alpha", 1.0), 1.0)
         elif name in ("GaussianBlur", "AverageBlur", "MedianBlur", "Sharpen", "Emboss", "EdgeDetect"):
             f = _filter(name, args, rng)
             if f is not None:
-                if len(sp.filters) >= MAX_FILTERS:
-                    raise ValueError("more than %d neighbourhood filters in one augmentation pipeline" % MAX_FILTERS)
-                sp.filters.append(f)
+                if not pl.strict and len(pl.cur.filters) >= MAX_FILTERS:
+                    raise ValueError("more than %d neighbourhood filters in one augmentation pass" % MAX_FILTERS)
+                pl.filt().filters.append(f)
         elif name == "Sequential":
-            _apply(_children(args), rng, sp)
+            _apply(_children(args), rng, pl)
         elif name == "Sometimes":
             a = args or {}
             if rng.uniform() < float(a.get("p", 0.5)):
-                _apply(a.get("then_list", []), rng, sp)
+                _apply(a.get("then_list", []), rng, pl)
         elif name == "OneOf":
             ch = _children(args)
             if ch:
-                _apply([ch[rng.randint(0, len(ch))]], rng, sp)
+                _apply([ch[rng.randint(0, len(ch))]], rng, pl)
         else:
             raise ValueError("augmenter %r is not available in the HIP augmentation stage" % name)
 
@@ -263,9 +322,10 @@ def filter_records(filters_per_image):
 
 def record(sp, out_hw, seed):
     """float32[24] record of ``stp_augment_u8`` (layout: include/stp_hip.h) for one sampled pipeline."""
-    oh, ow = out_hw
-    if (sp.h, sp.w) != (float(oh), float(ow)):
-        sp.resize(oh, ow)                      # the trailing Resize to the network shape
+    if out_hw is not None:
+        oh, ow = out_hw
+        if (sp.h, sp.w) != (float(oh), float(ow)):
+            sp.resize(oh, ow)                  # the trailing Resize to the network shape
     r = np.zeros(AUG_RECORD, np.float32)
     r[0:6] = sp.M[:2].reshape(-1)
     r[6:9], r[9:12] = sp.add, sp.mul
@@ -281,16 +341,51 @@ def record(sp, out_hw, seed):
     return r
 
 
+def _seed(sp, rng):
+    return int(rng.randint(0, 1 << 24)) if sp.flags or sp.noise or sp.drop else 0
+
+
 def sample_batch_ex(spec, rng, n, h, w, out_hw):
-    """(float32 [n,24] records for ``stp_augment_u8``, None or int32 [passes,n,173] records for ``stp_filter_u8``)."""
+    """(float32 [n,24] records for ``stp_augment_u8``, None or int32 [passes,n,173] records for ``stp_filter_u8``): the MERGED
+    single-pass form (every augmenter folded into one pass in the kernel's order; bench.py and the record-layout tests)."""
     out = np.zeros((n, AUG_RECORD), np.float32)
     filt = []
     for i in range(n):
-        sp = SampleParams(h, w)
-        _apply(spec, rng, sp)
-        out[i] = record(sp, out_hw, int(rng.randint(0, 1 << 24)) if sp.flags or sp.noise or sp.drop else 0)
+        pl = Pipeline(h, w, strict=False)
+        _apply(spec, rng, pl)
+        sp = pl.cur
+        out[i] = record(sp, out_hw, _seed(sp, rng))
         filt.append(sp.filters)
     return out, filter_records(filt)
+
+
+def sample_staged(spec, rng, h, w, out_hw):
+    """One image, listed order: [(float32[24] record, filters [(K, mode, weights)], (out_h, out_w)) per device pass]."""
+    pl = Pipeline(h, w, strict=True)
+    _apply(spec, rng, pl)
+    oh, ow = out_hw
+    last = pl.cur
+    if (last.h, last.w) != (float(oh), float(ow)) and pl.ranks[-1] > R_GEO:
+        pl._new()                                  # the trailing Resize follows point operations / filters: its own pass
+    passes = []
+    for k, sp in enumerate(pl.stages):
+        final = k == len(pl.stages) - 1
+        rec = record(sp, (oh, ow) if final else None, _seed(sp, rng))
+        passes.append((rec, sp.filters, (int(round(sp.h)), int(round(sp.w)))))
+    return passes
+
+
+def sample_batch_staged(spec, rng, n, h, w, out_hw):
+    """A batch of equally sized images in listed order -> (batch passes, per-image passes):
+    ``batch passes`` = [(records float32 [n,24], filter records int32 [f,n,173] or None, (out_h, out_w)) per device pass] when
+    every image has the same pass structure (same count, same canvas sizes: the batch kernels apply), else None and
+    ``per-image passes`` = [sample_staged(...) per image] (Sometimes / OneOf changed the structure of some images)."""
+    per = [sample_staged(spec, rng, h, w, out_hw) for _ in range(n)]
+    k = len(per[0])
+    if all(len(p) == k and all(p[j][2] == per[0][j][2] for j in range(k)) for p in per):
+        return [(np.stack([p[j][0] for p in per]).astype(np.float32), filter_records([p[j][1] for p in per]), per[0][j][2])
+                for j in range(k)], None
+    return None, per
 
 
 def sample_batch(spec, rng, n, h, w, out_hw):

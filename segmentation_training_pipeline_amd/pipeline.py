@@ -379,11 +379,12 @@ def prepare_item(it, classes, pin, channels=3):
 
 class HostBatch(object):
     """A full plan batch of equally sized items, already wrapped around to the plan's batch size: pinned pixel / label
-    blocks and the sampled augmentation records - one H2D copy and one kernel launch per block on the device side."""
-    __slots__ = ("items", "X", "Y", "prm", "filt", "h", "w")
+    blocks and the sampled augmentation passes (augment.sample_batch_staged: ``passes`` for the whole batch, or ``per_item``
+    when images differ in pass structure) - one H2D copy per block and, for one-pass pipelines, one kernel launch."""
+    __slots__ = ("items", "X", "Y", "passes", "per_item", "h", "w")
 
-    def __init__(self, items, X, Y, prm, filt, h, w):
-        self.items, self.X, self.Y, self.prm, self.filt, self.h, self.w = items, X, Y, prm, filt, h, w
+    def __init__(self, items, X, Y, passes, per_item, h, w):
+        self.items, self.X, self.Y, self.passes, self.per_item, self.h, self.w = items, X, Y, passes, per_item, h, w
 
     def __len__(self):
         return len(self.items)
@@ -398,8 +399,8 @@ class HostPrefetcher(object):
     (FAQ.md:15-22; ``AUGMENTER_QUEUE_LIMIT``), minus the augmentation itself, which runs on the device."""
 
     def __init__(self, ds, indexes, batch, classes, pin, depth=2, sampler=None, channels=3):
-        """``sampler(n, h, w) -> (records, filter records)``: when given and a batch's items share one size, the thread also
-        packs the batch into two pinned blocks and samples its augmentation records (HostBatch)."""
+        """``sampler(n, h, w) -> (batch passes, per-image passes)`` (augment.sample_batch_staged): when given and a batch's items
+        share one size, the thread also packs the batch into two pinned blocks and samples its augmentation passes (HostBatch)."""
         import queue
         import threading
         self.q = queue.Queue(maxsize=max(1, depth))
@@ -414,8 +415,8 @@ class HostPrefetcher(object):
             xv, yv = X.numpy(), Y.numpy()
             for i in range(batch):                      # a short last batch wraps around (static plan batch)
                 xv[i], yv[i] = items[i % len(items)].x.numpy(), items[i % len(items)].y.numpy()
-            prm, filt = sampler(batch, h, w)
-            return HostBatch(items, X, Y, prm, filt, h, w)
+            passes, per_item = sampler(batch, h, w)
+            return HostBatch(items, X, Y, passes, per_item, h, w)
 
         def work():
             try:
@@ -474,55 +475,61 @@ class DeviceFeeder(object):
                 staged.append((it, xd, yd))
         main.wait_stream(self.copy_stream)
         for i, (it, xd, yd) in enumerate(staged):
-            h, w = it.h, it.w
-            prm, filt = augment.sample_batch_ex(self.spec if training else [], self.rng, 1, h, w, (oh, ow))
-            pd = torch.from_numpy(prm).to(self.device, non_blocking=True)
-            self._keep += [xd, yd, pd, it]
+            passes = augment.sample_staged(self.spec if training else [], self.rng, it.h, it.w, (oh, ow))
+            self._keep += [xd, yd, it]
+            self._run_passes(xd, yd, img_buf[i], msk_buf[i], [(p[0][None], augment.filter_records([p[1]]), p[2]) for p in passes],
+                             1, it.h, it.w)
+
+    def _run_passes(self, x, y, img_out, msk_out, passes, n, h, w):
+        """Executes the device passes of a sampled pipeline (augment.sample_staged / sample_batch_staged) on ``n`` images of
+        ``h`` x ``w``: per pass one ``stp_augment_u8`` launch (warp + point operations, image and mask) and one ``stp_filter_u8``
+        launch per neighbourhood filter (ping-pong buffers); the last launch writes the plan's input buffers."""
+        ch = self.channels
+        lead = (n,) if x.dim() == 4 else ()
+        for k, (prm, filt, (ph, pw)) in enumerate(passes):
+            final = k == len(passes) - 1
+            pd = torch.from_numpy(np.ascontiguousarray(prm, dtype=np.float32)).to(self.device, non_blocking=True)
+            ydst = msk_out if final else torch.empty(lead + (ph, pw), dtype=torch.uint8, device=self.device)
+            self._keep += [pd, ydst]
             if filt is None:
-                ops.augment_u8(xd, yd, img_buf[i], msk_buf[i], pd, 1, h, w, oh, ow, ch)
-                continue
-            # neighbourhood filters: augment into a staging image, then one stp_filter_u8 pass per filter (ping-pong),
-            # the last one writing the plan's input buffer
-            fd = torch.from_numpy(filt).to(self.device, non_blocking=True)
-            bufs = [torch.empty((oh, ow, ch), dtype=torch.uint8, device=self.device) for _ in range(2)]
-            self._keep += [fd] + bufs
-            ops.augment_u8(xd, yd, bufs[0], msk_buf[i], pd, 1, h, w, oh, ow, ch)
-            src = 0
-            for ps in range(filt.shape[0]):
-                dst = img_buf[i] if ps == filt.shape[0] - 1 else bufs[1 - src]
-                ops.filter_u8(bufs[src], dst, fd[ps], 1, oh, ow, ch)
-                src = 1 - src
+                xdst = img_out if final else torch.empty(lead + (ph, pw, ch), dtype=torch.uint8, device=self.device)
+                self._keep.append(xdst)
+                ops.augment_u8(x, y, xdst, ydst, pd, n, h, w, ph, pw, ch)
+            else:
+                fd = torch.from_numpy(filt).to(self.device, non_blocking=True)
+                bufs = [torch.empty(lead + (ph, pw, ch), dtype=torch.uint8, device=self.device) for _ in range(2)]
+                self._keep += [fd] + bufs
+                ops.augment_u8(x, y, bufs[0], ydst, pd, n, h, w, ph, pw, ch)
+                src = 0
+                for ps in range(filt.shape[0]):
+                    last_f = ps == filt.shape[0] - 1
+                    dst = img_out if (final and last_f) else bufs[1 - src]
+                    ops.filter_u8(bufs[src], dst, fd[ps], n, ph, pw, ch)
+                    src = 1 - src
+                xdst = img_out if final else bufs[src]
+            x, y, h, w = xdst, ydst, ph, pw
 
 
 def _feed_block(self, plan, hb):
-    """Equal-size batch: two H2D copies (pixels, labels) on the copy stream, one ``stp_augment_u8`` launch for the batch."""
+    """Equal-size batch: two H2D copies (pixels, labels) on the copy stream, then the batch's device passes (one
+    ``stp_augment_u8`` launch for the common one-pass pipelines); images whose pass structure differs run one by one."""
     img_buf, msk_buf = plan.inputs["image"].buf, plan.inputs["mask"].buf
     n = img_buf.shape[0]
-    oh, ow = self.out_hw
-    ch = self.channels
     main = torch.cuda.current_stream()
     with torch.cuda.stream(self.copy_stream):
         xd = torch.empty(hb.X.shape, dtype=torch.uint8, device=self.device)
         yd = torch.empty(hb.Y.shape, dtype=torch.uint8, device=self.device)
         xd.copy_(hb.X, non_blocking=True)
         yd.copy_(hb.Y, non_blocking=True)
-        pd = torch.from_numpy(hb.prm).to(self.device, non_blocking=True)
-        fd = torch.from_numpy(hb.filt).to(self.device, non_blocking=True) if hb.filt is not None else None
-        for t in (xd, yd, pd) + ((fd,) if fd is not None else ()):
-            t.record_stream(main)
+        xd.record_stream(main); yd.record_stream(main)
     main.wait_stream(self.copy_stream)
-    self._keep += [xd, yd, pd, hb]
-    if fd is None:
-        ops.augment_u8(xd, yd, img_buf, msk_buf, pd, n, hb.h, hb.w, oh, ow, ch)
+    self._keep += [xd, yd, hb]
+    if hb.passes is not None:
+        self._run_passes(xd, yd, img_buf, msk_buf, hb.passes, n, hb.h, hb.w)
         return
-    bufs = [torch.empty((n, oh, ow, ch), dtype=torch.uint8, device=self.device) for _ in range(2)]
-    self._keep += [fd] + bufs
-    ops.augment_u8(xd, yd, bufs[0], msk_buf, pd, n, hb.h, hb.w, oh, ow, ch)
-    src = 0
-    for ps in range(hb.filt.shape[0]):
-        dst = img_buf if ps == hb.filt.shape[0] - 1 else bufs[1 - src]
-        ops.filter_u8(bufs[src], dst, fd[ps], n, oh, ow, ch)
-        src = 1 - src
+    for i, item_passes in enumerate(hb.per_item):
+        self._run_passes(xd[i], yd[i], img_buf[i], msk_buf[i], [(p[0][None], augment.filter_records([p[1]]), p[2]) for p in item_passes],
+                         1, hb.h, hb.w)
 
 
 DeviceFeeder._feed_block = _feed_block
@@ -547,7 +554,7 @@ class Trainer(object):
         # the loader thread samples the augmentation records: it gets its OWN generator (seeded from the feeder's), so the
         # training thread's draws (per-item path of DeviceFeeder.feed, DrawResults) never interleave with it
         rng = np.random.RandomState(f.rng.randint(0, 2 ** 31 - 1))
-        sampler = lambda n, h, w: augment.sample_batch_ex(f.spec if training else [], rng, n, h, w, oh_ow)
+        sampler = lambda n, h, w: augment.sample_batch_staged(f.spec if training else [], rng, n, h, w, oh_ow)
         return HostPrefetcher(self.ds, [int(i) for i in indexes], batch, f.classes, f.pin, sampler=sampler, channels=f.channels)
 
     def run_epoch_sums(self, indexes, training):

@@ -191,6 +191,40 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
 
 
+def test_augmentation_passes_follow_the_listed_order():
+    """imgaug Sequential semantics (README.md:247-268): augmenters apply in the YAML order.  One device pass = [warp, point
+    operations in the kernel's order, filters]; the sampler opens a new pass exactly where the listed order needs it."""
+    rng = np.random.RandomState(4)
+    stage = lambda spec, h=40, w=52, out=(40, 52): augment.sample_staged(spec, rng, h, w, out)
+    # the common shape (geometry, colour, blur; item size = network size): ONE pass, identical to the merged record
+    one = stage([{"Fliplr": 1.0}, {"Affine": {"rotate": 10}}, {"Add": 5}, {"Multiply": 1.1}, {"GaussianBlur": {"sigma": 1.0}}])
+    assert len(one) == 1 and len(one[0][1]) == 1 and one[0][2] == (40, 52)
+    merged, _ = augment.sample_batch_ex([{"Fliplr": 1.0}, {"Affine": {"rotate": 10}}, {"Add": 5}, {"Multiply": 1.1}], rng, 1, 40, 52, (40, 52))
+    np.testing.assert_allclose(one[0][0][:12], merged[0][:12], rtol=1e-6, atol=1e-6)
+    # colour BEFORE geometry, blur between two warps, Add after Multiply, a repeated Add: each boundary is a pass
+    p = stage([{"Add": 5}, {"Affine": {"rotate": 10}}, {"GaussianBlur": {"sigma": 1.0}}, {"Fliplr": 1.0}, {"Multiply": 1.1}, {"Add": 3}, {"Add": 2}])
+    assert len(p) == 5
+    assert list(p[0][0][6:9]) == [5, 5, 5] and np.allclose(p[0][0][:6], [1, 0, 0, 0, 1, 0])          # pass 1: Add on the raw pixels
+    assert not np.allclose(p[1][0][:6], [1, 0, 0, 0, 1, 0]) and len(p[1][1]) == 1 and p[1][0][6] == 0   # pass 2: rotate, then blur
+    assert p[2][0][0] == -1 and np.allclose(p[2][0][9:12], 1.1) and p[2][0][6] == 0                     # pass 3: flip, Multiply
+    assert list(p[3][0][6:9]) == [3, 3, 3] and list(p[4][0][6:9]) == [2, 2, 2]                         # passes 4, 5: the Adds (clipped between)
+    # the trailing Resize joins the last pass only when that pass is pure geometry
+    assert len(stage([{"Fliplr": 1.0}], out=(20, 26))) == 1
+    r = stage([{"Fliplr": 1.0}, {"Add": 5}], out=(20, 26))
+    assert len(r) == 2 and r[0][2] == (40, 52) and r[1][2] == (20, 26) and r[1][0][6] == 0 and np.isclose(r[1][0][0], 2.0)
+    # canvas-changing geometry between passes: the intermediate buffers take the canvas of their pass
+    c = stage([{"CropToFixedSize": {"width": 30, "height": 20}}, {"Invert": 1.0}, {"PadToFixedSize": {"width": 64, "height": 48}}], out=(24, 32))
+    assert [q[2] for q in c] == [(20, 30), (24, 32)] and int(c[0][0][12]) == augment.F_INVERT
+    # three filters: two per pass
+    f = stage([{"AverageBlur": 3}] * 3)
+    assert [len(q[1]) for q in f] == [2, 1]
+    # batches: equal structure -> batch passes, otherwise per image
+    bp, per = augment.sample_batch_staged([{"Add": 5}, {"Fliplr": 1.0}], rng, 3, 16, 16, (16, 16))
+    assert per is None and len(bp) == 2 and bp[0][0].shape == (3, 24) and bp[1][2] == (16, 16)
+    bp, per = augment.sample_batch_staged([{"Fliplr": 1.0}, {"Sometimes": {"p": 0.5, "then_list": [{"Add": 5}, {"Flipud": 1.0}]}}], np.random.RandomState(1), 8, 16, 16, (16, 16))
+    assert bp is None and sorted({len(q) for q in per}) == [1, 2]
+
+
 def test_cfg_gpus_without_torchrun_explains_how_to_launch(tmp_path, monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     cfg = segmentation.parse(write_cfg(tmp_path))
@@ -256,10 +290,11 @@ def test_host_prefetcher_prepares_batches_in_order_and_reports_errors():
     assert tuple(it.x.shape) == (6, 5, 3) and it.x.dtype == torch.uint8 and int(it.x[0, 0, 0]) == 5
     assert tuple(it.y.shape) == (6, 5) and int(it.y[0, 0]) == 5 % 3
     # equal-size batches are packed into two blocks (wrapped around to the plan's batch) with the sampled records
-    smp = lambda n, h, w: augment.sample_batch_ex([{"Fliplr": 0.5}], np.random.RandomState(0), n, h, w, (8, 8))
+    smp = lambda n, h, w: augment.sample_batch_staged([{"Fliplr": 0.5}], np.random.RandomState(0), n, h, w, (8, 8))
     hb = list(pipeline.HostPrefetcher(DS(5), list(range(5)), 4, classes=3, pin=False, sampler=smp))
     assert isinstance(hb[0], pipeline.HostBatch) and tuple(hb[1].X.shape) == (4, 6, 5, 3) and len(hb[1]) == 1
-    assert [int(v) for v in hb[1].X[:, 0, 0, 0]] == [4, 4, 4, 4] and hb[0].prm.shape == (4, 24) and hb[0].filt is None
+    assert [int(v) for v in hb[1].X[:, 0, 0, 0]] == [4, 4, 4, 4] and hb[0].per_item is None and len(hb[0].passes) == 1
+    assert hb[0].passes[0][0].shape == (4, 24) and hb[0].passes[0][1] is None and hb[0].passes[0][2] == (8, 8)
     b = pipeline.prepare_item(DS(1)[0], 1, False)                     # 1-class head: any non-zero label is foreground
     assert set(np.unique(b.y.numpy())) == {1}
     with pytest.raises(IOError, match="broken file 4"):

@@ -1494,6 +1494,48 @@ def test_neighbourhood_filters_bit_exact(ops):
                 np.testing.assert_array_equal(oaug.filter_u8(flat, recs[ps, i:i + 1]), flat)
 
 
+def test_listed_order_augmentation_passes_bit_exact(ops):
+    """imgaug Sequential semantics on the device: augmenters listed in an order one pass cannot serve (colour before geometry, a
+    blur between two warps, Add after Multiply, the Resize after colour) run as several passes (DeviceFeeder._run_passes); every
+    pass is the bit-exact kernel pair, so the result equals the numpy oracle applied pass by pass with the same records.  Batch
+    form (one launch per pass for the whole batch) and per-image form agree."""
+    from segmentation_training_pipeline_amd import augment, pipeline
+    spec = [{"Add": [-20, 20]}, {"Affine": {"rotate": [-20, 20], "scale": [0.8, 1.2]}}, {"GaussianBlur": {"sigma": [0.5, 1.5]}},
+            {"Fliplr": 1.0}, {"Multiply": [0.8, 1.2]}, {"Add": [-5, 5]}, {"CropAndPad": {"percent": [-0.1, 0.1]}},
+            {"AdditiveGaussianNoise": {"scale": 8.0}}]
+    n, h, w, ch, out = 3, 40, 52, 3, (32, 48)
+    rng = np.random.RandomState(23)
+    img = rng.randint(0, 256, size=(n, h, w, ch)).astype(np.uint8)
+    msk = rng.randint(0, 4, size=(n, h, w)).astype(np.uint8)
+    passes, per = augment.sample_batch_staged(spec, np.random.RandomState(5), n, h, w, out)
+    assert per is None and len(passes) == 6 and passes[-1][2] == out      # Add | Affine, blur | flip, Multiply | Add | CropAndPad, noise | Resize
+    # the oracle, pass by pass
+    rimg, rmsk = img, msk
+    for prm, filt, hw in passes:
+        rimg, rmsk = oaug.warp_u8(rimg, rmsk, prm, hw)
+        if filt is not None:
+            for ps in range(filt.shape[0]):
+                rimg = oaug.filter_u8(rimg, filt[ps])
+    feeder = pipeline.DeviceFeeder(DEV, out, spec, seed=0, classes=4, channels=ch)
+    xd, yd = keep(torch.from_numpy(img).to(DEV)), keep(torch.from_numpy(msk).to(DEV))
+    oi = torch.zeros((n,) + out + (ch,), dtype=torch.uint8, device=DEV)
+    om = torch.zeros((n,) + out, dtype=torch.uint8, device=DEV)
+    feeder._run_passes(xd, yd, oi, om, passes, n, h, w)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oi.cpu().numpy(), rimg)
+    np.testing.assert_array_equal(om.cpu().numpy(), rmsk)
+    # per-image execution of the same records
+    oi2, om2 = torch.zeros_like(oi), torch.zeros_like(om)
+    for i in range(n):
+        feeder._run_passes(xd[i], yd[i], oi2[i], om2[i], [(p[0][i:i + 1], None if p[1] is None else p[1][:, i:i + 1], p[2]) for p in passes], 1, h, w)
+    torch.cuda.synchronize()
+    assert torch.equal(oi2, oi) and torch.equal(om2, om)
+    # and the order matters: the merged single-pass form of the same list gives a different image
+    merged, mf = augment.sample_batch_ex(spec, np.random.RandomState(5), n, h, w, out)
+    mi, _ = oaug.warp_u8(img, msk, merged, out)
+    assert not np.array_equal(mi, rimg)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_batched_weight_prepare_equals_per_layer(ops, dtype):
     """The once-per-step batched launch (LDS tile transpose) must write exactly what stp_weight_prepare writes
