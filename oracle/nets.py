@@ -234,14 +234,18 @@ def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None)
     return resize_bilinear_tf1(lo, 4).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
-def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_filters=512):
-    """PSPNet (segmentation_models 0.2.1 defaults, ``schemas/segmentation.raml:225-249``): only the encoder up to
-    stage3_unit1_relu1 (1/8 resolution) exists; see pspnet_resnet_forward."""
+PSP_STAGE = {4: 2, 8: 3, 16: 4}     # downsample_factor -> the stage whose unit1_relu1 is the feature (schemas/segmentation.raml:228-230)
+
+
+def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_filters=512, downsample_factor=8):
+    """PSPNet (segmentation_models 0.2.1, ``schemas/segmentation.raml:225-249``): only the encoder up to the feature
+    stage<s>_unit1_relu1 (1/downsample_factor resolution; default 1/8 = stage 3) exists; see pspnet_resnet_forward."""
     full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
-    keep = ("bn_data", "conv0", "bn0", "stage1_", "stage2_", "stage3_unit1_bn1")
+    st = PSP_STAGE[int(downsample_factor)]
+    keep = ("bn_data", "conv0", "bn0") + tuple("stage%d_" % i for i in range(1, st)) + ("stage%d_unit1_bn1" % st,)
     P = OrderedDict((k, v) for k, v in full.items() if k.startswith(keep))
     rng = np.random.RandomState(seed + 3)
-    c = STAGE_FILTERS[1] * expansion(backbone)
+    c = STAGE_FILTERS[st - 2] * expansion(backbone)
     for level in (1, 2, 3, 6):
         P["psp_level%d_conv/kernel" % level] = _glorot_uniform(rng, (1, 1, c, conv_filters))
         _bn(P, "psp_level%d_bn" % level, conv_filters)
@@ -252,13 +256,14 @@ def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_fi
     return P
 
 
-def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None):
+def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8):
     """feature = stage3_unit1_relu1; for level in 1, 2, 3, 6: AveragePooling2D(size / level) -> Conv 1x1 (no bias) -> BN ->
     ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
     classes; bilinear x8.  Returns (logits_nhwc, bn_updates)."""
     ctx = _Ctx(P, training, taps)
-    _, skips = _resnet_encoder(ctx, x_nhwc, backbone, stop_at="stage3_unit1_relu1")
-    f = skips["stage3_unit1_relu1"]
+    feat = "stage%d_unit1_relu1" % PSP_STAGE[int(downsample_factor)]
+    _, skips = _resnet_encoder(ctx, x_nhwc, backbone, stop_at=feat)
+    f = skips[feat]
     parts = [f]
     for level in (1, 2, 3, 6):
         k = f.shape[2] // level
@@ -268,7 +273,7 @@ def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=No
         parts.append(resize_bilinear_tf1(p, k))
     y = _bn_apply(ctx, _conv(ctx, torch.cat(parts, dim=1), "psp_final"), "psp_final_bn", BN_EPS_DECODER, relu=True)
     lo = _conv(ctx, y, "final_conv", pad=1)
-    return resize_bilinear_tf1(lo, 8).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+    return resize_bilinear_tf1(lo, int(downsample_factor)).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
 ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1/", "block")

@@ -31,7 +31,8 @@ class OracleTrainer:
 
     def __init__(self, params, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss",
                  optimizer="adam", lr=1e-3, freeze_encoder=False, clipnorm=None, clipvalue=None,
-                 decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None, architecture="Unet", activation="sigmoid"):
+                 decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None, architecture="Unet", activation="sigmoid",
+                 net_kwargs=None):
         self.P = OrderedDict((k, v.copy()) for k, v in params.items())
         self.backbone = backbone
         self.loss_spec = loss
@@ -40,6 +41,7 @@ class OracleTrainer:
         self.clipnorm, self.clipvalue = clipnorm, clipvalue
         self.decoder_filters = tuple(decoder_filters)
         self.architecture = architecture
+        self.net_kwargs = dict(net_kwargs or {})      # PSPNet: downsample_factor
         self.steps_done = 0              # mirrors the device step counter that seeds DeepLab's dropout mask
         self.activation = activation     # "sigmoid": y [N,H,W,1] in {0,1};  "softmax": y [N,H,W,1] class index -> one-hot
 
@@ -50,7 +52,7 @@ class OracleTrainer:
         if self.architecture == "Linknet":
             return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
         if self.architecture == "PSPNet":
-            return nets.pspnet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
+            return nets.pspnet_resnet_forward(P, x, self.backbone, training=training, taps=taps, **self.net_kwargs)
         if self.architecture == "FPN":
             return nets.fpn_resnet_forward(P, x, self.backbone, training=training, taps=taps)
         return nets.unet_resnet_forward(P, x, self.backbone, training=training, taps=taps, decoder_filters=self.decoder_filters)

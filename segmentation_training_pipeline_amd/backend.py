@@ -44,7 +44,7 @@ class HipSegModel(object):
     def __init__(self, architecture="Unet", backbone="resnet34", input_shape=(512, 512, 3), classes=1, activation="sigmoid",
                  batch=16, dtype="bf16", loss="binary_crossentropy", optimizer="Adam", lr=1e-3, freeze_encoder=False,
                  decoder_filters=(256, 128, 64, 32, 16), clipnorm=None, clipvalue=None, use_graph=True, device="cuda",
-                 opt_kwargs=None, seed=42, decoder_block_type="upsampling"):
+                 opt_kwargs=None, seed=42, decoder_block_type="upsampling", net_kwargs=None):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
         if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet") \
@@ -59,6 +59,9 @@ class HipSegModel(object):
         if decoder_block_type not in ("upsampling", "transpose") or (decoder_block_type == "transpose" and architecture != "Unet"):
             raise ValueError("decoder_block_type %r is not available for %s" % (decoder_block_type, architecture))
         self.decoder_block_type = decoder_block_type
+        # architecture-specific graph options (FPN: pyramid_block_filters, segmentation_block_filters; PSPNet: downsample_factor,
+        # psp_conv_filters - schemas/segmentation.raml:179-249), passed to the network definition as keywords
+        self.net_kwargs = dict(net_kwargs or {})
         self.loss_w = parse_loss(loss, classes)
         self.optimizer = optimizer.lower()
         if self.optimizer not in ("adam", "sgd", "rmsprop", "nadam"):
@@ -105,7 +108,7 @@ class HipSegModel(object):
         with_loss = training if with_loss is None else with_loss
 
         def fn(plan):
-            kw = {"decoder_block_type": self.decoder_block_type} if self.architecture == "Unet" else {}
+            kw = {"decoder_block_type": self.decoder_block_type} if self.architecture == "Unet" else dict(self.net_kwargs)
             logits = nets.NETWORKS[self.architecture](plan, self.backbone, self.H, self.W, self.in_ch, self.classes,
                                                       self.decoder_filters, self.loss_w, with_loss=with_loss, **kw)
             if not with_loss and self.architecture != "DeepLabV3":      # (DeepLab's graph ends in probabilities itself)

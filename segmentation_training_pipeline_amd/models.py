@@ -50,7 +50,8 @@ class SegModel(object):
                                 decoder_block_type=getattr(self, "decoder_block_type", "upsampling"),
                                 batch=batch, dtype=dtype, loss=loss, optimizer=optimizer, lr=lr,
                                 freeze_encoder=self.freeze_encoder, decoder_filters=self.decoder_filters, clipnorm=clipnorm,
-                                clipvalue=clipvalue, use_graph=use_graph, device=device, opt_kwargs=opt_kwargs)
+                                clipvalue=clipvalue, use_graph=use_graph, device=device, opt_kwargs=opt_kwargs,
+                                net_kwargs=getattr(self, "net_kwargs", None))
         ew = self.encoder_weights
         if ew:
             path = resolve_pretrained(ew, self.backbone_name)
@@ -126,9 +127,14 @@ def FPN(backbone_name="vgg16", input_shape=(None, None, 3), classes=21, activati
     if backbone_name not in nets.RESNET_UNITS:
         raise ValueError("Unknown backbone")
     if fpn_layers != "default" or tuple(upsample_rates) != (2, 2, 2) or int(last_upsample) != 4 or interpolation != "bilinear" \
-            or not use_batchnorm or dropout or int(pyramid_block_filters) != 256 or int(segmentation_block_filters) != 128:
-        raise ValueError("the HIP FPN implements the default pyramid (256/128 filters, x2 rates, bilinear, BatchNorm, no dropout)")
-    return SegModel("FPN", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+            or not use_batchnorm or dropout:
+        raise ValueError("the HIP FPN implements the x2-rate pyramid ending at 1/4 resolution with bilinear resizes and BatchNorm, no dropout")
+    pf, sf = int(pyramid_block_filters), int(segmentation_block_filters)
+    if pf % 8 or sf % 8 or pf <= 0 or sf <= 0:
+        raise ValueError("pyramid_block_filters / segmentation_block_filters must be multiples of 8")
+    m = SegModel("FPN", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+    m.net_kwargs = {"pyramid_block_filters": pf, "segmentation_block_filters": sf}
+    return m
 
 
 def PSPNet(backbone_name="vgg16", input_shape=(384, 384, 3), classes=21, activation="softmax", encoder_weights="imagenet",
@@ -137,10 +143,14 @@ def PSPNet(backbone_name="vgg16", input_shape=(384, 384, 3), classes=21, activat
     """segmentation_models.PSPNet keyword surface (schemas/segmentation.raml:225-249)."""
     if backbone_name not in nets.RESNET_UNITS:
         raise ValueError("Unknown backbone")
-    if int(downsample_factor) != 8 or int(psp_conv_filters) != 512 or psp_pooling_type != "avg" or not use_batchnorm or dropout \
-            or final_interpolation != "bilinear":
-        raise ValueError("the HIP PSPNet implements the default module (1/8 feature, 512 filters, avg pooling, BatchNorm, bilinear)")
-    return SegModel("PSPNet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+    if int(downsample_factor) not in (4, 8, 16) or psp_pooling_type != "avg" or not use_batchnorm or dropout or final_interpolation != "bilinear":
+        raise ValueError("the HIP PSPNet implements downsample_factor 4 / 8 / 16 with average pooling, BatchNorm and the bilinear final resize, "
+                         "no dropout")
+    if int(psp_conv_filters) % 8 or int(psp_conv_filters) <= 0:
+        raise ValueError("psp_conv_filters must be a multiple of 8")
+    m = SegModel("PSPNet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+    m.net_kwargs = {"downsample_factor": int(downsample_factor), "psp_conv_filters": int(psp_conv_filters)}
+    return m
 
 
 def Deeplabv3(encoder_weights="pascal_voc", input_tensor=None, input_shape=(512, 512, 3), classes=21, backbone_name="mobilenetv2", OS=16,

@@ -562,3 +562,39 @@ def test_n_channel_inputs_match_the_oracle(backbone, in_ch):
     for _ in range(5):
         l1 = mb.train_on_batch(x, y)["loss"]
     assert np.isfinite(l1) and l1 < l0, (l0, l1)
+
+
+@pytest.mark.parametrize("arch,kw", [("PSPNet", {"downsample_factor": 4, "psp_conv_filters": 128}), ("PSPNet", {"downsample_factor": 16}),
+                                     ("FPN", {"pyramid_block_filters": 128, "segmentation_block_filters": 64})])
+def test_non_default_decoder_options_match_the_oracle(arch, kw):
+    """schemas/segmentation.raml:179-249: PSPNet ``downsample_factor`` 4 / 16 (feature = stage2 / stage4 unit1_relu1, final resize
+    x4 / x16) and ``psp_conv_filters``; FPN ``pyramid_block_filters`` / ``segmentation_block_filters``.  fp32 step at the north-star
+    bars, through the YAML-facing constructors (models.PSPNet / models.FPN keyword surface)."""
+    from segmentation_training_pipeline_amd import models
+    n = 2
+    if arch == "PSPNet":
+        f = kw["downsample_factor"]
+        size = 6 * f * (2 if f == 4 else 1)                                   # feature map 12x12 (1/4) or 6x6 (1/16)
+        P = onets.init_pspnet_resnet("resnet18", seed=42, conv_filters=kw.get("psp_conv_filters", 512), downsample_factor=f)
+        okw = {"downsample_factor": f}
+        ctor = models.PSPNet
+    else:
+        size = 64
+        P = onets.init_fpn_resnet("resnet18", seed=42, pyramid_filters=kw["pyramid_block_filters"], segmentation_filters=kw["segmentation_block_filters"])
+        okw = {}
+        ctor = models.FPN
+    x, y = ostep.synthetic_batch(n, size, size, seed=8)
+    tr = ostep.OracleTrainer(P, backbone="resnet18", loss=LOSS, optimizer="sgd", lr=0.02, architecture=arch, net_kwargs=okw)
+    sm = ctor("resnet18", input_shape=(size, size, 3), classes=1, activation="sigmoid", encoder_weights=None, **kw)
+    sm.compile(optimizer="SGD", loss=LOSS, lr=0.02, batch=n, dtype="fp32", use_graph=False)
+    m = sm.impl
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+    g = m.get_gradients()
+    assert rel_l2(g["final_conv/kernel"], o["grads"]["final_conv/kernel"]) < 1e-4
+    for k, ref in o["grads"].items():
+        assert rel_l2(g[k], ref) <= 3e-2, k
