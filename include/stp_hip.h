@@ -390,6 +390,10 @@ int stp_resize_bilinear_ac_bwd(const void* dy, void* dx, int32_t N, int32_t H, i
  * replay draws a fresh mask.  x == y allowed. */
 int stp_counter_tick(int32_t* state, void* stream);
 int stp_dropout(const void* x, void* y, int64_t count, float rate, const int32_t* state, uint32_t salt, int32_t dtype, void* stream);
+/* SpatialDropout2D(rate) on [N][HW][C] (segmentation_models' FPN / PSPNet `dropout`, schemas/segmentation.raml:201-203, 241-243):
+ * one keep / drop decision per (sample, channel), mask index n * C + c, same hash, scaling and step counter as stp_dropout. */
+int stp_dropout_spatial(const void* x, void* y, int32_t N, int64_t HW, int32_t C, float rate, const int32_t* state, uint32_t salt,
+                        int32_t dtype, void* stream);
 /* Activation('sigmoid') carried by the last convolution (model.py:485) as a tensor op on the first `channels` columns of
  * [rows][ld] tensors, and dz = dp * p * (1 - p) over [rows][ldg] gradients (padding columns written as 0). */
 int stp_sigmoid_act(const void* z, void* p, int64_t rows, int32_t channels, int32_t ldz, int32_t ldp, int32_t dtype, void* stream);

@@ -210,7 +210,19 @@ def resize_bilinear_tf1(x, f):
     return top + (bot - top) * fy
 
 
-def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None):
+DECODER_DROPOUT_SALT = 0x5D0D
+
+
+def _spatial_dropout(y, rate, step):
+    """SpatialDropout2D (training phase) with the device kernel's counter-based mask (stp_dropout_spatial): one decision per
+    (sample, channel), index n * C + c, inverted scaling."""
+    from .deeplab import dropout_mask
+    n, c = y.shape[0], y.shape[1]
+    keep = dropout_mask(step, DECODER_DROPOUT_SALT, n * c, rate).reshape(n, c, 1, 1)
+    return y * torch.from_numpy(keep.astype(np.float32)) / (1.0 - rate)
+
+
+def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, dropout=None, step=1):
     """Pyramid over [encoder output, stage4/3/2 unit-1 relu1]: lateral Conv2D 1x1 (bias) + UpSampling2D(2) of the level above,
     two (Conv2D 3x3 no bias, BN, ReLU) per level; the maps resized to 1/4 resolution, concatenated finest first,
     Conv 3x3 + BN + ReLU (4 x 128 filters), Conv2D 3x3 to the classes, bilinear x4.  Returns (logits_nhwc, bn_updates)."""
@@ -230,6 +242,8 @@ def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None)
         pyramid.append(p)
     cat = torch.cat([resize_bilinear_tf1(p, f) for p, f in zip(pyramid[::-1], (1, 2, 4, 8))], dim=1)
     y = _bn_apply(ctx, _conv(ctx, cat, "fpn_final", pad=1), "fpn_final_bn", BN_EPS_DECODER, relu=True)
+    if dropout and training:
+        y = _spatial_dropout(y, float(dropout), step)
     lo = _conv(ctx, y, "final_conv", pad=1)
     return resize_bilinear_tf1(lo, 4).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
@@ -256,7 +270,7 @@ def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_fi
     return P
 
 
-def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8):
+def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8, dropout=None, step=1):
     """feature = stage3_unit1_relu1; for level in 1, 2, 3, 6: AveragePooling2D(size / level) -> Conv 1x1 (no bias) -> BN ->
     ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
     classes; bilinear x8.  Returns (logits_nhwc, bn_updates)."""
@@ -272,6 +286,8 @@ def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=No
         ctx.tap("psp_level%d_out" % level, p)
         parts.append(resize_bilinear_tf1(p, k))
     y = _bn_apply(ctx, _conv(ctx, torch.cat(parts, dim=1), "psp_final"), "psp_final_bn", BN_EPS_DECODER, relu=True)
+    if dropout and training:
+        y = _spatial_dropout(y, float(dropout), step)
     lo = _conv(ctx, y, "final_conv", pad=1)
     return resize_bilinear_tf1(lo, int(downsample_factor)).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 

@@ -52,9 +52,9 @@ class OracleTrainer:
         if self.architecture == "Linknet":
             return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
         if self.architecture == "PSPNet":
-            return nets.pspnet_resnet_forward(P, x, self.backbone, training=training, taps=taps, **self.net_kwargs)
+            return nets.pspnet_resnet_forward(P, x, self.backbone, training=training, taps=taps, step=self.steps_done + 1, **self.net_kwargs)
         if self.architecture == "FPN":
-            return nets.fpn_resnet_forward(P, x, self.backbone, training=training, taps=taps)
+            return nets.fpn_resnet_forward(P, x, self.backbone, training=training, taps=taps, step=self.steps_done + 1, **self.net_kwargs)
         return nets.unet_resnet_forward(P, x, self.backbone, training=training, taps=taps, decoder_filters=self.decoder_filters)
 
     def forward(self, x_nhwc, training=False, taps=None):

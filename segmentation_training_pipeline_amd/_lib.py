@@ -115,6 +115,7 @@ SIGNATURES = {
     "stp_resize_bilinear_ac_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_counter_tick": (i32, [vp, vp]),
     "stp_dropout": (i32, [vp, vp, i64, f32, vp, C.c_uint32, i32, vp]),
+    "stp_dropout_spatial": (i32, [vp, vp, i32, i64, i32, f32, vp, C.c_uint32, i32, vp]),
     "stp_sigmoid_act": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "stp_sigmoid_act_bwd": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "stp_prob_bce_dice": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i32, vp, sz, vp]),

@@ -298,6 +298,34 @@ extern "C" int stp_counter_tick(int32_t* state, void* stream) {
   return STP_OK;
 }
 
+// SpatialDropout2D (noise_shape (batch, 1, 1, channels): a whole feature map of a sample is kept or dropped): the mask index is
+// (sample, channel) instead of the element
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_spatial_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t count, int64_t hwc, int C,
+                                                              uint32_t thresh, float scale, const int32_t* state, uint32_t salt) {
+  const uint32_t seed = (uint32_t)state[0] * 0x85EBCA77u + salt;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / hwc;
+    const uint32_t m = (uint32_t)(n * C + (i % C));
+    const bool keep = (drop_hash(seed, m) >> 8) >= thresh;
+    Elem<T>::store(y + i, keep ? Elem<T>::load(x + i) * scale : 0.f);
+  }
+}
+
+extern "C" int stp_dropout_spatial(const void* x, void* y, int32_t N, int64_t HW, int32_t C, float rate, const int32_t* state, uint32_t salt,
+                                   int32_t dtype, void* stream) {
+  if (!x || !y || !state || N <= 0 || HW <= 0 || C <= 0 || rate < 0.f || rate >= 1.f) return STP_E_BADARG;
+  const uint32_t thresh = (uint32_t)lrintf(rate * 16777216.f);
+  const float scale = 1.f / (1.f - rate);
+  const int64_t count = (int64_t)N * HW * C;
+  const int g = dl_grid(count);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(dropout_spatial_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, count, HW * C, C, thresh, scale, state, salt);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(dropout_spatial_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, count, HW * C, C, thresh, scale, state, salt);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // forward and backward are the same map (y = mask * x / (1 - rate)); x == y (in place) is allowed
 extern "C" int stp_dropout(const void* x, void* y, int64_t count, float rate, const int32_t* state, uint32_t salt, int32_t dtype, void* stream) {
   if (!x || !y || !state || count <= 0 || rate < 0.f || rate >= 1.f) return STP_E_BADARG;

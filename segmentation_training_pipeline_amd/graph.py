@@ -874,9 +874,10 @@ class Plan(object):
         self._tape.append(back)
         return out
 
-    def dropout(self, name, x, rate, salt):
-        """Keras ``Dropout(rate)``: training = inverted dropout in place (mask = hash of the device step counter, which the
-        first dropout of the plan ticks once per forward); inference = identity."""
+    def dropout(self, name, x, rate, salt, spatial=False):
+        """Keras ``Dropout(rate)`` / ``SpatialDropout2D(rate)`` (``spatial``: one decision per sample and channel): training =
+        inverted dropout in place (mask = hash of the device step counter, which the first dropout of the plan ticks once per
+        forward); inference = identity."""
         if not self.training:
             return x
         out = DT(name, self.N, x.H, x.W, x.C, x.buf, x.needs_grad)
@@ -890,14 +891,24 @@ class Plan(object):
             self._keep.append(self.step_state)
             self._emit(self.fwd, "stp_counter_tick", self.step_state.data_ptr())
         cnt = x.rows * x.C
-        self._emit(self.fwd, "stp_dropout", x.buf.data_ptr(), x.buf.data_ptr(), cnt, float(rate), self.step_state.data_ptr(), int(salt), self.cdt)
+        if spatial:
+            self._emit(self.fwd, "stp_dropout_spatial", x.buf.data_ptr(), x.buf.data_ptr(), self.N, x.H * x.W, x.C, float(rate),
+                       self.step_state.data_ptr(), int(salt), self.cdt)
+        else:
+            self._emit(self.fwd, "stp_dropout", x.buf.data_ptr(), x.buf.data_ptr(), cnt, float(rate), self.step_state.data_ptr(), int(salt), self.cdt)
 
         def back():
             if not (x.needs_grad and out.grad_ready):
                 return
             dy = out.grad
-            self._emit(self.bwd, "stp_dropout", dy.data_ptr(), dy.data_ptr(), x.rows * out.gradC, float(rate), self.step_state.data_ptr(),
-                       int(salt), self.cdt)
+            if spatial:
+                if out.gradC != x.C:
+                    raise StpShapeError("%s: spatial dropout needs an unpadded channel count" % name)
+                self._emit(self.bwd, "stp_dropout_spatial", dy.data_ptr(), dy.data_ptr(), self.N, x.H * x.W, x.C, float(rate),
+                           self.step_state.data_ptr(), int(salt), self.cdt)
+            else:
+                self._emit(self.bwd, "stp_dropout", dy.data_ptr(), dy.data_ptr(), x.rows * out.gradC, float(rate), self.step_state.data_ptr(),
+                           int(salt), self.cdt)
             x.grad, x.grad_ready = dy, True
 
         self._tape.append(back)

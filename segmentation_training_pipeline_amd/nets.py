@@ -140,7 +140,7 @@ def linknet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(No
 
 
 def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True,
-               pyramid_block_filters=256, segmentation_block_filters=128, last_upsample=4):
+               pyramid_block_filters=256, segmentation_block_filters=128, last_upsample=4, dropout=None):
     """segmentation_models 0.2.1 ``FPN(..., upsample_rates=(2,2,2), interpolation='bilinear', use_batchnorm=True)``
     (``schemas/segmentation.raml:180-203``).  Pyramid over [encoder output, stage4/3/2 unit1 relu1]: 1x1 lateral conv (+ the
     2x nearest upsampling of the level above), two conv3x3+BN+ReLU segmentation convs per level; the four maps are resized
@@ -161,6 +161,8 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
         pyramid.append(p)
     cat = plan.concat_resize("fpn_concat", [(pyramid[3], 1), (pyramid[2], 2), (pyramid[1], 4), (pyramid[0], 8)])
     y = plan.bn("fpn_final_bn", plan.conv("fpn_final", cat, sf * 4, 3, pad=1, bn_stats=True), BN_EPS_DECODER, relu=True)
+    if dropout:       # SpatialDropout2D between the final block and the class convolution (segmentation_models 0.2.1 fpn builder)
+        y = plan.dropout("fpn_dropout", y, float(dropout), DECODER_DROPOUT_SALT, spatial=True)
     lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
     logits = plan.resize("logits", lo, 4)
     if with_loss:
@@ -170,7 +172,7 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
 
 
 def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True,
-                  downsample_factor=8, psp_conv_filters=512):
+                  downsample_factor=8, psp_conv_filters=512, dropout=None):
     """segmentation_models 0.2.1 ``PSPNet(downsample_factor=8, psp_conv_filters=512, psp_pooling_type='avg', use_batchnorm=True,
     final_interpolation='bilinear')`` (``schemas/segmentation.raml:225-249``): the backbone is cut at the 1/8 feature
     (stage3_unit1_relu1; 1/4: stage2, 1/16: stage4); pyramid pooling levels 1, 2, 3, 6 = AveragePooling2D(size/level) ->
@@ -190,6 +192,8 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
         parts.append((p, k))
     cat = plan.concat_resize("psp_concat", parts)
     y = plan.bn("psp_final_bn", plan.conv("psp_final", cat, 512, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
+    if dropout:       # SpatialDropout2D between the final block and the class convolution (segmentation_models 0.2.1 psp builder)
+        y = plan.dropout("psp_dropout", y, float(dropout), DECODER_DROPOUT_SALT, spatial=True)
     lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
     logits = plan.resize("logits", lo, int(downsample_factor))
     if with_loss:
@@ -204,6 +208,7 @@ MOBILENETV2_BLOCKS = [(16, 1, 1, 0, False, 1), (24, 2, 6, 1, False, 1), (24, 1, 
                       (96, 1, 6, 10, False, 2), (96, 1, 6, 11, True, 2), (96, 1, 6, 12, True, 2), (160, 1, 6, 13, False, 2),
                       (160, 1, 6, 14, True, 4), (160, 1, 6, 15, True, 4), (320, 1, 6, 16, False, 4)]
 DEEPLAB_DROPOUT_SALT = 0x0D0D
+DECODER_DROPOUT_SALT = 0x5D0D      # FPN / PSPNet `dropout` (SpatialDropout2D)
 
 
 def deeplab_mobilenetv2(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True):

@@ -565,7 +565,9 @@ def test_n_channel_inputs_match_the_oracle(backbone, in_ch):
 
 
 @pytest.mark.parametrize("arch,kw", [("PSPNet", {"downsample_factor": 4, "psp_conv_filters": 128}), ("PSPNet", {"downsample_factor": 16}),
-                                     ("FPN", {"pyramid_block_filters": 128, "segmentation_block_filters": 64})])
+                                     ("FPN", {"pyramid_block_filters": 128, "segmentation_block_filters": 64}),
+                                     ("FPN", {"pyramid_block_filters": 256, "segmentation_block_filters": 128, "dropout": 0.3}),
+                                     ("PSPNet", {"downsample_factor": 8, "dropout": 0.25})])
 def test_non_default_decoder_options_match_the_oracle(arch, kw):
     """schemas/segmentation.raml:179-249: PSPNet ``downsample_factor`` 4 / 16 (feature = stage2 / stage4 unit1_relu1, final resize
     x4 / x16) and ``psp_conv_filters``; FPN ``pyramid_block_filters`` / ``segmentation_block_filters``.  fp32 step at the north-star
@@ -576,12 +578,12 @@ def test_non_default_decoder_options_match_the_oracle(arch, kw):
         f = kw["downsample_factor"]
         size = 6 * f * (2 if f == 4 else 1)                                   # feature map 12x12 (1/4) or 6x6 (1/16)
         P = onets.init_pspnet_resnet("resnet18", seed=42, conv_filters=kw.get("psp_conv_filters", 512), downsample_factor=f)
-        okw = {"downsample_factor": f}
+        okw = {"downsample_factor": f, "dropout": kw.get("dropout")}
         ctor = models.PSPNet
     else:
         size = 64
         P = onets.init_fpn_resnet("resnet18", seed=42, pyramid_filters=kw["pyramid_block_filters"], segmentation_filters=kw["segmentation_block_filters"])
-        okw = {}
+        okw = {"dropout": kw.get("dropout")}
         ctor = models.FPN
     x, y = ostep.synthetic_batch(n, size, size, seed=8)
     tr = ostep.OracleTrainer(P, backbone="resnet18", loss=LOSS, optimizer="sgd", lr=0.02, architecture=arch, net_kwargs=okw)
@@ -598,3 +600,15 @@ def test_non_default_decoder_options_match_the_oracle(arch, kw):
     assert rel_l2(g["final_conv/kernel"], o["grads"]["final_conv/kernel"]) < 1e-4
     for k, ref in o["grads"].items():
         assert rel_l2(g[k], ref) <= 3e-2, k
+    if kw.get("dropout"):
+        # SpatialDropout2D: the masked tensor has whole (sample, channel) maps at zero, about `dropout` of them, the kept ones scaled;
+        # a second step draws another mask (device step counter), inference is the identity
+        name = "fpn_dropout" if arch == "FPN" else "psp_dropout"
+        a = m.activation(name)
+        dead = (np.abs(a).reshape(n, -1, a.shape[-1]).max(axis=1) == 0)
+        assert 0.05 < dead.mean() < 0.6
+        assert np.isfinite(m.train_on_batch(x, y)["loss"])
+        dead2 = (np.abs(m.activation(name)).reshape(n, -1, a.shape[-1]).max(axis=1) == 0)
+        assert not np.array_equal(dead, dead2)
+        p1, p2 = m.predict(x), m.predict(x)
+        np.testing.assert_array_equal(p1, p2)
