@@ -185,39 +185,50 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
       *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
     }
   }
+#if defined(STP_EXP) && STP_EXP == 31   // what-if: no cross-thread reduction / partial-sum stores (values kept live)
+  if (EP >= 1 && a.P < 0) {
+#else
   if (EP >= 1) {
+#endif
     if (EP == 2 && cok) {   // sum g * xhat = rstd * (sum g * x - mean * sum g), per thread (linear, so the partition does not matter)
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co + 4);
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float mu = a.bnb.mean[co + e], rs = a.bnb.rstd[co + e];
+        const float mu = e < 4 ? m0[e & 3] : m1[e & 3], rs = e < 4 ? r0[e & 3] : r1[e & 3];
         qq[e >> 1][e & 1] = rs * (qq[e >> 1][e & 1] - mu * ss[e >> 1][e & 1]);
       }
     }
-    // threads with the same channel group: lanes c8 + CG*m of every wave -> butterfly inside the wave, then the 8 waves through LDS
-#pragma unroll
-    for (int off = CG; off < 64; off <<= 1)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ss[e].x += __shfl_xor(ss[e].x, off, 64); ss[e].y += __shfl_xor(ss[e].y, off, 64);
-        qq[e].x += __shfl_xor(qq[e].x, off, 64); qq[e].y += __shfl_xor(qq[e].y, off, 64);
-      }
+    // Fixed-order reduction over the 512 / CG threads that share a channel group, through LDS only (the ds_bpermute butterfly +
+    // per-wave table this replaces cost 4500-5600 cycles per workgroup, scratch/halo_timing.py): every thread writes its 16
+    // partials [k][thread] (k = channel pair, sum / sum of squares), 512 threads sum 512 / NPART / CG of them each, NOUT threads
+    // combine the NPART parts and store the tile's column of the [stat][channel][tile] partial sums.
+    constexpr int J = 512 / CG, NOUT = CG * 16, NPART = 512 / NOUT, JP = J / NPART, KS = 512 + CG;   // KS: conflict-free k stride
+    static_assert(NPART >= 1 && J % NPART == 0, "reduction shape");
     lds_barrier();                                          // the staged tile is dead
-    float* red = reinterpret_cast<float*>(smem);              // [8 waves][BM][2]
-    if (lane < CG) {
+    float* r1 = reinterpret_cast<float*>(smem);               // [16][KS]
+    float* r2 = r1 + 16 * KS;                                 // [NPART][NOUT]
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[(wave * BM + c8 * 8 + e) * 2] = ss[e >> 1][e & 1];
-        red[(wave * BM + c8 * 8 + e) * 2 + 1] = qq[e >> 1][e & 1];
-      }
+    for (int e = 0; e < 4; ++e) {
+      r1[(e * 4 + 0) * KS + tid] = ss[e].x; r1[(e * 4 + 1) * KS + tid] = ss[e].y;
+      r1[(e * 4 + 2) * KS + tid] = qq[e].x; r1[(e * 4 + 3) * KS + tid] = qq[e].y;
     }
     lds_barrier();
-    for (int c = tid; c < BM; c += 512) {
-      if (cout0 + c >= a.Cout) continue;
-      float s_ = 0.f, q_ = 0.f;
+    {
+      const int o = tid % NOUT, q = tid / NOUT;
+      const float* src = r1 + (o / CG) * KS + (o % CG) + CG * (q * JP);
+      float acc_ = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) { s_ += red[(w * BM + c) * 2]; q_ += red[(w * BM + c) * 2 + 1]; }
-      a.stats[(size_t)(cout0 + c) * a.ntile_n + tile_n] = s_;
-      a.stats[((size_t)a.Cout + cout0 + c) * a.ntile_n + tile_n] = q_;
+      for (int j = 0; j < JP; ++j) acc_ += src[CG * j];
+      r2[q * NOUT + o] = acc_;
+    }
+    lds_barrier();
+    if (tid < NOUT) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NPART; ++q) tot += r2[q * NOUT + tid];
+      const int k = tid / CG, ch = (tid % CG) * 8 + (k >> 2) * 2 + (k & 1), stat = (k >> 1) & 1;
+      if (cout0 + ch < a.Cout) a.stats[((size_t)stat * a.Cout + cout0 + ch) * a.ntile_n + tile_n] = tot;
     }
   }
 }
