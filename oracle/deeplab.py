@@ -114,6 +114,137 @@ def _bn_act(ctx, x, name, cfg, act):
     return F.relu(y) if act == "relu" else y
 
 
+def init_deeplab_xception(in_ch=3, classes=1, seed=42):
+    """Modified Xception + ASPP + decoder (model.py:338-379, 436-491); Keras layouts, layer names as in model.py."""
+    rng = np.random.RandomState(seed)
+    P = OrderedDict()
+
+    def conv(name, k, cin, cout):
+        P[name + "/kernel"] = _glorot(rng, (k, k, cin, cout), k * k * cin, k * k * cout)
+
+    def sep(prefix, cin, cout):
+        P[prefix + "_depthwise/depthwise_kernel"] = _glorot(rng, (3, 3, cin, 1), 9 * cin, 9)
+        _bn(P, prefix + "_depthwise_BN", cin)
+        conv(prefix + "_pointwise", 1, cin, cout)
+        _bn(P, prefix + "_pointwise_BN", cout)
+
+    def block(prefix, cin, depths, skip):
+        c = cin
+        for i, d in enumerate(depths):
+            sep(prefix + "_separable_conv%d" % (i + 1), c, d)
+            c = d
+        if skip == "conv":
+            conv(prefix + "_shortcut", 1, cin, depths[-1])
+            _bn(P, prefix + "_shortcut_BN", depths[-1])
+        return c
+
+    conv("entry_flow_conv1_1", 3, in_ch, 32); _bn(P, "entry_flow_conv1_1_BN", 32)
+    conv("entry_flow_conv1_2", 3, 32, 64); _bn(P, "entry_flow_conv1_2_BN", 64)
+    c = block("entry_flow_block1", 64, [128, 128, 128], "conv")
+    c = block("entry_flow_block2", c, [256, 256, 256], "conv")
+    c = block("entry_flow_block3", c, [728, 728, 728], "conv")
+    for i in range(16):
+        c = block("middle_flow_unit_%d" % (i + 1), c, [728, 728, 728], "sum")
+    c = block("exit_flow_block1", c, [728, 1024, 1024], "conv")
+    c = block("exit_flow_block2", c, [1536, 1536, 2048], "none")
+    for name in ("image_pooling", "aspp0"):
+        conv(name, 1, c, 256); _bn(P, name + "_BN", 256)
+    for i in (1, 2, 3):
+        sep("aspp%d" % i, c, 256)
+    conv("concat_projection", 1, 5 * 256, 256); _bn(P, "concat_projection_BN", 256)
+    conv("feature_projection0", 1, 256, 48); _bn(P, "feature_projection0_BN", 48)
+    sep("decoder_conv0", 256 + 48, 256)
+    sep("decoder_conv1", 256, 256)
+    conv("custom_logits_semantic", 1, 256, classes)
+    P["custom_logits_semantic/bias"] = np.zeros(classes, np.float32)
+    return P
+
+
+BN_XCEPTION = dict(eps=1e-3, momentum=0.99)          # model.py:137, 143 (epsilon=1e-3 default of SepConv_BN; Keras default momentum)
+
+
+def _dwconv_explicit(P, x, name, stride, rate):
+    """model.py:126-137: stride 1 -> 'same'; stride > 1 -> ZeroPadding2D((pad_beg, pad_end)) + 'valid'."""
+    if stride == 1:
+        return _dwconv_same(P, x, name, 1, rate)
+    w = P[name + "/depthwise_kernel"].permute(2, 3, 0, 1)
+    keff = 3 + 2 * (rate - 1)
+    beg = (keff - 1) // 2
+    end = keff - 1 - beg
+    return F.conv2d(F.pad(x, (beg, end, beg, end)), w, None, stride=stride, dilation=rate, groups=x.shape[1])
+
+
+def _sepconv_bn(ctx, x, filters, prefix, stride=1, rate=1, depth_activation=False, cfg=BN_XCEPTION):
+    """model.py:110-147."""
+    P = ctx.P
+    if not depth_activation:
+        x = F.relu(x)
+    x = _dwconv_explicit(P, x, prefix + "_depthwise", stride, rate)
+    x = _bn_act(ctx, x, prefix + "_depthwise_BN", cfg, "relu" if depth_activation else None)
+    x = _conv_same(P, x, prefix + "_pointwise")
+    return _bn_act(ctx, x, prefix + "_pointwise_BN", cfg, "relu" if depth_activation else None)
+
+
+def _xception_block(ctx, inputs, depths, prefix, skip_type, stride, rate=1, depth_activation=False):
+    """model.py:182-218; returns (outputs, skip = output of the second SepConv)."""
+    P = ctx.P
+    r, skip = inputs, None
+    for i in range(3):
+        r = _sepconv_bn(ctx, r, depths[i], prefix + "_separable_conv%d" % (i + 1), stride=stride if i == 2 else 1, rate=rate,
+                        depth_activation=depth_activation)
+        if i == 1:
+            skip = r
+    if skip_type == "conv":
+        w = P[prefix + "_shortcut/kernel"].permute(3, 2, 0, 1)
+        sc = F.conv2d(inputs, w, None, stride=stride)                             # _conv2d_same, kernel 1: no padding either way
+        return r + _bn_act(ctx, sc, prefix + "_shortcut_BN", BN_XCEPTION, None), skip
+    if skip_type == "sum":
+        return r + inputs, skip
+    return r, skip
+
+
+def deeplab_xception_forward(P, x_nhwc, training=True, taps=None, step=1, OS=16):
+    """model.py:338-379 (feature extractor), :436-469 (ASPP), :471-491 (decoder); returns (PROBABILITIES nhwc, bn_updates)."""
+    ctx = nets._Ctx(P, training, taps)
+    x = x_nhwc.permute(0, 3, 1, 2)
+    H, W = x.shape[2], x.shape[3]
+    b3_stride, mid_rate, exit_rates, aspp_rates = (1, 2, (2, 4), (12, 24, 36)) if OS == 8 else (2, 1, (1, 2), (6, 12, 18))
+    x = _bn_act(ctx, _conv_same(P, x, "entry_flow_conv1_1", stride=2), "entry_flow_conv1_1_BN", BN_XCEPTION, "relu")
+    x = _bn_act(ctx, _conv_same(P, x, "entry_flow_conv1_2"), "entry_flow_conv1_2_BN", BN_XCEPTION, "relu")
+    x, _ = _xception_block(ctx, x, [128, 128, 128], "entry_flow_block1", "conv", 2)
+    x, skip1 = _xception_block(ctx, x, [256, 256, 256], "entry_flow_block2", "conv", 2)
+    ctx.tap("entry_flow_block2", x)
+    x, _ = _xception_block(ctx, x, [728, 728, 728], "entry_flow_block3", "conv", b3_stride)
+    for i in range(16):
+        x, _ = _xception_block(ctx, x, [728, 728, 728], "middle_flow_unit_%d" % (i + 1), "sum", 1, rate=mid_rate)
+    ctx.tap("middle_flow", x)
+    x, _ = _xception_block(ctx, x, [728, 1024, 1024], "exit_flow_block1", "conv", 1, rate=exit_rates[0])
+    x, _ = _xception_block(ctx, x, [1536, 1536, 2048], "exit_flow_block2", "none", 1, rate=exit_rates[1], depth_activation=True)
+    ctx.tap("exit_flow", x)
+    hf, wf = x.shape[2], x.shape[3]
+    b4 = F.avg_pool2d(x, kernel_size=(hf, wf))
+    b4 = _bn_act(ctx, _conv_same(P, b4, "image_pooling"), "image_pooling_BN", BN_ASPP, "relu")
+    b4 = F.interpolate(b4, size=(hf, wf), mode="bilinear", align_corners=True)
+    b0 = _bn_act(ctx, _conv_same(P, x, "aspp0"), "aspp0_BN", BN_ASPP, "relu")
+    bs = [_sepconv_bn(ctx, x, 256, "aspp%d" % (i + 1), rate=r, depth_activation=True, cfg=BN_ASPP) for i, r in enumerate(aspp_rates)]
+    x = torch.cat([b4, b0] + bs, dim=1)                                           # model.py:467
+    x = _bn_act(ctx, _conv_same(P, x, "concat_projection"), "concat_projection_BN", BN_ASPP, "relu")
+    ctx.tap("concat_projection", x)
+    if training:
+        n, c, hh, ww = x.shape
+        keep = dropout_mask(step, DROPOUT_SALT, n * hh * ww * c, DROPOUT_RATE).reshape(n, hh, ww, c).transpose(0, 3, 1, 2)
+        x = x * torch.from_numpy(keep.astype(np.float32)) / (1.0 - DROPOUT_RATE)
+    x = F.interpolate(x, size=(H // 4, W // 4), mode="bilinear", align_corners=True)                   # model.py:476-477
+    d = _bn_act(ctx, _conv_same(P, skip1, "feature_projection0"), "feature_projection0_BN", BN_ASPP, "relu")
+    x = torch.cat([x, d], dim=1)
+    x = _sepconv_bn(ctx, x, 256, "decoder_conv0", depth_activation=True, cfg=BN_ASPP)
+    x = _sepconv_bn(ctx, x, 256, "decoder_conv1", depth_activation=True, cfg=BN_ASPP)
+    ctx.tap("decoder", x)
+    p = torch.sigmoid(_conv_same(P, x, "custom_logits_semantic"))
+    p = F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True)
+    return p.permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+
+
 def dropout_mask(step, salt, count, rate):
     """The kernel's counter-based mask (stp_dropout): keep where hash(step * 0x85EBCA77 + salt, i) >> 8 >= rate * 2^24."""
     with np.errstate(over="ignore"):

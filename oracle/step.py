@@ -48,6 +48,8 @@ class OracleTrainer:
     def _forward(self, P, x, training, taps):
         if self.architecture == "DeepLabV3":      # returns PROBABILITIES (the activation is inside the model, deeplab.py)
             from . import deeplab
+            if self.backbone == "xception":
+                return deeplab.deeplab_xception_forward(P, x, training=training, taps=taps, step=self.steps_done + 1, **self.net_kwargs)
             return deeplab.deeplab_forward(P, x, training=training, taps=taps, step=self.steps_done + 1)
         if self.architecture == "Linknet":
             return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps)

@@ -48,7 +48,7 @@ class HipSegModel(object):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
         if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet") \
-                or ((backbone == "mobilenetv2") != (architecture == "DeepLabV3")):     # VGG: U-Net only; MobileNetV2: DeepLabV3 only
+                or ((backbone in ("mobilenetv2", "xception")) != (architecture == "DeepLabV3")):   # VGG: U-Net only; MobileNetV2 / Xception: DeepLabV3 only
             raise ValueError("Unknown backbone")
         if not ((classes == 1 and activation in ("sigmoid", None)) or (2 <= classes <= 32 and activation == "softmax")):
             raise ValueError("the HIP backend trains 1-class sigmoid heads and 2..32-class softmax heads")
@@ -109,6 +109,8 @@ class HipSegModel(object):
 
         def fn(plan):
             kw = {"decoder_block_type": self.decoder_block_type} if self.architecture == "Unet" else dict(self.net_kwargs)
+            if self.architecture == "DeepLabV3" and self.backbone != "xception":
+                kw.pop("OS", None)                                   # (the output stride applies to the xception backbone only, model.py:296-297)
             logits = nets.NETWORKS[self.architecture](plan, self.backbone, self.H, self.W, self.in_ch, self.classes,
                                                       self.decoder_filters, self.loss_w, with_loss=with_loss, **kw)
             if not with_loss and self.architecture != "DeepLabV3":      # (DeepLab's graph ends in probabilities itself)

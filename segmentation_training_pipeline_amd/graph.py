@@ -757,6 +757,38 @@ class Plan(object):
         self._tape.append(back)
         return out
 
+    def relu(self, name, x):
+        """Keras ``Activation('relu')`` as a tensor of its own (DeepLab's xception blocks activate a tensor that its other
+        consumers - the shortcut convolution, the Add - read raw, model.py:133-134): y = max(x, 0) through the BatchNormalization
+        apply kernel with the identity affine; the gradient is masked in place by y > 0 and joins x's other gradients."""
+        Cn = x.C
+        out = self._new(name, x.H, x.W, Cn, x.needs_grad)
+        out.gradC = x.gradC
+        self._use(x)
+        if self.dry:
+            return out
+        zero, one = self._alloc((Cn,), torch.float32), self._alloc((Cn,), torch.float32)
+        zero.zero_(); one.fill_(1.0)
+        self._emit(self.fwd, "stp_bn_apply", x.buf.data_ptr(), self.cdt, out.buf.data_ptr(), self.cdt, x.rows, Cn, Cn, zero.data_ptr(),
+                   one.data_ptr(), None, None, 1, 0.0)
+        if not self.training:
+            return out
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            dy = out.grad
+            if out.gradC != Cn:
+                raise StpShapeError("%s: standalone ReLU needs an unpadded channel count" % name)
+            self._emit(self.bwd, "stp_relu_bwd", out.buf.data_ptr(), dy.data_ptr(), x.rows * Cn, self.cdt)
+            if not x.grad_ready and x.gradC == out.gradC:
+                x.grad, x.grad_ready = dy, True
+            else:
+                self._emit(self.bwd, "stp_add_inplace", self._gradbuf(x).data_ptr(), dy.data_ptr(), x.rows * Cn, self.cdt)
+
+        self._tape.append(back)
+        return out
+
     def upsample_add(self, name, x, m):
         """FPN top-down step ``Add()([x, UpSampling2D(2)(m)])`` in place on x's buffer (x must have no other consumer yet)."""
         if (x.H, x.W, x.C) != (2 * m.H, 2 * m.W, m.C):
@@ -840,7 +872,7 @@ class Plan(object):
         self._tape.append(back)
         return out
 
-    def dwconv(self, name, x, k=3, stride=1, dilation=1):
+    def dwconv(self, name, x, k=3, stride=1, dilation=1, explicit_pad=False):
         """Keras ``DepthwiseConv2D(k, strides, padding='same', dilation_rate, use_bias=False)`` (DeepLab model.py:136, 255-259).
         The fp32 master kernel [k][k][C] is read directly by the kernels (kind "dw": Keras' (kh,kw,C,1) layout as stored)."""
         Cn = x.C
@@ -849,6 +881,11 @@ class Plan(object):
         keff = (k - 1) * dilation + 1
         Ho, Wo = -(-x.H // stride), -(-x.W // stride)
         pt, pl = max((Ho - 1) * stride + keff - x.H, 0) // 2, max((Wo - 1) * stride + keff - x.W, 0) // 2
+        if explicit_pad:
+            # ZeroPadding2D((pad_beg, pad_end)) + 'valid' (DeepLab SepConv_BN with stride > 1, model.py:126-132): the padding does
+            # not depend on the input size, unlike TF 'same'
+            pt = pl = (keff - 1) // 2
+            Ho, Wo = (x.H + (keff - 1) - keff) // stride + 1, (x.W + (keff - 1) - keff) // stride + 1
         w = self.param(name + "/depthwise_kernel", (k, k, Cn), "dw")
         out = self._new(name, Ho, Wo, Cn, x.needs_grad or w.trainable)
         self._use(x)

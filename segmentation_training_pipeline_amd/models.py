@@ -163,11 +163,16 @@ def Deeplabv3(encoder_weights="pascal_voc", input_tensor=None, input_shape=(512,
                          "(pre-trained on PASCAL VOC)")
     if backbone_name not in ("xception", "mobilenetv2"):
         raise ValueError("The `backbone_name` argument should be either `xception`  or `mobilenetv2` ")
-    if backbone_name != "mobilenetv2" or float(alpha) != 1.0:
+    if backbone_name == "mobilenetv2" and float(alpha) != 1.0:
         raise ValueError("the HIP DeepLabV3 implements the mobilenetv2 branch with alpha = 1")
+    if backbone_name == "xception" and int(OS) not in (8, 16):
+        raise ValueError("OS (output stride of the xception backbone) is 8 or 16")
     if activation != "sigmoid" or int(classes) != 1:
         raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head")
-    return SegModel("DeepLabV3", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+    mdl = SegModel("DeepLabV3", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
+    if backbone_name == "xception":
+        mdl.net_kwargs = {"OS": int(OS)}
+    return mdl
 
 
 ARCHITECTURES = {"Unet": Unet, "Linknet": Linknet, "FPN": FPN, "PSPNet": PSPNet}

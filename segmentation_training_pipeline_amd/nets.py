@@ -20,13 +20,13 @@ STAGE_FILTERS = (64, 128, 256, 512)
 BN_EPS_ENCODER = 2e-5
 BN_EPS_DECODER = 1e-3
 
-ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1", "block", "Conv", "expanded_conv")
+ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1", "block", "Conv", "expanded_conv", "entry_flow", "middle_flow", "exit_flow")
 VGG_BLOCKS = {"vgg16": (2, 2, 3, 3, 3), "vgg19": (2, 2, 4, 4, 4)}      # keras.applications: 3x3 'same' convs + ReLU per block
 VGG_FILTERS = (64, 128, 256, 512, 512)
 
 
 def known_backbones():
-    return sorted(RESNET_UNITS) + sorted(VGG_BLOCKS) + ["mobilenetv2"]
+    return sorted(RESNET_UNITS) + sorted(VGG_BLOCKS) + ["mobilenetv2", "xception"]
 
 
 def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
@@ -257,4 +257,89 @@ def deeplab_mobilenetv2(plan, backbone, H, W, in_ch=3, classes=1, decoder_filter
     return probs
 
 
-NETWORKS = {"DeepLabV3": deeplab_mobilenetv2, "Unet": unet_resnet, "Linknet": linknet_resnet, "FPN": fpn_resnet, "PSPNet": pspnet_resnet}
+def _sepconv_bn(plan, x, filters, prefix, stride=1, rate=1, depth_activation=False, eps=1e-3):
+    """model.py:110-147 ``SepConv_BN``: [ReLU] -> DepthwiseConv2D 3x3 (stride / atrous rate; explicit symmetric padding + 'valid'
+    when strided) -> BN [-> ReLU] -> Conv2D 1x1 -> BN [-> ReLU]."""
+    if not depth_activation:
+        x = plan.relu(prefix + "_relu", x)
+    x = plan.dwconv(prefix + "_depthwise", x, 3, stride=stride, dilation=rate, explicit_pad=stride != 1)
+    x = plan.bn(prefix + "_depthwise_BN", x, eps, relu=1 if depth_activation else 0)
+    x = plan.conv(prefix + "_pointwise", x, filters, 1, bn_stats=True)
+    return plan.bn(prefix + "_pointwise_BN", x, eps, relu=1 if depth_activation else 0)
+
+
+def _xception_block(plan, x, depth_list, prefix, skip_type, stride, rate=1, depth_activation=False, return_skip=False):
+    """model.py:182-218 ``_xception_block``: three SepConv_BN (the last one strided), skip = the output of the second;
+    shortcut 'conv' (1x1 strided convolution + BN, added), 'sum' (the input added) or 'none'."""
+    inputs, r, skip = x, x, None
+    for i in range(3):
+        r = _sepconv_bn(plan, r, depth_list[i], prefix + "_separable_conv%d" % (i + 1), stride=stride if i == 2 else 1, rate=rate,
+                        depth_activation=depth_activation)
+        if i == 1:
+            skip = r
+    if skip_type == "conv":
+        sc = plan.bn(prefix + "_shortcut_BN", plan.conv(prefix + "_shortcut", inputs, depth_list[-1], 1, stride=stride, bn_stats=True), 1e-3,
+                     relu=0)
+        out = plan.add(prefix + "_add", r, sc)
+    elif skip_type == "sum":
+        out = plan.add(prefix + "_add", r, inputs)
+    else:
+        out = r
+    return (out, skip) if return_skip else out
+
+
+def deeplab_xception(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True, OS=16):
+    """The reference's in-tree DeepLabV3+ over the modified Xception (``impl/deeplab/model.py:338-379`` entry / middle / exit flow,
+    ``:436-469`` ASPP with three atrous SepConv branches, ``:471-491`` decoder with ``feature_projection0``): entry conv 3x3 s2 +
+    conv 3x3, blocks [128]x3 s2 (conv skip), [256]x3 s2 (conv skip; its second SepConv is the decoder skip), [728]x3 (stride 2 at
+    OS 16); 16 middle units [728]x3 (sum skip); exit blocks [728, 1024, 1024] (conv skip) and [1536, 1536, 2048] (no skip, activations
+    inside); ASPP = image pooling + 1x1 + SepConv rates (6, 12, 18) [(12, 24, 36) at OS 8]; projection + Dropout(0.1); decoder:
+    align-corners bilinear to 1/4, concat with the 48-channel projection of the skip, two SepConv 256; class convolution WITH the
+    activation; align-corners bilinear upsampling of the probabilities."""
+    if classes != 1:
+        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head")
+    if OS not in (8, 16) or H != W or H % OS:
+        raise ValueError("DeepLabV3 / xception needs a square input divisible by the output stride (8 or 16)")
+    b3_stride, mid_rate, exit_rates, aspp_rates = (1, 2, (2, 4), (12, 24, 36)) if OS == 8 else (2, 1, (1, 2), (6, 12, 18))
+    img = plan.input_u8("image", H, W, in_ch)
+    x = plan.input_cast("input_cast", img)
+    x = plan.bn("entry_flow_conv1_1_BN", plan.conv("entry_flow_conv1_1", x, 32, 3, stride=2, same_tf=True, bn_stats=True), 1e-3, relu=1)
+    x = plan.bn("entry_flow_conv1_2_BN", plan.conv("entry_flow_conv1_2", x, 64, 3, pad=1, bn_stats=True), 1e-3, relu=1)
+    x = _xception_block(plan, x, [128, 128, 128], "entry_flow_block1", "conv", 2)
+    x, skip1 = _xception_block(plan, x, [256, 256, 256], "entry_flow_block2", "conv", 2, return_skip=True)
+    x = _xception_block(plan, x, [728, 728, 728], "entry_flow_block3", "conv", b3_stride)
+    for i in range(16):
+        x = _xception_block(plan, x, [728, 728, 728], "middle_flow_unit_%d" % (i + 1), "sum", 1, rate=mid_rate)
+    x = _xception_block(plan, x, [728, 1024, 1024], "exit_flow_block1", "conv", 1, rate=exit_rates[0])
+    x = _xception_block(plan, x, [1536, 1536, 2048], "exit_flow_block2", "none", 1, rate=exit_rates[1], depth_activation=True)
+    b4 = plan.avgpool("image_pooling_pool", x, x.H)
+    b4 = plan.bn("image_pooling_BN", plan.conv("image_pooling", b4, 256, 1, bn_stats=True), 1e-5, relu=1)
+    b0 = plan.bn("aspp0_BN", plan.conv("aspp0", x, 256, 1, bn_stats=True), 1e-5, relu=1)
+    bs = [_sepconv_bn(plan, x, 256, "aspp%d" % (i + 1), rate=r, depth_activation=True, eps=1e-5) for i, r in enumerate(aspp_rates)]
+    cat = plan.concat_resize("aspp_concat", [(b4, x.H), (b0, 1)] + [(b, 1) for b in bs])
+    y = plan.bn("concat_projection_BN", plan.conv("concat_projection", cat, 256, 1, bn_stats=True), 1e-5, relu=1)
+    y = plan.dropout("dropout", y, 0.1, DEEPLAB_DROPOUT_SALT)
+    y = plan.resize_ac("decoder_upsample", y, H // 4, W // 4)
+    d = plan.bn("feature_projection0_BN", plan.conv("feature_projection0", skip1, 48, 1, bn_stats=True), 1e-5, relu=1)
+    y = plan.concat_resize("decoder_concat", [(y, 1), (d, 1)])
+    y = _sepconv_bn(plan, y, 256, "decoder_conv0", depth_activation=True, eps=1e-5)
+    y = _sepconv_bn(plan, y, 256, "decoder_conv1", depth_activation=True, eps=1e-5)
+    z = plan.conv("custom_logits_semantic", y, classes, 1, bias=True)
+    p_lo = plan.sigmoid_act("probs_lo", z)
+    probs = plan.resize_ac("logits", p_lo, H, W)
+    if with_loss:
+        target = plan.input_u8("mask", H, W, 1)
+        plan.prob_loss(probs, target, loss[0], loss[1])
+    else:
+        plan.probs_out(probs)
+    return probs
+
+
+def deeplab(plan, backbone, *args, **kw):
+    if backbone == "xception":
+        return deeplab_xception(plan, backbone, *args, **kw)
+    kw.pop("OS", None)
+    return deeplab_mobilenetv2(plan, backbone, *args, **kw)
+
+
+NETWORKS = {"DeepLabV3": deeplab, "Unet": unet_resnet, "Linknet": linknet_resnet, "FPN": fpn_resnet, "PSPNet": pspnet_resnet}

@@ -302,3 +302,26 @@ def test_four_channel_images_fit_and_predict(tmp_path):
         yaml.safe_dump(dict(base, encoder_weights="imagenet"), f)
     with pytest.raises(ValueError, match="N-channel"):
         segmentation.parse(cfg_path).createNet()
+
+
+def test_deeplabv3_xception_yaml_fits(tmp_path):
+    """``architecture: DeepLabV3`` with ``backbone: xception`` (reference impl/deeplab/model.py:338-379, custom_models at
+    segmentation.py:31-33) through parse() / fit() / predict."""
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    img_dir, msk_dir = make_dataset(str(tmp_path), n=6, size=64)
+    cfg_path = str(tmp_path / "config.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "DeepLabV3", "backbone": "xception", "OS": 16, "classes": 1, "activation": "sigmoid", "encoder_weights": None,
+                        "shape": [64, 64, 3], "optimizer": "Adam", "lr": 0.001, "batch": 2, "folds_count": 2, "loss": "binary_crossentropy",
+                        "metrics": ["binary_accuracy", "dice"], "primary_metric": "val_loss", "draw_examples": False,
+                        "stages": [{"epochs": 3}]}, f)
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
+    assert len(out) == 1
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        rows = list(csv.DictReader(f))
+    assert len(rows) == 3 and all(np.isfinite(float(r["loss"])) and np.isfinite(float(r["val_loss"])) for r in rows)
+    assert float(rows[-1]["loss"]) < float(rows[0]["loss"])
+    model = cfg.load_model(0, 0)
+    assert "middle_flow_unit_16_separable_conv3_pointwise/kernel" in model.impl.get_weights()

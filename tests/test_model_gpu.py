@@ -612,3 +612,52 @@ def test_non_default_decoder_options_match_the_oracle(arch, kw):
         assert not np.array_equal(dead, dead2)
         p1, p2 = m.predict(x), m.predict(x)
         np.testing.assert_array_equal(p1, p2)
+
+
+@pytest.mark.parametrize("OS", [16, 8])
+def test_fp32_deeplabv3_xception_step_matches_oracle(OS):
+    """The xception branch of the reference's in-tree DeepLabV3+ (impl/deeplab/model.py:338-379 entry / middle / exit flow with
+    SepConv_BN and the three skip types, :453-469 atrous SepConv ASPP, :471-491 decoder with feature_projection0), output stride
+    16 and 8: fp32 step against the oracle that follows model.py line by line (41.25 M parameters, the published size of
+    DeepLabV3+ / Xception-65), taps along the network, then the bf16 + hipGraph mode trains."""
+    from oracle import deeplab as odl
+    from segmentation_training_pipeline_amd import models
+    n, size = 2, 64
+    P = odl.init_deeplab_xception(seed=42)
+    assert abs(sum(v.size for k, v in P.items() if "moving" not in k) / 1e6 - 41.1) < 0.3
+    x, y = ostep.synthetic_batch(n, size, size, seed=21)
+    tr = ostep.OracleTrainer(P, backbone="xception", loss=LOSS, optimizer="sgd", lr=0.02, architecture="DeepLabV3", net_kwargs={"OS": OS})
+    sm = models.Deeplabv3(encoder_weights=None, input_shape=(size, size, 3), classes=1, backbone_name="xception", OS=OS, activation="sigmoid")
+    sm.compile(optimizer="SGD", loss=LOSS, lr=0.02, batch=n, dtype="fp32", use_graph=False)
+    m = sm.impl
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    taps = {}
+    o = tr.step(x.astype(np.float32), y.astype(np.float32), taps=taps)
+    m.load_batch(x, y)
+    m.forward_backward()
+    for oname, pname in (("entry_flow_block2", "entry_flow_block2_add"), ("middle_flow", "middle_flow_unit_16_add"),
+                         ("exit_flow", "exit_flow_block2_separable_conv3_pointwise_BN"), ("concat_projection", "concat_projection_BN"),
+                         ("decoder", "decoder_conv1_pointwise_BN")):
+        ref = taps[oname].detach().numpy()
+        if pname == "concat_projection_BN":
+            continue                                                             # (the Dropout that follows works in place on this buffer)
+        np.testing.assert_allclose(m.activation(pname), ref, atol=1e-3 * max(1.0, np.abs(ref).max()), err_msg=pname)
+    m.apply_gradients()
+    met = m.metrics()
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=2.5e-4)              # probabilities: 1e-3 on logits ~ 2.5e-4 on p
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+    g = m.get_gradients()
+    assert rel_l2(g["custom_logits_semantic/kernel"], o["grads"]["custom_logits_semantic/kernel"]) < 1e-4
+    for k in ("decoder_conv1_pointwise/kernel", "feature_projection0/kernel", "aspp2_depthwise/depthwise_kernel", "exit_flow_block1_shortcut/kernel",
+              "middle_flow_unit_8_separable_conv2_pointwise/kernel", "entry_flow_block2_separable_conv2_depthwise/depthwise_kernel",
+              "entry_flow_conv1_1/kernel"):
+        e = np.linalg.norm(g[k].astype(np.float64) - o["grads"][k]) / (np.linalg.norm(o["grads"][k].astype(np.float64)) + 1e-3)
+        assert e <= 8e-2, "grad %s: rel L2 %.3g" % (k, e)
+    mb = models.Deeplabv3(encoder_weights=None, input_shape=(size, size, 3), classes=1, backbone_name="xception", OS=OS, activation="sigmoid")
+    mb.compile(optimizer="Adam", loss=LOSS, lr=1e-3, batch=n, dtype="bf16")
+    mb.impl.set_weights(P)
+    l0 = mb.impl.train_on_batch(x, y)["loss"]
+    for _ in range(12):
+        l1 = mb.impl.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0, (l0, l1)
