@@ -26,8 +26,8 @@ Supported augmenters (YAML name -> effect):
   containers: Sequential, Sometimes{p, then_list}, OneOf.
   neighbourhood filters (a second kernel, ``stp_filter_u8``, on the augmented batch at the network resolution, after the
     point operations; up to MAX_FILTERS per image, in the listed order): GaussianBlur{sigma}, AverageBlur{k},
-    MedianBlur{k}, Sharpen{alpha, lightness}, Emboss{alpha, strength}, EdgeDetect{alpha}.
-PiecewiseAffine, ElasticTransformation, DirectedEdgeDetect and BackgroundReplacer raise ``ValueError`` naming the
+    MedianBlur{k}, Sharpen{alpha, lightness}, Emboss{alpha, strength}, EdgeDetect{alpha}, DirectedEdgeDetect{alpha, direction}.
+PiecewiseAffine, ElasticTransformation and BackgroundReplacer raise ``ValueError`` naming the
 augmenter (no silent skipping).
 """
 import math
@@ -240,7 +240,7 @@ def _apply(spec, rng, pl):
                 sp.flags |= F_DROP_PC
         elif name == "Grayscale":
             pl.point(R_GRAY).gray = _rng_range(rng, _arg(args, "alpha", 1.0), 1.0)
-        elif name in ("GaussianBlur", "AverageBlur", "MedianBlur", "Sharpen", "Emboss", "EdgeDetect"):
+        elif name in ("GaussianBlur", "AverageBlur", "MedianBlur", "Sharpen", "Emboss", "EdgeDetect", "DirectedEdgeDetect"):
             f = _filter(name, args, rng)
             if f is not None:
                 if not pl.strict and len(pl.cur.filters) >= MAX_FILTERS:
@@ -297,6 +297,21 @@ def _filter(name, args, rng):
     elif name == "Emboss":
         st = _rng_range(rng, _arg(args, "strength", 1.0) if isinstance(args, dict) else None, 1.0)
         eff = np.array([[-1 - st, 0 - st, 0], [0 - st, 1, 0 + st], [0, 0 + st, 1 + st]], np.float64)
+    elif name == "DirectedEdgeDetect":
+        # imgaug 0.3.0 convolutional.DirectedEdgeDetect: every neighbour cell is weighted by (1 - angle to the sampled direction
+        # / 180 deg)^4, the weights normalised to sum 1 and negated, the centre is 1 (schemas/augmenters.raml:118-121)
+        direction = _rng_range(rng, _arg(args, "direction", (0.0, 1.0)) if isinstance(args, dict) else (0.0, 1.0), 0.0)
+        rad = np.deg2rad(int(direction * 360) % 360)
+        dvec = np.array([np.cos(rad - 0.5 * np.pi), np.sin(rad - 0.5 * np.pi)])
+        eff = np.zeros((3, 3), np.float64)
+        for cx in (-1, 0, 1):
+            for cy in (-1, 0, 1):
+                if (cx, cy) != (0, 0):
+                    cell = np.array([cx, cy], np.float64)
+                    ang = np.degrees(np.arccos(np.clip(np.dot(cell / np.linalg.norm(cell), dvec / np.linalg.norm(dvec)), -1.0, 1.0)))
+                    eff[cy + 1, cx + 1] = (1.0 - ang / 180.0) ** 4
+        eff = -eff / eff.sum()
+        eff[1, 1] = 1.0
     else:
         eff = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], np.float64)
     if alpha <= 0:

@@ -189,6 +189,13 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     with pytest.raises(ValueError, match="more than 2"):
         augment.sample_batch_ex([{"AverageBlur": 3}] * 3, rng, 1, 8, 8, (8, 8))
     assert pipeline.aug_list({"Fliplr": 0.5, "Flipud": 0.5}) == [{"Fliplr": 0.5}, {"Flipud": 0.5}]
+    # DirectedEdgeDetect (schemas/augmenters.raml:118-121): neighbours weighted towards the direction, summing to -1 around a centre 1
+    _, f = augment.sample_batch_ex([{"DirectedEdgeDetect": {"alpha": 1.0, "direction": 0.0}}], rng, 1, 8, 8, (8, 8))
+    k = f[0, 0, 4:13].reshape(3, 3).astype(np.float64) / 16384.0
+    assert f[0, 0, 0] == 3 and abs(k[1, 1] - 1.0) < 1e-3 and abs(k.sum()) < 1e-3 and k[0, 1] < -0.5 < k[2, 1] <= 0     # direction 0 = "up": the cell above weighs most
+    _, f2 = augment.sample_batch_ex([{"DirectedEdgeDetect": {"alpha": 0.5, "direction": 0.25}}], rng, 1, 8, 8, (8, 8))
+    k2 = f2[0, 0, 4:13].reshape(3, 3).astype(np.float64) / 16384.0
+    assert abs(k2.sum() - 0.5) < 1e-3 and k2[1, 2] < -0.25 < k2[1, 0] <= 0                                                 # a quarter turn: the cell to the right
 
 
 def test_augmentation_passes_follow_the_listed_order():
