@@ -306,6 +306,12 @@ int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W,
 size_t stp_resize_bilinear_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor);
 int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
                             int32_t coff, int32_t dtype, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* ResizeImage(factor, interpolation='nearest') (= UpSampling2D(factor)) with the same slice addressing, and its gradient (the sum of
+ * the factor x factor outputs of every input pixel). */
+int stp_resize_nearest(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo, int32_t coff,
+                       int32_t dtype, void* stream);
+int stp_resize_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo, int32_t coff,
+                           int32_t dtype, int32_t accumulate, void* stream);
 
 /* Bias gradient: out[c] (+)= sum over rows of x[rows][C]; and the in-place tensor add used where two
  * gradient paths meet outside a GEMM epilogue.  workspace as for stp_bn_stats. */

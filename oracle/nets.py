@@ -222,7 +222,11 @@ def _spatial_dropout(y, rate, step):
     return y * torch.from_numpy(keep.astype(np.float32)) / (1.0 - rate)
 
 
-def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, dropout=None, step=1):
+def _resize(x, f, interpolation):
+    return F.interpolate(x, scale_factor=f, mode="nearest") if (interpolation == "nearest" and f > 1) else resize_bilinear_tf1(x, f)
+
+
+def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, dropout=None, step=1, interpolation="bilinear"):
     """Pyramid over [encoder output, stage4/3/2 unit-1 relu1]: lateral Conv2D 1x1 (bias) + UpSampling2D(2) of the level above,
     two (Conv2D 3x3 no bias, BN, ReLU) per level; the maps resized to 1/4 resolution, concatenated finest first,
     Conv 3x3 + BN + ReLU (4 x 128 filters), Conv2D 3x3 to the classes, bilinear x4.  Returns (logits_nhwc, bn_updates)."""
@@ -240,12 +244,12 @@ def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
         ctx.tap(pre + "out", p)
         m = lat
         pyramid.append(p)
-    cat = torch.cat([resize_bilinear_tf1(p, f) for p, f in zip(pyramid[::-1], (1, 2, 4, 8))], dim=1)
+    cat = torch.cat([_resize(p, f, interpolation) for p, f in zip(pyramid[::-1], (1, 2, 4, 8))], dim=1)
     y = _bn_apply(ctx, _conv(ctx, cat, "fpn_final", pad=1), "fpn_final_bn", BN_EPS_DECODER, relu=True)
     if dropout and training:
         y = _spatial_dropout(y, float(dropout), step)
     lo = _conv(ctx, y, "final_conv", pad=1)
-    return resize_bilinear_tf1(lo, 4).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+    return _resize(lo, 4, interpolation).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
 PSP_STAGE = {4: 2, 8: 3, 16: 4}     # downsample_factor -> the stage whose unit1_relu1 is the feature (schemas/segmentation.raml:228-230)
@@ -270,7 +274,8 @@ def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_fi
     return P
 
 
-def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8, dropout=None, step=1):
+def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8, dropout=None, step=1,
+                          final_interpolation="bilinear"):
     """feature = stage3_unit1_relu1; for level in 1, 2, 3, 6: AveragePooling2D(size / level) -> Conv 1x1 (no bias) -> BN ->
     ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
     classes; bilinear x8.  Returns (logits_nhwc, bn_updates)."""
@@ -289,7 +294,7 @@ def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=No
     if dropout and training:
         y = _spatial_dropout(y, float(dropout), step)
     lo = _conv(ctx, y, "final_conv", pad=1)
-    return resize_bilinear_tf1(lo, int(downsample_factor)).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+    return _resize(lo, int(downsample_factor), final_interpolation).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
 ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1/", "block")

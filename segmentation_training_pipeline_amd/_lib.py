@@ -95,6 +95,8 @@ SIGNATURES = {
     "stp_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_resize_bilinear_bwd_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "stp_resize_bilinear_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "stp_resize_nearest": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_resize_nearest_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_channel_sum": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
     "stp_add_inplace": (i32, [vp, vp, i64, i32, vp]),
     "stp_loss_workspace_bytes": (sz, []),

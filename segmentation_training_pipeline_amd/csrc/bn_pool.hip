@@ -1732,6 +1732,59 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
 }
 
 // ------------------------------------------------------------------------------------------
+// ResizeImage(factor, interpolation='nearest') = UpSampling2D(factor): y[n, yo, xo, coff + c] = x[n, yo / f, xo / f, c]; the
+// gradient sums the f x f outputs of an input pixel in row-major order (segmentation_models' FPN `interpolation: nearest`, PSPNet
+// `final_interpolation: nearest`, schemas/segmentation.raml:196-199, 245-248)
+template <typename T>
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int f,
+                                                             int ldo, int coff) {
+  const int Ho = H * f, Wo = W * f;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), n = (int)(p / ((int64_t)Wo * Ho));
+    y[p * ldo + coff + c] = x[(((int64_t)n * H + yo / f) * W + xo / f) * C + c];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_nearest_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C,
+                                                                 int f, int ldo, int coff, int accumulate) {
+  const int Wo = W * f, Ho = H * f;
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int xi = (int)(p % W), yi = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+    float s = 0.f;
+    for (int a = 0; a < f; ++a)
+      for (int b = 0; b < f; ++b) s += Elem<T>::load(dy + (((int64_t)n * Ho + yi * f + a) * Wo + xi * f + b) * ldo + coff + c);
+    if (accumulate) s += Elem<T>::load(dx + i);
+    Elem<T>::store(dx + i, s);
+  }
+}
+extern "C" int stp_resize_nearest(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo, int32_t coff,
+                                  int32_t dtype, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * H * factor * W * factor * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_nearest_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(resize_nearest_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, factor, ldo, coff);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+extern "C" int stp_resize_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
+                                      int32_t coff, int32_t dtype, int32_t accumulate, void* stream) {
+  if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * H * W * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_nearest_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(resize_nearest_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, factor, ldo, coff, accumulate);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // per-channel sums of a [rows][C] tensor (bias gradient) and dst += src
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* partial, int blocks, int C, float* out,
                                                               int accumulate) {

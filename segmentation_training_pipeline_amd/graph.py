@@ -817,9 +817,9 @@ class Plan(object):
         self._tape.append(back)
         return out
 
-    def concat_resize(self, name, parts):
-        """``Concatenate()([ResizeImage(f_i, 'bilinear')(t_i) ...])``: every part is resized (TF 1.x bilinear, integer
-        factor; 1 = copy) straight into its channel slice of the output."""
+    def concat_resize(self, name, parts, nearest=False):
+        """``Concatenate()([ResizeImage(f_i, interpolation)(t_i) ...])``: every part is resized (TF 1.x bilinear, or nearest;
+        integer factor; 1 = copy) straight into its channel slice of the output."""
         Ho, Wo = parts[0][0].H * parts[0][1], parts[0][0].W * parts[0][1]
         if any((t.H * f, t.W * f) != (Ho, Wo) for t, f in parts):
             raise StpShapeError("%s: resized parts differ in size" % name)
@@ -830,7 +830,8 @@ class Plan(object):
             return out
         off = 0
         for t, f in parts:
-            self._emit(self.fwd, "stp_resize_bilinear", t.buf.data_ptr(), out.buf.data_ptr(), self.N, t.H, t.W, t.C, f, Ct, off, self.cdt)
+            self._emit(self.fwd, "stp_resize_nearest" if nearest else "stp_resize_bilinear", t.buf.data_ptr(), out.buf.data_ptr(), self.N, t.H,
+                       t.W, t.C, f, Ct, off, self.cdt)
             off += t.C
         if not self.training:
             return out
@@ -840,7 +841,11 @@ class Plan(object):
                 return
             o = 0
             for t, f in parts:
-                if t.needs_grad:
+                if t.needs_grad and nearest:
+                    self._emit(self.bwd, "stp_resize_nearest_bwd", out.grad.data_ptr(), self._gradbuf(t).data_ptr(), self.N, t.H, t.W,
+                               t.C, f, out.gradC, o, self.cdt, int(t.grad_ready))
+                    t.grad_ready = True
+                elif t.needs_grad:
                     wp, wb = self._scratch(self.lib.stp_resize_bilinear_bwd_workspace_bytes(self.N, t.H, t.W, t.C, f))
                     self._emit(self.bwd, "stp_resize_bilinear_bwd", out.grad.data_ptr(), self._gradbuf(t).data_ptr(), self.N, t.H, t.W,
                                t.C, f, out.gradC, o, self.cdt, int(t.grad_ready), wp, wb)
@@ -850,19 +855,25 @@ class Plan(object):
         self._tape.append(back)
         return out
 
-    def resize(self, name, x, factor):
-        """``ResizeImage(factor, 'bilinear')`` of a tensor whose gradient carries padded channels (the class logits)."""
+    def resize(self, name, x, factor, nearest=False):
+        """``ResizeImage(factor, 'bilinear' | 'nearest')`` of a tensor whose gradient carries padded channels (the class logits)."""
         out = self._new(name, x.H * factor, x.W * factor, x.C, x.needs_grad)
         out.gradC = x.gradC
         self._use(x)
         if self.dry:
             return out
-        self._emit(self.fwd, "stp_resize_bilinear", x.buf.data_ptr(), out.buf.data_ptr(), self.N, x.H, x.W, x.C, factor, x.C, 0, self.cdt)
+        self._emit(self.fwd, "stp_resize_nearest" if nearest else "stp_resize_bilinear", x.buf.data_ptr(), out.buf.data_ptr(), self.N, x.H, x.W,
+                   x.C, factor, x.C, 0, self.cdt)
         if not self.training:
             return out
 
         def back():
             if not (x.needs_grad and out.grad_ready):
+                return
+            if nearest:
+                self._emit(self.bwd, "stp_resize_nearest_bwd", out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.gradC,
+                           factor, x.gradC, 0, self.cdt, int(x.grad_ready))
+                x.grad_ready = True
                 return
             wp, wb = self._scratch(self.lib.stp_resize_bilinear_bwd_workspace_bytes(self.N, x.H, x.W, x.gradC, factor))
             self._emit(self.bwd, "stp_resize_bilinear_bwd", out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.gradC,

@@ -126,14 +126,15 @@ def FPN(backbone_name="vgg16", input_shape=(None, None, 3), classes=21, activati
     """segmentation_models.FPN keyword surface (schemas/segmentation.raml:180-203)."""
     if backbone_name not in nets.RESNET_UNITS:
         raise ValueError("Unknown backbone")
-    if fpn_layers != "default" or tuple(upsample_rates) != (2, 2, 2) or int(last_upsample) != 4 or interpolation != "bilinear" \
+    if fpn_layers != "default" or tuple(upsample_rates) != (2, 2, 2) or int(last_upsample) != 4 or interpolation not in ("bilinear", "nearest") \
             or not use_batchnorm or (dropout and not 0.0 < float(dropout) < 1.0):
         raise ValueError("the HIP FPN implements the x2-rate pyramid ending at 1/4 resolution with bilinear resizes and BatchNorm")
     pf, sf = int(pyramid_block_filters), int(segmentation_block_filters)
     if pf % 8 or sf % 8 or pf <= 0 or sf <= 0:
         raise ValueError("pyramid_block_filters / segmentation_block_filters must be multiples of 8")
     m = SegModel("FPN", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
-    m.net_kwargs = {"pyramid_block_filters": pf, "segmentation_block_filters": sf, "dropout": float(dropout) if dropout else None}
+    m.net_kwargs = {"pyramid_block_filters": pf, "segmentation_block_filters": sf, "dropout": float(dropout) if dropout else None,
+                    "interpolation": interpolation}
     return m
 
 
@@ -143,14 +144,14 @@ def PSPNet(backbone_name="vgg16", input_shape=(384, 384, 3), classes=21, activat
     """segmentation_models.PSPNet keyword surface (schemas/segmentation.raml:225-249)."""
     if backbone_name not in nets.RESNET_UNITS:
         raise ValueError("Unknown backbone")
-    if int(downsample_factor) not in (4, 8, 16) or psp_pooling_type != "avg" or not use_batchnorm or final_interpolation != "bilinear" \
+    if int(downsample_factor) not in (4, 8, 16) or psp_pooling_type != "avg" or not use_batchnorm or final_interpolation not in ("bilinear", "nearest") \
             or (dropout and not 0.0 < float(dropout) < 1.0):
         raise ValueError("the HIP PSPNet implements downsample_factor 4 / 8 / 16 with average pooling, BatchNorm and the bilinear final resize")
     if int(psp_conv_filters) % 8 or int(psp_conv_filters) <= 0:
         raise ValueError("psp_conv_filters must be a multiple of 8")
     m = SegModel("PSPNet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
     m.net_kwargs = {"downsample_factor": int(downsample_factor), "psp_conv_filters": int(psp_conv_filters),
-                    "dropout": float(dropout) if dropout else None}
+                    "dropout": float(dropout) if dropout else None, "final_interpolation": final_interpolation}
     return m
 
 

@@ -140,7 +140,7 @@ def linknet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(No
 
 
 def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True,
-               pyramid_block_filters=256, segmentation_block_filters=128, last_upsample=4, dropout=None):
+               pyramid_block_filters=256, segmentation_block_filters=128, last_upsample=4, dropout=None, interpolation="bilinear"):
     """segmentation_models 0.2.1 ``FPN(..., upsample_rates=(2,2,2), interpolation='bilinear', use_batchnorm=True)``
     (``schemas/segmentation.raml:180-203``).  Pyramid over [encoder output, stage4/3/2 unit1 relu1]: 1x1 lateral conv (+ the
     2x nearest upsampling of the level above), two conv3x3+BN+ReLU segmentation convs per level; the four maps are resized
@@ -159,12 +159,13 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
         p = plan.bn(pre + "segm2_bn", plan.conv(pre + "segm2", p, sf, 3, pad=1, bn_stats=True), BN_EPS_DECODER, relu=True)
         m = lat
         pyramid.append(p)
-    cat = plan.concat_resize("fpn_concat", [(pyramid[3], 1), (pyramid[2], 2), (pyramid[1], 4), (pyramid[0], 8)])
+    near = interpolation == "nearest"
+    cat = plan.concat_resize("fpn_concat", [(pyramid[3], 1), (pyramid[2], 2), (pyramid[1], 4), (pyramid[0], 8)], nearest=near)
     y = plan.bn("fpn_final_bn", plan.conv("fpn_final", cat, sf * 4, 3, pad=1, bn_stats=True), BN_EPS_DECODER, relu=True)
     if dropout:       # SpatialDropout2D between the final block and the class convolution (segmentation_models 0.2.1 fpn builder)
         y = plan.dropout("fpn_dropout", y, float(dropout), DECODER_DROPOUT_SALT, spatial=True)
     lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
-    logits = plan.resize("logits", lo, 4)
+    logits = plan.resize("logits", lo, 4, nearest=near)
     if with_loss:
         target = plan.input_u8("mask", H, W, 1)
         (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, loss[0], loss[1])
@@ -172,7 +173,7 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
 
 
 def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True,
-                  downsample_factor=8, psp_conv_filters=512, dropout=None):
+                  downsample_factor=8, psp_conv_filters=512, dropout=None, final_interpolation="bilinear"):
     """segmentation_models 0.2.1 ``PSPNet(downsample_factor=8, psp_conv_filters=512, psp_pooling_type='avg', use_batchnorm=True,
     final_interpolation='bilinear')`` (``schemas/segmentation.raml:225-249``): the backbone is cut at the 1/8 feature
     (stage3_unit1_relu1; 1/4: stage2, 1/16: stage4); pyramid pooling levels 1, 2, 3, 6 = AveragePooling2D(size/level) ->
@@ -195,7 +196,7 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
     if dropout:       # SpatialDropout2D between the final block and the class convolution (segmentation_models 0.2.1 psp builder)
         y = plan.dropout("psp_dropout", y, float(dropout), DECODER_DROPOUT_SALT, spatial=True)
     lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
-    logits = plan.resize("logits", lo, int(downsample_factor))
+    logits = plan.resize("logits", lo, int(downsample_factor), nearest=final_interpolation == "nearest")
     if with_loss:
         target = plan.input_u8("mask", H, W, 1)
         (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, loss[0], loss[1])

@@ -567,7 +567,9 @@ def test_n_channel_inputs_match_the_oracle(backbone, in_ch):
 @pytest.mark.parametrize("arch,kw", [("PSPNet", {"downsample_factor": 4, "psp_conv_filters": 128}), ("PSPNet", {"downsample_factor": 16}),
                                      ("FPN", {"pyramid_block_filters": 128, "segmentation_block_filters": 64}),
                                      ("FPN", {"pyramid_block_filters": 256, "segmentation_block_filters": 128, "dropout": 0.3}),
-                                     ("PSPNet", {"downsample_factor": 8, "dropout": 0.25})])
+                                     ("PSPNet", {"downsample_factor": 8, "dropout": 0.25}),
+                                     ("FPN", {"pyramid_block_filters": 256, "segmentation_block_filters": 128, "interpolation": "nearest"}),
+                                     ("PSPNet", {"downsample_factor": 8, "final_interpolation": "nearest"})])
 def test_non_default_decoder_options_match_the_oracle(arch, kw):
     """schemas/segmentation.raml:179-249: PSPNet ``downsample_factor`` 4 / 16 (feature = stage2 / stage4 unit1_relu1, final resize
     x4 / x16) and ``psp_conv_filters``; FPN ``pyramid_block_filters`` / ``segmentation_block_filters``.  fp32 step at the north-star
@@ -578,12 +580,12 @@ def test_non_default_decoder_options_match_the_oracle(arch, kw):
         f = kw["downsample_factor"]
         size = 6 * f * (2 if f == 4 else 1)                                   # feature map 12x12 (1/4) or 6x6 (1/16)
         P = onets.init_pspnet_resnet("resnet18", seed=42, conv_filters=kw.get("psp_conv_filters", 512), downsample_factor=f)
-        okw = {"downsample_factor": f, "dropout": kw.get("dropout")}
+        okw = {"downsample_factor": f, "dropout": kw.get("dropout"), "final_interpolation": kw.get("final_interpolation", "bilinear")}
         ctor = models.PSPNet
     else:
         size = 64
         P = onets.init_fpn_resnet("resnet18", seed=42, pyramid_filters=kw["pyramid_block_filters"], segmentation_filters=kw["segmentation_block_filters"])
-        okw = {"dropout": kw.get("dropout")}
+        okw = {"dropout": kw.get("dropout"), "interpolation": kw.get("interpolation", "bilinear")}
         ctor = models.FPN
     x, y = ostep.synthetic_batch(n, size, size, seed=8)
     tr = ostep.OracleTrainer(P, backbone="resnet18", loss=LOSS, optimizer="sgd", lr=0.02, architecture=arch, net_kwargs=okw)
