@@ -281,6 +281,11 @@ int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t
                 size_t workspace_bytes, void* stream);
 int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
                     int32_t accumulate, void* stream);
+/* MaxPooling2D(pool_size = strides = k), any k dividing H and W (PSPNet `psp_pooling_type: max`): idx[N,H/k,W/k,C] int32 = position of the
+ * first maximum inside its window (NULL = not wanted); the gradient goes to that position. */
+int stp_maxpool_k(const void* x, void* y, int32_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* stream);
+int stp_maxpool_k_bwd(const int32_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
+                      int32_t accumulate, void* stream);
 /* dy <- dy * [y > 0] in place (gradient of a ReLU fused into a convolution epilogue); count % 4 == 0 */
 int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* stream);
 

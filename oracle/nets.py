@@ -275,7 +275,7 @@ def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_fi
 
 
 def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8, dropout=None, step=1,
-                          final_interpolation="bilinear"):
+                          final_interpolation="bilinear", psp_pooling_type="avg"):
     """feature = stage3_unit1_relu1; for level in 1, 2, 3, 6: AveragePooling2D(size / level) -> Conv 1x1 (no bias) -> BN ->
     ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
     classes; bilinear x8.  Returns (logits_nhwc, bn_updates)."""
@@ -286,7 +286,7 @@ def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=No
     parts = [f]
     for level in (1, 2, 3, 6):
         k = f.shape[2] // level
-        p = F.avg_pool2d(f, kernel_size=k, stride=k)
+        p = (F.max_pool2d if psp_pooling_type == "max" else F.avg_pool2d)(f, kernel_size=k, stride=k)
         p = _bn_apply(ctx, _conv(ctx, p, "psp_level%d_conv" % level), "psp_level%d_bn" % level, BN_EPS_DECODER, relu=True)
         ctx.tap("psp_level%d_out" % level, p)
         parts.append(resize_bilinear_tf1(p, k))

@@ -87,6 +87,8 @@ SIGNATURES = {
     "stp_avgpool_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "stp_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "stp_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_maxpool_k": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_maxpool_k_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_relu_bwd": (i32, [vp, vp, i64, i32, vp]),
     "stp_upsample2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_upsample2x_bwd_bn_tiles": (i32, [i32, i32, i32, i32, i32, i32]),

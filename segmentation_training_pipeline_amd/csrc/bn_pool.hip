@@ -1732,6 +1732,67 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
 }
 
 // ------------------------------------------------------------------------------------------
+// MaxPooling2D(pool_size = strides = k) for any k (PSPNet `psp_pooling_type: max`, schemas/segmentation.raml:233-236): one thread
+// per (output pixel, channel), channels fastest (coalesced); idx = position kh * k + kw of the FIRST maximum (int32, k up to the
+// whole map); the gradient goes to that position only (windows do not overlap: one thread per input element, no atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_k_kernel(const T* __restrict__ x, T* __restrict__ y, int32_t* __restrict__ idx, int N, int H, int W,
+                                                        int C, int k) {
+  const int Ho = H / k, Wo = W / k;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), n = (int)(p / ((int64_t)Wo * Ho));
+    const T* b = x + (((int64_t)n * H + yo * k) * W + xo * k) * C + c;
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int a = 0; a < k; ++a)
+      for (int q = 0; q < k; ++q) {
+        const float v = Elem<T>::load(b + ((int64_t)a * W + q) * C);
+        if (v > best) { best = v; bi = a * k + q; }
+      }
+    Elem<T>::store(y + i, best);
+    if (idx) idx[i] = bi;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_k_bwd_kernel(const int32_t* __restrict__ idx, const T* __restrict__ dy, T* __restrict__ dx, int N,
+                                                            int H, int W, int C, int k, int accumulate) {
+  const int Ho = H / k, Wo = W / k;
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int xi = (int)(p % W), yi = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+    const int64_t o = (((int64_t)n * Ho + yi / k) * Wo + xi / k) * C + c;
+    float g = (idx[o] == (yi % k) * k + (xi % k)) ? Elem<T>::load(dy + o) : 0.f;
+    if (accumulate) g += Elem<T>::load(dx + i);
+    Elem<T>::store(dx + i, g);
+  }
+}
+extern "C" int stp_maxpool_k(const void* x, void* y, int32_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
+                             void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * (H / k) * (W / k) * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(maxpool_k_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, k);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(maxpool_k_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, N, H, W, C, k);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+extern "C" int stp_maxpool_k_bwd(const int32_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
+                                 int32_t dtype, int32_t accumulate, void* stream) {
+  if (!idx || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
+  const int g = grid_for((int64_t)N * H * W * C);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(maxpool_k_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(maxpool_k_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, idx, (const float*)dy, (float*)dx, N, H, W, C, k, accumulate);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // ResizeImage(factor, interpolation='nearest') = UpSampling2D(factor): y[n, yo, xo, coff + c] = x[n, yo / f, xo / f, c]; the
 // gradient sums the f x f outputs of an input pixel in row-major order (segmentation_models' FPN `interpolation: nearest`, PSPNet
 // `final_interpolation: nearest`, schemas/segmentation.raml:196-199, 245-248)

@@ -1051,6 +1051,30 @@ class Plan(object):
         self._tape.append(back)
         return out
 
+    def maxpool_k(self, name, x, k):
+        """MaxPooling2D(pool_size = strides = k) (PSPNet ``psp_pooling_type: max``)."""
+        if x.H % k or x.W % k:
+            raise StpShapeError("%s: %dx%d is not divisible by the pooling size %d" % (name, x.H, x.W, k))
+        out = self._new(name, x.H // k, x.W // k, x.C, x.needs_grad)
+        self._use(x)
+        if self.dry:
+            return out
+        idx = self._alloc((self.N, x.H // k, x.W // k, x.C), torch.int32) if self.training else None
+        self._emit(self.fwd, "stp_maxpool_k", x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if idx is not None else None, self.N, x.H,
+                   x.W, x.C, k, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not (x.needs_grad and out.grad_ready):
+                return
+            self._emit(self.bwd, "stp_maxpool_k_bwd", idx.data_ptr(), out.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.C, k,
+                       self.cdt, int(x.grad_ready))
+            x.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
     def maxpool2(self, name, x):
         """MaxPooling2D(2, 2) without padding (VGG blocks)."""
         if x.H % 2 or x.W % 2:

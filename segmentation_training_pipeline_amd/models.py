@@ -144,14 +144,14 @@ def PSPNet(backbone_name="vgg16", input_shape=(384, 384, 3), classes=21, activat
     """segmentation_models.PSPNet keyword surface (schemas/segmentation.raml:225-249)."""
     if backbone_name not in nets.RESNET_UNITS:
         raise ValueError("Unknown backbone")
-    if int(downsample_factor) not in (4, 8, 16) or psp_pooling_type != "avg" or not use_batchnorm or final_interpolation not in ("bilinear", "nearest") \
+    if int(downsample_factor) not in (4, 8, 16) or psp_pooling_type not in ("avg", "max") or not use_batchnorm or final_interpolation not in ("bilinear", "nearest") \
             or (dropout and not 0.0 < float(dropout) < 1.0):
-        raise ValueError("the HIP PSPNet implements downsample_factor 4 / 8 / 16 with average pooling, BatchNorm and the bilinear final resize")
+        raise ValueError("the HIP PSPNet implements downsample_factor 4 / 8 / 16, avg / max pooling, BatchNorm, bilinear / nearest final resize")
     if int(psp_conv_filters) % 8 or int(psp_conv_filters) <= 0:
         raise ValueError("psp_conv_filters must be a multiple of 8")
     m = SegModel("PSPNet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
     m.net_kwargs = {"downsample_factor": int(downsample_factor), "psp_conv_filters": int(psp_conv_filters),
-                    "dropout": float(dropout) if dropout else None, "final_interpolation": final_interpolation}
+                    "dropout": float(dropout) if dropout else None, "final_interpolation": final_interpolation, "psp_pooling_type": psp_pooling_type}
     return m
 
 

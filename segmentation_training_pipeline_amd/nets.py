@@ -173,7 +173,7 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
 
 
 def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, loss=(1.0, 1.0), with_loss=True,
-                  downsample_factor=8, psp_conv_filters=512, dropout=None, final_interpolation="bilinear"):
+                  downsample_factor=8, psp_conv_filters=512, dropout=None, final_interpolation="bilinear", psp_pooling_type="avg"):
     """segmentation_models 0.2.1 ``PSPNet(downsample_factor=8, psp_conv_filters=512, psp_pooling_type='avg', use_batchnorm=True,
     final_interpolation='bilinear')`` (``schemas/segmentation.raml:225-249``): the backbone is cut at the 1/8 feature
     (stage3_unit1_relu1; 1/4: stage2, 1/16: stage4); pyramid pooling levels 1, 2, 3, 6 = AveragePooling2D(size/level) ->
@@ -188,7 +188,7 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
     for level in (1, 2, 3, 6):
         k = f.H // level
         pre = "psp_level%d_" % level
-        p = plan.avgpool(pre + "pool", f, k)
+        p = (plan.maxpool_k if psp_pooling_type == "max" else plan.avgpool)(pre + "pool", f, k)
         p = plan.bn(pre + "bn", plan.conv(pre + "conv", p, int(psp_conv_filters), 1, bn_stats=True), BN_EPS_DECODER, relu=True)
         parts.append((p, k))
     cat = plan.concat_resize("psp_concat", parts)

@@ -569,7 +569,8 @@ def test_n_channel_inputs_match_the_oracle(backbone, in_ch):
                                      ("FPN", {"pyramid_block_filters": 256, "segmentation_block_filters": 128, "dropout": 0.3}),
                                      ("PSPNet", {"downsample_factor": 8, "dropout": 0.25}),
                                      ("FPN", {"pyramid_block_filters": 256, "segmentation_block_filters": 128, "interpolation": "nearest"}),
-                                     ("PSPNet", {"downsample_factor": 8, "final_interpolation": "nearest"})])
+                                     ("PSPNet", {"downsample_factor": 8, "final_interpolation": "nearest"}),
+                                     ("PSPNet", {"downsample_factor": 8, "psp_pooling_type": "max"})])
 def test_non_default_decoder_options_match_the_oracle(arch, kw):
     """schemas/segmentation.raml:179-249: PSPNet ``downsample_factor`` 4 / 16 (feature = stage2 / stage4 unit1_relu1, final resize
     x4 / x16) and ``psp_conv_filters``; FPN ``pyramid_block_filters`` / ``segmentation_block_filters``.  fp32 step at the north-star
@@ -580,7 +581,8 @@ def test_non_default_decoder_options_match_the_oracle(arch, kw):
         f = kw["downsample_factor"]
         size = 6 * f * (2 if f == 4 else 1)                                   # feature map 12x12 (1/4) or 6x6 (1/16)
         P = onets.init_pspnet_resnet("resnet18", seed=42, conv_filters=kw.get("psp_conv_filters", 512), downsample_factor=f)
-        okw = {"downsample_factor": f, "dropout": kw.get("dropout"), "final_interpolation": kw.get("final_interpolation", "bilinear")}
+        okw = {"downsample_factor": f, "dropout": kw.get("dropout"), "final_interpolation": kw.get("final_interpolation", "bilinear"),
+               "psp_pooling_type": kw.get("psp_pooling_type", "avg")}
         ctor = models.PSPNet
     else:
         size = 64
