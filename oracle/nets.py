@@ -133,13 +133,16 @@ def _init_unet_vgg(rng, backbone, in_ch, classes, decoder_filters, decoder_block
     return P
 
 
-def _vgg_encoder(ctx, x_nhwc, backbone):
+def _vgg_encoder(ctx, x_nhwc, backbone, stop_block=None):
+    """``stop_block``: return the last convolution of that block (PSPNet's feature) instead of (block5_pool, skips)."""
     x = x_nhwc.permute(0, 3, 1, 2)
     skips = []
     for b, n_conv in enumerate(VGG_BLOCKS[backbone], start=1):
         for c in range(1, n_conv + 1):
             x = F.relu(_conv(ctx, x, "block%d_conv%d" % (b, c), pad=1))
         ctx.tap("block%d_out" % b, x)
+        if stop_block == b:
+            return x
         skips.append(x)
         x = F.max_pool2d(x, kernel_size=2, stride=2)
     return x, skips[::-1]
@@ -175,8 +178,11 @@ def init_fpn_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, pyramid_fi
     full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
     P = OrderedDict((k, v) for k, v in full.items() if not (k.startswith("decoder_") or k.startswith("final_")))
     rng = np.random.RandomState(seed + 2)
-    ex = expansion(backbone)
-    level_ch = (STAGE_FILTERS[3] * ex, STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex)
+    if backbone in VGG_BLOCKS:       # pyramid over block5_pool and the skip layers block5 / block4 / block3 (last convolution of the block)
+        level_ch = (VGG_FILTERS[4], VGG_FILTERS[4], VGG_FILTERS[3], VGG_FILTERS[2])
+    else:
+        ex = expansion(backbone)
+        level_ch = (STAGE_FILTERS[3] * ex, STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex)
     for i, c in enumerate(level_ch):
         pre = "fpn_stage%d_" % i
         P[pre + "lateral/kernel"] = _glorot_uniform(rng, (1, 1, c, pyramid_filters))
@@ -231,8 +237,12 @@ def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
     two (Conv2D 3x3 no bias, BN, ReLU) per level; the maps resized to 1/4 resolution, concatenated finest first,
     Conv 3x3 + BN + ReLU (4 x 128 filters), Conv2D 3x3 to the classes, bilinear x4.  Returns (logits_nhwc, bn_updates)."""
     ctx = _Ctx(P, training, taps)
-    x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
-    levels = (x, skips["stage4_unit1_relu1"], skips["stage3_unit1_relu1"], skips["stage2_unit1_relu1"])
+    if backbone in VGG_BLOCKS:
+        x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
+        levels = (x, sk[0], sk[1], sk[2])
+    else:
+        x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
+        levels = (x, skips["stage4_unit1_relu1"], skips["stage3_unit1_relu1"], skips["stage2_unit1_relu1"])
     m, pyramid = None, []
     for i, c in enumerate(levels):
         pre = "fpn_stage%d_" % i
@@ -260,10 +270,14 @@ def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_fi
     stage<s>_unit1_relu1 (1/downsample_factor resolution; default 1/8 = stage 3) exists; see pspnet_resnet_forward."""
     full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
     st = PSP_STAGE[int(downsample_factor)]
-    keep = ("bn_data", "conv0", "bn0") + tuple("stage%d_" % i for i in range(1, st)) + ("stage%d_unit1_bn1" % st,)
+    if backbone in VGG_BLOCKS:       # feature = the last convolution of block st + 1 (1/4: block3_conv3, 1/8: block4, 1/16: block5)
+        keep = tuple("block%d_" % b for b in range(1, st + 2))
+        c = VGG_FILTERS[st]
+    else:
+        keep = ("bn_data", "conv0", "bn0") + tuple("stage%d_" % i for i in range(1, st)) + ("stage%d_unit1_bn1" % st,)
+        c = STAGE_FILTERS[st - 2] * expansion(backbone)
     P = OrderedDict((k, v) for k, v in full.items() if k.startswith(keep))
     rng = np.random.RandomState(seed + 3)
-    c = STAGE_FILTERS[st - 2] * expansion(backbone)
     for level in (1, 2, 3, 6):
         P["psp_level%d_conv/kernel" % level] = _glorot_uniform(rng, (1, 1, c, conv_filters))
         _bn(P, "psp_level%d_bn" % level, conv_filters)
@@ -280,9 +294,12 @@ def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=No
     ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
     classes; bilinear x8.  Returns (logits_nhwc, bn_updates)."""
     ctx = _Ctx(P, training, taps)
-    feat = "stage%d_unit1_relu1" % PSP_STAGE[int(downsample_factor)]
-    _, skips = _resnet_encoder(ctx, x_nhwc, backbone, stop_at=feat)
-    f = skips[feat]
+    if backbone in VGG_BLOCKS:
+        f = _vgg_encoder(ctx, x_nhwc, backbone, stop_block=PSP_STAGE[int(downsample_factor)] + 1)
+    else:
+        feat = "stage%d_unit1_relu1" % PSP_STAGE[int(downsample_factor)]
+        _, skips = _resnet_encoder(ctx, x_nhwc, backbone, stop_at=feat)
+        f = skips[feat]
     parts = [f]
     for level in (1, 2, 3, 6):
         k = f.shape[2] // level

@@ -47,8 +47,8 @@ class HipSegModel(object):
                  opt_kwargs=None, seed=42, decoder_block_type="upsampling", net_kwargs=None):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
-        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture != "Unet") \
-                or ((backbone in ("mobilenetv2", "xception")) != (architecture == "DeepLabV3")):   # VGG: U-Net only; MobileNetV2 / Xception: DeepLabV3 only
+        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture not in ("Unet", "FPN", "PSPNet")) \
+                or ((backbone in ("mobilenetv2", "xception")) != (architecture == "DeepLabV3")):   # VGG: U-Net, FPN, PSPNet; MobileNetV2 / Xception: DeepLabV3 only
             raise ValueError("Unknown backbone")
         if not ((classes == 1 and activation in ("sigmoid", None)) or (2 <= classes <= 32 and activation == "softmax")):
             raise ValueError("the HIP backend trains 1-class sigmoid heads and 2..32-class softmax heads")

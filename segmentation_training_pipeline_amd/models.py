@@ -124,7 +124,7 @@ def FPN(backbone_name="vgg16", input_shape=(None, None, 3), classes=21, activati
         freeze_encoder=False, fpn_layers="default", pyramid_block_filters=256, segmentation_block_filters=128,
         upsample_rates=(2, 2, 2), last_upsample=4, interpolation="bilinear", use_batchnorm=True, dropout=None):
     """segmentation_models.FPN keyword surface (schemas/segmentation.raml:180-203)."""
-    if backbone_name not in nets.RESNET_UNITS:
+    if backbone_name not in nets.RESNET_UNITS and backbone_name not in nets.VGG_BLOCKS:
         raise ValueError("Unknown backbone")
     if fpn_layers != "default" or tuple(upsample_rates) != (2, 2, 2) or int(last_upsample) != 4 or interpolation not in ("bilinear", "nearest") \
             or not use_batchnorm or (dropout and not 0.0 < float(dropout) < 1.0):
@@ -142,7 +142,7 @@ def PSPNet(backbone_name="vgg16", input_shape=(384, 384, 3), classes=21, activat
            freeze_encoder=False, downsample_factor=8, psp_conv_filters=512, psp_pooling_type="avg", use_batchnorm=True, dropout=None,
            final_interpolation="bilinear"):
     """segmentation_models.PSPNet keyword surface (schemas/segmentation.raml:225-249)."""
-    if backbone_name not in nets.RESNET_UNITS:
+    if backbone_name not in nets.RESNET_UNITS and backbone_name not in nets.VGG_BLOCKS:
         raise ValueError("Unknown backbone")
     if int(downsample_factor) not in (4, 8, 16) or psp_pooling_type not in ("avg", "max") or not use_batchnorm or final_interpolation not in ("bilinear", "nearest") \
             or (dropout and not 0.0 < float(dropout) < 1.0):

@@ -68,9 +68,10 @@ def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
     return x, relu0, taps
 
 
-def _vgg_encoder(plan, backbone, H, W, in_ch):
+def _vgg_encoder(plan, backbone, H, W, in_ch, stop_block=None):
     """keras.applications VGG16/VGG19 (include_top=False) fed with raw pixels; returns (block5_pool, the last conv of each
-    block = segmentation_models' skip layers block5_conv3 ... block1_conv2, deepest first)."""
+    block = segmentation_models' skip layers block5_conv3 ... block1_conv2, deepest first).  ``stop_block``: build only up to the
+    last convolution of that block and return it (PSPNet's feature layer)."""
     if H % 32 or W % 32:
         raise ValueError("input height/width must be divisible by 32")
     img = plan.input_u8("image", H, W, in_ch)
@@ -79,6 +80,8 @@ def _vgg_encoder(plan, backbone, H, W, in_ch):
     for b, (n_conv, f) in enumerate(zip(VGG_BLOCKS[backbone], VGG_FILTERS), start=1):
         for c in range(1, n_conv + 1):
             x = plan.conv("block%d_conv%d" % (b, c), x, f, 3, pad=1, bias=True, relu=True)
+        if stop_block == b:
+            return x
         skips.append(x)
         x = plan.maxpool2("block%d_pool" % b, x)
     return x, skips[::-1]
@@ -147,10 +150,15 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
     to 1/4 resolution (TF 1.x bilinear) and concatenated, conv3x3+BN+ReLU, conv3x3 to the classes, bilinear x4."""
     if last_upsample != 4:
         raise ValueError("the HIP FPN pyramid ends at 1/4 resolution: last_upsample must be 4")
-    x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
+    if backbone in VGG_BLOCKS:      # block5_pool + the skip layers block5_conv3 / block4_conv3 / block3_conv3 (README.md:587-589 backbones)
+        x, sk = _vgg_encoder(plan, backbone, H, W, in_ch)
+        levels = (x, sk[0], sk[1], sk[2])
+    else:
+        x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
+        levels = (x, taps[4], taps[3], taps[2])
     pf, sf = int(pyramid_block_filters), int(segmentation_block_filters)
     m, pyramid = None, []
-    for i, c in enumerate((x, taps[4], taps[3], taps[2])):
+    for i, c in enumerate(levels):
         pre = "fpn_stage%d_" % i
         lat = plan.conv(pre + "lateral", c, pf, 1, bias=True)
         if m is not None:
@@ -180,8 +188,11 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
     Conv 1x1 + BN + ReLU -> bilinear resize back, concatenated with the feature; Conv 1x1 + BN + ReLU; Conv 3x3 to the classes;
     bilinear x downsample_factor."""
     stage = {4: 2, 8: 3, 16: 4}[int(downsample_factor)]
-    _, _, taps = _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=stage)
-    f = taps[stage]
+    if backbone in VGG_BLOCKS:      # feature = last convolution of block3 (1/4), block4 (1/8) or block5 (1/16)
+        f = _vgg_encoder(plan, backbone, H, W, in_ch, stop_block=stage + 1)
+    else:
+        _, _, taps = _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=stage)
+        f = taps[stage]
     if f.H != f.W or f.H % 6:
         raise ValueError("PSPNet needs a square input whose 1/%d feature map is divisible by 6 (got %dx%d)" % (downsample_factor, f.H, f.W))
     parts = [(f, 1)]

@@ -665,3 +665,27 @@ def test_fp32_deeplabv3_xception_step_matches_oracle(OS):
     for _ in range(12):
         l1 = mb.impl.train_on_batch(x, y)["loss"]
     assert np.isfinite(l1) and l1 < l0, (l0, l1)
+
+
+@pytest.mark.parametrize("arch", ["FPN", "PSPNet"])
+def test_vgg16_under_fpn_and_pspnet_matches_the_oracle(arch):
+    """README.md:587-589 lists the VGG encoders for every architecture: FPN over block5_pool + block5 / block4 / block3 skip layers,
+    PSPNet over block4_conv3 (1/8).  fp32 step at the north-star bars."""
+    from segmentation_training_pipeline_amd import models
+    n, size = 2, (64 if arch == "FPN" else 96)
+    P = (onets.init_fpn_resnet if arch == "FPN" else onets.init_pspnet_resnet)("vgg16", seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=8)
+    tr = ostep.OracleTrainer(P, backbone="vgg16", loss=LOSS, optimizer="sgd", lr=0.002, architecture=arch)
+    sm = (models.FPN if arch == "FPN" else models.PSPNet)("vgg16", input_shape=(size, size, 3), classes=1, activation="sigmoid", encoder_weights=None)
+    sm.compile(optimizer="SGD", loss=LOSS, lr=0.002, batch=n, dtype="fp32", use_graph=False)
+    m = sm.impl
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3 * max(1.0, np.abs(o["logits"]).max()))
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5
+    g = m.get_gradients()
+    assert rel_l2(g["final_conv/kernel"], o["grads"]["final_conv/kernel"]) < 1e-4
+    for k, ref in o["grads"].items():
+        assert rel_l2(g[k], ref) <= 3e-2, k
