@@ -337,6 +337,14 @@ size_t stp_loss_workspace_bytes(void);
 int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, int64_t count, int32_t dtype,
                          float w_bce, float w_dice, float* scalars, void* dlogits, int32_t dl_channels,
                          float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The rest of the loss registry of segmentation.py:15-22 for the sigmoid head: weights5 (HOST pointer, read at launch)
+ * = weights of {binary_crossentropy, dice_loss, iou_loss, jaccard_loss, focal_loss} in the composite `a+w*b` spec
+ * (README.md:210-214).  iou_loss = 1 - iou_coef (smooth 1); jaccard_loss = jaccard_distance_loss (smooth 100, per pixel,
+ * mean); focal_loss = binary focal loss (gamma 2, alpha 0.25, 1e-7 clip, mean).  scalars (fp32[12]) = the ten of
+ * stp_sigmoid_bce_dice + [10] jaccard_loss, [11] focal_loss. */
+int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, int64_t count, int32_t dtype, const float* weights5,
+                        float* scalars, void* dlogits, int32_t dl_channels, float grad_scale, void* workspace,
+                        size_t workspace_bytes, void* stream);
 int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, void* stream);
 /* Multi-class head (activation: softmax, loss: categorical_crossentropy[+w*dice_loss]; schemas/segmentation.raml:12-21,
  * 62-63): channel softmax over the first `classes` (2..32) channels of logits [pixels][ldc], target = uint8 class index

@@ -53,6 +53,23 @@ def iou_loss(y_true, p):
     return 1.0 - iou_coef(y_true, p)
 
 
+def jaccard_loss(y_true, p, smooth=100.0):
+    """``jaccard_loss`` = musket_core.losses.jaccard_distance_loss (the widely used Keras snippet): sums over the LAST
+    (class) axis, (1 - (|y p| + s) / (|y| + |p| - |y p| + s)) * s with s = 100, Keras then takes the mean."""
+    inter = (y_true * p).abs().sum(dim=-1)
+    tot = (y_true.abs() + p.abs()).sum(dim=-1)
+    return ((1.0 - (inter + smooth) / (tot - inter + smooth)) * smooth).mean()
+
+
+def focal_loss(y_true, p, gamma=2.0, alpha=0.25):
+    """``focal_loss``: binary focal loss, gamma 2 / alpha 0.25, probabilities clipped to [eps, 1-eps] (Keras epsilon), the
+    positive and the negative term each a mean over all elements (musket_core body unpinned; constants fixed HERE)."""
+    eps = float(KERAS_EPSILON)
+    pt1 = torch.clamp(torch.where(y_true == 1, p, torch.ones_like(p)), eps, 1.0 - eps)
+    pt0 = torch.clamp(torch.where(y_true == 0, p, torch.zeros_like(p)), eps, 1.0 - eps)
+    return -(alpha * (1.0 - pt1) ** gamma * torch.log(pt1)).mean() - ((1.0 - alpha) * pt0 ** gamma * torch.log(1.0 - pt0)).mean()
+
+
 def dice_metric(y_true, p):
     """``dice`` metric: soft-dice formula on predictions thresholded at 0.5."""
     return dice_coef(y_true, (p > 0.5).to(p.dtype))
@@ -72,6 +89,8 @@ LOSSES = {
     "categorical_crossentropy": categorical_crossentropy,
     "dice_loss": dice_loss,
     "iou_loss": iou_loss,
+    "jaccard_loss": jaccard_loss,
+    "focal_loss": focal_loss,
 }
 
 _TERM = re.compile(r"^\s*(?:([0-9.eE+-]+)\s*\*\s*)?([A-Za-z_][A-Za-z0-9_]*)\s*$")

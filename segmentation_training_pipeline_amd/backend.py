@@ -21,12 +21,18 @@ CAPTURE_MODE = "thread_local"
 SCALAR_NAMES = ("loss", "binary_crossentropy", "dice_loss", "dice", "binary_accuracy")
 
 
-def parse_loss(spec, classes=1):
-    """``"binary_crossentropy+0.1*dice_loss"`` -> (w_ce, w_dice)  (grammar: reference README.md:210-214).  The
-    cross-entropy term is ``binary_crossentropy`` for the 1-class sigmoid head and ``categorical_crossentropy`` for the
-    softmax head (schemas/segmentation.raml:12-21)."""
+EXTENDED_LOSSES = ("iou_loss", "jaccard_loss", "focal_loss")      # sigmoid head only (stp_sigmoid_loss_ex)
+
+
+def parse_loss(spec, classes=1, architecture=None):
+    """``"binary_crossentropy+0.1*dice_loss"`` -> (w_ce, w_dice) or, when the spec names one of the other registry entries
+    of reference segmentation.py:15-22, (w_ce, w_dice, w_iou, w_jaccard, w_focal)  (grammar: reference README.md:210-214).
+    The cross-entropy term is ``binary_crossentropy`` for the 1-class sigmoid head and ``categorical_crossentropy`` for
+    the softmax head (schemas/segmentation.raml:12-21).  ``lovasz_loss`` (a per-image sort) has no kernel here."""
     ce = "binary_crossentropy" if classes == 1 else "categorical_crossentropy"
     w = {ce: 0.0, "dice_loss": 0.0}
+    if classes == 1 and architecture != "DeepLabV3":
+        w.update((k, 0.0) for k in EXTENDED_LOSSES)
     for term in str(spec).split("+"):
         term = term.strip()
         if "*" in term:
@@ -37,6 +43,8 @@ def parse_loss(spec, classes=1):
         if name not in w:
             raise ValueError("loss %r is not available in the HIP backend (have: %s)" % (name, ", ".join(sorted(w))))
         w[name] += k
+    if any(w.get(k) for k in EXTENDED_LOSSES):
+        return (w[ce], w["dice_loss"]) + tuple(w[k] for k in EXTENDED_LOSSES)
     return w[ce], w["dice_loss"]
 
 
@@ -62,7 +70,7 @@ class HipSegModel(object):
         # architecture-specific graph options (FPN: pyramid_block_filters, segmentation_block_filters; PSPNet: downsample_factor,
         # psp_conv_filters - schemas/segmentation.raml:179-249), passed to the network definition as keywords
         self.net_kwargs = dict(net_kwargs or {})
-        self.loss_w = parse_loss(loss, classes)
+        self.loss_w = parse_loss(loss, classes, architecture)
         self.optimizer = optimizer.lower()
         if self.optimizer not in ("adam", "sgd", "rmsprop", "nadam"):
             raise ValueError("optimizer %r is not available in the HIP backend (have: SGD, Adam, RMSprop, Nadam)" % optimizer)
@@ -404,6 +412,8 @@ class HipSegModel(object):
         if self.classes > 1:
             out["categorical_crossentropy"] = out.pop("binary_crossentropy")
         out["iou"], out["iot"] = float(s[8]), float(s[9])
+        if len(self.loss_w) > 2:
+            out["iou_loss"], out["jaccard_loss"], out["focal_loss"] = 1.0 - float(s[8]), float(s[10]), float(s[11])
         return out
 
     def logits(self):

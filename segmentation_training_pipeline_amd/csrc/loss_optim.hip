@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ lo
   }
 }
 
-extern "C" size_t stp_loss_workspace_bytes(void) { return (size_t)LOSS_MAX_BLOCKS * LOSS_NSUM * sizeof(float); }
+// sized for the widest partial layout (stp_sigmoid_loss_ex: 16 floats per workgroup)
+extern "C" size_t stp_loss_workspace_bytes(void) { return (size_t)LOSS_MAX_BLOCKS * 16 * sizeof(float); }
 
 extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, int64_t count, int32_t dtype, float w_bce,
                                     float w_dice, float* scalars, void* dlogits, int32_t dl_channels, float grad_scale,
@@ -144,6 +145,168 @@ extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, i
     else
       hipLaunchKernelGGL(loss_grad_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, target, count, scalars,
                          w_bce, w_dice, inv_count, grad_scale, (float*)dlogits, dl_channels);
+    STP_LAUNCH_CHECK();
+  }
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The whole musket loss registry for the sigmoid head (reference segmentation.py:15-22): a weighted sum of
+//   0 binary_crossentropy  1 dice_loss  2 iou_loss  3 jaccard_loss  4 focal_loss
+// iou_loss = 1 - iou_coef (smooth 1, flattened batch); jaccard_loss = jaccard_distance_loss (smooth 100, over the
+// class axis = per pixel for one class, mean over pixels); focal_loss = binary focal loss, gamma 2, alpha 0.25,
+// Keras epsilon clip, mean over pixels.  Same two-stage fixed-order reduction as above with two more sums:
+//   7 jaccard_i   8 focal_i
+#define LOSS_NSUM_EX 16
+#define JACCARD_SMOOTH 100.f
+#define FOCAL_ALPHA 0.25f
+
+struct LossWeights { float w[5]; };
+
+__device__ __forceinline__ float focal_term(float p, float y) {
+  const float eps = 1e-7f, hi = 1.f - 1e-7f;
+  const float pc = fminf(fmaxf(p, eps), hi);
+  return y > 0.5f ? -FOCAL_ALPHA * (1.f - pc) * (1.f - pc) * logf(pc) : -(1.f - FOCAL_ALPHA) * pc * pc * logf(1.f - pc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_ex_partial_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                              int64_t count, float* partial) {
+  float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t per = (count + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < count ? i0 + per : count;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float z = Elem<T>::load(logits + i);
+    const float y = target[i] ? 1.f : 0.f;
+    const float p = 1.f / (1.f + expf(-z));
+    bool inr;
+    a[0] += keras_bce(p, y, &inr);
+    a[1] += p;
+    a[2] += y;
+    a[3] += p * y;
+    const float t = p > 0.5f ? 1.f : 0.f;
+    a[4] += t;
+    a[5] += t * y;
+    a[6] += (t == y) ? 1.f : 0.f;
+    const float inter = p * y;
+    a[7] += (1.f - (inter + JACCARD_SMOOTH) / (p + y - inter + JACCARD_SMOOTH)) * JACCARD_SMOOTH;
+    a[8] += focal_term(p, y);
+  }
+  __shared__ float red[4][9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) a[e] = wave_sum(a[e]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) red[threadIdx.x >> 6][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < LOSS_NSUM_EX)
+    partial[(size_t)blockIdx.x * LOSS_NSUM_EX + threadIdx.x] =
+        threadIdx.x < 9 ? red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] : 0.f;
+}
+
+// scalars 0..9 as loss_finalize_kernel, 10 jaccard_loss, 11 focal_loss  (iou_loss = 1 - scalars[8])
+__global__ __launch_bounds__(256) void loss_ex_finalize_kernel(const float* partial, int blocks, double inv_count, LossWeights lw,
+                                                               float* scalars) {
+  __shared__ double sh[16][LOSS_NSUM_EX];
+  const int e = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  double a = 0.0;
+  for (int b = lane; b < blocks; b += 16) a += (double)partial[(size_t)b * LOSS_NSUM_EX + e];
+  sh[lane][e] = a;
+  __syncthreads();
+  for (int w = 8; w > 0; w >>= 1) {
+    if (lane < w) sh[lane][e] += sh[lane + w][e];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double* s = sh[0];
+  const double bce = s[0] * inv_count;
+  const double dice_l = 1.0 - (2.0 * s[3] + 1.0) / (s[2] + s[1] + 1.0);
+  const double dice_m = (2.0 * s[5] + 1.0) / (s[2] + s[4] + 1.0);
+  const double iou = (s[3] + 1.0) / (s[2] + s[1] - s[3] + 1.0);
+  const double jac = s[7] * inv_count, focal = s[8] * inv_count;
+  scalars[0] = (float)(lw.w[0] * bce + lw.w[1] * dice_l + lw.w[2] * (1.0 - iou) + lw.w[3] * jac + lw.w[4] * focal);
+  scalars[1] = (float)bce;
+  scalars[2] = (float)dice_l;
+  scalars[3] = (float)dice_m;
+  scalars[4] = (float)(s[6] * inv_count);
+  scalars[5] = (float)s[1];
+  scalars[6] = (float)s[2];
+  scalars[7] = (float)s[3];
+  scalars[8] = (float)iou;
+  scalars[9] = (float)((s[5] + 1.0) / (s[2] + s[4] - s[5] + 1.0));
+  scalars[10] = (float)jac;
+  scalars[11] = (float)focal;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_ex_grad_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
+                                                           int64_t count, const float* scalars, LossWeights lw, float inv_count,
+                                                           float grad_scale, T* __restrict__ dl, int dlc) {
+  const float sp = scalars[5], sy = scalars[6], spy = scalars[7];
+  const float den = sy + sp + 1.f;
+  const float inv_den2 = 1.f / (den * den);
+  const float num = 2.f * spy + 1.f;
+  const float uden = sy + sp - spy + 1.f, unum = spy + 1.f;     // iou_coef = unum / uden
+  const float inv_uden2 = 1.f / (uden * uden);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const float z = Elem<T>::load(logits + i);
+    const float y = target[i] ? 1.f : 0.f;
+    const float p = 1.f / (1.f + expf(-z));
+    const bool inr = (p >= 1e-7f) && (p <= 1.f - 1e-7f);
+    float g = inr ? lw.w[0] * (p - y) * inv_count : 0.f;
+    // gp = d(loss)/dp of the probability-space terms
+    float gp = lw.w[1] * (-(2.f * y * den - num) * inv_den2);
+    // d iou / dp = (y uden - unum (1 - y)) / uden^2
+    gp -= lw.w[2] * (y * uden - unum * (1.f - y)) * inv_uden2;
+    {
+      const float inter = p * y, jd = p + y - inter + JACCARD_SMOOTH, jn = inter + JACCARD_SMOOTH;
+      gp -= lw.w[3] * JACCARD_SMOOTH * (y * jd - jn * (1.f - y)) / (jd * jd) * inv_count;
+    }
+    if (inr) {
+      const float fg = y > 0.5f ? FOCAL_ALPHA * (2.f * (1.f - p) * logf(p) - (1.f - p) * (1.f - p) / p)
+                                : -(1.f - FOCAL_ALPHA) * (2.f * p * logf(1.f - p) - p * p / (1.f - p));
+      gp += lw.w[4] * fg * inv_count;
+    }
+    g += gp * (p * (1.f - p));
+    g *= grad_scale;
+    T* o = dl + i * dlc;
+    Elem<T>::store(o, g);
+    for (int c = 1; c < dlc; ++c) Elem<T>::store(o + c, 0.f);
+  }
+}
+
+extern "C" int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, int64_t count, int32_t dtype, const float* weights5,
+                                   float* scalars, void* dlogits, int32_t dl_channels, float grad_scale, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (!logits || !target || !scalars || !workspace || !weights5 || count <= 0) return STP_E_BADARG;
+  if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
+  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  LossWeights lw;
+  for (int i = 0; i < 5; ++i) lw.w[i] = weights5[i];
+  int64_t b = count / 1024;
+  if (b < 1) b = 1;
+  if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
+  const int blocks = (int)b;
+  float* partial = (float*)workspace;
+  if (dtype == STP_BF16)
+    hipLaunchKernelGGL(loss_ex_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)logits, target, count, partial);
+  else
+    hipLaunchKernelGGL(loss_ex_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)logits, target, count, partial);
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_ex_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)count, lw, scalars);
+  STP_LAUNCH_CHECK();
+  if (dlogits) {
+    if (dl_channels < 1) return STP_E_BADARG;
+    int64_t g = (count + 255) / 256;
+    if (g > 4096) g = 4096;
+    const float inv_count = (float)(1.0 / (double)count);
+    if (dtype == STP_BF16)
+      hipLaunchKernelGGL(loss_ex_grad_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, target, count, scalars, lw,
+                         inv_count, grad_scale, (bf16_t*)dlogits, dl_channels);
+    else
+      hipLaunchKernelGGL(loss_ex_grad_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, target, count, scalars, lw,
+                         inv_count, grad_scale, (float*)dlogits, dl_channels);
     STP_LAUNCH_CHECK();
   }
   return STP_OK;

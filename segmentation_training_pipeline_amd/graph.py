@@ -1133,18 +1133,27 @@ class Plan(object):
             self._tape.append(back)
         return out
 
-    def sigmoid_loss(self, logits, target, w_bce, w_dice):
-        """sigmoid + w_bce*binary_crossentropy + w_dice*dice_loss; seeds the backward pass."""
+    def sigmoid_loss(self, logits, target, w_bce, w_dice, w_iou=0.0, w_jaccard=0.0, w_focal=0.0):
+        """sigmoid + w_bce*binary_crossentropy + w_dice*dice_loss [+ w*iou_loss + w*jaccard_loss + w*focal_loss, the rest of
+        the registry at reference segmentation.py:15-22]; seeds the backward pass."""
         if logits.C != 1:
             raise StpShapeError("binary loss expects one class")
         if self.dry:
             return
         self.loss_scalars = self._alloc((12,), torch.float32)
+        self.loss_scalars.zero_()
         count = logits.rows
         dl = self._gradbuf(logits) if self.training else None
-        self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),
-                   float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC, 1.0,
-                   self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        if w_iou or w_jaccard or w_focal:
+            import ctypes
+            self._loss_weights = (ctypes.c_float * 5)(w_bce, w_dice, w_iou, w_jaccard, w_focal)     # host array read at launch
+            self._emit(self.fwd, "stp_sigmoid_loss_ex", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt,
+                       ctypes.addressof(self._loss_weights), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None,
+                       logits.gradC, 1.0, self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        else:
+            self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),
+                       float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC, 1.0,
+                       self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
         logits.grad_ready = self.training
 
     def softmax_loss(self, logits, target, w_cce, w_dice):

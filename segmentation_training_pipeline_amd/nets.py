@@ -92,7 +92,7 @@ def _head(plan, x, H, W, classes, loss, with_loss):
     if with_loss:
         target = plan.input_u8("mask", H, W, 1)       # {0,1} for the sigmoid head, class index for the softmax head
         if classes == 1:
-            plan.sigmoid_loss(logits, target, loss[0], loss[1])
+            plan.sigmoid_loss(logits, target, *loss)
         else:
             plan.softmax_loss(logits, target, loss[0], loss[1])
     return logits
@@ -176,7 +176,7 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
     logits = plan.resize("logits", lo, 4, nearest=near)
     if with_loss:
         target = plan.input_u8("mask", H, W, 1)
-        (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, loss[0], loss[1])
+        (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, *loss)
     return logits
 
 
@@ -210,7 +210,7 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
     logits = plan.resize("logits", lo, int(downsample_factor), nearest=final_interpolation == "nearest")
     if with_loss:
         target = plan.input_u8("mask", H, W, 1)
-        (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, loss[0], loss[1])
+        (plan.sigmoid_loss if classes == 1 else plan.softmax_loss)(logits, target, *loss)
     return logits
 
 

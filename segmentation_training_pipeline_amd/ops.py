@@ -154,6 +154,14 @@ def sigmoid_bce_dice(logits, target, count, w_bce, w_dice, scalars, dlogits, dl_
               workspace.numel() * workspace.element_size(), stream())
 
 
+def sigmoid_loss_ex(logits, target, count, weights5, scalars, dlogits, dl_channels, grad_scale, workspace):
+    """weights5 = (binary_crossentropy, dice_loss, iou_loss, jaccard_loss, focal_loss) weights."""
+    import ctypes
+    w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
+    _lib.call("stp_sigmoid_loss_ex", ptr(logits), ptr(target), count, dt(logits), ctypes.addressof(w), ptr(scalars), ptr(dlogits),
+              dl_channels, float(grad_scale), ptr(workspace), workspace.numel() * workspace.element_size(), stream())
+
+
 def sigmoid(logits, probs, count):
     _lib.call("stp_sigmoid", ptr(logits), ptr(probs), count, dt(logits), stream())
 

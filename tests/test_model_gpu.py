@@ -689,3 +689,38 @@ def test_vgg16_under_fpn_and_pspnet_matches_the_oracle(arch):
     assert rel_l2(g["final_conv/kernel"], o["grads"]["final_conv/kernel"]) < 1e-4
     for k, ref in o["grads"].items():
         assert rel_l2(g[k], ref) <= 3e-2, k
+
+
+@pytest.mark.parametrize("arch,spec", [("Unet", "binary_crossentropy+0.5*iou_loss+0.02*jaccard_loss"), ("Unet", "focal_loss+dice_loss"),
+                                       ("FPN", "jaccard_loss"), ("Linknet", "iou_loss+0.5*focal_loss")])
+def test_registry_losses_step_matches_oracle(arch, spec):
+    """The other names of the loss registry (reference segmentation.py:15-22: iou_loss, jaccard_loss, focal_loss) in the
+    composite grammar of README.md:210-214, through one full training step."""
+    n, size, backbone = 2, 64, "resnet18"
+    P = {"Unet": onets.init_unet_resnet, "Linknet": onets.init_linknet_resnet, "FPN": onets.init_fpn_resnet}[arch](backbone, seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=77)
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=spec, optimizer="sgd", lr=0.05, opt_kwargs={"momentum": 0.9}, architecture=arch)
+    m = make(backbone, size, n, "fp32", optimizer="SGD", lr=0.05, opt_kwargs={"momentum": 0.9}, architecture=arch, loss=spec)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    m.load_batch(x, y)
+    m.forward_backward()
+    met = m.metrics()
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    assert abs(met["loss"] - o["loss"]) < 2e-5 * max(1.0, abs(o["loss"]))
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = rel_l2(g[k], ref)
+        assert e <= (1e-4 if k.startswith("final_conv") else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
+    with pytest.raises(ValueError):
+        make(backbone, size, n, "fp32", loss="lovasz_loss")
+
+
+def test_registry_losses_are_binary_head_only():
+    from segmentation_training_pipeline_amd.backend import parse_loss
+    assert parse_loss("binary_crossentropy+0.1*dice_loss") == (1.0, 0.1)
+    assert parse_loss("iou_loss+2*focal_loss") == (0.0, 0.0, 1.0, 0.0, 2.0)
+    with pytest.raises(ValueError):
+        parse_loss("categorical_crossentropy+iou_loss", classes=3)
+    with pytest.raises(ValueError):
+        parse_loss("jaccard_loss", classes=1, architecture="DeepLabV3")

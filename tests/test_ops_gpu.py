@@ -1288,6 +1288,44 @@ def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("spec,w5", [
+    ("iou_loss", (0, 0, 1, 0, 0)), ("jaccard_loss", (0, 0, 0, 1, 0)), ("focal_loss", (0, 0, 0, 0, 1)),
+    ("binary_crossentropy+0.5*dice_loss+0.25*iou_loss+0.01*jaccard_loss+2.0*focal_loss", (1, 0.5, 0.25, 0.01, 2.0))])
+def test_sigmoid_registry_losses_and_gradient(ops, dtype, spec, w5):
+    """stp_sigmoid_loss_ex: the other entries of the loss registry (reference segmentation.py:15-22) against the oracle's
+    formulas through torch autograd."""
+    rng = np.random.RandomState(17)
+    count = 2 * 48 * 48
+    z = q(rng.randn(count) * 3, dtype)
+    z[:4] = q(np.array([30.0, -30.0, 17.0, -17.0]), dtype)
+    y = (rng.rand(count) < 0.3).astype(np.uint8)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    yt = torch.from_numpy(y.astype(np.float32))
+    p = torch.sigmoid(zt)
+    # (the class axis of the oracle's jaccard_loss: one class)
+    loss = olosses.composite_loss(spec, yt[:, None], p[:, None])
+    loss.backward()
+    scal = torch.empty(12, device=DEV)
+    C = 8 if dtype == "bf16" else 4
+    dl = torch.full((count, C), float("nan"), dtype=TD[dtype], device=DEV)
+    ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
+    ops.sigmoid_loss_ex(dev(z, dtype), keep(torch.from_numpy(y).to(DEV)), count, w5, scal, dl, C, 1.0, ws)
+    s = host(scal)
+    pd, y1 = p.detach()[:, None], yt[:, None]
+    ref_loss = float(loss.detach())
+    assert abs(s[0] - ref_loss) < 2e-5 * max(1, abs(ref_loss))
+    assert abs(s[1] - float(olosses.binary_crossentropy(y1, pd))) < 1e-5
+    assert abs(s[2] - float(olosses.dice_loss(y1, pd))) < 1e-5
+    assert abs((1 - s[8]) - float(olosses.iou_loss(y1, pd))) < 1e-5
+    assert abs(s[10] - float(olosses.jaccard_loss(y1, pd))) < 2e-5 * max(1, float(olosses.jaccard_loss(y1, pd)))
+    assert abs(s[11] - float(olosses.focal_loss(y1, pd))) < 1e-5
+    g = host(dl)
+    ref = zt.grad.numpy()
+    np.testing.assert_allclose(g[:, 0], ref, atol=(2e-8 if dtype == "fp32" else 1e-2 * np.abs(ref).max()), rtol=1e-4 if dtype == "fp32" else 2e-2)
+    np.testing.assert_array_equal(g[:, 1:], 0)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("classes,ldc", [(3, 3), (5, 8), (21, 24)])
 def test_softmax_categorical_crossentropy_dice_loss_and_gradient(ops, dtype, classes, ldc):
     """stp_softmax_cce_dice / stp_softmax against the oracle's Keras categorical_crossentropy (+ musket dice over all class
