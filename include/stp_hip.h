@@ -422,6 +422,16 @@ int stp_sigmoid_act_bwd(const void* p, const void* dp, void* dz, int64_t rows, i
  * gradient w.r.t. the probabilities into column 0 of dprobs [count][dl_channels].  workspace >= stp_loss_workspace_bytes(). */
 int stp_prob_bce_dice(const void* probs, const uint8_t* target, int64_t count, int32_t dtype, float w_bce, float w_dice,
                       float* scalars, void* dprobs, int32_t dl_channels, void* workspace, size_t workspace_bytes, void* stream);
+/* The multi-class form of the same head (classes 2..32, activation softmax inside the class convolution, model.py:485):
+ * Activation('softmax') over the first `classes` columns as a tensor op with its gradient dz_c = p_c (dp_c - sum_k p_k dp_k),
+ * and Keras categorical_crossentropy (p / sum p, 1e-7 clip) + w_dice * dice_loss on the RESIZED probabilities
+ * [pixels][ldc] against class-index targets; scalars as stp_softmax_cce_dice, dprobs [pixels][dl_channels >= classes]. */
+int stp_softmax_act(const void* z, void* p, int64_t rows, int32_t classes, int32_t ldz, int32_t ldp, int32_t dtype, void* stream);
+int stp_softmax_act_bwd(const void* p, const void* dp, void* dz, int64_t rows, int32_t classes, int32_t ldp, int32_t ldg,
+                        int32_t dtype, void* stream);
+int stp_prob_cce_dice(const void* probs, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc, int32_t dtype,
+                      float w_cce, float w_dice, float* scalars, void* dprobs, int32_t dl_channels, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * On-device augmentation (replaces the imgaug worker processes, schemas/augmenters.raml:43-133).

@@ -240,7 +240,8 @@ def deeplab_xception_forward(P, x_nhwc, training=True, taps=None, step=1, OS=16)
     x = _sepconv_bn(ctx, x, 256, "decoder_conv0", depth_activation=True, cfg=BN_ASPP)
     x = _sepconv_bn(ctx, x, 256, "decoder_conv1", depth_activation=True, cfg=BN_ASPP)
     ctx.tap("decoder", x)
-    p = torch.sigmoid(_conv_same(P, x, "custom_logits_semantic"))
+    z = _conv_same(P, x, "custom_logits_semantic")
+    p = torch.sigmoid(z) if z.shape[1] == 1 else torch.softmax(z, dim=1)          # model.py:485: the activation lives in this layer
     p = F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True)
     return p.permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
@@ -287,6 +288,6 @@ def deeplab_forward(P, x_nhwc, training=True, taps=None, step=1):
         keep = dropout_mask(step, DROPOUT_SALT, n * hh * ww * c, DROPOUT_RATE).reshape(n, hh, ww, c).transpose(0, 3, 1, 2)
         x = x * torch.from_numpy(keep.astype(np.float32)) / (1.0 - DROPOUT_RATE)
     z = _conv_same(P, x, "custom_logits_semantic")                              # model.py:485 - the activation lives in this layer
-    p = torch.sigmoid(z)
+    p = torch.sigmoid(z) if z.shape[1] == 1 else torch.softmax(z, dim=1)       # sigmoid: one class; softmax: 2+ classes
     p = F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True)      # model.py:486
     return p.permute(0, 2, 3, 1).contiguous(), ctx.bn_updates

@@ -74,6 +74,8 @@ class OracleTrainer:
         logits, bn_updates = self._forward(P, x, True, taps)
         if self.architecture == "DeepLabV3":
             p = logits
+            if self.activation == "softmax":
+                y = torch.nn.functional.one_hot(y[..., 0].long(), logits.shape[-1]).to(torch.float32)
         elif self.activation == "softmax":
             p = torch.softmax(logits, dim=-1)
             y = torch.nn.functional.one_hot(y[..., 0].long(), logits.shape[-1]).to(torch.float32)

@@ -124,6 +124,9 @@ SIGNATURES = {
     "stp_sigmoid_act": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "stp_sigmoid_act_bwd": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "stp_prob_bce_dice": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i32, vp, sz, vp]),
+    "stp_softmax_act": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
+    "stp_softmax_act_bwd": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "stp_prob_cce_dice": (i32, [vp, vp, i64, i32, i32, i32, f32, f32, vp, vp, i32, vp, sz, vp]),
     "stp_augment_u8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_filter_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "stp_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),

@@ -390,6 +390,56 @@ extern "C" int stp_sigmoid_act_bwd(const void* p, const void* dp, void* dz, int6
 }
 
 // ------------------------------------------------------------------------------------------
+// Activation('softmax') as a tensor op for the multi-class head (the class convolution carries the activation, model.py:485;
+// 2..32 classes) and its gradient dz_c = p_c (dp_c - sum_k p_k dp_k).  One thread per pixel row.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_act_kernel(const T* __restrict__ z, T* __restrict__ p, int64_t rows, int classes, int ldz, int ldp) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const T* zr = z + r * ldz;
+    float m = -3.4e38f;
+    for (int c = 0; c < classes; ++c) m = fmaxf(m, Elem<T>::load(zr + c));
+    float sum = 0.f;
+    for (int c = 0; c < classes; ++c) sum += expf(Elem<T>::load(zr + c) - m);
+    const float inv = 1.f / sum;
+    for (int c = 0; c < classes; ++c) Elem<T>::store(p + r * ldp + c, expf(Elem<T>::load(zr + c) - m) * inv);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_act_bwd_kernel(const T* __restrict__ p, const T* __restrict__ dp, T* __restrict__ dz, int64_t rows,
+                                                              int classes, int ldp, int ldg) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const T* pr = p + r * ldp;
+    const T* gr = dp + r * ldg;
+    float dot = 0.f;
+    for (int c = 0; c < classes; ++c) dot += Elem<T>::load(pr + c) * Elem<T>::load(gr + c);
+    for (int c = 0; c < ldg; ++c)
+      Elem<T>::store(dz + r * ldg + c, c < classes ? Elem<T>::load(pr + c) * (Elem<T>::load(gr + c) - dot) : 0.f);
+  }
+}
+
+extern "C" int stp_softmax_act(const void* z, void* p, int64_t rows, int32_t classes, int32_t ldz, int32_t ldp, int32_t dtype, void* stream) {
+  if (!z || !p || rows <= 0 || classes < 2 || classes > 32 || ldz < classes || ldp < classes) return STP_E_BADARG;
+  const int g = dl_grid(rows);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(softmax_act_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)p, rows, classes, ldz, ldp);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(softmax_act_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)z, (float*)p, rows, classes, ldz, ldp);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// dp and dz are [rows][ldg] (columns >= classes of dz are written as 0); dp == dz allowed (a row is read before it is written)
+extern "C" int stp_softmax_act_bwd(const void* p, const void* dp, void* dz, int64_t rows, int32_t classes, int32_t ldp, int32_t ldg,
+                                   int32_t dtype, void* stream) {
+  if (!p || !dp || !dz || rows <= 0 || classes < 2 || classes > 32 || ldp < classes || ldg < classes) return STP_E_BADARG;
+  const int g = dl_grid(rows);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(softmax_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)dz, rows, classes, ldp, ldg);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(softmax_act_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)p, (const float*)dp, (float*)dz, rows, classes, ldp, ldg);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // w_bce * binary_crossentropy + w_dice * dice_loss on PROBABILITIES (1 class), scalars as stp_sigmoid_bce_dice, and the
 // gradient w.r.t. the probabilities into column 0 of dprobs [count][dl_channels]:
 //   d bce / d p = (p - y) / (p (1 - p)) / count inside the Keras clip [1e-7, 1 - 1e-7], 0 outside;  d dice_loss / d p = -(2 y den - num) / den^2
@@ -492,6 +542,128 @@ extern "C" int stp_prob_bce_dice(const void* probs, const uint8_t* target, int64
     const float inv_count = (float)(1.0 / (double)count);
     if (dtype == STP_BF16) hipLaunchKernelGGL(prob_loss_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)probs, target, count, scalars, w_bce, w_dice, inv_count, (bf16_t*)dprobs, dl_channels);
     else hipLaunchKernelGGL(prob_loss_grad_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)probs, target, count, scalars, w_bce, w_dice, inv_count, (float*)dprobs, dl_channels);
+    STP_LAUNCH_CHECK();
+  }
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-class loss on PROBABILITIES (the model resizes the softmax output, model.py:485-486): Keras categorical_crossentropy
+// (p <- p / sum p, clip to [1e-7, 1 - 1e-7], -log p_target) + w_dice * musket dice over every (pixel, class) element of the
+// one-hot target.  probs [pixels][ldc], target = class index per pixel; scalars as stp_softmax_cce_dice; the gradient
+// w.r.t. the probabilities goes to dprobs [pixels][dl_channels] (zero padding).  One thread per pixel.
+//   d cce / d p_k = -([k == t] / p_t - 1 / S) / pixels  where the clip is inactive on q_t = p_t / S, else 0
+template <typename T>
+__global__ __launch_bounds__(256) void prob_cce_partial_kernel(const T* __restrict__ probs, const uint8_t* __restrict__ target, int64_t pixels,
+                                                               int classes, int ldc, float* partial) {
+  float a[PL_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t per = (pixels + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < pixels ? i0 + per : pixels;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const T* pr = probs + i * ldc;
+    const int t = target[i];
+    float S = 0.f;
+    for (int c = 0; c < classes; ++c) S += Elem<T>::load(pr + c);
+    for (int c = 0; c < classes; ++c) {
+      const float p = Elem<T>::load(pr + c), y = c == t ? 1.f : 0.f;
+      a[1] += p;
+      a[3] += p * y;
+      const float th = p > 0.5f ? 1.f : 0.f;
+      a[4] += th;
+      a[5] += th * y;
+      a[6] += (th == y) ? 1.f : 0.f;
+      if (c == t) a[0] += -logf(fminf(fmaxf(p / S, 1e-7f), 1.f - 1e-7f));
+    }
+    a[2] += (t < classes) ? 1.f : 0.f;
+  }
+  __shared__ float red[4][PL_NSUM];
+#pragma unroll
+  for (int e = 0; e < PL_NSUM; ++e) a[e] = wave_sum(a[e]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < PL_NSUM; ++e) red[threadIdx.x >> 6][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < PL_NSUM)
+    partial[(size_t)blockIdx.x * PL_NSUM + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// sum 0 is per PIXEL, sum 6 per (pixel, class) element
+__global__ __launch_bounds__(256) void prob_cce_finalize_kernel(const float* partial, int blocks, double inv_pixels, double inv_elems, float w_cce,
+                                                                float w_dice, float* scalars) {
+  __shared__ double sh[32][PL_NSUM];
+  const int e = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  double a = 0.0;
+  for (int b = lane; b < blocks; b += 32) a += (double)partial[(size_t)b * PL_NSUM + e];
+  sh[lane][e] = a;
+  __syncthreads();
+  for (int w = 16; w > 0; w >>= 1) {
+    if (lane < w) sh[lane][e] += sh[lane + w][e];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double* s = sh[0];
+  const double cce = s[0] * inv_pixels;
+  const double dice_l = 1.0 - (2.0 * s[3] + 1.0) / (s[2] + s[1] + 1.0);
+  scalars[0] = (float)(w_cce * cce + w_dice * dice_l);
+  scalars[1] = (float)cce;
+  scalars[2] = (float)dice_l;
+  scalars[3] = (float)((2.0 * s[5] + 1.0) / (s[2] + s[4] + 1.0));
+  scalars[4] = (float)(s[6] * inv_elems);
+  scalars[5] = (float)s[1];
+  scalars[6] = (float)s[2];
+  scalars[7] = (float)s[3];
+  scalars[8] = (float)((s[3] + 1.0) / (s[2] + s[1] - s[3] + 1.0));
+  scalars[9] = (float)((s[5] + 1.0) / (s[2] + s[4] - s[5] + 1.0));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void prob_cce_grad_kernel(const T* __restrict__ probs, const uint8_t* __restrict__ target, int64_t pixels, int classes,
+                                                            int ldc, const float* scalars, float w_cce, float w_dice, float inv_pixels,
+                                                            T* __restrict__ dp, int dlc) {
+  const float sp = scalars[5], sy = scalars[6], spy = scalars[7];
+  const float den = sy + sp + 1.f, inv_den2 = 1.f / (den * den), num = 2.f * spy + 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * 256) {
+    const T* pr = probs + i * ldc;
+    const int t = target[i];
+    float S = 0.f;
+    for (int c = 0; c < classes; ++c) S += Elem<T>::load(pr + c);
+    const float pt = t < classes ? Elem<T>::load(pr + t) : 0.f;
+    const float q = pt / S;
+    const bool inr = t < classes && q >= 1e-7f && q <= 1.f - 1e-7f;
+    T* o = dp + i * dlc;
+    for (int c = 0; c < dlc; ++c) {
+      float g = 0.f;
+      if (c < classes) {
+        const float y = c == t ? 1.f : 0.f;
+        if (inr) g = -w_cce * (y / pt - 1.f / S) * inv_pixels;
+        g += w_dice * (-(2.f * y * den - num) * inv_den2);
+      }
+      Elem<T>::store(o + c, g);
+    }
+  }
+}
+
+extern "C" int stp_prob_cce_dice(const void* probs, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc, int32_t dtype, float w_cce,
+                                 float w_dice, float* scalars, void* dprobs, int32_t dl_channels, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (!probs || !target || !scalars || !workspace || pixels <= 0 || classes < 2 || classes > 32 || ldc < classes) return STP_E_BADARG;
+  if (workspace_bytes < (size_t)PL_MAX_BLOCKS * PL_NSUM * sizeof(float)) return STP_E_WORKSPACE;
+  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = pixels / 512;
+  if (b < 1) b = 1;
+  if (b > PL_MAX_BLOCKS) b = PL_MAX_BLOCKS;
+  const int blocks = (int)b;
+  float* partial = (float*)workspace;
+  if (dtype == STP_BF16) hipLaunchKernelGGL(prob_cce_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)probs, target, pixels, classes, ldc, partial);
+  else hipLaunchKernelGGL(prob_cce_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)probs, target, pixels, classes, ldc, partial);
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prob_cce_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)pixels, 1.0 / ((double)pixels * classes), w_cce,
+                     w_dice, scalars);
+  STP_LAUNCH_CHECK();
+  if (dprobs) {
+    if (dl_channels < classes) return STP_E_BADARG;
+    const int g = dl_grid(pixels);
+    if (dtype == STP_BF16) hipLaunchKernelGGL(prob_cce_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)probs, target, pixels, classes, ldc, scalars, w_cce, w_dice, (float)(1.0 / (double)pixels), (bf16_t*)dprobs, dl_channels);
+    else hipLaunchKernelGGL(prob_cce_grad_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)probs, target, pixels, classes, ldc, scalars, w_cce, w_dice, (float)(1.0 / (double)pixels), (float*)dprobs, dl_channels);
     STP_LAUNCH_CHECK();
   }
   return STP_OK;

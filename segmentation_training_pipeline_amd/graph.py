@@ -984,37 +984,43 @@ class Plan(object):
         return out
 
     def sigmoid_act(self, name, z):
-        """Activation('sigmoid') as a layer (DeepLab's last convolution carries it, model.py:485)."""
+        """The activation of DeepLab's last convolution as a layer (model.py:485): sigmoid for one class, channel softmax for
+        2..32 classes."""
         out = self._new(name, z.H, z.W, z.C, z.needs_grad)
         out.gradC = z.gradC
         self._use(z)
         if self.dry:
             return out
-        self._emit(self.fwd, "stp_sigmoid_act", z.buf.data_ptr(), out.buf.data_ptr(), z.rows, z.C, z.C, z.C, self.cdt)
+        fn = "stp_sigmoid_act" if z.C == 1 else "stp_softmax_act"
+        self._emit(self.fwd, fn, z.buf.data_ptr(), out.buf.data_ptr(), z.rows, z.C, z.C, z.C, self.cdt)
         if not self.training:
             return out
 
         def back():
             if not (z.needs_grad and out.grad_ready):
                 return
-            self._emit(self.bwd, "stp_sigmoid_act_bwd", out.buf.data_ptr(), out.grad.data_ptr(), self._gradbuf(z).data_ptr(), z.rows, z.C,
+            self._emit(self.bwd, fn + "_bwd", out.buf.data_ptr(), out.grad.data_ptr(), self._gradbuf(z).data_ptr(), z.rows, z.C,
                        z.C, z.gradC, self.cdt)
             z.grad_ready = True
 
         self._tape.append(back)
         return out
 
-    def prob_loss(self, probs, target, w_bce, w_dice):
-        """w_bce*binary_crossentropy + w_dice*dice_loss on probabilities (1 class); seeds the backward pass."""
-        if probs.C != 1:
-            raise StpShapeError("the probability loss expects one class")
+    def prob_loss(self, probs, target, w_ce, w_dice):
+        """w*binary_crossentropy (one class) or w*categorical_crossentropy (class-index target) + w_dice*dice_loss on
+        PROBABILITIES; seeds the backward pass."""
         if self.dry:
             return
         self.loss_scalars = self._alloc((12,), torch.float32)
         dp = self._gradbuf(probs) if self.training else None
-        self._emit(self.fwd, "stp_prob_bce_dice", probs.buf.data_ptr(), target.buf.data_ptr(), probs.rows, self.cdt, float(w_bce),
-                   float(w_dice), self.loss_scalars.data_ptr(), dp.data_ptr() if dp is not None else None, probs.gradC,
-                   self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        if probs.C == 1:
+            self._emit(self.fwd, "stp_prob_bce_dice", probs.buf.data_ptr(), target.buf.data_ptr(), probs.rows, self.cdt, float(w_ce),
+                       float(w_dice), self.loss_scalars.data_ptr(), dp.data_ptr() if dp is not None else None, probs.gradC,
+                       self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        else:
+            self._emit(self.fwd, "stp_prob_cce_dice", probs.buf.data_ptr(), target.buf.data_ptr(), probs.rows, probs.C, probs.C, self.cdt,
+                       float(w_ce), float(w_dice), self.loss_scalars.data_ptr(), dp.data_ptr() if dp is not None else None, probs.gradC,
+                       self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
         probs.grad_ready = self.training
 
     def probs_out(self, probs):

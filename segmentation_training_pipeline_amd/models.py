@@ -168,8 +168,8 @@ def Deeplabv3(encoder_weights="pascal_voc", input_tensor=None, input_shape=(512,
         raise ValueError("the HIP DeepLabV3 implements the mobilenetv2 branch with alpha = 1")
     if backbone_name == "xception" and int(OS) not in (8, 16):
         raise ValueError("OS (output stride of the xception backbone) is 8 or 16")
-    if activation != "sigmoid" or int(classes) != 1:
-        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head")
+    if not ((activation == "sigmoid" and int(classes) == 1) or (activation == "softmax" and 2 <= int(classes) <= 32)):
+        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head and 2..32-class softmax heads")
     mdl = SegModel("DeepLabV3", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, ())
     if backbone_name == "xception":
         mdl.net_kwargs = {"OS": int(OS)}

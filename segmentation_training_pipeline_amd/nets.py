@@ -233,8 +233,8 @@ def deeplab_mobilenetv2(plan, backbone, H, W, in_ch=3, classes=1, decoder_filter
     bilinear upsampling of the probabilities to the input size (:485-486).  The loss therefore works on probabilities."""
     if backbone != "mobilenetv2":
         raise ValueError("Unknown backbone")        # (the xception branch is not built)
-    if classes != 1:
-        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head")
+    if not 1 <= classes <= 32:
+        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head and 2..32-class softmax heads")
     if H % 8 or W % 8 or H != W:
         raise ValueError("DeepLabV3 (output stride 8) needs a square input divisible by 8")
     mob = dict(momentum=0.999)
@@ -308,8 +308,8 @@ def deeplab_xception(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=N
     inside); ASPP = image pooling + 1x1 + SepConv rates (6, 12, 18) [(12, 24, 36) at OS 8]; projection + Dropout(0.1); decoder:
     align-corners bilinear to 1/4, concat with the 48-channel projection of the skip, two SepConv 256; class convolution WITH the
     activation; align-corners bilinear upsampling of the probabilities."""
-    if classes != 1:
-        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head")
+    if not 1 <= classes <= 32:
+        raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head and 2..32-class softmax heads")
     if OS not in (8, 16) or H != W or H % OS:
         raise ValueError("DeepLabV3 / xception needs a square input divisible by the output stride (8 or 16)")
     b3_stride, mid_rate, exit_rates, aspp_rates = (1, 2, (2, 4), (12, 24, 36)) if OS == 8 else (2, 1, (1, 2), (6, 12, 18))

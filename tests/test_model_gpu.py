@@ -724,3 +724,44 @@ def test_registry_losses_are_binary_head_only():
         parse_loss("categorical_crossentropy+iou_loss", classes=3)
     with pytest.raises(ValueError):
         parse_loss("jaccard_loss", classes=1, architecture="DeepLabV3")
+
+
+@pytest.mark.parametrize("backbone,classes", [("mobilenetv2", 3), ("xception", 5)])
+def test_fp32_deeplabv3_multiclass_head_matches_oracle(backbone, classes):
+    """The reference's DeepLabV3 with `classes: N, activation: softmax` (model.py:485-486: the class convolution carries the
+    channel softmax, BilinearUpsampling resizes the PROBABILITIES), categorical_crossentropy + dice on them."""
+    from oracle import deeplab as odl
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    n, size = 2, 64
+    P = (odl.init_deeplab_mobilenetv2 if backbone == "mobilenetv2" else odl.init_deeplab_xception)(classes=classes, seed=42)
+    x, _ = ostep.synthetic_batch(n, size, size, seed=21)
+    yy, xx = np.mgrid[0:size, 0:size]
+    y = ((yy // 16 + xx // 24) % classes).astype(np.uint8)[None, :, :, None].repeat(n, axis=0)
+    spec = "categorical_crossentropy+0.5*dice_loss"
+    kw = {"net_kwargs": {"OS": 16}} if backbone == "xception" else {}
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=spec, optimizer="sgd", lr=0.02, architecture="DeepLabV3", activation="softmax", **kw)
+    m = HipSegModel("DeepLabV3", backbone, (size, size, 3), classes, "softmax", batch=n, dtype="fp32", loss=spec, optimizer="SGD", lr=0.02,
+                    use_graph=False, **kw)
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=2.5e-4)            # probabilities: 1e-3 on logits ~ 2.5e-4 on p
+    np.testing.assert_allclose(m.logits().sum(axis=-1), 1.0, atol=1e-5)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+    assert abs(met["categorical_crossentropy"] - o["bce"]) < 1e-5
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = np.linalg.norm(g[k].astype(np.float64) - ref) / (np.linalg.norm(ref.astype(np.float64)) + 1e-3)
+        assert e <= (1e-4 if k.startswith("custom_logits") else 8e-2), "grad %s: rel L2 %.3g" % (k, e)
+    m.set_weights(tr.P)
+    pr = m.predict(x)
+    assert pr.shape == (n, size, size, classes)
+    np.testing.assert_allclose(pr, tr.forward(x.astype(np.float32)), atol=5e-4)
+    # bf16 + hipGraph: runs and learns
+    mb = HipSegModel("DeepLabV3", backbone, (size, size, 3), classes, "softmax", batch=n, dtype="bf16", loss=spec, optimizer="Adam", lr=1e-3, **kw)
+    mb.set_weights(P)
+    l0 = mb.train_on_batch(x, y)["loss"]
+    for _ in range(15):
+        l1 = mb.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0
