@@ -148,23 +148,31 @@ def _vgg_encoder(ctx, x_nhwc, backbone, stop_block=None):
     return x, skips[::-1]
 
 
-def init_linknet_resnet(backbone="resnet34", in_ch=3, classes=1, decoder_filters=(None, None, None, None, 16), seed=42):
-    """Linknet over the same encoder (segmentation_models 0.2.1 ``Linknet(decoder_block_type='upsampling',
-    decoder_use_batchnorm=True)``, kwargs/defaults ``schemas/segmentation.raml:180-203``).  Decoder block i
-    (``decoder_stage{i}``): 1x1 conv to in/4 -> BN -> ReLU -> UpSampling2D(2) -> 3x3 conv in/4 -> BN -> ReLU -> 1x1 conv to
-    the skip's channel count (or ``decoder_filters[i]`` without a skip) -> BN -> ReLU -> Add(skip)."""
+def init_linknet_resnet(backbone="resnet34", in_ch=3, classes=1, decoder_filters=(None, None, None, None, 16), seed=42,
+                        decoder_block_type="upsampling"):
+    """Linknet over the same encoder (segmentation_models 0.2.1 ``Linknet(decoder_use_batchnorm=True)``, kwargs/defaults
+    ``schemas/segmentation.raml:180-203``).  Decoder block i (``decoder_stage{i}``): 1x1 conv to in/4 -> BN -> ReLU ->
+    UpSampling2D(2) -> 3x3 conv in/4 -> BN -> ReLU  (``decoder_block_type='transpose'``: Conv2DTranspose 4x4 s2 to in/4 -> BN
+    -> ReLU instead of the pair) -> 1x1 conv to the skip's channel count (or ``decoder_filters[i]`` without a skip) -> BN ->
+    ReLU -> Add(skip).  VGG encoders: block5_pool + the skips block5 / block4 / block3 / block2 last convolutions."""
     full = init_unet_resnet(backbone, in_ch, classes, seed=seed)
     P = OrderedDict((k, v) for k, v in full.items() if not (k.startswith("decoder_") or k.startswith("final_")))
     rng = np.random.RandomState(seed + 1)
-    ex = expansion(backbone)
-    cin = STAGE_FILTERS[3] * ex
-    skip_ch = (STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex, 64, None)
+    if backbone in VGG_BLOCKS:
+        cin, skip_ch = 512, (512, 512, 256, 128, None)
+    else:
+        ex = expansion(backbone)
+        cin = STAGE_FILTERS[3] * ex
+        skip_ch = (STAGE_FILTERS[2] * ex, STAGE_FILTERS[1] * ex, STAGE_FILTERS[0] * ex, 64, None)
     for i in range(5):
         pre = "decoder_stage%d_" % i
         mid = cin // 4
         out = skip_ch[i] if skip_ch[i] is not None else decoder_filters[i]
         for j, (k, ci, co) in enumerate(((1, cin, mid), (3, mid, mid), (1, mid, out)), start=1):
-            P[pre + "conv%d/kernel" % j] = _glorot_uniform(rng, (k, k, ci, co))
+            if j == 2 and decoder_block_type == "transpose":
+                P[pre + "upsample/kernel"] = _glorot_uniform(rng, (4, 4, co, ci))        # Keras Conv2DTranspose: (kh, kw, out, in)
+            else:
+                P[pre + "conv%d/kernel" % j] = _glorot_uniform(rng, (k, k, ci, co))
             _bn(P, pre + "bn%d" % j, co)
         cin = out
     P["final_conv/kernel"] = _glorot_uniform(rng, (3, 3, cin, classes))
@@ -425,13 +433,22 @@ def _resnet_encoder(ctx, x_nhwc, backbone, stop_at=None):
 def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None):
     """Linknet (see init_linknet_resnet).  Returns (logits_nhwc, bn_updates)."""
     ctx = _Ctx(P, training, taps)
-    x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
-    skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
+    if backbone in VGG_BLOCKS:
+        x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
+        skips = {"s%d" % i: t for i, t in enumerate(sk)}
+        skip_names = ("s0", "s1", "s2", "s3", None)
+    else:
+        x, skips = _resnet_encoder(ctx, x_nhwc, backbone)
+        skip_names = ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0", None)
     for i in range(5):
         pre = "decoder_stage%d_" % i
         x = _bn_apply(ctx, _conv(ctx, x, pre + "conv1"), pre + "bn1", BN_EPS_DECODER, relu=True)
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
-        x = _bn_apply(ctx, _conv(ctx, x, pre + "conv2", pad=1), pre + "bn2", BN_EPS_DECODER, relu=True)
+        if pre + "upsample/kernel" in P:      # Conv2DTranspose(4x4, strides 2, padding='same') = torch padding 1
+            x = F.conv_transpose2d(x, P[pre + "upsample/kernel"].permute(3, 2, 0, 1), stride=2, padding=1)
+        else:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+            x = _conv(ctx, x, pre + "conv2", pad=1)
+        x = _bn_apply(ctx, x, pre + "bn2", BN_EPS_DECODER, relu=True)
         x = _bn_apply(ctx, _conv(ctx, x, pre + "conv3"), pre + "bn3", BN_EPS_DECODER, relu=True)
         if skip_names[i] is not None:
             x = x + skips[skip_names[i]]

@@ -55,8 +55,8 @@ class HipSegModel(object):
                  opt_kwargs=None, seed=42, decoder_block_type="upsampling", net_kwargs=None):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
-        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture not in ("Unet", "FPN", "PSPNet")) \
-                or ((backbone in ("mobilenetv2", "xception")) != (architecture == "DeepLabV3")):   # VGG: U-Net, FPN, PSPNet; MobileNetV2 / Xception: DeepLabV3 only
+        if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture not in ("Unet", "Linknet", "FPN", "PSPNet")) \
+                or ((backbone in ("mobilenetv2", "xception")) != (architecture == "DeepLabV3")):   # VGG: every segmentation_models architecture; MobileNetV2 / Xception: DeepLabV3 only
             raise ValueError("Unknown backbone")
         if not ((classes == 1 and activation in ("sigmoid", None)) or (2 <= classes <= 32 and activation == "softmax")):
             raise ValueError("the HIP backend trains 1-class sigmoid heads and 2..32-class softmax heads")
@@ -64,7 +64,7 @@ class HipSegModel(object):
         self.H, self.W, self.in_ch = int(input_shape[0]), int(input_shape[1]), int(input_shape[2])
         self.classes, self.batch, self.dtype = classes, int(batch), dtype
         self.decoder_filters = tuple(decoder_filters)
-        if decoder_block_type not in ("upsampling", "transpose") or (decoder_block_type == "transpose" and architecture != "Unet"):
+        if decoder_block_type not in ("upsampling", "transpose") or (decoder_block_type == "transpose" and architecture not in ("Unet", "Linknet")):
             raise ValueError("decoder_block_type %r is not available for %s" % (decoder_block_type, architecture))
         self.decoder_block_type = decoder_block_type
         # architecture-specific graph options (FPN: pyramid_block_filters, segmentation_block_filters; PSPNet: downsample_factor,
@@ -116,7 +116,7 @@ class HipSegModel(object):
         with_loss = training if with_loss is None else with_loss
 
         def fn(plan):
-            kw = {"decoder_block_type": self.decoder_block_type} if self.architecture == "Unet" else dict(self.net_kwargs)
+            kw = {"decoder_block_type": self.decoder_block_type} if self.architecture in ("Unet", "Linknet") else dict(self.net_kwargs)
             if self.architecture == "DeepLabV3" and self.backbone != "xception":
                 kw.pop("OS", None)                                   # (the output stride applies to the xception backbone only, model.py:296-297)
             logits = nets.NETWORKS[self.architecture](plan, self.backbone, self.H, self.W, self.in_ch, self.classes,

@@ -112,12 +112,14 @@ def Linknet(backbone_name="vgg16", input_shape=(None, None, 3), classes=1, activ
             freeze_encoder=False, decoder_filters=(None, None, None, None, 16), decoder_use_batchnorm=True,
             decoder_block_type="upsampling", n_upsample_blocks=5, upsample_rates=(2, 2, 2, 2, 2)):
     """segmentation_models.Linknet keyword surface (schemas/segmentation.raml:180-203)."""
-    if backbone_name not in nets.RESNET_UNITS:
+    if backbone_name not in nets.RESNET_UNITS and backbone_name not in nets.VGG_BLOCKS:
         raise ValueError("Unknown backbone")
-    if decoder_block_type != "upsampling" or not decoder_use_batchnorm or int(n_upsample_blocks) != 5 \
+    if decoder_block_type not in ("upsampling", "transpose") or not decoder_use_batchnorm or int(n_upsample_blocks) != 5 \
             or tuple(upsample_rates) != (2, 2, 2, 2, 2) or decoder_filters[4] is None:
-        raise ValueError("the HIP Linknet implements the default decoder (upsampling blocks with BatchNorm, 5 x2 stages)")
-    return SegModel("Linknet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, decoder_filters)
+        raise ValueError("the HIP Linknet implements the upsampling / transpose decoder blocks with BatchNorm, 5 x2 stages")
+    m = SegModel("Linknet", backbone_name, input_shape, classes, activation, encoder_weights, freeze_encoder, decoder_filters)
+    m.decoder_block_type = decoder_block_type
+    return m
 
 
 def FPN(backbone_name="vgg16", input_shape=(None, None, 3), classes=21, activation="softmax", encoder_weights="imagenet",

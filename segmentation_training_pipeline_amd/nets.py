@@ -124,18 +124,27 @@ def unet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(256, 
 
 
 def linknet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=(None, None, None, None, 16),
-                   loss=(1.0, 1.0), with_loss=True):
-    """segmentation_models 0.2.1 ``Linknet(decoder_block_type='upsampling', decoder_use_batchnorm=True)``
-    (``schemas/segmentation.raml:180-203``): per decoder stage 1x1 conv to in/4, UpSampling2D(2) folded into the 3x3
-    conv's gather, 1x1 conv to the skip's channels, each followed by BN+ReLU, then Add(skip)."""
-    x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
-    skips = (taps[4], taps[3], taps[2], relu0, None)
+                   loss=(1.0, 1.0), with_loss=True, decoder_block_type="upsampling"):
+    """segmentation_models 0.2.1 ``Linknet(decoder_use_batchnorm=True)`` (``schemas/segmentation.raml:180-203``): per decoder
+    stage 1x1 conv to in/4, then UpSampling2D(2) folded into the 3x3 conv's gather ('upsampling') or Conv2DTranspose 4x4 s2
+    ('transpose', ``schemas/segmentation.raml:166-169``), 1x1 conv to the skip's channels, each followed by BN+ReLU, then
+    Add(skip).  VGG encoders: block5_pool + four skips (the last convolutions of block5 / 4 / 3 / 2)."""
+    if backbone in VGG_BLOCKS:
+        x, sk = _vgg_encoder(plan, backbone, H, W, in_ch)
+        skips = (sk[0], sk[1], sk[2], sk[3], None)
+    else:
+        x, relu0, taps = _resnet_encoder(plan, backbone, H, W, in_ch)
+        skips = (taps[4], taps[3], taps[2], relu0, None)
     for i in range(5):
         pre = "decoder_stage%d_" % i
         mid = x.C // 4
         out = skips[i].C if skips[i] is not None else int(decoder_filters[i])
         x = plan.bn(pre + "bn1", plan.conv(pre + "conv1", x, mid, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
-        x = plan.bn(pre + "bn2", plan.conv(pre + "conv2", x, mid, 3, pad=1, upsample=True, bn_stats=True), BN_EPS_DECODER, relu=True)
+        if decoder_block_type == "transpose":
+            x = plan.conv(pre + "upsample", x, mid, 4, transpose=True, bn_stats=True)
+        else:
+            x = plan.conv(pre + "conv2", x, mid, 3, pad=1, upsample=True, bn_stats=True)
+        x = plan.bn(pre + "bn2", x, BN_EPS_DECODER, relu=True)
         x = plan.bn(pre + "bn3", plan.conv(pre + "conv3", x, out, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
         if skips[i] is not None:
             x = plan.add(pre + "add", x, skips[i])

@@ -765,3 +765,41 @@ def test_fp32_deeplabv3_multiclass_head_matches_oracle(backbone, classes):
     for _ in range(15):
         l1 = mb.train_on_batch(x, y)["loss"]
     assert np.isfinite(l1) and l1 < l0
+
+
+@pytest.mark.parametrize("backbone,block", [("resnet18", "transpose"), ("vgg16", "upsampling"), ("vgg16", "transpose")])
+def test_linknet_transpose_blocks_and_vgg_encoders_match_the_oracle(backbone, block):
+    """Linknet's `decoder_block_type: transpose` (1x1 -> Conv2DTranspose 4x4 s2 -> 1x1, schemas/segmentation.raml:166-169) and
+    the VGG encoders under Linknet (README.md:587-589; block5_pool + four skips) through the YAML-facing constructor."""
+    from segmentation_training_pipeline_amd import models
+    n, size = 2, 64
+    lr = 0.002 if backbone == "vgg16" else 0.05
+    P = onets.init_linknet_resnet(backbone, seed=42, decoder_block_type=block)
+    x, y = ostep.synthetic_batch(n, size, size, seed=8)
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=LOSS, optimizer="sgd", lr=lr, architecture="Linknet")
+    sm = models.Linknet(backbone, input_shape=(size, size, 3), classes=1, activation="sigmoid", encoder_weights=None, decoder_block_type=block)
+    sm.compile(optimizer="SGD", loss=LOSS, lr=lr, batch=n, dtype="fp32", use_graph=False)
+    m = sm.impl
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    for k, v in m.get_weights().items():
+        np.testing.assert_array_equal(v, P[k], err_msg=k)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3 * max(1.0, np.abs(o["logits"]).max()))
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 1e-5 * max(1.0, abs(o["loss"]))
+    g = m.get_gradients()
+    assert rel_l2(g["final_conv/kernel"], o["grads"]["final_conv/kernel"]) < 1e-4
+    for k, ref in o["grads"].items():     # (ReLU-kink noise, see test_fp32_step_matches_oracle; 16-channel stages: one flip weighs more)
+        assert rel_l2(g[k], ref) <= 6e-2, k
+    w = m.get_weights()
+    for k in tr.P:
+        np.testing.assert_allclose(w[k], tr.P[k], atol=2e-4, err_msg=k)
+    # bf16 + hipGraph: runs and learns
+    sb = models.Linknet(backbone, input_shape=(size, size, 3), classes=1, activation="sigmoid", encoder_weights=None, decoder_block_type=block)
+    sb.compile(optimizer="Adam", loss=LOSS, lr=1e-4 if backbone == "vgg16" else 1e-3, batch=n, dtype="bf16")
+    sb.impl.set_weights(P)
+    l0 = sb.impl.train_on_batch(x, y)["loss"]
+    for _ in range(10):
+        l1 = sb.impl.train_on_batch(x, y)["loss"]
+    assert np.isfinite(l1) and l1 < l0
