@@ -58,7 +58,13 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   u32x2 r;
   r.x = pack_bf16x2(v.x, v.y);
   r.y = pack_bf16x2(v.z, v.w);
+#if defined(STP_EXP) && STP_EXP == 41      // what-if: write-through stores (no dirty lines left for the end-of-kernel L2 write-back)
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" ::"v"(p), "v"(r) : "memory");
+#elif defined(STP_EXP) && STP_EXP == 42
+  __builtin_nontemporal_store(r, reinterpret_cast<u32x2*>(p));
+#else
   *reinterpret_cast<u32x2*>(p) = r;
+#endif
 }
 
 // LDS-only workgroup barrier: __syncthreads() also fences global memory, i.e. waits for every outstanding global load AND store
