@@ -345,6 +345,13 @@ int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, int64_t coun
 int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, int64_t count, int32_t dtype, const float* weights5,
                         float* scalars, void* dlogits, int32_t dl_channels, float grad_scale, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* lovasz_loss (segmentation.py:18; README.md:379,411): binary Lovasz hinge per image on the Keras-recovered logits, mean over
+ * images.  Runs AFTER stp_sigmoid_bce_dice / stp_sigmoid_loss_ex on the same scalars / dlogits: scalars[12] = lovasz_loss,
+ * scalars[0] += weight * lovasz_loss, dlogits channel 0 += weight * gradient (scalars is fp32[16] here).  The workspace holds the
+ * sort keys and rocPRIM's temporary storage: stp_lovasz_workspace_bytes(images * per_image, images) (0 = not available). */
+size_t stp_lovasz_workspace_bytes(int64_t count, int32_t images);
+int stp_lovasz_hinge(const void* logits, const uint8_t* target, int32_t images, int64_t per_image, int32_t dtype, float weight,
+                     float* scalars, void* dlogits, int32_t dl_channels, void* workspace, size_t workspace_bytes, void* stream);
 int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, void* stream);
 /* Multi-class head (activation: softmax, loss: categorical_crossentropy[+w*dice_loss]; schemas/segmentation.raml:12-21,
  * 62-63): channel softmax over the first `classes` (2..32) channels of logits [pixels][ldc], target = uint8 class index

@@ -70,6 +70,29 @@ def focal_loss(y_true, p, gamma=2.0, alpha=0.25):
     return -(alpha * (1.0 - pt1) ** gamma * torch.log(pt1)).mean() - ((1.0 - alpha) * pt0 ** gamma * torch.log(1.0 - pt0)).mean()
 
 
+def lovasz_loss(y_true, p):
+    """``lovasz_loss``: binary Lovasz hinge (Berman et al. 2018) per image, mean over images, on the logits recovered the Keras
+    way from the probabilities (clip to [eps, 1 - eps], log(p / (1 - p))).  errors = 1 - logit * (2 y - 1), sorted descending;
+    loss = relu(errors_sorted) . grad with grad = the first differences of the Jaccard index of the sorted ground truth
+    (constant w.r.t. the logits).  musket_core's body is unpinned: this is the published algorithm, fixed HERE."""
+    eps = float(KERAS_EPSILON)
+    pc = torch.clamp(p, eps, 1.0 - eps)
+    logits = torch.log(pc / (1.0 - pc))
+    total = 0.0
+    for n in range(y_true.shape[0]):
+        lg, gt = logits[n].reshape(-1), y_true[n].reshape(-1)
+        errors = 1.0 - lg * (2.0 * gt - 1.0)
+        order = torch.argsort(errors.detach(), descending=True, stable=True)
+        es, gs = errors[order], gt[order].to(torch.float64)
+        gts = gs.sum()
+        inter = gts - gs.cumsum(0)
+        union = gts + (1.0 - gs).cumsum(0)
+        jac = 1.0 - inter / union
+        jac = torch.cat([jac[:1], jac[1:] - jac[:-1]])
+        total = total + (torch.relu(es).to(torch.float64) * jac).sum()
+    return (total / y_true.shape[0]).to(torch.float32)
+
+
 def dice_metric(y_true, p):
     """``dice`` metric: soft-dice formula on predictions thresholded at 0.5."""
     return dice_coef(y_true, (p > 0.5).to(p.dtype))
@@ -91,6 +114,7 @@ LOSSES = {
     "iou_loss": iou_loss,
     "jaccard_loss": jaccard_loss,
     "focal_loss": focal_loss,
+    "lovasz_loss": lovasz_loss,
 }
 
 _TERM = re.compile(r"^\s*(?:([0-9.eE+-]+)\s*\*\s*)?([A-Za-z_][A-Za-z0-9_]*)\s*$")

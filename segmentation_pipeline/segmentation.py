@@ -26,9 +26,9 @@ custom_objects = {
     "dice": "dice", "iou": "iou", "iot": "iot", "dice_loss": "dice_loss", "binary_crossentropy": "binary_crossentropy",
     "categorical_crossentropy": "categorical_crossentropy", "binary_accuracy": "binary_accuracy",
     "iou_loss": "iou_loss", "jaccard_loss": "jaccard_loss", "focal_loss": "focal_loss",        # sigmoid head (stp_sigmoid_loss_ex)
+    "lovasz_loss": "lovasz_loss",                                                                # sigmoid head (stp_lovasz_hinge)
 }
-# registered by the reference, no kernel here (a per-image sort): named so the error is explicit
-unsupported_objects = ("lovasz_loss",)
+unsupported_objects = ()
 
 extra_train = generic.extra_train     # name -> dataset added to every fold's training indexes (reference :29, README.md:698-709)
 dataset_augmenters = {}

@@ -21,14 +21,14 @@ CAPTURE_MODE = "thread_local"
 SCALAR_NAMES = ("loss", "binary_crossentropy", "dice_loss", "dice", "binary_accuracy")
 
 
-EXTENDED_LOSSES = ("iou_loss", "jaccard_loss", "focal_loss")      # sigmoid head only (stp_sigmoid_loss_ex)
+EXTENDED_LOSSES = ("iou_loss", "jaccard_loss", "focal_loss", "lovasz_loss")      # sigmoid head only (stp_sigmoid_loss_ex, stp_lovasz_hinge)
 
 
 def parse_loss(spec, classes=1, architecture=None):
     """``"binary_crossentropy+0.1*dice_loss"`` -> (w_ce, w_dice) or, when the spec names one of the other registry entries
-    of reference segmentation.py:15-22, (w_ce, w_dice, w_iou, w_jaccard, w_focal)  (grammar: reference README.md:210-214).
+    of reference segmentation.py:15-22, (w_ce, w_dice, w_iou, w_jaccard, w_focal, w_lovasz)  (grammar: reference README.md:210-214).
     The cross-entropy term is ``binary_crossentropy`` for the 1-class sigmoid head and ``categorical_crossentropy`` for
-    the softmax head (schemas/segmentation.raml:12-21).  ``lovasz_loss`` (a per-image sort) has no kernel here."""
+    the softmax head (schemas/segmentation.raml:12-21)."""
     ce = "binary_crossentropy" if classes == 1 else "categorical_crossentropy"
     w = {ce: 0.0, "dice_loss": 0.0}
     if classes == 1 and architecture != "DeepLabV3":
@@ -414,6 +414,7 @@ class HipSegModel(object):
         out["iou"], out["iot"] = float(s[8]), float(s[9])
         if len(self.loss_w) > 2:
             out["iou_loss"], out["jaccard_loss"], out["focal_loss"] = 1.0 - float(s[8]), float(s[10]), float(s[11])
+            out["lovasz_loss"] = float(s[12])
         return out
 
     def logits(self):

@@ -1139,14 +1139,14 @@ class Plan(object):
             self._tape.append(back)
         return out
 
-    def sigmoid_loss(self, logits, target, w_bce, w_dice, w_iou=0.0, w_jaccard=0.0, w_focal=0.0):
-        """sigmoid + w_bce*binary_crossentropy + w_dice*dice_loss [+ w*iou_loss + w*jaccard_loss + w*focal_loss, the rest of
-        the registry at reference segmentation.py:15-22]; seeds the backward pass."""
+    def sigmoid_loss(self, logits, target, w_bce, w_dice, w_iou=0.0, w_jaccard=0.0, w_focal=0.0, w_lovasz=0.0):
+        """sigmoid + w_bce*binary_crossentropy + w_dice*dice_loss [+ w*iou_loss + w*jaccard_loss + w*focal_loss + w*lovasz_loss,
+        the rest of the registry at reference segmentation.py:15-22]; seeds the backward pass."""
         if logits.C != 1:
             raise StpShapeError("binary loss expects one class")
         if self.dry:
             return
-        self.loss_scalars = self._alloc((12,), torch.float32)
+        self.loss_scalars = self._alloc((16,), torch.float32)
         self.loss_scalars.zero_()
         count = logits.rows
         dl = self._gradbuf(logits) if self.training else None
@@ -1160,6 +1160,14 @@ class Plan(object):
             self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),
                        float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC, 1.0,
                        self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        if w_lovasz:      # per-image Lovasz hinge: ADDS to scalars[0] and to the gradient the launch above wrote
+            nbytes = int(self.lib.stp_lovasz_workspace_bytes(count, self.N))
+            if nbytes <= 0:
+                raise StpShapeError("lovasz_loss: the sort workspace cannot be sized (no device)")
+            self.ws_lovasz = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._emit(self.fwd, "stp_lovasz_hinge", logits.buf.data_ptr(), target.buf.data_ptr(), self.N, count // self.N, self.cdt,
+                       float(w_lovasz), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC,
+                       self.ws_lovasz.data_ptr(), nbytes)
         logits.grad_ready = self.training
 
     def softmax_loss(self, logits, target, w_cce, w_dice):

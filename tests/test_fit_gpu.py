@@ -325,3 +325,26 @@ def test_deeplabv3_xception_yaml_fits(tmp_path):
     assert float(rows[-1]["loss"]) < float(rows[0]["loss"])
     model = cfg.load_model(0, 0)
     assert "middle_flow_unit_16_separable_conv3_pointwise/kernel" in model.impl.get_weights()
+
+
+def test_readme_stage_loss_override_lovasz(tmp_path):
+    """reference README.md:370-383: a second stage that overrides the loss with `lovasz_loss` (the stage recompiles the model
+    with the stage's loss, starting from the previous stage's best weights); the metric columns of both stages exist."""
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    img_dir, msk_dir = make_dataset(str(tmp_path))
+    cfg_path = str(tmp_path / "stages.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Unet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid",
+                        "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.002, "batch": 4, "folds_count": 2,
+                        "loss": "binary_crossentropy", "metrics": ["binary_accuracy", "dice"], "primary_metric": "val_dice",
+                        "augmentation": {"Fliplr": 0.5},
+                        "stages": [{"epochs": 4}, {"epochs": 3, "loss": "lovasz_loss", "lr": 0.0005}]}, f)
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
+    assert [(s["fold"], s["stage"]) for s in out] == [(0, 0), (0, 1)]
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.1.csv")) as f:
+        rows = list(csv.DictReader(f))
+    losses = [float(r["loss"]) for r in rows]
+    assert len(rows) == 3 and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert os.path.exists(os.path.join(str(tmp_path), "weights", "best-0.1.weights"))

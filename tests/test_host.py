@@ -86,8 +86,12 @@ def test_stages_and_unfreeze(tmp_path):
 def test_loss_grammar():
     assert parse_loss("binary_crossentropy+0.1*dice_loss") == (1.0, 0.1)
     assert parse_loss("dice_loss") == (0.0, 1.0)
+    assert parse_loss("lovasz_loss") == (0.0, 0.0, 0.0, 0.0, 0.0, 1.0)
+    assert parse_loss("binary_crossentropy+0.5*iou_loss") == (1.0, 0.0, 0.5, 0.0, 0.0, 0.0)
     with pytest.raises(ValueError):
-        parse_loss("lovasz_loss")
+        parse_loss("hinge_loss")
+    with pytest.raises(ValueError):
+        parse_loss("lovasz_loss", classes=3)
 
 
 def test_kfold_is_deterministic_disjoint_and_respects_test_split():

@@ -1326,6 +1326,53 @@ def test_sigmoid_registry_losses_and_gradient(ops, dtype, spec, w5):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("h,w", [(48, 50), (32, 32)])
+def test_lovasz_hinge_loss_and_gradient(ops, dtype, h, w):
+    """stp_lovasz_hinge (lovasz_loss of the registry, reference segmentation.py:18) against the oracle's per-image Lovasz hinge:
+    three images, one of them without positives, image size not a multiple of the scan chunk; the result is ADDED to what
+    stp_sigmoid_bce_dice left in scalars[0] and dlogits."""
+    from segmentation_training_pipeline_amd import _lib
+    rng = np.random.RandomState(23)
+    n = 3
+    count = n * h * w
+    z = q(rng.randn(count) * 3, dtype)
+    z[:4] = q(np.array([30.0, -30.0, 17.0, -17.0]), dtype)
+    y = (rng.rand(count) < 0.3).astype(np.uint8)
+    y[h * w:2 * h * w] = 0                                     # an image without positives
+    zt = torch.from_numpy(z).requires_grad_(True)
+    yt = torch.from_numpy(y.astype(np.float32))
+    p = torch.sigmoid(zt)
+    spec = "binary_crossentropy+0.5*lovasz_loss"
+    loss = olosses.composite_loss(spec, yt.reshape(n, h, w, 1), p.reshape(n, h, w, 1))
+    loss.backward()
+    lov = float(olosses.lovasz_loss(yt.reshape(n, h, w, 1), p.detach().reshape(n, h, w, 1)))
+    scal = torch.zeros(16, device=DEV)
+    C = 8 if dtype == "bf16" else 4
+    dl = torch.full((count, C), float("nan"), dtype=TD[dtype], device=DEV)
+    ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
+    zd, yd = dev(z, dtype), keep(torch.from_numpy(y).to(DEV))
+    ops.sigmoid_bce_dice(zd, yd, count, 1.0, 0.0, scal, dl, C, 1.0, ws)
+    nbytes = int(_lib.load().stp_lovasz_workspace_bytes(count, n))
+    assert nbytes > 0
+    wl = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.call("stp_lovasz_hinge", ops.ptr(zd), ops.ptr(yd), n, h * w, ops.dt(zd), 0.5, ops.ptr(scal), ops.ptr(dl), C, ops.ptr(wl), nbytes,
+              ops.stream())
+    s = host(scal)
+    assert abs(s[12] - lov) < 1e-4 * max(1.0, lov)
+    assert abs(s[0] - float(loss.detach())) < 1e-4 * max(1.0, abs(float(loss.detach())))
+    g = host(dl)
+    ref = zt.grad.numpy()
+    if dtype == "fp32":
+        np.testing.assert_allclose(g[:, 0], ref, atol=2e-8, rtol=1e-4)
+    else:
+        np.testing.assert_allclose(g[:, 0], ref, atol=1e-2 * np.abs(ref).max(), rtol=2e-2)
+    np.testing.assert_array_equal(g[:, 1:], 0)
+    # too small a workspace is refused
+    assert _lib.load().stp_lovasz_hinge(ops.ptr(zd), ops.ptr(yd), n, h * w, ops.dt(zd), 0.5, ops.ptr(scal), ops.ptr(dl), C, ops.ptr(wl), 1024,
+                                        None) != 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("classes,ldc", [(3, 3), (5, 8), (21, 24)])
 def test_softmax_categorical_crossentropy_dice_loss_and_gradient(ops, dtype, classes, ldc):
     """stp_softmax_cce_dice / stp_softmax against the oracle's Keras categorical_crossentropy (+ musket dice over all class
