@@ -465,6 +465,20 @@ int stp_augment_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, ui
 #define STP_FILTER_RECORD 173
 int stp_filter_u8(const uint8_t* src, uint8_t* dst, const int32_t* params, int32_t N, int32_t H, int32_t W, int32_t C,
                   void* stream);
+/* The non-affine geometric augmenters (schemas/augmenters.raml:126-133) as a per-pixel displacement field [N][Hout][Wout]
+ * (int32 = two int16 (dx, dy) in 1/64 pixel) that stp_augment_field_u8 adds to the output pixel position before its matrix:
+ * out(p) = in(M (p + D(p))), image bilinear / mask nearest as in stp_augment_u8 (field NULL = stp_augment_u8).
+ * stp_field_piecewise: PiecewiseAffine - grid int32 [N][rows][cols][2] = control-point jitter in 1/64 pixel at
+ * linspace(0, H, rows) x linspace(0, W, cols), affine per triangle.  stp_field_elastic: ElasticTransformation - per image
+ * int32[STP_ELASTIC_RECORD] = seed, alpha (1/64 pixel), blur radius r <= 64, 0, one-sided Gaussian weights w[0..r] in 1/32768
+ * (full kernel sums to 32768); tmp is a scratch buffer of the field's size.  Integer arithmetic, bit-exact against the oracle. */
+#define STP_ELASTIC_RECORD 69
+int stp_augment_field_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out, const float* params,
+                         const int32_t* field, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t C,
+                         void* stream);
+int stp_field_piecewise(int32_t* field, const int32_t* grid, int32_t N, int32_t H, int32_t W, int32_t rows, int32_t cols,
+                        void* stream);
+int stp_field_elastic(int32_t* field, int32_t* tmp, const int32_t* params, int32_t N, int32_t H, int32_t W, void* stream);
 
 /* Gradient-bucket helpers for the RCCL all-reduce (fp32 <-> bf16 wire format). */
 int stp_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);

@@ -177,15 +177,71 @@ def compose(h, w, steps, out_hw):
     return c.M
 
 
-def warp_u8(img, mask, params, out_hw):
-    """img [N,H,W,C] u8, mask [N,H,W] u8 or None, params float32 [N,24] -> (img_out, mask_out)."""
+def field_piecewise(grid, h, w):
+    """PiecewiseAffine displacement field (imgaug / skimage PiecewiseAffineTransform, schemas/augmenters.raml:126-129): control
+    points at linspace(0, h, rows) x linspace(0, w, cols) moved by ``grid`` int [n, rows, cols, 2] = (dx, dy) in 1/64 pixel;
+    affine on each of the two triangles the (0,0)-(1,1) diagonal cuts a cell into, cell position with 10 fractional bits.
+    Returns int64 [n, h, w, 2]."""
+    grid = np.asarray(grid, np.int64)
+    n, R, Cg, _ = grid.shape
+    x, y = np.arange(w, dtype=np.int64)[None, :], np.arange(h, dtype=np.int64)[:, None]
+    u, v = x * (Cg - 1) * 1024 // w, y * (R - 1) * 1024 // h
+    cx, cy = np.minimum(u >> 10, Cg - 2), np.minimum(v >> 10, R - 2)
+    fu, fv = np.broadcast_to(u - (cx << 10), (h, w)), np.broadcast_to(v - (cy << 10), (h, w))
+    cxb, cyb = np.broadcast_to(cx, (h, w)), np.broadcast_to(cy, (h, w))
+    out = np.zeros((n, h, w, 2), np.int64)
+    for i in range(n):
+        g = grid[i]
+        d00, d10, d01, d11 = g[cyb, cxb], g[cyb, cxb + 1], g[cyb + 1, cxb], g[cyb + 1, cxb + 1]
+        lower = (fu >= fv)[..., None]
+        t = np.where(lower, d00 * 1024 + fu[..., None] * (d10 - d00) + fv[..., None] * (d11 - d10),
+                     d00 * 1024 + fv[..., None] * (d01 - d00) + fu[..., None] * (d11 - d01))
+        out[i] = np.clip((t + 512) >> 10, -32768, 32767)
+    return out
+
+
+ELASTIC_RECORD = 69
+
+
+def field_elastic(recs, h, w):
+    """ElasticTransformation displacement field (imgaug: uniform(-1, 1) noise per pixel and axis, gaussian_filter(sigma,
+    mode='constant'), times alpha; schemas/augmenters.raml:130-133).  recs int [n, 69]: seed, alpha (1/64 pixel), radius,
+    0, one-sided weights in 1/32768.  The kernel's integer arithmetic: noise = 16 hash bits - 32768, two separable passes
+    each rounded to 1/32768, displacement = (alpha * v + 2^14) >> 15.  Returns int64 [n, h, w, 2]."""
+    recs = np.asarray(recs, np.int64)
+    n = recs.shape[0]
+    out = np.zeros((n, h, w, 2), np.int64)
+    pix = (np.arange(h, dtype=np.int64)[:, None] * w + np.arange(w, dtype=np.int64)[None, :])
+    for i in range(n):
+        seed, alpha, r = int(recs[i, 0]), int(recs[i, 1]), int(recs[i, 2])
+        wk = recs[i, 4:4 + r + 1]
+        for a in range(2):
+            nz = (aug_hash(seed, pix, np.asarray(a), 7).astype(np.int64) >> 16) - 32768
+            pad = np.zeros((h, w + 2 * r), np.int64)
+            pad[:, r:r + w] = nz
+            s = sum(int(wk[abs(k)]) * pad[:, r + k:r + k + w] for k in range(-r, r + 1))
+            t = np.clip((s + 16384) >> 15, -32768, 32767)
+            pad = np.zeros((h + 2 * r, w), np.int64)
+            pad[r:r + h] = t
+            s = sum(int(wk[abs(k)]) * pad[r + k:r + k + h] for k in range(-r, r + 1))
+            v = (s + 16384) >> 15
+            out[i, :, :, a] = np.clip((alpha * v + 16384) >> 15, -32768, 32767)
+    return out
+
+
+def warp_u8(img, mask, params, out_hw, field=None):
+    """img [N,H,W,C] u8, mask [N,H,W] u8 or None, params float32 [N,24] -> (img_out, mask_out).  ``field``: int [N,oh,ow,2]
+    displacement (dx, dy) in 1/64 pixel added to the output pixel position before the matrix (field_piecewise / field_elastic)."""
     n, h, w, c = img.shape
     oh, ow = out_hw
-    xo = np.arange(ow, dtype=np.float64)[None, :]
-    yo = np.arange(oh, dtype=np.float64)[:, None]
     img_out = np.zeros((n, oh, ow, c), np.uint8)
     mask_out = None if mask is None else np.zeros((n, oh, ow), np.uint8)
     for i in range(n):
+        xo = np.arange(ow, dtype=np.float64)[None, :]
+        yo = np.arange(oh, dtype=np.float64)[:, None]
+        if field is not None:
+            xo = xo + field[i, :, :, 0].astype(np.float64) * 0.015625
+            yo = yo + field[i, :, :, 1].astype(np.float64) * 0.015625
         m = params[i, :6].astype(np.float64)
         X0 = np.rint(m[0] * xo * 1024.0).astype(np.int64) + np.rint((m[1] * yo + m[2]) * 1024.0).astype(np.int64)
         Y0 = np.rint(m[3] * xo * 1024.0).astype(np.int64) + np.rint((m[4] * yo + m[5]) * 1024.0).astype(np.int64)

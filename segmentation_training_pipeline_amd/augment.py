@@ -27,8 +27,12 @@ Supported augmenters (YAML name -> effect):
   neighbourhood filters (a second kernel, ``stp_filter_u8``, on the augmented batch at the network resolution, after the
     point operations; up to MAX_FILTERS per image, in the listed order): GaussianBlur{sigma}, AverageBlur{k},
     MedianBlur{k}, Sharpen{alpha, lightness}, Emboss{alpha, strength}, EdgeDetect{alpha}, DirectedEdgeDetect{alpha, direction}.
-PiecewiseAffine, ElasticTransformation and BackgroundReplacer raise ``ValueError`` naming the
-augmenter (no silent skipping).
+  displacement fields (``stp_field_piecewise`` / ``stp_field_elastic`` -> ``stp_augment_field_u8``: the pass's warp samples
+    at p + D(p), so the field costs no extra resampling): PiecewiseAffine{scale, nb_rows, nb_cols},
+    ElasticTransformation{alpha, sigma}.  One field per pass, after the pass's matrix geometry and before its point
+    operations; listed-order sampling only (``sample_staged`` / ``sample_batch_staged``).
+BackgroundReplacer (musket's own augmenter: needs a directory of background images) raises ``ValueError`` naming the augmenter
+(no silent skipping).
 """
 import math
 
@@ -38,6 +42,7 @@ AUG_RECORD = 24
 F_INVERT, F_NOISE_PC, F_DROP_PC, F_ADDE_PC, F_MULE_PC, F_ADDE, F_MULE = 1, 2, 4, 8, 16, 32, 64
 IRWIN_HALL_STD = 147.8   # std of the sum of 4 uniform bytes (the kernel's Gaussian-noise generator)
 FILTER_RECORD, FILTER_KMAX, MAX_FILTERS = 173, 13, 2
+ELASTIC_RECORD, ELASTIC_RMAX = 69, 64
 
 
 def _rng_range(rng, v, default):
@@ -68,6 +73,7 @@ class SampleParams(object):
         self.gray, self.noise, self.drop = 0.0, 0.0, 0.0
         self.adde, self.mule = None, None
         self.filters = []                           # [(K, mode, weights K*K float or None)]
+        self.disp = None                            # ("piecewise", rows, cols, int32 [rows*cols*2]) | ("elastic", int32 [69])
 
     # ---- geometry: every op appends the map from the NEW canvas to the PREVIOUS one
     def push(self, cur_to_prev):
@@ -95,7 +101,7 @@ class SampleParams(object):
 
 # rank of an augmenter inside one device pass (the kernel's order: warp, add, mul, mul-elementwise, add-elementwise, noise,
 # dropout, grayscale, invert; then the filter kernel)
-R_GEO, R_ADD, R_MUL, R_MULE, R_ADDE, R_NOISE, R_DROP, R_GRAY, R_INVERT, R_FILTER = range(10)
+R_GEO, R_DISP, R_ADD, R_MUL, R_MULE, R_ADDE, R_NOISE, R_DROP, R_GRAY, R_INVERT, R_FILTER = range(11)
 
 
 class Pipeline(object):
@@ -118,6 +124,16 @@ class Pipeline(object):
     def geo(self):
         if self.strict and self.ranks[-1] > R_GEO:
             self._new()
+        return self.cur
+
+    def displace(self):
+        """A displacement field follows the matrix geometry of its pass (the warp samples at p + D(p)); a second field, or one
+        after point operations / filters, opens a new pass."""
+        if not self.strict:
+            raise ValueError("PiecewiseAffine / ElasticTransformation need the listed-order sampler (sample_staged)")
+        if self.ranks[-1] >= R_DISP:
+            self._new()
+        self.ranks[-1] = R_DISP
         return self.cur
 
     def point(self, rank):
@@ -246,6 +262,40 @@ def _apply(spec, rng, pl):
                 if not pl.strict and len(pl.cur.filters) >= MAX_FILTERS:
                     raise ValueError("more than %d neighbourhood filters in one augmentation pass" % MAX_FILTERS)
                 pl.filt().filters.append(f)
+        elif name == "PiecewiseAffine":
+            # imgaug 0.3.0 geometric.PiecewiseAffine: a nb_rows x nb_cols grid at linspace(0, h) x linspace(0, w); every point is
+            # moved by normal(0, scale) * (h, w) and clipped into the image (schemas/augmenters.raml:126-129)
+            a = args if isinstance(args, dict) else {"scale": args}
+            scale = _rng_range(rng, a.get("scale"), 0.0)
+            rows, cols = int(a.get("nb_rows", 4)), int(a.get("nb_cols", 4))
+            if rows < 2 or cols < 2:
+                raise ValueError("PiecewiseAffine needs nb_rows, nb_cols >= 2")
+            if scale > 0:
+                sp = pl.displace()
+                ys, xs = np.meshgrid(np.linspace(0, sp.h, rows), np.linspace(0, sp.w, cols), indexing="ij")
+                jit = rng.normal(0.0, scale, size=(rows, cols, 2))
+                dy = np.clip(ys + jit[..., 0] * sp.h, 0, sp.h - 1) - ys
+                dx = np.clip(xs + jit[..., 1] * sp.w, 0, sp.w - 1) - xs
+                grid = np.stack([np.rint(dx * 64.0), np.rint(dy * 64.0)], axis=-1)
+                sp.disp = ("piecewise", rows, cols, np.clip(grid, -32768, 32767).astype(np.int32).reshape(-1))
+        elif name == "ElasticTransformation":
+            # imgaug 0.3.0 geometric.ElasticTransformation(alpha, sigma): see stp_field_elastic (schemas/augmenters.raml:130-133;
+            # `scale` there is read as sigma)
+            a = args if isinstance(args, dict) else {"alpha": args}
+            alpha = _rng_range(rng, a.get("alpha"), 0.0)
+            sigma = _rng_range(rng, a.get("sigma", a.get("scale")), 0.0)
+            if alpha > 0:
+                radius = int(4.0 * sigma + 0.5) if sigma > 0 else 0          # scipy.ndimage.gaussian_filter, truncate = 4
+                if radius > ELASTIC_RMAX:
+                    raise ValueError("ElasticTransformation: sigma %.3g needs a blur radius above %d" % (sigma, ELASTIC_RMAX))
+                k = np.arange(-radius, radius + 1, dtype=np.float64)
+                g = np.exp(-0.5 * (k / sigma) ** 2) if radius else np.ones(1)
+                q = np.rint(g / g.sum() * 32768.0).astype(np.int64)
+                q[radius] += 32768 - int(q.sum())                            # the quantised kernel keeps the DC gain exactly
+                rec = np.zeros(ELASTIC_RECORD, np.int32)
+                rec[0], rec[1], rec[2] = int(rng.randint(0, 1 << 24)), min(int(round(alpha * 64.0)), 1 << 15), radius
+                rec[4:4 + radius + 1] = q[radius:]
+                pl.displace().disp = ("elastic", rec)
         elif name == "Sequential":
             _apply(_children(args), rng, pl)
         elif name == "Sometimes":
@@ -386,8 +436,26 @@ def sample_staged(spec, rng, h, w, out_hw):
     for k, sp in enumerate(pl.stages):
         final = k == len(pl.stages) - 1
         rec = record(sp, (oh, ow) if final else None, _seed(sp, rng))
-        passes.append((rec, sp.filters, (int(round(sp.h)), int(round(sp.w)))))
+        hw = (int(round(sp.h)), int(round(sp.w)))
+        passes.append((rec, sp.filters, hw) if sp.disp is None else (rec, sp.filters, hw, sp.disp))
     return passes
+
+
+def _disp_key(p):
+    return None if len(p) < 4 else (p[3][0],) + (tuple(p[3][1:3]) if p[3][0] == "piecewise" else ())
+
+
+def batch_disp(disps):
+    """[displacement of one image] of equal kind -> the batch form: ("piecewise", rows, cols, int32 [n, rows*cols*2]) or
+    ("elastic", int32 [n, 69])."""
+    d0 = disps[0]
+    return (d0[0], d0[1], d0[2], np.stack([d[3] for d in disps])) if d0[0] == "piecewise" else (d0[0], np.stack([d[1] for d in disps]))
+
+
+def batch_of_one(p):
+    """One image's pass -> the batch form ``DeviceFeeder._run_passes`` executes (n = 1)."""
+    out = (p[0][None], filter_records([p[1]]), p[2])
+    return out if len(p) < 4 else out + (batch_disp([p[3]]),)
 
 
 def sample_batch_staged(spec, rng, n, h, w, out_hw):
@@ -397,9 +465,12 @@ def sample_batch_staged(spec, rng, n, h, w, out_hw):
     ``per-image passes`` = [sample_staged(...) per image] (Sometimes / OneOf changed the structure of some images)."""
     per = [sample_staged(spec, rng, h, w, out_hw) for _ in range(n)]
     k = len(per[0])
-    if all(len(p) == k and all(p[j][2] == per[0][j][2] for j in range(k)) for p in per):
-        return [(np.stack([p[j][0] for p in per]).astype(np.float32), filter_records([p[j][1] for p in per]), per[0][j][2])
-                for j in range(k)], None
+    if all(len(p) == k and all(p[j][2] == per[0][j][2] and _disp_key(p[j]) == _disp_key(per[0][j]) for j in range(k)) for p in per):
+        out = []
+        for j in range(k):
+            bp = (np.stack([p[j][0] for p in per]).astype(np.float32), filter_records([p[j][1] for p in per]), per[0][j][2])
+            out.append(bp if len(per[0][j]) < 4 else bp + (batch_disp([p[j][3] for p in per]),))
+        return out, None
     return None, per
 
 

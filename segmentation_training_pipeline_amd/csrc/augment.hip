@@ -43,18 +43,26 @@ __device__ __forceinline__ int64_t fix10(double v) { return (int64_t)__double2ll
 __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask,
                                                       uint8_t* __restrict__ img_out, uint8_t* __restrict__ mask_out,
                                                       const AugSample* __restrict__ prm, int N, int Hin, int Win, int Hout,
-                                                      int Wout, int C) {
+                                                      int Wout, int C, const int32_t* __restrict__ field) {
   const int64_t total = (int64_t)N * Hout * Wout;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int xo = (int)(i % Wout);
     const int yo = (int)((i / Wout) % Hout);
     const int n = (int)(i / ((int64_t)Wout * Hout));
     const AugSample s = prm[n];
+    // displacement field (PiecewiseAffine / ElasticTransformation): the output pixel samples the warped canvas at p + D(p),
+    // D in 1/64 pixel (two int16 per pixel) - exact in double, so the matrix arithmetic below is unchanged
+    double xd = (double)xo, yd = (double)yo;
+    if (field) {
+      const int32_t f = field[i];
+      xd = __dadd_rn(xd, __dmul_rn((double)(int16_t)(f & 0xffff), 0.015625));
+      yd = __dadd_rn(yd, __dmul_rn((double)(int16_t)(f >> 16), 0.015625));
+    }
     // no fused multiply-add here: the CPU oracle rounds each product and sum separately
-    const int64_t X0 = fix10(__dmul_rn(__dmul_rn((double)s.m[0], (double)xo), 1024.0)) +
-                       fix10(__dmul_rn(__dadd_rn(__dmul_rn((double)s.m[1], (double)yo), (double)s.m[2]), 1024.0));
-    const int64_t Y0 = fix10(__dmul_rn(__dmul_rn((double)s.m[3], (double)xo), 1024.0)) +
-                       fix10(__dmul_rn(__dadd_rn(__dmul_rn((double)s.m[4], (double)yo), (double)s.m[5]), 1024.0));
+    const int64_t X0 = fix10(__dmul_rn(__dmul_rn((double)s.m[0], xd), 1024.0)) +
+                       fix10(__dmul_rn(__dadd_rn(__dmul_rn((double)s.m[1], yd), (double)s.m[2]), 1024.0));
+    const int64_t Y0 = fix10(__dmul_rn(__dmul_rn((double)s.m[3], xd), 1024.0)) +
+                       fix10(__dmul_rn(__dadd_rn(__dmul_rn((double)s.m[4], yd), (double)s.m[5]), 1024.0));
     // image: bilinear, 5 fractional bits
     const int64_t X = (X0 + 16) >> 5, Y = (Y0 + 16) >> 5;
     const int64_t ix = X >> 5, iy = Y >> 5;
@@ -111,13 +119,126 @@ __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict_
   }
 }
 
-extern "C" int stp_augment_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out, const float* params,
-                              int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t C, void* stream) {
+static int launch_augment(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out, const float* params,
+                          const int32_t* field, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t C, void* stream) {
   if (!img || !img_out || !params || N <= 0 || C <= 0 || (mask && !mask_out)) return STP_E_BADARG;
   int64_t g = ((int64_t)N * Hout * Wout + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(augment_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, img, mask, img_out, mask_out,
-                     (const AugSample*)params, N, Hin, Win, Hout, Wout, C);
+                     (const AugSample*)params, N, Hin, Win, Hout, Wout, C, field);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_augment_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out, const float* params,
+                              int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t C, void* stream) {
+  return launch_augment(img, mask, img_out, mask_out, params, nullptr, N, Hin, Win, Hout, Wout, C, stream);
+}
+
+// the same pass with a per-pixel displacement field [N][Hout][Wout] (stp_field_piecewise / stp_field_elastic; NULL = none)
+extern "C" int stp_augment_field_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_out, uint8_t* mask_out, const float* params,
+                                    const int32_t* field, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t C,
+                                    void* stream) {
+  return launch_augment(img, mask, img_out, mask_out, params, field, N, Hin, Win, Hout, Wout, C, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Displacement fields of the two non-affine geometric augmenters (schemas/augmenters.raml:126-133), integer arithmetic
+// throughout (bit-exact against oracle/augment.py); a field entry packs (dx, dy) as two int16 in 1/64 pixel.
+__device__ __forceinline__ int32_t pack_disp(int dx, int dy) {
+  dx = min(max(dx, -32768), 32767);
+  dy = min(max(dy, -32768), 32767);
+  return (int32_t)(((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16));
+}
+
+// PiecewiseAffine: a rows x cols grid of control points at linspace(0, H, rows) x linspace(0, W, cols) (imgaug / skimage
+// PiecewiseAffineTransform), each moved by the sampled jitter grid[n][row][col] = (dx, dy) in 1/64 pixel; inside a cell the
+// displacement is affine on each of the two triangles the (0,0)-(1,1) diagonal cuts (10 fractional bits of cell position).
+__global__ __launch_bounds__(256) void field_piecewise_kernel(int32_t* __restrict__ field, const int32_t* __restrict__ grid, int N, int H, int W,
+                                                              int R, int Cg) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / ((int64_t)W * H));
+    const int64_t u = (int64_t)x * (Cg - 1) * 1024 / W, v = (int64_t)y * (R - 1) * 1024 / H;
+    const int cx = min((int)(u >> 10), Cg - 2), cy = min((int)(v >> 10), R - 2);
+    const int64_t fu = u - ((int64_t)cx << 10), fv = v - ((int64_t)cy << 10);
+    const int32_t* g = grid + (((int64_t)n * R + cy) * Cg + cx) * 2;
+    int d[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int64_t d00 = g[a], d10 = g[2 + a], d01 = g[2 * Cg + a], d11 = g[2 * Cg + 2 + a];
+      const int64_t t = fu >= fv ? d00 * 1024 + fu * (d10 - d00) + fv * (d11 - d10) : d00 * 1024 + fv * (d01 - d00) + fu * (d11 - d01);
+      d[a] = (int)((t + 512) >> 10);
+    }
+    field[i] = pack_disp(d[0], d[1]);
+  }
+}
+
+extern "C" int stp_field_piecewise(int32_t* field, const int32_t* grid, int32_t N, int32_t H, int32_t W, int32_t rows, int32_t cols,
+                                   void* stream) {
+  if (!field || !grid || N <= 0 || H <= 0 || W <= 0 || rows < 2 || cols < 2) return STP_E_BADARG;
+  int64_t g = ((int64_t)N * H * W + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(field_piecewise_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, field, grid, N, H, W, rows, cols);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ElasticTransformation (imgaug: uniform(-1, 1) noise per pixel and axis -> gaussian_filter(sigma, mode='constant') -> * alpha).
+// Record int32[STP_ELASTIC_RECORD = 4 + 65]: seed, alpha in 1/64 pixel, radius r (<= 64; scipy truncate = 4 sigma), 0, then the
+// one-sided kernel w[0..r] in 1/32768 (the full kernel sums to exactly 32768).  Noise = 16 hash bits - 32768; separable blur in
+// two passes, each rounded to 1/32768; displacement = (alpha * v + 2^14) >> 15.
+#define STP_ELASTIC_RECORD 69
+__global__ __launch_bounds__(256) void field_elastic_h_kernel(int32_t* __restrict__ tmp, const int32_t* __restrict__ prm, int N, int H, int W) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / ((int64_t)W * H));
+    const int32_t* p = prm + (int64_t)n * STP_ELASTIC_RECORD;
+    const uint32_t seed = (uint32_t)p[0];
+    const int r = p[2];
+    int t[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int sum = 0;
+      for (int k = -r; k <= r; ++k) {
+        const int xx = x + k;
+        if (xx < 0 || xx >= W) continue;
+        const int nz = (int)(aug_hash(seed, (uint32_t)(y * W + xx), (uint32_t)a, 7u) >> 16) - 32768;
+        sum += p[4 + (k < 0 ? -k : k)] * nz;
+      }
+      t[a] = (sum + 16384) >> 15;
+    }
+    tmp[i] = pack_disp(t[0], t[1]);
+  }
+}
+__global__ __launch_bounds__(256) void field_elastic_v_kernel(int32_t* __restrict__ field, const int32_t* __restrict__ tmp,
+                                                              const int32_t* __restrict__ prm, int N, int H, int W) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / ((int64_t)W * H));
+    const int32_t* p = prm + (int64_t)n * STP_ELASTIC_RECORD;
+    const int alpha = p[1], r = p[2];
+    int s0 = 0, s1 = 0;
+    for (int k = -r; k <= r; ++k) {
+      const int yy = y + k;
+      if (yy < 0 || yy >= H) continue;
+      const int32_t f = tmp[((int64_t)n * H + yy) * W + x];
+      const int wk = p[4 + (k < 0 ? -k : k)];
+      s0 += wk * (int)(int16_t)(f & 0xffff);
+      s1 += wk * (int)(int16_t)(f >> 16);
+    }
+    const int v0 = (s0 + 16384) >> 15, v1 = (s1 + 16384) >> 15;
+    field[i] = pack_disp((alpha * v0 + 16384) >> 15, (alpha * v1 + 16384) >> 15);
+  }
+}
+
+extern "C" int stp_field_elastic(int32_t* field, int32_t* tmp, const int32_t* params, int32_t N, int32_t H, int32_t W, void* stream) {
+  if (!field || !tmp || !params || field == tmp || N <= 0 || H <= 0 || W <= 0) return STP_E_BADARG;
+  int64_t g = ((int64_t)N * H * W + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(field_elastic_h_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, tmp, params, N, H, W);
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(field_elastic_v_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, field, tmp, params, N, H, W);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }

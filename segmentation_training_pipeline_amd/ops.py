@@ -190,15 +190,33 @@ def grad_global_scale(grad, count, clipnorm, base, gscale, workspace):
               workspace.numel() * workspace.element_size(), stream())
 
 
-def augment_u8(img, mask, img_out, mask_out, params, N, Hin, Win, Hout, Wout, Cn):
+def augment_u8(img, mask, img_out, mask_out, params, N, Hin, Win, Hout, Wout, Cn, field=None):
     # the C entry point takes raw pointers: a destination smaller than N x Hout x Wout (x Cn) would be written past its end
     if img_out.numel() < N * Hout * Wout * Cn or img.numel() < N * Hin * Win * Cn:
         raise ValueError("augment_u8: image buffers are smaller than N x H x W x C (%d < %d or %d < %d)" % (
             img_out.numel(), N * Hout * Wout * Cn, img.numel(), N * Hin * Win * Cn))
     if mask is not None and mask_out is not None and (mask_out.numel() < N * Hout * Wout or mask.numel() < N * Hin * Win):
         raise ValueError("augment_u8: mask buffers are smaller than N x H x W")
+    if field is not None:
+        if field.numel() < N * Hout * Wout:
+            raise ValueError("augment_u8: the displacement field is smaller than N x Hout x Wout")
+        _lib.call("stp_augment_field_u8", ptr(img), ptr(mask), ptr(img_out), ptr(mask_out), ptr(params), ptr(field), N, Hin, Win, Hout,
+                  Wout, Cn, stream())
+        return
     _lib.call("stp_augment_u8", ptr(img), ptr(mask), ptr(img_out), ptr(mask_out), ptr(params), N, Hin, Win, Hout, Wout, Cn,
               stream())
+
+
+def field_piecewise(field, grid, N, H, W, rows, cols):
+    if field.numel() < N * H * W or grid.numel() < N * rows * cols * 2:
+        raise ValueError("field_piecewise: buffers are smaller than N x H x W / N x rows x cols x 2")
+    _lib.call("stp_field_piecewise", ptr(field), ptr(grid), N, H, W, rows, cols, stream())
+
+
+def field_elastic(field, tmp, params, N, H, W):
+    if field.numel() < N * H * W or tmp.numel() < N * H * W:
+        raise ValueError("field_elastic: buffers are smaller than N x H x W")
+    _lib.call("stp_field_elastic", ptr(field), ptr(tmp), ptr(params), N, H, W, stream())
 
 
 def filter_u8(src, dst, params, N, H, W, Cn):

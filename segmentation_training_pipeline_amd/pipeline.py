@@ -477,8 +477,7 @@ class DeviceFeeder(object):
         for i, (it, xd, yd) in enumerate(staged):
             passes = augment.sample_staged(self.spec if training else [], self.rng, it.h, it.w, (oh, ow))
             self._keep += [xd, yd, it]
-            self._run_passes(xd, yd, img_buf[i], msk_buf[i], [(p[0][None], augment.filter_records([p[1]]), p[2]) for p in passes],
-                             1, it.h, it.w)
+            self._run_passes(xd, yd, img_buf[i], msk_buf[i], [augment.batch_of_one(p) for p in passes], 1, it.h, it.w)
 
     def _run_passes(self, x, y, img_out, msk_out, passes, n, h, w):
         """Executes the device passes of a sampled pipeline (augment.sample_staged / sample_batch_staged) on ``n`` images of
@@ -486,20 +485,33 @@ class DeviceFeeder(object):
         launch per neighbourhood filter (ping-pong buffers); the last launch writes the plan's input buffers."""
         ch = self.channels
         lead = (n,) if x.dim() == 4 else ()
-        for k, (prm, filt, (ph, pw)) in enumerate(passes):
+        for k, ps_ in enumerate(passes):
+            prm, filt, (ph, pw) = ps_[:3]
             final = k == len(passes) - 1
             pd = torch.from_numpy(np.ascontiguousarray(prm, dtype=np.float32)).to(self.device, non_blocking=True)
             ydst = msk_out if final else torch.empty(lead + (ph, pw), dtype=torch.uint8, device=self.device)
             self._keep += [pd, ydst]
+            field = None
+            if len(ps_) > 3:      # PiecewiseAffine / ElasticTransformation: the per-pixel displacement this pass's warp adds
+                disp = ps_[3]
+                field = torch.empty((n, ph, pw), dtype=torch.int32, device=self.device)
+                rd = torch.from_numpy(np.ascontiguousarray(disp[-1], dtype=np.int32)).to(self.device, non_blocking=True)
+                self._keep += [field, rd]
+                if disp[0] == "piecewise":
+                    ops.field_piecewise(field, rd, n, ph, pw, disp[1], disp[2])
+                else:
+                    tmp = torch.empty_like(field)
+                    self._keep.append(tmp)
+                    ops.field_elastic(field, tmp, rd, n, ph, pw)
             if filt is None:
                 xdst = img_out if final else torch.empty(lead + (ph, pw, ch), dtype=torch.uint8, device=self.device)
                 self._keep.append(xdst)
-                ops.augment_u8(x, y, xdst, ydst, pd, n, h, w, ph, pw, ch)
+                ops.augment_u8(x, y, xdst, ydst, pd, n, h, w, ph, pw, ch, field)
             else:
                 fd = torch.from_numpy(filt).to(self.device, non_blocking=True)
                 bufs = [torch.empty(lead + (ph, pw, ch), dtype=torch.uint8, device=self.device) for _ in range(2)]
                 self._keep += [fd] + bufs
-                ops.augment_u8(x, y, bufs[0], ydst, pd, n, h, w, ph, pw, ch)
+                ops.augment_u8(x, y, bufs[0], ydst, pd, n, h, w, ph, pw, ch, field)
                 src = 0
                 for ps in range(filt.shape[0]):
                     last_f = ps == filt.shape[0] - 1
@@ -528,8 +540,7 @@ def _feed_block(self, plan, hb):
         self._run_passes(xd, yd, img_buf, msk_buf, hb.passes, n, hb.h, hb.w)
         return
     for i, item_passes in enumerate(hb.per_item):
-        self._run_passes(xd[i], yd[i], img_buf[i], msk_buf[i], [(p[0][None], augment.filter_records([p[1]]), p[2]) for p in item_passes],
-                         1, hb.h, hb.w)
+        self._run_passes(xd[i], yd[i], img_buf[i], msk_buf[i], [augment.batch_of_one(p) for p in item_passes], 1, hb.h, hb.w)
 
 
 DeviceFeeder._feed_block = _feed_block

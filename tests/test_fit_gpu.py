@@ -138,7 +138,10 @@ def test_linknet_yaml_fits(tmp_path):
                         "augmentation": {"Fliplr": 0.5, "CropAndPad": {"percent": [-0.05, 0.05]},
                                          "OneOf": [{"GaussianBlur": {"sigma": [0.0, 1.0]}}, {"AverageBlur": {"k": 3}},
                                                    {"MedianBlur": {"k": 3}}],
-                                         "AdditiveGaussianNoise": {"scale": [0, 8]}, "Multiply": {"mul": [0.9, 1.1], "per_channel": True}}}, f)
+                                         "AdditiveGaussianNoise": {"scale": [0, 8]}, "Multiply": {"mul": [0.9, 1.1], "per_channel": True},
+                                         # the displacement-field augmenters (schemas/augmenters.raml:126-133): passes of their own here
+                                         "PiecewiseAffine": {"scale": [0.01, 0.03]},
+                                         "ElasticTransformation": {"alpha": [0, 20], "sigma": 4.0}}}, f)
     cfg = segmentation.parse(cfg_path)
     out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
     assert [(s["fold"], s["stage"]) for s in out] == [(0, 0)]

@@ -236,6 +236,49 @@ def test_augmentation_passes_follow_the_listed_order():
     assert bp is None and sorted({len(q) for q in per}) == [1, 2]
 
 
+def test_displacement_augmenters_sample_into_their_own_passes_and_the_oracle_fields_behave():
+    """PiecewiseAffine / ElasticTransformation (schemas/augmenters.raml:126-133): a pass carries ONE displacement field after its
+    matrix geometry; the oracle's integer fields: zero jitter = zero field, constant jitter = constant field, the elastic
+    field scales with alpha and is bounded by it."""
+    from oracle import augment as oaug
+    rng = np.random.RandomState(3)
+    spec = [{"Fliplr": 1.0}, {"PiecewiseAffine": {"scale": [0.02, 0.05]}}, {"Add": 5},
+            {"ElasticTransformation": {"alpha": [20, 40], "sigma": [3, 5]}}, {"PiecewiseAffine": {"scale": 0.03, "nb_rows": 3, "nb_cols": 5}}]
+    p = augment.sample_staged(spec, rng, 40, 52, (40, 52))
+    assert [len(q) for q in p] == [4, 4, 4] and [q[3][0] for q in p] == ["piecewise", "elastic", "piecewise"]
+    assert p[0][0][0] == -1 and list(p[0][0][6:9]) == [5, 5, 5] and p[1][0][6] == 0          # flip + field + Add | field | field
+    assert p[0][3][1:3] == (4, 4) and p[0][3][3].shape == (32,) and p[2][3][1:3] == (3, 5)
+    rec = p[1][3][1]
+    assert rec.shape == (augment.ELASTIC_RECORD,) and 20 * 64 <= rec[1] <= 40 * 64 and 12 <= rec[2] <= 20
+    assert int(rec[4]) + 2 * int(rec[5:5 + rec[2]].sum()) == 32768                              # exact DC gain
+    # scale 0 / alpha 0: no field, no extra pass; the merged sampler refuses fields
+    assert [len(q) for q in augment.sample_staged([{"PiecewiseAffine": 0.0}, {"ElasticTransformation": {"alpha": 0}}], rng, 8, 8, (8, 8))] == [3]
+    with pytest.raises(ValueError):
+        augment.sample_batch_ex([{"PiecewiseAffine": 0.05}], rng, 1, 8, 8, (8, 8))
+    with pytest.raises(ValueError):
+        augment.sample_staged([{"BackgroundReplacer": {"path": "x"}}], rng, 8, 8, (8, 8))
+    # a resize after a field is a pass of its own
+    r = augment.sample_staged([{"PiecewiseAffine": 0.05}], rng, 40, 52, (20, 26))
+    assert [len(q) for q in r] == [4, 3] and r[0][2] == (40, 52) and r[1][2] == (20, 26)
+    # batches
+    bp, per = augment.sample_batch_staged([{"ElasticTransformation": {"alpha": 30, "sigma": 4}}], rng, 3, 16, 16, (16, 16))
+    assert per is None and bp[0][3][0] == "elastic" and bp[0][3][1].shape == (3, augment.ELASTIC_RECORD)
+    bp, per = augment.sample_batch_staged([{"OneOf": [{"PiecewiseAffine": 0.05}, {"ElasticTransformation": {"alpha": 30, "sigma": 4}}]}],
+                                          np.random.RandomState(0), 8, 16, 16, (16, 16))
+    assert bp is None and {q[0][3][0] for q in per} == {"piecewise", "elastic"}
+    # oracle fields
+    assert not oaug.field_piecewise(np.zeros((1, 4, 4, 2), np.int32), 20, 30).any()
+    assert set(np.unique(oaug.field_piecewise(np.full((2, 3, 5, 2), -64), 20, 30))) == {-64}
+    g = np.zeros((1, 2, 2, 2), np.int32)
+    g[0, :, 1, 0] = 640                                                     # right edge moves 10 px in x: a linear ramp in x
+    f = oaug.field_piecewise(g, 8, 10)
+    assert (f[..., 1] == 0).all() and (np.diff(f[0, 0, :, 0]) >= 0).all() and f[0, 0, 0, 0] == 0 and (f[0, :, :, 0] == f[0, :1, :, 0]).all()
+    e1 = oaug.field_elastic(p[1][3][1][None], 40, 52)
+    half = p[1][3][1].copy(); half[1] //= 2
+    e2 = oaug.field_elastic(half[None], 40, 52)
+    assert np.abs(e1).max() <= rec[1] and e1.std() > 8 and np.abs(e1 - 2 * e2).max() <= 2
+
+
 def test_cfg_gpus_without_torchrun_explains_how_to_launch(tmp_path, monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     cfg = segmentation.parse(write_cfg(tmp_path))

@@ -1621,6 +1621,74 @@ def test_listed_order_augmentation_passes_bit_exact(ops):
     assert not np.array_equal(mi, rimg)
 
 
+def test_displacement_field_augmenters_bit_exact(ops):
+    """PiecewiseAffine / ElasticTransformation on the device (stp_field_piecewise / stp_field_elastic -> stp_augment_field_u8)
+    against the numpy oracle: the fields themselves and the full listed-order pipeline through DeviceFeeder._run_passes (batch
+    and per-image form), bit for bit."""
+    from segmentation_training_pipeline_amd import augment, pipeline
+    n, h, w, ch, out = 3, 40, 52, 3, (32, 48)
+    rng = np.random.RandomState(29)
+    img = rng.randint(0, 256, size=(n, h, w, ch)).astype(np.uint8)
+    msk = rng.randint(0, 4, size=(n, h, w)).astype(np.uint8)
+    # the fields
+    grid = rng.randint(-300, 300, size=(n, 4, 5, 2)).astype(np.int32)
+    fd = torch.empty((n, h, w), dtype=torch.int32, device=DEV)
+    ops.field_piecewise(fd, keep(torch.from_numpy(grid).to(DEV)), n, h, w, 4, 5)
+    ref = oaug.field_piecewise(grid, h, w)
+    got = fd.cpu().numpy()
+    np.testing.assert_array_equal((got << 16) >> 16, ref[..., 0])
+    np.testing.assert_array_equal(got >> 16, ref[..., 1])
+    bp, per = augment.sample_batch_staged([{"ElasticTransformation": {"alpha": [20, 40], "sigma": [0.0, 5.0]}}], np.random.RandomState(2), n, h, w, (h, w))
+    recs = bp[0][3][1]
+    recs[0, 2], recs[0, 4:] = 0, 0
+    recs[0, 4] = 32768                                                        # sigma 0: the raw noise times alpha
+    tmp = torch.empty_like(fd)
+    ops.field_elastic(fd, tmp, keep(torch.from_numpy(recs).to(DEV)), n, h, w)
+    ref = oaug.field_elastic(recs, h, w)
+    got = fd.cpu().numpy()
+    np.testing.assert_array_equal((got << 16) >> 16, ref[..., 0])
+    np.testing.assert_array_equal(got >> 16, ref[..., 1])
+    assert np.abs(ref[1:]).max() > 30                                         # (a visible displacement, > 0.5 px)
+    # the pipeline: geometry + field in one pass, a second field after colour, a filter, the resize last
+    spec = [{"Affine": {"rotate": [-20, 20], "scale": [0.8, 1.2]}}, {"PiecewiseAffine": {"scale": [0.02, 0.05]}}, {"Add": [-20, 20]},
+            {"ElasticTransformation": {"alpha": [20, 40], "sigma": [2.0, 4.0]}}, {"GaussianBlur": {"sigma": [0.5, 1.5]}}]
+    passes, per = augment.sample_batch_staged(spec, np.random.RandomState(5), n, h, w, out)
+    assert per is None and [len(p) for p in passes] == [4, 4, 3] and passes[-1][2] == out
+    rimg, rmsk = img, msk
+    for p in passes:
+        field = None
+        if len(p) > 3:
+            field = oaug.field_piecewise(p[3][3].reshape(n, p[3][1], p[3][2], 2), *p[2]) if p[3][0] == "piecewise" else oaug.field_elastic(p[3][1], *p[2])
+        rimg, rmsk = oaug.warp_u8(rimg, rmsk, p[0], p[2], field)
+        if p[1] is not None:
+            for ps in range(p[1].shape[0]):
+                rimg = oaug.filter_u8(rimg, p[1][ps])
+    feeder = pipeline.DeviceFeeder(DEV, out, spec, seed=0, classes=4, channels=ch)
+    xd, yd = keep(torch.from_numpy(img).to(DEV)), keep(torch.from_numpy(msk).to(DEV))
+    oi = torch.zeros((n,) + out + (ch,), dtype=torch.uint8, device=DEV)
+    om = torch.zeros((n,) + out, dtype=torch.uint8, device=DEV)
+    feeder._run_passes(xd, yd, oi, om, passes, n, h, w)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oi.cpu().numpy(), rimg)
+    np.testing.assert_array_equal(om.cpu().numpy(), rmsk)
+    # the fields moved pixels: the same records without them give another image
+    plain, _ = oaug.warp_u8(img, msk, passes[0][0], passes[0][2])
+    withf, _ = oaug.warp_u8(img, msk, passes[0][0], passes[0][2], oaug.field_piecewise(passes[0][3][3].reshape(n, 4, 4, 2), *passes[0][2]))
+    assert (plain != withf).mean() > 0.3
+    # per-image execution of the same records
+    oi2, om2 = torch.zeros_like(oi), torch.zeros_like(om)
+    for i in range(n):
+        one = []
+        for p in passes:
+            q = (p[0][i:i + 1], None if p[1] is None else p[1][:, i:i + 1], p[2])
+            if len(p) > 3:
+                q += ((p[3][0], p[3][1], p[3][2], p[3][3][i:i + 1]) if p[3][0] == "piecewise" else (p[3][0], p[3][1][i:i + 1]),)
+            one.append(q)
+        feeder._run_passes(xd[i], yd[i], oi2[i], om2[i], one, 1, h, w)
+    torch.cuda.synchronize()
+    assert torch.equal(oi2, oi) and torch.equal(om2, om)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_batched_weight_prepare_equals_per_layer(ops, dtype):
     """The once-per-step batched launch (LDS tile transpose) must write exactly what stp_weight_prepare writes
