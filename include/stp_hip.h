@@ -479,6 +479,10 @@ int stp_augment_field_u8(const uint8_t* img, const uint8_t* mask, uint8_t* img_o
 int stp_field_piecewise(int32_t* field, const int32_t* grid, int32_t N, int32_t H, int32_t W, int32_t rows, int32_t cols,
                         void* stream);
 int stp_field_elastic(int32_t* field, int32_t* tmp, const int32_t* params, int32_t N, int32_t H, int32_t W, void* stream);
+/* BackgroundReplacer (README.md:270-278, FAQ.md:24-38): out = img inside the mask eroded by a (2*erosion+1)^2 minimum, bg
+ * (a background image already resized to H x W, same layout as img) elsewhere; out != img; the mask is not changed. */
+int stp_background_replace_u8(const uint8_t* img, const uint8_t* mask, const uint8_t* bg, uint8_t* out, int32_t N, int32_t H,
+                              int32_t W, int32_t C, int32_t erosion, void* stream);
 
 /* Gradient-bucket helpers for the RCCL all-reduce (fp32 <-> bf16 wire format). */
 int stp_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);

@@ -200,6 +200,21 @@ def field_piecewise(grid, h, w):
     return out
 
 
+def background_replace_u8(img, mask, bg, erosion=0):
+    """BackgroundReplacer (reference README.md:270-278): img [N,H,W,C], mask [N,H,W], bg [N,H,W,C] (already at the item's size) ->
+    img inside the mask eroded by a (2e+1)^2 minimum (image border does not erode), bg elsewhere."""
+    n, h, w = mask.shape
+    fg = mask != 0
+    er = fg.copy()
+    for dy in range(-erosion, erosion + 1):
+        for dx in range(-erosion, erosion + 1):
+            sh = np.ones_like(fg)
+            ys, ye, xs, xe = max(0, -dy), min(h, h - dy), max(0, -dx), min(w, w - dx)
+            sh[:, ys:ye, xs:xe] = fg[:, ys + dy:ye + dy, xs + dx:xe + dx]
+            er &= sh
+    return np.where(er[..., None], img, bg).astype(np.uint8)
+
+
 ELASTIC_RECORD = 69
 
 

@@ -134,6 +134,7 @@ SIGNATURES = {
     "stp_augment_field_u8": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_field_piecewise": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_field_elastic": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "stp_background_replace_u8": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "stp_cast_bf16_to_f32": (i32, [vp, vp, i64, f32, vp]),
 }

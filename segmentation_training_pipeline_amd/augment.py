@@ -31,9 +31,13 @@ Supported augmenters (YAML name -> effect):
     at p + D(p), so the field costs no extra resampling): PiecewiseAffine{scale, nb_rows, nb_cols},
     ElasticTransformation{alpha, sigma}.  One field per pass, after the pass's matrix geometry and before its point
     operations; listed-order sampling only (``sample_staged`` / ``sample_batch_staged``).
-BackgroundReplacer (musket's own augmenter: needs a directory of background images) raises ``ValueError`` naming the augmenter
-(no silent skipping).
+  BackgroundReplacer{path, rate, erosion, augmenters} (musket's augmenter for background-removal tasks, README.md:270-278,
+    FAQ.md:24-38): ``augmenters`` run first on the item; then, with probability 1 - rate, the pixels outside the mask (eroded
+    by ``erosion`` pixels) take a random image of the folder, resized to the item (``stp_background_replace_u8`` at the head of
+    a new pass).  3-channel items, listed-order sampling only.
+Unknown augmenter names raise ``ValueError`` (no silent skipping).
 """
+import os
 import math
 
 import numpy as np
@@ -74,6 +78,7 @@ class SampleParams(object):
         self.adde, self.mule = None, None
         self.filters = []                           # [(K, mode, weights K*K float or None)]
         self.disp = None                            # ("piecewise", rows, cols, int32 [rows*cols*2]) | ("elastic", int32 [69])
+        self.bg = None                              # (uint8 [bh,bw,3] background image, erosion): replaced BEFORE this pass's warp
 
     # ---- geometry: every op appends the map from the NEW canvas to the PREVIOUS one
     def push(self, cur_to_prev):
@@ -123,6 +128,16 @@ class Pipeline(object):
 
     def geo(self):
         if self.strict and self.ranks[-1] > R_GEO:
+            self._new()
+        return self.cur
+
+    def background(self):
+        """The background replacement reads the item as the previous augmenters left it: it heads a pass of its own unless
+        nothing has happened yet."""
+        if not self.strict:
+            raise ValueError("BackgroundReplacer needs the listed-order sampler (sample_staged)")
+        c = self.cur
+        if self.ranks[-1] > R_GEO or c.bg is not None or c.disp is not None or not np.array_equal(c.M, np.eye(3)):
             self._new()
         return self.cur
 
@@ -296,6 +311,19 @@ def _apply(spec, rng, pl):
                 rec[0], rec[1], rec[2] = int(rng.randint(0, 1 << 24)), min(int(round(alpha * 64.0)), 1 << 15), radius
                 rec[4:4 + radius + 1] = q[radius:]
                 pl.displace().disp = ("elastic", rec)
+        elif name == "BackgroundReplacer":
+            a = args or {}
+            sub = a.get("augmenters")
+            if sub:
+                _apply([{k: v} for k, v in sub.items()] if isinstance(sub, dict) else list(sub), rng, pl)
+            files = background_files(a.get("path"))
+            if rng.uniform() >= float(a.get("rate", 0.5)):                    # rate = fraction of original backgrounds preserved
+                bg = load_background(files[int(rng.randint(0, len(files)))])
+                er = a.get("erosion", 0)
+                er = int(rng.randint(int(er[0]), int(er[1]) + 1)) if isinstance(er, (list, tuple)) else int(er or 0)
+                if not 0 <= er <= 32:
+                    raise ValueError("BackgroundReplacer: erosion %d is outside 0..32" % er)
+                pl.background().bg = (bg, er)
         elif name == "Sequential":
             _apply(_children(args), rng, pl)
         elif name == "Sometimes":
@@ -437,12 +465,70 @@ def sample_staged(spec, rng, h, w, out_hw):
         final = k == len(pl.stages) - 1
         rec = record(sp, (oh, ow) if final else None, _seed(sp, rng))
         hw = (int(round(sp.h)), int(round(sp.w)))
-        passes.append((rec, sp.filters, hw) if sp.disp is None else (rec, sp.filters, hw, sp.disp))
+        t = (rec, sp.filters, hw)
+        if sp.disp is not None or sp.bg is not None:
+            t += (sp.disp,)
+        if sp.bg is not None:
+            t += (sp.bg,)
+        passes.append(t)
     return passes
 
 
 def _disp_key(p):
-    return None if len(p) < 4 else (p[3][0],) + (tuple(p[3][1:3]) if p[3][0] == "piecewise" else ())
+    """Structure of a pass beyond its canvas: images agree on it or run one by one (a background image is per image)."""
+    if len(p) > 4:
+        return object()
+    return None if len(p) < 4 or p[3] is None else (p[3][0],) + (tuple(p[3][1:3]) if p[3][0] == "piecewise" else ())
+
+
+_BG_FILES, _BG_IMAGES = {}, {}
+
+
+def background_files(path):
+    """Image files of a BackgroundReplacer folder (sorted; cached)."""
+    if not path or not os.path.isdir(str(path)):
+        raise ValueError("BackgroundReplacer: path %r is not a directory" % (path,))
+    path = os.path.abspath(str(path))
+    if path not in _BG_FILES:
+        fs = sorted(f for f in os.listdir(path) if f.lower().endswith((".jpg", ".jpeg", ".png", ".bmp")))
+        if not fs:
+            raise ValueError("BackgroundReplacer: no images in %r" % path)
+        _BG_FILES[path] = [os.path.join(path, f) for f in fs]
+    return _BG_FILES[path]
+
+
+def load_background(f, cache=256):
+    """uint8 [h, w, 3] (decoded once; at most ``cache`` images stay resident)."""
+    if f not in _BG_IMAGES:
+        from PIL import Image
+        if len(_BG_IMAGES) >= cache:
+            _BG_IMAGES.pop(next(iter(_BG_IMAGES)))
+        _BG_IMAGES[f] = np.array(Image.open(f).convert("RGB"), dtype=np.uint8, order="C")
+    return _BG_IMAGES[f]
+
+
+def resolve_paths(spec, base_dir):
+    """BackgroundReplacer paths such as ``./bg`` (README.md:275) that do not exist relative to the working directory are
+    taken relative to the experiment's directory.  Returns a new list."""
+    out = []
+    for item in spec or []:
+        if isinstance(item, dict):
+            (name, args), = item.items()
+            if name == "BackgroundReplacer" and isinstance(args, dict):
+                args = dict(args)
+                pth = args.get("path")
+                if pth and not os.path.isdir(str(pth)) and base_dir and os.path.isdir(os.path.join(base_dir, str(pth))):
+                    args["path"] = os.path.join(base_dir, str(pth))
+                sub = args.get("augmenters")
+                if sub:
+                    args["augmenters"] = resolve_paths([{k: v} for k, v in sub.items()] if isinstance(sub, dict) else sub, base_dir)
+                item = {name: args}
+            elif name in ("Sequential", "OneOf") and args:
+                item = {name: resolve_paths(_children(args), base_dir)}
+            elif name == "Sometimes" and isinstance(args, dict):
+                item = {name: dict(args, then_list=resolve_paths(args.get("then_list", []), base_dir))}
+        out.append(item)
+    return out
 
 
 def batch_disp(disps):
@@ -455,7 +541,9 @@ def batch_disp(disps):
 def batch_of_one(p):
     """One image's pass -> the batch form ``DeviceFeeder._run_passes`` executes (n = 1)."""
     out = (p[0][None], filter_records([p[1]]), p[2])
-    return out if len(p) < 4 else out + (batch_disp([p[3]]),)
+    if len(p) > 3:
+        out += (None if p[3] is None else batch_disp([p[3]]),)
+    return out + tuple(p[4:5])
 
 
 def sample_batch_staged(spec, rng, n, h, w, out_hw):
@@ -469,7 +557,7 @@ def sample_batch_staged(spec, rng, n, h, w, out_hw):
         out = []
         for j in range(k):
             bp = (np.stack([p[j][0] for p in per]).astype(np.float32), filter_records([p[j][1] for p in per]), per[0][j][2])
-            out.append(bp if len(per[0][j]) < 4 else bp + (batch_disp([p[j][3] for p in per]),))
+            out.append(bp if len(per[0][j]) < 4 or per[0][j][3] is None else bp + (batch_disp([p[j][3] for p in per]),))
         return out, None
     return None, per
 

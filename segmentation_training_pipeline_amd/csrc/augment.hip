@@ -244,6 +244,41 @@ extern "C" int stp_field_elastic(int32_t* field, int32_t* tmp, const int32_t* pa
 }
 
 // ------------------------------------------------------------------------------------------
+// BackgroundReplacer (musket's augmenter for background-removal tasks, reference README.md:270-278, FAQ.md:24-38): pixels outside
+// the (eroded) mask take the pixel of a background image already resized to the item's size.  Erosion e = a (2e+1) x (2e+1)
+// minimum over the mask (pixels outside the image do not erode, cv2.erode's default border); the mask itself is not changed.
+__global__ __launch_bounds__(256) void background_replace_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask,
+                                                                 const uint8_t* __restrict__ bg, uint8_t* __restrict__ out, int N, int H, int W,
+                                                                 int C, int erosion) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int64_t base = i - ((int64_t)y * W + x);
+    bool fg = mask[i] != 0;
+    for (int dy = -erosion; fg && dy <= erosion; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = -erosion; dx <= erosion; ++dx) {
+        const int xx = x + dx;
+        if (xx >= 0 && xx < W && mask[base + (int64_t)yy * W + xx] == 0) { fg = false; break; }
+      }
+    }
+    const uint8_t* src = fg ? img : bg;
+    for (int c = 0; c < C; ++c) out[i * C + c] = src[i * C + c];
+  }
+}
+
+extern "C" int stp_background_replace_u8(const uint8_t* img, const uint8_t* mask, const uint8_t* bg, uint8_t* out, int32_t N, int32_t H,
+                                         int32_t W, int32_t C, int32_t erosion, void* stream) {
+  if (!img || !mask || !bg || !out || out == img || N <= 0 || H <= 0 || W <= 0 || C <= 0 || erosion < 0 || erosion > 32) return STP_E_BADARG;
+  int64_t g = ((int64_t)N * H * W + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(background_replace_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, img, mask, bg, out, N, H, W, C, erosion);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Neighbourhood filters of the catalogue (GaussianBlur, AverageBlur, Sharpen, Emboss, EdgeDetect = a K x K linear
 // filter; MedianBlur = rank selection) on the augmented uint8 batch, one per-image record:
 //   int32[STP_FILTER_RECORD = 4 + 13*13]: K (odd, 0 = copy, <= 13), mode (0 linear, 1 median), 0, 0, then K*K weights

@@ -207,6 +207,12 @@ def augment_u8(img, mask, img_out, mask_out, params, N, Hin, Win, Hout, Wout, Cn
               stream())
 
 
+def background_replace_u8(img, mask, bg, out, N, H, W, Cn, erosion):
+    if min(img.numel(), bg.numel(), out.numel()) < N * H * W * Cn or mask.numel() < N * H * W:
+        raise ValueError("background_replace_u8: buffers are smaller than N x H x W (x C)")
+    _lib.call("stp_background_replace_u8", ptr(img), ptr(mask), ptr(bg), ptr(out), N, H, W, Cn, int(erosion), stream())
+
+
 def field_piecewise(field, grid, N, H, W, rows, cols):
     if field.numel() < N * H * W or grid.numel() < N * rows * cols * 2:
         raise ValueError("field_piecewise: buffers are smaller than N x H x W / N x rows x cols x 2")

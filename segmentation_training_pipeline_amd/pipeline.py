@@ -492,7 +492,19 @@ class DeviceFeeder(object):
             ydst = msk_out if final else torch.empty(lead + (ph, pw), dtype=torch.uint8, device=self.device)
             self._keep += [pd, ydst]
             field = None
-            if len(ps_) > 3:      # PiecewiseAffine / ElasticTransformation: the per-pixel displacement this pass's warp adds
+            if len(ps_) > 4:      # BackgroundReplacer heads this pass: resize the background to the item, composite outside the mask
+                bg, erosion = ps_[4]
+                if ch != 3 or n != 1:
+                    raise ValueError("BackgroundReplacer works on single 3-channel items")
+                bgd = torch.from_numpy(bg).to(self.device, non_blocking=True)
+                bgr = torch.empty((h, w, ch), dtype=torch.uint8, device=self.device)
+                rp = torch.from_numpy(augment.identity_batch(1, bg.shape[0], bg.shape[1], (h, w))).to(self.device, non_blocking=True)
+                xr = torch.empty((h, w, ch), dtype=torch.uint8, device=self.device)
+                self._keep += [bgd, bgr, rp, xr]
+                ops.augment_u8(bgd, None, bgr, None, rp, 1, bg.shape[0], bg.shape[1], h, w, ch)
+                ops.background_replace_u8(x, y, bgr, xr, 1, h, w, ch, erosion)
+                x = xr
+            if len(ps_) > 3 and ps_[3] is not None:      # PiecewiseAffine / ElasticTransformation: the displacement this pass's warp adds
                 disp = ps_[3]
                 field = torch.empty((n, ph, pw), dtype=torch.int32, device=self.device)
                 rd = torch.from_numpy(np.ascontiguousarray(disp[-1], dtype=np.int32)).to(self.device, non_blocking=True)
@@ -697,6 +709,12 @@ class GenericTaskConfig(object):
         return cleaned
 
     # --- paths (next to the YAML)
+    def _aug_spec(self):
+        """``augmentation`` + ``transforms`` with folder arguments (BackgroundReplacer ``path: ./bg``, README.md:275) resolved
+        against the experiment's directory."""
+        base = os.path.dirname(os.path.abspath(self.path)) if self.path else None
+        return augment.resolve_paths(self.augmentation + self.transforms, base)
+
     def _dir(self, name):
         d = os.path.join(os.path.dirname(os.path.abspath(self.path)), name)
         os.makedirs(d, exist_ok=True)
@@ -814,7 +832,7 @@ class GenericTaskConfig(object):
             impl.broadcast_state(src=0)
             impl.set_data_parallel(distributed.GradReducer())
         H, W = impl.H, impl.W                                  # = shape, or shape / crops
-        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state * 7919 + fold * 101 + si,
+        feeder = DeviceFeeder(impl.device, (H, W), self._aug_spec(), seed=self.random_state * 7919 + fold * 101 + si,
                               classes=self.classes, channels=impl.in_ch)
         cbs = stage.callbacks()
         trainer = Trainer(impl, feeder, ds, cbs, rank, world)
@@ -894,7 +912,7 @@ class GenericTaskConfig(object):
         model = self._compiled(st)
         impl = model.impl
         H, W = impl.H, impl.W                                  # = shape, or shape / crops: the size of the plan's input buffers
-        feeder = DeviceFeeder(impl.device, (H, W), self.augmentation + self.transforms, seed=self.random_state, classes=self.classes, channels=impl.in_ch)
+        feeder = DeviceFeeder(impl.device, (H, W), self._aug_spec(), seed=self.random_state, classes=self.classes, channels=impl.in_ch)
         trainer = Trainer(impl, feeder, d, [], 0, 1)
         nb = max(1, -(-len(idx) // impl.batch)) * int(epochs)
         finder = LRFinder(float(start_lr), float(end_lr), nb)

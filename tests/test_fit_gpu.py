@@ -351,3 +351,31 @@ def test_readme_stage_loss_override_lovasz(tmp_path):
     losses = [float(r["loss"]) for r in rows]
     assert len(rows) == 3 and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert os.path.exists(os.path.join(str(tmp_path), "weights", "best-0.1.weights"))
+
+
+def test_background_replacer_yaml_fits(tmp_path):
+    """reference README.md:270-278: `BackgroundReplacer: {path: ./bg, rate: 0.5}` (the folder next to the YAML) in the
+    augmentation list of a background-removal experiment, with FAQ.md:24-38's `augmenters` / `erosion` options."""
+    from PIL import Image
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    img_dir, msk_dir = make_dataset(str(tmp_path))
+    os.makedirs(str(tmp_path / "bg"))
+    rng = np.random.RandomState(5)
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 90, (96 + 8 * i, 160, 3)).astype(np.uint8)).save(str(tmp_path / "bg" / ("bg%d.jpg" % i)))
+    cfg_path = str(tmp_path / "bgr.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Unet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid",
+                        "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.002, "batch": 4, "folds_count": 2,
+                        "loss": "binary_crossentropy+1.0*dice_loss", "metrics": ["dice"], "primary_metric": "val_dice",
+                        "stages": [{"epochs": 4}],
+                        "augmentation": {"Fliplr": 0.5,
+                                         "BackgroundReplacer": {"path": "./bg", "rate": 0.5, "erosion": [0, 3],
+                                                                "augmenters": {"Affine": {"scale": [0.9, 1.1], "rotate": [-10, 10]}}}}}, f)
+    cfg = segmentation.parse(cfg_path)
+    out = cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
+    assert [(s["fold"], s["stage"]) for s in out] == [(0, 0)]
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        losses = [float(r["loss"]) for r in csv.DictReader(f)]
+    assert len(losses) == 4 and np.all(np.isfinite(losses)) and losses[-1] < losses[0]

@@ -256,7 +256,9 @@ def test_displacement_augmenters_sample_into_their_own_passes_and_the_oracle_fie
     with pytest.raises(ValueError):
         augment.sample_batch_ex([{"PiecewiseAffine": 0.05}], rng, 1, 8, 8, (8, 8))
     with pytest.raises(ValueError):
-        augment.sample_staged([{"BackgroundReplacer": {"path": "x"}}], rng, 8, 8, (8, 8))
+        augment.sample_staged([{"BackgroundReplacer": {"path": "no-such-folder"}}], rng, 8, 8, (8, 8))
+    with pytest.raises(ValueError):
+        augment.sample_staged([{"CoarseDropout": 0.1}], rng, 8, 8, (8, 8))
     # a resize after a field is a pass of its own
     r = augment.sample_staged([{"PiecewiseAffine": 0.05}], rng, 40, 52, (20, 26))
     assert [len(q) for q in r] == [4, 3] and r[0][2] == (40, 52) and r[1][2] == (20, 26)
@@ -277,6 +279,39 @@ def test_displacement_augmenters_sample_into_their_own_passes_and_the_oracle_fie
     half = p[1][3][1].copy(); half[1] //= 2
     e2 = oaug.field_elastic(half[None], 40, 52)
     assert np.abs(e1).max() <= rec[1] and e1.std() > 8 and np.abs(e1 - 2 * e2).max() <= 2
+
+
+def test_background_replacer_sampling_and_oracle(tmp_path):
+    """BackgroundReplacer (reference README.md:270-278, FAQ.md:24-38): `augmenters` first, then - with probability 1 - rate - a
+    random folder image replaces the pixels outside the eroded mask, at the head of a new pass; `./bg` resolves against the
+    experiment's directory."""
+    from PIL import Image
+    from oracle import augment as oaug
+    os.makedirs(str(tmp_path / "bg"))
+    for i in range(3):
+        Image.fromarray(np.full((20 + i, 30, 3), 50 * i + 10, np.uint8)).save(str(tmp_path / "bg" / ("b%d.png" % i)))
+    rng = np.random.RandomState(1)
+    raw = [{"BackgroundReplacer": {"path": "./bg", "rate": 0.0, "erosion": [0, 2], "augmenters": {"Fliplr": 1.0}}}, {"Add": 5}]
+    spec = augment.resolve_paths(raw, str(tmp_path))
+    assert os.path.isabs(spec[0]["BackgroundReplacer"]["path"]) and raw[0]["BackgroundReplacer"]["path"] == "./bg"
+    p = augment.sample_staged(spec, rng, 16, 24, (16, 24))
+    assert [len(q) for q in p] == [3, 5] and p[0][0][0] == -1 and p[1][3] is None and p[1][0][6] == 5
+    bg, er = p[1][4]
+    assert bg.dtype == np.uint8 and bg.shape[1:] == (30, 3) and 0 <= er <= 2
+    assert [len(q) for q in augment.sample_staged([{"BackgroundReplacer": {"path": spec[0]["BackgroundReplacer"]["path"], "rate": 1.0}}], rng, 16, 24, (16, 24))] == [3]
+    bp, per = augment.sample_batch_staged(spec, rng, 2, 16, 24, (16, 24))
+    assert bp is None and len(per) == 2                       # a background image is per image: items run one by one
+    b1 = augment.batch_of_one(p[1])
+    assert len(b1) == 5 and b1[0].shape == (1, 24) and b1[3] is None and b1[4][1] == er
+    # first in the list, nothing before it: no extra pass
+    assert [len(q) for q in augment.sample_staged([{"BackgroundReplacer": {"path": spec[0]["BackgroundReplacer"]["path"], "rate": 0.0}}], rng, 16, 24, (16, 24))] == [5]
+    m = np.zeros((1, 8, 8), np.uint8)
+    m[0, 2:6, 2:6] = 1
+    m[0, 0:3, 6:8] = 1                                         # touches the border: the border itself does not erode
+    img, bgi = np.full((1, 8, 8, 3), 200, np.uint8), np.full((1, 8, 8, 3), 7, np.uint8)
+    o0, o1 = oaug.background_replace_u8(img, m, bgi, 0), oaug.background_replace_u8(img, m, bgi, 1)
+    assert ((o0[0, :, :, 0] == 200) == (m[0] != 0)).all()
+    assert (o1[0, :, :, 0] == 200).sum() == 4 + 2 and o1[0, 3, 3, 0] == 200 and o1[0, 0, 7, 0] == 200 and o1[0, 2, 2, 0] == 7
 
 
 def test_cfg_gpus_without_torchrun_explains_how_to_launch(tmp_path, monkeypatch):

@@ -1689,6 +1689,48 @@ def test_displacement_field_augmenters_bit_exact(ops):
     assert torch.equal(oi2, oi) and torch.equal(om2, om)
 
 
+def test_background_replacer_bit_exact(ops, tmp_path):
+    """stp_background_replace_u8 against the oracle (erosion 0 / 1 / 3, masks touching the border) and the whole BackgroundReplacer
+    pass through DeviceFeeder._run_passes: sub-augmenters, background resized to the item, composite, then the pass's warp."""
+    import os
+    from PIL import Image
+    from segmentation_training_pipeline_amd import augment, pipeline
+    rng = np.random.RandomState(31)
+    n, h, w = 2, 37, 45
+    img = rng.randint(0, 256, size=(n, h, w, 3)).astype(np.uint8)
+    bgi = rng.randint(0, 256, size=(n, h, w, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    msk = np.stack([((yy - 18) ** 2 + (xx - 20) ** 2 < 150).astype(np.uint8), (xx > 30).astype(np.uint8) * 3])
+    for er in (0, 1, 3):
+        out = torch.zeros((n, h, w, 3), dtype=torch.uint8, device=DEV)
+        ops.background_replace_u8(keep(torch.from_numpy(img).to(DEV)), keep(torch.from_numpy(msk).to(DEV)), keep(torch.from_numpy(bgi).to(DEV)),
+                                  out, n, h, w, 3, er)
+        np.testing.assert_array_equal(out.cpu().numpy(), oaug.background_replace_u8(img, msk, bgi, er))
+    os.makedirs(str(tmp_path / "bg"))
+    for i in range(2):
+        Image.fromarray(rng.randint(0, 256, size=(50 + 7 * i, 64, 3)).astype(np.uint8)).save(str(tmp_path / "bg" / ("b%d.png" % i)))
+    spec = [{"BackgroundReplacer": {"path": str(tmp_path / "bg"), "rate": 0.0, "erosion": 2, "augmenters": {"Fliplr": 1.0}}},
+            {"Affine": {"rotate": [-10, 10]}}, {"Add": [-10, 10]}]
+    out_hw = (32, 40)
+    passes = augment.sample_staged(spec, np.random.RandomState(3), h, w, out_hw)
+    assert [len(p) for p in passes] == [3, 5, 3]                  # Fliplr | background, Affine, Add | the trailing Resize
+    rimg, rmsk = img[:1], msk[:1]
+    for p in passes:
+        if len(p) > 4:
+            bg, er = p[4]
+            bgr, _ = oaug.warp_u8(bg[None], None, augment.identity_batch(1, bg.shape[0], bg.shape[1], rimg.shape[1:3]), rimg.shape[1:3])
+            rimg = oaug.background_replace_u8(rimg, rmsk, bgr, er)
+        rimg, rmsk = oaug.warp_u8(rimg, rmsk, p[0][None], p[2])
+    feeder = pipeline.DeviceFeeder(DEV, out_hw, spec, seed=0, classes=4, channels=3)
+    oi = torch.zeros(out_hw + (3,), dtype=torch.uint8, device=DEV)
+    om = torch.zeros(out_hw, dtype=torch.uint8, device=DEV)
+    feeder._run_passes(keep(torch.from_numpy(img[0]).to(DEV)), keep(torch.from_numpy(msk[0]).to(DEV)), oi, om,
+                       [augment.batch_of_one(p) for p in passes], 1, h, w)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oi.cpu().numpy(), rimg[0])
+    np.testing.assert_array_equal(om.cpu().numpy(), rmsk[0])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_batched_weight_prepare_equals_per_layer(ops, dtype):
     """The once-per-step batched launch (LDS tile transpose) must write exactly what stp_weight_prepare writes
