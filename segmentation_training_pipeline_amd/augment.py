@@ -312,7 +312,7 @@ def _apply(spec, rng, pl):
                 rec[4:4 + radius + 1] = q[radius:]
                 pl.displace().disp = ("elastic", rec)
         elif name == "BackgroundReplacer":
-            a = args or {}
+            a = args if isinstance(args, dict) else {"path": args}
             sub = a.get("augmenters")
             if sub:
                 _apply([{k: v} for k, v in sub.items()] if isinstance(sub, dict) else list(sub), rng, pl)

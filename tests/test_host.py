@@ -181,7 +181,7 @@ def test_augment_matrices_match_the_oracle_and_reject_unknown():
     assert len(set(prm[6:9])) > 1                                   # per-channel Add drew three values
     picks = {int(augment.sample_batch([{"OneOf": [{"Invert": 1.0}, {"Dropout": 0.5}]}], rng, 1, 8, 8, (8, 8))[0, 12]) for _ in range(20)}
     assert picks == {0, 1}                                          # OneOf takes exactly one child
-    for bad in ("PiecewiseAffine", "ElasticTransformation", "BackgroundReplacer"):
+    for bad in ("PiecewiseAffine", "ElasticTransformation", "BackgroundReplacer"):     # (not in the MERGED single-pass sampler)
         with pytest.raises(ValueError, match=bad):
             augment.sample_batch([{bad: 1.0}], rng, 1, 8, 8, (8, 8))
     # neighbourhood filters come back as a second record set (stp_filter_u8), at most MAX_FILTERS per image
