@@ -862,22 +862,27 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
   float best[V];
   uint8_t bi[V];
+  // all nine taps are fetched BEFORE the first comparison (clamped addresses, out-of-image taps replaced by 0 afterwards): one
+  // memory round trip per thread instead of nine dependent ones (the predicated form waited for every tap before the next)
+  float v[9][V];
 #pragma unroll
-  for (int e = 0; e < V; ++e) { best[e] = 0.f; bi[e] = 0; }
-  bool firstTap = true;
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int h = min(max(2 * ho - 1 + kh, 0), H - 1), w = min(max(2 * wo - 1 + kw, 0), W - 1);
+      ldv<T, V>(x + (((size_t)n * H + h) * W + w) * C + c, v[kh * 3 + kw]);
+    }
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
-      float v[V];
+      const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;      // padded taps take part with value 0
 #pragma unroll
-      for (int e = 0; e < V; ++e) v[e] = 0.f;      // padded taps take part with value 0, as in the Keras graph
-      if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ldv<T, V>(x + (((size_t)n * H + h) * W + w) * C + c, v);
-#pragma unroll
-      for (int e = 0; e < V; ++e)
-        if (firstTap || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)(kh * 3 + kw); }
-      firstTap = false;
+      for (int e = 0; e < V; ++e) {
+        const float tv = in ? v[kh * 3 + kw][e] : 0.f;
+        if ((kh | kw) == 0 || tv > best[e]) { best[e] = tv; bi[e] = (uint8_t)(kh * 3 + kw); }
+      }
     }
   const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
   stv<T, V>(y + o, best);
@@ -961,31 +966,37 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
 #pragma unroll
     for (int e = 0; e < V; ++e) g[e] = 0.f;
     const size_t oo = (((size_t)n * H + h) * W + w) * C + c;
-    // windows (ho,wo) with 2*ho-1+kh == h  ->  kh = h+1-2*ho in [0,2]
+    // windows (ho,wo) with 2*ho-1+kh == h  ->  kh = h+1-2*ho in [0,2]: an even row has ONE (kh = 1), an odd row TWO (kh = 0
+    // of ho = (h+1)/2 and kh = 2 of ho = (h-1)/2); the same along w.  The <= 4 (index, gradient) pairs are fetched up front
+    // with clamped addresses - one memory round trip - and the invalid ones masked afterwards.
+    int hos[2], khs[2], wos[2], kws[2];
+    bool hv[2], wv[2];
+    if (h & 1) { hos[0] = (h + 1) >> 1; khs[0] = 0; hos[1] = (h - 1) >> 1; khs[1] = 2; hv[0] = hos[0] < Ho; hv[1] = true; }
+    else { hos[0] = h >> 1; khs[0] = 1; hos[1] = 0; khs[1] = 1; hv[0] = hos[0] < Ho; hv[1] = false; }
+    if (w & 1) { wos[0] = (w + 1) >> 1; kws[0] = 0; wos[1] = (w - 1) >> 1; kws[1] = 2; wv[0] = wos[0] < Wo; wv[1] = true; }
+    else { wos[0] = w >> 1; kws[0] = 1; wos[1] = 0; kws[1] = 1; wv[0] = wos[0] < Wo; wv[1] = false; }
+    uint8_t id[4][V];
+    float d[4][V];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int hh = h + 1 - kh;
-      if (hh < 0 || (hh & 1)) continue;
-      const int ho = hh >> 1;
-      if (ho >= Ho) continue;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ww = w + 1 - kw;
-        if (ww < 0 || (ww & 1)) continue;
-        const int wo = ww >> 1;
-        if (wo >= Wo) continue;
-        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
-        uint8_t id[V];
-        if constexpr (V == 8) *reinterpret_cast<uint2*>(id) = *reinterpret_cast<const uint2*>(idx + o);
-        else *reinterpret_cast<uint32_t*>(id) = *reinterpret_cast<const uint32_t*>(idx + o);
-        float d[V];
-        ldv<T, V>(dy + o, d);
-        const uint8_t me = (uint8_t)(kh * 3 + kw);
+      for (int b = 0; b < 2; ++b) {
+        const size_t o = (((size_t)n * Ho + min(hos[a], Ho - 1)) * Wo + min(wos[b], Wo - 1)) * C + c;
+        if constexpr (V == 8) *reinterpret_cast<uint2*>(id[a * 2 + b]) = *reinterpret_cast<const uint2*>(idx + o);
+        else *reinterpret_cast<uint32_t*>(id[a * 2 + b]) = *reinterpret_cast<const uint32_t*>(idx + o);
+        ldv<T, V>(dy + o, d[a * 2 + b]);
+      }
+    // (summation order = the former kh-major / kw-minor walk: kh 0 before kh 2, kw 0 before kw 2)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool ok = hv[a] && wv[b];
+        const uint8_t me = (uint8_t)(khs[a] * 3 + kws[b]);
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (id[e] == me) g[e] += d[e];
+          if (ok && id[a * 2 + b][e] == me) g[e] += d[a * 2 + b][e];
       }
-    }
     if (accumulate) {
       float o[V];
       ldv<T, V>(dx + oo, o);
