@@ -86,6 +86,18 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial
   scalars[9] = (float)((s[5] + 1.0) / (s[2] + s[4] - s[5] + 1.0));   // iot: the same on predictions thresholded at 0.5
 }
 
+// one row of the padded gradient tensor: g in channel 0, zeros behind it - ONE 16-byte store for the usual 8 x bf16 / 4 x fp32 row
+__device__ __forceinline__ void store_grad_row(float* o, float g, int dlc) {
+  if (dlc == 4) { *reinterpret_cast<f32x4*>(o) = f32x4{g, 0.f, 0.f, 0.f}; return; }
+  o[0] = g;
+  for (int c = 1; c < dlc; ++c) o[c] = 0.f;
+}
+__device__ __forceinline__ void store_grad_row(bf16_t* o, float g, int dlc) {
+  if (dlc == 8) { *reinterpret_cast<u32x4*>(o) = u32x4{(uint32_t)f32_to_bf16(g), 0u, 0u, 0u}; return; }
+  o[0] = f32_to_bf16(g);
+  for (int c = 1; c < dlc; ++c) o[c] = 0;
+}
+
 // pass 2: dL/dlogit, written to channel 0 of a [count][dl_channels] tensor (other channels 0)
 template <typename T>
 __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ target,
@@ -105,9 +117,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const T* __restrict__ lo
     // d dice_loss / d p = -(2 y den - num) / den^2 ;  dp/dz = p (1-p)
     g += w_dice * (-(2.f * y * den - num) * inv_den2) * (p * (1.f - p));
     g *= grad_scale;
-    T* o = dl + i * dlc;
-    Elem<T>::store(o, g);
-    for (int c = 1; c < dlc; ++c) Elem<T>::store(o + c, 0.f);
+    store_grad_row(dl + i * dlc, g, dlc);
   }
 }
 
@@ -269,9 +279,7 @@ __global__ __launch_bounds__(256) void loss_ex_grad_kernel(const T* __restrict__
     }
     g += gp * (p * (1.f - p));
     g *= grad_scale;
-    T* o = dl + i * dlc;
-    Elem<T>::store(o, g);
-    for (int c = 1; c < dlc; ++c) Elem<T>::store(o + c, 0.f);
+    store_grad_row(dl + i * dlc, g, dlc);
   }
 }
 
