@@ -352,6 +352,10 @@ int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, int64_t count
 size_t stp_lovasz_workspace_bytes(int64_t count, int32_t images);
 int stp_lovasz_hinge(const void* logits, const uint8_t* target, int32_t images, int64_t per_image, int32_t dtype, float weight,
                      float* scalars, void* dlogits, int32_t dl_channels, void* workspace, size_t workspace_bytes, void* stream);
+/* Bias gradient of the class convolution (= sum of dL/dlogit): stp_sigmoid_bce_dice / stp_sigmoid_loss_ex leave one partial sum
+ * per gradient workgroup in their workspace; this adds them up in a fixed order into dbias[0] (instead of a stp_channel_sum pass
+ * over the padded gradient tensor).  Same workspace and count as the loss call that wrote dlogits. */
+int stp_sigmoid_loss_bias_grad(const void* workspace, int64_t count, float* dbias, int32_t accumulate, void* stream);
 int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, void* stream);
 /* Multi-class head (activation: softmax, loss: categorical_crossentropy[+w*dice_loss]; schemas/segmentation.raml:12-21,
  * 62-63): channel softmax over the first `classes` (2..32) channels of logits [pixels][ldc], target = uint8 class index

@@ -104,6 +104,7 @@ SIGNATURES = {
     "stp_loss_workspace_bytes": (sz, []),
     "stp_sigmoid_bce_dice": (i32, [vp, vp, i64, i32, f32, f32, vp, vp, i32, f32, vp, sz, vp]),
     "stp_sigmoid_loss_ex": (i32, [vp, vp, i64, i32, vp, vp, vp, i32, f32, vp, sz, vp]),
+    "stp_sigmoid_loss_bias_grad": (i32, [vp, i64, vp, i32, vp]),
     "stp_lovasz_workspace_bytes": (sz, [i64, i32]),
     "stp_lovasz_hinge": (i32, [vp, vp, i32, i64, i32, f32, vp, vp, i32, vp, sz, vp]),
     "stp_sigmoid": (i32, [vp, vp, i64, i32, vp]),

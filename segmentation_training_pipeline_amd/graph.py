@@ -641,7 +641,10 @@ class Plan(object):
                 if stem and beta is not None and beta.trainable:
                     self._emit_side(self.bwd, "stp_stem_beta_grad", dwp.data_ptr(), self._pptr(w), self._gptr(beta), Cout, k, k,
                                real_c0, KWp, Cinp, real_c0)
-            if b is not None and b.trainable:
+            if b is not None and b.trainable and out.meta.get("loss_bias_grad") and Cout == 1:
+                # the 1-class head: the loss gradient kernel left the per-workgroup sums of dL/dlogit in its workspace
+                self._emit(self.bwd, "stp_sigmoid_loss_bias_grad", self.ws_loss.data_ptr(), rows, self._gptr(b), 0)
+            elif b is not None and b.trainable:
                 tmp = self._alloc((CoutB,), torch.float32)
                 self._emit(self.bwd, "stp_channel_sum", dy.data_ptr(), self.cdt, rows, CoutB, tmp.data_ptr(), 0,
                            self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
@@ -1160,6 +1163,9 @@ class Plan(object):
             self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),
                        float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC, 1.0,
                        self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        # the class convolution reads its bias gradient from the gradient kernel's per-workgroup sums (not when another launch
+        # adds to the gradient afterwards)
+        logits.meta["loss_bias_grad"] = bool(self.training and not w_lovasz)
         if w_lovasz:      # per-image Lovasz hinge: ADDS to scalars[0] and to the gradient the launch above wrote
             nbytes = int(self.lib.stp_lovasz_workspace_bytes(count, self.N))
             if nbytes <= 0:
