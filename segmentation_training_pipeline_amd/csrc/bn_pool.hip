@@ -120,6 +120,54 @@ __global__ __launch_bounds__(256) void bn_partial_u8_kernel(const uint8_t* __res
   }
 }
 
+// The same statistics for 1..8 interleaved uint8 channels (the raw image), vectorised: a thread takes 16 rows = C 16-byte loads
+// per iteration, so byte k of the group belongs to channel k % C at compile time; sums are exact integers (order-free, hence
+// deterministic), converted once per workgroup.  rows per workgroup are a multiple of 16; the ragged end goes byte by byte.
+template <int C>
+__global__ __launch_bounds__(256) void bn_partial_u8v_kernel(const uint8_t* __restrict__ x, int64_t rows, float* partial) {
+  __shared__ unsigned long long red[4][2 * C];
+  const int64_t rowsPerBlock = ((rows + gridDim.x - 1) / gridDim.x + 15) & ~(int64_t)15;
+  const int64_t r0 = (int64_t)blockIdx.x * rowsPerBlock;
+  const int64_t r1 = r0 + rowsPerBlock < rows ? r0 + rowsPerBlock : rows;
+  const int64_t rv = r0 + ((r1 > r0 ? r1 - r0 : 0) & ~(int64_t)15);            // end of the whole 16-row groups
+  uint32_t sm[C], sq[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) sm[c] = sq[c] = 0u;
+  for (int64_t r = r0 + (int64_t)threadIdx.x * 16; r < rv; r += 256 * 16) {
+    uint4 v[C];
+    const uint4* p = reinterpret_cast<const uint4*>(x + r * C);
+#pragma unroll
+    for (int j = 0; j < C; ++j) v[j] = p[j];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        sm[(j * 16 + k) % C] += b;
+        sq[(j * 16 + k) % C] += b * b;
+      }
+    }
+  }
+  for (int64_t i = rv * C + threadIdx.x; i < r1 * C; i += 256) {                 // (fewer than 16 rows)
+    const uint32_t b = x[i];
+    const int ch = (int)(i % C);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (c == ch) { sm[c] += b; sq[c] += b * b; }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    unsigned long long a = sm[c], b = sq[c];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][c] = a; red[threadIdx.x >> 6][C + c] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C)
+    partial[(size_t)blockIdx.x * 2 * C + threadIdx.x] =
+        (float)(double)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // Sums partial[b][which][c] over b for 4 consecutive channels per workgroup: 64 strided lanes per
 // channel (independent loads in flight), then a fixed-shape LDS tree -> deterministic.
 // Returns the totals (valid on lane 0 of each channel column) for `which` = 0 and 1.
@@ -184,7 +232,20 @@ extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t
   float* partial = (float*)workspace;
   if (xdtype == STP_U8) {
     if (C > 256) return STP_E_BADARG;
-    hipLaunchKernelGGL(bn_partial_u8_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)x, rows, C, partial);
+    const bool vec = ((uintptr_t)x & 15) == 0;
+#define STP_U8V(CC) hipLaunchKernelGGL(bn_partial_u8v_kernel<CC>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)x, rows, partial)
+    switch (vec ? C : 0) {
+      case 1: STP_U8V(1); break;
+      case 2: STP_U8V(2); break;
+      case 3: STP_U8V(3); break;
+      case 4: STP_U8V(4); break;
+      case 5: STP_U8V(5); break;
+      case 6: STP_U8V(6); break;
+      case 7: STP_U8V(7); break;
+      case 8: STP_U8V(8); break;
+      default: hipLaunchKernelGGL(bn_partial_u8_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)x, rows, C, partial);
+    }
+#undef STP_U8V
   } else {
     if (C & 3) return STP_E_BADARG;
     if (xdtype == STP_BF16 && (C & 7) == 0)
