@@ -6,6 +6,9 @@
 #include <algorithm>
 
 #define BN_MAX_BLOCKS 1024
+#ifndef POOL_ROWS
+#define POOL_ROWS 4  // image rows per workgroup of the max-pool kernels (one row per workgroup = 8-32 K tiny workgroups: dispatch-bound)
+#endif
 
 
 template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
@@ -920,7 +923,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= Wo * cg) return;
   const int wo = t / cg, c = (t - wo * cg) * V;
-  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  for (int rr = 0; rr < POOL_ROWS; ++rr) {
+  const int orow = blockIdx.y * POOL_ROWS + rr;
+  if (orow >= N * Ho) break;
+  const int n = orow / Ho, ho = orow - n * Ho;
   float best[V];
   uint8_t bi[V];
   // all nine taps are fetched BEFORE the first comparison (clamped addresses, out-of-image taps replaced by 0 afterwards): one
@@ -951,6 +957,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     if constexpr (V == 8) *reinterpret_cast<uint2*>(idx + o) = *reinterpret_cast<const uint2*>(bi);
     else *reinterpret_cast<uint32_t*>(idx + o) = *reinterpret_cast<const uint32_t*>(bi);
   }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -966,6 +973,7 @@ __device__ __forceinline__ f32x4 stored4(f32x4 v, const bf16_t*) {
 }
 
 #define BNB_ROWS 8   // image rows per workgroup of the *_bn gradient kernels: fewer, larger partial-sum tiles
+
 
 template <typename T, int V>
 __device__ __forceinline__ void bnb_mask_store(float (&g)[V], size_t o, int c, const BnBack& bnb, T* __restrict__ dx, float (&sg)[V],
@@ -1015,7 +1023,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
   const bool on = t < W * cg;
   if (!BNB && !on) return;
   const int w = on ? t / cg : 0, c = on ? (t - w * cg) * V : 0;
-  constexpr int ROWS = BNB ? BNB_ROWS : 1;
+  constexpr int ROWS = BNB ? BNB_ROWS : POOL_ROWS;
   float sg[V], sq[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { sg[e] = 0.f; sq[e] = 0.f; }
@@ -1077,7 +1085,7 @@ extern "C" int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N,
   if ((int64_t)N * Ho > 65535) return STP_E_BADARG;  // gridDim.y
   hipStream_t s = (hipStream_t)stream;
   const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
-  const dim3 grid(ceil_div(Wo * (C / (v8 ? 8 : 4)), 256), N * Ho);
+  const dim3 grid(ceil_div(Wo * (C / (v8 ? 8 : 4)), 256), ceil_div(N * Ho, POOL_ROWS));
   if (v8)
     hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
   else if (dtype == STP_BF16)
@@ -1097,7 +1105,7 @@ static int maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int3
   if ((int64_t)N * H > 65535) return STP_E_BADARG;  // gridDim.y
   const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
   const int V = v8 ? 8 : 4;
-  const dim3 grid(ceil_div(W * (C / V), 256), N * H);
+  const dim3 grid(ceil_div(W * (C / V), 256), ceil_div(N * H, POOL_ROWS));
   BnBack none;
   none.x = nullptr; none.mean = none.rstd = none.gamma = none.beta = nullptr; none.relu = 0;
   if (bnb) {
@@ -1149,7 +1157,10 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= Wo * cg) return;
   const int wo = t / cg, c = (t - wo * cg) * V;
-  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  for (int rr = 0; rr < POOL_ROWS; ++rr) {
+  const int orow = blockIdx.y * POOL_ROWS + rr;
+  if (orow >= N * Ho) break;
+  const int n = orow / Ho, ho = orow - n * Ho;
   float best[V];
   uint8_t bi[V];
 #pragma unroll
@@ -1165,6 +1176,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
   if (idx) {
     if constexpr (V == 8) *reinterpret_cast<uint2*>(idx + o) = *reinterpret_cast<const uint2*>(bi);
     else *reinterpret_cast<uint32_t*>(idx + o) = *reinterpret_cast<const uint32_t*>(bi);
+  }
   }
 }
 
