@@ -111,9 +111,22 @@ typedef struct stp_conv_params {
   const float* src_bn_gamma; /* may be NULL */
   const float* src_bn_beta;  /* may be NULL */
   int32_t src_bn_relu;
+  /* Optional class-collapsed weights for a NEAREST-2x source (uniform-tap kernel, forward of the decoder convolutions over
+   * UpSampling2D(2) + concat): for output parity class (py, px) the nine taps over the upsampled src0 read only 2 x 2 distinct
+   * low-resolution pixels, so with weight_up = [Cout_pad][4 classes][2][2][C0] (stp_weight_prepare_upcollapse: the 3x3 taps that
+   * share a pixel summed) the K loop takes 4 x C0 + 9 x C1 instead of 9 x (C0 + C1) steps.  NULL: the plain gather. */
+  const void* weight_up;
 } stp_conv_params;
 
 int stp_conv2d(const stp_conv_params* p, void* stream);
+/* weight_up of stp_conv_params from the fp32 master [Cout][3][3][C0 + C1]: rows = Cout rounded up to 16 (zero rows behind Cout),
+ * class c = py * 2 + px, tap t = ty * 2 + tx; row taps of (py, ty): (0,0) {0}, (0,1) {1,2}, (1,0) {0,1}, (1,1) {2}; columns alike. */
+int stp_weight_prepare_upcollapse(const float* master, void* weight_up, int32_t Cout, int32_t C0, int32_t C1, int32_t dtype,
+                                  void* stream);
+/* The same for several layers in ONE launch: desc_dev = nlayers records {const float* master; void* weight_up; int32 Cout, rows
+ * (= Cout rounded up to 16), C0, C0 + C1} (stp_weight_prepare_upcollapse_desc_bytes() = 32 bytes each) in device memory. */
+size_t stp_weight_prepare_upcollapse_desc_bytes(void);
+int stp_weight_prepare_upcollapse_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream);
 /* floats needed by stats_partial for this shape (tile choice included) */
 size_t stp_conv2d_stats_floats(const stp_conv_params* p);
 /* tile configuration stp_conv2d would pick for p (see conv_igemm.hip: 1..6 register-staged tiles, 32*STAGES+t

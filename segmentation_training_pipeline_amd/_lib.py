@@ -29,7 +29,8 @@ class ConvParams(C.Structure):
                 ("stats_tiles", i32), ("stats_partial", vp),
                 ("bnb_x", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_gamma", vp), ("bnb_beta", vp), ("bnb_relu", i32),
                 ("dst_sum2x2", i32), ("stats_slots", i32),
-                ("src_bn_mean", vp), ("src_bn_rstd", vp), ("src_bn_gamma", vp), ("src_bn_beta", vp), ("src_bn_relu", i32)]
+                ("src_bn_mean", vp), ("src_bn_rstd", vp), ("src_bn_gamma", vp), ("src_bn_beta", vp), ("src_bn_relu", i32),
+                ("weight_up", vp)]
 
 
 class WgradParams(C.Structure):
@@ -44,6 +45,9 @@ class WgradParams(C.Structure):
 SIGNATURES = {
     "stp_abi_version": (i32, []),
     "stp_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "stp_weight_prepare_upcollapse": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "stp_weight_prepare_upcollapse_desc_bytes": (sz, []),
+    "stp_weight_prepare_upcollapse_batched": (i32, [vp, i32, i32, vp]),
     "stp_conv2d_stats_floats": (sz, [C.POINTER(ConvParams)]),
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc_eligible": (i32, [C.POINTER(ConvParams)]),

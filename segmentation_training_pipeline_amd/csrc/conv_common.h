@@ -27,6 +27,12 @@ struct ConvArgs {
   // zero-inserted grid the same way and the K loop visits only the taps that hit real samples (1, 2, 2 or 4 of 9; 1 or 0 of 1)
   int zperm, zPc, zH2W2, zW2, zcpt;              // pixels per class, (Ho/2)*(Wo/2), Wo/2, K-tiles per tap
   FastDiv divPc, divH2W2, divW2, divCpt;
+  // upc (same kernel and pixel order, NEAREST-2x src0 of a 3x3 / pad 1 forward convolution): the taps over src0 collapse to the
+  // 2 x 2 low-resolution pixels a parity class touches, multiplied by the class-summed weights weight_up (stp_conv_params)
+  const char* weight_up;
+  uint32_t byteswu;
+  int upc, ucpt0, ucpt1;                          // K-tiles per collapsed tap (C0 / KE) and per src1 tap (C1 / KE)
+  FastDiv divU0, divU1;
 };
 
 // logical (parity-class major) pixel -> n, ho, wo
@@ -282,6 +288,7 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   a.bytes0 = (uint32_t)(b0 < lim ? b0 : 0); a.bytes1 = (uint32_t)(b1 < lim ? b1 : 0); a.bytesw = (uint32_t)(bw < lim ? bw : 0);
   a.ntile_m = a.ntile_n = 0;
   a.zperm = 0;
+  a.weight_up = (const char*)p->weight_up; a.byteswu = 0; a.upc = 0; a.ucpt0 = a.ucpt1 = 1;
   a.stats = p->stats_partial;
   a.stat_slots = p->stats_slots;
   if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;

@@ -67,8 +67,12 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
 
   // zperm: this tile's parity class fixes the taps that meet real samples of the zero-inserted source (all scalar)
   const bool zp = UNI && a.zperm;
+  // upc: parity-class pixel order too; the class fixes which 2 x 2 low-resolution pixels the taps over the upsampled src0 read
+  const bool up = UNI && a.upc;
+  const __amdgpu_buffer_rsrc_t rswu = __builtin_amdgcn_make_buffer_rsrc((void*)(up ? a.weight_up : a.weight), 0, up ? a.byteswu : 0u, 0x00020000);
+  const int upy = up ? ((int)fdiv((uint32_t)pix0, a.divPc) >> 1) : 0, upx = up ? ((int)fdiv((uint32_t)pix0, a.divPc) & 1) : 0;
   int zkh0 = 0, zkw0 = 0, znkw = 1, znk = 0;
-  if (zp) {
+  if (zp && !up) {
     const int zc = (int)fdiv((uint32_t)pix0, a.divPc);
     zkh0 = ((zc >> 1) + a.pad) & 1;                  // ho - pad + kh even  <=>  kh = zkh0 (mod 2)
     zkw0 = ((zc & 1) + a.pad) & 1;
@@ -109,12 +113,43 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   uint32_t wof[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) wof[i] = ((uint32_t)(cout0 + r0 + 32 * i) * (uint32_t)a.K + (uint32_t)lslot * VEC) * SZ;
+  uint32_t wofu[RA];   // rows of weight_up: [Cout_pad][16 * C0]
+#pragma unroll
+  for (int i = 0; i < RA; ++i) wofu[i] = ((uint32_t)(cout0 + r0 + 32 * i) * (uint32_t)(16 * a.C0) + (uint32_t)lslot * VEC) * SZ;
 
   auto issue_tile = [&](int kt, int buf) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + BM * 128;
     uint32_t k0 = (uint32_t)kt * KE;  // wave-uniform from here: scalar tap decomposition
-    if (zp) {   // kt-th K-tile of the class: (live tap, 64-channel chunk)
+    if (up) {
+      const int nk0 = 4 * a.ucpt0;
+      if (kt < nk0) {   // collapsed tap t = ty * 2 + tx of this class over the LOW-RESOLUTION src0, summed weights
+        const int t = (int)fdiv((uint32_t)kt, a.divU0), ch = kt - t * a.ucpt0;
+        const uint32_t ku = (uint32_t)((((upy * 2 + upx) * 4 + t) * a.C0 + ch * KE) * SZ);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool act = (i * 32 + wave * 8) < BM;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rswu, (__attribute__((address_space(3))) void*)(act ? sa + (i * 32 + wave * 8) * 128 : smem + DUMP + wave * 1024), 16,
+              act ? wofu[i] + ku : STP_OOB, 0, 0, 0);
+        }
+        const int dy = (t >> 1) - 1 + upy, dx = (t & 1) - 1 + upx;
+        const uint32_t ci = (uint32_t)(ch * KE + lslot * VEC);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          // hb = ho - 1 with ho = 2 * i_lo + upy (pad 1, stride 1): i_lo = (hb + 1) >> 1
+          const int hv = ((hb[i] + 1) >> 1) + dy, wv = ((wb[i] + 1) >> 1) + dx;
+          const bool ok = (unsigned)hv < (unsigned)a.Hs0 && (unsigned)wv < (unsigned)a.Ws0;
+          const uint32_t off = nof0[i] + (uint32_t)(hv * a.Ws0 + wv) * (uint32_t)a.C0 + ci;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(sb + (i * 32 + wave * 8) * 128), 16,
+                                                   ok ? off * SZ : STP_OOB, 0, 0, 0);
+        }
+        return;
+      }
+      // the nine taps of src1 with the original weights
+      const int k1 = kt - nk0, tap = (int)fdiv((uint32_t)k1, a.divU1), ch = k1 - tap * a.ucpt1;
+      k0 = (uint32_t)(tap * a.Ctot + a.C0 + ch * KE);
+    } else if (zp) {   // kt-th K-tile of the class: (live tap, 64-channel chunk)
       const int tix = (int)fdiv((uint32_t)kt, a.divCpt), ch = kt - tix * a.zcpt;
       const int ta = znkw == 2 ? tix >> 1 : tix, tb = znkw == 2 ? tix & 1 : 0;
       k0 = (uint32_t)(((zkh0 + 2 * ta) * a.KW + zkw0 + 2 * tb) * a.Ctot + ch * KE);
@@ -180,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int lr = lane & 15, lg = lane >> 4;
 
-  const int nk = zp ? znk : (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
+  const int nk = up ? 4 * a.ucpt0 + 9 * a.ucpt1 : zp ? znk : (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
   // epilogue operands (residual or the BatchNormalization-backward x; never both) fetched now: the loads are OLDER than every
   // tile load, so the counted vmcnt waits of the K loop also cover them, and their latency hides under the whole loop
   constexpr bool PRE = SZ == 2;
@@ -583,6 +618,25 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
       a.zPc = a.P / 4; a.zH2W2 = (a.Ho / 2) * (a.Wo / 2); a.zW2 = a.Wo / 2; a.zcpt = a.Ctot / ke;
       a.divPc = make_fastdiv((uint32_t)a.zPc); a.divH2W2 = make_fastdiv((uint32_t)a.zH2W2); a.divW2 = make_fastdiv((uint32_t)a.zW2);
       a.divCpt = make_fastdiv((uint32_t)a.zcpt);
+    }
+  }
+  {
+    // forward convolution over UpSampling2D(2) + concat with class-collapsed weights (see ConvArgs::upc)
+    static const bool upc_on = !(getenv("STP_UPCOLLAPSE") && atoi(getenv("STP_UPCOLLAPSE")) == 0);
+    const int ke = p->dtype == STP_BF16 ? 64 : 32;
+    const bool uni_tile = tile >= 64 && tile < 256;
+    if (upc_on && p->weight_up && a.mode == STP_SRC_NEAREST2X && ut == 1 && uni_tile && a.stride == 1 && a.KH == 3 && a.KW == 3 && a.pad == 1 &&
+        !(a.Ho & 1) && !(a.Wo & 1) && a.Ho == a.Hv && a.Wo == a.Wv && a.Hs0 * 2 == a.Hv && a.Ws0 * 2 == a.Wv && a.C1 > 0 && (a.C1 % ke) == 0 &&
+        ((a.P / 4) % tile_pixels(tile)) == 0) {
+      const int64_t bwu = (int64_t)a.wrows * 16 * a.C0 * (p->dtype == STP_BF16 ? 2 : 4);
+      if (bwu < (1ll << 31)) {
+        a.upc = 1; a.zperm = 1; a.byteswu = (uint32_t)bwu;
+        a.zPc = a.P / 4; a.zH2W2 = (a.Ho / 2) * (a.Wo / 2); a.zW2 = a.Wo / 2; a.zcpt = a.Ctot / ke;
+        a.divPc = make_fastdiv((uint32_t)a.zPc); a.divH2W2 = make_fastdiv((uint32_t)a.zH2W2); a.divW2 = make_fastdiv((uint32_t)a.zW2);
+        a.divCpt = make_fastdiv((uint32_t)a.zcpt);
+        a.ucpt0 = a.C0 / ke; a.ucpt1 = a.C1 / ke;
+        a.divU0 = make_fastdiv((uint32_t)a.ucpt0); a.divU1 = make_fastdiv((uint32_t)a.ucpt1);
+      }
     }
   }
   if (p->dtype == STP_BF16) return c4 ? launch_tile<bf16_t, true>(a, tile, ut, s) : launch_tile<bf16_t, false>(a, tile, ut, s);

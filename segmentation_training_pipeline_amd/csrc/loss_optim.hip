@@ -996,6 +996,70 @@ extern "C" int stp_weight_prepare_batched(const void* desc_dev, int32_t nlayers,
   return STP_OK;
 }
 
+// Class-collapsed weights of a 3x3 convolution over a NEAREST-2x upsampled source (stp_conv_params.weight_up): for output parity
+// (py, px) the taps that read the same low-resolution pixel are summed - rows (py, ty): (0,0) {0}, (0,1) {1,2}, (1,0) {0,1}, (1,1) {2}.
+// out[row][c = py*2+px][t = ty*2+tx][ci], row < round_up(Cout, 16) (zero rows behind Cout); sums in fp32, one rounding.
+struct UpcollapseDesc {     // 32 bytes (the host packs it as two pointers + four int32)
+  const float* master;
+  void* out;
+  int32_t Cout, rows, C0, Ctot;
+};
+
+template <typename T>
+__device__ __forceinline__ void weight_upcollapse_layer(const UpcollapseDesc& d, int64_t first, int64_t stride) {
+  T* out = reinterpret_cast<T*>(d.out);
+  const int64_t n = (int64_t)d.rows * 16 * d.C0;
+  for (int64_t i = first; i < n; i += stride) {
+    const int ci = (int)(i % d.C0);
+    const int ct = (int)((i / d.C0) & 15);
+    const int co = (int)(i / ((int64_t)16 * d.C0));
+    const int py = ct >> 3, px = (ct >> 2) & 1, ty = (ct >> 1) & 1, tx = ct & 1;
+    const int kh0 = (py == 0) ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), kh1 = (py == 0) ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+    const int kw0 = (px == 0) ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kw1 = (px == 0) ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+    float v = 0.f;
+    if (co < d.Cout)
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) v += d.master[(((int64_t)co * 3 + kh) * 3 + kw) * d.Ctot + ci];
+    Elem<T>::store(out + i, v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void weight_upcollapse_kernel(UpcollapseDesc d) {
+  weight_upcollapse_layer<T>(d, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+// grid.y = layer (descriptor table on the device): ONE launch per step for all decoder stages
+template <typename T>
+__global__ __launch_bounds__(256) void weight_upcollapse_batched_kernel(const UpcollapseDesc* __restrict__ desc) {
+  weight_upcollapse_layer<T>(desc[blockIdx.y], (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
+extern "C" int stp_weight_prepare_upcollapse(const float* master, void* weight_up, int32_t Cout, int32_t C0, int32_t C1, int32_t dtype,
+                                             void* stream) {
+  if (!master || !weight_up || Cout <= 0 || C0 <= 0 || C1 < 0) return STP_E_BADARG;
+  UpcollapseDesc d;
+  d.master = master; d.out = weight_up; d.Cout = Cout; d.rows = round_up(Cout, 16); d.C0 = C0; d.Ctot = C0 + C1;
+  int64_t g = ((int64_t)d.rows * 16 * C0 + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (dtype == STP_BF16) hipLaunchKernelGGL(weight_upcollapse_kernel<bf16_t>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, d);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(weight_upcollapse_kernel<float>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, d);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" size_t stp_weight_prepare_upcollapse_desc_bytes(void) { return sizeof(UpcollapseDesc); }
+
+// desc_dev: `nlayers` descriptors {const float* master; void* out; int32 Cout, rows (= Cout rounded up to 16), C0, C0 + C1} on the device
+extern "C" int stp_weight_prepare_upcollapse_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream) {
+  if (!desc_dev || nlayers <= 0) return STP_E_BADARG;
+  const dim3 grid(256, nlayers);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(weight_upcollapse_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(weight_upcollapse_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // padded gradient [CoutP][KH][KWp][Cinp] -> master layout [Cout][KH][KW][Cin]
 __global__ void weight_grad_unpad_kernel(const float* __restrict__ padded, float* __restrict__ grad, int Cout, int KH, int KW,
                                          int Cin, int KWp, int Cinp, int accumulate) {

@@ -97,6 +97,7 @@ class Plan(object):
         self._goffs = []
         self.bwd_marks, self.bwd_monotone = [], True
         self._prep_layers = []
+        self._upc_layers = []
         self._wg_ws_bytes = 0
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
@@ -155,6 +156,7 @@ class Plan(object):
         self.dry = False
         self._tape = []
         self._prep_layers = []
+        self._upc_layers = []
         self.tensors = OrderedDict()
         net_fn(self)
         self._fuse_bn_into_consumers()
@@ -209,6 +211,13 @@ class Plan(object):
         dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
         self._keep.append(dev)
         self._emit(self.prep, "stp_weight_prepare_batched", dev.data_ptr(), n, total, self.cdt)
+        if self._upc_layers:      # class-collapsed weight copies of the convolutions over upsample + concat (Plan.conv)
+            import struct
+            assert int(self.lib.stp_weight_prepare_upcollapse_desc_bytes()) == 32
+            tab = b"".join(struct.pack("<QQiiii", *lay) for lay in self._upc_layers)
+            udev = torch.frombuffer(bytearray(tab), dtype=torch.uint8).to(self.device)
+            self._keep.append(udev)
+            self._emit(self.prep, "stp_weight_prepare_upcollapse_batched", udev.data_ptr(), len(self._upc_layers), self.cdt)
 
     # ------------------------------------------------------------------ parameters / state
     def param(self, name, shape, kind="weight"):
@@ -570,6 +579,14 @@ class Plan(object):
                             src1=src1.buf if src1 is not None else None,
                             mode=src_mode, KH=k, KW=KWp, stride=stride, pad=pad,
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
+        if (upsample and src1 is not None and k == 3 and KWp == 3 and stride == 1 and pad == 1 and Cinp == Cin_master == C0 + C1
+                and os.environ.get("STP_UPCOLLAPSE", "1") != "0"):
+            # decoder conv1 = conv3x3(concat(UpSampling2D(2)(x), skip)): per output parity class the taps over the upsampled half read
+            # 2 x 2 low-resolution pixels - the forward multiplies them by class-summed weights (4 x C0 + 9 x C1 K columns instead
+            # of 9 x (C0 + C1)); the summed copy is rebuilt from the fp32 master with the other weight copies, once per step
+            wup = self._alloc((rows_f * 16 * C0,))
+            self._upc_layers.append((self._pptr(w), wup.data_ptr(), Cout, rows_f, C0, C0 + C1))     # one batched launch (_finish_prep)
+            p.weight_up = wup.data_ptr()
         if (self.training and x.meta.get("apply_rec") is not None and src1 is None and residual is None and not transpose and not stem
                 and self.lib.stp_conv2d_sc_eligible(C.byref(p)) and (not w.trainable or self.lib.stp_wgrad_sc_eligible(C.byref(wp)))):
             x.meta["sc_consumers"].append((p, wp))       # see _fuse_bn_into_consumers

@@ -197,6 +197,54 @@ def test_conv2d_upsample_concat_gather(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64, 32), (1, 16, 32, 128, 64, 64), (2, 8, 16, 64, 128, 128)])
+def test_conv2d_upsample_concat_with_class_collapsed_weights(ops, dtype, shape):
+    """stp_conv_params.weight_up: per output parity class the nine taps over the nearest-2x upsampled source read 2 x 2 low-resolution
+    pixels, so the uniform-tap kernel multiplies them by the class-summed weights (stp_weight_prepare_upcollapse) - 4 x C0 + 9 x C1
+    K columns instead of 9 x (C0 + C1).  Must equal the plain gather (up to the one extra rounding of the summed bf16 weights) and
+    the numpy reference, including the image borders; the per-tile statistics ride along."""
+    from segmentation_training_pipeline_amd import _lib
+    rng = np.random.RandomState(15)
+    n, h, w, c0, c1, co = shape                                  # low-resolution size of the upsampled source
+    x = q(rng.randn(n, h, w, c0), dtype)
+    skip = q(rng.randn(n, 2 * h, 2 * w, c1), dtype)
+    wt = q(rng.randn(3, 3, c0 + c1, co) / 30.0, dtype)
+    ref = np_ops.conv2d(np.concatenate([np_ops.upsample2x(x), skip], axis=-1), wt, 1, 1)
+    master, fwd, _, _ = prep_weights(ops, wt, dtype)
+    rows = (co + 15) // 16 * 16
+    wup = torch.full((rows * 16 * c0,), float("nan"), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_weight_prepare_upcollapse", ops.ptr(master), ops.ptr(wup), co, c0, c1, ops.dt(wup), ops.stream())
+    # the collapsed matrix against numpy: class (py, px), tap (ty, tx)
+    sets = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+    want = np.zeros((rows, 2, 2, 2, 2, c0), np.float32)
+    for py in (0, 1):
+        for px in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    want[:co, py, px, ty, tx] = sum(wt[kh, kw, :c0, :].T for kh in sets[(py, ty)] for kw in sets[(px, tx)])
+    np.testing.assert_allclose(host(wup).reshape(want.shape), q(want, dtype), atol=0 if dtype == "fp32" else 2e-3)
+
+    def run(weight_up, stats):
+        y = torch.empty((n, 2 * h, 2 * w, co), dtype=TD[dtype], device=DEV)
+        P = ops.conv_params(dev(x, dtype), fwd, y, N=n, Hs0=h, Ws0=w, Hv=2 * h, Wv=2 * w, C0=c0, C1=c1, src1=dev(skip, dtype),
+                            mode=ops.SRC_NEAREST2X, KH=3, KW=3, stride=1, pad=1, Ho=2 * h, Wo=2 * w, Cout=co, dtype=ops.dt(y))
+        P.weight_up = ops.ptr(weight_up)
+        st = None
+        if stats:
+            st = torch.zeros(max(ops.conv2d_stats_floats(P), 4), device=DEV)
+            P.stats_partial = ops.ptr(st)
+        ops.conv2d(P)
+        return host(y), (None if st is None else host(st).reshape(2, co, -1).sum(-1))
+    plain, pst = run(None, True)
+    coll, cst = run(wup, True)
+    np.testing.assert_allclose(plain, ref, atol=tol(ref, dtype))
+    np.testing.assert_allclose(coll, ref, atol=tol(ref, dtype))
+    np.testing.assert_allclose(coll, plain, atol=(1e-5 if dtype == "fp32" else 0.05) * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(cst, pst, rtol=2e-2, atol=0.5 if dtype == "bf16" else 1e-2)
+    assert np.abs(coll - plain).max() > 0 or dtype == "fp32"        # (the collapsed path really ran: bf16 rounds the sums once more)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("geom", [(3, 1, 1, 10, 12), (3, 2, 1, 12, 10), (1, 2, 0, 8, 8), (3, 2, 1, 9, 11)])
 def test_conv2d_data_gradient(ops, dtype, geom):
     """dgrad = stp_conv2d over dY with the flipped/transposed weight copy (zero-insertion for stride 2)."""
