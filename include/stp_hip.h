@@ -127,6 +127,10 @@ int stp_weight_prepare_upcollapse(const float* master, void* weight_up, int32_t 
  * (= Cout rounded up to 16), C0, C0 + C1} (stp_weight_prepare_upcollapse_desc_bytes() = 32 bytes each) in device memory. */
 size_t stp_weight_prepare_upcollapse_desc_bytes(void);
 int stp_weight_prepare_upcollapse_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream);
+/* Data gradient w.r.t. the low-resolution source of such a layer = a 4x4 / stride 2 / pad 1 convolution of dY (stp_conv2d, DIRECT
+ * source): this builds its weights [round_up(C0, 16)][4][4][CoutB] from the master - row taps {2}, {1,2}, {0,1}, {0} of the 3x3
+ * kernel summed, columns alike.  desc_dev: nlayers records {const float* master; void* out; int32 Cout, CoutB, C0, C0 + C1}. */
+int stp_weight_prepare_upcollapse_bwd_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream);
 /* floats needed by stats_partial for this shape (tile choice included) */
 size_t stp_conv2d_stats_floats(const stp_conv_params* p);
 /* tile configuration stp_conv2d would pick for p (see conv_igemm.hip: 1..6 register-staged tiles, 32*STAGES+t

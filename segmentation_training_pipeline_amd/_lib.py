@@ -48,6 +48,7 @@ SIGNATURES = {
     "stp_weight_prepare_upcollapse": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "stp_weight_prepare_upcollapse_desc_bytes": (sz, []),
     "stp_weight_prepare_upcollapse_batched": (i32, [vp, i32, i32, vp]),
+    "stp_weight_prepare_upcollapse_bwd_batched": (i32, [vp, i32, i32, vp]),
     "stp_conv2d_stats_floats": (sz, [C.POINTER(ConvParams)]),
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc_eligible": (i32, [C.POINTER(ConvParams)]),

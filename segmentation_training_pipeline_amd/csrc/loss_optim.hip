@@ -1060,6 +1060,43 @@ extern "C" int stp_weight_prepare_upcollapse_batched(const void* desc_dev, int32
   return STP_OK;
 }
 
+// The data gradient w.r.t. the LOW-RESOLUTION source of such a convolution is a plain 4x4 / stride 2 / pad 1 convolution of dY:
+// dX_lo[i] takes dY rows 2i-1 .. 2i+2 through the row-tap sums {2}, {1,2}, {0,1}, {0} of the 3x3 kernel (columns alike) - 16
+// instead of 36 taps per low-resolution pixel, and neither the high-resolution gradient nor its 2x2 fold exist.  out = the weight
+// matrix of that convolution, [round_up(C0, 16)][4][4][CoutB] (rows = input channels of the forward layer, zero padding).
+// Descriptor: UpcollapseDesc with `rows` holding CoutB.
+template <typename T>
+__global__ __launch_bounds__(256) void weight_upcollapse_bwd_batched_kernel(const UpcollapseDesc* __restrict__ desc) {
+  const UpcollapseDesc d = desc[blockIdx.y];
+  const int CoutB = d.rows, rows = (d.C0 + 15) / 16 * 16;
+  T* out = reinterpret_cast<T*>(d.out);
+  const int64_t n = (int64_t)rows * 16 * CoutB;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i % CoutB);
+    const int rs = (int)((i / CoutB) & 15);
+    const int ci = (int)(i / ((int64_t)16 * CoutB));
+    const int r = rs >> 2, c = rs & 3;
+    const int kh0 = r == 0 ? 2 : r == 1 ? 1 : 0, kh1 = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 0;
+    const int kw0 = c == 0 ? 2 : c == 1 ? 1 : 0, kw1 = c == 0 ? 2 : c == 1 ? 2 : c == 2 ? 1 : 0;
+    float v = 0.f;
+    if (co < d.Cout && ci < d.C0)
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) v += d.master[(((int64_t)co * 3 + kh) * 3 + kw) * d.Ctot + ci];
+    Elem<T>::store(out + i, v);
+  }
+}
+
+// desc_dev: nlayers records {const float* master; void* out; int32 Cout, CoutB, C0, C0 + C1} (32 bytes each) on the device
+extern "C" int stp_weight_prepare_upcollapse_bwd_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream) {
+  if (!desc_dev || nlayers <= 0) return STP_E_BADARG;
+  const dim3 grid(256, nlayers);
+  if (dtype == STP_BF16) hipLaunchKernelGGL(weight_upcollapse_bwd_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(weight_upcollapse_bwd_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // padded gradient [CoutP][KH][KWp][Cinp] -> master layout [Cout][KH][KW][Cin]
 __global__ void weight_grad_unpad_kernel(const float* __restrict__ padded, float* __restrict__ grad, int Cout, int KH, int KW,
                                          int Cin, int KWp, int Cinp, int accumulate) {

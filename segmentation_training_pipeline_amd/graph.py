@@ -98,6 +98,7 @@ class Plan(object):
         self.bwd_marks, self.bwd_monotone = [], True
         self._prep_layers = []
         self._upc_layers = []
+        self._upc4_layers = []
         self._wg_ws_bytes = 0
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
@@ -157,6 +158,7 @@ class Plan(object):
         self._tape = []
         self._prep_layers = []
         self._upc_layers = []
+        self._upc4_layers = []
         self.tensors = OrderedDict()
         net_fn(self)
         self._fuse_bn_into_consumers()
@@ -218,6 +220,11 @@ class Plan(object):
             udev = torch.frombuffer(bytearray(tab), dtype=torch.uint8).to(self.device)
             self._keep.append(udev)
             self._emit(self.prep, "stp_weight_prepare_upcollapse_batched", udev.data_ptr(), len(self._upc_layers), self.cdt)
+            if self._upc4_layers:
+                tab4 = b"".join(struct.pack("<QQiiii", *lay) for lay in self._upc4_layers)
+                udev4 = torch.frombuffer(bytearray(tab4), dtype=torch.uint8).to(self.device)
+                self._keep.append(udev4)
+                self._emit(self.prep, "stp_weight_prepare_upcollapse_bwd_batched", udev4.data_ptr(), len(self._upc4_layers), self.cdt)
 
     # ------------------------------------------------------------------ parameters / state
     def param(self, name, shape, kind="weight"):
@@ -579,6 +586,7 @@ class Plan(object):
                             src1=src1.buf if src1 is not None else None,
                             mode=src_mode, KH=k, KW=KWp, stride=stride, pad=pad,
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
+        w4 = None
         if (upsample and src1 is not None and k == 3 and KWp == 3 and stride == 1 and pad == 1 and Cinp == Cin_master == C0 + C1
                 and os.environ.get("STP_UPCOLLAPSE", "1") != "0"):
             # decoder conv1 = conv3x3(concat(UpSampling2D(2)(x), skip)): per output parity class the taps over the upsampled half read
@@ -587,6 +595,11 @@ class Plan(object):
             wup = self._alloc((rows_f * 16 * C0,))
             self._upc_layers.append((self._pptr(w), wup.data_ptr(), Cout, rows_f, C0, C0 + C1))     # one batched launch (_finish_prep)
             p.weight_up = wup.data_ptr()
+            if need_dgrad and x_ng and C0 % 16 == 0 and os.environ.get("STP_UPCOLLAPSE_BWD", "0") == "1":
+                # ... and the data gradient w.r.t. x is a 4x4 / stride-2 convolution of dY with the row / column tap sums.  OPT-IN:
+                # measured slower with today's kernels for the two resulting shapes, kept for the next round
+                w4 = self._alloc((C0 * 16 * CoutB,))
+                self._upc4_layers.append((self._pptr(w), w4.data_ptr(), Cout, CoutB, C0, C0 + C1))
         if (self.training and x.meta.get("apply_rec") is not None and src1 is None and residual is None and not transpose and not stem
                 and self.lib.stp_conv2d_sc_eligible(C.byref(p)) and (not w.trainable or self.lib.stp_wgrad_sc_eligible(C.byref(wp)))):
             x.meta["sc_consumers"].append((p, wp))       # see _fuse_bn_into_consumers
@@ -694,6 +707,21 @@ class Plan(object):
                     raise StpShapeError("data gradient supports stride 1 and 2")
                 bnm = x.meta.get("bn")
                 folded_up = False
+                qC1 = C1
+                if w4 is not None:
+                    # conv3x3(concat(UpSampling2D(2)(x), skip)): the skip gradient is the plain 3x3 data gradient with the skip's rows
+                    # of the flipped weight copy; the gradient of x is a 4x4 / stride-2 convolution of dY with the tap sums (w4) that
+                    # lands on the low-resolution tensor directly - no high-resolution gradient, no stp_upsample2x_bwd
+                    if s_ng:
+                        q1 = ops.conv_params(dy, wb, d1, N=self.N, Hs0=Ho, Ws0=Wo, Hv=Ho, Wv=Wo, C0=CoutB, mode=ops.SRC_DIRECT, KH=k, KW=k,
+                                             stride=1, pad=k - 1 - pad, Ho=Hv, Wo=Wv, Cout=C1, dtype=self.cdt, accumulate0=acc1)
+                        q1.weight = wb.data_ptr() + C0 * k * k * CoutB * wb.element_size()
+                        self._emit_conv(self.bwd, q1, {"layer": name, "pass": "dgrad", "flops": flops * C1 / float(C0 + C1),
+                                                       "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q1)))})
+                    q = ops.conv_params(dy, w4, self._gradbuf(x), N=self.N, Hs0=Ho, Ws0=Wo, Hv=Ho, Wv=Wo, C0=CoutB, mode=ops.SRC_DIRECT,
+                                        KH=4, KW=4, stride=2, pad=1, Ho=x.H, Wo=x.W, Cout=C0, dtype=self.cdt, accumulate0=int(x.grad_ready))
+                    folded_up, qC1 = True, 0
+                qflops = flops * (C0 - 0.0) / (C0 + C1) if w4 is not None else flops
                 if upsample and x_ng and C1 == 0 and self.fold_upsample_grad:
                     # the small-channel kernel sums each 2x2 block in its epilogue: the hi-res gradient of the upsampled
                     # tensor is never written and stp_upsample2x_bwd disappears
@@ -709,7 +737,7 @@ class Plan(object):
                 # share, this data gradient accumulates on top): its epilogue sees the complete gradient of the BN output
                 sole = uses == 1 and not q.accumulate0
                 last = self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and q.accumulate0 and not upsample
-                if (self.fuse_bn_backward and bnm is not None and (sole or last) and (folded_up or not upsample) and C1 == 0
+                if (self.fuse_bn_backward and bnm is not None and (sole or last) and (folded_up or not upsample) and qC1 == 0
                         and x_ng and C0 % 4 == 0):
                     q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
                     if self.slot_arena is not None and self.N * Hv * Wv <= self.bn_slots_max_rows:
@@ -721,7 +749,7 @@ class Plan(object):
                         st = self._alloc((max(nfl, 4),), torch.float32)
                         q.stats_partial = st.data_ptr()
                         x.meta["bnb"] = (st, q)
-                self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": flops,
+                self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": qflops,
                                               "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
                 if upsample and x_ng and not folded_up:
                     acc_up = int(x.grad_ready)

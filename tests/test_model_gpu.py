@@ -814,3 +814,26 @@ def test_linknet_transpose_blocks_and_vgg_encoders_match_the_oracle(backbone, bl
     for _ in range(10):
         l1 = sb.impl.train_on_batch(x, y)["loss"]
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_split_upsample_data_gradient_matches_the_oracle(monkeypatch):
+    """STP_UPCOLLAPSE_BWD=1 (opt-in): the data gradient of conv3x3(concat(UpSampling2D(2)(x), skip)) as two launches - the skip's
+    3x3 data gradient and a 4x4 / stride-2 convolution of dY with the summed taps that lands on the low-resolution x directly
+    (stp_weight_prepare_upcollapse_bwd_batched) - against the oracle's autograd, with the fused BatchNormalization backward."""
+    monkeypatch.setenv("STP_UPCOLLAPSE_BWD", "1")
+    n, size, backbone = 2, 64, "resnet18"
+    P = onets.init_unet_resnet(backbone, seed=42)
+    x, y = ostep.synthetic_batch(n, size, size, seed=1234)
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=LOSS, optimizer="sgd", lr=0.05)
+    m = make(backbone, size, n, "fp32", optimizer="SGD", lr=0.05)
+    assert any(rec[2] == "stp_weight_prepare_upcollapse_bwd_batched" for rec in m.plan.prep)
+    assert not any(rec[2].startswith("stp_upsample2x_bwd") for rec in m.plan.bwd if rec[0] is not None)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    m.load_batch(x, y)
+    m.forward_backward()
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=1e-3)
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = rel_l2(g[k], ref)
+        assert e <= (1e-4 if k.startswith("final_conv") else 3e-2), "grad %s: rel L2 %.3g" % (k, e)
