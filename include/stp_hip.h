@@ -37,6 +37,12 @@ extern "C" {
 
 #define STP_F32 0
 #define STP_BF16 1
+/* STP_U8 (2) is defined with the BatchNormalization entry points below. */
+#define STP_F16 3   /* IEEE half storage + v_mfma_*_f16 (BASELINE.json configs[3] "fp16 MFMA").  The 16-bit storage format is a
+                       BUILD parameter of the kernel set: libstp_hip.so serves STP_F32 and STP_BF16, libstp_hip_f16.so - the
+                       same sources compiled with -DSTP_STORAGE_F16=1, same symbols - serves STP_F32 and STP_F16.  Every
+                       "dtype" argument documented as bf16 below means "the library's 16-bit format".  fp16 needs loss scaling:
+                       the loss entry points' grad_scale and the optimizers' gscale carry it (host: HipSegModel loss_scale). */
 
 /* How src0 is resampled into the virtual input plane of the implicit GEMM gather. */
 #define STP_SRC_DIRECT 0     /* virtual (h,w) = src (h,w)                                        */
@@ -45,6 +51,8 @@ extern "C" {
                              /* (data-gradient of a stride-2 convolution)                        */
 
 int stp_abi_version(void);
+/* The 16-bit dtype code this library was built for: STP_BF16 (libstp_hip.so) or STP_F16 (libstp_hip_f16.so). */
+int stp_storage_dtype(void);
 
 /* ----------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA.  Replaces keras.layers.Conv2D forward and the

@@ -10,7 +10,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STP_LIB") or os.path.join(HERE, "libstp_hip.so")   # STP_LIB: another build of the same library (A/B and what-if runs)
 
-F32, BF16, U8 = 0, 1, 2
+LIB_F16_PATH = os.environ.get("STP_LIB_F16") or os.path.join(HERE, "libstp_hip_f16.so")   # the IEEE-half build of the same sources
+
+F32, BF16, U8, F16 = 0, 1, 2, 3
 SRC_DIRECT, SRC_NEAREST2X, SRC_ZEROINS2X = 0, 1, 2
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -44,6 +46,7 @@ class WgradParams(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/stp_hip.h
 SIGNATURES = {
     "stp_abi_version": (i32, []),
+    "stp_storage_dtype": (i32, []),
     "stp_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "stp_weight_prepare_upcollapse": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "stp_weight_prepare_upcollapse_desc_bytes": (sz, []),
@@ -145,25 +148,50 @@ SIGNATURES = {
     "stp_cast_bf16_to_f32": (i32, [vp, vp, i64, f32, vp]),
 }
 
-_lib = None
+_libs = {}          # storage format ("bf16" | "fp16") -> loaded library
+_active = "bf16"    # the library immediate calls (call()) go to; plans hold their own library
 
 
-def load():
-    """Loads the shared library (building is ``segmentation_training_pipeline_amd.build``).
+def load(storage=None):
+    """Loads the shared library serving the 16-bit storage format ``storage`` ("bf16": libstp_hip.so, also the fp32 mode's;
+    "fp16": libstp_hip_f16.so; None: the active one).  Building is ``segmentation_training_pipeline_amd.build``.
     Raises StpError if it is absent: there is no fallback path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise StpError("libstp_hip.so is missing (%s): build it with "
-                       "`python -m segmentation_training_pipeline_amd.build`; there is no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    storage = storage or _active
+    if storage in _libs:
+        return _libs[storage]
+    if storage not in ("bf16", "fp16"):
+        raise ValueError("storage must be 'bf16' or 'fp16'")
+    path = LIB_PATH if storage == "bf16" else LIB_F16_PATH
+    if not os.path.exists(path):
+        raise StpError("%s is missing (%s): build it with "
+                       "`python -m segmentation_training_pipeline_amd.build`; there is no CPU fallback" % (os.path.basename(path), path))
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if lib.stp_storage_dtype() != (BF16 if storage == "bf16" else F16):
+        raise StpError("%s was not built for %s storage" % (path, storage))
+    _libs[storage] = lib
     return lib
+
+
+class storage(object):
+    """``with _lib.storage("fp16"):`` - immediate calls (ops.*) inside the block go to that build's library."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _active
+        load(self.name)
+        self.prev, _active = _active, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self.prev
+        return False
 
 
 _ERR = {-1: "STP_E_BADARG", -2: "STP_E_LAUNCH", -3: "STP_E_WORKSPACE"}

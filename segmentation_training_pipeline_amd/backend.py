@@ -52,7 +52,7 @@ class HipSegModel(object):
     def __init__(self, architecture="Unet", backbone="resnet34", input_shape=(512, 512, 3), classes=1, activation="sigmoid",
                  batch=16, dtype="bf16", loss="binary_crossentropy", optimizer="Adam", lr=1e-3, freeze_encoder=False,
                  decoder_filters=(256, 128, 64, 32, 16), clipnorm=None, clipvalue=None, use_graph=True, device="cuda",
-                 opt_kwargs=None, seed=42, decoder_block_type="upsampling", net_kwargs=None):
+                 opt_kwargs=None, seed=42, decoder_block_type="upsampling", net_kwargs=None, loss_scale=None):
         if architecture not in nets.NETWORKS:
             raise ValueError("Unknown architecture")
         if backbone not in nets.known_backbones() or (backbone in nets.VGG_BLOCKS and architecture not in ("Unet", "Linknet", "FPN", "PSPNet")) \
@@ -85,6 +85,18 @@ class HipSegModel(object):
         self._works = []
         self._graphs = None
         self.plan = graph.Plan(self.batch, dtype, device, training=True)
+        # fp16 storage (BASELINE configs[3]): static loss scaling - the loss kernels seed the backward with loss_scale * dL/dlogits
+        # (their grad_scale argument), every gradient in the arena is linear in it, and the optimizers' device scalar gscale
+        # carries 1/loss_scale (times the data-parallel mean and the clipnorm factor).  2^14 keeps the 1/(N*H*W) BCE gradient
+        # of a 16x512x512 batch (2.4e-7, below fp16's normal range) at 4e-3.  The losses without a grad_scale argument (on
+        # probabilities: DeepLabV3; lovasz) run unscaled.
+        scalable = architecture != "DeepLabV3" and not (len(self.loss_w) == 6 and self.loss_w[5])      # (.., w_lovasz)
+        if loss_scale is None:
+            loss_scale = 16384.0 if (dtype == "fp16" and scalable) else 1.0
+        self.loss_scale = float(loss_scale)
+        if self.loss_scale <= 0:
+            raise ValueError("loss_scale must be positive")
+        self.plan.loss_scale = self.loss_scale
         if freeze_encoder:
             self.plan.frozen_prefixes = nets.ENCODER_PREFIXES
         self.plan.define(self._net(True))
@@ -107,7 +119,9 @@ class HipSegModel(object):
             self.m = torch.zeros(n, dtype=torch.float32, device=self.device)   # the squared-gradient accumulator
         elif self.opt_kwargs.get("momentum", 0.0):
             self.vel = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self._build_opt()
+        self.dp_scale = 1.0
+        self.gscale.fill_(1.0 / self.loss_scale)
+        self._build_opt(use_gscale=self.loss_scale != 1.0)
         self._infer = None
         self.init_weights(seed)
 
@@ -149,7 +163,7 @@ class HipSegModel(object):
         self._segments = None
         self._works = []
         self.dp_scale = float(reducer.scale)
-        self.gscale.fill_(self.dp_scale)
+        self.gscale.fill_(self.dp_scale / self.loss_scale)
         self._build_opt(use_gscale=True)
 
     def _build_opt(self, use_gscale=False):
@@ -159,7 +173,7 @@ class HipSegModel(object):
         p.opt = []
         n = p.P.numel()
         if self.clipnorm > 0:
-            p._emit(p.opt, "stp_grad_global_scale", p.G.data_ptr(), n, self.clipnorm, getattr(self, "dp_scale", 1.0),
+            p._emit(p.opt, "stp_grad_global_scale", p.G.data_ptr(), n, self.clipnorm, getattr(self, "dp_scale", 1.0) / self.loss_scale,
                     self.gscale.data_ptr(), self.ws_norm.data_ptr(), self.ws_norm.numel() * 4)
         gs = self.gscale.data_ptr() if (use_gscale or self.clipnorm > 0) else None
         has_frozen = any(not i.trainable for i in p.params.values())
@@ -264,7 +278,8 @@ class HipSegModel(object):
         return out
 
     def get_gradients(self):
-        return self._unflatten(self.plan.G.cpu().numpy())
+        """Gradients of the last step in Keras layout (the arena holds loss_scale x gradient in fp16 mode: divided out here)."""
+        return self._unflatten(self.plan.G.cpu().numpy() * np.float32(1.0 / self.loss_scale))
 
     def broadcast_state(self, src=0):
         """Data-parallel start of a stage: every replica takes rank ``src``'s parameters, BatchNormalization moving

@@ -1,4 +1,5 @@
-"""Builds libstp_hip.so (the C-ABI shared library, include/stp_hip.h) for gfx950 with hipcc.
+"""Builds libstp_hip.so (the C-ABI shared library, include/stp_hip.h) for gfx950 with hipcc, and libstp_hip_f16.so - the same
+sources with -DSTP_STORAGE_F16=1: IEEE-half storage and v_mfma_*_f16 instead of bfloat16 (same symbols, STP_F16 dtype code).
 
 In-tree build: the .so lands next to this file so it travels with the repo snapshot to the
 GPU box.  hipcc cross-compiles without a GPU.  Usage: ``python -m segmentation_training_pipeline_amd.build``.
@@ -12,7 +13,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstp_hip.so")
+LIB_F16 = os.path.join(HERE, "libstp_hip_f16.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
+# (library, object suffix, extra flags): the 16-bit storage format is a build parameter of the kernel set (csrc/common.h)
+VARIANTS = [(LIB, ".o", []), (LIB_F16, ".f16.o", ["-DSTP_STORAGE_F16=1"])]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result"]
 
@@ -41,13 +45,18 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "stp_hip.h"))
     jobs = []
-    objs = []
-    for src in sources():
-        s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src[:-4] + ".o")
-        objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+    link = []
+    for lib, suffix, extra in VARIANTS:
+        objs = []
+        stale = False
+        for src in sources():
+            s = os.path.join(CSRC, src)
+            o = os.path.join(OBJ, src[:-4] + suffix)
+            objs.append(o)
+            if force or _stale(o, [s] + headers):
+                jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
+                stale = True
+        link.append((lib, objs, stale))
 
     def run(cmd):
         if verbose:
@@ -58,10 +67,11 @@ def build(force=False, verbose=False):
         return r
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    for lib, objs, stale in link:
+        if stale or force or _stale(lib, objs):
+            run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
     return LIB
 
 

@@ -23,7 +23,7 @@ template <typename T, int V> __device__ __forceinline__ void ldv(const T* p, flo
   } else {  // 8 bf16 = one 16-byte load
     const u32x4 r = *reinterpret_cast<const u32x4*>(p);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(r[e] << 16); o[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+    for (int e = 0; e < 4; ++e) { o[2 * e] = h16lo_to_f32(r[e]); o[2 * e + 1] = h16hi_to_f32(r[e]); }
   }
 }
 template <typename T, int V> __device__ __forceinline__ void stv(T* p, const float (&o)[V]) {
@@ -251,9 +251,9 @@ extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t
 #undef STP_U8V
   } else {
     if (C & 3) return STP_E_BADARG;
-    if (xdtype == STP_BF16 && (C & 7) == 0)
+    if (xdtype == STP_H16 && (C & 7) == 0)
       hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
-    else if (xdtype == STP_BF16)
+    else if (xdtype == STP_H16)
       hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
     else if (xdtype == STP_F32)
       hipLaunchKernelGGL((bn_partial_kernel<float, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const float*)x, rows, C, partial);
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(256) void bn_apply_v8_kernel(const bf16_t* __restri
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float lo = bn_act(bn_affine(__uint_as_float(r[e] << 16), sc[2 * e], sh[2 * e]), relu);
-      const float hi = bn_act(bn_affine(__uint_as_float(r[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), relu);
+      const float lo = bn_act(bn_affine(h16lo_to_f32(r[e]), sc[2 * e], sh[2 * e]), relu);
+      const float hi = bn_act(bn_affine(h16hi_to_f32(r[e]), sc[2 * e + 1], sh[2 * e + 1]), relu);
       o[e] = pack_bf16x2(lo, hi);
     }
     return o;
@@ -476,7 +476,7 @@ static int bn_apply_dispatch(const void* x, int xdt, void* y, int ydt, int64_t r
 #define STP_APPLY_U8(TY_, CY_) \
     hipLaunchKernelGGL((bn_apply_u8_kernel<TY_, CY_>), dim3(g), dim3(256), 0, s, (const uint8_t*)x, (TY_*)y, rows, C, mean, rstd, gamma, beta, mvar, eps, \
                        relu, pad_value)
-    if (ydt == STP_BF16) { if (Cy == 4) STP_APPLY_U8(bf16_t, 4); else STP_APPLY_U8(bf16_t, 8); }
+    if (ydt == STP_H16) { if (Cy == 4) STP_APPLY_U8(bf16_t, 4); else STP_APPLY_U8(bf16_t, 8); }
     else if (ydt == STP_F32) { if (Cy == 4) STP_APPLY_U8(float, 4); else STP_APPLY_U8(float, 8); }
     else return STP_E_BADARG;
 #undef STP_APPLY_U8
@@ -484,7 +484,7 @@ static int bn_apply_dispatch(const void* x, int xdt, void* y, int ydt, int64_t r
     return STP_OK;
   }
   if ((C & 3) || Cy != C || xdt != ydt) return STP_E_BADARG;
-  if (xdt == STP_BF16 && (C & 7) == 0 && rstd && !mvar) {
+  if (xdt == STP_H16 && (C & 7) == 0 && rstd && !mvar) {
     const int gv = grid_multiple_of(grid_for_amortised(rows * (C >> 3), 8), C >> 3);   // 8 vectors per thread once the CUs are covered
     if (gv > 0) {
       hipLaunchKernelGGL(bn_apply_v8_kernel, dim3(gv), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, C, mean, rstd, gamma, beta, relu);
@@ -494,7 +494,7 @@ static int bn_apply_dispatch(const void* x, int xdt, void* y, int ydt, int64_t r
   }
   const size_t lds = 2 * (size_t)C * sizeof(float);
   const int g = grid_for(rows * (C >> 2));
-  if (xdt == STP_BF16)
+  if (xdt == STP_H16)
     hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, rows, C,
                        mean, rstd, gamma, beta, mvar, eps, relu);
   else if (xdt == STP_F32)
@@ -522,7 +522,7 @@ extern "C" int stp_bn_apply_slots(const void* x, void* y, int32_t dtype, int64_t
   const int g = grid_for(rows * (C >> 2));
   const double inv_rows = 1.0 / (double)rows, unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, rows, C, (const float*)nullptr,
                        (const float*)nullptr, gamma, beta, (const float*)nullptr, eps, relu, (const long long*)slots, nslots, inv_rows, unbias,
                        momentum, mean, rstd, moving_mean, moving_var);
@@ -804,11 +804,11 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
   const int blocks = bn_blocks(rows) > BN_MAX_BLOCKS - 1 ? BN_MAX_BLOCKS - 1 : bn_blocks(rows);
   float* partial = (float*)workspace;
   float* sums = partial + (size_t)(BN_MAX_BLOCKS - 1) * 2 * C;  // last slab holds the finalized sums
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   if (v8)
     hipLaunchKernelGGL((bn_bwd_partial_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t*)x,
                        (const bf16_t*)dy, rows, C, mean, rstd, gamma, beta, relu, partial);
-  else if (dtype == STP_BF16)
+  else if (dtype == STP_H16)
     hipLaunchKernelGGL((bn_bwd_partial_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t*)x,
                        (const bf16_t*)dy, rows, C, mean, rstd, gamma, beta, relu, partial);
   else if (dtype == STP_F32)
@@ -825,7 +825,7 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
   if (v8)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(g), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)dy,
                        (bf16_t*)dx, rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
-  else if (dtype == STP_BF16)
+  else if (dtype == STP_H16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(g), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)dy,
                        (bf16_t*)dx, rows, C, mean, rstd, gamma, beta, sums, inv_rows, relu, accumulate_dx);
   else
@@ -863,7 +863,7 @@ extern "C" int stp_bn_backward_slots(const void* x, const void* g, void* dx, int
                                      float* dbeta, int32_t accumulate_dx, void* stream) {
   if (!x || !g || !dx || !mean || !rstd || !slots || rows <= 0 || C <= 0 || (C & 3) || nslots < 1 || (nslots & (nslots - 1))) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   const size_t lds2 = 6 * (size_t)C * sizeof(float);
   const int gr = grid_fixed_channels(grid_for_amortised(rows * (C / (v8 ? 8 : 4)), 8), C / (v8 ? 8 : 4));
   const float inv_rows = (float)(1.0 / (double)rows);
@@ -871,7 +871,7 @@ extern "C" int stp_bn_backward_slots(const void* x, const void* g, void* dx, int
   if (v8)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, rows, C,
                        mean, rstd, gamma, (const float*)nullptr, (const float*)nullptr, inv_rows, 0, accumulate_dx, sl, nslots, dgamma, dbeta);
-  else if (dtype == STP_BF16)
+  else if (dtype == STP_H16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, rows, C,
                        mean, rstd, gamma, (const float*)nullptr, (const float*)nullptr, inv_rows, 0, accumulate_dx, sl, nslots, dgamma, dbeta);
   else if (dtype == STP_F32)
@@ -893,7 +893,7 @@ extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int
   float* sums = (float*)workspace + (size_t)(BN_MAX_BLOCKS - 1) * 2 * C;
   hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(C), dim3(256), 0, s, partial, tiles, C, sums, dgamma, dbeta);
   STP_LAUNCH_CHECK();
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   const size_t lds2 = 6 * (size_t)C * sizeof(float);
   const int gr = grid_fixed_channels(grid_for_amortised(rows * (C / (v8 ? 8 : 4)), 8), C / (v8 ? 8 : 4));
   const float inv_rows = (float)(1.0 / (double)rows);
@@ -901,7 +901,7 @@ extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int
   if (v8)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g,
                        (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
-  else if (dtype == STP_BF16)
+  else if (dtype == STP_H16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g,
                        (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
   else if (dtype == STP_F32)
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 __device__ __forceinline__ f32x4 stored4(f32x4 v, const float*) { return v; }   // the value as the destination dtype holds it
 __device__ __forceinline__ f32x4 stored4(f32x4 v, const bf16_t*) {
   const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
-  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+  return f32x4{h16lo_to_f32(a), h16hi_to_f32(a), h16lo_to_f32(b), h16hi_to_f32(b)};
 }
 
 #define BNB_ROWS 8   // image rows per workgroup of the *_bn gradient kernels: fewer, larger partial-sum tiles
@@ -1084,11 +1084,11 @@ extern "C" int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N,
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   if ((int64_t)N * Ho > 65535) return STP_E_BADARG;  // gridDim.y
   hipStream_t s = (hipStream_t)stream;
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   const dim3 grid(ceil_div(Wo * (C / (v8 ? 8 : 4)), 256), ceil_div(N * Ho, POOL_ROWS));
   if (v8)
     hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
-  else if (dtype == STP_BF16)
+  else if (dtype == STP_H16)
     hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
   else if (dtype == STP_F32)
     hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C, Ho, Wo);
@@ -1103,7 +1103,7 @@ static int maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int3
   if (!idx || !dy || !dx || (C & 3) || N <= 0) return STP_E_BADARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   if ((int64_t)N * H > 65535) return STP_E_BADARG;  // gridDim.y
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   const int V = v8 ? 8 : 4;
   const dim3 grid(ceil_div(W * (C / V), 256), ceil_div(N * H, POOL_ROWS));
   BnBack none;
@@ -1113,12 +1113,12 @@ static int maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int3
     const size_t lds = 256 * 2 * V * sizeof(float);
     const dim3 gridb(grid.x, ceil_div(N * H, BNB_ROWS));
     if (v8) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, true>), gridb, dim3(256), lds, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4, true>), gridb, dim3(256), lds, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4, true>), gridb, dim3(256), lds, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
     else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4, true>), gridb, dim3(256), lds, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
     else return STP_E_BADARG;
   } else {
     if (v8) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
     else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4, false>), grid, dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
     else return STP_E_BADARG;
   }
@@ -1133,7 +1133,7 @@ extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx
 
 // Same tile count rule as stp_upsample2x_bwd_bn_tiles (H, W = the pool INPUT size): workgroups of the launch, 0 = unsupported C.
 extern "C" int stp_maxpool3x3s2_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype) {
-  const int V = (dtype == STP_BF16 && (C & 7) == 0) ? 8 : 4;
+  const int V = (dtype == STP_H16 && (C & 7) == 0) ? 8 : 4;
   if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;
   return ceil_div(W * (C / V), 256) * ceil_div(N * H, BNB_ROWS);
 }
@@ -1211,10 +1211,10 @@ extern "C" int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, i
                               void* stream) {
   if (!x || !y || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * (H >> 1) > 65535) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   const dim3 grid(ceil_div((W >> 1) * (C / (v8 ? 8 : 4)), 256), N * (H >> 1));
   if (v8) hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C);
-  else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C);
+  else if (dtype == STP_H16) hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C);
   else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool2_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, idx, N, H, W, C);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1225,10 +1225,10 @@ extern "C" int stp_maxpool2x2_bwd(const uint8_t* idx, const void* dy, void* dx, 
                                   int32_t dtype, int32_t accumulate, void* stream) {
   if (!idx || !dy || !dx || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * H > 65535) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
   if (v8) hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
-  else if (dtype == STP_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
+  else if (dtype == STP_H16) hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float, 4>), grid, dim3(256), 0, s, idx, (const float*)dy, (float*)dx, N, H, W, C, accumulate);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ y, 
 extern "C" int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* stream) {
   if (!y || !dy || count <= 0 || (count & 3)) return STP_E_BADARG;
   const int g = grid_for(count >> 2);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)dy, count >> 2);
+  if (dtype == STP_H16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)dy, count >> 2);
   else if (dtype == STP_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)dy, count >> 2);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
 static int upsample2x_bwd_launch(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,
                                  int32_t accumulate, const BnBack* bnb, float* partial, hipStream_t s) {
   if (!dy || !dx || (C & 3) || (ldy & 3) || ldy < C || (int64_t)N * H > 65535) return STP_E_BADARG;
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0 && (ldy & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0 && (ldy & 7) == 0;
   const int V = v8 ? 8 : 4;
   const dim3 grid(ceil_div(W * (C / V), 256), N * H);
   BnBack none;
@@ -1312,12 +1312,12 @@ static int upsample2x_bwd_launch(const void* dy, void* dx, int32_t N, int32_t H,
     const size_t lds = 256 * 2 * V * sizeof(float);
     const dim3 gridb(grid.x, ceil_div(N * H, BNB_ROWS));
     if (v8) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8, true>), gridb, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, true>), gridb, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, true>), gridb, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
     else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4, true>), gridb, dim3(256), lds, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate, *bnb, partial);
     else return STP_E_BADARG;
   } else {
     if (v8) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
     else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 4, false>), grid, dim3(256), 0, s, (const float*)dy, (float*)dx, N, H, W, C, ldy, accumulate, none, nullptr);
     else return STP_E_BADARG;
   }
@@ -1332,7 +1332,7 @@ extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H
 
 // number of workgroups (= partial-sum tiles per channel) of stp_upsample2x_bwd_bn
 extern "C" int stp_upsample2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype) {
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0 && (ldy & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0 && (ldy & 7) == 0;
   const int V = v8 ? 8 : 4;
   if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;          // 0: not supported for this channel count
   return ceil_div(W * (C / V), 256) * ceil_div(N * H, BNB_ROWS);
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_vec_kernel(const T* __restric
 // vector width shared by the pooling / resize kernels: 16-byte (bf16 x8, fp32 x4) or 8-byte (bf16 x4) channel groups
 static int vec_for(int dtype, int a, int b, int c) {
   const int m = a | b | c;
-  if (dtype == STP_BF16 && !(m & 7)) return 8;
+  if (dtype == STP_H16 && !(m & 7)) return 8;
   return (m & 3) ? 1 : 4;
 }
 
@@ -1494,7 +1494,7 @@ extern "C" size_t stp_avgpool_workspace_bytes(int32_t N, int32_t H, int32_t W, i
 extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* workspace,
                            size_t workspace_bytes, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
-  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, 0, 0);
   if (V > 1 && k * k >= 32) {
     const int cg = C / V, VL = pool_vl(cg);
@@ -1507,20 +1507,20 @@ extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t
     const size_t lds = (size_t)(256 / VL) * VL * V * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (V == 8) hipLaunchKernelGGL((avgpool_win_kernel<bf16_t, 8>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, k, VL, rps, part);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((avgpool_win_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, k, VL, rps, part);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((avgpool_win_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, k, VL, rps, part);
     else hipLaunchKernelGGL((avgpool_win_kernel<float, 4>), grid, dim3(256), lds, s, (const float*)x, (float*)y, H, W, C, k, VL, rps, part);
     STP_LAUNCH_CHECK();
     if (S > 1) {
       const int64_t ne = nwin * C;
       const float sc = 1.f / (float)(k * k);
-      if (dtype == STP_BF16) hipLaunchKernelGGL(split_combine_kernel<bf16_t>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, sc, (bf16_t*)y, 0);
+      if (dtype == STP_H16) hipLaunchKernelGGL(split_combine_kernel<bf16_t>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, sc, (bf16_t*)y, 0);
       else hipLaunchKernelGGL(split_combine_kernel<float>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, sc, (float*)y, 0);
       STP_LAUNCH_CHECK();
     }
     return STP_OK;
   }
   const int g = grid_for((int64_t)N * (H / k) * (W / k) * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, k);
+  if (dtype == STP_H16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, k);
   else if (dtype == STP_F32) hipLaunchKernelGGL(avgpool_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, k);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1530,19 +1530,19 @@ extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t
 extern "C" int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
                                int32_t accumulate, void* stream) {
   if (!dy || !dx || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
-  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, 0, 0);
   if (V > 1 && (int64_t)N * H <= 65535) {
     const dim3 grid(ceil_div(W * (C / V), 256), N * H);
     hipStream_t s = (hipStream_t)stream;
     if (V == 8) hipLaunchKernelGGL((avgpool_bwd_vec_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, k, accumulate);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((avgpool_bwd_vec_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, k, accumulate);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((avgpool_bwd_vec_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, k, accumulate);
     else hipLaunchKernelGGL((avgpool_bwd_vec_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)dy, (float*)dx, H, W, C, k, accumulate);
     STP_LAUNCH_CHECK();
     return STP_OK;
   }
   const int g = grid_for((int64_t)N * H * W * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
+  if (dtype == STP_H16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, k, accumulate);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1570,10 +1570,10 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(T* __restrict__ x, 
 extern "C" int stp_upsample2x_add(void* x, const void* m, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
   if (!x || !m || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * H > 65535) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool v8 = dtype == STP_BF16 && (C & 7) == 0;
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
   const dim3 grid(ceil_div(W * (C / (v8 ? 8 : 4)), 256), N * H);
   if (v8) hipLaunchKernelGGL((upsample2x_add_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)m, N, H, W, C);
-  else if (dtype == STP_BF16) hipLaunchKernelGGL((upsample2x_add_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)m, N, H, W, C);
+  else if (dtype == STP_H16) hipLaunchKernelGGL((upsample2x_add_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)m, N, H, W, C);
   else if (dtype == STP_F32) hipLaunchKernelGGL((upsample2x_add_kernel<float, 4>), grid, dim3(256), 0, s, (float*)x, (const float*)m, N, H, W, C);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1740,19 +1740,19 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_blk_kernel(const T* _
 extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
                                    int32_t coff, int32_t dtype, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
-  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, ldo, coff);
   if (V > 1 && (int64_t)N * H * factor <= 65535) {
     const dim3 grid(ceil_div(W * factor * (C / V), 256), N * H * factor);
     hipStream_t s = (hipStream_t)stream;
     if (V == 8) hipLaunchKernelGGL((resize_bilinear_vec_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, factor, ldo, coff);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((resize_bilinear_vec_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, factor, ldo, coff);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((resize_bilinear_vec_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, factor, ldo, coff);
     else hipLaunchKernelGGL((resize_bilinear_vec_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, H, W, C, factor, ldo, coff);
     STP_LAUNCH_CHECK();
     return STP_OK;
   }
   const int g = grid_for((int64_t)N * H * factor * W * factor * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_bilinear_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
+  if (dtype == STP_H16) hipLaunchKernelGGL(resize_bilinear_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_bilinear_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, factor, ldo, coff);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1776,7 +1776,7 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
                                        int32_t ldo, int32_t coff, int32_t dtype, int32_t accumulate, void* workspace,
                                        size_t workspace_bytes, void* stream) {
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
-  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, ldo, coff);
   if (V > 1 && factor >= 2) {
     const int cg = C / V, span = 2 * factor;
@@ -1796,19 +1796,19 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
     const size_t lds = (size_t)(256 / VL) * VL * V * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (V == 8) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 8>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part, TLp, PPB, (int)npix);
-    else if (dtype == STP_BF16) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part, TLp, PPB, (int)npix);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part, TLp, PPB, (int)npix);
     else hipLaunchKernelGGL((resize_bilinear_bwd_blk_kernel<float, 4>), grid, dim3(256), lds, s, (const float*)dy, (float*)dx, H, W, C, factor, ldo, coff, accumulate, VL, rps, part, TLp, PPB, (int)npix);
     STP_LAUNCH_CHECK();
     if (S > 1) {
       const int64_t ne = npix * C;
-      if (dtype == STP_BF16) hipLaunchKernelGGL(split_combine_kernel<bf16_t>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, 1.f, (bf16_t*)dx, accumulate);
+      if (dtype == STP_H16) hipLaunchKernelGGL(split_combine_kernel<bf16_t>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, 1.f, (bf16_t*)dx, accumulate);
       else hipLaunchKernelGGL(split_combine_kernel<float>, dim3((unsigned)ceil_div(ne, (int64_t)256)), dim3(256), 0, s, part, S, ne, 1.f, (float*)dx, accumulate);
       STP_LAUNCH_CHECK();
     }
     return STP_OK;
   }
   const int g = grid_for((int64_t)N * H * W * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_bilinear_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
+  if (dtype == STP_H16) hipLaunchKernelGGL(resize_bilinear_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_bilinear_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, factor, ldo, coff, accumulate);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1859,7 +1859,7 @@ extern "C" int stp_maxpool_k(const void* x, void* y, int32_t* idx, int32_t N, in
                              void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * (H / k) * (W / k) * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(maxpool_k_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, k);
+  if (dtype == STP_H16) hipLaunchKernelGGL(maxpool_k_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, k);
   else if (dtype == STP_F32) hipLaunchKernelGGL(maxpool_k_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, N, H, W, C, k);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1869,7 +1869,7 @@ extern "C" int stp_maxpool_k_bwd(const int32_t* idx, const void* dy, void* dx, i
                                  int32_t dtype, int32_t accumulate, void* stream) {
   if (!idx || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * H * W * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(maxpool_k_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
+  if (dtype == STP_H16) hipLaunchKernelGGL(maxpool_k_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(maxpool_k_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, idx, (const float*)dy, (float*)dx, N, H, W, C, k, accumulate);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1912,7 +1912,7 @@ extern "C" int stp_resize_nearest(const void* x, void* y, int32_t N, int32_t H, 
                                   int32_t dtype, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * H * factor * W * factor * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_nearest_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
+  if (dtype == STP_H16) hipLaunchKernelGGL(resize_nearest_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_nearest_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, factor, ldo, coff);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1922,7 +1922,7 @@ extern "C" int stp_resize_nearest_bwd(const void* dy, void* dx, int32_t N, int32
                                       int32_t coff, int32_t dtype, int32_t accumulate, void* stream) {
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * H * W * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_nearest_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
+  if (dtype == STP_H16) hipLaunchKernelGGL(resize_nearest_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_nearest_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, factor, ldo, coff, accumulate);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1946,9 +1946,9 @@ extern "C" int stp_channel_sum(const void* x, int32_t dtype, int64_t rows, int32
   hipStream_t s = (hipStream_t)stream;
   const int blocks = bn_blocks(rows);
   float* partial = (float*)workspace;
-  if (dtype == STP_BF16 && (C & 7) == 0)
+  if (dtype == STP_H16 && (C & 7) == 0)
     hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 256 * 16 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
-  else if (dtype == STP_BF16)
+  else if (dtype == STP_H16)
     hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const bf16_t*)x, rows, C, partial);
   else if (dtype == STP_F32)
     hipLaunchKernelGGL((bn_partial_kernel<float, 4>), dim3(blocks), dim3(256), 256 * 8 * sizeof(float), s, (const float*)x, rows, C, partial);
@@ -1970,7 +1970,7 @@ extern "C" int stp_add_inplace(void* dst, const void* src, int64_t count, int32_
   if (!dst || !src || count <= 0 || (count & 3)) return STP_E_BADARG;
   const int g = grid_for(count >> 2);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (bf16_t*)dst, (const bf16_t*)src, count >> 2);
   else if (dtype == STP_F32)
     hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(g), dim3(256), 0, s, (float*)dst, (const float*)src, count >> 2);

@@ -10,22 +10,51 @@
     if (hipGetLastError() != hipSuccess) return STP_E_LAUNCH; \
   } while (0)
 
-typedef uint16_t bf16_t;  // raw bf16 bits
+// The 16-bit storage format is a BUILD parameter of the whole kernel set: libstp_hip.so stores bfloat16 (STP_BF16),
+// libstp_hip_f16.so - the same sources compiled with -DSTP_STORAGE_F16=1 - stores IEEE half (STP_F16) and feeds the
+// v_mfma_*_f16 instructions (same rate and fp32 accumulation as the bf16 ones on gfx950).  `bf16_t` is "the 16-bit storage
+// word" in either build; every conversion goes through the helpers below, STP_H16 is the dtype code this build accepts.
+#ifndef STP_STORAGE_F16
+#define STP_STORAGE_F16 0
+#endif
+#define STP_H16 (STP_STORAGE_F16 ? STP_F16 : STP_BF16)
+
+typedef uint16_t bf16_t;  // raw 16-bit storage word (bf16 or IEEE half, see above)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
+#if STP_STORAGE_F16
+// IEEE half: v_cvt_f32_f16 / v_cvt_f16_f32 (round-to-nearest-even, as torch.float16 casts)
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ float h16lo_to_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+template <typename V> __device__ __forceinline__ f32x4 mfma16_16x16x32(V a, V b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#else
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-
+__device__ __forceinline__ float h16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 // fp32 -> bf16, round-to-nearest-even: the gfx950 hardware conversion (v_cvt_pk_bf16_f32), same rule
 // as torch / ml_dtypes bf16 casts.
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+template <typename V> __device__ __forceinline__ f32x4 mfma16_16x16x32(V a, V b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+#endif
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
@@ -37,7 +66,7 @@ template <> struct Elem<float> {
 };
 template <> struct Elem<bf16_t> {
   static constexpr int VEC = 8;
-  static constexpr int DTYPE = STP_BF16;
+  static constexpr int DTYPE = STP_H16;
   __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
   __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
@@ -47,10 +76,10 @@ __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cas
 __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
   u32x2 r = *reinterpret_cast<const u32x2*>(p);
   f32x4 o;
-  o.x = __uint_as_float(r.x << 16);
-  o.y = __uint_as_float(r.x & 0xffff0000u);
-  o.z = __uint_as_float(r.y << 16);
-  o.w = __uint_as_float(r.y & 0xffff0000u);
+  o.x = h16lo_to_f32(r.x);
+  o.y = h16hi_to_f32(r.x);
+  o.z = h16lo_to_f32(r.y);
+  o.w = h16hi_to_f32(r.y);
   return o;
 }
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

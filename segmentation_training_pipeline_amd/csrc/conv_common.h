@@ -54,7 +54,7 @@ __device__ __forceinline__ int zperm_pixel(const ConvArgs& a, int pl) {
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    c = mfma16_16x16x32(a, b, c);
   }
 };
 template <> struct Mma<float> {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void compute_tile(const char* stage, int wm, int wn, 
 __device__ __forceinline__ f32x4 stored(f32x4 v, const float*) { return v; }
 __device__ __forceinline__ f32x4 stored(f32x4 v, const bf16_t*) {
   const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
-  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+  return f32x4{h16lo_to_f32(a), h16hi_to_f32(a), h16lo_to_f32(b), h16hi_to_f32(b)};
 }
 
 // bias, residual, ReLU, dual destination, optional accumulate, optional fused BatchNormalization statistics.
@@ -132,7 +132,7 @@ __device__ __forceinline__ f32x4 stored(f32x4 v, const bf16_t*) {
 // PRE: the residual / BatchNormalization-backward x values of this lane's outputs were fetched before the K loop (bf16,
 // buffer-DMA kernel) - the epilogue's own loads sit behind per-fragment branches and would be latency-serialised.
 __device__ __forceinline__ f32x4 unpack_bf16x4(const u32x2 r) {
-  return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+  return f32x4{h16lo_to_f32(r.x), h16hi_to_f32(r.x), h16lo_to_f32(r.y), h16hi_to_f32(r.y)};
 }
 
 // pixf(j) -> the flattened output pixel (n*Ho*Wo + ho*Wo + wo) of this lane's j-th fragment column, or < 0 to skip it.
@@ -254,11 +254,11 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
 // stp_conv_params -> ConvArgs (validation shared by every MFMA convolution kernel)
 static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* ut_out) {
   if (!p || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
-  if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
-  const int vec = p->dtype == STP_BF16 ? 8 : 4;
-  const int sz = p->dtype == STP_BF16 ? 2 : 4;
+  if (p->dtype != STP_F32 && p->dtype != STP_H16) return STP_E_BADARG;
+  const int vec = p->dtype == STP_H16 ? 8 : 4;
+  const int sz = p->dtype == STP_H16 ? 2 : 4;
   const int ke = 128 / sz;
-  const bool c4 = (p->dtype == STP_BF16) && p->C0 == 4 && p->C1 == 0;
+  const bool c4 = (p->dtype == STP_H16) && p->C0 == 4 && p->C1 == 0;
   if (c4) {
     if ((p->KW & 1) || p->src0_mode != STP_SRC_DIRECT) return STP_E_BADARG;
   } else if ((p->C0 % vec) || (p->C1 % vec)) {

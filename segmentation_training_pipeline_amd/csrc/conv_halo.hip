@@ -44,6 +44,14 @@
 #define HALO_NWST 4
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// v_mfma_f32_32x32x16 of the build's 16-bit storage format (common.h)
+template <typename V> __device__ __forceinline__ f32x16 mfma16_32x32x16(V a, V b, f32x16 c) {
+#if STP_STORAGE_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
 
 // counted wait with a count that is a constant only after loop unrolling
 __device__ __forceinline__ void wait_vmcnt_n(int n) {
@@ -70,7 +78,7 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 //   EP 2: (accumulate) + BatchNormalization-backward: store g = dY under the activation mask, reduce sum g and sum g * xhat
 // Same arithmetic per element as conv_common.h's epilogue (sum g * xhat is accumulated as sum g * x and centred once per channel).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2v unpack_bf16x2(uint32_t w) { return f32x2v{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2v unpack_bf16x2(uint32_t w) { return f32x2v{h16lo_to_f32(w), h16hi_to_f32(w)}; }
 
 template <int TH, int BM, int WM, int WN, int EP>
 __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][TH / WN / 2], char* smem, int n, int y0, int x0,
@@ -335,8 +343,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float lo = bn_act(bn_affine(__uint_as_float(v[e] << 16), e < 2 ? sc0[2 * e] : sc1[2 * e - 4], e < 2 ? sh0[2 * e] : sh1[2 * e - 4]), a.pbn.relu);
-        const float hi = bn_act(bn_affine(__uint_as_float(v[e] & 0xffff0000u), e < 2 ? sc0[2 * e + 1] : sc1[2 * e - 3], e < 2 ? sh0[2 * e + 1] : sh1[2 * e - 3]), a.pbn.relu);
+        const float lo = bn_act(bn_affine(h16lo_to_f32(v[e]), e < 2 ? sc0[2 * e] : sc1[2 * e - 4], e < 2 ? sh0[2 * e] : sh1[2 * e - 4]), a.pbn.relu);
+        const float hi = bn_act(bn_affine(h16hi_to_f32(v[e]), e < 2 ? sc0[2 * e + 1] : sc1[2 * e - 3], e < 2 ? sh0[2 * e + 1] : sh1[2 * e - 3]), a.pbn.relu);
         o[e] = pack_bf16x2(lo, hi);
       }
       *vp = o;
@@ -438,8 +446,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kc][i]), __builtin_bit_cast(bf16x8, fb[kc][j]),
-                                                                    acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16_32x32x16(fa[kc][i], fb[kc][j], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (piece < LW) {
                   if (wlive) issue_weight_piece(piece, st3, s3, t3);
@@ -512,7 +519,7 @@ static int launch_halo(ConvArgs& a, hipStream_t s) {
 }
 
 static bool halo_shape_ok(const stp_conv_params* p) {
-  return p && p->dtype == STP_BF16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->src0_mode == STP_SRC_DIRECT &&
+  return p && p->dtype == STP_H16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->src0_mode == STP_SRC_DIRECT &&
          p->C1 == 0 && p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv && p->Hs0 == p->Hv && p->Ws0 == p->Wv &&
          (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->dst_sum2x2 && !p->stats_slots &&
          (p->Cd0 % 8) == 0 &&

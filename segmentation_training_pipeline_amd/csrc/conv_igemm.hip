@@ -610,7 +610,7 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   {
     // data gradient of a stride-2 convolution through the uniform-tap kernel: parity-class pixel order (see ConvArgs::zperm)
     static const bool zperm_on = !(getenv("STP_ZPERM") && atoi(getenv("STP_ZPERM")) == 0);
-    const int ke = p->dtype == STP_BF16 ? 64 : 32;
+    const int ke = p->dtype == STP_H16 ? 64 : 32;
     const bool uni_tile = tile >= 64 && tile < 256;
     if (zperm_on && a.mode == STP_SRC_ZEROINS2X && ut == 1 && uni_tile && a.stride == 1 && a.KH <= 3 && a.KW <= 3 && !(a.Ho & 1) && !(a.Wo & 1) &&
         a.C1 == 0 && ((a.P / 4) % tile_pixels(tile)) == 0) {
@@ -623,12 +623,12 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   {
     // forward convolution over UpSampling2D(2) + concat with class-collapsed weights (see ConvArgs::upc)
     static const bool upc_on = !(getenv("STP_UPCOLLAPSE") && atoi(getenv("STP_UPCOLLAPSE")) == 0);
-    const int ke = p->dtype == STP_BF16 ? 64 : 32;
+    const int ke = p->dtype == STP_H16 ? 64 : 32;
     const bool uni_tile = tile >= 64 && tile < 256;
     if (upc_on && p->weight_up && a.mode == STP_SRC_NEAREST2X && ut == 1 && uni_tile && a.stride == 1 && a.KH == 3 && a.KW == 3 && a.pad == 1 &&
         !(a.Ho & 1) && !(a.Wo & 1) && a.Ho == a.Hv && a.Wo == a.Wv && a.Hs0 * 2 == a.Hv && a.Ws0 * 2 == a.Wv && a.C1 > 0 && (a.C1 % ke) == 0 &&
         ((a.P / 4) % tile_pixels(tile)) == 0) {
-      const int64_t bwu = (int64_t)a.wrows * 16 * a.C0 * (p->dtype == STP_BF16 ? 2 : 4);
+      const int64_t bwu = (int64_t)a.wrows * 16 * a.C0 * (p->dtype == STP_H16 ? 2 : 4);
       if (bwu < (1ll << 31)) {
         a.upc = 1; a.zperm = 1; a.byteswu = (uint32_t)bwu;
         a.zPc = a.P / 4; a.zH2W2 = (a.Ho / 2) * (a.Wo / 2); a.zW2 = a.Wo / 2; a.zcpt = a.Ctot / ke;
@@ -639,6 +639,6 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
       }
     }
   }
-  if (p->dtype == STP_BF16) return c4 ? launch_tile<bf16_t, true>(a, tile, ut, s) : launch_tile<bf16_t, false>(a, tile, ut, s);
+  if (p->dtype == STP_H16) return c4 ? launch_tile<bf16_t, true>(a, tile, ut, s) : launch_tile<bf16_t, false>(a, tile, ut, s);
   return launch_tile<float, false>(a, tile, ut, s);
 }

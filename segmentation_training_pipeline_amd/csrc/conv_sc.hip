@@ -63,7 +63,7 @@ template <> struct ScStageBn<bf16_t> {
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      f32x2 v = {__uint_as_float(r[e] << 16), __uint_as_float(r[e] & 0xffff0000u)};
+      f32x2 v = {h16lo_to_f32(r[e]), h16hi_to_f32(r[e])};
       v = __builtin_elementwise_fma(v, sc[e], sh[e]);               // = bn_affine per element (single rounding)
       o[e] = pack_bf16x2(bn_act(v.x, relu), bn_act(v.y, relu));
     }
@@ -74,13 +74,13 @@ template <> struct ScStageBn<bf16_t> {
 __device__ __forceinline__ f32x4 sc_stored(f32x4 v, const float*) { return v; }
 __device__ __forceinline__ f32x4 sc_stored(f32x4 v, const bf16_t*) {
   const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
-  return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+  return f32x4{h16lo_to_f32(a), h16hi_to_f32(a), h16lo_to_f32(b), h16hi_to_f32(b)};
 }
 
 template <typename T> struct ScMma;
 template <> struct ScMma<bf16_t> {
   __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    c = mfma16_16x16x32(a, b, c);
   }
 };
 template <> struct ScMma<float> {
@@ -103,7 +103,7 @@ template <> struct ScRaw4<bf16_t> {
   u32x2 v;
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x2*>(p); }
   __device__ __forceinline__ f32x4 get() const {
-    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+    return f32x4{h16lo_to_f32(v.x), h16hi_to_f32(v.x), h16lo_to_f32(v.y), h16hi_to_f32(v.y)};
   }
 };
 
@@ -589,7 +589,7 @@ static int sc_cu_count() {
 }
 // workgroups of the streaming kernel: CUs x the co-resident workgroups its launch bound leaves room for, at most one per tile
 static int sc_stream_blocks(int dtype, int cin, int cout, int ntiles) {
-  const int per_cu = cout <= 16 ? (dtype == STP_BF16 && cin <= 16 ? SC_WPE_SMALL : 3) : 2;
+  const int per_cu = cout <= 16 ? (dtype == STP_H16 && cin <= 16 ? SC_WPE_SMALL : 3) : 2;
   const int64_t b = (int64_t)sc_cu_count() * per_cu;
   return (int)(b < ntiles ? b : ntiles);
 }
@@ -643,7 +643,7 @@ static int dispatch_sc(const ScArgs& a, int cin, hipStream_t s) {
 // Is this convolution served by the small-channel kernel?  (stp_conv2d consults this before the GEMM path.)
 extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p) {
   if (!p) return 0;
-  const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  const int vec = p->dtype == STP_H16 ? 8 : 4;
   const int cin = p->C0;
   // fp32 holds half as many k per 16-byte vector: cap Cin at 16 there so the A fragments stay in registers
   const bool cin_ok = p->dtype == STP_F32 ? (cin == 4 || cin == 8 || cin == 16) : (cin == 8 || cin == 16 || cin == 32);
@@ -659,7 +659,7 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
   a.up = p->src0_mode == STP_SRC_NEAREST2X; a.accumulate = p->accumulate0; a.relu = p->relu;
   {
-    const uint64_t sb = (uint64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * (p->dtype == STP_BF16 ? 2 : 4);
+    const uint64_t sb = (uint64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * (p->dtype == STP_H16 ? 2 : 4);
     if (sb >= 0x80000000ull) return STP_E_BADARG;   // 32-bit LDS-DMA offsets
     a.src_bytes = (uint32_t)sb;
   }
@@ -679,7 +679,7 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   if (a.sum2 && ((p->Cout & 3) || (a.H & 1) || (a.W & 1) || p->bias || p->relu || (a.stats && !a.bnb.x))) return STP_E_BADARG;
   const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_sc_stats_tiles(p);
   hipStream_t s = (hipStream_t)stream;
-  return p->dtype == STP_BF16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);
+  return p->dtype == STP_H16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);
 }
 
 // =================================================================================================
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs a) {
 
 extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p) {
   if (!p) return 0;
-  return p->dtype == STP_BF16 && p->C0 == 4 && p->C1 == 0 && p->KH == 7 && p->KW == 8 && p->stride == 2 && p->pad == 3 && p->Cout == 64 &&
+  return p->dtype == STP_H16 && p->C0 == 4 && p->C1 == 0 && p->KH == 7 && p->KW == 8 && p->stride == 2 && p->pad == 3 && p->Cout == 64 &&
          p->Cd0 == 64 && p->src0_mode == STP_SRC_DIRECT && p->Hs0 == p->Hv && p->Ws0 == p->Wv && p->Ho == (p->Hv - 1) / 2 + 1 &&
          p->Wo == (p->Wv - 1) / 2 + 1 && !p->bias && !p->residual && !p->relu && !p->accumulate0 && !p->bnb_x && !p->dst_sum2x2 &&
          !p->stats_slots && !p->src_bn_mean;
@@ -967,8 +967,7 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_stream_kernel(const ScWgArg
               const u32x4 fb = u32x4{l2.x, l2.y, h2.x, h2.y};
 #pragma unroll
               for (int i = 0; i < TMo; ++i)
-                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb),
-                                                                       acc[t][i][j], 0, 0, 0);
+                acc[t][i][j] = mfma16_16x16x32(fa[i], fb, acc[t][i][j]);
             }
           }
         }
@@ -1105,8 +1104,7 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
               const u32x4 fb = u32x4{l2.x, l2.y, h2.x, h2.y};
 #pragma unroll
               for (int i = 0; i < TMo; ++i)
-                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb),
-                                                                       acc[t][i][j], 0, 0, 0);
+                acc[t][i][j] = mfma16_16x16x32(fa[i], fb, acc[t][i][j]);
             }
           }
         }
@@ -1158,7 +1156,7 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
 
 extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
   if (!p) return 0;
-  const int vec = p->dtype == STP_BF16 ? 8 : 4;
+  const int vec = p->dtype == STP_H16 ? 8 : 4;
   const bool c0ok = p->C0 == 16 || p->C0 == 32 || (p->C0 == 64 && vec == 8);
   const bool c1ok = p->C1 == 0 || p->C1 == 16 || p->C1 == 32 || (p->C1 == 64 && vec == 8);   // (shape-only: no pointers here)
   return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && c0ok && c1ok &&
@@ -1240,16 +1238,16 @@ extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, 
   if (a.pbn.mean && (!a.pbn.rstd || p->C1 > 0)) return STP_E_BADARG;
   const int blocks = stp_wgrad_sc_slabs(p);
   hipStream_t s = (hipStream_t)stream;
-  const uint64_t szb = p->dtype == STP_BF16 ? 2 : 4, lim = 0x80000000ull;
+  const uint64_t szb = p->dtype == STP_H16 ? 2 : 4, lim = 0x80000000ull;
   const uint64_t dyb = (uint64_t)p->N * p->Hv * p->Wv * p->Cout * szb, b0 = (uint64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * szb;
   const uint64_t b1 = (uint64_t)p->N * p->Hv * p->Wv * p->C1 * szb;
   a.dy_bytes = dyb < lim ? (uint32_t)dyb : 0u;      // (0 = beyond 32-bit LDS-DMA offsets: the register-staged kernel runs)
   a.src_bytes = b0 < lim ? (uint32_t)b0 : 0u;
   a.src = (const char*)p->src0; a.Hs = p->Hs0; a.Ws = p->Ws0; a.up = p->src0_mode == STP_SRC_NEAREST2X; a.coff = 0;
-  int rc = p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C0, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C0, p->Cout, blocks, s);
+  int rc = p->dtype == STP_H16 ? sc_wg_dispatch<bf16_t>(a, p->C0, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C0, p->Cout, blocks, s);
   if (rc != STP_OK || p->C1 == 0) return rc;
   a.pbn.mean = nullptr;
   a.src = (const char*)p->src1; a.Hs = p->Hv; a.Ws = p->Wv; a.up = 0; a.coff = p->C0;
   a.src_bytes = b1 < lim ? (uint32_t)b1 : 0u;
-  return p->dtype == STP_BF16 ? sc_wg_dispatch<bf16_t>(a, p->C1, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C1, p->Cout, blocks, s);
+  return p->dtype == STP_H16 ? sc_wg_dispatch<bf16_t>(a, p->C1, p->Cout, blocks, s) : sc_wg_dispatch<float>(a, p->C1, p->Cout, blocks, s);
 }

@@ -89,8 +89,7 @@ __device__ __forceinline__ void wgrad_compute(const char* sa, int wm, int wn, in
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16_16x16x32(fa[i], fb[j], acc[i][j]);
       }
     } else {
       // fp32: 32 pixels per step = 8 MFMA k-steps of 4 pixels; lane group g owns pixel 4s+g.
@@ -555,7 +554,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) 
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        f32x2 t = {__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u)};
+        f32x2 t = {h16lo_to_f32(v[e]), h16hi_to_f32(v[e])};
         t = __builtin_elementwise_fma(t, psc[e], psh[e]);
         o[e] = pack_bf16x2(bn_act(t.x, a.pbn.relu), bn_act(t.y, a.pbn.relu));
       }
@@ -638,7 +637,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16_16x16x32(fa[i], fb[j], acc[i][j]);
     }
   };
 
@@ -780,7 +779,7 @@ static WgradPlan plan_wgrad(const stp_wgrad_params* p) {
     return w;
   }
   const int K = p->KH * p->KW * (p->C0 + p->C1);
-  const int pk = p->dtype == STP_BF16 ? 64 : 32;
+  const int pk = p->dtype == STP_H16 ? 64 : 32;
   const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
   if (p->Cout <= 16) { w.tile = 4; w.bm = 16; w.bn = 256; }
   else if (p->Cout <= 32) { w.tile = 3; w.bm = 32; w.bn = 256; }
@@ -818,7 +817,7 @@ static WgradPlan plan_wgrad_gemm(const stp_wgrad_params* p);
 #define WG_TILE_ROW128 5
 #define WG_TILE_ROW64 6
 static bool wgrad_row_eligible(const stp_wgrad_params* p) {
-  if (!p || p->dtype != STP_BF16 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || (p->C0 & 63) || (p->C1 & 63) ||
+  if (!p || p->dtype != STP_H16 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || (p->C0 & 63) || (p->C1 & 63) ||
       p->Ho != p->Hv || p->Wo != p->Wv || (p->Cout & 7))
     return false;
   if (p->src_bn_mean && (!p->src_bn_rstd || p->C1 != 0 || p->src0_mode != STP_SRC_DIRECT)) return false;
@@ -962,10 +961,10 @@ static WgradPlan plan_wgrad_gemm(const stp_wgrad_params* p) {
 static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, WgradArgs& a, WgradPlan& w, bool* c4_out,
                       bool* dma_out) {
   if (!p || !p->src0 || !p->dy || !p->dw || !workspace) return STP_E_BADARG;
-  if (p->dtype != STP_F32 && p->dtype != STP_BF16) return STP_E_BADARG;
-  const int vec = p->dtype == STP_BF16 ? 8 : 4;
-  const int sz = p->dtype == STP_BF16 ? 2 : 4;
-  const bool c4 = (p->dtype == STP_BF16) && p->C0 == 4 && p->C1 == 0;
+  if (p->dtype != STP_F32 && p->dtype != STP_H16) return STP_E_BADARG;
+  const int vec = p->dtype == STP_H16 ? 8 : 4;
+  const int sz = p->dtype == STP_H16 ? 2 : 4;
+  const bool c4 = (p->dtype == STP_H16) && p->C0 == 4 && p->C1 == 0;
   if (c4) {
     if ((p->KW & 1) || p->src0_mode != STP_SRC_DIRECT) return STP_E_BADARG;
   } else if ((p->C0 % vec) || (p->C1 % vec)) {
@@ -1041,7 +1040,7 @@ extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspa
     if (w.tile == WG_TILE_ROW128) return launch_wg(conv_wgrad_row_kernel<128, 2, 2, 3>, a, lds, w.splits, attr128, s);
     return launch_wg(conv_wgrad_row_kernel<64, 1, 4, 3>, a, lds, w.splits, attr64, s);
   }
-  if (p->dtype == STP_BF16)
+  if (p->dtype == STP_H16)
     return c4 ? launch_wgrad_tile<bf16_t, true>(a, w, dma, variant, s) : launch_wgrad_tile<bf16_t, false>(a, w, dma, variant, s);
   return launch_wgrad_tile<float, false>(a, w, dma, variant, s);
 }

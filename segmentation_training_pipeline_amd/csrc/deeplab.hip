@@ -136,7 +136,7 @@ extern "C" int stp_dwconv(const void* x, const float* w, void* y, int32_t N, int
   DwArgs a;
   if (!x || !w || !y || !dw_fill(a, N, H, W, C, k, stride, pad_t, pad_l, dilation, Ho, Wo) || (int64_t)N * Ho > 65535) return STP_E_BADARG;
   const dim3 grid(ceil_div(Wo * (C >> 2), 256), N * Ho);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (bf16_t*)y, a);
+  if (dtype == STP_H16) hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (bf16_t*)y, a);
   else if (dtype == STP_F32) hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, w, (float*)y, a);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -149,7 +149,7 @@ extern "C" int stp_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_
   DwArgs a;
   if (!dy || !w || !dx || !dw_fill(a, N, H, W, C, k, stride, pad_t, pad_l, dilation, Ho, Wo) || (int64_t)N * H > 65535) return STP_E_BADARG;
   const dim3 grid(ceil_div(W * (C >> 2), 256), N * H);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(dwconv_dgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, w, (bf16_t*)dx, a, accumulate);
+  if (dtype == STP_H16) hipLaunchKernelGGL(dwconv_dgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, w, (bf16_t*)dx, a, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(dwconv_dgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, a, accumulate);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -167,7 +167,7 @@ extern "C" int stp_dwconv_wgrad(const void* x, const void* dy, float* dw, int32_
   int blocks = N * Ho < DW_MAX_BLOCKS ? N * Ho : DW_MAX_BLOCKS;
   const dim3 grid(blocks, ceil_div(C, 64));
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16) hipLaunchKernelGGL(dwconv_wgrad_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, a);
+  if (dtype == STP_H16) hipLaunchKernelGGL(dwconv_wgrad_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, a);
   else if (dtype == STP_F32) hipLaunchKernelGGL(dwconv_wgrad_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)workspace, a);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -251,7 +251,7 @@ extern "C" int stp_resize_bilinear_ac(const void* x, void* y, int32_t N, int32_t
                                       int32_t dtype, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return STP_E_BADARG;
   const int g = dl_grid((int64_t)N * Ho * Wo * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_ac_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
+  if (dtype == STP_H16) hipLaunchKernelGGL(resize_ac_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_ac_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, Ho, Wo);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -262,7 +262,7 @@ extern "C" int stp_resize_bilinear_ac_bwd(const void* dy, void* dx, int32_t N, i
                                           int32_t dtype, int32_t accumulate, void* stream) {
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return STP_E_BADARG;
   const int g = dl_grid((int64_t)N * H * W * C);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(resize_ac_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
+  if (dtype == STP_H16) hipLaunchKernelGGL(resize_ac_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
   else if (dtype == STP_F32) hipLaunchKernelGGL(resize_ac_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, accumulate);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -319,7 +319,7 @@ extern "C" int stp_dropout_spatial(const void* x, void* y, int32_t N, int64_t HW
   const float scale = 1.f / (1.f - rate);
   const int64_t count = (int64_t)N * HW * C;
   const int g = dl_grid(count);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(dropout_spatial_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, count, HW * C, C, thresh, scale, state, salt);
+  if (dtype == STP_H16) hipLaunchKernelGGL(dropout_spatial_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, count, HW * C, C, thresh, scale, state, salt);
   else if (dtype == STP_F32) hipLaunchKernelGGL(dropout_spatial_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, count, HW * C, C, thresh, scale, state, salt);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -332,7 +332,7 @@ extern "C" int stp_dropout(const void* x, void* y, int64_t count, float rate, co
   const uint32_t thresh = (uint32_t)lrintf(rate * 16777216.f);
   const float scale = 1.f / (1.f - rate);
   const int g = dl_grid(count);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, count, thresh, scale, state, salt);
+  if (dtype == STP_H16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, count, thresh, scale, state, salt);
   else if (dtype == STP_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, count, thresh, scale, state, salt);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void sigmoid_act_bwd_kernel(const T* __restric
 extern "C" int stp_sigmoid_act(const void* z, void* p, int64_t rows, int32_t channels, int32_t ldz, int32_t ldp, int32_t dtype, void* stream) {
   if (!z || !p || rows <= 0 || channels <= 0 || ldz < channels || ldp < channels) return STP_E_BADARG;
   const int g = dl_grid(rows * channels);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(sigmoid_act_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)p, rows, channels, ldz, ldp);
+  if (dtype == STP_H16) hipLaunchKernelGGL(sigmoid_act_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)p, rows, channels, ldz, ldp);
   else if (dtype == STP_F32) hipLaunchKernelGGL(sigmoid_act_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)z, (float*)p, rows, channels, ldz, ldp);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -382,7 +382,7 @@ extern "C" int stp_sigmoid_act_bwd(const void* p, const void* dp, void* dz, int6
                                    int32_t dtype, void* stream) {
   if (!p || !dp || !dz || rows <= 0 || channels <= 0 || ldp < channels || ldg < channels) return STP_E_BADARG;
   const int g = dl_grid(rows * ldg);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(sigmoid_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)dz, rows, channels, ldp, ldg);
+  if (dtype == STP_H16) hipLaunchKernelGGL(sigmoid_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)dz, rows, channels, ldp, ldg);
   else if (dtype == STP_F32) hipLaunchKernelGGL(sigmoid_act_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)p, (const float*)dp, (float*)dz, rows, channels, ldp, ldg);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void softmax_act_bwd_kernel(const T* __restric
 extern "C" int stp_softmax_act(const void* z, void* p, int64_t rows, int32_t classes, int32_t ldz, int32_t ldp, int32_t dtype, void* stream) {
   if (!z || !p || rows <= 0 || classes < 2 || classes > 32 || ldz < classes || ldp < classes) return STP_E_BADARG;
   const int g = dl_grid(rows);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(softmax_act_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)p, rows, classes, ldz, ldp);
+  if (dtype == STP_H16) hipLaunchKernelGGL(softmax_act_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)p, rows, classes, ldz, ldp);
   else if (dtype == STP_F32) hipLaunchKernelGGL(softmax_act_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)z, (float*)p, rows, classes, ldz, ldp);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -432,7 +432,7 @@ extern "C" int stp_softmax_act_bwd(const void* p, const void* dp, void* dz, int6
                                    int32_t dtype, void* stream) {
   if (!p || !dp || !dz || rows <= 0 || classes < 2 || classes > 32 || ldp < classes || ldg < classes) return STP_E_BADARG;
   const int g = dl_grid(rows);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(softmax_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)dz, rows, classes, ldp, ldg);
+  if (dtype == STP_H16) hipLaunchKernelGGL(softmax_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)dz, rows, classes, ldp, ldg);
   else if (dtype == STP_F32) hipLaunchKernelGGL(softmax_act_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)p, (const float*)dp, (float*)dz, rows, classes, ldp, ldg);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -530,7 +530,7 @@ extern "C" int stp_prob_bce_dice(const void* probs, const uint8_t* target, int64
   if (b > PL_MAX_BLOCKS) b = PL_MAX_BLOCKS;
   const int blocks = (int)b;
   float* partial = (float*)workspace;
-  if (dtype == STP_BF16) hipLaunchKernelGGL(prob_loss_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)probs, target, count, partial);
+  if (dtype == STP_H16) hipLaunchKernelGGL(prob_loss_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)probs, target, count, partial);
   else if (dtype == STP_F32) hipLaunchKernelGGL(prob_loss_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)probs, target, count, partial);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -540,7 +540,7 @@ extern "C" int stp_prob_bce_dice(const void* probs, const uint8_t* target, int64
     if (dl_channels < 1) return STP_E_BADARG;
     const int g = dl_grid(count);
     const float inv_count = (float)(1.0 / (double)count);
-    if (dtype == STP_BF16) hipLaunchKernelGGL(prob_loss_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)probs, target, count, scalars, w_bce, w_dice, inv_count, (bf16_t*)dprobs, dl_channels);
+    if (dtype == STP_H16) hipLaunchKernelGGL(prob_loss_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)probs, target, count, scalars, w_bce, w_dice, inv_count, (bf16_t*)dprobs, dl_channels);
     else hipLaunchKernelGGL(prob_loss_grad_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)probs, target, count, scalars, w_bce, w_dice, inv_count, (float*)dprobs, dl_channels);
     STP_LAUNCH_CHECK();
   }
@@ -646,14 +646,14 @@ extern "C" int stp_prob_cce_dice(const void* probs, const uint8_t* target, int64
                                  void* stream) {
   if (!probs || !target || !scalars || !workspace || pixels <= 0 || classes < 2 || classes > 32 || ldc < classes) return STP_E_BADARG;
   if (workspace_bytes < (size_t)PL_MAX_BLOCKS * PL_NSUM * sizeof(float)) return STP_E_WORKSPACE;
-  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   int64_t b = pixels / 512;
   if (b < 1) b = 1;
   if (b > PL_MAX_BLOCKS) b = PL_MAX_BLOCKS;
   const int blocks = (int)b;
   float* partial = (float*)workspace;
-  if (dtype == STP_BF16) hipLaunchKernelGGL(prob_cce_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)probs, target, pixels, classes, ldc, partial);
+  if (dtype == STP_H16) hipLaunchKernelGGL(prob_cce_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)probs, target, pixels, classes, ldc, partial);
   else hipLaunchKernelGGL(prob_cce_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)probs, target, pixels, classes, ldc, partial);
   STP_LAUNCH_CHECK();
   hipLaunchKernelGGL(prob_cce_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)pixels, 1.0 / ((double)pixels * classes), w_cce,
@@ -662,7 +662,7 @@ extern "C" int stp_prob_cce_dice(const void* probs, const uint8_t* target, int64
   if (dprobs) {
     if (dl_channels < classes) return STP_E_BADARG;
     const int g = dl_grid(pixels);
-    if (dtype == STP_BF16) hipLaunchKernelGGL(prob_cce_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)probs, target, pixels, classes, ldc, scalars, w_cce, w_dice, (float)(1.0 / (double)pixels), (bf16_t*)dprobs, dl_channels);
+    if (dtype == STP_H16) hipLaunchKernelGGL(prob_cce_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)probs, target, pixels, classes, ldc, scalars, w_cce, w_dice, (float)(1.0 / (double)pixels), (bf16_t*)dprobs, dl_channels);
     else hipLaunchKernelGGL(prob_cce_grad_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)probs, target, pixels, classes, ldc, scalars, w_cce, w_dice, (float)(1.0 / (double)pixels), (float*)dprobs, dl_channels);
     STP_LAUNCH_CHECK();
   }

@@ -181,7 +181,7 @@ extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, i
   if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
   const int blocks = (int)b;
   float* partial = (float*)workspace;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL(loss_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)logits, target, count, partial);
   else if (dtype == STP_F32)
     hipLaunchKernelGGL(loss_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)logits, target, count, partial);
@@ -195,7 +195,7 @@ extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, i
     const int g = loss_grad_blocks(count);
     float* gsum = partial + LOSS_GSUM_OFFSET;
     const float inv_count = (float)(1.0 / (double)count);
-    if (dtype == STP_BF16)
+    if (dtype == STP_H16)
       hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)logits, target, count, scalars,
                          w_bce, w_dice, inv_count, grad_scale, (bf16_t*)dlogits, dl_channels, gsum);
     else
@@ -336,7 +336,7 @@ extern "C" int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, in
                                    size_t workspace_bytes, void* stream) {
   if (!logits || !target || !scalars || !workspace || !weights5 || count <= 0) return STP_E_BADARG;
   if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
-  if (dtype != STP_BF16 && dtype != STP_F32) return STP_E_BADARG;
+  if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   LossWeights lw;
   for (int i = 0; i < 5; ++i) lw.w[i] = weights5[i];
@@ -345,7 +345,7 @@ extern "C" int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, in
   if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;
   const int blocks = (int)b;
   float* partial = (float*)workspace;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL(loss_ex_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)logits, target, count, partial);
   else
     hipLaunchKernelGGL(loss_ex_partial_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)logits, target, count, partial);
@@ -357,7 +357,7 @@ extern "C" int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, in
     const int g = loss_grad_blocks(count);
     float* gsum = partial + LOSS_GSUM_OFFSET;
     const float inv_count = (float)(1.0 / (double)count);
-    if (dtype == STP_BF16)
+    if (dtype == STP_H16)
       hipLaunchKernelGGL(loss_ex_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)logits, target, count, scalars, lw,
                          inv_count, grad_scale, (bf16_t*)dlogits, dl_channels, gsum);
     else
@@ -387,7 +387,7 @@ __device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, f
         const u32x4 r = *reinterpret_cast<const u32x4*>(z + v * V);
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { p[v * V + 2 * e] = __uint_as_float(r[e] << 16); p[v * V + 2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+          for (int e = 0; e < 4; ++e) { p[v * V + 2 * e] = h16lo_to_f32(r[e]); p[v * V + 2 * e + 1] = h16hi_to_f32(r[e]); }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) p[v * V + e] = __uint_as_float(r[e]);
@@ -571,7 +571,7 @@ extern "C" int stp_softmax_cce_dice(const void* logits, const uint8_t* target, i
   const int blocks = (int)b;
   float* partial = (float*)workspace;
   if (dlogits && dl_channels < classes) return STP_E_BADARG;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     dispatch_softmax_loss<bf16_t>((const bf16_t*)logits, target, pixels, classes, ldc, w_cce, w_dice, scalars, (bf16_t*)dlogits, dl_channels,
                                   grad_scale, partial, blocks, s);
   else if (dtype == STP_F32)
@@ -599,7 +599,7 @@ extern "C" int stp_softmax(const void* logits, float* probs, int64_t pixels, int
   int64_t g = (pixels + 255) / 256;
   if (g > 4096) g = 4096;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16) hipLaunchKernelGGL(softmax_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, probs, pixels, classes, ldc);
+  if (dtype == STP_H16) hipLaunchKernelGGL(softmax_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, probs, pixels, classes, ldc);
   else if (dtype == STP_F32) hipLaunchKernelGGL(softmax_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, probs, pixels, classes, ldc);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -617,7 +617,7 @@ extern "C" int stp_sigmoid(const void* logits, float* probs, int64_t count, int3
   int64_t g = (count + 255) / 256;
   if (g > 4096) g = 4096;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16) hipLaunchKernelGGL(sigmoid_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, probs, count);
+  if (dtype == STP_H16) hipLaunchKernelGGL(sigmoid_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, probs, count);
   else if (dtype == STP_F32) hipLaunchKernelGGL(sigmoid_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, probs, count);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -902,7 +902,7 @@ extern "C" int stp_weight_prepare(const float* master, void* fwd, void* bwd, int
   int64_t g = (total + 255) / 256;
   if (g > 2048) g = 2048;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL(weight_prepare_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, master, (bf16_t*)fwd, (bf16_t*)bwd, Cout, KH,
                        KW, Cin, KWp, Cinp, CoutB, rows_f, rows_b);
   else if (dtype == STP_F32)
@@ -986,7 +986,7 @@ extern "C" int stp_weight_prepare_batched(const void* desc_dev, int32_t nlayers,
   // layers exit at once (64 -> 256: the launch lasts as long as its largest layer, 130 -> see DESIGN)
   hipStream_t s = (hipStream_t)stream;
   static const int per_layer = getenv("STP_PREP_BLOCKS") ? atoi(getenv("STP_PREP_BLOCKS")) : 512;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL(weight_prepare_batched_kernel<bf16_t>, dim3(per_layer, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
   else if (dtype == STP_F32)
     hipLaunchKernelGGL(weight_prepare_batched_kernel<float>, dim3(per_layer, nlayers), dim3(256), 0, s, (const WeightPrepDesc*)desc_dev, nlayers, total);
@@ -1040,7 +1040,7 @@ extern "C" int stp_weight_prepare_upcollapse(const float* master, void* weight_u
   d.master = master; d.out = weight_up; d.Cout = Cout; d.rows = round_up(Cout, 16); d.C0 = C0; d.Ctot = C0 + C1;
   int64_t g = ((int64_t)d.rows * 16 * C0 + 255) / 256;
   if (g > 2048) g = 2048;
-  if (dtype == STP_BF16) hipLaunchKernelGGL(weight_upcollapse_kernel<bf16_t>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, d);
+  if (dtype == STP_H16) hipLaunchKernelGGL(weight_upcollapse_kernel<bf16_t>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, d);
   else if (dtype == STP_F32) hipLaunchKernelGGL(weight_upcollapse_kernel<float>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, d);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1053,7 +1053,7 @@ extern "C" size_t stp_weight_prepare_upcollapse_desc_bytes(void) { return sizeof
 extern "C" int stp_weight_prepare_upcollapse_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream) {
   if (!desc_dev || nlayers <= 0) return STP_E_BADARG;
   const dim3 grid(256, nlayers);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(weight_upcollapse_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
+  if (dtype == STP_H16) hipLaunchKernelGGL(weight_upcollapse_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
   else if (dtype == STP_F32) hipLaunchKernelGGL(weight_upcollapse_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(256) void weight_upcollapse_bwd_batched_kernel(cons
 extern "C" int stp_weight_prepare_upcollapse_bwd_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream) {
   if (!desc_dev || nlayers <= 0) return STP_E_BADARG;
   const dim3 grid(256, nlayers);
-  if (dtype == STP_BF16) hipLaunchKernelGGL(weight_upcollapse_bwd_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
+  if (dtype == STP_H16) hipLaunchKernelGGL(weight_upcollapse_bwd_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
   else if (dtype == STP_F32) hipLaunchKernelGGL(weight_upcollapse_bwd_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
   else return STP_E_BADARG;
   STP_LAUNCH_CHECK();
@@ -1181,3 +1181,4 @@ extern "C" int stp_cast_bf16_to_f32(const void* src, float* dst, int64_t count, 
 }
 
 extern "C" int stp_abi_version(void) { return 1; }
+extern "C" int stp_storage_dtype(void) { return STP_H16; }

@@ -169,7 +169,7 @@ extern "C" int stp_lovasz_hinge(const void* logits, const uint8_t* target, int32
                                 float* scalars, void* dlogits, int32_t dl_channels, void* workspace, size_t workspace_bytes, void* stream) {
   const int64_t count = (int64_t)images * per_image;
   if (!logits || !target || !scalars || !workspace || images <= 0 || per_image <= 0 || count >= ((int64_t)1 << 31) ||
-      per_image >= ((int64_t)1 << 31) || (dtype != STP_BF16 && dtype != STP_F32) || (dlogits && dl_channels < 1))
+      per_image >= ((int64_t)1 << 31) || (dtype != STP_H16 && dtype != STP_F32) || (dlogits && dl_channels < 1))
     return STP_E_BADARG;
   LvLayout L;
   if (lv_layout(count, images, &L) != STP_OK) return STP_E_LAUNCH;
@@ -181,7 +181,7 @@ extern "C" int stp_lovasz_hinge(const void* logits, const uint8_t* target, int32
   float* il = (float*)(ws + L.image_loss);
   int64_t g = (count + 255) / 256;
   if (g > 8192) g = 8192;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL(lovasz_keys_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)logits, target, count, per_image, kin, vin);
   else
     hipLaunchKernelGGL(lovasz_keys_kernel<float>, dim3((int)g), dim3(256), 0, s, (const float*)logits, target, count, per_image, kin, vin);
@@ -191,7 +191,7 @@ extern "C" int stp_lovasz_hinge(const void* logits, const uint8_t* target, int32
                                          lv_end_bit(images), s) != hipSuccess)
     return STP_E_LAUNCH;
   const float gscale = weight / (float)images;
-  if (dtype == STP_BF16)
+  if (dtype == STP_H16)
     hipLaunchKernelGGL(lovasz_scan_kernel<bf16_t>, dim3(images), dim3(LV_T), 0, s, (const bf16_t*)logits, kout, vout, per_image, gscale,
                        (bf16_t*)dlogits, dl_channels, il);
   else

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib, ops
 
-_TD = {"bf16": torch.bfloat16, "fp32": torch.float32}
+_TD = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 
 class StpShapeError(ValueError):
@@ -70,18 +70,20 @@ class ParamInfo(object):
 class Plan(object):
     def __init__(self, batch, dtype="bf16", device="cuda", training=True):
         if dtype not in _TD:
-            raise ValueError("dtype must be 'bf16' or 'fp32'")
+            raise ValueError("dtype must be 'bf16', 'fp16' or 'fp32'")
         self.device = torch.device(device)
         # A plan may be BUILT on CPU tensors (structure/shape checks in the CPU test suite);
         # it can only RUN on the GPU: run() raises otherwise - there is no CPU compute path.
         if self.device.type == "cuda" and not torch.cuda.is_available():
             raise _lib.StpError("the HIP training path needs a GPU; there is no CPU fallback")
-        self.lib = _lib.load()
+        # the 16-bit storage format is a build parameter of the kernel set: fp16 plans run on libstp_hip_f16.so
+        self.lib = _lib.load("fp16" if dtype == "fp16" else "bf16")
+        self.loss_scale = 1.0          # fp16: the loss gradient is seeded times this; the optimizer's gscale divides it out
         self.N = batch
         self.dtype = dtype
         self.tdt = _TD[dtype]
-        self.cdt = ops.BF16 if dtype == "bf16" else ops.F32
-        self.vec = 8 if dtype == "bf16" else 4
+        self.cdt = {"bf16": ops.BF16, "fp16": ops.F16, "fp32": ops.F32}[dtype]
+        self.vec = 4 if dtype == "fp32" else 8
         self.training = training
         self.params = OrderedDict()
         self.states = OrderedDict()
@@ -1059,6 +1061,8 @@ class Plan(object):
         PROBABILITIES; seeds the backward pass."""
         if self.dry:
             return
+        if self.training and self.loss_scale != 1.0:
+            raise StpShapeError("the losses on probabilities (DeepLabV3) have no loss-scaling form: use loss_scale=1 (or bf16)")
         self.loss_scalars = self._alloc((12,), torch.float32)
         dp = self._gradbuf(probs) if self.training else None
         if probs.C == 1:
@@ -1203,15 +1207,17 @@ class Plan(object):
             self._loss_weights = (ctypes.c_float * 5)(w_bce, w_dice, w_iou, w_jaccard, w_focal)     # host array read at launch
             self._emit(self.fwd, "stp_sigmoid_loss_ex", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt,
                        ctypes.addressof(self._loss_weights), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None,
-                       logits.gradC, 1.0, self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+                       logits.gradC, float(self.loss_scale), self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
         else:
             self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),
-                       float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC, 1.0,
-                       self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+                       float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC,
+                       float(self.loss_scale), self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
         # the class convolution reads its bias gradient from the gradient kernel's per-workgroup sums (not when another launch
         # adds to the gradient afterwards)
         logits.meta["loss_bias_grad"] = bool(self.training and not w_lovasz)
         if w_lovasz:      # per-image Lovasz hinge: ADDS to scalars[0] and to the gradient the launch above wrote
+            if self.training and self.loss_scale != 1.0:
+                raise StpShapeError("lovasz_loss has no loss-scaling form: use loss_scale=1 (or bf16) with it")
             nbytes = int(self.lib.stp_lovasz_workspace_bytes(count, self.N))
             if nbytes <= 0:
                 raise StpShapeError("lovasz_loss: the sort workspace cannot be sized (no device)")
@@ -1231,7 +1237,7 @@ class Plan(object):
         dl = self._gradbuf(logits) if self.training else None
         self._emit(self.fwd, "stp_softmax_cce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), logits.rows, logits.C, logits.C,
                    self.cdt, float(w_cce), float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None,
-                   logits.gradC, 1.0, self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+                   logits.gradC, float(self.loss_scale), self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
         logits.grad_ready = self.training
 
     def softmax_out(self, logits):

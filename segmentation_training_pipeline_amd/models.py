@@ -45,13 +45,13 @@ class SegModel(object):
         self._pending_weights = None
 
     def compile(self, optimizer="Adam", loss="binary_crossentropy", lr=1e-3, batch=16, dtype="bf16", clipnorm=None,
-                clipvalue=None, metrics=None, device="cuda", use_graph=True, opt_kwargs=None):
+                clipvalue=None, metrics=None, device="cuda", use_graph=True, opt_kwargs=None, loss_scale=None):
         self.impl = HipSegModel(self.architecture, self.backbone_name, self.input_shape, self.classes, self.activation,
                                 decoder_block_type=getattr(self, "decoder_block_type", "upsampling"),
                                 batch=batch, dtype=dtype, loss=loss, optimizer=optimizer, lr=lr,
                                 freeze_encoder=self.freeze_encoder, decoder_filters=self.decoder_filters, clipnorm=clipnorm,
                                 clipvalue=clipvalue, use_graph=use_graph, device=device, opt_kwargs=opt_kwargs,
-                                net_kwargs=getattr(self, "net_kwargs", None))
+                                net_kwargs=getattr(self, "net_kwargs", None), loss_scale=loss_scale)
         ew = self.encoder_weights
         if ew:
             path = resolve_pretrained(ew, self.backbone_name)

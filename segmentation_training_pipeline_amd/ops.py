@@ -8,9 +8,9 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, U8, SRC_DIRECT, SRC_NEAREST2X, SRC_ZEROINS2X  # noqa: F401
+from ._lib import BF16, F16, F32, U8, SRC_DIRECT, SRC_NEAREST2X, SRC_ZEROINS2X  # noqa: F401
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: U8}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.uint8: U8}
 
 
 def dt(t):

@@ -25,7 +25,7 @@ CUSTOM_KEYS = {
     "architecture", "crops", "augmentation", "transforms", "optimizer", "lr", "clipnorm", "clipvalue", "loss", "batch",
     "metrics", "primary_metric", "primary_metric_mode", "callbacks", "stages", "folds_count", "random_state",
     "extra_train_data", "dataset_augmenter", "classifier", "classifier_lr", "testSplit", "dataset", "datasets", "fit_with",
-    "imports", "import_tasks", "run_tasks", "copyWeights", "dtype", "gpus", "inference_batch", "testTimeAugmentation",
+    "imports", "import_tasks", "run_tasks", "copyWeights", "dtype", "loss_scale", "gpus", "inference_batch", "testTimeAugmentation",
     "compressPredictionsAsInts", "compressScale", "showDataExamples", "bgr", "stratified", "validationSplit", "draw_examples",
 }
 # (meta.alias) renames, schemas/segmentation.raml:50-51,67-68,175-176
@@ -682,7 +682,8 @@ class GenericTaskConfig(object):
         self.freeze_encoder = bool(a.get("freeze_encoder", False))
         self.augmentation = aug_list(a.get("augmentation"))
         self.transforms = aug_list(a.get("transforms"))
-        self.dtype = a.get("dtype", "bf16")
+        self.dtype = a.get("dtype", "bf16")          # "bf16" | "fp16" | "fp32" (a key of this backend)
+        self.loss_scale = a.get("loss_scale")        # fp16 only: static loss scale (default 2^14)
         self.gpus = int(a.get("gpus", 1))
         self.inference_batch = int(a.get("inference_batch", self.batch))
         self.showDataExamples = False
@@ -741,7 +742,8 @@ class GenericTaskConfig(object):
         rank, local_rank, world = distributed.env_world()
         device = "cuda:%d" % distributed.device_index(local_rank)
         model.compile(optimizer=self.optimizer, loss=loss, lr=lr, batch=self.batch, dtype=self.dtype, clipnorm=self.clipnorm,
-                      clipvalue=self.clipvalue, metrics=self.metrics, device=device, use_graph=use_graph)
+                      clipvalue=self.clipvalue, metrics=self.metrics, device=device, use_graph=use_graph,
+                      loss_scale=float(self.loss_scale) if self.loss_scale else None)
         return model
 
     def load_model(self, fold=0, stage=-1):

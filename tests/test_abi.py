@@ -24,6 +24,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libstp_hip.so does not export %s" % n
     assert lib.stp_abi_version() == 1
+    assert lib.stp_storage_dtype() == _lib.BF16
+    # the IEEE-half build of the same sources: same symbols, STP_F16 storage
+    f16 = _lib.load("fp16")
+    for n in names:
+        assert hasattr(f16, n), "libstp_hip_f16.so does not export %s" % n
+    assert f16.stp_storage_dtype() == _lib.F16 == 3 and f16.stp_abi_version() == 1
 
 
 def test_ctypes_signatures_cover_the_header():

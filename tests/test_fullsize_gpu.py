@@ -173,11 +173,11 @@ def test_headline_data_gradient_through_batchnorm(headline, conv_in, bn, conv_ou
     assert rel_l2(g[bn + "/gamma"], gam.grad) < 1e-2
 
 
-def _run_steps(arch, backbone, size, batch, classes, use_graph, steps, seed=3):
+def _run_steps(arch, backbone, size, batch, classes, use_graph, steps, seed=3, dtype="bf16"):
     from segmentation_training_pipeline_amd.backend import HipSegModel
     act = "sigmoid" if classes == 1 else "softmax"
     spec = LOSS if classes == 1 else "categorical_crossentropy+1.0*dice_loss"
-    m = HipSegModel(arch, backbone, (size, size, 3), classes, act, batch=batch, dtype="bf16", loss=spec, optimizer="Adam", lr=1e-3,
+    m = HipSegModel(arch, backbone, (size, size, 3), classes, act, batch=batch, dtype=dtype, loss=spec, optimizer="Adam", lr=1e-3,
                     use_graph=use_graph)
     rng = np.random.RandomState(seed)
     x = rng.randint(0, 256, (batch, size, size, 3)).astype(np.uint8)
@@ -207,6 +207,19 @@ def test_full_size_graph_replay_is_bitwise_and_the_loss_falls(arch, backbone, si
     losses = [h["loss"] for h in e[0]]
     assert all(np.isfinite(v) for v in losses), losses
     assert min(losses[3:]) < losses[0], losses                    # a fixed batch is being fitted
+
+
+def test_configs3_fpn_resnet50_1024_in_fp16():
+    """BASELINE.json configs[3] as named: FPN/ResNet50, 1024x1024, 3 classes, batch 4, fp16 MFMA (IEEE-half storage build,
+    static loss scale 2^14): eager == hipGraph replay bit for bit, every loss finite, the fixed batch is being fitted."""
+    e = _run_steps("FPN", "resnet50", 1024, 4, 3, False, 6, dtype="fp16")
+    g = _run_steps("FPN", "resnet50", 1024, 4, 3, True, 6, dtype="fp16")
+    assert e[0] == g[0]
+    assert torch.equal(torch.from_numpy(e[1]), torch.from_numpy(g[1]))
+    losses = [h["loss"] for h in e[0]]
+    assert all(np.isfinite(v) for v in losses), losses
+    assert np.isfinite(e[1]).all()
+    assert min(losses[3:]) < losses[0], losses
 
 
 HEAVY_AUG = [{"Fliplr": 0.5},

@@ -25,7 +25,17 @@ def ops():
 
 
 DEV = "cuda"
-TD = {"fp32": torch.float32, "bf16": torch.bfloat16}
+TD = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+H16 = ["bf16", "fp16"]      # the two 16-bit storage builds of the kernel set (libstp_hip.so / libstp_hip_f16.so)
+
+
+@pytest.fixture(autouse=True)
+def _storage_build(request):
+    """Tests parametrized with dtype "fp16" call into libstp_hip_f16.so (IEEE-half storage, v_mfma_*_f16)."""
+    from segmentation_training_pipeline_amd import _lib
+    dt = request.node.callspec.params.get("dtype") if hasattr(request.node, "callspec") else None
+    with _lib.storage("fp16" if dt == "fp16" else "bf16"):
+        yield
 
 
 def q(a, dtype):
@@ -63,7 +73,8 @@ def host(t):
 
 def tol(ref, dtype, k=1.0):
     s = float(np.abs(ref).max()) + 1e-6
-    return (2e-4 if dtype == "fp32" else 1.2e-2) * s * k
+    # one output rounding: 2^-8 relative for bf16, 2^-11 for IEEE half (the bound is stated on the tensor's scale)
+    return {"fp32": 2e-4, "bf16": 1.2e-2, "fp16": 2e-3}[dtype] * s * k
 
 
 def prep_weights(ops, w_hwio, dtype, KWp=None, Cinp=None, CoutB=None):
@@ -71,7 +82,7 @@ def prep_weights(ops, w_hwio, dtype, KWp=None, Cinp=None, CoutB=None):
     kh, kw, ci, co = w_hwio.shape
     KWp = KWp or kw
     Cinp = Cinp or ci
-    vec = 8 if dtype == "bf16" else 4
+    vec = 8 if dtype != "fp32" else 4
     CoutB = CoutB or ((co + vec - 1) // vec * vec)
     master = torch.from_numpy(np.ascontiguousarray(w_hwio.transpose(3, 0, 1, 2), dtype=np.float32)).to(DEV)
     rows_f = (co + 15) // 16 * 16
@@ -110,7 +121,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_forward(ops, dtype, case):
     n, h, w, ci, co, k, s, p, tile = case
@@ -134,7 +145,7 @@ def test_conv2d_forward(ops, dtype, case):
     np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_conv2d_epilogue_bias_residual_relu_dualdest_accumulate(ops, dtype):
     rng = np.random.RandomState(3)
     n, h, w, ci, co = 2, 10, 10, 32, 48
@@ -162,7 +173,7 @@ def test_conv2d_epilogue_bias_residual_relu_dualdest_accumulate(ops, dtype):
     np.testing.assert_allclose(host(d1), ref2[..., 16:] + init1, atol=tol(ref2, dtype, 2))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_conv2d_head_single_class_with_bias(ops, dtype):
     rng = np.random.RandomState(4)
     n, h, w, ci, co = 2, 12, 12, 16, 1
@@ -178,7 +189,7 @@ def test_conv2d_head_single_class_with_bias(ops, dtype):
     np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_conv2d_upsample_concat_gather(ops, dtype):
     """decoder conv1: conv3x3(concat(UpSampling2D(2)(x), skip)) without materialising either."""
     rng = np.random.RandomState(5)
@@ -196,7 +207,7 @@ def test_conv2d_upsample_concat_gather(ops, dtype):
     np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64, 32), (1, 16, 32, 128, 64, 64), (2, 8, 16, 64, 128, 128)])
 def test_conv2d_upsample_concat_with_class_collapsed_weights(ops, dtype, shape):
     """stp_conv_params.weight_up: per output parity class the nine taps over the nearest-2x upsampled source read 2 x 2 low-resolution
@@ -240,11 +251,11 @@ def test_conv2d_upsample_concat_with_class_collapsed_weights(ops, dtype, shape):
     np.testing.assert_allclose(plain, ref, atol=tol(ref, dtype))
     np.testing.assert_allclose(coll, ref, atol=tol(ref, dtype))
     np.testing.assert_allclose(coll, plain, atol=(1e-5 if dtype == "fp32" else 0.05) * max(1.0, np.abs(ref).max()))
-    np.testing.assert_allclose(cst, pst, rtol=2e-2, atol=0.5 if dtype == "bf16" else 1e-2)
+    np.testing.assert_allclose(cst, pst, rtol=2e-2, atol=0.5 if dtype != "fp32" else 1e-2)
     assert np.abs(coll - plain).max() > 0 or dtype == "fp32"        # (the collapsed path really ran: bf16 rounds the sums once more)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("geom", [(3, 1, 1, 10, 12), (3, 2, 1, 12, 10), (1, 2, 0, 8, 8), (3, 2, 1, 9, 11)])
 def test_conv2d_data_gradient(ops, dtype, geom):
     """dgrad = stp_conv2d over dY with the flipped/transposed weight copy (zero-insertion for stride 2)."""
@@ -266,12 +277,12 @@ def test_conv2d_data_gradient(ops, dtype, geom):
 
 @pytest.mark.parametrize("geom", [(3, 1, 32, 32, 128, 64), (1, 0, 16, 64, 128, 128), (3, 1, 16, 32, 64, 256), (3, 1, 64, 16, 256, 64)])
 @pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
-def test_stride2_data_gradient_in_parity_class_order(ops, geom, mode):
+@pytest.mark.parametrize("dtype", H16)
+def test_stride2_data_gradient_in_parity_class_order(ops, geom, mode, dtype):
     """Data gradient of a stride-2 convolution through the uniform-tap kernel (bf16, dY channels % 64 == 0, even maps whose quarter
     is a multiple of the pixel tile): pixels are ordered by parity class so that the K loop visits only the taps that meet real
     samples of the zero-inserted dY (ConvArgs::zperm).  Same results as the numpy data gradient; the epilogue (accumulate, fused
     BatchNormalization-backward sums) must address the REAL pixel of every logical one."""
-    dtype = "bf16"
     k, p, h, w, co, ci = geom
     rng = np.random.RandomState(16)
     n = 2
@@ -316,13 +327,14 @@ def test_stride2_data_gradient_in_parity_class_order(ops, geom, mode):
 
 
 @pytest.mark.parametrize("size", [(32, 36), (64, 64), (37, 70)])
-def test_stem_halo_kernel_with_fused_statistics(ops, size):
+@pytest.mark.parametrize("dtype", H16)
+def test_stem_halo_kernel_with_fused_statistics(ops, size, dtype):
     """conv_stem_kernel (bf16, tile id 768): the ResNet conv0 through the halo-tile kernel at even, tile-aligned and ragged / odd
     sizes, against the naive oracle and the generic implicit GEMM (tile 2) on the same buffers; its fused BatchNormalization
     sums through stp_bn_finalize against stp_bn_stats of the stored output."""
     from segmentation_training_pipeline_amd import _lib
     h, w = size
-    n, co, dtype = 2, 64, "bf16"
+    n, co = 2, 64
     rng = np.random.RandomState(9)
     x3 = q(rng.randn(n, h, w, 3), dtype)
     wt = q(rng.randn(7, 7, 3, co) / 12.0, dtype)
@@ -364,13 +376,13 @@ HALO_CASES = [
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_conv_halo_kernel_forward_statistics_residual(ops, case):
+@pytest.mark.parametrize("dtype", H16)
+def test_conv_halo_kernel_forward_statistics_residual(ops, case, dtype):
     """conv_halo_kernel (bf16, tile id 1024 + variant): 3x3 / stride 1 through halo-resident activation slabs against the naive
     oracle and the per-tap DMA kernel on the same buffers; fused BatchNormalization sums against stp_bn_stats of the stored output;
     residual + ReLU epilogue; image borders (zero padding through out-of-range buffer offsets) on every side of every tile."""
     from segmentation_training_pipeline_amd import _lib
     n, h, w, ci, co, var = case
-    dtype = "bf16"
     rng = np.random.RandomState(hash(case) % 2**31)
     x = q(rng.randn(n, h, w, ci), dtype)
     wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
@@ -409,13 +421,13 @@ def test_conv_halo_kernel_forward_statistics_residual(ops, case):
 
 @pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 0, 1), (1, 32, 16, 256, 64, 0, 0), (2, 8, 16, 192, 128, 1, 1), (1, 16, 16, 64, 64, 2, 1),
                                   (2, 8, 32, 512, 64, 3, 2)])
-def test_conv_halo_kernel_fused_producer_batchnorm(ops, case):
+@pytest.mark.parametrize("dtype", H16)
+def test_conv_halo_kernel_fused_producer_batchnorm(ops, case, dtype):
     """stp_conv_params.src_bn_* on the halo kernel: the pre-BatchNormalization tensor is normalised (+ activation) IN LDS, once
     per slab, by the thread that staged it.  Bit-identical to stp_bn_apply followed by the same kernel (same fma, activation and
     bf16 rounding; padding pixels stay zero), incl. the fused statistics of the output."""
     from segmentation_training_pipeline_amd import _lib
     n, h, w, ci, co, var, relu = case
-    dtype = "bf16"
     rng = np.random.RandomState(79)
     rows = n * h * w
     ypre = q(rng.randn(n, h, w, ci) * 2 + 0.5, dtype)
@@ -446,11 +458,11 @@ def test_conv_halo_kernel_fused_producer_batchnorm(ops, case):
 
 @pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 0), (2, 8, 16, 64, 256, 1), (1, 32, 16, 128, 64, 2), (2, 8, 32, 64, 64, 3)])
 @pytest.mark.parametrize("relu", [1, 0, 3])
-def test_conv_halo_kernel_batchnorm_backward_sums(ops, case, relu):
+@pytest.mark.parametrize("dtype", H16)
+def test_conv_halo_kernel_batchnorm_backward_sums(ops, case, relu, dtype):
     """bnb_x epilogue of the halo kernel == the same epilogue of the per-tap DMA kernel (masked gradient bit for bit where the
     two accumulation orders round alike, sums to rounding), incl. accumulate0 as the LAST consumer."""
     n, h, w, ci, co, var = case
-    dtype = "bf16"
     last = relu == 3
     relu = 1 if last else relu
     rng = np.random.RandomState(78)
@@ -489,7 +501,7 @@ def test_conv_halo_kernel_batchnorm_backward_sums(ops, case, relu):
     np.testing.assert_allclose(dx1, dx0, atol=tol(dx0, dtype))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_stem_conv_7x7_s2_padded_channels(ops, dtype):
     """conv0: 7x7/2 over a 3-channel image stored as 4 channels (4th = 1), weights padded to 7x8x4."""
     rng = np.random.RandomState(7)
@@ -545,7 +557,7 @@ WGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", WGRAD_CASES)
 def test_conv2d_weight_gradient(ops, dtype, case):
     n, h, w, ci, co, k, s, p, splits = case
@@ -572,7 +584,7 @@ def test_conv2d_weight_gradient(ops, dtype, case):
         ops.conv2d_wgrad_reduce(W, ws, variant)
         np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype), err_msg="variant %d" % variant)
     # variant 4 = row-of-taps kernel: runs on its shapes (bf16), refuses the others
-    row_ok = (dtype == "bf16" and k == 3 and s == 1 and p == 1 and ci % 64 == 0 and co % 8 == 0 and
+    row_ok = (dtype != "fp32" and k == 3 and s == 1 and p == 1 and ci % 64 == 0 and co % 8 == 0 and
               (w % 64 == 0 or (w >= 16 and 64 % w == 0 and (h * w) % 64 == 0)))
     dw.fill_(float("nan"))
     if row_ok:
@@ -585,7 +597,7 @@ def test_conv2d_weight_gradient(ops, dtype, case):
             ops.conv2d_wgrad_partial(W, ws, 4)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("chans", [(32, 16, 64), (64, 64, 32), (32, 16, 16), (128, 64, 64, 8, 8), (64, 64, 128, 4, 32), (128, 128, 136, 8, 16),
                                    (64, 192, 72, 16, 64)])
 def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
@@ -609,7 +621,7 @@ def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
     np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
     # the 64-channel-block shapes on power-of-two maps take the row-of-taps kernel in bf16 (two sources, the first upsampled)
     wo, howo = 2 * w, 4 * h * w
-    row = dtype == "bf16" and c0 % 64 == 0 and c1 % 64 == 0 and (wo % 64 == 0 or (wo >= 16 and 64 % wo == 0 and howo % 64 == 0))
+    row = dtype != "fp32" and c0 % 64 == 0 and c1 % 64 == 0 and (wo % 64 == 0 or (wo >= 16 and 64 % wo == 0 and howo % 64 == 0))
     lib = ops._lib.load()
     assert lib.stp_conv2d_wgrad_kernel_id(ops.C.byref(W)) == (1 if lib.stp_wgrad_sc_eligible(ops.C.byref(W)) else (3 if co <= 64 else 2) if row else 0)
     if row:
@@ -618,7 +630,7 @@ def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
         np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("C", [16, 64, 768])
 def test_batchnorm_train_forward_backward(ops, dtype, C):
     rng = np.random.RandomState(10)
@@ -657,7 +669,7 @@ def test_batchnorm_train_forward_backward(ops, dtype, C):
     np.testing.assert_allclose(host(dx)[safe], dxr[safe], atol=tol(dxr, dtype, 2))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0), (2, 9, 11, 128, 64, 5), (2, 19, 45, 16, 16, 512), (2, 19, 45, 16, 32, 512),
                                   (1, 24, 20, 16, 64, 258), (2, 13, 9, 64, 24, 0), (1, 20, 24, 128, 16, 68)])
 @pytest.mark.parametrize("relu", [1, 0, 3])
@@ -713,7 +725,7 @@ def test_batchnorm_backward_sums_fused_in_conv_epilogue(ops, dtype, case, relu):
     np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0), (2, 19, 45, 16, 16, 512), (2, 13, 9, 64, 24, 0), (3, 32, 32, 64, 512, 0)])
 def test_batchnorm_sums_in_fixed_point_slots(ops, dtype, case):
     """stp_conv_params.stats_slots: the epilogue adds its tile sums atomically into int64 fixed-point slots (order-independent,
@@ -782,7 +794,7 @@ def test_batchnorm_sums_in_fixed_point_slots(ops, dtype, case):
     np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 19, 45, 16, 16, 0, 1), (2, 20, 34, 16, 8, 1, 1), (1, 12, 40, 8, 16, 0, 0), (2, 16, 32, 32, 16, 1, 2)])
 def test_producer_batchnorm_fused_into_small_channel_staging(ops, dtype, case):
     """stp_conv_params.src_bn_* / stp_wgrad_params.src_bn_*: the small-channel forward and weight-gradient kernels normalise the
@@ -843,13 +855,13 @@ def test_producer_batchnorm_fused_into_small_channel_staging(ops, dtype, case):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 1), (1, 8, 64, 64, 72, 0), (2, 32, 16, 192, 64, 2), (1, 4, 128, 64, 136, 1)])
-def test_producer_batchnorm_fused_into_row_of_taps_weight_gradient(ops, case):
+@pytest.mark.parametrize("dtype", H16)
+def test_producer_batchnorm_fused_into_row_of_taps_weight_gradient(ops, case, dtype):
     """stp_wgrad_params.src_bn_* on the row-of-taps kernel (variant 4 / automatic): the halo tile of every pixel step is normalised
     in LDS by the thread that fetched it.  Bit-identical to stp_bn_apply followed by the same kernel on the normalised tensor
     (same fma, activation, rounding; padding stays zero); the pixel-reduction GEMM variants refuse the fields."""
     from segmentation_training_pipeline_amd import _lib
     n, h, w, ci, co, relu = case
-    dtype = "bf16"
     rng = np.random.RandomState(78)
     rows = n * h * w
     ypre = q(rng.randn(n, h, w, ci) * 2 + 0.5, dtype)
@@ -882,7 +894,7 @@ def test_producer_batchnorm_fused_into_row_of_taps_weight_gradient(ops, case):
     assert wgrad(yd, True, 2)[0] == -1                                      # the GEMM variants have no fused producer BN
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
 def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
     """stp_conv_params.dst_sum2x2: the data-gradient convolution of an UpSampling2D(2) input writes the 2x2 block sums
@@ -908,7 +920,7 @@ def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
     if mode != "bn_backward":
         ops.conv2d(P)
         # bf16: the unfused path rounds the hi-res gradient to bf16 before summing, the fused one sums in fp32
-        np.testing.assert_allclose(host(got), host(want), atol=tol(host(want), dtype, 1.0 if dtype == "bf16" else 0.05))
+        np.testing.assert_allclose(host(got), host(want), atol=tol(host(want), dtype, 1.0 if dtype != "fp32" else 0.05))
         return
     rows = n * (h // 2) * (w // 2)
     x = dev(q(rng.randn(n, h // 2, w // 2, co) + 0.2, dtype), dtype)
@@ -926,15 +938,15 @@ def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
     tiles = ops.conv2d_stats_floats(P) // (2 * co)
     dx1, dg1, db1 = torch.empty_like(want), torch.empty(co, device=DEV), torch.empty(co, device=DEV)
     ops.bn_backward_fused(x, got, dx1, rows, co, m, r, g, st, tiles, dg1, db1, accumulate_dx=0, workspace=ws)
-    k = 1.0 if dtype == "bf16" else 0.05
-    np.testing.assert_allclose(host(db1), host(db0), atol=(2e-2 if dtype == "bf16" else 1e-3) * np.abs(host(db0)).max() + 1e-3)
-    np.testing.assert_allclose(host(dg1), host(dg0), atol=(2e-2 if dtype == "bf16" else 1e-3) * np.abs(host(dg0)).max() + 1e-3)
+    k = 1.0 if dtype != "fp32" else 0.05
+    np.testing.assert_allclose(host(db1), host(db0), atol=(2e-2 if dtype != "fp32" else 1e-3) * np.abs(host(db0)).max() + 1e-3)
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=(2e-2 if dtype != "fp32" else 1e-3) * np.abs(host(dg0)).max() + 1e-3)
     pre = host(x) * (host(r) * host(g)) + (host(b) - host(m) * host(r) * host(g))
     safe = np.abs(pre) > 1e-3
     np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, k))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("C,Cy", [(5, 8), (4, 8), (7, 8), (1, 4)])
 def test_input_batchnorm_uint8_to_padded_channels(ops, dtype, C, Cy):
     """uint8 images of C channels -> BatchNormalization -> dtype tensor padded to 4 / 8 channels, padding = the constant 1."""
@@ -958,7 +970,7 @@ def test_input_batchnorm_uint8_to_padded_channels(ops, dtype, C, Cy):
     np.testing.assert_allclose(host(y).reshape(rows, Cy), want, atol=tol(want, dtype))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_input_batchnorm_uint8_to_padded4(ops, dtype):
     rng = np.random.RandomState(11)
     n, h, w = 2, 16, 18
@@ -977,7 +989,7 @@ def test_input_batchnorm_uint8_to_padded4(ops, dtype):
     np.testing.assert_array_equal(out[..., 3], 1.0)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_maxpool_and_upsample_gradients(ops, dtype):
     rng = np.random.RandomState(12)
     n, h, w, c = 2, 14, 12, 32
@@ -1007,7 +1019,7 @@ def test_maxpool_and_upsample_gradients(ops, dtype):
     np.testing.assert_allclose(host(dxu), np_ops.upsample2x_bwd(g), atol=tol(g, dtype, 4))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("factor", [1, 2, 4, 8])
 def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor):
     """stp_resize_bilinear(_bwd): TF 1.x resize_bilinear(align_corners=False) by an integer factor, written into a channel
@@ -1052,7 +1064,7 @@ def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor)
     np.testing.assert_allclose(host(xd2), xa + np_ops.upsample2x(ma), atol=tol(xa, dtype, 1.0))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 14, 12, 64, 1), (1, 9, 21, 64, 0), (2, 8, 8, 32, 1)])
 def test_maxpool_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
     """stp_maxpool3x3s2_bwd_bn (bn0 of the stem: its gradient = the pool gradient on top of a decoder skip's): must equal
@@ -1098,7 +1110,7 @@ def test_maxpool_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
     np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 6, 10, 64, 0), (2, 5, 7, 512, 1), (1, 8, 16, 128, 1), (2, 4, 4, 32, 0), (1, 3, 5, 256, 1)])
 def test_upsample_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
     """stp_upsample2x_bwd_bn: the 2x2 fold that completes the gradient of a BatchNormalization(+ReLU) output (optionally on top of
@@ -1141,7 +1153,7 @@ def test_upsample_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
     np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("geom", [(1, 1, 24, 320), (2, 2, 12, 72), (3, 3, 8, 40), (6, 6, 4, 24), (5, 7, 8, 20), (3, 2, 6, 3), (12, 12, 8, 24), (16, 16, 4, 8),
                                   (5, 7, 2, 8), (9, 3, 3, 16)])
 def test_pyramid_pooling_geometry_resize_and_pool(ops, dtype, geom):
@@ -1195,7 +1207,7 @@ def test_pyramid_pooling_geometry_resize_and_pool(ops, dtype, geom):
         np.testing.assert_allclose(host(dxp), want, atol=tol(want, dtype, 1.0))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("geom", [(3, 1, 1, 1, 1), (3, 2, 0, 0, 1), (3, 1, 2, 2, 2), (3, 1, 4, 4, 4), (3, 2, 1, 1, 1)])
 def test_depthwise_convolution_forward_and_gradients(ops, dtype, geom):
     """stp_dwconv / _dgrad / _wgrad (DeepLab model.py:136, 255-259): stride, dilation and explicit top/left padding (TF 'same'
@@ -1230,7 +1242,7 @@ def test_depthwise_convolution_forward_and_gradients(ops, dtype, geom):
     np.testing.assert_allclose(host(dw), refw, atol=(2e-4 if dtype == "fp32" else 2e-3) * np.abs(refw).max() + 1e-5)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("sizes", [((5, 7), (40, 56)), ((1, 1), (6, 9)), ((6, 6), (6, 6)), ((4, 3), (9, 5))])
 def test_align_corners_bilinear_dropout_sigmoid_and_probability_loss(ops, dtype, sizes):
     """The remaining DeepLab ops: resize_bilinear(align_corners=True) fwd/bwd vs torch, inverted dropout (mask reproducible,
@@ -1262,7 +1274,7 @@ def test_align_corners_bilinear_dropout_sigmoid_and_probability_loss(ops, dtype,
     a1 = host(o1)
     np.testing.assert_array_equal(a1, host(o2))                                # same step, same salt: same mask
     kept = a1 != 0
-    np.testing.assert_allclose(a1[kept], (gy / 0.75)[kept], rtol=1e-2 if dtype == "bf16" else 1e-6)
+    np.testing.assert_allclose(a1[kept], (gy / 0.75)[kept], rtol=1e-2 if dtype != "fp32" else 1e-6)
     _lib.call("stp_counter_tick", ops.ptr(state), ops.stream())
     _lib.call("stp_dropout", ops.ptr(yd), ops.ptr(o2), cnt, 0.25, ops.ptr(state), 7, ops.dt(yd), ops.stream())
     assert int(state[0].item()) == 1 and (cnt < 200 or not np.array_equal(host(o2) != 0, kept))
@@ -1301,11 +1313,11 @@ def test_align_corners_bilinear_dropout_sigmoid_and_probability_loss(ops, dtype,
     g = host(dl)
     refg = pt.grad.numpy()
     inr = (pp >= 1e-7) & (pp <= 1 - 1e-7) & (pp != 0.5)       # bf16 rounds some samples onto the kink as well
-    np.testing.assert_allclose(g[inr, 0], refg[inr], rtol=2e-2 if dtype == "bf16" else 2e-4, atol=1e-6)
+    np.testing.assert_allclose(g[inr, 0], refg[inr], rtol=2e-2 if dtype != "fp32" else 2e-4, atol=1e-6)
     np.testing.assert_array_equal(g[:, 1:], 0)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     rng = np.random.RandomState(13)
     count = 2 * 48 * 48
@@ -1318,7 +1330,7 @@ def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     loss = olosses.composite_loss("binary_crossentropy+0.5*dice_loss", yt, p)
     loss.backward()
     scal = torch.empty(10, device=DEV)
-    C = 8 if dtype == "bf16" else 4
+    C = 8 if dtype != "fp32" else 4
     dl = torch.full((count, C), float("nan"), dtype=TD[dtype], device=DEV)
     ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
     ops.sigmoid_bce_dice(dev(z, dtype), keep(torch.from_numpy(y).to(DEV)), count, 1.0, 0.5, scal, dl, C, 1.0, ws)
@@ -1335,7 +1347,7 @@ def test_sigmoid_bce_dice_loss_and_gradient(ops, dtype):
     np.testing.assert_array_equal(g[:, 1:], 0)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("spec,w5", [
     ("iou_loss", (0, 0, 1, 0, 0)), ("jaccard_loss", (0, 0, 0, 1, 0)), ("focal_loss", (0, 0, 0, 0, 1)),
     ("binary_crossentropy+0.5*dice_loss+0.25*iou_loss+0.01*jaccard_loss+2.0*focal_loss", (1, 0.5, 0.25, 0.01, 2.0))])
@@ -1354,7 +1366,7 @@ def test_sigmoid_registry_losses_and_gradient(ops, dtype, spec, w5):
     loss = olosses.composite_loss(spec, yt[:, None], p[:, None])
     loss.backward()
     scal = torch.empty(12, device=DEV)
-    C = 8 if dtype == "bf16" else 4
+    C = 8 if dtype != "fp32" else 4
     dl = torch.full((count, C), float("nan"), dtype=TD[dtype], device=DEV)
     ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
     ops.sigmoid_loss_ex(dev(z, dtype), keep(torch.from_numpy(y).to(DEV)), count, w5, scal, dl, C, 1.0, ws)
@@ -1373,7 +1385,7 @@ def test_sigmoid_registry_losses_and_gradient(ops, dtype, spec, w5):
     np.testing.assert_array_equal(g[:, 1:], 0)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("h,w", [(48, 50), (32, 32)])
 def test_lovasz_hinge_loss_and_gradient(ops, dtype, h, w):
     """stp_lovasz_hinge (lovasz_loss of the registry, reference segmentation.py:18) against the oracle's per-image Lovasz hinge:
@@ -1395,7 +1407,7 @@ def test_lovasz_hinge_loss_and_gradient(ops, dtype, h, w):
     loss.backward()
     lov = float(olosses.lovasz_loss(yt.reshape(n, h, w, 1), p.detach().reshape(n, h, w, 1)))
     scal = torch.zeros(16, device=DEV)
-    C = 8 if dtype == "bf16" else 4
+    C = 8 if dtype != "fp32" else 4
     dl = torch.full((count, C), float("nan"), dtype=TD[dtype], device=DEV)
     ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
     zd, yd = dev(z, dtype), keep(torch.from_numpy(y).to(DEV))
@@ -1420,7 +1432,7 @@ def test_lovasz_hinge_loss_and_gradient(ops, dtype, h, w):
                                         None) != 0
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("classes,ldc", [(3, 3), (5, 8), (21, 24)])
 def test_softmax_categorical_crossentropy_dice_loss_and_gradient(ops, dtype, classes, ldc):
     """stp_softmax_cce_dice / stp_softmax against the oracle's Keras categorical_crossentropy (+ musket dice over all class
@@ -1779,14 +1791,14 @@ def test_background_replacer_bit_exact(ops, tmp_path):
     np.testing.assert_array_equal(om.cpu().numpy(), rmsk[0])
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_batched_weight_prepare_equals_per_layer(ops, dtype):
     """The once-per-step batched launch (LDS tile transpose) must write exactly what stp_weight_prepare writes
     layer by layer: forward copies with channel/tap padding, flipped + transposed data-gradient copies."""
     import ctypes as C
     from segmentation_training_pipeline_amd import _lib
     lib = _lib.load()
-    vec = 8 if dtype == "bf16" else 4
+    vec = 8 if dtype != "fp32" else 4
     rng = np.random.RandomState(3)
     # Cout, KH, KW, Cin(master), KWp, Cinp, want_bwd
     layers = [(64, 7, 7, 3, 8, 4, False), (64, 3, 3, 64, 3, 64, True), (40, 3, 3, 24, 3, 24, True), (1, 3, 3, 16, 3, 16, True),
