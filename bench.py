@@ -40,7 +40,9 @@ def wgrad_tile(cout):
 
 
 def kernel_key(name, meta, dtype):
-    t = "unsigned short" if dtype == "bf16" else "float"
+    t = "float" if dtype == "fp32" else "unsigned short"
+    if dtype == "fp16":
+        dtype = "bf16"          # same kernel set, same template arguments: the storage format is a build parameter
     if name == "stp_conv2d":
         tile = meta["tile"]
         if tile == 512:
@@ -187,7 +189,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16 = the headline mode; fp16 = the IEEE-half build of the same kernels (libstp_hip_f16.so, loss scale 2^14); fp32 = the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet", "FPN"],
