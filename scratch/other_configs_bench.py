@@ -7,6 +7,8 @@ import bench
 # (.., dtype): configs[3] is named "fp16 MFMA" - the IEEE-half build (libstp_hip_f16.so); the bf16 line of the same workload beside it
 CASES = [("FPN", "resnet50", 1024, 4, 3, "fp16"), ("FPN", "resnet50", 1024, 4, 3, "bf16"), ("PSPNet", "resnet101", 768, 8, 20, "bf16"),
          ("Linknet", "resnet34", 512, 16, 1, "bf16"), ("Unet", "resnet34", 512, 16, 1, "bf16"), ("Unet", "resnet34", 512, 16, 1, "fp16")]
+if len(sys.argv) > 1:      # optional filter: "FPN:bf16 PSPNet:bf16"
+    CASES = [c for c in CASES if "%s:%s" % (c[0], c[5]) in sys.argv[1:]]
 for arch, bb, size, batch, classes, dtype in CASES:
     act = "sigmoid" if classes == 1 else "softmax"
     spec = "binary_crossentropy+1.0*dice_loss" if classes == 1 else "categorical_crossentropy+1.0*dice_loss"

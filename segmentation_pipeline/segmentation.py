@@ -98,16 +98,21 @@ class PipelineConfig(generic.GenericTaskConfig):
         if self.crops is not None and "input_shape" in cleaned:
             s = cleaned["input_shape"]
             cleaned["input_shape"] = (s[0] // self.crops, s[1] // self.crops, s[2])
+        nchannel = None
         if "input_shape" in cleaned and cleaned["input_shape"][2] > 3:
-            # reference :135-153: with encoder_weights an N-channel model is built from the 3-channel pretrained one (adaptNet
-            # copies the first convolution's kernels into the wider one); without them the N-channel model is simply built.
-            # Here: 4..7 channels train from random initialisation; the pretrained-weight adaptation is not available.
-            if cleaned.get("encoder_weights"):
-                raise ValueError("encoder_weights with more than 3 input channels (N-channel weight adaptation) is not available in "
-                                 "the HIP backend: set encoder_weights: null")
             if cleaned["input_shape"][2] > 7:
                 raise ValueError("the HIP backend takes images of up to 7 channels")
-        return clazz(**cleaned)
+            # reference :135-153: with encoder_weights an N-channel model is built from the 3-channel pretrained one (adaptNet
+            # copies the first convolution's kernels into the wider one, `copyWeights` seeds channel 3 from channel 2) and cached
+            # as `<experiment>.mdl-nchannel`; without them the N-channel model is simply built.  The adaptation runs when the
+            # model is compiled (models.adapt_nchannel), where the pretrained file is read.
+            ew = cleaned.get("encoder_weights")
+            if ew is not None and len(str(ew)) > 0:
+                nchannel = {"cache": str(self.path) + ".mdl-nchannel", "copy": bool(self.all.get("copyWeights", False))}
+        model = clazz(**cleaned)
+        if nchannel is not None:
+            model.nchannel_adapt = nchannel
+        return model
 
     def load_model(self, fold=0, stage=-1):
         if stage < 0:

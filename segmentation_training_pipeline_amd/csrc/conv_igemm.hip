@@ -34,7 +34,10 @@
 // UNI = true : Ctot % KE == 0 and C0 % KE == 0 -> one tap and one source per K-tile (scalar decomposition)
 // UNI = false: KE % Ctot == 0 and C1 == 0 (16/32-channel layers): a K-tile spans KE/Ctot taps, the tap is a
 //              per-lane constant offset from a scalar base, still no per-load division
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool UNI>
+// UPC = true : the instance the class-collapsed upsample + concat layers run on (ConvArgs::upc).  A compile-time parameter: as a run-
+//              time branch its registers and address arithmetic cost every OTHER user of the kernel - measured +9 % on the FPN/ResNet50
+//              and +11 % on the PSPNet/ResNet101 step (bottleneck 1x1 convolutions), for -0.5 % on the U-Net.
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool UNI, bool UPC = false>
 __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   static_assert(WM * WN == 4 && BM % 16 == 0 && BN % 32 == 0 && STAGES >= 2, "config");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   // zperm: this tile's parity class fixes the taps that meet real samples of the zero-inserted source (all scalar)
   const bool zp = UNI && a.zperm;
   // upc: parity-class pixel order too; the class fixes which 2 x 2 low-resolution pixels the taps over the upsampled src0 read
-  const bool up = UNI && a.upc;
+  const bool up = UNI && UPC && a.upc;
   const __amdgpu_buffer_rsrc_t rswu = __builtin_amdgcn_make_buffer_rsrc((void*)(up ? a.weight_up : a.weight), 0, up ? a.byteswu : 0u, 0x00020000);
   const int upy = up ? ((int)fdiv((uint32_t)pix0, a.divPc) >> 1) : 0, upx = up ? ((int)fdiv((uint32_t)pix0, a.divPc) & 1) : 0;
   int zkh0 = 0, zkw0 = 0, znkw = 1, znk = 0;
@@ -439,6 +442,12 @@ static int launch_ut(ConvArgs& a, hipStream_t s) {
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = ceil_div(a.P, BN);
   a.divNtm = make_fastdiv((uint32_t)a.ntile_m);
+  if constexpr (UNI && (STAGES == 2 || (STAGES == 4 && BM == 64 && BN == 64))) {      // (the tiles auto_tile() picks: stp_conv2d sets upc for these only)
+    static bool attr_set_upc = false;
+    if (a.upc)
+      return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI, true>, a, (size_t)STAGES * (BM + BN) * 128 + 4096, attr_set_upc, s);
+  }
+  if (a.upc) return STP_E_BADARG;
   return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI>, a, (size_t)STAGES * (BM + BN) * 128 + 4096, attr_set, s);
 }
 
@@ -624,7 +633,7 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
     // forward convolution over UpSampling2D(2) + concat with class-collapsed weights (see ConvArgs::upc)
     static const bool upc_on = !(getenv("STP_UPCOLLAPSE") && atoi(getenv("STP_UPCOLLAPSE")) == 0);
     const int ke = p->dtype == STP_H16 ? 64 : 32;
-    const bool uni_tile = tile >= 64 && tile < 256;
+    const bool uni_tile = (tile >= 64 && tile < 96) || tile == 128 + 5;       // the uniform-tap tiles auto_tile() picks: the UPC instances of the kernel
     if (upc_on && p->weight_up && a.mode == STP_SRC_NEAREST2X && ut == 1 && uni_tile && a.stride == 1 && a.KH == 3 && a.KW == 3 && a.pad == 1 &&
         !(a.Ho & 1) && !(a.Wo & 1) && a.Ho == a.Hv && a.Wo == a.Wv && a.Hs0 * 2 == a.Hv && a.Ws0 * 2 == a.Wv && a.C1 > 0 && (a.C1 % ke) == 0 &&
         ((a.P / 4) % tile_pixels(tile)) == 0) {

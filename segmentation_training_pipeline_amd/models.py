@@ -9,6 +9,8 @@ functions below carry the segmentation_models 0.2.1 keyword names and the defaul
 ``load_weights`` / ``save_weights`` / ``train_on_batch``) and is backed by the HIP plan.
 """
 import os
+
+import numpy as np
 import warnings
 
 from . import nets
@@ -27,6 +29,39 @@ def resolve_pretrained(name, backbone):
         return str(name)
     p = pretrained_path(name, backbone)
     return p if os.path.exists(p) else None
+
+
+def adapt_nchannel(pretrained, current, copy=False):
+    """N-channel adaptation of a 3-channel pretrained checkpoint (reference segmentation.py:138-153 builds the 3-channel model
+    with its weights and the N-channel one without, then calls musket_core's ``adaptNet(model, model1, self.copyWeights)``).
+    musket_core is not vendored in the reference tree, so the rule is restated from its published behaviour (unpinned): every
+    tensor of equal shape is copied; a tensor that differs only in the INPUT-CHANNEL axis - the first convolution's kernel
+    (kh, kw, 3, f) -> (kh, kw, C, f) and the per-channel vectors of the input BatchNormalization (3,) -> (C,) - keeps the
+    pretrained values in channels 0..2, the N-channel model's own fresh values elsewhere (zero kernels, beta 0, mean 0,
+    variance 1), and with ``copyWeights: true`` channel 3 starts as a copy of pretrained channel 2.
+    ``pretrained`` / ``current``: dict name -> numpy in Keras layouts; returns the dict to load (names ``current`` has)."""
+    out = {}
+    for name, a in pretrained.items():
+        if name not in current:
+            continue
+        a, cur = np.asarray(a, np.float32), np.asarray(current[name], np.float32)
+        if a.shape == cur.shape:
+            out[name] = a
+        elif a.ndim == 4 and cur.ndim == 4 and a.shape[:2] == cur.shape[:2] and a.shape[3] == cur.shape[3] and a.shape[2] == 3 < cur.shape[2]:
+            v = np.zeros_like(cur)
+            v[:, :, :3, :] = a
+            if copy:
+                v[:, :, 3, :] = a[:, :, 2, :]
+            out[name] = v
+        elif a.ndim == 1 and cur.ndim == 1 and a.shape[0] == 3 < cur.shape[0]:
+            v = cur.copy()
+            v[:3] = a
+            if copy:
+                v[3] = a[2]
+            out[name] = v
+        else:
+            raise ValueError("%s: pretrained shape %s cannot be adapted to %s" % (name, a.shape, cur.shape))
+    return out
 
 
 class SegModel(object):
@@ -55,7 +90,15 @@ class SegModel(object):
         ew = self.encoder_weights
         if ew:
             path = resolve_pretrained(ew, self.backbone_name)
-            if path is not None:
+            nch = getattr(self, "nchannel_adapt", None)        # set by createNet1 for C > 3 with encoder_weights (reference :138-153)
+            if nch is not None and os.path.exists(nch["cache"]):
+                self.impl.load_weights(nch["cache"])              # `<experiment>.mdl-nchannel` written by an earlier createNet
+            elif path is not None and nch is not None:
+                from safetensors.numpy import load_file
+                cur = self.impl.get_weights()
+                self.impl.set_weights(adapt_nchannel(load_file(path), cur, copy=nch["copy"]))
+                self.impl.save_weights(nch["cache"])
+            elif path is not None:
                 self.impl.load_weights(path, strict=False)
             elif os.environ.get("STP_ALLOW_RANDOM_ENCODER") == "1" or getattr(self, "allow_random_encoder_init", False):
                 warnings.warn("encoder_weights=%r: no pretrained file found; the encoder starts from he_uniform "

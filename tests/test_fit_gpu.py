@@ -301,9 +301,35 @@ def test_four_channel_images_fit_and_predict(tmp_path):
     assert np.abs(logits() - l0).max() > 1e-3                                        # the fourth band reaches the network
     # (16 optimizer steps: the moving statistics the inference plan normalises with have barely moved, so the maps themselves
     #  are not asserted; tests/test_model_gpu.py::test_n_channel_inputs_match_the_oracle pins the arithmetic)
+    # with encoder_weights: the 3-channel pretrained checkpoint is adapted (reference :138-153, adaptNet + copyWeights) and the
+    # adapted model is cached as <experiment>.mdl-nchannel
+    from segmentation_training_pipeline_amd import models
+    three = models.Unet("resnet18", input_shape=(64, 64, 3), classes=1, activation="sigmoid", encoder_weights=None)
+    three.compile(batch=2, dtype="fp32", loss="binary_crossentropy")
+    w3 = {k: v + np.float32(0.25) for k, v in three.impl.get_weights().items() if not k.startswith(("decoder", "final"))}
+    three.impl.set_weights(w3)
+    pre = str(tmp_path / "resnet18_pretrained.weights")
+    three.impl.save_weights(pre)
+    w3 = three.impl.get_weights()
     with open(cfg_path, "w") as f:
-        yaml.safe_dump(dict(base, encoder_weights="imagenet"), f)
-    with pytest.raises(ValueError, match="N-channel"):
+        yaml.safe_dump(dict(base, encoder_weights=pre, copyWeights=True, dtype="fp32"), f)
+    cfg4 = segmentation.parse(cfg_path)
+    m4 = cfg4.createNet()
+    m4.compile(batch=2, dtype="fp32", loss="binary_crossentropy")
+    w4 = m4.impl.get_weights()
+    k = w4["conv0/kernel"]
+    assert k.shape == (7, 7, 4, 64)
+    assert np.array_equal(k[:, :, :3, :], w3["conv0/kernel"]) and np.array_equal(k[:, :, 3, :], w3["conv0/kernel"][:, :, 2, :])
+    assert np.array_equal(w4["bn_data/beta"][:3], w3["bn_data/beta"]) and w4["bn_data/beta"][3] == w3["bn_data/beta"][2]
+    assert np.array_equal(w4["stage2_unit1_conv1/kernel"], w3["stage2_unit1_conv1/kernel"])
+    assert os.path.exists(cfg_path + ".mdl-nchannel")
+    m4b = segmentation.parse(cfg_path).createNet()                 # second createNet: served from the cache file
+    os.remove(pre)
+    m4b.compile(batch=2, dtype="fp32", loss="binary_crossentropy")
+    assert np.array_equal(m4b.impl.get_weights()["conv0/kernel"], k)
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(dict(base, shape=[64, 64, 9]), f)
+    with pytest.raises(ValueError, match="7 channels"):
         segmentation.parse(cfg_path).createNet()
 
 
