@@ -34,8 +34,11 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 __device__ __forceinline__ float h16lo_to_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
 __device__ __forceinline__ float h16hi_to_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+// Stores SATURATE at +-65504 (one v_med3_f32 per element): a value that overflows the format becomes its largest finite value, not
+// an inf that the next BatchNormalization turns into NaN for the whole map - e.g. the inference-phase pass of a barely trained
+// network, whose moving statistics do not normalise yet.  (NaN inputs stay NaN.)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  const f32x2 v = {lo, hi};
+  const f32x2 v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
 template <typename V> __device__ __forceinline__ f32x4 mfma16_16x16x32(V a, V b, f32x4 c) {

@@ -122,6 +122,33 @@ def test_configs0_unet_vgg16_plumbing(tmp_path):
     assert np.asarray(Image.open(os.path.join(dst, "s00.png"))).shape == (128, 128)
 
 
+def test_fp16_yaml_fits_and_predicts(tmp_path):
+    """``dtype: fp16`` (+ ``loss_scale``) in the experiment YAML: the whole fit() / predict surface on the IEEE-half build of the
+    kernel set (libstp_hip_f16.so) - training plan, validation plan, inference plan, checkpoint round trip."""
+    from segmentation_pipeline import segmentation
+    from segmentation_pipeline.impl.datasets import SimplePNGMaskDataSet
+    from segmentation_training_pipeline_amd import _lib
+    img_dir, msk_dir = make_dataset(str(tmp_path))
+    cfg_path = str(tmp_path / "fp16.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Unet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid", "encoder_weights": None,
+                        "shape": [128, 128, 3], "optimizer": "Adam", "lr": 0.002, "batch": 4, "folds_count": 2, "dtype": "fp16",
+                        "loss_scale": 4096, "clipnorm": 1.0,
+                        "loss": "binary_crossentropy+1.0*dice_loss", "metrics": ["binary_accuracy", "dice"],
+                        "primary_metric": "val_dice", "augmentation": {"Fliplr": 0.5}, "stages": [{"epochs": 5}]}, f)
+    cfg = segmentation.parse(cfg_path)
+    cfg.fit(SimplePNGMaskDataSet(img_dir, msk_dir), foldsToExecute=[0])
+    with open(os.path.join(str(tmp_path), "metrics", "metrics-0.0.csv")) as f:
+        rows = list(csv.DictReader(f))
+    assert len(rows) == 5 and all(np.isfinite(float(r["loss"])) and np.isfinite(float(r["val_loss"])) for r in rows), rows
+    assert float(rows[-1]["loss"]) < float(rows[0]["loss"])
+    model = cfg.load_model(0, 0)
+    assert model.impl.dtype == "fp16" and model.impl.plan.lib.stp_storage_dtype() == _lib.F16
+    dst = str(tmp_path / "pred")
+    cfg.predict_to_directory(img_dir, dst, fold=0, stage=0, batchSize=2)
+    assert len(os.listdir(dst)) == len(os.listdir(img_dir))
+
+
 def test_linknet_yaml_fits(tmp_path):
     """`architecture: Linknet` resolves to the HIP Linknet (same encoder, 1x1/3x3/1x1 decoder blocks + Add)."""
     from segmentation_pipeline import segmentation
