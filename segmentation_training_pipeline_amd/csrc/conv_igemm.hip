@@ -37,8 +37,10 @@
 // UPC = true : the instance the class-collapsed upsample + concat layers run on (ConvArgs::upc).  A compile-time parameter: as a run-
 //              time branch its registers and address arithmetic cost every OTHER user of the kernel - measured +9 % on the FPN/ResNet50
 //              and +11 % on the PSPNet/ResNet101 step (bottleneck 1x1 convolutions), for -0.5 % on the U-Net.
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool UNI, bool UPC = false>
+// ZP = true  : the instance the parity-class (zperm) launches run on - stride-2 data gradients and the UPC layers; same reasoning.
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool UNI, bool UPC = false, bool ZP = false>
 __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
+  static_assert(!UPC || ZP, "the class-collapsed layers use the parity-class pixel order");
   static_assert(WM * WN == 4 && BM % 16 == 0 && BN % 32 == 0 && STAGES >= 2, "config");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins exist in the device pass only; the host pass needs just the stub
   constexpr int SZ = (int)sizeof(T);
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.bytes1 : 0u, 0x00020000);
 
   // zperm: this tile's parity class fixes the taps that meet real samples of the zero-inserted source (all scalar)
-  const bool zp = UNI && a.zperm;
+  const bool zp = UNI && ZP && a.zperm;
   // upc: parity-class pixel order too; the class fixes which 2 x 2 low-resolution pixels the taps over the upsampled src0 read
   const bool up = UNI && UPC && a.upc;
   const __amdgpu_buffer_rsrc_t rswu = __builtin_amdgcn_make_buffer_rsrc((void*)(up ? a.weight_up : a.weight), 0, up ? a.byteswu : 0u, 0x00020000);
@@ -442,13 +444,18 @@ static int launch_ut(ConvArgs& a, hipStream_t s) {
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = ceil_div(a.P, BN);
   a.divNtm = make_fastdiv((uint32_t)a.ntile_m);
+  constexpr size_t LDS = (size_t)STAGES * (BM + BN) * 128 + 4096;
   if constexpr (UNI && (STAGES == 2 || (STAGES == 4 && BM == 64 && BN == 64))) {      // (the tiles auto_tile() picks: stp_conv2d sets upc for these only)
     static bool attr_set_upc = false;
-    if (a.upc)
-      return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI, true>, a, (size_t)STAGES * (BM + BN) * 128 + 4096, attr_set_upc, s);
+    if (a.upc) return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI, true, true>, a, LDS, attr_set_upc, s);
   }
   if (a.upc) return STP_E_BADARG;
-  return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI>, a, (size_t)STAGES * (BM + BN) * 128 + 4096, attr_set, s);
+  if constexpr (UNI) {
+    static bool attr_set_zp = false;
+    if (a.zperm) return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI, false, true>, a, LDS, attr_set_zp, s);
+  }
+  if (a.zperm) return STP_E_BADARG;
+  return launch_kernel(conv_igemm_ut_kernel<T, BM, BN, WM, WN, STAGES, UNI>, a, LDS, attr_set, s);
 }
 
 // Tile ids (output channels x pixels per workgroup):
