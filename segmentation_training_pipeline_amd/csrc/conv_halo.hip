@@ -241,8 +241,11 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
   }
 }
 
-template <int TH, int BM, int WM, int WN, int EP>
-__global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
+// PBN: the fused producer BatchNormalization (below) is a compile-time parameter of the body - as a run-time branch its 14-34 registers
+// tax every launch that does not use it (halo 8x64: 117 -> 102 VGPRs = one more wave per SIMD); the two __global__ entry points keep
+// the plain kernel's name (profiles, bench.py keys) and give the fused variant its own.
+template <int TH, int BM, int WM, int WN, int EP, bool PBN>
+__device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   static_assert(WM * WN == 8 && BM % (WM * 32) == 0 && TH % (WN * 2) == 0, "config");
 #if defined(__HIP_DEVICE_COMPILE__)
 #if defined(STP_TIMING)   // scratch build: `bias` carries a u64[4 * workgroups] buffer of shader-clock stamps (scratch/halo_timing.py)
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
   // y = act(fma(x, scale, shift)) is computed IN LDS on the slab, once per slab (9 K-steps), by the thread that DMA'd the 16 bytes
   // (own data: only its own vmcnt orders the read-modify-write, the K-step barrier publishes it).  Same fma / activation / bf16
   // rounding as stp_bn_apply -> bit-identical operands; pixels outside the image stay 0 (the padding applies to y, not x).
-  const bool fuse_bn = a.pbn.mean != nullptr;
+  const bool fuse_bn = PBN && a.pbn.mean != nullptr;
   float* const tab = reinterpret_cast<float*>(smem + off_w + NWST * WSTAGE);      // scale[C0], shift[C0]
   auto transform_slab = [&](int s_) {
     char* sb = smem + (s_ & 1) * SLAB;
@@ -484,6 +487,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a_in) {
 #endif
 }
 
+template <int TH, int BM, int WM, int WN, int EP>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false>(a); }
+template <int TH, int BM, int WM, int WN, int EP>
+__global__ __launch_bounds__(512) void conv_halo_pbn_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, true>(a); }
+
 // ================================================================================================ host side
 struct HaloCfg { int th, bm; };
 // variant ids (stp_conv_params.tile = STP_TILE_HALO + id)
@@ -500,11 +508,14 @@ static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   if (lds < lds_ep) lds = lds_ep;
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
-  auto kern = conv_halo_kernel<TH, BM, WM, WN, EP>;
-  if (!attr_set) {
+  static bool attr_set_pbn = false;
+  const bool pbn = a.pbn.mean != nullptr;
+  auto kern = pbn ? conv_halo_pbn_kernel<TH, BM, WM, WN, EP> : conv_halo_kernel<TH, BM, WM, WN, EP>;
+  bool& done = pbn ? attr_set_pbn : attr_set;
+  if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return STP_E_LAUNCH;
-    attr_set = true;
+    done = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.ntile_m * a.ntile_n), dim3(512), lds, s, a);
   STP_LAUNCH_CHECK();

@@ -464,8 +464,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
 //   tile: BM output channels x 192 columns of kernel row kh, input-channel block cib   (tile_n = kh * (C0 / 64) + cib)
 //   dW column of (kw, ci): (kh * 3 + kw) * Ctot + cib * 64 + ci.  Two concatenated sources (each a multiple of 64 channels, the first optionally
 //   nearest-2x upsampled: the decoder's UpSampling2D + Concatenate) are handled per 64-channel block: a block lies in one source.
-template <int BM, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) {
+// PBN (fused producer BatchNormalization of src0) is a compile-time parameter of the body: 20 VGPRs the plain launches do not carry.
+template <int BM, int WM, int WN, int STAGES, bool PBN>
+__device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a) {
   static_assert(WM * WN == 4, "4 waves");
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef bf16_t T;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) 
   // fused PRODUCER BatchNormalization (+activation): the thread that DMA'd a 16-byte vector of the halo tile normalises it in LDS
   // once it has landed (own data: its vmcnt orders the read-modify-write, the step's barrier publishes it) - same fma, activation
   // and bf16 rounding as stp_bn_apply, so the operand equals the tensor that launch would have stored; padding stays zero
-  const bool pbn = a.pbn.mean != nullptr;
+  const bool pbn = PBN && a.pbn.mean != nullptr;
   f32x2 psc[4], psh[4];
   if (pbn) {
     const int c0 = cb_src * 64 + (int)(colB >> 1);
@@ -677,6 +678,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) 
     for (int j = 0; j < TN; ++j) out[(i * TN + j) * 64] = acc[i][j];
 #endif
 }
+
+template <int BM, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) { conv_wgrad_row_body<BM, WM, WN, STAGES, false>(a); }
+template <int BM, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_row_pbn_kernel(const WgradArgs a) { conv_wgrad_row_body<BM, WM, WN, STAGES, true>(a); }
 
 // Reduction of the row-of-taps kernel's fragment-major slabs: element e = ((tile * 4 + wave) * TM*TN + i*TN + j) * 64 + lane.
 // SL lanes walk the splits of an element in parallel (fixed assignment, fixed-shape LDS tree: deterministic), then the 4 floats
@@ -1034,8 +1040,14 @@ extern "C" int stp_conv2d_wgrad_partial(const stp_wgrad_params* p, void* workspa
     const size_t lds = (size_t)(stages == 2 ? 2 : 3) * (64 * w.bm * 2 + 72 * 128);    // 25 / 17 KB per stage
     static bool attr128 = false, attr64 = false, attr_dummy = true;
     if (stages == 2) {
+      if (a.pbn.mean) return STP_E_BADARG;       // (the 2-stage what-if build has no fused producer BatchNormalization)
       if (w.tile == WG_TILE_ROW128) return launch_wg(conv_wgrad_row_kernel<128, 2, 2, 2>, a, lds, w.splits, attr_dummy, s);
       return launch_wg(conv_wgrad_row_kernel<64, 1, 4, 2>, a, lds, w.splits, attr_dummy, s);
+    }
+    if (a.pbn.mean) {      // fused producer BatchNormalization: its own instances
+      static bool attr128p = false, attr64p = false;
+      if (w.tile == WG_TILE_ROW128) return launch_wg(conv_wgrad_row_pbn_kernel<128, 2, 2, 3>, a, lds, w.splits, attr128p, s);
+      return launch_wg(conv_wgrad_row_pbn_kernel<64, 1, 4, 3>, a, lds, w.splits, attr64p, s);
     }
     if (w.tile == WG_TILE_ROW128) return launch_wg(conv_wgrad_row_kernel<128, 2, 2, 3>, a, lds, w.splits, attr128, s);
     return launch_wg(conv_wgrad_row_kernel<64, 1, 4, 3>, a, lds, w.splits, attr64, s);
