@@ -517,6 +517,7 @@ extern "C" int stp_bn_apply(const void* x, int32_t xdtype, void* y, int32_t ydty
 extern "C" int stp_bn_apply_slots(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C, const int64_t* slots, int32_t nslots,
                                   float eps, float momentum, float* mean, float* rstd, float* moving_mean, float* moving_var,
                                   const float* gamma, const float* beta, int32_t relu, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || !slots || !mean || !rstd || rows <= 0 || C <= 0 || (C & 3) || nslots < 1 || (nslots & (nslots - 1))) return STP_E_BADARG;
   const size_t lds = 2 * (size_t)C * sizeof(float);
   const int g = grid_for(rows * (C >> 2));
@@ -798,6 +799,7 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
                                const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma,
                                float* dbeta, int32_t relu, int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
                                void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !dy || !dx || !mean || !rstd || !workspace || rows <= 0 || C <= 0 || (C & 3)) return STP_E_BADARG;
   if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -861,6 +863,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_tiles_kernel(const float*
 extern "C" int stp_bn_backward_slots(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C, const float* mean,
                                      const float* rstd, const float* gamma, const int64_t* slots, int32_t nslots, float* dgamma,
                                      float* dbeta, int32_t accumulate_dx, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !g || !dx || !mean || !rstd || !slots || rows <= 0 || C <= 0 || (C & 3) || nslots < 1 || (nslots & (nslots - 1))) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const bool v8 = dtype == STP_H16 && (C & 7) == 0;
@@ -887,6 +890,7 @@ extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int
                                      const float* mean, const float* rstd, const float* gamma, const float* partial,
                                      int32_t tiles, float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !g || !dx || !mean || !rstd || !partial || !workspace || rows <= 0 || C <= 0 || (C & 3) || tiles <= 0) return STP_E_BADARG;
   if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -1080,6 +1084,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
 
 extern "C" int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C,
                                 int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || (C & 3) || N <= 0) return STP_E_BADARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   if ((int64_t)N * Ho > 65535) return STP_E_BADARG;  // gridDim.y
@@ -1128,11 +1133,13 @@ static int maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int3
 
 extern "C" int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                     int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   return maxpool_bwd_launch(idx, dy, dx, N, H, W, C, dtype, accumulate, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // Same tile count rule as stp_upsample2x_bwd_bn_tiles (H, W = the pool INPUT size): workgroups of the launch, 0 = unsupported C.
 extern "C" int stp_maxpool3x3s2_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   const int V = (dtype == STP_H16 && (C & 7) == 0) ? 8 : 4;
   if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;
   return ceil_div(W * (C / V), 256) * ceil_div(N * H, BNB_ROWS);
@@ -1141,6 +1148,7 @@ extern "C" int stp_maxpool3x3s2_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, in
 extern "C" int stp_maxpool3x3s2_bwd_bn(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                        int32_t dtype, int32_t accumulate, const void* bn_x, const float* mean, const float* rstd,
                                        const float* gamma, const float* beta, int32_t relu, float* partial, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!bn_x || !mean || !rstd || !partial) return STP_E_BADARG;
   BnBack b;
   b.x = (const char*)bn_x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.relu = relu;
@@ -1209,6 +1217,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const uint8_t* __rest
 
 extern "C" int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
                               void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * (H >> 1) > 65535) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const bool v8 = dtype == STP_H16 && (C & 7) == 0;
@@ -1223,6 +1232,7 @@ extern "C" int stp_maxpool2x2(const void* x, void* y, uint8_t* idx, int32_t N, i
 
 extern "C" int stp_maxpool2x2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                   int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!idx || !dy || !dx || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * H > 65535) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const bool v8 = dtype == STP_H16 && (C & 7) == 0;
@@ -1248,6 +1258,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ y, 
 }
 
 extern "C" int stp_relu_bwd(const void* y, void* dy, int64_t count, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!y || !dy || count <= 0 || (count & 3)) return STP_E_BADARG;
   const int g = grid_for(count >> 2);
   if (dtype == STP_H16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)dy, count >> 2);
@@ -1327,11 +1338,13 @@ static int upsample2x_bwd_launch(const void* dy, void* dx, int32_t N, int32_t H,
 
 extern "C" int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy,
                                   int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   return upsample2x_bwd_launch(dy, dx, N, H, W, C, ldy, dtype, accumulate, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // number of workgroups (= partial-sum tiles per channel) of stp_upsample2x_bwd_bn
 extern "C" int stp_upsample2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   const bool v8 = dtype == STP_H16 && (C & 7) == 0 && (ldy & 7) == 0;
   const int V = v8 ? 8 : 4;
   if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;          // 0: not supported for this channel count
@@ -1341,6 +1354,7 @@ extern "C" int stp_upsample2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int3
 extern "C" int stp_upsample2x_bwd_bn(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,
                                      int32_t accumulate, const void* bn_x, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, int32_t relu, float* partial, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!bn_x || !mean || !rstd || !partial) return STP_E_BADARG;
   BnBack b;
   b.x = (const char*)bn_x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.relu = relu;
@@ -1493,6 +1507,7 @@ extern "C" size_t stp_avgpool_workspace_bytes(int32_t N, int32_t H, int32_t W, i
 
 extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* workspace,
                            size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
   if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, 0, 0);
@@ -1529,6 +1544,7 @@ extern "C" int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t
 
 extern "C" int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
                                int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!dy || !dx || N <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
   if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, 0, 0);
@@ -1568,6 +1584,7 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(T* __restrict__ x, 
 }
 
 extern "C" int stp_upsample2x_add(void* x, const void* m, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !m || (C & 3) || N <= 0 || (H & 1) || (W & 1) || (int64_t)N * H > 65535) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const bool v8 = dtype == STP_H16 && (C & 7) == 0;
@@ -1739,6 +1756,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_blk_kernel(const T* _
 
 extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
                                    int32_t coff, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
   if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, ldo, coff);
@@ -1775,6 +1793,7 @@ extern "C" size_t stp_resize_bilinear_bwd_workspace_bytes(int32_t N, int32_t H, 
 extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor,
                                        int32_t ldo, int32_t coff, int32_t dtype, int32_t accumulate, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
   if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, ldo, coff);
@@ -1857,6 +1876,7 @@ __global__ __launch_bounds__(256) void maxpool_k_bwd_kernel(const int32_t* __res
 }
 extern "C" int stp_maxpool_k(const void* x, void* y, int32_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
                              void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * (H / k) * (W / k) * C);
   if (dtype == STP_H16) hipLaunchKernelGGL(maxpool_k_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, k);
@@ -1867,6 +1887,7 @@ extern "C" int stp_maxpool_k(const void* x, void* y, int32_t* idx, int32_t N, in
 }
 extern "C" int stp_maxpool_k_bwd(const int32_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
                                  int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!idx || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || H % k || W % k) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * H * W * C);
   if (dtype == STP_H16) hipLaunchKernelGGL(maxpool_k_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, k, accumulate);
@@ -1910,6 +1931,7 @@ __global__ __launch_bounds__(256) void resize_nearest_bwd_kernel(const T* __rest
 }
 extern "C" int stp_resize_nearest(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo, int32_t coff,
                                   int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * H * factor * W * factor * C);
   if (dtype == STP_H16) hipLaunchKernelGGL(resize_nearest_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, factor, ldo, coff);
@@ -1920,6 +1942,7 @@ extern "C" int stp_resize_nearest(const void* x, void* y, int32_t N, int32_t H, 
 }
 extern "C" int stp_resize_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
                                       int32_t coff, int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
   const int g = grid_for((int64_t)N * H * W * C);
   if (dtype == STP_H16) hipLaunchKernelGGL(resize_nearest_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, factor, ldo, coff, accumulate);
@@ -1941,6 +1964,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* parti
 
 extern "C" int stp_channel_sum(const void* x, int32_t dtype, int64_t rows, int32_t C, float* out, int32_t accumulate,
                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !out || !workspace || rows <= 0 || C <= 0 || (C & 3)) return STP_E_BADARG;
   if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -1967,6 +1991,7 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, c
 }
 
 extern "C" int stp_add_inplace(void* dst, const void* src, int64_t count, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!dst || !src || count <= 0 || (count & 3)) return STP_E_BADARG;
   const int g = grid_for(count >> 2);
   hipStream_t s = (hipStream_t)stream;

@@ -18,6 +18,8 @@
 #define STP_STORAGE_F16 0
 #endif
 #define STP_H16 (STP_STORAGE_F16 ? STP_F16 : STP_BF16)
+// every entry point with a `dtype` argument starts with this: fp32 or THIS build's 16-bit format
+static inline bool stp_dtype_ok(int dtype) { return dtype == STP_F32 || dtype == STP_H16; }
 
 typedef uint16_t bf16_t;  // raw 16-bit storage word (bf16 or IEEE half, see above)
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -642,7 +642,7 @@ static int dispatch_sc(const ScArgs& a, int cin, hipStream_t s) {
 
 // Is this convolution served by the small-channel kernel?  (stp_conv2d consults this before the GEMM path.)
 extern "C" int stp_conv2d_sc_eligible(const stp_conv_params* p) {
-  if (!p) return 0;
+  if (!p || !stp_dtype_ok(p->dtype)) return 0;
   const int vec = p->dtype == STP_H16 ? 8 : 4;
   const int cin = p->C0;
   // fp32 holds half as many k per 16-byte vector: cap Cin at 16 there so the A fragments stay in registers
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
 #define SC_WG_MAX_BLOCKS 1024
 
 extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
-  if (!p) return 0;
+  if (!p || !stp_dtype_ok(p->dtype)) return 0;
   const int vec = p->dtype == STP_H16 ? 8 : 4;
   const bool c0ok = p->C0 == 16 || p->C0 == 32 || (p->C0 == 64 && vec == 8);
   const bool c1ok = p->C1 == 0 || p->C1 == 16 || p->C1 == 32 || (p->C1 == 64 && vec == 8);   // (shape-only: no pointers here)

@@ -133,6 +133,7 @@ static bool dw_fill(DwArgs& a, int N, int H, int W, int C, int k, int stride, in
 
 extern "C" int stp_dwconv(const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
                           int32_t pad_t, int32_t pad_l, int32_t dilation, int32_t Ho, int32_t Wo, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   DwArgs a;
   if (!x || !w || !y || !dw_fill(a, N, H, W, C, k, stride, pad_t, pad_l, dilation, Ho, Wo) || (int64_t)N * Ho > 65535) return STP_E_BADARG;
   const dim3 grid(ceil_div(Wo * (C >> 2), 256), N * Ho);
@@ -146,6 +147,7 @@ extern "C" int stp_dwconv(const void* x, const float* w, void* y, int32_t N, int
 extern "C" int stp_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
                                 int32_t stride, int32_t pad_t, int32_t pad_l, int32_t dilation, int32_t Ho, int32_t Wo, int32_t dtype,
                                 int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   DwArgs a;
   if (!dy || !w || !dx || !dw_fill(a, N, H, W, C, k, stride, pad_t, pad_l, dilation, Ho, Wo) || (int64_t)N * H > 65535) return STP_E_BADARG;
   const dim3 grid(ceil_div(W * (C >> 2), 256), N * H);
@@ -161,6 +163,7 @@ extern "C" size_t stp_dwconv_wgrad_workspace_bytes(int32_t C, int32_t k) { retur
 extern "C" int stp_dwconv_wgrad(const void* x, const void* dy, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k,
                                 int32_t stride, int32_t pad_t, int32_t pad_l, int32_t dilation, int32_t Ho, int32_t Wo, int32_t dtype,
                                 int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   DwArgs a;
   if (!x || !dy || !dw || !workspace || !dw_fill(a, N, H, W, C, k, stride, pad_t, pad_l, dilation, Ho, Wo)) return STP_E_BADARG;
   if (workspace_bytes < stp_dwconv_wgrad_workspace_bytes(C, k)) return STP_E_WORKSPACE;
@@ -249,6 +252,7 @@ static int dl_grid(int64_t items) {
 
 extern "C" int stp_resize_bilinear_ac(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                                       int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return STP_E_BADARG;
   const int g = dl_grid((int64_t)N * Ho * Wo * C);
   if (dtype == STP_H16) hipLaunchKernelGGL(resize_ac_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
@@ -260,6 +264,7 @@ extern "C" int stp_resize_bilinear_ac(const void* x, void* y, int32_t N, int32_t
 
 extern "C" int stp_resize_bilinear_ac_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                                           int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return STP_E_BADARG;
   const int g = dl_grid((int64_t)N * H * W * C);
   if (dtype == STP_H16) hipLaunchKernelGGL(resize_ac_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate);
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(256) void dropout_spatial_kernel(const T* __restric
 
 extern "C" int stp_dropout_spatial(const void* x, void* y, int32_t N, int64_t HW, int32_t C, float rate, const int32_t* state, uint32_t salt,
                                    int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || !state || N <= 0 || HW <= 0 || C <= 0 || rate < 0.f || rate >= 1.f) return STP_E_BADARG;
   const uint32_t thresh = (uint32_t)lrintf(rate * 16777216.f);
   const float scale = 1.f / (1.f - rate);
@@ -328,6 +334,7 @@ extern "C" int stp_dropout_spatial(const void* x, void* y, int32_t N, int64_t HW
 
 // forward and backward are the same map (y = mask * x / (1 - rate)); x == y (in place) is allowed
 extern "C" int stp_dropout(const void* x, void* y, int64_t count, float rate, const int32_t* state, uint32_t salt, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!x || !y || !state || count <= 0 || rate < 0.f || rate >= 1.f) return STP_E_BADARG;
   const uint32_t thresh = (uint32_t)lrintf(rate * 16777216.f);
   const float scale = 1.f / (1.f - rate);
@@ -368,6 +375,7 @@ __global__ __launch_bounds__(256) void sigmoid_act_bwd_kernel(const T* __restric
 }
 
 extern "C" int stp_sigmoid_act(const void* z, void* p, int64_t rows, int32_t channels, int32_t ldz, int32_t ldp, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!z || !p || rows <= 0 || channels <= 0 || ldz < channels || ldp < channels) return STP_E_BADARG;
   const int g = dl_grid(rows * channels);
   if (dtype == STP_H16) hipLaunchKernelGGL(sigmoid_act_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)p, rows, channels, ldz, ldp);
@@ -380,6 +388,7 @@ extern "C" int stp_sigmoid_act(const void* z, void* p, int64_t rows, int32_t cha
 // dp and dz are [rows][ldg] (padded gradient channels; columns >= channels of dz are written as 0); dp == dz allowed
 extern "C" int stp_sigmoid_act_bwd(const void* p, const void* dp, void* dz, int64_t rows, int32_t channels, int32_t ldp, int32_t ldg,
                                    int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!p || !dp || !dz || rows <= 0 || channels <= 0 || ldp < channels || ldg < channels) return STP_E_BADARG;
   const int g = dl_grid(rows * ldg);
   if (dtype == STP_H16) hipLaunchKernelGGL(sigmoid_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)dz, rows, channels, ldp, ldg);
@@ -418,6 +427,7 @@ __global__ __launch_bounds__(256) void softmax_act_bwd_kernel(const T* __restric
 }
 
 extern "C" int stp_softmax_act(const void* z, void* p, int64_t rows, int32_t classes, int32_t ldz, int32_t ldp, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!z || !p || rows <= 0 || classes < 2 || classes > 32 || ldz < classes || ldp < classes) return STP_E_BADARG;
   const int g = dl_grid(rows);
   if (dtype == STP_H16) hipLaunchKernelGGL(softmax_act_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)p, rows, classes, ldz, ldp);
@@ -430,6 +440,7 @@ extern "C" int stp_softmax_act(const void* z, void* p, int64_t rows, int32_t cla
 // dp and dz are [rows][ldg] (columns >= classes of dz are written as 0); dp == dz allowed (a row is read before it is written)
 extern "C" int stp_softmax_act_bwd(const void* p, const void* dp, void* dz, int64_t rows, int32_t classes, int32_t ldp, int32_t ldg,
                                    int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!p || !dp || !dz || rows <= 0 || classes < 2 || classes > 32 || ldp < classes || ldg < classes) return STP_E_BADARG;
   const int g = dl_grid(rows);
   if (dtype == STP_H16) hipLaunchKernelGGL(softmax_act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)dz, rows, classes, ldp, ldg);
@@ -522,6 +533,7 @@ __global__ __launch_bounds__(256) void prob_loss_grad_kernel(const T* __restrict
 
 extern "C" int stp_prob_bce_dice(const void* probs, const uint8_t* target, int64_t count, int32_t dtype, float w_bce, float w_dice,
                                  float* scalars, void* dprobs, int32_t dl_channels, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!probs || !target || !scalars || !workspace || count <= 0) return STP_E_BADARG;
   if (workspace_bytes < (size_t)PL_MAX_BLOCKS * PL_NSUM * sizeof(float)) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -644,6 +656,7 @@ __global__ __launch_bounds__(256) void prob_cce_grad_kernel(const T* __restrict_
 extern "C" int stp_prob_cce_dice(const void* probs, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc, int32_t dtype, float w_cce,
                                  float w_dice, float* scalars, void* dprobs, int32_t dl_channels, void* workspace, size_t workspace_bytes,
                                  void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!probs || !target || !scalars || !workspace || pixels <= 0 || classes < 2 || classes > 32 || ldc < classes) return STP_E_BADARG;
   if (workspace_bytes < (size_t)PL_MAX_BLOCKS * PL_NSUM * sizeof(float)) return STP_E_WORKSPACE;
   if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;

@@ -173,6 +173,7 @@ extern "C" int stp_sigmoid_loss_bias_grad(const void* workspace, int64_t count, 
 extern "C" int stp_sigmoid_bce_dice(const void* logits, const uint8_t* target, int64_t count, int32_t dtype, float w_bce,
                                     float w_dice, float* scalars, void* dlogits, int32_t dl_channels, float grad_scale,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!logits || !target || !scalars || !workspace || count <= 0) return STP_E_BADARG;
   if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(256) void loss_ex_grad_kernel(const T* __restrict__
 extern "C" int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, int64_t count, int32_t dtype, const float* weights5,
                                    float* scalars, void* dlogits, int32_t dl_channels, float grad_scale, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!logits || !target || !scalars || !workspace || !weights5 || count <= 0) return STP_E_BADARG;
   if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
   if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
@@ -561,6 +563,7 @@ static void dispatch_softmax_loss(const T* logits, const uint8_t* target, int64_
 extern "C" int stp_softmax_cce_dice(const void* logits, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc,
                                     int32_t dtype, float w_cce, float w_dice, float* scalars, void* dlogits, int32_t dl_channels,
                                     float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!logits || !target || !scalars || !workspace || pixels <= 0 || classes < 2 || classes > STP_MAX_CLASSES || ldc < classes)
     return STP_E_BADARG;
   if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
@@ -595,6 +598,7 @@ __global__ void softmax_kernel(const T* __restrict__ logits, float* __restrict__
 }
 
 extern "C" int stp_softmax(const void* logits, float* probs, int64_t pixels, int32_t classes, int32_t ldc, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!logits || !probs || pixels <= 0 || classes < 1 || classes > STP_MAX_CLASSES || ldc < classes) return STP_E_BADARG;
   int64_t g = (pixels + 255) / 256;
   if (g > 4096) g = 4096;
@@ -613,6 +617,7 @@ __global__ void sigmoid_kernel(const T* __restrict__ logits, float* __restrict__
 }
 
 extern "C" int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!logits || !probs || count <= 0) return STP_E_BADARG;
   int64_t g = (count + 255) / 256;
   if (g > 4096) g = 4096;
@@ -896,6 +901,7 @@ __global__ __launch_bounds__(256) void weight_prepare_kernel(const float* __rest
 
 extern "C" int stp_weight_prepare(const float* master, void* fwd, void* bwd, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
                                   int32_t KWp, int32_t Cinp, int32_t CoutB, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!master || (!fwd && !bwd) || KWp < KW || Cinp < Cin || CoutB < Cout) return STP_E_BADARG;
   const int rows_f = round_up(Cout, 16), rows_b = round_up(Cin, 16);
   const int64_t total = (fwd ? (int64_t)rows_f * KH * KWp * Cinp : 0) + (bwd ? (int64_t)rows_b * KH * KW * CoutB : 0);
@@ -981,6 +987,7 @@ extern "C" int64_t stp_weight_prepare_desc_fill(void* desc_host, int32_t index, 
 }
 
 extern "C" int stp_weight_prepare_batched(const void* desc_dev, int32_t nlayers, int64_t total, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!desc_dev || nlayers <= 0 || total <= 0) return STP_E_BADARG;
   // grid.x workgroups per layer: the big layers (9.4 MB, 2304 units) grid-stride over them, the surplus workgroups of the small
   // layers exit at once (64 -> 256: the launch lasts as long as its largest layer, 130 -> see DESIGN)
@@ -1035,6 +1042,7 @@ __global__ __launch_bounds__(256) void weight_upcollapse_batched_kernel(const Up
 
 extern "C" int stp_weight_prepare_upcollapse(const float* master, void* weight_up, int32_t Cout, int32_t C0, int32_t C1, int32_t dtype,
                                              void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!master || !weight_up || Cout <= 0 || C0 <= 0 || C1 < 0) return STP_E_BADARG;
   UpcollapseDesc d;
   d.master = master; d.out = weight_up; d.Cout = Cout; d.rows = round_up(Cout, 16); d.C0 = C0; d.Ctot = C0 + C1;
@@ -1051,6 +1059,7 @@ extern "C" size_t stp_weight_prepare_upcollapse_desc_bytes(void) { return sizeof
 
 // desc_dev: `nlayers` descriptors {const float* master; void* out; int32 Cout, rows (= Cout rounded up to 16), C0, C0 + C1} on the device
 extern "C" int stp_weight_prepare_upcollapse_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!desc_dev || nlayers <= 0) return STP_E_BADARG;
   const dim3 grid(256, nlayers);
   if (dtype == STP_H16) hipLaunchKernelGGL(weight_upcollapse_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);
@@ -1088,6 +1097,7 @@ __global__ __launch_bounds__(256) void weight_upcollapse_bwd_batched_kernel(cons
 
 // desc_dev: nlayers records {const float* master; void* out; int32 Cout, CoutB, C0, C0 + C1} (32 bytes each) on the device
 extern "C" int stp_weight_prepare_upcollapse_bwd_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   if (!desc_dev || nlayers <= 0) return STP_E_BADARG;
   const dim3 grid(256, nlayers);
   if (dtype == STP_H16) hipLaunchKernelGGL(weight_upcollapse_bwd_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const UpcollapseDesc*)desc_dev);

@@ -167,6 +167,7 @@ extern "C" size_t stp_lovasz_workspace_bytes(int64_t count, int32_t images) {
 
 extern "C" int stp_lovasz_hinge(const void* logits, const uint8_t* target, int32_t images, int64_t per_image, int32_t dtype, float weight,
                                 float* scalars, void* dlogits, int32_t dl_channels, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
   const int64_t count = (int64_t)images * per_image;
   if (!logits || !target || !scalars || !workspace || images <= 0 || per_image <= 0 || count >= ((int64_t)1 << 31) ||
       per_image >= ((int64_t)1 << 31) || (dtype != STP_H16 && dtype != STP_F32) || (dlogits && dl_channels < 1))

@@ -1837,3 +1837,27 @@ def test_bf16_wire_casts(ops):
     ops.cast_bf16_to_f32(b, y, x.numel(), 0.5)
     torch.cuda.synchronize()
     assert torch.equal(y, b.to(torch.float32) * 0.5)
+
+
+def test_each_build_rejects_the_other_builds_16bit_code(ops):
+    """libstp_hip.so serves STP_F32 + STP_BF16, libstp_hip_f16.so STP_F32 + STP_F16 (include/stp_hip.h): the other 16-bit code must
+    come back as STP_E_BADARG from the plain-argument entry points and from the parameter-struct ones, not run as something else."""
+    from segmentation_training_pipeline_amd import _lib
+    x = torch.zeros(1024, dtype=torch.float16, device=DEV)
+    pr = torch.empty(1024, dtype=torch.float32, device=DEV)
+    y = torch.empty((1, 8, 8, 16), dtype=torch.float16, device=DEV)
+    w = torch.zeros(16 * 9 * 16, dtype=torch.float16, device=DEV)
+    for storage, good, bad in (("bf16", _lib.BF16, _lib.F16), ("fp16", _lib.F16, _lib.BF16)):
+        lib = _lib.load(storage)
+        assert lib.stp_storage_dtype() == good
+        assert lib.stp_sigmoid(ops.ptr(x), ops.ptr(pr), 1024, good, ops.stream()) == 0
+        assert lib.stp_sigmoid(ops.ptr(x), ops.ptr(pr), 1024, bad, ops.stream()) == -1
+        assert lib.stp_add_inplace(ops.ptr(x), ops.ptr(x), 1024, bad, ops.stream()) == -1
+        assert lib.stp_sigmoid(ops.ptr(x), ops.ptr(pr), 1024, 7, ops.stream()) == -1
+        P = ops.conv_params(x.view(1, 8, 8, 16), w, y, N=1, Hs0=8, Ws0=8, Hv=8, Wv=8, C0=16, KH=3, KW=3, stride=1, pad=1, Ho=8, Wo=8, Cout=16,
+                            dtype=bad)
+        import ctypes
+        assert lib.stp_conv2d(ctypes.byref(P), ops.stream()) == -1
+        P.dtype = good
+        assert lib.stp_conv2d(ctypes.byref(P), ops.stream()) == 0
+    torch.cuda.synchronize()
