@@ -499,3 +499,36 @@ def test_nchannel_adaptation_of_pretrained_weights():
     assert out["bn_data/beta"][3] == pre["bn_data/beta"][2] and out["bn_data/beta"][4] == 0
     with pytest.raises(ValueError):
         adapt_nchannel({"stage1/kernel": np.zeros((3, 3, 4, 8), np.float32)}, cur)
+
+
+def test_extra_train_data_joins_every_folds_training_set_only(tmp_path):
+    """``extra_train_data: name`` + ``segmentation.extra_train[name] = ds`` (reference segmentation.py:29, README.md:698-709): the
+    extra items are appended to the TRAINING indexes of every fold, never to a validation split; an unregistered name raises."""
+    class DS(object):
+        def __init__(self, n, tag):
+            self.n, self.tag = n, tag
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return (self.tag, int(i))
+
+    base, extra = DS(10, "base"), DS(4, "extra")
+    cat = pipeline.ConcatDataSet(base, extra)
+    assert len(cat) == 14 and cat[9] == ("base", 9) and cat[10] == ("extra", 0) and cat[13] == ("extra", 3)
+    kf = pipeline.KFoldedDataSet(cat, range(len(base)), folds_count=5, random_state=33)
+    kf.extra_train_indexes = range(10, 14)
+    for f in range(5):
+        tr, va = kf.sampledIndexes(f, True), kf.sampledIndexes(f, False)
+        assert set(range(10, 14)) <= set(tr.tolist()) and not (set(va.tolist()) & set(range(10, 14)))
+        assert len(tr) == 8 + 4 and len(va) == 2 and not (set(tr.tolist()) & set(va.tolist()))
+    assert segmentation.extra_train is pipeline.extra_train
+    cfg_path = str(tmp_path / "c.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump({"architecture": "Unet", "backbone": "resnet18", "classes": 1, "activation": "sigmoid", "encoder_weights": None,
+                        "shape": [64, 64, 3], "optimizer": "Adam", "lr": 0.001, "batch": 2, "folds_count": 2, "loss": "binary_crossentropy",
+                        "extra_train_data": "people_not_registered", "stages": [{"epochs": 1}]}, f)
+    cfg = segmentation.parse(cfg_path)
+    with pytest.raises(ValueError, match="not registered"):
+        cfg.fit(base)
