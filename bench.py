@@ -57,6 +57,8 @@ def kernel_key(name, meta, dtype):
             return "conv_igemm_ut_kernel<%s, %s, %d, true>" % (t, CONV_TILES[tile % 32], tile // 32)
         c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
         return "conv_igemm_kernel<%s, %s, %s>" % (t, CONV_TILES[tile], c4)
+    if name == "stp_wgrad_group_partial":      # grouped row-of-taps weight gradient (conv_wgrad.hip): one launch per group of layers
+        return "conv_wgrad_row_group_kernel<%s, 3>" % {128: "128, 2, 2", 64: "64, 1, 4", 32: "32, 1, 4"}[meta["bm"]]
     if name == "stp_conv2d_wgrad":
         if meta.get("sc"):
             return "conv_sc_wgrad_kernel<%s>" % t
@@ -205,10 +207,14 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...` (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # the GPU of this rank: its own device; wrapped around when the node exposes fewer devices than ranks (the 2-rank dry run on
+    # one GPU under STP_DIST_BACKEND=gloo, tests/test_dp_gpu.py) - on an 8-GPU node rank i drives GPU i
+    dev_index = distributed.device_index(local_rank)
+    torch.cuda.set_device(dev_index)
     force_dp = os.environ.get("STP_FORCE_DP") == "1"      # single-GPU exercise of the RCCL path
-    distributed.init("nccl", force=force_dp)
-    dev = torch.device("cuda", local_rank)
+    # backend: RCCL ("nccl") unless STP_DIST_BACKEND names another one (gloo for several ranks on one GPU: RCCL refuses duplicate devices)
+    distributed.init(os.environ.get("STP_DIST_BACKEND") or "nccl", force=force_dp)
+    dev = torch.device("cuda", dev_index)
 
     model = HipSegModel(args.architecture, "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
                         lr=1e-3, use_graph=not args.eager, device=str(dev))

@@ -209,6 +209,24 @@ int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* strea
  * 1 = small-channel halo kernel, 2 / 3 = row-of-taps kernel with 128 / 64 output channels per workgroup. */
 int stp_conv2d_wgrad_kernel_id(const stp_wgrad_params* p);
 
+/* Grouped weight gradient (row-of-taps kernel): ONE partial launch + ONE reduce launch for several layers (the 3x3 / stride-1
+ * layers of a network stage).  A layer launched alone offers 6-96 output tiles to 512-768 workgroup slots, so its pixel reduction
+ * is split 5-85 ways (~12 steps per workgroup, one 96 KB partial slab each); the group's (layer, tile, step) space is cut into one
+ * contiguous chunk per workgroup slot instead (fixed partition -> deterministic), a tile is covered by 1-3 partial slabs.
+ *   stp_wgrad_group_class        : 0 = the layer cannot join a group; otherwise the class (32 / 64 / 128 output channels per tile) -
+ *                                  the layers of one group must share it
+ *   stp_wgrad_group_table_bytes  : size of the descriptor table of a group (0: invalid group)
+ *   stp_wgrad_group_workspace_bytes : size of the partial slabs
+ *   stp_wgrad_group_build        : fills the HOST copy of the table (it holds the layers' device pointers: build it when src0 / src1 /
+ *                                  dy / dw are final); the caller copies it to device memory
+ *   stp_wgrad_group_partial / _reduce : the two launches; host_table (header read on the host) and its device copy */
+int stp_wgrad_group_class(const stp_wgrad_params* p);
+size_t stp_wgrad_group_table_bytes(const stp_wgrad_params* const* layers, int32_t n);
+size_t stp_wgrad_group_workspace_bytes(const stp_wgrad_params* const* layers, int32_t n);
+int stp_wgrad_group_build(const stp_wgrad_params* const* layers, int32_t n, void* host_table, size_t table_bytes);
+int stp_wgrad_group_partial(const void* host_table, const void* dev_table, void* workspace, size_t workspace_bytes, void* stream);
+int stp_wgrad_group_reduce(const void* host_table, const void* dev_table, const void* workspace, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Compute copies of a convolution kernel from the fp32 master (layout [Cout][KH][KW][Cin]):
  *   fwd : [Cout_pad16][KH][KWp][Cinp] dtype, zero padded (operand of stp_conv2d / layout of dW)
@@ -264,6 +282,12 @@ int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype,
                           const float* mean, const float* rstd, const float* gamma, const float* partial, int32_t tiles,
                           float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* the same with the accumulated addend in ANOTHER buffer: dx = result + dadd when accumulate_dx (dadd is left intact - a residual
+ * gradient that a grouped weight gradient, stp_wgrad_group_partial, still reads as its dY); dadd == dx is the in-place form above */
+int stp_bn_backward_fused_add(const void* x, const void* g, void* dx, const void* dadd, int32_t dtype, int64_t rows, int32_t C,
+                              const float* mean, const float* rstd, const float* gamma, const float* partial, int32_t tiles,
+                              float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
+                              void* stream);
 int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t C, float eps, float momentum,
                  float* mean, float* rstd, float* moving_mean, float* moving_var,
                  void* workspace, size_t workspace_bytes, void* stream);

@@ -70,6 +70,12 @@ SIGNATURES = {
     "stp_wgrad_sc_slabs": (i32, [C.POINTER(WgradParams)]),
     "stp_wgrad_sc_partial": (i32, [C.POINTER(WgradParams), vp, vp]),
     "stp_conv2d_wgrad_kernel_id": (i32, [C.POINTER(WgradParams)]),
+    "stp_wgrad_group_class": (i32, [C.POINTER(WgradParams)]),
+    "stp_wgrad_group_table_bytes": (sz, [vp, i32]),
+    "stp_wgrad_group_workspace_bytes": (sz, [vp, i32]),
+    "stp_wgrad_group_build": (i32, [vp, i32, vp, sz]),
+    "stp_wgrad_group_partial": (i32, [vp, vp, vp, sz, vp]),
+    "stp_wgrad_group_reduce": (i32, [vp, vp, vp, vp]),
     "stp_weight_prepare": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_weight_prepare_desc_bytes": (sz, []),
     "stp_weight_prepare_desc_fill": (i64, [vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
@@ -86,6 +92,7 @@ SIGNATURES = {
     "stp_bn_backward_slots": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "stp_zero_bytes": (i32, [vp, i64, vp]),
     "stp_bn_backward_fused": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "stp_bn_backward_fused_add": (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "stp_maxpool3x3s2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool3x3s2_bwd_bn_tiles": (i32, [i32, i32, i32, i32, i32]),

@@ -644,11 +644,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* dx,
                                                            int64_t rows, int C, const float* mean, const float* rstd,
                                                            const float* gamma, const float* beta, const float* sums,
                                                            float inv_rows, int relu, int accumulate, const long long* slots = nullptr,
-                                                           int nslots = 0, float* dgamma = nullptr, float* dbeta = nullptr) {
+                                                           int nslots = 0, float* dgamma = nullptr, float* dbeta = nullptr, const T* dadd = nullptr) {
+  // accumulate: dx = result + dadd (dadd == nullptr: in place, dadd = dx; otherwise the addend lives in ANOTHER buffer and stays intact -
+  // a residual gradient that a pending grouped weight gradient still reads as its dY)
+  if (!dadd) dadd = dx;
   extern __shared__ float ss[];  // mean, rstd, scale, shift, k1 = dbeta/M, k2 = dgamma/M   [6][C]
   if (!slots && V == 8 && ((int64_t)gridDim.x * 256) % (C / V) == 0) {
     // The thread keeps its 8 channels for the whole launch and fetches their constants ITSELF (twelve 16-byte loads that hit L2, one
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       ldv<T, V>(x + (i + stride8) * V, x1);
       ldv<T, V>(dy + i * V, g0);
       ldv<T, V>(dy + (i + stride8) * V, g1);
-      if (accumulate) { ldv<T, V>(dx + i * V, d0); ldv<T, V>(dx + (i + stride8) * V, d1); }
+      if (accumulate) { ldv<T, V>(dadd + i * V, d0); ldv<T, V>(dadd + (i + stride8) * V, d1); }
       one8(i, x0, g0, d0);
       one8(i + stride8, x1, g1, d1);
     }
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       float x0[V], g0[V], d0[V];
       ldv<T, V>(x + i * V, x0);
       ldv<T, V>(dy + i * V, g0);
-      if (accumulate) ldv<T, V>(dx + i * V, d0);
+      if (accumulate) ldv<T, V>(dadd + i * V, d0);
       one8(i, x0, g0, d0);
     }
     return;
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       ldv<T, V>(x + (i + stride) * V, x1);
       ldv<T, V>(dy + i * V, g0);
       ldv<T, V>(dy + (i + stride) * V, g1);
-      if (accumulate) { ldv<T, V>(dx + i * V, d0); ldv<T, V>(dx + (i + stride) * V, d1); }
+      if (accumulate) { ldv<T, V>(dadd + i * V, d0); ldv<T, V>(dadd + (i + stride) * V, d1); }
       one(i, x0, g0, d0);
       one(i + stride, x1, g1, d1);
     }
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       float x0[V], g0[V], d0[V];
       ldv<T, V>(x + i * V, x0);
       ldv<T, V>(dy + i * V, g0);
-      if (accumulate) ldv<T, V>(dx + i * V, d0);
+      if (accumulate) ldv<T, V>(dadd + i * V, d0);
       one(i, x0, g0, d0);
     }
     return;
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     if (accumulate) {
       float d[V];
-      ldv<T, V>(dx + i * V, d);
+      ldv<T, V>(dadd + i * V, d);
 #pragma unroll
       for (int e = 0; e < V; ++e) o[e] += d[e];
     }
@@ -886,12 +889,12 @@ extern "C" int stp_bn_backward_slots(const void* x, const void* g, void* dx, int
   return STP_OK;
 }
 
-extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C,
+extern "C" int stp_bn_backward_fused_add(const void* x, const void* g, void* dx, const void* dadd, int32_t dtype, int64_t rows, int32_t C,
                                      const float* mean, const float* rstd, const float* gamma, const float* partial,
                                      int32_t tiles, float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace,
                                      size_t workspace_bytes, void* stream) {
   if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
-  if (!x || !g || !dx || !mean || !rstd || !partial || !workspace || rows <= 0 || C <= 0 || (C & 3) || tiles <= 0) return STP_E_BADARG;
+  if (!x || !g || !dx || (accumulate_dx && !dadd) || !mean || !rstd || !partial || !workspace || rows <= 0 || C <= 0 || (C & 3) || tiles <= 0) return STP_E_BADARG;
   if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* sums = (float*)workspace + (size_t)(BN_MAX_BLOCKS - 1) * 2 * C;
@@ -904,17 +907,28 @@ extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int
   // the ReLU mask is already folded into g
   if (v8)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 8>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g,
-                       (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
+                       (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx, (const long long*)nullptr, 0, (float*)nullptr, (float*)nullptr,
+                       (const bf16_t*)dadd);
   else if (dtype == STP_H16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 4>), dim3(gr), dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)g,
-                       (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
+                       (bf16_t*)dx, rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx, (const long long*)nullptr, 0, (float*)nullptr, (float*)nullptr,
+                       (const bf16_t*)dadd);
   else if (dtype == STP_F32)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), dim3(gr), dim3(256), lds2, s, (const float*)x, (const float*)g, (float*)dx,
-                       rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx);
+                       rows, C, mean, rstd, gamma, (const float*)nullptr, sums, inv_rows, 0, accumulate_dx, (const long long*)nullptr, 0, (float*)nullptr, (float*)nullptr,
+                       (const float*)dadd);
   else
     return STP_E_BADARG;
   STP_LAUNCH_CHECK();
   return STP_OK;
+}
+
+extern "C" int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype, int64_t rows, int32_t C,
+                                     const float* mean, const float* rstd, const float* gamma, const float* partial,
+                                     int32_t tiles, float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return stp_bn_backward_fused_add(x, g, dx, dx, dtype, rows, C, mean, rstd, gamma, partial, tiles, dgamma, dbeta, accumulate_dx, workspace,
+                                   workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------

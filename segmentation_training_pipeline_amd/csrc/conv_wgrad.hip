@@ -16,6 +16,8 @@
 // a second kernel sums in fixed order: deterministic, no atomics.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -465,8 +467,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
 //   dW column of (kw, ci): (kh * 3 + kw) * Ctot + cib * 64 + ci.  Two concatenated sources (each a multiple of 64 channels, the first optionally
 //   nearest-2x upsampled: the decoder's UpSampling2D + Concatenate) are handled per 64-channel block: a block lies in one source.
 // PBN (fused producer BatchNormalization of src0) is a compile-time parameter of the body: 20 VGPRs the plain launches do not carry.
+// (t, step0, step1, out_tile): the tile of the layer (tile_m fastest), the range of 64-pixel steps summed and the fragment-major
+// partial slab [wave][i][j][lane] float4 that receives the sums - the single-layer kernel derives them from the block id, the
+// grouped kernel (below) from its work list.
 template <int BM, int WM, int WN, int STAGES, bool PBN>
-__device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a) {
+__device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a, const int t, const int step0, const int step1, f32x4* const out_tile) {
   static_assert(WM * WN == 4, "4 waves");
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef bf16_t T;
@@ -485,10 +490,6 @@ __device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a) {
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 15, lg = lane >> 4;
 
-  const int tiles = a.ntile_m * a.ntile_n;
-  const int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int split = bid / tiles;
-  const int t = bid - split * tiles;
   const int tile_m = t % a.ntile_m, tile_n = t / a.ntile_m;
   const int ncib = a.Ctot >> 6;
   const int kh = tile_n / ncib, cib = tile_n - kh * ncib;       // cib: 64-channel block of the CONCATENATED input
@@ -497,8 +498,6 @@ __device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a) {
   const int sh = (first && a.mode == STP_SRC_NEAREST2X) ? 1 : 0;  // UpSampling2D(2) folded into the gather: source pixel = (h >> 1, w >> 1)
   const int Hs = first ? a.Hs0 : a.Hv, Ws = first ? a.Ws0 : a.Wv;
   const int cout0 = tile_m * BM;
-  const int step0 = split * a.steps_per_split;
-  const int step1 = min(step0 + a.steps_per_split, a.nsteps);
 
   const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.bytesdy, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? a.src0 : a.src1), 0, first ? a.bytes0 : a.bytes1, 0x00020000);
@@ -671,7 +670,7 @@ __device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a) {
   // ---- slab, FRAGMENT-MAJOR: [split][tile][wave][i][j][lane] float4 (the lane's 4 output channels of one column) - every store is
   // a 16-byte lane-contiguous vector (1 KB per wave instruction) instead of 4-byte stores K floats apart (measured: the scattered
   // slab write was a third of the launch); wgrad_reduce_row_kernel sums the splits in this order and scatters into dW once
-  f32x4* out = reinterpret_cast<f32x4*>(a.out) + ((size_t)(split * tiles + t) * 4 + wave) * (TM * TN * 64) + lane;
+  f32x4* out = out_tile + (size_t)wave * (TM * TN * 64) + lane;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -679,10 +678,93 @@ __device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a) {
 #endif
 }
 
+// single layer: block = (split, tile), the tiles of one split (same pixels) next to each other
+template <int BM, int WM, int WN, int STAGES, bool PBN>
+__device__ __forceinline__ void conv_wgrad_row_single(const WgradArgs& a) {
+  const int tiles = a.ntile_m * a.ntile_n;
+  const int bid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int split = bid / tiles;
+  const int t = bid - split * tiles;
+  const int step0 = split * a.steps_per_split;
+  const int step1 = min(step0 + a.steps_per_split, a.nsteps);
+  conv_wgrad_row_body<BM, WM, WN, STAGES, PBN>(a, t, step0, step1, reinterpret_cast<f32x4*>(a.out) + (size_t)(split * tiles + t) * (BM * 192 / 4));
+}
 template <int BM, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) { conv_wgrad_row_body<BM, WM, WN, STAGES, false>(a); }
+__global__ __launch_bounds__(256) void conv_wgrad_row_kernel(const WgradArgs a) { conv_wgrad_row_single<BM, WM, WN, STAGES, false>(a); }
 template <int BM, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256) void conv_wgrad_row_pbn_kernel(const WgradArgs a) { conv_wgrad_row_body<BM, WM, WN, STAGES, true>(a); }
+__global__ __launch_bounds__(256) void conv_wgrad_row_pbn_kernel(const WgradArgs a) { conv_wgrad_row_single<BM, WM, WN, STAGES, true>(a); }
+
+// ------------------------------------------------------------------------------------------------
+// GROUPED launch (round 3).  A layer launched alone has 6-96 output tiles for 512-768 workgroup slots, so its pixel reduction was
+// split 5-85 ways: ~12 steps per workgroup, a 3-stage pipeline fill and a 96 KB partial slab per 12 steps - the launch ran at
+// 520-700 TFLOP/s and the slabs were 3.65x the algorithmic bytes (profiles/r02g_*).  The same kernel body with 130+ steps per
+// workgroup reaches 1060-1070 TFLOP/s (scratch/r03_probe.py).  The weight gradients feed nothing but the optimizer, so the plan
+// collects the layers of a stage and issues ONE launch for them: the (layer, tile, step) space of the group is laid out as a line
+// (layer-major, tile, step), cut into one contiguous chunk per workgroup slot (stream-K), and a workgroup walks the segments of
+// its chunk.  Every segment writes one partial slab; a tile is covered by 1-3 segments that `wgrad_group_reduce_kernel` sums in
+// line order (fixed partition, fixed order: deterministic, no atomics) and scatters into dW.
+struct WgLayer {
+  WgradArgs a;
+  float* dw;
+  int accumulate, tile0, pad0, pad1;
+};
+struct WgSeg { int layer, tile, step0, step1, slot, pad0, pad1, pad2; };
+struct WgTile { int layer, t, slot0, nslots; };
+struct WgGroupHeader {
+  int magic, bm, n_layers, n_segs, n_wg, n_tiles;
+  int off_layers, off_segs, off_first, off_tiles;      // byte offsets from the start of the table
+  int total_bytes, pad0;
+};
+#define WG_GROUP_MAGIC 0x57474733
+
+template <int BM, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_row_group_kernel(const char* __restrict__ table, f32x4* __restrict__ slabs) {
+  const WgGroupHeader* const hd = reinterpret_cast<const WgGroupHeader*>(table);
+  const WgLayer* const layers = reinterpret_cast<const WgLayer*>(table + hd->off_layers);
+  const WgSeg* const segs = reinterpret_cast<const WgSeg*>(table + hd->off_segs);
+  const int* const first = reinterpret_cast<const int*>(table + hd->off_first);
+  // consecutive block ids round-robin over the XCDs: give every XCD one contiguous run of the line (the tiles of a layer read
+  // the same dY / x pixels at the same time: they meet in one L2)
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int s0 = __builtin_amdgcn_readfirstlane(first[w]), s1 = __builtin_amdgcn_readfirstlane(first[w + 1]);
+  for (int s = s0; s < s1; ++s) {
+    const WgSeg sg = segs[s];
+    if (s != s0) __syncthreads();        // the previous segment's last fragment reads precede this segment's first LDS-DMA
+    conv_wgrad_row_body<BM, WM, WN, STAGES, false>(layers[sg.layer].a, sg.tile, sg.step0, sg.step1, slabs + (size_t)sg.slot * (BM * 192 / 4));
+  }
+}
+
+// sum of a tile's partial slabs in line order, scattered into dW (the element decode of wgrad_reduce_row_kernel)
+template <int BM, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const char* __restrict__ table, const f32x4* __restrict__ slabs) {
+  constexpr int TM = BM / WM / 16, TN = 192 / WN / 16, PER = BM * 192 / 4, BPT = PER / 256;
+  static_assert(PER % 256 == 0, "whole blocks per tile");
+  const WgGroupHeader* const hd = reinterpret_cast<const WgGroupHeader*>(table);
+  const WgLayer* const layers = reinterpret_cast<const WgLayer*>(table + hd->off_layers);
+  const WgTile tl = reinterpret_cast<const WgTile*>(table + hd->off_tiles)[blockIdx.x / BPT];
+  const int e = (blockIdx.x % BPT) * 256 + threadIdx.x;
+  const f32x4* p = slabs + (size_t)tl.slot0 * PER + e;
+  f32x4 s = p[0];
+  for (int k = 1; k < tl.nslots; ++k) s += p[(size_t)k * PER];
+  const WgLayer& L = layers[tl.layer];
+  const int lane = e & 63, lr = lane & 15, lg = lane >> 4;
+  int q = e >> 6;
+  const int ij = q % (TM * TN); q /= (TM * TN);
+  const int wave = q & 3;
+  const int i = ij / TN, j = ij - i * TN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = tl.t % L.a.ntile_m, tile_n = tl.t / L.a.ntile_m;
+  const int ncib = L.a.Ctot >> 6, kh = tile_n / ncib, cib = tile_n - kh * ncib;
+  const int col = wn * (192 / WN) + j * 16 + lr;
+  const int kc = (kh * 3 + (col >> 6)) * L.a.Ctot + cib * 64 + (col & 63);
+  const int co = tile_m * BM + wm * (BM / WM) + i * 16 + lg * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (co + r < L.a.Cout) {
+      float* d = L.dw + (size_t)(co + r) * L.a.K + kc;
+      *d = L.accumulate ? *d + s[r] : s[r];
+    }
+}
 
 // Reduction of the row-of-taps kernel's fragment-major slabs: element e = ((tile * 4 + wave) * TM*TN + i*TN + j) * 64 + lane.
 // SL lanes walk the splits of an element in parallel (fixed assignment, fixed-shape LDS tree: deterministic), then the 4 floats
@@ -1007,6 +1089,172 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
   *dma_out = !c4 && b0 < lim && b1 < lim && bd < lim;
   a.pbn.x = nullptr; a.pbn.mean = p->src_bn_mean; a.pbn.rstd = p->src_bn_rstd; a.pbn.gamma = p->src_bn_gamma; a.pbn.beta = p->src_bn_beta;
   a.pbn.relu = p->src_bn_relu;
+  return STP_OK;
+}
+
+// ---- grouped row-of-taps launch: host side -----------------------------------------------------------------------------------
+// class of a layer = the output-channel tile of its kernel instance (layers of one group share it); 0 = not eligible
+static int wg_group_bm(const stp_wgrad_params* p) {
+  if (!p || !wgrad_row_eligible(p) || p->src_bn_mean || p->splits != 0) return 0;
+  const int64_t lim = 1ll << 31;
+  const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
+  if ((int64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * 2 >= lim || (int64_t)p->N * p->Hv * p->Wv * p->C1 * 2 >= lim || P * p->Cout * 2 >= lim) return 0;
+  return p->Cout <= 32 ? 32 : p->Cout <= 64 ? 64 : 128;
+}
+extern "C" int stp_wgrad_group_class(const stp_wgrad_params* p) { return wg_group_bm(p); }
+
+struct WgGroupPlan {
+  int bm = 0;
+  std::vector<int> ntile_m, ntile_n, nsteps, tile0;
+  std::vector<WgSeg> segs;
+  std::vector<int> first;
+  std::vector<WgTile> tiles;
+};
+
+static int wg_group_slots(int bm) {
+  static const int cus = device_cu_count();
+  static const int target = getenv("STP_WGRAD_GROUP_SLOTS") ? atoi(getenv("STP_WGRAD_GROUP_SLOTS")) : 0;
+  if (target > 0) return target;
+  return cus * (bm == 128 ? 2 : bm == 64 ? 3 : 4);     // co-resident workgroups: 77 KB of LDS / 224 registers at 128 channels, 52 KB / 144 and 40 KB / 114 below
+}
+
+static int wg_group_plan(const stp_wgrad_params* const* L, int n, WgGroupPlan& g) {
+  if (!L || n <= 0) return STP_E_BADARG;
+  g.bm = wg_group_bm(L[0]);
+  if (!g.bm) return STP_E_BADARG;
+  int64_t total = 0;
+  int ntiles = 0;
+  for (int l = 0; l < n; ++l) {
+    if (wg_group_bm(L[l]) != g.bm || !L[l]->src0 || !L[l]->dy || !L[l]->dw) return STP_E_BADARG;
+    const int tm = ceil_div(L[l]->Cout, g.bm), tn = 3 * ((L[l]->C0 + L[l]->C1) / 64);
+    const int ns = (int)((int64_t)L[l]->N * L[l]->Ho * L[l]->Wo / 64);
+    g.ntile_m.push_back(tm); g.ntile_n.push_back(tn); g.nsteps.push_back(ns); g.tile0.push_back(ntiles);
+    ntiles += tm * tn;
+    total += (int64_t)tm * tn * ns;
+  }
+  const int slots = wg_group_slots(g.bm);
+  const int MINSEG = 8;       // no segment shorter than this unless its tile is (a 3-stage pipeline fill + a slab per segment)
+  int64_t chunk = (total + slots - 1) / slots;
+  if (chunk < 2 * MINSEG) chunk = 2 * MINSEG;
+  for (;; ++chunk) {
+    g.segs.clear(); g.first.clear(); g.tiles.clear();
+    int l = 0, t = 0, s = 0;
+    while (l < n) {
+      g.first.push_back((int)g.segs.size());
+      int64_t rem = chunk;
+      int mine = 0;
+      while (rem > 0 && l < n) {
+        const int avail = g.nsteps[l] - s;
+        int take = (int)(rem < avail ? rem : avail);
+        if (avail - take > 0 && avail - take < MINSEG) take = avail;             // do not leave a sliver of the tile behind
+        if (take < MINSEG && take < avail && mine > 0) break;                     // a sliver at the end of the chunk: the next workgroup takes it
+        WgSeg sg = {l, t, s, s + take, (int)g.segs.size(), 0, 0, 0};
+        if (s == 0) g.tiles.push_back(WgTile{l, t, sg.slot, 1}); else g.tiles.back().nslots++;
+        g.segs.push_back(sg);
+        ++mine;
+        rem -= take; s += take;
+        if (s == g.nsteps[l]) { s = 0; if (++t == g.ntile_m[l] * g.ntile_n[l]) { t = 0; ++l; } }
+      }
+    }
+    g.first.push_back((int)g.segs.size());
+    if ((int)g.first.size() - 1 <= slots) break;       // (slivers moved between neighbours can cost one workgroup more than the slots)
+  }
+  return STP_OK;
+}
+
+static size_t wg_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+extern "C" size_t stp_wgrad_group_table_bytes(const stp_wgrad_params* const* layers, int32_t n) {
+  WgGroupPlan g;
+  if (wg_group_plan(layers, n, g) != STP_OK) return 0;
+  return wg_align16(sizeof(WgGroupHeader)) + wg_align16(sizeof(WgLayer) * n) + wg_align16(sizeof(WgSeg) * g.segs.size()) +
+         wg_align16(sizeof(int) * g.first.size()) + wg_align16(sizeof(WgTile) * g.tiles.size());
+}
+
+extern "C" size_t stp_wgrad_group_workspace_bytes(const stp_wgrad_params* const* layers, int32_t n) {
+  WgGroupPlan g;
+  if (wg_group_plan(layers, n, g) != STP_OK) return 0;
+  return g.segs.size() * (size_t)g.bm * 192 * sizeof(float);
+}
+
+// Fills `host_table` (stp_wgrad_group_table_bytes): the caller copies it to device memory and passes both to the launches
+// (the header is read on the host, everything else on the device; the table holds the layers' device pointers).
+extern "C" int stp_wgrad_group_build(const stp_wgrad_params* const* layers, int32_t n, void* host_table, size_t table_bytes) {
+  WgGroupPlan g;
+  int rc = wg_group_plan(layers, n, g);
+  if (rc != STP_OK) return rc;
+  if (!host_table || table_bytes < stp_wgrad_group_table_bytes(layers, n)) return STP_E_WORKSPACE;
+  char* tb = (char*)host_table;
+  WgGroupHeader hd = {};
+  hd.magic = WG_GROUP_MAGIC; hd.bm = g.bm; hd.n_layers = n; hd.n_segs = (int)g.segs.size(); hd.n_wg = (int)g.first.size() - 1;
+  hd.n_tiles = (int)g.tiles.size();
+  size_t off = wg_align16(sizeof(WgGroupHeader));
+  hd.off_layers = (int)off; off += wg_align16(sizeof(WgLayer) * n);
+  hd.off_segs = (int)off; off += wg_align16(sizeof(WgSeg) * g.segs.size());
+  hd.off_first = (int)off; off += wg_align16(sizeof(int) * g.first.size());
+  hd.off_tiles = (int)off; off += wg_align16(sizeof(WgTile) * g.tiles.size());
+  hd.total_bytes = (int)off;
+  memset(tb, 0, off);
+  memcpy(tb, &hd, sizeof(hd));
+  for (int l = 0; l < n; ++l) {
+    WgLayer wl = {};
+    WgradPlan w;
+    bool c4, dma;
+    rc = wgrad_fill(layers[l], (void*)tb, ~(size_t)0, wl.a, w, &c4, &dma);     // (workspace arguments: validation only, unused by the group)
+    if (rc != STP_OK) return rc;
+    if (!dma) return STP_E_BADARG;
+    wl.a.out = nullptr;
+    wl.a.ntile_m = g.ntile_m[l]; wl.a.ntile_n = g.ntile_n[l]; wl.a.nsteps = g.nsteps[l]; wl.a.steps_per_split = g.nsteps[l];
+    wl.a.xcd = 0;
+    wl.dw = layers[l]->dw; wl.accumulate = layers[l]->accumulate; wl.tile0 = g.tile0[l];
+    memcpy(tb + hd.off_layers + sizeof(WgLayer) * l, &wl, sizeof(wl));
+  }
+  memcpy(tb + hd.off_segs, g.segs.data(), sizeof(WgSeg) * g.segs.size());
+  memcpy(tb + hd.off_first, g.first.data(), sizeof(int) * g.first.size());
+  memcpy(tb + hd.off_tiles, g.tiles.data(), sizeof(WgTile) * g.tiles.size());
+  return STP_OK;
+}
+
+static const WgGroupHeader* wg_group_header(const void* host_table) {
+  const WgGroupHeader* hd = (const WgGroupHeader*)host_table;
+  return (hd && hd->magic == WG_GROUP_MAGIC && (hd->bm == 32 || hd->bm == 64 || hd->bm == 128) && hd->n_wg > 0 && hd->n_tiles > 0) ? hd : nullptr;
+}
+
+extern "C" int stp_wgrad_group_partial(const void* host_table, const void* dev_table, void* workspace, size_t workspace_bytes, void* stream) {
+  const WgGroupHeader* hd = wg_group_header(host_table);
+  if (!hd || !dev_table || !workspace) return STP_E_BADARG;
+  if ((size_t)hd->n_segs * hd->bm * 192 * sizeof(float) > workspace_bytes) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)3 * (64 * hd->bm * 2 + 72 * 128);
+  static bool attr128 = false, attr64 = false, attr32 = false;
+#define STP_GROUP_LAUNCH(BM_, WM_, WN_, FLAG_)                                                                                      \
+  do {                                                                                                                              \
+    auto kern = conv_wgrad_row_group_kernel<BM_, WM_, WN_, 3>;                                                                      \
+    if (lds > 64 * 1024 && !FLAG_) {                                                                                                \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return STP_E_LAUNCH;                                                                                                        \
+      FLAG_ = true;                                                                                                                 \
+    }                                                                                                                               \
+    hipLaunchKernelGGL(kern, dim3(hd->n_wg), dim3(256), lds, s, (const char*)dev_table, (f32x4*)workspace);                         \
+  } while (0)
+  if (hd->bm == 128) STP_GROUP_LAUNCH(128, 2, 2, attr128);
+  else if (hd->bm == 64) STP_GROUP_LAUNCH(64, 1, 4, attr64);
+  else STP_GROUP_LAUNCH(32, 1, 4, attr32);
+#undef STP_GROUP_LAUNCH
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+extern "C" int stp_wgrad_group_reduce(const void* host_table, const void* dev_table, const void* workspace, void* stream) {
+  const WgGroupHeader* hd = wg_group_header(host_table);
+  if (!hd || !dev_table || !workspace) return STP_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int bpt = hd->bm * 192 / 4 / 256;
+  const dim3 grid(hd->n_tiles * bpt);
+  if (hd->bm == 128) hipLaunchKernelGGL((wgrad_group_reduce_kernel<128, 2, 2>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);
+  else if (hd->bm == 64) hipLaunchKernelGGL((wgrad_group_reduce_kernel<64, 1, 4>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);
+  else hipLaunchKernelGGL((wgrad_group_reduce_kernel<32, 1, 4>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);
+  STP_LAUNCH_CHECK();
   return STP_OK;
 }
 

@@ -109,10 +109,24 @@ class Plan(object):
         # weight gradients (needed only by the optimizer / all-reduce) run on a second stream next to the data-gradient
         # + BatchNormalization-backward chain of the same layer: the small latency-bound kernels of one chain fill the
         # tails of the other's GEMMs (captured into the same hipGraph as a fork/join)
-        self.side_stream_wgrad = os.environ.get("STP_SIDE_STREAM_WGRAD", "1") != "0"
+        # Round 3: OFF by default.  With the row-of-taps layers grouped into a few long launches (stp_wgrad_group_*) the second
+        # stream no longer pays: same box, 40 graph steps, U-Net/ResNet34 bs16 - one stream 7.97 ms, two streams 8.07 ms (the grouped
+        # launch holds every CU's LDS, the main chain waits for it either way), per-layer launches on two streams 8.38 ms
+        # (profiles/r03c_ab.txt).  STP_SIDE_STREAM_WGRAD=1 restores the fork / join schedule.
+        self.side_stream_wgrad = os.environ.get("STP_SIDE_STREAM_WGRAD", "0") != "0"
         self.fold_upsample_grad = os.environ.get("STP_FOLD_UPSAMPLE_GRAD", "1") != "0"
         self._side = None
         self._side_reads = set()
+        # grouped weight gradients (stp_wgrad_group_*): the row-of-taps layers of a stage are collected and issued as ONE partial
+        # + ONE reduce launch once their work reaches this many GFLOP (0: every layer is launched alone, as in round 2)
+        self.wgrad_group_gflop = float(os.environ.get("STP_WGRAD_GROUP_GFLOP", "300"))
+        self._wgroup, self._wgroup_cls, self._wgroup_flops, self._wgroup_hi = [], 0, 0.0, 0
+        self._wgroup_reads = set()      # dY buffers of the pending layers: nothing may rewrite them before the group is issued
+        self.wgroups = []               # (layer names, class) of every issued group (inspection / tests)
+        # STP_WGRAD_GROUP_JOIN=0: a grouped launch in flight is NOT joined at the next layer (only where a buffer it reads is
+        # rewritten, and at the end of the launch list); per-layer weight-gradient chains keep their lag-1 join
+        self._side_lag_join = os.environ.get("STP_WGRAD_GROUP_JOIN", "1") != "0"
+        self._side_groups_only = True   # nothing but grouped launches has been forked since the last join
         self._dw_ws_bytes = 0
         self.step_state = None
         # fused BatchNormalization sums in fixed-point slots (stp_conv_params.stats_slots): no finalize kernels
@@ -179,6 +193,11 @@ class Plan(object):
                     if max(e for _, e in self._goffs) > low:
                         self.bwd_monotone = False
                     low = min(low, min(o for o, _ in self._goffs))
+                # a pending grouped weight gradient has asked for its addresses but not been launched: the arena is final only
+                # above the highest pending layer
+                self.bwd_marks.append((len(self.bwd), max(low, self._wgroup_hi)))
+            if self._wgroup:
+                self._flush_wgroup()
                 self.bwd_marks.append((len(self.bwd), low))
         self._tape = []
         return self
@@ -272,9 +291,12 @@ class Plan(object):
         still in flight on the side stream reads that buffer (a dY aliased as a residual gradient), join first."""
         if t.grad is None:
             t.grad = self._alloc((t.N, t.H, t.W, t.gradC))
+        if self._wgroup_reads and t.grad.data_ptr() in self._wgroup_reads:
+            self._flush_wgroup()          # a pending grouped weight gradient reads this buffer as its dY: issue it first
         if self._side_reads and t.grad.data_ptr() in self._side_reads:
             self._mark(self.bwd, "join")
             self._side_reads.clear()
+            self._side_groups_only = True
         return t.grad
 
     @staticmethod
@@ -391,6 +413,35 @@ class Plan(object):
         lst.append((self.lib.stp_conv2d_wgrad_reduce, (C.byref(p), self.ws_wgrad.data_ptr(), 0), "stp_conv2d_wgrad_reduce",
                     {"stream": 1}))
 
+    def _flush_wgroup(self):
+        """Issues the pending grouped weight gradient: descriptor table (built now - every pointer is final), one partial launch
+        and one reduce launch on the side stream.  Each group owns its partial-slab workspace."""
+        if not self._wgroup:
+            return
+        layers, cls = self._wgroup, self._wgroup_cls
+        reads = self._wgroup_reads
+        self._wgroup, self._wgroup_cls, self._wgroup_flops, self._wgroup_hi, self._wgroup_reads = [], 0, 0.0, 0, set()
+        n = len(layers)
+        arr = (C.POINTER(_lib.WgradParams) * n)(*[C.pointer(wp) for wp, _, _ in layers])
+        tb = int(self.lib.stp_wgrad_group_table_bytes(arr, n))
+        wsb = int(self.lib.stp_wgrad_group_workspace_bytes(arr, n))
+        if tb <= 0 or wsb <= 0:
+            raise StpShapeError("grouped weight gradient: the layers %s do not form a group" % [nm for _, nm, _ in layers])
+        host = (C.c_char * tb)()
+        _lib.check(self.lib.stp_wgrad_group_build(arr, n, C.addressof(host), tb), "stp_wgrad_group_build")
+        dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
+        ws = self._alloc((wsb // 4,), torch.float32)
+        self._keep += [arr, host, dev] + [wp for wp, _, _ in layers]
+        names = [nm for _, nm, _ in layers]
+        self.wgroups.append((names, cls))
+        self._mark(self.bwd, "fork")
+        self._side_reads.update(reads)
+        meta = {"layer": "group[%d]:%s..%s" % (n, names[0], names[-1]), "pass": "wgrad", "flops": sum(f for _, _, f in layers), "cout": cls,
+                "bm": cls, "layers": names, "stream": 1}
+        self.bwd.append((self.lib.stp_wgrad_group_partial, (C.addressof(host), dev.data_ptr(), ws.data_ptr(), wsb), "stp_wgrad_group_partial", meta))
+        self.bwd.append((self.lib.stp_wgrad_group_reduce, (C.addressof(host), dev.data_ptr(), ws.data_ptr()), "stp_wgrad_group_reduce",
+                         {"stream": 1}))
+
     # ------------------------------------------------------------------ layers
     def input_u8(self, name, H, W, Cn):
         t = DT(name, self.N, H, W, Cn, None if self.dry else self._alloc((self.N, H, W, Cn), torch.uint8))
@@ -490,8 +541,15 @@ class Plan(object):
             if not out.needs_grad or not out.grad_ready:
                 return
             # dx is always produced (it is cheap relative to skipping logic); frozen params are masked in the optimizer
-            dx = self._gradbuf(x) if x.needs_grad else self._alloc((x.N, x.H, x.W, Cn))
             bslots = out.meta.get("bnb_slots")
+            dadd = None
+            if (x.needs_grad and x.grad_ready and x.grad is not None and x.grad.data_ptr() in self._wgroup_reads and bslots is None
+                    and out.meta.get("bnb") is not None):
+                # x's gradient so far is the dY of a convolution whose weight gradient waits in the pending group (the residual
+                # branch aliases it): accumulate OUT OF PLACE - the sum lands in a fresh buffer, the dY stays intact
+                dadd = x.grad
+                x.grad = None
+            dx = self._gradbuf(x) if x.needs_grad else self._alloc((x.N, x.H, x.W, Cn))
             if bslots is not None:
                 self._emit(self.bwd, "stp_bn_backward_slots", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt, x.rows, Cn,
                            mean.data_ptr(), rstd.data_ptr(), gp, bslots[0], bslots[1], self._gptr(gamma) if gamma else None,
@@ -504,10 +562,15 @@ class Plan(object):
                 # the only consumer's data-gradient epilogue already masked dY and reduced the per-tile sums
                 st, q = fused_b
                 tiles = q if isinstance(q, int) else int(self.lib.stp_conv2d_stats_floats(C.byref(q))) // (2 * Cn)
-                self._emit(self.bwd, "stp_bn_backward_fused", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt,
-                           x.rows, Cn, mean.data_ptr(), rstd.data_ptr(), gp, st.data_ptr(), tiles,
-                           self._gptr(gamma) if gamma else None, self._gptr(beta), int(x.grad_ready and x.needs_grad),
-                           self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
+                if dadd is not None:
+                    self._emit(self.bwd, "stp_bn_backward_fused_add", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), dadd.data_ptr(),
+                               self.cdt, x.rows, Cn, mean.data_ptr(), rstd.data_ptr(), gp, st.data_ptr(), tiles,
+                               self._gptr(gamma) if gamma else None, self._gptr(beta), 1, self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
+                else:
+                    self._emit(self.bwd, "stp_bn_backward_fused", x.buf.data_ptr(), out.grad.data_ptr(), dx.data_ptr(), self.cdt,
+                               x.rows, Cn, mean.data_ptr(), rstd.data_ptr(), gp, st.data_ptr(), tiles,
+                               self._gptr(gamma) if gamma else None, self._gptr(beta), int(x.grad_ready and x.needs_grad),
+                               self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
                 if x.needs_grad:
                     x.grad_ready = True
                 return
@@ -641,8 +704,10 @@ class Plan(object):
             # lag-1 join: the previous convolution's weight-gradient chain finishes before this layer's kernels start.
             # (Letting the side chain fall further behind - joining only on a buffer hazard, see _gradbuf - measured
             # SLOWER, 11.15 vs 10.88 ms/step: the chain then reads dY / x long after the main chain left them in L2.)
-            self._mark(self.bwd, "join")
-            self._side_reads.clear()
+            if self._side_lag_join or not self._side_groups_only:
+                self._mark(self.bwd, "join")
+                self._side_reads.clear()
+                self._side_groups_only = True
             # residual branch: d(residual) = dY
             if residual is not None and residual.needs_grad:
                 if not residual.grad_ready and residual.gradC == out.gradC:
@@ -654,8 +719,6 @@ class Plan(object):
             # weight gradient: on the side stream, forked here (dY is final); joined before any kernel rewrites dY (_gradbuf)
             # and at the end of the launch list
             if w.trainable:
-                self._mark(self.bwd, "fork")
-                self._side_reads.add(dy.data_ptr())     # see _gradbuf: the only buffer of the chain that is ever rewritten
                 padded = stem or CoutB != Cout
                 if padded:
                     dwp = self._alloc((CoutB * k * KWp * Cinp,), torch.float32)
@@ -663,9 +726,29 @@ class Plan(object):
                 else:
                     wp.dw = self._gptr(w)
                 wp.src0, wp.src1, wp.dy = x.meta.get("src_override") or x.buf.data_ptr(), (src1.buf.data_ptr() if src1 is not None else None), dy.data_ptr()
-                self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
-                                                "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp))),
-                                                "kernel_id": int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp)))})
+                cls = int(self.lib.stp_wgrad_group_class(C.byref(wp))) if (self.wgrad_group_gflop > 0 and not padded) else 0
+                if cls:
+                    # row-of-taps layer: joins the pending group (one launch per stage instead of one per layer); dY stays untouched
+                    # until the group is issued (_gradbuf / the BatchNormalization backward's out-of-place accumulate see to that)
+                    if self._wgroup and self._wgroup_cls != cls:
+                        self._flush_wgroup()
+                    self._wgroup.append((wp, name, flops))
+                    self._wgroup_cls = cls
+                    self._wgroup_flops += flops
+                    self._wgroup_hi = max(self._wgroup_hi, w.offset + int(np.prod(w.shape)))
+                    self._wgroup_reads.add(dy.data_ptr())
+                    if self._wgroup_flops >= self.wgrad_group_gflop * 1e9:
+                        self._flush_wgroup()
+                else:
+                    # a layer outside the groups (stride 2, 1x1, stem, small-channel): the pending group is issued first, so a group
+                    # = consecutive row-of-taps layers (a network stage) and the gradient arena stays final above the last visited layer
+                    self._flush_wgroup()
+                    self._mark(self.bwd, "fork")
+                    self._side_groups_only = False
+                    self._side_reads.add(dy.data_ptr())     # see _gradbuf: the only buffer of the chain that is ever rewritten
+                    self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
+                                                    "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp))),
+                                                    "kernel_id": int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp)))})
                 if padded:
                     self._emit_side(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
                                     Cinp, 0)
@@ -1288,23 +1371,32 @@ class Plan(object):
         if forked:
             main.wait_stream(side)
 
-    LOSS_LAUNCHES = ("stp_sigmoid_bce_dice", "stp_softmax_cce_dice", "stp_prob_bce_dice")
+    # loss launches whose third argument is the element / pixel count of the batch ([N, ...] -> the first n_valid samples)
+    LOSS_LAUNCHES = ("stp_sigmoid_bce_dice", "stp_softmax_cce_dice", "stp_prob_bce_dice", "stp_sigmoid_loss_ex", "stp_prob_cce_dice")
 
     def rerun_loss(self, n_valid):
         """Re-evaluates the loss / metric reduction over the first ``n_valid`` samples only (an evaluation batch whose tail
         was filled by wrapping around: the duplicates must not enter val_loss / dice - Keras evaluates a short last batch
-        as it is).  Samples are the slowest dimension of every tensor, so the real ones are a prefix of the element range."""
+        as it is).  Samples are the slowest dimension of every tensor, so the real ones are a prefix of the element range.
+        ``stp_lovasz_hinge`` ADDS its term to the scalars the first launch wrote, so it is re-run after it with
+        ``images = n_valid`` (its third argument)."""
         n_valid = int(n_valid)
         if not 0 < n_valid <= self.N:
             raise ValueError("n_valid out of range")
         st = torch.cuda.current_stream().cuda_stream
+        done = False
         for fn, args, name, _meta in self.fwd:
-            if name in self.LOSS_LAUNCHES:
+            if name in self.LOSS_LAUNCHES and not done:
                 a = list(args)
                 a[2] = args[2] // self.N * n_valid        # element / pixel count: [N, ...] -> [n_valid, ...]
                 _lib.check(fn(*a, st), name)
-                return
-        raise _lib.StpError("the plan has no loss launch")
+                done = True
+            elif name == "stp_lovasz_hinge" and done:
+                a = list(args)
+                a[2] = n_valid                            # images
+                _lib.check(fn(*a, st), name)
+        if not done:
+            raise _lib.StpError("the plan has no loss launch")
 
     def _side_stream(self):
         if self._side is None:

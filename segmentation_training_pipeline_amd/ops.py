@@ -80,6 +80,41 @@ def conv2d_wgrad_reduce(p, workspace, variant=0):
     _lib.check(_lib.load().stp_conv2d_wgrad_reduce(C.byref(p), ptr(workspace), variant, stream()), "stp_conv2d_wgrad_reduce")
 
 
+class WgradGroup(object):
+    """Descriptor table of a grouped weight gradient (stp_wgrad_group_*): built from the layers' parameter blocks once their
+    device pointers are final; holds the host table, its device copy and the partial-slab workspace."""
+
+    def __init__(self, params, device="cuda"):
+        lib = _lib.load()
+        self.params = list(params)
+        n = len(self.params)
+        self.arr = (C.POINTER(_lib.WgradParams) * n)(*[C.pointer(p) for p in self.params])
+        tb = int(lib.stp_wgrad_group_table_bytes(self.arr, n))
+        wsb = int(lib.stp_wgrad_group_workspace_bytes(self.arr, n))
+        if tb <= 0 or wsb <= 0:
+            raise _lib.StpError("the layers do not form a weight-gradient group")
+        self.host = (C.c_char * tb)()
+        _lib.check(lib.stp_wgrad_group_build(self.arr, n, C.addressof(self.host), tb), "stp_wgrad_group_build")
+        self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
+        self.ws = torch.empty(wsb // 4, dtype=torch.float32, device=device)
+        self.header = list((C.c_int32 * 12).from_buffer_copy(bytes(self.host)[:48]))   # magic, bm, layers, segments, workgroups, tiles, ...
+
+    def partial(self):
+        _lib.check(_lib.load().stp_wgrad_group_partial(C.addressof(self.host), self.dev.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4, stream()),
+                   "stp_wgrad_group_partial")
+
+    def reduce(self):
+        _lib.check(_lib.load().stp_wgrad_group_reduce(C.addressof(self.host), self.dev.data_ptr(), self.ws.data_ptr(), stream()), "stp_wgrad_group_reduce")
+
+    def run(self):
+        self.partial()
+        self.reduce()
+
+
+def wgrad_group_class(p):
+    return int(_lib.load().stp_wgrad_group_class(C.byref(p)))
+
+
 def weight_prepare(master, fwd, bwd, Cout, KH, KW, Cin, KWp, Cinp, CoutB, dtype):
     _lib.call("stp_weight_prepare", ptr(master), ptr(fwd), ptr(bwd), Cout, KH, KW, Cin, KWp, Cinp, CoutB, dtype, stream())
 

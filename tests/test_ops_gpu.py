@@ -630,6 +630,61 @@ def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
         np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
 
 
+# (n, h, w, c0, c1 (c1 > 0: src0 is nearest-2x upsampled and concatenated with a c1-channel skip), cout) per layer; one class per group
+WGRAD_GROUPS = {
+    "class128": [(2, 32, 32, 128, 0, 128), (1, 16, 64, 256, 0, 72), (3, 16, 16, 192, 0, 200), (2, 8, 8, 128, 64, 136), (1, 4, 192, 64, 0, 128)],
+    "class64": [(2, 32, 32, 64, 0, 64), (2, 4, 16, 64, 0, 40), (2, 4, 32, 128, 64, 64)],
+    "class32": [(2, 32, 32, 64, 0, 32), (1, 4, 32, 64, 64, 24), (1, 16, 64, 128, 0, 16)],
+    "one_layer": [(4, 32, 32, 128, 0, 256)],
+}
+
+
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("group", sorted(WGRAD_GROUPS))
+def test_grouped_weight_gradient(ops, dtype, group):
+    """stp_wgrad_group_*: one partial + one reduce launch for several row-of-taps layers (work list cut into one chunk per
+    workgroup slot) against the numpy oracle, layer by layer; replay is bit-identical; accumulate; foreign layers are refused."""
+    rng = np.random.RandomState(11)
+    layers, refs, dws = [], [], []
+    for n, h, w, c0, c1, co in WGRAD_GROUPS[group]:
+        up = c1 > 0
+        x = q(rng.randn(n, h, w, c0), dtype)
+        H, W_ = (2 * h, 2 * w) if up else (h, w)
+        skip = q(rng.randn(n, H, W_, c1), dtype) if up else None
+        dy = q(rng.randn(n, H, W_, co), dtype)
+        v = np.concatenate([np_ops.upsample2x(x), skip], axis=-1) if up else x
+        refs.append(np_ops.conv2d_wgrad(v, dy, (3, 3), 1, 1))
+        dw = torch.full((co, 3, 3, c0 + c1), float("nan"), dtype=torch.float32, device=DEV)
+        dws.append(dw)
+        layers.append(ops.wgrad_params(dev(x, dtype), dev(dy, dtype), dw, N=n, Hs0=h, Ws0=w, Hv=H, Wv=W_, C0=c0, C1=c1,
+                                       src1=dev(skip, dtype) if up else None, mode=ops.SRC_NEAREST2X if up else ops.SRC_DIRECT, KH=3, KW=3,
+                                       stride=1, pad=1, Ho=H, Wo=W_, Cout=co, dtype=ops.dt(dev(x, dtype))))
+    want = {"class128": 128, "class64": 64, "class32": 32, "one_layer": 128}[group]
+    assert [ops.wgrad_group_class(p) for p in layers] == [want] * len(layers)
+    g = ops.WgradGroup(layers)
+    magic, bm, nl, nseg, nwg, ntile = g.header[:6]
+    assert (bm, nl) == (want, len(layers)) and nseg >= ntile >= nl and 0 < nwg <= nseg
+    g.run()
+    first = [host(dw).copy() for dw in dws]
+    for dw, ref in zip(first, refs):
+        np.testing.assert_allclose(dw.transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
+    g.run()                                         # same table, same partition: bit-identical
+    for dw, a in zip(dws, first):
+        assert np.array_equal(host(dw), a)
+    for p in layers:
+        p.accumulate = 1
+    g2 = ops.WgradGroup(layers)
+    g2.run()
+    for dw, ref in zip(dws, refs):
+        np.testing.assert_allclose(host(dw).transpose(1, 2, 3, 0), 2 * ref, atol=tol(ref, dtype, 2))
+    # a layer of another class, or one the row-of-taps kernel does not take, cannot join
+    odd = ops.wgrad_params(dev(np.zeros((1, 16, 16, 32)), dtype), dev(np.zeros((1, 16, 16, 64)), dtype), dws[0], N=1, Hs0=16, Ws0=16, Hv=16, Wv=16,
+                           C0=32, KH=3, KW=3, stride=1, pad=1, Ho=16, Wo=16, Cout=64, dtype=ops.dt(dev(np.zeros(1), dtype)))
+    assert ops.wgrad_group_class(odd) == 0
+    with pytest.raises(Exception):
+        ops.WgradGroup(layers + [odd])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("C", [16, 64, 768])
 def test_batchnorm_train_forward_backward(ops, dtype, C):
