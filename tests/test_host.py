@@ -422,30 +422,62 @@ def test_plan_structure_matches_unet_resnet34():
     # statistics from the epilogue of the conv that produces their input
     assert names.count("stp_conv2d") == 48 and names.count("stp_bn_stats") == 2 and names.count("stp_bn_finalize") == 43
     bnames = [n for _, _, n, _ in plan.bwd]
-    assert bnames.count("stp_conv2d_wgrad") == 48 and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
-    assert bnames.count("stp_conv2d_wgrad_reduce") == 48
+    # weight gradients: the row-of-taps layers (3x3 / stride 1, 64-channel blocks, maps of 16+ columns) are collected into
+    # grouped launches (stp_wgrad_group_*: consecutive eligible layers of one class), the others are launched alone
+    grouped = sum(len(names_) for names_, _ in plan.wgroups)
+    assert grouped == 9 and [c for _, c in plan.wgroups] == [32, 64, 64]       # at 64 px only the 16- / 32- / 64-pixel maps qualify
+    assert bnames.count("stp_wgrad_group_partial") == bnames.count("stp_wgrad_group_reduce") == len(plan.wgroups) == 3
+    assert bnames.count("stp_conv2d_wgrad") == 48 - grouped and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
+    assert bnames.count("stp_conv2d_wgrad_reduce") == 48 - grouped
     # BatchNormalization outputs read by exactly one convolution get their backward sums from that convolution's
     # data-gradient epilogue: 16 bn2 + 12 bn1 of the non-first units + 5 decoder bn1 + the last decoder bn2, plus
     # decoder_stage3_bn2 whose consumer's data-gradient folds the UpSampling2D gradient (dst_sum2x2, small-channel kernel);
     # and the bn1 of the four stage-first units (read by the shortcut, conv1 and - stages 2..4 - a decoder concat): the last
     # data gradient to arrive accumulates on top of the others and reduces the sums of the complete gradient
-    assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward") == 44
+    assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward_fused_add") + bnames.count("stp_bn_backward") == 44
     # ... and the four BN outputs whose gradient is completed by an UpSampling2D gradient (bn1, decoder_stage0..2_bn2: their
     # consumer concatenates a skip, so the fold does not apply): stp_upsample2x_bwd_bn masks and reduces in the same pass.
     # bn0 is completed by the max-pool gradient; stp_maxpool3x3s2_bwd_bn can fuse that too but measured slower than the pair
     # (opt-in: STP_FUSE_POOL_BN=1), so bn0 keeps the two-pass stp_bn_backward.
-    assert bnames.count("stp_bn_backward_fused") == 43 and bnames.count("stp_maxpool3x3s2_bwd_bn") == 0
+    # (stp_bn_backward_fused_add: the bn1 of a non-first unit accumulates onto the residual gradient, which is the dY of a convolution
+    # whose weight gradient waits in a pending group - the sum goes to a fresh buffer, that dY stays intact)
+    assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward_fused_add") == 43 and bnames.count("stp_maxpool3x3s2_bwd_bn") == 0
+    assert bnames.count("stp_bn_backward_fused_add") == 2              # stage1_unit3 / unit2 bn1 (the 16-pixel maps of stage 1 are grouped)
     assert bnames.count("stp_upsample2x_bwd_bn") == 4 and bnames.count("stp_upsample2x_bwd") == 0    # 5 decoder stages, one folded
-    # weight-gradient chains run on the side stream: one fork per trainable convolution, joins at the next one
-    assert bnames.count("fork") == 48 and bnames.count("join") == 48
+    # stream markers (honoured only with STP_SIDE_STREAM_WGRAD=1): one fork per per-layer chain and per group, a join at every convolution
+    assert bnames.count("fork") == 48 - grouped + 3 and bnames.count("join") == 48
     assert "stp_add_inplace" not in bnames                             # every residual gradient aliases
     fl = sum(m["flops"] for _, _, _, m in plan.fwd if m)
     assert abs(fl / 2 / (2 * 1e6) - 31323 * (64 * 64) / (512 * 512)) < 2.0   # 31.3 GMAC/img at 512^2
     frozen = graph.Plan(2, "fp32", "cpu", training=True)
     frozen.frozen_prefixes = nets.ENCODER_PREFIXES
     frozen.define(lambda p: nets.unet_resnet(p, "resnet18", 64, 64))
-    fb = [m["layer"] for _, _, n, m in frozen.bwd if n == "stp_conv2d_wgrad"]
+    fb = [m["layer"] for _, _, n, m in frozen.bwd if n == "stp_conv2d_wgrad"] + [l for names_, _ in frozen.wgroups for l in names_]
     assert fb and all(l.startswith("decoder_") or l.startswith("final_") for l in fb)
+
+
+def test_weight_gradient_groups_of_the_headline_workload():
+    """U-Net/ResNet34 512x512 bs16 (BASELINE configs[1]): 35 of the 48 weight gradients run in 6 grouped launches - one per stage
+    (consecutive row-of-taps layers of one class, cut at the stride-2 / 1x1 layers) - the arena fills from its tail as before."""
+    plan = graph.Plan(16, "bf16", "cpu", training=True)
+    plan.define(lambda p: nets.unet_resnet(p, "resnet34", 512, 512))
+    got = [(c, len(n), n[0], n[-1]) for n, c in plan.wgroups]
+    assert got == [(32, 1, "decoder_stage3_conv1", "decoder_stage3_conv1"), (64, 2, "decoder_stage2_conv2", "decoder_stage2_conv1"),
+                   (128, 9, "decoder_stage1_conv2", "stage4_unit1_conv2"), (128, 11, "stage3_unit6_conv2", "stage3_unit1_conv2"),
+                   (128, 7, "stage2_unit4_conv2", "stage2_unit1_conv2"), (64, 6, "stage1_unit3_conv2", "stage1_unit1_conv1")]
+    bnames = [n for _, _, n, _ in plan.bwd]
+    assert bnames.count("stp_conv2d_wgrad") == 12 and bnames.count("stp_wgrad_group_partial") == 6
+    assert bnames.count("stp_bn_backward_fused_add") == 12 and "stp_add_inplace" not in bnames      # 12 non-first units
+    assert plan.bwd_monotone
+    lows = [low for _, low in plan.bwd_marks]
+    assert lows == sorted(lows, reverse=True) and lows[-1] == 0
+    # every group's table: all workgroup slots used, 1-3 partial slabs per tile
+    import ctypes
+    for fn, args, name, meta in plan.bwd:
+        if name == "stp_wgrad_group_partial":
+            magic, bm, nl, nseg, nwg, ntile = list((ctypes.c_int32 * 6).from_address(args[0]))
+            assert bm == meta["bm"] and nl == len(meta["layers"]) and ntile <= nseg <= 3 * ntile + nwg
+            assert nwg <= 256 * {128: 2, 64: 3, 32: 4}[bm]
 
 
 def test_simple_png_mask_dataset(tmp_path):
