@@ -487,8 +487,12 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
 #endif
 }
 
+// 64-channel tiles of 16 x 16 pixels: one slab + the ring = 76 KB, so TWO workgroups fit a CU - if the kernel stays within 128 registers
+// (4 waves per SIMD).  Left to itself the allocator took 139 and every CU ran one workgroup at a time (stage 1: 1024 tiles in four
+// rounds instead of two).
+#define HALO_MIN_WAVES(TH, BM) ((TH) == 16 && (BM) == 64 ? 4 : 1)
 template <int TH, int BM, int WM, int WN, int EP>
-__global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false>(a); }
+__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false>(a); }
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512) void conv_halo_pbn_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, true>(a); }
 

@@ -709,13 +709,24 @@ struct WgLayer {
   int accumulate, tile0, pad0, pad1;
 };
 struct WgSeg { int layer, tile, step0, step1, slot, pad0, pad1, pad2; };
-struct WgTile { int layer, t, slot0, nslots; };
+struct WgTile { int layer, t, list0, nslots; };        // the tile's partial slabs: slot_list[list0 .. list0 + nslots), in line order
 struct WgGroupHeader {
   int magic, bm, n_layers, n_segs, n_wg, n_tiles;
   int off_layers, off_segs, off_first, off_tiles;      // byte offsets from the start of the table
-  int total_bytes, pad0;
+  int total_bytes, off_slots;
+  int reduce_lanes, xcd, pad1, pad2;                    // lanes per element of the reduce launch (1 or 4); xcd: contiguous line runs per XCD
 };
 #define WG_GROUP_MAGIC 0x57474733
+
+// dword-wise copy of a descriptor through the constant address space (scalar, invariant loads)
+template <typename T> __device__ __forceinline__ void load_constant(T& dst, const T* src) {
+  static_assert(sizeof(T) % 4 == 0, "dwords");
+  typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
+  const cptr_t q = (cptr_t)(reinterpret_cast<const uint32_t*>(src));
+  uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = q[i];
+}
 
 template <int BM, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(256) void conv_wgrad_row_group_kernel(const char* __restrict__ table, f32x4* __restrict__ slabs) {
@@ -725,27 +736,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_group_kernel(const char* _
   const int* const first = reinterpret_cast<const int*>(table + hd->off_first);
   // consecutive block ids round-robin over the XCDs: give every XCD one contiguous run of the line (the tiles of a layer read
   // the same dY / x pixels at the same time: they meet in one L2)
-  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  // hd->xcd: 0 = identity (line neighbours on different XCDs), 1 = one contiguous run of the line per XCD, G >= 2 = runs of G line
+  // neighbours per XCD, the runs dealt round-robin (G workgroups share their operands in one L2, no more: 64 workgroups fetching the
+  // same lines at the same time from ONE L2 measured slower for the 512-channel layers)
+  int w = blockIdx.x;
+  if (hd->xcd == 1) {
+    w = xcd_remap(blockIdx.x, gridDim.x);
+  } else if (hd->xcd >= 2) {
+    const int G = hd->xcd, nmain = (int)gridDim.x / (8 * G) * (8 * G);
+    if ((int)blockIdx.x < nmain) {
+      const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+      w = ((j / G) * 8 + x) * G + (j % G);
+    }
+  }
   const int s0 = __builtin_amdgcn_readfirstlane(first[w]), s1 = __builtin_amdgcn_readfirstlane(first[w + 1]);
   for (int s = s0; s < s1; ++s) {
-    const WgSeg sg = segs[s];
+    // The descriptors are read through the CONSTANT address space: invariant scalar loads the compiler may hoist out of the step
+    // loop and keep in SGPRs, as it does for kernel arguments.  Through a global pointer every `memory`-clobbering s_waitcnt of the
+    // loop forced a reload (s_load + lgkmcnt(0) in every step, which also drains the fragment reads: -17 % on the first build).
+    WgSeg sg;
+    load_constant(sg, segs + s);
+    WgradArgs a;
+    load_constant(a, &layers[sg.layer].a);
     if (s != s0) __syncthreads();        // the previous segment's last fragment reads precede this segment's first LDS-DMA
-    conv_wgrad_row_body<BM, WM, WN, STAGES, false>(layers[sg.layer].a, sg.tile, sg.step0, sg.step1, slabs + (size_t)sg.slot * (BM * 192 / 4));
+    conv_wgrad_row_body<BM, WM, WN, STAGES, false>(a, sg.tile, sg.step0, sg.step1, slabs + (size_t)sg.slot * (BM * 192 / 4));
   }
 }
 
-// sum of a tile's partial slabs in line order, scattered into dW (the element decode of wgrad_reduce_row_kernel)
-template <int BM, int WM, int WN>
+// sum of a tile's partial slabs in line order, scattered into dW (the element decode of wgrad_reduce_row_kernel).  SL lanes walk the
+// slab list of an element in parallel (fixed assignment, fixed-shape LDS tree: deterministic) - stage-1 tiles have 40+ slabs.
+template <int BM, int WM, int WN, int SL>
 __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const char* __restrict__ table, const f32x4* __restrict__ slabs) {
-  constexpr int TM = BM / WM / 16, TN = 192 / WN / 16, PER = BM * 192 / 4, BPT = PER / 256;
-  static_assert(PER % 256 == 0, "whole blocks per tile");
+  constexpr int TM = BM / WM / 16, TN = 192 / WN / 16, PER = BM * 192 / 4, EPB = 256 / SL, BPT = PER / EPB;
+  static_assert(PER % EPB == 0, "whole blocks per tile");
+  __shared__ f32x4 sh[SL][EPB];
   const WgGroupHeader* const hd = reinterpret_cast<const WgGroupHeader*>(table);
   const WgLayer* const layers = reinterpret_cast<const WgLayer*>(table + hd->off_layers);
+  const int* const slot_list = reinterpret_cast<const int*>(table + hd->off_slots);
   const WgTile tl = reinterpret_cast<const WgTile*>(table + hd->off_tiles)[blockIdx.x / BPT];
-  const int e = (blockIdx.x % BPT) * 256 + threadIdx.x;
-  const f32x4* p = slabs + (size_t)tl.slot0 * PER + e;
-  f32x4 s = p[0];
-  for (int k = 1; k < tl.nslots; ++k) s += p[(size_t)k * PER];
+  const int ev = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+  const int e = (blockIdx.x % BPT) * EPB + ev;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int k = sl; k < tl.nslots; k += SL) s += slabs[(size_t)slot_list[tl.list0 + k] * PER + e];
+  if (SL > 1) {
+    sh[sl][ev] = s;
+    __syncthreads();
+#pragma unroll
+    for (int w = SL / 2; w > 0; w >>= 1) {
+      if (sl < w) sh[sl][ev] += sh[sl + w][ev];
+      __syncthreads();
+    }
+    s = sh[0][ev];
+    if (sl != 0) return;
+  }
   const WgLayer& L = layers[tl.layer];
   const int lane = e & 63, lr = lane & 15, lg = lane >> 4;
   int q = e >> 6;
@@ -1104,11 +1147,12 @@ static int wg_group_bm(const stp_wgrad_params* p) {
 extern "C" int stp_wgrad_group_class(const stp_wgrad_params* p) { return wg_group_bm(p); }
 
 struct WgGroupPlan {
-  int bm = 0;
+  int bm = 0, max_slots_per_tile = 1;
   std::vector<int> ntile_m, ntile_n, nsteps, tile0;
   std::vector<WgSeg> segs;
   std::vector<int> first;
   std::vector<WgTile> tiles;
+  std::vector<int> slot_list;
 };
 
 static int wg_group_slots(int bm) {
@@ -1118,6 +1162,10 @@ static int wg_group_slots(int bm) {
   return cus * (bm == 128 ? 2 : bm == 64 ? 3 : 4);     // co-resident workgroups: 77 KB of LDS / 224 registers at 128 channels, 52 KB / 144 and 40 KB / 114 below
 }
 
+// The line: layer-major; inside a layer RANGE-major (a range = ~one workgroup chunk of steps), tile-minor - the tiles of a layer over
+// the same pixel range are neighbours on the line, i.e. run at the same time on the same XCD (contiguous runs of the line per XCD)
+// and share dY / x through its L2.  With the tile-major line of the first build a stage-1 layer (3 tiles x 4096 steps) put 43
+// workgroups on 43 different pixel ranges of one tile: every operand byte came from HBM three times (541 TFLOP/s, 5.9 TB/s).
 static int wg_group_plan(const stp_wgrad_params* const* L, int n, WgGroupPlan& g) {
   if (!L || n <= 0) return STP_E_BADARG;
   g.bm = wg_group_bm(L[0]);
@@ -1133,32 +1181,49 @@ static int wg_group_plan(const stp_wgrad_params* const* L, int n, WgGroupPlan& g
     total += (int64_t)tm * tn * ns;
   }
   const int slots = wg_group_slots(g.bm);
-  const int MINSEG = 8;       // no segment shorter than this unless its tile is (a 3-stage pipeline fill + a slab per segment)
+  const int MINSEG = 8;       // no segment shorter than this unless its item is (a 3-stage pipeline fill + a slab per segment)
   int64_t chunk = (total + slots - 1) / slots;
   if (chunk < 2 * MINSEG) chunk = 2 * MINSEG;
+  std::vector<std::vector<int>> lists;
   for (;; ++chunk) {
-    g.segs.clear(); g.first.clear(); g.tiles.clear();
-    int l = 0, t = 0, s = 0;
+    g.segs.clear(); g.first.clear();
+    lists.assign(ntiles, std::vector<int>());
+    // items of the line: (layer, range, tile) -> steps [r * R, min(ns, (r + 1) * R))
+    int l = 0, r = 0, t = 0, s = 0;
+    auto ranges_of = [&](int l_) { int64_t nr = (g.nsteps[l_] + chunk / 2) / chunk; return (int)(nr < 1 ? 1 : nr); };
+    auto rlen_of = [&](int l_) { return ceil_div(g.nsteps[l_], ranges_of(l_)); };
     while (l < n) {
       g.first.push_back((int)g.segs.size());
       int64_t rem = chunk;
       int mine = 0;
       while (rem > 0 && l < n) {
-        const int avail = g.nsteps[l] - s;
+        const int R = rlen_of(l), i0 = r * R, i1 = (i0 + R < g.nsteps[l]) ? i0 + R : g.nsteps[l];
+        const int avail = i1 - i0 - s;
         int take = (int)(rem < avail ? rem : avail);
-        if (avail - take > 0 && avail - take < MINSEG) take = avail;             // do not leave a sliver of the tile behind
+        if (avail - take > 0 && avail - take < MINSEG) take = avail;             // do not leave a sliver of the item behind
         if (take < MINSEG && take < avail && mine > 0) break;                     // a sliver at the end of the chunk: the next workgroup takes it
-        WgSeg sg = {l, t, s, s + take, (int)g.segs.size(), 0, 0, 0};
-        if (s == 0) g.tiles.push_back(WgTile{l, t, sg.slot, 1}); else g.tiles.back().nslots++;
+        WgSeg sg = {l, t, i0 + s, i0 + s + take, (int)g.segs.size(), 0, 0, 0};
+        lists[g.tile0[l] + t].push_back(sg.slot);
         g.segs.push_back(sg);
         ++mine;
         rem -= take; s += take;
-        if (s == g.nsteps[l]) { s = 0; if (++t == g.ntile_m[l] * g.ntile_n[l]) { t = 0; ++l; } }
+        if (s == i1 - i0) {
+          s = 0;
+          if (++t == g.ntile_m[l] * g.ntile_n[l]) { t = 0; if (++r == ranges_of(l)) { r = 0; ++l; } }
+        }
       }
     }
     g.first.push_back((int)g.segs.size());
     if ((int)g.first.size() - 1 <= slots) break;       // (slivers moved between neighbours can cost one workgroup more than the slots)
   }
+  g.tiles.clear(); g.slot_list.clear(); g.max_slots_per_tile = 1;
+  for (int l = 0; l < n; ++l)
+    for (int t = 0; t < g.ntile_m[l] * g.ntile_n[l]; ++t) {
+      const std::vector<int>& v = lists[g.tile0[l] + t];
+      g.tiles.push_back(WgTile{l, t, (int)g.slot_list.size(), (int)v.size()});
+      g.slot_list.insert(g.slot_list.end(), v.begin(), v.end());
+      if ((int)v.size() > g.max_slots_per_tile) g.max_slots_per_tile = (int)v.size();
+    }
   return STP_OK;
 }
 
@@ -1168,7 +1233,7 @@ extern "C" size_t stp_wgrad_group_table_bytes(const stp_wgrad_params* const* lay
   WgGroupPlan g;
   if (wg_group_plan(layers, n, g) != STP_OK) return 0;
   return wg_align16(sizeof(WgGroupHeader)) + wg_align16(sizeof(WgLayer) * n) + wg_align16(sizeof(WgSeg) * g.segs.size()) +
-         wg_align16(sizeof(int) * g.first.size()) + wg_align16(sizeof(WgTile) * g.tiles.size());
+         wg_align16(sizeof(int) * g.first.size()) + wg_align16(sizeof(WgTile) * g.tiles.size()) + wg_align16(sizeof(int) * g.slot_list.size());
 }
 
 extern "C" size_t stp_wgrad_group_workspace_bytes(const stp_wgrad_params* const* layers, int32_t n) {
@@ -1193,7 +1258,22 @@ extern "C" int stp_wgrad_group_build(const stp_wgrad_params* const* layers, int3
   hd.off_segs = (int)off; off += wg_align16(sizeof(WgSeg) * g.segs.size());
   hd.off_first = (int)off; off += wg_align16(sizeof(int) * g.first.size());
   hd.off_tiles = (int)off; off += wg_align16(sizeof(WgTile) * g.tiles.size());
+  hd.off_slots = (int)off; off += wg_align16(sizeof(int) * g.slot_list.size());
   hd.total_bytes = (int)off;
+  hd.reduce_lanes = g.max_slots_per_tile >= 12 ? 4 : 1;
+  {
+    static const int xcd_env = getenv("STP_WGRAD_GROUP_XCD") ? atoi(getenv("STP_WGRAD_GROUP_XCD")) : -1;
+    // measured per group (profiles/r03f_group_xcd_ab.txt, r03g_*): one contiguous run per XCD wins (stage 1: 140 vs 181 us, stage 3: 224
+    // vs 244) except where most of the work sits in layers of 64+ tiles over ONE pixel range (the 512-channel layers at 16 x 16 x 16:
+    // 96 tiles x 64 steps - an XCD's 64 workgroups then fetch the same lines at the same time: 275 vs 247 us) -> identity there
+    int64_t wide = 0, all = 0;
+    for (int l = 0; l < n; ++l) {
+      const int64_t wk = (int64_t)g.ntile_m[l] * g.ntile_n[l] * g.nsteps[l];
+      all += wk;
+      if (g.ntile_m[l] * g.ntile_n[l] >= 64) wide += wk;
+    }
+    hd.xcd = xcd_env >= 0 ? xcd_env : (2 * wide > all ? 0 : 1);
+  }
   memset(tb, 0, off);
   memcpy(tb, &hd, sizeof(hd));
   for (int l = 0; l < n; ++l) {
@@ -1212,6 +1292,7 @@ extern "C" int stp_wgrad_group_build(const stp_wgrad_params* const* layers, int3
   memcpy(tb + hd.off_segs, g.segs.data(), sizeof(WgSeg) * g.segs.size());
   memcpy(tb + hd.off_first, g.first.data(), sizeof(int) * g.first.size());
   memcpy(tb + hd.off_tiles, g.tiles.data(), sizeof(WgTile) * g.tiles.size());
+  memcpy(tb + hd.off_slots, g.slot_list.data(), sizeof(int) * g.slot_list.size());
   return STP_OK;
 }
 
@@ -1249,11 +1330,18 @@ extern "C" int stp_wgrad_group_reduce(const void* host_table, const void* dev_ta
   const WgGroupHeader* hd = wg_group_header(host_table);
   if (!hd || !dev_table || !workspace) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  const int bpt = hd->bm * 192 / 4 / 256;
+  const int sl = hd->reduce_lanes == 4 ? 4 : 1;
+  const int bpt = hd->bm * 192 / 4 / (256 / sl);
   const dim3 grid(hd->n_tiles * bpt);
-  if (hd->bm == 128) hipLaunchKernelGGL((wgrad_group_reduce_kernel<128, 2, 2>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);
-  else if (hd->bm == 64) hipLaunchKernelGGL((wgrad_group_reduce_kernel<64, 1, 4>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);
-  else hipLaunchKernelGGL((wgrad_group_reduce_kernel<32, 1, 4>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);
+#define STP_GROUP_REDUCE(BM_, WM_, WN_)                                                                                                     \
+  do {                                                                                                                                      \
+    if (sl == 4) hipLaunchKernelGGL((wgrad_group_reduce_kernel<BM_, WM_, WN_, 4>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace); \
+    else hipLaunchKernelGGL((wgrad_group_reduce_kernel<BM_, WM_, WN_, 1>), grid, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);         \
+  } while (0)
+  if (hd->bm == 128) STP_GROUP_REDUCE(128, 2, 2);
+  else if (hd->bm == 64) STP_GROUP_REDUCE(64, 1, 4);
+  else STP_GROUP_REDUCE(32, 1, 4);
+#undef STP_GROUP_REDUCE
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
