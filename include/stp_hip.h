@@ -282,6 +282,14 @@ int stp_bn_backward_fused(const void* x, const void* g, void* dx, int32_t dtype,
                           const float* mean, const float* rstd, const float* gamma, const float* partial, int32_t tiles,
                           float* dgamma, float* dbeta, int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* stp_bn_finalize + stp_bn_apply as ONE launch (16-bit dtype, C % 64 == 0, tiles <= 128; stp_bn_finalize_apply_ok tells): every
+ * workgroup of the apply pass owns a 64-channel slab x a chunk of rows and reduces the [2][64][tiles] partial sums of its slab
+ * itself (fp64, fixed order - all workgroups of a slab normalise with bit-identical constants), the first chunk of a slab also
+ * writes mean / rstd / the moving statistics.  stp_bn_backward_fused(_add) takes the same one-launch form where eligible. */
+int stp_bn_finalize_apply_ok(int32_t dtype, int64_t rows, int32_t C, int32_t tiles);
+int stp_bn_finalize_apply(const float* partial, int32_t tiles, const void* x, void* y, int32_t dtype, int64_t rows, int32_t C,
+                          float eps, float momentum, float* mean, float* rstd, float* moving_mean, float* moving_var,
+                          const float* gamma, const float* beta, int32_t relu, void* stream);
 /* the same with the accumulated addend in ANOTHER buffer: dx = result + dadd when accumulate_dx (dadd is left intact - a residual
  * gradient that a grouped weight gradient, stp_wgrad_group_partial, still reads as its dY); dadd == dx is the in-place form above */
 int stp_bn_backward_fused_add(const void* x, const void* g, void* dx, const void* dadd, int32_t dtype, int64_t rows, int32_t C,

@@ -5,8 +5,8 @@ from segmentation_training_pipeline_amd import ops
 DEV = "cuda"
 # name, n, h, w, ci, co, [old tile ids], [halo variants]
 LAYERS = [("stage1 64->64 @128", 16, 128, 128, 64, 64, [71], [2, 3, 4]),
-          ("stage2 128->128 @64", 16, 64, 64, 128, 128, [65], [0, 1]),
-          ("stage3 256->256 @32", 16, 32, 32, 256, 256, [70], [0, 1]),
+          ("stage2 128->128 @64", 16, 64, 64, 128, 128, [65], [0, 1, 2, 3]),
+          ("stage3 256->256 @32", 16, 32, 32, 256, 256, [70], [0, 1, 2, 3]),
           ("stage4 512->512 @16", 16, 16, 16, 512, 512, [133], [1, 3]),
           ("dec0c2 256->256 @32", 16, 32, 32, 256, 256, [70], [1]),
           ("dec1c1d 128->384 @64", 16, 64, 64, 128, 384, [65], [0, 1]),

@@ -92,6 +92,8 @@ SIGNATURES = {
     "stp_bn_backward_slots": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "stp_zero_bytes": (i32, [vp, i64, vp]),
     "stp_bn_backward_fused": (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "stp_bn_finalize_apply_ok": (i32, [i32, i64, i32, i32]),
+    "stp_bn_finalize_apply": (i32, [vp, i32, vp, vp, i32, i64, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "stp_bn_backward_fused_add": (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "stp_maxpool3x3s2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -4,6 +4,7 @@
 // deterministic run to run.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 #define BN_MAX_BLOCKS 1024
 #ifndef POOL_ROWS
@@ -840,6 +841,194 @@ extern "C" int stp_bn_backward(const void* x, const void* dy, void* dx, int32_t 
   return STP_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// FUSED finalize + apply (round 3).  The finalize launches (one workgroup per channel, ~5 us each: 86 per U-Net/ResNet34 step, pure
+// launch latency on the critical chain conv -> finalize -> apply -> conv) disappear where the partial table is small: a workgroup
+// of the apply pass owns a SLAB of 64 channels (128 bytes of every row: whole cache lines) x a chunk of rows, and first reduces the
+// [2][64][tiles] partial sums of its own slab - fp64, fixed order, the same for every workgroup of the slab, so all of them
+// normalise with bit-identical constants; the chunk-0 workgroup of a slab also publishes mean / rstd / moving statistics
+// (dgamma / dbeta in the backward form).  Each workgroup re-reads 512 x tiles bytes that sit in L2 - eligible while that is <= 64 KB.
+#define BNF_SLAB 64
+static bool bn_fused_ok(int dtype, int64_t rows, int C, int tiles) {
+  static const bool on = !(getenv("STP_BN_FUSE_FINALIZE") && atoi(getenv("STP_BN_FUSE_FINALIZE")) == 0);
+  // measured per shape (U-Net/ResNet34 bs16, eager launches, profiles/r03j_bn_fused_vs_separate.txt): 32 columns (stage 4) 8.1 vs 6.7 + 7.0 us
+  // forward and 7.7 vs 11.4 backward, 128 columns (stage 3) 10.4 vs 13.7 and 10.9 vs 12.5, 256 columns (stage 2: 128 KB of partial sums
+  // per workgroup, twice its own rows) 14.7 vs 16.0 and 17.8 vs 15.8 - the fused form stops at 128 columns
+  return on && dtype == STP_H16 && (C % BNF_SLAB) == 0 && tiles >= 1 && tiles <= 128 && rows >= 64;
+}
+static int bn_fused_chunks(int64_t rows, int C) {
+  // ~8 rows per thread once the CUs are covered (a thread owns 8 channels of a row: 32 rows per workgroup pass)
+  const int slabs = C / BNF_SLAB;
+  int64_t want = (rows + 255) / 256;              // 8 passes of 32 rows
+  const int64_t lo = (2 * 256 + slabs - 1) / slabs;
+  if (want < lo) want = lo;
+  const int64_t hi = (rows + 31) / 32;
+  if (want > hi) want = hi;
+  return (int)(want < 1 ? 1 : want);
+}
+
+// sum of partial[stat][c][0..tiles) for the 64 channels of the slab: 4 lanes per channel, fp64, fixed order; result in lanes j == 0
+__device__ __forceinline__ void bnf_slab_sums(const float* __restrict__ partial, int tiles, int C, int c0, double& s, double& q) {
+  const int cl = threadIdx.x >> 2, j = threadIdx.x & 3;
+  const float* ps = partial + (size_t)(c0 + cl) * tiles;
+  const float* pq = partial + ((size_t)C + c0 + cl) * tiles;
+  s = 0.0; q = 0.0;
+  if ((tiles & 3) == 0) {
+    for (int t = 4 * j; t < tiles; t += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ps + t), b = *reinterpret_cast<const f32x4*>(pq + t);
+      s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+      q += ((double)b.x + (double)b.y) + ((double)b.z + (double)b.w);
+    }
+  } else {
+    for (int t = j; t < tiles; t += 4) { s += (double)ps[t]; q += (double)pq[t]; }
+  }
+  s += __shfl_xor(s, 1, 64); q += __shfl_xor(q, 1, 64);
+  s += __shfl_xor(s, 2, 64); q += __shfl_xor(q, 2, 64);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ partial, int tiles, const bf16_t* __restrict__ x,
+                                                                bf16_t* __restrict__ y, int64_t rows, int C, int chunks, double inv_rows,
+                                                                double unbias, float eps, float momentum, float* mean, float* rstd,
+                                                                float* mm, float* mv, const float* gamma, const float* beta, int relu) {
+  __shared__ float tab[2][BNF_SLAB];
+  const int slab = blockIdx.x / chunks, chunk = blockIdx.x - slab * chunks, c0 = slab * BNF_SLAB;
+  {
+    double s, q;
+    bnf_slab_sums(partial, tiles, C, c0, s, q);
+    if ((threadIdx.x & 3) == 0) {
+      const int c = c0 + (threadIdx.x >> 2);
+      const double m = s * inv_rows;
+      double var = q * inv_rows - m * m;
+      if (var < 0.0) var = 0.0;
+      const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+      const float k = gamma ? rf * gamma[c] : rf;
+      tab[0][threadIdx.x >> 2] = k;
+      tab[1][threadIdx.x >> 2] = (beta ? beta[c] : 0.f) - mf * k;
+      if (chunk == 0) {
+        mean[c] = mf;
+        rstd[c] = rf;
+        if (mm) mm[c] = mm[c] * momentum + mf * (1.f - momentum);
+        if (mv) mv[c] = mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+      }
+    }
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = tab[0][cg * 8 + e]; sh[e] = tab[1][cg * 8 + e]; }
+  const int64_t per = (rows + chunks - 1) / chunks, ra = (int64_t)chunk * per, rb = ra + per < rows ? ra + per : rows;
+  const size_t col = (size_t)c0 + cg * 8;
+  auto one = [&](const u32x4 r) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = bn_act(bn_affine(h16lo_to_f32(r[e]), sc[2 * e], sh[2 * e]), relu);
+      const float hi = bn_act(bn_affine(h16hi_to_f32(r[e]), sc[2 * e + 1], sh[2 * e + 1]), relu);
+      o[e] = pack_bf16x2(lo, hi);
+    }
+    return o;
+  };
+  int64_t r = ra + r0;
+  for (; r + 96 < rb; r += 128) {       // four rows in flight per thread
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + (size_t)r * C + col), v1 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 32) * C + col);
+    const u32x4 v2 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 64) * C + col), v3 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 96) * C + col);
+    *reinterpret_cast<u32x4*>(y + (size_t)r * C + col) = one(v0);
+    *reinterpret_cast<u32x4*>(y + (size_t)(r + 32) * C + col) = one(v1);
+    *reinterpret_cast<u32x4*>(y + (size_t)(r + 64) * C + col) = one(v2);
+    *reinterpret_cast<u32x4*>(y + (size_t)(r + 96) * C + col) = one(v3);
+  }
+  for (; r < rb; r += 32) *reinterpret_cast<u32x4*>(y + (size_t)r * C + col) = one(*reinterpret_cast<const u32x4*>(x + (size_t)r * C + col));
+}
+
+extern "C" int stp_bn_finalize_apply_ok(int32_t dtype, int64_t rows, int32_t C, int32_t tiles) { return bn_fused_ok(dtype, rows, C, tiles) ? 1 : 0; }
+
+extern "C" int stp_bn_finalize_apply(const float* partial, int32_t tiles, const void* x, void* y, int32_t dtype, int64_t rows, int32_t C,
+                                     float eps, float momentum, float* mean, float* rstd, float* moving_mean, float* moving_var,
+                                     const float* gamma, const float* beta, int32_t relu, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;
+  if (!partial || !x || !y || !mean || !rstd || rows <= 0 || C <= 0 || !bn_fused_ok(dtype, rows, C, tiles)) return STP_E_BADARG;
+  const int chunks = bn_fused_chunks(rows, C);
+  const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3((C / BNF_SLAB) * chunks), dim3(256), 0, (hipStream_t)stream, partial, tiles, (const bf16_t*)x,
+                     (bf16_t*)y, rows, C, chunks, 1.0 / (double)rows, unbias, eps, momentum, mean, rstd, moving_mean, moving_var, gamma, beta, relu);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// backward form: dx = scale * (g - sum(g)/M - xhat * sum(g xhat)/M) (+ dadd); g already carries the activation mask
+__global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, int tiles, const bf16_t* __restrict__ x,
+                                                                    const bf16_t* __restrict__ g, bf16_t* dx, const bf16_t* dadd, int64_t rows, int C,
+                                                                    int chunks, float inv_rows, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma, float* dgamma,
+                                                                    float* dbeta) {
+  __shared__ float tab[4][BNF_SLAB];      // mean, rstd, scale * ... see below
+  const int slab = blockIdx.x / chunks, chunk = blockIdx.x - slab * chunks, c0 = slab * BNF_SLAB;
+  {
+    double s, q;
+    bnf_slab_sums(partial, tiles, C, c0, s, q);
+    if ((threadIdx.x & 3) == 0) {
+      const int cl = threadIdx.x >> 2, c = c0 + cl;
+      const float sf = (float)s, qf = (float)q;
+      tab[0][cl] = sf * inv_rows;
+      tab[1][cl] = qf * inv_rows;
+      tab[2][cl] = mean[c];
+      tab[3][cl] = rstd[c];
+      if (chunk == 0) {
+        if (dbeta) dbeta[c] = sf;
+        if (dgamma) dgamma[c] = qf;
+      }
+    }
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  float k1[8], k2[8], mu[8], rs[8], sc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    k1[e] = tab[0][cg * 8 + e]; k2[e] = tab[1][cg * 8 + e]; mu[e] = tab[2][cg * 8 + e]; rs[e] = tab[3][cg * 8 + e];
+    sc[e] = gamma ? rs[e] * gamma[c0 + cg * 8 + e] : rs[e];
+  }
+  const int64_t per = (rows + chunks - 1) / chunks, ra = (int64_t)chunk * per, rb = ra + per < rows ? ra + per : rows;
+  const size_t col = (size_t)c0 + cg * 8;
+  auto one = [&](size_t off, const float (&xv)[8], const float (&gv)[8], const float (&dv)[8]) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (xv[e] - mu[e]) * rs[e];
+      o[e] = sc[e] * (gv[e] - k1[e] - xh * k2[e]);
+      if (dadd) o[e] += dv[e];
+    }
+    stv<bf16_t, 8>(dx + off, o);
+  };
+  int64_t r = ra + r0;
+  for (; r + 32 < rb; r += 64) {          // two rows in flight per thread
+    const size_t o0 = (size_t)r * C + col, o1 = (size_t)(r + 32) * C + col;
+    float x0[8], g0[8], d0[8], x1[8], g1[8], d1[8];
+    ldv<bf16_t, 8>(x + o0, x0); ldv<bf16_t, 8>(x + o1, x1);
+    ldv<bf16_t, 8>(g + o0, g0); ldv<bf16_t, 8>(g + o1, g1);
+    if (dadd) { ldv<bf16_t, 8>(dadd + o0, d0); ldv<bf16_t, 8>(dadd + o1, d1); }
+    one(o0, x0, g0, d0);
+    one(o1, x1, g1, d1);
+  }
+  for (; r < rb; r += 32) {
+    const size_t o0 = (size_t)r * C + col;
+    float x0[8], g0[8], d0[8];
+    ldv<bf16_t, 8>(x + o0, x0); ldv<bf16_t, 8>(g + o0, g0);
+    if (dadd) ldv<bf16_t, 8>(dadd + o0, d0);
+    one(o0, x0, g0, d0);
+  }
+}
+
+static int bn_bwd_fused_launch(const void* x, const void* g, void* dx, const void* dadd, int64_t rows, int C, const float* mean, const float* rstd,
+                               const float* gamma, const float* partial, int tiles, float* dgamma, float* dbeta, int accumulate_dx, hipStream_t s) {
+  const int chunks = bn_fused_chunks(rows, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel, dim3((C / BNF_SLAB) * chunks), dim3(256), 0, s, partial, tiles, (const bf16_t*)x, (const bf16_t*)g,
+                     (bf16_t*)dx, accumulate_dx ? (const bf16_t*)dadd : (const bf16_t*)nullptr, rows, C, chunks, (float)(1.0 / (double)rows), mean, rstd,
+                     gamma, dgamma, dbeta);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // [2][C][tiles] epilogue partials -> sums (same contract as bn_bwd_finalize_kernel); one workgroup per channel
 __global__ __launch_bounds__(256) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, float* sums,
                                                                     float* dgamma, float* dbeta) {
@@ -897,6 +1086,8 @@ extern "C" int stp_bn_backward_fused_add(const void* x, const void* g, void* dx,
   if (!x || !g || !dx || (accumulate_dx && !dadd) || !mean || !rstd || !partial || !workspace || rows <= 0 || C <= 0 || (C & 3) || tiles <= 0) return STP_E_BADARG;
   if (workspace_bytes < stp_bn_workspace_bytes(C)) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  if (bn_fused_ok(dtype, rows, C, tiles))      // one launch: every workgroup reduces the partial sums of its own 64-channel slab
+    return bn_bwd_fused_launch(x, g, dx, dadd, rows, C, mean, rstd, gamma, partial, tiles, dgamma, dbeta, accumulate_dx, s);
   float* sums = (float*)workspace + (size_t)(BN_MAX_BLOCKS - 1) * 2 * C;
   hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(C), dim3(256), 0, s, partial, tiles, C, sums, dgamma, dbeta);
   STP_LAUNCH_CHECK();

@@ -178,6 +178,7 @@ class Plan(object):
         self.tensors = OrderedDict()
         net_fn(self)
         self._fuse_bn_into_consumers()
+        self._fuse_bn_finalize()
         self._finish_prep()
         if self.training:
             # bwd_marks[i] = (launches issued after the i-th backward closure, lowest gradient offset written so far):
@@ -371,6 +372,31 @@ class Plan(object):
                 out.append(r)
             flush()
             self.fwd = out
+
+    def _fuse_bn_finalize(self):
+        """stp_bn_finalize directly followed by the stp_bn_apply of the same BatchNormalization -> ONE stp_bn_finalize_apply launch where
+        the library takes it (16-bit dtype, whole 64-channel slabs, <= 128 partial-sum columns): the apply pass reduces the partial
+        sums of its own channel slab in its prologue, the single-workgroup-per-channel finalize launch (~5 us of latency on the
+        critical chain conv -> finalize -> apply -> conv) disappears.  The backward pair is merged inside stp_bn_backward_fused(_add)."""
+        if os.environ.get("STP_BN_FUSE_FINALIZE", "1") == "0":
+            return
+        out, i, fwd = [], 0, self.fwd
+        while i < len(fwd):
+            r = fwd[i]
+            nxt = fwd[i + 1] if i + 1 < len(fwd) else None
+            if (r[2] == "stp_bn_finalize" and nxt is not None and nxt[2] == "stp_bn_apply" and not (nxt[3] or {}).get("stream")
+                    and nxt[1][7] == r[1][6] and nxt[1][8] == r[1][7] and nxt[1][1] == nxt[1][3] == self.cdt and nxt[1][5] == nxt[1][6] == r[1][3]
+                    and nxt[1][12] == 0.0):
+                part, tiles, rows, Cn, eps, mom, mean, rstd, mm, mv = r[1]
+                x, _, y, _, rows2, _, _, _, _, gp, beta, relu, _ = nxt[1]
+                if rows2 == rows and int(self.lib.stp_bn_finalize_apply_ok(self.cdt, rows, Cn, tiles)):
+                    out.append((self.lib.stp_bn_finalize_apply, (part, tiles, x, y, self.cdt, rows, Cn, eps, mom, mean, rstd, mm, mv, gp, beta, relu),
+                                "stp_bn_finalize_apply", None))
+                    i += 2
+                    continue
+            out.append(r)
+            i += 1
+        self.fwd = out
 
     def tensor(self, name):
         """The named tensor with its buffer valid: a normalised tensor that only exists inside its consumers' staging is

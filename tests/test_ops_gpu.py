@@ -780,6 +780,75 @@ def test_batchnorm_backward_sums_fused_in_conv_epilogue(ops, dtype, case, relu):
     np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
 
 
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("case", [(4096, 128, 32), (640, 64, 5), (16384, 256, 128), (333, 192, 7), (2048, 512, 96)])
+def test_batchnorm_finalize_fused_into_the_apply_pass(ops, dtype, case):
+    """stp_bn_finalize_apply (one launch: every workgroup reduces the partial sums of its own 64-channel slab, then normalises its
+    rows) against stp_bn_finalize + stp_bn_apply; and the one-launch form of stp_bn_backward_fused_add - with the accumulated addend
+    in ANOTHER buffer, left intact - against the float64 formula."""
+    from segmentation_training_pipeline_amd import _lib
+    lib = _lib.load()
+    rows, C, tiles = case
+    rng = np.random.RandomState(rows + C)
+    x = q(rng.randn(rows, C) * 1.3 + 0.2, dtype)
+    bounds = np.linspace(0, rows, tiles + 1).astype(int)
+    part = np.zeros((2, C, tiles), np.float32)
+    for t in range(tiles):
+        blk = x[bounds[t]:bounds[t + 1]].astype(np.float64)
+        part[0, :, t], part[1, :, t] = blk.sum(0), (blk * blk).sum(0)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    gamma, beta = f(rng.rand(C) + 0.5), f(rng.randn(C) * 0.3)
+    xd, pd = dev(x, dtype), f(part)
+    assert lib.stp_bn_finalize_apply_ok(ops.dt(xd), rows, C, tiles) == 1
+    outs = []
+    for fused in (0, 1):
+        m, r = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        mm, mv = f(np.full(C, 0.25)), f(np.full(C, 2.0))
+        y = torch.full((rows, C), float("nan"), dtype=TD[dtype], device=DEV)
+        if fused:
+            _lib.call("stp_bn_finalize_apply", ops.ptr(pd), tiles, ops.ptr(xd), ops.ptr(y), ops.dt(xd), rows, C, 1e-3, 0.9, ops.ptr(m), ops.ptr(r),
+                      ops.ptr(mm), ops.ptr(mv), ops.ptr(gamma), ops.ptr(beta), 1, ops.stream())
+        else:
+            _lib.call("stp_bn_finalize", ops.ptr(pd), tiles, rows, C, 1e-3, 0.9, ops.ptr(m), ops.ptr(r), ops.ptr(mm), ops.ptr(mv), ops.stream())
+            ops.bn_apply(xd, y, rows, C, C, m, r, gamma, beta, relu=1)
+        outs.append([host(t) for t in (m, r, mm, mv, y)])
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        np.testing.assert_allclose(b, a, rtol=2e-6, atol=1e-7)
+    y0, y1 = outs[0][4], outs[1][4]
+    assert np.isfinite(y1).all()
+    np.testing.assert_allclose(y1, y0, atol=tol(y0, dtype, 0.6))        # (a constant one float ulp apart can flip a 16-bit rounding)
+    assert (y1 != y0).mean() < 2e-3
+    mean, rstd = outs[0][0].astype(np.float64), outs[0][1].astype(np.float64)
+    # backward: g is the masked gradient, partial its per-tile sums of g and g * xhat
+    g = q(rng.randn(rows, C), dtype)
+    add = q(rng.randn(rows, C), dtype)
+    xh = (x.astype(np.float64) - mean) * rstd
+    pb = np.zeros((2, C, tiles), np.float32)
+    for t in range(tiles):
+        sl = slice(bounds[t], bounds[t + 1])
+        pb[0, :, t], pb[1, :, t] = g[sl].astype(np.float64).sum(0), (g[sl] * xh[sl]).sum(0)
+    S, Q = pb[0].astype(np.float64).sum(1), pb[1].astype(np.float64).sum(1)
+    gm = host(gamma).astype(np.float64)
+    want = gm * rstd * (g - S / rows - xh * (Q / rows))
+    md, rd = f(mean), f(rstd)
+    ws = torch.empty(ops.bn_workspace_bytes(C) // 4, dtype=torch.float32, device=DEV)
+    gd, addd, pbd = dev(g, dtype), dev(add, dtype), f(pb)
+    for acc in (0, 1):
+        dx = torch.full((rows, C), float("nan"), dtype=TD[dtype], device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        _lib.call("stp_bn_backward_fused_add", ops.ptr(xd), ops.ptr(gd), ops.ptr(dx), ops.ptr(addd), ops.dt(xd), rows, C, ops.ptr(md), ops.ptr(rd),
+                  ops.ptr(gamma), ops.ptr(pbd), tiles, ops.ptr(dg), ops.ptr(db), acc, ops.ptr(ws), ws.numel() * 4, ops.stream())
+        ref = want + (add if acc else 0.0)
+        np.testing.assert_allclose(host(dx), ref, atol=tol(ref, dtype))
+        np.testing.assert_allclose(host(db), S, rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(host(dg), Q, rtol=1e-5, atol=1e-4)
+        assert np.array_equal(host(addd), add)                          # the addend is read, never written
+    # in place (dadd == dx): the form stp_bn_backward_fused keeps
+    dx = dev(add, dtype)
+    ops.bn_backward_fused(xd, gd, dx, rows, C, md, rd, gamma, pbd, tiles, dg, db, accumulate_dx=1, workspace=ws)
+    np.testing.assert_allclose(host(dx), want + add, atol=tol(want + add, dtype))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0), (2, 19, 45, 16, 16, 512), (2, 13, 9, 64, 24, 0), (3, 32, 32, 64, 512, 0)])
 def test_batchnorm_sums_in_fixed_point_slots(ops, dtype, case):
