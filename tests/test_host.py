@@ -420,7 +420,9 @@ def test_plan_structure_matches_unet_resnet34():
     names = [n for _, _, n, _ in plan.fwd]
     # the raw-image BN and the BN after the max-pool reduce on their own; the other 43 take their batch
     # statistics from the epilogue of the conv that produces their input
-    assert names.count("stp_conv2d") == 48 and names.count("stp_bn_stats") == 2 and names.count("stp_bn_finalize") == 43
+    # (where the partial table is small the finalize rides in the apply pass: stp_bn_finalize_apply)
+    assert names.count("stp_conv2d") == 48 and names.count("stp_bn_stats") == 2
+    assert names.count("stp_bn_finalize") + names.count("stp_bn_finalize_apply") == 43 and names.count("stp_bn_finalize_apply") >= 10
     bnames = [n for _, _, n, _ in plan.bwd]
     # weight gradients: the row-of-taps layers (3x3 / stride 1, 64-channel blocks, maps of 16+ columns) are collected into
     # grouped launches (stp_wgrad_group_*: consecutive eligible layers of one class), the others are launched alone
