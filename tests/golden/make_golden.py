@@ -82,10 +82,38 @@ def make_unet(backbone, size, n, fname, arch="Unet"):
     print(fname, "loss", o1["loss"], o2["loss"], "dice", o1["dice"])
 
 
+def make_unet_fullsize(fname="unet_resnet34_512_bs2.npz", size=512, n=2, stride=4):
+    """BASELINE.json configs[1]'s network at its real resolution (512 x 512; batch 2 keeps the CPU step in seconds): ONE training step
+    of the oracle.  The inputs are regenerated from the seed by the test (step.synthetic_batch), the logits are kept on a
+    stride-4 pixel grid (the full map is 2 MB), plus the scalars and every parameter's gradient norm."""
+    from oracle import nets, step
+    P = nets.init_unet_resnet("resnet34", seed=42)
+    tr = step.OracleTrainer(P, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss", optimizer="adam", lr=1e-3)
+    x, y = step.synthetic_batch(n, size, size, seed=1234)
+    o1 = tr.step(x.astype(np.float32), y.astype(np.float32))
+    names = list(o1["grads"].keys())
+    lg = o1["logits"].astype(np.float32)
+    np.savez_compressed(
+        os.path.join(HERE, fname), seed=42, data_seed=1234, size=size, n=n, stride=stride,
+        logits1_sampled=lg[:, ::stride, ::stride, :],
+        logits1_sum=np.float64(lg.astype(np.float64).sum()), logits1_abs_sum=np.float64(np.abs(lg.astype(np.float64)).sum()),
+        logits1_row_sums=lg.astype(np.float64).sum(axis=(2, 3)),
+        scalars1=np.array([o1[k] for k in ("loss", "bce", "dice_loss", "dice", "binary_accuracy")], np.float64),
+        grad_names=np.array(names),
+        grad_l2_step1=np.array([np.sqrt((o1["grads"][k].astype(np.float64) ** 2).sum()) for k in names]),
+        param_sum_after1=np.array([tr.P[k].astype(np.float64).sum() for k in names]),
+    )
+    print(fname, "loss", o1["loss"], "dice", o1["dice"], "logit range", lg.min(), lg.max())
+
+
 if __name__ == "__main__":
+    if "--fullsize-only" in sys.argv:
+        make_unet_fullsize()
+        sys.exit(0)
     make_rle()
     make_unet("resnet18", 64, 2, "unet_resnet18_64.npz")
     make_unet("resnet34", 64, 2, "unet_resnet34_64.npz")
     make_unet("resnet18", 64, 2, "linknet_resnet18_64.npz", arch="Linknet")
     make_unet("resnet18", 64, 2, "fpn_resnet18_64.npz", arch="FPN")
     make_unet("resnet18", 96, 2, "pspnet_resnet18_96.npz", arch="PSPNet")
+    make_unet_fullsize()

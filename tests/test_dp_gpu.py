@@ -70,3 +70,23 @@ def test_two_rank_fit_is_rank_consistent(tmp_path):
         rows = list(csv.DictReader(f))
     assert len(rows) == summ[0]["epochs_run"] and np.all(np.isfinite([float(r_["val_loss"]) for r_ in rows]))
     assert os.path.exists(str(tmp_path / "weights" / "best-0.1.weights"))
+
+
+def test_bench_two_ranks_on_one_gpu_prints_one_line():
+    """The driver's multi-GPU form of bench.py, dry-run with two ranks on ONE GPU (gloo instead of RCCL, which refuses duplicate
+    devices; the rank -> device map wraps around): exactly one JSON line, from rank 0, with the world size in it - so the first
+    8-GPU run is not the first time ``bench.py --gpus N`` executes."""
+    import json
+    env = dict(os.environ, STP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-kernel-profile"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 32
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak" and out["value"] > 0
+    assert "cpu_baseline" not in out and "roofline" not in out          # rank 0 at N = 1 only / --no-kernel-profile

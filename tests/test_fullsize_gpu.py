@@ -144,6 +144,37 @@ def test_headline_weight_gradient_layers(headline, layer, src, stride, pad):
     assert rel_l2(got, k.grad) < 2e-3
 
 
+@pytest.mark.parametrize("layer,src", [("stage3_unit4_conv2", "stage3_unit4_bn2"), ("stage1_unit2_conv2", "stage1_unit2_bn2"),
+                                       ("stage4_unit3_conv2", "stage4_unit3_bn2"), ("decoder_stage0_conv2", "decoder_stage0_bn1")])
+def test_headline_grouped_weight_gradients_of_residual_units(headline, layer, src):
+    """The conv2 of a residual unit: its dY is also the residual branch's gradient, which the next BatchNormalization backward
+    accumulates onto.  With the grouped weight gradients (one launch per stage, issued after the stage's last data gradient) that
+    accumulate goes to a fresh buffer (stp_bn_backward_fused_add), so the dY the grouped launch reads - and this test re-reads
+    after the step - is intact."""
+    m, w, g = headline
+    assert any(layer in names for names, _ in m.plan.wgroups)
+    ts = _Tensors(m.plan)
+    k = kernel(w, layer).requires_grad_(True)
+    F.conv2d(nchw(ts[src].buf), k, padding=1).backward(nchw(ts[layer].grad))
+    assert rel_l2(g[layer + "/kernel"].permute(3, 2, 0, 1), k.grad) < 2e-3
+
+
+@pytest.mark.parametrize("layer,low,skip", [("decoder_stage0_conv1", "bn1", "stage4_unit1_bn1"), ("decoder_stage1_conv1", "decoder_stage0_bn2", "stage3_unit1_bn1"),
+                                            ("decoder_stage2_conv1", "decoder_stage1_bn2", "stage2_unit1_bn1"), ("decoder_stage3_conv1", "decoder_stage2_bn2", "bn0")])
+def test_headline_two_source_weight_gradients(headline, layer, low, skip):
+    """Decoder conv1 = conv3x3(concat(UpSampling2D(2)(low), skip)): the row-of-taps kernel's two-source gather (the first source
+    nearest-2x upsampled) inside the grouped launches of classes 128 / 64 / 32, at the real sizes (58-77 GFLOP per layer)."""
+    m, w, g = headline
+    assert any(layer in names for names, _ in m.plan.wgroups)
+    ts = _Tensors(m.plan)
+    a = torch.cat([F.interpolate(nchw(ts[low].buf), scale_factor=2, mode="nearest"), nchw(ts[skip].buf)], dim=1)
+    k = kernel(w, layer).requires_grad_(True)
+    F.conv2d(a, k, padding=1).backward(nchw(ts[layer].grad))
+    assert rel_l2(g[layer + "/kernel"].permute(3, 2, 0, 1), k.grad) < 2e-3
+    del a
+    torch.cuda.empty_cache()
+
+
 def _bn_relu(x, gamma, beta, eps):
     mean = x.mean(dim=(0, 2, 3), keepdim=True)
     var = (x - mean).pow(2).mean(dim=(0, 2, 3), keepdim=True)

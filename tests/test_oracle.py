@@ -36,6 +36,19 @@ def test_oracle_matches_golden(golden_dir, arch, backbone, size):
     np.testing.assert_allclose(l2, g["grad_l2_step1"], rtol=1e-3, atol=1e-6)
 
 
+def test_oracle_matches_the_fullsize_golden(golden_dir):
+    """The 512 x 512 batch-2 fixture of BASELINE configs[1]'s network (one step, ~10 s of CPU): the oracle reproduces what it committed."""
+    g = np.load(os.path.join(golden_dir, "unet_resnet34_512_bs2.npz"))
+    size, n, stride = int(g["size"]), int(g["n"]), int(g["stride"])
+    tr = step.OracleTrainer(nets.init_unet_resnet("resnet34", seed=int(g["seed"])), backbone="resnet34",
+                            loss="binary_crossentropy+1.0*dice_loss", optimizer="adam", lr=1e-3)
+    x, y = step.synthetic_batch(n, size, size, seed=int(g["data_seed"]))
+    o1 = tr.step(x.astype(np.float32), y.astype(np.float32))
+    np.testing.assert_allclose([o1[k] for k in ("loss", "bce", "dice_loss", "dice", "binary_accuracy")], g["scalars1"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(o1["logits"][:, ::stride, ::stride, :], g["logits1_sampled"], atol=2e-4)
+    np.testing.assert_allclose(o1["logits"].astype(np.float64).sum(axis=(2, 3)), g["logits1_row_sums"], atol=2e-4 * size)
+
+
 def test_rle_golden_vectors_from_reference(golden_dir):
     """The in-repo RLE restatement against vectors produced by the reference's own rle.py."""
     from segmentation_pipeline.impl import rle
