@@ -124,7 +124,18 @@ typedef struct stp_conv_params {
    * low-resolution pixels, so with weight_up = [Cout_pad][4 classes][2][2][C0] (stp_weight_prepare_upcollapse: the 3x3 taps that
    * share a pixel summed) the K loop takes 4 x C0 + 9 x C1 instead of 9 x (C0 + C1) steps.  NULL: the plain gather. */
   const void* weight_up;
+  /* Data gradient of a 1x1 / stride-2 SHORTCUT folded into the data gradient of its sibling 3x3 / stride-2 / pad-1 convolution (both
+   * read the same tensor, ResNet basic block with a projection shortcut): in the parity-class order of that launch the shortcut
+   * touches only the (even, even) class, where it is one more tap - fold_src = dY of the shortcut ([N,Hs0,Ws0,fold_C], fold_C == C0),
+   * fold_weight = its data-gradient weight copy [round_up(Cout,16)][fold_C] (rows = channels of the shared input).  The K loop of
+   * that class runs fold_C / 64 more tiles; no separate launch reads and rewrites the whole gradient tensor.  Honoured only where
+   * stp_conv2d_fold_ok(p) != 0 (STP_E_BADARG otherwise). */
+  const void* fold_src;
+  const void* fold_weight;
+  int32_t fold_C;
 } stp_conv_params;
+/* 1: stp_conv2d(p) takes the parity-class path that honours fold_src / fold_weight / fold_C for this shape (p->fold_* need not be set). */
+int stp_conv2d_fold_ok(const stp_conv_params* p);
 
 int stp_conv2d(const stp_conv_params* p, void* stream);
 /* weight_up of stp_conv_params from the fp32 master [Cout][3][3][C0 + C1]: rows = Cout rounded up to 16 (zero rows behind Cout),
@@ -447,7 +458,10 @@ int stp_nadam(float* param, const float* grad, float* m, float* v, int64_t count
               float eps, float schedule_decay, int32_t* state, float* fstate, const uint8_t* mask, const float* gscale,
               float clipvalue, void* stream);
 /* gscale[0] = min(1, clipnorm / ||base*grad||_2) * base  (base = 1/world_size for summed data-parallel
- * gradients; deterministic two-stage reduction).  workspace >= 4 KiB. */
+ * gradients, times 1/loss_scale in fp16 mode; clipnorm <= 0: no clipping; deterministic two-stage reduction).  workspace >= 4 KiB.
+ * OVERFLOW GUARD: gscale is float[2]; when the squared norm is not finite (an inf / NaN anywhere in the arena - fp16 overflow
+ * under loss scaling) gscale[0] = -1 and gscale[1] is incremented, and every optimizer entry point (stp_adam, stp_sgd,
+ * stp_rmsprop, stp_nadam) given that gscale returns without touching parameters, moments or its step counter: the step is skipped. */
 int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, float base, float* gscale,
                           void* workspace, size_t workspace_bytes, void* stream);
 

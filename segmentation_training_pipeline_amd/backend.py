@@ -93,6 +93,10 @@ class HipSegModel(object):
         scalable = architecture != "DeepLabV3" and not (len(self.loss_w) == 6 and self.loss_w[5])      # (.., w_lovasz)
         if loss_scale is None:
             loss_scale = 16384.0 if (dtype == "fp16" and scalable) else 1.0
+            if dtype == "fp16" and not scalable:
+                import warnings
+                warnings.warn("fp16 storage without loss scaling: the losses on probabilities (DeepLabV3) and lovasz_loss have no scaled form, "
+                              "their 1/(N*H*W) gradients sit in fp16's subnormal range - use dtype bf16 for this model / loss", RuntimeWarning)
         self.loss_scale = float(loss_scale)
         if self.loss_scale <= 0:
             raise ValueError("loss_scale must be positive")
@@ -106,7 +110,8 @@ class HipSegModel(object):
         n = p.P.numel()
         self.lr = torch.tensor([float(lr)], dtype=torch.float32, device=self.device)
         self.opt_state = torch.zeros(2, dtype=torch.int32, device=self.device)
-        self.gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.gscale = torch.ones(2, dtype=torch.float32, device=self.device)       # [gradient scale (<= 0: skip the step), skipped steps]
+        self.gscale[1] = 0.0
         self.ws_norm = torch.empty(1024, dtype=torch.float32, device=self.device)
         self.m = self.v = self.vel = self.opt_fstate = None
         if self.optimizer in ("adam", "nadam"):
@@ -120,7 +125,7 @@ class HipSegModel(object):
         elif self.opt_kwargs.get("momentum", 0.0):
             self.vel = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.dp_scale = 1.0
-        self.gscale.fill_(1.0 / self.loss_scale)
+        self.gscale[0] = 1.0 / self.loss_scale
         self._build_opt(use_gscale=self.loss_scale != 1.0)
         self._infer = None
         self.init_weights(seed)
@@ -163,7 +168,7 @@ class HipSegModel(object):
         self._segments = None
         self._works = []
         self.dp_scale = float(reducer.scale)
-        self.gscale.fill_(self.dp_scale / self.loss_scale)
+        self.gscale[0] = self.dp_scale / self.loss_scale
         self._build_opt(use_gscale=True)
 
     def _build_opt(self, use_gscale=False):
@@ -172,10 +177,13 @@ class HipSegModel(object):
         p = self.plan
         p.opt = []
         n = p.P.numel()
-        if self.clipnorm > 0:
+        # clipnorm, and - whenever the loss is scaled (fp16) - the overflow guard: a non-finite gradient norm turns the step into a no-op
+        # (stp_grad_global_scale writes the skip marker; parameters, moments and the step counter stay as they were)
+        guard = self.loss_scale != 1.0
+        if self.clipnorm > 0 or guard:
             p._emit(p.opt, "stp_grad_global_scale", p.G.data_ptr(), n, self.clipnorm, getattr(self, "dp_scale", 1.0) / self.loss_scale,
                     self.gscale.data_ptr(), self.ws_norm.data_ptr(), self.ws_norm.numel() * 4)
-        gs = self.gscale.data_ptr() if (use_gscale or self.clipnorm > 0) else None
+        gs = self.gscale.data_ptr() if (use_gscale or self.clipnorm > 0 or guard) else None
         has_frozen = any(not i.trainable for i in p.params.values())
         mask = p.mask.data_ptr() if has_frozen else None
         kw = self.opt_kwargs
@@ -420,6 +428,11 @@ class HipSegModel(object):
         self.forward_backward()
         self.apply_gradients()
         return self.metrics() if fetch else None
+
+    @property
+    def skipped_steps(self):
+        """Optimizer steps skipped by the overflow guard (non-finite gradients under loss scaling) since the model was built."""
+        return int(self.gscale[1].item())
 
     def metrics(self):
         s = self.plan.loss_scalars.cpu().numpy()

@@ -60,6 +60,15 @@ template <typename V> __device__ __forceinline__ f32x4 mfma16_16x16x32(V a, V b,
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 #endif
+// v_mfma_f32_32x32x16 of the build's 16-bit storage format
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename V> __device__ __forceinline__ f32x16 mfma16_32x32x16(V a, V b, f32x16 c) {
+#if STP_STORAGE_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;

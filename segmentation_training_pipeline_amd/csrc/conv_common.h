@@ -33,6 +33,12 @@ struct ConvArgs {
   uint32_t byteswu;
   int upc, ucpt0, ucpt1;                          // K-tiles per collapsed tap (C0 / KE) and per src1 tap (C1 / KE)
   FastDiv divU0, divU1;
+  // folded shortcut data gradient (zperm launches): fold_cpt more K-tiles for the (even, even) class, read from fold_src at the
+  // centre tap with the rows of fold_weight ([wrows][C0])
+  const char* fold_src;
+  const char* fold_weight;
+  int fold_cpt;
+  uint32_t bytes_fold, bytesw_fold;
 };
 
 // logical (parity-class major) pixel -> n, ho, wo
@@ -140,9 +146,12 @@ __device__ __forceinline__ f32x4 unpack_bf16x4(const u32x2 r) {
 // A lane's accumulators are viewed as TM x TN fragments of 4 channels x 1 pixel; the 16 lanes of a DPP row hold 16 different
 // pixels of the same channels.  `vn` of WNN = which of the WNN groups of DPP rows that share this lane's channels (waves along
 // the pixel dimension, times the pixel halves inside a 32x32 MFMA tile), NT threads per workgroup.
+// prea (optional): the ACCUMULATE operands of dst0 (what the destination holds), fetched before the K loop like `pre` - the
+// parity-class data gradients that complete a multi-consumer gradient (accumulate0 + BatchNormalization-backward sums) otherwise
+// pay one dependent load round trip per fragment here.
 template <typename T, int TM, int TN, int BM, int WNN, int NT, bool PRE, typename PixF, typename CoF>
 __device__ __forceinline__ void epilogue_cf(const ConvArgs& a, int cout0, int vn, int lr, f32x4 (&acc)[TM][TN], char* smem,
-                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf, CoF cof) {
+                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf, CoF cof, const u32x2 (*prea)[TN] = nullptr) {
   const T* res = reinterpret_cast<const T*>(a.residual);
   float* red = reinterpret_cast<float*>(smem);  // [WN][BM][2], valid after the barrier below
   if (a.stats) __syncthreads();                 // the K-loop's LDS tiles are dead from here on
@@ -168,7 +177,10 @@ __device__ __forceinline__ void epilogue_cf(const ConvArgs& a, int cout0, int vn
           bool accum;
           if (co < a.Cd0) { d = reinterpret_cast<T*>(a.dst0) + (size_t)pm * a.Cd0 + co; accum = a.acc0; }
           else { d = reinterpret_cast<T*>(a.dst1) + (size_t)pm * a.Cd1 + (co - a.Cd0); accum = a.acc1; }
-          if (accum) v += load4(d);
+          if (accum) {
+            if (PRE && prea && co < a.Cd0) v += unpack_bf16x4(prea[i][j]);
+            else v += load4(d);
+          }
           if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           if (a.bnb.x) {
             f32x4 xv;
@@ -237,8 +249,8 @@ __device__ __forceinline__ void epilogue_cf(const ConvArgs& a, int cout0, int vn
 // 16x16 MFMA fragments: row i = channels cw + i*16 + (lane>>4)*4 .. +3, the wave index along pixels selects the reduction slot
 template <typename T, int TM, int TN, int BM, int WNN, int NT, bool PRE, typename PixF>
 __device__ __forceinline__ void epilogue_px(const ConvArgs& a, int cout0, int cw, int wn, int lr, int lg, f32x4 (&acc)[TM][TN], char* smem,
-                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf) {
-  epilogue_cf<T, TM, TN, BM, WNN, NT, PRE>(a, cout0, wn, lr, acc, smem, tile_n, pre, pixf, [cw, lg](int i) { return cw + i * 16 + lg * 4; });
+                                            int tile_n, const u32x2 (*pre)[TN], PixF pixf, const u32x2 (*prea)[TN] = nullptr) {
+  epilogue_cf<T, TM, TN, BM, WNN, NT, PRE>(a, cout0, wn, lr, acc, smem, tile_n, pre, pixf, [cw, lg](int i) { return cw + i * 16 + lg * 4; }, prea);
 }
 
 // linear pixel tiles (conv_igemm.hip): the BN pixels of a tile are consecutive flattened pixels
@@ -289,6 +301,7 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   a.ntile_m = a.ntile_n = 0;
   a.zperm = 0;
   a.weight_up = (const char*)p->weight_up; a.byteswu = 0; a.upc = 0; a.ucpt0 = a.ucpt1 = 1;
+  a.fold_src = a.fold_weight = nullptr; a.fold_cpt = 0; a.bytes_fold = a.bytesw_fold = 0;
   a.stats = p->stats_partial;
   a.stat_slots = p->stats_slots;
   if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;

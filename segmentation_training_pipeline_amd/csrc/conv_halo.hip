@@ -43,15 +43,7 @@
 #define STP_OOB 0x80000000u
 #define HALO_NWST 4
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// v_mfma_f32_32x32x16 of the build's 16-bit storage format (common.h)
-template <typename V> __device__ __forceinline__ f32x16 mfma16_32x32x16(V a, V b, f32x16 c) {
-#if STP_STORAGE_F16
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-#else
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-#endif
-}
+// (f32x16 / mfma16_32x32x16: common.h)
 
 // counted wait with a count that is a constant only after loop unrolling
 __device__ __forceinline__ void wait_vmcnt_n(int n) {

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   const bool up = UNI && UPC && a.upc;
   const __amdgpu_buffer_rsrc_t rswu = __builtin_amdgcn_make_buffer_rsrc((void*)(up ? a.weight_up : a.weight), 0, up ? a.byteswu : 0u, 0x00020000);
   const int upy = up ? ((int)fdiv((uint32_t)pix0, a.divPc) >> 1) : 0, upx = up ? ((int)fdiv((uint32_t)pix0, a.divPc) & 1) : 0;
-  int zkh0 = 0, zkw0 = 0, znkw = 1, znk = 0;
+  int zkh0 = 0, zkw0 = 0, znkw = 1, znk = 0, zfn = 0;
   if (zp && !up) {
     const int zc = (int)fdiv((uint32_t)pix0, a.divPc);
     zkh0 = ((zc >> 1) + a.pad) & 1;                  // ho - pad + kh even  <=>  kh = zkh0 (mod 2)
@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     const int znkh = (a.KH - zkh0 + 1) >> 1;
     znkw = (a.KW - zkw0 + 1) >> 1;
     znk = znkh * znkw * a.zcpt;
+    // folded shortcut gradient: the 1x1 / stride-2 sibling reaches the (even, even) pixels only, as one more (centre) tap
+    if (a.fold_src && zc == 0) zfn = a.fold_cpt;
   }
+  const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc((void*)(zfn ? a.fold_src : a.src0), 0, zfn ? a.bytes_fold : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rswf = __builtin_amdgcn_make_buffer_rsrc((void*)(zfn ? a.fold_weight : a.weight), 0, zfn ? a.bytesw_fold : 0u, 0x00020000);
 
   // per-thread pixel rows: image offsets (elements) in both sources and the top-left tap coordinate
   int hb[RB], wb[RB];
@@ -155,6 +159,25 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
       const int k1 = kt - nk0, tap = (int)fdiv((uint32_t)k1, a.divU1), ch = k1 - tap * a.ucpt1;
       k0 = (uint32_t)(tap * a.Ctot + a.C0 + ch * KE);
     } else if (zp) {   // kt-th K-tile of the class: (live tap, 64-channel chunk)
+      if (ZP && kt >= znk) {   // folded shortcut: chunk kt - znk of its dY at the centre tap (pixel (ho, wo) / 2), its own weight rows [.][C0]
+        const uint32_t cf = (uint32_t)((kt - znk) * KE + lslot * VEC);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool act = (i * 32 + wave * 8) < BM;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rswf, (__attribute__((address_space(3))) void*)(act ? sa + (i * 32 + wave * 8) * 128 : smem + DUMP + wave * 1024), 16,
+              act ? ((uint32_t)(cout0 + r0 + 32 * i) * (uint32_t)a.C0 + cf) * SZ : STP_OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int hv = hb[i] + a.pad, wv = wb[i] + a.pad;        // = (ho, wo): both even in this class
+          const bool ok = (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+          const uint32_t off = nof0[i] + (uint32_t)((hv >> 1) * a.Ws0 + (wv >> 1)) * (uint32_t)a.C0 + cf;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (__attribute__((address_space(3))) void*)(sb + (i * 32 + wave * 8) * 128), 16,
+                                                   ok ? off * SZ : STP_OOB, 0, 0, 0);
+        }
+        return;
+      }
       const int tix = (int)fdiv((uint32_t)kt, a.divCpt), ch = kt - tix * a.zcpt;
       const int ta = znkw == 2 ? tix >> 1 : tix, tb = znkw == 2 ? tix & 1 : 0;
       k0 = (uint32_t)(((zkh0 + 2 * ta) * a.KW + zkw0 + 2 * tb) * a.Ctot + ch * KE);
@@ -220,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int lr = lane & 15, lg = lane >> 4;
 
-  const int nk = up ? 4 * a.ucpt0 + 9 * a.ucpt1 : zp ? znk : (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
+  const int nk = up ? 4 * a.ucpt0 + 9 * a.ucpt1 : zp ? znk + zfn : (a.K + KE - 1) / KE;  // !UNI: the tail taps of the last tile are out of range -> zeros on both operands
   // epilogue operands (residual or the BatchNormalization-backward x; never both) fetched now: the loads are OLDER than every
   // tile load, so the counted vmcnt waits of the K loop also cover them, and their latency hides under the whole loop
   constexpr bool PRE = SZ == 2;
@@ -237,6 +260,25 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
           if (zp) pm = zperm_pixel(a, pm);                                      // (P is a multiple of the tile in this mode)
           const bool ok = co + 3 < a.Cout && pm < a.P;                       // others are never read; clamp keeps the load in bounds
           pre[i][j] = *reinterpret_cast<const u32x2*>(ps + (ok ? (size_t)pm * a.Cout + co : (size_t)0));
+        }
+      }
+    }
+  }
+  // parity-class launches (ZP) that accumulate into dst0: its current contents are fetched here as well (see epilogue_cf)
+  constexpr bool PREA = PRE && ZP && !UPC;
+  u32x2 prea[PREA ? TM : 1][TN];
+  const bool use_prea = PREA && zp && a.acc0 && a.Cd0 == a.Cout;
+  if constexpr (PREA) {
+    if (use_prea) {
+      const T* pd = reinterpret_cast<const T*>(a.dst0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int pm = zperm_pixel(a, pix0 + wn * (BN / WN) + j * 16 + lr);
+          const bool ok = co + 3 < a.Cout && pm < a.P;
+          prea[i][j] = *reinterpret_cast<const u32x2*>(pd + (ok ? (size_t)pm * a.Cout + co : (size_t)0));
         }
       }
     }
@@ -264,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   if (zp) {
     const int pb = pix0 + wn * (BN / WN) + lr;
     epilogue_px<T, TM, TN, BM, WN, 256, PRE>(a, cout0, wm * (BM / WM), wn, lr, lg, acc, smem, tile_n, pre,
-                                              [pb, &a](int j) { return zperm_pixel(a, pb + j * 16); });
+                                              [pb, &a](int j) { return zperm_pixel(a, pb + j * 16); }, use_prea ? prea : nullptr);
   } else {
     epilogue<T, BM, BN, WM, WN, PRE>(a, cout0, pix0, wm, wn, lr, lg, acc, smem, tile_n, pre);
   }
@@ -597,6 +639,24 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
 }
 
+static bool zperm_applies(const ConvArgs& a, int tile, int ut) {
+  static const bool zperm_on = !(getenv("STP_ZPERM") && atoi(getenv("STP_ZPERM")) == 0);
+  const bool uni_tile = tile >= 64 && tile < 256;
+  return zperm_on && a.mode == STP_SRC_ZEROINS2X && ut == 1 && uni_tile && a.stride == 1 && a.KH <= 3 && a.KW <= 3 && !(a.Ho & 1) && !(a.Wo & 1) &&
+         a.C1 == 0 && ((a.P / 4) % tile_pixels(tile)) == 0;
+}
+static bool fold_geometry_ok(const ConvArgs& a) { return a.KH == 3 && a.KW == 3 && a.pad == 1 && a.Hv == 2 * a.Hs0 - 1 && a.Wv == 2 * a.Ws0 - 1; }
+
+extern "C" int stp_conv2d_fold_ok(const stp_conv_params* p) {
+  static const bool on = !(getenv("STP_FOLD_SHORTCUT") && atoi(getenv("STP_FOLD_SHORTCUT")) == 0);
+  if (!on || !p || p->tile != 0 || stp_conv2d_sc_eligible(p) || stp_conv2d_stem_eligible(p) || halo_variant_for(p) >= 0) return 0;
+  ConvArgs a;
+  bool c4;
+  int ut;
+  if (fill_args(p, a, &c4, &ut) != STP_OK || c4) return 0;
+  return zperm_applies(a, auto_tile(a, ut), ut) && fold_geometry_ok(a) ? 1 : 0;
+}
+
 extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SC)) {
     if (stp_conv2d_sc_eligible(p)) return stp_conv2d_sc(p, stream);
@@ -625,15 +685,19 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   const_cast<stp_conv_params*>(p)->stats_tiles = ceil_div(a.P, tile_pixels(tile));
   {
     // data gradient of a stride-2 convolution through the uniform-tap kernel: parity-class pixel order (see ConvArgs::zperm)
-    static const bool zperm_on = !(getenv("STP_ZPERM") && atoi(getenv("STP_ZPERM")) == 0);
     const int ke = p->dtype == STP_H16 ? 64 : 32;
-    const bool uni_tile = tile >= 64 && tile < 256;
-    if (zperm_on && a.mode == STP_SRC_ZEROINS2X && ut == 1 && uni_tile && a.stride == 1 && a.KH <= 3 && a.KW <= 3 && !(a.Ho & 1) && !(a.Wo & 1) &&
-        a.C1 == 0 && ((a.P / 4) % tile_pixels(tile)) == 0) {
+    if (zperm_applies(a, tile, ut)) {
       a.zperm = 1;
       a.zPc = a.P / 4; a.zH2W2 = (a.Ho / 2) * (a.Wo / 2); a.zW2 = a.Wo / 2; a.zcpt = a.Ctot / ke;
       a.divPc = make_fastdiv((uint32_t)a.zPc); a.divH2W2 = make_fastdiv((uint32_t)a.zH2W2); a.divW2 = make_fastdiv((uint32_t)a.zW2);
       a.divCpt = make_fastdiv((uint32_t)a.zcpt);
+    }
+    if (p->fold_src) {      // folded shortcut data gradient: only on this path, 3x3 / pad 1 geometry, equal channel counts
+      if (!a.zperm || !fold_geometry_ok(a) || !p->fold_weight || p->fold_C != a.C0) return STP_E_BADARG;
+      const int64_t bf = (int64_t)a.N * a.Hs0 * a.Ws0 * a.C0 * (p->dtype == STP_H16 ? 2 : 4), bwf = (int64_t)a.wrows * a.C0 * (p->dtype == STP_H16 ? 2 : 4);
+      if (bf >= (1ll << 31) || bwf >= (1ll << 31)) return STP_E_BADARG;
+      a.fold_src = (const char*)p->fold_src; a.fold_weight = (const char*)p->fold_weight; a.fold_cpt = a.C0 / ke;
+      a.bytes_fold = (uint32_t)bf; a.bytesw_fold = (uint32_t)bwf;
     }
   }
   {

@@ -467,6 +467,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
 //   dW column of (kw, ci): (kh * 3 + kw) * Ctot + cib * 64 + ci.  Two concatenated sources (each a multiple of 64 channels, the first optionally
 //   nearest-2x upsampled: the decoder's UpSampling2D + Concatenate) are handled per 64-channel block: a block lies in one source.
 // PBN (fused producer BatchNormalization of src0) is a compile-time parameter of the body: 20 VGPRs the plain launches do not carry.
+// which instances run on v_mfma_f32_32x32x16 (STP_ROW_M32=0: a what-if build on the 16 x 16 x 32 form everywhere)
+#ifndef STP_ROW_M32
+#define STP_ROW_M32 0
+#endif
+template <int BM, int WM, int WN> struct RowM32 { static constexpr bool value = STP_ROW_M32 && BM == 128 && WM == 2 && WN == 2; };
+
+// element e (float4) of a tile's fragment-major slab -> first of its 4 output channels (relative to the tile) and its column (0..191)
+template <int BM, int WM, int WN>
+__device__ __forceinline__ void row_slab_decode(int e, int& co, int& col) {
+  const int lane = e & 63;
+  int q = e >> 6;
+  if constexpr (RowM32<BM, WM, WN>::value) {
+    constexpr int TM = BM / WM / 32, TN = 192 / WN / 32;
+    const int qq = q & 3; q >>= 2;
+    const int ij = q % (TM * TN), wave = q / (TM * TN);
+    const int i = ij / TN, j = ij - i * TN, wm = wave / WN, wn = wave % WN;
+    co = wm * (BM / WM) + i * 32 + 8 * qq + 4 * (lane >> 5);
+    col = wn * (192 / WN) + j * 32 + (lane & 31);
+  } else {
+    constexpr int TM = BM / WM / 16, TN = 192 / WN / 16;
+    const int ij = q % (TM * TN), wave = q / (TM * TN);
+    const int i = ij / TN, j = ij - i * TN, wm = wave / WN, wn = wave % WN;
+    co = wm * (BM / WM) + i * 16 + (lane >> 4) * 4;
+    col = wn * (192 / WN) + j * 16 + (lane & 15);
+  }
+}
+
 // (t, step0, step1, out_tile): the tile of the layer (tile_m fastest), the range of 64-pixel steps summed and the fragment-major
 // partial slab [wave][i][j][lane] float4 that receives the sums - the single-layer kernel derives them from the block id, the
 // grouped kernel (below) from its work list.
@@ -608,14 +635,77 @@ __device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a, const in
   }
   const int ca = (wm * (BM / WM)) * SZ + qb;
 
-  f32x4 acc[TM][TN];
+  // M32 (128-channel class, 2 x 2 waves of 64 x 96): v_mfma_f32_32x32x16 - half the MFMA instructions per step for the same
+  // transpose reads (the operand bytes of a wave tile do not depend on the MFMA shape), which frees issue slots for the reads.
+  // Operand layout of the 32 x 32 x 16 form: lane group g = lane >> 4 holds rows / columns 16 (g & 1) .. +15 and k = 8 (g >> 1) .. +7;
+  // a k-step = 16 pixels: pixel 16 kk + 8 (g >> 1) + {0..3} from the first transpose read, + {4..7} from the second - the same map
+  // for both operands, which is all the contraction needs.
+  constexpr bool M32 = RowM32<BM, WM, WN>::value;
+  constexpr int TM32 = M32 ? BM / WM / 32 : 1, TN32 = M32 ? BN / WN / 32 : 1;
+  int prowA32[8], hrowB32[8], kwB32[TN32], cbB32[TN32];
+  int ca32 = 0;
+  if constexpr (M32) {
+    const int hh = lg & 1, kh2 = lg >> 1;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int e = 0; e < 8; ++e) {      // e = kk * 2 + half
+      const int q = (e >> 1) * 16 + kh2 * 8 + (e & 1) * 4 + (lr >> 2);
+      prowA32[e] = q;
+      const int r = q / seg;
+      hrowB32[e] = r * hw + (q - r * seg);
+    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN32; ++j) {
+      const int col = wn * (BN / WN) + j * 32 + hh * 16;
+      kwB32[j] = col >> 6;
+      cbB32[j] = (col & 63) * SZ + qb;
+    }
+    ca32 = (wm * (BM / WM) + hh * 16) * SZ + qb;
+  }
+
+  f32x4 acc[M32 ? 1 : TM][M32 ? 1 : TN];
+  f32x16 acc32[TM32][TN32];
+  if constexpr (M32) {
+#pragma unroll
+    for (int i = 0; i < TM32; ++i)
+#pragma unroll
+      for (int j = 0; j < TN32; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   auto compute = [&](const char* sa) {
     const char* sb = sa + PK * ROWA;
+    if constexpr (M32) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        u32x4 fa[TM32], fb[TN32];
+#pragma unroll
+        for (int i = 0; i < TM32; ++i) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prowA32[2 * kk], ca32 + i * 64)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sa + tile_addr<ROWA>(prowA32[2 * kk + 1], ca32 + i * 64)));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int j = 0; j < TN32; ++j) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(hrowB32[2 * kk] + kwB32[j], cbB32[j])));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + tile_addr<ROWB>(hrowB32[2 * kk + 1] + kwB32[j], cbB32[j])));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          fb[j] = u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int i = 0; i < TM32; ++i)
+#pragma unroll
+          for (int j = 0; j < TN32; ++j)
+            acc32[i][j] = mfma16_32x32x16(fa[i], fb[j], acc32[i][j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       u32x4 fa[TM], fb[TN];
@@ -671,10 +761,20 @@ __device__ __forceinline__ void conv_wgrad_row_body(const WgradArgs& a, const in
   // a 16-byte lane-contiguous vector (1 KB per wave instruction) instead of 4-byte stores K floats apart (measured: the scattered
   // slab write was a third of the launch); wgrad_reduce_row_kernel sums the splits in this order and scatters into dW once
   f32x4* out = out_tile + (size_t)wave * (TM * TN * 64) + lane;
+  if constexpr (M32) {      // [wave][i][j][q][lane]: the lane's rows 8 q + 4 (lane >> 5) + {0..3} of column lane & 31 (row_slab_decode)
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM32; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) out[(i * TN + j) * 64] = acc[i][j];
+      for (int j = 0; j < TN32; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          out[((i * TN32 + j) * 4 + q) * 64] = f32x4{acc32[i][j][4 * q], acc32[i][j][4 * q + 1], acc32[i][j][4 * q + 2], acc32[i][j][4 * q + 3]};
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) out[(i * TN + j) * 64] = acc[i][j];
+  }
 #endif
 }
 
@@ -767,7 +867,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_group_kernel(const char* _
 // slab list of an element in parallel (fixed assignment, fixed-shape LDS tree: deterministic) - stage-1 tiles have 40+ slabs.
 template <int BM, int WM, int WN, int SL>
 __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const char* __restrict__ table, const f32x4* __restrict__ slabs) {
-  constexpr int TM = BM / WM / 16, TN = 192 / WN / 16, PER = BM * 192 / 4, EPB = 256 / SL, BPT = PER / EPB;
+  constexpr int PER = BM * 192 / 4, EPB = 256 / SL, BPT = PER / EPB;
   static_assert(PER % EPB == 0, "whole blocks per tile");
   __shared__ f32x4 sh[SL][EPB];
   const WgGroupHeader* const hd = reinterpret_cast<const WgGroupHeader*>(table);
@@ -790,17 +890,12 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const char* __r
     if (sl != 0) return;
   }
   const WgLayer& L = layers[tl.layer];
-  const int lane = e & 63, lr = lane & 15, lg = lane >> 4;
-  int q = e >> 6;
-  const int ij = q % (TM * TN); q /= (TM * TN);
-  const int wave = q & 3;
-  const int i = ij / TN, j = ij - i * TN;
-  const int wm = wave / WN, wn = wave % WN;
+  int col, co;
+  row_slab_decode<BM, WM, WN>(e, co, col);
   const int tile_m = tl.t % L.a.ntile_m, tile_n = tl.t / L.a.ntile_m;
   const int ncib = L.a.Ctot >> 6, kh = tile_n / ncib, cib = tile_n - kh * ncib;
-  const int col = wn * (192 / WN) + j * 16 + lr;
   const int kc = (kh * 3 + (col >> 6)) * L.a.Ctot + cib * 64 + (col & 63);
-  const int co = tile_m * BM + wm * (BM / WM) + i * 16 + lg * 4;
+  co += tile_m * BM;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (co + r < L.a.Cout) {
@@ -815,7 +910,7 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const char* __r
 template <int BM, int WM, int WN, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_row_kernel(const f32x4* __restrict__ slabs, float* __restrict__ dw, int64_t per_split,
                                                                int splits, int accumulate, int ntile_m, int C0, int Cout, int K) {
-  constexpr int TM = BM / WM / 16, TN = 192 / WN / 16, EPB = 256 / SL;
+  constexpr int EPB = 256 / SL;
   __shared__ f32x4 sh[SL][EPB];
   const int ev = threadIdx.x % EPB, sl = threadIdx.x / EPB;
   const int64_t e = (int64_t)blockIdx.x * EPB + ev;
@@ -833,17 +928,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_row_kernel(const f32x4* __re
     s = sh[0][ev];
   }
   if (sl != 0 || e >= per_split) return;
-  const int lane = (int)(e & 63), lr = lane & 15, lg = lane >> 4;
-  int q = (int)(e >> 6);
-  const int ij = q % (TM * TN); q /= (TM * TN);
-  const int wave = q & 3, t = q >> 2;
-  const int i = ij / TN, j = ij - i * TN;
-  const int wm = wave / WN, wn = wave % WN;
+  constexpr int PERT = BM * 192 / 4;                       // float4 elements per tile
+  const int t = (int)(e / PERT);
+  int col, co;
+  row_slab_decode<BM, WM, WN>((int)(e - (int64_t)t * PERT), co, col);
   const int tile_m = t % ntile_m, tile_n = t / ntile_m;
   const int ncib = C0 >> 6, kh = tile_n / ncib, cib = tile_n - kh * ncib;
-  const int col = wn * (192 / WN) + j * 16 + lr;
   const int kc = (kh * 3 + (col >> 6)) * C0 + cib * 64 + (col & 63);
-  const int co = tile_m * BM + wm * (BM / WM) + i * 16 + lg * 4;
+  co += tile_m * BM;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (co + r < Cout) {

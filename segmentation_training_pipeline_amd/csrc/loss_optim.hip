@@ -631,8 +631,13 @@ extern "C" int stp_sigmoid(const void* logits, float* probs, int64_t count, int3
 
 // ------------------------------------------------------------------------------------------
 // Optimizers (Keras 2.2.4 formulas).  state[0] = iteration t (int), state[1] = lr_t (float bits)
-__global__ void adam_prep_kernel(int32_t* state, const float* lr, float beta1, float beta2) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// gscale[0] <= 0 (or NaN) = "skip this step": stp_grad_global_scale found a non-finite gradient (fp16 overflow under loss scaling).
+// Every optimizer kernel - the per-step scalar preparation included - returns without touching parameters, moments or the step
+// counter, so one overflowing batch cannot poison P / m / v.
+__device__ __forceinline__ bool opt_skip(const float* gscale) { return gscale && !(gscale[0] > 0.f); }
+
+__global__ void adam_prep_kernel(int32_t* state, const float* lr, float beta1, float beta2, const float* gscale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || opt_skip(gscale)) return;
   const int t = state[0] + 1;
   state[0] = t;
   const double lr_t = (double)lr[0] * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
@@ -644,6 +649,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float b2, float eps, const uint8_t* __restrict__ mask,
                                                    const float* gscale, float clipvalue) {
   const float lr_t = reinterpret_cast<const float*>(state)[1];
+  if (opt_skip(gscale)) return;
   const float gs = gscale ? gscale[0] : 1.f;
   const int64_t n4 = count >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -673,7 +679,7 @@ extern "C" int stp_adam(float* param, const float* grad, float* m, float* v, int
                         void* stream) {
   if (!param || !grad || !m || !v || !lr || !state || count <= 0 || (count & 3)) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2);
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2, gscale);
   STP_LAUNCH_CHECK();
   int64_t g = ((count >> 2) + 255) / 256;
   if (g > 4096) g = 4096;
@@ -688,6 +694,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, con
                                                       int64_t count, const float* lr, float rho, float eps,
                                                       const uint8_t* __restrict__ mask, const float* gscale, float clipvalue) {
   const float l = lr[0];
+  if (opt_skip(gscale)) return;
   const float gs = gscale ? gscale[0] : 1.f;
   const int64_t n4 = count >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -722,8 +729,8 @@ extern "C" int stp_rmsprop(float* param, const float* grad, float* acc, int64_t 
 
 // Nadam (keras/optimizers.py 2.2.4, schedule_decay form).  state[0] = iteration t, fstate[0] = m_schedule (starts at 1),
 // fstate[1..5] = this step's scalars {1/(1-m_schedule_new), 1/(1-m_schedule_next), 1/(1-beta2^t), 1-mu_t, mu_{t+1}}
-__global__ void nadam_prep_kernel(int32_t* state, float* fstate, float beta1, float beta2, float schedule_decay) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void nadam_prep_kernel(int32_t* state, float* fstate, float beta1, float beta2, float schedule_decay, const float* gscale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || opt_skip(gscale)) return;
   const int t = state[0] + 1;
   state[0] = t;
   const double mu_t = (double)beta1 * (1.0 - 0.5 * pow(0.96, (double)t * (double)schedule_decay));
@@ -744,6 +751,7 @@ __global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ p, const
                                                     const float* gscale, float clipvalue) {
   const float l = lr[0];
   const float ig = fstate[1], im = fstate[2], iv = fstate[3], cg = fstate[4], cm = fstate[5];
+  if (opt_skip(gscale)) return;
   const float gs = gscale ? gscale[0] : 1.f;
   const int64_t n4 = count >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -774,7 +782,7 @@ extern "C" int stp_nadam(float* param, const float* grad, float* m, float* v, in
                          const float* gscale, float clipvalue, void* stream) {
   if (!param || !grad || !m || !v || !lr || !state || !fstate || count <= 0 || (count & 3)) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(nadam_prep_kernel, dim3(1), dim3(64), 0, s, state, fstate, beta1, beta2, schedule_decay);
+  hipLaunchKernelGGL(nadam_prep_kernel, dim3(1), dim3(64), 0, s, state, fstate, beta1, beta2, schedule_decay, gscale);
   STP_LAUNCH_CHECK();
   int64_t g = ((count >> 2) + 255) / 256;
   if (g > 4096) g = 4096;
@@ -788,6 +796,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
                                                   int64_t count, const float* lr, float mu, int nesterov,
                                                   const uint8_t* __restrict__ mask, const float* gscale, float clipvalue) {
   const float l = lr[0];
+  if (opt_skip(gscale)) return;
   const float gs = gscale ? gscale[0] : 1.f;
   const int64_t n4 = count >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -845,6 +854,11 @@ __global__ __launch_bounds__(256) void gscale_finalize_kernel(const float* parti
   }
   if (threadIdx.x != 0) return;
   const double norm = sqrt(sh[0]) * (double)base;  // norm of the (mean) gradient the optimizer will see
+  if (!(sh[0] >= 0.0 && sh[0] < 1e300 * 1e300) || !(norm == norm)) {   // inf / NaN somewhere in the arena: the step is skipped (opt_skip)
+    gscale[0] = -1.f;
+    gscale[1] += 1.f;                              // skipped steps so far (host: HipSegModel.skipped_steps)
+    return;
+  }
   double k = 1.0;
   if (clipnorm > 0.f && norm > (double)clipnorm) k = (double)clipnorm / norm;
   gscale[0] = (float)(k * (double)base);

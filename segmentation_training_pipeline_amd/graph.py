@@ -611,9 +611,12 @@ class Plan(object):
         return out
 
     def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False,
-             transpose=False, relu=False, same_tf=False):
+             transpose=False, relu=False, same_tf=False, fold_shortcut=None):
         """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
         ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add().
+
+        ``fold_shortcut``: the output tensor of the 1x1 / stride-2 projection shortcut that reads the same ``x`` as this 3x3 / stride-2
+        convolution (ResNet basic block): its data gradient is folded into this layer's data-gradient launch (stp_conv_params.fold_*).
 
         ``transpose``: Keras ``Conv2DTranspose(Cout, k, strides=2, padding='same')`` (k even, 4 in segmentation_models'
         transpose decoder blocks).  TF pads the equivalent forward convolution by k/2-1 on each side, so the transposed
@@ -670,6 +673,7 @@ class Plan(object):
         wf = self._alloc((rows_f * k * KWp * Cinp,))
         need_dgrad = self.training and (x_ng or s_ng) and not stem
         wb = self._alloc((rows_b * k * k * CoutB,)) if need_dgrad else None
+        out.meta["wb"] = wb
         # collected here, issued as ONE batched launch per step (see _finish_prep)
         self._prep_layers.append((self._pptr(w), wf.data_ptr(), wb.data_ptr() if wb is not None else None,
                                   Cout, k, k, Cin_master, KWp, Cinp, CoutB))
@@ -791,7 +795,9 @@ class Plan(object):
                            self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
                 self._emit(self.bwd, "stp_weight_grad_unpad", tmp.data_ptr(), self._gptr(b), Cout, 1, 1, 1, 1, 1, 0)
             # data gradient
-            if need_dgrad:
+            if need_dgrad and out.meta.get("dgrad_folded"):
+                pass        # a projection shortcut whose data gradient rode in its sibling's launch (fold_shortcut): nothing to issue
+            elif need_dgrad:
                 if upsample:
                     d0 = self._alloc((self.N, Hv, Wv, C0)) if x_ng else None
                     acc0 = 0
@@ -816,6 +822,14 @@ class Plan(object):
                                         accumulate0=acc0, accumulate1=acc1)
                 if stride not in (1, 2):
                     raise StpShapeError("data gradient supports stride 1 and 2")
+                fs = fold_shortcut
+                if (fs is not None and stride == 2 and k == 3 and not transpose and src1 is None and x_ng and fs.needs_grad and fs.grad_ready
+                        and fs.meta.get("wb") is not None and fs.gradC == CoutB and (fs.H, fs.W) == (Ho, Wo)
+                        and int(self.lib.stp_conv2d_fold_ok(C.byref(q)))):
+                    # the shortcut's 1x1 / stride-2 data gradient = one more (centre) tap of this launch's (even, even) parity class
+                    q.fold_src, q.fold_weight, q.fold_C = fs.grad.data_ptr(), fs.meta["wb"].data_ptr(), CoutB
+                    fs.meta["dgrad_folded"] = True
+                    x.grad_writes += 1          # its share of x's gradient arrives with this launch
                 bnm = x.meta.get("bn")
                 folded_up = False
                 qC1 = C1

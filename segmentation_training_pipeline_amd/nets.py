@@ -55,7 +55,8 @@ def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
             else:
                 shortcut = x
             if ex == 1:
-                y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1, bn_stats=True)
+                # (a stride-2 projection shortcut reads the same tensor: its data gradient rides in conv1's launch)
+                y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1, bn_stats=True, fold_shortcut=shortcut if (u == 1 and stride == 2) else None)
                 y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
                 x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut, bn_stats=True)
             else:

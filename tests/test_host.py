@@ -429,7 +429,11 @@ def test_plan_structure_matches_unet_resnet34():
     grouped = sum(len(names_) for names_, _ in plan.wgroups)
     assert grouped == 9 and [c for _, c in plan.wgroups] == [32, 64, 64]       # at 64 px only the 16- / 32- / 64-pixel maps qualify
     assert bnames.count("stp_wgrad_group_partial") == bnames.count("stp_wgrad_group_reduce") == len(plan.wgroups) == 3
-    assert bnames.count("stp_conv2d_wgrad") == 48 - grouped and bnames.count("stp_conv2d") == 47   # no data-gradient for the stem
+    # data gradients: none for the stem; a stride-2 projection shortcut's rides in its sibling conv1's launch where the parity-class
+    # path takes the shape (stp_conv_params.fold_*: at 64 px stage 2 only - the later maps are too small for a pixel tile per class)
+    folded = sum(1 for t in plan.tensors.values() if t.meta.get("dgrad_folded"))
+    assert folded == 1 and plan.tensors["stage2_unit1_sc"].meta.get("dgrad_folded")
+    assert bnames.count("stp_conv2d_wgrad") == 48 - grouped and bnames.count("stp_conv2d") == 47 - folded
     assert bnames.count("stp_conv2d_wgrad_reduce") == 48 - grouped
     # BatchNormalization outputs read by exactly one convolution get their backward sums from that convolution's
     # data-gradient epilogue: 16 bn2 + 12 bn1 of the non-first units + 5 decoder bn1 + the last decoder bn2, plus
@@ -469,6 +473,8 @@ def test_weight_gradient_groups_of_the_headline_workload():
                    (128, 7, "stage2_unit4_conv2", "stage2_unit1_conv2"), (64, 6, "stage1_unit3_conv2", "stage1_unit1_conv1")]
     bnames = [n for _, _, n, _ in plan.bwd]
     assert bnames.count("stp_conv2d_wgrad") == 12 and bnames.count("stp_wgrad_group_partial") == 6
+    assert sorted(n for n, t in plan.tensors.items() if t.meta.get("dgrad_folded")) == ["stage2_unit1_sc", "stage3_unit1_sc", "stage4_unit1_sc"]
+    assert bnames.count("stp_conv2d") == 47 - 3
     assert bnames.count("stp_bn_backward_fused_add") == 12 and "stp_add_inplace" not in bnames      # 12 non-first units
     assert plan.bwd_monotone
     lows = [low for _, low in plan.bwd_marks]

@@ -568,6 +568,32 @@ def test_fp16_step_close_to_fp32_oracle():
         make("resnet18", size, n, "fp16", loss="binary_crossentropy+0.5*lovasz_loss", loss_scale=128.0)
 
 
+def test_fp16_non_finite_gradients_skip_the_step_instead_of_poisoning_the_state():
+    """fp16 storage, loss scaling on: a non-finite value in the gradient arena (fp16 stores saturate, so it takes a NaN to get one -
+    planted here through one BatchNormalization gamma) makes the overflow guard skip the update: every other weight, Adam's moments
+    and the step counter are untouched and skipped_steps counts it.  With the NaN removed the same model steps normally."""
+    x, y = ostep.synthetic_batch(2, 64, 64, seed=5)
+    m = make("resnet18", 64, 2, "fp16")
+    m.init_weights(seed=9)
+    w0 = m.get_weights()
+    poisoned = dict(w0)
+    g = w0["decoder_stage4_bn2/gamma"].copy()
+    g[3] = np.nan
+    poisoned["decoder_stage4_bn2/gamma"] = g
+    m.set_weights(poisoned)
+    met = m.train_on_batch(x, y)
+    assert not np.isfinite(met["loss"])
+    assert m.skipped_steps == 1 and int(m.opt_state[0].item()) == 0
+    w1 = m.get_weights()
+    for k in m.plan.params:
+        assert np.array_equal(poisoned[k], w1[k], equal_nan=True), k
+    assert float(m.m.abs().max().item()) == 0.0 and float(m.v.abs().max().item()) == 0.0
+    m.set_weights(w0)
+    met = m.train_on_batch(x, y)
+    assert np.isfinite(met["loss"]) and m.skipped_steps == 1 and int(m.opt_state[0].item()) == 1
+    assert any(not np.array_equal(w0[k], v) for k, v in m.get_weights().items() if k in m.plan.params)
+
+
 def test_freeze_encoder_and_predict_and_checkpoint(tmp_path):
     n, size = 2, 64
     P = onets.init_unet_resnet("resnet18", seed=3)

@@ -1598,6 +1598,46 @@ def test_softmax_categorical_crossentropy_dice_loss_and_gradient(ops, dtype, cla
     np.testing.assert_allclose(host(probs), pd.numpy(), atol=2e-6)
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_overflow_guard_skips_the_optimizer_step(ops, bad):
+    """stp_grad_global_scale on an arena that holds an inf / NaN (fp16 overflow under loss scaling) writes the skip marker; Adam,
+    SGD, RMSprop and Nadam given that gscale leave parameters, moments and the step counter exactly as they were.  A finite arena
+    restores the scale and the step runs."""
+    rng = np.random.RandomState(3)
+    n = 8192
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    g_bad = rng.randn(n).astype(np.float32)
+    g_bad[1234] = bad
+    gs = torch.tensor([0.5, 0.0], device=DEV)
+    ws = torch.empty(1024, dtype=torch.float32, device=DEV)
+    gd = f(g_bad)
+    ops.grad_global_scale(gd, n, 0.0, 0.25, gs, ws)
+    assert host(gs).tolist() == [-1.0, 1.0]
+    p0 = rng.randn(n).astype(np.float32)
+    lr = torch.tensor([1e-2], device=DEV)
+    for name in ("adam", "nadam", "rmsprop", "sgd"):
+        p, m, v = f(p0), f(np.full(n, 0.1)), f(np.full(n, 0.2))
+        state = torch.tensor([7, 0], dtype=torch.int32, device=DEV)
+        fst = torch.ones(8, device=DEV)
+        if name == "adam":
+            ops.adam(p, gd, m, v, n, lr, 0.9, 0.999, 1e-7, state, gscale=gs)
+        elif name == "nadam":
+            ops.nadam(p, gd, m, v, n, lr, 0.9, 0.999, 1e-7, 0.004, state, fst, gscale=gs)
+        elif name == "rmsprop":
+            ops.rmsprop(p, gd, m, n, lr, 0.9, 1e-7, gscale=gs)
+        else:
+            ops.sgd(p, gd, m, n, lr, 0.9, False, gscale=gs)
+        assert np.array_equal(host(p), p0) and np.all(host(m) == np.float32(0.1)) and np.all(host(v) == np.float32(0.2)), name
+        assert host(state.float()).tolist()[0] == 7.0 and np.all(host(fst) == 1.0), name
+    good = f(rng.randn(n) * 0.1)
+    ops.grad_global_scale(good, n, 0.0, 0.25, gs, ws)
+    assert host(gs).tolist() == [0.25, 1.0]                     # scale restored, the count of skipped steps stays
+    p, m, v = f(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ops.adam(p, good, m, v, n, lr, 0.9, 0.999, 1e-7, state, gscale=gs)
+    assert not np.array_equal(host(p), p0) and int(state[0].item()) == 1
+
+
 def test_adam_and_sgd_match_keras_rules(ops):
     rng = np.random.RandomState(14)
     n = 4096 + 8
