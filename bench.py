@@ -112,6 +112,28 @@ def flop_per_image(model):
     return 3.0 * fwd / model.batch
 
 
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel sources of the build: the counter files under profiles/ record the fingerprint of
+    the build they were collected on (scratch/pmc_aggregate*.py), so a bench line can say whether its ``traffic`` / ``mfma_util`` -
+    which need separate profiler passes and are therefore read from those files - belong to the kernels that just ran."""
+    import hashlib
+    d = os.path.join(ROOT, "segmentation_training_pipeline_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_stale(path):
+    try:
+        with open(path) as f:
+            return json.load(f).get("csrc_sha16") != csrc_fingerprint()
+    except (OSError, ValueError):
+        return True
+
+
 def pmc_traffic(kernel):
     """L2-miss bytes per launch of ``kernel`` (read + write) from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
@@ -146,7 +168,7 @@ def pmc_mfma_util(kernel):
     return None, None
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=25.0, full_protocol=False):
     """The in-repo CPU oracle (a PORT: the reference's Keras-CPU fit() is not installable here) running the
     same step - CPU augmentation (oracle/augment.py, the S1 pipeline of BASELINE.md 4) + forward + Dice/BCE + backward + Adam - on
     a bounded sample: U-Net/ResNet-34, 512x512, batch 2 (BASELINE.md 4's batch-16, 3 warm-up / 10 timed protocol does not fit
@@ -156,7 +178,9 @@ def cpu_baseline(seconds_budget=25.0):
     from oracle import nets as onets
     from oracle import step as ostep
     from segmentation_training_pipeline_amd import augment
-    n = 2
+    # full_protocol (bench runs of >= 100 steps): BASELINE.md 4 as written - batch 16, 3 warm-up + 10 timed steps, median (~10 minutes
+    # of host time); the default form is the bounded sample the driver's 20-step run can afford
+    n = 16 if full_protocol else 2
     P = onets.init_unet_resnet("resnet34", seed=42)
     tr = ostep.OracleTrainer(P, backbone="resnet34", loss=LOSS, optimizer="adam", lr=1e-3)
     x, y = ostep.synthetic_batch(n, H, W, seed=1234)
@@ -168,17 +192,19 @@ def cpu_baseline(seconds_budget=25.0):
         xa, ya = oaug.warp_u8(x8, y8, prm, (H, W))
         tr.step(xa.astype(np.float32), ya.reshape(n, H, W, 1).astype(np.float32))
 
-    one_step()  # warm-up
+    for _ in range(3 if full_protocol else 1):
+        one_step()  # warm-up
     times, t_all = [], time.time()
-    while len(times) < 3 or (time.time() - t_all < seconds_budget and len(times) < 10):
+    while len(times) < (10 if full_protocol else 3) or (not full_protocol and time.time() - t_all < seconds_budget and len(times) < 10):
         t0 = time.time()
         one_step()
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": round(n / med, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": "oracle (numpy augmentation + PyTorch-CPU fp32) training step incl. the S1 augmentation, U-Net/ResNet34 512x512x3, "
-                      "batch %d, median of %d timed steps after 1 warm-up (BASELINE.md 4 protocol shortened to fit the bench budget)"
-                      % (n, len(times))}
+                      "batch %d, median of %d timed steps after %d warm-up (%s)"
+                      % (n, len(times), 3 if full_protocol else 1,
+                         "BASELINE.md 4 protocol" if full_protocol else "BASELINE.md 4 protocol shortened to fit the bench budget; --steps >= 100 runs it in full")}
 
 
 def main():
@@ -283,6 +309,9 @@ def main():
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                            "traffic_source": traffic_src, "mfma_util": mu, "mfma_util_source": mu_src,
+                           # the counter files come from separate profiler passes: true = collected on ANOTHER build of csrc/
+                           "counters_stale": bool((traffic_src and _pmc_stale(os.path.join(ROOT, traffic_src))) or
+                                                  (mu_src and _pmc_stale(os.path.join(ROOT, mu_src)))),
                            "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
                            "share_of_step_kernel_time": round(sec / tot, 3)}
         top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:16]
@@ -291,7 +320,7 @@ def main():
         out["gemm_time_us"] = round(1e6 * sum(v[1] for v in gemm.values()), 1)
         out["non_gemm_time_us"] = round(1e6 * (tot - sum(v[1] for v in gemm.values())), 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(full_protocol=args.steps >= 100 and os.environ.get("STP_CPU_BASELINE_FULL", "1") != "0")
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():

@@ -341,12 +341,36 @@ def conv_param_count(P):
     return int(sum(v.size for k, v in P.items() if k.endswith("/kernel")))
 
 
+class _StoreRound(torch.autograd.Function):
+    """A tensor that the device path STORES in a 16-bit format: forward = round to that format; backward = round the incoming
+    gradient the same way (the gradient of a stored tensor is itself a stored tensor on the device).  Straight-through otherwise."""
+
+    @staticmethod
+    def forward(fctx, x, dt):
+        fctx.dt = dt
+        return x.to(dt).to(torch.float32)
+
+    @staticmethod
+    def backward(fctx, g):
+        return g.to(fctx.dt).to(torch.float32), None
+
+
 class _Ctx:
-    def __init__(self, P, training, taps):
+    """``storage``: None = the fp32 oracle.  torch.bfloat16 / torch.float16 = the STORAGE-QUANTISED oracle: every tensor
+    the HIP path keeps in HBM in that format - convolution outputs (after the fused residual add), BatchNormalization outputs, the
+    pooled / upsampled tensors, the logits - and every gradient of such a tensor is rounded where the kernels round it, and the
+    convolutions read rounded weight copies; statistics, accumulation, loss and optimizer stay fp32.  Used to hold the 16-bit
+    training modes to a tight bar (tests/test_model_gpu.py); U-Net / Linknet over the ResNet encoders."""
+
+    def __init__(self, P, training, taps, storage=None):
         self.P = P
         self.training = training
         self.taps = taps
         self.bn_updates = OrderedDict()
+        self.storage = storage
+
+    def st(self, t):
+        return t if self.storage is None else _StoreRound.apply(t, self.storage)
 
     def tap(self, name, t):
         if self.taps is not None:
@@ -354,11 +378,15 @@ class _Ctx:
         return t
 
 
-def _conv(ctx, x, name, stride=1, pad=0):
+def _conv(ctx, x, name, stride=1, pad=0, store=True):
     # Keras HWIO -> torch OIHW ; explicit symmetric ZeroPadding2D + 'valid'
     w = ctx.P[name + "/kernel"].permute(3, 2, 0, 1)
     b = ctx.P.get(name + "/bias")
-    return F.conv2d(x, w, b, stride=stride, padding=pad)
+    if ctx.storage is not None:
+        # the 16-bit compute copy of the fp32 master (the weight gradient is a function of dY and x only: straight-through)
+        w = w + (w.detach().to(ctx.storage).to(torch.float32) - w.detach())
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    return ctx.st(y) if store else y       # store=False: the epilogue adds a residual before the one rounding (caller stores)
 
 
 def _bn_apply(ctx, x, name, eps, relu):
@@ -384,7 +412,7 @@ def _bn_apply(ctx, x, name, eps, relu):
     inv = torch.rsqrt(var + eps)
     scale = inv if gamma is None else inv * gamma
     y = (x - mean.view(1, c, 1, 1)) * scale.view(1, c, 1, 1) + beta.view(1, c, 1, 1)
-    return F.relu(y) if relu else y
+    return ctx.st(F.relu(y) if relu else y)
 
 
 def _resnet_encoder(ctx, x_nhwc, backbone, stop_at=None):
@@ -398,7 +426,7 @@ def _resnet_encoder(ctx, x_nhwc, backbone, stop_at=None):
     x = _bn_apply(ctx, x, "bn0", BN_EPS_ENCODER, relu=True)
     skips = {"relu0": x}
     ctx.tap("relu0", x)
-    x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), kernel_size=3, stride=2)  # ZeroPadding2D(1) + valid pool
+    x = ctx.st(F.max_pool2d(F.pad(x, (1, 1, 1, 1)), kernel_size=3, stride=2))  # ZeroPadding2D(1) + valid pool
     ctx.tap("pooling0", x)
     for s, (n_units, f) in enumerate(zip(units, STAGE_FILTERS), start=1):
         for u in range(1, n_units + 1):
@@ -416,14 +444,14 @@ def _resnet_encoder(ctx, x_nhwc, backbone, stop_at=None):
             if expansion(backbone) == 1:
                 y = _conv(ctx, a, pre + "conv1", stride=stride, pad=1)
                 y = _bn_apply(ctx, y, pre + "bn2", BN_EPS_ENCODER, relu=True)
-                y = _conv(ctx, y, pre + "conv2", stride=1, pad=1)
+                y = _conv(ctx, y, pre + "conv2", stride=1, pad=1, store=False)
             else:   # bottleneck: the stride sits on the 3x3 convolution
                 y = _conv(ctx, a, pre + "conv1")
                 y = _bn_apply(ctx, y, pre + "bn2", BN_EPS_ENCODER, relu=True)
                 y = _conv(ctx, y, pre + "conv2", stride=stride, pad=1)
                 y = _bn_apply(ctx, y, pre + "bn3", BN_EPS_ENCODER, relu=True)
-                y = _conv(ctx, y, pre + "conv3")
-            x = y + shortcut
+                y = _conv(ctx, y, pre + "conv3", store=False)
+            x = ctx.st(y + shortcut)       # the residual Add rides in the convolution's epilogue: one rounding of the sum
             ctx.tap(pre + "out", x)
     x = _bn_apply(ctx, x, "bn1", BN_EPS_ENCODER, relu=True)
     ctx.tap("relu1", x)
@@ -458,10 +486,10 @@ def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=N
 
 
 def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
-                        decoder_filters=(256, 128, 64, 32, 16)):
+                        decoder_filters=(256, 128, 64, 32, 16), storage=None):
     """P: dict name -> torch tensor (Keras layouts).  x_nhwc: [N,H,W,C] float32 raw 0..255.
-    Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits)."""
-    ctx = _Ctx(P, training, taps)
+    Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits).  ``storage``: see _Ctx."""
+    ctx = _Ctx(P, training, taps, storage)
     if backbone in VGG_BLOCKS:
         x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
         skips = {"s%d" % i: t for i, t in enumerate(sk)}
@@ -482,7 +510,7 @@ def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None
             x = _bn_apply(ctx, x, pre + "bn2", BN_EPS_DECODER, relu=True)
             ctx.tap(pre + "relu2", x)
             continue
-        x = F.interpolate(x, scale_factor=2, mode="nearest")  # UpSampling2D(2)
+        x = ctx.st(F.interpolate(x, scale_factor=2, mode="nearest"))  # UpSampling2D(2) (its high-resolution gradient is a stored tensor)
         if skip_names[i] is not None:
             x = torch.cat([x, skips[skip_names[i]]], dim=1)
         x = _conv(ctx, x, pre + "conv1", pad=1)

@@ -36,5 +36,9 @@ for k in sorted(set(ft) | set(wt)):
     out["kernels"][k] = {"dispatches": max(fc.get(k, 0), wc.get(k, 0)),
                          "fetch_bytes_per_launch": int(2 * 1024 * ft[k] / fc[k]) if fc.get(k) else None,
                          "write_bytes_per_launch": int(1024 * wt[k] / wc[k]) if wc.get(k) else None}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["csrc_sha16"] = bench.csrc_fingerprint()     # the build these counters were collected on (bench.py: roofline.counters_stale)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(len(out["kernels"]), "kernels ->", sys.argv[3])

@@ -48,5 +48,9 @@ for k in sorted(cnt):
         e["active_frac"] = round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
     e["counters"] = {n: int(v) for n, v in c.items()}
     out["kernels"][k] = e
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["csrc_sha16"] = bench.csrc_fingerprint()     # the build these counters were collected on (bench.py: roofline.counters_stale)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(len(out["kernels"]), "kernels ->", sys.argv[3])
