@@ -245,7 +245,7 @@ def main():
     model = HipSegModel(args.architecture, "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
                         lr=1e-3, use_graph=not args.eager, device=str(dev))
     if world > 1 or force_dp:
-        model.set_data_parallel(distributed.GradReducer(bucket_mb=float(os.environ.get("STP_DP_BUCKET_MB", "32")), force=force_dp), overlap={"0": False, "1": True}.get(os.environ.get("STP_DP_OVERLAP", "1"), "buckets"))
+        model.set_data_parallel(distributed.make_reducer(force=force_dp), overlap={"0": False, "1": True}.get(os.environ.get("STP_DP_OVERLAP", "1"), "buckets"))
 
     # synthetic data: uniform uint8 images, 3 random discs per mask, seed 1234 + rank
     rng = np.random.RandomState(1234 + rank)

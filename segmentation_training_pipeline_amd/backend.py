@@ -162,7 +162,7 @@ class HipSegModel(object):
         asynchronously as soon as its segment has been launched, so RCCL runs under the remaining backward GEMMs.
         ``overlap=True`` uses distributed.two_phase_bounds; ``overlap="buckets"`` keeps the reducer's own buckets."""
         self.reducer = reducer
-        self.dp_overlap = bool(overlap) and not reducer.wire_bf16 and self.plan.bwd_monotone
+        self.dp_overlap = bool(overlap) and self.plan.bwd_monotone
         if self.dp_overlap and overlap != "buckets":
             reducer.set_bounds(distributed.two_phase_bounds(self.plan.bwd_marks, self.plan.G.numel()))
         self._segments = None

@@ -832,7 +832,7 @@ class GenericTaskConfig(object):
         if world > 1:
             # replicas start the stage bit-identical: parameters, BatchNormalization statistics and optimizer state of rank 0
             impl.broadcast_state(src=0)
-            impl.set_data_parallel(distributed.GradReducer())
+            impl.set_data_parallel(distributed.make_reducer())
         H, W = impl.H, impl.W                                  # = shape, or shape / crops
         feeder = DeviceFeeder(impl.device, (H, W), self._aug_spec(), seed=self.random_state * 7919 + fold * 101 + si,
                               classes=self.classes, channels=impl.in_ch)

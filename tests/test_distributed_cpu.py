@@ -40,6 +40,14 @@ def _worker(rank, world, port, q):
     for wk in works:
         wk.wait()
     ok = ok and torch.equal(g3, expect)
+    # ... and the overlapped form in the bf16 wire format (cast in, asynchronous reduce, cast back at wait)
+    g4 = torch.arange(2048, dtype=torch.float32).remainder(64) * (rank + 1)       # small integers: exact in bf16
+    red4 = distributed.GradReducer(bucket_mb=0.002, wire_bf16=True,
+                                   cast_fns=(lambda s, d, c: d.copy_(s.to(torch.bfloat16)), lambda s, d, c: d.copy_(s.to(torch.float32))))
+    works = [red4.allreduce_range(g4, s, e) for s, e in reversed(red4.bounds(2048))]
+    for wk in works:
+        wk.wait()
+    ok = ok and len(works) == 4 and torch.equal(g4, torch.arange(2048, dtype=torch.float32).remainder(64) * 3)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
