@@ -558,12 +558,21 @@ def _feed_block(self, plan, hb):
 DeviceFeeder._feed_block = _feed_block
 
 
-def derived_metrics(scal, classes=1):
+def derived_metrics(scal, classes=1, extended=False):
     """scal: the loss scalars of stp_sigmoid_bce_dice -> Keras-style log entries (metric names of
-    schemas/segmentation.raml:98-105: binary_accuracy, dice, iou, iot)."""
+    schemas/segmentation.raml:98-105: binary_accuracy, dice, iou, iot).  ``extended``: the loss names one of the other registry
+    entries (stp_sigmoid_loss_ex / stp_lovasz_hinge leave them in scalars 10..12): they are logged too, so that
+    ``primary_metric: val_focal_loss`` or a callback monitoring it sees the quantity it names."""
     loss, bce, dice_l, dice_m, acc, _sp, _sy, _spy, iou, iot = (float(v) for v in scal[:10])
-    return {"loss": loss, ("binary_crossentropy" if classes == 1 else "categorical_crossentropy"): bce, "dice_loss": dice_l,
-            "dice": dice_m, "binary_accuracy": acc, "iou": iou, "iot": iot}
+    out = {"loss": loss, ("binary_crossentropy" if classes == 1 else "categorical_crossentropy"): bce, "dice_loss": dice_l,
+           "dice": dice_m, "binary_accuracy": acc, "iou": iou, "iot": iot}
+    if extended and len(scal) >= 13:
+        out.update(iou_loss=1.0 - iou, jaccard_loss=float(scal[10]), focal_loss=float(scal[11]), lovasz_loss=float(scal[12]))
+    return out
+
+
+def _extended(model):
+    return len(getattr(model, "loss_w", ())) > 2
 
 
 class Trainer(object):
@@ -607,7 +616,7 @@ class Trainer(object):
         sums = {}
         if snaps:
             for scal, n in zip(torch.stack(snaps).cpu().numpy(), counts):
-                for k, v in derived_metrics(scal, getattr(m, "classes", 1)).items():
+                for k, v in derived_metrics(scal, getattr(m, "classes", 1), _extended(m)).items():
                     sums[k] = sums.get(k, 0.0) + v * n
         return sums, int(sum(counts))
 
@@ -615,17 +624,17 @@ class Trainer(object):
         """Sample-weighted epoch means, combined over all ranks (one small SUM-all-reduce per call): every rank returns
         the same values bit for bit."""
         sums, n = self.run_epoch_sums(indexes, training)
-        return reduce_epoch_sums(sums, n, getattr(self.model, "classes", 1))
+        return reduce_epoch_sums(sums, n, getattr(self.model, "classes", 1), _extended(self.model))
 
 
-def epoch_log_names(classes=1):
-    return sorted(derived_metrics(np.zeros(12, np.float32), classes))
+def epoch_log_names(classes=1, extended=False):
+    return sorted(derived_metrics(np.zeros(16, np.float32), classes, extended))
 
 
-def reduce_epoch_sums(sums, n, classes=1):
+def reduce_epoch_sums(sums, n, classes=1, extended=False):
     """{name: weighted sum}, samples -> {name: mean over the samples of ALL ranks}.  The vector layout is fixed by the
     metric names (not by what a rank happened to see), so a rank with an empty shard still takes part in the collective."""
-    names = epoch_log_names(classes)
+    names = epoch_log_names(classes, extended)
     vec = distributed.allreduce_sums([sums.get(k, 0.0) for k in names] + [float(n)])
     total = vec[-1]
     if total <= 0:
@@ -840,8 +849,9 @@ class GenericTaskConfig(object):
         trainer = Trainer(impl, feeder, ds, cbs, rank, world)
         train_idx = kf.sampledIndexes(fold, True, stage.negatives)
         val_idx = kf.sampledIndexes(fold, False, stage.validation_negatives)
-        if self.draw_examples:
-            # SegmentationStage.add_visualization_callbacks (reference segmentation.py:251-257)
+        if self.draw_examples and rank == 0:
+            # SegmentationStage.add_visualization_callbacks (reference segmentation.py:251-257); rank 0 only: the sheets are files
+            # under one fold / stage name, and drawing takes values from the feeder's generator
             cbs.append(DrawResults(self, ds, val_idx, fold, si, drawingFunction=self.drawingFunction))
             if self.showDataExamples:
                 cbs.append(DrawResults(self, ds, train_idx, fold, si, train=True, drawingFunction=self.drawingFunction))
@@ -863,8 +873,10 @@ class GenericTaskConfig(object):
             logs["lr"] = impl.get_lr()
             rows.append(dict(epoch=epoch, **logs))
             cur = log_value(logs, self.primary_metric)
-            if cur is None:
-                cur = logs.get("loss")
+            if cur is None and not len(val_idx) and self.primary_metric.startswith("val_"):
+                cur = log_value(logs, self.primary_metric[4:])     # a fold without validation samples: the training value stands in
+            if cur is None:      # choosing the best checkpoint on another quantity than the one named would be silent and wrong
+                raise ValueError("primary_metric %r is not among the epoch logs %s" % (self.primary_metric, sorted(logs)))
             if best is None or (cur < best if mode == "min" else cur > best):
                 best, best_epoch = cur, epoch
                 if rank == 0:
