@@ -448,6 +448,18 @@ class Plan(object):
         reads = self._wgroup_reads
         self._wgroup, self._wgroup_cls, self._wgroup_flops, self._wgroup_hi, self._wgroup_reads = [], 0, 0.0, 0, set()
         n = len(layers)
+        if n == 1 and cls != 32:
+            # a lone layer gains nothing from the work list (measured on the bottleneck ResNets, whose 3x3 layers never neighbour:
+            # FPN/ResNet50 1024x1024 18.25 -> 17.85 ms, PSPNet/ResNet101 768x768 10.13 -> 10.03 ms with the per-layer launch and its
+            # tuned split count); the 32-channel class exists only as a grouped kernel (the per-layer one pads it to 64)
+            wp, name, flops = layers[0]
+            self._mark(self.bwd, "fork")
+            self._side_groups_only = False
+            self._side_reads.update(reads)
+            self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": wp.Cout,
+                                            "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp))),
+                                            "kernel_id": int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp)))})
+            return
         arr = (C.POINTER(_lib.WgradParams) * n)(*[C.pointer(wp) for wp, _, _ in layers])
         tb = int(self.lib.stp_wgrad_group_table_bytes(arr, n))
         wsb = int(self.lib.stp_wgrad_group_workspace_bytes(arr, n))

@@ -635,6 +635,30 @@ def test_fp16_non_finite_gradients_skip_the_step_instead_of_poisoning_the_state(
     assert any(not np.array_equal(w0[k], v) for k, v in m.get_weights().items() if k in m.plan.params)
 
 
+@pytest.mark.parametrize("spec", [LOSS, "focal_loss+dice_loss", "binary_crossentropy+0.5*iou_loss+0.02*jaccard_loss",
+                                  "binary_crossentropy+0.5*lovasz_loss"])
+def test_short_validation_batch_reruns_every_loss_family(spec):
+    """Plan.rerun_loss (a validation batch padded by wrapping around is re-evaluated over its real samples only) for every loss
+    launch the plan can hold - stp_sigmoid_bce_dice, stp_sigmoid_loss_ex, and stp_lovasz_hinge on top of either: the scalars of the
+    first two samples of a padded batch of four equal those of a batch-2 model evaluating those two samples."""
+    x, y = ostep.synthetic_batch(4, 64, 64, seed=21)
+    x[2:], y[2:] = x[:2], y[:2]                      # the wrapped tail
+    m4 = make("resnet18", 64, 4, "fp32", loss=spec)
+    m2 = make("resnet18", 64, 2, "fp32", loss=spec)
+    m4.init_weights(seed=3)
+    m2.set_weights(m4.get_weights())
+    out = []
+    for m, xs, ys, n_real in ((m4, x, y, 2), (m2, x[:2], y[:2], 2)):
+        ep = m.eval_plan()
+        ep.inputs["image"].buf.copy_(torch.from_numpy(xs).reshape(ep.inputs["image"].buf.shape))
+        ep.inputs["mask"].buf.copy_(torch.from_numpy(ys).to(torch.uint8).reshape(ep.inputs["mask"].buf.shape))
+        ep.run(ep.prep); ep.run(ep.fwd)
+        if n_real < m.batch:
+            ep.rerun_loss(n_real)
+        out.append(ep.loss_scalars.cpu().numpy().copy())
+    np.testing.assert_allclose(out[0][:13], out[1][:13], rtol=2e-5, atol=2e-6)
+
+
 def test_freeze_encoder_and_predict_and_checkpoint(tmp_path):
     n, size = 2, 64
     P = onets.init_unet_resnet("resnet18", seed=3)
