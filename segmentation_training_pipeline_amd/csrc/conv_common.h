@@ -2,6 +2,7 @@
 // activation slabs): argument block, MFMA wrappers, the fused epilogue.
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 struct ConvArgs {
   const char* src0;
@@ -39,6 +40,7 @@ struct ConvArgs {
   const char* fold_weight;
   int fold_cpt;
   uint32_t bytes_fold, bytesw_fold;
+  int no_rm;      // 1: keep the fragment-order epilogue (STP_IGEMM_RM=0: A/B of the row-major one)
 };
 
 // logical (parity-class major) pixel -> n, ho, wo
@@ -263,6 +265,164 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cout0, int pix0,
                                                                [pb, P](int j) { const int pm = pb + j * 16; return pm < P ? pm : -1; });
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// ROW-MAJOR epilogue for the linear-pixel tiles of conv_igemm.hip (16-bit storage, 256 threads, 16 x 16 MFMA fragments).
+// In the MFMA C layout a lane owns 4 channels of one pixel: residual / accumulate / BatchNormalization-input loads and the stores
+// are 8-byte accesses scattered over 16 pixel rows per instruction, one dependent round trip per fragment, and the per-channel sums
+// cost a DPP reduction per fragment (scratch/igemm_ep_bench.py: 1x1 64 -> 256 @ 4 x 256 x 256 plain 51 us, with a residual 98 us, with
+// the BatchNormalization-backward sums 126 us).  Here - as in conv_halo.hip's epilogue_rm - the workgroup's fp32 tile goes through
+// LDS ([pixel][BM channels], rows padded by 16 bytes) and a thread owns 8 CONSECUTIVE channels of a pixel: 16-byte coalesced
+// operand loads issued up front, 16-byte stores, sums as plain register adds + one fixed-order reduction per workgroup.
+// Needs Cout, Cd0 and Cout - Cd0 multiples of 8 (otherwise the caller keeps the fragment-order epilogue above).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v unpack_bf16x2(uint32_t w) { return f32x2v{h16lo_to_f32(w), h16hi_to_f32(w)}; }
+
+template <int BM, int BN, int WM, int WN, typename PixF>
+__device__ __forceinline__ void epilogue_rm_lin(const ConvArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int cout0, int tile_n,
+                                                int wm, int wn, int lr, int lg, int tid, PixF pixf) {
+  typedef bf16_t T;
+  constexpr int NT = 256, TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int RS = BM * 4 + 16;                            // staged row: BM floats + 16 bytes of padding
+  constexpr int CG = BM / 8, PP = NT / CG, NP = BN / PP;     // channel groups of 8, pixels per pass, passes
+  static_assert(BM % 8 == 0 && NT % CG == 0 && BN % PP == 0, "tile shape");
+  const int c8 = tid % CG, p0 = tid / CG;
+  const int co = cout0 + c8 * 8;
+  const bool cok = co < a.Cout;                               // Cout % 8 == 0: a group is valid as a whole
+  const bool first = co < a.Cd0;
+  T* const dbase = first ? reinterpret_cast<T*>(a.dst0) + co : reinterpret_cast<T*>(a.dst1) + (co - a.Cd0);
+  const int dC = first ? a.Cd0 : a.Cd1;
+  const bool accum = first ? a.acc0 : a.acc1;
+  const bool bnb = a.bnb.x != nullptr, st = a.stats != nullptr;
+  const T* res = bnb ? reinterpret_cast<const T*>(a.bnb.x) : reinterpret_cast<const T*>(a.residual);
+
+  // global operands of this thread's NP pixels: issued before the staging so their latency hides under it
+  int pm[NP];
+  u32x4 opr[NP], opa[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    pm[k] = pixf(p0 + k * PP);
+    opr[k] = opa[k] = u32x4{0u, 0u, 0u, 0u};
+  }
+  if (cok) {
+    if (res) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (pm[k] >= 0) opr[k] = *reinterpret_cast<const u32x4*>(res + (size_t)pm[k] * a.Cout + co);
+    }
+    if (accum) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (pm[k] >= 0) opa[k] = *reinterpret_cast<const u32x4*>(dbase + (size_t)pm[k] * dC);
+    }
+  }
+  lds_barrier();                                              // every wave has left the K loop: the operand ring is dead
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int px = wn * (BN / WN) + j * 16 + lr, c = wm * (BM / WM) + i * 16 + lg * 4;
+      *reinterpret_cast<f32x4*>(smem + px * RS + c * 4) = acc[i][j];
+    }
+  lds_barrier();
+
+  f32x2v ss[4], qq[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ss[e] = qq[e] = f32x2v{0.f, 0.f};
+  if (cok) {
+    f32x2v bias2[4], ksc[4], ksh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias2[e] = ksc[e] = ksh[e] = f32x2v{0.f, 0.f};
+    if (!bnb && a.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias2[e] = *reinterpret_cast<const f32x2v*>(a.bias + co + 2 * e);
+    }
+    if (bnb) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float r = a.bnb.rstd[co + e], sc = a.bnb.gamma ? r * a.bnb.gamma[co + e] : r;
+        ksc[e >> 1][e & 1] = sc;
+        ksh[e >> 1][e & 1] = (a.bnb.beta ? a.bnb.beta[co + e] : 0.f) - a.bnb.mean[co + e] * sc;
+      }
+    }
+    const bool relu = a.relu != 0;
+    const float alo = a.bnb.relu ? __uint_as_float(1u) : -__builtin_inff();
+    const float ahi = a.bnb.relu == 2 ? __uint_as_float(0x40bfffffu) : __builtin_inff();      // largest float below 6
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (pm[k] < 0) continue;
+      const int px = p0 + k * PP;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
+      f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!bnb) {
+          v[e] += bias2[e];
+          if (res) v[e] += unpack_bf16x2(opr[k][e]);
+        }
+        if (accum) v[e] += unpack_bf16x2(opa[k][e]);
+        if (!bnb && relu) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
+        o[e] = pack_bf16x2(v[e].x, v[e].y);
+        if (st && !bnb) {
+          const f32x2v sv = unpack_bf16x2(o[e]);
+          ss[e] += sv;
+          qq[e] += sv * sv;
+        }
+        if (bnb) {   // dY as stored -> masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma)
+          const f32x2v xv = unpack_bf16x2(opr[k][e]), dy = unpack_bf16x2(o[e]);
+          const f32x2v tt = xv * ksc[e] + ksh[e];
+          const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+          ss[e] += g;
+          qq[e] += g * xv;
+          o[e] = pack_bf16x2(g.x, g.y);
+        }
+      }
+      *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
+    }
+  }
+  if (st) {     // (workgroup-uniform)
+    if (bnb && cok) {   // sum g * xhat = rstd * (sum g * x - mean * sum g), per thread (linear, so the partition does not matter)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float mu = a.bnb.mean[co + e], rs = a.bnb.rstd[co + e];
+        qq[e >> 1][e & 1] = rs * (qq[e >> 1][e & 1] - mu * ss[e >> 1][e & 1]);
+      }
+    }
+    // fixed-order reduction over the NT / CG threads that share a channel group (the shape of conv_halo.hip's, for 256 threads)
+    constexpr int J = NT / CG, NOUT = (CG * 16 < NT) ? CG * 16 : NT, NPART = NT / NOUT, JP = J / NPART, KS = NT + CG;
+    static_assert(NPART >= 1 && J % NPART == 0 && CG * 16 <= NT * 16, "reduction shape");
+    lds_barrier();                                          // the staged tile is dead
+    float* r1 = reinterpret_cast<float*>(smem);               // [16][KS]
+    float* r2 = r1 + 16 * KS;                                 // [NPART][CG * 16]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r1[(e * 4 + 0) * KS + tid] = ss[e].x; r1[(e * 4 + 1) * KS + tid] = ss[e].y;
+      r1[(e * 4 + 2) * KS + tid] = qq[e].x; r1[(e * 4 + 3) * KS + tid] = qq[e].y;
+    }
+    lds_barrier();
+    // CG * 16 outputs (k = 0..15 per channel group); each is the sum of J threads' partials: NPART threads take JP of them each
+    for (int o = tid; o < CG * 16 * NPART; o += NT) {
+      const int oo = o % (CG * 16), q = o / (CG * 16);
+      const float* src = r1 + (oo / CG) * KS + (oo % CG) + CG * (q * JP);
+      float acc_ = 0.f;
+#pragma unroll
+      for (int j = 0; j < JP; ++j) acc_ += src[CG * j];
+      r2[q * (CG * 16) + oo] = acc_;
+    }
+    lds_barrier();
+    if (tid < CG * 16) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NPART; ++q) tot += r2[q * (CG * 16) + tid];
+      const int k = tid / CG, ch = (tid % CG) * 8 + (k >> 2) * 2 + (k & 1), stat = (k >> 1) & 1;
+      if (cout0 + ch < a.Cout) a.stats[((size_t)stat * a.Cout + cout0 + ch) * a.ntile_n + tile_n] = tot;
+    }
+  }
+}
+__device__ __forceinline__ bool epilogue_rm_ok(const ConvArgs& a) {
+  return !a.no_rm && !(a.Cout & 7) && !(a.Cd0 & 7) && !(a.Cd1 & 7) && !a.stat_slots;
+}
+
 // stp_conv_params -> ConvArgs (validation shared by every MFMA convolution kernel)
 static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out, int* ut_out) {
   if (!p || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
@@ -302,6 +462,10 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   a.zperm = 0;
   a.weight_up = (const char*)p->weight_up; a.byteswu = 0; a.upc = 0; a.ucpt0 = a.ucpt1 = 1;
   a.fold_src = a.fold_weight = nullptr; a.fold_cpt = 0; a.bytes_fold = a.bytesw_fold = 0;
+  {
+    static const int no_rm = (getenv("STP_IGEMM_RM") && atoi(getenv("STP_IGEMM_RM")) == 0) ? 1 : 0;
+    a.no_rm = no_rm;
+  }
   a.stats = p->stats_partial;
   a.stat_slots = p->stats_slots;
   if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;

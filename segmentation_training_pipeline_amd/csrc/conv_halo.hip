@@ -69,8 +69,7 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 //   EP 0: bias / residual / accumulate / ReLU                      EP 1: EP 0 + sum, sum of squares of the stored values
 //   EP 2: (accumulate) + BatchNormalization-backward: store g = dY under the activation mask, reduce sum g and sum g * xhat
 // Same arithmetic per element as conv_common.h's epilogue (sum g * xhat is accumulated as sum g * x and centred once per channel).
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2v unpack_bf16x2(uint32_t w) { return f32x2v{h16lo_to_f32(w), h16hi_to_f32(w)}; }
+// (f32x2v / unpack_bf16x2: conv_common.h)
 
 template <int TH, int BM, int WM, int WN, int EP>
 __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][TH / WN / 2], char* smem, int n, int y0, int x0,

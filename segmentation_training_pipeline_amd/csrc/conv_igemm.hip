@@ -247,10 +247,16 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   // epilogue operands (residual or the BatchNormalization-backward x; never both) fetched now: the loads are OLDER than every
   // tile load, so the counted vmcnt waits of the K loop also cover them, and their latency hides under the whole loop
   constexpr bool PRE = SZ == 2;
+  // row-major epilogue (conv_common.h: epilogue_rm_lin) where the channel counts allow: it fetches its own operands, 16 bytes a lane
+  bool rm = false;
+  if constexpr (SZ == 2) {
+    static_assert((size_t)BN * (BM * 4 + 16) <= (size_t)STAGES * STAGE + 4096, "the staged fp32 tile fits the operand ring");
+    rm = epilogue_rm_ok(a);
+  }
   u32x2 pre[PRE ? TM : 1][TN];
   if constexpr (PRE) {
     const T* ps = a.residual ? reinterpret_cast<const T*>(a.residual) : reinterpret_cast<const T*>(a.bnb.x);
-    if (ps) {
+    if (ps && !rm) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int co = cout0 + wm * (BM / WM) + i * 16 + lg * 4;
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
   // parity-class launches (ZP) that accumulate into dst0: its current contents are fetched here as well (see epilogue_cf)
   constexpr bool PREA = PRE && ZP && !UPC;
   u32x2 prea[PREA ? TM : 1][TN];
-  const bool use_prea = PREA && zp && a.acc0 && a.Cd0 == a.Cout;
+  const bool use_prea = PREA && zp && a.acc0 && a.Cd0 == a.Cout && !rm;
   if constexpr (PREA) {
     if (use_prea) {
       const T* pd = reinterpret_cast<const T*>(a.dst0);
@@ -302,6 +308,15 @@ __global__ __launch_bounds__(256) void conv_igemm_ut_kernel(const ConvArgs a) {
 #endif
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
+  }
+  if constexpr (SZ == 2) {
+    if (rm) {
+      epilogue_rm_lin<BM, BN, WM, WN>(a, acc, smem, cout0, tile_n, wm, wn, lr, lg, tid, [&a, pix0, zp](int p) {
+        const int pl = pix0 + p;
+        return pl >= a.P ? -1 : (zp ? zperm_pixel(a, pl) : pl);
+      });
+      return;
+    }
   }
   if (zp) {
     const int pb = pix0 + wn * (BN / WN) + lr;
