@@ -103,7 +103,10 @@ typedef struct stp_conv_params {
   /* Gradient of UpSampling2D(2) folded into the epilogue of the data-gradient convolution whose (virtual) destination
    * is the upsampled tensor: with dst_sum2x2 != 0, dst0 is [N,Ho/2,Wo/2,Cout] and receives the sum of each 2x2 block
    * (the hi-res gradient is never written); bnb_x / stats_partial / accumulate0 then refer to that low-resolution
-   * tensor.  Small-channel kernel only (stp_conv2d_sc_eligible), Ho and Wo even, no bias / relu. */
+   * tensor.  Small-channel kernel only (stp_conv2d_sc_eligible), Ho and Wo even, no bias / relu.
+   * With a second destination (dst1 != NULL: the data gradient of conv3x3(concat(UpSampling2D(2)(x), skip)), served by the
+   * wide-output kernel, stp_conv2d_scw_eligible) only dst0 - the first Cd0 channels - is summed, and bnb_x / stats_partial
+   * refer to those Cd0 channels; dst1 stays [N,Ho,Wo,Cout-Cd0]. */
   int32_t dst_sum2x2;
   /* stats_slots > 0 (a power of two <= 64): stats_partial points to PRE-ZEROED int64 fixed-point slots [2][Cout][stats_slots]
    * (2^-24 units) and every pixel tile ADDS its sums atomically into slot (tile % stats_slots) - integer addition, hence
@@ -163,6 +166,14 @@ int stp_conv2d_sc_eligible(const stp_conv_params* p);
  * one per 8x32 tile, or one per persistent workgroup in the streaming form. */
 int stp_conv2d_sc_stats_tiles(const stp_conv_params* p);
 int stp_conv2d_sc(const stp_conv_params* p, void* stream);
+/* Wide-output form of the small-channel kernel (conv_sc.hip: conv_scw_stream_kernel): 3x3 / stride 1 / pad 1, 32 input channels,
+ * 128 output channels split over dst0 (Cd0 channels, a multiple of 32, dst_sum2x2 = 1: low-resolution, optional bnb_x + stats_partial)
+ * and dst1 (full resolution); 16-bit storage.  Replaces the generic per-tap data gradient of decoder_stage3_conv1 + stp_upsample2x_bwd
+ * (TF: Conv2DBackpropInput + ResizeNearestNeighborGrad + FusedBatchNormGrad's reductions).  stp_conv2d uses it automatically
+ * (tile id 640; STP_SCW=0 in the environment switches it off).  stats_tiles = stp_conv2d_scw_stats_tiles(p) columns of [2][Cd0][columns]. */
+int stp_conv2d_scw_eligible(const stp_conv_params* p);
+int stp_conv2d_scw_stats_tiles(const stp_conv_params* p);
+int stp_conv2d_scw(const stp_conv_params* p, void* stream);
 /* The ResNet stem (classification_models conv0: 7x7 / stride 2 / pad 3, 3+1 input channels -> 64, bf16): halo-tile kernel,
  * used by stp_conv2d automatically when eligible (tile id 768); optional fused BatchNormalization sums (stats_partial). */
 int stp_conv2d_stem_eligible(const stp_conv_params* p);

@@ -683,6 +683,273 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
 }
 
 // =================================================================================================
+// WIDE-OUTPUT form: data gradient of the first full-resolution decoder convolution,
+//   conv3x3(concat(UpSampling2D(2)(x), skip)) -> 32 channels   (U-Net decoder_stage3_conv1 at 16 x 256 x 256)
+// i.e. a 3x3 convolution of dY (32 channels) into 128 channels that belong to TWO tensors: the first Cd0 are the gradient of the
+// upsampled tensor - its 2x2 blocks are summed here (dst_sum2x2) and land on the low-resolution gradient directly, optionally
+// with the fused BatchNormalization-backward sums - the rest the gradient of the skip tensor.  The generic per-tap kernel spent
+// 216 us on it (K = 32 per tap: a ring stage per MFMA step) and wrote a full-resolution gradient of the upsampled tensor that
+// stp_upsample2x_bwd read back; the layer moves 67 MB in and 168 MB out, ~45 us at HBM speed.
+// Same streaming scheme as conv_sc_stream_kernel (persistent workgroups, 8 x 32 tiles, the next tile's dY halo written into the
+// other half of a double buffer by LDS-DMA); what differs is the split: the 4 waves share every B fragment (pixels) and own 32
+// OUTPUT CHANNELS each (A fragments = 32 x 288 weights = 72 registers), a tile is walked in two passes of 4 rows (accumulators:
+// 2 x 8 fragments).  Waves below Cd0 / 32 take the summed epilogue, the others store the skip gradient.
+// =================================================================================================
+struct ScwArgs {
+  const char* src;      // dY [N,H,W,32]
+  const char* weight;   // [128][9*32]  (the data-gradient weight copy: rows = input channels of the forward convolution)
+  char* dst_up;         // [N,H/2,W/2,C0]
+  char* dst_sk;         // [N,H,W,C1]
+  int N, H, W, C0, C1, acc_up, acc_sk;
+  int tiles_x, tiles_y;
+  FastDiv divTx, divTy;
+  float* stats;         // [2][C0][workgroups] (fused BatchNormalization-backward sums of the first C0 channels)
+  BnBack bnb;
+  uint32_t src_bytes;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a) {
+  constexpr int CIN = 32, SZ = (int)sizeof(T), K = 9 * CIN, NCH = 9, VPP = 4, PIXB = CIN * SZ;
+  constexpr int NV = SC_HH * SC_HW * VPP, NPASS = (NV + 255) / 256, BUF = NPASS * 4096;
+  static_assert(SZ == 2, "16-bit storage");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ktab = reinterpret_cast<float*>(smem + 2 * BUF);     // [4][128]: scale, shift, mean, rstd of the first C0 channels
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int cb = wave * 32;                                   // this wave's output channels
+  const bool upw = cb < a.C0;                                 // (wave-uniform) summed epilogue / skip epilogue
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
+  } else {
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = ntiles;
+  }
+  if (t_first >= t_end) {    // (no tile: its statistics column must still be defined)
+    if (a.stats && tid < a.C0) {
+      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = 0.f;
+      a.stats[((size_t)a.C0 + tid) * gridDim.x + blockIdx.x] = 0.f;
+    }
+    return;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  int hyx[NPASS];
+  const int cvb = (tid % VPP) * 16;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int v = p * 256 + tid, pix = v / VPP;
+    const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+    hyx[p] = v < NV ? (hy << 16 | hx) : -1;
+  }
+  auto decode = [&](int tile, int& n, int& y0, int& x0) {
+    const int bq = (int)fdiv((uint32_t)tile, a.divTx);
+    const int tx = tile - bq * a.tiles_x;
+    n = (int)fdiv((uint32_t)bq, a.divTy);
+    const int ty = bq - n * a.tiles_y;
+    y0 = ty * SC_TH; x0 = tx * SC_TW;
+  };
+  auto issue_tile = [&](int tile, int b) {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int gy = y0 - 1 + (hyx[p] >> 16), gx = x0 - 1 + (hyx[p] & 0xffff);
+      const bool ok = hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const uint32_t off = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
+      if (p * 256 + wave * 64 < NV)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  issue_tile(t_first, 0);
+
+  // once per workgroup: this wave's weights -> registers; chunk c of K = tap c (32 channels: lane group lg holds channels 8 lg ..)
+  u32x4 fa[2][NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      fa[i][c] = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(cb + i * 16 + lr) * K + c * CIN + lg * 8) * SZ);
+  const uint32_t lbase = (uint32_t)((lr * CIN + lg * 8) * SZ);     // lane part of every B-fragment address
+  const bool bnb = a.bnb.x != nullptr;
+  if (bnb && tid < 128) {
+    float sc = 0.f, sh = 0.f, mu = 0.f, rsd = 0.f;
+    if (tid < a.C0) {
+      mu = a.bnb.mean[tid]; rsd = a.bnb.rstd[tid];
+      sc = a.bnb.gamma ? rsd * a.bnb.gamma[tid] : rsd;
+      sh = (a.bnb.beta ? a.bnb.beta[tid] : 0.f) - mu * sc;
+    }
+    ktab[tid] = sc; ktab[128 + tid] = sh; ktab[256 + tid] = mu; ktab[384 + tid] = rsd;
+  }
+  f32x4 ssp[2], qqp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ssp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qqp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  lds_barrier();               // the table is visible
+  const int H2 = a.H >> 1, W2 = a.W >> 1;
+  T* const oup = reinterpret_cast<T*>(a.dst_up);
+  T* const osk = reinterpret_cast<T*>(a.dst_sk);
+  const T* const xbn = reinterpret_cast<const T*>(a.bnb.x);
+
+  auto body = [&](int tile, auto curc) {
+    constexpr int CUR = decltype(curc)::value;
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's own pieces have landed
+    lds_barrier();                                        // ... everybody's; and every wave has left the other half
+    const int next = tile + t_step;
+    // BatchNormalization input of the summed epilogue, one pass at a time: pass 0's is issued before the next tile's LDS-DMA (waiting
+    // for it does not wait for that tile), pass 1's under pass 1's MFMAs (the DMA, issued a pass earlier, has landed by then)
+    ScRaw4<T> xpre[2][2][2];          // [row pair][column half][channel tile]
+    auto prefetch = [&](int h) {
+      if (!(upw && bnb)) return;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int gy = y0 + h * 4 + q * 2, gx = x0 + h2 * 16 + lr;
+          const bool ok = !(lr & 1) && gy < a.H && gx < a.W;
+          const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) xpre[q][h2][i].load(xbn + (ok ? pm * a.C0 + cb + i * 16 + lg * 4 : (size_t)0));
+        }
+    };
+    prefetch(0);
+    if (next < t_end) issue_tile(next, CUR ^ 1);
+
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) prefetch(1);
+      f32x4 acc[2][8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int f = 0; f < 8; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int kh = c / 3, kw = c - kh * 3;
+          const u32x4 fb = *reinterpret_cast<const u32x4*>(smem + lbase + (CUR * BUF + ((h * 4 + (f >> 1) + kh) * SC_HW + (f & 1) * 16 + kw) * PIXB));
+          acc[0][f] = mfma16_16x16x32(fa[0][c], fb, acc[0][f]);
+          acc[1][f] = mfma16_16x16x32(fa[1][c], fb, acc[1][f]);
+        }
+      }
+      if (upw) {
+        // gradient of UpSampling2D(2): fragments f and f + 2 are the two rows of an output row, lanes lr and lr ^ 1 its columns
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int gy = y0 + h * 4 + q * 2, gx = x0 + h2 * 16 + lr;
+            const bool own = !(lr & 1) && gy < a.H && gx < a.W;
+            const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              f32x4 v = acc[i][q * 4 + h2] + acc[i][q * 4 + h2 + 2];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+              if (!own) continue;
+              const int co = cb + i * 16 + lg * 4;
+              if (a.acc_up) v += load4(oup + pm * a.C0 + co);
+              if (bnb) {
+                BnBackCh k;
+                k.sc = *reinterpret_cast<const f32x4*>(ktab + co); k.sh = *reinterpret_cast<const f32x4*>(ktab + 128 + co);
+                k.mu = *reinterpret_cast<const f32x4*>(ktab + 256 + co); k.rs = *reinterpret_cast<const f32x4*>(ktab + 384 + co);
+                v = bnback_apply(k, a.bnb.relu, xpre[q][h2][i].get(), sc_stored(v, (const T*)nullptr), ssp[i], qqp[i]);
+              }
+              store4(oup + pm * a.C0 + co, v);
+            }
+          }
+      } else {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          const int gy = y0 + h * 4 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+          if (gy >= a.H || gx >= a.W) continue;
+          const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            T* d = osk + pm * a.C1 + (cb - a.C0) + i * 16 + lg * 4;
+            f32x4 v = acc[i][f];
+            if (a.acc_sk) v += load4(d);
+            store4(d, v);
+          }
+        }
+      }
+    }
+  };
+
+  for (int tile = t_first; tile < t_end; tile += 2 * t_step) {
+    body(tile, std::integral_constant<int, 0>{});
+    if (tile + t_step < t_end) body(tile + t_step, std::integral_constant<int, 1>{});
+  }
+  // fused sums: one column per workgroup; each summed-epilogue wave owns its 32 channels outright (no cross-wave step)
+  if (a.stats && upw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = row_sum16_to_lane15(ssp[i][e]), qv = row_sum16_to_lane15(qqp[i][e]);
+        if (lr == 15) {
+          const int ch = cb + i * 16 + lg * 4 + e;
+          a.stats[(size_t)ch * gridDim.x + blockIdx.x] = sv;
+          a.stats[((size_t)a.C0 + ch) * gridDim.x + blockIdx.x] = qv;
+        }
+      }
+  }
+}
+
+static int scw_blocks(int ntiles) {
+  const int64_t b = (int64_t)sc_cu_count() * 2;
+  return (int)(b < ntiles ? b : ntiles);
+}
+
+// Is this convolution the two-destination data gradient served by conv_scw_stream_kernel?  (stp_conv2d consults this first.)
+extern "C" int stp_conv2d_scw_eligible(const stp_conv_params* p) {
+  static const bool on = !(getenv("STP_SCW") && atoi(getenv("STP_SCW")) == 0);
+  if (!on || !p || p->dtype != STP_H16) return 0;
+  return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->C0 == 32 && p->C1 == 0 && p->Cout == 128 && p->dst1 != nullptr &&
+         p->Cd0 > 0 && p->Cd0 < 128 && (p->Cd0 % 32) == 0 && p->dst_sum2x2 == 1 && p->src0_mode == STP_SRC_DIRECT && p->Hs0 == p->Hv &&
+         p->Ws0 == p->Wv && p->Ho == p->Hv && p->Wo == p->Wv && !(p->Ho & 1) && !(p->Wo & 1) && !p->bias && !p->relu && !p->residual &&
+         !p->src_bn_mean && !p->stats_slots && !p->fold_src && !p->weight_up;
+}
+extern "C" int stp_conv2d_scw_stats_tiles(const stp_conv_params* p) {
+  return scw_blocks(p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW));
+}
+
+extern "C" int stp_conv2d_scw(const stp_conv_params* p, void* stream) {
+  if (!stp_conv2d_scw_eligible(p) || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
+  ScwArgs a;
+  a.src = (const char*)p->src0; a.weight = (const char*)p->weight; a.dst_up = (char*)p->dst0; a.dst_sk = (char*)p->dst1;
+  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.C0 = p->Cd0; a.C1 = p->Cout - p->Cd0; a.acc_up = p->accumulate0; a.acc_sk = p->accumulate1;
+  {
+    const uint64_t sb = (uint64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * 2;
+    if (sb >= 0x80000000ull) return STP_E_BADARG;   // 32-bit LDS-DMA offsets
+    a.src_bytes = (uint32_t)sb;
+  }
+  a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
+  a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
+  a.stats = p->stats_partial;
+  a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
+  a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
+  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd)) return STP_E_BADARG;
+  if (a.stats && !a.bnb.x) return STP_E_BADARG;      // the only sums this kernel fuses are the BatchNormalization-backward ones
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  const int blocks = scw_blocks(ntiles);
+  const_cast<stp_conv_params*>(p)->stats_tiles = blocks;
+  constexpr int NPASS = (SC_HH * SC_HW * 4 + 255) / 256;
+  const size_t lds = (size_t)2 * NPASS * 4096 + 512 * sizeof(float);
+  hipLaunchKernelGGL((conv_scw_stream_kernel<bf16_t>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// =================================================================================================
 // Stem: 7x7 / stride 2 / pad 3 convolution of the 4-channel (3 image channels + 1) bf16 input to 64 channels (ResNet conv0).
 // The generic implicit GEMM gathers 49 taps of 8 bytes per output pixel through the vector-memory path; this layer is
 // HBM-bound (33 MB in, 134 MB out at 16x512x512), so the same halo-tile scheme as above is used: the (2*8+5) x (2*32+5)

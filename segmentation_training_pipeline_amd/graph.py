@@ -869,12 +869,23 @@ class Plan(object):
                         q.accumulate0 = int(x.grad_ready)
                     else:
                         q.dst_sum2x2 = 0
+                two_dest = False
+                if upsample and x_ng and C1 and w4 is None and self.fold_upsample_grad:
+                    # ... and the wide-output kernel does the same for conv3x3(concat(UpSampling2D(2)(x), skip)): the first C0
+                    # channels are summed into the low-resolution gradient, the skip's C1 channels stay at full resolution
+                    q.dst_sum2x2 = 1
+                    if self.lib.stp_conv2d_scw_eligible(C.byref(q)):
+                        folded_up = two_dest = True
+                        q.dst0 = self._gradbuf(x).data_ptr()
+                        q.accumulate0 = int(x.grad_ready)
+                    else:
+                        q.dst_sum2x2 = 0
                 uses = x.meta.get("uses", 0)
                 # the only consumer, or the LAST of several (every other consumer has already written or accumulated its
                 # share, this data gradient accumulates on top): its epilogue sees the complete gradient of the BN output
                 sole = uses == 1 and not q.accumulate0
                 last = self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and q.accumulate0 and not upsample
-                if (self.fuse_bn_backward and bnm is not None and (sole or last) and (folded_up or not upsample) and qC1 == 0
+                if (self.fuse_bn_backward and bnm is not None and (sole or last) and (folded_up or not upsample) and (qC1 == 0 or two_dest)
                         and x_ng and C0 % 4 == 0):
                     q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
                     if self.slot_arena is not None and self.N * Hv * Wv <= self.bn_slots_max_rows:

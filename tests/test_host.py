@@ -449,7 +449,7 @@ def test_plan_structure_matches_unet_resnet34():
     # whose weight gradient waits in a pending group - the sum goes to a fresh buffer, that dY stays intact)
     assert bnames.count("stp_bn_backward_fused") + bnames.count("stp_bn_backward_fused_add") == 43 and bnames.count("stp_maxpool3x3s2_bwd_bn") == 0
     assert bnames.count("stp_bn_backward_fused_add") == 2              # stage1_unit3 / unit2 bn1 (the 16-pixel maps of stage 1 are grouped)
-    assert bnames.count("stp_upsample2x_bwd_bn") == 4 and bnames.count("stp_upsample2x_bwd") == 0    # 5 decoder stages, one folded
+    assert bnames.count("stp_upsample2x_bwd_bn") == 3 and bnames.count("stp_upsample2x_bwd") == 0    # 5 decoder stages, two folded
     # stream markers (honoured only with STP_SIDE_STREAM_WGRAD=1): one fork per per-layer chain and per group, a join at every convolution
     assert bnames.count("fork") == 48 - grouped + 3 and bnames.count("join") == 48
     assert "stp_add_inplace" not in bnames                             # every residual gradient aliases

@@ -1070,6 +1070,75 @@ def test_upsample_gradient_folded_into_small_channel_epilogue(ops, dtype, mode):
     np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, k))
 
 
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
+@pytest.mark.parametrize("c_up", [64, 32, 96])
+def test_wide_output_data_gradient_of_upsample_concat(ops, dtype, mode, c_up):
+    """stp_conv2d_scw: the data gradient of conv3x3(concat(UpSampling2D(2)(x), skip)) -> 32 channels in ONE launch - the first
+    c_up of the 128 output channels are summed 2x2 into the low-resolution gradient (optionally with the fused
+    BatchNormalization-backward mask + sums), the others are the skip gradient.  Must equal the generic two-destination kernel at
+    high resolution followed by stp_upsample2x_bwd (and the unfused BatchNormalization backward)."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co = 2, 20, 72, 32, 128        # ragged 8 x 32 tiles in both directions; more tiles than one workgroup pass
+    c_sk = co - c_up
+    rng = np.random.RandomState(33)
+    dyv = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    dy = dev(dyv, dtype)
+    acc = int(mode == "accumulate")
+    base_up, base_sk = q(rng.randn(n, h // 2, w // 2, c_up), dtype), q(rng.randn(n, h, w, c_sk), dtype)
+    fresh = lambda a: dev(a, dtype) if acc else torch.full(a.shape, float("nan"), dtype=TD[dtype], device=DEV)
+    mk = lambda d0, d1, tile: ops.conv_params(dy, fwd, d0, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
+                                              Cout=co, dtype=ops.dt(d0), dst1=d1, Cd0=c_up, accumulate1=acc, tile=tile)
+    # reference: generic kernel at high resolution, then the upsampling gradient
+    hi, want_sk, want_up = torch.empty((n, h, w, c_up), dtype=TD[dtype], device=DEV), fresh(base_sk), fresh(base_up)
+    R = mk(hi, want_sk, 0)
+    assert not _lib.load().stp_conv2d_scw_eligible(ops.C.byref(R))
+    ops.conv2d(R)
+    ops.upsample2x_bwd(hi, want_up, n, h // 2, w // 2, c_up, c_up, accumulate=acc)
+    got_sk, got_up = fresh(base_sk), fresh(base_up)
+    P = mk(got_up, got_sk, 0)
+    P.dst_sum2x2, P.accumulate0 = 1, acc
+    assert _lib.load().stp_conv2d_scw_eligible(ops.C.byref(P)) and _lib.load().stp_conv2d_tile_for(ops.C.byref(P)) == 640
+    if mode != "bn_backward":
+        ops.conv2d(P)
+        np.testing.assert_allclose(host(got_sk), host(want_sk), atol=tol(host(want_sk), dtype, 1.0))
+        # the unfused path rounds the hi-res gradient to 16 bits before summing, the fused one sums in fp32
+        np.testing.assert_allclose(host(got_up), host(want_up), atol=tol(host(want_up), dtype, 1.0))
+        return
+    rows = n * (h // 2) * (w // 2)
+    x = dev(q(rng.randn(n, h // 2, w // 2, c_up) + 0.2, dtype), dtype)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    g, b = f(rng.rand(c_up) + 0.5), f(rng.randn(c_up) * 0.3)
+    m, r = torch.empty(c_up, device=DEV), torch.empty(c_up, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(c_up) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(x, rows, c_up, 1e-3, 0.99, m, r, None, None, ws)
+    dx0, dg0, db0 = torch.empty_like(want_up), torch.empty(c_up, device=DEV), torch.empty(c_up, device=DEV)
+    ops.bn_backward(x, want_up, dx0, rows, c_up, m, r, g, b, dg0, db0, relu=1, accumulate_dx=0, workspace=ws)
+    P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(x), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1
+    st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    tiles = ops.conv2d_stats_floats(P) // (2 * c_up)
+    assert tiles == P.stats_tiles and np.isfinite(host(st)[:2 * c_up * tiles]).all()
+    np.testing.assert_allclose(host(got_sk), host(want_sk), atol=tol(host(want_sk), dtype, 1.0))
+    dx1, dg1, db1 = torch.empty_like(want_up), torch.empty(c_up, device=DEV), torch.empty(c_up, device=DEV)
+    ops.bn_backward_fused(x, got_up, dx1, rows, c_up, m, r, g, st, tiles, dg1, db1, accumulate_dx=0, workspace=ws)
+    np.testing.assert_allclose(host(db1), host(db0), atol=2e-2 * np.abs(host(db0)).max() + 1e-3)
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=2e-2 * np.abs(host(dg0)).max() + 1e-3)
+    pre = host(x) * (host(r) * host(g)) + (host(b) - host(m) * host(r) * host(g))
+    safe = np.abs(pre) > 1e-3
+    np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 1.0))
+    # replay: fixed partition, fixed order
+    st2 = torch.full_like(st, float("nan"))
+    P.stats_partial = ops.ptr(st2)
+    again = fresh(base_up)
+    P.dst0 = ops.ptr(again)
+    ops.conv2d(P)
+    assert torch.equal(again, got_up) and torch.equal(st2[:2 * c_up * tiles], st[:2 * c_up * tiles])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("C,Cy", [(5, 8), (4, 8), (7, 8), (1, 4)])
 def test_input_batchnorm_uint8_to_padded_channels(ops, dtype, C, Cy):
