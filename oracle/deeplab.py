@@ -29,6 +29,11 @@ DROPOUT_RATE = 0.1                                   # model.py:461
 DROPOUT_SALT = 0x0D0D
 
 
+def logits_name(classes):
+    """model.py:494-497: 'logits_semantic' for the 21 PASCAL-VOC classes, 'custom_logits_semantic' otherwise."""
+    return "logits_semantic" if classes == 21 else "custom_logits_semantic"
+
+
 def _glorot(rng, shape, fan_in, fan_out):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)
@@ -65,8 +70,8 @@ def init_deeplab_mobilenetv2(in_ch=3, classes=1, seed=42):
         _bn(P, name + "_BN", 256)
     P["concat_projection/kernel"] = _glorot(rng, (1, 1, 512, 256), 512, 256)
     _bn(P, "concat_projection_BN", 256)
-    P["custom_logits_semantic/kernel"] = _glorot(rng, (1, 1, 256, classes), 256, classes)
-    P["custom_logits_semantic/bias"] = np.zeros(classes, np.float32)
+    P[logits_name(classes) + "/kernel"] = _glorot(rng, (1, 1, 256, classes), 256, classes)
+    P[logits_name(classes) + "/bias"] = np.zeros(classes, np.float32)
     return P
 
 
@@ -155,8 +160,8 @@ def init_deeplab_xception(in_ch=3, classes=1, seed=42):
     conv("feature_projection0", 1, 256, 48); _bn(P, "feature_projection0_BN", 48)
     sep("decoder_conv0", 256 + 48, 256)
     sep("decoder_conv1", 256, 256)
-    conv("custom_logits_semantic", 1, 256, classes)
-    P["custom_logits_semantic/bias"] = np.zeros(classes, np.float32)
+    conv(logits_name(classes), 1, 256, classes)
+    P[logits_name(classes) + "/bias"] = np.zeros(classes, np.float32)
     return P
 
 
@@ -234,13 +239,13 @@ def deeplab_xception_forward(P, x_nhwc, training=True, taps=None, step=1, OS=16)
         n, c, hh, ww = x.shape
         keep = dropout_mask(step, DROPOUT_SALT, n * hh * ww * c, DROPOUT_RATE).reshape(n, hh, ww, c).transpose(0, 3, 1, 2)
         x = x * torch.from_numpy(keep.astype(np.float32)) / (1.0 - DROPOUT_RATE)
-    x = F.interpolate(x, size=(H // 4, W // 4), mode="bilinear", align_corners=True)                   # model.py:476-477
+    x = F.interpolate(x, size=(-(-H // 4), -(-W // 4)), mode="bilinear", align_corners=True)         # model.py:480-481 (ceil)
     d = _bn_act(ctx, _conv_same(P, skip1, "feature_projection0"), "feature_projection0_BN", BN_ASPP, "relu")
     x = torch.cat([x, d], dim=1)
     x = _sepconv_bn(ctx, x, 256, "decoder_conv0", depth_activation=True, cfg=BN_ASPP)
     x = _sepconv_bn(ctx, x, 256, "decoder_conv1", depth_activation=True, cfg=BN_ASPP)
     ctx.tap("decoder", x)
-    z = _conv_same(P, x, "custom_logits_semantic")
+    z = _conv_same(P, x, "logits_semantic" if "logits_semantic/kernel" in P else "custom_logits_semantic")
     p = torch.sigmoid(z) if z.shape[1] == 1 else torch.softmax(z, dim=1)          # model.py:485: the activation lives in this layer
     p = F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True)
     return p.permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
@@ -287,7 +292,7 @@ def deeplab_forward(P, x_nhwc, training=True, taps=None, step=1):
         n, c, hh, ww = x.shape
         keep = dropout_mask(step, DROPOUT_SALT, n * hh * ww * c, DROPOUT_RATE).reshape(n, hh, ww, c).transpose(0, 3, 1, 2)
         x = x * torch.from_numpy(keep.astype(np.float32)) / (1.0 - DROPOUT_RATE)
-    z = _conv_same(P, x, "custom_logits_semantic")                              # model.py:485 - the activation lives in this layer
+    z = _conv_same(P, x, "logits_semantic" if "logits_semantic/kernel" in P else "custom_logits_semantic")                              # model.py:485 - the activation lives in this layer
     p = torch.sigmoid(z) if z.shape[1] == 1 else torch.softmax(z, dim=1)       # sigmoid: one class; softmax: 2+ classes
     p = F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True)      # model.py:486
     return p.permute(0, 2, 3, 1).contiguous(), ctx.bn_updates

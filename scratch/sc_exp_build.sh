@@ -9,7 +9,7 @@ for n in ${EXPS:-11 12 13}; do
 done
 wait
 for n in ${EXPS:-11 12 13}; do
-  objs=$(ls $C/_obj/*.o | grep -v -e conv_sc.o)
+  objs=$(ls $C/_obj/*.o | grep -v -e "conv_sc\.o" -e "\.f16\.o" -e "_prev\.o")
   hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/_exp/libstp_sc_exp$n.so scratch/_exp/conv_sc_exp$n.o $objs
 done
 ls -la scratch/_exp/*.so

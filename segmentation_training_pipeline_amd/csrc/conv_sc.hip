@@ -705,7 +705,7 @@ struct ScwArgs {
   FastDiv divTx, divTy;
   float* stats;         // [2][C0][workgroups] (fused BatchNormalization-backward sums of the first C0 channels)
   BnBack bnb;
-  uint32_t src_bytes;
+  uint32_t src_bytes, x_bytes;   // sizes of src and bnb.x (buffer descriptors of the LDS-DMA)
 };
 
 template <typename T>
@@ -715,11 +715,19 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
   static_assert(SZ == 2, "16-bit storage");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ktab = reinterpret_cast<float*>(smem + 2 * BUF);     // [4][128]: scale, shift, mean, rstd of the first C0 channels
+  // [2][XBUF]: the BatchNormalization input of the tile's 4 x 16 low-resolution pixels ([pixel][C0]), staged by LDS-DMA with the
+  // halo tile - a tile ahead of its use (fetched where it is used, each pass of the summed epilogue stalled on an HBM round trip:
+  // 135 vs 86 us without the fused sums)
+  constexpr int XBUF = 3 * 4096;
+  char* const xlds = smem + 2 * BUF + 2048;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int cb = wave * 32;                                   // this wave's output channels
-  const bool upw = cb < a.C0;                                 // (wave-uniform) summed epilogue / skip epilogue
+  // this wave's two 16-channel groups.  With as many summed as skip channels (the U-Net shape) every wave takes one group of each:
+  // the summed epilogue carries the BatchNormalization-backward arithmetic, and two waves doing all of it while the other two
+  // wait at the tile barrier cost 40 us of 125
+  const int cbi[2] = {a.C0 == 64 ? wave * 16 : wave * 32, a.C0 == 64 ? 64 + wave * 16 : wave * 32 + 16};
+  const bool upi[2] = {cbi[0] < a.C0, cbi[1] < a.C0};          // (wave-uniform) summed epilogue / skip epilogue
 
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
   int t_first, t_step, t_end;
@@ -739,6 +747,10 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
   }
 
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  const int H2 = a.H >> 1, W2 = a.W >> 1;
+  const bool bnb = a.bnb.x != nullptr;
+  const bool xrs_on = bnb;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? a.bnb.x : a.src), 0, bnb ? a.x_bytes : 0u, 0x00020000);
   int hyx[NPASS];
   const int cvb = (tid % VPP) * 16;
 #pragma unroll
@@ -746,6 +758,15 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
     const int v = p * 256 + tid, pix = v / VPP;
     const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
     hyx[p] = v < NV ? (hy << 16 | hx) : -1;
+  }
+  int xq[3];                 // vector p * 256 + tid of the x tile: low-res row << 16 | column << 8 | 16-byte vector of the pixel; -1 past it
+  {
+    const int vpp = a.C0 >> 3;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int v = p * 256 + tid, px = v / vpp;
+      xq[p] = (xrs_on && px < 64) ? ((px >> 4) << 16 | (px & 15) << 8 | (v - px * vpp)) : -1;
+    }
   }
   auto decode = [&](int tile, int& n, int& y0, int& x0) {
     const int bq = (int)fdiv((uint32_t)tile, a.divTx);
@@ -762,8 +783,20 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
       const int gy = y0 - 1 + (hyx[p] >> 16), gx = x0 - 1 + (hyx[p] & 0xffff);
       const bool ok = hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
       const uint32_t off = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
+#if !defined(STP_EXP) || STP_EXP != 32   // (what-if builds, scratch/sc_exp_build.sh: 31 = no output stores, 32 = no halo loads, 33 = no LDS reads / MFMAs)
       if (p * 256 + wave * 64 < NV)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
+#endif
+    }
+    if (xrs_on) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const int ly = (y0 >> 1) + (xq[p] >> 16), lx = (x0 >> 1) + ((xq[p] >> 8) & 0xff);
+        const bool ok = xq[p] >= 0 && ly < H2 && lx < W2;
+        const uint32_t off = ok ? (uint32_t)(((n * H2 + ly) * W2 + lx) * a.C0 + (xq[p] & 0xff) * 8) * 2u : 0x80000000u;
+        if (p * 256 + wave * 64 < 8 * a.C0)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(xlds + b * XBUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
+      }
     }
   };
   issue_tile(t_first, 0);
@@ -774,9 +807,8 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      fa[i][c] = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(cb + i * 16 + lr) * K + c * CIN + lg * 8) * SZ);
+      fa[i][c] = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(cbi[i] + lr) * K + c * CIN + lg * 8) * SZ);
   const uint32_t lbase = (uint32_t)((lr * CIN + lg * 8) * SZ);     // lane part of every B-fragment address
-  const bool bnb = a.bnb.x != nullptr;
   if (bnb && tid < 128) {
     float sc = 0.f, sh = 0.f, mu = 0.f, rsd = 0.f;
     if (tid < a.C0) {
@@ -786,121 +818,158 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
     }
     ktab[tid] = sc; ktab[128 + tid] = sh; ktab[256 + tid] = mu; ktab[384 + tid] = rsd;
   }
-  f32x4 ssp[2], qqp[2];
+  f32x2 ssp[2], qqp[2];        // fused sums of the lane's two channels (see the summed epilogue)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { ssp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qqp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  lds_barrier();               // the table is visible
-  const int H2 = a.H >> 1, W2 = a.W >> 1;
+  for (int i = 0; i < 2; ++i) { ssp[i] = f32x2{0.f, 0.f}; qqp[i] = f32x2{0.f, 0.f}; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile's own pieces have landed
+  lds_barrier();               // ... everybody's; the table is visible
   T* const oup = reinterpret_cast<T*>(a.dst_up);
   T* const osk = reinterpret_cast<T*>(a.dst_sk);
-  const T* const xbn = reinterpret_cast<const T*>(a.bnb.x);
 
   auto body = [&](int tile, auto curc) {
     constexpr int CUR = decltype(curc)::value;
     int n, y0, x0;
     decode(tile, n, y0, x0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's own pieces have landed
-    lds_barrier();                                        // ... everybody's; and every wave has left the other half
+    // (this tile's halo is complete and visible, and every wave has left the other half: the wait + barrier at the end of the
+    //  previous tile - there the wait sits BEFORE the last pass's stores, so it drains the stores of a pass ago instead of the
+    //  ones just issued: at the top of the tile it exposed a store round trip per tile)
     const int next = tile + t_step;
-    // BatchNormalization input of the summed epilogue, one pass at a time: pass 0's is issued before the next tile's LDS-DMA (waiting
-    // for it does not wait for that tile), pass 1's under pass 1's MFMAs (the DMA, issued a pass earlier, has landed by then)
-    ScRaw4<T> xpre[2][2][2];          // [row pair][column half][channel tile]
-    auto prefetch = [&](int h) {
-      if (!(upw && bnb)) return;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int gy = y0 + h * 4 + q * 2, gx = x0 + h2 * 16 + lr;
-          const bool ok = !(lr & 1) && gy < a.H && gx < a.W;
-          const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) xpre[q][h2][i].load(xbn + (ok ? pm * a.C0 + cb + i * 16 + lg * 4 : (size_t)0));
-        }
-    };
-    prefetch(0);
     if (next < t_end) issue_tile(next, CUR ^ 1);
 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (h == 1) prefetch(1);
       f32x4 acc[2][8];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int f = 0; f < 8; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // a B fragment = 16 pixels of halo row r shifted by kw: it serves the taps (kh, kw) of the output rows r - kh, so each of the
+      // 6 x 3 x 2 fragments of a pass is read ONCE and used by up to three output rows (36 LDS reads for 72 fragment uses).
+      // Software pipeline, three reads ahead: left alone the compiler keeps ONE fragment register (ds_read -> lgkmcnt(0) -> 2-6
+      // MFMAs: 36 exposed LDS latencies a pass); the scheduling barriers pin read s + 3 in front of the MFMAs of read s
+      auto bfrag = [&](int sidx) -> u32x4 {
+        const int r = sidx / 6, kw = (sidx >> 1) % 3, h2 = sidx & 1;
+        return *reinterpret_cast<const u32x4*>(smem + lbase + (CUR * BUF + ((h * 4 + r) * SC_HW + h2 * 16 + kw) * PIXB));
+      };
+      u32x4 fbq[4];
+#if defined(STP_EXP) && STP_EXP == 33
+      if (a.N < 0) acc[0][0][0] += __uint_as_float(fa[0][h][0] + fa[1][h][1] + lbase);
+#else
+      fbq[0] = bfrag(0); fbq[1] = bfrag(1); fbq[2] = bfrag(2);
 #pragma unroll
-      for (int f = 0; f < 8; ++f) {
+      for (int sidx = 0; sidx < 36; ++sidx) {
+#if !defined(STP_EXP) || STP_EXP != 34
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (sidx + 3 < 36) fbq[(sidx + 3) & 3] = bfrag(sidx + 3);
+        const int r = sidx / 6, kw = (sidx >> 1) % 3, h2 = sidx & 1;
+        const u32x4 fb = fbq[sidx & 3];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int kh = c / 3, kw = c - kh * 3;
-          const u32x4 fb = *reinterpret_cast<const u32x4*>(smem + lbase + (CUR * BUF + ((h * 4 + (f >> 1) + kh) * SC_HW + (f & 1) * 16 + kw) * PIXB));
-          acc[0][f] = mfma16_16x16x32(fa[0][c], fb, acc[0][f]);
-          acc[1][f] = mfma16_16x16x32(fa[1][c], fb, acc[1][f]);
+        for (int kh = 0; kh < 3; ++kh) {
+          const int orow = r - kh;
+          if (orow < 0 || orow > 3) continue;
+          acc[0][orow * 2 + h2] = mfma16_16x16x32(fa[0][kh * 3 + kw], fb, acc[0][orow * 2 + h2]);
+          acc[1][orow * 2 + h2] = mfma16_16x16x32(fa[1][kh * 3 + kw], fb, acc[1][orow * 2 + h2]);
         }
       }
-      if (upw) {
-        // gradient of UpSampling2D(2): fragments f and f + 2 are the two rows of an output row, lanes lr and lr ^ 1 its columns
+#if !defined(STP_EXP) || STP_EXP != 34
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
+      if (h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's own pieces have landed (issued two passes ago)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+      for (int i = 0; i < 2; ++i) {
+        if (upi[i]) {
+          // gradient of UpSampling2D(2): fragments f and f + 2 are the two rows of an output row, lanes lr and lr ^ 1 its columns.
+          // After the quad_perm add both lanes of a pair hold the 4 channel sums: the even lane finishes channels 0, 1, the odd lane
+          // channels 2, 3 (half the per-lane arithmetic of the fused BatchNormalization backward, 4-byte accesses, no idle lanes)
+          const int par = lr & 1;
+          const int co = cbi[i] + lg * 4 + 2 * par;
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const int gy = y0 + h * 4 + q * 2, gx = x0 + h2 * 16 + lr;
-            const bool own = !(lr & 1) && gy < a.H && gx < a.W;
-            const size_t pm = ((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1);
+          for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int h2 = 0; h2 < 2; ++h2) {
+              asm volatile("" ::: "memory");       // (keeps the table / x reads of the iterations from being hoisted together: registers)
+              const int gy = y0 + h * 4 + q * 2, gx = x0 + h2 * 16 + lr;
               f32x4 v = acc[i][q * 4 + h2] + acc[i][q * 4 + h2 + 2];
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-              if (!own) continue;
-              const int co = cb + i * 16 + lg * 4;
-              if (a.acc_up) v += load4(oup + pm * a.C0 + co);
-              if (bnb) {
-                BnBackCh k;
-                k.sc = *reinterpret_cast<const f32x4*>(ktab + co); k.sh = *reinterpret_cast<const f32x4*>(ktab + 128 + co);
-                k.mu = *reinterpret_cast<const f32x4*>(ktab + 256 + co); k.rs = *reinterpret_cast<const f32x4*>(ktab + 384 + co);
-                v = bnback_apply(k, a.bnb.relu, xpre[q][h2][i].get(), sc_stored(v, (const T*)nullptr), ssp[i], qqp[i]);
+              if (gy >= a.H || gx >= a.W) continue;
+              f32x2 v2 = par ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+              T* d = oup + (((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1)) * a.C0 + co;
+              if (a.acc_up) {
+                const uint32_t w0 = *reinterpret_cast<const uint32_t*>(d);
+                v2 += f32x2{h16lo_to_f32(w0), h16hi_to_f32(w0)};
               }
-              store4(oup + pm * a.C0 + co, v);
+              uint32_t w = pack_bf16x2(v2.x, v2.y);
+              if (bnb) {
+                const f32x2 ksc = *reinterpret_cast<const f32x2*>(ktab + co), ksh = *reinterpret_cast<const f32x2*>(ktab + 128 + co);
+                const f32x2 kmu = *reinterpret_cast<const f32x2*>(ktab + 256 + co), krs = *reinterpret_cast<const f32x2*>(ktab + 384 + co);
+                const uint32_t xw = *reinterpret_cast<const uint32_t*>(xlds + CUR * XBUF + (((h * 2 + q) * 16 + h2 * 8 + (lr >> 1)) * a.C0 + co) * 2);
+                const f32x2 xv = {h16lo_to_f32(xw), h16hi_to_f32(xw)}, dy = {h16lo_to_f32(w), h16hi_to_f32(w)};     // dY as stored
+                f32x2 g;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  g[e] = bn_act_on(bn_affine(xv[e], ksc[e], ksh[e]), a.bnb.relu) ? dy[e] : 0.f;
+                  ssp[i][e] += g[e];
+                  qqp[i][e] += g[e] * ((xv[e] - kmu[e]) * krs[e]);
+                }
+                w = pack_bf16x2(g.x, g.y);
+              }
+#if defined(STP_EXP) && STP_EXP == 31
+              if (a.N < 0)
+#endif
+              *reinterpret_cast<uint32_t*>(d) = w;
             }
-          }
-      } else {
+        } else {
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          const int gy = y0 + h * 4 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
-          if (gy >= a.H || gx >= a.W) continue;
-          const size_t pm = ((size_t)n * a.H + gy) * a.W + gx;
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            T* d = osk + pm * a.C1 + (cb - a.C0) + i * 16 + lg * 4;
+          for (int f = 0; f < 8; ++f) {
+            const int gy = y0 + h * 4 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+            if (gy >= a.H || gx >= a.W) continue;
+            T* d = osk + (((size_t)n * a.H + gy) * a.W + gx) * a.C1 + (cbi[i] - a.C0) + lg * 4;
             f32x4 v = acc[i][f];
             if (a.acc_sk) v += load4(d);
+#if defined(STP_EXP) && STP_EXP == 31
+            if (a.N < 0)
+#endif
             store4(d, v);
           }
         }
       }
     }
+    lds_barrier();        // the next tile is visible to everybody, and everybody has left this one
   };
 
   for (int tile = t_first; tile < t_end; tile += 2 * t_step) {
     body(tile, std::integral_constant<int, 0>{});
     if (tile + t_step < t_end) body(tile + t_step, std::integral_constant<int, 1>{});
   }
-  // fused sums: one column per workgroup; each summed-epilogue wave owns its 32 channels outright (no cross-wave step)
-  if (a.stats && upw) {
+  // fused sums: one column per workgroup; a 16-channel group belongs to one wave outright (no cross-wave step).  Even lanes hold
+  // the sums of channels 0, 1 of their 4-channel block, odd lanes of channels 2, 3: row_shr 2, 4, 8 leave them in lanes 14 and 15
+  if (a.stats) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      if (!upi[i]) continue;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sv = row_sum16_to_lane15(ssp[i][e]), qv = row_sum16_to_lane15(qqp[i][e]);
-        if (lr == 15) {
-          const int ch = cb + i * 16 + lg * 4 + e;
+      for (int e = 0; e < 2; ++e) {
+        float sv = ssp[i][e], qv = qqp[i][e];
+#pragma unroll
+        for (int sh = 0; sh < 3; ++sh) {
+          sv += __builtin_bit_cast(float, sh == 0 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x112, 0xf, 0xf, true)
+                                          : sh == 1 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x114, 0xf, 0xf, true)
+                                                    : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x118, 0xf, 0xf, true));
+          qv += __builtin_bit_cast(float, sh == 0 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv), 0x112, 0xf, 0xf, true)
+                                          : sh == 1 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv), 0x114, 0xf, 0xf, true)
+                                                    : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv), 0x118, 0xf, 0xf, true));
+        }
+        if (lr >= 14) {
+          const int ch = cbi[i] + lg * 4 + 2 * (lr & 1) + e;
           a.stats[(size_t)ch * gridDim.x + blockIdx.x] = sv;
           a.stats[((size_t)a.C0 + ch) * gridDim.x + blockIdx.x] = qv;
         }
       }
+    }
   }
 }
 
@@ -931,6 +1000,7 @@ extern "C" int stp_conv2d_scw(const stp_conv_params* p, void* stream) {
     const uint64_t sb = (uint64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * 2;
     if (sb >= 0x80000000ull) return STP_E_BADARG;   // 32-bit LDS-DMA offsets
     a.src_bytes = (uint32_t)sb;
+    a.x_bytes = (uint32_t)((uint64_t)p->N * (p->Hv / 2) * (p->Wv / 2) * p->Cd0 * 2);    // (a quarter of the pixels, < 128 channels: smaller)
   }
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
   a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
@@ -943,7 +1013,13 @@ extern "C" int stp_conv2d_scw(const stp_conv_params* p, void* stream) {
   const int blocks = scw_blocks(ntiles);
   const_cast<stp_conv_params*>(p)->stats_tiles = blocks;
   constexpr int NPASS = (SC_HH * SC_HW * 4 + 255) / 256;
-  const size_t lds = (size_t)2 * NPASS * 4096 + 512 * sizeof(float);
+  const size_t lds = (size_t)2 * NPASS * 4096 + 512 * sizeof(float) + 2 * 3 * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_scw_stream_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
+  }
   hipLaunchKernelGGL((conv_scw_stream_kernel<bf16_t>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
   STP_LAUNCH_CHECK();
   return STP_OK;

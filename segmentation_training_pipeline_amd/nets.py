@@ -229,6 +229,12 @@ MOBILENETV2_BLOCKS = [(16, 1, 1, 0, False, 1), (24, 2, 6, 1, False, 1), (24, 1, 
                       (32, 1, 6, 5, True, 1), (64, 1, 6, 6, False, 1), (64, 1, 6, 7, True, 2), (64, 1, 6, 8, True, 2), (64, 1, 6, 9, True, 2),
                       (96, 1, 6, 10, False, 2), (96, 1, 6, 11, True, 2), (96, 1, 6, 12, True, 2), (160, 1, 6, 13, False, 2),
                       (160, 1, 6, 14, True, 4), (160, 1, 6, 15, True, 4), (320, 1, 6, 16, False, 4)]
+def deeplab_logits_name(classes):
+    """impl/deeplab/model.py:494-497: the class convolution is 'logits_semantic' for the 21 PASCAL-VOC classes (so that the published
+    weights load by name) and 'custom_logits_semantic' for any other count."""
+    return "logits_semantic" if classes == 21 else "custom_logits_semantic"
+
+
 DEEPLAB_DROPOUT_SALT = 0x0D0D
 DECODER_DROPOUT_SALT = 0x5D0D      # FPN / PSPNet `dropout` (SpatialDropout2D)
 
@@ -245,8 +251,8 @@ def deeplab_mobilenetv2(plan, backbone, H, W, in_ch=3, classes=1, decoder_filter
         raise ValueError("Unknown backbone")        # (the xception branch is not built)
     if not 1 <= classes <= 32:
         raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head and 2..32-class softmax heads")
-    if H % 8 or W % 8 or H != W:
-        raise ValueError("DeepLabV3 (output stride 8) needs a square input divisible by 8")
+    if H != W:
+        raise ValueError("DeepLabV3 needs a square input (any size: the reference sizes its layers with ceil(input / OS), model.py:440-445)")
     mob = dict(momentum=0.999)
     img = plan.input_u8("image", H, W, in_ch)
     x = plan.input_cast("input_cast", img)
@@ -268,7 +274,7 @@ def deeplab_mobilenetv2(plan, backbone, H, W, in_ch=3, classes=1, decoder_filter
     cat = plan.concat_resize("aspp_concat", [(b4, x.H), (b0, 1)])
     y = plan.bn("concat_projection_BN", plan.conv("concat_projection", cat, 256, 1, bn_stats=True), 1e-5, relu=1)
     y = plan.dropout("dropout", y, 0.1, DEEPLAB_DROPOUT_SALT)
-    z = plan.conv("custom_logits_semantic", y, classes, 1, bias=True)
+    z = plan.conv(deeplab_logits_name(classes), y, classes, 1, bias=True)
     p_lo = plan.sigmoid_act("probs_lo", z)
     probs = plan.resize_ac("logits", p_lo, H, W)          # named like the other heads' output tensor; holds PROBABILITIES
     if with_loss:
@@ -320,8 +326,8 @@ def deeplab_xception(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=N
     activation; align-corners bilinear upsampling of the probabilities."""
     if not 1 <= classes <= 32:
         raise ValueError("the HIP DeepLabV3 trains the 1-class sigmoid head and 2..32-class softmax heads")
-    if OS not in (8, 16) or H != W or H % OS:
-        raise ValueError("DeepLabV3 / xception needs a square input divisible by the output stride (8 or 16)")
+    if OS not in (8, 16) or H != W:
+        raise ValueError("DeepLabV3 / xception needs a square input and output stride 8 or 16")
     b3_stride, mid_rate, exit_rates, aspp_rates = (1, 2, (2, 4), (12, 24, 36)) if OS == 8 else (2, 1, (1, 2), (6, 12, 18))
     img = plan.input_u8("image", H, W, in_ch)
     x = plan.input_cast("input_cast", img)
@@ -341,12 +347,12 @@ def deeplab_xception(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=N
     cat = plan.concat_resize("aspp_concat", [(b4, x.H), (b0, 1)] + [(b, 1) for b in bs])
     y = plan.bn("concat_projection_BN", plan.conv("concat_projection", cat, 256, 1, bn_stats=True), 1e-5, relu=1)
     y = plan.dropout("dropout", y, 0.1, DEEPLAB_DROPOUT_SALT)
-    y = plan.resize_ac("decoder_upsample", y, H // 4, W // 4)
+    y = plan.resize_ac("decoder_upsample", y, -(-H // 4), -(-W // 4))      # model.py:480-481: ceil(input / 4) = skip1's size
     d = plan.bn("feature_projection0_BN", plan.conv("feature_projection0", skip1, 48, 1, bn_stats=True), 1e-5, relu=1)
     y = plan.concat_resize("decoder_concat", [(y, 1), (d, 1)])
     y = _sepconv_bn(plan, y, 256, "decoder_conv0", depth_activation=True, eps=1e-5)
     y = _sepconv_bn(plan, y, 256, "decoder_conv1", depth_activation=True, eps=1e-5)
-    z = plan.conv("custom_logits_semantic", y, classes, 1, bias=True)
+    z = plan.conv(deeplab_logits_name(classes), y, classes, 1, bias=True)
     p_lo = plan.sigmoid_act("probs_lo", z)
     probs = plan.resize_ac("logits", p_lo, H, W)
     if with_loss:

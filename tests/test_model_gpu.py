@@ -941,6 +941,37 @@ def test_fp32_deeplabv3_multiclass_head_matches_oracle(backbone, classes):
     assert np.isfinite(l1) and l1 < l0
 
 
+@pytest.mark.parametrize("backbone", ["mobilenetv2", "xception"])
+def test_fp32_deeplabv3_non_divisible_input_and_voc_layer_name(backbone):
+    """impl/deeplab/model.py:440,445,480-481 size its pooling / upsampling layers with ceil(input / OS) and ceil(input / 4), and
+    :494-497 names the class convolution 'logits_semantic' when there are 21 classes: a 65 x 65 input (feature maps 33 / 17 / 9 / 5
+    under TF 'same' padding) with 21 softmax classes, one fp32 step against the oracle."""
+    from oracle import deeplab as odl
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    n, size, classes = 2, 65, 21
+    P = (odl.init_deeplab_mobilenetv2 if backbone == "mobilenetv2" else odl.init_deeplab_xception)(classes=classes, seed=42)
+    assert "logits_semantic/kernel" in P and "custom_logits_semantic/kernel" not in P
+    x, _ = ostep.synthetic_batch(n, size, size, seed=21)
+    yy, xx = np.mgrid[0:size, 0:size]
+    y = ((yy // 7 + xx // 11) % classes).astype(np.uint8)[None, :, :, None].repeat(n, axis=0)
+    spec = "categorical_crossentropy+0.5*dice_loss"
+    kw = {"net_kwargs": {"OS": 16}} if backbone == "xception" else {}
+    tr = ostep.OracleTrainer(P, backbone=backbone, loss=spec, optimizer="sgd", lr=0.02, architecture="DeepLabV3", activation="softmax", **kw)
+    m = HipSegModel("DeepLabV3", backbone, (size, size, 3), classes, "softmax", batch=n, dtype="fp32", loss=spec, optimizer="SGD", lr=0.02,
+                    use_graph=False, **kw)
+    assert sorted(m.get_weights()) == sorted(P)
+    m.set_weights(P)
+    o = tr.step(x.astype(np.float32), y.astype(np.float32))
+    met = m.train_on_batch(x, y)
+    assert m.logits().shape == (n, size, size, classes)
+    np.testing.assert_allclose(m.logits(), o["logits"], atol=2.5e-4)
+    assert abs(met["dice_loss"] - o["dice_loss"]) < 1e-5 and abs(met["loss"] - o["loss"]) < 2e-5
+    g = m.get_gradients()
+    for k, ref in o["grads"].items():
+        e = np.linalg.norm(g[k].astype(np.float64) - ref) / (np.linalg.norm(ref.astype(np.float64)) + 1e-3)
+        assert e <= (1e-4 if k.startswith("logits_semantic") else 8e-2), "grad %s: rel L2 %.3g" % (k, e)
+
+
 @pytest.mark.parametrize("backbone,block", [("resnet18", "transpose"), ("vgg16", "upsampling"), ("vgg16", "transpose")])
 def test_linknet_transpose_blocks_and_vgg_encoders_match_the_oracle(backbone, block):
     """Linknet's `decoder_block_type: transpose` (1x1 -> Conv2DTranspose 4x4 s2 -> 1x1, schemas/segmentation.raml:166-169) and
