@@ -2,11 +2,11 @@
 shape of the U-Net/ResNet34 512x512 bs16 step.  EXP=<n> loads the what-if build scratch/_exp/libstp_sc_exp<n>.so
 (scratch/sc_exp_build.sh: 11 = no output stores, 12 = no halo loads, 13 = no LDS reads / MFMAs)."""
 import sys, os, torch
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from segmentation_training_pipeline_amd import _lib
 exp = os.environ.get("EXP")
 if exp:
-    _lib.LIB_PATH = os.path.abspath("scratch/_exp/libstp_sc_exp%s.so" % exp)
+    _lib.LIB_PATH = os.path.join(ROOT, "scratch/_exp/libstp_sc_exp%s.so" % exp)
 from segmentation_training_pipeline_amd import ops
 DEV = "cuda"
 # name, N, H, W, Cin, Cout, upsampled source

@@ -1,11 +1,11 @@
 """Wide-output small-channel data gradient (decoder_stage3_conv1 dgrad, 16 x 256 x 256, 32 -> 64 summed + 64 skip): HIP-event time.
 EXP=<n> loads scratch/_exp/libstp_sc_exp<n>.so (31 = no output stores, 32 = no halo loads, 33 = no LDS reads / MFMAs)."""
 import sys, os, torch
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from segmentation_training_pipeline_amd import _lib
 exp = os.environ.get("EXP")
 if exp:
-    _lib.LIB_PATH = os.path.abspath("scratch/_exp/libstp_sc_exp%s.so" % exp)
+    _lib.LIB_PATH = os.path.join(ROOT, "scratch/_exp/libstp_sc_exp%s.so" % exp)
 from segmentation_training_pipeline_amd import ops
 DEV = "cuda"
 def timeit(fn, n=30):

@@ -949,10 +949,56 @@ struct WeightPrepDesc {
 // from the fp32 master (cin fastest: coalesced), held in LDS, and written twice: the forward copy in the same
 // orientation and the data-gradient copy transposed (cout fastest) with the taps flipped - both coalesced.
 // Padding (Cinp > Cin, KWp > KW, row padding to 16, CoutB > Cout) is written as zeros.
+// 16-bit layers without padding (Cin a multiple of 64, Cout of 32: every layer that matters by bytes): a unit is (tap, 32 cout,
+// 64 cin) - 16-byte loads of the fp32 master, 16-byte stores of BOTH copies (8 consecutive cin of a cout row forward, 8 consecutive
+// cout of a cin row transposed).  Same rounding per element as the generic path below: bit-identical copies.
+template <typename T>
+__device__ __forceinline__ void weight_prepare_fast_layer(const WeightPrepDesc& d, float (*tile)[65]) {
+  const int CT = d.Cout >> 5, IT = d.Cin >> 6, taps = d.KH * d.KW;
+  const int units = taps * CT * IT;
+  const int tid = threadIdx.x;
+  T* fwd = reinterpret_cast<T*>(d.fwd);
+  T* bwd = reinterpret_cast<T*>(d.bwd);
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int it = u % IT, ct = (u / IT) % CT, tap = u / (IT * CT);
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int co0 = ct * 32, ci0 = it * 64;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = p * 16 + (tid >> 4), c4 = (tid & 15) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.master + (((int64_t)(co0 + r) * d.KH + kh) * d.KW + kw) * d.Cin + ci0 + c4);
+      tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    if (fwd) {
+      const int r = tid >> 3, c8 = (tid & 7) * 8;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(tile[r][c8 + 2 * e], tile[r][c8 + 2 * e + 1]);
+      *reinterpret_cast<u32x4*>(fwd + (((int64_t)(co0 + r) * d.KH + kh) * d.KW + kw) * d.Cin + ci0 + c8) = o;
+    }
+    if (bwd) {
+      const int ci = tid >> 2, c8 = (tid & 3) * 8;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(tile[c8 + 2 * e][ci], tile[c8 + 2 * e + 1][ci]);
+      *reinterpret_cast<u32x4*>(bwd + (((int64_t)(ci0 + ci) * d.KH + (d.KH - 1 - kh)) * d.KW + (d.KW - 1 - kw)) * d.Cout + co0 + c8) = o;
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prepare_batched_kernel(const WeightPrepDesc* __restrict__ desc, int nlayers, int64_t total) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[32][65];
   const WeightPrepDesc d = desc[blockIdx.y];
+  if constexpr (sizeof(T) == 2) {
+    if (!(d.Cin & 63) && !(d.Cout & 31) && d.Cinp == d.Cin && d.KWp == d.KW && d.CoutB == d.Cout && d.rows_f == d.Cout && d.rows_b == d.Cin &&
+        !(reinterpret_cast<uintptr_t>(d.master) & 15) && !(reinterpret_cast<uintptr_t>(d.fwd) & 15) && !(reinterpret_cast<uintptr_t>(d.bwd) & 15)) {
+      weight_prepare_fast_layer<T>(d, tile);
+      return;
+    }
+  }
   const int co_ext = d.bwd ? (d.rows_f > d.CoutB ? d.rows_f : d.CoutB) : d.rows_f;
   const int ci_ext = d.bwd ? (d.Cinp > d.rows_b ? d.Cinp : d.rows_b) : d.Cinp;
   const int CT = (co_ext + 31) >> 5, IT = (ci_ext + 31) >> 5, taps = d.KH * d.KWp;
@@ -1029,6 +1075,30 @@ struct UpcollapseDesc {     // 32 bytes (the host packs it as two pointers + fou
 template <typename T>
 __device__ __forceinline__ void weight_upcollapse_layer(const UpcollapseDesc& d, int64_t first, int64_t stride) {
   T* out = reinterpret_cast<T*>(d.out);
+  if constexpr (sizeof(T) == 2) {
+    // 8 consecutive input channels per thread (C0 and Ctot multiples of 8, 16-byte aligned rows): 16-byte loads and stores, 32-bit
+    // index arithmetic; same fp32 sums in the same order, one rounding: bit-identical to the element-wise loop below
+    if (!(d.C0 & 7) && !(d.Ctot & 7) && !(reinterpret_cast<uintptr_t>(d.master) & 15) && !(reinterpret_cast<uintptr_t>(d.out) & 15) &&
+        (int64_t)d.rows * 16 * d.C0 < (1ll << 31)) {
+      const uint32_t c8n = (uint32_t)d.C0 >> 3, n8 = (uint32_t)d.rows * 16u * c8n;
+      for (uint32_t i = (uint32_t)first; i < n8; i += (uint32_t)stride) {
+        const uint32_t q = i / c8n, ci = (i - q * c8n) * 8u, ct = q & 15u, co = q >> 4;
+        const int py = ct >> 3, px = (ct >> 2) & 1, ty = (ct >> 1) & 1, tx = ct & 1;
+        const int kh0 = (py == 0) ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), kh1 = (py == 0) ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int kw0 = (px == 0) ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kw1 = (px == 0) ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if ((int)co < d.Cout)
+          for (int kh = kh0; kh <= kh1; ++kh)
+            for (int kw = kw0; kw <= kw1; ++kw) {
+              const float* src = d.master + (((int64_t)co * 3 + kh) * 3 + kw) * d.Ctot + ci;
+              v0 += *reinterpret_cast<const f32x4*>(src);
+              v1 += *reinterpret_cast<const f32x4*>(src + 4);
+            }
+        *reinterpret_cast<u32x4*>(out + (size_t)i * 8) = u32x4{pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w)};
+      }
+      return;
+    }
+  }
   const int64_t n = (int64_t)d.rows * 16 * d.C0;
   for (int64_t i = first; i < n; i += stride) {
     const int ci = (int)(i % d.C0);
