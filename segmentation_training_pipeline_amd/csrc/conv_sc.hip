@@ -706,6 +706,7 @@ struct ScwArgs {
   float* stats;         // [2][C0][workgroups] (fused BatchNormalization-backward sums of the first C0 channels)
   BnBack bnb;
   uint32_t src_bytes, x_bytes;   // sizes of src and bnb.x (buffer descriptors of the LDS-DMA)
+  uint32_t up_bytes, sk_bytes;   // sizes of dst_up and dst_sk (buffer descriptors of the stores)
 };
 
 template <typename T>
@@ -775,14 +776,26 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
     const int ty = bq - n * a.tiles_y;
     y0 = ty * SC_TH; x0 = tx * SC_TW;
   };
+  // (instruction count matters here: the waves of these streaming kernels spend as long in address arithmetic as in MFMAs.  A tile
+  //  whose halo lies inside the image - all but the border tiles - takes its LDS-DMA offsets as (per-thread constant) + (tile base))
+  uint32_t hrel[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) hrel[p] = hyx[p] >= 0 ? (uint32_t)(((hyx[p] >> 16) * a.W + (hyx[p] & 0xffff)) * PIXB + cvb) : 0x80000000u;
   auto issue_tile = [&](int tile, int b) {
     int n, y0, x0;
     decode(tile, n, y0, x0);
+    const bool inner = y0 >= 1 && x0 >= 1 && y0 + SC_TH + 1 <= a.H && x0 + SC_TW + 1 <= a.W;      // (uniform)
+    const uint32_t tbase = (uint32_t)(((n * a.H + y0 - 1) * a.W + x0 - 1) * PIXB);
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int gy = y0 - 1 + (hyx[p] >> 16), gx = x0 - 1 + (hyx[p] & 0xffff);
-      const bool ok = hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      const uint32_t off = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
+      uint32_t off;
+      if (inner) {
+        off = hyx[p] >= 0 ? tbase + hrel[p] : 0x80000000u;
+      } else {
+        const int gy = y0 - 1 + (hyx[p] >> 16), gx = x0 - 1 + (hyx[p] & 0xffff);
+        const bool ok = hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        off = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
+      }
 #if !defined(STP_EXP) || STP_EXP != 32   // (what-if builds, scratch/sc_exp_build.sh: 31 = no output stores, 32 = no halo loads, 33 = no LDS reads / MFMAs)
       if (p * 256 + wave * 64 < NV)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
@@ -823,8 +836,16 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
   for (int i = 0; i < 2; ++i) { ssp[i] = f32x2{0.f, 0.f}; qqp[i] = f32x2{0.f, 0.f}; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile's own pieces have landed
   lds_barrier();               // ... everybody's; the table is visible
-  T* const oup = reinterpret_cast<T*>(a.dst_up);
-  T* const osk = reinterpret_cast<T*>(a.dst_sk);
+  const __amdgpu_buffer_rsrc_t rup = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst_up, 0, a.up_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst_sk, 0, a.sk_bytes, 0x00020000);
+  // per-lane byte offsets inside an output row segment (see the epilogues): summed half = low-resolution pixel lr / 2, channels
+  // cbi + 4 lg + 2 (lr & 1); skip half = pixel lr, channels cbi - C0 + 4 lg
+  uint32_t lup[2], lsk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    lup[i] = (uint32_t)((lr >> 1) * a.C0 + cbi[i] + lg * 4 + 2 * (lr & 1)) * 2u;
+    lsk[i] = (uint32_t)(lr * a.C1 + (cbi[i] - a.C0) + lg * 4) * 2u;
+  }
 
   auto body = [&](int tile, auto curc) {
     constexpr int CUR = decltype(curc)::value;
@@ -834,6 +855,7 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
     //  previous tile - there the wait sits BEFORE the last pass's stores, so it drains the stores of a pass ago instead of the
     //  ones just issued: at the top of the tile it exposed a store round trip per tile)
     const int next = tile + t_step;
+    const bool full = y0 + SC_TH <= a.H && x0 + SC_TW <= a.W;      // (uniform) no pixel of the tile lies outside the image
     if (next < t_end) issue_tile(next, CUR ^ 1);
 
 #pragma unroll
@@ -877,6 +899,8 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
 #endif
 #endif
       if (h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's own pieces have landed (issued two passes ago)
+      auto epilogue = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;      // no pixel of the tile lies outside the image: no per-lane bounds work
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (upi[i]) {
@@ -895,15 +919,16 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-              if (gy >= a.H || gx >= a.W) continue;
               f32x2 v2 = par ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
-              T* d = oup + (((size_t)n * H2 + (gy >> 1)) * W2 + (gx >> 1)) * a.C0 + co;
+              // buffer addressing: (per-lane constant voffset) + (scalar soffset of the output row / column half) - no per-store VALU
+              const uint32_t so = (uint32_t)(((n * H2 + (y0 >> 1) + h * 2 + q) * W2 + (x0 >> 1) + h2 * 8) * a.C0) * 2u;
+              const uint32_t vo = (FULL || (gy < a.H && gx < a.W)) ? lup[i] : 0x80000000u;
               if (a.acc_up) {
-                const uint32_t w0 = *reinterpret_cast<const uint32_t*>(d);
+                const uint32_t w0 = __builtin_amdgcn_raw_buffer_load_b32(rup, vo, so, 0);
                 v2 += f32x2{h16lo_to_f32(w0), h16hi_to_f32(w0)};
               }
               uint32_t w = pack_bf16x2(v2.x, v2.y);
-              if (bnb) {
+              if (bnb && (FULL || vo != 0x80000000u)) {
                 const f32x2 ksc = *reinterpret_cast<const f32x2*>(ktab + co), ksh = *reinterpret_cast<const f32x2*>(ktab + 128 + co);
                 const f32x2 kmu = *reinterpret_cast<const f32x2*>(ktab + 256 + co), krs = *reinterpret_cast<const f32x2*>(ktab + 384 + co);
                 const uint32_t xw = *reinterpret_cast<const uint32_t*>(xlds + CUR * XBUF + (((h * 2 + q) * 16 + h2 * 8 + (lr >> 1)) * a.C0 + co) * 2);
@@ -920,23 +945,28 @@ __global__ __launch_bounds__(256, 2) void conv_scw_stream_kernel(const ScwArgs a
 #if defined(STP_EXP) && STP_EXP == 31
               if (a.N < 0)
 #endif
-              *reinterpret_cast<uint32_t*>(d) = w;
+              __builtin_amdgcn_raw_buffer_store_b32(w, rup, vo, so, 0);
             }
         } else {
 #pragma unroll
           for (int f = 0; f < 8; ++f) {
             const int gy = y0 + h * 4 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
-            if (gy >= a.H || gx >= a.W) continue;
-            T* d = osk + (((size_t)n * a.H + gy) * a.W + gx) * a.C1 + (cbi[i] - a.C0) + lg * 4;
+            const uint32_t so = (uint32_t)(((n * a.H + y0 + h * 4 + (f >> 1)) * a.W + x0 + (f & 1) * 16) * a.C1) * 2u;
+            const uint32_t vo = (FULL || (gy < a.H && gx < a.W)) ? lsk[i] : 0x80000000u;
             f32x4 v = acc[i][f];
-            if (a.acc_sk) v += load4(d);
+            if (a.acc_sk) {
+              const u32x2 w0 = __builtin_amdgcn_raw_buffer_load_b64(rsk, vo, so, 0);
+              v += f32x4{h16lo_to_f32(w0.x), h16hi_to_f32(w0.x), h16lo_to_f32(w0.y), h16hi_to_f32(w0.y)};
+            }
 #if defined(STP_EXP) && STP_EXP == 31
             if (a.N < 0)
 #endif
-            store4(d, v);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, rsk, vo, so, 0);
           }
         }
       }
+      };
+      if (full) epilogue(std::integral_constant<bool, true>{}); else epilogue(std::integral_constant<bool, false>{});
     }
     lds_barrier();        // the next tile is visible to everybody, and everybody has left this one
   };
@@ -1001,6 +1031,10 @@ extern "C" int stp_conv2d_scw(const stp_conv_params* p, void* stream) {
     if (sb >= 0x80000000ull) return STP_E_BADARG;   // 32-bit LDS-DMA offsets
     a.src_bytes = (uint32_t)sb;
     a.x_bytes = (uint32_t)((uint64_t)p->N * (p->Hv / 2) * (p->Wv / 2) * p->Cd0 * 2);    // (a quarter of the pixels, < 128 channels: smaller)
+    a.up_bytes = a.x_bytes;
+    const uint64_t kb = (uint64_t)p->N * p->Hv * p->Wv * (p->Cout - p->Cd0) * 2;
+    if (kb >= 0x80000000ull) return STP_E_BADARG;
+    a.sk_bytes = (uint32_t)kb;
   }
   a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
   a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
