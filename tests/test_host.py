@@ -488,6 +488,26 @@ def test_weight_gradient_groups_of_the_headline_workload():
             assert nwg <= 256 * {128: 2, 64: 3, 32: 4}[bm]
 
 
+def test_bench_names_every_launch_of_the_headline_plan():
+    """bench.py's instrumented pass maps every launch of the step to the kernel the library runs for it (kernel_key): a launch kind
+    it does not know (a new tile id) must fail here, on CPU, not in the driver's bench run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for dtype in ("bf16", "fp16", "fp32"):
+        plan = graph.Plan(16, dtype, "cpu", training=True)
+        plan.define(lambda p: nets.unet_resnet(p, "resnet34", 512, 512))
+        keys = set()
+        for lst in (plan.prep, plan.fwd, plan.bwd):
+            for fn, args, name, meta in lst:
+                if fn is not None:
+                    keys.add(bench.kernel_key(name, meta or {}, dtype))
+        assert any(k.startswith("conv_halo_kernel") for k in keys) == (dtype != "fp32")
+        if dtype != "fp32":
+            assert "conv_scw_stream_kernel<unsigned short>" in keys and "conv_wgrad_row_group_kernel<128, 2, 2, 3>" in keys
+
+
 def test_simple_png_mask_dataset(tmp_path):
     from PIL import Image
     img_dir, msk_dir = tmp_path / "img", tmp_path / "msk"
