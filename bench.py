@@ -45,8 +45,8 @@ def kernel_key(name, meta, dtype):
         dtype = "bf16"          # same kernel set, same template arguments: the storage format is a build parameter
     if name == "stp_conv2d":
         tile = meta["tile"]
-        if tile == 512:
-            return "conv_sc_kernel<%s>" % t
+        if tile == 512:   # small-channel streaming kernel (conv_sc.hip): <storage, input channels, 16-channel output tiles>
+            return "conv_sc_stream_kernel<%s, %d, %d>" % ((t,) + tuple(meta["sc"])) if meta.get("sc") else "conv_sc_stream_kernel<%s>" % t
         if tile == 640:   # wide-output small-channel data gradient (conv_sc.hip: stp_conv2d_scw)
             return "conv_scw_stream_kernel<%s>" % t
         if tile == 768:

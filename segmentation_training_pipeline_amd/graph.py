@@ -427,6 +427,8 @@ class Plan(object):
 
     def _emit_conv(self, lst, p, meta=None):
         self._keep.append(p)
+        if meta is not None and meta.get("tile") == 512:
+            meta = dict(meta, sc=(int(p.C0), 1 if p.Cout <= 16 else 2))    # the small-channel kernel's instance <Cin, 16-channel tiles> (bench.py)
         lst.append((self.lib.stp_conv2d, (C.byref(p),), "stp_conv2d", meta))
 
     def _emit_wgrad(self, lst, p, meta=None):
