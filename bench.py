@@ -49,6 +49,8 @@ def kernel_key(name, meta, dtype):
             return "conv_sc_stream_kernel<%s, %d, %d>" % ((t,) + tuple(meta["sc"])) if meta.get("sc") else "conv_sc_stream_kernel<%s>" % t
         if tile == 640:   # wide-output small-channel data gradient (conv_sc.hip: stp_conv2d_scw)
             return "conv_scw_stream_kernel<%s>" % t
+        if tile == 704:   # narrow-output small-channel forward (conv_sc.hip: stp_conv2d_scn)
+            return "conv_scn_stream_kernel<%s>" % t
         if tile == 768:
             return "conv_stem_kernel"
         if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows> (the profiler's name carries the epilogue variant as a 5th argument)

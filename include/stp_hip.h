@@ -174,6 +174,14 @@ int stp_conv2d_sc(const stp_conv_params* p, void* stream);
 int stp_conv2d_scw_eligible(const stp_conv_params* p);
 int stp_conv2d_scw_stats_tiles(const stp_conv_params* p);
 int stp_conv2d_scw(const stp_conv_params* p, void* stream);
+/* Narrow-output form (conv_sc.hip: conv_scn_stream_kernel): the FORWARD of Conv2D(32, 3x3)(Concatenate([UpSampling2D(2)(x), skip])) with 64 + 64
+ * input channels (src0 = x at half resolution, src0_mode = STP_SRC_NEAREST2X, src1 = skip), 16-bit storage: both halos resident in LDS (x as its
+ * low-resolution pixels), all weights in registers, one wave per SIMD.  Takes `weight` (the plain forward copy [32][3][3][128]); weight_up is
+ * ignored.  bias / relu / accumulate0 / stats_partial as for stp_conv2d.  stp_conv2d uses it automatically (tile id 704; STP_SCN=0 switches it
+ * off).  stats_tiles = stp_conv2d_scn_stats_tiles(p) columns. */
+int stp_conv2d_scn_eligible(const stp_conv_params* p);
+int stp_conv2d_scn_stats_tiles(const stp_conv_params* p);
+int stp_conv2d_scn(const stp_conv_params* p, void* stream);
 /* The ResNet stem (classification_models conv0: 7x7 / stride 2 / pad 3, 3+1 input channels -> 64, bf16): halo-tile kernel,
  * used by stp_conv2d automatically when eligible (tile id 768); optional fused BatchNormalization sums (stats_partial). */
 int stp_conv2d_stem_eligible(const stp_conv_params* p);

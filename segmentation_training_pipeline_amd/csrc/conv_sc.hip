@@ -1060,6 +1060,288 @@ extern "C" int stp_conv2d_scw(const stp_conv_params* p, void* stream) {
 }
 
 // =================================================================================================
+// NARROW-OUTPUT form: forward of the first full-resolution decoder convolution,
+//   conv3x3(concat(UpSampling2D(2)(x), skip)) : 64 + 64 -> 32 channels   (U-Net decoder_stage3_conv1 at 16 x 256 x 256)
+// The generic per-tap kernel stages every pixel once per tap and channel block: 1.9 GB through L2 -> LDS per launch (8.5 TB/s, 221 us;
+// ring depth and tile size change nothing).  Halo residency stages each input byte once (the upsampled half as its LOW-RESOLUTION
+// pixels: 6 x 18 instead of 10 x 34), 220 MB.  With 32 output channels a staged byte feeds one MFMA column block only, so nothing is
+// shared across channel tiles: every wave keeps ALL the weights as A fragments - 32 x 1152 = 288 registers, which is why this kernel
+// runs ONE wave per SIMD (512 registers a lane: 256 VGPRs + the accumulators and the rest of the weights in AGPRs) - and owns two rows
+// of the 8 x 32 tile like conv_sc_stream_kernel, whose epilogue (bias, ReLU, fused BatchNormalization statistics) it reuses.
+// LDS per buffer: the halo as four 32-channel planes ([skip 0-31][skip 32-63][up 0-31][up 32-63]: 64-byte pixels, conflict-free
+// ds_read_b128 fragments) = 56 KB, double-buffered by LDS-DMA one tile ahead.  A fragment of halo row r shifted by kw serves the taps
+// (kh, kw) of both output rows; with one wave per SIMD the LDS latency is hidden by hand: the scheduling barriers keep three fragment
+// reads in flight ahead of the MFMAs that consume them.
+// =================================================================================================
+struct ScnArgs {         // (next to a ScArgs = the epilogue's view: dst, Cout, N, H, W, bias, relu, accumulate, stats; src = the upsampled tensor [N,H/2,W/2,64])
+  const char* skip;     // [N,H,W,64]
+  uint32_t up_bytes, skip_bytes, dst_bytes;
+};
+
+constexpr int SCN_SKV = SC_HH * SC_HW * 4, SCN_UH = SC_TH / 2 + 2, SCN_UW = SC_TW / 2 + 2, SCN_UPV = SCN_UH * SCN_UW * 4;   // 16-byte vectors of a plane
+constexpr int SCN_UP0 = (2 * SCN_SKV + 63) / 64 * 64;        // the upsampled planes start at a wave boundary of the staging (one descriptor per wave and pass)
+constexpr int SCN_NV = SCN_UP0 + 2 * SCN_UPV, SCN_NPASS = (SCN_NV + 255) / 256, SCN_BUF = SCN_NPASS * 4096;
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void conv_scn_stream_kernel(const ScArgs a, const ScnArgs aa) {
+  constexpr int SZ = (int)sizeof(T), K = 9 * 128, PIXB = 64;
+  static_assert(SZ == 2, "16-bit storage");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + 2 * SCN_BUF);      // statistics scratch [4][32][2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int Hs = a.H >> 1, Ws = a.W >> 1;
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
+  } else {
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = ntiles;
+  }
+  // fused BatchNormalization statistics: sums of the STORED values over all tiles of the workgroup, one column per workgroup
+  f32x4 ssp[2], qqp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ssp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qqp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  auto flush_stats = [&]() __attribute__((always_inline)) {
+    if (!a.stats) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e_ = 0; e_ < 4; ++e_) {
+        const float sv = row_sum16_to_lane15(ssp[i][e_]), qv = row_sum16_to_lane15(qqp[i][e_]);
+        if (lr == 15) {
+          const int cl = i * 16 + lg * 4 + e_;
+          red[(wave * 32 + cl) * 2] = sv;
+          red[(wave * 32 + cl) * 2 + 1] = qv;
+        }
+      }
+    lds_barrier();
+    if (tid < 32) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { sv += red[(w * 32 + tid) * 2]; qv += red[(w * 32 + tid) * 2 + 1]; }
+      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][workgroup]
+      a.stats[((size_t)32 + tid) * gridDim.x + blockIdx.x] = qv;
+    }
+  };
+  if (t_first >= t_end) {      // (no tile: the statistics column of this workgroup must still be defined)
+    flush_stats();
+    return;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)aa.skip, 0, aa.skip_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rup = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, aa.up_bytes, 0x00020000);
+  // staging pass p of this thread: vector v = p * 256 + tid of the buffer image.  Per-thread constants: which tensor, the halo
+  // coordinates (border tiles) and the byte offset relative to the tile's first halo pixel (interior tiles: offset = tile base + rel)
+  // vector v -> (upsampled tensor?, halo row, halo column, byte offset relative to the first halo pixel); evaluated once per thread
+  // for hrel (interior tiles) and again per border tile for the bounds (registers are the scarce resource of this kernel)
+  auto vcoord = [&](int v, bool& isup, int& cy, int& cx) __attribute__((always_inline)) -> uint32_t {
+    cy = cx = 0; isup = v >= SCN_UP0;
+    if (v < 2 * SCN_SKV) {
+      const int plane = v / SCN_SKV, r = v - plane * SCN_SKV, px = r >> 2, vec = r & 3;
+      cy = px / SC_HW; cx = px - cy * SC_HW;
+      return (uint32_t)((cy * a.W + cx) * 128 + plane * 64 + vec * 16);
+    }
+    const int u = v - SCN_UP0;
+    if (u < 0 || u >= 2 * SCN_UPV) return 0x80000000u;      // padding between / behind the planes
+    const int plane = u / SCN_UPV, r = u - plane * SCN_UPV, px = r >> 2, vec = r & 3;
+    cy = px / SCN_UW; cx = px - cy * SCN_UW;
+    return (uint32_t)((cy * Ws + cx) * 128 + plane * 64 + vec * 16);
+  };
+  uint32_t hrel[SCN_NPASS];
+#pragma unroll
+  for (int p = 0; p < SCN_NPASS; ++p) {
+    bool u_; int cy_, cx_;
+    hrel[p] = vcoord(p * 256 + tid, u_, cy_, cx_);
+  }
+  auto decode = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+    const int bq = (int)fdiv((uint32_t)tile, a.divTx);
+    const int tx = tile - bq * a.tiles_x;
+    n = (int)fdiv((uint32_t)bq, a.divTy);
+    const int ty = bq - n * a.tiles_y;
+    y0 = ty * SC_TH; x0 = tx * SC_TW;
+  };
+  auto issue_tile = [&](int tile, int b) __attribute__((always_inline)) {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    const bool inner = y0 >= 2 && x0 >= 2 && y0 + SC_TH + 2 <= a.H && x0 + SC_TW + 2 <= a.W;      // (uniform) both halos inside
+    const uint32_t bsk = (uint32_t)(((n * a.H + y0 - 1) * a.W + x0 - 1) * 128);
+    const uint32_t bup = (uint32_t)(((n * Hs + (y0 >> 1) - 1) * Ws + (x0 >> 1) - 1) * 128);
+#pragma unroll
+    for (int p = 0; p < SCN_NPASS; ++p) {
+      const bool wup = (p * 256 + wave * 64) >= SCN_UP0;       // (wave-uniform) this wave's 64 vectors of the pass belong to the upsampled tensor
+      uint32_t off = hrel[p] == 0x80000000u ? 0x80000000u : (wup ? bup : bsk) + hrel[p];
+      if (!inner && off != 0x80000000u) {
+        bool u_; int cy, cx;
+        vcoord(p * 256 + tid, u_, cy, cx);
+        const int gy = u_ ? (y0 >> 1) - 1 + cy : y0 - 1 + cy, gx = u_ ? (x0 >> 1) - 1 + cx : x0 - 1 + cx;
+        if (!((unsigned)gy < (unsigned)(u_ ? Hs : a.H) && (unsigned)gx < (unsigned)(u_ ? Ws : a.W))) off = 0x80000000u;
+      }
+      if (p * 256 + wave * 64 < SCN_NV) {
+        char* dst = smem + b * SCN_BUF + p * 4096 + wave * 1024;
+        if (wup) __builtin_amdgcn_raw_ptr_buffer_load_lds(rup, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+      }
+    }
+  };
+  issue_tile(t_first, 0);
+
+  // once per workgroup: ALL the weights -> registers.  chunk c = slice * 9 + tap; slice s = 32 input channels (0, 1: upsampled, 2, 3: skip)
+  u32x4 fa[2][36];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fa[i][s_ * 9 + t] = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(i * 16 + lr) * K + t * 128 + s_ * 32 + lg * 8) * SZ);
+  // lane parts of the fragment addresses: skip planes: pixel lr (+ kw as an immediate); upsampled planes: low-res column ((lr + kw - 1) >> 1) + 1
+  // (the wave's rows are part of the lane constant: halo rows 2 wave .., low-resolution rows wave ..)
+  const uint32_t lsk = (uint32_t)(lr * PIXB + lg * 16 + wave * 2 * SC_HW * PIXB);
+  uint32_t lup[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) lup[kw] = (uint32_t)((((lr + kw - 1) >> 1) + 1) * PIXB + lg * 16 + wave * SCN_UW * PIXB);
+  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, aa.dst_bytes, 0x00020000);
+  const uint32_t lvo = (uint32_t)((lr * 32 + lg * 4) * SZ);      // lane part of the output offsets: pixel lr of a 16-pixel row segment, channels 4 lg ..
+  f32x4 bias4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (a.bias) { bias4[0] = *reinterpret_cast<const f32x4*>(a.bias + lg * 4); bias4[1] = *reinterpret_cast<const f32x4*>(a.bias + 16 + lg * 4); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile's own pieces have landed
+  lds_barrier();
+
+  auto body = [&](int tile, auto curc) {
+    constexpr int CUR = decltype(curc)::value;
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    const int next = tile + t_step;
+    if (next < t_end) issue_tile(next, CUR ^ 1);
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // read sidx = ((slice * 4 + r) * 3 + kw) * 2 + h2: halo row 2 wave + r (r = 0..3), shifted by kw, column half h2
+    auto bfrag = [&](int sidx) __attribute__((always_inline)) -> u32x4 {
+      const int h2 = sidx & 1, kw = (sidx >> 1) % 3, r = (sidx / 6) & 3, sl = sidx / 24;
+      if (sl >= 2) {
+        return *reinterpret_cast<const u32x4*>(smem + lsk + (CUR * SCN_BUF + (sl - 2) * SCN_SKV * 16 + (r * SC_HW + h2 * 16 + kw) * PIXB));
+      } else {
+        // hi-res halo row hyy = 2 wave + r -> low-res row ((hyy - 1) >> 1) + 1 = wave + ((r - 1) >> 1) + 1; column half: + 8 low-res pixels
+        const int lrow = ((r + 1) >> 1);      // ((r - 1) >> 1) + 1 for r = 0..3: 0, 1, 1, 2
+        return *reinterpret_cast<const u32x4*>(smem + lup[kw] + (CUR * SCN_BUF + SCN_UP0 * 16 + sl * SCN_UPV * 16 + (lrow * SCN_UW + h2 * 8) * PIXB));
+      }
+    };
+    u32x4 fbq[4];
+    fbq[0] = bfrag(0); fbq[1] = bfrag(1); fbq[2] = bfrag(2);
+#pragma unroll
+    for (int sidx = 0; sidx < 96; ++sidx) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (sidx + 3 < 96) fbq[(sidx + 3) & 3] = bfrag(sidx + 3);
+      const int h2 = sidx & 1, kw = (sidx >> 1) % 3, r = (sidx / 6) & 3, sl = sidx / 24;
+      const u32x4 fb = fbq[sidx & 3];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int orow = r - kh;
+        if (orow < 0 || orow > 1) continue;
+        acc[0][orow * 2 + h2] = mfma16_16x16x32(fa[0][sl * 9 + kh * 3 + kw], fb, acc[0][orow * 2 + h2]);
+        acc[1][orow * 2 + h2] = mfma16_16x16x32(fa[1][sl * 9 + kh * 3 + kw], fb, acc[1][orow * 2 + h2]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's own pieces have landed (before this tile's stores are issued)
+    // epilogue: bias, accumulate, ReLU, store (buffer addressing: lane constant + scalar row-segment offset), statistics of the stored values
+    const bool full = y0 + SC_TH <= a.H && x0 + SC_TW <= a.W;      // (uniform)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+      const uint32_t so = (uint32_t)(((n * a.H + gy) * a.W + x0 + (f & 1) * 16) * 32) * (uint32_t)SZ;
+      const bool ok = full || (gy < a.H && gx < a.W);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t vo = ok ? lvo + (uint32_t)(i * 16 * SZ) : 0x80000000u;
+        f32x4 v = acc[i][f] + bias4[i];
+        if (a.accumulate) {
+          const u32x2 w0 = __builtin_amdgcn_raw_buffer_load_b64(rdst, vo, so, 0);
+          v += f32x4{h16lo_to_f32(w0.x), h16hi_to_f32(w0.x), h16lo_to_f32(w0.y), h16hi_to_f32(w0.y)};
+        }
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const u32x2 o = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        __builtin_amdgcn_raw_buffer_store_b64(o, rdst, vo, so, 0);
+        if (a.stats && ok) {
+          const f32x4 sv = {h16lo_to_f32(o.x), h16hi_to_f32(o.x), h16lo_to_f32(o.y), h16hi_to_f32(o.y)};
+          ssp[i] += sv;
+          qqp[i] += sv * sv;
+        }
+      }
+    }
+    lds_barrier();        // the next tile is visible to everybody, and everybody has left this one
+  };
+
+  for (int tile = t_first; tile < t_end; tile += 2 * t_step) {
+    body(tile, std::integral_constant<int, 0>{});
+    if (tile + t_step < t_end) body(tile + t_step, std::integral_constant<int, 1>{});
+  }
+  flush_stats();
+}
+
+static int scn_blocks(int ntiles) {
+  const int b = sc_cu_count();
+  return b < ntiles ? b : ntiles;
+}
+
+// Is this convolution the forward served by conv_scn_stream_kernel?  (stp_conv2d consults this before the generic kernels.)
+extern "C" int stp_conv2d_scn_eligible(const stp_conv_params* p) {
+  static const bool on = !(getenv("STP_SCN") && atoi(getenv("STP_SCN")) == 0);
+  if (!on || !p || p->dtype != STP_H16) return 0;
+  return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->C0 == 64 && p->C1 == 64 && p->src1 != nullptr && p->Cout == 32 &&
+         p->Cd0 == 32 && p->src0_mode == STP_SRC_NEAREST2X && p->Hv == 2 * p->Hs0 && p->Wv == 2 * p->Ws0 && p->Ho == p->Hv && p->Wo == p->Wv &&
+         !p->residual && !p->dst_sum2x2 && !p->src_bn_mean && !p->stats_slots && !p->fold_src && !p->bnb_x;
+}
+extern "C" int stp_conv2d_scn_stats_tiles(const stp_conv_params* p) {
+  return scn_blocks(p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW));
+}
+
+extern "C" int stp_conv2d_scn(const stp_conv_params* p, void* stream) {
+  if (!stp_conv2d_scn_eligible(p) || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
+  ScnArgs aa;
+  ScArgs a;
+  a.src = (const char*)p->src0; a.weight = (const char*)p->weight; a.bias = p->bias; a.dst = (char*)p->dst0;
+  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = p->Cout;
+  a.up = 1; a.accumulate = p->accumulate0; a.relu = p->relu;
+  aa.skip = (const char*)p->src1;
+  {
+    const uint64_t ub = (uint64_t)p->N * p->Hs0 * p->Ws0 * 64 * 2, kb = (uint64_t)p->N * p->Hv * p->Wv * 64 * 2;
+    if (kb >= 0x80000000ull) return STP_E_BADARG;   // 32-bit LDS-DMA offsets
+    aa.up_bytes = (uint32_t)ub; aa.skip_bytes = (uint32_t)kb; aa.dst_bytes = (uint32_t)((uint64_t)p->N * p->Hv * p->Wv * 32 * 2);
+    a.src_bytes = aa.up_bytes;
+  }
+  a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
+  a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
+  a.stats = p->stats_partial;
+  a.stat_slots = 0;
+  a.bnb.x = nullptr; a.bnb.mean = nullptr; a.bnb.rstd = nullptr; a.bnb.gamma = nullptr; a.bnb.beta = nullptr; a.bnb.relu = 0;
+  a.sum2 = 0;
+  a.pbn.x = nullptr; a.pbn.mean = nullptr; a.pbn.rstd = nullptr; a.pbn.gamma = nullptr; a.pbn.beta = nullptr; a.pbn.relu = 0;
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  const int blocks = scn_blocks(ntiles);
+  const_cast<stp_conv_params*>(p)->stats_tiles = blocks;
+  const size_t lds = (size_t)2 * SCN_BUF + (4 * 32 * 2 + 128 + 64) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_scn_stream_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_scn_stream_kernel<bf16_t>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, aa);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// =================================================================================================
 // Stem: 7x7 / stride 2 / pad 3 convolution of the 4-channel (3 image channels + 1) bf16 input to 64 channels (ResNet conv0).
 // The generic implicit GEMM gathers 49 taps of 8 bytes per output pixel through the vector-memory path; this layer is
 // HBM-bound (33 MB in, 134 MB out at 16x512x512), so the same halo-tile scheme as above is used: the (2*8+5) x (2*32+5)

@@ -697,7 +697,8 @@ class Plan(object):
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
         w4 = None
         if (upsample and src1 is not None and k == 3 and KWp == 3 and stride == 1 and pad == 1 and Cinp == Cin_master == C0 + C1
-                and os.environ.get("STP_UPCOLLAPSE", "1") != "0"):
+                and os.environ.get("STP_UPCOLLAPSE", "1") != "0" and not self.lib.stp_conv2d_scn_eligible(C.byref(p))):
+            # (the narrow-output kernel - 64 + 64 -> 32 channels - keeps both halos in LDS and takes the plain weight copy)
             # decoder conv1 = conv3x3(concat(UpSampling2D(2)(x), skip)): per output parity class the taps over the upsampled half read
             # 2 x 2 low-resolution pixels - the forward multiplies them by class-summed weights (4 x C0 + 9 x C1 K columns instead
             # of 9 x (C0 + C1)); the summed copy is rebuilt from the fp32 master with the other weight copies, once per step

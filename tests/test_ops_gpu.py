@@ -1139,6 +1139,52 @@ def test_wide_output_data_gradient_of_upsample_concat(ops, dtype, mode, c_up):
     assert torch.equal(again, got_up) and torch.equal(st2[:2 * c_up * tiles], st[:2 * c_up * tiles])
 
 
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("mode", ["plain", "stats", "bias_relu_accumulate"])
+def test_narrow_output_forward_of_upsample_concat(ops, dtype, mode):
+    """stp_conv2d_scn: Conv2D(32, 3x3)(Concatenate([UpSampling2D(2)(x), skip])) with 64 + 64 input channels - both halos resident in
+    LDS, the upsampled one as low-resolution pixels.  Against numpy on the materialised concatenation, and against the generic
+    kernel for the fused statistics; ragged 8 x 32 tiles, more tiles than workgroups' first pass."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c0, c1, co = 2, 36, 88, 64, 64, 32
+    rng = np.random.RandomState(44)
+    xlo = q(rng.randn(n, h // 2, w // 2, c0), dtype)
+    skip = q(rng.randn(n, h, w, c1), dtype)
+    wt = q(rng.randn(3, 3, c0 + c1, co) / np.sqrt(9 * (c0 + c1)), dtype)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    xd, sd = dev(xlo, dtype), dev(skip, dtype)
+    cat = np.concatenate([xlo.repeat(2, axis=1).repeat(2, axis=2), skip], axis=-1)
+    want = np_ops.conv2d(cat, wt, 1, 1)
+    base = q(rng.randn(n, h, w, co), dtype)
+    bias = keep(torch.from_numpy(rng.randn(co).astype(np.float32)).to(DEV)) if mode == "bias_relu_accumulate" else None
+    def run(tile):
+        y = dev(base, dtype) if mode == "bias_relu_accumulate" else torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+        P = ops.conv_params(xd, fwd, y, N=n, Hs0=h // 2, Ws0=w // 2, Hv=h, Wv=w, C0=c0, C1=c1, src1=sd, mode=ops.SRC_NEAREST2X, KH=3, KW=3,
+                            stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.dt(y), bias=bias, relu=int(mode == "bias_relu_accumulate"),
+                            accumulate0=int(mode == "bias_relu_accumulate"), tile=tile)
+        st = None
+        if mode == "stats":
+            st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+            P.stats_partial = ops.ptr(st)
+        ops.conv2d(P)
+        return y, st, P
+    y, st, P = run(0)
+    assert _lib.load().stp_conv2d_scn_eligible(ops.C.byref(P)) and _lib.load().stp_conv2d_tile_for(ops.C.byref(P)) == 704
+    ref = want
+    if mode == "bias_relu_accumulate":
+        ref = np.maximum(want + host(bias) + base, 0.0)
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+    if mode == "stats":
+        tiles = ops.conv2d_stats_floats(P) // (2 * co)
+        assert tiles == P.stats_tiles
+        part = host(st)[:2 * co * tiles].reshape(2, co, tiles).astype(np.float64).sum(-1)
+        yv = host(y).reshape(-1, co).astype(np.float64)
+        np.testing.assert_allclose(part[0], yv.sum(0), rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(part[1], (yv * yv).sum(0), rtol=1e-4, atol=1e-2)
+        y2, st2, _ = run(0)                                   # replay: fixed partition, fixed order
+        assert torch.equal(y2, y) and torch.equal(st2[:2 * co * tiles], st[:2 * co * tiles])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("C,Cy", [(5, 8), (4, 8), (7, 8), (1, 4)])
 def test_input_batchnorm_uint8_to_padded_channels(ops, dtype, C, Cy):
