@@ -51,6 +51,8 @@ def kernel_key(name, meta, dtype):
             return "conv_scw_stream_kernel<%s>" % t
         if tile == 704:   # narrow-output small-channel forward (conv_sc.hip: stp_conv2d_scn)
             return "conv_scn_stream_kernel<%s>" % t
+        if tile == 736:   # 64 -> 64 channels with the weights in registers (conv_sc.hip: stp_conv2d_s64)
+            return "conv_s64_stream_kernel<%s>" % t
         if tile == 768:
             return "conv_stem_kernel"
         if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows> (the profiler's name carries the epilogue variant as a 5th argument)

@@ -182,6 +182,14 @@ int stp_conv2d_scw(const stp_conv_params* p, void* stream);
 int stp_conv2d_scn_eligible(const stp_conv_params* p);
 int stp_conv2d_scn_stats_tiles(const stp_conv_params* p);
 int stp_conv2d_scn(const stp_conv_params* p, void* stream);
+/* 64 -> 64 channels, 3x3 / stride 1 / pad 1, 16-bit storage, single source and destination (conv_sc.hip: conv_s64_stream_kernel; ResNet stage 1
+ * forward and data gradient): the whole weight matrix in the registers of every wave, the halo double-buffered in LDS.  residual, or stats_partial,
+ * or bnb_x + stats_partial; no bias / relu / accumulate.  OPT-IN (tile id 736, or STP_S64=1 in the environment for stp_conv2d's automatic choice
+ * when the launch has at least two tiles of 8 x 32 pixels per CU): at the U-Net's batch the halo kernel is as fast (conv_sc.hip has the numbers).
+ * stats_tiles = stp_conv2d_s64_stats_tiles(p) columns (one per workgroup). */
+int stp_conv2d_s64_eligible(const stp_conv_params* p);
+int stp_conv2d_s64_stats_tiles(const stp_conv_params* p);
+int stp_conv2d_s64(const stp_conv_params* p, void* stream);
 /* The ResNet stem (classification_models conv0: 7x7 / stride 2 / pad 3, 3+1 input channels -> 64, bf16): halo-tile kernel,
  * used by stp_conv2d automatically when eligible (tile id 768); optional fused BatchNormalization sums (stats_partial). */
 int stp_conv2d_stem_eligible(const stp_conv_params* p);

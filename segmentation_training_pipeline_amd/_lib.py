@@ -64,6 +64,9 @@ SIGNATURES = {
     "stp_conv2d_scn": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_scn_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_scn_stats_tiles": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_s64": (i32, [C.POINTER(ConvParams), vp]),
+    "stp_conv2d_s64_eligible": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_s64_stats_tiles": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stem_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stem": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_halo_variant": (i32, [C.POINTER(ConvParams)]),

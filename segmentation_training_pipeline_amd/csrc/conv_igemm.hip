@@ -614,6 +614,9 @@ extern "C" int stp_conv2d_scw_stats_tiles(const stp_conv_params* p);
 extern "C" int stp_conv2d_scn_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_scn(const stp_conv_params* p, void* stream);
 extern "C" int stp_conv2d_scn_stats_tiles(const stp_conv_params* p);
+extern "C" int stp_conv2d_s64_eligible(const stp_conv_params* p);
+extern "C" int stp_conv2d_s64(const stp_conv_params* p, void* stream);
+extern "C" int stp_conv2d_s64_stats_tiles(const stp_conv_params* p);
 extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream);
 extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p);
@@ -633,12 +636,18 @@ static int halo_variant_for(const stp_conv_params* p) {
 #define STP_TILE_STEM 768  // the 7x7 / stride-2 stem kernel of conv_sc.hip
 #define STP_TILE_SCW 640  // the wide-output (two-destination, 2x2-summed) data-gradient kernel of conv_sc.hip
 #define STP_TILE_SCN 704  // the narrow-output (upsample + concat -> 32 channels) forward kernel of conv_sc.hip
+#define STP_TILE_S64 736  // the 64 -> 64 channel weights-in-registers kernel of conv_sc.hip (opt-in: STP_S64=1, or this tile id)
+static bool s64_auto() {
+  static const bool on = getenv("STP_S64") && atoi(getenv("STP_S64")) == 1;
+  return on;
+}
 
 // Which tile configuration stp_conv2d would launch (profiling / roofline bookkeeping).
 extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SC) && stp_conv2d_sc_eligible(p)) return STP_TILE_SC;
   if (p && (p->tile == 0 || p->tile == STP_TILE_SCW) && stp_conv2d_scw_eligible(p)) return STP_TILE_SCW;
   if (p && (p->tile == 0 || p->tile == STP_TILE_SCN) && stp_conv2d_scn_eligible(p)) return STP_TILE_SCN;
+  if (p && ((p->tile == 0 && s64_auto()) || p->tile == STP_TILE_S64) && stp_conv2d_s64_eligible(p)) return STP_TILE_S64;
   if (p && (p->tile == 0 || p->tile == STP_TILE_STEM) && stp_conv2d_stem_eligible(p)) return STP_TILE_STEM;
   {
     const int hv = halo_variant_for(p);
@@ -661,6 +670,7 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   if (tile == STP_TILE_SC) return (size_t)stp_conv2d_sc_stats_tiles(p) * 2 * p->Cout;
   if (tile == STP_TILE_SCW) return (size_t)stp_conv2d_scw_stats_tiles(p) * 2 * p->Cd0;
   if (tile == STP_TILE_SCN) return (size_t)stp_conv2d_scn_stats_tiles(p) * 2 * p->Cout;
+  if (tile == STP_TILE_S64) return (size_t)stp_conv2d_s64_stats_tiles(p) * 2 * p->Cout;
   if (tile == STP_TILE_STEM) return (size_t)p->N * ceil_div(p->Ho, 8) * ceil_div(p->Wo, 32) * 2 * p->Cout;
   if (tile >= STP_TILE_HALO) return (size_t)stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO) * 2 * p->Cout;
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
@@ -676,7 +686,7 @@ static bool fold_geometry_ok(const ConvArgs& a) { return a.KH == 3 && a.KW == 3 
 
 extern "C" int stp_conv2d_fold_ok(const stp_conv_params* p) {
   static const bool on = !(getenv("STP_FOLD_SHORTCUT") && atoi(getenv("STP_FOLD_SHORTCUT")) == 0);
-  if (!on || !p || p->tile != 0 || stp_conv2d_sc_eligible(p) || stp_conv2d_scw_eligible(p) || stp_conv2d_stem_eligible(p) || halo_variant_for(p) >= 0) return 0;
+  if (!on || !p || p->tile != 0 || stp_conv2d_sc_eligible(p) || stp_conv2d_scw_eligible(p) || stp_conv2d_scn_eligible(p) || (s64_auto() && stp_conv2d_s64_eligible(p)) || stp_conv2d_stem_eligible(p) || halo_variant_for(p) >= 0) return 0;
   ConvArgs a;
   bool c4;
   int ut;
@@ -696,6 +706,10 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SCN)) {
     if (stp_conv2d_scn_eligible(p)) return stp_conv2d_scn(p, stream);
     if (p->tile == STP_TILE_SCN) return STP_E_BADARG;
+  }
+  if (p && ((p->tile == 0 && s64_auto()) || p->tile == STP_TILE_S64)) {
+    if (stp_conv2d_s64_eligible(p)) return stp_conv2d_s64(p, stream);
+    if (p->tile == STP_TILE_S64) return STP_E_BADARG;
   }
   if (p && (p->tile == 0 || p->tile == STP_TILE_STEM)) {
     if (stp_conv2d_stem_eligible(p)) return stp_conv2d_stem(p, stream);

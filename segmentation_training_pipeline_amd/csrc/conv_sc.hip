@@ -1087,7 +1087,9 @@ __global__ __launch_bounds__(256, 1) void conv_scn_stream_kernel(const ScArgs a,
   constexpr int SZ = (int)sizeof(T), K = 9 * 128, PIXB = 64;
   static_assert(SZ == 2, "16-bit storage");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem + 2 * SCN_BUF);      // statistics scratch [4][32][2]
+  // LDS: [halo buffer 0][statistics scratch [4][32][2]][halo buffer 1 = the weight staging of the prologue (73.7 KB)]
+  float* red = reinterpret_cast<float*>(smem + SCN_BUF);
+  constexpr int SCN_B1 = SCN_BUF + 4 * 32 * 2 * 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
@@ -1182,7 +1184,7 @@ __global__ __launch_bounds__(256, 1) void conv_scn_stream_kernel(const ScArgs a,
         if (!((unsigned)gy < (unsigned)(u_ ? Hs : a.H) && (unsigned)gx < (unsigned)(u_ ? Ws : a.W))) off = 0x80000000u;
       }
       if (p * 256 + wave * 64 < SCN_NV) {
-        char* dst = smem + b * SCN_BUF + p * 4096 + wave * 1024;
+        char* dst = smem + (b ? SCN_B1 : 0) + p * 4096 + wave * 1024;
         if (wup) __builtin_amdgcn_raw_ptr_buffer_load_lds(rup, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
       }
@@ -1190,16 +1192,26 @@ __global__ __launch_bounds__(256, 1) void conv_scn_stream_kernel(const ScArgs a,
   };
   issue_tile(t_first, 0);
 
-  // once per workgroup: ALL the weights -> registers.  chunk c = slice * 9 + tap; slice s = 32 input channels (0, 1: upsampled, 2, 3: skip)
+  // once per workgroup: the weight matrix (73.7 KB) -> LDS by LDS-DMA, fragment-major ([chunk][lane group][32 output channels] 16-byte
+  // vectors: conflict-free fragment reads), then ALL of it -> the registers of every wave.  (Each wave fetching its 72 fragments from L2
+  // itself: 75 MB of L2 reads per launch.)  chunk c = slice * 9 + tap; slice s = 32 input channels (0, 1: upsampled, 2, 3: skip)
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, 32 * K * SZ, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 18; ++p) {      // 4608 vectors = 72 wave instructions: vector ((c * 4 + g) * 32 + co) <- weight[co][k0(c) + 8 g]
+      const int wi = p * 4 + wave, grp = wi * 2 + (lane >> 5), c = grp >> 2, g = grp & 3, s_ = c / 9, t = c - s_ * 9;
+      const uint32_t off = (uint32_t)(((lane & 31) * K + t * 128 + s_ * 32 + g * 8) * SZ);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + SCN_B1 + wi * 1024), 16, off, 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weights' and the first tile's own pieces have landed
+  lds_barrier();
   u32x4 fa[2][36];
 #pragma unroll
-  for (int s_ = 0; s_ < 4; ++s_)
+  for (int c = 0; c < 36; ++c)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        fa[i][s_ * 9 + t] = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(i * 16 + lr) * K + t * 128 + s_ * 32 + lg * 8) * SZ);
-  // lane parts of the fragment addresses: skip planes: pixel lr (+ kw as an immediate); upsampled planes: low-res column ((lr + kw - 1) >> 1) + 1
+    for (int i = 0; i < 2; ++i)
+      fa[i][c] = *reinterpret_cast<const u32x4*>(smem + SCN_B1 + ((c * 4 + lg) * 32 + i * 16 + lr) * 16);
   // (the wave's rows are part of the lane constant: halo rows 2 wave .., low-resolution rows wave ..)
   const uint32_t lsk = (uint32_t)(lr * PIXB + lg * 16 + wave * 2 * SC_HW * PIXB);
   uint32_t lup[3];
@@ -1209,8 +1221,7 @@ __global__ __launch_bounds__(256, 1) void conv_scn_stream_kernel(const ScArgs a,
   const uint32_t lvo = (uint32_t)((lr * 32 + lg * 4) * SZ);      // lane part of the output offsets: pixel lr of a 16-pixel row segment, channels 4 lg ..
   f32x4 bias4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   if (a.bias) { bias4[0] = *reinterpret_cast<const f32x4*>(a.bias + lg * 4); bias4[1] = *reinterpret_cast<const f32x4*>(a.bias + 16 + lg * 4); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile's own pieces have landed
-  lds_barrier();
+  lds_barrier();               // every wave holds the weights: halo buffer 1 is free
 
   auto body = [&](int tile, auto curc) {
     constexpr int CUR = decltype(curc)::value;
@@ -1228,11 +1239,11 @@ __global__ __launch_bounds__(256, 1) void conv_scn_stream_kernel(const ScArgs a,
     auto bfrag = [&](int sidx) __attribute__((always_inline)) -> u32x4 {
       const int h2 = sidx & 1, kw = (sidx >> 1) % 3, r = (sidx / 6) & 3, sl = sidx / 24;
       if (sl >= 2) {
-        return *reinterpret_cast<const u32x4*>(smem + lsk + (CUR * SCN_BUF + (sl - 2) * SCN_SKV * 16 + (r * SC_HW + h2 * 16 + kw) * PIXB));
+        return *reinterpret_cast<const u32x4*>(smem + lsk + ((CUR ? SCN_B1 : 0) + (sl - 2) * SCN_SKV * 16 + (r * SC_HW + h2 * 16 + kw) * PIXB));
       } else {
         // hi-res halo row hyy = 2 wave + r -> low-res row ((hyy - 1) >> 1) + 1 = wave + ((r - 1) >> 1) + 1; column half: + 8 low-res pixels
         const int lrow = ((r + 1) >> 1);      // ((r - 1) >> 1) + 1 for r = 0..3: 0, 1, 1, 2
-        return *reinterpret_cast<const u32x4*>(smem + lup[kw] + (CUR * SCN_BUF + SCN_UP0 * 16 + sl * SCN_UPV * 16 + (lrow * SCN_UW + h2 * 8) * PIXB));
+        return *reinterpret_cast<const u32x4*>(smem + lup[kw] + ((CUR ? SCN_B1 : 0) + SCN_UP0 * 16 + sl * SCN_UPV * 16 + (lrow * SCN_UW + h2 * 8) * PIXB));
       }
     };
     u32x4 fbq[4];
@@ -1329,7 +1340,7 @@ extern "C" int stp_conv2d_scn(const stp_conv_params* p, void* stream) {
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
   const int blocks = scn_blocks(ntiles);
   const_cast<stp_conv_params*>(p)->stats_tiles = blocks;
-  const size_t lds = (size_t)2 * SCN_BUF + (4 * 32 * 2 + 128 + 64) * sizeof(float);
+  const size_t lds = (size_t)SCN_BUF + 4 * 32 * 2 * 4 + 32 * 9 * 128 * 2;      // the weight staging (73.7 KB) covers halo buffer 1 (60 KB)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_scn_stream_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1337,6 +1348,301 @@ extern "C" int stp_conv2d_scn(const stp_conv_params* p, void* stream) {
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_scn_stream_kernel<bf16_t>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, aa);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// =================================================================================================
+// 64 -> 64 channels, 3x3 / stride 1 (ResNet stage 1 and decoder_stage2_conv2 at 16 x 128 x 128: 14 launches of the U-Net step, forward
+// and data gradient): the weight matrix lives in REGISTERS - every wave keeps 32 output channels x 576 = 144 registers of A fragments
+// (8 waves: 2 channel halves x 4 row pairs of the 8 x 32 tile, two waves per SIMD) - so nothing but the halo moves through LDS
+// (2 x 32-channel planes of 10 x 34 pixels, double-buffered by LDS-DMA one tile ahead) and a pixel fragment is read once for up to 6
+// MFMAs (2 channel tiles x the taps (kh, kw) of the output rows r - kh).  conv_halo_kernel<16, 64, 1, 8> streams the weights through a
+// ring for every 256-pixel tile (73 KB per tile = 64 % of its L2 -> LDS bytes) and spends 43 % of a workgroup's life outside its K
+// loop: 31-39 us per layer, 500-600 TFLOP/s; the layer moves 80-115 MB (16-23 us at 5 TB/s) and needs 10 us of MFMA time.
+// (First version: ALL 288 weight registers per wave at one wave per SIMD, as in the narrow-output kernel above: 47 us - with a single
+//  wave per SIMD the MFMA phase ran at 39 % and the LDS-DMA of the next tile cost 4 us per tile on top; what-if builds in DESIGN 3.2b.)
+// Epilogue from the accumulators (8-byte buffer stores): residual | fused BatchNormalization statistics of the stored values | fused
+// BatchNormalization-backward mask + sums (stp_conv_params.bnb_x); the sums run over all tiles of the persistent workgroup (per-thread
+// accumulators in LDS) and are written once, one column per workgroup.
+// =================================================================================================
+struct S64Args {        // (next to a ScArgs: src, weight [64][576], dst, N, H, W, stats, bnb, tiles)
+  const char* residual;
+  uint32_t io_bytes;    // size of src = dst = residual = bnb.x
+};
+constexpr int S64_NT = 512, S64_PLV = SC_HH * SC_HW * 4, S64_NV = 2 * S64_PLV, S64_NPASS = (S64_NV + S64_NT - 1) / S64_NT, S64_BUF = S64_NPASS * S64_NT * 16;
+
+template <typename T>
+__global__ __launch_bounds__(S64_NT, 2) void conv_s64_stream_kernel(const ScArgs a, const S64Args aa) {
+  constexpr int SZ = (int)sizeof(T), K = 9 * 64, PIXB = 64;
+  static_assert(SZ == 2, "16-bit storage");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: [halo buffer 0][tables][halo buffer 1 = the weight staging of the prologue (73.7 KB)]
+  float* wsum = reinterpret_cast<float*>(smem + S64_BUF);          // [8 waves][32 channels][2]: running sums of the fused statistics
+  float* ktab = wsum + 8 * 32 * 2;                                 // [4][64]: scale, shift, mean, rstd of the fused BatchNormalization backward
+  uint32_t* hrel = reinterpret_cast<uint32_t*>(ktab + 256);        // [S64_NPASS][512 threads]: LDS-DMA offsets relative to the first halo pixel
+  constexpr int S64_B1 = S64_BUF + (8 * 32 * 2 + 256) * 4 + S64_NPASS * S64_NT * 4;      // byte offset of halo buffer 1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wv & 3, cg = wv >> 2;                           // row pair of the tile, channel half
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
+  } else {
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = ntiles;
+  }
+  const bool bnb = a.bnb.x != nullptr;
+  if (tid < 8 * 32 * 2) wsum[tid] = 0.f;
+  auto flush_stats = [&]() __attribute__((always_inline)) {
+    if (!a.stats) return;
+    lds_barrier();
+    if (tid < 64) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { sv += wsum[(((tid >> 5) * 4 + w) * 32 + (tid & 31)) * 2]; qv += wsum[(((tid >> 5) * 4 + w) * 32 + (tid & 31)) * 2 + 1]; }
+      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][workgroup]
+      a.stats[((size_t)64 + tid) * gridDim.x + blockIdx.x] = qv;
+    }
+  };
+  if (t_first >= t_end) {      // (no tile: the statistics column of this workgroup must still be defined)
+    flush_stats();
+    return;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, aa.io_bytes, 0x00020000);
+  // staging: vector v = p * 512 + tid of the buffer image [plane][10 x 34 pixels][4 vectors]; byte offset relative to the first halo pixel
+  auto vcoord = [&](int v, int& cy, int& cx) __attribute__((always_inline)) -> uint32_t {
+    cy = cx = 0;
+    if (v >= S64_NV) return 0x80000000u;
+    const int plane = v / S64_PLV, r = v - plane * S64_PLV, px = r >> 2, vec = r & 3;
+    cy = px / SC_HW; cx = px - cy * SC_HW;
+    return (uint32_t)((cy * a.W + cx) * 128 + plane * 64 + vec * 16);
+  };
+#pragma unroll
+  for (int p = 0; p < S64_NPASS; ++p) {
+    int cy_, cx_;
+    hrel[p * S64_NT + tid] = vcoord(p * S64_NT + tid, cy_, cx_);
+  }
+  auto decode = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+    const int bq = (int)fdiv((uint32_t)tile, a.divTx);
+    const int tx = tile - bq * a.tiles_x;
+    n = (int)fdiv((uint32_t)bq, a.divTy);
+    const int ty = bq - n * a.tiles_y;
+    y0 = ty * SC_TH; x0 = tx * SC_TW;
+  };
+  auto issue_tile = [&](int tile, int b) __attribute__((always_inline)) {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    const bool inner = y0 >= 1 && x0 >= 1 && y0 + SC_TH + 1 <= a.H && x0 + SC_TW + 1 <= a.W;      // (uniform) the halo lies inside the image
+    const uint32_t base = (uint32_t)(((n * a.H + y0 - 1) * a.W + x0 - 1) * 128);
+#pragma unroll
+    for (int p = 0; p < S64_NPASS; ++p) {
+      const uint32_t hr = hrel[p * S64_NT + tid];
+      uint32_t off = hr == 0x80000000u ? 0x80000000u : base + hr;
+      if (!inner && off != 0x80000000u) {
+        int cy, cx;
+        vcoord(p * S64_NT + tid, cy, cx);
+        if (!((unsigned)(y0 - 1 + cy) < (unsigned)a.H && (unsigned)(x0 - 1 + cx) < (unsigned)a.W)) off = 0x80000000u;
+      }
+      if (p * S64_NT + wv * 64 < S64_NV)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + (b ? S64_B1 : 0) + p * (S64_NT * 16) + wv * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  issue_tile(t_first, 0);
+
+  // once per workgroup: the weight matrix (73.7 KB) -> LDS by LDS-DMA, fragment-major ([chunk][lane group][64 output channels] 16-byte
+  // vectors: conflict-free fragment reads), then this wave's 32 output channels -> registers.  (Every wave fetching its fragments from
+  // L2 itself = 75 MB of L2 reads per launch for 4 tiles per workgroup: 9 us of a 35 us launch.)  chunk c = slice * 9 + tap
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, 64 * K * SZ, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {      // 4608 vectors = 72 wave instructions: vector (c * 4 + g) * 64 + co <- weight[co][k0(c) + 8 g]
+      const int wi = p * 8 + wv, c = wi >> 2, g = wi & 3, s_ = c / 9, t = c - s_ * 9;
+      const uint32_t off = (uint32_t)((lane * K + t * 64 + s_ * 32 + g * 8) * SZ);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + S64_B1 + wi * 1024), 16, off, 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weights' and the first tile's own pieces have landed
+  lds_barrier();
+  u32x4 fa[2][18];
+#pragma unroll
+  for (int c = 0; c < 18; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      fa[i][c] = *reinterpret_cast<const u32x4*>(smem + S64_B1 + ((c * 4 + lg) * 64 + cg * 32 + i * 16 + lr) * 16);
+  const uint32_t lsk = (uint32_t)(lr * PIXB + lg * 16 + wave * 2 * SC_HW * PIXB);       // lane part of every fragment address (halo rows 2 wave ..)
+  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, aa.io_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rop = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? a.bnb.x : (aa.residual ? aa.residual : a.dst)), 0, aa.io_bytes, 0x00020000);
+  const bool hasop = bnb || aa.residual != nullptr;
+  const uint32_t lvo = (uint32_t)((lr * 64 + cg * 32 + lg * 4) * SZ);      // lane part of the output offsets: pixel lr of a 16-pixel row segment, channels 32 cg + 4 lg ..
+  if (bnb && tid < 64) {
+    const float mu = a.bnb.mean[tid], rsd = a.bnb.rstd[tid];
+    const float sc = a.bnb.gamma ? rsd * a.bnb.gamma[tid] : rsd;
+    ktab[tid] = sc; ktab[64 + tid] = (a.bnb.beta ? a.bnb.beta[tid] : 0.f) - mu * sc; ktab[128 + tid] = mu; ktab[192 + tid] = rsd;
+  }
+  lds_barrier();               // every wave holds its weights: halo buffer 1 is free; the tables are visible
+
+  auto body = [&](int tile, auto curc) {
+    constexpr int CUR = decltype(curc)::value;
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    const bool full = y0 + SC_TH <= a.H && x0 + SC_TW <= a.W;      // (uniform)
+    const int next = tile + t_step;
+    if (next < t_end) issue_tile(next, CUR ^ 1);
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // read sidx = ((slice * 4 + r) * 3 + kw) * 2 + h2: halo row 2 wave + r (r = 0..3), shifted by kw, column half h2
+    auto bfrag = [&](int sidx) __attribute__((always_inline)) -> u32x4 {
+      const int h2 = sidx & 1, kw = (sidx >> 1) % 3, r = (sidx / 6) & 3, sl = sidx / 24;
+      return *reinterpret_cast<const u32x4*>(smem + lsk + ((CUR ? S64_B1 : 0) + sl * S64_PLV * 16 + (r * SC_HW + h2 * 16 + kw) * PIXB));
+    };
+    u32x4 fbq[4];
+    fbq[0] = bfrag(0); fbq[1] = bfrag(1); fbq[2] = bfrag(2);
+#pragma unroll
+    for (int sidx = 0; sidx < 48; ++sidx) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (sidx + 3 < 48) fbq[(sidx + 3) & 3] = bfrag(sidx + 3);
+      const int h2 = sidx & 1, kw = (sidx >> 1) % 3, r = (sidx / 6) & 3, sl = sidx / 24;
+      const u32x4 fb = fbq[sidx & 3];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int orow = r - kh;
+        if (orow < 0 || orow > 1) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][orow * 2 + h2] = mfma16_16x16x32(fa[i][sl * 9 + kh * 3 + kw], fb, acc[i][orow * 2 + h2]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's own pieces (and this tile's operands) have landed
+    // epilogue.  Operands (residual, or the BatchNormalization input of the fused backward) are fetched one fragment ahead
+    auto opload = [&](int f, u32x2 (&o)[2]) __attribute__((always_inline)) {
+      const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+      const uint32_t so = (uint32_t)(((n * a.H + gy) * a.W + x0 + (f & 1) * 16) * 64) * (uint32_t)SZ;
+      const bool ok = full || (gy < a.H && gx < a.W);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_raw_buffer_load_b64(rop, ok ? lvo + (uint32_t)(i * 16 * SZ) : 0x80000000u, so, 0);
+    };
+    u32x2 opq[2][2];
+    if (hasop) opload(0, opq[0]);
+    f32x4 ssl[2], qql[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ssl[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qql[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (hasop && f + 1 < 4) opload(f + 1, opq[(f + 1) & 1]);
+      const int gy = y0 + wave * 2 + (f >> 1), gx = x0 + (f & 1) * 16 + lr;
+      const uint32_t so = (uint32_t)(((n * a.H + gy) * a.W + x0 + (f & 1) * 16) * 64) * (uint32_t)SZ;
+      const bool ok = full || (gy < a.H && gx < a.W);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t vo = ok ? lvo + (uint32_t)(i * 16 * SZ) : 0x80000000u;
+        f32x4 v = acc[i][f];
+        const u32x2 ow = opq[f & 1][i];
+        const f32x4 op = {h16lo_to_f32(ow.x), h16hi_to_f32(ow.x), h16lo_to_f32(ow.y), h16hi_to_f32(ow.y)};
+        if (!bnb && hasop) v += op;
+        u32x2 o = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        f32x4 sv = {h16lo_to_f32(o.x), h16hi_to_f32(o.x), h16lo_to_f32(o.y), h16hi_to_f32(o.y)};      // as stored
+        if (bnb) {
+          const int co = cg * 32 + i * 16 + lg * 4;
+          BnBackCh kk;
+          kk.sc = *reinterpret_cast<const f32x4*>(ktab + co); kk.sh = *reinterpret_cast<const f32x4*>(ktab + 64 + co);
+          kk.mu = *reinterpret_cast<const f32x4*>(ktab + 128 + co); kk.rs = *reinterpret_cast<const f32x4*>(ktab + 192 + co);
+          f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, q0 = s0;
+          const f32x4 g = bnback_apply(kk, a.bnb.relu, op, sv, s0, q0);
+          if (ok) { ssl[i] += s0; qql[i] += q0; }
+          o = u32x2{pack_bf16x2(g.x, g.y), pack_bf16x2(g.z, g.w)};
+        } else if (a.stats && ok) {
+          ssl[i] += sv;
+          qql[i] += sv * sv;
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(o, rdst, vo, so, 0);
+      }
+    }
+    if (a.stats) {      // this wave's 32 channels: row reduction, lane 15 of each row adds into the wave's running sums
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e_ = 0; e_ < 4; ++e_) {
+          const float sv = row_sum16_to_lane15(ssl[i][e_]), qv = row_sum16_to_lane15(qql[i][e_]);
+          if (lr == 15) {
+            float* ws = wsum + ((wv * 32) + i * 16 + lg * 4 + e_) * 2;
+            ws[0] += sv; ws[1] += qv;
+          }
+        }
+    }
+    lds_barrier();        // the next tile is visible to everybody, and everybody has left this one
+  };
+
+  for (int tile = t_first; tile < t_end; tile += 2 * t_step) {
+    body(tile, std::integral_constant<int, 0>{});
+    if (tile + t_step < t_end) body(tile + t_step, std::integral_constant<int, 1>{});
+  }
+  flush_stats();
+}
+
+static int s64_blocks(int ntiles) {
+  const int b = sc_cu_count();
+  return b < ntiles ? b : ntiles;
+}
+
+// Can conv_s64_stream_kernel serve this convolution?  NOT used automatically (STP_S64=1 makes stp_conv2d prefer it to the halo kernel; an
+// explicit tile id 736 always works): measured on 16 x 128 x 128 against conv_halo_kernel<16, 64, 1, 8> - plain 30.1 vs 33.3 us, with the
+// fused statistics 32.6 vs 34.6, residual + statistics 35.5 vs 35.7, BatchNormalization-backward sums 42.4 vs 37.1 (its epilogue works
+// from the accumulator layout: 8-byte accesses); at batch 64 (16 tiles per workgroup instead of 4) 99.8 vs 128.8 us = 775 vs 600 TFLOP/s:
+// the prologue (weights -> LDS -> registers, 7 us) is what four tiles per workgroup cannot amortise.
+extern "C" int stp_conv2d_s64_eligible(const stp_conv_params* p) {
+  if (!p || p->dtype != STP_H16) return 0;
+  return p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->C0 == 64 && p->C1 == 0 && p->Cout == 64 && p->Cd0 == 64 && !p->dst1 &&
+         p->src0_mode == STP_SRC_DIRECT && p->Hs0 == p->Hv && p->Ws0 == p->Wv && p->Ho == p->Hv && p->Wo == p->Wv && !p->bias && !p->relu &&
+         !p->accumulate0 && !p->dst_sum2x2 && !p->src_bn_mean && !p->stats_slots && !p->fold_src && !(p->bnb_x && p->residual) &&
+         (int64_t)p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW) >= 2 * sc_cu_count();      // two tiles per workgroup at least: the weights load once per workgroup
+}
+extern "C" int stp_conv2d_s64_stats_tiles(const stp_conv_params* p) {
+  return s64_blocks(p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW));
+}
+
+extern "C" int stp_conv2d_s64(const stp_conv_params* p, void* stream) {
+  if (!stp_conv2d_s64_eligible(p) || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
+  S64Args aa;
+  ScArgs a;
+  a.src = (const char*)p->src0; a.weight = (const char*)p->weight; a.bias = nullptr; a.dst = (char*)p->dst0;
+  a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Hs = p->Hs0; a.Ws = p->Ws0; a.Cout = 64;
+  a.up = 0; a.accumulate = 0; a.relu = 0;
+  aa.residual = (const char*)p->residual;
+  {
+    const uint64_t ib = (uint64_t)p->N * p->Hv * p->Wv * 64 * 2;
+    if (ib >= 0x80000000ull) return STP_E_BADARG;   // 32-bit buffer offsets
+    aa.io_bytes = (uint32_t)ib; a.src_bytes = aa.io_bytes;
+  }
+  a.tiles_x = ceil_div(a.W, SC_TW); a.tiles_y = ceil_div(a.H, SC_TH);
+  a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
+  a.stats = p->stats_partial;
+  a.stat_slots = 0;
+  a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
+  a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;
+  if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd)) return STP_E_BADARG;
+  a.sum2 = 0;
+  a.pbn.x = nullptr; a.pbn.mean = nullptr; a.pbn.rstd = nullptr; a.pbn.gamma = nullptr; a.pbn.beta = nullptr; a.pbn.relu = 0;
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  const int blocks = s64_blocks(ntiles);
+  const_cast<stp_conv_params*>(p)->stats_tiles = blocks;
+  const size_t lds = (size_t)S64_BUF + (8 * 32 * 2 + 256) * 4 + S64_NPASS * S64_NT * 4 + 64 * 9 * 64 * 2;      // the weight staging (73.7 KB) covers halo buffer 1
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s64_stream_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_s64_stream_kernel<bf16_t>), dim3(blocks), dim3(S64_NT), lds, (hipStream_t)stream, a, aa);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }

@@ -1140,6 +1140,58 @@ def test_wide_output_data_gradient_of_upsample_concat(ops, dtype, mode, c_up):
 
 
 @pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("mode", ["plain", "stats", "residual_stats", "bn_backward"])
+def test_64_channel_kernel_with_weights_in_registers(ops, dtype, mode):
+    """stp_conv2d_s64 (64 -> 64 channels, 3x3: ResNet stage 1 forward / data gradient): against a plain PyTorch fp32 convolution of
+    the same 16-bit operands, and against the generic kernel for the fused statistics / BatchNormalization-backward sums.  Ragged
+    8 x 32 tiles in both directions, three tiles per workgroup."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c = 3, 100, 440, 64
+    rng = np.random.RandomState(45)
+    x = q(rng.randn(n, h, w, c), dtype)
+    wt = q(rng.randn(3, 3, c, c) / np.sqrt(9 * c), dtype)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    xd = dev(x, dtype)
+    res = dev(q(rng.randn(n, h, w, c), dtype), dtype) if mode == "residual_stats" else None
+    bx = dev(q(rng.randn(n, h, w, c) + 0.2, dtype), dtype) if mode == "bn_backward" else None
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    g, b, m, r = f(rng.rand(c) + 0.5), f(rng.randn(c) * 0.3), f(rng.randn(c) * 0.1 + 0.2), f(rng.rand(c) + 0.5)
+    def run(tile):
+        y = torch.full((n, h, w, c), float("nan"), dtype=TD[dtype], device=DEV)
+        P = ops.conv_params(xd, fwd, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=c, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=c, dtype=ops.dt(y),
+                            residual=res, tile=tile)
+        st = None
+        if mode != "plain":
+            if mode == "bn_backward":
+                P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(bx), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1
+            st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+            P.stats_partial = ops.ptr(st)
+        ops.conv2d(P)
+        tiles = ops.conv2d_stats_floats(P) // (2 * c)
+        sums = host(st)[:2 * c * tiles].reshape(2, c, tiles).astype(np.float64).sum(-1) if st is not None else None
+        return y, st, sums, P
+    y, st, sums, P = run(736)                                    # (opt-in kernel: by tile id)
+    assert _lib.load().stp_conv2d_s64_eligible(ops.C.byref(P)) and _lib.load().stp_conv2d_tile_for(ops.C.byref(P)) == 736
+    yr, _, sums_r, Pr = run(2)                                   # the general implicit-GEMM kernel
+    assert _lib.load().stp_conv2d_tile_for(ops.C.byref(Pr)) == 2
+    if mode != "bn_backward":
+        ref = torch.nn.functional.conv2d(xd.float().permute(0, 3, 1, 2), torch.from_numpy(wt.transpose(3, 2, 0, 1).astype(np.float32)).to(DEV), padding=1)
+        ref = ref.permute(0, 2, 3, 1)
+        if res is not None:
+            ref = ref + res.float()
+        np.testing.assert_allclose(host(y), host(ref), atol=tol(host(ref), dtype))
+    else:
+        # masked gradients: equal to the generic kernel's except where the two accumulate in a different order across a rounding boundary
+        d = np.abs(host(y) - host(yr))
+        assert (d > tol(host(yr), dtype)).mean() < 1e-4
+    if sums is not None:
+        np.testing.assert_allclose(sums, sums_r, rtol=2e-3, atol=2e-3 * np.abs(sums_r).max())
+        assert P.stats_tiles == ops.conv2d_stats_floats(P) // (2 * c)
+        y2, st2, _, _ = run(736)                              # replay: fixed partition, fixed order
+        assert torch.equal(y2, y) and torch.equal(st2[:2 * c * P.stats_tiles], st[:2 * c * P.stats_tiles])
+
+
+@pytest.mark.parametrize("dtype", H16)
 @pytest.mark.parametrize("mode", ["plain", "stats", "bias_relu_accumulate"])
 def test_narrow_output_forward_of_upsample_concat(ops, dtype, mode):
     """stp_conv2d_scn: Conv2D(32, 3x3)(Concatenate([UpSampling2D(2)(x), skip])) with 64 + 64 input channels - both halos resident in
