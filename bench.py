@@ -140,37 +140,51 @@ def _pmc_stale(path):
         return True
 
 
+def _pmc_entries(kernels, kernel):
+    """Counter records of ``kernel``: the exact name, or - the profiler's names of some kernels carry one more template argument than
+    bench.py's keys (the epilogue variant of conv_halo_kernel) - every instance that extends it."""
+    if kernel in kernels:
+        return [kernels[kernel]]
+    if kernel.endswith(">"):
+        pre = kernel[:-1] + ","
+        return [v for k, v in kernels.items() if k.startswith(pre)]
+    return []
+
+
 def pmc_traffic(kernel):
     """L2-miss bytes per launch of ``kernel`` (read + write) from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
-    that kernel was not in the measured build."""
+    that kernel was not in the measured build.  Several instances of one key: dispatch-weighted mean."""
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     names = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")), reverse=True) if os.path.isdir(pdir) else []
     for name in names:      # newest measurement that knows this kernel
         path = os.path.join(pdir, name)
         try:
             with open(path) as f:
-                k = json.load(f)["kernels"].get(kernel)
+                ks = _pmc_entries(json.load(f)["kernels"], kernel)
         except (OSError, ValueError, KeyError):
             continue
-        if k:
-            return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], "profiles/" + name
+        n = sum(k.get("dispatches", 1) for k in ks)
+        if n:
+            return int(sum((k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) * k.get("dispatches", 1) for k in ks) / n), "profiles/" + name
     return None, None
 
 
 def pmc_mfma_util(kernel):
     """MFMA pipe utilisation of ``kernel`` from the committed SQ counter pass (profiles/*_pmc_sq.json, scratch/pmc_aggregate_sq.py):
-    SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles); None when that kernel was not measured."""
+    SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles); None when that kernel was not measured.  Several instances of one key:
+    weighted by their total duration."""
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     names = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_sq.json")), reverse=True) if os.path.isdir(pdir) else []
     for name in names:
         try:
             with open(os.path.join(pdir, name)) as f:
-                k = json.load(f)["kernels"].get(kernel)
+                ks = [k for k in _pmc_entries(json.load(f)["kernels"], kernel) if k.get("mfma_util") is not None]
         except (OSError, ValueError, KeyError):
             continue
-        if k and k.get("mfma_util") is not None:
-            return k["mfma_util"], "profiles/" + name
+        wsum = sum(k.get("dispatches", 1) * k.get("avg_duration_us", 1.0) for k in ks)
+        if wsum:
+            return round(sum(k["mfma_util"] * k.get("dispatches", 1) * k.get("avg_duration_us", 1.0) for k in ks) / wsum, 4), "profiles/" + name
     return None, None
 
 

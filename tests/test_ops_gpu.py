@@ -240,6 +240,8 @@ def test_conv2d_upsample_concat_with_class_collapsed_weights(ops, dtype, shape):
         P = ops.conv_params(dev(x, dtype), fwd, y, N=n, Hs0=h, Ws0=w, Hv=2 * h, Wv=2 * w, C0=c0, C1=c1, src1=dev(skip, dtype),
                             mode=ops.SRC_NEAREST2X, KH=3, KW=3, stride=1, pad=1, Ho=2 * h, Wo=2 * w, Cout=co, dtype=ops.dt(y))
         P.weight_up = ops.ptr(weight_up)
+        if _lib.load().stp_conv2d_scn_eligible(ops.C.byref(P)):
+            P.tile = 64 + 3              # (64 + 64 -> 32 channels: the narrow-output kernel would take it and ignore weight_up; this test is about the generic one)
         st = None
         if stats:
             st = torch.zeros(max(ops.conv2d_stats_floats(P), 4), device=DEV)
