@@ -877,7 +877,16 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const char* __r
   const int ev = threadIdx.x % EPB, sl = threadIdx.x / EPB;
   const int e = (blockIdx.x % BPT) * EPB + ev;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int k = sl; k < tl.nslots; k += SL) s += slabs[(size_t)slot_list[tl.list0 + k] * PER + e];
+  {
+    // (four slab loads in flight per lane; same order of additions)
+    int k = sl;
+    for (; k + 3 * SL < tl.nslots; k += 4 * SL) {
+      const f32x4 a0 = slabs[(size_t)slot_list[tl.list0 + k] * PER + e], a1 = slabs[(size_t)slot_list[tl.list0 + k + SL] * PER + e];
+      const f32x4 a2 = slabs[(size_t)slot_list[tl.list0 + k + 2 * SL] * PER + e], a3 = slabs[(size_t)slot_list[tl.list0 + k + 3 * SL] * PER + e];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < tl.nslots; k += SL) s += slabs[(size_t)slot_list[tl.list0 + k] * PER + e];
+  }
   if (SL > 1) {
     sh[sl][ev] = s;
     __syncthreads();
@@ -963,8 +972,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
   const int ev = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = ((int64_t)blockIdx.x * 16 + ev) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (i < count)
-    for (int k = sl; k < splits; k += 16) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * count + i);
+  if (i < count) {
+    // eight loads in flight per lane (the loop is latency-bound otherwise: 13.5 us for 10-20 MB of slabs); same order of additions
+    int k = sl;
+    for (; k + 112 < splits; k += 128) {
+      f32x4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(k + 16 * u) * count + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += a[u];
+    }
+    for (; k < splits; k += 16) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * count + i);
+  }
   sh[sl][ev] = s;
   __syncthreads();
   for (int w = 8; w > 0; w >>= 1) {
