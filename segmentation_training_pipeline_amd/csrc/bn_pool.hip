@@ -873,7 +873,23 @@ __device__ __forceinline__ void bnf_slab_sums(const float* __restrict__ partial,
   const float* ps = partial + (size_t)(c0 + cl) * tiles;
   const float* pq = partial + ((size_t)C + c0 + cl) * tiles;
   s = 0.0; q = 0.0;
-  if ((tiles & 3) == 0) {
+  if ((tiles & 3) == 0 && tiles <= 128) {
+    // (the fused kernels' case.)  All loads first - as a loop with a run-time trip count every one of the up to 8 iterations exposed
+    // a memory round trip at the start of EVERY workgroup of the apply pass; then the sums in the same order
+    f32x4 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = 4 * j + 16 * u;
+      a[u] = b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < tiles) { a[u] = *reinterpret_cast<const f32x4*>(ps + t); b[u] = *reinterpret_cast<const f32x4*>(pq + t); }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (4 * j + 16 * u < tiles) {
+        s += ((double)a[u].x + (double)a[u].y) + ((double)a[u].z + (double)a[u].w);
+        q += ((double)b[u].x + (double)b[u].y) + ((double)b[u].z + (double)b[u].w);
+      }
+  } else if ((tiles & 3) == 0) {
     for (int t = 4 * j; t < tiles; t += 16) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(ps + t), b = *reinterpret_cast<const f32x4*>(pq + t);
       s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
