@@ -269,25 +269,65 @@ extern "C" int stp_bn_stats(const void* x, int32_t xdtype, int64_t rows, int32_t
   return STP_OK;
 }
 
+// Sum of the [2][tiles] partial columns of one channel by 256 threads (one workgroup per channel), fp64, fixed order: up to four
+// columns per thread with all loads issued first, a DPP row reduction on the two halves of the doubles (no LDS round trips: the
+// ds_bpermute butterfly this replaces was 24 dependent LDS operations of a 5 us launch), the four row totals of a wave by
+// v_readlane, the four waves through LDS (one barrier).  Valid in thread 0.
+__device__ __forceinline__ double bnf_row_shr_add(double v, int ctl_id) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  int lo = (int)(u & 0xffffffffull), hi = (int)(u >> 32);
+  int mlo, mhi;
+  switch (ctl_id) {      // bound_ctrl: lanes shifted in from outside the row read 0.0
+    case 1: mlo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); mhi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
+    case 2: mlo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); mhi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
+    case 4: mlo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); mhi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
+    default: mlo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); mhi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
+  }
+  return v + __builtin_bit_cast(double, ((unsigned long long)(unsigned)mhi << 32) | (unsigned long long)(unsigned)mlo);
+}
+__device__ __forceinline__ double bnf_readlane_f64(double v, int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void bnf_channel_sums(const float* __restrict__ ps, const float* __restrict__ pq, int tiles, double (*sh)[4], double& S, double& Q) {
+  double s = 0.0, q = 0.0;
+  if (tiles <= 1024) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = (int)threadIdx.x + 256 * u;
+      a[u] = b[u] = 0.f;
+      if (t < tiles) { a[u] = ps[t]; b[u] = pq[t]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if ((int)threadIdx.x + 256 * u < tiles) { s += (double)a[u]; q += (double)b[u]; }
+  } else {
+    for (int t = threadIdx.x; t < tiles; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
+  }
+  s = bnf_row_shr_add(s, 1); q = bnf_row_shr_add(q, 1);
+  s = bnf_row_shr_add(s, 2); q = bnf_row_shr_add(q, 2);
+  s = bnf_row_shr_add(s, 4); q = bnf_row_shr_add(q, 4);
+  s = bnf_row_shr_add(s, 8); q = bnf_row_shr_add(q, 8);      // lane 15 of every 16-lane row: the row's total
+  const double ws = (bnf_readlane_f64(s, 15) + bnf_readlane_f64(s, 31)) + (bnf_readlane_f64(s, 47) + bnf_readlane_f64(s, 63));
+  const double wq = (bnf_readlane_f64(q, 15) + bnf_readlane_f64(q, 31)) + (bnf_readlane_f64(q, 47) + bnf_readlane_f64(q, 63));
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = ws; sh[1][threadIdx.x >> 6] = wq; }
+  __syncthreads();
+  S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+  Q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+}
+
 // Finalize for statistics produced by a convolution epilogue: partial is [2][C][tiles] (tile contiguous).
 // One wave per channel: coalesced strided walk + wave reduction, fixed order.
 __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, double inv_rows,
                                                                 double unbias, float eps, float momentum, float* mean, float* rstd,
                                                                 float* mm, float* mv) {
-  // 256 threads per channel: strided fp64 accumulation, a butterfly inside each wave, then the 4 waves through LDS (ONE barrier;
-  // the 8-round LDS tree this replaces spent the launch in barriers)
   __shared__ double sh[2][4];
   const int c = blockIdx.x;
-  const float* ps = partial + (size_t)c * tiles;
-  const float* pq = partial + ((size_t)C + c) * tiles;
-  double s = 0.0, q = 0.0;
-  for (int t = threadIdx.x; t < tiles; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
-  __syncthreads();
+  double S, Q;
+  bnf_channel_sums(partial + (size_t)c * tiles, partial + ((size_t)C + c) * tiles, tiles, sh, S, Q);
   if (threadIdx.x != 0) return;
-  const double S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), Q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
   const double m = S * inv_rows;
   double var = Q * inv_rows - m * m;
   if (var < 0.0) var = 0.0;
@@ -1048,20 +1088,11 @@ static int bn_bwd_fused_launch(const void* x, const void* g, void* dx, const voi
 // [2][C][tiles] epilogue partials -> sums (same contract as bn_bwd_finalize_kernel); one workgroup per channel
 __global__ __launch_bounds__(256) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ partial, int tiles, int C, float* sums,
                                                                     float* dgamma, float* dbeta) {
-  // 256 threads per channel: strided fp64 accumulation, a butterfly inside each wave, then the 4 waves through LDS (ONE barrier;
-  // the 8-round LDS tree this replaces spent the launch in barriers)
   __shared__ double sh[2][4];
   const int c = blockIdx.x;
-  const float* ps = partial + (size_t)c * tiles;
-  const float* pq = partial + ((size_t)C + c) * tiles;
-  double s = 0.0, q = 0.0;
-  for (int t = threadIdx.x; t < tiles; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
-  __syncthreads();
+  double S, Q;
+  bnf_channel_sums(partial + (size_t)c * tiles, partial + ((size_t)C + c) * tiles, tiles, sh, S, Q);
   if (threadIdx.x != 0) return;
-  const double S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), Q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
   sums[c] = (float)S;
   sums[C + c] = (float)Q;
   if (dbeta) dbeta[c] = (float)S;
