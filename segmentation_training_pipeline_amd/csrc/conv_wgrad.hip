@@ -959,7 +959,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= count) return;
   f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
-  for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * count + i);
+  int k = 1;
+  for (; k + 3 < splits; k += 4) {      // four slab loads in flight; same order of additions
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (size_t)k * count + i), a1 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(k + 1) * count + i);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(k + 2) * count + i), a3 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(k + 3) * count + i);
+    s += a0; s += a1; s += a2; s += a3;
+  }
+  for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * count + i);
   if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i);
   *reinterpret_cast<f32x4*>(dw + i) = s;
 }

@@ -62,7 +62,17 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial
   __shared__ double sh[32][LOSS_NSUM];
   const int e = threadIdx.x & 7, lane = threadIdx.x >> 3;
   double a = 0.0;
-  for (int b = lane; b < blocks; b += 32) a += (double)partial[(size_t)b * LOSS_NSUM + e];
+  {
+    int b = lane;
+    for (; b + 224 < blocks; b += 256) {      // eight partials in flight; same order of additions
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 32 * u) * LOSS_NSUM + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (double)v[u];
+    }
+    for (; b < blocks; b += 32) a += (double)partial[(size_t)b * LOSS_NSUM + e];
+  }
   sh[lane][e] = a;
   __syncthreads();
   for (int w = 16; w > 0; w >>= 1) {
