@@ -140,6 +140,14 @@ def _pmc_stale(path):
         return True
 
 
+def _pmc_files(pdir, suffix):
+    """Counter files under profiles/: those collected on this build of csrc/ (matching fingerprint) first, then by name, newest first."""
+    if not os.path.isdir(pdir):
+        return []
+    names = sorted((f for f in os.listdir(pdir) if f.endswith(suffix)), reverse=True)
+    return sorted(names, key=lambda f: _pmc_stale(os.path.join(pdir, f)))      # (stable: False < True)
+
+
 def _pmc_entries(kernels, kernel):
     """Counter records of ``kernel``: the exact name, or - the profiler's names of some kernels carry one more template argument than
     bench.py's keys (the epilogue variant of conv_halo_kernel) - every instance that extends it."""
@@ -156,8 +164,8 @@ def pmc_traffic(kernel):
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
     that kernel was not in the measured build.  Several instances of one key: dispatch-weighted mean."""
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    names = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")), reverse=True) if os.path.isdir(pdir) else []
-    for name in names:      # newest measurement that knows this kernel
+    names = _pmc_files(pdir, "_pmc_traffic.json")
+    for name in names:      # the measurement of THIS build first, then the newest that knows this kernel
         path = os.path.join(pdir, name)
         try:
             with open(path) as f:
@@ -175,7 +183,7 @@ def pmc_mfma_util(kernel):
     SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles); None when that kernel was not measured.  Several instances of one key:
     weighted by their total duration."""
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    names = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_sq.json")), reverse=True) if os.path.isdir(pdir) else []
+    names = _pmc_files(pdir, "_pmc_sq.json")
     for name in names:
         try:
             with open(os.path.join(pdir, name)) as f:
