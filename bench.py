@@ -63,8 +63,10 @@ def kernel_key(name, meta, dtype):
             return "conv_igemm_ut_kernel<%s, %s, %d, true>" % (t, CONV_TILES[tile % 32], tile // 32)
         c4 = "true" if (dtype == "bf16" and meta["layer"] == "conv0") else "false"
         return "conv_igemm_kernel<%s, %s, %s>" % (t, CONV_TILES[tile], c4)
-    if name == "stp_wgrad_group_partial":      # grouped row-of-taps weight gradient (conv_wgrad.hip): one launch per group of layers
-        return "conv_wgrad_row_group_kernel<%s, 3>" % {128: "128, 2, 2", 64: "64, 1, 4", 32: "32, 1, 4"}[meta["bm"]]
+    if name == "stp_wgrad_group_partial":      # grouped weight gradient (conv_wgrad.hip): one launch per group of layers
+        if meta.get("taps9"):                  # all-taps tiles (round 4): <output channels per workgroup, ring stages>
+            return "conv_wgrad_taps9_group_kernel<%d, 3>" % meta["bm"]
+        return "conv_wgrad_row_group%s_kernel<%s, 3>" % ("_pbn" if meta.get("pbn") else "", {128: "128, 2, 2", 64: "64, 1, 4", 32: "32, 1, 4"}[meta["bm"]])
     if name == "stp_conv2d_wgrad":
         if meta.get("sc"):
             return "conv_sc_wgrad_kernel<%s>" % t
@@ -196,19 +198,18 @@ def pmc_mfma_util(kernel):
     return None, None
 
 
-def cpu_baseline(seconds_budget=25.0, full_protocol=False):
+def cpu_baseline(full_protocol=False):
     """The in-repo CPU oracle (a PORT: the reference's Keras-CPU fit() is not installable here) running the
     same step - CPU augmentation (oracle/augment.py, the S1 pipeline of BASELINE.md 4) + forward + Dice/BCE + backward + Adam - on
-    a bounded sample: U-Net/ResNet-34, 512x512, batch 2 (BASELINE.md 4's batch-16, 3 warm-up / 10 timed protocol does not fit
-    the bench's time budget on the CPU, so: 1 warm-up, then as many timed steps as fit in ``seconds_budget`` (>= 3, <= 10),
-    MEDIAN step time; the value is batch / median)."""
+    a bounded sample of the workload: U-Net/ResNet-34, 512x512.  BASELINE.md 4's protocol (batch 16, 3 warm-up + 10 timed steps,
+    median) costs ~5 minutes of host time, so the default line runs the SHORT protocol - batch 8, 1 warm-up + 2 timed steps
+    (~30 s; round 3's batch-2 sample under-reported the rate by 1.85x: the per-image cost falls with the batch) - and says so in
+    ``protocol``; ``full_protocol`` (bench runs of >= 100 steps) runs BASELINE.md 4 as written."""
     from oracle import augment as oaug
     from oracle import nets as onets
     from oracle import step as ostep
     from segmentation_training_pipeline_amd import augment
-    # full_protocol (bench runs of >= 100 steps): BASELINE.md 4 as written - batch 16, 3 warm-up + 10 timed steps, median (~10 minutes
-    # of host time); the default form is the bounded sample the driver's 20-step run can afford
-    n = 16 if full_protocol else 2
+    n, warm, reps = (16, 3, 10) if full_protocol else (8, 1, 2)
     P = onets.init_unet_resnet("resnet34", seed=42)
     tr = ostep.OracleTrainer(P, backbone="resnet34", loss=LOSS, optimizer="adam", lr=1e-3)
     x, y = ostep.synthetic_batch(n, H, W, seed=1234)
@@ -220,19 +221,19 @@ def cpu_baseline(seconds_budget=25.0, full_protocol=False):
         xa, ya = oaug.warp_u8(x8, y8, prm, (H, W))
         tr.step(xa.astype(np.float32), ya.reshape(n, H, W, 1).astype(np.float32))
 
-    for _ in range(3 if full_protocol else 1):
-        one_step()  # warm-up
-    times, t_all = [], time.time()
-    while len(times) < (10 if full_protocol else 3) or (not full_protocol and time.time() - t_all < seconds_budget and len(times) < 10):
+    for _ in range(warm):
+        one_step()
+    times = []
+    for _ in range(reps):
         t0 = time.time()
         one_step()
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": round(n / med, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "protocol": "BASELINE.md 4 (batch 16, 3 + 10, median)" if full_protocol else
+                        "short (batch 8, 1 warm-up + 2 timed, median; BASELINE.md 4 asks batch 16, 3 + 10: --steps >= 100 runs it in full)",
             "sample": "oracle (numpy augmentation + PyTorch-CPU fp32) training step incl. the S1 augmentation, U-Net/ResNet34 512x512x3, "
-                      "batch %d, median of %d timed steps after %d warm-up (%s)"
-                      % (n, len(times), 3 if full_protocol else 1,
-                         "BASELINE.md 4 protocol" if full_protocol else "BASELINE.md 4 protocol shortened to fit the bench budget; --steps >= 100 runs it in full")}
+                      "batch %d, median of %d timed steps after %d warm-up" % (n, len(times), warm)}
 
 
 def main():
@@ -252,6 +253,8 @@ def main():
     ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet", "FPN"],
                     help="Unet = BASELINE.json's headline workload; Linknet = SURVEY 8f N1 on the same kernels (not the headline metric)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (for rocprofv3 kernel traces of the launches themselves)")
+    ap.add_argument("--sustain", type=float, default=8.0,
+                    help="seconds of extra back-to-back steps after the counted ones, reported as `sustained` (0 = skip; 1-GPU runs only)")
     args = ap.parse_args()
 
     from segmentation_training_pipeline_amd import augment, distributed, ops
@@ -291,25 +294,75 @@ def main():
     in_img, in_msk = model.plan.inputs["image"].buf, model.plan.inputs["mask"].buf
 
     def step(i):
-        ops.augment_u8(raw_img, raw_msk, in_img, in_msk, prm[i], BATCH, H, W, H, W, 3)
+        ops.augment_u8(raw_img, raw_msk, in_img, in_msk, prm[i % total], BATCH, H, W, H, W, 3)
         model.train_on_batch(None, None, fetch=False)
+
+    def timed(fn, first, count):
+        """EXACTLY ``count`` steps bracketed by barrier + synchronize on both sides; MAX over ranks (seconds)."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(first, first + count):
+            fn(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
-        dist.barrier()
+    elapsed = timed(step, args.warmup, args.steps)          # the contract's region: raw uint8 batch RESIDENT in HBM
+
+    # ---- the same step FED from pinned host memory (north_star: "fed by pinned hipMemcpyAsync"; pipeline.DeviceFeeder's scheme):
+    # NHOST distinct raw batches in pinned memory, two device staging buffers, a copy stream - the H2D copy of batch i+1 is issued
+    # right after the augmentation kernel of step i (which frees the other staging buffer one step later) and runs under step i's
+    # kernels.  Reported next to the resident number (`value` stays the resident one, as the bench contract prescribes).
+    NHOST = 4
+    h_img = [torch.from_numpy(np.roll(img, k, axis=0).copy()).pin_memory() for k in range(NHOST)]
+    h_msk = [torch.from_numpy(np.roll(msk, k, axis=0).copy()).pin_memory() for k in range(NHOST)]
+    d_img = [torch.empty_like(raw_img) for _ in range(2)]
+    d_msk = [torch.empty_like(raw_msk) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def stage(i):
+        b = i % 2
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[b])            # the augmentation kernel that read this staging buffer two steps ago
+            d_img[b].copy_(h_img[i % NHOST], non_blocking=True)
+            d_msk[b].copy_(h_msk[i % NHOST], non_blocking=True)
+            ready[b].record(copy_stream)
+
+    def step_fed(i):
+        b = i % 2
+        main = torch.cuda.current_stream()
+        main.wait_event(ready[b])
+        ops.augment_u8(d_img[b], d_msk[b], in_img, in_msk, prm[i % total], BATCH, H, W, H, W, 3)
+        consumed[b].record(main)
+        stage(i + 1)
+        model.train_on_batch(None, None, fetch=False)
+
+    for b in range(2):
+        consumed[b].record(torch.cuda.current_stream())
+    stage(0)
+    for i in range(2):
+        step_fed(i)
+    elapsed_fed = timed(step_fed, 2, args.steps)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    # ---- a LONG region of the resident step (world 1 only): the 20 counted steps last 0.15 s, which a 5 s utilisation sampler
+    # misses entirely; ~8 s of back-to-back replays give an independent observer something to see, and a drift-free average
+    sustained = None
+    if world == 1 and args.sustain > 0:
+        n_sus = max(200, int(args.sustain / max(elapsed / args.steps, 1e-4)))
+        sustained = (n_sus, timed(step, 0, n_sus))
     metrics = model.metrics()
     images_per_sec = world * BATCH * args.steps / elapsed
 
@@ -324,7 +377,14 @@ def main():
                    "hipgraph": not args.eager, "loss_after_run": round(metrics["loss"], 5)},
         # algorithmic FLOP per trained image = 3 x the forward conv FLOP the plan recorded (187.94 GFLOP for the U-Net)
         "step_mfma_frac": round(images_per_sec / world * flop_per_image(model) / (PEAK_BF16_TFLOPS * 1e12), 4),
+        # the same K steps with every batch copied from pinned host memory (double-buffered hipMemcpyAsync on a copy stream)
+        "ms_per_step_resident": round(1e3 * elapsed / args.steps, 3),
+        "ms_per_step_with_feed": round(1e3 * elapsed_fed / args.steps, 3),
+        "value_with_feed": round(world * BATCH * args.steps / elapsed_fed, 2),
     }
+    if sustained is not None:
+        out["sustained"] = {"steps": sustained[0], "seconds": round(sustained[1], 3), "ms_per_step": round(1e3 * sustained[1] / sustained[0], 3),
+                            "images_per_sec": round(BATCH * sustained[0] / sustained[1], 2)}
     if rank == 0 and not args.no_kernel_profile:
         prof = per_kernel_profile(model)
         tot = sum(v[1] for v in prof.values())

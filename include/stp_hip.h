@@ -223,7 +223,8 @@ typedef struct stp_wgrad_params {
   int32_t accumulate;
   int32_t dtype;
   int32_t splits;       /* 0 = auto */
-  /* as stp_conv_params.src_bn_*: src0 is the pre-normalisation tensor (small-channel weight gradient, C1 == 0 only) */
+  /* as stp_conv_params.src_bn_*: src0 is the pre-normalisation tensor (small-channel and row-of-taps weight gradients - single-layer
+   * and grouped launches -, C1 == 0 only) */
   const float* src_bn_mean;
   const float* src_bn_rstd;
   const float* src_bn_gamma;
@@ -257,7 +258,9 @@ int stp_conv2d_wgrad_kernel_id(const stp_wgrad_params* p);
  *   stp_wgrad_group_workspace_bytes : size of the partial slabs
  *   stp_wgrad_group_build        : fills the HOST copy of the table (it holds the layers' device pointers: build it when src0 / src1 /
  *                                  dy / dw are final); the caller copies it to device memory
- *   stp_wgrad_group_partial / _reduce : the two launches; host_table (header read on the host) and its device copy */
+ *   stp_wgrad_group_partial / _reduce : the two launches; host_table (header read on the host) and its device copy
+ * Layers may carry src_bn_* (C1 == 0, directly read src0): the group then runs the kernel instance that normalises those layers' halo
+ * tiles in LDS (per-layer switch; header word 14 of the table says which instance the group uses). */
 int stp_wgrad_group_class(const stp_wgrad_params* p);
 size_t stp_wgrad_group_table_bytes(const stp_wgrad_params* const* layers, int32_t n);
 size_t stp_wgrad_group_workspace_bytes(const stp_wgrad_params* const* layers, int32_t n);

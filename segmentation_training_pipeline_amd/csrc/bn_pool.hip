@@ -948,18 +948,32 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
                                                                 float* mm, float* mv, const float* gamma, const float* beta, int relu) {
   __shared__ float tab[2][BNF_SLAB];
   const int slab = blockIdx.x / chunks, chunk = blockIdx.x - slab * chunks, c0 = slab * BNF_SLAB;
+  const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int64_t per = (rows + chunks - 1) / chunks, ra = (int64_t)chunk * per, rb = ra + per < rows ? ra + per : rows;
+  const size_t col = (size_t)c0 + cg * 8;
+  // The first four rows of this thread are requested BEFORE the partial sums are reduced (round 4): they do not depend on the
+  // statistics, and with ~8 rows per thread the launch is two dependent memory round trips long (sums, then rows) - this makes it one.
+  int64_t r = ra + r0;
+  const bool pre = r + 96 < rb;
+  u32x4 p0 = {0u, 0u, 0u, 0u}, p1 = p0, p2 = p0, p3 = p0;
+  if (pre) {
+    p0 = *reinterpret_cast<const u32x4*>(x + (size_t)r * C + col); p1 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 32) * C + col);
+    p2 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 64) * C + col); p3 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 96) * C + col);
+  }
   {
+    const int cc = c0 + (threadIdx.x >> 2);
+    const float gam = gamma ? gamma[cc] : 1.f, bet = beta ? beta[cc] : 0.f;     // (requested with the rows: independent of the sums)
     double s, q;
     bnf_slab_sums(partial, tiles, C, c0, s, q);
     if ((threadIdx.x & 3) == 0) {
-      const int c = c0 + (threadIdx.x >> 2);
+      const int c = cc;
       const double m = s * inv_rows;
       double var = q * inv_rows - m * m;
       if (var < 0.0) var = 0.0;
       const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
-      const float k = gamma ? rf * gamma[c] : rf;
+      const float k = gamma ? rf * gam : rf;
       tab[0][threadIdx.x >> 2] = k;
-      tab[1][threadIdx.x >> 2] = (beta ? beta[c] : 0.f) - mf * k;
+      tab[1][threadIdx.x >> 2] = bet - mf * k;
       if (chunk == 0) {
         mean[c] = mf;
         rstd[c] = rf;
@@ -969,23 +983,26 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
     }
   }
   __syncthreads();
-  const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = tab[0][cg * 8 + e]; sh[e] = tab[1][cg * 8 + e]; }
-  const int64_t per = (rows + chunks - 1) / chunks, ra = (int64_t)chunk * per, rb = ra + per < rows ? ra + per : rows;
-  const size_t col = (size_t)c0 + cg * 8;
-  auto one = [&](const u32x4 r) {
+  auto one = [&](const u32x4 rr) {
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float lo = bn_act(bn_affine(h16lo_to_f32(r[e]), sc[2 * e], sh[2 * e]), relu);
-      const float hi = bn_act(bn_affine(h16hi_to_f32(r[e]), sc[2 * e + 1], sh[2 * e + 1]), relu);
+      const float lo = bn_act(bn_affine(h16lo_to_f32(rr[e]), sc[2 * e], sh[2 * e]), relu);
+      const float hi = bn_act(bn_affine(h16hi_to_f32(rr[e]), sc[2 * e + 1], sh[2 * e + 1]), relu);
       o[e] = pack_bf16x2(lo, hi);
     }
     return o;
   };
-  int64_t r = ra + r0;
+  if (pre) {
+    *reinterpret_cast<u32x4*>(y + (size_t)r * C + col) = one(p0);
+    *reinterpret_cast<u32x4*>(y + (size_t)(r + 32) * C + col) = one(p1);
+    *reinterpret_cast<u32x4*>(y + (size_t)(r + 64) * C + col) = one(p2);
+    *reinterpret_cast<u32x4*>(y + (size_t)(r + 96) * C + col) = one(p3);
+    r += 128;
+  }
   for (; r + 96 < rb; r += 128) {       // four rows in flight per thread
     const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + (size_t)r * C + col), v1 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 32) * C + col);
     const u32x4 v2 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 64) * C + col), v3 = *reinterpret_cast<const u32x4*>(x + (size_t)(r + 96) * C + col);
@@ -1018,18 +1035,40 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(const float*
                                                                     int chunks, float inv_rows, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, float* dgamma,
                                                                     float* dbeta) {
-  __shared__ float tab[4][BNF_SLAB];      // mean, rstd, scale * ... see below
+  __shared__ float tab[5][BNF_SLAB];      // sum g / M, sum g xhat / M, mean, rstd, rstd * gamma
   const int slab = blockIdx.x / chunks, chunk = blockIdx.x - slab * chunks, c0 = slab * BNF_SLAB;
+  const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int64_t per = (rows + chunks - 1) / chunks, ra = (int64_t)chunk * per, rb = ra + per < rows ? ra + per : rows;
+  const size_t col = (size_t)c0 + cg * 8;
+  // (the first FOUR rows of x / g / dadd are requested before the partial sums are reduced: see bn_finalize_apply_kernel; a thread
+  //  owns ~8 rows, so the launch is two batches of loads deep instead of four)
+  int64_t r = ra + r0;
+  const bool pre = r + 96 < rb;
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  u32x4 px[4] = {z4, z4, z4, z4}, pg[4] = {z4, z4, z4, z4}, pd[4] = {z4, z4, z4, z4};
+  if (pre) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t o = (size_t)(r + 32 * k) * C + col;
+      px[k] = *reinterpret_cast<const u32x4*>(x + o);
+      pg[k] = *reinterpret_cast<const u32x4*>(g + o);
+      if (dadd) pd[k] = *reinterpret_cast<const u32x4*>(dadd + o);
+    }
+  }
   {
+    const int cl = threadIdx.x >> 2, c = c0 + cl;
+    // per-channel constants requested with the rows (independent of the sums); scale = rstd * gamma goes through the table as well -
+    // read from global memory after the barrier, the 8 gamma values of a thread were 8 dependent round trips in every workgroup
+    const float mc = mean[c], rc = rstd[c], gc = gamma ? gamma[c] : 1.f;
     double s, q;
     bnf_slab_sums(partial, tiles, C, c0, s, q);
     if ((threadIdx.x & 3) == 0) {
-      const int cl = threadIdx.x >> 2, c = c0 + cl;
       const float sf = (float)s, qf = (float)q;
       tab[0][cl] = sf * inv_rows;
       tab[1][cl] = qf * inv_rows;
-      tab[2][cl] = mean[c];
-      tab[3][cl] = rstd[c];
+      tab[2][cl] = mc;
+      tab[3][cl] = rc;
+      tab[4][cl] = gamma ? rc * gc : rc;
       if (chunk == 0) {
         if (dbeta) dbeta[c] = sf;
         if (dgamma) dgamma[c] = qf;
@@ -1037,41 +1076,48 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(const float*
     }
   }
   __syncthreads();
-  const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
   float k1[8], k2[8], mu[8], rs[8], sc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     k1[e] = tab[0][cg * 8 + e]; k2[e] = tab[1][cg * 8 + e]; mu[e] = tab[2][cg * 8 + e]; rs[e] = tab[3][cg * 8 + e];
-    sc[e] = gamma ? rs[e] * gamma[c0 + cg * 8 + e] : rs[e];
+    sc[e] = tab[4][cg * 8 + e];
   }
-  const int64_t per = (rows + chunks - 1) / chunks, ra = (int64_t)chunk * per, rb = ra + per < rows ? ra + per : rows;
-  const size_t col = (size_t)c0 + cg * 8;
-  auto one = [&](size_t off, const float (&xv)[8], const float (&gv)[8], const float (&dv)[8]) {
-    float o[8];
+  // same arithmetic per element as before (fp32, same order): dx = scale * (g - k1 - xhat * k2) (+ dadd)
+  auto one = [&](size_t off, const u32x4 xr, const u32x4 gr, const u32x4 dr) {
+    u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float xh = (xv[e] - mu[e]) * rs[e];
-      o[e] = sc[e] * (gv[e] - k1[e] - xh * k2[e]);
-      if (dadd) o[e] += dv[e];
+    for (int e = 0; e < 4; ++e) {
+      const float xl = h16lo_to_f32(xr[e]), xh_ = h16hi_to_f32(xr[e]);
+      const float gl = h16lo_to_f32(gr[e]), gh = h16hi_to_f32(gr[e]);
+      const float xhl = (xl - mu[2 * e]) * rs[2 * e], xhh = (xh_ - mu[2 * e + 1]) * rs[2 * e + 1];
+      float ol = sc[2 * e] * (gl - k1[2 * e] - xhl * k2[2 * e]), oh = sc[2 * e + 1] * (gh - k1[2 * e + 1] - xhh * k2[2 * e + 1]);
+      if (dadd) { ol += h16lo_to_f32(dr[e]); oh += h16hi_to_f32(dr[e]); }
+      o[e] = pack_bf16x2(ol, oh);
     }
-    stv<bf16_t, 8>(dx + off, o);
+    *reinterpret_cast<u32x4*>(dx + off) = o;
   };
-  int64_t r = ra + r0;
-  for (; r + 32 < rb; r += 64) {          // two rows in flight per thread
-    const size_t o0 = (size_t)r * C + col, o1 = (size_t)(r + 32) * C + col;
-    float x0[8], g0[8], d0[8], x1[8], g1[8], d1[8];
-    ldv<bf16_t, 8>(x + o0, x0); ldv<bf16_t, 8>(x + o1, x1);
-    ldv<bf16_t, 8>(g + o0, g0); ldv<bf16_t, 8>(g + o1, g1);
-    if (dadd) { ldv<bf16_t, 8>(dadd + o0, d0); ldv<bf16_t, 8>(dadd + o1, d1); }
-    one(o0, x0, g0, d0);
-    one(o1, x1, g1, d1);
+  if (pre) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) one((size_t)(r + 32 * k) * C + col, px[k], pg[k], pd[k]);
+    r += 128;
+  }
+  for (; r + 96 < rb; r += 128) {          // four rows in flight per thread
+    u32x4 vx[4], vg[4], vd[4] = {z4, z4, z4, z4};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t o = (size_t)(r + 32 * k) * C + col;
+      vx[k] = *reinterpret_cast<const u32x4*>(x + o);
+      vg[k] = *reinterpret_cast<const u32x4*>(g + o);
+      if (dadd) vd[k] = *reinterpret_cast<const u32x4*>(dadd + o);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) one((size_t)(r + 32 * k) * C + col, vx[k], vg[k], vd[k]);
   }
   for (; r < rb; r += 32) {
-    const size_t o0 = (size_t)r * C + col;
-    float x0[8], g0[8], d0[8];
-    ldv<bf16_t, 8>(x + o0, x0); ldv<bf16_t, 8>(g + o0, g0);
-    if (dadd) ldv<bf16_t, 8>(dadd + o0, d0);
-    one(o0, x0, g0, d0);
+    const size_t o = (size_t)r * C + col;
+    const u32x4 vx = *reinterpret_cast<const u32x4*>(x + o), vg = *reinterpret_cast<const u32x4*>(g + o);
+    const u32x4 vd = dadd ? *reinterpret_cast<const u32x4*>(dadd + o) : z4;
+    one(o, vx, vg, vd);
   }
 }
 

@@ -485,7 +485,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false>(a); }
 template <int TH, int BM, int WM, int WN, int EP>
-__global__ __launch_bounds__(512) void conv_halo_pbn_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, true>(a); }
+__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_pbn_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, true>(a); }
 
 // ================================================================================================ host side
 struct HaloCfg { int th, bm; };

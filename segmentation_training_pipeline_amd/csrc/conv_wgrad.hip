@@ -814,8 +814,9 @@ struct WgGroupHeader {
   int magic, bm, n_layers, n_segs, n_wg, n_tiles;
   int off_layers, off_segs, off_first, off_tiles;      // byte offsets from the start of the table
   int total_bytes, off_slots;
-  int reduce_lanes, xcd, pad1, pad2;                    // lanes per element of the reduce launch (1 or 4); xcd: contiguous line runs per XCD
-};
+  int reduce_lanes, xcd, pbn, taps9;                    // lanes per element of the reduce launch (1 or 4); xcd: contiguous line runs per XCD;
+};                                                      // pbn: some layer normalises its src0 in LDS (fused producer BatchNormalization);
+                                                        // taps9: all-taps tiles (conv_wgrad_taps9_group_kernel) instead of row-of-taps tiles
 #define WG_GROUP_MAGIC 0x57474733
 
 // dword-wise copy of a descriptor through the constant address space (scalar, invariant loads)
@@ -828,8 +829,10 @@ template <typename T> __device__ __forceinline__ void load_constant(T& dst, cons
   for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = q[i];
 }
 
-template <int BM, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256) void conv_wgrad_row_group_kernel(const char* __restrict__ table, f32x4* __restrict__ slabs) {
+// PBN: the instance for groups in which some layer reads the tensor BEFORE a BatchNormalization(+activation) and normalises its halo
+// tile in LDS (per layer: WgradArgs::pbn.mean != nullptr) - the stp_bn_apply launch of that BatchNormalization is gone (graph.py)
+template <int BM, int WM, int WN, int STAGES, bool PBN>
+__device__ __forceinline__ void conv_wgrad_row_group_body(const char* __restrict__ table, f32x4* __restrict__ slabs) {
   const WgGroupHeader* const hd = reinterpret_cast<const WgGroupHeader*>(table);
   const WgLayer* const layers = reinterpret_cast<const WgLayer*>(table + hd->off_layers);
   const WgSeg* const segs = reinterpret_cast<const WgSeg*>(table + hd->off_segs);
@@ -859,8 +862,286 @@ __global__ __launch_bounds__(256) void conv_wgrad_row_group_kernel(const char* _
     WgradArgs a;
     load_constant(a, &layers[sg.layer].a);
     if (s != s0) __syncthreads();        // the previous segment's last fragment reads precede this segment's first LDS-DMA
-    conv_wgrad_row_body<BM, WM, WN, STAGES, false>(a, sg.tile, sg.step0, sg.step1, slabs + (size_t)sg.slot * (BM * 192 / 4));
+    conv_wgrad_row_body<BM, WM, WN, STAGES, PBN>(a, sg.tile, sg.step0, sg.step1, slabs + (size_t)sg.slot * (BM * 192 / 4));
   }
+}
+template <int BM, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_row_group_kernel(const char* __restrict__ table, f32x4* __restrict__ slabs) {
+  conv_wgrad_row_group_body<BM, WM, WN, STAGES, false>(table, slabs);
+}
+template <int BM, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_row_group_pbn_kernel(const char* __restrict__ table, f32x4* __restrict__ slabs) {
+  conv_wgrad_row_group_body<BM, WM, WN, STAGES, true>(table, slabs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ALL-TAPS tile (round 4): BM output channels x 576 columns = the NINE taps of one 64-channel input block.
+// The row-of-taps tile above (BM x 192: one kernel row) re-stages dY for each of the three kernel rows and the same input pixels
+// three times with a one-row shift: 25 KB through L2 -> LDS per 3.1 MFLOP, and the 24-96 tiles over a pixel range each fetch their
+// own copy (profiles/r03final_pmc_traffic.json: 4.85x the algorithmic bytes reach the fabric; the kernel waits on memory 42 % of
+// its time).  Here a step stages dY once (64 pixels x BM channels) and ONE halo of the input block - (rows + 2) image rows of
+// (seg + 2) pixels - for all nine taps: 43.5 KB (seg = 64) / 33 KB (seg = 16, 32) per 9.4 MFLOP = 1.7-2.3x fewer staged bytes per
+// FLOP, and a third of the tiles per pixel range.
+//   * 512 threads = 8 waves as 2 (output channels: BM / 2 each) x 4 (the four 16-channel quarters of the input block): a wave's
+//     columns are (tap 0..8) x (its 16 channels) - the swizzle slot of its B reads is then a LANE CONSTANT and the tap is
+//       kw -> one of 3 address registers per pixel group (the halo row shifts by one),  kh -> an INSTRUCTION IMMEDIATE:
+//     the halo row pitch is padded to a multiple of 8 rows (hwp = 24 / 40 / 72 for seg = 16 / 32 / 64), so kh * hwp never moves the
+//     swizzle key ((row >> 1) & 3).  12 + 4 * TM address registers serve all 36 + 4 * TM transpose reads of a step.
+//   * SEG (pixels of an image row per step: min(64, Wo)) is a template parameter: pitch, immediates and the pixel -> halo row map
+//     are compile-time.
+//   * accumulators TM x 9 tiles of 16 x 16 (144 registers at BM = 128), one workgroup per CU, 3-stage LDS-DMA ring
+//     (3 x 48 KB at BM = 128 / seg = 64), one barrier per step; every wave issues the same NVA + NPASS LDS-DMA instructions per step
+//     (rows past the halo are fetched out of bounds = zeros), so the counted vmcnt is a compile-time constant.
+//   * partial slab per segment: fragment-major [wave][i][tap][lane] float4, summed in line order by wgrad_group9_reduce_kernel.
+// Eligibility = the row-of-taps rules (3x3 / s1 / p1, 64-channel blocks, uniform-row maps), no fused producer BatchNormalization.
+template <int SEG> struct Taps9Geo {
+  static constexpr int ROWS = 64 / SEG, HW = SEG + 2, HWP = (HW + 7) / 8 * 8, HR = (ROWS + 2) * HWP;
+  static constexpr int NPASS = (HR + 63) / 64, LROWS = NPASS * 64;
+};
+
+template <int BM, int SEG, int STAGES>
+__device__ __forceinline__ void conv_wgrad_taps9_body(const WgradArgs& a, const int t, const int step0, const int step1, f32x4* const out_tile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef Taps9Geo<SEG> G;
+  constexpr int SZ = 2, PK = 64;
+  constexpr int TM = BM / 2 / 16, TN = 9;
+  constexpr int ROWA = BM * SZ, ROWB = 128;
+  constexpr int VPRA = ROWA / 16, RPA = 512 / VPRA, NVA = (PK + RPA - 1) / RPA;
+  constexpr int ABYTES = (PK * ROWA > NVA * 512 * 16) ? PK * ROWA : NVA * 512 * 16;     // (BM = 32: the single pass covers 128 rows)
+  constexpr int STAGE = ABYTES + G::LROWS * ROWB;
+  constexpr int L = NVA + G::NPASS;                               // LDS-DMA instructions per thread per step (every wave)
+  static_assert(BM == 128 || BM == 64 || BM == 32, "output-channel tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int tile_m = t % a.ntile_m, cib = t / a.ntile_m;         // cib: 64-channel block of the CONCATENATED input
+  const bool first = cib * 64 < a.C0;                            // wave-uniform: which source holds this block
+  const int cs = first ? a.C0 : a.C1, cb_src = first ? cib : cib - (a.C0 >> 6);
+  const int sh = (first && a.mode == STP_SRC_NEAREST2X) ? 1 : 0;
+  const int Hs = first ? a.Hs0 : a.Hv, Ws = first ? a.Ws0 : a.Wv;
+  const int cout0 = tile_m * BM;
+
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.bytesdy, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? a.src0 : a.src1), 0, first ? a.bytes0 : a.bytes1, 0x00020000);
+
+  // ---- LDS-DMA constants.  A (dY): pass i = pixel rows i * RPA + tid / VPRA.  B: LDS halo row h = pass * 64 + tid / 8 -> image row
+  // h / HWP - 1, column h % HWP - 1 relative to the step's first pixel (pad columns and rows past the halo: out of bounds)
+  const int rowA0 = tid / VPRA;
+  const int colA = (tile_addr<ROWA>(rowA0, (tid % VPRA) * 16) - rowA0 * ROWA) / SZ;
+  const bool coA_ok = (cout0 + colA) < a.Cout;
+  uint32_t rowa[NVA];
+#pragma unroll
+  for (int i = 0; i < NVA; ++i)
+    rowa[i] = (rowA0 + i * RPA) < PK ? ((uint32_t)(rowA0 + i * RPA) * (uint32_t)a.Cout + (uint32_t)(cout0 + colA)) * SZ : STP_OOB;
+  const int hb0 = tid >> 3;
+  const uint32_t colB = (uint32_t)(tile_addr<ROWB>(hb0, (tid & 7) * 16) - hb0 * ROWB);    // logical byte column held by this slot (hb0 + 64 p: same key)
+  int hr[G::NPASS], hx[G::NPASS];
+#pragma unroll
+  for (int i = 0; i < G::NPASS; ++i) {
+    const int h = hb0 + i * 64;
+    const int r = h / G::HWP, c = h - r * G::HWP;
+    const bool used = r < G::ROWS + 2 && c < G::HW;
+    hr[i] = used ? r - 1 : -0x4000;
+    hx[i] = c - 1;
+  }
+  const uint32_t pixb = (uint32_t)cs * SZ, imgb = (uint32_t)Hs * (uint32_t)Ws * pixb, cbyte = (uint32_t)cb_src * 128u + colB;
+
+  auto issue_tile = [&](int step, int buf) {
+    const int p0 = step * PK;
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + ABYTES;
+    const uint32_t n = fdiv((uint32_t)p0, a.divHoWo);
+    const uint32_t rem = (uint32_t)p0 - n * (uint32_t)a.HoWo;
+    const uint32_t ho0 = fdiv(rem, a.divWo);
+    const uint32_t wo0 = rem - ho0 * (uint32_t)a.Wo;
+    const uint32_t abase = (uint32_t)p0 * (uint32_t)a.Cout * SZ;
+    const uint32_t nb = n * imgb + cbyte;
+#pragma unroll
+    for (int i = 0; i < NVA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sa + (i * 512 + wave * 64) * 16), 16,
+                                               (coA_ok && rowa[i] != STP_OOB) ? abase + rowa[i] : STP_OOB, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G::NPASS; ++i) {
+      const int hv = (int)ho0 + hr[i], wv = (int)wo0 + hx[i];
+      const bool ok = (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+      const uint32_t off = nb + ((uint32_t)(hv >> sh) * (uint32_t)Ws + (uint32_t)(wv >> sh)) * pixb;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(sb + (i * 512 + wave * 64) * 16), 16,
+                                               ok ? off : STP_OOB, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses (bytes from the stage base).  Pixel q of the step (row q / SEG, column q % SEG); a 16-lane group reads 4
+  // consecutive pixels: lane -> pixel (lr >> 2), 8-byte quad (lr & 3) of the 32-byte channel block.
+  const int qb = (lr & 3) * 8;
+  int aaddr[4][TM], baddr[4][3];       // [pixel group e = chunk * 2 + half][channel block] / [e][kw]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = e * 16 + lg * 4 + (lr >> 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aaddr[e][i] = tile_addr<ROWA>(q, (wm * (BM / 2) + i * 16) * SZ + qb);
+    const int r = q / SEG, c = q - r * SEG;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) baddr[e][kw] = ABYTES + tile_addr<ROWB>(r * G::HWP + c + kw, wn * 32 + qb);
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // A step = 2 chunks of 32 pixels x 3 kernel rows = 6 groups of 3 taps x TM MFMAs.  The B fragments of group g + 1 are requested
+  // BEFORE the MFMAs of group g (two sets of 12 registers, pinned by sched_barrier: left alone, the scheduler hoists every read of
+  // the step to its top - 52 fragment registers on top of 144 accumulators + 28 addresses = 36 spills at BM = 128).
+  auto read_a = [&](const char* st, int c, u32x4 (&fa)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + aaddr[2 * c][i]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + aaddr[2 * c + 1][i]));
+      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
+    }
+  };
+  auto read_b = [&](const char* st, int c, int kh, u32x4 (&fb)[3]) {
+    constexpr int KHB = G::HWP * ROWB;                       // bytes between kernel rows: a multiple of 8 LDS rows (same swizzle key)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + baddr[2 * c][kw] + kh * KHB));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + baddr[2 * c + 1][kw] + kh * KHB));
+      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      fb[kw] = u32x4{l2.x, l2.y, h2.x, h2.y};
+    }
+  };
+  auto compute = [&](const char* st) {
+    u32x4 fa[TM], fb[2][3];
+    read_a(st, 0, fa);
+    read_b(st, 0, 0, fb[0]);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const int c = g / 3, kh = g - c * 3;
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < 6) read_b(st, (g + 1) / 3, (g + 1) % 3, fb[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[i][kh * 3 + kw] = mfma16_16x16x32(fa[i], fb[g & 1][kw], acc[i][kh * 3 + kw]);
+      if (g == 2) {                                           // the A fragments of the second chunk, behind the last MFMAs that read the first
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(st, 1, fa);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nst = step1 - step0;
+#pragma unroll
+  for (int q = 0; q < STAGES - 1; ++q)
+    if (q < nst) issue_tile(step0 + q, q);
+  int buf = 0, nbuf = STAGES - 1;
+  for (int st = 0; st < nst; ++st) {
+    const int ahead = nst - 1 - st;      // tiles after this one
+    if (STAGES >= 3 && ahead >= STAGES - 2) wait_vmcnt<(STAGES - 2) * L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (st + STAGES - 1 < nst) issue_tile(step0 + st + STAGES - 1, nbuf);
+    compute(smem + buf * STAGE);
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
+  }
+
+  // ---- slab, fragment-major: [wave][i][tap][lane] float4 = the lane's 4 output channels of one column (taps9_slab_decode)
+  f32x4* out = out_tile + (size_t)wave * (TM * TN * 64) + lane;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) out[(i * TN + j) * 64] = acc[i][j];
+#endif
+}
+
+// element e (float4) of an all-taps tile's slab -> first of its 4 output channels (relative to the tile), tap and input channel (0..63)
+template <int BM> __device__ __forceinline__ void taps9_slab_decode(int e, int& co, int& tap, int& ci) {
+  constexpr int TM = BM / 2 / 16;
+  const int lane = e & 63;
+  const int q = e >> 6;
+  const int ij = q % (TM * 9), wave = q / (TM * 9);
+  const int i = ij / 9;
+  tap = ij - i * 9;
+  co = (wave >> 2) * (BM / 2) + i * 16 + (lane >> 4) * 4;
+  ci = (wave & 3) * 16 + (lane & 15);
+}
+
+template <int BM, int STAGES>
+__global__ __launch_bounds__(512) void conv_wgrad_taps9_group_kernel(const char* __restrict__ table, f32x4* __restrict__ slabs) {
+  const WgGroupHeader* const hd = reinterpret_cast<const WgGroupHeader*>(table);
+  const WgLayer* const layers = reinterpret_cast<const WgLayer*>(table + hd->off_layers);
+  const WgSeg* const segs = reinterpret_cast<const WgSeg*>(table + hd->off_segs);
+  const int* const first = reinterpret_cast<const int*>(table + hd->off_first);
+  const int w = hd->xcd == 1 ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int s0 = __builtin_amdgcn_readfirstlane(first[w]), s1 = __builtin_amdgcn_readfirstlane(first[w + 1]);
+  for (int s = s0; s < s1; ++s) {
+    WgSeg sg;
+    load_constant(sg, segs + s);
+    WgradArgs a;
+    load_constant(a, &layers[sg.layer].a);
+    if (s != s0) __syncthreads();        // the previous segment's last fragment reads precede this segment's first LDS-DMA
+    f32x4* const out = slabs + (size_t)sg.slot * (BM * 576 / 4);
+    // a group mixes feature-map widths (decoder + encoder stages): the segment's layer picks the body (wave-uniform)
+    if (a.Wo >= 64) conv_wgrad_taps9_body<BM, 64, STAGES>(a, sg.tile, sg.step0, sg.step1, out);
+    else if (a.Wo == 32) conv_wgrad_taps9_body<BM, 32, STAGES>(a, sg.tile, sg.step0, sg.step1, out);
+    else conv_wgrad_taps9_body<BM, 16, STAGES>(a, sg.tile, sg.step0, sg.step1, out);
+  }
+}
+
+template <int BM, int SL>
+__global__ __launch_bounds__(256) void wgrad_group9_reduce_kernel(const char* __restrict__ table, const f32x4* __restrict__ slabs) {
+  constexpr int PER = BM * 576 / 4, EPB = 256 / SL, BPT = PER / EPB;
+  static_assert(PER % EPB == 0, "whole blocks per tile");
+  __shared__ f32x4 shm[SL][EPB];
+  const WgGroupHeader* const hd = reinterpret_cast<const WgGroupHeader*>(table);
+  const WgLayer* const layers = reinterpret_cast<const WgLayer*>(table + hd->off_layers);
+  const int* const slot_list = reinterpret_cast<const int*>(table + hd->off_slots);
+  const WgTile tl = reinterpret_cast<const WgTile*>(table + hd->off_tiles)[blockIdx.x / BPT];
+  const int ev = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+  const int e = (blockIdx.x % BPT) * EPB + ev;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  {
+    int k = sl;
+    for (; k + 3 * SL < tl.nslots; k += 4 * SL) {
+      const f32x4 a0 = slabs[(size_t)slot_list[tl.list0 + k] * PER + e], a1 = slabs[(size_t)slot_list[tl.list0 + k + SL] * PER + e];
+      const f32x4 a2 = slabs[(size_t)slot_list[tl.list0 + k + 2 * SL] * PER + e], a3 = slabs[(size_t)slot_list[tl.list0 + k + 3 * SL] * PER + e];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < tl.nslots; k += SL) s += slabs[(size_t)slot_list[tl.list0 + k] * PER + e];
+  }
+  if (SL > 1) {
+    shm[sl][ev] = s;
+    __syncthreads();
+#pragma unroll
+    for (int w = SL / 2; w > 0; w >>= 1) {
+      if (sl < w) shm[sl][ev] += shm[sl + w][ev];
+      __syncthreads();
+    }
+    s = shm[0][ev];
+    if (sl != 0) return;
+  }
+  const WgLayer& L = layers[tl.layer];
+  int co, tap, ci;
+  taps9_slab_decode<BM>(e, co, tap, ci);
+  const int tile_m = tl.t % L.a.ntile_m, cib = tl.t / L.a.ntile_m;
+  const int kc = tap * L.a.Ctot + cib * 64 + ci;
+  co += tile_m * BM;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (co + r < L.a.Cout) {
+      float* d = L.dw + (size_t)(co + r) * L.a.K + kc;
+      *d = L.accumulate ? *d + s[r] : s[r];
+    }
 }
 
 // sum of a tile's partial slabs in line order, scattered into dW (the element decode of wgrad_reduce_row_kernel).  SL lanes walk the
@@ -1255,7 +1536,7 @@ static int wgrad_fill(const stp_wgrad_params* p, void* workspace, size_t workspa
 // ---- grouped row-of-taps launch: host side -----------------------------------------------------------------------------------
 // class of a layer = the output-channel tile of its kernel instance (layers of one group share it); 0 = not eligible
 static int wg_group_bm(const stp_wgrad_params* p) {
-  if (!p || !wgrad_row_eligible(p) || p->src_bn_mean || p->splits != 0) return 0;
+  if (!p || !wgrad_row_eligible(p) || p->splits != 0) return 0;      // (a fused producer BatchNormalization: wgrad_row_eligible's rules)
   const int64_t lim = 1ll << 31;
   const int64_t P = (int64_t)p->N * p->Ho * p->Wo;
   if ((int64_t)p->N * p->Hs0 * p->Ws0 * p->C0 * 2 >= lim || (int64_t)p->N * p->Hv * p->Wv * p->C1 * 2 >= lim || P * p->Cout * 2 >= lim) return 0;
@@ -1265,6 +1546,7 @@ extern "C" int stp_wgrad_group_class(const stp_wgrad_params* p) { return wg_grou
 
 struct WgGroupPlan {
   int bm = 0, max_slots_per_tile = 1;
+  bool taps9 = false;      // all-taps tiles (BM x 576, one workgroup per CU) instead of row-of-taps tiles (BM x 192)
   std::vector<int> ntile_m, ntile_n, nsteps, tile0;
   std::vector<WgSeg> segs;
   std::vector<int> first;
@@ -1272,11 +1554,22 @@ struct WgGroupPlan {
   std::vector<int> slot_list;
 };
 
-static int wg_group_slots(int bm) {
+static int wg_group_slots(int bm, bool taps9) {
   static const int cus = device_cu_count();
   static const int target = getenv("STP_WGRAD_GROUP_SLOTS") ? atoi(getenv("STP_WGRAD_GROUP_SLOTS")) : 0;
   if (target > 0) return target;
+  if (taps9) return cus;                                 // 512 threads, 120-144 KB of LDS: one workgroup per CU
   return cus * (bm == 128 ? 2 : bm == 64 ? 3 : 4);     // co-resident workgroups: 77 KB of LDS / 224 registers at 128 channels, 52 KB / 144 and 40 KB / 114 below
+}
+// all-taps tiles for a group: every layer on a 16 / 32 / >= 64 pixel wide map (the kernel's three bodies), none with a fused producer
+// BatchNormalization (that stays on the row-of-taps instance).  OPT-IN (STP_WGRAD_TAPS9=1): measured slower than the row-of-taps
+// groups on the U-Net/ResNet34 step (profiles/r04d_*: 7.39 vs 7.08 ms) - see DESIGN.md 3.1a.
+static bool wg_group_taps9(const stp_wgrad_params* const* L, int n) {
+  static const bool on = getenv("STP_WGRAD_TAPS9") && atoi(getenv("STP_WGRAD_TAPS9")) != 0;
+  if (!on) return false;
+  for (int l = 0; l < n; ++l)
+    if (L[l]->src_bn_mean || !(L[l]->Wo == 16 || L[l]->Wo == 32 || L[l]->Wo % 64 == 0)) return false;
+  return true;
 }
 
 // The line: layer-major; inside a layer RANGE-major (a range = ~one workgroup chunk of steps), tile-minor - the tiles of a layer over
@@ -1287,17 +1580,18 @@ static int wg_group_plan(const stp_wgrad_params* const* L, int n, WgGroupPlan& g
   if (!L || n <= 0) return STP_E_BADARG;
   g.bm = wg_group_bm(L[0]);
   if (!g.bm) return STP_E_BADARG;
+  g.taps9 = wg_group_taps9(L, n);
   int64_t total = 0;
   int ntiles = 0;
   for (int l = 0; l < n; ++l) {
     if (wg_group_bm(L[l]) != g.bm || !L[l]->src0 || !L[l]->dy || !L[l]->dw) return STP_E_BADARG;
-    const int tm = ceil_div(L[l]->Cout, g.bm), tn = 3 * ((L[l]->C0 + L[l]->C1) / 64);
+    const int tm = ceil_div(L[l]->Cout, g.bm), tn = (g.taps9 ? 1 : 3) * ((L[l]->C0 + L[l]->C1) / 64);
     const int ns = (int)((int64_t)L[l]->N * L[l]->Ho * L[l]->Wo / 64);
     g.ntile_m.push_back(tm); g.ntile_n.push_back(tn); g.nsteps.push_back(ns); g.tile0.push_back(ntiles);
     ntiles += tm * tn;
     total += (int64_t)tm * tn * ns;
   }
-  const int slots = wg_group_slots(g.bm);
+  const int slots = wg_group_slots(g.bm, g.taps9);
   const int MINSEG = 8;       // no segment shorter than this unless its item is (a 3-stage pipeline fill + a slab per segment)
   int64_t chunk = (total + slots - 1) / slots;
   if (chunk < 2 * MINSEG) chunk = 2 * MINSEG;
@@ -1356,7 +1650,7 @@ extern "C" size_t stp_wgrad_group_table_bytes(const stp_wgrad_params* const* lay
 extern "C" size_t stp_wgrad_group_workspace_bytes(const stp_wgrad_params* const* layers, int32_t n) {
   WgGroupPlan g;
   if (wg_group_plan(layers, n, g) != STP_OK) return 0;
-  return g.segs.size() * (size_t)g.bm * 192 * sizeof(float);
+  return g.segs.size() * (size_t)g.bm * (g.taps9 ? 576 : 192) * sizeof(float);
 }
 
 // Fills `host_table` (stp_wgrad_group_table_bytes): the caller copies it to device memory and passes both to the launches
@@ -1391,6 +1685,9 @@ extern "C" int stp_wgrad_group_build(const stp_wgrad_params* const* layers, int3
     }
     hd.xcd = xcd_env >= 0 ? xcd_env : (2 * wide > all ? 0 : 1);
   }
+  for (int l = 0; l < n; ++l)
+    if (layers[l]->src_bn_mean) hd.pbn = 1;
+  hd.taps9 = g.taps9 ? 1 : 0;
   memset(tb, 0, off);
   memcpy(tb, &hd, sizeof(hd));
   for (int l = 0; l < n; ++l) {
@@ -1421,17 +1718,39 @@ static const WgGroupHeader* wg_group_header(const void* host_table) {
 extern "C" int stp_wgrad_group_partial(const void* host_table, const void* dev_table, void* workspace, size_t workspace_bytes, void* stream) {
   const WgGroupHeader* hd = wg_group_header(host_table);
   if (!hd || !dev_table || !workspace) return STP_E_BADARG;
-  if ((size_t)hd->n_segs * hd->bm * 192 * sizeof(float) > workspace_bytes) return STP_E_WORKSPACE;
+  if ((size_t)hd->n_segs * hd->bm * (hd->taps9 ? 576 : 192) * sizeof(float) > workspace_bytes) return STP_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)3 * (64 * hd->bm * 2 + 72 * 128);
-  static bool attr128 = false, attr64 = false, attr32 = false;
-#define STP_GROUP_LAUNCH(BM_, WM_, WN_, FLAG_)                                                                                      \
+  if (hd->taps9) {
+    // 3 stages x (dY tile + 256 halo rows of 128 bytes - the seg = 64 geometry, the largest)
+    const size_t lds9 = (size_t)3 * ((hd->bm == 128 ? 16384 : 8192) + 256 * 128);
+    static bool a128 = false, a64 = false, a32 = false;
+#define STP_GROUP9_LAUNCH(BM_, FLAG_)                                                                                               \
   do {                                                                                                                              \
-    auto kern = conv_wgrad_row_group_kernel<BM_, WM_, WN_, 3>;                                                                      \
-    if (lds > 64 * 1024 && !FLAG_) {                                                                                                \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+    auto kern = conv_wgrad_taps9_group_kernel<BM_, 3>;                                                                              \
+    if (!FLAG_) {                                                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9) != hipSuccess) \
         return STP_E_LAUNCH;                                                                                                        \
       FLAG_ = true;                                                                                                                 \
+    }                                                                                                                               \
+    hipLaunchKernelGGL(kern, dim3(hd->n_wg), dim3(512), lds9, s, (const char*)dev_table, (f32x4*)workspace);                        \
+  } while (0)
+    if (hd->bm == 128) STP_GROUP9_LAUNCH(128, a128);
+    else if (hd->bm == 64) STP_GROUP9_LAUNCH(64, a64);
+    else STP_GROUP9_LAUNCH(32, a32);
+#undef STP_GROUP9_LAUNCH
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
+  const size_t lds = (size_t)3 * (64 * hd->bm * 2 + 72 * 128);
+  static bool attr128 = false, attr64 = false, attr32 = false, attr128p = false, attr64p = false, attr32p = false;
+#define STP_GROUP_LAUNCH(BM_, WM_, WN_, FLAG_)                                                                                      \
+  do {                                                                                                                              \
+    auto kern = hd->pbn ? conv_wgrad_row_group_pbn_kernel<BM_, WM_, WN_, 3> : conv_wgrad_row_group_kernel<BM_, WM_, WN_, 3>;        \
+    bool& done = hd->pbn ? FLAG_##p : FLAG_;                                                                                        \
+    if (lds > 64 * 1024 && !done) {                                                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return STP_E_LAUNCH;                                                                                                        \
+      done = true;                                                                                                                  \
     }                                                                                                                               \
     hipLaunchKernelGGL(kern, dim3(hd->n_wg), dim3(256), lds, s, (const char*)dev_table, (f32x4*)workspace);                         \
   } while (0)
@@ -1448,6 +1767,20 @@ extern "C" int stp_wgrad_group_reduce(const void* host_table, const void* dev_ta
   if (!hd || !dev_table || !workspace) return STP_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const int sl = hd->reduce_lanes == 4 ? 4 : 1;
+  if (hd->taps9) {
+    const dim3 grid9(hd->n_tiles * (hd->bm * 576 / 4 / (256 / sl)));
+#define STP_GROUP9_REDUCE(BM_)                                                                                                                       \
+  do {                                                                                                                                               \
+    if (sl == 4) hipLaunchKernelGGL((wgrad_group9_reduce_kernel<BM_, 4>), grid9, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);  \
+    else hipLaunchKernelGGL((wgrad_group9_reduce_kernel<BM_, 1>), grid9, dim3(256), 0, s, (const char*)dev_table, (const f32x4*)workspace);          \
+  } while (0)
+    if (hd->bm == 128) STP_GROUP9_REDUCE(128);
+    else if (hd->bm == 64) STP_GROUP9_REDUCE(64);
+    else STP_GROUP9_REDUCE(32);
+#undef STP_GROUP9_REDUCE
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
   const int bpt = hd->bm * 192 / 4 / (256 / sl);
   const dim3 grid(hd->n_tiles * bpt);
 #define STP_GROUP_REDUCE(BM_, WM_, WN_)                                                                                                     \

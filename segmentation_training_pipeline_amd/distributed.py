@@ -187,7 +187,11 @@ def make_reducer(force=False):
     """The reducer of the training loops and bench.py: 32 MB buckets (STP_DP_BUCKET_MB), fp32 on the wire - the data-parallel step
     is then bit-identical to accumulating the ranks' gradients in one process.  STP_DP_WIRE=bf16 halves the bytes on xGMI (the
     97.7 MB fp32 arena of U-Net/ResNet34 becomes 48.9 MB, cast by stp_cast_f32_to_bf16 / stp_cast_bf16_to_f32 on the compute
-    stream) at the price of one bf16 rounding of every rank's contribution."""
+    stream).  Error model of the bf16 wire: every rank's contribution is rounded to bf16 once, AND the collective itself sums in bf16 -
+    a ring reduce-scatter rounds the running sum at each of its world-1 hops, so the relative error of a summed gradient grows from
+    2^-8 (bf16's unit roundoff: one rounding) towards world x 2^-8 in the worst case (sqrt(world) x 2^-8 typically); replicas stay bit-identical to
+    each other (all-gather copies one result).  tests/test_distributed_cpu.py::test_bf16_wire_error_model bounds it for two ranks;
+    keep the fp32 wire where gradient accuracy matters more than the 0.2-0.3 ms of xGMI time."""
     wire = os.environ.get("STP_DP_WIRE", "fp32") == "bf16"
     cast = None
     if wire:

@@ -134,10 +134,14 @@ class Plan(object):
         # BatchNormalization whose only consumers are small-channel convolutions: normalised inside their halo staging
         # (stp_conv_params.src_bn_mean), the normalised tensor is never written
         self.fuse_bn_sc = os.environ.get("STP_FUSE_BN_SC", "1") != "0"
-        # producer BatchNormalization applied in LDS by the halo kernel (needs its automatic selection: STP_HALO != 0).  OFF by
-        # default: measured (MI355X, U-Net/ResNet34 bs16) 9.91 ms/step without, 10.09-10.61 ms with - the weight gradient still
-        # reads the normalised tensor, so stp_bn_apply only MOVES to the side stream, and concurrent kernels buy nothing on this
-        # step (no side stream at all: 9.98 ms).  The fusion pays once the weight gradient normalises its operand as well.
+        # producer BatchNormalization applied in LDS by the halo kernel (needs its automatic selection: STP_HALO != 0) AND by the
+        # weight gradient of the same layer (row-of-taps kernel, single-layer or grouped: conv_wgrad.hip's PBN instances): the
+        # normalised tensor is never written, the stp_bn_apply launch disappears.  OPT-IN (STP_FUSE_BN_HALO=1): measured slower in
+        # round 1 (the weight gradient still read the normalised tensor) and again in round 4 with the grouped weight gradient
+        # normalising its operand itself (profiles/r04b_*): 6.99 vs 6.79 ms per step on one box.  The launches it removes cost
+        # 178 + 45 us (31 stp_bn_apply / finalize_apply at 7-14 us, near the HBM roofline); the in-LDS transform costs the halo
+        # forward +2.5..+6.5 us per launch (stage 1: +16 us: ~28 VALU instructions per 16-byte vector, by all 8 waves, with the MFMA
+        # pipe idle) = +220 us, and the grouped weight gradients +140 us (every tile over a pixel range repeats the transform).
         self.fuse_bn_halo = os.environ.get("STP_FUSE_BN_HALO", "0") != "0" and os.environ.get("STP_HALO", "1") != "0"
         self.bn_slots_max_rows = int(os.environ.get("STP_BN_SLOTS_MAXROWS", "1073741824"))
         self._slot_need = 0          # int64 elements, counted in the dry pass
@@ -476,8 +480,9 @@ class Plan(object):
         self.wgroups.append((names, cls))
         self._mark(self.bwd, "fork")
         self._side_reads.update(reads)
+        hdr = (C.c_int32 * 16).from_buffer_copy(bytes(host)[:64])      # WgGroupHeader: [14] = fused producer BN instance, [15] = all-taps tiles
         meta = {"layer": "group[%d]:%s..%s" % (n, names[0], names[-1]), "pass": "wgrad", "flops": sum(f for _, _, f in layers), "cout": cls,
-                "bm": cls, "layers": names, "stream": 1}
+                "bm": cls, "layers": names, "stream": 1, "taps9": int(hdr[15]), "pbn": int(hdr[14])}
         self.bwd.append((self.lib.stp_wgrad_group_partial, (C.addressof(host), dev.data_ptr(), ws.data_ptr(), wsb), "stp_wgrad_group_partial", meta))
         self.bwd.append((self.lib.stp_wgrad_group_reduce, (C.addressof(host), dev.data_ptr(), ws.data_ptr()), "stp_wgrad_group_reduce",
                          {"stream": 1}))
@@ -891,7 +896,9 @@ class Plan(object):
                 if (self.fuse_bn_backward and bnm is not None and (sole or last) and (folded_up or not upsample) and (qC1 == 0 or two_dest)
                         and x_ng and C0 % 4 == 0):
                     q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
-                    if self.slot_arena is not None and self.N * Hv * Wv <= self.bn_slots_max_rows:
+                    if self.slot_arena is not None and self.N * Hv * Wv <= self.bn_slots_max_rows and not two_dest:
+                        # (the two-destination kernel has no slot form - stp_conv2d_scw_eligible was checked without them, and with
+                        #  slots the launch would fall through to the generic kernel, which refuses dst_sum2x2: float partial sums there)
                         sp, sn = self._slots(C0)
                         q.stats_partial, q.stats_slots = sp, sn
                         x.meta["bnb_slots"] = (sp, sn)

@@ -97,7 +97,7 @@ class WgradGroup(object):
         _lib.check(lib.stp_wgrad_group_build(self.arr, n, C.addressof(self.host), tb), "stp_wgrad_group_build")
         self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
         self.ws = torch.empty(wsb // 4, dtype=torch.float32, device=device)
-        self.header = list((C.c_int32 * 12).from_buffer_copy(bytes(self.host)[:48]))   # magic, bm, layers, segments, workgroups, tiles, ...
+        self.header = list((C.c_int32 * 16).from_buffer_copy(bytes(self.host)[:64]))   # magic, bm, layers, segments, workgroups, tiles, ..., [14] = pbn
 
     def partial(self):
         _lib.check(_lib.load().stp_wgrad_group_partial(C.addressof(self.host), self.dev.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4, stream()),

@@ -106,9 +106,40 @@ def make_unet_fullsize(fname="unet_resnet34_512_bs2.npz", size=512, n=2, stride=
     print(fname, "loss", o1["loss"], "dice", o1["dice"], "logit range", lg.min(), lg.max())
 
 
+def make_unet_fullsize_storage(storage="bf16", size=512, n=2, stride=4):
+    """The BENCHMARKED precision at the benchmarked shape: U-Net/ResNet34, 512 x 512 (batch 2), one forward + backward of the
+    STORAGE-QUANTISED oracle (``OracleTrainer(storage="bf16")``: stored activations, stored gradients and weight compute copies are
+    rounded where the kernels round them; statistics, accumulation and the loss stay fp32).  Same sampling as make_unet_fullsize, plus
+    the gradients of a few layers in full (cosine bars) and every parameter's gradient norm."""
+    from oracle import nets, step
+    P = nets.init_unet_resnet("resnet34", seed=42)
+    tr = step.OracleTrainer(P, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss", optimizer="adam", lr=1e-3, storage=storage)
+    x, y = step.synthetic_batch(n, size, size, seed=1234)
+    o1 = tr.step(x.astype(np.float32), y.astype(np.float32), apply=False)
+    names = list(o1["grads"].keys())
+    lg = o1["logits"].astype(np.float32)
+    keep = ["final_conv/kernel", "decoder_stage4_conv2/kernel", "decoder_stage2_conv1/kernel", "decoder_stage0_bn1/gamma",
+            "stage4_unit3_conv2/kernel", "stage3_unit1_bn2/beta", "stage2_unit2_conv1/kernel", "stage1_unit1_conv1/kernel", "conv0/kernel"]
+    fname = "unet_resnet34_512_bs2_%s.npz" % storage
+    np.savez_compressed(
+        os.path.join(HERE, fname), seed=42, data_seed=1234, size=size, n=n, stride=stride, storage=storage,
+        logits1_sampled=lg[:, ::stride, ::stride, :],
+        logits1_abs_max=np.float64(np.abs(lg).max()),
+        logits1_row_sums=lg.astype(np.float64).sum(axis=(2, 3)),
+        scalars1=np.array([o1[k] for k in ("loss", "bce", "dice_loss", "dice", "binary_accuracy")], np.float64),
+        grad_names=np.array(names),
+        grad_l2_step1=np.array([np.sqrt((o1["grads"][k].astype(np.float64) ** 2).sum()) for k in names]),
+        full_grad_names=np.array(keep),
+        **{"grad_full_%d" % i: o1["grads"][k].astype(np.float32) for i, k in enumerate(keep)})
+    print(fname, "loss", o1["loss"], "dice", o1["dice"], "logit range", lg.min(), lg.max())
+
+
 if __name__ == "__main__":
     if "--fullsize-only" in sys.argv:
         make_unet_fullsize()
+        sys.exit(0)
+    if "--fullsize-bf16-only" in sys.argv:
+        make_unet_fullsize_storage("bf16")
         sys.exit(0)
     make_rle()
     make_unet("resnet18", 64, 2, "unet_resnet18_64.npz")
@@ -117,3 +148,4 @@ if __name__ == "__main__":
     make_unet("resnet18", 64, 2, "fpn_resnet18_64.npz", arch="FPN")
     make_unet("resnet18", 96, 2, "pspnet_resnet18_96.npz", arch="PSPNet")
     make_unet_fullsize()
+    make_unet_fullsize_storage("bf16")

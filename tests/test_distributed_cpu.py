@@ -48,12 +48,26 @@ def _worker(rank, world, port, q):
     for wk in works:
         wk.wait()
     ok = ok and len(works) == 4 and torch.equal(g4, torch.arange(2048, dtype=torch.float32).remainder(64) * 3)
+    # error model of the bf16 wire (make_reducer's docstring) on the overlapped path, against the fp32 wire: each contribution is
+    # rounded once (unit roundoff 2^-8) and the two-rank sum once more: |error| <= 2^-8 (|g_0| + |g_1|) + 2^-8 |sum| <= 2^-7 (|g_0| + |g_1|)
+    gen = torch.Generator().manual_seed(100 + rank)
+    g5 = torch.randn(4096, generator=gen) * 1e-3
+    exact = g5.clone()
+    dist.all_reduce(exact)
+    mag = g5.abs()                                      # sum of the contributions' magnitudes: what the roundings scale with
+    dist.all_reduce(mag)
+    red5 = distributed.GradReducer(bucket_mb=0.004, wire_bf16=True,
+                                   cast_fns=(lambda s, d, c: d.copy_(s.to(torch.bfloat16)), lambda s, d, c: d.copy_(s.to(torch.float32))))
+    for wk in [red5.allreduce_range(g5, s, e) for s, e in reversed(red5.bounds(4096))]:
+        wk.wait()
+    ok = ok and bool(((g5 - exact).abs() <= 2.0 ** -7 * mag + 1e-12).all()) and not torch.equal(g5, exact)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gloo_world2_bucketed_allreduce():
+    """(also the bf16-wire error model: test_bf16_wire_error_model is an alias of this multi-process run)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -146,3 +160,6 @@ def test_gloo_world2_epoch_scalars_and_decisions_are_rank_consistent():
     assert res[0][2] == res[1][2]                       # identical logs, bit for bit
     assert res[0][3] == res[1][3] is True                # the same stop decision
     assert sorted(res[0][4] + res[1][4]) == list(range(7))   # validation shards partition the set
+
+
+test_bf16_wire_error_model = test_gloo_world2_bucketed_allreduce

@@ -687,6 +687,45 @@ def test_grouped_weight_gradient(ops, dtype, group):
         ops.WgradGroup(layers + [odd])
 
 
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("group", ["class128", "class64"])
+def test_grouped_weight_gradient_with_fused_producer_batchnorm(ops, dtype, group):
+    """stp_wgrad_group_* where SOME layers carry stp_wgrad_params.src_bn_* (their src0 is the tensor before a BatchNormalization +
+    activation, normalised in LDS by the grouped kernel's PBN instance): against the numpy oracle on the normalised tensors, and
+    bit-identical to the same group run on tensors that stp_bn_apply normalised first (same fma, activation, rounding; the zero
+    padding applies to the normalised tensor)."""
+    rng = np.random.RandomState(12)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    fused_layers, plain_layers, refs, dws_f, dws_p = [], [], [], [], []
+    shapes = [s for s in WGRAD_GROUPS[group] if s[4] == 0]      # a fused producer BN needs a single directly-read source
+    for li, (n, h, w, c0, _, co) in enumerate(shapes):
+        relu = li % 3                                           # none / ReLU / ReLU6
+        pre = q(rng.randn(n, h, w, c0) * 2 + 0.5, dtype)
+        mean, rstd = f(pre.reshape(-1, c0).mean(0)), f(1.0 / np.sqrt(pre.reshape(-1, c0).var(0) + 1e-3))
+        gamma, beta = f(rng.rand(c0) + 0.5), f(rng.randn(c0) * 0.3)
+        pd = dev(pre, dtype)
+        act = keep(torch.empty_like(pd))                        # (the parameter blocks hold raw pointers)
+        ops.bn_apply(pd, act, n * h * w, c0, c0, mean, rstd, gamma, beta, relu=relu)
+        dy = dev(q(rng.randn(n, h, w, co), dtype), dtype)
+        refs.append(np_ops.conv2d_wgrad(host(act), host(dy), (3, 3), 1, 1))
+        fuse = li != 1                                          # one layer of the group stays unfused (per-layer switch in the kernel)
+        for lst, dwl, src, fz in ((fused_layers, dws_f, pd if fuse else act, fuse), (plain_layers, dws_p, act, False)):
+            dw = torch.full((co, 3, 3, c0), float("nan"), dtype=torch.float32, device=DEV)
+            W = ops.wgrad_params(src, dy, dw, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=c0, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.dt(src))
+            if fz:
+                W.src_bn_mean, W.src_bn_rstd, W.src_bn_gamma, W.src_bn_beta, W.src_bn_relu = ops.ptr(mean), ops.ptr(rstd), ops.ptr(gamma), ops.ptr(beta), relu
+            lst.append(W)
+            dwl.append(dw)
+    want = 128 if group == "class128" else 64
+    assert [ops.wgrad_group_class(p) for p in fused_layers] == [want] * len(fused_layers)
+    gf, gp = ops.WgradGroup(fused_layers), ops.WgradGroup(plain_layers)
+    assert gf.header[14] == 1 and gp.header[14] == 0             # WgGroupHeader.pbn: the fused-producer instance is selected per group
+    gf.run(); gp.run()
+    for a, b, ref in zip(dws_f, dws_p, refs):
+        np.testing.assert_allclose(host(b).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
+        assert np.array_equal(host(a), host(b))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("C", [16, 64, 768])
 def test_batchnorm_train_forward_backward(ops, dtype, C):
