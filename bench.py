@@ -389,19 +389,23 @@ def main():
         prof = per_kernel_profile(model)
         tot = sum(v[1] for v in prof.values())
         gemm = {k: v for k, v in prof.items() if v[2] > 0}
-        dom = max(gemm, key=lambda k: gemm[k][1])
-        n_l, sec, fl = gemm[dom]
-        ach = fl / sec / 1e12
-        traffic, traffic_src = pmc_traffic(dom)
-        mu, mu_src = pmc_mfma_util(dom)
-        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
-                           "traffic_source": traffic_src, "mfma_util": mu, "mfma_util_source": mu_src,
-                           # the counter files come from separate profiler passes: true = collected on ANOTHER build of csrc/
-                           "counters_stale": bool((traffic_src and _pmc_stale(os.path.join(ROOT, traffic_src))) or
-                                                  (mu_src and _pmc_stale(os.path.join(ROOT, mu_src)))),
-                           "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
-                           "share_of_step_kernel_time": round(sec / tot, 3)}
+
+        def roofline_of(key):
+            n_l, sec, fl = gemm[key]
+            ach = fl / sec / 1e12
+            traffic, traffic_src = pmc_traffic(key)
+            mu, mu_src = pmc_mfma_util(key)
+            return {"kernel": key, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src, "mfma_util": mu, "mfma_util_source": mu_src,
+                    # the counter files come from separate profiler passes: true = collected on ANOTHER build of csrc/
+                    "counters_stale": bool((traffic_src and _pmc_stale(os.path.join(ROOT, traffic_src))) or
+                                           (mu_src and _pmc_stale(os.path.join(ROOT, mu_src)))),
+                    "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
+                    "share_of_step_kernel_time": round(sec / tot, 3)}
+        order = sorted(gemm, key=lambda k: -gemm[k][1])
+        out["roofline"] = roofline_of(order[0])                      # the GEMM kernel with the largest total time per step
+        out["roofline_next"] = [roofline_of(k) for k in order[1:4]]  # and the three after it (same fields)
         top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:16]
         out["kernel_time_us"] = {k: [round(v[0], 1), round(1e6 * v[1], 1), round(v[2] / v[1] / 1e12, 1) if v[2] else None] for k, v in top}
         out["kernel_time_total_us"] = round(1e6 * tot, 1)

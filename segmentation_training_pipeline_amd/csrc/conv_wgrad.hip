@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -913,7 +914,12 @@ __device__ __forceinline__ void conv_wgrad_taps9_body(const WgradArgs& a, const 
   static_assert(BM == 128 || BM == 64 || BM == 32, "output-channel tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  // The thread index passes through an opaque asm: the lane constants below (fragment and LDS-DMA addresses) depend only on it and
+  // on SEG, so the compiler would hoist those of ALL THREE bodies of conv_wgrad_taps9_group_kernel out of its segment loop and keep
+  // them alive across it - ~50 registers that the BM = 128 instance does not have (42 spills).  Recomputed per segment instead.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int lr = lane & 15, lg = lane >> 4;
@@ -939,50 +945,58 @@ __device__ __forceinline__ void conv_wgrad_taps9_body(const WgradArgs& a, const 
     rowa[i] = (rowA0 + i * RPA) < PK ? ((uint32_t)(rowA0 + i * RPA) * (uint32_t)a.Cout + (uint32_t)(cout0 + colA)) * SZ : STP_OOB;
   const int hb0 = tid >> 3;
   const uint32_t colB = (uint32_t)(tile_addr<ROWB>(hb0, (tid & 7) * 16) - hb0 * ROWB);    // logical byte column held by this slot (hb0 + 64 p: same key)
-  int hr[G::NPASS], hx[G::NPASS];
-#pragma unroll
-  for (int i = 0; i < G::NPASS; ++i) {
-    const int h = hb0 + i * 64;
-    const int r = h / G::HWP, c = h - r * G::HWP;
-    const bool used = r < G::ROWS + 2 && c < G::HW;
-    hr[i] = used ? r - 1 : -0x4000;
-    hx[i] = c - 1;
-  }
+  // (image row / column of halo row pass * 64 + hb0 relative to the step's first pixel: recomputed per piece from hb0 - compile-time
+  //  divisor, ~6 VALU - instead of 2 x NPASS registers: the BM = 128 instance sits at the 256-register limit)
   const uint32_t pixb = (uint32_t)cs * SZ, imgb = (uint32_t)Hs * (uint32_t)Ws * pixb, cbyte = (uint32_t)cb_src * 128u + colB;
 
-  auto issue_tile = [&](int step, int buf) {
+  // a tile = L pieces (LDS-DMA instructions): pieces 0 .. NVA-1 = dY, NVA .. L-1 = halo passes.  The step's scalar geometry
+  // (image, first row / column, byte bases) is computed once (tile_geo), a piece adds its lane constants.
+  struct TileGeo { uint32_t ho0, wo0, abase, nb; };
+  auto tile_geo = [&](int step) {
     const int p0 = step * PK;
-    char* sa = smem + buf * STAGE;
-    char* sb = sa + ABYTES;
     const uint32_t n = fdiv((uint32_t)p0, a.divHoWo);
     const uint32_t rem = (uint32_t)p0 - n * (uint32_t)a.HoWo;
-    const uint32_t ho0 = fdiv(rem, a.divWo);
-    const uint32_t wo0 = rem - ho0 * (uint32_t)a.Wo;
-    const uint32_t abase = (uint32_t)p0 * (uint32_t)a.Cout * SZ;
-    const uint32_t nb = n * imgb + cbyte;
-#pragma unroll
-    for (int i = 0; i < NVA; ++i)
+    TileGeo tg;
+    tg.ho0 = fdiv(rem, a.divWo);
+    tg.wo0 = rem - tg.ho0 * (uint32_t)a.Wo;
+    tg.abase = (uint32_t)p0 * (uint32_t)a.Cout * SZ;
+    tg.nb = n * imgb + cbyte;
+    return tg;
+  };
+  auto issue_piece = [&](const TileGeo& tg, int buf, int piece) __attribute__((always_inline)) {
+    char* sa = smem + buf * STAGE;
+    if (piece < NVA) {
+      const int i = piece;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sa + (i * 512 + wave * 64) * 16), 16,
-                                               (coA_ok && rowa[i] != STP_OOB) ? abase + rowa[i] : STP_OOB, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < G::NPASS; ++i) {
-      const int hv = (int)ho0 + hr[i], wv = (int)wo0 + hx[i];
-      const bool ok = (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
-      const uint32_t off = nb + ((uint32_t)(hv >> sh) * (uint32_t)Ws + (uint32_t)(wv >> sh)) * pixb;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(sb + (i * 512 + wave * 64) * 16), 16,
+                                               (coA_ok && rowa[i] != STP_OOB) ? tg.abase + rowa[i] : STP_OOB, 0, 0, 0);
+    } else {
+      const int i = piece - NVA;
+      const int h = hb0 + i * 64;
+      const int r = h / G::HWP, c = h - r * G::HWP;
+      const int hv = (int)tg.ho0 + r - 1, wv = (int)tg.wo0 + c - 1;
+      const bool ok = r < G::ROWS + 2 && c < G::HW && (unsigned)hv < (unsigned)a.Hv && (unsigned)wv < (unsigned)a.Wv;
+      const uint32_t off = tg.nb + ((uint32_t)(hv >> sh) * (uint32_t)Ws + (uint32_t)(wv >> sh)) * pixb;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(sa + ABYTES + (i * 512 + wave * 64) * 16), 16,
                                                ok ? off : STP_OOB, 0, 0, 0);
     }
+  };
+  auto issue_tile = [&](int step, int buf) {
+    const TileGeo tg = tile_geo(step);
+#pragma unroll
+    for (int pc = 0; pc < L; ++pc) issue_piece(tg, buf, pc);
   };
 
   // ---- fragment addresses (bytes from the stage base).  Pixel q of the step (row q / SEG, column q % SEG); a 16-lane group reads 4
   // consecutive pixels: lane -> pixel (lr >> 2), 8-byte quad (lr & 3) of the 32-byte channel block.
   const int qb = (lr & 3) * 8;
-  int aaddr[4][TM], baddr[4][3];       // [pixel group e = chunk * 2 + half][channel block] / [e][kw]
+  // A: the 32-byte channel block i of a wave sits in byte bits 5.. of the row, the swizzle key XORs the same bits: block i = block 0
+  // XOR (i * 32) - one address register per pixel group (4 instead of 4 x TM)
+  int aaddr[4], baddr[4][3];           // [pixel group e = chunk * 2 + half] / [e][kw]
+  static_assert(ROWA >= 64 && ((BM / 2) * SZ) % (TM * 32) == 0, "the wave's channel blocks occupy an aligned bit field of the row");
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = e * 16 + lg * 4 + (lr >> 2);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) aaddr[e][i] = tile_addr<ROWA>(q, (wm * (BM / 2) + i * 16) * SZ + qb);
+    aaddr[e] = tile_addr<ROWA>(q, (wm * (BM / 2)) * SZ + qb);
     const int r = q / SEG, c = q - r * SEG;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) baddr[e][kw] = ABYTES + tile_addr<ROWB>(r * G::HWP + c + kw, wn * 32 + qb);
@@ -997,48 +1011,84 @@ __device__ __forceinline__ void conv_wgrad_taps9_body(const WgradArgs& a, const 
   // A step = 2 chunks of 32 pixels x 3 kernel rows = 6 groups of 3 taps x TM MFMAs.  The B fragments of group g + 1 are requested
   // BEFORE the MFMAs of group g (two sets of 12 registers, pinned by sched_barrier: left alone, the scheduler hoists every read of
   // the step to its top - 52 fragment registers on top of 144 accumulators + 28 addresses = 36 spills at BM = 128).
-  auto read_a = [&](const char* st, int c, u32x4 (&fa)[TM]) {
+  // The transpose reads are INLINE ASM with hand-counted lgkmcnt waits: through the builtin, the compiler's wait-count pass puts
+  // `s_waitcnt vmcnt(0)` in front of the first LDS read after every LDS-DMA instruction (it cannot tell that the ring slot being
+  // filled is not the one being read) - with the pieces of the next tile issued between the MFMA groups that drained the whole DMA
+  // queue six times per step (first build: 5600 cycles per step for 2304 cycles of MFMA work).  The step's barrier + counted vmcnt
+  // order the slot that IS read.
+  auto tr_read = [&](uint32_t addr, auto off) __attribute__((always_inline)) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off)::value));
+    return v;
+  };
+  auto read_a = [&](uint32_t st, int c, u32x4 (&fa)[TM]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + aaddr[2 * c][i]));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + aaddr[2 * c + 1][i]));
-      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      const u32x2 l2 = tr_read(st + (uint32_t)(aaddr[2 * c] ^ (i * 32)), std::integral_constant<int, 0>{});
+      const u32x2 h2 = tr_read(st + (uint32_t)(aaddr[2 * c + 1] ^ (i * 32)), std::integral_constant<int, 0>{});
       fa[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
     }
   };
-  auto read_b = [&](const char* st, int c, int kh, u32x4 (&fb)[3]) {
-    constexpr int KHB = G::HWP * ROWB;                       // bytes between kernel rows: a multiple of 8 LDS rows (same swizzle key)
+  // (kernel row kh = a compile-time byte offset: a multiple of 8 LDS rows, same swizzle key)
+  auto read_b = [&](uint32_t st, int c, auto khc, u32x4 (&fb)[3]) __attribute__((always_inline)) {
+    constexpr int OFF = decltype(khc)::value * G::HWP * ROWB;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + baddr[2 * c][kw] + kh * KHB));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + baddr[2 * c + 1][kw] + kh * KHB));
-      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      const u32x2 l2 = tr_read(st + (uint32_t)baddr[2 * c][kw], std::integral_constant<int, OFF>{});
+      const u32x2 h2 = tr_read(st + (uint32_t)baddr[2 * c + 1][kw], std::integral_constant<int, OFF>{});
       fb[kw] = u32x4{l2.x, l2.y, h2.x, h2.y};
     }
   };
-  auto compute = [&](const char* st) {
+  // everything but the `young` most recent LDS reads has returned; the fragments are operands of the asm, so no MFMA that consumes
+  // them can be scheduled above the wait
+  auto wait_frags = [&](auto young, u32x4 (&fa)[TM], u32x4 (&fb)[3]) __attribute__((always_inline)) {
+    if constexpr (TM == 4)
+      asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]) : "n"(decltype(young)::value));
+    else if constexpr (TM == 2)
+      asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]) : "n"(decltype(young)::value));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]) : "n"(decltype(young)::value));
+  };
+  static_assert(L <= 6, "one LDS-DMA piece per MFMA group");
+  // A step = 2 chunks of 32 pixels x 3 kernel rows = 6 groups of 3 taps x TM MFMAs.  The B fragments of group g + 1 are requested
+  // BEFORE the MFMAs of group g (two sets of 12 registers).  `next`: the pieces of tile `nstep` go into ring slot `nb_` BETWEEN the
+  // MFMA groups, one per group (an LDS-DMA instruction costs ~60 issue cycles among MFMAs, 100-180 in a burst that opens the step).
+  auto compute = [&](uint32_t st, bool next, int nstep, int nb_) {
     u32x4 fa[TM], fb[2][3];
+    TileGeo tg = {0u, 0u, 0u, 0u};
+    if (next) tg = tile_geo(nstep);
     read_a(st, 0, fa);
-    read_b(st, 0, 0, fb[0]);
-#pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      const int c = g / 3, kh = g - c * 3;
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 1 < 6) read_b(st, (g + 1) / 3, (g + 1) % 3, fb[(g + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          acc[i][kh * 3 + kw] = mfma16_16x16x32(fa[i], fb[g & 1][kw], acc[i][kh * 3 + kw]);
-      if (g == 2) {                                           // the A fragments of the second chunk, behind the last MFMAs that read the first
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(st, 1, fa);
-      }
+    read_b(st, 0, std::integral_constant<int, 0>{}, fb[0]);
+#define STP_T9_GROUP(G_, C_, KH_, CN_, KHN_)                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (G_ + 1 < 6) {                                                                                            \
+      read_b(st, CN_, std::integral_constant<int, KHN_>{}, fb[(G_ + 1) & 1]);                                    \
+      wait_frags(std::integral_constant<int, 6>{}, fa, fb[G_ & 1]);                                              \
+    } else {                                                                                                     \
+      wait_frags(std::integral_constant<int, 0>{}, fa, fb[G_ & 1]);                                              \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                             \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+        acc[i][KH_ * 3 + kw] = mfma16_16x16x32(fa[i], fb[G_ & 1][kw], acc[i][KH_ * 3 + kw]);                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (G_ < L && next) issue_piece(tg, nb_, G_);                                                                \
+    if (G_ == 2) {   /* the A fragments of the second chunk, behind the last MFMAs that read the first */        \
+      __builtin_amdgcn_sched_barrier(0);                                                                         \
+      read_a(st, 1, fa);                                                                                         \
     }
+    // (group 2 -> 3: the 2 * TM reads of read_a(1) are OLDER than the 6 of read_b(group 4), so "all but the youngest 6" covers them)
+    STP_T9_GROUP(0, 0, 0, 0, 1)
+    STP_T9_GROUP(1, 0, 1, 0, 2)
+    STP_T9_GROUP(2, 0, 2, 1, 0)
+    STP_T9_GROUP(3, 1, 0, 1, 1)
+    STP_T9_GROUP(4, 1, 1, 1, 2)
+    STP_T9_GROUP(5, 1, 2, 1, 0)
+#undef STP_T9_GROUP
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the ring (the asm reads take addresses)
   const int nst = step1 - step0;
 #pragma unroll
   for (int q = 0; q < STAGES - 1; ++q)
@@ -1049,8 +1099,7 @@ __device__ __forceinline__ void conv_wgrad_taps9_body(const WgradArgs& a, const 
     if (STAGES >= 3 && ahead >= STAGES - 2) wait_vmcnt<(STAGES - 2) * L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (st + STAGES - 1 < nst) issue_tile(step0 + st + STAGES - 1, nbuf);
-    compute(smem + buf * STAGE);
+    compute(lds0 + (uint32_t)(buf * STAGE), st + STAGES - 1 < nst, step0 + st + STAGES - 1, nbuf);
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }
@@ -1562,11 +1611,14 @@ static int wg_group_slots(int bm, bool taps9) {
   return cus * (bm == 128 ? 2 : bm == 64 ? 3 : 4);     // co-resident workgroups: 77 KB of LDS / 224 registers at 128 channels, 52 KB / 144 and 40 KB / 114 below
 }
 // all-taps tiles for a group: every layer on a 16 / 32 / >= 64 pixel wide map (the kernel's three bodies), none with a fused producer
-// BatchNormalization (that stays on the row-of-taps instance).  OPT-IN (STP_WGRAD_TAPS9=1): measured slower than the row-of-taps
-// groups on the U-Net/ResNet34 step (profiles/r04d_*: 7.39 vs 7.08 ms) - see DESIGN.md 3.1a.
+// BatchNormalization (that stays on the row-of-taps instance).  Default for the 128-channel class (profiles/r04f_*: the three groups
+// 265 / 234 / 150 -> 210 / 173 / 117 us, 1150-1230 TFLOP/s, step 6.78 -> 6.64 ms on one box); STP_WGRAD_TAPS9=0 keeps the round-3 kernel.
 static bool wg_group_taps9(const stp_wgrad_params* const* L, int n) {
-  static const bool on = getenv("STP_WGRAD_TAPS9") && atoi(getenv("STP_WGRAD_TAPS9")) != 0;
-  if (!on) return false;
+  static const int mode = getenv("STP_WGRAD_TAPS9") ? atoi(getenv("STP_WGRAD_TAPS9")) : 1;      // 0: off; 1 (default): 128-channel class; 2: every class (tests)
+  if (!mode) return false;
+  // (the 64 / 32-channel classes: 32 / 16 output channels per wave against 9 taps x 16 input channels = 1.2 / 2 transpose reads per
+  //  MFMA - LDS-bound, measured 25 % / 45 % slower than their row-of-taps instances, whose fabric traffic is already ~1x algorithmic)
+  if (mode != 2 && wg_group_bm(L[0]) != 128) return false;
   for (int l = 0; l < n; ++l)
     if (L[l]->src_bn_mean || !(L[l]->Wo == 16 || L[l]->Wo == 32 || L[l]->Wo % 64 == 0)) return false;
   return true;

@@ -304,6 +304,19 @@ class Plan(object):
             self._side_groups_only = True
         return t.grad
 
+    def _before_inplace_write(self, buf):
+        """A main-stream kernel is about to rewrite ``buf`` in place (stp_relu_bwd masks a dY): a pending grouped weight gradient
+        that still reads it as its dY is issued first, a side chain in flight that reads it is joined (the rule _gradbuf applies
+        to gradient buffers it hands out; advisor finding, round 3: no current network aliases such a buffer, nothing guarded it)."""
+        if buf is None:
+            return
+        if self._wgroup_reads and buf.data_ptr() in self._wgroup_reads:
+            self._flush_wgroup()
+        if self._side_reads and buf.data_ptr() in self._side_reads:
+            self._mark(self.bwd, "join")
+            self._side_reads.clear()
+            self._side_groups_only = True
+
     @staticmethod
     def _use(*ts):
         """Counts the consumers of a tensor: a BatchNormalization output read by exactly one convolution gets its
@@ -750,6 +763,7 @@ class Plan(object):
             dy = out.grad
             rows = out.rows
             if relu:
+                self._before_inplace_write(dy)
                 self._emit(self.bwd, "stp_relu_bwd", out.buf.data_ptr(), dy.data_ptr(), rows * out.gradC, self.cdt)
             # lag-1 join: the previous convolution's weight-gradient chain finishes before this layer's kernels start.
             # (Letting the side chain fall further behind - joining only on a buffer hazard, see _gradbuf - measured
@@ -986,6 +1000,7 @@ class Plan(object):
             dy = out.grad
             if out.gradC != Cn:
                 raise StpShapeError("%s: standalone ReLU needs an unpadded channel count" % name)
+            self._before_inplace_write(dy)
             self._emit(self.bwd, "stp_relu_bwd", out.buf.data_ptr(), dy.data_ptr(), x.rows * Cn, self.cdt)
             if not x.grad_ready and x.gradC == out.gradC:
                 x.grad, x.grad_ready = dy, True

@@ -856,6 +856,15 @@ class GenericTaskConfig(object):
             if self.showDataExamples:
                 cbs.append(DrawResults(self, ds, train_idx, fold, si, train=True, drawingFunction=self.drawingFunction))
         mode = metric_mode(self.primary_metric, self.primary_metric_mode)
+        # primary_metric / callback monitors are checked against the names an epoch will log BEFORE the first epoch trains (a typo used
+        # to surface only after a whole epoch: advisor finding, round 3)
+        known = {}
+        for k in epoch_log_names(self.classes, _extended(impl)) + ["lr"]:
+            known[k] = 0.0
+            known["val_" + k] = 0.0
+        for what, name in [("primary_metric", self.primary_metric)] + [("%s.monitor" % type(cb).__name__, cb.monitor) for cb in cbs if hasattr(cb, "monitor")]:
+            if log_value(known, name) is None:
+                raise ValueError("%s %r is not among the quantities an epoch logs: %s" % (what, name, sorted(known)))
         best, best_epoch, rows = None, -1, []
         t0 = time.time()
         for epoch in range(stage.epochs):

@@ -115,9 +115,13 @@ def make_unet_fullsize_storage(storage="bf16", size=512, n=2, stride=4):
     P = nets.init_unet_resnet("resnet34", seed=42)
     tr = step.OracleTrainer(P, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss", optimizer="adam", lr=1e-3, storage=storage)
     x, y = step.synthetic_batch(n, size, size, seed=1234)
-    o1 = tr.step(x.astype(np.float32), y.astype(np.float32), apply=False)
+    taps = {}
+    o1 = tr.step(x.astype(np.float32), y.astype(np.float32), apply=False, taps=taps)
     names = list(o1["grads"].keys())
     lg = o1["logits"].astype(np.float32)
+    # early activations on a stride-16 pixel grid: before rounding ties start to cascade the device must reproduce them EXACTLY
+    early = {"tap_bn0": taps["relu0"], "tap_pooling0": taps["pooling0"], "tap_stage1_unit1_conv2": taps["stage1_unit1_out"]}
+    early = {k: v.detach().float().numpy()[:, ::16, ::16, :].astype(np.float32) for k, v in early.items()}
     keep = ["final_conv/kernel", "decoder_stage4_conv2/kernel", "decoder_stage2_conv1/kernel", "decoder_stage0_bn1/gamma",
             "stage4_unit3_conv2/kernel", "stage3_unit1_bn2/beta", "stage2_unit2_conv1/kernel", "stage1_unit1_conv1/kernel", "conv0/kernel"]
     fname = "unet_resnet34_512_bs2_%s.npz" % storage
@@ -130,6 +134,7 @@ def make_unet_fullsize_storage(storage="bf16", size=512, n=2, stride=4):
         grad_names=np.array(names),
         grad_l2_step1=np.array([np.sqrt((o1["grads"][k].astype(np.float64) ** 2).sum()) for k in names]),
         full_grad_names=np.array(keep),
+        **early,
         **{"grad_full_%d" % i: o1["grads"][k].astype(np.float32) for i, k in enumerate(keep)})
     print(fname, "loss", o1["loss"], "dice", o1["dice"], "logit range", lg.min(), lg.max())
 

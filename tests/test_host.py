@@ -505,7 +505,9 @@ def test_bench_names_every_launch_of_the_headline_plan():
                     keys.add(bench.kernel_key(name, meta or {}, dtype))
         assert any(k.startswith("conv_halo_kernel") for k in keys) == (dtype != "fp32")
         if dtype != "fp32":
-            assert "conv_scw_stream_kernel<unsigned short>" in keys and "conv_wgrad_row_group_kernel<128, 2, 2, 3>" in keys
+            assert "conv_scw_stream_kernel<unsigned short>" in keys
+            # the 128-channel groups run the all-taps kernel (round 4), the 64 / 32-channel groups the row-of-taps one
+            assert "conv_wgrad_taps9_group_kernel<128, 3>" in keys and "conv_wgrad_row_group_kernel<64, 1, 4, 3>" in keys
 
 
 def test_simple_png_mask_dataset(tmp_path):
