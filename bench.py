@@ -293,9 +293,31 @@ def main():
     prm = torch.from_numpy(prm).to(dev)
     in_img, in_msk = model.plan.inputs["image"].buf, model.plan.inputs["mask"].buf
 
+    # The schedules of pipeline.Trainer.run_epoch_sums.  Default: augmentation, then the step, on one stream.  STP_FEED_OVERLAP=1 (opt-in,
+    # measured slower: profiles/r04j_schedule_ab.txt): the augmentation kernel of the NEXT step is issued on an auxiliary stream once this
+    # step's forward + backward has read the input buffers, and runs next to the optimizer.  Either way one step = one augmentation + one
+    # forward / backward / optimizer.
+    overlap = os.environ.get("STP_FEED_OVERLAP", "0") == "1"
+    aux = torch.cuda.Stream(device=dev)
+
+    def augment_into_plan(src_img, src_msk, i):
+        ops.augment_u8(src_img, src_msk, in_img, in_msk, prm[i % total], BATCH, H, W, H, W, 3)
+
     def step(i):
-        ops.augment_u8(raw_img, raw_msk, in_img, in_msk, prm[i % total], BATCH, H, W, H, W, 3)
-        model.train_on_batch(None, None, fetch=False)
+        if not overlap:
+            augment_into_plan(raw_img, raw_msk, i)
+            model.train_on_batch(None, None, fetch=False)
+            return
+        main = torch.cuda.current_stream()
+        model.forward_backward()                     # (on the batch the previous step - or the priming call below - augmented)
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            augment_into_plan(raw_img, raw_msk, i + 1)
+        model.apply_gradients()
+        main.wait_stream(aux)
+
+    if overlap:
+        augment_into_plan(raw_img, raw_msk, 0)
 
     def timed(fn, first, count):
         """EXACTLY ``count`` steps bracketed by barrier + synchronize on both sides; MAX over ranks (seconds)."""
@@ -340,18 +362,31 @@ def main():
             d_msk[b].copy_(h_msk[i % NHOST], non_blocking=True)
             ready[b].record(copy_stream)
 
-    def step_fed(i):
+    def feed_into_plan(i, stream):
         b = i % 2
-        main = torch.cuda.current_stream()
-        main.wait_event(ready[b])
-        ops.augment_u8(d_img[b], d_msk[b], in_img, in_msk, prm[i % total], BATCH, H, W, H, W, 3)
-        consumed[b].record(main)
+        stream.wait_event(ready[b])
+        augment_into_plan(d_img[b], d_msk[b], i)
+        consumed[b].record(stream)
         stage(i + 1)
-        model.train_on_batch(None, None, fetch=False)
+
+    def step_fed(i):
+        main = torch.cuda.current_stream()
+        if not overlap:
+            feed_into_plan(i, main)
+            model.train_on_batch(None, None, fetch=False)
+            return
+        model.forward_backward()
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            feed_into_plan(i + 1, aux)
+        model.apply_gradients()
+        main.wait_stream(aux)
 
     for b in range(2):
         consumed[b].record(torch.cuda.current_stream())
     stage(0)
+    if overlap:
+        feed_into_plan(0, torch.cuda.current_stream())
     for i in range(2):
         step_fed(i)
     elapsed_fed = timed(step_fed, 2, args.steps)

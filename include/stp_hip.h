@@ -494,6 +494,14 @@ int stp_nadam(float* param, const float* grad, float* m, float* v, int64_t count
  * stp_rmsprop, stp_nadam) given that gscale returns without touching parameters, moments or its step counter: the step is skipped. */
 int stp_grad_global_scale(const float* grad, int64_t count, float clipnorm, float base, float* gscale,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* DYNAMIC LOSS SCALING (fp16 storage; replaces a Keras LossScaleOptimizer / torch GradScaler around the reference's fit()).
+ * dls = float[8] on the device: [0] multiplier m of the next backward pass (on top of the static scale of the loss kernels),
+ * [1] clean steps, [2] growth interval, [3] smallest m, [4] m of the gradients now in the arena, [5] largest m.
+ * stp_scale_by_device: x *= scalar[0] (the loss gradient right after the loss kernel seeded it; record = dls + 4).  stp_grad_global_scale_dls: as
+ * stp_grad_global_scale with base / m; a skipped step halves m, `interval` clean steps double it - all on the device (graph-safe). */
+int stp_scale_by_device(void* x, int64_t count, int32_t dtype, const float* scalar, float* record /* may be NULL: receives scalar[0] */, void* stream);
+int stp_grad_global_scale_dls(const float* grad, int64_t count, float clipnorm, float base, float* gscale, float* dls,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * DeepLabV3+ (the in-tree model, segmentation_pipeline/impl/deeplab/model.py) - the ops nothing else needs.

@@ -142,6 +142,8 @@ SIGNATURES = {
     "stp_rmsprop": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, f32, vp]),
     "stp_nadam": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, vp, vp, f32, vp]),
     "stp_grad_global_scale": (i32, [vp, i64, f32, f32, vp, vp, sz, vp]),
+    "stp_scale_by_device": (i32, [vp, i64, i32, vp, vp, vp]),
+    "stp_grad_global_scale_dls": (i32, [vp, i64, f32, f32, vp, vp, vp, sz, vp]),
     "stp_dwconv": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_dwconv_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_dwconv_wgrad_workspace_bytes": (sz, [i32, i32]),

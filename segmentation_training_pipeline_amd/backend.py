@@ -7,6 +7,7 @@ layer names of segmentation_models / classification_models; on the device they l
 flat fp32 arena (kernels as OHWI) so the optimizer and the gradient all-reduce are single
 streaming launches.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -101,6 +102,14 @@ class HipSegModel(object):
         if self.loss_scale <= 0:
             raise ValueError("loss_scale must be positive")
         self.plan.loss_scale = self.loss_scale
+        # DYNAMIC re-scaling on top of the static scale (fp16 only; STP_DYNAMIC_LOSS_SCALE=0 keeps the static scale + skip-on-overflow of
+        # round 3): a device multiplier m (float[8] record, include/stp_hip.h) applied to the loss gradient right after the loss kernel,
+        # halved when a step is skipped, doubled after `interval` clean steps - all inside the captured step.
+        self.dls = None
+        if dtype == "fp16" and self.loss_scale != 1.0 and os.environ.get("STP_DYNAMIC_LOSS_SCALE", "1") != "0":
+            interval = float(os.environ.get("STP_LOSS_SCALE_INTERVAL", "2000"))
+            self.dls = torch.tensor([1.0, 0.0, interval, 2.0 ** -14, 1.0, 2.0 ** 8, 0.0, 0.0], dtype=torch.float32, device=self.device)
+            self.plan.dls = self.dls
         if freeze_encoder:
             self.plan.frozen_prefixes = nets.ENCODER_PREFIXES
         self.plan.define(self._net(True))
@@ -180,7 +189,10 @@ class HipSegModel(object):
         # clipnorm, and - whenever the loss is scaled (fp16) - the overflow guard: a non-finite gradient norm turns the step into a no-op
         # (stp_grad_global_scale writes the skip marker; parameters, moments and the step counter stay as they were)
         guard = self.loss_scale != 1.0
-        if self.clipnorm > 0 or guard:
+        if self.dls is not None:
+            p._emit(p.opt, "stp_grad_global_scale_dls", p.G.data_ptr(), n, self.clipnorm, getattr(self, "dp_scale", 1.0) / self.loss_scale,
+                    self.gscale.data_ptr(), self.dls.data_ptr(), self.ws_norm.data_ptr(), self.ws_norm.numel() * 4)
+        elif self.clipnorm > 0 or guard:
             p._emit(p.opt, "stp_grad_global_scale", p.G.data_ptr(), n, self.clipnorm, getattr(self, "dp_scale", 1.0) / self.loss_scale,
                     self.gscale.data_ptr(), self.ws_norm.data_ptr(), self.ws_norm.numel() * 4)
         gs = self.gscale.data_ptr() if (use_gscale or self.clipnorm > 0 or guard) else None
@@ -207,7 +219,7 @@ class HipSegModel(object):
 
     def _mutable_state(self):
         p = self.plan
-        return [t for t in (p.P, p.S, self.opt_state, self.opt_fstate, self.m, self.v, self.vel, self.gscale, p.step_state) if t is not None]
+        return [t for t in (p.P, p.S, self.opt_state, self.opt_fstate, self.m, self.v, self.vel, self.gscale, p.step_state, self.dls) if t is not None]
 
     # ------------------------------------------------------------------ weights
     def init_weights(self, seed=42):
@@ -287,7 +299,13 @@ class HipSegModel(object):
 
     def get_gradients(self):
         """Gradients of the last step in Keras layout (the arena holds loss_scale x gradient in fp16 mode: divided out here)."""
-        return self._unflatten(self.plan.G.cpu().numpy() * np.float32(1.0 / self.loss_scale))
+        m = float(self.dls[4].item()) if self.dls is not None else 1.0      # the dynamic multiplier these gradients were computed under
+        return self._unflatten(self.plan.G.cpu().numpy() * np.float32(1.0 / (self.loss_scale * m)))
+
+    @property
+    def dynamic_loss_scale(self):
+        """Total loss scale of the NEXT backward pass (static x dynamic multiplier); the static scale when dynamic re-scaling is off."""
+        return self.loss_scale * (float(self.dls[0].item()) if self.dls is not None else 1.0)
 
     def broadcast_state(self, src=0):
         """Data-parallel start of a stage: every replica takes rank ``src``'s parameters, BatchNormalization moving
@@ -333,7 +351,7 @@ class HipSegModel(object):
             return
         p = self.plan
         saved = [t.clone() for t in self._mutable_state()]
-        p.run(p.prep); p.run(p.fwd); p.run(p.bwd); p.run(p.opt)
+        p.run_prep_fwd(); p.run(p.bwd); p.run(p.opt)
         torch.cuda.synchronize()
         for t, s in zip(self._mutable_state(), saved):
             t.copy_(s)
@@ -343,7 +361,7 @@ class HipSegModel(object):
         if segs is None:
             gfb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gfb, capture_error_mode=CAPTURE_MODE):
-                p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+                p.run_prep_fwd(); p.run(p.bwd)
             self._graphs = {"fb": gfb, "opt": gopt}
         else:
             # one graph per backward segment; the first also holds the weight copies, the forward and the loss
@@ -352,7 +370,7 @@ class HipSegModel(object):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     if i == 0:
-                        p.run(p.prep); p.run(p.fwd)
+                        p.run_prep_fwd()
                     p.run(p.bwd[a:b])
                 gs.append(g)
                 a = b
@@ -391,7 +409,7 @@ class HipSegModel(object):
             if self.use_graph:
                 self._graphs["fb"].replay()
             else:
-                p.run(p.prep); p.run(p.fwd); p.run(p.bwd)
+                p.run_prep_fwd(); p.run(p.bwd)
             return
         self._works, a = [], 0
         for i, (b, ranges) in enumerate(segs):
@@ -399,7 +417,7 @@ class HipSegModel(object):
                 self._graphs["segs"][i].replay()
             else:
                 if i == 0:
-                    p.run(p.prep); p.run(p.fwd)
+                    p.run_prep_fwd()
                 p.run(p.bwd[a:b])
             a = b
             for s, e in ranges:

@@ -889,6 +889,77 @@ extern "C" int stp_grad_global_scale(const float* grad, int64_t count, float cli
   return STP_OK;
 }
 
+// ---- dynamic loss scaling (fp16 storage).  dls = float[8] on the device: [0] multiplier m of the NEXT backward pass (a power of two, on
+// top of the static scale the loss kernels apply), [1] clean steps since the last change, [2] growth interval (steps), [3] smallest m,
+// [4] m of the gradients now in the arena (written by stp_scale_by_device when the backward pass is seeded), [5] largest m.  Everything happens on the device, inside the
+// captured step: stp_scale_by_device multiplies the loss gradient by m right after the loss kernel seeded it; the _dls form of
+// stp_grad_global_scale folds 1/m into gscale, halves m when the step is skipped (non-finite gradient) and doubles it after
+// `interval` clean steps - the schedule of torch.cuda.amp.GradScaler / Keras' LossScaleOptimizer.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_by_device_kernel(T* __restrict__ x, int64_t count, const float* __restrict__ scalar, float* record) {
+  const float m = scalar[0];
+  if (record && blockIdx.x == 0 && threadIdx.x == 0) record[0] = m;      // (the multiplier this backward pass runs under: dls[4])
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    Elem<T>::store(x + i, Elem<T>::load(x + i) * m);
+}
+extern "C" int stp_scale_by_device(void* x, int64_t count, int32_t dtype, const float* scalar, float* record, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;
+  if (!x || !scalar || count <= 0) return STP_E_BADARG;
+  int64_t g = (count + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_H16) hipLaunchKernelGGL(scale_by_device_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, (bf16_t*)x, count, scalar, record);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(scale_by_device_kernel<float>, dim3((int)g), dim3(256), 0, s, (float*)x, count, scalar, record);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+__global__ __launch_bounds__(256) void gscale_finalize_dls_kernel(const float* partial, int blocks, float clipnorm, float base,
+                                                                  float* gscale, float* dls) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 256) a += (double)partial[b];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const float m = dls[0];
+  const double eff = (double)base / (double)m;       // what turns an arena value into the gradient the optimizer sees
+  const double norm = sqrt(sh[0]) * eff;
+  if (!(sh[0] >= 0.0 && sh[0] < 1e300 * 1e300) || !(norm == norm)) {   // overflow: skip the step, halve the multiplier
+    gscale[0] = -1.f;
+    gscale[1] += 1.f;
+    dls[0] = fmaxf(m * 0.5f, dls[3]);
+    dls[1] = 0.f;
+    return;
+  }
+  double k = 1.0;
+  if (clipnorm > 0.f && norm > (double)clipnorm) k = (double)clipnorm / norm;
+  gscale[0] = (float)(k * eff);
+  const float clean = dls[1] + 1.f;
+  if (clean >= dls[2]) { dls[0] = fminf(m * 2.f, dls[5]); dls[1] = 0.f; }
+  else dls[1] = clean;
+}
+
+extern "C" int stp_grad_global_scale_dls(const float* grad, int64_t count, float clipnorm, float base, float* gscale, float* dls,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grad || !gscale || !dls || !workspace || count <= 0) return STP_E_BADARG;
+  if (workspace_bytes < 1024 * sizeof(float)) return STP_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = count / 4096;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(sqsum_partial_kernel, dim3((int)b), dim3(256), 0, s, grad, count, (float*)workspace);
+  STP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gscale_finalize_dls_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, (int)b, clipnorm, base, gscale, dls);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // weight compute copies.  master [Cout][KH][KW][Cin] fp32.
 //   fwd [rows_f][KH][KWp][Cinp]  (rows_f = Cout rounded up to 16; zero padded)

@@ -79,6 +79,7 @@ class Plan(object):
         # the 16-bit storage format is a build parameter of the kernel set: fp16 plans run on libstp_hip_f16.so
         self.lib = _lib.load("fp16" if dtype == "fp16" else "bf16")
         self.loss_scale = 1.0          # fp16: the loss gradient is seeded times this; the optimizer's gscale divides it out
+        self.dls = None                # fp16: device record of the dynamic multiplier on top of it (backend.HipSegModel, stp_scale_by_device)
         self.N = batch
         self.dtype = dtype
         self.tdt = _TD[dtype]
@@ -1383,9 +1384,11 @@ class Plan(object):
             self._emit(self.fwd, "stp_sigmoid_bce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), count, self.cdt, float(w_bce),
                        float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None, logits.gradC,
                        float(self.loss_scale), self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        if self.training and self.dls is not None:
+            self._emit(self.fwd, "stp_scale_by_device", dl.data_ptr(), count * logits.gradC, self.cdt, self.dls.data_ptr(), self.dls.data_ptr() + 16)
         # the class convolution reads its bias gradient from the gradient kernel's per-workgroup sums (not when another launch
-        # adds to the gradient afterwards)
-        logits.meta["loss_bias_grad"] = bool(self.training and not w_lovasz)
+        # adds to / rescales the gradient afterwards)
+        logits.meta["loss_bias_grad"] = bool(self.training and not w_lovasz and self.dls is None)
         if w_lovasz:      # per-image Lovasz hinge: ADDS to scalars[0] and to the gradient the launch above wrote
             if self.training and self.loss_scale != 1.0:
                 raise StpShapeError("lovasz_loss has no loss-scaling form: use loss_scale=1 (or bf16) with it")
@@ -1409,6 +1412,8 @@ class Plan(object):
         self._emit(self.fwd, "stp_softmax_cce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), logits.rows, logits.C, logits.C,
                    self.cdt, float(w_cce), float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None,
                    logits.gradC, float(self.loss_scale), self.ws_loss.data_ptr(), self.ws_loss.numel() * 4)
+        if self.training and self.dls is not None:
+            self._emit(self.fwd, "stp_scale_by_device", dl.data_ptr(), logits.rows * logits.gradC, self.cdt, self.dls.data_ptr(), self.dls.data_ptr() + 16)
         logits.grad_ready = self.training
 
     def softmax_out(self, logits):
@@ -1458,6 +1463,32 @@ class Plan(object):
                 _lib.check(rc, name)
         if forked:
             main.wait_stream(side)
+
+    # launches that read neither the weight compute copies nor the slot arena: they may run next to the weight preparation
+    _PREP_FREE = ("stp_bn_stats", "stp_bn_apply", "stp_bn_inference", "stp_counter_tick")
+
+    def run_prep_fwd(self):
+        """``run(prep); run(fwd)`` with the weight compute copies (they depend on the master parameters only) on the side stream, next to
+        the input BatchNormalization of the raw image (statistics + normalisation: ~25 us of small launches against ~55 us of weight
+        copies on U-Net/ResNet34) - joined before the first launch that reads a weight.  Captured into the step's hipGraph as a
+        fork / join.  OPT-IN (STP_PREP_SIDE=1): measured SLOWER - 7.27 vs 7.13 ms per step on one box (profiles/r04j_schedule_ab.txt): a
+        fork / join inside a hipGraph costs far more (~0.14 ms here) than the 55 us of copies it hides."""
+        k = 0
+        while k < len(self.fwd) and self.fwd[k][2] in self._PREP_FREE:
+            k += 1
+        if os.environ.get("STP_PREP_SIDE", "0") != "1" or not self.prep or k == 0 or self.device.type != "cuda":
+            self.run(self.prep)
+            self.run(self.fwd)
+            return
+        main, side = torch.cuda.current_stream(), self._side_stream()
+        side.wait_stream(main)
+        for fn, args, name, _meta in self.prep:
+            rc = fn(*args, side.cuda_stream)
+            if rc != 0:
+                _lib.check(rc, name)
+        self.run(self.fwd[:k])
+        main.wait_stream(side)
+        self.run(self.fwd[k:])
 
     # loss launches whose third argument is the element / pixel count of the batch ([N, ...] -> the first n_valid samples)
     LOSS_LAUNCHES = ("stp_sigmoid_bce_dice", "stp_softmax_cce_dice", "stp_prob_bce_dice", "stp_sigmoid_loss_ex", "stp_prob_cce_dice")

@@ -107,8 +107,10 @@ class SegModel(object):
                 # the reference downloads these weights; a silent random start would train something else under the same YAML
                 raise RuntimeError(
                     "encoder_weights=%r: no pretrained weights for %r are available offline. Put a checkpoint at %s "
-                    "(safetensors with Keras-layout tensors under the classification_models layer names - convert a Keras "
-                    "model with {w.name: value} -> safetensors), or pass a path as encoder_weights, or set `encoder_weights: null` "
+                    "(safetensors, float32, Keras layout, keys '<layer>/<weight>': 'conv0/kernel' (7, 7, 3, 64) HWIO, 'bn0/gamma', "
+                    "'bn0/moving_mean', 'stage1_unit1_conv1/kernel' ... - the key list is HipSegModel.get_weights().keys(); "
+                    "docs/PRETRAINED_WEIGHTS.md has the layout table and a conversion snippet), or pass a path as encoder_weights, "
+                    "or set `encoder_weights: null` "
                     "in the YAML, or export STP_ALLOW_RANDOM_ENCODER=1 to train from random initialisation knowingly."
                     % (ew, self.backbone_name, pretrained_path(ew, self.backbone_name)))
         if self._pending_weights is not None:

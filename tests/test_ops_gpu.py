@@ -721,9 +721,13 @@ def test_grouped_weight_gradient_with_fused_producer_batchnorm(ops, dtype, group
     gf, gp = ops.WgradGroup(fused_layers), ops.WgradGroup(plain_layers)
     assert gf.header[14] == 1 and gp.header[14] == 0             # WgGroupHeader.pbn: the fused-producer instance is selected per group
     gf.run(); gp.run()
+    same_kernel = gf.header[15] == gp.header[15]               # (the plain 128-channel group runs on the all-taps kernel: another summation order)
     for a, b, ref in zip(dws_f, dws_p, refs):
         np.testing.assert_allclose(host(b).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
-        assert np.array_equal(host(a), host(b))
+        if same_kernel:
+            assert np.array_equal(host(a), host(b))
+        else:
+            np.testing.assert_allclose(host(a), host(b), atol=2e-5 * float(np.abs(ref).max()))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
