@@ -15,7 +15,7 @@ class DS(object):
 m = HipSegModel("Unet", "resnet34", (H, W, 3), 1, "sigmoid", batch=16, dtype="bf16", loss="binary_crossentropy+1.0*dice_loss", optimizer="Adam", lr=1e-3)
 feeder = pipeline.DeviceFeeder(m.device, (H, W), augment.BENCH_SPEC, seed=1)
 tr = pipeline.Trainer(m, feeder, DS(), [], 0, 1)
-idx = list(range(64)) * 4
+idx = list(range(64)) * 24      # 96 steps
 tr.run_epoch(idx[:64], True); torch.cuda.synchronize()
 t0 = time.time(); logs = tr.run_epoch(idx, True); torch.cuda.synchronize(); dt = time.time() - t0
 print("fit loop: %.1f images/s (%.2f ms/step), loss %.4f" % (len(idx) / dt, 1e3 * dt / (len(idx) / 16), logs["loss"]))
