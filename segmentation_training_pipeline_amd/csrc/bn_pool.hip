@@ -894,7 +894,9 @@ static bool bn_fused_ok(int dtype, int64_t rows, int C, int tiles) {
   // measured per shape (U-Net/ResNet34 bs16, eager launches, profiles/r03j_bn_fused_vs_separate.txt): 32 columns (stage 4) 8.1 vs 6.7 + 7.0 us
   // forward and 7.7 vs 11.4 backward, 128 columns (stage 3) 10.4 vs 13.7 and 10.9 vs 12.5, 256 columns (stage 2: 128 KB of partial sums
   // per workgroup, twice its own rows) 14.7 vs 16.0 and 17.8 vs 15.8 - the fused form stops at 128 columns
-  return on && dtype == STP_H16 && (C % BNF_SLAB) == 0 && tiles >= 1 && tiles <= 128 && rows >= 64;
+  // (STP_BN_FUSE_MAXCOLS: A/B switch for the column limit; round 4 re-measured 256 columns with the rows prefetched before the sums)
+  static const int maxcols = getenv("STP_BN_FUSE_MAXCOLS") ? atoi(getenv("STP_BN_FUSE_MAXCOLS")) : 128;
+  return on && dtype == STP_H16 && (C % BNF_SLAB) == 0 && tiles >= 1 && tiles <= maxcols && rows >= 64;
 }
 static int bn_fused_chunks(int64_t rows, int C) {
   // ~8 rows per thread once the CUs are covered (a thread owns 8 channels of a row: 32 rows per workgroup pass)
@@ -913,7 +915,25 @@ __device__ __forceinline__ void bnf_slab_sums(const float* __restrict__ partial,
   const float* ps = partial + (size_t)(c0 + cl) * tiles;
   const float* pq = partial + ((size_t)C + c0 + cl) * tiles;
   s = 0.0; q = 0.0;
-  if ((tiles & 3) == 0 && tiles <= 128) {
+  if ((tiles & 3) == 0 && tiles > 128 && tiles <= 256) {
+    // two batches of the 128-column form below (same order of additions as the generic loop: t ascending per lane)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = 4 * j + 16 * (u + 8 * h);
+        a[u] = b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < tiles) { a[u] = *reinterpret_cast<const f32x4*>(ps + t); b[u] = *reinterpret_cast<const f32x4*>(pq + t); }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (4 * j + 16 * (u + 8 * h) < tiles) {
+          s += ((double)a[u].x + (double)a[u].y) + ((double)a[u].z + (double)a[u].w);
+          q += ((double)b[u].x + (double)b[u].y) + ((double)b[u].z + (double)b[u].w);
+        }
+    }
+  } else if ((tiles & 3) == 0 && tiles <= 128) {
     // (the fused kernels' case.)  All loads first - as a loop with a run-time trip count every one of the up to 8 iterations exposed
     // a memory round trip at the start of EVERY workgroup of the apply pass; then the sums in the same order
     f32x4 a[8], b[8];

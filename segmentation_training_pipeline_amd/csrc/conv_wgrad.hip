@@ -1159,38 +1159,62 @@ __device__ __forceinline__ void conv_wgrad_taps9_body(const WgradArgs& a, const 
   // A step = 2 chunks of 32 pixels x 3 kernel rows = 6 groups of 3 taps x TM MFMAs.  The B fragments of group g + 1 are requested
   // BEFORE the MFMAs of group g (two sets of 12 registers).  `next`: the pieces of tile `nstep` go into ring slot `nb_` BETWEEN the
   // MFMA groups, one per group (an LDS-DMA instruction costs ~60 issue cycles among MFMAs, 100-180 in a burst that opens the step).
-  auto compute = [&](uint32_t st, bool next, int nstep, int nb_) {
-    u32x4 fa[TM], fb[2][3];
+  // Steps are software-pipelined ACROSS the step barrier (-DSTP_T9_NOPIPE: the what-if build without): the barrier of step st + 1 sits in front of the
+  // LAST MFMA group of step st - every wave has waited for its own pieces of tile st + 1 and for every fragment read of the current
+  // slot - and the first fragments of step st + 1 are requested before / right behind those MFMAs.  With the barrier at the top of the
+  // step every wave sat through the first read round trip of every step with the MFMA pipe empty (~400 of ~3700 cycles per step).
+  constexpr int P5 = L < 5 ? L : 5;                          // pieces of the next-but-one tile issued before the last group
+#if defined(STP_T9_NOPIPE)
+  constexpr bool PIPE = false;
+#else
+  constexpr bool PIPE = true;
+#endif
+  u32x4 fa[TM], fb[2][3];
+  auto compute = [&](uint32_t st, uint32_t st_nx, bool more, bool next, int nstep, int nb_) {
     TileGeo tg = {0u, 0u, 0u, 0u};
     if (next) tg = tile_geo(nstep);
-    read_a(st, 0, fa);
-    read_b(st, 0, std::integral_constant<int, 0>{}, fb[0]);
-#define STP_T9_GROUP(G_, C_, KH_, CN_, KHN_)                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
-    if (G_ + 1 < 6) {                                                                                            \
-      read_b(st, CN_, std::integral_constant<int, KHN_>{}, fb[(G_ + 1) & 1]);                                    \
-      wait_frags(std::integral_constant<int, 6>{}, fa, fb[G_ & 1]);                                              \
-    } else {                                                                                                     \
-      wait_frags(std::integral_constant<int, 0>{}, fa, fb[G_ & 1]);                                              \
-    }                                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
+#define STP_T9_MFMAS(G_, KH_)                                                                                    \
     _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                             \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
-        acc[i][KH_ * 3 + kw] = mfma16_16x16x32(fa[i], fb[G_ & 1][kw], acc[i][KH_ * 3 + kw]);                    \
+        acc[i][KH_ * 3 + kw] = mfma16_16x16x32(fa[i], fb[G_ & 1][kw], acc[i][KH_ * 3 + kw]);
+#define STP_T9_GROUP(G_, C_, KH_, CN_, KHN_)                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    read_b(st, CN_, std::integral_constant<int, KHN_>{}, fb[(G_ + 1) & 1]);                                      \
+    wait_frags(std::integral_constant<int, 6>{}, fa, fb[G_ & 1]);                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    STP_T9_MFMAS(G_, KH_)                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     if (G_ < L && next) issue_piece(tg, nb_, G_);                                                                \
     if (G_ == 2) {   /* the A fragments of the second chunk, behind the last MFMAs that read the first */        \
       __builtin_amdgcn_sched_barrier(0);                                                                         \
       read_a(st, 1, fa);                                                                                         \
     }
+    // (fa = A fragments of chunk 0 and fb[0] = group 0 of THIS step are in flight: requested by the prologue / the previous step)
     // (group 2 -> 3: the 2 * TM reads of read_a(1) are OLDER than the 6 of read_b(group 4), so "all but the youngest 6" covers them)
     STP_T9_GROUP(0, 0, 0, 0, 1)
     STP_T9_GROUP(1, 0, 1, 0, 2)
     STP_T9_GROUP(2, 0, 2, 1, 0)
     STP_T9_GROUP(3, 1, 0, 1, 1)
     STP_T9_GROUP(4, 1, 1, 1, 2)
-    STP_T9_GROUP(5, 1, 2, 1, 0)
+    // ---- group 5 (its B fragments were requested in group 4) + the hand-over to the next step
+    __builtin_amdgcn_sched_barrier(0);
+    wait_frags(std::integral_constant<int, 0>{}, fa, fb[1]);        // every LDS read of this wave has returned (the current slot is done with)
+    if (PIPE && more) {
+      if (next) wait_vmcnt<P5>(); else wait_vmcnt<0>();              // own pieces of tile st + 1 have landed (the P5 youngest: tile st + 2)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(st_nx, 0, std::integral_constant<int, 0>{}, fb[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STP_T9_MFMAS(5, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    if (5 < L && next) issue_piece(tg, nb_, 5);
+    if (PIPE && more) {
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(st_nx, 0, fa);
+    }
 #undef STP_T9_GROUP
+#undef STP_T9_MFMAS
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -1198,14 +1222,22 @@ __device__ __forceinline__ void conv_wgrad_taps9_body(const WgradArgs& a, const 
 #pragma unroll
   for (int q = 0; q < STAGES - 1; ++q)
     if (q < nst) issue_tile(step0 + q, q);
+  static_assert(STAGES == 3, "the pipelined hand-over assumes the 3-slot ring");
+  if (nst > 1) wait_vmcnt<L>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  read_a(lds0, 0, fa);
+  read_b(lds0, 0, std::integral_constant<int, 0>{}, fb[0]);
   int buf = 0, nbuf = STAGES - 1;
   for (int st = 0; st < nst; ++st) {
-    const int ahead = nst - 1 - st;      // tiles after this one
-    if (STAGES >= 3 && ahead >= STAGES - 2) wait_vmcnt<(STAGES - 2) * L>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    compute(lds0 + (uint32_t)(buf * STAGE), st + STAGES - 1 < nst, step0 + st + STAGES - 1, nbuf);
-    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    const int nx = (buf + 1 == STAGES) ? 0 : buf + 1;
+    if (!PIPE && st > 0) {                                   // (what-if build: barrier and first reads at the top of every step)
+      if (st + 1 < nst) wait_vmcnt<L>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      read_a(lds0 + (uint32_t)(buf * STAGE), 0, fa);
+      read_b(lds0 + (uint32_t)(buf * STAGE), 0, std::integral_constant<int, 0>{}, fb[0]);
+    }
+    compute(lds0 + (uint32_t)(buf * STAGE), lds0 + (uint32_t)(nx * STAGE), st + 1 < nst, st + STAGES - 1 < nst, step0 + st + STAGES - 1, nbuf);
+    buf = nx;
     nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
   }
 
