@@ -103,9 +103,10 @@ typedef struct stp_conv_params {
   /* Gradient of UpSampling2D(2) folded into the epilogue of the data-gradient convolution whose (virtual) destination
    * is the upsampled tensor: with dst_sum2x2 != 0, dst0 is [N,Ho/2,Wo/2,Cout] and receives the sum of each 2x2 block
    * (the hi-res gradient is never written); bnb_x / stats_partial / accumulate0 then refer to that low-resolution
-   * tensor.  Small-channel kernel only (stp_conv2d_sc_eligible), Ho and Wo even, no bias / relu.
+   * tensor.  Small-channel kernel (stp_conv2d_sc_eligible), Ho and Wo even, no bias / relu - and, for 64+ channels, the halo kernel
+   * in its fused form (bnb_x set, Cd0 a multiple of the variant's channel tile: conv_halo.hip's EP 3, with or without dst1).
    * With a second destination (dst1 != NULL: the data gradient of conv3x3(concat(UpSampling2D(2)(x), skip)), served by the
-   * wide-output kernel, stp_conv2d_scw_eligible) only dst0 - the first Cd0 channels - is summed, and bnb_x / stats_partial
+   * wide-output kernel, stp_conv2d_scw_eligible, or by the halo kernel) only dst0 - the first Cd0 channels - is summed, and bnb_x / stats_partial
    * refer to those Cd0 channels; dst1 stays [N,Ho,Wo,Cout-Cd0]. */
   int32_t dst_sum2x2;
   /* stats_slots > 0 (a power of two <= 64): stats_partial points to PRE-ZEROED int64 fixed-point slots [2][Cout][stats_slots]

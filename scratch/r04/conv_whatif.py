@@ -28,7 +28,7 @@ def timeit(q, reps=20):
     e1.record(st); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 
-want = [("stage2_unit1_conv1", "dgrad"), ("stage3_unit1_conv1", "dgrad"), ("stage4_unit1_conv1", "dgrad"), ("stage1_unit1_sc", "dgrad")]
+want = [("stage2_unit1_conv1", "dgrad"), ("stage3_unit1_conv1", "dgrad"), ("stage1_unit1_sc", "dgrad"), ("stage1_unit1_sc", "fwd"), ("stage2_unit1_conv1", "fwd")]
 import functools
 print = functools.partial(print, flush=True)
 for fn, args, name, meta in m.plan.fwd + m.plan.bwd:
@@ -54,8 +54,3 @@ for fn, args, name, meta in m.plan.fwd + m.plan.bwd:
     if p.accumulate0:
         q = clone(p); q.accumulate0 = 0
         print("  no accumulate             %8.1f us" % timeit(q))
-    for tile in (65, 66, 69, 70, 71, 97, 101, 102, 103):
-        q = clone(p); q.tile = tile
-        t = timeit(q)
-        if t is not None:
-            print("  tile %3d                  %8.1f us" % (tile, t))

@@ -41,6 +41,7 @@ struct ConvArgs {
   int fold_cpt;
   uint32_t bytes_fold, bytesw_fold;
   int no_rm;      // 1: keep the fragment-order epilogue (STP_IGEMM_RM=0: A/B of the row-major one)
+  int sum2x2;     // halo kernel, two destinations: dst0 = [N][Ho/2][Wo/2][Cd0] receives the 2 x 2 block sums of the first Cd0 channels (+ bnb)
 };
 
 // logical (parity-class major) pixel -> n, ho, wo
@@ -468,7 +469,8 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   }
   a.stats = p->stats_partial;
   a.stat_slots = p->stats_slots;
-  if (a.stats && ((p->Cout & 3) || p->Cd0 != p->Cout)) return STP_E_BADARG;
+  if (a.stats && ((p->Cout & 3) || (p->Cd0 != p->Cout && !p->dst_sum2x2))) return STP_E_BADARG;   // (two destinations: only the 2 x 2-summed form has sums)
+  a.sum2x2 = p->dst_sum2x2 ? 1 : 0;
   if (a.stat_slots && (!a.stats || (a.stat_slots & (a.stat_slots - 1)) || a.stat_slots > 64)) return STP_E_BADARG;
   a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
   a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;

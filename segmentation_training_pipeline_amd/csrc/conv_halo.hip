@@ -68,6 +68,9 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 // time (no per-element branches) and the arithmetic is written on float pairs (v_pk_* instructions).
 //   EP 0: bias / residual / accumulate / ReLU                      EP 1: EP 0 + sum, sum of squares of the stored values
 //   EP 2: (accumulate) + BatchNormalization-backward: store g = dY under the activation mask, reduce sum g and sum g * xhat
+//   EP 3: two destinations (data gradient of conv3x3(concat(UpSampling2D(2)(x), skip))): channel tiles below Cd0 sum every 2 x 2 pixel
+//         block of the staged fp32 tile and treat the LOW-RESOLUTION result as EP 2 does (accumulate, mask, sums over [2][Cd0][tiles]) -
+//         the gradient of the upsampled tensor is never written, stp_upsample2x_bwd_bn disappears; tiles at or above Cd0: EP 0 into dst1
 // Same arithmetic per element as conv_common.h's epilogue (sum g * xhat is accumulated as sum g * x and centred once per channel).
 // (f32x2v / unpack_bf16x2: conv_common.h)
 
@@ -87,8 +90,10 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
   T* const dbase = first ? reinterpret_cast<T*>(a.dst0) + co : reinterpret_cast<T*>(a.dst1) + (co - a.Cd0);
   const int dC = first ? a.Cd0 : a.Cd1;
   const bool accum = first ? a.acc0 : a.acc1;
-  const T* res = EP == 2 ? reinterpret_cast<const T*>(a.bnb.x) : reinterpret_cast<const T*>(a.residual);
+  const T* res = EP == 2 ? reinterpret_cast<const T*>(a.bnb.x) : reinterpret_cast<const T*>(a.residual);      // (EP 3: no residual)
 
+  // EP 3, channel tile of the UPSAMPLED source (cout0 < Cd0, the whole tile: Cd0 % BM == 0): see below
+  const bool summed = EP == 3 && cout0 < a.Cd0;
   // global operands of this thread's NP pixels: issued before the staging so their latency hides under it
   int pm[NP];
   u32x4 opr[NP], opa[NP];
@@ -97,7 +102,7 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
     const int px = p0 + k * PP;
     pm[k] = n * a.HoWo + (y0 + (px >> 4)) * a.Wo + x0 + (px & 15);
   }
-  if (cok) {
+  if (cok && !summed) {
     if (res) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) opr[k] = *reinterpret_cast<const u32x4*>(res + (size_t)pm[k] * a.Cout + co);
@@ -123,7 +128,69 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
   f32x2v ss[4], qq[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) ss[e] = qq[e] = f32x2v{0.f, 0.f};
-  if (cok) {
+  // EP 3, channel tile of the UPSAMPLED source (cout0 < Cd0, whole tile: Cd0 % BM == 0): 2 x 2 block sums of the staged tile -> the
+  // low-resolution gradient [N][Ho/2][Wo/2][Cd0], accumulated / masked / summed as EP 2 does (a.bnb refers to that tensor)
+  if (EP == 3 && summed && cok) {
+    constexpr int LNPX = NPX / 4, NLP = (LNPX + PP - 1) / PP;
+    const int Hl = a.Ho >> 1, Wl = a.Wo >> 1;
+    const T* const xlow = reinterpret_cast<const T*>(a.bnb.x);
+    T* const dlow = reinterpret_cast<T*>(a.dst0);
+    size_t plow[NLP];
+    u32x4 oxl[NLP], oal[NLP];
+#pragma unroll
+    for (int k = 0; k < NLP; ++k) {
+      const int lp = p0 + k * PP;
+      plow[k] = ((size_t)n * Hl * Wl + (size_t)((y0 >> 1) + (lp >> 3)) * Wl + (x0 >> 1) + (lp & 7)) * a.Cd0 + co;
+      if (lp < LNPX) {
+        oxl[k] = *reinterpret_cast<const u32x4*>(xlow + plow[k]);
+        if (a.acc0) oal[k] = *reinterpret_cast<const u32x4*>(dlow + plow[k]);
+      }
+    }
+    f32x2v ksc[4], ksh[4];
+    {
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co + 4);
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co + 4);
+      f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (a.bnb.gamma) { g0 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + co); g1 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + co + 4); }
+      if (a.bnb.beta) { b0 = *reinterpret_cast<const f32x4*>(a.bnb.beta + co); b1 = *reinterpret_cast<const f32x4*>(a.bnb.beta + co + 4); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float r = e < 4 ? r0[e & 3] : r1[e & 3], mu = e < 4 ? m0[e & 3] : m1[e & 3];
+        const float sc = a.bnb.gamma ? r * (e < 4 ? g0[e & 3] : g1[e & 3]) : r;
+        ksc[e >> 1][e & 1] = sc;
+        ksh[e >> 1][e & 1] = (e < 4 ? b0[e & 3] : b1[e & 3]) - mu * sc;
+      }
+    }
+    const float alo = a.bnb.relu ? __uint_as_float(1u) : -__builtin_inff();
+    const float ahi = a.bnb.relu == 2 ? __uint_as_float(0x40bfffffu) : __builtin_inff();
+#pragma unroll
+    for (int k = 0; k < NLP; ++k) {
+      const int lp = p0 + k * PP;
+      if (lp >= LNPX) continue;
+      const int hp = ((lp >> 3) * 2) * 16 + (lp & 7) * 2;       // top-left pixel of the 2 x 2 block in the staged tile
+      f32x2v v[4] = {f32x2v{0.f, 0.f}, f32x2v{0.f, 0.f}, f32x2v{0.f, 0.f}, f32x2v{0.f, 0.f}};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int px = hp + (q >> 1) * 16 + (q & 1);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
+        v[0] += f32x2v{v0.x, v0.y}; v[1] += f32x2v{v0.z, v0.w}; v[2] += f32x2v{v1.x, v1.y}; v[3] += f32x2v{v1.z, v1.w};
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.acc0) v[e] += unpack_bf16x2(oal[k][e]);
+        const uint32_t st = pack_bf16x2(v[e].x, v[e].y);          // dY of the low-resolution tensor as it would be stored
+        const f32x2v xv = unpack_bf16x2(oxl[k][e]), dy = unpack_bf16x2(st);
+        const f32x2v tt = xv * ksc[e] + ksh[e];
+        const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+        ss[e] += g;
+        qq[e] += g * xv;
+        o[e] = pack_bf16x2(g.x, g.y);
+      }
+      *reinterpret_cast<u32x4*>(dlow + plow[k]) = o;
+    }
+  }
+  if (cok && !summed) {
     // per-channel constants of the thread's 8 channels, as pairs
     f32x2v bias2[4], ksc[4], ksh[4];
 #pragma unroll
@@ -187,9 +254,10 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
 #if defined(STP_EXP) && STP_EXP == 31   // what-if: no cross-thread reduction / partial-sum stores (values kept live)
   if (EP >= 1 && a.P < 0) {
 #else
+  if (EP == 3 && !summed) return;                                // (workgroup-uniform: the skip tensor's tiles have no sums)
   if (EP >= 1) {
 #endif
-    if (EP == 2 && cok) {   // sum g * xhat = rstd * (sum g * x - mean * sum g), per thread (linear, so the partition does not matter)
+    if ((EP == 2 || EP == 3) && cok) {   // sum g * xhat = rstd * (sum g * x - mean * sum g), per thread (linear, so the partition does not matter)
       const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co + 4);
       const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co + 4);
 #pragma unroll
@@ -227,7 +295,8 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
 #pragma unroll
       for (int q = 0; q < NPART; ++q) tot += r2[q * NOUT + tid];
       const int k = tid / CG, ch = (tid % CG) * 8 + (k >> 2) * 2 + (k & 1), stat = (k >> 1) & 1;
-      if (cout0 + ch < a.Cout) a.stats[((size_t)stat * a.Cout + cout0 + ch) * a.ntile_n + tile_n] = tot;
+      const int Cs = EP == 3 ? a.Cd0 : a.Cout;                  // EP 3: the table covers the summed destination's channels
+      if (cout0 + ch < Cs) a.stats[((size_t)stat * Cs + cout0 + ch) * a.ntile_n + tile_n] = tot;
     }
   }
 }
@@ -519,6 +588,7 @@ static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
 
 template <int TH, int BM, int WM, int WN>
 static int launch_halo(ConvArgs& a, hipStream_t s) {
+  if (a.sum2x2) return launch_halo_ep<TH, BM, WM, WN, 3>(a, s);
   if (a.bnb.x) return launch_halo_ep<TH, BM, WM, WN, 2>(a, s);
   if (a.stats) return launch_halo_ep<TH, BM, WM, WN, 1>(a, s);
   return launch_halo_ep<TH, BM, WM, WN, 0>(a, s);
@@ -527,7 +597,11 @@ static int launch_halo(ConvArgs& a, hipStream_t s) {
 static bool halo_shape_ok(const stp_conv_params* p) {
   return p && p->dtype == STP_H16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->src0_mode == STP_SRC_DIRECT &&
          p->C1 == 0 && p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv && p->Hs0 == p->Hv && p->Ws0 == p->Wv &&
-         (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->dst_sum2x2 && !p->stats_slots &&
+         (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->stats_slots &&
+         // 2 x 2-summed first destination (EP 3): two destinations, fused BatchNormalization backward of the summed one, whole 64-channel tiles
+         // (or ONE destination, every channel tile summed: Cd0 == Cout, the data gradient of conv3x3(UpSampling2D(2)(x)))
+         (!p->dst_sum2x2 || (p->bnb_x && (p->Cd0 % 64) == 0 && !p->bias && !p->relu && !p->residual &&
+                             (p->Cd0 == p->Cout || (p->dst1 && p->Cd0 < p->Cout)))) &&
          (p->Cd0 % 8) == 0 &&
          (!p->src_bn_mean || (p->src_bn_rstd && p->C0 <= 512));
 }
@@ -560,12 +634,15 @@ static int halo_auto(const stp_conv_params* p) {
 
 extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p) {
   if (!p) return -1;
+  int v = -1;
   if (p->tile >= STP_TILE_HALO && p->tile < STP_TILE_HALO + HALO_NCFG) {
-    const int v = p->tile - STP_TILE_HALO;
+    v = p->tile - STP_TILE_HALO;
     if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && p->C0 != 64)) return -1;
-    return v;
+  } else if (p->tile == 0) {
+    v = halo_auto(p);
   }
-  return p->tile == 0 ? halo_auto(p) : -1;
+  if (v >= 0 && p->dst_sum2x2 && (p->Cd0 % HALO_CFGS[v].bm)) return -1;      // (a channel tile lies in ONE destination)
+  return v;
 }
 
 // number of pixel tiles (BatchNormalization partial-sum columns) of a variant
@@ -582,6 +659,7 @@ extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stre
   if (rc != STP_OK) return rc;
   if (ut != 1) return STP_E_BADARG;   // 32-bit buffer offsets, 64-channel K-steps
   if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->relu || p->residual)) return STP_E_BADARG;
+  if (a.sum2x2 && (!a.bnb.x || (p->Cd0 % HALO_CFGS[variant].bm))) return STP_E_BADARG;
   const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_halo_tiles(p, variant);
   hipStream_t s = (hipStream_t)stream;
   switch (variant) {

@@ -892,6 +892,18 @@ class Plan(object):
                         q.accumulate0 = int(x.grad_ready)
                     else:
                         q.dst_sum2x2 = 0
+                        # the halo kernel's summed epilogue (EP 3) for 64+ channels - in its fused form only (see the two-destination case below)
+                        if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses", 0) == 1 and not x.grad_ready
+                                and self.slot_arena is None and os.environ.get("STP_HALO_FOLD_UP", "1") != "0"):
+                            keep = (q.dst0, q.accumulate0)
+                            q.dst_sum2x2, q.dst0, q.accumulate0 = 1, self._gradbuf(x).data_ptr(), 0
+                            q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
+                            if int(self.lib.stp_conv2d_halo_variant(C.byref(q))) >= 0:
+                                folded_up = True
+                            else:
+                                q.dst_sum2x2, (q.dst0, q.accumulate0) = 0, keep
+                                q.bnb_x = q.bnb_mean = q.bnb_rstd = q.bnb_gamma = q.bnb_beta = None
+                                q.bnb_relu = 0
                 two_dest = False
                 if upsample and x_ng and C1 and w4 is None and self.fold_upsample_grad:
                     # ... and the wide-output kernel does the same for conv3x3(concat(UpSampling2D(2)(x), skip)): the first C0
@@ -903,6 +915,21 @@ class Plan(object):
                         q.accumulate0 = int(x.grad_ready)
                     else:
                         q.dst_sum2x2 = 0
+                        # ... and the halo kernel (64+ channel decoder stages, round 4): its epilogue sums the 2 x 2 blocks of the channel
+                        # tiles of the upsampled source and runs the fused BatchNormalization backward on the LOW-resolution result
+                        # (EP 3) - only in that fused form, i.e. when this launch completes the gradient of a BatchNormalization output
+                        # that nothing else reads
+                        if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses", 0) == 1 and not x.grad_ready
+                                and self.slot_arena is None and os.environ.get("STP_HALO_FOLD_UP", "1") != "0"):
+                            keep = (q.dst0, q.accumulate0)
+                            q.dst_sum2x2, q.dst0, q.accumulate0 = 1, self._gradbuf(x).data_ptr(), 0
+                            q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
+                            if int(self.lib.stp_conv2d_halo_variant(C.byref(q))) >= 0:
+                                folded_up = two_dest = True
+                            else:
+                                q.dst_sum2x2, (q.dst0, q.accumulate0) = 0, keep
+                                q.bnb_x = q.bnb_mean = q.bnb_rstd = q.bnb_gamma = q.bnb_beta = None
+                                q.bnb_relu = 0
                 uses = x.meta.get("uses", 0)
                 # the only consumer, or the LAST of several (every other consumer has already written or accumulated its
                 # share, this data gradient accumulates on top): its epilogue sees the complete gradient of the BN output

@@ -503,6 +503,78 @@ def test_conv_halo_kernel_batchnorm_backward_sums(ops, case, relu, dtype):
     np.testing.assert_allclose(dx1, dx0, atol=tol(dx0, dtype))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 64, 0), (1, 16, 16, 128, 256, 128, 1), (1, 32, 16, 64, 128, 64, 4), (2, 8, 16, 64, 64, 128, 3)])
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("dtype", H16)
+def test_conv_halo_kernel_two_destinations_with_summed_upsampling_gradient(ops, case, relu, dtype):
+    """dst_sum2x2 + dst1 on the halo kernel (EP 3): the data gradient of conv3x3(concat(UpSampling2D(2)(x), skip)) - the channel tiles of
+    the upsampled source are summed over 2 x 2 pixel blocks in the epilogue and receive the fused BatchNormalization backward of the
+    LOW-resolution tensor (mask + [2][Cd0][tiles] sums), the skip channels go to dst1 (accumulated) at full resolution.  Against float64
+    numpy (conv2d_dgrad -> upsample2x_bwd -> mask / BatchNormalization backward), and the dx of stp_bn_backward_fused on the table."""
+    n, h, w, ci, cd0, cd1, var = case                  # h, w: the (virtual) high-resolution size = dY's size
+    rng = np.random.RandomState(91)
+    co = cd0 + cd1
+    dy = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)                    # data-gradient weights in forward form: dY (ci) -> d(input) (co)
+    xlow = q(rng.randn(n, h // 2, w // 2, cd0) * 1.5 + 0.3, dtype)              # BatchNormalization input of the upsampled tensor
+    skip_prev = q(rng.randn(n, h, w, cd1), dtype)                               # gradient already in the skip tensor's buffer
+    gamma, beta = (rng.rand(cd0) + 0.5).astype(np.float32), (rng.randn(cd0) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    rows_low = n * (h // 2) * (w // 2)
+    xd, g, b = dev(xlow, dtype), f(gamma), f(beta)
+    m, r = torch.empty(cd0, device=DEV), torch.empty(cd0, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(cd0) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows_low, cd0, 1e-3, 0.99, m, r, None, None, ws)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    d0 = torch.full((n, h // 2, w // 2, cd0), float("nan"), dtype=TD[dtype], device=DEV)
+    d1 = dev(skip_prev, dtype)
+    P = ops.conv_params(dev(dy, dtype), fwd, d0, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co,
+                        dtype=ops.dt(d0), tile=1024 + var, dst1=d1, Cd0=cd0, accumulate1=1)
+    P.dst_sum2x2 = 1
+    P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), relu
+    nfl = ops.conv2d_stats_floats(P)
+    st = torch.full((max(4, nfl),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    tiles = nfl // (2 * cd0)
+    assert tiles == P.stats_tiles and tiles > 0
+    # numpy: full-resolution data gradient, then the two halves
+    full = np_ops.conv2d(dy, wt, 1, 1)
+    low = np_ops.upsample2x_bwd(full[..., :cd0])
+    mean, rstd = host(m).astype(np.float64), host(r).astype(np.float64)
+    pre = (xlow - mean) * rstd * gamma + beta
+    mask = (pre > 0) if relu else np.ones_like(pre, bool)
+    gref = low * mask
+    got = host(d0)
+    near = np.abs(pre) < 1e-2 * (np.abs(pre).max() + 1.0)                       # a pre-activation within rounding of 0 may take either side
+    np.testing.assert_allclose(got[~near], gref[~near], atol=tol(low, dtype))
+    np.testing.assert_allclose(host(d1), skip_prev + full[..., cd0:], atol=tol(full, dtype, 2))
+    dx, dg, db = torch.empty_like(d0), torch.empty(cd0, device=DEV), torch.empty(cd0, device=DEV)
+    ops.bn_backward_fused(xd, d0, dx, rows_low, cd0, m, r, g, st, tiles, dg, db, accumulate_dx=0, workspace=ws)
+    gh = host(d0).astype(np.float64)                                            # the sums must be those of the STORED masked gradient
+    xh = (xlow - mean) * rstd
+    sc = lambda a: 2e-3 * np.abs(a).max() + 1e-3
+    np.testing.assert_allclose(host(db), gh.sum(axis=(0, 1, 2)), atol=sc(gh.sum(axis=(0, 1, 2))))
+    np.testing.assert_allclose(host(dg), (gh * xh).sum(axis=(0, 1, 2)), atol=sc((gh * xh).sum(axis=(0, 1, 2))))
+    dxr = gamma * rstd * (gh - gh.mean(axis=(0, 1, 2)) - xh * (gh * xh).mean(axis=(0, 1, 2)))
+    np.testing.assert_allclose(host(dx), dxr, atol=tol(dxr, dtype, 2))
+    # a channel tile must lie in one destination: Cd0 = 96 cannot take 64- or 128-channel tiles
+    P.Cd0 = cd0 - 32
+    assert ops._lib.load().stp_conv2d_halo_variant(ops.C.byref(P)) == -1
+    # ONE destination, every channel tile summed (the data gradient of conv3x3(UpSampling2D(2)(x)), Linknet's decoder): Cd0 == Cout
+    wt1 = wt[..., :cd0].copy()
+    _, fwd1, _, _ = prep_weights(ops, wt1, dtype)
+    e0 = torch.full((n, h // 2, w // 2, cd0), float("nan"), dtype=TD[dtype], device=DEV)
+    P1 = ops.conv_params(dev(dy, dtype), fwd1, e0, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=cd0,
+                         dtype=ops.dt(e0), tile=1024 + var)
+    P1.dst_sum2x2 = 1
+    P1.bnb_x, P1.bnb_mean, P1.bnb_rstd, P1.bnb_gamma, P1.bnb_beta, P1.bnb_relu = ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), relu
+    st1 = torch.full((max(4, ops.conv2d_stats_floats(P1)),), float("nan"), dtype=torch.float32, device=DEV)
+    P1.stats_partial = ops.ptr(st1)
+    ops.conv2d(P1)
+    assert np.array_equal(host(e0), got) and np.array_equal(host(st1), host(st))        # same tiles, same arithmetic as the two-destination launch
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_stem_conv_7x7_s2_padded_channels(ops, dtype):
     """conv0: 7x7/2 over a 3-channel image stored as 4 channels (4th = 1), weights padded to 7x8x4."""
