@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet", "FPN"],
                     help="Unet = BASELINE.json's headline workload; Linknet = SURVEY 8f N1 on the same kernels (not the headline metric)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (for rocprofv3 kernel traces of the launches themselves)")
+    ap.add_argument("--no-feed", action="store_true", help="skip the region fed from pinned host memory (profiler traces of the resident step only)")
     ap.add_argument("--sustain", type=float, default=8.0,
                     help="seconds of extra back-to-back steps after the counted ones, reported as `sustained` (0 = skip; 1-GPU runs only)")
     args = ap.parse_args()
@@ -395,9 +396,11 @@ def main():
     if overlap:
         stage(1)
         feed_into_plan(0, torch.cuda.current_stream())
-    for i in range(2):
-        step_fed(i)
-    elapsed_fed = timed(step_fed, 2, args.steps)
+    elapsed_fed = None
+    if not args.no_feed:
+        for i in range(2):
+            step_fed(i)
+        elapsed_fed = timed(step_fed, 2, args.steps)
     torch.cuda.synchronize()
 
     # ---- a LONG region of the resident step (world 1 only): the 20 counted steps last 0.15 s, which a 5 s utilisation sampler
@@ -422,8 +425,8 @@ def main():
         "step_mfma_frac": round(images_per_sec / world * flop_per_image(model) / (PEAK_BF16_TFLOPS * 1e12), 4),
         # the same K steps with every batch copied from pinned host memory (double-buffered hipMemcpyAsync on a copy stream)
         "ms_per_step_resident": round(1e3 * elapsed / args.steps, 3),
-        "ms_per_step_with_feed": round(1e3 * elapsed_fed / args.steps, 3),
-        "value_with_feed": round(world * BATCH * args.steps / elapsed_fed, 2),
+        "ms_per_step_with_feed": round(1e3 * elapsed_fed / args.steps, 3) if elapsed_fed else None,
+        "value_with_feed": round(world * BATCH * args.steps / elapsed_fed, 2) if elapsed_fed else None,
     }
     if sustained is not None:
         out["sustained"] = {"steps": sustained[0], "seconds": round(sustained[1], 3), "ms_per_step": round(1e3 * sustained[1] / sustained[0], 3),

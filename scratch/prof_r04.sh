@@ -6,7 +6,7 @@ T=${1:-r04z}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
-Q="--no-cpu-baseline --sustain 0"
+Q="--no-cpu-baseline --sustain 0 --no-feed"
 python bench.py --steps 100 --warmup 10 > $O/bench.json 2> $O/bench.err
 python bench.py > $O/bench_default.json 2>> $O/bench.err
 python bench.py --dtype fp32 --steps 10 --warmup 3 $Q --no-kernel-profile > $O/bench_fp32.json 2>> $O/bench.err
@@ -29,9 +29,11 @@ rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 idx=[i for i,r in enumerate(rows) if "augment_kernel" in r["Kernel_Name"]]
 idx=idx[-10:]
 seg=rows[idx[0]:]
-t0=int(seg[0]["Start_Timestamp"]); t1=max(int(r["End_Timestamp"]) for r in seg)
-busy=sum(int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in seg)
-print("last %d steps: kernels/step %.1f  wall/step %.1f us  sum of kernel durations/step %.1f us  gaps/step %.1f us"%(len(idx),len(seg)/len(idx),(t1-t0)/1e3/len(idx),busy/1e3/len(idx),((t1-t0)-busy)/1e3/len(idx)))
+# wall clock per step from augmentation kernel to augmentation kernel (9 intervals; kernels launched after the run do not count)
+wall=(int(rows[idx[-1]]["Start_Timestamp"])-int(rows[idx[0]]["Start_Timestamp"]))/(len(idx)-1)
+inner=rows[idx[0]:idx[-1]]
+busy=sum(int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in inner)/(len(idx)-1)
+print("last %d steps: kernels/step %.1f  wall/step %.1f us  sum of kernel durations/step %.1f us  gaps/step %.1f us"%(len(idx),len(inner)/(len(idx)-1),wall/1e3,busy/1e3,(wall-busy)/1e3))
 fam={}
 for r in seg:
     k=r["Kernel_Name"].split("(")[0].replace("void ","")

@@ -54,3 +54,17 @@ for fn, args, name, meta in m.plan.fwd + m.plan.bwd:
     if p.accumulate0:
         q = clone(p); q.accumulate0 = 0
         print("  no accumulate             %8.1f us" % timeit(q))
+    if meta["pass"] == "dgrad" and meta.get("tile", 0) in (65, 70, 71):
+        for tile in (meta["tile"] + 32, meta["tile"] + 64):      # same pixel / channel tile, 3 and 4 ring stages (same partial-sum columns)
+            q = clone(p); q.tile = tile
+            t = timeit(q)
+            print("  tile %3d                  %s" % (tile, "refused" if t is None else "%8.1f us" % t))
+        for tile in (69, 101, 66, 98, 70, 102, 65):      # other pixel / channel tiles: own partial-sum buffer of the size that tile needs
+            q = clone(p); q.tile = tile
+            nfl = int(lib.stp_conv2d_stats_floats(C.byref(q)))
+            if nfl <= 0:
+                print("  tile %3d                  not available" % tile); continue
+            buf = torch.empty(nfl + 1024, dtype=torch.float32, device="cuda")
+            q.stats_partial = buf.data_ptr()
+            t = timeit(q)
+            print("  tile %3d                  %s" % (tile, "refused" if t is None else "%8.1f us" % t))
