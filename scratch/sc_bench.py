@@ -21,7 +21,8 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 a = torch.empty(134217728 // 2, device=DEV, dtype=torch.bfloat16); b = torch.empty_like(a)
 us = timeit(lambda: b.copy_(a)); print("copy 134 MB -> 134 MB: %.1f us = %.2f TB/s" % (us, 2 * 134.2 / us))
-for name, n, h, w, ci, co, up in LAYERS:
+ONLY = os.environ.get("ONLY")      # ONLY=<feature>: just that variant of the 16->16 @512 layer (PMC runs)
+for name, n, h, w, ci, co, up in ([] if ONLY else LAYERS):
     hs, ws = (h // 2, w // 2) if up else (h, w)
     x = torch.randn(n, hs, ws, ci, device=DEV).to(torch.bfloat16)
     wt = (torch.randn(max(co, 16), 3, 3, ci, device=DEV) / (9 * ci) ** 0.5).to(torch.bfloat16)
@@ -40,7 +41,7 @@ y = torch.empty(n, h, w, co, device=DEV, dtype=torch.bfloat16)
 xb = torch.randn(n, h, w, co, device=DEV).to(torch.bfloat16)
 f32 = lambda k: torch.rand(k, device=DEV) + 0.5
 m, r, g, b = f32(16), f32(16), f32(16), f32(16)
-for feat in ("plain", "pbn", "stats", "pbn+stats", "bnb", "pbn+bnb"):
+for feat in ((ONLY,) if ONLY else ("plain", "pbn", "stats", "pbn+stats", "bnb", "pbn+bnb")):
     P = ops.conv_params(x, wt, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.BF16)
     if "pbn" in feat:
         P.src_bn_mean, P.src_bn_rstd, P.src_bn_gamma, P.src_bn_beta, P.src_bn_relu = ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1

@@ -12,64 +12,7 @@
 //   C[cout][pixel] = sum_k W[cout][k] * halo[pixel + tap(k)][ch(k)],   k = tap*Cin + ch, tap = kh*3 + kw
 // The k -> (lane group, vector slot) assignment is the same for A and B (all a contraction needs).
 // Used for forward and (with the flipped/transposed weight copy) for the data gradient.
-#include "common.h"
-#include <cstdlib>
-#include <type_traits>
-
-struct ScArgs {
-  const char* src;     // [N,Hs,Ws,CIN]  (Hs = H/2 when upsampling)
-  const char* weight;  // [Cout_pad16][9*CIN]
-  const float* bias;
-  char* dst;           // [N,H,W,Cout]
-  int N, H, W, Hs, Ws, Cout, up, accumulate, relu;
-  int tiles_x, tiles_y;
-  FastDiv divTx, divTy;
-  float* stats;        // optional fused BatchNorm statistics [2][Cout][tiles] (or int64 slots, see stat_slots)
-  int stat_slots;
-  BnBack bnb;          // see stp_conv_params.bnb_x
-  int sum2;            // see stp_conv_params.dst_sum2x2: dst is [N,H/2,W/2,Cout]
-  uint32_t src_bytes;  // size of src (buffer descriptor of the streaming kernel's LDS-DMA)
-  BnBack pbn;          // see stp_conv_params.src_bn_mean: src is normalised while it is staged (pbn.x unused)
-};
-
-// BatchNormalization (+activation) of one staged 16-byte vector: V consecutive channels with per-lane constants.  Same fma,
-// activation and bf16 rounding as bn_apply_kernel, so the staged tile equals what stp_bn_apply would have stored.
-template <typename T> struct ScStageBn;
-template <> struct ScStageBn<float> {
-  f32x4 sc, sh;
-  __device__ __forceinline__ void load(const BnBack& b, int c) { const BnBackCh k = bnback_load(b, c); sc = k.sc; sh = k.sh; }
-  __device__ __forceinline__ void load_tab(const float* tsc, const float* tsh, int c) {
-    sc = *reinterpret_cast<const f32x4*>(tsc + c); sh = *reinterpret_cast<const f32x4*>(tsh + c);
-  }
-  __device__ __forceinline__ u32x4 apply(const u32x4& r, int relu) const {
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(bn_act(bn_affine(__uint_as_float(r[e]), sc[e], sh[e]), relu));
-    return o;
-  }
-};
-template <> struct ScStageBn<bf16_t> {
-  f32x2 sc[4], sh[4];   // channel pairs: one v_pk_fma_f32 each
-  __device__ __forceinline__ void load(const BnBack& b, int c) {
-    const BnBackCh k0 = bnback_load(b, c), k1 = bnback_load(b, c + 4);
-    sc[0] = f32x2{k0.sc[0], k0.sc[1]}; sc[1] = f32x2{k0.sc[2], k0.sc[3]}; sc[2] = f32x2{k1.sc[0], k1.sc[1]}; sc[3] = f32x2{k1.sc[2], k1.sc[3]};
-    sh[0] = f32x2{k0.sh[0], k0.sh[1]}; sh[1] = f32x2{k0.sh[2], k0.sh[3]}; sh[2] = f32x2{k1.sh[0], k1.sh[1]}; sh[3] = f32x2{k1.sh[2], k1.sh[3]};
-  }
-  __device__ __forceinline__ void load_tab(const float* tsc, const float* tsh, int c) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { sc[e] = *reinterpret_cast<const f32x2*>(tsc + c + 2 * e); sh[e] = *reinterpret_cast<const f32x2*>(tsh + c + 2 * e); }
-  }
-  __device__ __forceinline__ u32x4 apply(const u32x4& r, int relu) const {
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      f32x2 v = {h16lo_to_f32(r[e]), h16hi_to_f32(r[e])};
-      v = __builtin_elementwise_fma(v, sc[e], sh[e]);               // = bn_affine per element (single rounding)
-      o[e] = pack_bf16x2(bn_act(v.x, relu), bn_act(v.y, relu));
-    }
-    return o;
-  }
-};
+#include "conv_sc.h"
 
 __device__ __forceinline__ f32x4 sc_stored(f32x4 v, const float*) { return v; }
 __device__ __forceinline__ f32x4 sc_stored(f32x4 v, const bf16_t*) {
@@ -107,7 +50,6 @@ template <> struct ScRaw4<bf16_t> {
   }
 };
 
-constexpr int SC_TH = 8, SC_TW = 32, SC_HW = SC_TW + 2, SC_HH = SC_TH + 2;
 
 // Epilogue of the small-channel kernels, shared by the single-shot and the streaming form.  prefetch() issues the global
 // operands of the fused BatchNormalization backward (the BN input x of every output this lane owns: clamped addresses, no
@@ -123,6 +65,9 @@ struct ScEpilogue {
   // LDSK (persistent workgroup): the fused sums run over ALL tiles of the workgroup in these registers and are reduced once
   // (flush_stats) into column `workgroup` of [stat][channel][workgroups]; the slot form still adds per tile
   f32x4 ssp[LDSK ? TM : 1], qqp[LDSK ? TM : 1];
+  // LDSK: the bias of the lane's channels, fetched ONCE per persistent workgroup (fill_table) - as a global load in finish() it was a
+  // memory round trip (and a vmcnt(0), which also waits for the next tile's LDS-DMA) per tile
+  f32x4 biasr[LDSK ? TM : 1];
   __device__ __forceinline__ void reset_stats() {
 #pragma unroll
     for (int i = 0; i < (LDSK ? TM : 1); ++i) { ssp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qqp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -138,6 +83,16 @@ struct ScEpilogue {
   // (all 256 threads) fill the LDS table; the caller's next barrier publishes it
   __device__ __forceinline__ void fill_table(const ScArgs& a, float* tab, int tid) {
     ktab = tab;
+    if constexpr (LDSK) {
+      const int lg = (tid & 63) >> 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = i * 16 + lg * 4 + r;
+          biasr[i][r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        }
+    }
     if (a.bnb.x && tid < 32) {
       float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
       if (tid < a.Cout) {
@@ -150,10 +105,15 @@ struct ScEpilogue {
   }
   __device__ __forceinline__ BnBackCh bk(int i, int lg) const {
     if constexpr (LDSK) {
+      // Inline asm: a ds_read the compiler knows about, issued while the next tile's LDS-DMA is in flight, gets an s_waitcnt vmcnt(0)
+      // in front of it (the wait-count pass assumes the two may alias) - that put the whole DMA latency into every tile's epilogue.
       BnBackCh k;
-      const int c = i * 16 + lg * 4;
-      k.sc = *reinterpret_cast<const f32x4*>(ktab + c); k.sh = *reinterpret_cast<const f32x4*>(ktab + 32 + c);
-      k.mu = *reinterpret_cast<const f32x4*>(ktab + 64 + c); k.rs = *reinterpret_cast<const f32x4*>(ktab + 96 + c);
+      const uint32_t ad = (uint32_t)(uintptr_t)ktab + (uint32_t)(i * 16 + lg * 4) * 4u;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(k.sc) : "v"(ad));
+      asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(k.sh) : "v"(ad));
+      asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(k.mu) : "v"(ad));
+      asm volatile("ds_read_b128 %0, %1 offset:384" : "=v"(k.rs) : "v"(ad));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k.sc), "+v"(k.sh), "+v"(k.mu), "+v"(k.rs));
       return k;
     } else {
       return bks[i];
@@ -235,7 +195,9 @@ struct ScEpilogue {
           if (co >= a.Cout) continue;
           f32x4 v = acc[i][f];
           if (co + 3 < a.Cout) {
-            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+            if (a.bias) {
+              if constexpr (LDSK) v += biasr[i]; else v += *reinterpret_cast<const f32x4*>(a.bias + co);
+            }
             T* d = out + pm * a.Cout + co;
             if (a.accumulate) v += load4(d);
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -252,7 +214,9 @@ struct ScEpilogue {
           } else {
             for (int r = 0; r < 4 && co + r < a.Cout; ++r) {
               float x = v[r];
-              if (a.bias) x += a.bias[co + r];
+              if (a.bias) {
+                if constexpr (LDSK) x += biasr[i][r]; else x += a.bias[co + r];
+              }
               T* d = out + pm * a.Cout + co + r;
               if (a.accumulate) x += Elem<T>::load(d);
               if (a.relu) x = fmaxf(x, 0.f);
@@ -419,11 +383,6 @@ __global__ __launch_bounds__(256) void conv_sc_kernel(const ScArgs a) {
 // =================================================================================================
 // (second launch bound = waves per SIMD = workgroups per CU the register allocation must leave room for)
 template <typename T, int CIN, int TM>
-#if defined(STP_EXP) && STP_EXP == 21   // what-if: 3 workgroups per CU for the 16-channel bf16 instantiations (no spill at 168 registers)
-#define SC_WPE_SMALL 3
-#else
-#define SC_WPE_SMALL 4
-#endif
 __global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? SC_WPE_SMALL : 3) : 2)) void conv_sc_stream_kernel(const ScArgs a) {
   constexpr int SZ = (int)sizeof(T);
   constexpr int VEC = Elem<T>::VEC;
@@ -479,25 +438,28 @@ __global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? SC_W
     y0 = ty * SC_TH; x0 = tx * SC_TW;
   };
   // LDS-DMA of a tile into buffer half b; returns the mask of passes whose vector lies inside the image
-  auto issue_tile = [&](int tile, int b) -> uint32_t {
+  // (EVERY wave issues NPASS instructions for EVERY tile slot - a piece that lies past the tile, or a tile past the end of the list
+  //  (live == false), is requested out of range: zeros into the buffer's slack / the idle half, no memory traffic.  With a
+  //  conditional issue the compiler cannot count the instructions that follow the epilogue's operand prefetch and waits for
+  //  (nearly) all of them, i.e. for the NEXT tile, in every tile's epilogue.)
+  auto issue_tile = [&](int tile, int b, bool live) -> uint32_t {
     int n, y0, x0;
     decode(tile, n, y0, x0);
     uint32_t inside = 0;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int gy = y0 - 1 + (hyx[p] >> 16), gx = x0 - 1 + (hyx[p] & 0xffff);
-      const bool ok = hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
       const uint32_t off = ok ? (uint32_t)((n * a.Hs + (gy >> sh)) * a.Ws + (gx >> sh)) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
       inside |= ok ? (1u << p) : 0u;
 #if !defined(STP_EXP) || STP_EXP != 12   // (what-if builds of scratch/sc_exp_build.sh: 11 = no output stores, 12 = no halo loads, 13 = no LDS reads / MFMAs)
-      if (p * 256 + wave * 64 < NV)    // wave-uniform: a wave whose 64 vectors all lie past the tile issues nothing
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, off, 0, 0, 0);
 #endif
     }
     return inside;
   };
 
-  uint32_t inside_cur = issue_tile(t_first, 0);
+  uint32_t inside_cur = issue_tile(t_first, 0, true);
 
   // ---- once per workgroup: weights -> registers (A fragments), lane addresses of the B fragments, constant tables -> LDS ----
   u32x4 fa[TM][NCH];
@@ -515,6 +477,11 @@ __global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? SC_W
       fa[i][c] = w;
     }
   }
+  // (asm read path) the same addresses with the lane groups past K parked on address 0; last_ok: this lane's slot of the last chunk is below K
+  uint32_t bla[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) bla[c] = (uint32_t)(uintptr_t)smem + (bl[c] == 0xffffffffu ? 0u : bl[c]);
+  const bool last_ok = (NCH - 1) * KC + lg * VEC < K;
   ScEpilogue<T, TM, true> ep;
   ep.fill_table(a, ktab, tid);
   if (pbn && tid < CIN) {
@@ -528,27 +495,70 @@ __global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? SC_W
     constexpr int CUR = decltype(curc)::value;
     int n, y0, x0;
     decode(tile, n, y0, x0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's pieces (own) have landed; the previous tile's stores are out
+    // this tile's pieces (own) have landed; the previous tile's stores are out.  (The builtin, not inline asm: the compiler's
+    // wait-count bookkeeping restarts from zero here instead of carrying the prologue's pending loads around the loop.)
+    ScStageBn<T> sbn;
+    if (pbn) sbn.load_tab(ptab, ptab + 32, (tid % VPP) * VEC);      // (table reads: requested before the wait)
+    __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
+    asm volatile("" ::: "memory");
     if (pbn) {
-      ScStageBn<T> sbn;
-      sbn.load_tab(ptab, ptab + 32, (tid % VPP) * VEC);
+      // padding applies to the NORMALISED tensor: out-of-image vectors stay zero.  Reads in batches of three (one LDS round trip per
+      // batch instead of one per vector).
 #pragma unroll
-      for (int p = 0; p < NPASS; ++p)
-        if (inside_cur & (1u << p)) {     // padding applies to the NORMALISED tensor: out-of-image vectors stay zero
-          u32x4* vp = reinterpret_cast<u32x4*>(smem + CUR * BUF + (p * 256 + tid) * 16);
-          *vp = sbn.apply(*vp, a.pbn.relu);
-        }
+      for (int p0 = 0; p0 < NPASS; p0 += 3) {
+        u32x4 v[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (p0 + q < NPASS) v[q] = *reinterpret_cast<const u32x4*>(smem + CUR * BUF + ((p0 + q) * 256 + tid) * 16);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (p0 + q < NPASS && (inside_cur & (1u << (p0 + q))))
+            *reinterpret_cast<u32x4*>(smem + CUR * BUF + ((p0 + q) * 256 + tid) * 16) = sbn.apply(v[q], a.pbn.relu);
+      }
     }
     lds_barrier();
     ep.prefetch(a, n, y0, x0, wave, lr, lg);
     const int next = tile + t_step;
-    if (next < t_end) inside_cur = issue_tile(next, CUR ^ 1);
+    inside_cur = issue_tile(next < t_end ? next : tile, CUR ^ 1, next < t_end);
 
     f32x4 acc[TM][4];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !defined(STP_SC_PLAIN_READS)
+    if constexpr (SZ == 2) {
+      // SC_RING reads are kept IN FLIGHT ahead of the MFMAs that consume them (a ring of register quads, refilled after every
+      // MFMA) and released one by one with counted waits.  As plain C++ the compiler kept one or two reads in flight (register budget of 4 waves per SIMD)
+      // and paired every ds_read_b128 with an lgkmcnt(0): 12-36 exposed LDS round trips per tile in every wave, the largest item
+      // of the per-tile serial chain (what-if without the reads / MFMAs: -25..-40 %).  Inline asm, so the order is ours; a counted
+      // wait only ever over-waits when the compiler adds LDS / scalar-memory operations of its own (they are older or younger than
+      // the whole group it releases).  The fragment's tile row / column half and the buffer half are instruction offsets.
+      constexpr bool PART = (K % KC) != 0;                 // last chunk: lane groups past K read address 0 and are zeroed below
+      constexpr int R = 4 * NCH;                            // reads of a tile, fragment-major: k = f * NCH + c
+      constexpr int D = SC_RING < R ? SC_RING : R;          // reads in flight (a ring of D register quads)
+      u32x4 ring[D];
+      (void)bla; (void)last_ok;
+      auto issue = [&ring, &bla](auto kc) {
+        constexpr int k = decltype(kc)::value, F = k / NCH, c = k % NCH;
+        constexpr int OFF = CUR * BUF + ((F >> 1) * SC_HW + (F & 1) * 16) * PIXB;
+        static_assert(OFF + 2 * SC_HW * PIXB < 65536, "ds_read offset field");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k % D]) : "v"(bla[c]), "n"(OFF));
+      };
+      sc_unroll<D>(issue);
+      sc_unroll<R>([&ring, &fa, &acc, &issue, last_ok](auto kc) {
+        constexpr int k = decltype(kc)::value, F = k / NCH, c = k % NCH;
+        constexpr int young = (R - 1 - k) < (D - 1) ? (R - 1 - k) : (D - 1);      // reads issued after read k at this point
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[k % D]) : "n"(young));
+        u32x4 v = ring[k % D];
+        if (PART && c == NCH - 1 && !last_ok) v = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ScMma<T>::run(fa[i][c], v, acc[i][F]);
+        if constexpr (k + D < R) issue(std::integral_constant<int, k + D>{});
+      });
+    } else
+#endif
+    {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -564,6 +574,7 @@ __global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? SC_W
 #endif
       }
     }
+    }
     ep.finish(a, acc, red, n, y0, x0, tile, ntiles, tid, wave, lr, lg);
   };
 
@@ -573,25 +584,6 @@ __global__ __launch_bounds__(256, (TM == 1 ? (sizeof(T) == 2 && CIN <= 16 ? SC_W
     if (tile + t_step < t_end) body(tile + t_step, std::integral_constant<int, 1>{});
   }
   ep.flush_stats(a, red, (int)blockIdx.x, (int)gridDim.x, tid, wave, lr, lg);
-}
-
-static bool sc_stream_on() {
-  static const bool on = !(getenv("STP_SC_STREAM") && atoi(getenv("STP_SC_STREAM")) == 0);
-  return on;
-}
-static int sc_cu_count() {
-  static const int cus = [] {
-    int d = 0, n = 0;
-    if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
-    return n;      // MI355X (also the answer on a build host without a GPU: plan sizes must not depend on where they are computed)
-  }();
-  return cus;
-}
-// workgroups of the streaming kernel: CUs x the co-resident workgroups its launch bound leaves room for, at most one per tile
-static int sc_stream_blocks(int dtype, int cin, int cout, int ntiles) {
-  const int per_cu = cout <= 16 ? (dtype == STP_H16 && cin <= 16 ? SC_WPE_SMALL : 3) : 2;
-  const int64_t b = (int64_t)sc_cu_count() * per_cu;
-  return (int)(b < ntiles ? b : ntiles);
 }
 
 template <typename T, int CIN, int TM>
@@ -679,6 +671,10 @@ extern "C" int stp_conv2d_sc(const stp_conv_params* p, void* stream) {
   if (a.sum2 && ((p->Cout & 3) || (a.H & 1) || (a.W & 1) || p->bias || p->relu || (a.stats && !a.bnb.x))) return STP_E_BADARG;
   const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_sc_stats_tiles(p);
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int r = sc_lean_launch(a, p->C0, p->dtype, s);      // the lean kernel (conv_sc_lean.hip) where it serves the configuration
+    if (r != 1) return r;
+  }
   return p->dtype == STP_H16 ? dispatch_sc<bf16_t>(a, p->C0, s) : dispatch_sc<float>(a, p->C0, s);
 }
 

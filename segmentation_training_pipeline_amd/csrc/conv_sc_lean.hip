@@ -1,0 +1,430 @@
+// LEAN form of the small-channel streaming kernel (round 4) - 16-bit storage, the four configurations the training step uses.
+//
+// conv_sc_stream_kernel (conv_sc.hip) serves every combination of bias / ReLU / accumulate / statistics / BatchNormalization-backward /
+// summed upsampling gradient / producer BatchNormalization with run-time flags.  Counters (scratch/r04/pmc_sc_feat.sh, 16 -> 16 channels at
+// 16 x 512 x 512, per wave and 8 x 32 tile): 220 VALU + 204 SALU instructions plain, 290 + 210 with the producer BatchNormalization,
+// 479 + 378 with the BatchNormalization-backward epilogue - against 20 MFMAs and 20 LDS reads.  With four waves per SIMD that is 58-75 %
+// of the vector-issue slots of the launch: these kernels were INSTRUCTION-bound at 2.3-4.4 TB/s, not memory-bound (what-if builds of
+// round 2: no stores -7 %, no loads -15 %).  Where the instructions went: per-tile address arithmetic in 64 bits per fragment and per
+// staging pass, bounds checks of every fragment, per-ELEMENT branches on the run-time activation mode, one branch per feature flag per
+// fragment, (x - mean) * rstd per element, selects for the lanes past K.
+// Here:
+//   * the configuration is a template parameter (EPI, PBN): no feature branches in the tile loop;
+//   * a tile whose halo lies inside the image ("interior": all but the image border) takes a path without bounds checks: the LDS-DMA
+//     offsets are (tile base, scalar) + (per-lane constant), the stores / epilogue loads are (tile base, scalar) + (per-lane constant)
+//     + (per-fragment scalar) - no per-tile 64-bit vector arithmetic; border tiles take the checked path of the generic kernel;
+//   * the activation mask of the fused BatchNormalization backward is one v_med3 + compare against bounds that depend on the mode only
+//     (as in conv_halo.hip), sum g * xhat is accumulated as sum g * x and centred once per workgroup, packed fp32 arithmetic on pairs;
+//   * everything the generic streaming kernel learned stays: persistent workgroups, weights as register-resident A fragments, the next
+//     tile's halo by LDS-DMA into the other half of a double buffer (EVERY wave issues the same number of DMA instructions for every
+//     tile, so the compiler's counted wait for the epilogue operands leaves them in flight), a ring of LDS fragment reads in flight
+//     (inline asm, counted waits), per-workgroup statistic columns.
+// Same MFMA order as the generic kernel: outputs are bit-identical to it; the statistic sums differ in the last bits (other order).
+#include "conv_sc.h"
+
+enum { SCL_STATS = 0, SCL_BNB = 1, SCL_BNB_SUM2 = 2, SCL_HEAD = 3 };
+
+struct TileC { int n, y0, x0; bool interior; };      // a tile of the walk: image, first pixel, halo inside the image
+
+__device__ __forceinline__ f32x2 scl_unpack(uint32_t w) { return f32x2{h16lo_to_f32(w), h16hi_to_f32(w)}; }
+
+template <int CIN, int TM, int EPI, bool PBN>
+__global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)) void conv_sc_lean_kernel(const ScArgs a) {
+  typedef bf16_t T;
+  constexpr int SZ = 2, VEC = 8, KC = 32, K = 9 * CIN, NCH = (K + KC - 1) / KC, VPP = CIN / VEC, PIXB = CIN * SZ;
+  constexpr int NV = SC_HH * SC_HW * VPP, NPASS = (NV + 255) / 256, BUF = NPASS * 4096;
+  constexpr bool PART = (K % KC) != 0;
+  constexpr int COUT = EPI == SCL_HEAD ? 1 : TM * 16;      // (the launcher checks a.Cout == COUT)
+  constexpr int CB = COUT * SZ;                              // bytes of an output pixel
+  static_assert(EPI != SCL_HEAD || TM == 1, "head: one output channel");
+  static_assert(!PBN || EPI == SCL_STATS || EPI == SCL_HEAD, "producer BatchNormalization: forward only");
+
+  // LDS: [2][BUF] halo tiles | statistics scratch [4][TM*16][2] | producer-BN table [2][32]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + 2 * BUF);
+  float* ptab = red + 4 * TM * 16 * 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int sh = a.up ? 1 : 0;
+
+  // ---- tiles of this workgroup (XCD by XCD, as the generic kernel) -----------------------------------
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
+  } else {
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = ntiles;
+  }
+  if (t_first >= t_end) return;
+
+  // ---- staging constants: halo coordinates (border tiles) and the byte offset relative to the tile's first pixel (interior tiles) ----
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  int hyx[NPASS];            // hy << 16 | hx ; -1 past the tile
+  uint32_t lo[NPASS];        // ((hy - 1) >> sh) * Ws + ((hx - 1) >> sh)) * PIXB + channel vector; past the tile: 2^31 (out of range for any tile)
+  const int cvb = (tid % VPP) * 16;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int v = p * 256 + tid, pix = v / VPP;
+    const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+    hyx[p] = v < NV ? (hy << 16 | hx) : -1;
+    lo[p] = v < NV ? (uint32_t)((((hy - 1) >> sh) * a.Ws + ((hx - 1) >> sh)) * PIXB + cvb) : 0x80000000u;
+  }
+
+  auto decode = [&](int tile) -> TileC {
+    const int bq = (int)fdiv((uint32_t)tile, a.divTx);
+    const int tx = tile - bq * a.tiles_x;
+    const int n = (int)fdiv((uint32_t)bq, a.divTy);
+    const int ty = bq - n * a.tiles_y;
+    TileC t;
+    t.n = n; t.y0 = ty * SC_TH; t.x0 = tx * SC_TW;
+    t.interior = ty > 0 && tx > 0 && t.y0 + SC_TH < a.H && t.x0 + SC_TW < a.W;      // the halo lies inside the image
+    return t;
+  };
+  // LDS-DMA of a tile into buffer half b (NPASS instructions on every path); returns the mask of passes whose vector lies inside the image
+  auto issue_tile = [&](const TileC& t, int b, bool live) -> uint32_t {
+    uint32_t inside = 0;
+    if (live && t.interior) {
+      const uint32_t tb = (uint32_t)((t.n * a.Hs + (t.y0 >> sh)) * a.Ws + (t.x0 >> sh)) * (uint32_t)PIXB;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, (int)(tb + lo[p]), 0, 0, 0);
+      inside = (1u << NPASS) - 1u;
+    } else {
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int gy = t.y0 - 1 + (hyx[p] >> 16), gx = t.x0 - 1 + (hyx[p] & 0xffff);
+        const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const uint32_t off = ok ? (uint32_t)((t.n * a.Hs + (gy >> sh)) * a.Ws + (gx >> sh)) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
+        inside |= ok ? (1u << p) : 0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+    return inside;
+  };
+
+  TileC tc = decode(t_first);
+  uint32_t inside_cur = issue_tile(tc, 0, true);
+
+  // ---- once per workgroup: weights -> registers (A fragments), lane addresses of the B fragments, constants --------------------
+  u32x4 fa[TM][NCH];
+  uint32_t bla[NCH];           // LDS address of fragment chunk c for tile row 2*wave, column lr (buffer half 0); lane groups past K: address 0
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k0 = c * KC + lg * VEC;
+    const int tap = k0 / CIN, ch = k0 - tap * CIN;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    bla[c] = (uint32_t)(uintptr_t)smem + ((k0 < K) ? (uint32_t)((((wave * 2 + kh) * SC_HW + kw + lr) * CIN + ch) * SZ) : 0u);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (k0 < K) w = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(i * 16 + lr) * K + k0) * SZ);
+      fa[i][c] = w;
+    }
+  }
+  const bool last_ok = (NCH - 1) * KC + lg * VEC < K;
+  if (PBN && tid < CIN) {
+    const float r = a.pbn.rstd[tid], sc = a.pbn.gamma ? r * a.pbn.gamma[tid] : r;
+    ptab[tid] = sc;
+    ptab[32 + tid] = (a.pbn.beta ? a.pbn.beta[tid] : 0.f) - a.pbn.mean[tid] * sc;
+  }
+  // epilogue constants
+  f32x2 ksc[TM][2], ksh[TM][2];      // fused BatchNormalization backward: scale / shift of the lane's 4 channels per 16-channel block, as pairs
+  float alo = 0.f, ahi = 0.f;
+  if constexpr (EPI == SCL_BNB || EPI == SCL_BNB_SUM2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const BnBackCh k = bnback_load(a.bnb, i * 16 + lg * 4);
+      ksc[i][0] = f32x2{k.sc[0], k.sc[1]}; ksc[i][1] = f32x2{k.sc[2], k.sc[3]};
+      ksh[i][0] = f32x2{k.sh[0], k.sh[1]}; ksh[i][1] = f32x2{k.sh[2], k.sh[3]};
+    }
+    // activation window of the fused BatchNormalization (the gradient passes strictly inside it): t is "on" iff it equals its clamp
+    // to [smallest positive number, largest float below the upper bound]
+    alo = a.bnb.relu ? __uint_as_float(1u) : -__builtin_inff();
+    ahi = a.bnb.relu == 2 ? __uint_as_float(0x40bfffffu) : __builtin_inff();
+  }
+  float bias0 = 0.f;
+  if constexpr (EPI == SCL_HEAD) bias0 = a.bias ? a.bias[0] : 0.f;
+  // per-lane byte offset of the lane's first output inside a tile (pixel (2 * wave, lr), channels lg * 4 ..); fragment f adds
+  // ((f >> 1) * W + (f & 1) * 16) * CB, channel block i adds 32 bytes
+  const uint32_t so = EPI == SCL_BNB_SUM2 ? (uint32_t)((wave * (a.W >> 1) + (lr >> 1)) * CB + lg * 8)
+                      : EPI == SCL_HEAD   ? (uint32_t)(((wave * 2) * a.W + lr) * CB)
+                                          : (uint32_t)(((wave * 2) * a.W + lr) * CB + lg * 8);
+  f32x4 ss[TM], qq[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  lds_barrier();               // the table is visible
+
+  // (one copy of the tile body: the buffer half is a run-time scalar - the per-lane fragment addresses are re-based once per tile, NCH
+  //  additions, and the code is half the size of the generic kernel's two specialised copies)
+  int cur = 0;
+  for (int tile = t_first; tile < t_end; tile += t_step, cur ^= 1) {
+    const TileC t = tc;
+    ScStageBn<T> sbn;
+    if (PBN) sbn.load_tab(ptab, ptab + 32, (tid % VPP) * VEC);      // (table reads: requested before the wait)
+    // this tile's pieces (own) have landed; the previous tile's stores are out.  (The builtin, not inline asm: the compiler's
+    // wait-count bookkeeping restarts from zero here.)
+    __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
+    asm volatile("" ::: "memory");
+    if (PBN) {
+      // padding applies to the NORMALISED tensor: out-of-image vectors stay zero (border tiles; the slack past the tile does not matter)
+#pragma unroll
+      for (int p0 = 0; p0 < NPASS; p0 += 3) {
+        u32x4 v[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (p0 + q < NPASS) v[q] = *reinterpret_cast<const u32x4*>(smem + cur * BUF + ((p0 + q) * 256 + tid) * 16);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (p0 + q < NPASS && (inside_cur & (1u << (p0 + q))))
+            *reinterpret_cast<u32x4*>(smem + cur * BUF + ((p0 + q) * 256 + tid) * 16) = sbn.apply(v[q], a.pbn.relu);
+      }
+    }
+    lds_barrier();
+
+    // ---- epilogue operands of THIS tile (BatchNormalization input), then the next tile's halo ------------------
+    // (border tiles: okf = the lane's pixel of fragment f lies inside the image; interior tiles carry no checks at all)
+    const bool edge = !t.interior;
+    const bool own = !(lr & 1);        // summed upsampling gradient: even lanes own the low-resolution pixel
+    u32x2 xp[TM][4];
+    auto prefetch = [&](const bool EDGE) __attribute__((always_inline)) {
+      if constexpr (EPI == SCL_BNB) {
+        const char* xb = a.bnb.x + (((size_t)t.n * a.H + t.y0) * a.W + t.x0) * CB;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const char* xf = xb + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
+          const bool ok = !EDGE || (t.y0 + wave * 2 + (f >> 1) < a.H && t.x0 + (f & 1) * 16 + lr < a.W);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) xp[i][f] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
+        }
+      }
+      if constexpr (EPI == SCL_BNB_SUM2) {
+        const char* xb = a.bnb.x + (((size_t)t.n * (a.H >> 1) + (t.y0 >> 1)) * (a.W >> 1) + (t.x0 >> 1)) * CB;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const char* xf = xb + (size_t)(h2 * 8 * CB);
+          const bool ok = own && (!EDGE || (t.y0 + wave * 2 < a.H && t.x0 + h2 * 16 + lr < a.W));
+#pragma unroll
+          for (int i = 0; i < TM; ++i) xp[i][h2] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
+        }
+      }
+    };
+    if (edge) prefetch(true); else prefetch(false);
+    const int next = tile + t_step;
+    const bool live = next < t_end;
+    if (live) tc = decode(next);
+    inside_cur = issue_tile(tc, cur ^ 1, live);
+
+    // ---- MFMAs: wave w owns tile rows 2w, 2w+1; 4 fragments of 16 pixels; a ring of fragment reads in flight ----------
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int R = 4 * NCH;                            // reads of a tile, fragment-major: k = f * NCH + c
+      constexpr int D = SC_RING < R ? SC_RING : R;
+      u32x4 ring[D];
+      uint32_t blc[NCH];                                    // fragment addresses in this tile's buffer half
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) blc[c] = bla[c] + (uint32_t)(cur * BUF);
+      auto issue = [&ring, &blc](auto kc) {
+        constexpr int k = decltype(kc)::value, F = k / NCH, c = k % NCH;
+        constexpr int OFF = ((F >> 1) * SC_HW + (F & 1) * 16) * PIXB;      // the fragment's tile row / column half: an instruction offset
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k % D]) : "v"(blc[c]), "n"(OFF));
+      };
+      sc_unroll<D>(issue);
+      sc_unroll<R>([&ring, &fa, &acc, &issue, last_ok](auto kc) {
+        constexpr int k = decltype(kc)::value, F = k / NCH, c = k % NCH;
+        constexpr int young = (R - 1 - k) < (D - 1) ? (R - 1 - k) : (D - 1);      // reads issued after read k at this point
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[k % D]) : "n"(young));
+        u32x4 v = ring[k % D];
+        if (PART && c == NCH - 1 && !last_ok) v = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][F] = mfma16_16x16x32(fa[i][c], v, acc[i][F]);
+        if constexpr (k + D < R) issue(std::integral_constant<int, k + D>{});
+      });
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    auto epilogue = [&](const bool EDGE) __attribute__((always_inline)) {
+      bool okf[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) okf[f] = !EDGE || (t.y0 + wave * 2 + (f >> 1) < a.H && t.x0 + (f & 1) * 16 + lr < a.W);
+      if constexpr (EPI == SCL_STATS) {
+        char* ob = a.dst + (((size_t)t.n * a.H + t.y0) * a.W + t.x0) * CB;
+        const bool st = a.stats != nullptr;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          char* of = ob + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const f32x4 v = acc[i][f];
+            const u32x2 o = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            if (okf[f]) {
+              *reinterpret_cast<u32x2*>(of + so + i * 32) = o;
+              if (st) {
+                const f32x2 s0 = scl_unpack(o.x), s1 = scl_unpack(o.y);
+                const f32x4 sv = {s0.x, s0.y, s1.x, s1.y};
+                ss[i] += sv;
+                qq[i] += sv * sv;
+              }
+            }
+          }
+        }
+      }
+      if constexpr (EPI == SCL_HEAD) {
+        char* ob = a.dst + (((size_t)t.n * a.H + t.y0) * a.W + t.x0) * CB;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          char* of = ob + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
+          const float x = acc[0][f][0] + bias0;
+          if (lg == 0 && okf[f]) *reinterpret_cast<T*>(of + so) = (T)(pack_bf16x2(x, 0.f) & 0xffffu);
+        }
+      }
+      if constexpr (EPI == SCL_BNB) {
+        char* ob = a.dst + (((size_t)t.n * a.H + t.y0) * a.W + t.x0) * CB;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          char* of = ob + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const f32x4 v = acc[i][f];
+            u32x2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const uint32_t stw = pack_bf16x2(v[2 * e], v[2 * e + 1]);        // dY as it would be stored
+              const f32x2 dy = scl_unpack(stw), xv = scl_unpack(xp[i][f][e]);
+              const f32x2 tt = __builtin_elementwise_fma(xv, ksc[i][e], ksh[i][e]);
+              const f32x2 g = {okf[f] && __builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f,
+                               okf[f] && __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+              ss[i][2 * e] += g.x; ss[i][2 * e + 1] += g.y;
+              qq[i][2 * e] = fmaf(g.x, xv.x, qq[i][2 * e]); qq[i][2 * e + 1] = fmaf(g.y, xv.y, qq[i][2 * e + 1]);
+              o[e] = pack_bf16x2(g.x, g.y);
+            }
+            if (okf[f]) *reinterpret_cast<u32x2*>(of + so + i * 32) = o;
+          }
+        }
+      }
+      if constexpr (EPI == SCL_BNB_SUM2) {
+        // gradient of UpSampling2D(2): the wave's two tile rows are one output row (fragments h2 and h2 + 2, same lane), lanes lr and
+        // lr ^ 1 one output column (quad_perm DPP); even lanes own the low-resolution pixel
+        char* ob = a.dst + (((size_t)t.n * (a.H >> 1) + (t.y0 >> 1)) * (a.W >> 1) + (t.x0 >> 1)) * CB;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          char* of = ob + (size_t)(h2 * 8 * CB);
+          const bool mine = own && okf[h2];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            f32x4 v = acc[i][h2] + acc[i][h2 + 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+            u32x2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const uint32_t stw = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+              const f32x2 dy = scl_unpack(stw), xv = scl_unpack(xp[i][h2][e]);
+              const f32x2 tt = __builtin_elementwise_fma(xv, ksc[i][e], ksh[i][e]);
+              const f32x2 g = {mine && __builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f,
+                               mine && __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+              ss[i][2 * e] += g.x; ss[i][2 * e + 1] += g.y;
+              qq[i][2 * e] = fmaf(g.x, xv.x, qq[i][2 * e]); qq[i][2 * e + 1] = fmaf(g.y, xv.y, qq[i][2 * e + 1]);
+              o[e] = pack_bf16x2(g.x, g.y);
+            }
+            if (mine) *reinterpret_cast<u32x2*>(of + so + i * 32) = o;
+          }
+        }
+      }
+    };
+    if (edge) epilogue(true); else epilogue(false);
+  }
+
+  // ---- one column of [stat][channel][workgroups] per workgroup --------------------------------------------
+  if (EPI != SCL_HEAD && a.stats) {
+    if constexpr (EPI == SCL_BNB || EPI == SCL_BNB_SUM2) {
+      // sum g * xhat = rstd * (sum g * x - mean * sum g), per lane (linear, so the partition does not matter)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bnb.mean + i * 16 + lg * 4), rsd = *reinterpret_cast<const f32x4*>(a.bnb.rstd + i * 16 + lg * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qq[i][e] = rsd[e] * (qq[i][e] - mu[e] * ss[i][e]);
+      }
+    }
+    // butterfly over the 16 pixel lanes, then the 4 waves (same channels, different rows) through LDS
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = row_sum16_to_lane15(ss[i][e]), qv = row_sum16_to_lane15(qq[i][e]);
+        if (lr == 15) {
+          const int cl = i * 16 + lg * 4 + e;
+          red[(wave * TM * 16 + cl) * 2] = sv;
+          red[(wave * TM * 16 + cl) * 2 + 1] = qv;
+        }
+      }
+    lds_barrier();
+    if (tid < TM * 16) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { sv += red[(w * TM * 16 + tid) * 2]; qv += red[(w * TM * 16 + tid) * 2 + 1]; }
+      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = sv;                     // [stat][channel][workgroup]
+      a.stats[((size_t)COUT + tid) * gridDim.x + blockIdx.x] = qv;
+    }
+  }
+}
+
+template <int CIN, int TM, int EPI, bool PBN>
+static int launch_scl(const ScArgs& a, hipStream_t s) {
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  constexpr int NV = SC_HH * SC_HW * (CIN / 8), NPASS = (NV + 255) / 256;
+  const size_t lds = (size_t)2 * NPASS * 4096 + (4 * TM * 16 * 2 + 64) * sizeof(float);
+  const int blocks = sc_stream_blocks(STP_H16, CIN, TM * 16, ntiles);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_lean_kernel<CIN, TM, EPI, PBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_sc_lean_kernel<CIN, TM, EPI, PBN>), dim3(blocks), dim3(256), lds, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+template <int EPI, bool PBN>
+static int dispatch_scl(const ScArgs& a, int cin, int tm, hipStream_t s) {
+  switch (cin * 4 + tm) {
+    case 8 * 4 + 1: return launch_scl<8, 1, EPI, PBN>(a, s);
+    case 16 * 4 + 1: return launch_scl<16, 1, EPI, PBN>(a, s);
+    case 32 * 4 + 1: return launch_scl<32, 1, EPI, PBN>(a, s);
+    case 8 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<8, 2, EPI, PBN>(a, s); else return 1;
+    case 16 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<16, 2, EPI, PBN>(a, s); else return 1;
+    case 32 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<32, 2, EPI, PBN>(a, s); else return 1;
+    default: return 1;
+  }
+}
+
+static bool sc_lean_on() {
+  static const bool on = !(getenv("STP_SC_LEAN") && atoi(getenv("STP_SC_LEAN")) == 0);
+  return on;
+}
+
+// Does the lean kernel serve this configuration?  1 = no (the caller falls back to the generic streaming kernel).
+int sc_lean_launch(const ScArgs& a, int cin, int dtype, hipStream_t s) {
+  if (!sc_lean_on() || !sc_stream_on() || dtype != STP_H16 || a.stat_slots || a.accumulate || a.relu) return 1;
+  const bool pbn = a.pbn.mean != nullptr;
+  const int tm = a.Cout <= 16 ? 1 : 2;
+  if (a.bnb.x) {
+    if (pbn || a.bias || !a.stats || a.Cout != tm * 16) return 1;
+    return a.sum2 ? dispatch_scl<SCL_BNB_SUM2, false>(a, cin, tm, s) : dispatch_scl<SCL_BNB, false>(a, cin, tm, s);
+  }
+  if (a.sum2) return 1;
+  if (a.Cout == 1) {
+    if (a.stats) return 1;
+    return pbn ? dispatch_scl<SCL_HEAD, true>(a, cin, 1, s) : dispatch_scl<SCL_HEAD, false>(a, cin, 1, s);
+  }
+  if (a.bias || a.Cout != tm * 16) return 1;
+  return pbn ? dispatch_scl<SCL_STATS, true>(a, cin, tm, s) : dispatch_scl<SCL_STATS, false>(a, cin, tm, s);
+}
