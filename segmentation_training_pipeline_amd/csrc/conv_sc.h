@@ -99,5 +99,17 @@ static inline int sc_stream_blocks(int dtype, int cin, int cout, int ntiles) {
 }
 
 
+struct ScWgArgs {
+  const char* src;  // x  [N,Hs,Ws,CIN]
+  const char* dy;   // dY [N,H,W,COUT]
+  float* slabs;     // [gridDim][Cout][9*CIN]
+  int N, H, W, Hs, Ws, Cout, up;
+  int tiles_x, tiles_y, ntiles;
+  int ctot, coff;   // this source occupies channels [coff, coff+CIN) of the Ctot-channel concatenated input
+  uint32_t src_bytes, dy_bytes;   // buffer descriptors of the streaming kernel's LDS-DMA
+  BnBack pbn;       // see stp_wgrad_params.src_bn_mean
+};
+
 // conv_sc_lean.hip: launches the lean kernel if it serves this configuration (returns STP_OK / an error), or returns 1 = "not served"
 int sc_lean_launch(const ScArgs& a, int cin, int dtype, hipStream_t s);
+int sc_wg_lean_launch(const ScWgArgs& a, int cin, int cout, int dtype, int blocks, hipStream_t s);

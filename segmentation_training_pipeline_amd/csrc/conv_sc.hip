@@ -1787,16 +1787,6 @@ extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream) {
 // =================================================================================================
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-struct ScWgArgs {
-  const char* src;  // x  [N,Hs,Ws,CIN]
-  const char* dy;   // dY [N,H,W,COUT]
-  float* slabs;     // [gridDim][Cout][9*CIN]
-  int N, H, W, Hs, Ws, Cout, up;
-  int tiles_x, tiles_y, ntiles;
-  int ctot, coff;   // this source occupies channels [coff, coff+CIN) of the Ctot-channel concatenated input
-  uint32_t src_bytes, dy_bytes;   // buffer descriptors of the streaming kernel's LDS-DMA
-  BnBack pbn;       // see stp_wgrad_params.src_bn_mean
-};
 
 // STREAMING form of conv_sc_wgrad_kernel below (the one stp_wgrad_sc_partial launches; the register-staged form stays for A/B runs,
 // STP_SC_STREAM=0): the X halo tile and the dY tile of the NEXT tile are written into the other half of a double buffer by LDS-DMA
@@ -2130,7 +2120,16 @@ extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
 extern "C" int stp_wgrad_sc_slabs(const stp_wgrad_params* p) {
   const int64_t tiles = (int64_t)p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW);
   static const int max_blocks = getenv("STP_SC_WG_BLOCKS") ? atoi(getenv("STP_SC_WG_BLOCKS")) : SC_WG_MAX_BLOCKS;
-  return (int)(tiles < max_blocks ? tiles : max_blocks);
+  // one workgroup per slot the double-buffered staging leaves on a CU (round 4: 1024 workgroups of an 80 KB kernel were two rounds of
+  // 512, each with its own prologue, slab and share of the reduce kernel's input)
+  const int vec = p->dtype == STP_H16 ? 8 : 4, cin = p->C0 > p->C1 ? p->C0 : p->C1;
+  const int64_t npx = ((int64_t)SC_HH * SC_HW * (cin / vec) + 255) / 256, npd = ((int64_t)SC_TH * SC_TW * ((p->Cout + vec - 1) / vec) + 255) / 256;
+  const int64_t lds = 2 * (npx + npd) * 4096;
+  int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+  per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+  int64_t blocks = (int64_t)sc_cu_count() * per_cu;
+  if (blocks > max_blocks) blocks = max_blocks;
+  return (int)(tiles < blocks ? tiles : blocks);
 }
 
 template <typename T, int CIN, int COUT>
@@ -2157,6 +2156,10 @@ static int launch_sc_wg(const ScWgArgs& a, int blocks, hipStream_t s) {
 
 template <typename T>
 static int sc_wg_dispatch(const ScWgArgs& a, int cin, int cout, int blocks, hipStream_t s) {
+  {
+    const int r = sc_wg_lean_launch(a, cin, cout, Elem<T>::DTYPE, blocks, s);      // the lean kernel (conv_sc_lean.hip) where it serves the configuration
+    if (r != 1) return r;
+  }
   const int key = cin * 64 + cout;
   if constexpr (sizeof(T) == 2) {
     switch (key) {

@@ -428,3 +428,269 @@ int sc_lean_launch(const ScArgs& a, int cin, int dtype, hipStream_t s) {
   if (a.bias || a.Cout != tm * 16) return 1;
   return pbn ? dispatch_scl<SCL_STATS, true>(a, cin, tm, s) : dispatch_scl<SCL_STATS, false>(a, cin, tm, s);
 }
+
+// =================================================================================================
+// LEAN small-channel WEIGHT GRADIENT:  dW[co][tap * CIN + ci] = sum over pixels of dY[p][co] * X[p + tap][ci]
+//
+// conv_sc_wgrad_stream_kernel (conv_sc.hip) gives wave w the taps w, w + 4, w + 8 of every tile row: wave 0 does 3/2 of the others' work,
+// every wave re-reads the dY fragment of every row, the row loop keeps one transpose read in flight, and the compiler puts an
+// s_waitcnt vmcnt(0) - i.e. the NEXT tile's LDS-DMA - in front of the first LDS read of every tile (it cannot tell the two apart).
+// 56-130 us per launch for layers whose operands take 17-34 us at HBM speed.  Here:
+//   * a wave owns two of the tile's eight rows and ALL nine taps: per halo row (four per wave) three B fragments per 16-channel block
+//     serve the taps (kh, 0..2) of both rows that see it - 28 / 52 transpose reads and 18 / 36 MFMAs per tile and wave (16 / 32 input
+//     channels) instead of 64 / 112 and 24 / 48 on the critical wave; the four waves' accumulators meet once per workgroup, through LDS,
+//     in a fixed order;
+//   * the reads of the next halo row are in flight while the MFMAs of this one issue (inline asm, counted waits: the compiler never
+//     sees an LDS read next to the DMA);
+//   * interior tiles: LDS-DMA offsets = (tile base, scalar) + (per-lane constant); every wave issues the same number of DMA
+//     instructions for every tile; tiles walked XCD by XCD.
+// Slab contract unchanged (one fp32 slab per workgroup, summed by the fixed-order reduce kernel); the sums are taken in another
+// order than the generic kernel's, so the two agree to fp32 rounding, not bit for bit.
+// =================================================================================================
+template <int CIN, int COUT, bool PBN>
+__global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs a) {
+  typedef bf16_t T;
+  constexpr int SZ = 2, VEC = 8, TMo = (COUT + 15) / 16, TNi = CIN / 16, PIXB = CIN * SZ, DYB = COUT * SZ;
+  constexpr int VPPX = CIN / VEC, VPPD = COUT / VEC;
+  constexpr int NVX = SC_HH * SC_HW * VPPX, NPX = (NVX + 255) / 256;      // halo vectors / passes
+  constexpr int NVD = SC_TH * SC_TW * VPPD, NPD = (NVD + 255) / 256;      // dY vectors / passes
+  constexpr int XBUF = NPX * 4096, DBUF = NPD * 4096, BUF = XBUF + DBUF;  // whole 1 KB wave pieces
+  constexpr int F3 = 3 * TMo * TNi;                                        // accumulator fragments of one filter row
+  static_assert(4 * F3 * 1024 <= 2 * BUF, "the final reduction of a filter row fits the (dead) staging buffers");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][halo tile | dY tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int sh = a.up ? 1 : 0;
+
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
+  } else {
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = a.ntiles;
+  }
+
+  f32x4 acc[9][TMo][TNi];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < TMo; ++i)
+#pragma unroll
+      for (int j = 0; j < TNi; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (t_first < t_end) {
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+    int hyx[NPX], pyx[NPD];
+    uint32_t lox[NPX], lod[NPD];     // byte offset relative to the tile's first pixel (interior tiles); past the tile: 2^31
+    const uint32_t cvx = (uint32_t)(tid % VPPX) * 16u, cvd = (uint32_t)(tid % VPPD) * 16u;
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) {
+      const int v = p * 256 + tid, pix = v / VPPX;
+      const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+      hyx[p] = v < NVX ? (hy << 16 | hx) : -1;
+      lox[p] = v < NVX ? (uint32_t)((((hy - 1) >> sh) * a.Ws + ((hx - 1) >> sh)) * PIXB) + cvx : 0x80000000u;
+    }
+#pragma unroll
+    for (int p = 0; p < NPD; ++p) {
+      const int v = p * 256 + tid, pix = v / VPPD;
+      const int py = pix / SC_TW, px = pix % SC_TW;
+      pyx[p] = v < NVD ? (py << 16 | px) : -1;
+      lod[p] = v < NVD ? (uint32_t)((py * a.W + px) * DYB) + cvd : 0x80000000u;
+    }
+    auto decode = [&](int tile) -> TileC {
+      int b = tile;
+      const int tx = b % a.tiles_x; b /= a.tiles_x;
+      const int ty = b % a.tiles_y;
+      TileC t;
+      t.n = b / a.tiles_y; t.y0 = ty * SC_TH; t.x0 = tx * SC_TW;
+      t.interior = ty > 0 && tx > 0 && t.y0 + SC_TH < a.H && t.x0 + SC_TW < a.W;
+      return t;
+    };
+    // NPX + NPD LDS-DMA instructions on every path; returns the mask of halo passes whose vector lies inside the image
+    auto issue_tile = [&](const TileC& t, int bsel, bool live) -> uint32_t {
+      uint32_t inside = 0;
+      char* xb = smem + bsel * BUF;
+      if (live && t.interior) {
+        const uint32_t tbx = (uint32_t)((t.n * a.Hs + (t.y0 >> sh)) * a.Ws + (t.x0 >> sh)) * (uint32_t)PIXB;
+        const uint32_t tbd = (uint32_t)((t.n * a.H + t.y0) * a.W + t.x0) * (uint32_t)DYB;
+#pragma unroll
+        for (int p = 0; p < NPX; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xb + p * 4096 + wave * 1024), 16, (int)(tbx + lox[p]), 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < NPD; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(xb + XBUF + p * 4096 + wave * 1024), 16, (int)(tbd + lod[p]), 0, 0, 0);
+        inside = (1u << NPX) - 1u;
+      } else {
+#pragma unroll
+        for (int p = 0; p < NPX; ++p) {
+          const int gy = t.y0 - 1 + (hyx[p] >> 16), gx = t.x0 - 1 + (hyx[p] & 0xffff);
+          const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+          const uint32_t off = ok ? (uint32_t)((t.n * a.Hs + (gy >> sh)) * a.Ws + (gx >> sh)) * (uint32_t)PIXB + cvx : 0x80000000u;
+          inside |= ok ? (1u << p) : 0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xb + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < NPD; ++p) {
+          const int gy = t.y0 + (pyx[p] >> 16), gx = t.x0 + (pyx[p] & 0xffff);
+          const bool ok = live && pyx[p] >= 0 && gy < a.H && gx < a.W;
+          const uint32_t off = ok ? (uint32_t)((t.n * a.H + gy) * a.W + gx) * (uint32_t)DYB + cvd : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(xb + XBUF + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
+        }
+      }
+      return inside;
+    };
+
+    TileC tc = decode(t_first);
+    uint32_t inside_cur = issue_tile(tc, 0, true);
+    ScStageBn<T> sbn;
+    if (PBN) sbn.load(a.pbn, (tid % VPPX) * VEC);
+    // lane group g owns pixels x = 4g..4g+3 (lo) and 16+4g..16+4g+3 (hi) of a 32-pixel row; lane i of a group addresses pixel (i>>2), quad (i&3)
+    const int xl = lg * 4 + (lr >> 2), qb = (lr & 3) * 8;
+    const uint32_t aA0 = (uint32_t)(uintptr_t)smem + (uint32_t)(XBUF + ((2 * wave * SC_TW + xl) * COUT) * SZ + qb);      // dY row 2 * wave
+    const uint32_t aB0 = (uint32_t)(uintptr_t)smem + (uint32_t)((((2 * wave) * SC_HW + xl) * CIN) * SZ + qb);            // halo row 2 * wave
+
+    int cur = 0;
+    for (int tile = t_first; tile < t_end; tile += t_step, cur ^= 1) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0): own pieces of this tile have landed
+      asm volatile("" ::: "memory");
+      if (PBN) {
+        // padding applies to the NORMALISED tensor: out-of-image vectors stay zero
+#pragma unroll
+        for (int p0 = 0; p0 < NPX; p0 += 3) {
+          u32x4 v[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (p0 + q < NPX) v[q] = *reinterpret_cast<const u32x4*>(smem + cur * BUF + ((p0 + q) * 256 + tid) * 16);
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (p0 + q < NPX && (inside_cur & (1u << (p0 + q))))
+              *reinterpret_cast<u32x4*>(smem + cur * BUF + ((p0 + q) * 256 + tid) * 16) = sbn.apply(v[q], a.pbn.relu);
+        }
+      }
+      lds_barrier();                                          // tile visible; every wave has left the other buffer
+      const int next = tile + t_step;
+      const bool live = next < t_end;
+      if (live) tc = decode(next);
+      inside_cur = issue_tile(tc, cur ^ 1, live);
+
+      const uint32_t aA = aA0 + (uint32_t)(cur * BUF), aB = aB0 + (uint32_t)(cur * BUF);
+      u32x2 fa[2][TMo][2];          // dY fragments of the wave's two rows: [row][16-channel block][lo / hi pixels]
+      u32x2 fb[2][3][TNi][2];       // X fragments of one halo row, double-buffered: [buffer][kw][16-channel block][lo / hi]
+      sc_unroll<2 * TMo * 2>([&fa, aA](auto kc) {
+        constexpr int k = decltype(kc)::value, r = k / (TMo * 2), i = (k / 2) % TMo, hl = k & 1;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[r][i][hl]) : "v"(aA), "n"((r * SC_TW * COUT + i * 16 + hl * 16 * COUT) * SZ));
+      });
+      auto issue_b = [&fb, aB](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        sc_unroll<3 * TNi * 2>([&fb, aB](auto kc) {
+          constexpr int k = decltype(kc)::value, kw = k / (TNi * 2), j = (k / 2) % TNi, hl = k & 1;
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[h & 1][kw][j][hl]) : "v"(aB), "n"(((h * SC_HW + kw + hl * 16) * CIN + j * 16) * SZ));
+        });
+      };
+      issue_b(std::integral_constant<int, 0>{});
+      sc_unroll<4>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        if constexpr (h < 3) issue_b(std::integral_constant<int, h + 1>{});
+        // all but the reads of the next halo row have returned
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(h < 3 ? 3 * TNi * 2 : 0) : "memory");
+        if constexpr (h == 0) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < TMo; ++i) { asm volatile("" : "+v"(fa[r][i][0])); asm volatile("" : "+v"(fa[r][i][1])); }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int j = 0; j < TNi; ++j) { asm volatile("" : "+v"(fb[h & 1][kw][j][0])); asm volatile("" : "+v"(fb[h & 1][kw][j][1])); }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int kh = h - r;           // halo row h of the wave = tile row 2 * wave + r under filter row kh
+          if (kh < 0 || kh > 2) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int j = 0; j < TNi; ++j) {
+              const u32x4 vb = {fb[h & 1][kw][j][0].x, fb[h & 1][kw][j][0].y, fb[h & 1][kw][j][1].x, fb[h & 1][kw][j][1].y};
+#pragma unroll
+              for (int i = 0; i < TMo; ++i) {
+                const u32x4 va = {fa[r][i][0].x, fa[r][i][0].y, fa[r][i][1].x, fa[r][i][1].y};
+                acc[kh * 3 + kw][i][j] = mfma16_16x16x32(va, vb, acc[kh * 3 + kw][i][j]);
+              }
+            }
+        }
+      });
+    }
+  }
+
+  // ---- the four waves' partial sums meet in LDS, one filter row per round (fixed order: wave 0..3); C layout row (co) = lg*4 + r, col (ci) = lr ----
+  float* out = a.slabs + (size_t)blockIdx.x * a.Cout * (9 * a.ctot);
+  f32x4* rbuf = reinterpret_cast<f32x4*>(smem);              // [4 waves][F3][64 lanes]
+  __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): the last (idle) LDS-DMA has written its zeros - rbuf reuses that memory
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    lds_barrier();                                            // staging buffers / the previous round are dead
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int i = 0; i < TMo; ++i)
+#pragma unroll
+        for (int j = 0; j < TNi; ++j) rbuf[(wave * F3 + (kw * TMo + i) * TNi + j) * 64 + lane] = acc[kh * 3 + kw][i][j];
+    lds_barrier();
+    for (int f = wave; f < F3; f += 4) {
+      const f32x4 s01 = rbuf[(0 * F3 + f) * 64 + lane] + rbuf[(1 * F3 + f) * 64 + lane];
+      const f32x4 s23 = rbuf[(2 * F3 + f) * 64 + lane] + rbuf[(3 * F3 + f) * 64 + lane];
+      const f32x4 v = s01 + s23;
+      const int kw = f / (TMo * TNi), i = (f / TNi) % TMo, j = f % TNi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = i * 16 + lg * 4 + r;
+        if (co < a.Cout) out[(size_t)co * (9 * a.ctot) + (kh * 3 + kw) * a.ctot + a.coff + j * 16 + lr] = v[r];
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT, bool PBN>
+static int launch_scwl(const ScWgArgs& a, int blocks, hipStream_t s) {
+  constexpr int NPX = (SC_HH * SC_HW * (CIN / 8) + 255) / 256, NPD = (SC_TH * SC_TW * (COUT / 8) + 255) / 256;
+  const size_t lds = (size_t)2 * (NPX + NPD) * 4096;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_wgrad_lean_kernel<CIN, COUT, PBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_sc_wgrad_lean_kernel<CIN, COUT, PBN>), dim3(blocks), dim3(256), lds, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+static bool sc_wg_lean_3232() {
+  static const bool on = getenv("STP_SC_WG_LEAN_3232") && atoi(getenv("STP_SC_WG_LEAN_3232")) != 0;
+  return on;
+}
+
+template <bool PBN>
+static int dispatch_scwl(const ScWgArgs& a, int cin, int cout, int blocks, hipStream_t s) {
+  switch (cin * 64 + cout) {
+    case 16 * 64 + 8: return launch_scwl<16, 8, PBN>(a, blocks, s);
+    case 16 * 64 + 16: return launch_scwl<16, 16, PBN>(a, blocks, s);
+    case 16 * 64 + 32: return launch_scwl<16, 32, PBN>(a, blocks, s);
+    case 32 * 64 + 8: return launch_scwl<32, 8, PBN>(a, blocks, s);
+    case 32 * 64 + 16: return launch_scwl<32, 16, PBN>(a, blocks, s);
+    // (32 -> 32 stays with the generic kernel: 80 KB of staging = two workgroups per CU, measured 54 us against 58 us here)
+    case 32 * 64 + 32: if (sc_wg_lean_3232()) return launch_scwl<32, 32, PBN>(a, blocks, s); else return 1;
+    default: return 1;
+  }
+}
+
+// 1 = not served (the caller falls back to the generic streaming kernel)
+int sc_wg_lean_launch(const ScWgArgs& a, int cin, int cout, int dtype, int blocks, hipStream_t s) {
+  if (!sc_lean_on() || !sc_stream_on() || dtype != STP_H16 || !a.src_bytes || !a.dy_bytes) return 1;
+  return a.pbn.mean ? dispatch_scwl<true>(a, cin, cout, blocks, s) : dispatch_scwl<false>(a, cin, cout, blocks, s);
+}
