@@ -73,9 +73,8 @@ __device__ __forceinline__ void sc_unroll(F&& f) { sc_unroll_seq(std::make_integ
 #define SC_RING 8
 #endif
 
-#if defined(STP_EXP) && STP_EXP == 21   // what-if: 3 workgroups per CU for the 16-channel bf16 instantiations (no spill at 168 registers)
-#define SC_WPE_SMALL 3
-#else
+// workgroups per CU of the 16-bit instantiations with <= 16 input and output channels (what-if builds: -DSC_WPE_SMALL=3 / 5)
+#ifndef SC_WPE_SMALL
 #define SC_WPE_SMALL 4
 #endif
 
