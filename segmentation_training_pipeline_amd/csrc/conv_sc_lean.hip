@@ -28,11 +28,14 @@ struct TileC { int n, y0, x0; bool interior; };      // a tile of the walk: imag
 
 __device__ __forceinline__ f32x2 scl_unpack(uint32_t w) { return f32x2{h16lo_to_f32(w), h16hi_to_f32(w)}; }
 
-template <int CIN, int TM, int EPI, bool PBN>
+template <int CIN, int TM, int EPI, bool PBN, bool UP>
 __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)) void conv_sc_lean_kernel(const ScArgs a) {
   typedef bf16_t T;
   constexpr int SZ = 2, VEC = 8, KC = 32, K = 9 * CIN, NCH = (K + KC - 1) / KC, VPP = CIN / VEC, PIXB = CIN * SZ;
-  constexpr int NV = SC_HH * SC_HW * VPP, NPASS = (NV + 255) / 256, BUF = NPASS * 4096;
+  // UP (nearest-2x upsampled source): the tile is staged at the source's LOW resolution - 6 x 18 instead of 10 x 34 pixels (a third of
+  // the LDS-DMA bytes, of the LDS and of the producer-BatchNormalization work); the fragment reads resolve hi-res pixel -> low-res pixel
+  constexpr int HH = UP ? SC_TH / 2 + 2 : SC_HH, HW = UP ? SC_TW / 2 + 2 : SC_HW;      // staged tile, in source pixels
+  constexpr int NV = HH * HW * VPP, NPASS = (NV + 255) / 256, BUF = NPASS * 4096;
   constexpr bool PART = (K % KC) != 0;
   constexpr int COUT = EPI == SCL_HEAD ? 1 : TM * 16;      // (the launcher checks a.Cout == COUT)
   constexpr int CB = COUT * SZ;                              // bytes of an output pixel
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int sh = a.up ? 1 : 0;
+  constexpr int sh = UP ? 1 : 0;                              // (the launcher checks a.up == UP)
 
   // ---- tiles of this workgroup (XCD by XCD, as the generic kernel) -----------------------------------
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
@@ -63,14 +66,14 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
   // ---- staging constants: halo coordinates (border tiles) and the byte offset relative to the tile's first pixel (interior tiles) ----
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
   int hyx[NPASS];            // hy << 16 | hx ; -1 past the tile
-  uint32_t lo[NPASS];        // ((hy - 1) >> sh) * Ws + ((hx - 1) >> sh)) * PIXB + channel vector; past the tile: 2^31 (out of range for any tile)
+  uint32_t lo[NPASS];        // ((hy - 1) * Ws + (hx - 1)) * PIXB + channel vector (source pixels); past the tile: 2^31 (out of range for any tile)
   const int cvb = (tid % VPP) * 16;
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
     const int v = p * 256 + tid, pix = v / VPP;
-    const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+    const int hy = pix / HW, hx = pix - hy * HW;
     hyx[p] = v < NV ? (hy << 16 | hx) : -1;
-    lo[p] = v < NV ? (uint32_t)((((hy - 1) >> sh) * a.Ws + ((hx - 1) >> sh)) * PIXB + cvb) : 0x80000000u;
+    lo[p] = v < NV ? (uint32_t)(((hy - 1) * a.Ws + (hx - 1)) * PIXB + cvb) : 0x80000000u;
   }
 
   auto decode = [&](int tile) -> TileC {
@@ -95,9 +98,9 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
     } else {
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
-        const int gy = t.y0 - 1 + (hyx[p] >> 16), gx = t.x0 - 1 + (hyx[p] & 0xffff);
-        const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const uint32_t off = ok ? (uint32_t)((t.n * a.Hs + (gy >> sh)) * a.Ws + (gx >> sh)) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
+        const int gy = (t.y0 >> sh) - 1 + (hyx[p] >> 16), gx = (t.x0 >> sh) - 1 + (hyx[p] & 0xffff);      // source pixel
+        const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws;
+        const uint32_t off = ok ? (uint32_t)((t.n * a.Hs + gy) * a.Ws + gx) * (uint32_t)PIXB + (uint32_t)cvb : 0x80000000u;
         inside |= ok ? (1u << p) : 0u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * BUF + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
       }
@@ -110,13 +113,21 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
 
   // ---- once per workgroup: weights -> registers (A fragments), lane addresses of the B fragments, constants --------------------
   u32x4 fa[TM][NCH];
-  uint32_t bla[NCH];           // LDS address of fragment chunk c for tile row 2*wave, column lr (buffer half 0); lane groups past K: address 0
+  // LDS address of fragment chunk c for tile row 2*wave (+ a under UP: the low-res row of a tile row depends on the tap row), column lr
+  // (buffer half 0); lane groups past K: address 0
+  constexpr int NA = UP ? 2 : 1;
+  uint32_t bla[NA][NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int k0 = c * KC + lg * VEC;
     const int tap = k0 / CIN, ch = k0 - tap * CIN;
     const int kh = tap / 3, kw = tap - kh * 3;
-    bla[c] = (uint32_t)(uintptr_t)smem + ((k0 < K) ? (uint32_t)((((wave * 2 + kh) * SC_HW + kw + lr) * CIN + ch) * SZ) : 0u);
+#pragma unroll
+    for (int ar = 0; ar < NA; ++ar) {
+      // UP: hi-res halo pixel (2 wave + ar + kh, lr + kw) -> low-res tile pixel ((hy + 1) >> 1, (hx + 1) >> 1)
+      const int prow = UP ? wave + ((ar + kh + 1) >> 1) : wave * 2 + kh, pcol = UP ? ((lr + kw + 1) >> 1) : kw + lr;
+      bla[ar][c] = (uint32_t)(uintptr_t)smem + ((k0 < K) ? (uint32_t)(((prow * HW + pcol) * CIN + ch) * SZ) : 0u);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       u32x4 w = {0u, 0u, 0u, 0u};
@@ -227,13 +238,16 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
       constexpr int R = 4 * NCH;                            // reads of a tile, fragment-major: k = f * NCH + c
       constexpr int D = SC_RING < R ? SC_RING : R;
       u32x4 ring[D];
-      uint32_t blc[NCH];                                    // fragment addresses in this tile's buffer half
+      uint32_t blc[NA][NCH];                                // fragment addresses in this tile's buffer half
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) blc[c] = bla[c] + (uint32_t)(cur * BUF);
+      for (int ar = 0; ar < NA; ++ar)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) blc[ar][c] = bla[ar][c] + (uint32_t)(cur * BUF);
       auto issue = [&ring, &blc](auto kc) {
         constexpr int k = decltype(kc)::value, F = k / NCH, c = k % NCH;
-        constexpr int OFF = ((F >> 1) * SC_HW + (F & 1) * 16) * PIXB;      // the fragment's tile row / column half: an instruction offset
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k % D]) : "v"(blc[c]), "n"(OFF));
+        // the fragment's tile row / column half: an instruction offset (UP: the row is part of the address register, the half = 8 low-res pixels)
+        constexpr int OFF = UP ? (F & 1) * 8 * PIXB : ((F >> 1) * SC_HW + (F & 1) * 16) * PIXB;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k % D]) : "v"(blc[UP ? (F >> 1) : 0][c]), "n"(OFF));
       };
       sc_unroll<D>(issue);
       sc_unroll<R>([&ring, &fa, &acc, &issue, last_ok](auto kc) {
@@ -376,34 +390,42 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
   }
 }
 
-template <int CIN, int TM, int EPI, bool PBN>
+template <int CIN, int TM, int EPI, bool PBN, bool UP>
 static int launch_scl(const ScArgs& a, hipStream_t s) {
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
-  constexpr int NV = SC_HH * SC_HW * (CIN / 8), NPASS = (NV + 255) / 256;
+  constexpr int NV = (UP ? (SC_TH / 2 + 2) * (SC_TW / 2 + 2) : SC_HH * SC_HW) * (CIN / 8), NPASS = (NV + 255) / 256;
   const size_t lds = (size_t)2 * NPASS * 4096 + (4 * TM * 16 * 2 + 64) * sizeof(float);
   const int blocks = sc_stream_blocks(STP_H16, CIN, TM * 16, ntiles);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_lean_kernel<CIN, TM, EPI, PBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_lean_kernel<CIN, TM, EPI, PBN, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return STP_E_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_sc_lean_kernel<CIN, TM, EPI, PBN>), dim3(blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_sc_lean_kernel<CIN, TM, EPI, PBN, UP>), dim3(blocks), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
 
-template <int EPI, bool PBN>
-static int dispatch_scl(const ScArgs& a, int cin, int tm, hipStream_t s) {
+template <int EPI, bool PBN, bool UP>
+static int dispatch_scl2(const ScArgs& a, int cin, int tm, hipStream_t s) {
   switch (cin * 4 + tm) {
-    case 8 * 4 + 1: return launch_scl<8, 1, EPI, PBN>(a, s);
-    case 16 * 4 + 1: return launch_scl<16, 1, EPI, PBN>(a, s);
-    case 32 * 4 + 1: return launch_scl<32, 1, EPI, PBN>(a, s);
-    case 8 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<8, 2, EPI, PBN>(a, s); else return 1;
-    case 16 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<16, 2, EPI, PBN>(a, s); else return 1;
-    case 32 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<32, 2, EPI, PBN>(a, s); else return 1;
+    case 8 * 4 + 1: return launch_scl<8, 1, EPI, PBN, UP>(a, s);
+    case 16 * 4 + 1: return launch_scl<16, 1, EPI, PBN, UP>(a, s);
+    case 32 * 4 + 1: return launch_scl<32, 1, EPI, PBN, UP>(a, s);
+    case 8 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<8, 2, EPI, PBN, UP>(a, s); else return 1;
+    case 16 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<16, 2, EPI, PBN, UP>(a, s); else return 1;
+    case 32 * 4 + 2: if constexpr (EPI != SCL_HEAD) return launch_scl<32, 2, EPI, PBN, UP>(a, s); else return 1;
     default: return 1;
   }
+}
+// (the upsampled-source form exists for the forward with statistics only: decoder conv3x3(UpSampling2D(2)(x)))
+template <int EPI, bool PBN>
+static int dispatch_scl(const ScArgs& a, int cin, int tm, hipStream_t s) {
+  if (a.up) {
+    if constexpr (EPI == SCL_STATS) return dispatch_scl2<EPI, PBN, true>(a, cin, tm, s); else return 1;
+  }
+  return dispatch_scl2<EPI, PBN, false>(a, cin, tm, s);
 }
 
 static bool sc_lean_on() {
@@ -447,12 +469,13 @@ int sc_lean_launch(const ScArgs& a, int cin, int dtype, hipStream_t s) {
 // Slab contract unchanged (one fp32 slab per workgroup, summed by the fixed-order reduce kernel); the sums are taken in another
 // order than the generic kernel's, so the two agree to fp32 rounding, not bit for bit.
 // =================================================================================================
-template <int CIN, int COUT, bool PBN>
+template <int CIN, int COUT, bool PBN, bool UP>
 __global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs a) {
   typedef bf16_t T;
   constexpr int SZ = 2, VEC = 8, TMo = (COUT + 15) / 16, TNi = CIN / 16, PIXB = CIN * SZ, DYB = COUT * SZ;
   constexpr int VPPX = CIN / VEC, VPPD = COUT / VEC;
-  constexpr int NVX = SC_HH * SC_HW * VPPX, NPX = (NVX + 255) / 256;      // halo vectors / passes
+  constexpr int HH = UP ? SC_TH / 2 + 2 : SC_HH, HW = UP ? SC_TW / 2 + 2 : SC_HW;      // staged X tile in SOURCE pixels (UP: low resolution, see above)
+  constexpr int NVX = HH * HW * VPPX, NPX = (NVX + 255) / 256;      // halo vectors / passes
   constexpr int NVD = SC_TH * SC_TW * VPPD, NPD = (NVD + 255) / 256;      // dY vectors / passes
   constexpr int XBUF = NPX * 4096, DBUF = NPD * 4096, BUF = XBUF + DBUF;  // whole 1 KB wave pieces
   constexpr int F3 = 3 * TMo * TNi;                                        // accumulator fragments of one filter row
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int sh = a.up ? 1 : 0;
+  constexpr int sh = UP ? 1 : 0;                              // (the launcher checks a.up == UP)
 
   int t_first, t_step, t_end;
   if ((gridDim.x & 7) == 0) {
@@ -490,9 +513,9 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs 
 #pragma unroll
     for (int p = 0; p < NPX; ++p) {
       const int v = p * 256 + tid, pix = v / VPPX;
-      const int hy = pix / SC_HW, hx = pix - hy * SC_HW;
+      const int hy = pix / HW, hx = pix - hy * HW;
       hyx[p] = v < NVX ? (hy << 16 | hx) : -1;
-      lox[p] = v < NVX ? (uint32_t)((((hy - 1) >> sh) * a.Ws + ((hx - 1) >> sh)) * PIXB) + cvx : 0x80000000u;
+      lox[p] = v < NVX ? (uint32_t)(((hy - 1) * a.Ws + (hx - 1)) * PIXB) + cvx : 0x80000000u;
     }
 #pragma unroll
     for (int p = 0; p < NPD; ++p) {
@@ -527,9 +550,9 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs 
       } else {
 #pragma unroll
         for (int p = 0; p < NPX; ++p) {
-          const int gy = t.y0 - 1 + (hyx[p] >> 16), gx = t.x0 - 1 + (hyx[p] & 0xffff);
-          const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-          const uint32_t off = ok ? (uint32_t)((t.n * a.Hs + (gy >> sh)) * a.Ws + (gx >> sh)) * (uint32_t)PIXB + cvx : 0x80000000u;
+          const int gy = (t.y0 >> sh) - 1 + (hyx[p] >> 16), gx = (t.x0 >> sh) - 1 + (hyx[p] & 0xffff);      // source pixel
+          const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws;
+          const uint32_t off = ok ? (uint32_t)((t.n * a.Hs + gy) * a.Ws + gx) * (uint32_t)PIXB + cvx : 0x80000000u;
           inside |= ok ? (1u << p) : 0u;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xb + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
         }
@@ -551,7 +574,12 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs 
     // lane group g owns pixels x = 4g..4g+3 (lo) and 16+4g..16+4g+3 (hi) of a 32-pixel row; lane i of a group addresses pixel (i>>2), quad (i&3)
     const int xl = lg * 4 + (lr >> 2), qb = (lr & 3) * 8;
     const uint32_t aA0 = (uint32_t)(uintptr_t)smem + (uint32_t)(XBUF + ((2 * wave * SC_TW + xl) * COUT) * SZ + qb);      // dY row 2 * wave
-    const uint32_t aB0 = (uint32_t)(uintptr_t)smem + (uint32_t)((((2 * wave) * SC_HW + xl) * CIN) * SZ + qb);            // halo row 2 * wave
+    // X fragments: halo row 2 * wave (+ h), pixel xl + kw (+ 16); UP: hi-res halo pixel (hy, hx) -> low-res tile pixel ((hy + 1) >> 1, (hx + 1) >> 1),
+    // one address register per kw (the column mapping is not additive in kw)
+    uint32_t aB0[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+      aB0[kw] = (uint32_t)(uintptr_t)smem + (uint32_t)((UP ? (wave * HW + ((xl + kw + 1) >> 1)) : ((2 * wave) * HW + xl + kw)) * CIN * SZ + qb);
 
     int cur = 0;
     for (int tile = t_first; tile < t_end; tile += t_step, cur ^= 1) {
@@ -577,18 +605,23 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs 
       if (live) tc = decode(next);
       inside_cur = issue_tile(tc, cur ^ 1, live);
 
-      const uint32_t aA = aA0 + (uint32_t)(cur * BUF), aB = aB0 + (uint32_t)(cur * BUF);
+      const uint32_t aA = aA0 + (uint32_t)(cur * BUF);
+      uint32_t aB[3];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) aB[kw] = aB0[kw] + (uint32_t)(cur * BUF);
       u32x2 fa[2][TMo][2];          // dY fragments of the wave's two rows: [row][16-channel block][lo / hi pixels]
       u32x2 fb[2][3][TNi][2];       // X fragments of one halo row, double-buffered: [buffer][kw][16-channel block][lo / hi]
       sc_unroll<2 * TMo * 2>([&fa, aA](auto kc) {
         constexpr int k = decltype(kc)::value, r = k / (TMo * 2), i = (k / 2) % TMo, hl = k & 1;
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[r][i][hl]) : "v"(aA), "n"((r * SC_TW * COUT + i * 16 + hl * 16 * COUT) * SZ));
       });
-      auto issue_b = [&fb, aB](auto hc) {
+      auto issue_b = [&fb, &aB](auto hc) {
         constexpr int h = decltype(hc)::value;
-        sc_unroll<3 * TNi * 2>([&fb, aB](auto kc) {
+        sc_unroll<3 * TNi * 2>([&fb, &aB](auto kc) {
           constexpr int k = decltype(kc)::value, kw = k / (TNi * 2), j = (k / 2) % TNi, hl = k & 1;
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[h & 1][kw][j][hl]) : "v"(aB), "n"(((h * SC_HW + kw + hl * 16) * CIN + j * 16) * SZ));
+          // row h of the wave's four halo rows, pixel half hl (UP: low-res row (h + 1) >> 1, half = 8 low-res pixels)
+          constexpr int OFF = UP ? ((((h + 1) >> 1) * HW + hl * 8) * CIN + j * 16) * SZ : ((h * HW + hl * 16) * CIN + j * 16) * SZ;
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[h & 1][kw][j][hl]) : "v"(aB[kw]), "n"(OFF));
         });
       };
       issue_b(std::integral_constant<int, 0>{});
@@ -655,17 +688,17 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_lean_kernel(const ScWgArgs 
   }
 }
 
-template <int CIN, int COUT, bool PBN>
+template <int CIN, int COUT, bool PBN, bool UP>
 static int launch_scwl(const ScWgArgs& a, int blocks, hipStream_t s) {
-  constexpr int NPX = (SC_HH * SC_HW * (CIN / 8) + 255) / 256, NPD = (SC_TH * SC_TW * (COUT / 8) + 255) / 256;
+  constexpr int NPX = ((UP ? (SC_TH / 2 + 2) * (SC_TW / 2 + 2) : SC_HH * SC_HW) * (CIN / 8) + 255) / 256, NPD = (SC_TH * SC_TW * (COUT / 8) + 255) / 256;
   const size_t lds = (size_t)2 * (NPX + NPD) * 4096;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_wgrad_lean_kernel<CIN, COUT, PBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sc_wgrad_lean_kernel<CIN, COUT, PBN, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return STP_E_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_sc_wgrad_lean_kernel<CIN, COUT, PBN>), dim3(blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_sc_wgrad_lean_kernel<CIN, COUT, PBN, UP>), dim3(blocks), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
@@ -675,16 +708,16 @@ static bool sc_wg_lean_3232() {
   return on;
 }
 
-template <bool PBN>
+template <bool PBN, bool UP>
 static int dispatch_scwl(const ScWgArgs& a, int cin, int cout, int blocks, hipStream_t s) {
   switch (cin * 64 + cout) {
-    case 16 * 64 + 8: return launch_scwl<16, 8, PBN>(a, blocks, s);
-    case 16 * 64 + 16: return launch_scwl<16, 16, PBN>(a, blocks, s);
-    case 16 * 64 + 32: return launch_scwl<16, 32, PBN>(a, blocks, s);
-    case 32 * 64 + 8: return launch_scwl<32, 8, PBN>(a, blocks, s);
-    case 32 * 64 + 16: return launch_scwl<32, 16, PBN>(a, blocks, s);
-    // (32 -> 32 stays with the generic kernel: 80 KB of staging = two workgroups per CU, measured 54 us against 58 us here)
-    case 32 * 64 + 32: if (sc_wg_lean_3232()) return launch_scwl<32, 32, PBN>(a, blocks, s); else return 1;
+    case 16 * 64 + 8: return launch_scwl<16, 8, PBN, UP>(a, blocks, s);
+    case 16 * 64 + 16: return launch_scwl<16, 16, PBN, UP>(a, blocks, s);
+    case 16 * 64 + 32: return launch_scwl<16, 32, PBN, UP>(a, blocks, s);
+    case 32 * 64 + 8: return launch_scwl<32, 8, PBN, UP>(a, blocks, s);
+    case 32 * 64 + 16: return launch_scwl<32, 16, PBN, UP>(a, blocks, s);
+    // (32 -> 32 at full resolution stays with the generic kernel: 80 KB of staging = two workgroups per CU, measured 54 us against 58 us here)
+    case 32 * 64 + 32: if (UP || sc_wg_lean_3232()) return launch_scwl<32, 32, PBN, UP>(a, blocks, s); else return 1;
     default: return 1;
   }
 }
@@ -692,5 +725,6 @@ static int dispatch_scwl(const ScWgArgs& a, int cin, int cout, int blocks, hipSt
 // 1 = not served (the caller falls back to the generic streaming kernel)
 int sc_wg_lean_launch(const ScWgArgs& a, int cin, int cout, int dtype, int blocks, hipStream_t s) {
   if (!sc_lean_on() || !sc_stream_on() || dtype != STP_H16 || !a.src_bytes || !a.dy_bytes) return 1;
-  return a.pbn.mean ? dispatch_scwl<true>(a, cin, cout, blocks, s) : dispatch_scwl<false>(a, cin, cout, blocks, s);
+  if (a.up) return a.pbn.mean ? dispatch_scwl<true, true>(a, cin, cout, blocks, s) : dispatch_scwl<false, true>(a, cin, cout, blocks, s);
+  return a.pbn.mean ? dispatch_scwl<true, false>(a, cin, cout, blocks, s) : dispatch_scwl<false, false>(a, cin, cout, blocks, s);
 }
