@@ -168,6 +168,39 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
   for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   lds_barrier();               // the table is visible
 
+  // epilogue operands (the BatchNormalization input at the lane's output pixels) of tile pt -> xo
+  // (border tiles: the lane's pixel of fragment f may lie outside the image; interior tiles carry no checks at all)
+  const bool own = !(lr & 1);        // summed upsampling gradient: even lanes own the low-resolution pixel
+  auto prefetch = [&](const TileC& pt, const bool EDGE, u32x2 (&xo)[TM][4]) __attribute__((always_inline)) {
+    if constexpr (EPI == SCL_BNB) {
+      const char* xb = a.bnb.x + (((size_t)pt.n * a.H + pt.y0) * a.W + pt.x0) * CB;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const char* xf = xb + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
+        const bool ok = !EDGE || (pt.y0 + wave * 2 + (f >> 1) < a.H && pt.x0 + (f & 1) * 16 + lr < a.W);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xo[i][f] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
+      }
+    }
+    if constexpr (EPI == SCL_BNB_SUM2) {
+      const char* xb = a.bnb.x + (((size_t)pt.n * (a.H >> 1) + (pt.y0 >> 1)) * (a.W >> 1) + (pt.x0 >> 1)) * CB;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const char* xf = xb + (size_t)(h2 * 8 * CB);
+        const bool ok = own && (!EDGE || (pt.y0 + wave * 2 < a.H && pt.x0 + h2 * 16 + lr < a.W));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xo[i][h2] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
+      }
+    }
+  };
+  u32x2 xp[TM][4];                   // ... of the CURRENT tile
+  // (32 -> 32 channels: the second operand set does not fit 256 registers - measured with 64 bytes of spills - so that instance fetches
+  //  them at the top of their own tile)
+  constexpr bool AHEAD = (EPI == SCL_BNB || EPI == SCL_BNB_SUM2) && !(CIN == 32 && TM == 2 && EPI == SCL_BNB);
+  if constexpr (AHEAD) {
+    if (tc.interior) prefetch(tc, false, xp); else prefetch(tc, true, xp);
+  }
+
   // (one copy of the tile body: the buffer half is a run-time scalar - the per-lane fragment addresses are re-based once per tile, NCH
   //  additions, and the code is half the size of the generic kernel's two specialised copies)
   int cur = 0;
@@ -195,38 +228,20 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
     }
     lds_barrier();
 
-    // ---- epilogue operands of THIS tile (BatchNormalization input), then the next tile's halo ------------------
-    // (border tiles: okf = the lane's pixel of fragment f lies inside the image; interior tiles carry no checks at all)
+    // ---- the next tile's halo, then the epilogue operands of the NEXT tile (BatchNormalization input): requested a whole tile ahead -
+    // fetched at the top of their own tile they came back after the (short) MFMA phase: 540 of 2200 wave-cycles per tile waiting ------
     const bool edge = !t.interior;
-    const bool own = !(lr & 1);        // summed upsampling gradient: even lanes own the low-resolution pixel
-    u32x2 xp[TM][4];
-    auto prefetch = [&](const bool EDGE) __attribute__((always_inline)) {
-      if constexpr (EPI == SCL_BNB) {
-        const char* xb = a.bnb.x + (((size_t)t.n * a.H + t.y0) * a.W + t.x0) * CB;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const char* xf = xb + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
-          const bool ok = !EDGE || (t.y0 + wave * 2 + (f >> 1) < a.H && t.x0 + (f & 1) * 16 + lr < a.W);
-#pragma unroll
-          for (int i = 0; i < TM; ++i) xp[i][f] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
-        }
-      }
-      if constexpr (EPI == SCL_BNB_SUM2) {
-        const char* xb = a.bnb.x + (((size_t)t.n * (a.H >> 1) + (t.y0 >> 1)) * (a.W >> 1) + (t.x0 >> 1)) * CB;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const char* xf = xb + (size_t)(h2 * 8 * CB);
-          const bool ok = own && (!EDGE || (t.y0 + wave * 2 < a.H && t.x0 + h2 * 16 + lr < a.W));
-#pragma unroll
-          for (int i = 0; i < TM; ++i) xp[i][h2] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
-        }
-      }
-    };
-    if (edge) prefetch(true); else prefetch(false);
+    if constexpr (!AHEAD) {             // (this tile's operands, at the top of the tile)
+      if (edge) prefetch(t, true, xp); else prefetch(t, false, xp);
+    }
     const int next = tile + t_step;
     const bool live = next < t_end;
     if (live) tc = decode(next);
     inside_cur = issue_tile(tc, cur ^ 1, live);
+    u32x2 xn[TM][4];
+    if (AHEAD && live) {
+      if (tc.interior) prefetch(tc, false, xn); else prefetch(tc, true, xn);
+    }
 
     // ---- MFMAs: wave w owns tile rows 2w, 2w+1; 4 fragments of 16 pixels; a ring of fragment reads in flight ----------
     f32x4 acc[TM][4];
@@ -236,18 +251,15 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
       for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
       constexpr int R = 4 * NCH;                            // reads of a tile, fragment-major: k = f * NCH + c
-      constexpr int D = SC_RING < R ? SC_RING : R;
+      // (32 -> 32 channels with the BatchNormalization-backward operands of two tiles live: a shorter ring instead of spills)
+      constexpr int RING = (CIN == 32 && TM == 2 && EPI == SCL_BNB_SUM2) ? 4 : SC_RING;
+      constexpr int D = RING < R ? RING : R;
       u32x4 ring[D];
-      uint32_t blc[NA][NCH];                                // fragment addresses in this tile's buffer half
-#pragma unroll
-      for (int ar = 0; ar < NA; ++ar)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) blc[ar][c] = bla[ar][c] + (uint32_t)(cur * BUF);
-      auto issue = [&ring, &blc](auto kc) {
+      auto issue = [&ring, &bla](auto kc) {                  // (bla points into this tile's buffer half: re-based at the end of every tile)
         constexpr int k = decltype(kc)::value, F = k / NCH, c = k % NCH;
         // the fragment's tile row / column half: an instruction offset (UP: the row is part of the address register, the half = 8 low-res pixels)
         constexpr int OFF = UP ? (F & 1) * 8 * PIXB : ((F >> 1) * SC_HW + (F & 1) * 16) * PIXB;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k % D]) : "v"(blc[UP ? (F >> 1) : 0][c]), "n"(OFF));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k % D]) : "v"(bla[UP ? (F >> 1) : 0][c]), "n"(OFF));
       };
       sc_unroll<D>(issue);
       sc_unroll<R>([&ring, &fa, &acc, &issue, last_ok](auto kc) {
@@ -354,6 +366,19 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
       }
     };
     if (edge) epilogue(true); else epilogue(false);
+    {
+      const uint32_t flip = cur ? (uint32_t)(-BUF) : (uint32_t)BUF;      // the fragment addresses move to the other buffer half
+#pragma unroll
+      for (int ar = 0; ar < NA; ++ar)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) bla[ar][c] += flip;
+    }
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) xp[i][f] = xn[i][f];
+    }
   }
 
   // ---- one column of [stat][channel][workgroups] per workgroup --------------------------------------------
