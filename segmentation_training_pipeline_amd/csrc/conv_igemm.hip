@@ -619,6 +619,7 @@ extern "C" int stp_conv2d_s64(const stp_conv_params* p, void* stream);
 extern "C" int stp_conv2d_s64_stats_tiles(const stp_conv_params* p);
 extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p);
 extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream);
+extern "C" int stp_conv2d_stem_stats_tiles(const stp_conv_params* p);
 extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p);
 extern "C" int stp_conv2d_halo_tiles(const stp_conv_params* p, int variant);
 extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stream);
@@ -671,7 +672,7 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   if (tile == STP_TILE_SCW) return (size_t)stp_conv2d_scw_stats_tiles(p) * 2 * p->Cd0;
   if (tile == STP_TILE_SCN) return (size_t)stp_conv2d_scn_stats_tiles(p) * 2 * p->Cout;
   if (tile == STP_TILE_S64) return (size_t)stp_conv2d_s64_stats_tiles(p) * 2 * p->Cout;
-  if (tile == STP_TILE_STEM) return (size_t)p->N * ceil_div(p->Ho, 8) * ceil_div(p->Wo, 32) * 2 * p->Cout;
+  if (tile == STP_TILE_STEM) return (size_t)stp_conv2d_stem_stats_tiles(p) * 2 * p->Cout;
   if (tile >= STP_TILE_HALO) return (size_t)stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO) * 2 * (p->dst_sum2x2 ? p->Cd0 : p->Cout);
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
 }

@@ -109,6 +109,23 @@ struct ScWgArgs {
   BnBack pbn;       // see stp_wgrad_params.src_bn_mean
 };
 
+constexpr int ST_HH = (SC_TH - 1) * 2 + 7, ST_HW = 70, ST_WROW = 464, ST_HALO = ST_HH * ST_HW * 8, ST_WBYTES = 64 * ST_WROW;
+
+struct StemArgs {
+  const char* src;     // [N,H,W,4] bf16
+  const char* weight;  // [64][7][8][4] bf16
+  char* dst;           // [N,Ho,Wo,64] bf16
+  int N, H, W, Ho, Wo, tiles_x, tiles_y;
+  FastDiv divTx, divTy;
+  float* stats;        // optional fused BatchNorm statistics [2][64][tiles]
+  uint32_t src_bytes;  // size of src (buffer descriptor of the persistent kernel's LDS-DMA); 0 = too large
+};
+
+// conv_sc_lean.hip, persistent stem kernel: does it serve the shape (switch, even width, 32-bit offsets) / its workgroups / launch (1 = not served)
+bool stem_lean_serves(int N, int H, int W);
+int stem_lean_blocks(int ntiles);
+int stem_lean_launch(const StemArgs& a, hipStream_t s);
+
 // conv_sc_lean.hip: launches the lean kernel if it serves this configuration (returns STP_OK / an error), or returns 1 = "not served"
 int sc_lean_launch(const ScArgs& a, int cin, int dtype, hipStream_t s);
 int sc_wg_lean_launch(const ScWgArgs& a, int cin, int cout, int dtype, int blocks, hipStream_t s);

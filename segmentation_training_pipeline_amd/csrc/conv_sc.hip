@@ -1653,17 +1653,6 @@ extern "C" int stp_conv2d_s64(const stp_conv_params* p, void* stream) {
 // lane group g of chunk kh reads taps kw = 2g, 2g+1 (2 pixels x 4 channels, contiguous).  (Weights in registers - 112 VGPRs -
 // leave one wave per SIMD; from LDS the kernel runs 4.)
 // =================================================================================================
-constexpr int ST_HH = (SC_TH - 1) * 2 + 7, ST_HW = 70, ST_WROW = 464, ST_HALO = ST_HH * ST_HW * 8, ST_WBYTES = 64 * ST_WROW;
-
-struct StemArgs {
-  const char* src;     // [N,H,W,4] bf16
-  const char* weight;  // [64][7][8][4] bf16
-  char* dst;           // [N,Ho,Wo,64] bf16
-  int N, H, W, Ho, Wo, tiles_x, tiles_y;
-  FastDiv divTx, divTy;
-  float* stats;        // optional fused BatchNorm statistics [2][64][tiles]
-};
-
 __global__ __launch_bounds__(256) void conv_stem_kernel(const StemArgs a) {
   constexpr int TM = 4, NCH = 7, K = 224, COUT = 64;
   extern __shared__ __attribute__((aligned(16))) char halo[];  // [ST_HH][ST_HW] pixels of 8 bytes, then the stats scratch
@@ -1761,6 +1750,12 @@ extern "C" int stp_conv2d_stem_eligible(const stp_conv_params* p) {
          !p->stats_slots && !p->src_bn_mean;
 }
 
+// columns of the [stat][channel][column] partial sums: one per workgroup of the persistent kernel, one per tile of the single-shot one
+extern "C" int stp_conv2d_stem_stats_tiles(const stp_conv_params* p) {
+  const int ntiles = p->N * ceil_div(p->Ho, SC_TH) * ceil_div(p->Wo, SC_TW);
+  return stem_lean_serves(p->N, p->Hv, p->Wv) ? stem_lean_blocks(ntiles) : ntiles;
+}
+
 extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream) {
   if (!stp_conv2d_stem_eligible(p) || !p->src0 || !p->weight || !p->dst0) return STP_E_BADARG;
   StemArgs a;
@@ -1769,7 +1764,13 @@ extern "C" int stp_conv2d_stem(const stp_conv_params* p, void* stream) {
   a.tiles_x = ceil_div(a.Wo, SC_TW); a.tiles_y = ceil_div(a.Ho, SC_TH);
   a.divTx = make_fastdiv((uint32_t)a.tiles_x); a.divTy = make_fastdiv((uint32_t)a.tiles_y);
   a.stats = p->stats_partial;
-  const_cast<stp_conv_params*>(p)->stats_tiles = a.N * a.tiles_x * a.tiles_y;
+  const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_stem_stats_tiles(p);
+  {
+    const uint64_t sb = (uint64_t)p->N * p->Hv * p->Wv * 8;
+    a.src_bytes = sb < 0x80000000ull ? (uint32_t)sb : 0u;
+    const int r = stem_lean_launch(a, (hipStream_t)stream);      // the persistent form (conv_sc_lean.hip) where it serves the shape
+    if (r != 1) return r;
+  }
   const size_t lds = (size_t)ST_HALO + ST_WBYTES;
   hipLaunchKernelGGL(conv_stem_kernel, dim3(a.N * a.tiles_x * a.tiles_y), dim3(256), lds, (hipStream_t)stream, a);
   STP_LAUNCH_CHECK();

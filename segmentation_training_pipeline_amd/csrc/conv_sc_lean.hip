@@ -28,6 +28,13 @@ struct TileC { int n, y0, x0; bool interior; };      // a tile of the walk: imag
 
 __device__ __forceinline__ f32x2 scl_unpack(uint32_t w) { return f32x2{h16lo_to_f32(w), h16hi_to_f32(w)}; }
 
+// one store per fragment: 8 bytes (TM == 1) or the lane's two channel blocks as 16 bytes (TM == 2)
+template <int TM>
+__device__ __forceinline__ void scl_store(char* p, const u32x2 (&o)[TM]) {
+  if constexpr (TM == 2) *reinterpret_cast<u32x4*>(p) = u32x4{o[0].x, o[0].y, o[1].x, o[1].y};
+  else *reinterpret_cast<u32x2*>(p) = o[0];
+}
+
 template <int CIN, int TM, int EPI, bool PBN, bool UP>
 __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)) void conv_sc_lean_kernel(const ScArgs a) {
   typedef bf16_t T;
@@ -131,7 +138,10 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       u32x4 w = {0u, 0u, 0u, 0u};
-      if (k0 < K) w = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)(i * 16 + lr) * K + k0) * SZ);
+      // (TM == 2: row slot (i, m) holds output channel (m >> 2) * 8 + i * 4 + (m & 3) - the lane's two blocks are 8 consecutive channels,
+      //  ONE 16-byte store / operand load per fragment, 64 contiguous bytes per pixel and instruction instead of 32)
+      const int wrow = TM == 2 ? (lr >> 2) * 8 + i * 4 + (lr & 3) : i * 16 + lr;
+      if (k0 < K) w = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)wrow * K + k0) * SZ);
       fa[i][c] = w;
     }
   }
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
   if constexpr (EPI == SCL_BNB || EPI == SCL_BNB_SUM2) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const BnBackCh k = bnback_load(a.bnb, i * 16 + lg * 4);
+      const BnBackCh k = bnback_load(a.bnb, TM == 2 ? lg * 8 + i * 4 : i * 16 + lg * 4);
       ksc[i][0] = f32x2{k.sc[0], k.sc[1]}; ksc[i][1] = f32x2{k.sc[2], k.sc[3]};
       ksh[i][0] = f32x2{k.sh[0], k.sh[1]}; ksh[i][1] = f32x2{k.sh[2], k.sh[3]};
     }
@@ -160,9 +170,10 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
   if constexpr (EPI == SCL_HEAD) bias0 = a.bias ? a.bias[0] : 0.f;
   // per-lane byte offset of the lane's first output inside a tile (pixel (2 * wave, lr), channels lg * 4 ..); fragment f adds
   // ((f >> 1) * W + (f & 1) * 16) * CB, channel block i adds 32 bytes
-  const uint32_t so = EPI == SCL_BNB_SUM2 ? (uint32_t)((wave * (a.W >> 1) + (lr >> 1)) * CB + lg * 8)
+  constexpr int LB = TM == 2 ? 16 : 8;      // bytes of a pixel owned by one lane
+  const uint32_t so = EPI == SCL_BNB_SUM2 ? (uint32_t)((wave * (a.W >> 1) + (lr >> 1)) * CB + lg * LB)
                       : EPI == SCL_HEAD   ? (uint32_t)(((wave * 2) * a.W + lr) * CB)
-                                          : (uint32_t)(((wave * 2) * a.W + lr) * CB + lg * 8);
+                                          : (uint32_t)(((wave * 2) * a.W + lr) * CB + lg * LB);
   f32x4 ss[TM], qq[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -178,8 +189,12 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
       for (int f = 0; f < 4; ++f) {
         const char* xf = xb + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
         const bool ok = !EDGE || (pt.y0 + wave * 2 + (f >> 1) < a.H && pt.x0 + (f & 1) * 16 + lr < a.W);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) xo[i][f] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
+        if constexpr (TM == 2) {
+          const u32x4 w4 = *reinterpret_cast<const u32x4*>(ok ? xf + so : a.bnb.x);
+          xo[0][f] = u32x2{w4.x, w4.y}; xo[TM - 1][f] = u32x2{w4.z, w4.w};
+        } else {
+          xo[0][f] = *reinterpret_cast<const u32x2*>(ok ? xf + so : a.bnb.x);
+        }
       }
     }
     if constexpr (EPI == SCL_BNB_SUM2) {
@@ -188,8 +203,12 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
       for (int h2 = 0; h2 < 2; ++h2) {
         const char* xf = xb + (size_t)(h2 * 8 * CB);
         const bool ok = own && (!EDGE || (pt.y0 + wave * 2 < a.H && pt.x0 + h2 * 16 + lr < a.W));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) xo[i][h2] = *reinterpret_cast<const u32x2*>((ok ? xf + so : a.bnb.x) + i * 32);
+        if constexpr (TM == 2) {
+          const u32x4 w4 = *reinterpret_cast<const u32x4*>(ok ? xf + so : a.bnb.x);
+          xo[0][h2] = u32x2{w4.x, w4.y}; xo[TM - 1][h2] = u32x2{w4.z, w4.w};
+        } else {
+          xo[0][h2] = *reinterpret_cast<const u32x2*>(ok ? xf + so : a.bnb.x);
+        }
       }
     }
   };
@@ -285,20 +304,19 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
           char* of = ob + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
+          u32x2 o[TM];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const f32x4 v = acc[i][f];
-            const u32x2 o = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-            if (okf[f]) {
-              *reinterpret_cast<u32x2*>(of + so + i * 32) = o;
-              if (st) {
-                const f32x2 s0 = scl_unpack(o.x), s1 = scl_unpack(o.y);
-                const f32x4 sv = {s0.x, s0.y, s1.x, s1.y};
-                ss[i] += sv;
-                qq[i] += sv * sv;
-              }
+            o[i] = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            if (st && okf[f]) {
+              const f32x2 s0 = scl_unpack(o[i].x), s1 = scl_unpack(o[i].y);
+              const f32x4 sv = {s0.x, s0.y, s1.x, s1.y};
+              ss[i] += sv;
+              qq[i] += sv * sv;
             }
           }
+          if (okf[f]) scl_store<TM>(of + so, o);
         }
       }
       if constexpr (EPI == SCL_HEAD) {
@@ -315,10 +333,11 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
           char* of = ob + (size_t)(((f >> 1) * a.W + (f & 1) * 16) * CB);
+          u32x2 oo[TM];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const f32x4 v = acc[i][f];
-            u32x2 o;
+            u32x2& o = oo[i];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const uint32_t stw = pack_bf16x2(v[2 * e], v[2 * e + 1]);        // dY as it would be stored
@@ -330,8 +349,8 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
               qq[i][2 * e] = fmaf(g.x, xv.x, qq[i][2 * e]); qq[i][2 * e + 1] = fmaf(g.y, xv.y, qq[i][2 * e + 1]);
               o[e] = pack_bf16x2(g.x, g.y);
             }
-            if (okf[f]) *reinterpret_cast<u32x2*>(of + so + i * 32) = o;
           }
+          if (okf[f]) scl_store<TM>(of + so, oo);
         }
       }
       if constexpr (EPI == SCL_BNB_SUM2) {
@@ -342,13 +361,14 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
         for (int h2 = 0; h2 < 2; ++h2) {
           char* of = ob + (size_t)(h2 * 8 * CB);
           const bool mine = own && okf[h2];
+          u32x2 oo[TM];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             f32x4 v = acc[i][h2] + acc[i][h2 + 2];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               v[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-            u32x2 o;
+            u32x2& o = oo[i];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const uint32_t stw = pack_bf16x2(v[2 * e], v[2 * e + 1]);
@@ -360,8 +380,8 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
               qq[i][2 * e] = fmaf(g.x, xv.x, qq[i][2 * e]); qq[i][2 * e + 1] = fmaf(g.y, xv.y, qq[i][2 * e + 1]);
               o[e] = pack_bf16x2(g.x, g.y);
             }
-            if (mine) *reinterpret_cast<u32x2*>(of + so + i * 32) = o;
           }
+          if (mine) scl_store<TM>(of + so, oo);
         }
       }
     };
@@ -387,7 +407,8 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
       // sum g * xhat = rstd * (sum g * x - mean * sum g), per lane (linear, so the partition does not matter)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bnb.mean + i * 16 + lg * 4), rsd = *reinterpret_cast<const f32x4*>(a.bnb.rstd + i * 16 + lg * 4);
+        const int cb = TM == 2 ? lg * 8 + i * 4 : i * 16 + lg * 4;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bnb.mean + cb), rsd = *reinterpret_cast<const f32x4*>(a.bnb.rstd + cb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) qq[i][e] = rsd[e] * (qq[i][e] - mu[e] * ss[i][e]);
       }
@@ -399,7 +420,7 @@ __global__ __launch_bounds__(256, (TM == 1 ? (CIN <= 16 ? SC_WPE_SMALL : 3) : 2)
       for (int e = 0; e < 4; ++e) {
         const float sv = row_sum16_to_lane15(ss[i][e]), qv = row_sum16_to_lane15(qq[i][e]);
         if (lr == 15) {
-          const int cl = i * 16 + lg * 4 + e;
+          const int cl = (TM == 2 ? lg * 8 + i * 4 : i * 16 + lg * 4) + e;
           red[(wave * TM * 16 + cl) * 2] = sv;
           red[(wave * TM * 16 + cl) * 2 + 1] = qv;
         }
@@ -752,4 +773,243 @@ int sc_wg_lean_launch(const ScWgArgs& a, int cin, int cout, int dtype, int block
   if (!sc_lean_on() || !sc_stream_on() || dtype != STP_H16 || !a.src_bytes || !a.dy_bytes) return 1;
   if (a.up) return a.pbn.mean ? dispatch_scwl<true, true>(a, cin, cout, blocks, s) : dispatch_scwl<false, true>(a, cin, cout, blocks, s);
   return a.pbn.mean ? dispatch_scwl<true, false>(a, cin, cout, blocks, s) : dispatch_scwl<false, false>(a, cin, cout, blocks, s);
+}
+
+// =================================================================================================
+// PERSISTENT form of the stem kernel (7x7 / stride 2 / pad 3, 4 padded input channels -> 64; conv_stem_kernel in conv_sc.hip is the
+// single-shot form): there every one of the 4096 workgroups of the headline launch copied the 29 KB weight matrix and its 11.8 KB input
+// patch through registers into LDS, synchronised, multiplied and retired - 79 us for a layer that moves 168 MB (25 us at HBM speed).
+// Here workgroups are persistent (two per CU): the weights go to LDS once per workgroup, the input patch of the NEXT 8 x 32 output
+// tile is written into the other half of a double buffer by LDS-DMA while this one is multiplied, interior tiles take their DMA
+// offsets as (tile base) + (per-lane constant), all LDS reads of the tile loop are inline asm (the compiler would put the next
+// tile's DMA in front of the first one), the fused statistics run over all tiles of the workgroup in registers (one column per
+// workgroup instead of one per tile: 512 instead of 4096 columns for the finalize).
+// Patch geometry: 16-byte DMA vectors = two 8-byte pixels, so the patch starts at the EVEN column 2 x0 - 4 (the single-shot form starts
+// at 2 x0 - 3): 21 rows x 35 vectors; a B fragment (two horizontally adjacent taps x 4 channels) then sits at an odd pixel, 8-byte
+// aligned: two ds_read_b64.  Same MFMA order as the single-shot kernel: bit-identical outputs.
+// =================================================================================================
+constexpr int STL_VPR = 35, STL_NV = ST_HH * STL_VPR, STL_NPASS = (STL_NV + 255) / 256, STL_BUF = STL_NPASS * 4096, STL_ROW = STL_VPR * 16;
+constexpr int STL_LDS = ST_WBYTES + 2 * STL_BUF + 4 * 64 * 2 * 4;
+
+__global__ __launch_bounds__(256, 2) void conv_stem_lean_kernel(const StemArgs a) {
+  constexpr int TM = 4, NCH = 7, K = 224, COUT = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [weights 64 x 464][patch 0][patch 1][statistics scratch]
+  char* const wl = smem;
+  char* const hb = smem + ST_WBYTES;
+  float* const red = reinterpret_cast<float*>(smem + ST_WBYTES + 2 * STL_BUF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
+  } else {
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = ntiles;
+  }
+  f32x4 ss[TM], qq[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { ss[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  if (t_first < t_end) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    int hyx[STL_NPASS];
+    uint32_t lo[STL_NPASS];      // (hy * W + 2 vx) * 8: byte offset relative to the patch's first pixel; past the patch: 2^31
+#pragma unroll
+    for (int p = 0; p < STL_NPASS; ++p) {
+      const int v = p * 256 + tid, hy = v / STL_VPR, vx = v - hy * STL_VPR;
+      hyx[p] = v < STL_NV ? (hy << 16 | vx) : -1;
+      lo[p] = v < STL_NV ? (uint32_t)((hy * a.W + 2 * vx) * 8) : 0x80000000u;
+    }
+    auto decode = [&](int tile) -> TileC {
+      const int bq = (int)fdiv((uint32_t)tile, a.divTx);
+      const int tx = tile - bq * a.tiles_x;
+      const int n = (int)fdiv((uint32_t)bq, a.divTy);
+      const int ty = bq - n * a.tiles_y;
+      TileC t;
+      t.n = n; t.y0 = ty * SC_TH; t.x0 = tx * SC_TW;
+      // the whole patch (rows 2 y0 - 3 .. + 20, columns 2 x0 - 4 .. + 69) and the whole output tile lie inside the images
+      t.interior = 2 * t.y0 >= 3 && 2 * t.x0 >= 4 && 2 * t.y0 + 17 < a.H && 2 * t.x0 + 65 < a.W && t.y0 + SC_TH <= a.Ho && t.x0 + SC_TW <= a.Wo;
+      return t;
+    };
+    auto issue_tile = [&](const TileC& t, int b, bool live) {
+      if (live && t.interior) {
+        const uint32_t tb = (uint32_t)(((t.n * a.H + 2 * t.y0 - 3) * a.W + 2 * t.x0 - 4) * 8);
+#pragma unroll
+        for (int p = 0; p < STL_NPASS; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(hb + b * STL_BUF + p * 4096 + wave * 1024), 16, (int)(tb + lo[p]), 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int p = 0; p < STL_NPASS; ++p) {
+          const int gy = 2 * t.y0 - 3 + (hyx[p] >> 16), gx = 2 * t.x0 - 4 + 2 * (hyx[p] & 0xffff);      // (W is even: a vector is inside or outside as a whole)
+          const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+          const uint32_t off = ok ? (uint32_t)(((t.n * a.H + gy) * a.W + gx) * 8) : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(hb + b * STL_BUF + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
+        }
+      }
+    };
+    TileC tc = decode(t_first);
+    issue_tile(tc, 0, true);
+    // once per workgroup: the weights [64][7][8][4] -> LDS, FRAGMENT-major: vector ((c * 4 + g) * 64 + co) = weight[co][chunk c][lane group g]
+    // (an A fragment read = 64 consecutive vectors: conflict-free for the lane groups of ds_read_b128; rows of 464 bytes, the single-shot
+    // kernel's layout, cost one extra LDS cycle in every group: SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE)
+    // Row slot of output channel co: MFMA block i = (co >> 5) * 2 + ((co >> 2) & 1), row m = ((co >> 3) & 3) * 4 + (co & 3) - a lane (pixel lr,
+    // lane group lg) then holds channels (i >> 1) * 32 + lg * 8 + (i & 1) * 4 + r: blocks 2h, 2h + 1 are EIGHT consecutive channels, one
+    // 16-byte store, and the four lanes of a pixel write 64 contiguous bytes per instruction (32 with the natural order)
+    for (int v = tid; v < COUT * (K / 8); v += 256) {
+      const int co = v / (K / 8), q = v - co * (K / 8);      // q = c * 4 + g
+      const int slot = ((co >> 5) * 2 + ((co >> 2) & 1)) * 16 + ((co >> 3) & 3) * 4 + (co & 3);
+      *reinterpret_cast<u32x4*>(wl + (q * COUT + slot) * 16) = *reinterpret_cast<const u32x4*>(a.weight + ((size_t)co * K + q * 8) * 2);
+    }
+    // lane addresses: A fragment (channel block i, chunk c) = wa + (c * 256 + i * 16) vectors; B fragment (tile row 2 wave + (f >> 1), pixel
+    // (f & 1) * 16 + lr, chunk c = kh, taps kw = 2 lg, 2 lg + 1) = patch row 2 py + c, pixel 2 px + 2 lg + 1 (the patch starts at column 2 x0 - 4)
+    const uint32_t wa = (uint32_t)(uintptr_t)wl + (uint32_t)((lg * COUT + lr) * 16);
+    uint32_t ba = (uint32_t)(uintptr_t)hb + (uint32_t)((4 * wave) * STL_ROW + (2 * lr + 2 * lg + 1) * 8);
+    // per-lane byte offset of the lane's first output inside a tile: pixel (2 wave, lr), channels lg * 4 ..
+    const uint32_t so = (uint32_t)(((wave * 2) * a.Wo + lr) * (COUT * 2) + lg * 16);
+#if defined(STP_STEM_WAIT_LATE)
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    asm volatile("" ::: "memory");
+#endif
+
+    int cur = 0;
+    bool prev_full = false;
+    for (int tile = t_first; tile < t_end; tile += t_step, cur ^= 1) {
+      const TileC t = tc;
+#if defined(STP_STEM_COUNTED)
+      // (what-if) the previous tile's 16 stores - issued AFTER this tile's LDS-DMA - stay in flight when that tile was an interior one
+      if (prev_full) __builtin_amdgcn_s_waitcnt(0x4f70);    // vmcnt(16)
+      else __builtin_amdgcn_s_waitcnt(0x0f70);
+      asm volatile("" ::: "memory");
+      prev_full = t.interior;
+#elif !defined(STP_STEM_WAIT_LATE)
+      __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0): this tile's pieces (own) and the weights have landed
+      asm volatile("" ::: "memory");
+#endif
+      lds_barrier();
+      const int next = tile + t_step;
+      const bool live = next < t_end;
+      if (live) tc = decode(next);
+      issue_tile(tc, cur ^ 1, live);
+
+      f32x4 acc[TM][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // chunk c + 1's twelve reads are in flight while chunk c's sixteen MFMAs issue
+      u32x4 fa[2][TM];
+      u32x2 fb[2][4][2];
+      auto reads = [&fa, &fb, wa, ba](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        sc_unroll<TM>([&fa, wa](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[c & 1][i]) : "v"(wa), "n"((c * 4 * 64 + i * 16) * 16));
+        });
+        sc_unroll<8>([&fb, ba](auto kc) {
+          constexpr int k = decltype(kc)::value, f = k >> 1, hl = k & 1;
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[c & 1][f][hl]) : "v"(ba), "n"((2 * (f >> 1) + c) * STL_ROW + (f & 1) * 32 * 8 + hl * 8));
+        });
+      };
+      reads(std::integral_constant<int, 0>{});
+      sc_unroll<NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c + 1 < NCH) reads(std::integral_constant<int, c + 1>{});
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(c + 1 < NCH ? 12 : 0) : "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[c & 1][i]));
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { asm volatile("" : "+v"(fb[c & 1][f][0])); asm volatile("" : "+v"(fb[c & 1][f][1])); }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const u32x4 vb = {fb[c & 1][f][0].x, fb[c & 1][f][0].y, fb[c & 1][f][1].x, fb[c & 1][f][1].y};
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[i][f] = mfma16_16x16x32(fa[c & 1][i], vb, acc[i][f]);
+        }
+      });
+      ba += cur ? (uint32_t)(-STL_BUF) : (uint32_t)STL_BUF;      // the B addresses move to the other buffer half
+
+#if defined(STP_STEM_WAIT_LATE)
+      // (what-if) the next tile's pieces are waited for HERE, a whole MFMA phase after their issue and BEFORE this tile's stores: the
+      // stores then drain under the next tile's MFMAs instead of in front of its barrier
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      asm volatile("" ::: "memory");
+#endif
+      // epilogue: store, statistics of the stored values
+      char* ob = a.dst + (((size_t)t.n * a.Ho + t.y0) * a.Wo + t.x0) * (COUT * 2);
+      const bool st = a.stats != nullptr;
+      auto epilogue = [&](const bool EDGE) __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          char* of = ob + (size_t)(((f >> 1) * a.Wo + (f & 1) * 16) * (COUT * 2));
+          const bool ok = !EDGE || (t.y0 + wave * 2 + (f >> 1) < a.Ho && t.x0 + (f & 1) * 16 + lr < a.Wo);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 v0 = acc[2 * h][f], v1 = acc[2 * h + 1][f];
+            const u32x4 o = {pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w)};
+            if (ok) {
+              *reinterpret_cast<u32x4*>(of + so + h * 64) = o;
+              if (st) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                  const f32x2 s0 = scl_unpack(o[2 * u]), s1 = scl_unpack(o[2 * u + 1]);
+                  const f32x4 sv = {s0.x, s0.y, s1.x, s1.y};
+                  ss[2 * h + u] += sv;
+                  qq[2 * h + u] += sv * sv;
+                }
+              }
+            }
+          }
+        }
+      };
+      if (t.interior) epilogue(false); else epilogue(true);
+    }
+  }
+  // one column of [stat][channel][workgroups] per workgroup (a workgroup without tiles contributes zeros)
+  if (a.stats) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = row_sum16_to_lane15(ss[i][e]), qv = row_sum16_to_lane15(qq[i][e]);
+        if (lr == 15) {
+          const int cl = (i >> 1) * 32 + lg * 8 + (i & 1) * 4 + e;      // (the channel order of the row slots, see the weight staging)
+          red[(wave * COUT + cl) * 2] = sv;
+          red[(wave * COUT + cl) * 2 + 1] = qv;
+        }
+      }
+    lds_barrier();
+    if (tid < COUT) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { sv += red[(w * COUT + tid) * 2]; qv += red[(w * COUT + tid) * 2 + 1]; }
+      a.stats[(size_t)tid * gridDim.x + blockIdx.x] = sv;
+      a.stats[((size_t)COUT + tid) * gridDim.x + blockIdx.x] = qv;
+    }
+  }
+}
+
+bool stem_lean_serves(int N, int H, int W) {
+  static const bool on = !(getenv("STP_STEM_LEAN") && atoi(getenv("STP_STEM_LEAN")) == 0);
+  return on && !(W & 1) && (uint64_t)N * H * W * 8 < 0x80000000ull;
+}
+int stem_lean_blocks(int ntiles) {
+  const int64_t b = (int64_t)sc_cu_count() * 2;
+  return (int)(b < ntiles ? b : ntiles);
+}
+int stem_lean_launch(const StemArgs& a, hipStream_t s) {
+  if (!stem_lean_serves(a.N, a.H, a.W) || !a.src_bytes) return 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STL_LDS) != hipSuccess)
+      return STP_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_stem_lean_kernel, dim3(stem_lean_blocks(a.N * a.tiles_x * a.tiles_y)), dim3(256), STL_LDS, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
 }

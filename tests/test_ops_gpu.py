@@ -329,7 +329,7 @@ def test_stride2_data_gradient_in_parity_class_order(ops, geom, mode, dtype):
     np.testing.assert_allclose(part[1], (gs * xhat).reshape(-1, ci).sum(0), atol=2e-4 * np.abs(gs * xhat).sum(axis=(0, 1, 2)).max() + 1e-3)
 
 
-@pytest.mark.parametrize("size", [(32, 36), (64, 64), (37, 70)])
+@pytest.mark.parametrize("size", [(32, 36), (64, 64), (37, 70), (70, 330), (59, 262)])      # the last two: interior tiles of the persistent form
 @pytest.mark.parametrize("dtype", H16)
 def test_stem_halo_kernel_with_fused_statistics(ops, size, dtype):
     """conv_stem_kernel (bf16, tile id 768): the ResNet conv0 through the halo-tile kernel at even, tile-aligned and ragged / odd
@@ -358,7 +358,7 @@ def test_stem_halo_kernel_with_fused_statistics(ops, size, dtype):
     np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
     np.testing.assert_allclose(host(y), host(y2), atol=tol(ref, dtype))          # two summation orders, one output rounding each
     tiles = ops.conv2d_stats_floats(P) // (2 * co)
-    assert tiles == P.stats_tiles == n * -(-ho // 8) * -(-wo // 32)
+    assert tiles == P.stats_tiles and tiles <= n * -(-ho // 8) * -(-wo // 32)      # one column per tile, or per workgroup of the persistent form
     rows = n * ho * wo
     m1, r1, m0, r0 = (torch.empty(co, device=DEV) for _ in range(4))
     _lib.call("stp_bn_finalize", ops.ptr(st), tiles, rows, co, 2e-5, 0.99, ops.ptr(m1), ops.ptr(r1), None, None, ops.stream())
