@@ -125,6 +125,10 @@ struct StemArgs {
 bool stem_lean_serves(int N, int H, int W);
 int stem_lean_blocks(int ntiles);
 int stem_lean_launch(const StemArgs& a, hipStream_t s);
+// stem weight gradient (conv_stem_wgrad_lean_kernel): shape served / workgroups (= slabs [64][224]) / launch
+bool stem_wg_lean_serves(int N, int H, int W, int Ho, int Wo);
+int stem_wg_lean_blocks(int N, int Ho, int Wo);
+int stem_wg_lean_launch(const void* src, const void* dy, float* slabs, int N, int H, int W, int Ho, int Wo, hipStream_t s);
 
 // conv_sc_lean.hip: launches the lean kernel if it serves this configuration (returns STP_OK / an error), or returns 1 = "not served"
 int sc_lean_launch(const ScArgs& a, int cin, int dtype, hipStream_t s);

@@ -2106,8 +2106,16 @@ __global__ __launch_bounds__(256) void conv_sc_wgrad_kernel(const ScWgArgs a) {
 
 #define SC_WG_MAX_BLOCKS 1024
 
+// the stem's weight gradient (7x7 / stride 2, 4 padded input channels -> 64) through conv_stem_wgrad_lean_kernel (conv_sc_lean.hip)
+static bool wgrad_stem_shape(const stp_wgrad_params* p) {
+  return p->dtype == STP_H16 && p->C0 == 4 && p->C1 == 0 && p->KH == 7 && p->KW == 8 && p->stride == 2 && p->pad == 3 && p->Cout == 64 &&
+         p->src0_mode == STP_SRC_DIRECT && p->Hs0 == p->Hv && p->Ws0 == p->Wv && p->Ho == (p->Hv - 1) / 2 + 1 && p->Wo == (p->Wv - 1) / 2 + 1 &&
+         !p->src_bn_mean && stem_wg_lean_serves(p->N, p->Hv, p->Wv, p->Ho, p->Wo);
+}
+
 extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
   if (!p || !stp_dtype_ok(p->dtype)) return 0;
+  if (wgrad_stem_shape(p)) return 1;
   const int vec = p->dtype == STP_H16 ? 8 : 4;
   const bool c0ok = p->C0 == 16 || p->C0 == 32 || (p->C0 == 64 && vec == 8);
   const bool c1ok = p->C1 == 0 || p->C1 == 16 || p->C1 == 32 || (p->C1 == 64 && vec == 8);   // (shape-only: no pointers here)
@@ -2119,6 +2127,7 @@ extern "C" int stp_wgrad_sc_eligible(const stp_wgrad_params* p) {
 
 // number of slabs (= workgroups) the small-channel weight gradient writes
 extern "C" int stp_wgrad_sc_slabs(const stp_wgrad_params* p) {
+  if (wgrad_stem_shape(p)) return stem_wg_lean_blocks(p->N, p->Ho, p->Wo);
   const int64_t tiles = (int64_t)p->N * ceil_div(p->Hv, SC_TH) * ceil_div(p->Wv, SC_TW);
   static const int max_blocks = getenv("STP_SC_WG_BLOCKS") ? atoi(getenv("STP_SC_WG_BLOCKS")) : SC_WG_MAX_BLOCKS;
   // one workgroup per slot the double-buffered staging leaves on a CU (round 4: 1024 workgroups of an 80 KB kernel were two rounds of
@@ -2193,6 +2202,7 @@ static int sc_wg_dispatch(const ScWgArgs& a, int cin, int cout, int blocks, hipS
 // One launch per source of the concatenated input; both write disjoint column ranges of the same slabs.
 extern "C" int stp_wgrad_sc_partial(const stp_wgrad_params* p, void* workspace, void* stream) {
   if (!stp_wgrad_sc_eligible(p) || !p->src0 || !p->dy || !workspace || (p->C1 > 0 && !p->src1)) return STP_E_BADARG;
+  if (wgrad_stem_shape(p)) return stem_wg_lean_launch(p->src0, p->dy, (float*)workspace, p->N, p->Hv, p->Wv, p->Ho, p->Wo, (hipStream_t)stream);
   ScWgArgs a;
   a.dy = (const char*)p->dy; a.slabs = (float*)workspace;
   a.N = p->N; a.H = p->Hv; a.W = p->Wv; a.Cout = p->Cout;

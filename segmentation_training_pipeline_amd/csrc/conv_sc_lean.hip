@@ -1013,3 +1013,188 @@ int stem_lean_launch(const StemArgs& a, hipStream_t s) {
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
+
+// =================================================================================================
+// Stem WEIGHT GRADIENT (7x7 / stride 2 / pad 3, input 4 padded channels, 64 output channels):
+//   dW[co][kh][kw (8)][c (4)] = sum over output pixels of dY[p][co] * X[2 py - 3 + kh][2 px - 3 + kw][c]
+// The generic pixel-reduction GEMM gathers its 7 x 8 x 4 patch columns pixel by pixel through the vector-memory path: 96-100 us for a
+// layer that reads 168 MB (25 us at HBM speed; SQ_ACTIVE_INST_ANY / SQ_BUSY_CYCLES 9.8, MFMA 14 % busy).  Here, with the recipe of the
+// kernels above: persistent workgroups walk 4 x 32-pixel output tiles; the 13 x 70-pixel input patch (16-byte vectors = two pixels,
+// starting at the even column 2 x0 - 4 as in conv_stem_lean_kernel) and the dY tile go to a double buffer by LDS-DMA.  Reduction index =
+// the 32 pixels of a tile row, fragments by transpose reads: A = dY^T (wave w owns output channels 16 w .. 16 w + 15: no cross-wave
+// reduction), B = 32 pixels x 16 columns, the 16 columns being FOUR taps kw x 4 channels = 32 contiguous bytes of the patch.  A B
+// fragment of patch row r serves every (tile row, kh) pair with 2 * row + kh = r: 52 + 8 transpose reads for 56 MFMAs per tile and wave.
+// One fp32 slab [64][224] per workgroup, summed by the generic fixed-order reduce kernel (the small-channel plan of conv_wgrad.hip).
+// =================================================================================================
+constexpr int SWG_TH = 4, SWG_PH = 2 * (SWG_TH - 1) + 7;                      // tile rows, patch rows (13)
+constexpr int SWG_NVX = SWG_PH * STL_VPR, SWG_NPX = (SWG_NVX + 255) / 256;    // patch vectors / passes
+constexpr int SWG_NVD = SWG_TH * SC_TW * 8, SWG_NPD = (SWG_NVD + 255) / 256;  // dY vectors (64 channels = 8 per pixel) / passes
+constexpr int SWG_XBUF = SWG_NPX * 4096, SWG_BUF = SWG_XBUF + SWG_NPD * 4096;
+
+struct StemWgArgs {
+  const char* src;   // [N,H,W,4]
+  const char* dy;    // [N,Ho,Wo,64]
+  float* slabs;      // [workgroups][64][224]
+  int N, H, W, Ho, Wo, tiles_x, tiles_y, ntiles;
+  uint32_t src_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_stem_wgrad_lean_kernel(const StemWgArgs a) {
+  constexpr int COUT = 64, K = 224, NF = 14;             // accumulator fragments of a wave: (kh, kw half)
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][patch | dY tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+
+  int t_first, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, x = blockIdx.x & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    t_first = start + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = start + q + (x < r ? 1 : 0);
+  } else {
+    t_first = (int)blockIdx.x; t_step = (int)gridDim.x; t_end = a.ntiles;
+  }
+  f32x4 acc[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (t_first < t_end) {
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+    int hyx[SWG_NPX], pyx[SWG_NPD];
+    uint32_t lox[SWG_NPX], lod[SWG_NPD];
+#pragma unroll
+    for (int p = 0; p < SWG_NPX; ++p) {
+      const int v = p * 256 + tid, hy = v / STL_VPR, vx = v - hy * STL_VPR;
+      hyx[p] = v < SWG_NVX ? (hy << 16 | vx) : -1;
+      lox[p] = v < SWG_NVX ? (uint32_t)((hy * a.W + 2 * vx) * 8) : 0x80000000u;
+    }
+#pragma unroll
+    for (int p = 0; p < SWG_NPD; ++p) {
+      const int v = p * 256 + tid, pix = v >> 3, py = pix / SC_TW, px = pix % SC_TW;
+      pyx[p] = v < SWG_NVD ? (py << 16 | px) : -1;
+      lod[p] = v < SWG_NVD ? (uint32_t)((py * a.Wo + px) * (COUT * 2) + (v & 7) * 16) : 0x80000000u;
+    }
+    const uint32_t cvd = (uint32_t)(tid & 7) * 16u;
+    auto decode = [&](int tile) -> TileC {
+      int b = tile;
+      const int tx = b % a.tiles_x; b /= a.tiles_x;
+      const int ty = b % a.tiles_y;
+      TileC t;
+      t.n = b / a.tiles_y; t.y0 = ty * SWG_TH; t.x0 = tx * SC_TW;
+      t.interior = 2 * t.y0 >= 3 && 2 * t.x0 >= 4 && 2 * t.y0 - 3 + SWG_PH <= a.H && 2 * t.x0 + 65 < a.W && t.y0 + SWG_TH <= a.Ho && t.x0 + SC_TW <= a.Wo;
+      return t;
+    };
+    auto issue_tile = [&](const TileC& t, int bsel, bool live) {
+      char* xb = smem + bsel * SWG_BUF;
+      if (live && t.interior) {
+        const uint32_t tbx = (uint32_t)(((t.n * a.H + 2 * t.y0 - 3) * a.W + 2 * t.x0 - 4) * 8);
+        const uint32_t tbd = (uint32_t)(((t.n * a.Ho + t.y0) * a.Wo + t.x0) * (COUT * 2));
+#pragma unroll
+        for (int p = 0; p < SWG_NPX; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xb + p * 4096 + wave * 1024), 16, (int)(tbx + lox[p]), 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < SWG_NPD; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(xb + SWG_XBUF + p * 4096 + wave * 1024), 16, (int)(tbd + lod[p]), 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int p = 0; p < SWG_NPX; ++p) {
+          const int gy = 2 * t.y0 - 3 + (hyx[p] >> 16), gx = 2 * t.x0 - 4 + 2 * (hyx[p] & 0xffff);      // (W is even: a vector is inside or outside as a whole)
+          const bool ok = live && hyx[p] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+          const uint32_t off = ok ? (uint32_t)(((t.n * a.H + gy) * a.W + gx) * 8) : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xb + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < SWG_NPD; ++p) {
+          const int gy = t.y0 + (pyx[p] >> 16), gx = t.x0 + (pyx[p] & 0xffff);
+          const bool ok = live && pyx[p] >= 0 && gy < a.Ho && gx < a.Wo;
+          const uint32_t off = ok ? (uint32_t)(((t.n * a.Ho + gy) * a.Wo + gx) * (COUT * 2)) + cvd : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(xb + SWG_XBUF + p * 4096 + wave * 1024), 16, (int)off, 0, 0, 0);
+        }
+      }
+    };
+    TileC tc = decode(t_first);
+    issue_tile(tc, 0, true);
+    // lane group g owns pixels x = 4g..4g+3 (lo) and 16+4g..16+4g+3 (hi) of a 32-pixel tile row; lane i of a group addresses pixel (i>>2), quad (i&3).
+    // A (dY^T, channels 16 wave ..): quad = 4 channels.  B: quad = tap kw (4 channels = 8 bytes); output pixel x, tap kw (of the fragment's
+    // four) sit at patch pixel 2 x + 1 + kw (the patch starts at column 2 x0 - 4), the upper four taps 32 bytes further
+    const int xl = lg * 4 + (lr >> 2), qd = lr & 3;
+    uint32_t aA = (uint32_t)(uintptr_t)smem + (uint32_t)(SWG_XBUF + (xl * COUT + wave * 16) * 2 + qd * 8);
+    uint32_t aB = (uint32_t)(uintptr_t)smem + (uint32_t)((2 * xl + 1 + qd) * 8);
+
+    int cur = 0;
+    for (int tile = t_first; tile < t_end; tile += t_step, cur ^= 1) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0): own pieces of this tile have landed
+      asm volatile("" ::: "memory");
+      lds_barrier();
+      const int next = tile + t_step;
+      const bool live = next < t_end;
+      if (live) tc = decode(next);
+      issue_tile(tc, cur ^ 1, live);
+
+      u32x2 fa[SWG_TH][2];          // dY fragments of the four tile rows: [row][lo / hi pixels]
+      u32x2 fb[2][2][2];            // X fragments of one patch row, double-buffered: [buffer][kw half][lo / hi pixels]
+      sc_unroll<SWG_TH * 2>([&fa, aA](auto kc) {
+        constexpr int k = decltype(kc)::value, r = k >> 1, hl = k & 1;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[r][hl]) : "v"(aA), "n"((r * SC_TW + hl * 16) * COUT * 2));
+      });
+      auto issue_b = [&fb, aB](auto rc) {
+        constexpr int pr = decltype(rc)::value;
+        sc_unroll<4>([&fb, aB](auto kc) {
+          constexpr int k = decltype(kc)::value, kwh = k >> 1, hl = k & 1;
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[pr & 1][kwh][hl]) : "v"(aB), "n"(pr * STL_ROW + kwh * 32 + hl * 32 * 8));
+        });
+      };
+      issue_b(std::integral_constant<int, 0>{});
+      sc_unroll<SWG_PH>([&](auto rc) {
+        constexpr int pr = decltype(rc)::value;           // patch row: serves (tile row r, kh) with 2 r + kh == pr
+        if constexpr (pr + 1 < SWG_PH) issue_b(std::integral_constant<int, pr + 1>{});
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(pr + 1 < SWG_PH ? 4 : 0) : "memory");
+        if constexpr (pr == 0) {
+#pragma unroll
+          for (int r = 0; r < SWG_TH; ++r) { asm volatile("" : "+v"(fa[r][0])); asm volatile("" : "+v"(fa[r][1])); }
+        }
+#pragma unroll
+        for (int kwh = 0; kwh < 2; ++kwh) { asm volatile("" : "+v"(fb[pr & 1][kwh][0])); asm volatile("" : "+v"(fb[pr & 1][kwh][1])); }
+#pragma unroll
+        for (int r = 0; r < SWG_TH; ++r) {
+          const int kh = pr - 2 * r;
+          if (kh < 0 || kh > 6) continue;
+          const u32x4 va = {fa[r][0].x, fa[r][0].y, fa[r][1].x, fa[r][1].y};
+#pragma unroll
+          for (int kwh = 0; kwh < 2; ++kwh) {
+            const u32x4 vb = {fb[pr & 1][kwh][0].x, fb[pr & 1][kwh][0].y, fb[pr & 1][kwh][1].x, fb[pr & 1][kwh][1].y};
+            acc[kh * 2 + kwh] = mfma16_16x16x32(va, vb, acc[kh * 2 + kwh]);
+          }
+        }
+      });
+      const uint32_t flip = cur ? (uint32_t)(-SWG_BUF) : (uint32_t)SWG_BUF;
+      aA += flip; aB += flip;
+    }
+  }
+  // slab: C layout row (channel) = lg*4 + r, column = lr = (tap of the half, input channel): k = kh * 32 + kw half * 16 + lr
+  float* out = a.slabs + (size_t)blockIdx.x * COUT * K;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(size_t)(wave * 16 + lg * 4 + r) * K + (f >> 1) * 32 + (f & 1) * 16 + lr] = acc[f][r];
+}
+
+bool stem_wg_lean_serves(int N, int H, int W, int Ho, int Wo) {
+  static const bool on = !(getenv("STP_STEM_WG_LEAN") && atoi(getenv("STP_STEM_WG_LEAN")) == 0);
+  return on && !(W & 1) && (uint64_t)N * H * W * 8 < 0x80000000ull && (uint64_t)N * Ho * Wo * 128 < 0x80000000ull;
+}
+int stem_wg_lean_blocks(int N, int Ho, int Wo) {
+  const int64_t tiles = (int64_t)N * ((Ho + SWG_TH - 1) / SWG_TH) * ((Wo + SC_TW - 1) / SC_TW), b = (int64_t)sc_cu_count() * 2;
+  return (int)(b < tiles ? b : tiles);
+}
+int stem_wg_lean_launch(const void* src, const void* dy, float* slabs, int N, int H, int W, int Ho, int Wo, hipStream_t s) {
+  StemWgArgs a;
+  a.src = (const char*)src; a.dy = (const char*)dy; a.slabs = slabs;
+  a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  a.tiles_x = (Wo + SC_TW - 1) / SC_TW; a.tiles_y = (Ho + SWG_TH - 1) / SWG_TH; a.ntiles = N * a.tiles_x * a.tiles_y;
+  a.src_bytes = (uint32_t)((uint64_t)N * H * W * 8); a.dy_bytes = (uint32_t)((uint64_t)N * Ho * Wo * 128);
+  hipLaunchKernelGGL(conv_stem_wgrad_lean_kernel, dim3(stem_wg_lean_blocks(N, Ho, Wo)), dim3(256), 2 * SWG_BUF, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}

@@ -577,10 +577,11 @@ def test_conv_halo_kernel_two_destinations_with_summed_upsampling_gradient(ops, 
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
-def test_stem_conv_7x7_s2_padded_channels(ops, dtype):
+@pytest.mark.parametrize("shape", [(2, 32, 36), (1, 58, 268)])      # the second: interior tiles of the persistent stem kernels (forward and weight gradient)
+def test_stem_conv_7x7_s2_padded_channels(ops, dtype, shape):
     """conv0: 7x7/2 over a 3-channel image stored as 4 channels (4th = 1), weights padded to 7x8x4."""
     rng = np.random.RandomState(7)
-    n, h, w, co = 2, 32, 36, 64
+    (n, h, w), co = shape, 64
     x3 = q(rng.randn(n, h, w, 3), dtype)
     wt = q(rng.randn(7, 7, 3, co) / 12.0, dtype)
     ref = np_ops.conv2d(x3, wt, 2, 3)
