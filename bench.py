@@ -45,7 +45,10 @@ def kernel_key(name, meta, dtype):
         dtype = "bf16"          # same kernel set, same template arguments: the storage format is a build parameter
     if name == "stp_conv2d":
         tile = meta["tile"]
-        if tile == 512:   # small-channel streaming kernel (conv_sc.hip): <storage, input channels, 16-channel output tiles>
+        if tile == 512:   # small-channel streaming kernel: the lean form (conv_sc_lean.hip, 16-bit storage: <input channels, 16-channel output
+            # tiles, epilogue, ...>) or the generic one (conv_sc.hip: <storage, input channels, 16-channel output tiles>)
+            if dtype == "bf16" and os.environ.get("STP_SC_LEAN", "1") != "0" and meta.get("sc"):
+                return "conv_sc_lean_kernel<%d, %d" % tuple(meta["sc"])
             return "conv_sc_stream_kernel<%s, %d, %d>" % ((t,) + tuple(meta["sc"])) if meta.get("sc") else "conv_sc_stream_kernel<%s>" % t
         if tile == 640:   # wide-output small-channel data gradient (conv_sc.hip: stp_conv2d_scw)
             return "conv_scw_stream_kernel<%s>" % t
@@ -53,8 +56,8 @@ def kernel_key(name, meta, dtype):
             return "conv_scn_stream_kernel<%s>" % t
         if tile == 736:   # 64 -> 64 channels with the weights in registers (conv_sc.hip: stp_conv2d_s64)
             return "conv_s64_stream_kernel<%s>" % t
-        if tile == 768:
-            return "conv_stem_kernel"
+        if tile == 768:   # the stem: persistent form (conv_sc_lean.hip) unless switched off
+            return "conv_stem_lean_kernel" if os.environ.get("STP_STEM_LEAN", "1") != "0" else "conv_stem_kernel"
         if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows> (the profiler's name carries the epilogue variant as a 5th argument)
             return "conv_halo_kernel<%s>" % ("16, 128, 2, 4", "8, 128, 2, 4", "16, 64, 1, 8", "8, 64, 2, 4", "32, 64, 1, 8")[tile - 1024]
         if tile >= 256:  # buffer-DMA kernel, per-lane tap (small channel counts), 2 stages
@@ -69,7 +72,9 @@ def kernel_key(name, meta, dtype):
         return "conv_wgrad_row_group%s_kernel<%s, 3>" % ("_pbn" if meta.get("pbn") else "", {128: "128, 2, 2", 64: "64, 1, 4", 32: "32, 1, 4"}[meta["bm"]])
     if name == "stp_conv2d_wgrad":
         if meta.get("sc"):
-            return "conv_sc_wgrad_kernel<%s>" % t
+            if dtype == "bf16" and meta["layer"] == "conv0":
+                return "conv_stem_wgrad_lean_kernel"
+            return "conv_sc_wgrad_lean_kernel" if (dtype == "bf16" and os.environ.get("STP_SC_LEAN", "1") != "0") else "conv_sc_wgrad_kernel<%s>" % t
         if meta.get("kernel_id") in (2, 3):   # row-of-taps kernel (conv_wgrad.hip): <output channels per workgroup, waves over channels x columns>
             return "conv_wgrad_row_kernel<%s, %s>" % ("128, 2, 2" if meta["kernel_id"] == 2 else "64, 1, 4", os.environ.get("STP_WGRAD_ROW_STAGES", "3"))
         if dtype == "bf16" and meta["layer"] == "conv0":
