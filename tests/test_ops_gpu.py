@@ -2317,3 +2317,26 @@ def test_each_build_rejects_the_other_builds_16bit_code(ops):
         P.dtype = good
         assert lib.stp_conv2d(ctypes.byref(P), ops.stream()) == 0
     torch.cuda.synchronize()
+
+
+def test_lean_kernels_equal_the_generic_ones():
+    """conv_sc_lean.hip (lean small-channel kernels, persistent stem kernels) against the generic kernels they replace: the switches are
+    read once per process, so the same seeded launches (tests/_lean_vs_generic.py: every configuration of the training step, a shape
+    with interior and ragged border tiles) run in two subprocesses.  Outputs: BIT-identical (same MFMA order, one rounding); statistic
+    sums / the stem's weight gradient: equal to fp32 rounding (other summation order)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for v in ("0", "1"):
+        env = dict(os.environ, STP_SC_LEAN=v, STP_STEM_LEAN=v, STP_STEM_WG_LEAN=v, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_lean_vs_generic.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("LEANJSON ")][-1][9:]))
+    gen, lean = res
+    assert set(gen) == set(lean)
+    for k in gen:
+        assert gen[k]["y"] == lean[k]["y"], k
+        a, b = np.array(gen[k]["sums"]), np.array(lean[k]["sums"])
+        assert a.shape == b.shape, k
+        if a.size:
+            np.testing.assert_allclose(b, a, atol=3e-5 * np.abs(a).max() + 1e-6, err_msg=k)
