@@ -109,3 +109,71 @@ class DirectoryDataSet(DataSet):
     def __getitem__(self, item):
         f = self.ids[item]
         return PredictionItem(f, _imread_rgb(os.path.join(self.path, f)), None)
+
+
+# ------------------------------------------------------------------------------------------ writeable datasets
+# musket_core.datasets (un-vendored; imported by reference segmentation.py:12) supplies WriteableDataSet / DirectWriteableDS /
+# CompressibleWriteableDS.  What is reproduced is what the reference's call sites need (segmentation.py:196-208): a dataset of
+# per-item PREDICTIONS that lives in a folder, is filled with ``append`` + ``commit`` and read back as
+# ``PredictionItem(id, parent[i].x, prediction)``; the compressible form stores ``round-down(p * scale)`` as uint8 (scale <= 255)
+# or uint16 inside a compressed .npz and divides on load (``compressPredictionsAsInts`` / ``compressScale`` of the YAML).
+class WriteableDataSet(DataSet):
+    def append(self, item):
+        raise NotImplementedError
+
+    def commit(self):
+        raise NotImplementedError
+
+
+class DirectWriteableDS(WriteableDataSet):
+    """One file per item under ``dsPath`` (``<index>.npy``); ``count`` = items already present (re-opening a folder)."""
+
+    def __init__(self, orig, name, dsPath, count=0):
+        self.parent, self.name, self.dsPath, self.count = orig, name, dsPath, int(count)
+        os.makedirs(dsPath, exist_ok=True)
+
+    def item_path(self, i):
+        return os.path.join(self.dsPath, str(int(i)))
+
+    def saveItem(self, path, item):
+        np.save(path + ".npy", np.asarray(item))
+
+    def loadItem(self, path):
+        return np.load(path + ".npy")
+
+    def append(self, item):
+        self.saveItem(self.item_path(self.count), item)
+        self.count += 1
+
+    def commit(self):
+        return self
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, item):
+        i = int(item)
+        if i < 0 or i >= self.count:
+            raise IndexError(i)
+        src = self.parent[i] if self.parent is not None else None
+        return PredictionItem(src.id if src is not None else i, src.x if src is not None else None, self.loadItem(self.item_path(i)))
+
+    def isPositive(self, item):
+        return self.parent.isPositive(item) if self.parent is not None and hasattr(self.parent, "isPositive") else True
+
+
+class CompressibleWriteableDS(DirectWriteableDS):
+    def __init__(self, orig, name, dsPath, count=0, asUints=True, scale=255):
+        super().__init__(orig, name, dsPath, count)
+        self.asUints, self.scale = bool(asUints), scale
+
+    def saveItem(self, path, item):
+        a = np.asarray(item)
+        if self.asUints:
+            a = (a * self.scale).astype(np.uint8 if self.scale <= 255 else np.uint16)
+        np.savez_compressed(path + ".npy.npz", arr=a)
+
+    def loadItem(self, path):
+        with np.load(path + ".npy.npz") as z:
+            a = z["arr"]
+        return a.astype(np.float32) / self.scale if self.asUints else a

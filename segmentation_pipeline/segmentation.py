@@ -9,7 +9,8 @@ What is mirrored: ``parse`` (sets ``cfg.path``), ``PipelineConfig`` with ``creat
 (the YAML -> constructor-kwargs rules of reference :96-155: ``activation: none``, architecture lookup
 order, backbone check and its error messages, alias renaming, signature filtering, ``crops``),
 ``createStage`` / ``SegmentationStage.unfreeze`` (:49-50, :249-260), ``custom_models`` (:31-33), the
-loss/metric name registry (:15-22) and ``predict_to_directory`` (:62-79).  The Keras / imgaug objects
+loss/metric name registry (:15-22), ``evaluate`` / ``update`` (:37-47, :58-60), ``predict_to_directory`` (:62-79) and
+``load_writeable_dataset`` / ``create_writeable_dataset`` (:196-208).  The Keras / imgaug objects
 behind those names are replaced by the HIP plan; nothing here computes on the CPU.
 """
 import inspect
@@ -61,6 +62,38 @@ class PipelineConfig(generic.GenericTaskConfig):
 
     def createStage(self, x):
         return SegmentationStage(x, self)
+
+    def evaluate(self, d, fold, stage, negatives="all", limit=16):
+        """Reference :37-47: up to ``limit`` validation items of ``fold`` go through the validation pipeline
+        (``transformAugmentor``: ``transforms`` + Resize, on the device) and ``model.predict``; yields the batch with
+        ``images_aug`` and ``heatmaps_aug`` (one probability map per item, ``.arr`` H x W x classes) filled in."""
+        mdl = self.load_model(fold, stage)
+        ta = self.transformAugmentor()
+        folds = self.kfold(d, range(0, len(d)))
+        rs = folds.load(fold, False, negatives, limit)
+        for z in ta.augment_batches([rs]):
+            res = mdl.predict(np.array(z.images_aug))
+            z.heatmaps_aug = [PredictedMap(x) for x in res]
+            yield z
+
+    def update(self, z, res):
+        """Reference :58-60: attaches predictions ``res`` to the batch ``z`` as its ``segmentation_maps_aug``."""
+        z.segmentation_maps_aug = [PredictedMap(x) for x in res]
+
+    def _writeable(self, ds, path, count):
+        from segmentation_pipeline.impl.datasets import CompressibleWriteableDS
+        resName = (ds.name if hasattr(ds, "name") else "") + "_predictions"
+        if self.compressScale is not None:
+            return CompressibleWriteableDS(ds, resName, path, count, asUints=self.compressPredictionsAsInts, scale=self.compressScale)
+        return CompressibleWriteableDS(ds, resName, path, count, asUints=self.compressPredictionsAsInts)
+
+    def load_writeable_dataset(self, ds, path):
+        """Reference :196-201: re-opens the predictions stored for ``ds`` under ``path`` (one entry per item of ``ds``)."""
+        return self._writeable(ds, path, len(ds))
+
+    def create_writeable_dataset(self, dataset, dsPath):
+        """Reference :203-208: an empty predictions dataset over ``dataset`` stored under ``dsPath`` (``append`` + ``commit``)."""
+        return self._writeable(dataset, dsPath, 0)
 
     def createNet(self):
         return self.createNet1(False)

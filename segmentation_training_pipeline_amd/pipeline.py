@@ -304,6 +304,89 @@ class KFoldedDataSet(object):
         return np.array(pos + neg[:k], np.int64)
 
 
+class ItemBatch(object):
+    """Stand-in for the ``imgaug.Batch`` that ``folds.load`` returns in the reference (musket_core, un-vendored; call sites
+    segmentation.py:41,228): ``images`` (original uint8 arrays), ``segmentation_maps`` (ground-truth masks), ``data`` (ids); an
+    augmentor adds ``images_aug`` / ``segmentation_maps_aug`` at the network shape, ``evaluate`` adds ``heatmaps_aug``."""
+
+    def __init__(self, images, segmentation_maps, data, items=None):
+        self.images, self.segmentation_maps, self.data, self.items = images, segmentation_maps, data, items
+        self.images_aug = self.segmentation_maps_aug = self.heatmaps_aug = None
+
+
+def _folds_load(self, fold, isTrain, negatives="all", limit=16):
+    """Up to ``limit`` items of the fold's train / validation indexes as one batch (reference segmentation.py:41, 228)."""
+    idx = [int(i) for i in list(self.sampledIndexes(fold, isTrain, negatives))[:limit]]
+    items = [self.ds[i] for i in idx]
+    return ItemBatch([it.x for it in items], [it.y for it in items], [it.id for it in items], items)
+
+
+def _folds_augmentor(self, isTrain=True):
+    """The fold's augmentor (reference segmentation.py:223 ``folds.augmentor(isTrain=True)``): set by ``cfg.kfold`` - the training
+    pipeline ``augmentation`` + ``transforms`` + Resize, or the validation one."""
+    if getattr(self, "cfg", None) is None:
+        raise ValueError("this fold set was not created by cfg.kfold(): no augmentation pipeline is attached")
+    return TransformAugmentor(self.cfg, train=bool(isTrain))
+
+
+KFoldedDataSet.load = _folds_load
+KFoldedDataSet.augmentor = _folds_augmentor
+
+
+class _FeedTarget(object):
+    """The two input buffers a DeviceFeeder fills (what it reads of a plan)."""
+
+    class _T(object):
+        def __init__(self, buf):
+            self.buf = buf
+
+    def __init__(self, n, H, W, ch, device):
+        self.inputs = {"image": self._T(torch.empty((n, H, W, ch), dtype=torch.uint8, device=device)),
+                       "mask": self._T(torch.empty((n, H, W, 1), dtype=torch.uint8, device=device))}
+
+
+class TransformAugmentor(object):
+    """``cfg.transformAugmentor()`` (reference segmentation.py:39, 224): ``transforms`` + Resize to the network shape, applied jointly
+    to images and masks - on the device (``stp_augment_u8``), like every other resize of this backend.  ``augment_batches`` takes
+    ItemBatch objects (``folds.load``) and yields them with ``images_aug`` uint8 [n, H, W, C] and ``segmentation_maps_aug``
+    uint8 [n, H, W, 1] filled in.  ``train=True``: the training pipeline (``augmentation`` as well)."""
+
+    def __init__(self, cfg, train=False, seed=None):
+        self.cfg, self.train = cfg, bool(train)
+        s = cfg.shape
+        c = int(cfg.crops) if cfg.crops else 1
+        self.H, self.W, self.ch = int(s[0]) // c, int(s[1]) // c, int(s[2]) if len(s) > 2 else 3
+        _, local_rank, _ = distributed.env_world()
+        self.device = "cuda:%d" % distributed.device_index(local_rank)
+        spec = cfg._aug_spec() if self.train else augment.resolve_paths(
+            cfg.transforms, os.path.dirname(os.path.abspath(cfg.path)) if cfg.path else None)
+        self.feeder = DeviceFeeder(self.device, (self.H, self.W), spec, seed=cfg.random_state if seed is None else seed,
+                                   classes=cfg.classes, channels=self.ch)
+
+    def augment_batches(self, batches):
+        for b in batches:
+            items = b.items if getattr(b, "items", None) is not None else [
+                _Item(i, x, y) for i, x, y in zip(b.data, b.images, b.segmentation_maps)]
+            n = len(items)
+            if n == 0:
+                b.images_aug = np.zeros((0, self.H, self.W, self.ch), np.uint8)
+                b.segmentation_maps_aug = np.zeros((0, self.H, self.W, 1), np.uint8)
+                yield b
+                continue
+            tgt = _FeedTarget(n, self.H, self.W, self.ch, self.device)
+            # validation = Resize only (+ `transforms`): the feeder's `training` flag selects whether its spec is sampled at all
+            self.feeder.feed(tgt, items, training=True if (self.train or self.feeder.spec) else False)
+            torch.cuda.synchronize(self.device)
+            b.images_aug = tgt.inputs["image"].buf.cpu().numpy()
+            b.segmentation_maps_aug = tgt.inputs["mask"].buf.cpu().numpy()
+            yield b
+
+
+class _Item(object):
+    def __init__(self, ident, x, y):
+        self.id, self.x, self.y = ident, x, y
+
+
 def crop_bounds(size, crops):
     """Cell boundaries along one axis for ``crops`` cells (README.md:476-491): floor(k * size / crops)."""
     return [(k * size) // crops for k in range(crops + 1)]
@@ -727,6 +810,9 @@ class GenericTaskConfig(object):
         self.gpus = int(a.get("gpus", 1))
         self.inference_batch = int(a.get("inference_batch", self.batch))
         self.showDataExamples = False
+        # storage of predictions in writeable datasets (reference segmentation.py:196-208 reads both attributes)
+        self.compressPredictionsAsInts = bool(a.get("compressPredictionsAsInts", True))
+        self.compressScale = a.get("compressScale")
         self.drawingFunction = None
         # the reference always draws validation examples each epoch; `draw_examples: false` in the YAML (a key of this
         # backend) switches the per-epoch JPG sheets off for throughput runs
@@ -770,7 +856,13 @@ class GenericTaskConfig(object):
     def kfold(self, ds, indexes=None):
         if indexes is None:
             indexes = range(len(ds))
-        return self.dataset_clazz(ds, indexes, self.folds_count, self.random_state, self.testSplit)
+        kf = self.dataset_clazz(ds, indexes, self.folds_count, self.random_state, self.testSplit)
+        kf.cfg = self            # folds.augmentor(isTrain) builds this experiment's pipeline (reference segmentation.py:223)
+        return kf
+
+    def transformAugmentor(self):
+        """Validation-time pipeline: ``transforms`` + Resize to the network shape (reference segmentation.py:39, 224)."""
+        return TransformAugmentor(self, train=False)
 
     # --- model lifecycle
     def _compiled(self, stage=None, use_graph=True):

@@ -92,6 +92,28 @@ def test_parse_fit_predict_end_to_end(tmp_path):
             assert np.array_equal(rle_decode(rle_encode(p1), (128, 128)) > 0, p1)     # the submission helper round-trips
             n_val += 1
     assert n_val == 4 and np.mean(dices) > 0.2      # 8 epochs on 4 images: plumbing, not accuracy
+    # evaluate (reference :37-47): `limit` validation items through transformAugmentor (Resize on the device) + predict
+    zs = list(cfg.evaluate(ds, 0, 1, limit=3))
+    assert len(zs) == 1 and zs[0].images_aug.shape == (3, 128, 128, 3) and zs[0].images_aug.dtype == np.uint8
+    assert len(zs[0].heatmaps_aug) == 3 and zs[0].heatmaps_aug[0].arr.shape == (128, 128, 1)
+    assert np.array_equal(zs[0].images_aug[0], zs[0].images[0])               # 128 -> 128 resize is the identity
+    assert np.array_equal(zs[0].segmentation_maps_aug[0][:, :, 0], (zs[0].segmentation_maps[0][:, :, 0] != 0).astype(np.uint8))
+    ref = segmentation.PipelineConfig.predict_on_batch(cfg, cfg.load_model(0, 1), None, zs[0].images_aug)
+    assert np.allclose(ref[0], zs[0].heatmaps_aug[0].arr, atol=1e-6)
+    # update (:58-60) + writeable predictions dataset (:196-208), uint8-compressed on disk
+    cfg.update(zs[0], ref)
+    assert zs[0].segmentation_maps_aug[1].arr.shape == (128, 128, 1)
+    wds = cfg.create_writeable_dataset(ds, str(tmp_path / "preds"))
+    for it in zs[0].heatmaps_aug:
+        wds.append(it.arr)
+    wds.commit()
+    assert len(wds) == 3 and wds.name == "train_predictions"
+    back = cfg.load_writeable_dataset(ds, str(tmp_path / "preds"))
+    assert np.abs(back[0].y - zs[0].heatmaps_aug[0].arr).max() <= 1.0 / 255 and back[0].id == ds[0].id
+    # the training-side augmentor of a fold set (reference :223 `folds.augmentor(isTrain=True)`)
+    kf = cfg.kfold(ds)
+    tb = next(iter(kf.augmentor(isTrain=True).augment_batches([kf.load(0, True, "all", 2)])))
+    assert tb.images_aug.shape == (2, 128, 128, 3) and tb.segmentation_maps_aug.shape == (2, 128, 128, 1)
 
 
 def test_configs0_unet_vgg16_plumbing(tmp_path):

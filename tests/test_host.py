@@ -594,3 +594,54 @@ def test_extra_train_data_joins_every_folds_training_set_only(tmp_path):
     cfg = segmentation.parse(cfg_path)
     with pytest.raises(ValueError, match="not registered"):
         cfg.fit(base)
+
+
+def test_writeable_prediction_datasets_and_update(tmp_path):
+    """reference segmentation.py:58-60, :196-208: ``update`` attaches predictions; ``create_/load_writeable_dataset`` keep
+    predictions in a folder, uint8 (scale <= 255) or uint16-compressed per ``compressPredictionsAsInts`` / ``compressScale``."""
+    class DS(datasets.DataSet):
+        name = "val"
+        def __len__(self): return 3
+        def __getitem__(self, i): return datasets.PredictionItem("id%d" % i, np.full((4, 4, 3), i, np.uint8), None)
+    rng = np.random.RandomState(0)
+    preds = [rng.rand(4, 4, 1).astype(np.float32) for _ in range(3)]
+    for over, tol, dt in (({}, 1.0 / 255, np.uint8), ({"compressScale": 1000}, 1e-3, np.uint16), ({"compressPredictionsAsInts": False}, 0.0, np.float32)):
+        sub = tmp_path / ("p%d" % len(over) if not over else "p_" + list(over)[0])
+        sub.mkdir()
+        cfg = segmentation.parse(write_cfg(sub, **over))
+        w = cfg.create_writeable_dataset(DS(), str(sub / "out"))
+        assert isinstance(w, datasets.WriteableDataSet) and len(w) == 0 and w.name == "val_predictions"
+        for p in preds:
+            w.append(p)
+        w.commit()
+        with np.load(str(sub / "out" / "1.npy.npz")) as z:
+            assert z["arr"].dtype == dt
+        r = cfg.load_writeable_dataset(DS(), str(sub / "out"))
+        assert len(r) == 3
+        for i in range(3):
+            it = r[i]
+            assert it.id == "id%d" % i and it.x[0, 0, 0] == i and np.abs(it.y - preds[i]).max() <= tol + 1e-7
+        with pytest.raises(IndexError):
+            r[3]
+    cfg = segmentation.parse(write_cfg(tmp_path))
+    z = pipeline.ItemBatch([None], [None], ["a"])
+    cfg.update(z, [preds[0]])
+    assert len(z.segmentation_maps_aug) == 1 and z.segmentation_maps_aug[0].arr is preds[0] and z.segmentation_maps_aug[0].shape == (4, 4, 1)
+
+
+def test_folds_load_returns_the_first_items_of_the_fold():
+    """reference segmentation.py:41, 228: ``folds.load(fold, isTrain, negatives, limit)``."""
+    class DS(object):
+        def __len__(self): return 10
+        def __getitem__(self, i): return datasets.PredictionItem("i%d" % i, np.full((2, 2, 3), i, np.uint8), np.full((2, 2, 1), i % 2, np.uint8))
+        def isPositive(self, i): return i % 2 == 1
+    cfg = pipeline.GenericTaskConfig(folds_count=2, shape=[8, 8, 3])
+    kf = cfg.kfold(DS())
+    b = kf.load(0, False, "all", 3)
+    want = [int(i) for i in kf.sampledIndexes(0, False, "all")[:3]]
+    assert b.data == ["i%d" % i for i in want] and [int(x[0, 0, 0]) for x in b.images] == want and len(b.segmentation_maps) == 3
+    pos = kf.load(0, False, "none", 16)
+    assert all(int(x[0, 0, 0]) % 2 == 1 for x in pos.images)
+    assert kf.cfg is cfg
+    with pytest.raises(ValueError):
+        pipeline.KFoldedDataSet(DS(), range(10)).augmentor(True)
