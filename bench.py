@@ -86,9 +86,46 @@ def kernel_key(name, meta, dtype):
     return name
 
 
+_ESIZE = {0: 4, 1: 2, 2: 1, 3: 2}      # stp dtype codes (include/stp_hip.h): F32, BF16, U8, F16
+
+
+def hbm_bytes(name, a):
+    """ALGORITHMIC HBM bytes of one launch of a memory-bound C-ABI entry point (every operand tensor read or written exactly once;
+    per-channel tables and partial sums ignored), from its argument list (include/stp_hip.h).  None = not a streaming pass."""
+    if name == "stp_bn_apply":                       # (x, xdtype, y, ydtype, rows, C, Cy, ...)
+        return a[4] * (a[5] * _ESIZE[a[1]] + a[6] * _ESIZE[a[3]])
+    if name == "stp_bn_finalize_apply":              # (partial, tiles, x, y, dtype, rows, C, ...)
+        return 2 * a[5] * a[6] * _ESIZE[a[4]]
+    if name == "stp_bn_backward_fused":              # (x, g, dx, dtype, rows, C, mean, rstd, gamma, partial, tiles, dgamma, dbeta, accumulate_dx, ...)
+        return (3 + int(bool(a[13]))) * a[4] * a[5] * _ESIZE[a[3]]
+    if name == "stp_bn_backward_fused_add":          # (x, g, dx, dadd, dtype, rows, C, ..., accumulate_dx at 14)
+        return (3 + int(bool(a[14]))) * a[5] * a[6] * _ESIZE[a[4]]
+    if name == "stp_bn_backward":                    # (x, dy, dx, dtype, rows, C, ..., accumulate_dx at 13): sums pass + apply pass
+        return (5 + int(bool(a[13]))) * a[4] * a[5] * _ESIZE[a[3]]
+    if name == "stp_adam":                           # (param, grad, m, v, count, ...): 4 reads + 3 writes of fp32
+        return 28 * a[4]
+    if name == "stp_maxpool3x3s2":                   # (x, y, idx, N, H, W, C, dtype)
+        n, h, w, c, es = a[3], a[4], a[5], a[6], _ESIZE[a[7]]
+        return n * h * w * c * es + n * ((h + 1) // 2) * ((w + 1) // 2) * c * (es + 1)
+    if name == "stp_maxpool3x3s2_bwd":               # (idx, dy, dx, N, H, W, C, dtype, accumulate)
+        n, h, w, c, es = a[3], a[4], a[5], a[6], _ESIZE[a[7]]
+        return n * ((h + 1) // 2) * ((w + 1) // 2) * c * (es + 1) + n * h * w * c * es * (1 + int(bool(a[8])))
+    return None
+
+
+# C-ABI entry point -> the device kernels it launches (profiler names, prefix match) for the PMC traffic of a non-GEMM roofline
+HBM_KERNELS = {"stp_bn_backward_fused": ("bn_bwd_apply_kernel", "bn_bwd_finalize_apply_kernel", "bn_bwd_finalize_tiles_kernel"),
+               "stp_bn_backward_fused_add": ("bn_bwd_apply_kernel", "bn_bwd_finalize_apply_kernel", "bn_bwd_finalize_tiles_kernel"),
+               "stp_bn_apply": ("bn_apply_v8_kernel", "bn_apply_u8_kernel", "bn_apply_kernel"),
+               "stp_bn_finalize_apply": ("bn_finalize_apply_kernel",),
+               "stp_bn_backward": ("bn_bwd_partial_kernel", "bn_bwd_finalize_kernel", "bn_bwd_apply_kernel"),
+               "stp_adam": ("adam_kernel", "adam_prep_kernel"), "stp_maxpool3x3s2": ("maxpool_fwd_kernel",),
+               "stp_maxpool3x3s2_bwd": ("maxpool_bwd_kernel",)}
+
+
 def per_kernel_profile(model, reps=3):
     """Eager instrumented passes: every launch of the step bracketed by HIP events on the stream the
-    kernels run on (torch's current stream).  Returns {kernel: [launches, seconds, flops]} per step."""
+    kernels run on (torch's current stream).  Returns {kernel: [launches, seconds, flops, algorithmic HBM bytes]} per step."""
     p = model.plan
     st = torch.cuda.current_stream()
     launches = [(l, "prep") for l in p.prep] + [(l, "fwd") for l in p.fwd] + [(l, "bwd") for l in p.bwd]
@@ -105,19 +142,20 @@ def per_kernel_profile(model, reps=3):
             e1.record(st)
             if rc != 0:
                 raise RuntimeError("%s failed (%d)" % (name, rc))
-            evs.append((name, meta, e0, e1))
+            evs.append((name, meta, e0, e1, hbm_bytes(name, args)))
         torch.cuda.synchronize()
         if rep == 0:
             continue  # first pass warms caches / clocks
-        for name, meta, e0, e1 in evs:
+        for name, meta, e0, e1, byt in evs:
             key = kernel_key(name, meta, model.dtype) if (meta and "flops" in meta) else name
-            a = acc.setdefault(key, [0, 0.0, 0.0])
+            a = acc.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += meta["flops"] if (meta and "flops" in meta) else 0.0
+            a[3] += byt or 0
     for t, s in zip(model._mutable_state(), saved):
         t.copy_(s)
-    return {k: [v[0] / reps, v[1] / reps, v[2] / reps] for k, v in acc.items()}
+    return {k: [v[0] / reps, v[1] / reps, v[2] / reps, v[3] / reps] for k, v in acc.items()}
 
 
 def flop_per_image(model):
@@ -185,6 +223,47 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def pmc_step_traffic():
+    """Sum of the L2-miss bytes (FETCH_SIZE + WRITE_SIZE passes) over EVERY kernel of one step, from the counter file of this build
+    (profiles/*_pmc_traffic.json; the pass runs `steps` eager steps, 3 unless the file says otherwise): (bytes per step, file) or
+    (None, None)."""
+    pdir = os.path.join(ROOT, "profiles")
+    for name in _pmc_files(pdir, "_pmc_traffic.json"):
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                d = json.load(f)
+            steps = float(d.get("steps", 3))
+            return sum(((k.get("fetch_bytes_per_launch") or 0) + (k.get("write_bytes_per_launch") or 0)) * k.get("dispatches", 0)
+                       for k in d["kernels"].values()) / steps, "profiles/" + name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+def pmc_entry_traffic(entry, launches_per_step):
+    """L2-miss bytes per launch of a C-ABI entry point = the bytes of the device kernels it launches (HBM_KERNELS) per step / its
+    launches per step.  Kernels shared by two entry points (bn_bwd_apply_kernel) are split by launch count upstream - here the
+    figure is reported for the kernel family as a whole, with the family named in ``traffic_kernels``."""
+    pdir = os.path.join(ROOT, "profiles")
+    pre = HBM_KERNELS.get(entry)
+    if not pre:
+        return None, None, None
+    for name in _pmc_files(pdir, "_pmc_traffic.json"):
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                d = json.load(f)
+            steps = float(d.get("steps", 3))
+            ks = {k: v for k, v in d["kernels"].items() if k.startswith(pre)}
+            if not ks:
+                continue
+            tot = sum(((v.get("fetch_bytes_per_launch") or 0) + (v.get("write_bytes_per_launch") or 0)) * v.get("dispatches", 0) for v in ks.values())
+            n = sum(v.get("dispatches", 0) for k, v in ks.items() if k.startswith(pre[0])) / steps      # launches of the family's main kernel
+            return int(tot / steps / max(n, 1.0)), "profiles/" + name, sorted(ks)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None, None
+
+
 def pmc_mfma_util(kernel):
     """MFMA pipe utilisation of ``kernel`` from the committed SQ counter pass (profiles/*_pmc_sq.json, scratch/pmc_aggregate_sq.py):
     SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles); None when that kernel was not measured.  Several instances of one key:
@@ -206,15 +285,14 @@ def pmc_mfma_util(kernel):
 def cpu_baseline(full_protocol=False):
     """The in-repo CPU oracle (a PORT: the reference's Keras-CPU fit() is not installable here) running the
     same step - CPU augmentation (oracle/augment.py, the S1 pipeline of BASELINE.md 4) + forward + Dice/BCE + backward + Adam - on
-    a bounded sample of the workload: U-Net/ResNet-34, 512x512.  BASELINE.md 4's protocol (batch 16, 3 warm-up + 10 timed steps,
-    median) costs ~5 minutes of host time, so the default line runs the SHORT protocol - batch 8, 1 warm-up + 2 timed steps
-    (~30 s; round 3's batch-2 sample under-reported the rate by 1.85x: the per-image cost falls with the batch) - and says so in
-    ``protocol``; ``full_protocol`` (bench runs of >= 100 steps) runs BASELINE.md 4 as written."""
+    a bounded sample of the workload: U-Net/ResNet-34, 512x512.  DEFAULT = BASELINE.md 4's protocol as written (batch 16, 3 warm-up
+    + 10 timed steps, median: ~5 minutes of host time on the GPU box's cores - the driver's budget for the bench is 30 minutes);
+    ``--cpu-baseline short`` runs batch 16 with 1 warm-up + 3 timed steps (~1.5 minutes) and says so in ``protocol``."""
     from oracle import augment as oaug
     from oracle import nets as onets
     from oracle import step as ostep
     from segmentation_training_pipeline_amd import augment
-    n, warm, reps = (16, 3, 10) if full_protocol else (8, 1, 2)
+    n, warm, reps = (16, 3, 10) if full_protocol else (16, 1, 3)
     P = onets.init_unet_resnet("resnet34", seed=42)
     tr = ostep.OracleTrainer(P, backbone="resnet34", loss=LOSS, optimizer="adam", lr=1e-3)
     x, y = ostep.synthetic_batch(n, H, W, seed=1234)
@@ -235,10 +313,36 @@ def cpu_baseline(full_protocol=False):
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": round(n / med, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "protocol": "BASELINE.md 4 (batch 16, 3 + 10, median)" if full_protocol else
-                        "short (batch 8, 1 warm-up + 2 timed, median; BASELINE.md 4 asks batch 16, 3 + 10: --steps >= 100 runs it in full)",
+            "protocol": "BASELINE.md 4" if full_protocol else "short (batch 16, 1 warm-up + 3 timed, median; BASELINE.md 4 asks 3 + 10)",
+            "protocol_detail": "batch %d, %d warm-up + %d timed steps, median" % (n, warm, reps),
             "sample": "oracle (numpy augmentation + PyTorch-CPU fp32) training step incl. the S1 augmentation, U-Net/ResNet34 512x512x3, "
                       "batch %d, median of %d timed steps after %d warm-up" % (n, len(times), warm)}
+
+
+def dice_delta_vs_oracle(device):
+    """BASELINE.json's metric names "Dice delta vs ref": one training step of the headline network at its real resolution (U-Net/ResNet34,
+    512 x 512, batch 2 - what one oracle step on the build container's CPU could pin) from the oracle's initial weights on the
+    oracle's synthetic batch, against the Dice value of the fp32 CPU oracle's committed step (tests/golden/unet_resnet34_512_bs2.npz,
+    tests/golden/make_golden.py --fullsize-only) - in the benchmarked precision AND in fp32 mode.  Part of the CPU-baseline /
+    checker leg: the oracle supplies the initial weights and the batch, nothing here is timed."""
+    from oracle import nets as onets
+    from oracle import step as ostep
+    from segmentation_training_pipeline_amd.backend import HipSegModel
+    g = np.load(os.path.join(ROOT, "tests", "golden", "unet_resnet34_512_bs2.npz"))
+    size, n = int(g["size"]), int(g["n"])
+    x, y = ostep.synthetic_batch(n, size, size, seed=int(g["data_seed"]))
+    P = onets.init_unet_resnet("resnet34", seed=int(g["seed"]))
+    want_dice_loss, want_dice = float(g["scalars1"][2]), float(g["scalars1"][3])
+    out = {"reference": "in-repo fp32 CPU oracle (parity unpinned by the reference: SURVEY 8c), U-Net/ResNet34 512x512 batch 2, first step",
+           "oracle_dice": round(want_dice, 7), "north_star_bar": 1e-5}
+    for dt in ("bf16", "fp32"):
+        m = HipSegModel("Unet", "resnet34", (size, size, 3), 1, "sigmoid", batch=n, dtype=dt, loss=LOSS, optimizer="Adam", lr=1e-3,
+                        use_graph=False, device=device)
+        m.set_weights(P)
+        met = m.train_on_batch(x, y)
+        out[dt] = {"dice_delta": float("%.3g" % abs(met["dice"] - want_dice)), "dice_loss_delta": float("%.3g" % abs(met["dice_loss"] - want_dice_loss))}
+        del m
+    return out
 
 
 def main():
@@ -254,6 +358,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="bf16 = the headline mode; fp16 = the IEEE-half build of the same kernels (libstp_hip_f16.so, loss scale 2^14); fp32 = the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "short"],
+                    help="full = BASELINE.md 4 as written (batch 16, 3 warm-up + 10 timed steps: ~5 min of host time); short = 1 + 3")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet", "FPN"],
                     help="Unet = BASELINE.json's headline workload; Linknet = SURVEY 8f N1 on the same kernels (not the headline metric)")
@@ -282,7 +388,8 @@ def main():
     model = HipSegModel(args.architecture, "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
                         lr=1e-3, use_graph=not args.eager, device=str(dev))
     if world > 1 or force_dp:
-        model.set_data_parallel(distributed.make_reducer(force=force_dp), overlap={"0": False, "1": True}.get(os.environ.get("STP_DP_OVERLAP", "1"), "buckets"))
+        ov = os.environ.get("STP_DP_OVERLAP", "auto")
+        model.set_data_parallel(distributed.make_reducer(force=force_dp), overlap={"0": False, "1": True, "auto": True}.get(ov, "buckets"))
 
     # synthetic data: uniform uint8 images, 3 random discs per mask, seed 1234 + rank
     rng = np.random.RandomState(1234 + rank)
@@ -322,6 +429,12 @@ def main():
         model.apply_gradients()
         main.wait_stream(aux)
 
+    dp_schedule = None
+    if (world > 1 or force_dp) and os.environ.get("STP_DP_OVERLAP", "auto") == "auto":
+        # overlapped vs serialised all-reduce: measured here, before the warm-up, on an augmented batch (10 steps each way; the state
+        # is restored).  STP_DP_OVERLAP=0|1 skips the measurement.
+        augment_into_plan(raw_img, raw_msk, 0)
+        dp_schedule = model.calibrate_dp_schedule()
     if overlap:
         augment_into_plan(raw_img, raw_msk, 0)
 
@@ -425,7 +538,7 @@ def main():
                                "(%s%s)" % ("BASELINE.json configs[1]" if args.architecture == "Unet" else "SURVEY 8f N1 workload, not the headline metric",
                                            "; configs[2] data-parallel" if world > 1 else ""),
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                   "hipgraph": not args.eager, "loss_after_run": round(metrics["loss"], 5)},
+                   "hipgraph": not args.eager, "loss_after_run": round(metrics["loss"], 5), "dp_schedule": dp_schedule},
         # algorithmic FLOP per trained image = 3 x the forward conv FLOP the plan recorded (187.94 GFLOP for the U-Net)
         "step_mfma_frac": round(images_per_sec / world * flop_per_image(model) / (PEAK_BF16_TFLOPS * 1e12), 4),
         # the same K steps with every batch copied from pinned host memory (double-buffered hipMemcpyAsync on a copy stream)
@@ -442,7 +555,7 @@ def main():
         gemm = {k: v for k, v in prof.items() if v[2] > 0}
 
         def roofline_of(key):
-            n_l, sec, fl = gemm[key]
+            n_l, sec, fl, _ = gemm[key]
             ach = fl / sec / 1e12
             traffic, traffic_src = pmc_traffic(key)
             mu, mu_src = pmc_mfma_util(key)
@@ -457,13 +570,38 @@ def main():
         order = sorted(gemm, key=lambda k: -gemm[k][1])
         out["roofline"] = roofline_of(order[0])                      # the GEMM kernel with the largest total time per step
         out["roofline_next"] = [roofline_of(k) for k in order[1:4]]  # and the three after it (same fields)
+
+        # the memory-bound half of the step: the non-GEMM entry point with the largest time per step whose algorithmic bytes are known
+        def roofline_hbm_of(key):
+            n_l, sec, _, byt = prof[key]
+            ach = byt / sec / 1e9
+            traffic, traffic_src, fam = pmc_entry_traffic(key, n_l)
+            return {"kernel": key, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(byt / n_l),
+                    "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss, the entry point's kernel family)", "traffic_kernels": fam,
+                    "traffic_source": traffic_src, "counters_stale": bool(traffic_src and _pmc_stale(os.path.join(ROOT, traffic_src))),
+                    "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
+                    "share_of_step_kernel_time": round(sec / tot, 3)}
+        hbm = sorted((k for k, v in prof.items() if v[2] == 0 and v[3] > 0), key=lambda k: -prof[k][1])
+        if hbm:
+            out["roofline_hbm"] = roofline_hbm_of(hbm[0])
+            out["roofline_hbm_next"] = [roofline_hbm_of(k) for k in hbm[1:3]]
+        st_bytes, st_src = pmc_step_traffic()
+        if st_bytes:
+            out["step_traffic_gb"] = round(st_bytes / 1e9, 2)        # sum of L2-miss bytes of every kernel of one step (PMC passes)
+            out["step_traffic_source"] = st_src
+            out["step_traffic_stale"] = bool(_pmc_stale(os.path.join(ROOT, st_src)))
+            out["step_hbm_floor_ms"] = round(st_bytes / (PEAK_HBM_GBS * 1e9) * 1e3, 3)       # that traffic at the 8 TB/s peak
+            out["step_hbm_floor_ms_at_6300"] = round(st_bytes / 6.3e12 * 1e3, 3)             # ... at the rate a device copy reaches
         top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:16]
         out["kernel_time_us"] = {k: [round(v[0], 1), round(1e6 * v[1], 1), round(v[2] / v[1] / 1e12, 1) if v[2] else None] for k, v in top}
         out["kernel_time_total_us"] = round(1e6 * tot, 1)
         out["gemm_time_us"] = round(1e6 * sum(v[1] for v in gemm.values()), 1)
         out["non_gemm_time_us"] = round(1e6 * (tot - sum(v[1] for v in gemm.values())), 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(full_protocol=args.steps >= 100 and os.environ.get("STP_CPU_BASELINE_FULL", "1") != "0")
+        if args.dtype == "bf16" and args.architecture == "Unet":
+            out["config"]["dice_delta_vs_oracle"] = dice_delta_vs_oracle(str(dev))
+        out["cpu_baseline"] = cpu_baseline(full_protocol=args.cpu_baseline == "full")
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():

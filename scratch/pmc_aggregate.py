@@ -29,7 +29,7 @@ out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pa
                "fetch_bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM section; check: "
                "adam_kernel reads 4 x 97.7 MB); write_bytes = WRITE_SIZE x 1024 (check: adam_kernel writes 3 x 97.7 MB).  Infinity-Cache "
                "hits are counted, so this is L2-miss traffic, an upper bound on HBM traffic.",
-       "kernels": {}}
+       "steps": 3, "kernels": {}}
 for k in sorted(set(ft) | set(wt)):
     if not (k.startswith("conv") or k.startswith("bn") or k.startswith("adam") or k.startswith("wgrad") or "kernel" in k and "at::" not in k):
         continue

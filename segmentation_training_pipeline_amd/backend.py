@@ -108,7 +108,12 @@ class HipSegModel(object):
         self.dls = None
         if dtype == "fp16" and self.loss_scale != 1.0 and os.environ.get("STP_DYNAMIC_LOSS_SCALE", "1") != "0":
             interval = float(os.environ.get("STP_LOSS_SCALE_INTERVAL", "2000"))
-            self.dls = torch.tensor([1.0, 0.0, interval, 2.0 ** -14, 1.0, 2.0 ** 8, 0.0, 0.0], dtype=torch.float32, device=self.device)
+            # largest multiplier: 1 - the schedule only backs off after a non-finite gradient and recovers to the static scale.  The fp16
+            # build saturates every 16-bit store at +-65504, so an overflowing activation gradient is clamped, never inf: growth beyond
+            # the static scale could not be policed by the non-finite guard and would drift into silently clipped gradients (advisor,
+            # round 4).  STP_LOSS_SCALE_MAX_MULT=<power of two> restores a growing schedule for experiments.
+            mmax = float(os.environ.get("STP_LOSS_SCALE_MAX_MULT", "1"))
+            self.dls = torch.tensor([1.0, 0.0, interval, 2.0 ** -14, 1.0, mmax, 0.0, 0.0], dtype=torch.float32, device=self.device)
             self.plan.dls = self.dls
         if freeze_encoder:
             self.plan.frozen_prefixes = nets.ENCODER_PREFIXES
@@ -179,6 +184,47 @@ class HipSegModel(object):
         self.dp_scale = float(reducer.scale)
         self.gscale[0] = self.dp_scale / self.loss_scale
         self._build_opt(use_gscale=True)
+
+    def calibrate_dp_schedule(self, steps=10, warm=2, log=True):
+        """Chooses between the overlapped and the serialised gradient all-reduce BY MEASUREMENT on this node: ``warm`` +
+        ``steps`` training steps under each schedule on whatever the input buffers hold, MAX over the ranks, the faster one stays -
+        so the first multi-GPU run cannot regress on the question no 1-GPU box can answer (do RCCL's channel workgroups co-reside with
+        the 100-150 KB-LDS convolution workgroups of the backward, or queue behind them?).  Every piece of mutable state (parameters,
+        moments, BatchNormalization statistics, step counters) is restored afterwards, the replicas end bit-identical to how they
+        started, and both schedules produce bit-identical gradients anyway (tests/test_dp_gpu.py).  Returns the record it logs."""
+        import sys
+        import time
+        if self.reducer is None or not self.reducer.active or not self.plan.bwd_monotone:
+            return None
+        saved = [t.clone() for t in self._mutable_state()]
+        want = self.dp_overlap
+        times = {}
+        for mode in (True, False):
+            self.dp_overlap, self._segments, self._graphs, self._works = mode, None, None, []
+            for _ in range(warm):
+                self.forward_backward(); self.apply_gradients()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.forward_backward(); self.apply_gradients()
+            torch.cuda.synchronize(self.device)
+            times[mode] = (time.perf_counter() - t0) / steps
+        t = torch.tensor([times[True], times[False]], dtype=torch.float64, device=self.device)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)          # every rank takes the same decision
+        t_ov, t_ser = float(t[0].item()), float(t[1].item())
+        choice = bool(t_ov <= t_ser)
+        self.dp_overlap, self._segments, self._graphs, self._works = choice, None, None, []
+        for d, sv in zip(self._mutable_state(), saved):
+            d.copy_(sv)
+        torch.cuda.synchronize(self.device)
+        rec = {"overlapped_ms": round(1e3 * t_ov, 4), "serialised_ms": round(1e3 * t_ser, 4), "steps": steps,
+               "chosen": "overlapped" if choice else "serialised", "configured": "overlapped" if want else "serialised"}
+        self.dp_schedule = rec
+        if log and distributed.env_world()[0] == 0:
+            print("[stp] data-parallel schedule: overlapped %.3f ms/step, serialised %.3f ms/step over %d steps -> %s "
+                  "(STP_DP_OVERLAP=0|1 fixes the schedule without measuring)" % (1e3 * t_ov, 1e3 * t_ser, steps, rec["chosen"]), file=sys.stderr)
+        return rec
 
     def _build_opt(self, use_gscale=False):
         """(Re)creates the optimizer launch list.  ``use_gscale``: multiply gradients by the device

@@ -966,7 +966,9 @@ __global__ __launch_bounds__(256) void gscale_finalize_dls_kernel(const float* p
   }
   if (threadIdx.x != 0) return;
   const float m = dls[0];
-  const double eff = (double)base / (double)m;       // what turns an arena value into the gradient the optimizer sees
+  // the gradients in the arena were produced under dls[4] (recorded by stp_scale_by_device when their backward pass was seeded);
+  // dls[0] is the multiplier of the NEXT pass - equal only while every step is one backward pass followed by one optimizer launch
+  const double eff = (double)base / (double)dls[4];  // what turns an arena value into the gradient the optimizer sees
   const double norm = sqrt(sh[0]) * eff;
   if (!(sh[0] >= 0.0 && sh[0] < 1e300 * 1e300) || !(norm == norm)) {   // overflow: skip the step, halve the multiplier
     gscale[0] = -1.f;

@@ -833,8 +833,9 @@ class Plan(object):
             if need_dgrad and out.meta.get("dgrad_folded"):
                 pass        # a projection shortcut whose data gradient rode in its sibling's launch (fold_shortcut): nothing to issue
             elif need_dgrad:
+                d0_hires = None
                 if upsample:
-                    d0 = self._alloc((self.N, Hv, Wv, C0)) if x_ng else None
+                    d0 = d0_hires = self._alloc((self.N, Hv, Wv, C0)) if x_ng else None      # released below when the launch folds the 2 x 2 sums
                     acc0 = 0
                 else:
                     d0 = self._gradbuf(x) if x_ng else None
@@ -894,7 +895,8 @@ class Plan(object):
                         q.dst_sum2x2 = 0
                         # the halo kernel's summed epilogue (EP 3) for 64+ channels - in its fused form only (see the two-destination case below)
                         if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses", 0) == 1 and not x.grad_ready
-                                and self.slot_arena is None and os.environ.get("STP_HALO_FOLD_UP", "1") != "0"):
+                                and self.slot_arena is None and os.environ.get("STP_HALO_FOLD_UP", "1") != "0"
+                                and os.environ.get("STP_HALO", "1") != "0"):      # (the dispatcher honours STP_HALO=0: plan and dispatcher agree)
                             keep = (q.dst0, q.accumulate0)
                             q.dst_sum2x2, q.dst0, q.accumulate0 = 1, self._gradbuf(x).data_ptr(), 0
                             q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
@@ -920,7 +922,8 @@ class Plan(object):
                         # (EP 3) - only in that fused form, i.e. when this launch completes the gradient of a BatchNormalization output
                         # that nothing else reads
                         if (self.fuse_bn_backward and bnm is not None and x.meta.get("uses", 0) == 1 and not x.grad_ready
-                                and self.slot_arena is None and os.environ.get("STP_HALO_FOLD_UP", "1") != "0"):
+                                and self.slot_arena is None and os.environ.get("STP_HALO_FOLD_UP", "1") != "0"
+                                and os.environ.get("STP_HALO", "1") != "0"):      # (the dispatcher honours STP_HALO=0: plan and dispatcher agree)
                             keep = (q.dst0, q.accumulate0)
                             q.dst_sum2x2, q.dst0, q.accumulate0 = 1, self._gradbuf(x).data_ptr(), 0
                             q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
@@ -930,6 +933,11 @@ class Plan(object):
                                 q.dst_sum2x2, (q.dst0, q.accumulate0) = 0, keep
                                 q.bnb_x = q.bnb_mean = q.bnb_rstd = q.bnb_gamma = q.bnb_beta = None
                                 q.bnb_relu = 0
+                if folded_up and d0_hires is not None:
+                    # the full-resolution gradient of the upsampled tensor is never written: give its buffer back (33-134 MB per decoder
+                    # stage at batch 16, 512 x 512 - it used to stay allocated for the life of the plan)
+                    self._keep = [t for t in self._keep if t is not d0_hires]
+                    d0_hires = None
                 uses = x.meta.get("uses", 0)
                 # the only consumer, or the LAST of several (every other consumer has already written or accumulated its
                 # share, this data gradient accumulates on top): its epilogue sees the complete gradient of the BN output

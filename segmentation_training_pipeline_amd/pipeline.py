@@ -965,6 +965,11 @@ class GenericTaskConfig(object):
             # replicas start the stage bit-identical: parameters, BatchNormalization statistics and optimizer state of rank 0
             impl.broadcast_state(src=0)
             impl.set_data_parallel(distributed.make_reducer())
+            if os.environ.get("STP_DP_OVERLAP", "auto") not in ("0", "1", "buckets"):
+                # overlapped or serialised gradient all-reduce: measured on this node before the first epoch (state restored afterwards)
+                impl.calibrate_dp_schedule()
+            elif os.environ["STP_DP_OVERLAP"] == "0":
+                impl.dp_overlap, impl._segments, impl._graphs = False, None, None
         H, W = impl.H, impl.W                                  # = shape, or shape / crops
         feeder = DeviceFeeder(impl.device, (H, W), self._aug_spec(), seed=self.random_state * 7919 + fold * 101 + si,
                               classes=self.classes, channels=impl.in_ch)

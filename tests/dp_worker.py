@@ -27,6 +27,16 @@ def main(out_dir):
     m = build(graph=True)
     m.broadcast_state(src=0)
     m.set_data_parallel(distributed.GradReducer(), overlap=True)
+    # start-up measurement of the two schedules (backend.calibrate_dp_schedule): both run, every rank takes the same decision, and
+    # the state is restored bit for bit - the reference comparison below would catch a stray optimizer step or BatchNormalization update
+    m.load_batch(*halves[rank])
+    before = [t.clone() for t in m._mutable_state()]
+    rec = m.calibrate_dp_schedule(steps=2, warm=1, log=False)
+    assert rec["chosen"] in ("overlapped", "serialised") and rec["overlapped_ms"] > 0 and rec["serialised_ms"] > 0, rec
+    assert all(torch.equal(a, b) for a, b in zip(before, m._mutable_state())), "calibration must leave the state untouched"
+    both = distributed.allreduce_sums([1.0 if rec["chosen"] == "overlapped" else 0.0])
+    assert float(both[0]) in (0.0, 2.0), "the ranks disagree on the schedule"
+    m.dp_overlap, m._segments, m._graphs = True, None, None          # the rest of the test exercises the overlapped schedule
     assert m._dp_segments() is not None and len(m._dp_segments()) >= 2, "the overlapped schedule must be active"
     for _ in range(2):                                        # two steps: the second one runs on replayed graphs
         m.train_on_batch(*halves[rank])

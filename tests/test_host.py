@@ -508,6 +508,20 @@ def test_bench_names_every_launch_of_the_headline_plan():
             assert "conv_scw_stream_kernel<unsigned short>" in keys
             # the 128-channel groups run the all-taps kernel (round 4), the 64 / 32-channel groups the row-of-taps one
             assert "conv_wgrad_taps9_group_kernel<128, 3>" in keys and "conv_wgrad_row_group_kernel<64, 1, 4, 3>" in keys
+        if dtype == "bf16":
+            # roofline_hbm: algorithmic bytes of the streaming entry points from their argument lists (include/stp_hip.h order)
+            byt = {}
+            for lst in (plan.prep, plan.fwd, plan.bwd, plan.opt):
+                for fn, args, name, meta in lst:
+                    b = bench.hbm_bytes(name, args) if fn is not None else None
+                    if b is not None:
+                        assert b > 0, name
+                        byt.setdefault(name, []).append(b)
+            assert set(byt) >= {"stp_bn_apply", "stp_bn_finalize_apply", "stp_bn_backward_fused", "stp_maxpool3x3s2", "stp_maxpool3x3s2_bwd"}
+            assert max(byt["stp_bn_backward_fused"]) == 3 * 16 * 512 * 512 * 16 * 2         # decoder_stage4: x, g read + dx written, bf16
+            assert bench.hbm_bytes("stp_adam", (0, 0, 0, 0, 1000)) == 28000          # (the optimizer launch is the backend's, not the plan's)
+            assert byt["stp_maxpool3x3s2"] == [16 * 256 * 256 * 64 * 2 + 16 * 128 * 128 * 64 * 3]
+            assert set(bench.HBM_KERNELS) >= set(byt)
 
 
 def test_simple_png_mask_dataset(tmp_path):

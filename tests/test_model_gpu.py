@@ -810,7 +810,22 @@ def test_fp16_dynamic_loss_scale_halves_on_overflow_and_grows_back(monkeypatch, 
     assert m.dynamic_loss_scale == 16384.0 and m.skipped_steps == 1 and int(m.opt_state[0].item()) == 3
     for _ in range(3):
         losses.append(m.train_on_batch(x, y)["loss"])
-    assert m.dynamic_loss_scale == 32768.0 and np.isfinite(losses).all() and losses[-1] < losses[0]
+    # the multiplier is capped at 1 (the static scale): the saturating fp16 stores would hide an overflow from the guard above it
+    assert m.dynamic_loss_scale == 16384.0 and np.isfinite(losses).all() and losses[-1] < losses[0]
+    # the optimizer divides by the multiplier the gradients were PRODUCED under (dls[4]), not the next pass's (dls[0])
+    m.forward_backward()
+    m.dls[0] = 0.25
+    w0 = m.plan.P.clone()
+    m.apply_gradients()
+    assert torch.isfinite(m.plan.P).all() and float((m.plan.P - w0).abs().max()) < 5e-3      # an Adam step of lr 1e-3, not one of 4x the gradient
+    # a growing schedule stays available for experiments
+    monkeypatch.setenv("STP_LOSS_SCALE_MAX_MULT", "4")
+    mg = make("resnet18", 64, 2, "fp16", use_graph=use_graph)
+    mg.init_weights(seed=9)
+    for _ in range(3):
+        mg.train_on_batch(x, y)
+    assert mg.dynamic_loss_scale == 32768.0
+    monkeypatch.delenv("STP_LOSS_SCALE_MAX_MULT")
     # the static-scale schedule of round 3 is still there
     monkeypatch.setenv("STP_DYNAMIC_LOSS_SCALE", "0")
     ms = make("resnet18", 64, 2, "fp16", use_graph=use_graph)
