@@ -113,14 +113,19 @@ def hbm_bytes(name, a):
     return None
 
 
-# C-ABI entry point -> the device kernels it launches (profiler names, prefix match) for the PMC traffic of a non-GEMM roofline
-HBM_KERNELS = {"stp_bn_backward_fused": ("bn_bwd_apply_kernel", "bn_bwd_finalize_apply_kernel", "bn_bwd_finalize_tiles_kernel"),
-               "stp_bn_backward_fused_add": ("bn_bwd_apply_kernel", "bn_bwd_finalize_apply_kernel", "bn_bwd_finalize_tiles_kernel"),
-               "stp_bn_apply": ("bn_apply_v8_kernel", "bn_apply_u8_kernel", "bn_apply_kernel"),
-               "stp_bn_finalize_apply": ("bn_finalize_apply_kernel",),
-               "stp_bn_backward": ("bn_bwd_partial_kernel", "bn_bwd_finalize_kernel", "bn_bwd_apply_kernel"),
-               "stp_adam": ("adam_kernel", "adam_prep_kernel"), "stp_maxpool3x3s2": ("maxpool_fwd_kernel",),
-               "stp_maxpool3x3s2_bwd": ("maxpool_bwd_kernel",)}
+# Memory-bound kernel FAMILIES: the C-ABI entry points of one family launch the same device kernels (profiler names, prefix match),
+# so the PMC traffic of the family = the bytes of those kernels per step / the launches of its pass kernels (`main`) per step.
+HBM_FAMILIES = {
+    "BatchNormalization backward": {"entries": ("stp_bn_backward_fused", "stp_bn_backward_fused_add", "stp_bn_backward"),
+                                    "kernels": ("bn_bwd_apply_kernel", "bn_bwd_finalize_apply_kernel", "bn_bwd_finalize_tiles_kernel",
+                                                "bn_bwd_partial_kernel", "bn_bwd_finalize_kernel"),
+                                    "main": ("bn_bwd_apply_kernel", "bn_bwd_finalize_apply_kernel")},
+    "BatchNormalization forward": {"entries": ("stp_bn_apply", "stp_bn_finalize_apply"),
+                                   "kernels": ("bn_apply_v8_kernel", "bn_apply_u8_kernel", "bn_apply_kernel", "bn_finalize_apply_kernel"),
+                                   "main": ("bn_apply_v8_kernel", "bn_apply_u8_kernel", "bn_apply_kernel", "bn_finalize_apply_kernel")},
+    "max-pooling forward + backward": {"entries": ("stp_maxpool3x3s2", "stp_maxpool3x3s2_bwd"), "kernels": ("maxpool_fwd_kernel", "maxpool_bwd_kernel"),
+                                       "main": ("maxpool_fwd_kernel", "maxpool_bwd_kernel")},
+}
 
 
 def per_kernel_profile(model, reps=3):
@@ -240,25 +245,21 @@ def pmc_step_traffic():
     return None, None
 
 
-def pmc_entry_traffic(entry, launches_per_step):
-    """L2-miss bytes per launch of a C-ABI entry point = the bytes of the device kernels it launches (HBM_KERNELS) per step / its
-    launches per step.  Kernels shared by two entry points (bn_bwd_apply_kernel) are split by launch count upstream - here the
-    figure is reported for the kernel family as a whole, with the family named in ``traffic_kernels``."""
+def pmc_family_traffic(family):
+    """L2-miss bytes per launch of a memory-bound kernel family (HBM_FAMILIES): the bytes of its device kernels per step / the
+    launches of its pass kernels per step, from the counter file of this build: (bytes per launch, file, kernels) or Nones."""
     pdir = os.path.join(ROOT, "profiles")
-    pre = HBM_KERNELS.get(entry)
-    if not pre:
-        return None, None, None
+    fam = HBM_FAMILIES[family]
     for name in _pmc_files(pdir, "_pmc_traffic.json"):
         try:
             with open(os.path.join(pdir, name)) as f:
                 d = json.load(f)
-            steps = float(d.get("steps", 3))
-            ks = {k: v for k, v in d["kernels"].items() if k.startswith(pre)}
-            if not ks:
+            ks = {k: v for k, v in d["kernels"].items() if k.startswith(fam["kernels"])}
+            n = sum(v.get("dispatches", 0) for k, v in ks.items() if k.startswith(fam["main"]))
+            if not n:
                 continue
             tot = sum(((v.get("fetch_bytes_per_launch") or 0) + (v.get("write_bytes_per_launch") or 0)) * v.get("dispatches", 0) for v in ks.values())
-            n = sum(v.get("dispatches", 0) for k, v in ks.items() if k.startswith(pre[0])) / steps      # launches of the family's main kernel
-            return int(tot / steps / max(n, 1.0)), "profiles/" + name, sorted(ks)
+            return int(tot / n), "profiles/" + name, sorted(ks)
         except (OSError, ValueError, KeyError):
             continue
     return None, None, None
@@ -571,21 +572,25 @@ def main():
         out["roofline"] = roofline_of(order[0])                      # the GEMM kernel with the largest total time per step
         out["roofline_next"] = [roofline_of(k) for k in order[1:4]]  # and the three after it (same fields)
 
-        # the memory-bound half of the step: the non-GEMM entry point with the largest time per step whose algorithmic bytes are known
-        def roofline_hbm_of(key):
-            n_l, sec, _, byt = prof[key]
+        # the memory-bound half of the step: the non-GEMM kernel family (HBM_FAMILIES: entry points that launch the same device kernels)
+        # with the largest time per step; achieved = algorithmic bytes (hbm_bytes: every operand tensor once) / HIP-event time
+        def roofline_hbm_of(family):
+            ent = [prof[e] for e in HBM_FAMILIES[family]["entries"] if e in prof]
+            n_l, sec, byt = sum(v[0] for v in ent), sum(v[1] for v in ent), sum(v[3] for v in ent)
             ach = byt / sec / 1e9
-            traffic, traffic_src, fam = pmc_entry_traffic(key, n_l)
-            return {"kernel": key, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(byt / n_l),
-                    "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss, the entry point's kernel family)", "traffic_kernels": fam,
-                    "traffic_source": traffic_src, "counters_stale": bool(traffic_src and _pmc_stale(os.path.join(ROOT, traffic_src))),
+            traffic, traffic_src, fam = pmc_family_traffic(family)
+            return {"kernel": family, "entry_points": [e for e in HBM_FAMILIES[family]["entries"] if e in prof], "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "algorithmic_bytes_per_launch": int(byt / n_l), "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss: FETCH_SIZE + WRITE_SIZE passes)",
+                    "traffic_kernels": fam, "traffic_source": traffic_src,
+                    "counters_stale": bool(traffic_src and _pmc_stale(os.path.join(ROOT, traffic_src))),
                     "launches_per_step": round(n_l, 1), "avg_launch_us": round(1e6 * sec / n_l, 2),
                     "share_of_step_kernel_time": round(sec / tot, 3)}
-        hbm = sorted((k for k, v in prof.items() if v[2] == 0 and v[3] > 0), key=lambda k: -prof[k][1])
-        if hbm:
-            out["roofline_hbm"] = roofline_hbm_of(hbm[0])
-            out["roofline_hbm_next"] = [roofline_hbm_of(k) for k in hbm[1:3]]
+        fams = [f for f in HBM_FAMILIES if any(e in prof for e in HBM_FAMILIES[f]["entries"])]
+        fams.sort(key=lambda f: -sum(prof[e][1] for e in HBM_FAMILIES[f]["entries"] if e in prof))
+        if fams:
+            out["roofline_hbm"] = roofline_hbm_of(fams[0])
+            out["roofline_hbm_next"] = [roofline_hbm_of(f) for f in fams[1:3]]
         st_bytes, st_src = pmc_step_traffic()
         if st_bytes:
             out["step_traffic_gb"] = round(st_bytes / 1e9, 2)        # sum of L2-miss bytes of every kernel of one step (PMC passes)

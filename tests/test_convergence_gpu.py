@@ -76,13 +76,14 @@ def ellipses_at(size, n, seed):
 
 def test_headline_bf16_trains_like_fp32():
     """The BENCHMARKED workload in the benchmarked precision: U-Net/ResNet34, 512 x 512, batch 16 - the shapes, tiles and
-    grouped weight gradients bench.py times - trained for 160 Adam steps on the ellipse task from identical initial weights on
+    grouped weight gradients bench.py times - trained for 400 Adam steps on the ellipse task from identical initial weights on
     identical batches in fp32 mode (the parity mode, 35 ms / step) and in bf16 mode.  One bf16 step's stage-1..3 gradients sit at
     cosine 0.79-0.81 to the storage-quantised oracle's (tests/test_model_gpu.py: rounding ties spread by ~50 layers); what that is
     worth is decided here: both runs must learn the task, land on the same held-out Dice (gap <= 1e-2) and keep their loss curves
     within 15 % of the initial loss of each other."""
     from segmentation_training_pipeline_amd.backend import HipSegModel
-    size, batch, steps = 512, 16, 160
+    size, batch, steps = 512, 16, 400      # (160 steps: the moving statistics that predict() normalises with are 80 % converged at
+    #                                        momentum 0.99 - held-out Dice 0.92 vs 0.99 at equal training loss; 400: 98 %)
     xs, ys = ellipses_at(size, 64, 1)
     xv, yv = ellipses_at(size, 16, 2)
     order = np.random.RandomState(5).randint(0, len(xs), size=(steps, batch))
