@@ -137,7 +137,22 @@ typedef struct stp_conv_params {
   const void* fold_src;
   const void* fold_weight;
   int32_t fold_C;
+  /* GROUP-LEVEL PRE-REDUCTION of the fused sums (round 5).  stats_group = G > 1: the pixel tiles of a channel tile are taken in groups
+   * of G consecutive tiles; every workgroup publishes its column of stats_partial write-through and draws an arrival ticket from
+   * stats_group_counters[channel tile x groups] (uint32, ZERO before the first launch; the launch leaves them at zero); the workgroup
+   * that draws the last ticket of a group sums the group's columns IN TILE ORDER (fixed order: deterministic, replay bit-identical)
+   * into stats_group_out = [2][C][ceil(tiles / G)].  The table the BatchNormalization reads then has <= 128 columns, which
+   * stp_bn_finalize_apply / the one-launch form of stp_bn_backward_fused reduce in their prologue: no finalize launch on the chain
+   * conv -> finalize -> apply -> conv.  G must be stp_conv2d_stats_group_for(p) (0 = this shape's kernel has no such epilogue). */
+  float* stats_group_out;
+  uint32_t* stats_group_counters;
+  int32_t stats_group;
 } stp_conv_params;
+/* Group size G (a power of two, >= 2) for which stp_conv2d(p) can pre-reduce its stats_partial columns to <= 128 (see stats_group), or 0
+ * when the table is small enough already / the kernel that serves p has no such epilogue.  stp_conv2d_stats_group_counters(p, G) =
+ * uint32 words stats_group_counters must hold. */
+int stp_conv2d_stats_group_for(const stp_conv_params* p);
+size_t stp_conv2d_stats_group_counters(const stp_conv_params* p, int32_t G);
 /* 1: stp_conv2d(p) takes the parity-class path that honours fold_src / fold_weight / fold_C for this shape (p->fold_* need not be set). */
 int stp_conv2d_fold_ok(const stp_conv_params* p);
 

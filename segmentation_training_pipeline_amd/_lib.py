@@ -32,7 +32,8 @@ class ConvParams(C.Structure):
                 ("bnb_x", vp), ("bnb_mean", vp), ("bnb_rstd", vp), ("bnb_gamma", vp), ("bnb_beta", vp), ("bnb_relu", i32),
                 ("dst_sum2x2", i32), ("stats_slots", i32),
                 ("src_bn_mean", vp), ("src_bn_rstd", vp), ("src_bn_gamma", vp), ("src_bn_beta", vp), ("src_bn_relu", i32),
-                ("weight_up", vp), ("fold_src", vp), ("fold_weight", vp), ("fold_C", i32)]
+                ("weight_up", vp), ("fold_src", vp), ("fold_weight", vp), ("fold_C", i32),
+                ("stats_group_out", vp), ("stats_group_counters", vp), ("stats_group", i32)]
 
 
 class WgradParams(C.Structure):
@@ -54,6 +55,8 @@ SIGNATURES = {
     "stp_weight_prepare_upcollapse_bwd_batched": (i32, [vp, i32, i32, vp]),
     "stp_conv2d_fold_ok": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stats_floats": (sz, [C.POINTER(ConvParams)]),
+    "stp_conv2d_stats_group_for": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_stats_group_counters": (sz, [C.POINTER(ConvParams), i32]),
     "stp_conv2d_tile_for": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_sc": (i32, [C.POINTER(ConvParams), vp]),

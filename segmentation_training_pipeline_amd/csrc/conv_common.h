@@ -42,7 +42,60 @@ struct ConvArgs {
   uint32_t bytes_fold, bytesw_fold;
   int no_rm;      // 1: keep the fragment-order epilogue (STP_IGEMM_RM=0: A/B of the row-major one)
   int sum2x2;     // halo kernel, two destinations: dst0 = [N][Ho/2][Wo/2][Cd0] receives the 2 x 2 block sums of the first Cd0 channels (+ bnb)
+  // group-level pre-reduction of the statistic columns (stp_conv_params.stats_group): see stats_group_finish
+  float* sg_out;
+  unsigned* sg_cnt;
+  int sg_G;
 };
+
+// ---- group-level pre-reduction of the fused sums (round 5) ---------------------------------------------------------------------------
+// The BatchNormalization that follows a convolution reads [2][C][tiles] partial sums.  Up to 128 columns the apply kernels reduce them in
+// their own prologue (stp_bn_finalize_apply); the 256 ... 2048-column tables of the large feature maps needed a finalize LAUNCH in
+// between - ~5 us of pure latency on the critical chain, 50 times per step.  Here the last-arriving workgroup of every G consecutive
+// tiles sums the group's columns in tile order into a [2][C][tiles / G] table.  Visibility across CUs / XCDs (per-XCD L2s are not
+// coherent: MI355X_MICROARCH.md, inter-workgroup visibility): the columns are stored WRITE-THROUGH (sc1), every wave drains its
+// stores (asm s_waitcnt vmcnt(0): invisible to the wait-count pass), the workgroup meets at a barrier, ONE lane draws a device-scope
+// ticket; the workgroup that draws the last ticket reads the columns with sc1 loads (L1 bypassed, the write-through stores dropped the
+// lines from every L2).  Fixed membership, fixed order: the sums do not depend on who arrives last.
+__device__ __forceinline__ void stats_store(const ConvArgs& a, size_t idx, float v) {
+  if (a.sg_out) __hip_atomic_store(a.stats + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else a.stats[idx] = v;
+}
+// Every thread of the workgroup calls this AFTER the column `tile_n` (rows cout0 .. cout0 + nch - 1 of both statistics, Cs channels per
+// statistic, ntile columns) has been written with stats_store.  `word`: one LDS word nobody else touches until the workgroup ends.
+template <int NT>
+__device__ __forceinline__ void stats_group_finish(const ConvArgs& a, int Cs, int cout0, int nch, int tile_m, int tile_n, int ntile, int tid,
+                                                   unsigned* word) {
+  if (!a.sg_out) return;                                       // (launch-uniform)
+  const int G = a.sg_G, g = tile_n / G, ngroups = (ntile + G - 1) / G;
+  const int members = (ntile - g * G) < G ? (ntile - g * G) : G;
+  unsigned* const cnt = a.sg_cnt + (size_t)tile_m * ngroups + g;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's column stores have left the CU
+  __syncthreads();
+  if (tid == 0) *word = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*word != (unsigned)(members - 1)) return;                 // (workgroup-uniform) not the last of the group
+  if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch / graph replay
+  for (int r = tid; r < 2 * nch; r += NT) {
+    const int stat = r / nch, ch = cout0 + (r - stat * nch);
+    if (ch >= Cs) continue;
+    const float* col = a.stats + ((size_t)stat * Cs + ch) * ntile + (size_t)g * G;
+    float v[16];                                                // G <= 16: all loads in flight before the first addition
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = j < members ? __hip_atomic_load(col + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    float sum = v[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) sum += v[j];                   // tile order; the zeros of a short group change nothing
+    a.sg_out[((size_t)stat * Cs + ch) * ngroups + g] = sum;
+  }
+}
+// group size that brings `cols` columns to <= 128 (0: nothing to do)
+static inline int stats_group_size(int cols) {
+  if (cols <= 128) return 0;
+  int G = 2;
+  while ((cols + G - 1) / G > 128) G *= 2;
+  return G <= 16 ? G : 0;
+}
 
 // logical (parity-class major) pixel -> n, ho, wo
 __device__ __forceinline__ void zperm_decode(const ConvArgs& a, int pl, int& n, int& ho, int& wo) {
@@ -416,11 +469,12 @@ __device__ __forceinline__ void epilogue_rm_lin(const ConvArgs& a, f32x4 (&acc)[
 #pragma unroll
       for (int q = 0; q < NPART; ++q) tot += r2[q * (CG * 16) + tid];
       const int k = tid / CG, ch = (tid % CG) * 8 + (k >> 2) * 2 + (k & 1), stat = (k >> 1) & 1;
-      if (cout0 + ch < a.Cout) a.stats[((size_t)stat * a.Cout + cout0 + ch) * a.ntile_n + tile_n] = tot;
+      if (cout0 + ch < a.Cout) stats_store(a, ((size_t)stat * a.Cout + cout0 + ch) * a.ntile_n + tile_n, tot);
     }
+    stats_group_finish<NT>(a, a.Cout, cout0, BM, cout0 / BM, tile_n, a.ntile_n, tid, reinterpret_cast<unsigned*>(smem));
   }
 }
-__device__ __forceinline__ bool epilogue_rm_ok(const ConvArgs& a) {
+__host__ __device__ __forceinline__ bool epilogue_rm_ok(const ConvArgs& a) {
   return !a.no_rm && !(a.Cout & 7) && !(a.Cd0 & 7) && !(a.Cd1 & 7) && !a.stat_slots;
 }
 
@@ -471,6 +525,12 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   a.stat_slots = p->stats_slots;
   if (a.stats && ((p->Cout & 3) || (p->Cd0 != p->Cout && !p->dst_sum2x2))) return STP_E_BADARG;   // (two destinations: only the 2 x 2-summed form has sums)
   a.sum2x2 = p->dst_sum2x2 ? 1 : 0;
+  a.sg_out = nullptr; a.sg_cnt = nullptr; a.sg_G = 0;
+  if (p->stats_group > 1) {        // (the launcher checks that its kernel has the grouped epilogue and that G is the one it would choose)
+    if (!p->stats_group_out || !p->stats_group_counters || !a.stats || a.stat_slots || p->stats_group > 16 || (p->stats_group & (p->stats_group - 1)))
+      return STP_E_BADARG;
+    a.sg_out = p->stats_group_out; a.sg_cnt = p->stats_group_counters; a.sg_G = p->stats_group;
+  }
   if (a.stat_slots && (!a.stats || (a.stat_slots & (a.stat_slots - 1)) || a.stat_slots > 64)) return STP_E_BADARG;
   a.bnb.x = (const char*)p->bnb_x; a.bnb.mean = p->bnb_mean; a.bnb.rstd = p->bnb_rstd; a.bnb.gamma = p->bnb_gamma;
   a.bnb.beta = p->bnb_beta; a.bnb.relu = p->bnb_relu;

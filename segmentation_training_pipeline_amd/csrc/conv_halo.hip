@@ -296,15 +296,22 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
       for (int q = 0; q < NPART; ++q) tot += r2[q * NOUT + tid];
       const int k = tid / CG, ch = (tid % CG) * 8 + (k >> 2) * 2 + (k & 1), stat = (k >> 1) & 1;
       const int Cs = EP == 3 ? a.Cd0 : a.Cout;                  // EP 3: the table covers the summed destination's channels
-      if (cout0 + ch < Cs) a.stats[((size_t)stat * Cs + cout0 + ch) * a.ntile_n + tile_n] = tot;
+      if (cout0 + ch < Cs) stats_store(a, ((size_t)stat * Cs + cout0 + ch) * a.ntile_n + tile_n, tot);
     }
+    // group-level pre-reduction (conv_common.h): the last workgroup of every G tiles brings the table under 128 columns
+    stats_group_finish<512>(a, EP == 3 ? a.Cd0 : a.Cout, cout0, BM, cout0 / BM, tile_n, a.ntile_n, tid, reinterpret_cast<unsigned*>(smem));
   }
 }
 
 // PBN: the fused producer BatchNormalization (below) is a compile-time parameter of the body - as a run-time branch its 14-34 registers
 // tax every launch that does not use it (halo 8x64: 117 -> 102 VGPRs = one more wave per SIMD); the two __global__ entry points keep
 // the plain kernel's name (profiles, bench.py keys) and give the fused variant its own.
-template <int TH, int BM, int WM, int WN, int EP, bool PBN>
+// SRC2 (round 5): the input is concat(src0, src1) along the channels, src0 optionally behind UpSampling2D(2) (nearest) - the forward of the
+// U-Net decoder's conv3x3(concat(UpSampling2D(2)(x), skip)).  A slab (64 channels) lies in ONE source: slabs below C0 / 64 are staged from
+// src0 - with the halo pixel (y, x) fetched from the low-resolution pixel (y >> 1, x >> 1): the 2 x 2 replicas come out of L2, the slab in
+// LDS is the upsampled one and the K loop does not know - the others from src1; the weight column of slab s is s * 64 of the
+// concatenated channel order either way.  A compile-time parameter: a second set of per-pass offsets would tax the one-source kernels.
+template <int TH, int BM, int WM, int WN, int EP, bool PBN, bool SRC2>
 __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   static_assert(WM * WN == 8 && BM % (WM * 32) == 0 && TH % (WN * 2) == 0, "config");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -348,18 +355,26 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
 
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, a.bytesw, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(SRC2 && a.src1 ? a.src1 : a.src0), 0, SRC2 && a.src1 ? a.bytes1 : a.bytes0, 0x00020000);
 
   // ---- per-thread LDS-DMA source offsets ------------------------------------------------------------------------------
   // slab pass i: halo pixel hp = i*64 + tid/8 (column hx) at physical slot tid&7, which holds logical slot (tid&7) ^ ((hx>>1)&7)
   const int prow = tid >> 3, pslot = tid & 7;
-  uint32_t soff[NPASS];
+  uint32_t soff[NPASS], soff1[SRC2 ? NPASS : 1];
+  const int up = (SRC2 && a.mode == STP_SRC_NEAREST2X) ? 1 : 0;      // src0 behind UpSampling2D(2): [N][Hv / 2][Wv / 2][C0]
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
     const int hp = i * 64 + prow;
     const int hy = hp / HWD, hx = hp - hy * HWD;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = hp < NHP && (unsigned)y < (unsigned)a.Hv && (unsigned)x < (unsigned)a.Wv;
-    soff[i] = ok ? (((uint32_t)(n * a.Hv + y) * (uint32_t)a.Wv + (uint32_t)x) * (uint32_t)a.C0 + (uint32_t)((pslot ^ ((hx >> 1) & 7)) * 8)) * 2u : STP_OOB;
+    const uint32_t ch = (uint32_t)((pslot ^ ((hx >> 1) & 7)) * 8);
+    if (SRC2) {
+      soff[i] = ok ? (((uint32_t)(n * a.Hs0 + (y >> up)) * (uint32_t)a.Ws0 + (uint32_t)(x >> up)) * (uint32_t)a.C0 + ch) * 2u : STP_OOB;
+      soff1[i] = ok ? (((uint32_t)(n * a.Hv + y) * (uint32_t)a.Wv + (uint32_t)x) * (uint32_t)a.C1 + ch) * 2u : STP_OOB;
+    } else {
+      soff[i] = ok ? (((uint32_t)(n * a.Hv + y) * (uint32_t)a.Wv + (uint32_t)x) * (uint32_t)a.C0 + ch) * 2u : STP_OOB;
+    }
   }
   // weight instruction i: row i*64 + tid/8 of the channel tile, logical slot (tid&7) ^ ((row>>1)&7)
   uint32_t woff[LW];
@@ -367,9 +382,9 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   for (int i = 0; i < LW; ++i)
     woff[i] = ((uint32_t)(cout0 + i * 64 + prow) * (uint32_t)a.K + (uint32_t)((pslot ^ ((prow >> 1) & 7)) * 8)) * 2u;
 
-  const int nslab = a.C0 >> 6;
+  const int nslab = (SRC2 ? a.Ctot : a.C0) >> 6, nslab0 = a.C0 >> 6;
   const int off_w = (nslab > 1 ? 2 : 1) * SLAB;   // one slab buffer is enough for a 64-channel input: two workgroups share a CU
-  const uint32_t tapb = (uint32_t)a.C0 * 2u;     // bytes between the weight columns of consecutive taps
+  const uint32_t tapb = (uint32_t)(SRC2 ? a.Ctot : a.C0) * 2u;     // bytes between the weight columns of consecutive taps
 
   // piece i of the weights of K-step (slab s, tap t) -> ring stage st; the column offset travels in the scalar soffset
   auto issue_weight_piece = [&](int i, int st, int s, int t) {
@@ -379,7 +394,11 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   // pass p (compile-time) of slab s.  A wave whose 8 rows lie past the slab issues nothing: pass_on() enters the vmcnt counts
   auto pass_on = [&](int p) { return (p * 64 + wave * 8) < SROWS; };   // wave-uniform
   auto issue_slab_pass = [&](int s, int p) {
-    if (pass_on(p))
+    if (!pass_on(p)) return;
+    if (SRC2 && s >= nslab0)       // (s is a loop counter: wave-uniform) a slab of the second source
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(smem + (s & 1) * SLAB + (p * 64 + wave * 8) * 128), 16,
+                                               soff1[SRC2 ? p : 0], (uint32_t)(s - nslab0) * 128u, 0, 0);
+    else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(smem + (s & 1) * SLAB + (p * 64 + wave * 8) * 128), 16, soff[p],
                                                (uint32_t)s * 128u, 0, 0);
   };
@@ -388,6 +407,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   // y = act(fma(x, scale, shift)) is computed IN LDS on the slab, once per slab (9 K-steps), by the thread that DMA'd the 16 bytes
   // (own data: only its own vmcnt orders the read-modify-write, the K-step barrier publishes it).  Same fma / activation / bf16
   // rounding as stp_bn_apply -> bit-identical operands; pixels outside the image stay 0 (the padding applies to y, not x).
+  static_assert(!(PBN && SRC2), "the fused producer BatchNormalization is a one-source feature");
   const bool fuse_bn = PBN && a.pbn.mean != nullptr;
   float* const tab = reinterpret_cast<float*>(smem + off_w + NWST * WSTAGE);      // scale[C0], shift[C0]
   auto transform_slab = [&](int s_) {
@@ -552,9 +572,12 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
 // rounds instead of two).
 #define HALO_MIN_WAVES(TH, BM) ((TH) == 16 && (BM) == 64 ? 4 : 1)
 template <int TH, int BM, int WM, int WN, int EP>
-__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false>(a); }
+__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, false>(a); }
 template <int TH, int BM, int WM, int WN, int EP>
-__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_pbn_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, true>(a); }
+__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_pbn_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, true, false>(a); }
+// two sources / upsampled first source (forward only: EP 0 / 1)
+template <int TH, int BM, int WM, int WN, int EP>
+__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo2_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true>(a); }
 
 // ================================================================================================ host side
 struct HaloCfg { int th, bm; };
@@ -567,15 +590,20 @@ template <int TH, int BM, int WM, int WN, int EP>
 static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
-  size_t lds = (size_t)(a.C0 > 64 ? 2 : 1) * SROWS * 128 + HALO_NWST * BM * 128 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
+  const bool src2 = a.C1 > 0 || a.mode == STP_SRC_NEAREST2X;
+  size_t lds = (size_t)((src2 ? a.Ctot : a.C0) > 64 ? 2 : 1) * SROWS * 128 + HALO_NWST * BM * 128 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
   const size_t lds_ep = (size_t)TH * 16 * (BM * 4 + 16);   // the epilogue's staged fp32 tile
   if (lds < lds_ep) lds = lds_ep;
   a.ntile_m = ceil_div(a.Cout, BM);
   a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
-  static bool attr_set_pbn = false;
+  static bool attr_set_pbn = false, attr_set_src2 = false;
   const bool pbn = a.pbn.mean != nullptr;
+  if (src2 && (pbn || EP > 1)) return STP_E_BADARG;
   auto kern = pbn ? conv_halo_pbn_kernel<TH, BM, WM, WN, EP> : conv_halo_kernel<TH, BM, WM, WN, EP>;
-  bool& done = pbn ? attr_set_pbn : attr_set;
+  if constexpr (EP <= 1) {
+    if (src2) kern = conv_halo2_kernel<TH, BM, WM, WN, EP>;
+  }
+  bool& done = src2 ? attr_set_src2 : pbn ? attr_set_pbn : attr_set;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return STP_E_LAUNCH;
@@ -594,9 +622,22 @@ static int launch_halo(ConvArgs& a, hipStream_t s) {
   return launch_halo_ep<TH, BM, WM, WN, 0>(a, s);
 }
 
+// two sources / an upsampled first source (round 5, forward launches: no BatchNormalization-backward epilogue, no fused producer
+// BatchNormalization, one destination).  STP_HALO2=0 sends those launches back to the per-tap kernel (A/B).
+static bool halo2_enabled() {
+  static const bool on = !(getenv("STP_HALO2") && atoi(getenv("STP_HALO2")) == 0);
+  return on;
+}
+static bool halo_src_ok(const stp_conv_params* p) {
+  const bool direct = p->src0_mode == STP_SRC_DIRECT && p->Hs0 == p->Hv && p->Ws0 == p->Wv;
+  if (direct && p->C1 == 0) return true;
+  const bool up2 = p->src0_mode == STP_SRC_NEAREST2X && p->Hs0 * 2 == p->Hv && p->Ws0 * 2 == p->Wv;
+  return halo2_enabled() && (direct || up2) && (p->C1 == 0 || (p->src1 && (p->C1 % 64) == 0)) && !p->src_bn_mean && !p->bnb_x && !p->dst_sum2x2 &&
+         p->Cd0 == p->Cout;
+}
 static bool halo_shape_ok(const stp_conv_params* p) {
-  return p && p->dtype == STP_H16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->src0_mode == STP_SRC_DIRECT &&
-         p->C1 == 0 && p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv && p->Hs0 == p->Hv && p->Ws0 == p->Wv &&
+  return p && p->dtype == STP_H16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && halo_src_ok(p) &&
+         p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv &&
          (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->stats_slots &&
          // 2 x 2-summed first destination (EP 3): two destinations, fused BatchNormalization backward of the summed one, whole 64-channel tiles
          // (or ONE destination, every channel tile summed: Cd0 == Cout, the data gradient of conv3x3(UpSampling2D(2)(x)))
@@ -617,7 +658,13 @@ static int halo_auto(const stp_conv_params* p) {
   }
   const int64_t px16 = (p->Ho % 16) == 0 ? (int64_t)p->N * (p->Ho / 16) * (p->Wo / 16) : 0;
   const int64_t px8 = (int64_t)p->N * (p->Ho / 8) * (p->Wo / 16);
-  if (p->C0 == 64) {   // one slab, nine K-steps: the 64-channel tiles keep one slab + the ring under 80 KB, two workgroups per CU
+  if (p->C1 > 0 || p->src0_mode != STP_SRC_DIRECT) {
+    // two sources / upsampled source, 64-channel outputs (decoder_stage2_conv1: 128 upsampled + 64 skip -> 64 @ 16 x 128 x 128): 69 us on the
+    // 8 x 16 x 64 tiles against 89 us on the per-tap kernel (profiles/r05c_*); STP_HALO2_64=0 sends them back
+    static const bool c64 = !(getenv("STP_HALO2_64") && atoi(getenv("STP_HALO2_64")) == 0);
+    if (p->Cout <= 64 && !c64) return -1;
+  }
+  if (p->C0 == 64 && p->C1 == 0) {   // one slab, nine K-steps: the 64-channel tiles keep one slab + the ring under 80 KB, two workgroups per CU
     // several channel tiles over the same pixels (a data gradient into concatenated sources: 64 -> 192): 32 x 16 pixel tiles halve
     // the weight stream per pixel (scratch/halo_bench.py: 89 -> 81 us); one channel tile: no gain (35 us either way)
     if (p->Cout > 64 && (p->Ho % 32) == 0 && (int64_t)p->N * (p->Ho / 32) * (p->Wo / 16) * ceil_div(p->Cout, 64) >= 512) return 4;
@@ -637,7 +684,7 @@ extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p) {
   int v = -1;
   if (p->tile >= STP_TILE_HALO && p->tile < STP_TILE_HALO + HALO_NCFG) {
     v = p->tile - STP_TILE_HALO;
-    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && p->C0 != 64)) return -1;
+    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && (p->C0 != 64 || p->C1))) return -1;
   } else if (p->tile == 0) {
     v = halo_auto(p);
   }
@@ -651,7 +698,7 @@ extern "C" int stp_conv2d_halo_tiles(const stp_conv_params* p, int variant) {
 }
 
 extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stream) {
-  if (variant < 0 || variant >= HALO_NCFG || !halo_shape_ok(p) || (p->Ho % HALO_CFGS[variant].th) || (variant == 4 && p->C0 != 64)) return STP_E_BADARG;
+  if (variant < 0 || variant >= HALO_NCFG || !halo_shape_ok(p) || (p->Ho % HALO_CFGS[variant].th) || (variant == 4 && (p->C0 != 64 || p->C1))) return STP_E_BADARG;
   ConvArgs a;
   bool c4;
   int ut;

@@ -677,6 +677,32 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
 }
 
+// Group-level pre-reduction of the statistic columns (conv_common.h: stats_group_finish): the kernels whose epilogue has it are the halo
+// kernel and the buffer-DMA kernel with its row-major epilogue (16-bit storage).  STP_STATS_GROUP=0 switches the feature off (A/B).
+extern "C" int stp_conv2d_stats_group_for(const stp_conv_params* p) {
+  static const bool on = !(getenv("STP_STATS_GROUP") && atoi(getenv("STP_STATS_GROUP")) == 0);
+  if (!on || !p || p->stats_slots) return 0;
+  const int tile = stp_conv2d_tile_for(p);
+  if (tile < 0) return 0;
+  if (tile >= STP_TILE_HALO) return stats_group_size(stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO));
+  if (tile >= 64 && tile < 512 && p->dtype == STP_H16) {
+    ConvArgs a;
+    bool c4;
+    int ut;
+    stp_conv_params q = *p;
+    q.stats_group = 0;
+    if (fill_args(&q, a, &c4, &ut) != STP_OK || c4 || !epilogue_rm_ok(a)) return 0;
+    return stats_group_size(ceil_div(a.P, tile_pixels(tile)));
+  }
+  return 0;
+}
+extern "C" size_t stp_conv2d_stats_group_counters(const stp_conv_params* p, int32_t G) {
+  if (!p || G < 2) return 0;
+  const int Cs = p->dst_sum2x2 ? p->Cd0 : p->Cout;
+  const size_t cols = stp_conv2d_stats_floats(p) / (2 * (size_t)(Cs > 0 ? Cs : 1));
+  return (size_t)ceil_div(Cs, 16) * ceil_div((int64_t)cols, G);         // (channel tiles are 16 channels or wider)
+}
+
 static bool zperm_applies(const ConvArgs& a, int tile, int ut) {
   static const bool zperm_on = !(getenv("STP_ZPERM") && atoi(getenv("STP_ZPERM")) == 0);
   const bool uni_tile = tile >= 64 && tile < 256;
@@ -696,6 +722,7 @@ extern "C" int stp_conv2d_fold_ok(const stp_conv_params* p) {
 }
 
 extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
+  if (p && p->stats_group > 1 && p->stats_group != stp_conv2d_stats_group_for(p)) return STP_E_BADARG;   // (only the kernels that have the epilogue)
   if (p && (p->tile == 0 || p->tile == STP_TILE_SC)) {
     if (stp_conv2d_sc_eligible(p)) return stp_conv2d_sc(p, stream);
     if (p->tile == STP_TILE_SC) return STP_E_BADARG;

@@ -443,6 +443,21 @@ class Plan(object):
     def _mark(lst, what):
         lst.append((None, (), what, None))
 
+    def _group_stats(self, p, st, Cs):
+        """Group-level pre-reduction of a convolution's statistic columns (stp_conv_params.stats_group): where the kernel that serves
+        ``p`` has the epilogue and its table has more than 128 columns, the launch also writes a [2][Cs][columns / G] table that the
+        one-launch finalize + apply kernels take - returns (the table a BatchNormalization should read, its columns)."""
+        cols = int(self.lib.stp_conv2d_stats_floats(C.byref(p))) // (2 * Cs)
+        G = int(self.lib.stp_conv2d_stats_group_for(C.byref(p)))
+        if G < 2:
+            return st, cols
+        ng = -(-cols // G)
+        out = self._alloc((2 * Cs * ng,), torch.float32)
+        cnt = torch.zeros((max(1, int(self.lib.stp_conv2d_stats_group_counters(C.byref(p), G))),), dtype=torch.int32, device=self.device)
+        self._keep.append(cnt)
+        p.stats_group_out, p.stats_group_counters, p.stats_group = out.data_ptr(), cnt.data_ptr(), G
+        return out, ng
+
     def _emit_conv(self, lst, p, meta=None):
         self._keep.append(p)
         if meta is not None and meta.get("tile") == 512:
@@ -582,6 +597,8 @@ class Plan(object):
         elif fused is not None:
             st, cp = fused
             tiles = int(self.lib.stp_conv2d_stats_floats(C.byref(cp))) // (2 * Cn)
+            if x.meta.get("stats_table") is not None:
+                st, tiles = x.meta["stats_table"]
             self._emit(self.fwd, "stp_bn_finalize", st.data_ptr(), tiles, x.rows, Cn, eps, momentum, mean.data_ptr(),
                        rstd.data_ptr(), self._sptr(mm), self._sptr(mv))
         else:
@@ -716,8 +733,10 @@ class Plan(object):
                             Ho=Ho, Wo=Wo, Cout=Cout, dtype=self.cdt, residual=residual.buf if residual is not None else None)
         w4 = None
         if (upsample and src1 is not None and k == 3 and KWp == 3 and stride == 1 and pad == 1 and Cinp == Cin_master == C0 + C1
-                and os.environ.get("STP_UPCOLLAPSE", "1") != "0" and not self.lib.stp_conv2d_scn_eligible(C.byref(p))):
-            # (the narrow-output kernel - 64 + 64 -> 32 channels - keeps both halos in LDS and takes the plain weight copy)
+                and os.environ.get("STP_UPCOLLAPSE", "1") != "0" and not self.lib.stp_conv2d_scn_eligible(C.byref(p))
+                and int(self.lib.stp_conv2d_halo_variant(C.byref(p))) < 0):
+            # (the narrow-output kernel - 64 + 64 -> 32 channels - keeps both halos in LDS and takes the plain weight copy; so does the
+            #  two-source form of the halo kernel, round 5: 128+ output channels)
             # decoder conv1 = conv3x3(concat(UpSampling2D(2)(x), skip)): per output parity class the taps over the upsampled half read
             # 2 x 2 low-resolution pixels - the forward multiplies them by class-summed weights (4 x C0 + 9 x C1 K columns instead
             # of 9 x (C0 + C1)); the summed copy is rebuilt from the fp32 master with the other weight copies, once per step
@@ -752,9 +771,11 @@ class Plan(object):
             st = self._alloc((max(nfl, 4),), torch.float32)
             p.stats_partial = st.data_ptr()
             out.meta["stats"] = (st, p)
+            out.meta["stats_table"] = self._group_stats(p, st, Cout)       # (table, columns) the BatchNormalization reads
         # algorithmic work of this layer: 2 * pixels * Cout * KH*KW*Cin with the REAL (unpadded) dims
         flops = 2.0 * self.N * Ho * Wo * Cout * k * k * Cin_master / (4.0 if transpose else 1.0)   # zero-inserted taps are not work
-        self._emit_conv(self.fwd, p, {"layer": name, "pass": "fwd", "flops": flops, "tile": int(self.lib.stp_conv2d_tile_for(C.byref(p)))})
+        self._emit_conv(self.fwd, p, {"layer": name, "pass": "fwd", "flops": flops, "tile": int(self.lib.stp_conv2d_tile_for(C.byref(p))),
+                                      "src2": bool(C1 or upsample)})
         if not self.training:
             return out
 
@@ -957,6 +978,9 @@ class Plan(object):
                         st = self._alloc((max(nfl, 4),), torch.float32)
                         q.stats_partial = st.data_ptr()
                         x.meta["bnb"] = (st, q)
+                        gt, gcols = self._group_stats(q, st, C0)
+                        if gt is not st:
+                            x.meta["bnb"] = (gt, gcols)           # the pre-reduced table ([2][C0][columns / G]) and its column count
                 self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": qflops,
                                               "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
                 if upsample and x_ng and not folded_up:

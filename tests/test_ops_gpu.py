@@ -422,6 +422,144 @@ def test_conv_halo_kernel_forward_statistics_residual(ops, case, dtype):
     np.testing.assert_allclose(host(y3), ref3, atol=tol(ref3, dtype))
 
 
+HALO2_CASES = [
+    # n, h, w, c0, c1, co, variant, upsampled first source
+    (2, 16, 32, 128, 64, 128, 0, True), (1, 32, 16, 64, 64, 192, 0, True), (2, 8, 16, 256, 128, 256, 1, True),
+    (1, 32, 16, 128, 64, 64, 2, True), (2, 8, 32, 64, 128, 64, 3, True),
+    (1, 16, 16, 64, 128, 128, 0, False), (2, 24, 16, 128, 0, 64, 3, True),       # plain concatenation; one upsampled source (Linknet)
+]
+
+
+@pytest.mark.parametrize("case", HALO2_CASES)
+@pytest.mark.parametrize("dtype", H16)
+def test_conv_halo_kernel_two_sources_with_upsampled_first(ops, case, dtype):
+    """conv_halo2_kernel (round 5): Conv2D(3x3)(Concatenate([UpSampling2D(2)(x), skip])) on the halo-resident kernel - a 64-channel slab
+    lies in one source, the slabs of the first are staged from the LOW-resolution pixels (y >> 1, x >> 1).  Against numpy on the
+    materialised concatenation and against the per-tap kernel on the same buffers; fused statistics against the stored output;
+    bias + ReLU + accumulate; every image border of every tile; replay bit-identical."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c0, c1, co, var, up = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    hs, ws_ = (h // 2, w // 2) if up else (h, w)
+    xlo = q(rng.randn(n, hs, ws_, c0), dtype)
+    skip = q(rng.randn(n, h, w, c1), dtype) if c1 else None
+    wt = q(rng.randn(3, 3, c0 + c1, co) / np.sqrt(9 * (c0 + c1)), dtype)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    xd, sd = dev(xlo, dtype), (dev(skip, dtype) if c1 else None)
+    xhi = xlo.repeat(2, axis=1).repeat(2, axis=2) if up else xlo
+    want = np_ops.conv2d(np.concatenate([xhi, skip], axis=-1) if c1 else xhi, wt, 1, 1)
+
+    def run(tile, stats=False, **kw):
+        y = kw.pop("y", None)
+        if y is None:
+            y = torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+        P = ops.conv_params(xd, fwd, y, N=n, Hs0=hs, Ws0=ws_, Hv=h, Wv=w, C0=c0, C1=c1, src1=sd, mode=ops.SRC_NEAREST2X if up else ops.SRC_DIRECT,
+                            KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.dt(y), tile=tile, **kw)
+        st = None
+        if stats:
+            st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+            P.stats_partial = ops.ptr(st)
+        ops.conv2d(P)
+        return y, st, P
+    y, st, P = run(1024 + var, stats=True)
+    assert _lib.load().stp_conv2d_tile_for(ops.C.byref(P)) == 1024 + var
+    np.testing.assert_allclose(host(y), want, atol=tol(want, dtype))
+    y_tap, _, _ = run(69)                                                      # the per-tap kernel on the same buffers
+    np.testing.assert_allclose(host(y), host(y_tap), atol=tol(want, dtype))
+    tiles = ops.conv2d_stats_floats(P) // (2 * co)
+    assert tiles == P.stats_tiles == n * (h // {0: 16, 1: 8, 2: 16, 3: 8}[var]) * (w // 16)
+    part = host(st)[:2 * co * tiles].reshape(2, co, tiles).astype(np.float64).sum(-1)
+    yv = host(y).reshape(-1, co).astype(np.float64)
+    np.testing.assert_allclose(part[0], yv.sum(0), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(part[1], (yv * yv).sum(0), rtol=1e-4, atol=1e-2)
+    y2, st2, _ = run(1024 + var, stats=True)
+    assert torch.equal(y2, y) and torch.equal(st2[:2 * co * tiles], st[:2 * co * tiles])
+    base = q(rng.randn(n, h, w, co), dtype)
+    bias = keep(torch.from_numpy(rng.randn(co).astype(np.float32)).to(DEV))
+    y3, _, _ = run(1024 + var, y=dev(base, dtype), bias=bias, relu=1, accumulate0=1)
+    ref3 = np.maximum(want + host(bias) + base, 0.0)
+    np.testing.assert_allclose(host(y3), ref3, atol=tol(ref3, dtype))
+
+
+GROUP_CASES = [
+    # n, h, w, ci, co, tile, expected G: more than 128 statistic columns -> the last workgroup of every G tiles pre-reduces them
+    (3, 56, 112, 64, 64, 1027, 2),       # 147 tiles of 8 x 16: 74 groups, the last one short
+    (2, 128, 128, 64, 256, 1025, 2),     # 256 tiles x 2 channel tiles
+    (5, 64, 128, 64, 64, 1027, 4),       # 320 tiles -> G = 4
+    (2, 64, 128, 64, 64, 1026, 0),       # 64 tiles: nothing to do
+    (3, 80, 72, 64, 128, 69, 4),         # the buffer-DMA kernel's row-major epilogue: 17280 pixels / 64 = 270 tiles
+]
+
+
+@pytest.mark.parametrize("case", GROUP_CASES)
+@pytest.mark.parametrize("bnb", [False, True])
+@pytest.mark.parametrize("dtype", H16)
+def test_statistic_columns_pre_reduced_by_the_last_workgroup_of_a_group(ops, case, bnb, dtype):
+    """stp_conv_params.stats_group (round 5): the group table equals the tile-order fp32 sum of the group's columns of stats_partial
+    EXACTLY (fixed membership, fixed order - whoever arrives last), the arrival counters are back at zero, a second launch is
+    bit-identical, and stp_bn_finalize over the group table equals stp_bn_finalize over the full table (forward statistics and the
+    BatchNormalization-backward sums)."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co, tile, G_want = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    xd = dev(x, dtype)
+    f32 = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    bx = dev(q(rng.randn(n, h, w, co), dtype), dtype) if bnb else None
+    mean, rstd, gamma, beta = (f32(rng.randn(co) * 0.1), f32(rng.rand(co) + 0.5), f32(rng.rand(co) + 0.5), f32(rng.randn(co) * 0.1)) if bnb else (None,) * 4
+
+    def run(group):
+        y = torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+        P = ops.conv_params(xd, fwd, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.dt(y), tile=tile)
+        if bnb:
+            P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(bx), ops.ptr(mean), ops.ptr(rstd), ops.ptr(gamma), ops.ptr(beta), 1
+        st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+        P.stats_partial = ops.ptr(st)
+        G = int(_lib.load().stp_conv2d_stats_group_for(ops.C.byref(P)))
+        gt = cnt = None
+        if group and G:
+            cols = ops.conv2d_stats_floats(P) // (2 * co)
+            ng = -(-cols // G)
+            gt = torch.full((2 * co * ng,), float("nan"), dtype=torch.float32, device=DEV)
+            cnt = torch.zeros(int(_lib.load().stp_conv2d_stats_group_counters(ops.C.byref(P), G)), dtype=torch.int32, device=DEV)
+            P.stats_group_out, P.stats_group_counters, P.stats_group = ops.ptr(gt), ops.ptr(cnt), G
+        ops.conv2d(P)
+        return y, st, gt, cnt, G, P
+    y, st, gt, cnt, G, P = run(True)
+    assert G == G_want
+    y0, st0, _, _, _, _ = run(False)
+    assert torch.equal(y, y0)                                      # the grouped launch changes nothing else
+    cols = ops.conv2d_stats_floats(P) // (2 * co)
+    full = host(st)[:2 * co * cols].reshape(2 * co, cols)
+    np.testing.assert_array_equal(full, host(st0)[:2 * co * cols].reshape(2 * co, cols))
+    if not G:
+        return
+    ng = -(-cols // G)
+    want = np.zeros((2 * co, ng), np.float32)
+    for g in range(ng):
+        acc = full[:, g * G].copy()
+        for j in range(1, min(G, cols - g * G)):
+            acc = (acc + full[:, g * G + j]).astype(np.float32)
+        want[:, g] = acc
+    np.testing.assert_array_equal(host(gt).reshape(2 * co, ng), want)
+    assert int(cnt.abs().sum().item()) == 0                        # tickets returned: the next launch / graph replay starts from zero
+    y2, st2, gt2, cnt2, _, _ = run(True)
+    assert torch.equal(gt2, gt) and torch.equal(y2, y)
+    if not bnb:
+        rows = n * h * w
+        m1, r1, m0, r0 = (torch.empty(co, device=DEV) for _ in range(4))
+        _lib.call("stp_bn_finalize", ops.ptr(gt), ng, rows, co, 1e-3, 0.99, ops.ptr(m1), ops.ptr(r1), None, None, ops.stream())
+        _lib.call("stp_bn_finalize", ops.ptr(st), cols, rows, co, 1e-3, 0.99, ops.ptr(m0), ops.ptr(r0), None, None, ops.stream())
+        np.testing.assert_allclose(host(m1), host(m0), atol=2e-6 * max(1.0, np.abs(host(m0)).max()))
+        np.testing.assert_allclose(host(r1), host(r0), rtol=2e-5)
+    # a group size the kernel would not choose is refused
+    P.stats_group = 16 if G != 16 else 8
+    with pytest.raises(_lib.StpError):
+        ops.conv2d(P)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 0, 1), (1, 32, 16, 256, 64, 0, 0), (2, 8, 16, 192, 128, 1, 1), (1, 16, 16, 64, 64, 2, 1),
                                   (2, 8, 32, 512, 64, 3, 2)])
 @pytest.mark.parametrize("dtype", H16)
