@@ -33,7 +33,7 @@ class ConvParams(C.Structure):
                 ("dst_sum2x2", i32), ("stats_slots", i32),
                 ("src_bn_mean", vp), ("src_bn_rstd", vp), ("src_bn_gamma", vp), ("src_bn_beta", vp), ("src_bn_relu", i32),
                 ("weight_up", vp), ("fold_src", vp), ("fold_weight", vp), ("fold_C", i32),
-                ("stats_group_out", vp), ("stats_group_counters", vp), ("stats_group", i32)]
+                ("stats_group_out", vp), ("stats_group_counters", vp), ("stats_group", i32), ("s2d_dgrad", i32)]
 
 
 class WgradParams(C.Structure):
@@ -53,6 +53,8 @@ SIGNATURES = {
     "stp_weight_prepare_upcollapse_desc_bytes": (sz, []),
     "stp_weight_prepare_upcollapse_batched": (i32, [vp, i32, i32, vp]),
     "stp_weight_prepare_upcollapse_bwd_batched": (i32, [vp, i32, i32, vp]),
+    "stp_weight_prepare_s2d_desc_bytes": (sz, []),
+    "stp_weight_prepare_s2d_batched": (i32, [vp, i32, i32, vp]),
     "stp_conv2d_fold_ok": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stats_floats": (sz, [C.POINTER(ConvParams)]),
     "stp_conv2d_stats_group_for": (i32, [C.POINTER(ConvParams)]),

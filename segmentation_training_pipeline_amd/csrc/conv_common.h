@@ -46,6 +46,7 @@ struct ConvArgs {
   float* sg_out;
   unsigned* sg_cnt;
   int sg_G;
+  int d2s;        // halo kernel, stp_conv_params.s2d_dgrad: depth-to-space store of the 4 x Cq parity-class-major channels
 };
 
 // ---- group-level pre-reduction of the fused sums (round 5) ---------------------------------------------------------------------------
@@ -526,6 +527,7 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   if (a.stats && ((p->Cout & 3) || (p->Cd0 != p->Cout && !p->dst_sum2x2))) return STP_E_BADARG;   // (two destinations: only the 2 x 2-summed form has sums)
   a.sum2x2 = p->dst_sum2x2 ? 1 : 0;
   a.sg_out = nullptr; a.sg_cnt = nullptr; a.sg_G = 0;
+  a.d2s = p->s2d_dgrad ? 1 : 0;
   if (p->stats_group > 1) {        // (the launcher checks that its kernel has the grouped epilogue and that G is the one it would choose)
     if (!p->stats_group_out || !p->stats_group_counters || !a.stats || a.stat_slots || p->stats_group > 16 || (p->stats_group & (p->stats_group - 1)))
       return STP_E_BADARG;

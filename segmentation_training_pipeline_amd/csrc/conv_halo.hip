@@ -87,10 +87,17 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
   const int co = cout0 + c8 * 8;
   const bool cok = co < a.Cout;                               // Cout % 8 == 0: a group is valid as a whole
   const bool first = co < a.Cd0;
-  T* const dbase = first ? reinterpret_cast<T*>(a.dst0) + co : reinterpret_cast<T*>(a.dst1) + (co - a.Cd0);
-  const int dC = first ? a.Cd0 : a.Cd1;
+  // D2S (a.d2s, the space-to-depth data gradient of a stride-2 convolution): the Cout = 4 x Cq channels are parity-class major - channel
+  // co = cls * Cq + pc of tile pixel (a, b) is channel pc of the destination pixel (2a + (cls >> 1), 2b + (cls & 1)) of [N][2 Ho][2 Wo][Cq];
+  // the per-channel operands (BatchNormalization constants, the sums) belong to pc.  Cq % 8 == 0: a thread's 8 channels share a class.
+  const bool d2s = (EP == 0 || EP == 2) && a.d2s;
+  const int Cq = d2s ? a.Cout >> 2 : a.Cout;
+  const int cls = d2s ? co / Cq : 0, pc = co - cls * Cq;
+  T* const dbase = d2s ? reinterpret_cast<T*>(a.dst0) + pc : first ? reinterpret_cast<T*>(a.dst0) + co : reinterpret_cast<T*>(a.dst1) + (co - a.Cd0);
+  const int dC = d2s ? Cq : first ? a.Cd0 : a.Cd1;
   const bool accum = first ? a.acc0 : a.acc1;
   const T* res = EP == 2 ? reinterpret_cast<const T*>(a.bnb.x) : reinterpret_cast<const T*>(a.residual);      // (EP 3: no residual)
+  const int rC = d2s ? Cq : a.Cout;                           // row stride of `res` (same pixel grid as the destination)
 
   // EP 3, channel tile of the UPSAMPLED source (cout0 < Cd0, the whole tile: Cd0 % BM == 0): see below
   const bool summed = EP == 3 && cout0 < a.Cd0;
@@ -100,12 +107,13 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int px = p0 + k * PP;
-    pm[k] = n * a.HoWo + (y0 + (px >> 4)) * a.Wo + x0 + (px & 15);
+    pm[k] = d2s ? (n * a.Ho * 2 + (y0 + (px >> 4)) * 2 + (cls >> 1)) * (a.Wo * 2) + (x0 + (px & 15)) * 2 + (cls & 1)
+                : n * a.HoWo + (y0 + (px >> 4)) * a.Wo + x0 + (px & 15);
   }
   if (cok && !summed) {
     if (res) {
 #pragma unroll
-      for (int k = 0; k < NP; ++k) opr[k] = *reinterpret_cast<const u32x4*>(res + (size_t)pm[k] * a.Cout + co);
+      for (int k = 0; k < NP; ++k) opr[k] = *reinterpret_cast<const u32x4*>(res + (size_t)pm[k] * rC + pc);
     }
     if (accum) {
 #pragma unroll
@@ -197,14 +205,14 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
     for (int e = 0; e < 4; ++e) bias2[e] = ksc[e] = ksh[e] = f32x2v{0.f, 0.f};
     if (EP != 2 && a.bias) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bias2[e] = *reinterpret_cast<const f32x2v*>(a.bias + co + 2 * e);
+      for (int e = 0; e < 4; ++e) bias2[e] = *reinterpret_cast<const f32x2v*>(a.bias + pc + 2 * e);
     }
     if (EP == 2) {
-      const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co + 4);
-      const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co + 4);
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + pc), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + pc + 4);
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + pc), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + pc + 4);
       f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-      if (a.bnb.gamma) { g0 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + co); g1 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + co + 4); }
-      if (a.bnb.beta) { b0 = *reinterpret_cast<const f32x4*>(a.bnb.beta + co); b1 = *reinterpret_cast<const f32x4*>(a.bnb.beta + co + 4); }
+      if (a.bnb.gamma) { g0 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + pc); g1 = *reinterpret_cast<const f32x4*>(a.bnb.gamma + pc + 4); }
+      if (a.bnb.beta) { b0 = *reinterpret_cast<const f32x4*>(a.bnb.beta + pc); b1 = *reinterpret_cast<const f32x4*>(a.bnb.beta + pc + 4); }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float r = e < 4 ? r0[e & 3] : r1[e & 3], mu = e < 4 ? m0[e & 3] : m1[e & 3];
@@ -258,8 +266,8 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
   if (EP >= 1) {
 #endif
     if ((EP == 2 || EP == 3) && cok) {   // sum g * xhat = rstd * (sum g * x - mean * sum g), per thread (linear, so the partition does not matter)
-      const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + co + 4);
-      const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + co + 4);
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.bnb.mean + pc), m1 = *reinterpret_cast<const f32x4*>(a.bnb.mean + pc + 4);
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + pc), r1 = *reinterpret_cast<const f32x4*>(a.bnb.rstd + pc + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float mu = e < 4 ? m0[e & 3] : m1[e & 3], rs = e < 4 ? r0[e & 3] : r1[e & 3];
@@ -296,8 +304,13 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
       for (int q = 0; q < NPART; ++q) tot += r2[q * NOUT + tid];
       const int k = tid / CG, ch = (tid % CG) * 8 + (k >> 2) * 2 + (k & 1), stat = (k >> 1) & 1;
       const int Cs = EP == 3 ? a.Cd0 : a.Cout;                  // EP 3: the table covers the summed destination's channels
-      if (cout0 + ch < Cs) stats_store(a, ((size_t)stat * Cs + cout0 + ch) * a.ntile_n + tile_n, tot);
+      if (d2s) {
+        // the four parity classes of a destination channel are four column blocks of ITS row: [stat][Cq][4 x tiles]
+        const int v = cout0 + ch, vc = v / Cq, vp = v - vc * Cq;
+        if (v < a.Cout) a.stats[(((size_t)stat * Cq + vp) * 4 + vc) * a.ntile_n + tile_n] = tot;
+      } else if (cout0 + ch < Cs) stats_store(a, ((size_t)stat * Cs + cout0 + ch) * a.ntile_n + tile_n, tot);
     }
+    if (d2s) return;                                            // (launch-uniform; no group-level pre-reduction in this form)
     // group-level pre-reduction (conv_common.h): the last workgroup of every G tiles brings the table under 128 columns
     stats_group_finish<512>(a, EP == 3 ? a.Cd0 : a.Cout, cout0, BM, cout0 / BM, tile_n, a.ntile_n, tid, reinterpret_cast<unsigned*>(smem));
   }
@@ -311,9 +324,17 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
 // src0 - with the halo pixel (y, x) fetched from the low-resolution pixel (y >> 1, x >> 1): the 2 x 2 replicas come out of L2, the slab in
 // LDS is the upsampled one and the K loop does not know - the others from src1; the weight column of slab s is s * 64 of the
 // concatenated channel order either way.  A compile-time parameter: a second set of per-pass offsets would tax the one-source kernels.
-template <int TH, int BM, int WM, int WN, int EP, bool PBN, bool SRC2>
+// NT (round 5) = taps per slab: 9 = the 3 x 3 window; 4 = the 2 x 2 window at offsets (+0 / +1, +0 / +1) - the SPACE-TO-DEPTH form of
+// the data gradient of a 3x3 / stride-2 / pad-1 convolution (stp_conv_params.s2d_dgrad): per output parity class (py, px) the gradient
+// at (2a + py, 2b + px) reads dY at (a, b), (a, b + 1), (a + 1, b), (a + 1, b + 1) under 1 / 2 / 2 / 4 of the nine kernel taps, so all
+// four classes are ONE dense 2 x 2-tap convolution of dY into 4 x Cin channels (class-major; weights zero where a class has no tap:
+// 9 of the 16 (tap, class) blocks are live) whose store is a depth-to-space (epilogue_rm, D2S).  A tap is an LDS offset of the slab, as
+// before; only the prefetch schedule depends on NT: the passes of the next slab must have been issued three K-steps before its first
+// use, i.e. in the taps 0 .. NT - 3 of the current one (PPS passes per K-step).
+template <int TH, int BM, int WM, int WN, int EP, bool PBN, bool SRC2, int NT = 9>
 __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   static_assert(WM * WN == 8 && BM % (WM * 32) == 0 && TH % (WN * 2) == 0, "config");
+  static_assert(NT == 9 || NT == 4, "taps per slab");
 #if defined(__HIP_DEVICE_COMPILE__)
 #if defined(STP_TIMING)   // scratch build: `bias` carries a u64[4 * workgroups] buffer of shader-clock stamps (scratch/halo_timing.py)
   ConvArgs a = a_in;
@@ -337,7 +358,11 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   constexpr int LW = BM / 64;                    // weight LDS-DMA instructions per thread per K-step
   constexpr int CW = BM / WM, RW = TH / WN;      // channels / pixel rows per wave
   constexpr int TM = CW / 32, TN = RW / 2;       // 32x32 MFMA tiles per wave
-  static_assert(LW + 1 <= TM * TN * 4, "one LDS-DMA instruction per MFMA at most");
+  constexpr int PPS = (NPASS + (NT - 2) - 1) / (NT - 2);   // slab passes per K-step: all issued in taps 0 .. NT - 3
+  constexpr int NPT = (NPASS + PPS - 1) / PPS;              // K-steps that carry passes
+  static_assert(LW + PPS <= TM * TN * 4, "one LDS-DMA instruction per MFMA at most");
+  static_assert(NPT <= NT - 2 || TH == 32, "the next slab is complete three K-steps before its first use");
+  static_assert(LW + PPS <= 5, "wait_vmcnt_n covers 0 .. 5");
   // LDS: [slab 0][slab 1 unless Cin == 64][NWST weight stages][scale/shift table of a fused producer BatchNormalization]
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -490,10 +515,10 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
     for (int s = 0; s < nslab; ++s) {
       const bool last = s + 1 == nslab;    // no slab to prefetch, and the weights of the next "slab" do not exist
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3, dx = t - dy * 3;             // compile-time after unrolling
+      for (int t = 0; t < NT; ++t) {
+        const int dy = NT == 9 ? t / 3 : 1 + t / 2, dx = NT == 9 ? t - (t / 3) * 3 : 1 + (t & 1);             // compile-time after unrolling
         // ---------------- MEM(k)
-        if (fuse_bn && t == 8 && !last) transform_slab(s + 1);   // its passes landed (own pieces) before MEM(9s+7) ended
+        if (fuse_bn && t == NT - 1 && !last) transform_slab(s + 1);   // its passes landed (own pieces) before MEM(9s+7) ended
         {
           const uint32_t so = (uint32_t)(wst * WSTAGE);
 #pragma unroll
@@ -509,10 +534,15 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
         // leave the youngest group (issued in MMA(k-1)) in flight: LW weight pieces unless that K-step had none left to
         // prefetch, plus its slab pass if there is a next slab and this wave has rows in that pass
         if (t == 0) {
-          wait_vmcnt_n(LW);                                 // previous K-step = tap 8 (never of the last slab): no pass
+          wait_vmcnt_n(LW);                                 // previous K-step = the last tap of a slab that is not the last: weights, no pass
         } else {
-          const int np = ((t - 1) < NPASS && !last && pass_on(t - 1)) ? 1 : 0;
-          wait_vmcnt_n(((last && t - 1 >= 6) ? 0 : LW) + np);
+          int np = 0;                                       // passes issued in MMA(k - 1) by this wave
+          if ((t - 1) < NPT && !last) {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i)
+              if ((t - 1) * PPS + i < NPASS && pass_on((t - 1) * PPS + i)) ++np;
+          }
+          wait_vmcnt_n(((last && t - 1 + 3 >= NT) ? 0 : LW) + np);
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -520,8 +550,8 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
         __builtin_amdgcn_s_setprio(1);
         {
           const int st3 = (wst + 3) & 3;
-          const int t3 = t + 3 < 9 ? t + 3 : t - 6, s3 = t + 3 < 9 ? s : s + 1;
-          const bool wlive = !(last && t >= 6);
+          const int t3 = t + 3 < NT ? t + 3 : t + 3 - NT, s3 = t + 3 < NT ? s : s + 1;
+          const bool wlive = !(last && t + 3 >= NT);
           int piece = 0;
 #pragma unroll
           for (int kc = 0; kc < 4; ++kc)
@@ -533,8 +563,8 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (piece < LW) {
                   if (wlive) issue_weight_piece(piece, st3, s3, t3);
-                } else if (piece == LW && t < NPASS) {
-                  if (!last) issue_slab_pass(s + 1, t);
+                } else if (piece < LW + PPS && t < NPT && t * PPS + (piece - LW) < NPASS) {
+                  if (!last) issue_slab_pass(s + 1, t * PPS + (piece - LW));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 ++piece;
@@ -578,6 +608,9 @@ __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_pbn_ker
 // two sources / upsampled first source (forward only: EP 0 / 1)
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo2_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true>(a); }
+// space-to-depth data gradient of a stride-2 convolution: 2 x 2 taps, one or two sources, depth-to-space store (EP 0 / 2)
+template <int TH, int BM, int WM, int WN, int EP>
+__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_s2d_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true, 4>(a); }
 
 // ================================================================================================ host side
 struct HaloCfg { int th, bm; };
@@ -590,7 +623,7 @@ template <int TH, int BM, int WM, int WN, int EP>
 static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
-  const bool src2 = a.C1 > 0 || a.mode == STP_SRC_NEAREST2X;
+  const bool src2 = a.C1 > 0 || a.mode == STP_SRC_NEAREST2X || a.d2s;
   size_t lds = (size_t)((src2 ? a.Ctot : a.C0) > 64 ? 2 : 1) * SROWS * 128 + HALO_NWST * BM * 128 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
   const size_t lds_ep = (size_t)TH * 16 * (BM * 4 + 16);   // the epilogue's staged fp32 tile
   if (lds < lds_ep) lds = lds_ep;
@@ -598,12 +631,18 @@ static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
   static bool attr_set_pbn = false, attr_set_src2 = false;
   const bool pbn = a.pbn.mean != nullptr;
-  if (src2 && (pbn || EP > 1)) return STP_E_BADARG;
+  static bool attr_set_s2d = false;
+  if (a.d2s) {
+    if (pbn || BM != 128 || (EP != 0 && EP != 2)) return STP_E_BADARG;
+  } else if (src2 && (pbn || EP > 1)) return STP_E_BADARG;
   auto kern = pbn ? conv_halo_pbn_kernel<TH, BM, WM, WN, EP> : conv_halo_kernel<TH, BM, WM, WN, EP>;
   if constexpr (EP <= 1) {
-    if (src2) kern = conv_halo2_kernel<TH, BM, WM, WN, EP>;
+    if (src2 && !a.d2s) kern = conv_halo2_kernel<TH, BM, WM, WN, EP>;
   }
-  bool& done = src2 ? attr_set_src2 : pbn ? attr_set_pbn : attr_set;
+  if constexpr (BM == 128 && (EP == 0 || EP == 2)) {
+    if (a.d2s) kern = conv_halo_s2d_kernel<TH, BM, WM, WN, EP>;
+  }
+  bool& done = a.d2s ? attr_set_s2d : src2 ? attr_set_src2 : pbn ? attr_set_pbn : attr_set;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return STP_E_LAUNCH;
@@ -635,7 +674,16 @@ static bool halo_src_ok(const stp_conv_params* p) {
   return halo2_enabled() && (direct || up2) && (p->C1 == 0 || (p->src1 && (p->C1 % 64) == 0)) && !p->src_bn_mean && !p->bnb_x && !p->dst_sum2x2 &&
          p->Cd0 == p->Cout;
 }
+// space-to-depth data gradient (stp_conv_params.s2d_dgrad; STP_S2D=0 refuses it - the plan then keeps the parity-class launch)
+static bool halo_s2d_ok(const stp_conv_params* p) {
+  static const bool on = !(getenv("STP_S2D") && atoi(getenv("STP_S2D")) == 0);
+  return on && p && p->s2d_dgrad && p->dtype == STP_H16 && p->KH == 2 && p->KW == 2 && p->stride == 1 && p->pad == 0 && p->src0_mode == STP_SRC_DIRECT &&
+         p->Hs0 == p->Hv && p->Ws0 == p->Wv && p->Ho == p->Hv && p->Wo == p->Wv && (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && p->C0 >= 64 &&
+         (p->C0 % 64) == 0 && (p->C1 == 0 || (p->src1 && (p->C1 % 64) == 0)) && (p->Cout % 128) == 0 && p->Cd0 == p->Cout && !p->dst1 &&
+         !p->dst_sum2x2 && !p->stats_slots && !p->src_bn_mean && !p->bias && !p->relu && !p->residual && !p->accumulate1;
+}
 static bool halo_shape_ok(const stp_conv_params* p) {
+  if (p && p->s2d_dgrad) return halo_s2d_ok(p);
   return p && p->dtype == STP_H16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && halo_src_ok(p) &&
          p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv &&
          (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->stats_slots &&
@@ -658,6 +706,11 @@ static int halo_auto(const stp_conv_params* p) {
   }
   const int64_t px16 = (p->Ho % 16) == 0 ? (int64_t)p->N * (p->Ho / 16) * (p->Wo / 16) : 0;
   const int64_t px8 = (int64_t)p->N * (p->Ho / 8) * (p->Wo / 16);
+  if (p->s2d_dgrad) {     // 128-channel tiles only (a channel tile of 4 x Cq outputs never straddles... it may: classes are handled per thread)
+    const int ct2 = ceil_div(p->Cout, 128);
+    if (px16 * ct2 >= 256) return 0;
+    return px8 * ct2 >= 192 ? 1 : -1;
+  }
   if (p->C1 > 0 || p->src0_mode != STP_SRC_DIRECT) {
     // two sources / upsampled source, 64-channel outputs (decoder_stage2_conv1: 128 upsampled + 64 skip -> 64 @ 16 x 128 x 128): 69 us on the
     // 8 x 16 x 64 tiles against 89 us on the per-tap kernel (profiles/r05c_*); STP_HALO2_64=0 sends them back
@@ -684,7 +737,7 @@ extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p) {
   int v = -1;
   if (p->tile >= STP_TILE_HALO && p->tile < STP_TILE_HALO + HALO_NCFG) {
     v = p->tile - STP_TILE_HALO;
-    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && (p->C0 != 64 || p->C1))) return -1;
+    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && (p->C0 != 64 || p->C1)) || (p->s2d_dgrad && v > 1)) return -1;
   } else if (p->tile == 0) {
     v = halo_auto(p);
   }
@@ -698,7 +751,8 @@ extern "C" int stp_conv2d_halo_tiles(const stp_conv_params* p, int variant) {
 }
 
 extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stream) {
-  if (variant < 0 || variant >= HALO_NCFG || !halo_shape_ok(p) || (p->Ho % HALO_CFGS[variant].th) || (variant == 4 && (p->C0 != 64 || p->C1))) return STP_E_BADARG;
+  if (variant < 0 || variant >= HALO_NCFG || !halo_shape_ok(p) || (p->Ho % HALO_CFGS[variant].th) || (variant == 4 && (p->C0 != 64 || p->C1)) ||
+      (p->s2d_dgrad && variant > 1)) return STP_E_BADARG;
   ConvArgs a;
   bool c4;
   int ut;
@@ -707,7 +761,7 @@ extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stre
   if (ut != 1) return STP_E_BADARG;   // 32-bit buffer offsets, 64-channel K-steps
   if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->relu || p->residual)) return STP_E_BADARG;
   if (a.sum2x2 && (!a.bnb.x || (p->Cd0 % HALO_CFGS[variant].bm))) return STP_E_BADARG;
-  const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_halo_tiles(p, variant);
+  const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_halo_tiles(p, variant) * (p->s2d_dgrad ? 4 : 1);   // (s2d: four column blocks per channel)
   hipStream_t s = (hipStream_t)stream;
   switch (variant) {
     case 0: return launch_halo<16, 128, 2, 4>(a, s);   // wave: 64 channels x 4 rows

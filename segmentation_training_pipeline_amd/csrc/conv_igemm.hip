@@ -680,11 +680,22 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
 // Group-level pre-reduction of the statistic columns (conv_common.h: stats_group_finish): the kernels whose epilogue has it are the halo
 // kernel and the buffer-DMA kernel with its row-major epilogue (16-bit storage).  STP_STATS_GROUP=0 switches the feature off (A/B).
 extern "C" int stp_conv2d_stats_group_for(const stp_conv_params* p) {
-  static const bool on = !(getenv("STP_STATS_GROUP") && atoi(getenv("STP_STATS_GROUP")) == 0);
-  if (!on || !p || p->stats_slots) return 0;
+  // OPT-IN (STP_STATS_GROUP=1).  Measured on the headline step, same box (profiles/r05e_stats_group_ab.txt): 40 of the 50 finalize launches
+  // disappear (BatchNormalization launches -118 us in the eager table) but every ROUND of convolution workgroups pays ~2.2 us for the
+  // protocol - a drained store queue before the ticket, the ticket's round trip before the workgroup may end (halo 16 x 16 x 128, one
+  // round: +2.2 us; 16 x 16 x 64, two rounds: +4.3; 8 x 16 x 64 at 128 x 128, four rounds: +12) = +121 us; in the captured graph, where a
+  // finalize launch costs ~3 us rather than the 5 of the eager table, the step is 0.02 (G <= 2) to 0.10 ms (all groups) SLOWER.
+  static const bool on = getenv("STP_STATS_GROUP") && atoi(getenv("STP_STATS_GROUP")) == 1;
+  if (!on || !p || p->stats_slots || p->s2d_dgrad) return 0;
   const int tile = stp_conv2d_tile_for(p);
   if (tile < 0) return 0;
-  if (tile >= STP_TILE_HALO) return stats_group_size(stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO));
+  // STP_STATS_GROUP_MAXG: largest group taken (experiments: the protocol costs every workgroup a drained store queue + one ticket,
+  // which a kernel of several ROUNDS of workgroups pays once per round)
+  static const int maxg = getenv("STP_STATS_GROUP_MAXG") ? atoi(getenv("STP_STATS_GROUP_MAXG")) : 16;
+  if (tile >= STP_TILE_HALO) {
+    const int G = stats_group_size(stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO));
+    return G <= maxg ? G : 0;
+  }
   if (tile >= 64 && tile < 512 && p->dtype == STP_H16) {
     ConvArgs a;
     bool c4;
@@ -692,7 +703,9 @@ extern "C" int stp_conv2d_stats_group_for(const stp_conv_params* p) {
     stp_conv_params q = *p;
     q.stats_group = 0;
     if (fill_args(&q, a, &c4, &ut) != STP_OK || c4 || !epilogue_rm_ok(a)) return 0;
-    return stats_group_size(ceil_div(a.P, tile_pixels(tile)));
+    const int G = stats_group_size(ceil_div(a.P, tile_pixels(tile)));
+    static const bool igemm_on = !(getenv("STP_STATS_GROUP_IGEMM") && atoi(getenv("STP_STATS_GROUP_IGEMM")) == 0);
+    return (igemm_on && G <= maxg) ? G : 0;
   }
   return 0;
 }

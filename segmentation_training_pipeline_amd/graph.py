@@ -102,6 +102,7 @@ class Plan(object):
         self._prep_layers = []
         self._upc_layers = []
         self._upc4_layers = []
+        self._s2d_layers = []
         self._wg_ws_bytes = 0
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
@@ -180,6 +181,7 @@ class Plan(object):
         self._prep_layers = []
         self._upc_layers = []
         self._upc4_layers = []
+        self._s2d_layers = []
         self.tensors = OrderedDict()
         net_fn(self)
         self._fuse_bn_into_consumers()
@@ -205,6 +207,14 @@ class Plan(object):
             if self._wgroup:
                 self._flush_wgroup()
                 self.bwd_marks.append((len(self.bwd), low))
+            if self._s2d_layers:
+                # weights of the space-to-depth data gradients (decided while the tape was replayed): one batched launch per step
+                import struct
+                assert int(self.lib.stp_weight_prepare_s2d_desc_bytes()) == 32
+                tab = b"".join(struct.pack("<QQQii", *lay) for lay in self._s2d_layers)
+                sdev = torch.frombuffer(bytearray(tab), dtype=torch.uint8).to(self.device)
+                self._keep.append(sdev)
+                self._emit(self.prep, "stp_weight_prepare_s2d_batched", sdev.data_ptr(), len(self._s2d_layers), self.cdt)
         self._tape = []
         return self
 
@@ -724,6 +734,7 @@ class Plan(object):
         need_dgrad = self.training and (x_ng or s_ng) and not stem
         wb = self._alloc((rows_b * k * k * CoutB,)) if need_dgrad else None
         out.meta["wb"] = wb
+        out.meta["w_master"] = (self._pptr(w), Cout, Cin_master, k)      # (the space-to-depth data gradient builds its weights from the masters)
         # collected here, issued as ONE batched launch per step (see _finish_prep)
         self._prep_layers.append((self._pptr(w), wf.data_ptr(), wb.data_ptr() if wb is not None else None,
                                   Cout, k, k, Cin_master, KWp, Cinp, CoutB))
@@ -880,7 +891,28 @@ class Plan(object):
                 if stride not in (1, 2):
                     raise StpShapeError("data gradient supports stride 1 and 2")
                 fs = fold_shortcut
-                if (fs is not None and stride == 2 and k == 3 and not transpose and src1 is None and x_ng and fs.needs_grad and fs.grad_ready
+                s2d = False
+                if (stride == 2 and k == 3 and pad == 1 and not transpose and src1 is None and x_ng and self.dtype != "fp32" and not stem
+                        and Cout == CoutB and C0 == Cin_master and (Hv, Wv) == (2 * Ho, 2 * Wo) and os.environ.get("STP_S2D", "1") != "0"):
+                    # SPACE-TO-DEPTH form (round 5, stp_conv_params.s2d_dgrad): the four output parity classes as ONE dense 2 x 2-tap
+                    # convolution of dY into 4 x C0 class-major channels on the halo kernel, stored depth-to-space; the sibling 1x1 /
+                    # stride-2 shortcut's dY rides along as a second source (its weights live at class 0 / tap 0 only)
+                    fold = (fs is not None and fs.needs_grad and fs.grad_ready and fs.meta.get("w_master") is not None and fs.gradC == CoutB
+                            and (fs.H, fs.W) == (Ho, Wo) and fs.meta["w_master"][1:] == (Cout, C0, 1))
+                    ct = 2 * CoutB if fold else CoutB
+                    qs = ops.conv_params(dy, dy, d0, N=self.N, Hs0=Ho, Ws0=Wo, Hv=Ho, Wv=Wo, C0=CoutB, C1=(CoutB if fold else 0),
+                                         src1=(fs.grad if fold else None), mode=ops.SRC_DIRECT, KH=2, KW=2, stride=1, pad=0, Ho=Ho, Wo=Wo,
+                                         Cout=4 * C0, dtype=self.cdt, accumulate0=acc0)
+                    qs.s2d_dgrad = 1
+                    if int(self.lib.stp_conv2d_halo_variant(C.byref(qs))) >= 0:
+                        ws2d = self._alloc((4 * C0 * 4 * ct,))
+                        qs.weight = ws2d.data_ptr()
+                        self._s2d_layers.append((self._pptr(w), fs.meta["w_master"][0] if fold else 0, ws2d.data_ptr(), Cout, C0))
+                        q, s2d = qs, True
+                        if fold:
+                            fs.meta["dgrad_folded"] = True
+                            x.grad_writes += 1          # its share of x's gradient arrives with this launch
+                if (not s2d and fs is not None and stride == 2 and k == 3 and not transpose and src1 is None and x_ng and fs.needs_grad and fs.grad_ready
                         and fs.meta.get("wb") is not None and fs.gradC == CoutB and (fs.H, fs.W) == (Ho, Wo)
                         and int(self.lib.stp_conv2d_fold_ok(C.byref(q)))):
                     # the shortcut's 1x1 / stride-2 data gradient = one more (centre) tap of this launch's (even, even) parity class
@@ -982,7 +1014,7 @@ class Plan(object):
                         if gt is not st:
                             x.meta["bnb"] = (gt, gcols)           # the pre-reduced table ([2][C0][columns / G]) and its column count
                 self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": qflops,
-                                              "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q)))})
+                                              "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q))), "s2d": s2d})
                 if upsample and x_ng and not folded_up:
                     acc_up = int(x.grad_ready)
                     done = (uses == 1 and not acc_up) or (self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and acc_up)
