@@ -150,10 +150,13 @@ typedef struct stp_conv_params {
   /* SPACE-TO-DEPTH data gradient of a 3x3 / stride-2 / pad-1 convolution (+ its sibling 1x1 / stride-2 projection shortcut), round 5.
    * s2d_dgrad = 1 describes ONE dense launch for the four output parity classes: src0 = dY of the 3x3 layer [N,Ho,Wo,C0], src1 = dY of
    * the shortcut [N,Ho,Wo,C1] or NULL, KH = KW = 2, stride 1, pad 0 (tap (da, db) reads (a + da, b + db); past the bottom / right
-   * edge = zero), Cout = 4 x Cq output channels in parity-class-major order, weight = [Cout][2][2][C0 + C1] as built by
-   * stp_weight_prepare_s2d_batched (zero where a class has no tap), dst0 = [N,2Ho,2Wo,Cq]: channel cls * Cq + c of pixel (a, b) is
+   * edge = zero), Cout = 4 x Cq output channels in parity-class-major order (class cls = py * 2 + px), dst0 = [N,2Ho,2Wo,Cq]: channel
+   * cls * Cq + c of pixel (a, b) is
    * stored as channel c of pixel (2a + (cls >> 1), 2b + (cls & 1)).  accumulate0, bnb_x (+ stats_partial = [2][Cq][4 x tiles]: four
-   * column blocks per channel, stp_conv2d_stats_floats counts them) refer to that destination.  Served by the halo kernel only:
+   * column blocks per channel, stp_conv2d_stats_floats counts them) refer to that destination.  NO weight copy of its own: weight = the
+   * 3x3 layer's ordinary data-gradient copy [Cq^16][3][3][C0] (stp_weight_prepare's `bwd`), fold_weight = the shortcut's [Cq^16][C1]
+   * (required when C1 > 0) - the kernel addresses, per output row, the kernel tap its class meets under each of the 2 x 2 taps
+   * (9 of the 16 (tap, class) blocks are live; the dead ones move no bytes and issue no MFMAs).  Served by the halo kernel only:
    * stp_conv2d_halo_variant(p) >= 0 tells. */
   int32_t s2d_dgrad;
 } stp_conv_params;
@@ -178,12 +181,6 @@ int stp_weight_prepare_upcollapse_batched(const void* desc_dev, int32_t nlayers,
  * source): this builds its weights [round_up(C0, 16)][4][4][CoutB] from the master - row taps {2}, {1,2}, {0,1}, {0} of the 3x3
  * kernel summed, columns alike.  desc_dev: nlayers records {const float* master; void* out; int32 Cout, CoutB, C0, C0 + C1}. */
 int stp_weight_prepare_upcollapse_bwd_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream);
-/* Weights of a space-to-depth data gradient (stp_conv_params.s2d_dgrad), several layers in ONE launch: desc_dev = nlayers records
- * {const float* master3 (the 3x3 / stride-2 layer's fp32 master [C0][3][3][Cq]); const float* master_sc (its sibling 1x1 / stride-2
- * shortcut's master [C0][Cq], or NULL); void* out ([4 x Cq][2][2][C0 or 2 x C0], 16-bit); int32 C0, Cq}
- * (stp_weight_prepare_s2d_desc_bytes() = 32 bytes each) in device memory. */
-size_t stp_weight_prepare_s2d_desc_bytes(void);
-int stp_weight_prepare_s2d_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream);
 /* floats needed by stats_partial for this shape (tile choice included) */
 size_t stp_conv2d_stats_floats(const stp_conv_params* p);
 /* tile configuration stp_conv2d would pick for p (see conv_igemm.hip: 1..6 register-staged tiles, 32*STAGES+t

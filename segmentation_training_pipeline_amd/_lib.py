@@ -53,8 +53,6 @@ SIGNATURES = {
     "stp_weight_prepare_upcollapse_desc_bytes": (sz, []),
     "stp_weight_prepare_upcollapse_batched": (i32, [vp, i32, i32, vp]),
     "stp_weight_prepare_upcollapse_bwd_batched": (i32, [vp, i32, i32, vp]),
-    "stp_weight_prepare_s2d_desc_bytes": (sz, []),
-    "stp_weight_prepare_s2d_batched": (i32, [vp, i32, i32, vp]),
     "stp_conv2d_fold_ok": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stats_floats": (sz, [C.POINTER(ConvParams)]),
     "stp_conv2d_stats_group_for": (i32, [C.POINTER(ConvParams)]),

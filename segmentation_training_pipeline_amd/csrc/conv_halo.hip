@@ -331,8 +331,12 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
 // 9 of the 16 (tap, class) blocks are live) whose store is a depth-to-space (epilogue_rm, D2S).  A tap is an LDS offset of the slab, as
 // before; only the prefetch schedule depends on NT: the passes of the next slab must have been issued three K-steps before its first
 // use, i.e. in the taps 0 .. NT - 3 of the current one (PPS passes per K-step).
-template <int TH, int BM, int WM, int WN, int EP, bool PBN, bool SRC2, int NT = 9>
+// FOLD1 (round 5, NT == 9 with a second source): the second source is dY of a SIBLING 1x1 / stride-1 convolution that reads the same tensor
+// (the projection shortcut of a ResNet basic block's first unit): its data gradient is the centre tap of this launch over
+// a.fold_weight = [Cout^16][C1] - the slabs of the second source run one live K-step (tap 4) and eight that keep only their barriers.
+template <int TH, int BM, int WM, int WN, int EP, bool PBN, bool SRC2, int NT = 9, bool FOLD1 = false>
 __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
+  static_assert(!FOLD1 || (SRC2 && NT == 9 && !PBN), "the folded 1x1 sibling is a second source of the 3 x 3 window");
   static_assert(WM * WN == 8 && BM % (WM * 32) == 0 && TH % (WN * 2) == 0, "config");
   static_assert(NT == 9 || NT == 4, "taps per slab");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -379,6 +383,8 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   const int y0 = ty * TH, x0 = tx * TW, cout0 = tile_m * BM;
 
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, a.bytesw, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw2 = __builtin_amdgcn_make_buffer_rsrc((void*)((NT == 4 || FOLD1) && a.fold_weight ? a.fold_weight : a.weight), 0,
+                                                                         (NT == 4 || FOLD1) && a.fold_weight ? a.bytesw_fold : a.bytesw, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(SRC2 && a.src1 ? a.src1 : a.src0), 0, SRC2 && a.src1 ? a.bytes1 : a.bytes0, 0x00020000);
 
@@ -406,15 +412,63 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
 #pragma unroll
   for (int i = 0; i < LW; ++i)
     woff[i] = ((uint32_t)(cout0 + i * 64 + prow) * (uint32_t)a.K + (uint32_t)((pslot ^ ((prow >> 1) & 7)) * 8)) * 2u;
+  // NT == 4 (space-to-depth data gradient): NO weight copy of its own - row r = cls * Cq + ci of the dense 2 x 2-tap matrix is row ci of the
+  // 3x3 layer's ordinary data-gradient copy a.weight = [Cq^16][3][3][C0] (bwd[ci][kh'][kw'][co] = W[co][2 - kh'][2 - kw'][ci]) at the kernel
+  // tap that class (py, px) meets under tap (da, db): kh = (py, da): (0,0) 1, (0,1) none, (1,0) 2, (1,1) 0; kw alike - or nothing: an
+  // out-of-range offset, the LDS-DMA then writes zeros and moves no bytes.  The slabs of the second source (the sibling 1x1 / stride-2
+  // shortcut's dY) take a.fold_weight = [Cq^16][C1], live for class 0 / tap 0 only.
+  uint32_t wtap[NT == 4 ? LW : 1][4], wsc[(NT == 4 || FOLD1) ? LW : 1];
+  unsigned live_main = 0xfu, live_sc = 0x1u;      // taps with live weights for THIS WAVE's channels (dead K-steps skip their MFMAs)
+  if constexpr (FOLD1) {
+    live_main = 0x1ffu; live_sc = 0x10u;          // nine taps of the 3 x 3 layer; the centre tap of the folded 1x1 sibling
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      const int r = cout0 + i * 64 + prow;
+      wsc[i] = r < a.Cout ? ((uint32_t)r * (uint32_t)a.C1 + (uint32_t)((pslot ^ ((prow >> 1) & 7)) * 8)) * 2u : STP_OOB;
+    }
+  }
+  if constexpr (NT == 4) {
+    const int Cq = a.Cout >> 2;
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      const int r = cout0 + i * 64 + prow, cls = r / Cq, ci = r - cls * Cq;
+      const uint32_t slot = (uint32_t)((pslot ^ ((prow >> 1) & 7)) * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int da = t >> 1, db = t & 1;
+        const int kh = (cls >> 1) == 0 ? (da == 0 ? 1 : -1) : (da == 0 ? 2 : 0), kw = (cls & 1) == 0 ? (db == 0 ? 1 : -1) : (db == 0 ? 2 : 0);
+        wtap[i][t] = (r < a.Cout && kh >= 0 && kw >= 0) ? ((uint32_t)((ci * 3 + (2 - kh)) * 3 + (2 - kw)) * (uint32_t)a.C0 + slot) * 2u : STP_OOB;
+      }
+      wsc[i] = (r < a.Cout && cls == 0 && a.C1) ? ((uint32_t)ci * (uint32_t)a.C1 + slot) * 2u : STP_OOB;
+    }
+    if (CW <= Cq && (Cq % CW) == 0) {             // the wave's channels lie in one class
+      const int wc = (cout0 + wm * CW) / Cq;
+      live_main = wc == 0 ? 0x1u : wc == 1 ? 0x3u : wc == 2 ? 0x5u : 0xfu;
+      live_sc = wc == 0 ? 0x1u : 0x0u;
+    }
+  }
 
   const int nslab = (SRC2 ? a.Ctot : a.C0) >> 6, nslab0 = a.C0 >> 6;
   const int off_w = (nslab > 1 ? 2 : 1) * SLAB;   // one slab buffer is enough for a 64-channel input: two workgroups share a CU
-  const uint32_t tapb = (uint32_t)(SRC2 ? a.Ctot : a.C0) * 2u;     // bytes between the weight columns of consecutive taps
+  const uint32_t tapb = (uint32_t)((SRC2 && !FOLD1) ? a.Ctot : a.C0) * 2u;     // bytes between the weight columns of consecutive taps
 
   // piece i of the weights of K-step (slab s, tap t) -> ring stage st; the column offset travels in the scalar soffset
   auto issue_weight_piece = [&](int i, int st, int s, int t) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + off_w + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
-                                             woff[i], (uint32_t)t * tapb + (uint32_t)s * 128u, 0, 0);
+    if constexpr (NT == 4) {
+      if (s >= nslab0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)(smem + off_w + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
+                                                 t == 0 ? wsc[i] : STP_OOB, (uint32_t)(s - nslab0) * 128u, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + off_w + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
+                                                 wtap[i][t], (uint32_t)s * 128u, 0, 0);
+    } else {
+      if (FOLD1 && s >= nslab0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (__attribute__((address_space(3))) void*)(smem + off_w + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
+                                                 t == 4 ? wsc[i] : STP_OOB, (uint32_t)(s - nslab0) * 128u, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + off_w + st * WSTAGE + (i * 64 + wave * 8) * 128), 16,
+                                                 woff[i], (uint32_t)t * tapb + (uint32_t)s * 128u, 0, 0);
+    }
   };
   // pass p (compile-time) of slab s.  A wave whose 8 rows lie past the slab issues nothing: pass_on() enters the vmcnt counts
   auto pass_on = [&](int p) { return (p * 64 + wave * 8) < SROWS; };   // wave-uniform
@@ -519,7 +573,9 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
         const int dy = NT == 9 ? t / 3 : 1 + t / 2, dx = NT == 9 ? t - (t / 3) * 3 : 1 + (t & 1);             // compile-time after unrolling
         // ---------------- MEM(k)
         if (fuse_bn && t == NT - 1 && !last) transform_slab(s + 1);   // its passes landed (own pieces) before MEM(9s+7) ended
-        {
+        // NT == 4: a K-step whose weights are all zero for this wave's channels keeps its barriers and its LDS-DMA issue, nothing else
+        const bool live = (NT != 4 && !FOLD1) || (((s < nslab0 ? live_main : live_sc) >> t) & 1u);      // (wave-uniform)
+        if (live) {
           const uint32_t so = (uint32_t)(wst * WSTAGE);
 #pragma unroll
           for (int kc = 0; kc < 4; ++kc) {
@@ -553,6 +609,16 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
           const int t3 = t + 3 < NT ? t + 3 : t + 3 - NT, s3 = t + 3 < NT ? s : s + 1;
           const bool wlive = !(last && t + 3 >= NT);
           int piece = 0;
+          if (!live) {
+#pragma unroll
+            for (int pz = 0; pz < LW + PPS; ++pz) {
+              if (pz < LW) {
+                if (wlive) issue_weight_piece(pz, st3, s3, t3);
+              } else if (t < NPT && t * PPS + (pz - LW) < NPASS) {
+                if (!last) issue_slab_pass(s + 1, t * PPS + (pz - LW));
+              }
+            }
+          } else
 #pragma unroll
           for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
@@ -608,6 +674,9 @@ __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_pbn_ker
 // two sources / upsampled first source (forward only: EP 0 / 1)
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo2_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true>(a); }
+// data gradient of a 3x3 / stride-1 layer with its sibling 1x1 / stride-1 shortcut folded in as a second source (EP 0 / 2)
+template <int TH, int BM, int WM, int WN, int EP>
+__global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_fold1_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true, 9, true>(a); }
 // space-to-depth data gradient of a stride-2 convolution: 2 x 2 taps, one or two sources, depth-to-space store (EP 0 / 2)
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_s2d_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true, 4>(a); }
@@ -631,18 +700,24 @@ static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
   static bool attr_set_pbn = false, attr_set_src2 = false;
   const bool pbn = a.pbn.mean != nullptr;
-  static bool attr_set_s2d = false;
+  static bool attr_set_s2d = false, attr_set_fold1 = false;
+  const bool fold1 = !a.d2s && a.fold_weight != nullptr;      // (set by stp_conv2d_halo: fold_src / fold_weight / fold_C on a stride-1 launch)
   if (a.d2s) {
     if (pbn || BM != 128 || (EP != 0 && EP != 2)) return STP_E_BADARG;
+  } else if (fold1) {
+    if (pbn || (EP != 0 && EP != 2)) return STP_E_BADARG;
   } else if (src2 && (pbn || EP > 1)) return STP_E_BADARG;
   auto kern = pbn ? conv_halo_pbn_kernel<TH, BM, WM, WN, EP> : conv_halo_kernel<TH, BM, WM, WN, EP>;
   if constexpr (EP <= 1) {
-    if (src2 && !a.d2s) kern = conv_halo2_kernel<TH, BM, WM, WN, EP>;
+    if (src2 && !a.d2s && !fold1) kern = conv_halo2_kernel<TH, BM, WM, WN, EP>;
+  }
+  if constexpr (EP == 0 || EP == 2) {
+    if (fold1) kern = conv_halo_fold1_kernel<TH, BM, WM, WN, EP>;
   }
   if constexpr (BM == 128 && (EP == 0 || EP == 2)) {
     if (a.d2s) kern = conv_halo_s2d_kernel<TH, BM, WM, WN, EP>;
   }
-  bool& done = a.d2s ? attr_set_s2d : src2 ? attr_set_src2 : pbn ? attr_set_pbn : attr_set;
+  bool& done = a.d2s ? attr_set_s2d : fold1 ? attr_set_fold1 : src2 ? attr_set_src2 : pbn ? attr_set_pbn : attr_set;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return STP_E_LAUNCH;
@@ -679,11 +754,19 @@ static bool halo_s2d_ok(const stp_conv_params* p) {
   static const bool on = !(getenv("STP_S2D") && atoi(getenv("STP_S2D")) == 0);
   return on && p && p->s2d_dgrad && p->dtype == STP_H16 && p->KH == 2 && p->KW == 2 && p->stride == 1 && p->pad == 0 && p->src0_mode == STP_SRC_DIRECT &&
          p->Hs0 == p->Hv && p->Ws0 == p->Wv && p->Ho == p->Hv && p->Wo == p->Wv && (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && p->C0 >= 64 &&
-         (p->C0 % 64) == 0 && (p->C1 == 0 || (p->src1 && (p->C1 % 64) == 0)) && (p->Cout % 128) == 0 && p->Cd0 == p->Cout && !p->dst1 &&
+         (p->C0 % 64) == 0 && (p->C1 == 0 || (p->src1 && p->fold_weight && (p->C1 % 64) == 0)) && (p->Cout % 128) == 0 && p->Cd0 == p->Cout && !p->dst1 &&
          !p->dst_sum2x2 && !p->stats_slots && !p->src_bn_mean && !p->bias && !p->relu && !p->residual && !p->accumulate1;
+}
+// fold_src / fold_weight / fold_C on a 3x3 / stride-1 / pad-1 launch: the dY of a sibling 1x1 / stride-1 convolution over the same input
+// (STP_FOLD1=0 refuses it)
+static bool halo_fold1_ok(const stp_conv_params* p) {
+  static const bool on = !(getenv("STP_FOLD1") && atoi(getenv("STP_FOLD1")) == 0);
+  return on && p->fold_src && p->fold_weight && p->fold_C >= 64 && (p->fold_C % 64) == 0 && p->C1 == 0 && p->src0_mode == STP_SRC_DIRECT &&
+         !p->src_bn_mean && !p->dst_sum2x2 && !p->dst1 && p->Cd0 == p->Cout && !p->bias && !p->relu && !p->residual;
 }
 static bool halo_shape_ok(const stp_conv_params* p) {
   if (p && p->s2d_dgrad) return halo_s2d_ok(p);
+  if (p && p->fold_src && !halo_fold1_ok(p)) return false;
   return p && p->dtype == STP_H16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && halo_src_ok(p) &&
          p->C0 >= 64 && (p->C0 % 64) == 0 && p->Ho == p->Hv && p->Wo == p->Wv &&
          (p->Wo % 16) == 0 && (p->Ho % 8) == 0 && (p->Cout % 16) == 0 && p->Cout >= 64 && !p->stats_slots &&
@@ -716,6 +799,10 @@ static int halo_auto(const stp_conv_params* p) {
     // 8 x 16 x 64 tiles against 89 us on the per-tap kernel (profiles/r05c_*); STP_HALO2_64=0 sends them back
     static const bool c64 = !(getenv("STP_HALO2_64") && atoi(getenv("STP_HALO2_64")) == 0);
     if (p->Cout <= 64 && !c64) return -1;
+  }
+  if (p->fold_src && p->C0 == 64) {
+    // a folded 1x1 sibling is a second slab: the 16 x 16 tiles would lose their second workgroup per CU (116 KB) - 8 x 16 x 64 keeps it (79 KB)
+    return px8 * ceil_div(p->Cout, 64) >= 512 ? 3 : -1;
   }
   if (p->C0 == 64 && p->C1 == 0) {   // one slab, nine K-steps: the 64-channel tiles keep one slab + the ring under 80 KB, two workgroups per CU
     // several channel tiles over the same pixels (a data gradient into concatenated sources: 64 -> 192): 32 x 16 pixel tiles halve
@@ -761,6 +848,21 @@ extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stre
   if (ut != 1) return STP_E_BADARG;   // 32-bit buffer offsets, 64-channel K-steps
   if (a.bnb.x && (!a.stats || !a.bnb.mean || !a.bnb.rstd || p->relu || p->residual)) return STP_E_BADARG;
   if (a.sum2x2 && (!a.bnb.x || (p->Cd0 % HALO_CFGS[variant].bm))) return STP_E_BADARG;
+  if (!p->s2d_dgrad && p->fold_src) {      // stride-1 sibling 1x1 folded in: its dY is the second source, its weights ride in fold_weight
+    if (!halo_fold1_ok(p)) return STP_E_BADARG;
+    const int64_t bf = (int64_t)p->N * p->Hv * p->Wv * p->fold_C * 2, bwf = (int64_t)round_up(p->Cout, 16) * p->fold_C * 2;
+    if (bf >= (1ll << 31) || bwf >= (1ll << 31)) return STP_E_BADARG;
+    a.src1 = (const char*)p->fold_src; a.C1 = p->fold_C; a.Ctot = a.C0 + a.C1; a.bytes1 = (uint32_t)bf;
+    a.fold_weight = (const char*)p->fold_weight; a.bytesw_fold = (uint32_t)bwf;
+    // (a.K stays 9 x C0: the row pitch of the 3 x 3 layer's own weight copy)
+  }
+  if (p->s2d_dgrad) {      // weights: the ordinary data-gradient copies of the 3x3 layer (and of the shortcut), addressed per parity class
+    const int64_t rows = round_up(p->Cout / 4, 16), bw = rows * 9 * p->C0 * 2, bf = rows * (int64_t)p->C1 * 2;
+    if (bw >= (1ll << 31) || bf >= (1ll << 31) || (p->C1 > 0 && !p->fold_weight)) return STP_E_BADARG;
+    a.bytesw = (uint32_t)bw;
+    a.fold_weight = p->C1 > 0 ? (const char*)p->fold_weight : nullptr;
+    a.bytesw_fold = (uint32_t)bf;
+  }
   const_cast<stp_conv_params*>(p)->stats_tiles = stp_conv2d_halo_tiles(p, variant) * (p->s2d_dgrad ? 4 : 1);   // (s2d: four column blocks per channel)
   hipStream_t s = (hipStream_t)stream;
   switch (variant) {

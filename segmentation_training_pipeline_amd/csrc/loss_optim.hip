@@ -1312,50 +1312,6 @@ extern "C" int stp_weight_prepare_upcollapse_bwd_batched(const void* desc_dev, i
   return STP_OK;
 }
 
-// Weights of the SPACE-TO-DEPTH data gradient of a 3x3 / stride-2 / pad-1 convolution (stp_conv_params.s2d_dgrad) and its sibling 1x1 /
-// stride-2 shortcut: out[row = cls * Cq + ci][tap t = da * 2 + db][k], k < C0 + C1.  Class cls = py * 2 + px is the parity of the gradient
-// pixel (2a + py, 2b + px); tap (da, db) reads dY at (a + da, b + db).  Kernel row of (py, da): (0, 0) -> 1, (0, 1) -> none,
-// (1, 0) -> 2, (1, 1) -> 0 (2Y + kh - 1 = y); columns alike.  k < C0: master3[k][kh][kw][ci] of the 3x3 layer (OHWI, C0 = its output
-// channels) or zero; k >= C0: the shortcut's master_sc[k - C0][ci], live for class 0 / tap 0 only.  Plain copies: one rounding.
-struct S2dDesc {            // 32 bytes: three pointers + two int32
-  const float* master3;
-  const float* master_sc;   // NULL: no shortcut (C1 = 0)
-  void* out;
-  int32_t C0, Cq;           // C1 = C0 when master_sc != NULL
-};
-template <typename T>
-__global__ __launch_bounds__(256) void weight_s2d_batched_kernel(const S2dDesc* __restrict__ desc) {
-  const S2dDesc d = desc[blockIdx.y];
-  const int Ct = d.master_sc ? 2 * d.C0 : d.C0;
-  T* out = reinterpret_cast<T*>(d.out);
-  const int64_t n = (int64_t)4 * d.Cq * 4 * Ct;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int k = (int)(i % Ct);
-    const int t = (int)((i / Ct) & 3);
-    const int row = (int)(i / ((int64_t)4 * Ct));
-    const int cls = row / d.Cq, ci = row - cls * d.Cq;
-    const int py = cls >> 1, px = cls & 1, da = t >> 1, db = t & 1;
-    const int kh = py == 0 ? (da == 0 ? 1 : -1) : (da == 0 ? 2 : 0), kw = px == 0 ? (db == 0 ? 1 : -1) : (db == 0 ? 2 : 0);
-    float v = 0.f;
-    if (k < d.C0) {
-      if (kh >= 0 && kw >= 0) v = d.master3[(((int64_t)k * 3 + kh) * 3 + kw) * d.Cq + ci];
-    } else if (cls == 0 && t == 0) {
-      v = d.master_sc[(int64_t)(k - d.C0) * d.Cq + ci];
-    }
-    Elem<T>::store(out + i, v);
-  }
-}
-extern "C" size_t stp_weight_prepare_s2d_desc_bytes(void) { return sizeof(S2dDesc); }
-// desc_dev: nlayers records {const float* master3 [C0][3][3][Cq]; const float* master_sc [C0][Cq] or NULL; void* out; int32 C0, Cq} on the device
-extern "C" int stp_weight_prepare_s2d_batched(const void* desc_dev, int32_t nlayers, int32_t dtype, void* stream) {
-  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
-  if (!desc_dev || nlayers <= 0 || dtype != STP_H16) return STP_E_BADARG;
-  const dim3 grid(512, nlayers);
-  hipLaunchKernelGGL(weight_s2d_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const S2dDesc*)desc_dev);
-  STP_LAUNCH_CHECK();
-  return STP_OK;
-}
-
 // padded gradient [CoutP][KH][KWp][Cinp] -> master layout [Cout][KH][KW][Cin]
 __global__ void weight_grad_unpad_kernel(const float* __restrict__ padded, float* __restrict__ grad, int Cout, int KH, int KW,
                                          int Cin, int KWp, int Cinp, int accumulate) {

@@ -102,7 +102,6 @@ class Plan(object):
         self._prep_layers = []
         self._upc_layers = []
         self._upc4_layers = []
-        self._s2d_layers = []
         self._wg_ws_bytes = 0
         self._bn_ws_c = 4
         self.bn_momentum = 0.99
@@ -181,7 +180,6 @@ class Plan(object):
         self._prep_layers = []
         self._upc_layers = []
         self._upc4_layers = []
-        self._s2d_layers = []
         self.tensors = OrderedDict()
         net_fn(self)
         self._fuse_bn_into_consumers()
@@ -207,14 +205,6 @@ class Plan(object):
             if self._wgroup:
                 self._flush_wgroup()
                 self.bwd_marks.append((len(self.bwd), low))
-            if self._s2d_layers:
-                # weights of the space-to-depth data gradients (decided while the tape was replayed): one batched launch per step
-                import struct
-                assert int(self.lib.stp_weight_prepare_s2d_desc_bytes()) == 32
-                tab = b"".join(struct.pack("<QQQii", *lay) for lay in self._s2d_layers)
-                sdev = torch.frombuffer(bytearray(tab), dtype=torch.uint8).to(self.device)
-                self._keep.append(sdev)
-                self._emit(self.prep, "stp_weight_prepare_s2d_batched", sdev.data_ptr(), len(self._s2d_layers), self.cdt)
         self._tape = []
         return self
 
@@ -897,17 +887,16 @@ class Plan(object):
                     # SPACE-TO-DEPTH form (round 5, stp_conv_params.s2d_dgrad): the four output parity classes as ONE dense 2 x 2-tap
                     # convolution of dY into 4 x C0 class-major channels on the halo kernel, stored depth-to-space; the sibling 1x1 /
                     # stride-2 shortcut's dY rides along as a second source (its weights live at class 0 / tap 0 only)
-                    fold = (fs is not None and fs.needs_grad and fs.grad_ready and fs.meta.get("w_master") is not None and fs.gradC == CoutB
-                            and (fs.H, fs.W) == (Ho, Wo) and fs.meta["w_master"][1:] == (Cout, C0, 1))
-                    ct = 2 * CoutB if fold else CoutB
+                    fold = (fs is not None and fs.needs_grad and fs.grad_ready and fs.meta.get("wb") is not None and fs.gradC == CoutB
+                            and (fs.H, fs.W) == (Ho, Wo) and fs.meta.get("w_master", (0, 0, 0, 0))[1:] == (Cout, C0, 1))
                     qs = ops.conv_params(dy, dy, d0, N=self.N, Hs0=Ho, Ws0=Wo, Hv=Ho, Wv=Wo, C0=CoutB, C1=(CoutB if fold else 0),
                                          src1=(fs.grad if fold else None), mode=ops.SRC_DIRECT, KH=2, KW=2, stride=1, pad=0, Ho=Ho, Wo=Wo,
                                          Cout=4 * C0, dtype=self.cdt, accumulate0=acc0)
                     qs.s2d_dgrad = 1
+                    qs.weight = wb.data_ptr()                   # the ordinary data-gradient copies: the kernel addresses them per parity class
+                    if fold:
+                        qs.fold_weight = fs.meta["wb"].data_ptr()
                     if int(self.lib.stp_conv2d_halo_variant(C.byref(qs))) >= 0:
-                        ws2d = self._alloc((4 * C0 * 4 * ct,))
-                        qs.weight = ws2d.data_ptr()
-                        self._s2d_layers.append((self._pptr(w), fs.meta["w_master"][0] if fold else 0, ws2d.data_ptr(), Cout, C0))
                         q, s2d = qs, True
                         if fold:
                             fs.meta["dgrad_folded"] = True
@@ -919,6 +908,20 @@ class Plan(object):
                     q.fold_src, q.fold_weight, q.fold_C = fs.grad.data_ptr(), fs.meta["wb"].data_ptr(), CoutB
                     fs.meta["dgrad_folded"] = True
                     x.grad_writes += 1          # its share of x's gradient arrives with this launch
+                folded1 = False
+                if (fs is not None and stride == 1 and k == 3 and pad == 1 and not transpose and not upsample and src1 is None and x_ng
+                        and fs.needs_grad and fs.grad_ready and fs.meta.get("wb") is not None and (fs.H, fs.W) == (Ho, Wo)
+                        and fs.meta.get("w_master", (0, 0, 0, 0))[2:] == (C0, 1) and self.dtype != "fp32"):
+                    # the sibling 1x1 / stride-1 shortcut (first unit of ResNet18 / 34's stage 1): its dY is a second source of this launch
+                    # whose centre tap carries the shortcut's weights (conv_halo.hip, FOLD1) - no separate launch accumulates into dX
+                    q.fold_src, q.fold_weight, q.fold_C = fs.grad.data_ptr(), fs.meta["wb"].data_ptr(), fs.gradC
+                    if int(self.lib.stp_conv2d_halo_variant(C.byref(q))) >= 0:
+                        folded1 = True
+                        fs.meta["dgrad_folded"] = True
+                        x.grad_writes += 1          # its share of x's gradient arrives with this launch
+                    else:
+                        q.fold_src = q.fold_weight = None
+                        q.fold_C = 0
                 bnm = x.meta.get("bn")
                 folded_up = False
                 qC1 = C1
@@ -996,6 +999,8 @@ class Plan(object):
                 # share, this data gradient accumulates on top): its epilogue sees the complete gradient of the BN output
                 sole = uses == 1 and not q.accumulate0
                 last = self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and q.accumulate0 and not upsample
+                if (folded1 or s2d) and uses == 2 and x.grad_writes == 1 and not q.accumulate0:
+                    sole = True       # this launch and the sibling folded into it are the only two consumers: the gradient is complete
                 if (self.fuse_bn_backward and bnm is not None and (sole or last) and (folded_up or not upsample) and (qC1 == 0 or two_dest)
                         and x_ng and C0 % 4 == 0):
                     q.bnb_x, q.bnb_mean, q.bnb_rstd, q.bnb_gamma, q.bnb_beta, q.bnb_relu = bnm
@@ -1014,7 +1019,7 @@ class Plan(object):
                         if gt is not st:
                             x.meta["bnb"] = (gt, gcols)           # the pre-reduced table ([2][C0][columns / G]) and its column count
                 self._emit_conv(self.bwd, q, {"layer": name, "pass": "dgrad", "flops": qflops,
-                                              "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q))), "s2d": s2d})
+                                              "tile": int(self.lib.stp_conv2d_tile_for(C.byref(q))), "s2d": s2d, "fold1": folded1})
                 if upsample and x_ng and not folded_up:
                     acc_up = int(x.grad_ready)
                     done = (uses == 1 and not acc_up) or (self.fuse_bn_backward_last and uses > 1 and x.grad_writes == uses - 1 and acc_up)

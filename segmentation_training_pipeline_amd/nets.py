@@ -55,8 +55,9 @@ def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
             else:
                 shortcut = x
             if ex == 1:
-                # (a stride-2 projection shortcut reads the same tensor: its data gradient rides in conv1's launch)
-                y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1, bn_stats=True, fold_shortcut=shortcut if (u == 1 and stride == 2) else None)
+                # (a projection shortcut reads the same tensor: its data gradient rides in conv1's launch - stride 2: parity-class / space-to-
+                #  depth form; stride 1, the first unit of stage 1: the centre tap of a second source on the halo kernel)
+                y = plan.conv(pre + "conv1", a, f, 3, stride=stride, pad=1, bn_stats=True, fold_shortcut=shortcut if u == 1 else None)
                 y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
                 x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut, bn_stats=True)
             else:

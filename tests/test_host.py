@@ -473,8 +473,11 @@ def test_weight_gradient_groups_of_the_headline_workload():
                    (128, 7, "stage2_unit4_conv2", "stage2_unit1_conv2"), (64, 6, "stage1_unit3_conv2", "stage1_unit1_conv1")]
     bnames = [n for _, _, n, _ in plan.bwd]
     assert bnames.count("stp_conv2d_wgrad") == 12 and bnames.count("stp_wgrad_group_partial") == 6
-    assert sorted(n for n, t in plan.tensors.items() if t.meta.get("dgrad_folded")) == ["stage2_unit1_sc", "stage3_unit1_sc", "stage4_unit1_sc"]
-    assert bnames.count("stp_conv2d") == 47 - 3
+    # every projection shortcut's data gradient rides in its sibling's launch (stride 2: space-to-depth form; stage 1: a second source)
+    assert sorted(n for n, t in plan.tensors.items() if t.meta.get("dgrad_folded")) == ["stage1_unit1_sc", "stage2_unit1_sc", "stage3_unit1_sc", "stage4_unit1_sc"]
+    dg = {m["layer"]: m for _, _, n, m in plan.bwd if m and m.get("pass") == "dgrad"}
+    assert all(dg["stage%d_unit1_conv1" % k]["s2d"] for k in (2, 3, 4)) and dg["stage1_unit1_conv1"]["fold1"] and "stage1_unit1_sc" not in dg
+    assert bnames.count("stp_conv2d") == 47 - 4
     assert bnames.count("stp_bn_backward_fused_add") == 12 and "stp_add_inplace" not in bnames      # 12 non-first units
     assert plan.bwd_monotone
     lows = [low for _, low in plan.bwd_marks]

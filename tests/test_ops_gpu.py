@@ -331,22 +331,6 @@ def test_stride2_data_gradient_in_parity_class_order(ops, geom, mode, dtype):
     np.testing.assert_allclose(part[1], (gs * xhat).reshape(-1, ci).sum(0), atol=2e-4 * np.abs(gs * xhat).sum(axis=(0, 1, 2)).max() + 1e-3)
 
 
-def _s2d_weights(ops, w3, wsc, dtype):
-    """stp_weight_prepare_s2d_batched for one layer: w3 HWIO [3,3,cq,c0] (+ wsc [cq,c0] of the 1x1 / stride-2 shortcut) -> device copy."""
-    import struct
-    from segmentation_training_pipeline_amd import _lib
-    cq, c0 = w3.shape[2], w3.shape[3]
-    m3 = keep(torch.from_numpy(np.ascontiguousarray(w3.transpose(3, 0, 1, 2), dtype=np.float32)).to(DEV))           # OHWI master
-    msc = keep(torch.from_numpy(np.ascontiguousarray(wsc.T, dtype=np.float32)).to(DEV)) if wsc is not None else None  # [c0][cq]
-    ct = 2 * c0 if wsc is not None else c0
-    out = torch.full((4 * cq * 4 * ct,), float("nan"), dtype=TD[dtype], device=DEV)
-    assert int(_lib.load().stp_weight_prepare_s2d_desc_bytes()) == 32
-    tab = struct.pack("<QQQii", ops.ptr(m3), ops.ptr(msc) if msc is not None else 0, ops.ptr(out), c0, cq)
-    dd = keep(torch.frombuffer(bytearray(tab), dtype=torch.uint8).to(DEV))
-    _lib.call("stp_weight_prepare_s2d_batched", ops.ptr(dd), 1, ops.dt(out), ops.stream())
-    return keep(out)
-
-
 @pytest.mark.parametrize("geom", [(2, 32, 32, 128, 64, 0), (1, 16, 64, 128, 128, 1), (2, 32, 64, 64, 32, 1), (1, 64, 32, 256, 64, 0), (3, 16, 32, 64, 256, 1)])
 @pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
 @pytest.mark.parametrize("shortcut", [False, True])
@@ -355,7 +339,7 @@ def test_stride2_data_gradient_space_to_depth(ops, geom, mode, shortcut, dtype):
     """stp_conv_params.s2d_dgrad (round 5): the data gradient of a 3x3 / stride-2 / pad-1 convolution as ONE dense 2 x 2-tap convolution
     of dY into the four parity classes on the halo kernel (conv_halo_s2d_kernel), stored depth-to-space, with the sibling 1x1 / stride-2
     shortcut's dY as a second source.  Against the numpy data gradients; accumulate; the fused BatchNormalization-backward epilogue
-    (masked store at the REAL pixel + the sums as four column blocks per channel); weights from stp_weight_prepare_s2d_batched."""
+    (masked store at the REAL pixel + the sums as four column blocks per channel); the weights are the layers' ordinary data-gradient copies."""
     from segmentation_training_pipeline_amd import _lib
     n, ho, wo, co, ci, var = geom               # co = channels of dY, ci = channels of the gradient
     h, w = 2 * ho, 2 * wo
@@ -367,13 +351,16 @@ def test_stride2_data_gradient_space_to_depth(ops, geom, mode, shortcut, dtype):
     ref = np_ops.conv2d_dgrad(dy, w3, (h, w), 2, 1)
     if shortcut:
         ref = ref + np_ops.conv2d_dgrad(dysc, wsc.reshape(1, 1, ci, co), (h, w), 2, 0)
-    wd = _s2d_weights(ops, w3, wsc, dtype)
+    _, _, wd, _ = prep_weights(ops, w3, dtype)                                   # the ordinary data-gradient copies [ci][3][3][co] ...
+    wsd = prep_weights(ops, wsc.reshape(1, 1, ci, co), dtype)[2] if shortcut else None      # ... and [ci][co] of the shortcut
     prev = q(rng.randn(n, h, w, ci), dtype)
     dx = dev(prev, dtype) if mode != "plain" else torch.full((n, h, w, ci), float("nan"), dtype=TD[dtype], device=DEV)
     P = ops.conv_params(dev(dy, dtype), wd, dx, N=n, Hs0=ho, Ws0=wo, Hv=ho, Wv=wo, C0=co, C1=(co if shortcut else 0),
                         src1=(dev(dysc, dtype) if shortcut else None), mode=ops.SRC_DIRECT, KH=2, KW=2, stride=1, pad=0, Ho=ho, Wo=wo,
                         Cout=4 * ci, dtype=ops.dt(dx), accumulate0=int(mode != "plain"), tile=1024 + var)
     P.s2d_dgrad = 1
+    if shortcut:
+        P.fold_weight = ops.ptr(wsd)
     assert _lib.load().stp_conv2d_tile_for(ops.C.byref(P)) == 1024 + var
     want = ref + (prev if mode != "plain" else 0.0)
     if mode != "bn_backward":
@@ -394,6 +381,56 @@ def test_stride2_data_gradient_space_to_depth(ops, geom, mode, shortcut, dtype):
     ops.conv2d(P)
     cols = ops.conv2d_stats_floats(P) // (2 * ci)
     assert cols == P.stats_tiles == 4 * n * (ho // (16 if var == 0 else 8)) * (wo // 16)
+    pre = host(xd) * (host(r) * gamma) + (beta - host(m) * host(r) * gamma)
+    safe = np.abs(pre) > 1e-3
+    gm = want * (pre > 0)
+    np.testing.assert_allclose(host(dx)[safe], gm[safe], atol=tol(want, dtype))
+    part = host(st).reshape(2, ci, cols).sum(axis=2)
+    gs = host(dx).astype(np.float64)
+    xhat = (host(xd).astype(np.float64) - host(m)) * host(r)
+    np.testing.assert_allclose(part[0], gs.reshape(-1, ci).sum(0), atol=2e-4 * np.abs(gs).sum(axis=(0, 1, 2)).max() + 1e-3)
+    np.testing.assert_allclose(part[1], (gs * xhat).reshape(-1, ci).sum(0), atol=2e-4 * np.abs(gs * xhat).sum(axis=(0, 1, 2)).max() + 1e-3)
+
+
+@pytest.mark.parametrize("geom", [(2, 32, 32, 64, 64, 3), (1, 16, 32, 128, 128, 0), (2, 16, 16, 64, 128, 1), (1, 32, 16, 128, 64, 2)])
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "bn_backward"])
+@pytest.mark.parametrize("dtype", H16)
+def test_stride1_data_gradient_with_folded_shortcut(ops, geom, mode, dtype):
+    """fold_src / fold_weight / fold_C on a 3x3 / stride-1 data gradient (conv_halo_fold1_kernel, round 5): the dY of the sibling 1x1 /
+    stride-1 shortcut is a second source whose centre tap carries the shortcut's data-gradient weights - one launch produces
+    dgrad3x3(dY) + dgrad1x1(dY_sc), with accumulate and the fused BatchNormalization-backward epilogue; against numpy."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, co, ci, var = geom               # co = channels of both dYs, ci = channels of the gradient
+    rng = np.random.RandomState(hash(geom) % 2**31)
+    w3 = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * co), dtype)
+    wsc = q(rng.randn(1, 1, ci, co) / np.sqrt(co), dtype)
+    dy, dysc = q(rng.randn(n, h, w, co), dtype), q(rng.randn(n, h, w, co), dtype)
+    ref = np_ops.conv2d_dgrad(dy, w3, (h, w), 1, 1) + np_ops.conv2d_dgrad(dysc, wsc, (h, w), 1, 0)
+    wd, wsd = prep_weights(ops, w3, dtype)[2], prep_weights(ops, wsc, dtype)[2]
+    prev = q(rng.randn(n, h, w, ci), dtype)
+    dx = dev(prev, dtype) if mode != "plain" else torch.full((n, h, w, ci), float("nan"), dtype=TD[dtype], device=DEV)
+    P = ops.conv_params(dev(dy, dtype), wd, dx, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=co, mode=ops.SRC_DIRECT, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w,
+                        Cout=ci, dtype=ops.dt(dx), accumulate0=int(mode != "plain"), tile=1024 + var)
+    P.fold_src, P.fold_weight, P.fold_C = ops.ptr(dev(dysc, dtype)), ops.ptr(wsd), co
+    assert _lib.load().stp_conv2d_tile_for(ops.C.byref(P)) == 1024 + var
+    want = ref + (prev if mode != "plain" else 0.0)
+    if mode != "bn_backward":
+        ops.conv2d(P)
+        np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype))
+        return
+    rows = n * h * w
+    x = q(rng.randn(n, h, w, ci) * 1.5 + 0.3, dtype)
+    gamma, beta = (rng.rand(ci) + 0.5).astype(np.float32), (rng.randn(ci) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd, g, b = dev(x, dtype), f(gamma), f(beta)
+    m, r = torch.empty(ci, device=DEV), torch.empty(ci, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(ci) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, ci, 1e-3, 0.99, m, r, None, None, ws)
+    P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g), ops.ptr(b), 1
+    st = torch.full((max(4, ops.conv2d_stats_floats(P)),), float("nan"), dtype=torch.float32, device=DEV)
+    P.stats_partial = ops.ptr(st)
+    ops.conv2d(P)
+    cols = ops.conv2d_stats_floats(P) // (2 * ci)
     pre = host(xd) * (host(r) * gamma) + (beta - host(m) * host(r) * gamma)
     safe = np.abs(pre) > 1e-3
     gm = want * (pre > 0)
