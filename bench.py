@@ -109,6 +109,9 @@ def hbm_bytes(name, a):
     if name == "stp_maxpool3x3s2":                   # (x, y, idx, N, H, W, C, dtype)
         n, h, w, c, es = a[3], a[4], a[5], a[6], _ESIZE[a[7]]
         return n * h * w * c * es + n * ((h + 1) // 2) * ((w + 1) // 2) * c * (es + 1)
+    if name == "stp_bn_apply_maxpool3x3s2":          # (x, yb, y, idx, N, H, W, C, dtype, ...): one read + one write of the map, pooled map + indexes
+        n, h, w, c, es = a[4], a[5], a[6], a[7], _ESIZE[a[8]]
+        return 2 * n * h * w * c * es + n * (h // 2) * (w // 2) * c * (es + 1)
     if name == "stp_maxpool3x3s2_bwd":               # (idx, dy, dx, N, H, W, C, dtype, accumulate)
         n, h, w, c, es = a[3], a[4], a[5], a[6], _ESIZE[a[7]]
         return n * ((h + 1) // 2) * ((w + 1) // 2) * c * (es + 1) + n * h * w * c * es * (1 + int(bool(a[8])))
@@ -125,8 +128,9 @@ HBM_FAMILIES = {
     "BatchNormalization forward": {"entries": ("stp_bn_apply", "stp_bn_finalize_apply"),
                                    "kernels": ("bn_apply_v8_kernel", "bn_apply_u8_kernel", "bn_apply_kernel", "bn_finalize_apply_kernel"),
                                    "main": ("bn_apply_v8_kernel", "bn_apply_u8_kernel", "bn_apply_kernel", "bn_finalize_apply_kernel")},
-    "max-pooling forward + backward": {"entries": ("stp_maxpool3x3s2", "stp_maxpool3x3s2_bwd"), "kernels": ("maxpool_fwd_kernel", "maxpool_bwd_kernel"),
-                                       "main": ("maxpool_fwd_kernel", "maxpool_bwd_kernel")},
+    "max-pooling forward + backward": {"entries": ("stp_maxpool3x3s2", "stp_bn_apply_maxpool3x3s2", "stp_maxpool3x3s2_bwd"),
+                                       "kernels": ("maxpool_fwd_kernel", "bn_apply_maxpool_kernel", "maxpool_bwd_kernel"),
+                                       "main": ("maxpool_fwd_kernel", "bn_apply_maxpool_kernel", "maxpool_bwd_kernel")},
 }
 
 

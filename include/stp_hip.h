@@ -389,6 +389,11 @@ int stp_maxpool3x3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H,
                      int32_t dtype, void* stream);
 int stp_maxpool3x3s2_bwd(const uint8_t* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                          int32_t dtype, int32_t accumulate, void* stream);
+/* stp_bn_apply (+ activation) and the stp_maxpool3x3s2 that follows it as ONE launch (the ResNet stem: bn0 -> relu0 -> pooling0): x = the
+ * tensor before the BatchNormalization, yb = the normalised tensor (written, bit-identical to stp_bn_apply's - other layers read it),
+ * y / idx = the pooling outputs.  16-bit storage, H and W even, C % 8 == 0. */
+int stp_bn_apply_maxpool3x3s2(const void* x, void* yb, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, void* stream);
 /* The same when dx is the gradient of a BatchNormalization(+activation) output that this launch completes (bn0 of the ResNet
  * stem: pooled, and read by a decoder skip): mask + partial sums for stp_bn_backward_fused, as stp_upsample2x_bwd_bn. */
 int stp_maxpool3x3s2_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype);

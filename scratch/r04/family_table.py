@@ -1,6 +1,6 @@
 """Per-family sums of a graph_gaps.txt (scratch/prof_r04.sh): us per step and launches per step."""
 import sys, re
-fam = [("3x3 halo forward / data gradient", r"conv_halo"), ("grouped weight gradients", r"conv_wgrad_taps9_group|conv_wgrad_row_group"),
+fam = [("3x3 halo forward / data gradient (incl. two-source, space-to-depth, folded-shortcut forms)", r"conv_halo"), ("grouped weight gradients", r"conv_wgrad_taps9_group|conv_wgrad_row_group"),
        ("their reduces", r"wgrad_group9_reduce|wgrad_group_reduce"), ("BatchNormalization backward", r"bn_bwd"), ("BatchNormalization forward", r"bn_apply|bn_finalize|bn_partial"),
        ("small-channel forward / data gradient (lean)", r"conv_sc_lean|conv_sc_stream"), ("small-channel weight gradient", r"conv_sc_wgrad"),
        ("stem forward + weight gradient", r"conv_stem"), ("generic per-tap kernel", r"conv_igemm"), ("decoder_stage3_conv1 (scn / scw)", r"conv_scn|conv_scw"),

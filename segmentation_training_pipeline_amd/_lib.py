@@ -110,6 +110,7 @@ SIGNATURES = {
     "stp_bn_backward_fused_add": (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "stp_maxpool3x3s2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_bn_apply_maxpool3x3s2": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "stp_maxpool3x3s2_bwd_bn_tiles": (i32, [i32, i32, i32, i32, i32]),
     "stp_maxpool3x3s2_bwd_bn": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
     "stp_maxpool2x2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -1282,6 +1282,85 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// BatchNormalization apply (+ activation) FUSED with the max-pooling that follows it (round 5: the stem's bn0 -> relu0 -> pooling0).
+// The thread of pooled pixel (ho, wo) fetches the nine taps of the PRE-normalisation tensor, normalises them with the arithmetic and
+// the rounding of stp_bn_apply (the maximum is taken over the values AS STORED), writes the pooled value + index, and stores the
+// normalised tensor for the 2 x 2 block of input pixels (2ho, 2wo) .. (2ho + 1, 2wo + 1) - its taps (1..2, 1..2): every input pixel
+// of an even-sized map belongs to exactly one block.  One read of the 134 MB tensor instead of two (apply: read + write, pool: read).
+__global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ yb, bf16_t* __restrict__ y,
+                                                               uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo,
+                                                               const float* mean, const float* rstd, const float* gamma, const float* beta, int relu) {
+  const int cg = C >> 3;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cg) return;
+  const int wo = t / cg, c = (t - wo * cg) * 8;
+  float sc[8], sh[8];
+  {
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + c), m1 = *reinterpret_cast<const f32x4*>(mean + c + 4);
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rstd + c), r1 = *reinterpret_cast<const f32x4*>(rstd + c + 4);
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (gamma) { g0 = *reinterpret_cast<const f32x4*>(gamma + c); g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4); }
+    if (beta) { b0 = *reinterpret_cast<const f32x4*>(beta + c); b1 = *reinterpret_cast<const f32x4*>(beta + c + 4); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float r = e < 4 ? r0[e & 3] : r1[e & 3], k = gamma ? r * (e < 4 ? g0[e & 3] : g1[e & 3]) : r;
+      sc[e] = k;
+      sh[e] = (e < 4 ? b0[e & 3] : b1[e & 3]) - (e < 4 ? m0[e & 3] : m1[e & 3]) * k;
+    }
+  }
+  for (int rr = 0; rr < POOL_ROWS; ++rr) {
+    const int orow = blockIdx.y * POOL_ROWS + rr;
+    if (orow >= N * Ho) break;
+    const int n = orow / Ho, ho = orow - n * Ho;
+    u32x4 v[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int h = min(max(2 * ho - 1 + kh, 0), H - 1), w = min(max(2 * wo - 1 + kw, 0), W - 1);
+        v[kh * 3 + kw] = *reinterpret_cast<const u32x4*>(x + (((size_t)n * H + h) * W + w) * C + c);
+      }
+    float best[8];
+    uint8_t bi[8];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
+        const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;      // padded taps take part with value 0
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bn_act(bn_affine(h16lo_to_f32(v[kh * 3 + kw][e]), sc[2 * e], sh[2 * e]), relu);
+          const float hi = bn_act(bn_affine(h16hi_to_f32(v[kh * 3 + kw][e]), sc[2 * e + 1], sh[2 * e + 1]), relu);
+          o[e] = pack_bf16x2(lo, hi);
+          const float tl = in ? h16lo_to_f32(o[e]) : 0.f, th = in ? h16hi_to_f32(o[e]) : 0.f;      // the values as stored
+          if ((kh | kw) == 0 || tl > best[2 * e]) { best[2 * e] = tl; bi[2 * e] = (uint8_t)(kh * 3 + kw); }
+          if ((kh | kw) == 0 || th > best[2 * e + 1]) { best[2 * e + 1] = th; bi[2 * e + 1] = (uint8_t)(kh * 3 + kw); }
+        }
+        if (kh >= 1 && kw >= 1 && in) *reinterpret_cast<u32x4*>(yb + (((size_t)n * H + h) * W + w) * C + c) = o;   // this thread's 2 x 2 block
+      }
+    const size_t oo = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+    *reinterpret_cast<u32x4*>(y + oo) = u32x4{pack_bf16x2(best[0], best[1]), pack_bf16x2(best[2], best[3]), pack_bf16x2(best[4], best[5]),
+                                             pack_bf16x2(best[6], best[7])};
+    if (idx) *reinterpret_cast<uint2*>(idx + oo) = *reinterpret_cast<const uint2*>(bi);
+  }
+}
+// H, W even, C % 8 == 0, 16-bit storage.  x = the tensor BEFORE the BatchNormalization, yb = the normalised (+ activated) tensor
+// [N,H,W,C] (stp_bn_apply's output, bit for bit), y / idx = stp_maxpool3x3s2's outputs for it.
+extern "C" int stp_bn_apply_maxpool3x3s2(const void* x, void* yb, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                         const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  if (dtype != STP_H16 || !x || !yb || !y || !mean || !rstd || N <= 0 || (C & 7) || (H & 1) || (W & 1)) return STP_E_BADARG;
+  const int Ho = H / 2, Wo = W / 2;
+  if ((int64_t)N * Ho > 65535 * POOL_ROWS) return STP_E_BADARG;  // gridDim.y
+  const dim3 grid(ceil_div(Wo * (C / 8), 256), ceil_div(N * Ho, POOL_ROWS));
+  hipLaunchKernelGGL(bn_apply_maxpool_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)yb, (bf16_t*)y, idx, N, H, W, C, Ho, Wo,
+                     mean, rstd, gamma, beta, relu);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Shared tail of the gradient kernels that COMPLETE the gradient of a BatchNormalization(+activation) output (the 2x2 fold of
 // UpSampling2D, the max-pool gather): the thread's V values are masked with the activation re-derived from the BN input x,

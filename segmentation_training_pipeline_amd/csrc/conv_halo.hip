@@ -53,7 +53,14 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
     case 2: wait_vmcnt<2>(); break;
     case 3: wait_vmcnt<3>(); break;
     case 4: wait_vmcnt<4>(); break;
-    default: wait_vmcnt<5>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    case 8: wait_vmcnt<8>(); break;
+    case 9: wait_vmcnt<9>(); break;
+    case 10: wait_vmcnt<10>(); break;
+    case 11: wait_vmcnt<11>(); break;
+    default: wait_vmcnt<12>(); break;
   }
 }
 
@@ -334,8 +341,14 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
 // FOLD1 (round 5, NT == 9 with a second source): the second source is dY of a SIBLING 1x1 / stride-1 convolution that reads the same tensor
 // (the projection shortcut of a ResNet basic block's first unit): its data gradient is the centre tap of this launch over
 // a.fold_weight = [Cout^16][C1] - the slabs of the second source run one live K-step (tap 4) and eight that keep only their barriers.
-template <int TH, int BM, int WM, int WN, int EP, bool PBN, bool SRC2, int NT = 9, bool FOLD1 = false>
+// RING (round 5) = stages of the weight ring; W(k + RING - 1) is requested during MMA(k).  What the space-to-depth launches showed
+// (profiles/r05h_s2d_layer_bench.txt): a K-step that issues NO MFMAs still costs 0.45 us - an LDS-DMA needs ~1 us from issue to landing
+// under load, and with 4 stages a piece has 1.5 - 2 K-steps.  RING = 6 gives it 3.5 - 4: the wait that ends MEM(k) then leaves the
+// RING - 3 youngest groups in flight (their sizes are kept in scalar registers), the passes of the next slab must be issued in the
+// taps 0 .. NT - RING + 1.  LDS allows it for the 8-row tiles (111 -> 143 KB) and the one-slab 64-channel tiles.
+template <int TH, int BM, int WM, int WN, int EP, bool PBN, bool SRC2, int NT = 9, bool FOLD1 = false, int RING = HALO_NWST>
 __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
+  static_assert(RING == 4 || (RING == 6 && NT == 9), "weight ring depth");
   static_assert(!FOLD1 || (SRC2 && NT == 9 && !PBN), "the folded 1x1 sibling is a second source of the 3 x 3 window");
   static_assert(WM * WN == 8 && BM % (WM * 32) == 0 && TH % (WN * 2) == 0, "config");
   static_assert(NT == 9 || NT == 4, "taps per slab");
@@ -357,16 +370,17 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   static_assert(NPASS <= 6 || TH == 32, "the next slab must have landed (own pieces) when the K-step of tap 8 begins (TH = 32: one-slab inputs only)");
   constexpr int SROWS = (NHP + 7) / 8 * 8;       // slab rows kept in LDS (8 per wave instruction; rows >= NHP are never read)
   constexpr int SLAB = SROWS * 128;
-  constexpr int NWST = HALO_NWST;                // weight ring stages
+  constexpr int NWST = RING;                     // weight ring stages
+  constexpr int PD = RING - 1;                   // prefetch distance of the weights (K-steps)
   constexpr int WSTAGE = BM * 128;
   constexpr int LW = BM / 64;                    // weight LDS-DMA instructions per thread per K-step
   constexpr int CW = BM / WM, RW = TH / WN;      // channels / pixel rows per wave
   constexpr int TM = CW / 32, TN = RW / 2;       // 32x32 MFMA tiles per wave
-  constexpr int PPS = (NPASS + (NT - 2) - 1) / (NT - 2);   // slab passes per K-step: all issued in taps 0 .. NT - 3
+  constexpr int PPS = (NPASS + (NT - PD + 1) - 1) / (NT - PD + 1);   // slab passes per K-step: all issued in taps 0 .. NT - PD
   constexpr int NPT = (NPASS + PPS - 1) / PPS;              // K-steps that carry passes
   static_assert(LW + PPS <= TM * TN * 4, "one LDS-DMA instruction per MFMA at most");
-  static_assert(NPT <= NT - 2 || TH == 32, "the next slab is complete three K-steps before its first use");
-  static_assert(LW + PPS <= 5, "wait_vmcnt_n covers 0 .. 5");
+  static_assert(NPT <= NT - PD + 1 || TH == 32, "the next slab is complete PD K-steps before its first use");
+  static_assert((PD - 2) * (LW + PPS) <= 12, "wait_vmcnt_n covers 0 .. 12");
   // LDS: [slab 0][slab 1 unless Cin == 64][NWST weight stages][scale/shift table of a fused producer BatchNormalization]
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -539,9 +553,10 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) issue_slab_pass(0, p);
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < PD; ++t)             // W(0) .. W(PD - 1)  (NT >= PD: all of slab 0)
 #pragma unroll
     for (int i = 0; i < LW; ++i) issue_weight_piece(i, t, 0, t);
+  static_assert(NT >= PD || RING == 4, "the prologue's weight tiles lie in slab 0");
 
   if (fuse_bn) {
     for (int c = tid; c < a.C0; c += 512) {
@@ -556,7 +571,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
 
   {
     const bool grp_b = wave >= 4;          // wave-uniform
-    wait_vmcnt<2 * LW>();                  // slab 0 and W(0): everything but W(1), W(2)
+    wait_vmcnt<(PD - 1) * LW>();           // slab 0 and W(0): everything but W(1) .. W(PD - 1)
     if (fuse_bn) {
       transform_slab(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -565,7 +580,8 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
     if (grp_b) __builtin_amdgcn_s_barrier();
 
     u32x4 fa[4][TM], fb[4][TN];
-    int wst = 0;                           // ring stage of the current K-step = k % 4
+    int wst = 0;                           // ring stage of the current K-step = k % RING
+    int gq0 = LW, gq1 = LW, gq2 = LW;      // RING = 6: LDS-DMA instructions of this wave in the three youngest groups (the prologue's W(2 ..) count)
     for (int s = 0; s < nslab; ++s) {
       const bool last = s + 1 == nslab;    // no slab to prefetch, and the weights of the next "slab" do not exist
 #pragma unroll
@@ -589,7 +605,9 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // leave the youngest group (issued in MMA(k-1)) in flight: LW weight pieces unless that K-step had none left to
         // prefetch, plus its slab pass if there is a next slab and this wave has rows in that pass
-        if (t == 0) {
+        if constexpr (RING != 4) {
+          wait_vmcnt_n(gq0 + gq1 + gq2);                    // the three youngest groups stay in flight
+        } else if (t == 0) {
           wait_vmcnt_n(LW);                                 // previous K-step = the last tap of a slab that is not the last: weights, no pass
         } else {
           int np = 0;                                       // passes issued in MMA(k - 1) by this wave
@@ -605,9 +623,18 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
         // ---------------- MMA(k) + group(k)
         __builtin_amdgcn_s_setprio(1);
         {
-          const int st3 = (wst + 3) & 3;
-          const int t3 = t + 3 < NT ? t + 3 : t + 3 - NT, s3 = t + 3 < NT ? s : s + 1;
-          const bool wlive = !(last && t + 3 >= NT);
+          const int st3 = RING == 4 ? ((wst + 3) & 3) : (wst == 0 ? RING - 1 : wst - 1);
+          const int t3 = (t + PD) % NT, s3 = s + (t + PD) / NT;
+          const bool wlive = RING == 4 ? !(last && t + 3 >= NT) : (s3 < nslab);
+          if constexpr (RING != 4) {          // sizes of the youngest groups: this K-step's joins, the oldest leaves
+            int np = 0;
+            if (t < NPT && !last) {
+#pragma unroll
+              for (int i = 0; i < PPS; ++i)
+                if (t * PPS + i < NPASS && pass_on(t * PPS + i)) ++np;
+            }
+            gq2 = gq1; gq1 = gq0; gq0 = (wlive ? LW : 0) + np;
+          }
           int piece = 0;
           if (!live) {
 #pragma unroll
@@ -639,7 +666,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        wst = (wst + 1) & 3;
+        wst = RING == 4 ? ((wst + 1) & 3) : (wst + 1 == RING ? 0 : wst + 1);
       }
       // the fragment addresses follow the slab: slot (s+1) & 1
       const uint32_t d = (s & 1) ? (uint32_t)(-SLAB) : (uint32_t)SLAB;
@@ -671,6 +698,9 @@ template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, false>(a); }
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_pbn_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, true, false>(a); }
+// six-stage weight ring (8-row tiles: the LDS has room), one source
+template <int TH, int BM, int WM, int WN, int EP>
+__global__ __launch_bounds__(512, 1) void conv_halo_r6_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, false, 9, false, 6>(a); }
 // two sources / upsampled first source (forward only: EP 0 / 1)
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo2_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true>(a); }
@@ -693,7 +723,10 @@ static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
   const bool src2 = a.C1 > 0 || a.mode == STP_SRC_NEAREST2X || a.d2s;
-  size_t lds = (size_t)((src2 ? a.Ctot : a.C0) > 64 ? 2 : 1) * SROWS * 128 + HALO_NWST * BM * 128 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
+  // STP_HALO_RING=6: the 8-row tiles with one source take the six-stage weight ring (experiment switch; default below)
+  static const int ring_env = getenv("STP_HALO_RING") ? atoi(getenv("STP_HALO_RING")) : 4;
+  const bool ring6 = ring_env == 6 && TH == 8 && !src2 && !a.pbn.mean && !a.fold_weight;
+  size_t lds = (size_t)((src2 ? a.Ctot : a.C0) > 64 ? 2 : 1) * SROWS * 128 + (ring6 ? 6 : HALO_NWST) * BM * 128 + (a.pbn.mean ? (size_t)8 * a.C0 : 0);
   const size_t lds_ep = (size_t)TH * 16 * (BM * 4 + 16);   // the epilogue's staged fp32 tile
   if (lds < lds_ep) lds = lds_ep;
   a.ntile_m = ceil_div(a.Cout, BM);
@@ -717,7 +750,11 @@ static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
   if constexpr (BM == 128 && (EP == 0 || EP == 2)) {
     if (a.d2s) kern = conv_halo_s2d_kernel<TH, BM, WM, WN, EP>;
   }
-  bool& done = a.d2s ? attr_set_s2d : fold1 ? attr_set_fold1 : src2 ? attr_set_src2 : pbn ? attr_set_pbn : attr_set;
+  static bool attr_set_r6 = false;
+  if constexpr (TH == 8) {
+    if (ring6) kern = conv_halo_r6_kernel<TH, BM, WM, WN, EP>;
+  }
+  bool& done = ring6 ? attr_set_r6 : a.d2s ? attr_set_s2d : fold1 ? attr_set_fold1 : src2 ? attr_set_src2 : pbn ? attr_set_pbn : attr_set;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return STP_E_LAUNCH;

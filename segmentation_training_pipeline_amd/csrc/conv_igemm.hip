@@ -584,7 +584,9 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
     if (tail > 0 && tail <= 64 && ceil_div(a.P, 128) >= 384) return 64 + 7;
     // one or two K steps (1x1 bottleneck convolutions): nothing to pipeline, the narrower pixel tile's extra workgroups hide
     // more of the per-workgroup latency (scratch/conv1x1_bench.py: 64->256 @ 4x256^2 65 -> 57 us)
-    if (a.K <= 128 && mid >= 384) return 64 + 6;
+    // ... with the BatchNormalization-backward epilogue (three operand tensors per output tile) the 64-channel x 128-pixel tile is the
+    // faster one (scratch/r05/dgrad1x1_bench.py: 128 -> 512 @ 8 x 96^2 73.6 -> 57.3 us, 64 -> 256 @ 8 x 192^2 137.5 -> 113.5 us)
+    if (a.K <= 128 && mid >= 384) return a.bnb.x ? 64 + 7 : 64 + 6;
     if (big >= 384) return 64 + 1;
     if (mid >= 384) return 64 + 6;
     return 128 + 5;

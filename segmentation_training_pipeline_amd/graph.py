@@ -1431,8 +1431,21 @@ class Plan(object):
         if self.dry:
             return out
         idx = self._alloc((self.N, Ho, Wo, x.C), torch.uint8) if self.training else None
-        self._emit(self.fwd, "stp_maxpool3x3s2", x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if idx is not None else None,
-                   self.N, x.H, x.W, x.C, self.cdt)
+        last = self.fwd[-1] if self.fwd else None
+        if (self.training and self.dtype != "fp32" and last is not None and last[2] == "stp_bn_apply" and last[1][2] == x.buf.data_ptr()
+                and last[1][1] == last[1][3] == self.cdt and last[1][5] == last[1][6] == x.C and last[1][12] == 0.0 and x.C % 8 == 0
+                and x.H % 2 == 0 and x.W % 2 == 0 and x.meta.get("apply_rec") in (None, last) and not x.meta.get("sc_consumers")
+                and not x.meta.get("halo_consumers") and os.environ.get("STP_FUSE_BN_POOL_FWD", "1") != "0"):
+            # the BatchNormalization apply that produced x is the previous launch (the stem: bn0 -> relu0 -> pooling0): ONE launch normalises,
+            # stores x (the decoder's skip tensor) and pools - the 134 MB pre-normalisation tensor is read once instead of twice
+            xa = last[1]
+            self.fwd.pop()
+            x.meta.pop("apply_rec", None)      # (the launch no longer exists on its own: nothing may drop or move it)
+            self._emit(self.fwd, "stp_bn_apply_maxpool3x3s2", xa[0], x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if idx is not None else None,
+                       self.N, x.H, x.W, x.C, self.cdt, xa[7], xa[8], xa[9], xa[10], xa[11])
+        else:
+            self._emit(self.fwd, "stp_maxpool3x3s2", x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if idx is not None else None,
+                       self.N, x.H, x.W, x.C, self.cdt)
 
         def back():
             if not (x.needs_grad and out.grad_ready):

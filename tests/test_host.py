@@ -520,10 +520,10 @@ def test_bench_names_every_launch_of_the_headline_plan():
                     if b is not None:
                         assert b > 0, name
                         byt.setdefault(name, []).append(b)
-            assert set(byt) >= {"stp_bn_apply", "stp_bn_finalize_apply", "stp_bn_backward_fused", "stp_maxpool3x3s2", "stp_maxpool3x3s2_bwd"}
+            assert set(byt) >= {"stp_bn_apply", "stp_bn_finalize_apply", "stp_bn_backward_fused", "stp_bn_apply_maxpool3x3s2", "stp_maxpool3x3s2_bwd"}
             assert max(byt["stp_bn_backward_fused"]) == 3 * 16 * 512 * 512 * 16 * 2         # decoder_stage4: x, g read + dx written, bf16
             assert bench.hbm_bytes("stp_adam", (0, 0, 0, 0, 1000)) == 28000          # (the optimizer launch is the backend's, not the plan's)
-            assert byt["stp_maxpool3x3s2"] == [16 * 256 * 256 * 64 * 2 + 16 * 128 * 128 * 64 * 3]
+            assert byt["stp_bn_apply_maxpool3x3s2"] == [2 * 16 * 256 * 256 * 64 * 2 + 16 * 128 * 128 * 64 * 3]      # bn0 + relu0 + pooling0 in one launch
             assert {e for f in bench.HBM_FAMILIES.values() for e in f["entries"]} >= set(byt)
 
 

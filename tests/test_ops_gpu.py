@@ -1688,6 +1688,35 @@ def test_maxpool_and_upsample_gradients(ops, dtype):
     np.testing.assert_allclose(host(dxu), np_ops.upsample2x_bwd(g), atol=tol(g, dtype, 4))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 24, 64, 1, True), (1, 64, 70, 64, 1, True), (3, 6, 4, 16, 2, False), (2, 128, 256, 8, 0, True)])
+@pytest.mark.parametrize("dtype", H16)
+def test_batchnorm_apply_fused_with_the_max_pooling_behind_it(ops, case, dtype):
+    """stp_bn_apply_maxpool3x3s2 (round 5: the stem's bn0 -> relu0 -> pooling0 as one launch): the normalised tensor, the pooled tensor
+    and the argmax indexes are BIT-identical to stp_bn_apply followed by stp_maxpool3x3s2."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c, relu, with_gamma = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = q(rng.randn(n, h, w, c) * 2.0 + 0.5, dtype)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd = dev(x, dtype)
+    m, r = f(rng.randn(c) * 0.3), f(rng.rand(c) + 0.5)
+    g, b = (f(rng.rand(c) + 0.5) if with_gamma else None), f(rng.randn(c) * 0.3)
+    ho, wo = h // 2, w // 2
+    act0, act1 = torch.empty_like(xd), torch.full_like(xd, float("nan"))
+    y0, y1 = (torch.full((n, ho, wo, c), float("nan"), dtype=TD[dtype], device=DEV) for _ in range(2))
+    i0, i1 = (torch.full((n, ho, wo, c), 255, dtype=torch.uint8, device=DEV) for _ in range(2))
+    ops.bn_apply(xd, act0, n * h * w, c, c, m, r, g, b, relu=relu)
+    ops.maxpool3x3s2(act0, y0, i0, n, h, w, c)
+    _lib.call("stp_bn_apply_maxpool3x3s2", ops.ptr(xd), ops.ptr(act1), ops.ptr(y1), ops.ptr(i1), n, h, w, c, ops.dt(xd), ops.ptr(m), ops.ptr(r),
+              ops.ptr(g) if g is not None else None, ops.ptr(b), relu, ops.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(act1.view(torch.int16), act0.view(torch.int16))
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)) and torch.equal(i1, i0)
+    with pytest.raises(_lib.StpError):      # odd maps: the 2 x 2 blocks would not cover the tensor
+        _lib.call("stp_bn_apply_maxpool3x3s2", ops.ptr(xd), ops.ptr(act1), ops.ptr(y1), ops.ptr(i1), n, h - 1, w, c, ops.dt(xd), ops.ptr(m), ops.ptr(r),
+                  None, ops.ptr(b), relu, ops.stream())
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("factor", [1, 2, 4, 8])
 def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor):
