@@ -53,3 +53,9 @@ print("---- GEMM launches")
 for us, name, meta in rows:
     if meta and 'flops' in meta:
         print("%-28s %-6s tile=%-3s %8.1f us %7.1f TF" % (meta["layer"], meta["pass"], meta.get("tile", meta.get("cout")), us, meta["flops"] / us / 1e6))
+print("---- resize / pooling / loss launches (N, H, W, C, factor, ldo, coff)")
+for i, (fn, args, name, meta) in enumerate(launches):
+    if name in ("stp_resize_bilinear", "stp_resize_bilinear_bwd"):
+        print("%-26s N %d H %d W %d C %d f %d ldo %d coff %d   %8.1f us" % ((name,) + tuple(args[2:9]) + (tot[i],)))
+    elif name in ("stp_avgpool", "stp_avgpool_bwd", "stp_softmax_cce_dice", "stp_upsample2x_add", "stp_channel_sum", "stp_upsample2x_bwd"):
+        print("%-26s %s   %8.1f us" % (name, tuple(a for a in args[2:8] if isinstance(a, int) and a < 10**7), tot[i]))

@@ -2151,6 +2151,125 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_blk_kernel(const T* _
   }
 }
 
+// gradient, ROW-STREAMING form for the resize of CLASS LOGITS (few channels, x4 / x8: PSPNet's final_interpolation, FPN's last_upsample -
+// round 5): one workgroup per input row (n, h).  The <= 2f output rows that touch it are streamed whole through a double-buffered LDS
+// row (coalesced 16-byte loads; the row of the next iteration sits in registers while this one is reduced); a thread owns up to two
+// (w, 16-byte channel group) items and takes the 2f taps of its item from the staged row in a fixed order - deterministic.  The gather
+// kernel below gives such shapes ONE input pixel per workgroup (256 tap lanes, an LDS reduction per 48 output bytes): 224 us for PSPNet's
+// x8 gradient (226 MB), 128 us for FPN's x4.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_rows_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int C, int f,
+                                                                       int ldo, int coff, int accumulate, int nvec) {
+  extern __shared__ __attribute__((aligned(16))) char rb_smem[];
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+  const int Ho = H * f, Wo = W * f;
+  const int rowV = Wo * ldo / EV, rowB = rowV * 16;                   // vectors / bytes of one output row (host: ldo % EV == 0)
+  const int yo0 = max((h - 1) * f, 0), yo1 = min((h + 1) * f, Ho);    // output rows that may read input row h
+  const float inv = 1.f / (float)f;
+  const int cgv = C / EV, nitem = W * cgv;
+  float acc[2][EV];
+  int iw[2], ic[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int e = 0; e < EV; ++e) acc[k][e] = 0.f;
+    const int it = threadIdx.x + k * 256;
+    iw[k] = it < nitem ? it / cgv : -1;
+    ic[k] = it < nitem ? (it - (it / cgv) * cgv) * EV : 0;
+  }
+  constexpr int MAXV = 10;                                            // 16-byte vectors of a row per thread (host: nvec <= MAXV)
+  u32x4 pre[MAXV];
+  auto fetch = [&](int yo) {
+    const char* src = reinterpret_cast<const char*>(dy + ((int64_t)(n * Ho + yo) * Wo) * ldo);
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int o = threadIdx.x + v * 256;
+      if (v < nvec && o < rowV) pre[v] = *reinterpret_cast<const u32x4*>(src + (size_t)o * 16);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int o = threadIdx.x + v * 256;
+      if (v < nvec && o < rowV) *reinterpret_cast<u32x4*>(rb_smem + buf * rowB + o * 16) = pre[v];
+    }
+  };
+  fetch(yo0);
+  int buf = 0;
+  for (int yo = yo0; yo < yo1; ++yo) {
+    park(buf);
+    __syncthreads();                        // row yo is staged; the buffer of row yo - 1 is free
+    if (yo + 1 < yo1) fetch(yo + 1);
+    const int y0 = yo / f;
+    const float fy = (float)(yo - y0 * f) * inv;
+    float wy = 0.f;
+    if (y0 == h) wy += 1.f - fy;
+    if (min(y0 + 1, H - 1) == h) wy += fy;
+    if (wy != 0.f) {
+      const T* row = reinterpret_cast<const T*>(rb_smem + buf * rowB) + coff;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int w = iw[k];
+        if (w < 0) continue;
+        float r[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) r[e] = 0.f;
+        for (int tx = 0; tx < 2 * f; ++tx) {
+          const int xo = (w - 1) * f + tx;
+          if (xo < 0) continue;
+          const int x0 = xo / f;
+          const float fx = (float)(xo - x0 * f) * inv;
+          float wx = 0.f;
+          if (x0 == w) wx += 1.f - fx;
+          if (min(x0 + 1, W - 1) == w) wx += fx;
+          float v[EV];
+          ldv<T, EV>(row + xo * ldo + ic[k], v);
+#pragma unroll
+          for (int e = 0; e < EV; ++e) r[e] += wx * v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EV; ++e) acc[k][e] += wy * r[e];
+      }
+    }
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (iw[k] < 0) continue;
+    T* d = dx + ((int64_t)(n * H + h) * W + iw[k]) * C + ic[k];
+    if (accumulate) {
+      float a[EV];
+      ldv<T, EV>(d, a);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) acc[k][e] += a[e];
+    }
+    stv<T, EV>(d, acc[k]);
+  }
+}
+
+// factor 1 (the level of a concatenation that keeps its resolution: PSPNet's feature map, FPN's stride-4 branch): the gradient is the
+// channel slice [coff, coff + C) of dY copied (or added) back - 16-byte vectors, four in flight.  The generic gather kernel ran its 2 x 2
+// tap loops with integer divisions and 2-byte loads on it: 244 us for 151 MB (PSPNet 768 x 768 batch 8), 236 us for FPN's (round 5).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void slice_copy_kernel(const T* __restrict__ dy, T* __restrict__ dx, int64_t pixels, int C, int ldo, int coff, int accumulate) {
+  const int cg = C / V;
+  const int64_t total = pixels * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / cg;
+    const int c = (int)(i - p * cg) * V;
+    float v[V];
+    ldv<T, V>(dy + p * ldo + coff + c, v);
+    if (accumulate) {
+      float a[V];
+      ldv<T, V>(dx + p * C + c, a);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += a[e];
+    }
+    stv<T, V>(dx + p * C + c, v);
+  }
+}
+
 extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor, int32_t ldo,
                                    int32_t coff, int32_t dtype, void* stream) {
   if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
@@ -2194,6 +2313,36 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 1 || ldo < coff + C || coff < 0) return STP_E_BADARG;
   if (dtype != STP_H16 && dtype != STP_F32) return STP_E_BADARG;
   const int V = vec_for(dtype, C, ldo, coff);
+  if (V > 1 && factor == 1) {      // a channel slice copied (or added) back
+    const int64_t pixels = (int64_t)N * H * W;
+    const int g = grid_for_amortised(pixels * (C / V), 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 8) hipLaunchKernelGGL((slice_copy_kernel<bf16_t, 8>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, pixels, C, ldo, coff, accumulate);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((slice_copy_kernel<bf16_t, 4>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, pixels, C, ldo, coff, accumulate);
+    else hipLaunchKernelGGL((slice_copy_kernel<float, 4>), dim3(g), dim3(256), 0, s, (const float*)dy, (float*)dx, pixels, C, ldo, coff, accumulate);
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
+  {
+    // class logits (few channels, whole output rows fit an LDS buffer): the row-streaming kernel.  STP_RESIZE_BWD_ROWS=0: the gather kernel.
+    static const bool rows_on = !(getenv("STP_RESIZE_BWD_ROWS") && atoi(getenv("STP_RESIZE_BWD_ROWS")) == 0);
+    const int esz = dtype == STP_H16 ? 2 : 4, ev = 16 / esz;
+    const int64_t rowB = (int64_t)W * factor * ldo * esz;
+    const int nvec = (int)((rowB / 16 + 255) / 256);
+    if (rows_on && factor >= 2 && !(C % ev) && !(ldo % ev) && !(coff % ev) && (int64_t)W * (C / ev) <= 512 && rowB <= 40960 && nvec <= 10 &&
+        !(reinterpret_cast<uintptr_t>(dy) & 15) && !(reinterpret_cast<uintptr_t>(dx) & 15) && (int64_t)N * H < (1ll << 31)) {
+      const dim3 grid((unsigned)(N * H));
+      hipStream_t s = (hipStream_t)stream;
+      if (dtype == STP_H16)
+        hipLaunchKernelGGL(resize_bilinear_bwd_rows_kernel<bf16_t>, grid, dim3(256), (size_t)(2 * rowB), s, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, factor, ldo,
+                           coff, accumulate, nvec);
+      else
+        hipLaunchKernelGGL(resize_bilinear_bwd_rows_kernel<float>, grid, dim3(256), (size_t)(2 * rowB), s, (const float*)dy, (float*)dx, H, W, C, factor, ldo, coff,
+                           accumulate, nvec);
+      STP_LAUNCH_CHECK();
+      return STP_OK;
+    }
+  }
   if (V > 1 && factor >= 2) {
     const int cg = C / V, span = 2 * factor;
     const int64_t npix = (int64_t)N * H * W;

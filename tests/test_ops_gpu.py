@@ -1717,6 +1717,34 @@ def test_batchnorm_apply_fused_with_the_max_pooling_behind_it(ops, case, dtype):
                   None, ops.ptr(b), relu, ops.stream())
 
 
+@pytest.mark.parametrize("case", [(2, 12, 24, 24, 24, 0, 8), (1, 16, 64, 8, 8, 0, 4), (2, 6, 10, 8, 24, 8, 2), (1, 9, 33, 16, 16, 0, 8),
+                                  (2, 5, 7, 16, 48, 16, 1), (1, 8, 8, 128, 320, 64, 1)])      # the last two: factor 1 = a channel slice copied / added back
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bilinear_resize_gradient_of_class_logits_and_of_an_unresized_slice(ops, case, dtype):
+    """Round 5: resize_bilinear_bwd_rows_kernel - the gradient of the x4 / x8 bilinear resize of class logits (channel count padded to
+    the 16-byte group: PSPNet's 20 classes in rows of 24, FPN's 3 in rows of 8), output rows streamed whole through LDS - and
+    slice_copy_kernel (factor 1: the concatenation level that keeps its resolution).  Against torch autograd of the oracle's TF-1.x
+    resize; channel slices (ldo / coff), accumulate, edge rows and columns, replay bit-identical."""
+    from oracle import nets as onets
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c, ldo, coff, f = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    xt = torch.zeros(n, c, h, w, requires_grad=True)
+    gy = q(rng.randn(n, h * f, w * f, ldo), dtype)
+    onets.resize_bilinear_tf1(xt, f).backward(torch.from_numpy(gy[..., coff:coff + c]).permute(0, 3, 1, 2))
+    ref = xt.grad.permute(0, 2, 3, 1).numpy()
+    gd = dev(gy, dtype)
+    base = q(rng.randn(n, h, w, c), dtype)
+    outs = []
+    for acc in (0, 1, 1):
+        dx = dev(base, dtype) if acc else torch.full((n, h, w, c), float("nan"), dtype=TD[dtype], device=DEV)
+        _lib.call("stp_resize_bilinear_bwd", ops.ptr(gd), ops.ptr(dx), n, h, w, c, f, ldo, coff, ops.dt(dx), acc, None, 0, ops.stream())
+        want = ref + (base if acc else 0.0)
+        np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
+        outs.append(host(dx).copy())
+    assert np.array_equal(outs[1], outs[2])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("factor", [1, 2, 4, 8])
 def test_tf1_bilinear_resize_into_channel_slice_and_gradient(ops, dtype, factor):
