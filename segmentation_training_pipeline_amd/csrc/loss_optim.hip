@@ -428,7 +428,7 @@ extern "C" int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, in
 // Rows are held in registers: the class loops are unrolled to a compile-time bound CM (4, 8, 16, 24 or 32 >= classes) and
 // predicated, rows whose stride allows it are read / written as 16-byte vectors.
 template <typename T, int CM>
-__device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, float (&p)[CM]) {
+__device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, float (&p)[CM], bool vec4 = false) {
   constexpr int V = Elem<T>::VEC;
   if (vec) {
 #pragma unroll
@@ -444,6 +444,17 @@ __device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, f
         }
       }
     }
+  } else if (sizeof(T) == 2 && vec4) {
+    // 16-bit rows whose stride is a multiple of 4 elements only (PSPNet's 20 classes: 40-byte rows): 8-byte loads instead of 20 scalar ones
+#pragma unroll
+    for (int v = 0; v < CM / 4; ++v) {
+      if (v * 4 < classes) {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(z + v * 4);
+        p[v * 4] = h16lo_to_f32(r.x); p[v * 4 + 1] = h16hi_to_f32(r.x); p[v * 4 + 2] = h16lo_to_f32(r.y); p[v * 4 + 3] = h16hi_to_f32(r.y);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) p[c] = c < classes ? p[c] : 0.f;
   } else {
 #pragma unroll
     for (int c = 0; c < CM; ++c) p[c] = c < classes ? Elem<T>::load(z + c) : 0.f;
@@ -466,9 +477,10 @@ __global__ __launch_bounds__(256) void softmax_loss_partial_kernel(const T* __re
   const int64_t per = (pixels + gridDim.x - 1) / gridDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < pixels ? i0 + per : pixels;
   const bool vec = (ldc % Elem<T>::VEC) == 0 && CM % Elem<T>::VEC == 0;
+  const bool vec4 = !vec && sizeof(T) == 2 && (ldc % 4) == 0 && (CM % 4) == 0 && !(reinterpret_cast<uintptr_t>(logits) & 7);
   for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
     float p[CM];
-    softmax_row<T, CM>(logits + i * ldc, classes, vec, p);
+    softmax_row<T, CM>(logits + i * ldc, classes, vec, p, vec4);
     const int t = target[i] < classes ? target[i] : classes - 1;
     float pt = 0.f;
 #pragma unroll
@@ -538,9 +550,10 @@ __global__ __launch_bounds__(256) void softmax_loss_grad_kernel(const T* __restr
   const float inv_den2 = 1.f / (den * den);
   const float num = 2.f * spy + 1.f;
   const bool vec = (ldc % V) == 0 && CM % V == 0, vout = (dlc % V) == 0;
+  const bool vec4 = !vec && sizeof(T) == 2 && (ldc % 4) == 0 && (CM % 4) == 0 && !(reinterpret_cast<uintptr_t>(logits) & 7);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * 256) {
     float p[CM];
-    softmax_row<T, CM>(logits + i * ldc, classes, vec, p);
+    softmax_row<T, CM>(logits + i * ldc, classes, vec, p, vec4);
     const int t = target[i] < classes ? target[i] : classes - 1;
     float pt = 0.f;
 #pragma unroll
