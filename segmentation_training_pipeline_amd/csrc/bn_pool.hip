@@ -2248,6 +2248,124 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_rows_kernel(const T* 
   }
 }
 
+// gradient, TINY input maps resized by a large factor (PSPNet's pyramid levels: 1 x 1 ... 6 x 6 maps of 512 channels, factors 96 ... 16,
+// written into a slice of the concatenation - round 5): the reduction is separable.  Pass 1, one workgroup per OUTPUT row (n, yo): a
+// thread owns one 16-byte channel group and every G-th pixel of the row (a wave reads one pixel's whole channel slice: 1 KB contiguous),
+// keeps W <= 8 column accumulators, the G pixel groups meet through LDS in a fixed order -> part[n][yo][w][c] (fp32).  Pass 2: input
+// row h sums its <= 2f rows of `part` with the row weights.  Every byte of dY is read once, coalesced; the gather kernel below took 51-80 us
+// per level for 75 MB (one scattered 16-byte load per tap, an LDS reduction per input pixel).
+#define RBT_MAXW 8
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_tiny_rows_kernel(const T* __restrict__ dy, float* __restrict__ part, int H, int W, int C, int f,
+                                                                            int ldo, int coff) {
+  extern __shared__ float rbt_red[];                    // [G - 1][W][C]
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int cgv = C / EV, G = 256 / cgv;                // pixel groups of the workgroup (host: 256 % cgv == 0)
+  const int cv = threadIdx.x % cgv, g = threadIdx.x / cgv;
+  const int Wo = W * f;
+  const int64_t row = blockIdx.x;                       // n * Ho + yo
+  const T* src = dy + row * Wo * ldo + coff + cv * EV;
+  const float inv = 1.f / (float)f;
+  float acc[RBT_MAXW][EV];
+#pragma unroll
+  for (int w = 0; w < RBT_MAXW; ++w)
+#pragma unroll
+    for (int e = 0; e < EV; ++e) acc[w][e] = 0.f;
+  // four pixels per iteration, their loads issued before the first use (a run-time trip count keeps ONE load in flight otherwise: §3.5a)
+  for (int xb = g; xb < Wo; xb += 4 * G) {
+    float v[4][EV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int xo = xb + u * G;
+      if (xo < Wo) ldv<T, EV>(src + (int64_t)xo * ldo, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int xo = xb + u * G;
+      if (xo >= Wo) break;
+      const int x0 = xo / f;
+      const float fx = (float)(xo - x0 * f) * inv;
+      const int x1 = min(x0 + 1, W - 1);
+#pragma unroll
+      for (int w = 0; w < RBT_MAXW; ++w) {
+        float wx = 0.f;
+        if (x0 == w) wx += 1.f - fx;
+        if (x1 == w) wx += fx;
+        if (wx != 0.f) {
+#pragma unroll
+          for (int e = 0; e < EV; ++e) acc[w][e] += wx * v[u][e];
+        }
+      }
+    }
+  }
+  if (g > 0) {
+#pragma unroll
+    for (int w = 0; w < RBT_MAXW; ++w)
+      if (w < W)
+#pragma unroll
+        for (int e = 0; e < EV; ++e) rbt_red[((size_t)(g - 1) * W + w) * C + cv * EV + e] = acc[w][e];
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int w = 0; w < RBT_MAXW; ++w) {
+      if (w >= W) break;
+#pragma unroll
+      for (int e = 0; e < EV; ++e) {
+        float sum = acc[w][e];
+        for (int q = 1; q < G; ++q) sum += rbt_red[((size_t)(q - 1) * W + w) * C + cv * EV + e];
+        part[(row * W + w) * C + cv * EV + e] = sum;
+      }
+    }
+  }
+}
+// pass 2: one WAVE per (n, h, w, 4 channels): its 64 lanes take the <= 2f rows of `part` in slices (all loads in flight), a fixed butterfly
+// sums them (an output summed its rows one load at a time in the first version: 192 dependent-latency steps for PSPNet's level 1)
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_tiny_cols_kernel(const float* __restrict__ part, T* __restrict__ dx, int N, int H, int W, int C,
+                                                                            int f, int accumulate) {
+  const int Ho = H * f, c4n = C >> 2;
+  const int64_t nvec = (int64_t)N * H * W * c4n;
+  const int lane = threadIdx.x & 63;
+  const int64_t ov = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ov >= nvec) return;                                 // (wave-uniform)
+  const int c4 = (int)(ov % c4n);
+  const int w = (int)((ov / c4n) % W), h = (int)((ov / ((int64_t)c4n * W)) % H), n = (int)(ov / ((int64_t)c4n * W * H));
+  const float inv = 1.f / (float)f;
+  const int yo0 = max((h - 1) * f, 0), yo1 = min((h + 1) * f, Ho);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int yo = yo0 + lane; yo < yo1; yo += 64) {
+    const int y0 = yo / f;
+    const float fy = (float)(yo - y0 * f) * inv;
+    float wy = 0.f;
+    if (y0 == h) wy += 1.f - fy;
+    if (min(y0 + 1, H - 1) == h) wy += fy;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part + (((int64_t)n * Ho + yo) * W + w) * C + c4 * 4);
+    acc += wy * v;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = wave_sum(acc[e]);
+  if (lane == 0) {
+    T* d = dx + (((int64_t)n * H + h) * W + w) * C + c4 * 4;
+    float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (accumulate) {
+      float a[4];
+      ldv<T, 4>(d, a);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += a[e];
+    }
+    stv<T, 4>(d, o);
+  }
+}
+// eligibility + workspace of the two-pass form
+static bool resize_bwd_tiny_ok(int N, int H, int W, int C, int factor, int ldo, int coff, int dtype) {
+  static const bool on = !(getenv("STP_RESIZE_BWD_TINY") && atoi(getenv("STP_RESIZE_BWD_TINY")) == 0);
+  const int ev = dtype == STP_H16 ? 8 : 4;
+  if (!on || factor < 8 || W > RBT_MAXW || H > 16 || (C % ev) || (ldo % ev) || (coff % ev)) return false;
+  const int cgv = C / ev;
+  return cgv >= 1 && cgv <= 256 && (256 % cgv) == 0 && (size_t)(256 / cgv - 1) * W * C * sizeof(float) <= 64 * 1024 && (int64_t)N * H * factor < (1ll << 31);
+}
+
 // factor 1 (the level of a concatenation that keeps its resolution: PSPNet's feature map, FPN's stride-4 branch): the gradient is the
 // channel slice [coff, coff + C) of dY copied (or added) back - 16-byte vectors, four in flight.  The generic gather kernel ran its 2 x 2
 // tap loops with integer divisions and 2-byte loads on it: 244 us for 151 MB (PSPNet 768 x 768 batch 8), 236 us for FPN's (round 5).
@@ -2298,6 +2416,8 @@ extern "C" size_t stp_resize_bilinear_bwd_workspace_bytes(int32_t N, int32_t H, 
   const int64_t npix = (int64_t)N * H * W;
   const int span = 2 * factor;
   size_t need = 0;
+  // the two-pass form for tiny maps (part[N][H * factor][W][C] fp32); sized for either 16-bit or fp32 vectors, any slice alignment
+  if (factor >= 8 && W <= RBT_MAXW && H <= 16) need = (size_t)N * H * factor * W * C * sizeof(float);
   for (int V = 4; V <= 8; V += 4) {
     const int cg = ceil_div(C, V);
     const int rps = split_rows(npix * ceil_div(cg, pool_vl(cg)), span, span);
@@ -2320,6 +2440,23 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
     if (V == 8) hipLaunchKernelGGL((slice_copy_kernel<bf16_t, 8>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, pixels, C, ldo, coff, accumulate);
     else if (dtype == STP_H16) hipLaunchKernelGGL((slice_copy_kernel<bf16_t, 4>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, pixels, C, ldo, coff, accumulate);
     else hipLaunchKernelGGL((slice_copy_kernel<float, 4>), dim3(g), dim3(256), 0, s, (const float*)dy, (float*)dx, pixels, C, ldo, coff, accumulate);
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
+  if (resize_bwd_tiny_ok(N, H, W, C, factor, ldo, coff, dtype) && workspace &&
+      workspace_bytes >= (size_t)N * H * factor * W * C * sizeof(float) && !(reinterpret_cast<uintptr_t>(dy) & 15)) {
+    // tiny map, large factor (pyramid levels): separable two-pass reduction, every byte of dY read once
+    const int ev = dtype == STP_H16 ? 8 : 4, cgv = C / ev, G = 256 / cgv;
+    const size_t lds = (size_t)(G - 1) * W * C * sizeof(float);
+    float* part = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(N * H * factor));
+    if (dtype == STP_H16) hipLaunchKernelGGL(resize_bilinear_bwd_tiny_rows_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)dy, part, H, W, C, factor, ldo, coff);
+    else hipLaunchKernelGGL(resize_bilinear_bwd_tiny_rows_kernel<float>, grid, dim3(256), lds, s, (const float*)dy, part, H, W, C, factor, ldo, coff);
+    STP_LAUNCH_CHECK();
+    const int g2 = (int)(((int64_t)N * H * W * (C / 4) + 3) / 4);
+    if (dtype == STP_H16) hipLaunchKernelGGL(resize_bilinear_bwd_tiny_cols_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, part, (bf16_t*)dx, N, H, W, C, factor, accumulate);
+    else hipLaunchKernelGGL(resize_bilinear_bwd_tiny_cols_kernel<float>, dim3(g2), dim3(256), 0, s, part, (float*)dx, N, H, W, C, factor, accumulate);
     STP_LAUNCH_CHECK();
     return STP_OK;
   }

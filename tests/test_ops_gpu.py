@@ -1718,7 +1718,9 @@ def test_batchnorm_apply_fused_with_the_max_pooling_behind_it(ops, case, dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 12, 24, 24, 24, 0, 8), (1, 16, 64, 8, 8, 0, 4), (2, 6, 10, 8, 24, 8, 2), (1, 9, 33, 16, 16, 0, 8),
-                                  (2, 5, 7, 16, 48, 16, 1), (1, 8, 8, 128, 320, 64, 1)])      # the last two: factor 1 = a channel slice copied / added back
+                                  (2, 5, 7, 16, 48, 16, 1), (1, 8, 8, 128, 320, 64, 1),       # factor 1 = a channel slice copied / added back
+                                  # tiny maps, large factors, a slice of a wide tensor (PSPNet's pyramid levels): the separable two-pass form
+                                  (2, 1, 1, 128, 320, 64, 32), (1, 2, 2, 512, 1024, 512, 16), (2, 3, 3, 64, 192, 128, 24), (1, 6, 6, 256, 256, 0, 8)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_bilinear_resize_gradient_of_class_logits_and_of_an_unresized_slice(ops, case, dtype):
     """Round 5: resize_bilinear_bwd_rows_kernel - the gradient of the x4 / x8 bilinear resize of class logits (channel count padded to
@@ -1738,7 +1740,9 @@ def test_bilinear_resize_gradient_of_class_logits_and_of_an_unresized_slice(ops,
     outs = []
     for acc in (0, 1, 1):
         dx = dev(base, dtype) if acc else torch.full((n, h, w, c), float("nan"), dtype=TD[dtype], device=DEV)
-        _lib.call("stp_resize_bilinear_bwd", ops.ptr(gd), ops.ptr(dx), n, h, w, c, f, ldo, coff, ops.dt(dx), acc, None, 0, ops.stream())
+        wsb = int(_lib.load().stp_resize_bilinear_bwd_workspace_bytes(n, h, w, c, f))
+        ws = keep(torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=DEV))
+        _lib.call("stp_resize_bilinear_bwd", ops.ptr(gd), ops.ptr(dx), n, h, w, c, f, ldo, coff, ops.dt(dx), acc, ops.ptr(ws) if wsb else None, wsb, ops.stream())
         want = ref + (base if acc else 0.0)
         np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
         outs.append(host(dx).copy())
