@@ -59,9 +59,10 @@ def kernel_key(name, meta, dtype):
         if tile == 768:   # the stem: persistent form (conv_sc_lean.hip) unless switched off
             return "conv_stem_lean_kernel" if os.environ.get("STP_STEM_LEAN", "1") != "0" else "conv_stem_kernel"
         if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows> (the profiler's name carries the epilogue variant as a 5th argument)
-            return "%s<%s>" % ("conv_halo_s2d_kernel" if meta.get("s2d") else "conv_halo_fold1_kernel" if meta.get("fold1") else
+            return "%s<%s>" % ("conv_halo_p64_kernel" if tile == 1029 else          # (p64: one workgroup per CU walks the tiles of a 64 -> 64 layer, weights in registers)
+                               "conv_halo_s2d_kernel" if meta.get("s2d") else "conv_halo_fold1_kernel" if meta.get("fold1") else
                                "conv_halo2_kernel" if meta.get("src2") else "conv_halo_kernel",      # (halo2: two sources / upsampled first source; s2d: space-to-depth data gradient of a stride-2 layer)
-                               ("16, 128, 2, 4", "8, 128, 2, 4", "16, 64, 1, 8", "8, 64, 2, 4", "32, 64, 1, 8")[tile - 1024])
+                               ("16, 128, 2, 4", "8, 128, 2, 4", "16, 64, 1, 8", "8, 64, 2, 4", "32, 64, 1, 8", "16, 64, 2, 4")[tile - 1024])
         if tile >= 256:  # buffer-DMA kernel, per-lane tap (small channel counts), 2 stages
             return "conv_igemm_ut_kernel<%s, %s, 2, false>" % (t, CONV_TILES[tile - 256])
         if tile >= 64:   # uniform-tap buffer-DMA kernel: tile = 32*STAGES + base tile

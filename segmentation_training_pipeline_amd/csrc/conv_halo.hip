@@ -42,6 +42,11 @@
 
 #define STP_OOB 0x80000000u
 #define HALO_NWST 4
+#if defined(STP_TIMING_REAL)   // scratch builds: the 100 MHz counter every CU shares (phase relations between workgroups) instead of the per-engine shader clock
+#define STP_CLOCK() __builtin_amdgcn_s_memrealtime()
+#else
+#define STP_CLOCK() __builtin_amdgcn_s_memtime()
+#endif
 
 // (f32x16 / mfma16_32x32x16: common.h)
 
@@ -358,8 +363,8 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a_in) {
   unsigned long long* const tdbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a_in.bias));
   a.bias = nullptr;
   unsigned long long tstamp[4];
-  tstamp[0] = __builtin_amdgcn_s_memtime();
-#define STP_STAMP(i) tstamp[i] = __builtin_amdgcn_s_memtime()
+  tstamp[0] = STP_CLOCK();
+#define STP_STAMP(i) tstamp[i] = STP_CLOCK()
 #else
   const ConvArgs& a = a_in;
 #define STP_STAMP(i)
@@ -711,12 +716,142 @@ __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_fold1_k
 template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_s2d_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true, 4>(a); }
 
+// ================================================================================================ persistent 64 -> 64 form (P64)
+// The 64 -> 64-channel layers at 128 x 128 (ResNet34 stage 1 forward + data gradient: 13 launches of the U-Net step) were the worst-placed
+// launches of the family: 39 us each against an HBM floor of 13 (67 MB) and an MFMA floor of 8.  The shared-clock timeline of the 16 x 16 x 64
+// tiles (scratch/r05/halo_phase.py, profiles/r05p_halo64_phase_timeline.txt) shows why: the two co-resident workgroups of a CU start together
+// and stay in LOCKSTEP - 512 workgroups fetch their halos (2.3 us, HBM busy, MFMA idle), 512 run their nine K-steps (7.3 us, HBM idle), 512
+// store (4.7 us, MFMA idle), and the second round repeats it.  Nothing of one phase ever runs under another.
+// Here ONE workgroup per CU walks its tiles (tile = round * workgroups + workgroup):
+//  * the layer's whole weight matrix is 64 x 576 x 2 = 72 KB: a wave's 32 channels x 576 are 144 registers of MFMA A fragments, loaded ONCE per
+//    workgroup from L2 - no weight ring, no LDS-DMA of weights, no barrier inside the K loop, and a K-step reads only its B fragments from LDS
+//    (8 waves x 72 KB per tile: half the LDS time of the 72 MFMAs per wave);
+//  * two slab buffers: the halo of tile i + 2 is requested (LDS-DMA) when the epilogue of tile i ends and has the K loop of tile i + 1 to land;
+//  * the epilogue stages through its OWN region of the LDS (2 x 41 + 68 = 150 KB), so its stores drain under the next tile's K loop.
+// Per tile a wave runs: K loop (72 MFMAs, reads two steps ahead) | vmcnt(0): the next slab has landed, barrier | epilogue_rm | request slab i + 2.
+// Shape: one directly read source, C0 == Cout == 64, 3 x 3 / stride 1 / pad 1, EP 0 - 2 (plain, statistics, BatchNormalization backward).
+template <int TH, int BM, int WM, int WN, int EP>
+__global__ __launch_bounds__(512, 1) void conv_halo_p64_kernel(const ConvArgs a_in) {
+  static_assert(TH == 16 && BM == 64 && WM == 2 && WN == 4 && EP <= 2, "the 64 -> 64 form");
+#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(STP_TIMING)   // scratch build: `bias` carries u64[4 * workgroups]: prologue, sum of the K loops, of the slab waits, of the epilogues (scratch/r05/p64_phase.py)
+  ConvArgs a = a_in;
+  unsigned long long* const tdbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a_in.bias));
+  a.bias = nullptr;
+  unsigned long long tsum[4] = {0, 0, 0, 0}, tlast = STP_CLOCK();
+#define P64_LAP(i) { const unsigned long long now_ = STP_CLOCK(); tsum[i] += now_ - tlast; tlast = now_; }
+#else
+  const ConvArgs& a = a_in;
+#define P64_LAP(i)
+#endif
+  typedef bf16_t T;
+  constexpr int TW = 16, HWD = TW + 2, HH = TH + 2, NHP = HH * HWD;
+  constexpr int NPASS = (NHP + 63) / 64;
+  constexpr int SROWS = (NHP + 7) / 8 * 8, SLAB = SROWS * 128;
+  constexpr int RW = TH / WN, TN = RW / 2;         // a wave: 32 channels x RW rows of 16 pixels = TN MFMA tiles
+  constexpr int PF = 2;                            // B fragments are read PF (tap, k-chunk) steps ahead of their MFMAs
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const stage = smem + 2 * SLAB;             // the epilogue's staged fp32 tile (+ its reduction scratch)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l15 = lane & 15, l31 = lane & 31, l4b = (lane >> 4) & 1, l5 = lane >> 5;
+  const int ntile = a.ntile_n, nwg = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, nwg);       // neighbouring tiles of a round share an L2
+  const int tx_n = a.Wo / TW, ty_n = a.Ho / TH, tpi = tx_n * ty_n;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
+
+  // slab pass p: halo pixel hp = p * 64 + tid / 8 at physical 16-byte slot tid & 7 = logical slot (tid & 7) ^ ((hx >> 1) & 7) (the main kernel's image)
+  const int prow = tid >> 3, pslot = tid & 7;
+  auto request_slab = [&](int tile, int buf) {
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / tx_n, tx = trem - ty * tx_n;
+    const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      if ((p * 64 + wave * 8) >= SROWS) continue;                      // wave-uniform: rows past the slab
+      const int hp = p * 64 + prow;
+      const int hy = hp / HWD, hx = hp - hy * HWD;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = hp < NHP && (unsigned)y < (unsigned)a.Hv && (unsigned)x < (unsigned)a.Wv;
+      const uint32_t off = ok ? (((uint32_t)(n * a.Hv + y) * (uint32_t)a.Wv + (uint32_t)x) * 64u + (uint32_t)((pslot ^ ((hx >> 1) & 7)) * 8)) * 2u : STP_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(smem + buf * SLAB + (p * 64 + wave * 8) * 128), 16, off, 0, 0, 0);
+    }
+  };
+  if (wg < ntile) request_slab(wg, 0);
+  if (wg + nwg < ntile) request_slab(wg + nwg, 1);
+
+  // the wave's A fragments: row wm * 32 + l31 of [64][a.K], elements tap * 64 + (kc * 2 + l5) * 8 .. + 8
+  u32x4 fa[9][4];
+  {
+    const T* const wrow = reinterpret_cast<const T*>(a.weight) + (size_t)(wm * 32 + l31) * a.K + l5 * 8;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) fa[t][kc] = *reinterpret_cast<const u32x4*>(wrow + t * 64 + kc * 16);
+  }
+  // B (pixels): halo pixel (wn * RW + 2 j + l4b + dy) * 18 + l15 + dx of the slab -> + (2 j + dy) * 2304 (immediate) + the buffer
+  uint32_t b_lane[3][4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hx = l15 + dx;
+      b_lane[dx][kc] = (uint32_t)(((wn * RW + l4b) * HWD + hx) * 128 + (((kc * 2 + l5) ^ ((hx >> 1) & 7)) << 4));
+    }
+
+  int buf = 0;
+  for (int tile = wg; tile < ntile; tile += nwg, buf ^= 1) {
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / tx_n, tx = trem - ty * tx_n;
+    const int y0 = ty * TH, x0 = tx * TW;
+    if (tile == wg) {                              // first tile: its slab (and the A fragments) have to be here; later ones were awaited below
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      P64_LAP(0);
+    }
+    f32x16 acc[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+    const char* const sb = smem + buf * SLAB;
+    u32x4 fb[PF + 1][TN];
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const u32x4*>(sb + b_lane[(q >> 2) % 3][q & 3] + (2 * j + (q >> 2) / 3) * (HWD * 128));
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+      if (q + PF < 36) {
+        const int t = (q + PF) >> 2, kc = (q + PF) & 3, dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[(q + PF) % (PF + 1)][j] = *reinterpret_cast<const u32x4*>(sb + b_lane[dx][kc] + (2 * j + dy) * (HWD * 128));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[0][j] = mfma16_32x32x16(fa[q >> 2][q & 3], fb[q % (PF + 1)][j], acc[0][j]);
+      __builtin_amdgcn_sched_barrier(0);           // (keeps the scheduler from hoisting the tile's 72 reads over the 144 resident A registers)
+    }
+    P64_LAP(1);
+    // the next tile's slab (requested one K loop ago) has landed: own pieces here, everyone's behind the epilogue's first barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P64_LAP(2);
+    epilogue_rm<TH, BM, WM, WN, EP>(a, acc, stage, n, y0, x0, 0, tile, wm, wn, lane, tid, wave);
+    // every wave has left this tile's K loop (the epilogue's barriers): its slab buffer takes the tile after the next
+    if (tile + 2 * nwg < ntile) request_slab(tile + 2 * nwg, buf);
+    P64_LAP(3);
+  }
+#if defined(STP_TIMING)
+  if (tid == 0)
+    for (int i = 0; i < 4; ++i) tdbg[(size_t)blockIdx.x * 4 + i] = tsum[i];
+#endif
+#endif
+}
+
 // ================================================================================================ host side
 struct HaloCfg { int th, bm; };
 // variant ids (stp_conv_params.tile = STP_TILE_HALO + id)
-static const HaloCfg HALO_CFGS[] = {{16, 128}, {8, 128}, {16, 64}, {8, 64}, {32, 64}};
+static const HaloCfg HALO_CFGS[] = {{16, 128}, {8, 128}, {16, 64}, {8, 64}, {32, 64}, {16, 64}};      // 5: the persistent 64 -> 64 form of variant 2
 #define STP_TILE_HALO 1024
-#define HALO_NCFG 5
+#define HALO_NCFG 6
 
 template <int TH, int BM, int WM, int WN, int EP>
 static int launch_halo_ep(ConvArgs& a, hipStream_t s) {
@@ -801,6 +936,46 @@ static bool halo_fold1_ok(const stp_conv_params* p) {
   return on && p->fold_src && p->fold_weight && p->fold_C >= 64 && (p->fold_C % 64) == 0 && p->C1 == 0 && p->src0_mode == STP_SRC_DIRECT &&
          !p->src_bn_mean && !p->dst_sum2x2 && !p->dst1 && p->Cd0 == p->Cout && !p->bias && !p->relu && !p->residual;
 }
+// persistent 64 -> 64 form (variant 5, conv_halo_p64_kernel; STP_HALO_P64=0 refuses it): one directly read source, C0 == Cout == 64, one
+// destination, no fused producer BatchNormalization, no 2 x 2-summed destination
+static bool halo_p64_ok(const stp_conv_params* p) {
+  static const bool on = !(getenv("STP_HALO_P64") && atoi(getenv("STP_HALO_P64")) == 0);
+  return on && p->C0 == 64 && p->C1 == 0 && p->Cout == 64 && p->Cd0 == 64 && !p->dst1 && p->src0_mode == STP_SRC_DIRECT && !p->fold_src && !p->s2d_dgrad &&
+         !p->src_bn_mean && !p->dst_sum2x2 && (p->Ho % 16) == 0;
+}
+static int halo_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+template <int EP>
+static int launch_halo_p64_ep(ConvArgs& a, hipStream_t s) {
+  constexpr int TH = 16, NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
+  const size_t lds = (size_t)2 * SROWS * 128 + (size_t)TH * 16 * (64 * 4 + 16);      // two slabs + the epilogue's staged tile: 150 KB
+  a.ntile_m = 1;
+  a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
+  auto kern = conv_halo_p64_kernel<16, 64, 2, 4, EP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STP_E_LAUNCH;
+    attr_set = true;
+  }
+  const int nwg = a.ntile_n < halo_cus() ? a.ntile_n : halo_cus();       // one workgroup per CU walks tile = round * nwg + workgroup
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, s, a);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+static int launch_halo_p64(ConvArgs& a, hipStream_t s) {
+  if (a.sum2x2 || a.pbn.mean) return STP_E_BADARG;
+  if (a.bnb.x) return launch_halo_p64_ep<2>(a, s);
+  if (a.stats) return launch_halo_p64_ep<1>(a, s);
+  return launch_halo_p64_ep<0>(a, s);
+}
+
 static bool halo_shape_ok(const stp_conv_params* p) {
   if (p && p->s2d_dgrad) return halo_s2d_ok(p);
   if (p && p->fold_src && !halo_fold1_ok(p)) return false;
@@ -845,6 +1020,10 @@ static int halo_auto(const stp_conv_params* p) {
     // several channel tiles over the same pixels (a data gradient into concatenated sources: 64 -> 192): 32 x 16 pixel tiles halve
     // the weight stream per pixel (scratch/halo_bench.py: 89 -> 81 us); one channel tile: no gain (35 us either way)
     if (p->Cout > 64 && (p->Ho % 32) == 0 && (int64_t)p->N * (p->Ho / 32) * (p->Wo / 16) * ceil_div(p->Cout, 64) >= 512) return 4;
+    static const int p64 = getenv("STP_HALO_P64") ? atoi(getenv("STP_HALO_P64")) : 0;      // (experiment: 1 = the persistent form wherever a CU gets two or more tiles)
+    if (p64 == 1 && halo_p64_ok(p) && px16 >= 2 * halo_cus()) return 5;
+    static const int v4 = getenv("STP_HALO_64V4") ? atoi(getenv("STP_HALO_64V4")) : 0;      // (experiment: 32-row tiles for one channel tile, too)
+    if (v4 == 1 && (p->Ho % 32) == 0 && (int64_t)p->N * (p->Ho / 32) * (p->Wo / 16) >= 512) return 4;
     if (px16 * ceil_div(p->Cout, 64) >= 512) return 2;
     if (px8 * ceil_div(p->Cout, 64) >= 512) return 3;
     return -1;
@@ -861,7 +1040,7 @@ extern "C" int stp_conv2d_halo_variant(const stp_conv_params* p) {
   int v = -1;
   if (p->tile >= STP_TILE_HALO && p->tile < STP_TILE_HALO + HALO_NCFG) {
     v = p->tile - STP_TILE_HALO;
-    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && (p->C0 != 64 || p->C1)) || (p->s2d_dgrad && v > 1)) return -1;
+    if (!halo_shape_ok(p) || (p->Ho % HALO_CFGS[v].th) || (v == 4 && (p->C0 != 64 || p->C1)) || (p->s2d_dgrad && v > 1) || (v == 5 && !halo_p64_ok(p))) return -1;
   } else if (p->tile == 0) {
     v = halo_auto(p);
   }
@@ -876,7 +1055,7 @@ extern "C" int stp_conv2d_halo_tiles(const stp_conv_params* p, int variant) {
 
 extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stream) {
   if (variant < 0 || variant >= HALO_NCFG || !halo_shape_ok(p) || (p->Ho % HALO_CFGS[variant].th) || (variant == 4 && (p->C0 != 64 || p->C1)) ||
-      (p->s2d_dgrad && variant > 1)) return STP_E_BADARG;
+      (p->s2d_dgrad && variant > 1) || (variant == 5 && !halo_p64_ok(p))) return STP_E_BADARG;
   ConvArgs a;
   bool c4;
   int ut;
@@ -908,6 +1087,7 @@ extern "C" int stp_conv2d_halo(const stp_conv_params* p, int variant, void* stre
     case 2: return launch_halo<16, 64, 1, 8>(a, s);    // wave: 64 channels x 2 rows
     case 3: return launch_halo<8, 64, 2, 4>(a, s);     // wave: 32 channels x 2 rows
     case 4: return launch_halo<32, 64, 1, 8>(a, s);    // wave: 64 channels x 4 rows; 64-channel inputs: the weights stream once per 512 pixels
+    case 5: return launch_halo_p64(a, s);              // wave: 32 channels x 4 rows, weights in registers, one workgroup per CU over its tiles
     default: return STP_E_BADARG;
   }
 }
