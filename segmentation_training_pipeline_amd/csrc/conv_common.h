@@ -41,6 +41,7 @@ struct ConvArgs {
   int fold_cpt;
   uint32_t bytes_fold, bytesw_fold;
   int no_rm;      // 1: keep the fragment-order epilogue (STP_IGEMM_RM=0: A/B of the row-major one)
+  int ep_generic; // 1: the halo kernel's epilogue takes its all-operands loop (STP_EPILOGUE_SPECIAL=0: A/B of the per-combination copies)
   int sum2x2;     // halo kernel, two destinations: dst0 = [N][Ho/2][Wo/2][Cd0] receives the 2 x 2 block sums of the first Cd0 channels (+ bnb)
   // group-level pre-reduction of the statistic columns (stp_conv_params.stats_group): see stats_group_finish
   float* sg_out;
@@ -521,6 +522,8 @@ static inline int fill_args(const stp_conv_params* p, ConvArgs& a, bool* c4_out,
   {
     static const int no_rm = (getenv("STP_IGEMM_RM") && atoi(getenv("STP_IGEMM_RM")) == 0) ? 1 : 0;
     a.no_rm = no_rm;
+    static const int ep_generic = (getenv("STP_EPILOGUE_SPECIAL") && atoi(getenv("STP_EPILOGUE_SPECIAL")) == 0) ? 1 : 0;
+    a.ep_generic = ep_generic;
   }
   a.stats = p->stats_partial;
   a.stat_slots = p->stats_slots;

@@ -39,6 +39,7 @@
 // sums): conv_common.h, shared with conv_igemm.hip.
 #include "conv_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define STP_OOB 0x80000000u
 #define HALO_NWST 4
@@ -86,13 +87,14 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 // Same arithmetic per element as conv_common.h's epilogue (sum g * xhat is accumulated as sum g * x and centred once per channel).
 // (f32x2v / unpack_bf16x2: conv_common.h)
 
-template <int TH, int BM, int WM, int WN, int EP>
+// NTH = threads of the workgroup (512; 256 in the persistent 64 -> 64 form)
+template <int TH, int BM, int WM, int WN, int EP, int NTH = 512>
 __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][TH / WN / 2], char* smem, int n, int y0, int x0,
                                             int cout0, int tile_n, int wm, int wn, int lane, int tid, int wave) {
   typedef bf16_t T;
   constexpr int CW = BM / WM, RW = TH / WN, TM = CW / 32, TN = RW / 2;
   constexpr int NPX = TH * 16, RS = BM * 4 + 16;          // staged row: BM floats + 16 bytes of padding
-  constexpr int CG = BM / 8, PP = 512 / CG, NP = NPX / PP;   // channel groups of 8, pixels per pass, passes
+  constexpr int CG = BM / 8, PP = NTH / CG, NP = NPX / PP;   // channel groups of 8, pixels per pass, passes
   static_assert(NPX % PP == 0, "tile pixels per pass");
   const int l15 = lane & 15, l4b = (lane >> 4) & 1, l5 = lane >> 5;
   const int c8 = tid % CG, p0 = tid / CG;
@@ -234,42 +236,84 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
       }
     }
     const bool relu = a.relu != 0;
+    const bool hb = EP != 2 && a.bias != nullptr, hr = EP != 2 && res != nullptr, hl = EP != 2 && relu;
     // activation window of the fused BatchNormalization (the gradient passes strictly inside it): t is "on" iff it equals its
     // clamp to [smallest positive number, below the upper bound] - one v_med3 + one compare instead of two compares + mask logic
     const float alo = a.bnb.relu ? __uint_as_float(1u) : -__builtin_inff();
     const float ahi = a.bnb.relu == 2 ? __uint_as_float(0x40bfffffu) : __builtin_inff();      // largest float below 6
+    // The optional operands (bias, residual, accumulate, ReLU) are LAUNCH-uniform.  As run-time conditions inside the element loop the
+    // compiler turned them into selects - every launch paid the adds, the unpacks and ~100 v_cndmask of all of them (the epilogue is
+    // VALU-issue bound: 560 - 1020 instructions per thread for 32 outputs, profiles/r05q_epilogue_instruction_counts.txt).  The loop is
+    // therefore instantiated per combination; the common ones (nothing / residual (+ ReLU) / accumulate) get their own copy.
+    auto passes = [&](auto hb_, auto hr_, auto ha_, auto hl_) {
+      constexpr bool HB = decltype(hb_)::value, HR = decltype(hr_)::value, HA = decltype(ha_)::value, HL = decltype(hl_)::value;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const int px = p0 + k * PP;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
-      f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
-      u32x4 o;
+      for (int k = 0; k < NP; ++k) {
+        const int px = p0 + k * PP;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
+        f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
+        u32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (EP != 2) {
-          v[e] += bias2[e];
-          if (res) v[e] += unpack_bf16x2(opr[k][e]);
+        for (int e = 0; e < 4; ++e) {
+          if (EP != 2) {
+            if (HB) v[e] += bias2[e];
+            if (HR) v[e] += unpack_bf16x2(opr[k][e]);
+          }
+          if (HA) v[e] += unpack_bf16x2(opa[k][e]);
+          if (EP != 2 && HL) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
+          o[e] = pack_bf16x2(v[e].x, v[e].y);
+          if (EP == 1) {
+            const f32x2v sv = unpack_bf16x2(o[e]);
+            ss[e] += sv;
+            qq[e] += sv * sv;
+          }
+          if (EP == 2) {
+            // dY as stored -> masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma)
+            const f32x2v xv = unpack_bf16x2(opr[k][e]), dy = unpack_bf16x2(o[e]);
+            const f32x2v tt = xv * ksc[e] + ksh[e];
+            const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+            ss[e] += g;
+            qq[e] += g * xv;
+            o[e] = pack_bf16x2(g.x, g.y);
+          }
         }
-        if (accum) v[e] += unpack_bf16x2(opa[k][e]);
-        if (EP != 2 && relu) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
-        o[e] = pack_bf16x2(v[e].x, v[e].y);
-        if (EP == 1) {
-          const f32x2v sv = unpack_bf16x2(o[e]);
-          ss[e] += sv;
-          qq[e] += sv * sv;
-        }
-        if (EP == 2) {
-          // dY as stored -> masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma)
-          const f32x2v xv = unpack_bf16x2(opr[k][e]), dy = unpack_bf16x2(o[e]);
-          const f32x2v tt = xv * ksc[e] + ksh[e];
-          const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
-          ss[e] += g;
-          qq[e] += g * xv;
-          o[e] = pack_bf16x2(g.x, g.y);
-        }
+        *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
       }
-      *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
-    }
+    };
+    // the rest: every operand behind its own (launch-uniform) test, as the one loop of the earlier rounds had it
+    auto passes_all = [&]() {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int px = p0 + k * PP;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
+        f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += bias2[e];
+          if (hr) v[e] += unpack_bf16x2(opr[k][e]);
+          if (accum) v[e] += unpack_bf16x2(opa[k][e]);
+          if (hl) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
+          o[e] = pack_bf16x2(v[e].x, v[e].y);
+          if (EP == 1) {
+            const f32x2v sv = unpack_bf16x2(o[e]);
+            ss[e] += sv;
+            qq[e] += sv * sv;
+          }
+        }
+        *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
+      }
+    };
+    typedef std::true_type Y_;
+    typedef std::false_type N_;
+    if (EP == 2) {                                  // (res = the BatchNormalization input: always read)
+      if (accum) passes(N_(), N_(), Y_(), N_()); else passes(N_(), N_(), N_(), N_());
+    } else if (a.ep_generic) passes_all();
+    else if (!hb && !hr && !accum && !hl) passes(N_(), N_(), N_(), N_());
+    else if (!hb && hr && !accum) { if (hl) passes(N_(), Y_(), N_(), Y_()); else passes(N_(), Y_(), N_(), N_()); }
+    else if (!hb && !hr && accum && !hl) passes(N_(), N_(), Y_(), N_());
+    else if (hb && !hr && !accum) { if (hl) passes(Y_(), N_(), N_(), Y_()); else passes(Y_(), N_(), N_(), N_()); }
+    else passes_all();
   }
 #if defined(STP_EXP) && STP_EXP == 31   // what-if: no cross-thread reduction / partial-sum stores (values kept live)
   if (EP >= 1 && a.P < 0) {
@@ -290,7 +334,7 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
     // per-wave table this replaces cost 4500-5600 cycles per workgroup, scratch/halo_timing.py): every thread writes its 16
     // partials [k][thread] (k = channel pair, sum / sum of squares), 512 threads sum 512 / NPART / CG of them each, NOUT threads
     // combine the NPART parts and store the tile's column of the [stat][channel][tile] partial sums.
-    constexpr int J = 512 / CG, NOUT = CG * 16, NPART = 512 / NOUT, JP = J / NPART, KS = 512 + CG;   // KS: conflict-free k stride
+    constexpr int J = NTH / CG, NOUT = CG * 16, NPART = NTH / NOUT, JP = J / NPART, KS = NTH + CG;   // KS: conflict-free k stride
     static_assert(NPART >= 1 && J % NPART == 0, "reduction shape");
     lds_barrier();                                          // the staged tile is dead
     float* r1 = reinterpret_cast<float*>(smem);               // [16][KS]
@@ -324,7 +368,7 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
     }
     if (d2s) return;                                            // (launch-uniform; no group-level pre-reduction in this form)
     // group-level pre-reduction (conv_common.h): the last workgroup of every G tiles brings the table under 128 columns
-    stats_group_finish<512>(a, EP == 3 ? a.Cd0 : a.Cout, cout0, BM, cout0 / BM, tile_n, a.ntile_n, tid, reinterpret_cast<unsigned*>(smem));
+    stats_group_finish<NTH>(a, EP == 3 ? a.Cd0 : a.Cout, cout0, BM, cout0 / BM, tile_n, a.ntile_n, tid, reinterpret_cast<unsigned*>(smem));
   }
 }
 
@@ -717,37 +761,45 @@ template <int TH, int BM, int WM, int WN, int EP>
 __global__ __launch_bounds__(512, HALO_MIN_WAVES(TH, BM)) void conv_halo_s2d_kernel(const ConvArgs a) { conv_halo_body<TH, BM, WM, WN, EP, false, true, 4>(a); }
 
 // ================================================================================================ persistent 64 -> 64 form (P64)
-// The 64 -> 64-channel layers at 128 x 128 (ResNet34 stage 1 forward + data gradient: 13 launches of the U-Net step) were the worst-placed
+// The 64 -> 64-channel layers at 128 x 128 (ResNet34 stage 1 forward + data gradient: 13 launches of the U-Net step) are the worst-placed
 // launches of the family: 39 us each against an HBM floor of 13 (67 MB) and an MFMA floor of 8.  The shared-clock timeline of the 16 x 16 x 64
 // tiles (scratch/r05/halo_phase.py, profiles/r05p_halo64_phase_timeline.txt) shows why: the two co-resident workgroups of a CU start together
 // and stay in LOCKSTEP - 512 workgroups fetch their halos (2.3 us, HBM busy, MFMA idle), 512 run their nine K-steps (7.3 us, HBM idle), 512
-// store (4.7 us, MFMA idle), and the second round repeats it.  Nothing of one phase ever runs under another.
-// Here ONE workgroup per CU walks its tiles (tile = round * workgroups + workgroup):
-//  * the layer's whole weight matrix is 64 x 576 x 2 = 72 KB: a wave's 32 channels x 576 are 144 registers of MFMA A fragments, loaded ONCE per
-//    workgroup from L2 - no weight ring, no LDS-DMA of weights, no barrier inside the K loop, and a K-step reads only its B fragments from LDS
-//    (8 waves x 72 KB per tile: half the LDS time of the 72 MFMAs per wave);
+// store (4.7 us, MFMA idle), and the second round repeats it.  Nothing of one phase ever runs under another; and with K = 576 the epilogue of
+// a tile (staging, rounding, sums: VALU + LDS) costs about what its 72 MFMAs per wave do.
+// Here TWO 4-wave workgroups per CU (one wave per SIMD each) walk 8 x 16-pixel tiles (tile = round * workgroups + workgroup), half a tile apart:
+//  * the layer's whole weight matrix is 64 x 576 x 2 = 72 KB: a wave's 32 channels x 576 are 144 registers of MFMA A fragments, fetched ONCE per
+//    workgroup (LDS-DMA into the not yet used slab / staging space, then ds_read) - no weight ring, no LDS-DMA of weights and no barrier inside
+//    the K loop, and a K-step reads only its B fragments from LDS;
 //  * two slab buffers: the halo of tile i + 2 is requested (LDS-DMA) when the epilogue of tile i ends and has the K loop of tile i + 1 to land;
-//  * the epilogue stages through its OWN region of the LDS (2 x 41 + 68 = 150 KB), so its stores drain under the next tile's K loop.
-// Per tile a wave runs: K loop (72 MFMAs, reads two steps ahead) | vmcnt(0): the next slab has landed, barrier | epilogue_rm | request slab i + 2.
+//  * the epilogue stages through its OWN region of the LDS (2 x 23 + 34 = 80 KB per workgroup, 160 KB per CU), its stores drain under the next
+//    K loop - and while one workgroup of the CU is in its epilogue (VALU, LDS, HBM) the other has the MFMA pipes to itself: the workgroups of
+//    the second slot start STP_P64_STAGGER x ~0.4 us late and the two stay out of phase from there.
+// Per tile a wave runs: K loop (72 MFMAs, reads PF steps ahead) | vmcnt(0): the next slab has landed | epilogue_rm (barriers) | request slab i + 2.
 // Shape: one directly read source, C0 == Cout == 64, 3 x 3 / stride 1 / pad 1, EP 0 - 2 (plain, statistics, BatchNormalization backward).
+#if !defined(STP_P64_STAGGER)
+#define STP_P64_STAGGER 4
+#endif
 template <int TH, int BM, int WM, int WN, int EP>
-__global__ __launch_bounds__(512, 1) void conv_halo_p64_kernel(const ConvArgs a_in) {
-  static_assert(TH == 16 && BM == 64 && WM == 2 && WN == 4 && EP <= 2, "the 64 -> 64 form");
+__global__ __launch_bounds__(256, 2) void conv_halo_p64_kernel(const ConvArgs a_in) {
+  static_assert(TH == 8 && BM == 64 && WM == 2 && WN == 2 && EP <= 2, "the 64 -> 64 form");
 #if defined(__HIP_DEVICE_COMPILE__)
 #if defined(STP_TIMING)   // scratch build: `bias` carries u64[4 * workgroups]: prologue, sum of the K loops, of the slab waits, of the epilogues (scratch/r05/p64_phase.py)
   ConvArgs a = a_in;
   unsigned long long* const tdbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a_in.bias));
   a.bias = nullptr;
   unsigned long long tsum[4] = {0, 0, 0, 0}, tlast = STP_CLOCK();
+  const unsigned long long tfirst = tlast;
 #define P64_LAP(i) { const unsigned long long now_ = STP_CLOCK(); tsum[i] += now_ - tlast; tlast = now_; }
 #else
   const ConvArgs& a = a_in;
 #define P64_LAP(i)
 #endif
   typedef bf16_t T;
+  constexpr int NTH = 256;
   constexpr int TW = 16, HWD = TW + 2, HH = TH + 2, NHP = HH * HWD;
-  constexpr int NPASS = (NHP + 63) / 64;
   constexpr int SROWS = (NHP + 7) / 8 * 8, SLAB = SROWS * 128;
+  constexpr int NPASS = (SROWS + 31) / 32;         // 32 halo pixels (8 per wave) per pass of the 256 threads
   constexpr int RW = TH / WN, TN = RW / 2;         // a wave: 32 channels x RW rows of 16 pixels = TN MFMA tiles
   constexpr int PF = 2;                            // B fragments are read PF (tap, k-chunk) steps ahead of their MFMAs
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -759,36 +811,50 @@ __global__ __launch_bounds__(512, 1) void conv_halo_p64_kernel(const ConvArgs a_
   const int ntile = a.ntile_n, nwg = gridDim.x;
   const int wg = xcd_remap(blockIdx.x, nwg);       // neighbouring tiles of a round share an L2
   const int tx_n = a.Wo / TW, ty_n = a.Ho / TH, tpi = tx_n * ty_n;
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
-
-  // slab pass p: halo pixel hp = p * 64 + tid / 8 at physical 16-byte slot tid & 7 = logical slot (tid & 7) ^ ((hx >> 1) & 7) (the main kernel's image)
   const int prow = tid >> 3, pslot = tid & 7;
+
+  if (STP_P64_STAGGER > 0 && (int)blockIdx.x >= (nwg >> 1)) {          // second slot of a CU: half a tile behind the first
+    for (int i = 0; i < STP_P64_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  // ---- the weights, once: [tap][64 rows][128 bytes] (the main kernel's swizzled stage image) over the slab + staging space -> A fragments
+  {
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, a.bytesw, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {                  // pass i: rows (i & 1) * 32 + tid / 8 of tap i / 2
+      const int r = (i & 1) * 32 + prow;
+      const uint32_t off = ((uint32_t)r * (uint32_t)a.K + (uint32_t)((pslot ^ ((r >> 1) & 7)) * 8)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + (i * 32 + wave * 8) * 128), 16, off, (uint32_t)(i >> 1) * 128u, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  u32x4 fa[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+      fa[t][kc] = *reinterpret_cast<const u32x4*>(smem + (t * 64 + wm * 32 + l31) * 128 + (((kc * 2 + l5) ^ ((l31 >> 1) & 7)) << 4));
+  lds_barrier();                                   // every wave holds its fragments: the space is free for the slabs
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
+  // slab pass p: halo pixel hp = p * 32 + tid / 8 at physical 16-byte slot tid & 7 = logical slot (tid & 7) ^ ((hx >> 1) & 7) (the main kernel's image)
   auto request_slab = [&](int tile, int buf) {
     const int n = tile / tpi, trem = tile - n * tpi, ty = trem / tx_n, tx = trem - ty * tx_n;
     const int y0 = ty * TH, x0 = tx * TW;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      if ((p * 64 + wave * 8) >= SROWS) continue;                      // wave-uniform: rows past the slab
-      const int hp = p * 64 + prow;
+      if ((p * 32 + wave * 8) >= SROWS) continue;                      // wave-uniform: rows past the slab
+      const int hp = p * 32 + prow;
       const int hy = hp / HWD, hx = hp - hy * HWD;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = hp < NHP && (unsigned)y < (unsigned)a.Hv && (unsigned)x < (unsigned)a.Wv;
       const uint32_t off = ok ? (((uint32_t)(n * a.Hv + y) * (uint32_t)a.Wv + (uint32_t)x) * 64u + (uint32_t)((pslot ^ ((hx >> 1) & 7)) * 8)) * 2u : STP_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(smem + buf * SLAB + (p * 64 + wave * 8) * 128), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(smem + buf * SLAB + (p * 32 + wave * 8) * 128), 16, off, 0, 0, 0);
     }
   };
   if (wg < ntile) request_slab(wg, 0);
   if (wg + nwg < ntile) request_slab(wg + nwg, 1);
 
-  // the wave's A fragments: row wm * 32 + l31 of [64][a.K], elements tap * 64 + (kc * 2 + l5) * 8 .. + 8
-  u32x4 fa[9][4];
-  {
-    const T* const wrow = reinterpret_cast<const T*>(a.weight) + (size_t)(wm * 32 + l31) * a.K + l5 * 8;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) fa[t][kc] = *reinterpret_cast<const u32x4*>(wrow + t * 64 + kc * 16);
-  }
   // B (pixels): halo pixel (wn * RW + 2 j + l4b + dy) * 18 + l15 + dx of the slab -> + (2 j + dy) * 2304 (immediate) + the buffer
   uint32_t b_lane[3][4];
 #pragma unroll
@@ -803,7 +869,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_p64_kernel(const ConvArgs a_
   for (int tile = wg; tile < ntile; tile += nwg, buf ^= 1) {
     const int n = tile / tpi, trem = tile - n * tpi, ty = trem / tx_n, tx = trem - ty * tx_n;
     const int y0 = ty * TH, x0 = tx * TW;
-    if (tile == wg) {                              // first tile: its slab (and the A fragments) have to be here; later ones were awaited below
+    if (tile == wg) {                              // first tile: its slab has to be here; later ones were awaited below
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       P64_LAP(0);
@@ -834,14 +900,18 @@ __global__ __launch_bounds__(512, 1) void conv_halo_p64_kernel(const ConvArgs a_
     // the next tile's slab (requested one K loop ago) has landed: own pieces here, everyone's behind the epilogue's first barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P64_LAP(2);
-    epilogue_rm<TH, BM, WM, WN, EP>(a, acc, stage, n, y0, x0, 0, tile, wm, wn, lane, tid, wave);
+    epilogue_rm<TH, BM, WM, WN, EP, NTH>(a, acc, stage, n, y0, x0, 0, tile, wm, wn, lane, tid, wave);
     // every wave has left this tile's K loop (the epilogue's barriers): its slab buffer takes the tile after the next
     if (tile + 2 * nwg < ntile) request_slab(tile + 2 * nwg, buf);
     P64_LAP(3);
   }
 #if defined(STP_TIMING)
-  if (tid == 0)
-    for (int i = 0; i < 4; ++i) tdbg[(size_t)blockIdx.x * 4 + i] = tsum[i];
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) tdbg[(size_t)blockIdx.x * 8 + i] = tsum[i];
+    tdbg[(size_t)blockIdx.x * 8 + 4] = tfirst;
+    tdbg[(size_t)blockIdx.x * 8 + 5] = tlast;
+    tdbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID: wave / SIMD / CU / SE / XCC ids
+  }
 #endif
 #endif
 }
@@ -849,7 +919,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_p64_kernel(const ConvArgs a_
 // ================================================================================================ host side
 struct HaloCfg { int th, bm; };
 // variant ids (stp_conv_params.tile = STP_TILE_HALO + id)
-static const HaloCfg HALO_CFGS[] = {{16, 128}, {8, 128}, {16, 64}, {8, 64}, {32, 64}, {16, 64}};      // 5: the persistent 64 -> 64 form of variant 2
+static const HaloCfg HALO_CFGS[] = {{16, 128}, {8, 128}, {16, 64}, {8, 64}, {32, 64}, {8, 64}};       // 5: the persistent 64 -> 64 form (8 x 16-pixel tiles, two 4-wave workgroups per CU)
 #define STP_TILE_HALO 1024
 #define HALO_NCFG 6
 
@@ -941,7 +1011,7 @@ static bool halo_fold1_ok(const stp_conv_params* p) {
 static bool halo_p64_ok(const stp_conv_params* p) {
   static const bool on = !(getenv("STP_HALO_P64") && atoi(getenv("STP_HALO_P64")) == 0);
   return on && p->C0 == 64 && p->C1 == 0 && p->Cout == 64 && p->Cd0 == 64 && !p->dst1 && p->src0_mode == STP_SRC_DIRECT && !p->fold_src && !p->s2d_dgrad &&
-         !p->src_bn_mean && !p->dst_sum2x2 && (p->Ho % 16) == 0;
+         !p->src_bn_mean && !p->dst_sum2x2 && (p->Ho % 8) == 0;
 }
 static int halo_cus() {
   static int n = 0;
@@ -954,18 +1024,20 @@ static int halo_cus() {
 }
 template <int EP>
 static int launch_halo_p64_ep(ConvArgs& a, hipStream_t s) {
-  constexpr int TH = 16, NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
-  const size_t lds = (size_t)2 * SROWS * 128 + (size_t)TH * 16 * (64 * 4 + 16);      // two slabs + the epilogue's staged tile: 150 KB
+  constexpr int TH = 8, NHP = (TH + 2) * 18, SROWS = (NHP + 7) / 8 * 8;
+  const size_t lds = (size_t)2 * SROWS * 128 + (size_t)TH * 16 * (64 * 4 + 16);      // two slabs + the epilogue's staged tile: 80 KB, two workgroups per CU
+  static_assert(2 * SROWS * 128 + TH * 16 * (64 * 4 + 16) >= 9 * 64 * 128, "the weight image fits the workgroup's LDS");
   a.ntile_m = 1;
   a.ntile_n = a.N * (a.Ho / TH) * (a.Wo / 16);
-  auto kern = conv_halo_p64_kernel<16, 64, 2, 4, EP>;
+  auto kern = conv_halo_p64_kernel<8, 64, 2, 2, EP>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return STP_E_LAUNCH;
     attr_set = true;
   }
-  const int nwg = a.ntile_n < halo_cus() ? a.ntile_n : halo_cus();       // one workgroup per CU walks tile = round * nwg + workgroup
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, s, a);
+  const int slots = 2 * halo_cus();
+  const int nwg = a.ntile_n < slots ? a.ntile_n : slots;       // two workgroups per CU walk tile = round * nwg + workgroup
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }
@@ -1021,7 +1093,7 @@ static int halo_auto(const stp_conv_params* p) {
     // the weight stream per pixel (scratch/halo_bench.py: 89 -> 81 us); one channel tile: no gain (35 us either way)
     if (p->Cout > 64 && (p->Ho % 32) == 0 && (int64_t)p->N * (p->Ho / 32) * (p->Wo / 16) * ceil_div(p->Cout, 64) >= 512) return 4;
     static const int p64 = getenv("STP_HALO_P64") ? atoi(getenv("STP_HALO_P64")) : 0;      // (experiment: 1 = the persistent form wherever a CU gets two or more tiles)
-    if (p64 == 1 && halo_p64_ok(p) && px16 >= 2 * halo_cus()) return 5;
+    if (p64 == 1 && halo_p64_ok(p) && px8 >= 4 * halo_cus()) return 5;      // (two or more tiles per workgroup)
     static const int v4 = getenv("STP_HALO_64V4") ? atoi(getenv("STP_HALO_64V4")) : 0;      // (experiment: 32-row tiles for one channel tile, too)
     if (v4 == 1 && (p->Ho % 32) == 0 && (int64_t)p->N * (p->Ho / 32) * (p->Wo / 16) >= 512) return 4;
     if (px16 * ceil_div(p->Cout, 64) >= 512) return 2;

@@ -488,7 +488,7 @@ HALO_CASES = [
     (1, 32, 16, 64, 64, 2), (2, 16, 16, 192, 64, 2),
     (2, 8, 32, 128, 64, 3), (1, 24, 16, 512, 64, 3),
     (1, 32, 32, 64, 64, 4), (2, 64, 16, 64, 80, 4),           # 32x16 pixels x 64 channels: 64-channel inputs only
-    # 5 = the persistent 64 -> 64 form (conv_halo_p64_kernel: one workgroup per CU walks its tiles): 2 tiles; 18; 320 = a second, ragged round
+    # 5 = the persistent 64 -> 64 form (conv_halo_p64_kernel: two 4-wave workgroups per CU walk 8 x 16-pixel tiles): 4 tiles; 36; 640 = a second, ragged round
     (1, 32, 16, 64, 64, 5), (3, 48, 32, 64, 64, 5), (5, 128, 128, 64, 64, 5),
 ]
 
@@ -519,7 +519,7 @@ def test_conv_halo_kernel_forward_statistics_residual(ops, case, dtype):
     ops.conv2d(mk(y2, 69))                                                   # per-tap DMA kernel, 64x64 tile
     np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
     np.testing.assert_allclose(host(y), host(y2), atol=tol(ref, dtype))
-    th = {0: 16, 1: 8, 2: 16, 3: 8, 4: 32, 5: 16}[var]
+    th = {0: 16, 1: 8, 2: 16, 3: 8, 4: 32, 5: 8}[var]
     tiles = ops.conv2d_stats_floats(P) // (2 * co)
     assert tiles == P.stats_tiles == n * (h // th) * (w // 16)
     rows = n * h * w
@@ -715,7 +715,7 @@ def test_conv_halo_kernel_fused_producer_batchnorm(ops, case, dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 0), (2, 8, 16, 64, 256, 1), (1, 32, 16, 128, 64, 2), (2, 8, 32, 64, 64, 3),
-                                  (2, 32, 32, 64, 64, 5), (6, 128, 112, 64, 64, 5)])      # (5: persistent 64 -> 64 form; 336 tiles = two rounds)
+                                  (2, 32, 32, 64, 64, 5), (6, 128, 112, 64, 64, 5)])      # (5: persistent 64 -> 64 form; 672 tiles = two rounds)
 @pytest.mark.parametrize("relu", [1, 0, 3])
 @pytest.mark.parametrize("dtype", H16)
 def test_conv_halo_kernel_batchnorm_backward_sums(ops, case, relu, dtype):
