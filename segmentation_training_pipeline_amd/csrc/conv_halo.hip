@@ -246,6 +246,8 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
     // VALU-issue bound: 560 - 1020 instructions per thread for 32 outputs, profiles/r05q_epilogue_instruction_counts.txt).  The loop is
     // therefore instantiated per combination; the common ones (nothing / residual (+ ReLU) / accumulate) get their own copy.
     auto passes = [&](auto hb_, auto hr_, auto ha_, auto hl_) {
+      // (EP 2: HL = "the fused activation is a plain ReLU" - the gradient passes iff the re-derived output is > 0: one compare instead of
+      //  clamp + compare; identical decisions: the clamp window of ReLU is [smallest positive number, inf])
       constexpr bool HB = decltype(hb_)::value, HR = decltype(hr_)::value, HA = decltype(ha_)::value, HL = decltype(hl_)::value;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
@@ -261,20 +263,23 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
           }
           if (HA) v[e] += unpack_bf16x2(opa[k][e]);
           if (EP != 2 && HL) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
-          o[e] = pack_bf16x2(v[e].x, v[e].y);
+          if (EP != 2) o[e] = pack_bf16x2(v[e].x, v[e].y);
           if (EP == 1) {
             const f32x2v sv = unpack_bf16x2(o[e]);
             ss[e] += sv;
             qq[e] += sv * sv;
           }
           if (EP == 2) {
-            // dY as stored -> masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma)
-            const f32x2v xv = unpack_bf16x2(opr[k][e]), dy = unpack_bf16x2(o[e]);
+            // masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma), rounded ONCE:
+            // round(on ? dY : 0) = on ? round(dY) : 0; the sums take the values as stored
+            const f32x2v xv = unpack_bf16x2(opr[k][e]);
             const f32x2v tt = xv * ksc[e] + ksh[e];
-            const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+            const bool on0 = HL ? tt.x > 0.f : __builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x;
+            const bool on1 = HL ? tt.y > 0.f : __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y;
+            o[e] = pack_bf16x2(on0 ? v[e].x : 0.f, on1 ? v[e].y : 0.f);
+            const f32x2v g = unpack_bf16x2(o[e]);
             ss[e] += g;
             qq[e] += g * xv;
-            o[e] = pack_bf16x2(g.x, g.y);
           }
         }
         *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
@@ -307,7 +312,9 @@ __device__ __forceinline__ void epilogue_rm(const ConvArgs& a, f32x16 (&acc)[BM 
     typedef std::true_type Y_;
     typedef std::false_type N_;
     if (EP == 2) {                                  // (res = the BatchNormalization input: always read)
-      if (accum) passes(N_(), N_(), Y_(), N_()); else passes(N_(), N_(), N_(), N_());
+      const bool r1 = a.bnb.relu == 1 && !a.ep_generic;
+      if (accum) { if (r1) passes(N_(), N_(), Y_(), Y_()); else passes(N_(), N_(), Y_(), N_()); }
+      else { if (r1) passes(N_(), N_(), N_(), Y_()); else passes(N_(), N_(), N_(), N_()); }
     } else if (a.ep_generic) passes_all();
     else if (!hb && !hr && !accum && !hl) passes(N_(), N_(), N_(), N_());
     else if (!hb && hr && !accum) { if (hl) passes(N_(), Y_(), N_(), Y_()); else passes(N_(), Y_(), N_(), N_()); }
