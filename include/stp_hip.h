@@ -426,6 +426,16 @@ int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W
 /* The same when dx is the gradient of a BatchNormalization(+activation) output that this launch completes: the stored value
  * is masked with the activation re-derived from the BN input bn_x and `partial` ([2][C][tiles], tiles from the query; 0 =
  * channel count not supported) receives the sums stp_bn_backward_fused consumes - see stp_conv_params.bnb_x. */
+/* Second half of the data gradient of a 1x1 / stride-2 convolution (reference: the projection shortcut `sc` of
+ * classification_models' bottleneck ResNets, reached through segmentation.py:109-118): t = W^T dY is computed at LOW resolution by a plain
+ * 1x1 / stride-1 stp_conv2d; stp_scatter2x_bwd puts t[n, a, b] at (2a, 2b) of dx [N, H, W, C] (zeros elsewhere; accumulate != 0: dx +=).
+ * The _bn form completes the gradient of a BatchNormalization(+activation) output as stp_maxpool3x3s2_bwd_bn does: masked in place,
+ * partial[2][C][stp_scatter2x_bwd_bn_tiles] for stp_bn_backward_fused. */
+int stp_scatter2x_bwd(const void* t, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate, void* stream);
+int stp_scatter2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype);
+int stp_scatter2x_bwd_bn(const void* t, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate,
+                         const void* bn_x, const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu,
+                         float* partial, void* stream);
 int stp_upsample2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype);
 int stp_upsample2x_bwd_bn(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldy, int32_t dtype,
                           int32_t accumulate, const void* bn_x, const float* mean, const float* rstd, const float* gamma,

@@ -1553,6 +1553,128 @@ extern "C" int stp_maxpool3x3s2_bwd_bn(const uint8_t* idx, const void* dy, void*
 }
 
 // ------------------------------------------------------------------------------------------
+// Data gradient of a 1x1 / stride-2 convolution (the projection shortcut of a bottleneck ResNet's first unit), second half: the GEMM
+// t = W^T dY runs at LOW resolution ([N, Ho, Wo, C], a plain 1x1 / stride-1 launch); this pass puts t[n, a, b] at (2a, 2b) of the
+// [N, H, W, C] gradient - zeros elsewhere, or on top of what the tensor's other consumers wrote (accumulate) - and, when it completes the
+// gradient of a BatchNormalization(+activation) output, masks it and reduces the backward sums (bnb_mask_store / bnb_reduce, as the
+// max-pool gather above).  The zero-inserted form it replaces ran the GEMM over all four parity classes of the high-resolution grid:
+// 229 us for 256 <- 512 channels at 4 x 256 x 256 (FPN/ResNet50), 3.4 x its memory floor.
+template <typename T, int V, bool BNB>
+__global__ __launch_bounds__(256) void scatter2x_bwd_kernel(const T* __restrict__ t, T* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo,
+                                                            int accumulate, BnBack bnb, float* __restrict__ partial) {
+  const int cg = C / V;
+  const int tt = blockIdx.x * 256 + threadIdx.x;
+  const bool on = tt < W * cg;
+  if (!BNB && !on) return;
+  const int w = on ? tt / cg : 0, c = on ? (tt - w * cg) * V : 0;
+  constexpr int ROWS = BNB ? BNB_ROWS : POOL_ROWS;
+  constexpr int RB = 4;                                 // rows requested together: one memory round trip per RB rows, not per row
+  static_assert(ROWS % RB == 0, "row batches");
+  float sg[V], sq[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { sg[e] = 0.f; sq[e] = 0.f; }
+  BnBackCh kc[V / 4];
+  if constexpr (BNB) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) kc[q] = bnback_load(bnb, c + 4 * q);
+  }
+  const bool wev = !(w & 1) && (w >> 1) < Wo;
+  for (int r0 = 0; r0 < ROWS; r0 += RB) {
+    float g[RB][V], o[RB][V], xv[RB][V];
+    bool live[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int row = blockIdx.y * ROWS + r0 + j;
+      live[j] = on && row < N * H;
+      const int n = live[j] ? row / H : 0, h = live[j] ? row - n * H : 0;
+      const size_t oo = (((size_t)n * H + h) * W + w) * C + c;
+      const bool hit = live[j] && wev && !(h & 1) && (h >> 1) < Ho;
+      if (!BNB && accumulate && !hit) live[j] = false;   // nothing to add there, nothing to mask: the position keeps what it holds
+#pragma unroll
+      for (int e = 0; e < V; ++e) g[j][e] = o[j][e] = xv[j][e] = 0.f;
+      if (hit) ldv<T, V>(t + (((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c, g[j]);
+      if (live[j] && accumulate) ldv<T, V>(dx + oo, o[j]);
+      if (BNB && live[j]) ldv<T, V>(reinterpret_cast<const T*>(bnb.x) + oo, xv[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      if (!live[j]) continue;
+      const int row = blockIdx.y * ROWS + r0 + j;
+      const int n = row / H, h = row - n * H;
+      const size_t oo = (((size_t)n * H + h) * W + w) * C + c;
+#pragma unroll
+      for (int e = 0; e < V; ++e) g[j][e] += o[j][e];
+      if constexpr (BNB) {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+          const f32x4 st = stored4(f32x4{g[j][4 * q], g[j][4 * q + 1], g[j][4 * q + 2], g[j][4 * q + 3]}, (const T*)nullptr);
+          f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 m = bnback_apply(kc[q], bnb.relu, f32x4{xv[j][4 * q], xv[j][4 * q + 1], xv[j][4 * q + 2], xv[j][4 * q + 3]}, st, s4, q4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { g[j][4 * q + e] = m[e]; sg[4 * q + e] += s4[e]; sq[4 * q + e] += q4[e]; }
+        }
+      }
+      stv<T, V>(dx + oo, g[j]);
+    }
+  }
+  if constexpr (BNB) bnb_reduce<V>(sg, sq, cg, C, partial);
+}
+
+static int scatter2x_bwd_launch(const void* t, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate,
+                                const BnBack* bnb, float* partial, hipStream_t s) {
+  if (!t || !dx || (C & 3) || N <= 0 || H <= 0 || W <= 0) return STP_E_BADARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if ((int64_t)N * H > 65535 * (int64_t)(bnb ? BNB_ROWS : POOL_ROWS)) return STP_E_BADARG;      // gridDim.y
+  const bool v8 = dtype == STP_H16 && (C & 7) == 0;
+  const int V = v8 ? 8 : 4;
+  BnBack none;
+  none.x = nullptr; none.mean = none.rstd = none.gamma = none.beta = nullptr; none.relu = 0;
+  if (bnb) {
+    if (256 % (C / V) != 0 || !partial) return STP_E_BADARG;
+    const size_t lds = 256 * 2 * V * sizeof(float);
+    const dim3 grid(ceil_div(W * (C / V), 256), ceil_div(N * H, BNB_ROWS));
+    if (v8) hipLaunchKernelGGL((scatter2x_bwd_kernel<bf16_t, 8, true>), grid, dim3(256), lds, s, (const bf16_t*)t, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((scatter2x_bwd_kernel<bf16_t, 4, true>), grid, dim3(256), lds, s, (const bf16_t*)t, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
+    else if (dtype == STP_F32) hipLaunchKernelGGL((scatter2x_bwd_kernel<float, 4, true>), grid, dim3(256), lds, s, (const float*)t, (float*)dx, N, H, W, C, Ho, Wo, accumulate, *bnb, partial);
+    else return STP_E_BADARG;
+  } else {
+    const dim3 grid(ceil_div(W * (C / V), 256), ceil_div(N * H, POOL_ROWS));
+    if (v8) hipLaunchKernelGGL((scatter2x_bwd_kernel<bf16_t, 8, false>), grid, dim3(256), 0, s, (const bf16_t*)t, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
+    else if (dtype == STP_H16) hipLaunchKernelGGL((scatter2x_bwd_kernel<bf16_t, 4, false>), grid, dim3(256), 0, s, (const bf16_t*)t, (bf16_t*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
+    else if (dtype == STP_F32) hipLaunchKernelGGL((scatter2x_bwd_kernel<float, 4, false>), grid, dim3(256), 0, s, (const float*)t, (float*)dx, N, H, W, C, Ho, Wo, accumulate, none, nullptr);
+    else return STP_E_BADARG;
+  }
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// t: [N, (H - 1) / 2 + 1, (W - 1) / 2 + 1, C]; dx: [N, H, W, C].  accumulate != 0: dx += the scattered t (odd positions untouched).
+extern "C" int stp_scatter2x_bwd(const void* t, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  return scatter2x_bwd_launch(t, dx, N, H, W, C, dtype, accumulate, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// columns of the [2][C][tiles] partial table of stp_scatter2x_bwd_bn (H, W = the HIGH-resolution size); 0 = unsupported C
+extern "C" int stp_scatter2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  const int V = (dtype == STP_H16 && (C & 7) == 0) ? 8 : 4;
+  if (C <= 0 || (C & 3) || 256 % (C / V) != 0) return 0;
+  return ceil_div(W * (C / V), 256) * ceil_div(N * H, BNB_ROWS);
+}
+
+// ... and the completed gradient masked with the activation of the BatchNormalization whose output the tensor is (bn_x: its input),
+// stored in place of dY, sum g / sum g * xhat reduced into partial[2][C][tiles] for stp_bn_backward_fused
+extern "C" int stp_scatter2x_bwd_bn(const void* t, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate,
+                                    const void* bn_x, const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu,
+                                    float* partial, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  if (!bn_x || !mean || !rstd || !partial) return STP_E_BADARG;
+  BnBack b;
+  b.x = (const char*)bn_x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.relu = relu;
+  return scatter2x_bwd_launch(t, dx, N, H, W, C, dtype, accumulate, &b, partial, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
 // MaxPooling2D(2, 2) without padding (keras.applications VGG blocks).  idx[n,ho,wo,c] = 2*dy+dx of the first maximum;
 // every input pixel belongs to exactly one window, so the gradient is a masked copy.  H and W even.
 template <typename T, int V>

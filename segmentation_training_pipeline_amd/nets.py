@@ -51,7 +51,11 @@ def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
                 taps[s] = a
                 if s == stop_stage:
                     return None, relu0, taps
-                shortcut = plan.conv(pre + "sc", a, f * ex, 1, stride=stride, pad=0)
+                # (bottleneck units: the shortcut is issued AFTER conv1, so in the backward pass its data gradient arrives FIRST: the
+                #  stride-2 scatter then writes into a fresh buffer - no read of what conv1 accumulated, no BatchNormalization input - and
+                #  conv1's dense 1x1 launch completes the gradient in its epilogue)
+                if ex == 1:
+                    shortcut = plan.conv(pre + "sc", a, f * ex, 1, stride=stride, pad=0)
             else:
                 shortcut = x
             if ex == 1:
@@ -62,6 +66,8 @@ def _resnet_encoder(plan, backbone, H, W, in_ch, stop_stage=None):
                 x = plan.conv(pre + "conv2", y, f, 3, stride=1, pad=1, residual=shortcut, bn_stats=True)
             else:
                 y = plan.conv(pre + "conv1", a, f, 1, bn_stats=True)
+                if u == 1:
+                    shortcut = plan.conv(pre + "sc", a, f * ex, 1, stride=stride, pad=0)
                 y = plan.bn(pre + "bn2", y, BN_EPS_ENCODER, relu=True)
                 y = plan.conv(pre + "conv2", y, f, 3, stride=stride, pad=1, bn_stats=True)
                 y = plan.bn(pre + "bn3", y, BN_EPS_ENCODER, relu=True)

@@ -491,6 +491,25 @@ def test_weight_gradient_groups_of_the_headline_workload():
             assert nwg <= 256 * {128: 2, 64: 3, 32: 4}[bm]
 
 
+def test_bottleneck_shortcut_data_gradients_run_at_low_resolution():
+    """FPN/ResNet50 (BASELINE configs[3]): the 1x1 / stride-2 projection shortcuts of stages 2-4 - their data gradient is a 1x1 / stride-1
+    launch at LOW resolution + stp_scatter2x_bwd (round 5; the zero-inserted form ran the GEMM over four parity classes).  nets.py issues
+    the shortcut AFTER conv1, so in the backward pass it arrives first: the scatter writes a fresh buffer (no accumulate, no mask) and
+    conv1's dense 1x1 data gradient completes the gradient of bn1's output in its epilogue (stp_bn_backward_fused follows)."""
+    plan = graph.Plan(4, "bf16", "cpu", training=True)
+    plan.define(lambda p: nets.fpn_resnet(p, "resnet50", 256, 256, classes=3))
+    bnames = [n for _, _, n, _ in plan.bwd]
+    assert bnames.count("stp_scatter2x_bwd") == 3 and bnames.count("stp_scatter2x_bwd_bn") == 0
+    for k in (2, 3, 4):
+        i_sc = next(i for i, (_, _, n, m) in enumerate(plan.bwd) if n == "stp_conv2d" and m and m.get("layer") == "stage%d_unit1_sc" % k)
+        i_c1 = next(i for i, (_, _, n, m) in enumerate(plan.bwd) if n == "stp_conv2d" and m and m.get("layer") == "stage%d_unit1_conv1" % k)
+        assert i_sc < i_c1 and plan.bwd[i_sc + 1][2] == "stp_scatter2x_bwd"
+    dg = {m["layer"]: m for _, _, n, m in plan.bwd if n == "stp_conv2d" and m and m.get("pass") == "dgrad"}
+    for k, (cin, cout, hw) in {2: (256, 512, 32), 3: (512, 1024, 16), 4: (1024, 2048, 8)}.items():
+        m = dg["stage%d_unit1_sc" % k]
+        assert abs(m["flops"] - 2.0 * 4 * hw * hw * cin * cout) < 1.0          # the GEMM of ONE parity class
+
+
 def test_bench_names_every_launch_of_the_headline_plan():
     """bench.py's instrumented pass maps every launch of the step to the kernel the library runs for it (kernel_key): a launch kind
     it does not know (a new tile id) must fail here, on CPU, not in the driver's bench run."""

@@ -1844,6 +1844,84 @@ def test_maxpool_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 8, 12, 64, 0), (1, 9, 7, 256, 1), (2, 6, 6, 32, 1), (1, 16, 16, 512, 0), (3, 5, 8, 20, 1)])
+def test_scatter2x_gradient_of_a_1x1_stride_2_convolution(ops, dtype, case):
+    """stp_scatter2x_bwd (round 5): t[n, a, b] lands at (2a, 2b) of dx - zeros elsewhere, or added to what dx holds; with a 1x1 / stride-1
+    stp_conv2d in front it is the data gradient of a 1x1 / stride-2 convolution: checked against the zero-inserted launch it replaces
+    and against numpy.  The _bn form (the launch that completes the gradient of a BatchNormalization + ReLU output): must equal
+    stp_scatter2x_bwd + stp_bn_backward."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, c, acc = case
+    rng = np.random.RandomState(8)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    t = q(rng.randn(n, ho, wo, c), dtype)
+    prior = q(rng.randn(n, h, w, c), dtype)
+    td, dx = dev(t, dtype), dev(prior, dtype)
+    _lib.call("stp_scatter2x_bwd", ops.ptr(td), ops.ptr(dx), n, h, w, c, ops.dt(td), acc, ops.stream())
+    ref = prior.copy() if acc else np.zeros_like(prior)
+    ref[:, ::2, ::2, :] += t
+    np.testing.assert_allclose(host(dx), ref, atol=tol(ref, dtype, 0.5))
+    if not acc:
+        assert np.array_equal(host(dx)[:, 1::2], np.zeros_like(prior)[:, 1::2]) and np.array_equal(host(dx)[:, ::2, ::2], t)
+    tiles = int(_lib.load().stp_scatter2x_bwd_bn_tiles(n, h, w, c, ops.dt(td)))
+    v = 8 if (dtype != "fp32" and c % 8 == 0) else 4
+    if 256 % (c // v):
+        assert tiles == 0
+        return
+    assert tiles > 0
+    rows = n * h * w
+    x = q(rng.randn(n, h, w, c) * 1.5 + 0.3, dtype)                    # BN input
+    gamma, beta = (rng.rand(c) + 0.5).astype(np.float32), (rng.randn(c) * 0.3).astype(np.float32)
+    f = lambda a: keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV))
+    xd, g, b = dev(x, dtype), f(gamma), f(beta)
+    m, r = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ws = torch.empty(ops.bn_workspace_bytes(c) // 4, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, rows, c, 1e-3, 0.99, m, r, None, None, ws)
+    dx0, dg0, db0 = torch.empty_like(dx), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.bn_backward(xd, dx, dx0, rows, c, m, r, g, b, dg0, db0, relu=1, accumulate_dx=0, workspace=ws)
+    st = torch.full((2 * c * tiles,), float("nan"), dtype=torch.float32, device=DEV)
+    gbuf = dev(prior, dtype)
+    _lib.call("stp_scatter2x_bwd_bn", ops.ptr(td), ops.ptr(gbuf), n, h, w, c, ops.dt(td), acc, ops.ptr(xd), ops.ptr(m), ops.ptr(r), ops.ptr(g),
+              ops.ptr(b), 1, ops.ptr(st), ops.stream())
+    assert not np.isnan(host(st)).any()
+    dx1, dg1, db1 = torch.empty_like(dx), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.bn_backward_fused(xd, gbuf, dx1, rows, c, m, r, g, st, tiles, dg1, db1, accumulate_dx=0, workspace=ws)
+    pre = host(xd) * (host(r) * gamma) + (beta - host(m) * host(r) * gamma)
+    safe = np.abs(pre) > 1e-3
+    np.testing.assert_array_equal(host(gbuf)[safe], (host(dx) * (pre > 0))[safe])
+    scale = lambda a: 2e-4 * np.abs(a).max() + 1e-4
+    np.testing.assert_allclose(host(db1), host(db0), atol=scale(host(db0)) * 5)
+    np.testing.assert_allclose(host(dg1), host(dg0), atol=scale(host(dg0)) * 5)
+    np.testing.assert_allclose(host(dx1)[safe], host(dx0)[safe], atol=tol(host(dx0), dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_1x1_stride_2_data_gradient_low_resolution_gemm_plus_scatter_equals_the_zero_inserted_launch(ops, dtype):
+    """The two forms of the data gradient of Conv2D(1x1, strides=2) on the same buffers: the zero-inserted stp_conv2d over the high-resolution
+    grid (what graph.py issued before round 5) and 1x1 / stride-1 GEMM at low resolution + stp_scatter2x_bwd."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co = 2, 16, 24, 64, 128
+    rng = np.random.RandomState(9)
+    ho, wo = h // 2, w // 2
+    dy = q(rng.randn(n, ho, wo, co), dtype)
+    wt = q(rng.randn(1, 1, ci, co) / np.sqrt(ci), dtype)
+    _, _, bwd, _ = prep_weights(ops, wt, dtype)
+    dyd = dev(dy, dtype)
+    d0 = torch.full((n, h, w, ci), float("nan"), dtype=TD[dtype], device=DEV)
+    ops.conv2d(ops.conv_params(dyd, bwd, d0, N=n, Hs0=ho, Ws0=wo, Hv=2 * ho - 1, Wv=2 * wo - 1, C0=co, mode=ops.SRC_ZEROINS2X, KH=1, KW=1, stride=1,
+                               pad=0, Ho=h, Wo=w, Cout=ci, dtype=ops.dt(d0)))
+    tl = torch.empty((n, ho, wo, ci), dtype=TD[dtype], device=DEV)
+    ops.conv2d(ops.conv_params(dyd, bwd, tl, N=n, Hs0=ho, Ws0=wo, Hv=ho, Wv=wo, C0=co, KH=1, KW=1, stride=1, pad=0, Ho=ho, Wo=wo, Cout=ci,
+                               dtype=ops.dt(tl)))
+    d1 = torch.full((n, h, w, ci), float("nan"), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_scatter2x_bwd", ops.ptr(tl), ops.ptr(d1), n, h, w, ci, ops.dt(tl), 0, ops.stream())
+    ref = np.zeros((n, h, w, ci), np.float32)
+    ref[:, ::2, ::2, :] = np.einsum("nhwo,io->nhwi", dy.astype(np.float64), wt[0, 0].astype(np.float64))
+    np.testing.assert_allclose(host(d1), ref, atol=tol(ref, dtype))
+    np.testing.assert_allclose(host(d1), host(d0), atol=tol(ref, dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 6, 10, 64, 0), (2, 5, 7, 512, 1), (1, 8, 16, 128, 1), (2, 4, 4, 32, 0), (1, 3, 5, 256, 1)])
 def test_upsample_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
     """stp_upsample2x_bwd_bn: the 2x2 fold that completes the gradient of a BatchNormalization(+ReLU) output (optionally on top of
