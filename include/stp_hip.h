@@ -431,6 +431,14 @@ int stp_upsample2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W
  * 1x1 / stride-1 stp_conv2d; stp_scatter2x_bwd puts t[n, a, b] at (2a, 2b) of dx [N, H, W, C] (zeros elsewhere; accumulate != 0: dx +=).
  * The _bn form completes the gradient of a BatchNormalization(+activation) output as stp_maxpool3x3s2_bwd_bn does: masked in place,
  * partial[2][C][stp_scatter2x_bwd_bn_tiles] for stp_bn_backward_fused. */
+/* Conv2D(3x3, padding 1) with few output channels over many input channels (segmentation_models' class heads `final_conv` of FPN / PSPNet,
+ * reached through segmentation.py:109-118) as a 1x1 stp_conv2d into 9 x Cout tap channels (the 3x3 kernel [Cout][3][3][Cin] read as the
+ * matrix [9 Cout][Cin]: tap channel (o, t) = o * 9 + t) followed by stp_tapsum_fwd:
+ *   y[n, h, w, o] = bias[o] + sum_t z[n, h + t / 3 - 1, w + t % 3 - 1, o * 9 + t]   (taps outside the image contribute zero)
+ * stp_tapsum_bwd is its adjoint: dz[n, h, w, o * 9 + t] = dy[n, h - (t / 3 - 1), w - (t % 3 - 1), o]; the padded channels of dz are zeroed. */
+int stp_tapsum_fwd(const void* z, void* y, const float* bias, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t Zc, int32_t Cy, int32_t dtype,
+                   void* stream);
+int stp_tapsum_bwd(const void* dy, void* dz, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t Cdy, int32_t Cdz, int32_t dtype, void* stream);
 int stp_scatter2x_bwd(const void* t, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate, void* stream);
 int stp_scatter2x_bwd_bn_tiles(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype);
 int stp_scatter2x_bwd_bn(const void* t, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate,

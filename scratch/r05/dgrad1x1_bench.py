@@ -3,13 +3,18 @@ import sys, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 from segmentation_training_pipeline_amd import ops
 DEV = "cuda"; bf = torch.bfloat16
+import os
+LAYERS_HEAD = [("fpn head taps dgrad 64->512 @256 bs4", 4, 256, 256, 64, 512), ("psp head taps dgrad 192->512 @96 bs8", 8, 96, 96, 192, 512)]
 LAYERS = [  # name, N,H,W, channels of dY, channels of dX
     ("psp s2 conv1 dgrad 128->512 @96 bs8", 8, 96, 96, 128, 512),
     ("psp s2 conv3 dgrad 512->128 @96 bs8", 8, 96, 96, 512, 128),
     ("psp s1 conv1 dgrad 64->256 @192 bs8", 8, 192, 192, 64, 256),
     ("psp s1 conv3 dgrad 256->64 @192 bs8", 8, 192, 192, 256, 64),
 ]
+if os.environ.get("HEAD") == "1":
+    LAYERS = LAYERS_HEAD
 TILES = [0, 65, 69, 70, 71, 133, 134, 97, 101]
+MODES = os.environ.get("MODES", "plain,acc,bnb,acc+bnb").split(",")
 def timeit(fn, n=20):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,7 +27,7 @@ for name, n, h, w, co, ci in LAYERS:
     wb = (torch.randn(ci, co, device=DEV) / co ** 0.5).to(bf)
     x = torch.randn(n, h, w, ci, device=DEV).to(bf)
     mean, rstd = torch.zeros(ci, device=DEV), torch.ones(ci, device=DEV)
-    for mode in ("plain", "acc", "bnb", "acc+bnb"):
+    for mode in MODES:
         for tile in TILES:
             dx = torch.zeros(n, h, w, ci, device=DEV, dtype=bf)
             P = ops.conv_params(dy, wb, dx, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=co, KH=1, KW=1, stride=1, pad=0, Ho=h, Wo=w, Cout=ci, dtype=ops.BF16, tile=tile,

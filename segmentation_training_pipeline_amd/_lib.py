@@ -122,6 +122,8 @@ SIGNATURES = {
     "stp_maxpool_k_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_relu_bwd": (i32, [vp, vp, i64, i32, vp]),
     "stp_upsample2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_tapsum_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_tapsum_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_scatter2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_scatter2x_bwd_bn_tiles": (i32, [i32, i32, i32, i32, i32]),
     "stp_scatter2x_bwd_bn": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]),

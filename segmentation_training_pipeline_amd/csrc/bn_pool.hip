@@ -1675,6 +1675,76 @@ extern "C" int stp_scatter2x_bwd_bn(const void* t, void* dx, int32_t N, int32_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// Conv2D(3x3, padding 1) with FEW output channels over MANY input channels (the class heads of FPN and PSPNet: 512 -> 3 / 20) as a 1x1
+// convolution into 9 x Cout TAP CHANNELS + a tap sum.  Channel mixing is pointwise, so W_t . shift_t(x) = shift_t(W_t . x): the 3x3 kernel
+// [Cout][3][3][Cin] IS the matrix [9 Cout][Cin] of a 1x1 convolution z = W x (row o * 9 + t: no copy, the master parameter's own bytes) and
+//   y[n, h, w, o] = bias[o] + sum_t z[n, h + t / 3 - 1, w + t % 3 - 1, o * 9 + t]        (taps outside the image: zero, as the padding)
+// The per-tap kernel read the 512-channel input nine times from L2 for 3 useful output channels (340 us forward, 308 us data gradient,
+// 183 us weight gradient on FPN/ResNet50 1024 x 1024 batch 4); the 1x1 form reads it once per pass and everything else is 27 channels wide.
+// Backward: dz[n, h, w, o * 9 + t] = dy[n, h - (t / 3 - 1), w - (t % 3 - 1), o], then the 1x1 convolution's ordinary gradients - its weight
+// gradient is the 3x3 kernel's gradient in place.
+template <typename T>
+__global__ __launch_bounds__(256) void tapsum_fwd_kernel(const T* __restrict__ z, T* __restrict__ y, const float* __restrict__ bias, int N, int H, int W,
+                                                         int Cout, int Zc, int Cy) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * H * W * Cout) return;
+  const int o = (int)(idx % Cout);
+  const long long p = idx / Cout;
+  const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
+  float acc = bias ? bias[o] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+    if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) acc += Elem<T>::load(z + (((size_t)n * H + hh) * W + ww) * Zc + o * 9 + t);
+  }
+  Elem<T>::store(y + (size_t)p * Cy + o, acc);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tapsum_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dz, int N, int H, int W, int Cout, int Cdy, int Cdz) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * H * W * Cdz) return;
+  const int j = (int)(idx % Cdz);
+  const long long p = idx / Cdz;
+  const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
+  float v = 0.f;
+  if (j < 9 * Cout) {
+    const int o = j / 9, t = j - o * 9;
+    const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
+    if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) v = Elem<T>::load(dy + (((size_t)n * H + hh) * W + ww) * Cdy + o);
+  }
+  Elem<T>::store(dz + (size_t)idx, v);                      // (the padded tap channels j >= 9 Cout: zero)
+}
+
+// z: [N, H, W, Zc] with the tap channel (o, t) at o * 9 + t (Zc >= 9 Cout); y: [N, H, W, Cy] (channels >= Cout untouched); bias: [Cout] or NULL
+extern "C" int stp_tapsum_fwd(const void* z, void* y, const float* bias, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t Zc, int32_t Cy,
+                              int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  if (!z || !y || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Zc < 9 * Cout || Cy < Cout) return STP_E_BADARG;
+  const long long total = (long long)N * H * W * Cout;
+  if (total > 0x7fffffffll * 128) return STP_E_BADARG;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == STP_H16) hipLaunchKernelGGL(tapsum_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)y, bias, N, H, W, Cout, Zc, Cy);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(tapsum_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)z, (float*)y, bias, N, H, W, Cout, Zc, Cy);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+// dy: [N, H, W, Cdy] (the first Cout channels are read); dz: [N, H, W, Cdz], written whole (Cdz >= 9 Cout)
+extern "C" int stp_tapsum_bwd(const void* dy, void* dz, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t Cdy, int32_t Cdz, int32_t dtype,
+                              void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  if (!dy || !dz || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cdz < 9 * Cout || Cdy < Cout) return STP_E_BADARG;
+  const long long total = (long long)N * H * W * Cdz;
+  if (total > 0x7fffffffll * 128) return STP_E_BADARG;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == STP_H16) hipLaunchKernelGGL(tapsum_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dz, N, H, W, Cout, Cdy, Cdz);
+  else if (dtype == STP_F32) hipLaunchKernelGGL(tapsum_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dz, N, H, W, Cout, Cdy, Cdz);
+  else return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // MaxPooling2D(2, 2) without padding (keras.applications VGG blocks).  idx[n,ho,wo,c] = 2*dy+dx of the first maximum;
 // every input pixel belongs to exactly one window, so the gradient is a masked copy.  H and W even.
 template <typename T, int V>

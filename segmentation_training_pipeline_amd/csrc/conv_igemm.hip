@@ -587,6 +587,10 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
     // ... with the BatchNormalization-backward epilogue (three operand tensors per output tile) the 64-channel x 128-pixel tile is the
     // faster one (scratch/r05/dgrad1x1_bench.py: 128 -> 512 @ 8 x 96^2 73.6 -> 57.3 us, 64 -> 256 @ 8 x 192^2 137.5 -> 113.5 us)
     if (a.K <= 128 && mid >= 384) return a.bnb.x ? 64 + 7 : 64 + 6;
+    // ... and up to four K steps under that epilogue (the class head's tap channels, 192 -> 512 @ 8 x 96^2: 73.1 -> 64.3 us;
+    // STP_DGRAD1X1_BNB_K=<largest K> for A/Bs)
+    static const int k71 = getenv("STP_DGRAD1X1_BNB_K") ? atoi(getenv("STP_DGRAD1X1_BNB_K")) : 256;
+    if (a.bnb.x && a.KH == 1 && a.KW == 1 && a.K <= k71 && mid >= 384) return 64 + 7;
     if (big >= 384) return 64 + 1;
     if (mid >= 384) return 64 + 6;
     return 128 + 5;

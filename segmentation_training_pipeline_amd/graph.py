@@ -660,8 +660,46 @@ class Plan(object):
         self._tape.append(back)
         return out
 
+    def conv3x3_taps(self, name, x, Cout, bias=False):
+        """``Conv2D(Cout, 3x3, padding 1)`` with few output channels over many input channels (the class heads of FPN / PSPNet: 512 -> 3 /
+        20) as a 1x1 convolution into 9 x Cout tap channels + stp_tapsum_fwd (bn_pool.hip: W_t . shift_t(x) = shift_t(W_t . x)).  The
+        parameters keep the layer's names and shapes (``name/kernel`` = (Cout, 3, 3, Cin), ``name/bias``): the 1x1 launch reads the 3x3
+        kernel's own bytes as [9 Cout][Cin], its weight gradient IS the kernel's gradient."""
+        cin = x.meta.get("real_c", x.C)
+        # (the gradient of the tap channels in rows of 64: the data gradient's K is then whole 64-channel steps of the buffer-DMA kernel -
+        #  with K = 32 it ran at 1.8 TB/s, 302 us on FPN's 4 x 256 x 256 x 512 map)
+        z = self.conv(name + "_taps", x, 9 * Cout, 1, param_name=name, param_shape=(Cout, 3, 3, cin), cout_pad=64 if self.dtype != "fp32" else None)
+        b = self.param(name + "/bias", (Cout,), "bias") if bias else None
+        out = self._new(name, x.H, x.W, Cout, z.needs_grad or (b is not None and b.trainable))
+        out.gradC = _rup(Cout, self.vec)
+        if bias:
+            self._bn_ws_c = max(self._bn_ws_c, out.gradC)
+        self._use(z)
+        if self.dry:
+            return out
+        self._emit(self.fwd, "stp_tapsum_fwd", z.buf.data_ptr(), out.buf.data_ptr(), self._pptr(b) if b is not None else None, self.N, x.H, x.W,
+                   Cout, z.C, Cout, self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not out.grad_ready:
+                return
+            dy = out.grad
+            if b is not None and b.trainable:
+                tmp = self._alloc((out.gradC,), torch.float32)
+                self._emit(self.bwd, "stp_channel_sum", dy.data_ptr(), self.cdt, out.rows, out.gradC, tmp.data_ptr(), 0,
+                           self.ws_bn.data_ptr(), self.ws_bn.numel() * 4)
+                self._emit(self.bwd, "stp_weight_grad_unpad", tmp.data_ptr(), self._gptr(b), Cout, 1, 1, 1, 1, 1, 0)
+            if z.needs_grad:
+                self._emit(self.bwd, "stp_tapsum_bwd", dy.data_ptr(), self._gradbuf(z).data_ptr(), self.N, x.H, x.W, Cout, out.gradC, z.gradC, self.cdt)
+                z.grad_ready = True
+
+        self._tape.append(back)
+        return out
+
     def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False,
-             transpose=False, relu=False, same_tf=False, fold_shortcut=None):
+             transpose=False, relu=False, same_tf=False, fold_shortcut=None, param_name=None, param_shape=None, cout_pad=None):
         """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
         ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add().
 
@@ -698,9 +736,12 @@ class Plan(object):
         KWp = k + (k & 1) if (stem and x.C == 4) else k      # 4 padded channels: one 16-byte vector = two horizontally adjacent taps
         Cin_master = real_c0 + C1
         Cinp = C0 + C1
-        w = self.param(name + "/kernel", (Cout, k, k, Cin_master), "tkernel" if transpose else "kernel")
+        # (param_name / param_shape: conv3x3_taps - the 1x1 launch over the bytes of a 3x3 kernel registered under the layer's own name)
+        w = self.param((param_name or name) + "/kernel", param_shape or (Cout, k, k, Cin_master), "tkernel" if transpose else "kernel")
+        if param_shape is not None and int(np.prod(param_shape)) != Cout * k * k * Cin_master:
+            raise StpShapeError("%s: parameter view of %s does not match %d x %d x %d x %d" % (name, param_shape, Cout, k, k, Cin_master))
         b = self.param(name + "/bias", (Cout,), "bias") if bias else None
-        CoutB = _rup(Cout, self.vec)
+        CoutB = _rup(Cout, cout_pad or self.vec)      # channels of the gradient buffer = K of the data gradient (cout_pad: conv3x3_taps)
         x_ng = x.needs_grad
         s_ng = src1.needs_grad if src1 is not None else False
         out = self._new(name, Ho, Wo, Cout, x_ng or s_ng or w.trainable or (residual is not None and residual.needs_grad))

@@ -95,6 +95,16 @@ def _vgg_encoder(plan, backbone, H, W, in_ch, stop_block=None):
     return x, skips[::-1]
 
 
+def _class_head(plan, y, classes):
+    """``final_conv`` = Conv2D(classes, 3x3, padding 1, bias) of the FPN / PSPNet decoders.  With few classes over a wide feature map
+    (512 -> 3 / 20) the per-tap kernel reads the input nine times for a handful of output channels: the tap-channel form
+    (Plan.conv3x3_taps) reads it once.  STP_TAPSUM=0: the plain launch."""
+    import os
+    if 18 * classes <= y.C and y.C >= 128 and os.environ.get("STP_TAPSUM", "1") != "0":
+        return plan.conv3x3_taps("final_conv", y, classes, bias=True)
+    return plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
+
+
 def _head(plan, x, H, W, classes, loss, with_loss):
     logits = plan.conv("final_conv", x, classes, 3, pad=1, bias=True)
     if with_loss:
@@ -189,7 +199,7 @@ def fpn_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None, l
     y = plan.bn("fpn_final_bn", plan.conv("fpn_final", cat, sf * 4, 3, pad=1, bn_stats=True), BN_EPS_DECODER, relu=True)
     if dropout:       # SpatialDropout2D between the final block and the class convolution (segmentation_models 0.2.1 fpn builder)
         y = plan.dropout("fpn_dropout", y, float(dropout), DECODER_DROPOUT_SALT, spatial=True)
-    lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
+    lo = _class_head(plan, y, classes)
     logits = plan.resize("logits", lo, 4, nearest=near)
     if with_loss:
         target = plan.input_u8("mask", H, W, 1)
@@ -223,7 +233,7 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
     y = plan.bn("psp_final_bn", plan.conv("psp_final", cat, 512, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
     if dropout:       # SpatialDropout2D between the final block and the class convolution (segmentation_models 0.2.1 psp builder)
         y = plan.dropout("psp_dropout", y, float(dropout), DECODER_DROPOUT_SALT, spatial=True)
-    lo = plan.conv("final_conv", y, classes, 3, pad=1, bias=True)
+    lo = _class_head(plan, y, classes)
     logits = plan.resize("logits", lo, int(downsample_factor), nearest=final_interpolation == "nearest")
     if with_loss:
         target = plan.input_u8("mask", H, W, 1)

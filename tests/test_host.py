@@ -510,6 +510,26 @@ def test_bottleneck_shortcut_data_gradients_run_at_low_resolution():
         assert abs(m["flops"] - 2.0 * 4 * hw * hw * cin * cout) < 1.0          # the GEMM of ONE parity class
 
 
+def test_class_heads_of_fpn_and_pspnet_take_the_tap_channel_form():
+    """final_conv of FPN (512 -> 3) and PSPNet (512 -> 20): a 1x1 launch into 9 x classes tap channels + stp_tapsum_fwd; the parameters keep
+    the layer's names and shapes (checkpoints, set_weights / get_weights and the oracle's weight mapping do not change); U-Net's 16 -> 1 head
+    stays a 3x3 launch."""
+    for build, classes, cin in ((lambda p: nets.fpn_resnet(p, "resnet50", 256, 256, classes=3), 3, 512),
+                                (lambda p: nets.pspnet_resnet(p, "resnet50", 192, 192, classes=20), 20, 512)):
+        plan = graph.Plan(2, "bf16", "cpu", training=True)
+        plan.define(build)
+        assert plan.params["final_conv/kernel"].shape == (classes, 3, 3, cin) and plan.params["final_conv/bias"].shape == (classes,)
+        assert plan.tensors["final_conv_taps"].C == 9 * classes and plan.tensors["final_conv"].C == classes
+        fn = [n for _, _, n, _ in plan.fwd]
+        bn = [n for _, _, n, _ in plan.bwd]
+        assert fn.count("stp_tapsum_fwd") == 1 and bn.count("stp_tapsum_bwd") == 1
+        head = [m for _, _, n, m in plan.fwd if n == "stp_conv2d" and m and m.get("layer") == "final_conv_taps"]
+        assert len(head) == 1 and abs(head[0]["flops"] - 2.0 * 2 * plan.tensors["final_conv"].H ** 2 * 9 * classes * cin) < 1.0
+    plan = graph.Plan(2, "bf16", "cpu", training=True)
+    plan.define(lambda p: nets.unet_resnet(p, "resnet18", 64, 64))
+    assert "final_conv_taps" not in plan.tensors
+
+
 def test_bench_names_every_launch_of_the_headline_plan():
     """bench.py's instrumented pass maps every launch of the step to the kernel the library runs for it (kernel_key): a launch kind
     it does not know (a new tile id) must fail here, on CPU, not in the driver's bench run."""

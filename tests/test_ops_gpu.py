@@ -1844,6 +1844,56 @@ def test_maxpool_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 12, 16, 128, 3), (1, 9, 7, 256, 20), (2, 6, 6, 64, 1)])
+def test_class_head_as_tap_channels_plus_tap_sum(ops, dtype, case):
+    """Conv2D(classes, 3x3, padding 1, bias) over a wide feature map as a 1x1 stp_conv2d into 9 x classes tap channels (the 3x3 kernel's own
+    bytes read as [9 classes][Cin]) + stp_tapsum_fwd (round 5): against the float64 oracle and the direct 3x3 launch; stp_tapsum_bwd
+    against numpy (the adjoint: <tapsum(z), dy> = <z, tapsum_bwd(dy)> on the values it produced)."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, ci, co = case
+    rng = np.random.RandomState(12)
+    x = q(rng.randn(n, h, w, ci), dtype)
+    wt = q(rng.randn(3, 3, ci, co) / np.sqrt(9 * ci), dtype)
+    bias = (rng.randn(co) * 0.2).astype(np.float32)
+    ref = np_ops.conv2d(x, wt, 1, 1) + bias
+    # the 3x3 master [co][3][3][ci] read as a 1x1 kernel with 9 co outputs: HWIO view (1, 1, ci, 9 co) with column o * 9 + t
+    w11 = np.ascontiguousarray(wt.transpose(3, 0, 1, 2).reshape(co * 9, ci).T.reshape(1, 1, ci, co * 9))
+    _, f11, _, _ = prep_weights(ops, w11, dtype)
+    xd = dev(x, dtype)
+    zc = co * 9
+    z = torch.full((n, h, w, zc), float("nan"), dtype=TD[dtype], device=DEV)
+    ops.conv2d(ops.conv_params(xd, f11, z, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=1, KW=1, stride=1, pad=0, Ho=h, Wo=w, Cout=zc, dtype=ops.dt(z)))
+    y = torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV)
+    bd = keep(torch.from_numpy(bias).to(DEV))
+    _lib.call("stp_tapsum_fwd", ops.ptr(z), ops.ptr(y), ops.ptr(bd), n, h, w, co, zc, co, ops.dt(z), ops.stream())
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype, 2.0))
+    zh = host(z)
+    want = np.tile(bias, (n, h, w, 1)).astype(np.float64)
+    zp = np.pad(zh.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for o in range(co):
+        for t in range(9):
+            want[..., o] += zp[:, t // 3:t // 3 + h, t % 3:t % 3 + w, o * 9 + t]
+    np.testing.assert_allclose(host(y), want, atol=tol(want, dtype, 0.6))
+    # backward: dz of the padded gradient layout [.., rup(co, vec)] -> [.., rup(9 co, vec)]
+    vec = 4 if dtype == "fp32" else 8
+    cdy, cdz = -(-co // vec) * vec, -(-zc // vec) * vec
+    dy = np.zeros((n, h, w, cdy), np.float32)
+    dy[..., :co] = q(rng.randn(n, h, w, co), dtype)
+    dyd = dev(dy, dtype)
+    dz = torch.full((n, h, w, cdz), float("nan"), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_tapsum_bwd", ops.ptr(dyd), ops.ptr(dz), n, h, w, co, cdy, cdz, ops.dt(dz), ops.stream())
+    dzh = host(dz)
+    dyp = np.pad(dy, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for o in range(co):
+        for t in range(9):
+            np.testing.assert_array_equal(dzh[..., o * 9 + t], dyp[:, 2 - t // 3:2 - t // 3 + h, 2 - t % 3:2 - t % 3 + w, o])
+    assert not dzh[..., zc:].any()
+    lhs = float((want - bias) .reshape(-1, co).astype(np.float64).ravel() @ dy[..., :co].astype(np.float64).ravel())
+    rhs = float(zh.astype(np.float64).ravel() @ dzh[..., :zc].astype(np.float64).ravel())
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 8, 12, 64, 0), (1, 9, 7, 256, 1), (2, 6, 6, 32, 1), (1, 16, 16, 512, 0), (3, 5, 8, 20, 1)])
 def test_scatter2x_gradient_of_a_1x1_stride_2_convolution(ops, dtype, case):
     """stp_scatter2x_bwd (round 5): t[n, a, b] lands at (2a, 2b) of dx - zeros elsewhere, or added to what dx holds; with a 1x1 / stride-1
