@@ -1,6 +1,7 @@
 // Shared pieces of the MFMA convolution kernels (conv_igemm.hip: per-tap operand tiles; conv_halo.hip: halo-resident
 // activation slabs): argument block, MFMA wrappers, the fused epilogue.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include <cstdlib>
 
@@ -403,37 +404,105 @@ __device__ __forceinline__ void epilogue_rm_lin(const ConvArgs& a, f32x4 (&acc)[
     const bool relu = a.relu != 0;
     const float alo = a.bnb.relu ? __uint_as_float(1u) : -__builtin_inff();
     const float ahi = a.bnb.relu == 2 ? __uint_as_float(0x40bfffffu) : __builtin_inff();      // largest float below 6
+    // The operands of a launch (BatchNormalization-backward form, statistics, bias, residual, accumulate, ReLU) are launch-uniform; as
+    // run-time conditions inside the unrolled element loop they were if-converted into selects, and EVERY launch paid the clamp /
+    // compare / select / fma of the backward form, the sums of the statistics form and the adds of all optional operands (the same
+    // finding as conv_halo.hip's epilogue, DESIGN 3.11: the epilogue is VALU-issue bound).  The loop is instantiated per combination;
+    // the ones the networks use get their own copy, the rest takes the all-operands copy (STP_EPILOGUE_SPECIAL=0: always).
+    // B_: backward form; S_: statistics; HB / HR / HA: bias / residual / accumulate; HL: ReLU (backward form: the fused activation is a
+    // plain ReLU - the gradient passes iff the re-derived output is > 0, the clamp window of ReLU being [smallest positive, inf]).
+    auto passes = [&](auto b_, auto s_, auto hb_, auto hr_, auto ha_, auto hl_) {
+      constexpr bool B_ = decltype(b_)::value, S_ = decltype(s_)::value, HB = decltype(hb_)::value, HR = decltype(hr_)::value,
+                     HA = decltype(ha_)::value, HL = decltype(hl_)::value;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      if (pm[k] < 0) continue;
-      const int px = p0 + k * PP;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
-      f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
-      u32x4 o;
+      for (int k = 0; k < NP; ++k) {
+        if (pm[k] < 0) continue;
+        const int px = p0 + k * PP;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
+        f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
+        u32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (!bnb) {
-          v[e] += bias2[e];
-          if (res) v[e] += unpack_bf16x2(opr[k][e]);
+        for (int e = 0; e < 4; ++e) {
+          if (!B_) {
+            if (HB) v[e] += bias2[e];
+            if (HR) v[e] += unpack_bf16x2(opr[k][e]);
+          }
+          if (HA) v[e] += unpack_bf16x2(opa[k][e]);
+          if (!B_ && HL) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
+          if (!B_) o[e] = pack_bf16x2(v[e].x, v[e].y);
+          if (S_ && !B_) {
+            const f32x2v sv = unpack_bf16x2(o[e]);
+            ss[e] += sv;
+            qq[e] += sv * sv;
+          }
+          if (B_) {   // masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma), rounded ONCE
+            const f32x2v xv = unpack_bf16x2(opr[k][e]);
+            const f32x2v tt = xv * ksc[e] + ksh[e];
+            const bool on0 = HL ? tt.x > 0.f : __builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x;
+            const bool on1 = HL ? tt.y > 0.f : __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y;
+            o[e] = pack_bf16x2(on0 ? v[e].x : 0.f, on1 ? v[e].y : 0.f);
+            const f32x2v g = unpack_bf16x2(o[e]);
+            ss[e] += g;
+            qq[e] += g * xv;
+          }
         }
-        if (accum) v[e] += unpack_bf16x2(opa[k][e]);
-        if (!bnb && relu) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
-        o[e] = pack_bf16x2(v[e].x, v[e].y);
-        if (st && !bnb) {
-          const f32x2v sv = unpack_bf16x2(o[e]);
-          ss[e] += sv;
-          qq[e] += sv * sv;
-        }
-        if (bnb) {   // dY as stored -> masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma)
-          const f32x2v xv = unpack_bf16x2(opr[k][e]), dy = unpack_bf16x2(o[e]);
-          const f32x2v tt = xv * ksc[e] + ksh[e];
-          const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
-          ss[e] += g;
-          qq[e] += g * xv;
-          o[e] = pack_bf16x2(g.x, g.y);
-        }
+        *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
       }
-      *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
+    };
+    // every operand behind its own launch-uniform test, as the one loop of the earlier rounds had it
+    auto passes_all = [&]() {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (pm[k] < 0) continue;
+        const int px = p0 + k * PP;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32), v1 = *reinterpret_cast<const f32x4*>(smem + px * RS + c8 * 32 + 16);
+        f32x2v v[4] = {f32x2v{v0.x, v0.y}, f32x2v{v0.z, v0.w}, f32x2v{v1.x, v1.y}, f32x2v{v1.z, v1.w}};
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!bnb) {
+            v[e] += bias2[e];
+            if (res) v[e] += unpack_bf16x2(opr[k][e]);
+          }
+          if (accum) v[e] += unpack_bf16x2(opa[k][e]);
+          if (!bnb && relu) v[e] = f32x2v{fmaxf(v[e].x, 0.f), fmaxf(v[e].y, 0.f)};
+          o[e] = pack_bf16x2(v[e].x, v[e].y);
+          if (st && !bnb) {
+            const f32x2v sv = unpack_bf16x2(o[e]);
+            ss[e] += sv;
+            qq[e] += sv * sv;
+          }
+          if (bnb) {   // dY as stored -> masked gradient (the activation mask re-derived from the BatchNormalization input with the forward's fma)
+            const f32x2v xv = unpack_bf16x2(opr[k][e]), dy = unpack_bf16x2(o[e]);
+            const f32x2v tt = xv * ksc[e] + ksh[e];
+            const f32x2v g = f32x2v{__builtin_amdgcn_fmed3f(tt.x, alo, ahi) == tt.x ? dy.x : 0.f, __builtin_amdgcn_fmed3f(tt.y, alo, ahi) == tt.y ? dy.y : 0.f};
+            ss[e] += g;
+            qq[e] += g * xv;
+            o[e] = pack_bf16x2(g.x, g.y);
+          }
+        }
+        *reinterpret_cast<u32x4*>(dbase + (size_t)pm[k] * dC) = o;
+      }
+    };
+    typedef std::true_type Y_;
+    typedef std::false_type N_;
+    const bool hb = !bnb && a.bias != nullptr, hr = !bnb && res != nullptr, hl = !bnb && relu;
+    if (a.ep_generic) passes_all();
+    else if (bnb) {
+      const bool r1 = a.bnb.relu == 1;
+      if (accum) { if (r1) passes(Y_(), Y_(), N_(), N_(), Y_(), Y_()); else passes(Y_(), Y_(), N_(), N_(), Y_(), N_()); }
+      else { if (r1) passes(Y_(), Y_(), N_(), N_(), N_(), Y_()); else passes(Y_(), Y_(), N_(), N_(), N_(), N_()); }
+    } else if (st) {
+      if (!hb && !hr && !accum && !hl) passes(N_(), Y_(), N_(), N_(), N_(), N_());
+      else if (!hb && hr && !accum && !hl) passes(N_(), Y_(), N_(), Y_(), N_(), N_());
+      else if (!hb && !hr && accum && !hl) passes(N_(), Y_(), N_(), N_(), Y_(), N_());
+      else passes_all();
+    } else {
+      if (!hb && !hr && !accum && !hl) passes(N_(), N_(), N_(), N_(), N_(), N_());
+      else if (!hb && hr && !accum && !hl) passes(N_(), N_(), N_(), Y_(), N_(), N_());
+      else if (!hb && !hr && accum && !hl) passes(N_(), N_(), N_(), N_(), Y_(), N_());
+      else if (hb && !hr && !accum) { if (hl) passes(N_(), N_(), Y_(), N_(), N_(), Y_()); else passes(N_(), N_(), Y_(), N_(), N_(), N_()); }
+      else passes_all();
     }
   }
   if (st) {     // (workgroup-uniform)
