@@ -5,6 +5,8 @@ from segmentation_training_pipeline_amd import ops
 DEV = "cuda"; bf = torch.bfloat16
 import os
 LAYERS_HEAD = [("fpn head taps dgrad 64->512 @256 bs4", 4, 256, 256, 64, 512), ("psp head taps dgrad 192->512 @96 bs8", 8, 96, 96, 192, 512)]
+LAYERS_EXPAND = [("fpn s1 conv1 dgrad 64->256 @256 bs4", 4, 256, 256, 64, 256), ("fpn s2 conv1 dgrad 128->512 @128 bs4", 4, 128, 128, 128, 512),
+                 ("fpn s3 conv1 dgrad 256->1024 @64 bs4", 4, 64, 64, 256, 1024), ("fpn s1 conv3 fwd-like 64->256 @256 bs4", 4, 256, 256, 64, 256)]
 LAYERS = [  # name, N,H,W, channels of dY, channels of dX
     ("psp s2 conv1 dgrad 128->512 @96 bs8", 8, 96, 96, 128, 512),
     ("psp s2 conv3 dgrad 512->128 @96 bs8", 8, 96, 96, 512, 128),
@@ -13,7 +15,9 @@ LAYERS = [  # name, N,H,W, channels of dY, channels of dX
 ]
 if os.environ.get("HEAD") == "1":
     LAYERS = LAYERS_HEAD
-TILES = [0, 65, 69, 70, 71, 133, 134, 97, 101]
+if os.environ.get("HEAD") == "2":
+    LAYERS = LAYERS_EXPAND
+TILES = [int(t) for t in os.environ.get("TILES", "0,65,69,70,71,133,134,97,101").split(",")]
 MODES = os.environ.get("MODES", "plain,acc,bnb,acc+bnb").split(",")
 def timeit(fn, n=20):
     fn(); torch.cuda.synchronize()

@@ -482,19 +482,24 @@ __global__ __launch_bounds__(256) void softmax_loss_partial_kernel(const T* __re
     float p[CM];
     softmax_row<T, CM>(logits + i * ldc, classes, vec, p, vec4);
     const int t = target[i] < classes ? target[i] : classes - 1;
-    float pt = 0.f;
+    // the per-class sums of the one-hot target in closed form (the loop over the classes cost ~12 instructions per class and pixel - the
+    // kernel is VALU-bound: 137 us per pass for PSPNet's 20 classes against a 38 us memory floor): sum_c y_c = 1, sum_c p_c y_c = p_t, at
+    // most ONE class passes the 0.5 threshold (the probabilities sum to 1), so sum_c th_c = [pmax > 0.5], sum_c th_c y_c = [p_t > 0.5] and
+    // the count of th_c == y_c is classes - (p_t > 0.5 ? 0 : 1 + [pmax > 0.5]).  The counts are the same integers; sum_c p_c is added per pixel.
+    float pt = 0.f, pmax = 0.f, psum = 0.f;
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
-      if (c >= classes) continue;
-      const float y = c == t ? 1.f : 0.f, th = p[c] > 0.5f ? 1.f : 0.f;
       pt = c == t ? p[c] : pt;
-      a[1] += p[c];
-      a[2] += y;
-      a[3] += p[c] * y;
-      a[4] += th;
-      a[5] += th * y;
-      a[6] += (th == y) ? 1.f : 0.f;
+      pmax = fmaxf(pmax, p[c]);                      // (p[c] = 0 beyond `classes`)
+      psum += p[c];
     }
+    const float tt = pt > 0.5f ? 1.f : 0.f, tm = pmax > 0.5f ? 1.f : 0.f;
+    a[1] += psum;
+    a[2] += 1.f;
+    a[3] += pt;
+    a[4] += tm;
+    a[5] += tt;
+    a[6] += (float)classes - (pt > 0.5f ? 0.f : 1.f + tm);
     // Keras: p <- p / sum(p) (a no-op on a softmax up to rounding), clip to [eps, 1-eps], -sum(y log p)
     a[0] += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
   }
@@ -560,9 +565,11 @@ __global__ __launch_bounds__(256) void softmax_loss_grad_kernel(const T* __restr
     for (int c = 0; c < CM; ++c) pt = c == t ? p[c] : pt;
     const bool inr = pt >= 1e-7f && pt <= 1.f - 1e-7f;   // the clip passes no gradient outside
     // dice: G_c = d dice_loss / d p_c = -(2 y_c den - num) / den^2 ; dz_k = p_k (G_k - sum_c G_c p_c)
-    float gp = 0.f;
+    // sum_c G_c p_c with G_c = (num - 2 y_c den) / den^2: (num sum_c p_c - 2 den p_t) / den^2 - no loop over the classes
+    float psum = 0.f;
 #pragma unroll
-    for (int c = 0; c < CM; ++c) gp += (-(2.f * (c == t ? 1.f : 0.f) * den - num) * inv_den2) * p[c];   // p[c] = 0 beyond classes
+    for (int c = 0; c < CM; ++c) psum += p[c];                                                           // p[c] = 0 beyond classes
+    const float gp = (num * psum - 2.f * den * pt) * inv_den2;
     float g[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
