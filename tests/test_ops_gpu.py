@@ -2798,3 +2798,19 @@ def test_opt_in_statistic_groups_run_in_their_own_process():
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+def test_all_operands_epilogue_copies_in_their_own_process():
+    """STP_EPILOGUE_SPECIAL=0 (the A/B switch of DESIGN 3.11, read once per process) sends every launch of the halo and per-tap kernels through
+    the all-operands copy of the epilogue's element loop instead of the per-combination copies: the same op tests (halo forward / statistics /
+    residual / BatchNormalization backward, the per-tap kernel's epilogue forms, the class heads) and a whole training step against the oracle
+    run in a subprocess with the switch off, so the copy that the A/Bs compare against stays correct."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STP_EPILOGUE_SPECIAL="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", os.path.join(root, "tests", "test_ops_gpu.py"), "-k",
+                        "halo_kernel_forward_statistics_residual or halo_kernel_batchnorm_backward_sums or tap_channels or conv2d_bnb or fused_bn_backward or residual",
+                        os.path.join(root, "tests", "test_model_gpu.py") + "::test_hipgraph_replay_equals_eager"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout, r.stdout[-500:]
