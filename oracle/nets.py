@@ -144,7 +144,7 @@ def _vgg_encoder(ctx, x_nhwc, backbone, stop_block=None):
         if stop_block == b:
             return x
         skips.append(x)
-        x = F.max_pool2d(x, kernel_size=2, stride=2)
+        x = ctx.st(F.max_pool2d(x, kernel_size=2, stride=2))
     return x, skips[::-1]
 
 
@@ -233,18 +233,21 @@ def _spatial_dropout(y, rate, step):
     from .deeplab import dropout_mask
     n, c = y.shape[0], y.shape[1]
     keep = dropout_mask(step, DECODER_DROPOUT_SALT, n * c, rate).reshape(n, c, 1, 1)
-    return y * torch.from_numpy(keep.astype(np.float32)) / (1.0 - rate)
+    return y * torch.from_numpy(keep.astype(np.float32)) / (1.0 - rate)        # (the caller stores it: ctx.st)
 
 
 def _resize(x, f, interpolation):
     return F.interpolate(x, scale_factor=f, mode="nearest") if (interpolation == "nearest" and f > 1) else resize_bilinear_tf1(x, f)
 
 
-def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, dropout=None, step=1, interpolation="bilinear"):
+def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, dropout=None, step=1, interpolation="bilinear",
+                       storage=None, grad_scale=1.0):
     """Pyramid over [encoder output, stage4/3/2 unit-1 relu1]: lateral Conv2D 1x1 (bias) + UpSampling2D(2) of the level above,
     two (Conv2D 3x3 no bias, BN, ReLU) per level; the maps resized to 1/4 resolution, concatenated finest first,
-    Conv 3x3 + BN + ReLU (4 x 128 filters), Conv2D 3x3 to the classes, bilinear x4.  Returns (logits_nhwc, bn_updates)."""
-    ctx = _Ctx(P, training, taps)
+    Conv 3x3 + BN + ReLU (4 x 128 filters), Conv2D 3x3 to the classes, bilinear x4.  Returns (logits_nhwc, bn_updates).
+    ``storage``: see _Ctx - stored on the device: the lateral convolution, the top-down sum (stp_upsample2x_add, in place), every
+    resized slice of the concatenation, the class convolution (tap-channel form: _class_head) and the resized logits."""
+    ctx = _Ctx(P, training, taps, storage, grad_scale)
     if backbone in VGG_BLOCKS:
         x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
         levels = (x, sk[0], sk[1], sk[2])
@@ -256,18 +259,19 @@ def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
         pre = "fpn_stage%d_" % i
         lat = _conv(ctx, c, pre + "lateral")
         if m is not None:
-            lat = lat + F.interpolate(m, scale_factor=2, mode="nearest")
+            lat = ctx.st(lat + F.interpolate(m, scale_factor=2, mode="nearest"))
         p = _bn_apply(ctx, _conv(ctx, lat, pre + "segm1", pad=1), pre + "segm1_bn", BN_EPS_DECODER, relu=True)
         p = _bn_apply(ctx, _conv(ctx, p, pre + "segm2", pad=1), pre + "segm2_bn", BN_EPS_DECODER, relu=True)
         ctx.tap(pre + "out", p)
         m = lat
         pyramid.append(p)
-    cat = torch.cat([_resize(p, f, interpolation) for p, f in zip(pyramid[::-1], (1, 2, 4, 8))], dim=1)
+    cat = torch.cat([ctx.st(_resize(p, f, interpolation)) for p, f in zip(pyramid[::-1], (1, 2, 4, 8))], dim=1)
     y = _bn_apply(ctx, _conv(ctx, cat, "fpn_final", pad=1), "fpn_final_bn", BN_EPS_DECODER, relu=True)
     if dropout and training:
-        y = _spatial_dropout(y, float(dropout), step)
-    lo = _conv(ctx, y, "final_conv", pad=1)
-    return _resize(lo, 4, interpolation).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+        y = ctx.st(_spatial_dropout(y, float(dropout), step))
+    lo = _class_head(ctx, y)
+    ctx.tap("final_conv", lo)
+    return ctx.st(_resize(lo, 4, interpolation)).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
 PSP_STAGE = {4: 2, 8: 3, 16: 4}     # downsample_factor -> the stage whose unit1_relu1 is the feature (schemas/segmentation.raml:228-230)
@@ -297,11 +301,12 @@ def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_fi
 
 
 def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8, dropout=None, step=1,
-                          final_interpolation="bilinear", psp_pooling_type="avg"):
+                          final_interpolation="bilinear", psp_pooling_type="avg", storage=None, grad_scale=1.0):
     """feature = stage3_unit1_relu1; for level in 1, 2, 3, 6: AveragePooling2D(size / level) -> Conv 1x1 (no bias) -> BN ->
     ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
-    classes; bilinear x8.  Returns (logits_nhwc, bn_updates)."""
-    ctx = _Ctx(P, training, taps)
+    classes; bilinear x8.  Returns (logits_nhwc, bn_updates).  ``storage``: see _Ctx - stored on the device: the pooled maps, every
+    resized slice of the concatenation, the class convolution (tap-channel form: _class_head) and the resized logits."""
+    ctx = _Ctx(P, training, taps, storage, grad_scale)
     if backbone in VGG_BLOCKS:
         f = _vgg_encoder(ctx, x_nhwc, backbone, stop_block=PSP_STAGE[int(downsample_factor)] + 1)
     else:
@@ -311,15 +316,17 @@ def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=No
     parts = [f]
     for level in (1, 2, 3, 6):
         k = f.shape[2] // level
-        p = (F.max_pool2d if psp_pooling_type == "max" else F.avg_pool2d)(f, kernel_size=k, stride=k)
+        p = ctx.st((F.max_pool2d if psp_pooling_type == "max" else F.avg_pool2d)(f, kernel_size=k, stride=k))
         p = _bn_apply(ctx, _conv(ctx, p, "psp_level%d_conv" % level), "psp_level%d_bn" % level, BN_EPS_DECODER, relu=True)
         ctx.tap("psp_level%d_out" % level, p)
-        parts.append(resize_bilinear_tf1(p, k))
+        parts.append(ctx.st(resize_bilinear_tf1(p, k)))
     y = _bn_apply(ctx, _conv(ctx, torch.cat(parts, dim=1), "psp_final"), "psp_final_bn", BN_EPS_DECODER, relu=True)
+    ctx.tap("psp_final_out", y)
     if dropout and training:
-        y = _spatial_dropout(y, float(dropout), step)
-    lo = _conv(ctx, y, "final_conv", pad=1)
-    return _resize(lo, int(downsample_factor), final_interpolation).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
+        y = ctx.st(_spatial_dropout(y, float(dropout), step))
+    lo = _class_head(ctx, y)
+    ctx.tap("final_conv", lo)
+    return ctx.st(_resize(lo, int(downsample_factor), final_interpolation)).permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
 ENCODER_PREFIXES = ("bn_data", "conv0", "bn0", "stage", "bn1/", "block")
@@ -346,13 +353,16 @@ class _StoreRound(torch.autograd.Function):
     gradient the same way (the gradient of a stored tensor is itself a stored tensor on the device).  Straight-through otherwise."""
 
     @staticmethod
-    def forward(fctx, x, dt):
-        fctx.dt = dt
+    def forward(fctx, x, dt, gscale=1.0):
+        fctx.dt, fctx.gscale = dt, float(gscale)
         return x.to(dt).to(torch.float32)
 
     @staticmethod
     def backward(fctx, g):
-        return g.to(fctx.dt).to(torch.float32), None
+        # (the fp16 build stores gradients TIMES its loss scale - a power of two, divided out by the optimizer: the rounding, and
+        #  what falls below the format's range, happen at that scale)
+        s = fctx.gscale
+        return (g * s).to(fctx.dt).to(torch.float32) / s, None, None
 
 
 class _Ctx:
@@ -360,17 +370,25 @@ class _Ctx:
     the HIP path keeps in HBM in that format - convolution outputs (after the fused residual add), BatchNormalization outputs, the
     pooled / upsampled tensors, the logits - and every gradient of such a tensor is rounded where the kernels round it, and the
     convolutions read rounded weight copies; statistics, accumulation, loss and optimizer stay fp32.  Used to hold the 16-bit
-    training modes to a tight bar (tests/test_model_gpu.py); U-Net / Linknet over the ResNet encoders."""
+    training modes to a tight bar (tests/test_model_gpu.py); U-Net / Linknet / FPN / PSPNet over the ResNet (basic and bottleneck) and
+    VGG encoders.  ``grad_scale``: the loss scale the stored GRADIENTS carry (fp16 build: 2^14 by default, backend.HipSegModel)."""
 
-    def __init__(self, P, training, taps, storage=None):
+    def __init__(self, P, training, taps, storage=None, grad_scale=1.0):
         self.P = P
         self.training = training
         self.taps = taps
         self.bn_updates = OrderedDict()
         self.storage = storage
+        self.grad_scale = float(grad_scale)
 
     def st(self, t):
-        return t if self.storage is None else _StoreRound.apply(t, self.storage)
+        return t if self.storage is None else _StoreRound.apply(t, self.storage, self.grad_scale)
+
+    def wq(self, w):
+        """The 16-bit compute copy of an fp32 master weight (the weight gradient is a function of dY and x only: straight-through)."""
+        if self.storage is None:
+            return w
+        return w + (w.detach().to(self.storage).to(torch.float32) - w.detach())
 
     def tap(self, name, t):
         if self.taps is not None:
@@ -380,13 +398,42 @@ class _Ctx:
 
 def _conv(ctx, x, name, stride=1, pad=0, store=True):
     # Keras HWIO -> torch OIHW ; explicit symmetric ZeroPadding2D + 'valid'
-    w = ctx.P[name + "/kernel"].permute(3, 2, 0, 1)
+    w = ctx.wq(ctx.P[name + "/kernel"].permute(3, 2, 0, 1))
     b = ctx.P.get(name + "/bias")
-    if ctx.storage is not None:
-        # the 16-bit compute copy of the fp32 master (the weight gradient is a function of dY and x only: straight-through)
-        w = w + (w.detach().to(ctx.storage).to(torch.float32) - w.detach())
     y = F.conv2d(x, w, b, stride=stride, padding=pad)
     return ctx.st(y) if store else y       # store=False: the epilogue adds a residual before the one rounding (caller stores)
+
+
+def _conv_transpose(ctx, x, name):
+    """Conv2DTranspose(4x4, strides 2, padding='same'), Keras kernel (kh, kw, out, in): the gradient of a stride-2 'same' convolution =
+    torch padding 1.  Stored like any convolution output."""
+    wt = ctx.wq(ctx.P[name + "/kernel"].permute(3, 2, 0, 1))           # (kh,kw,out,in) -> (in,out,kh,kw)
+    return ctx.st(F.conv_transpose2d(x, wt, stride=2, padding=1))
+
+
+def class_head_uses_taps(cin, classes):
+    """segmentation_training_pipeline_amd/nets.py:_class_head - the condition under which the device evaluates ``final_conv`` of the
+    FPN / PSPNet decoders in its tap-channel form."""
+    return 18 * classes <= cin and cin >= 128
+
+
+def _class_head(ctx, y, name="final_conv"):
+    """``Conv2D(classes, 3x3, padding 1, bias)`` of the FPN / PSPNet decoders.  The fp32 oracle evaluates it directly.  The STORAGE-QUANTISED
+    oracle follows the device's tap-channel form where the device uses it (graph.Plan.conv3x3_taps): a 1x1 convolution into 9 x classes
+    tap channels that are STORED (one rounding per tap), then the shifted taps and the bias summed in fp32 and stored once more."""
+    w = ctx.P[name + "/kernel"]                                        # HWIO
+    classes = int(w.shape[3])
+    if ctx.storage is None or not class_head_uses_taps(int(y.shape[1]), classes):
+        return _conv(ctx, y, name, pad=1)
+    wq = ctx.wq(w)
+    n, _, h, wd = y.shape
+    acc = None
+    for kh in range(3):
+        for kw in range(3):
+            z = ctx.st(F.conv2d(y, wq[kh, kw].t().reshape(classes, -1, 1, 1)))           # tap channel (kh, kw): stored
+            zs = F.pad(z, (1, 1, 1, 1))[:, :, kh:kh + h, kw:kw + wd]                     # out[h, w] += z[h + kh - 1, w + kw - 1]
+            acc = zs if acc is None else acc + zs
+    return ctx.st(acc + ctx.P[name + "/bias"].view(1, -1, 1, 1))
 
 
 def _bn_apply(ctx, x, name, eps, relu):
@@ -458,9 +505,10 @@ def _resnet_encoder(ctx, x_nhwc, backbone, stop_at=None):
     return x, skips
 
 
-def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None):
-    """Linknet (see init_linknet_resnet).  Returns (logits_nhwc, bn_updates)."""
-    ctx = _Ctx(P, training, taps)
+def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, storage=None, grad_scale=1.0):
+    """Linknet (see init_linknet_resnet).  Returns (logits_nhwc, bn_updates).  ``storage``: see _Ctx - the Add() with the encoder
+    feature is a tensor op of its own on the device (stp_add_inplace): the sum is stored."""
+    ctx = _Ctx(P, training, taps, storage, grad_scale)
     if backbone in VGG_BLOCKS:
         x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
         skips = {"s%d" % i: t for i, t in enumerate(sk)}
@@ -472,24 +520,24 @@ def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=N
         pre = "decoder_stage%d_" % i
         x = _bn_apply(ctx, _conv(ctx, x, pre + "conv1"), pre + "bn1", BN_EPS_DECODER, relu=True)
         if pre + "upsample/kernel" in P:      # Conv2DTranspose(4x4, strides 2, padding='same') = torch padding 1
-            x = F.conv_transpose2d(x, P[pre + "upsample/kernel"].permute(3, 2, 0, 1), stride=2, padding=1)
+            x = _conv_transpose(ctx, x, pre + "upsample")
         else:
-            x = F.interpolate(x, scale_factor=2, mode="nearest")
+            x = F.interpolate(x, scale_factor=2, mode="nearest")      # (folded into the convolution's gather: no tensor of its own)
             x = _conv(ctx, x, pre + "conv2", pad=1)
         x = _bn_apply(ctx, x, pre + "bn2", BN_EPS_DECODER, relu=True)
         x = _bn_apply(ctx, _conv(ctx, x, pre + "conv3"), pre + "bn3", BN_EPS_DECODER, relu=True)
         if skip_names[i] is not None:
-            x = x + skips[skip_names[i]]
+            x = ctx.st(x + skips[skip_names[i]])
         ctx.tap(pre + "out", x)
     x = _conv(ctx, x, "final_conv", pad=1)
     return x.permute(0, 2, 3, 1).contiguous(), ctx.bn_updates
 
 
 def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
-                        decoder_filters=(256, 128, 64, 32, 16), storage=None):
+                        decoder_filters=(256, 128, 64, 32, 16), storage=None, grad_scale=1.0):
     """P: dict name -> torch tensor (Keras layouts).  x_nhwc: [N,H,W,C] float32 raw 0..255.
     Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits).  ``storage``: see _Ctx."""
-    ctx = _Ctx(P, training, taps, storage)
+    ctx = _Ctx(P, training, taps, storage, grad_scale)
     if backbone in VGG_BLOCKS:
         x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
         skips = {"s%d" % i: t for i, t in enumerate(sk)}
@@ -501,8 +549,7 @@ def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None
         pre = "decoder_stage%d_" % i
         if pre + "upsample/kernel" in P:
             # Conv2DTranspose(4x4, strides 2, padding='same'): the gradient of a stride-2 'same' conv = torch padding 1
-            wt = P[pre + "upsample/kernel"].permute(3, 2, 0, 1)           # (kh,kw,out,in) -> (in,out,kh,kw)
-            x = F.conv_transpose2d(x, wt, stride=2, padding=1)
+            x = _conv_transpose(ctx, x, pre + "upsample")
             x = _bn_apply(ctx, x, pre + "bn1", BN_EPS_DECODER, relu=True)
             if skip_names[i] is not None:
                 x = torch.cat([x, skips[skip_names[i]]], dim=1)

@@ -32,7 +32,7 @@ class OracleTrainer:
     def __init__(self, params, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss",
                  optimizer="adam", lr=1e-3, freeze_encoder=False, clipnorm=None, clipvalue=None,
                  decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None, architecture="Unet", activation="sigmoid",
-                 net_kwargs=None, storage=None):
+                 net_kwargs=None, storage=None, grad_scale=None):
         self.P = OrderedDict((k, v.copy()) for k, v in params.items())
         self.backbone = backbone
         self.loss_spec = loss
@@ -44,10 +44,12 @@ class OracleTrainer:
         self.net_kwargs = dict(net_kwargs or {})      # PSPNet: downsample_factor
         self.steps_done = 0              # mirrors the device step counter that seeds DeepLab's dropout mask
         self.activation = activation     # "sigmoid": y [N,H,W,1] in {0,1};  "softmax": y [N,H,W,1] class index -> one-hot
-        # "bf16" / "fp16": the storage-quantised oracle (nets._Ctx) - U-Net over ResNet only
+        # "bf16" / "fp16": the storage-quantised oracle (nets._Ctx) - U-Net / Linknet / FPN / PSPNet over the ResNet and VGG encoders.
+        # grad_scale: the loss scale the device's stored gradients carry (None: 1 - the fp16 tests pass the build's 2^14)
         self.storage = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16}[storage]
-        if self.storage is not None and architecture != "Unet":
-            raise ValueError("the storage-quantised oracle covers the U-Net graph")
+        self.grad_scale = float(grad_scale or 1.0)
+        if self.storage is not None and architecture == "DeepLabV3":
+            raise ValueError("the storage-quantised oracle covers the U-Net / Linknet / FPN / PSPNet graphs")
 
     def _forward(self, P, x, training, taps):
         if self.architecture == "DeepLabV3":      # returns PROBABILITIES (the activation is inside the model, deeplab.py)
@@ -55,14 +57,14 @@ class OracleTrainer:
             if self.backbone == "xception":
                 return deeplab.deeplab_xception_forward(P, x, training=training, taps=taps, step=self.steps_done + 1, **self.net_kwargs)
             return deeplab.deeplab_forward(P, x, training=training, taps=taps, step=self.steps_done + 1)
+        q = dict(storage=self.storage, grad_scale=self.grad_scale)
         if self.architecture == "Linknet":
-            return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps)
+            return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps, **q)
         if self.architecture == "PSPNet":
-            return nets.pspnet_resnet_forward(P, x, self.backbone, training=training, taps=taps, step=self.steps_done + 1, **self.net_kwargs)
+            return nets.pspnet_resnet_forward(P, x, self.backbone, training=training, taps=taps, step=self.steps_done + 1, **q, **self.net_kwargs)
         if self.architecture == "FPN":
-            return nets.fpn_resnet_forward(P, x, self.backbone, training=training, taps=taps, step=self.steps_done + 1, **self.net_kwargs)
-        return nets.unet_resnet_forward(P, x, self.backbone, training=training, taps=taps, decoder_filters=self.decoder_filters,
-                                        storage=self.storage)
+            return nets.fpn_resnet_forward(P, x, self.backbone, training=training, taps=taps, step=self.steps_done + 1, **q, **self.net_kwargs)
+        return nets.unet_resnet_forward(P, x, self.backbone, training=training, taps=taps, decoder_filters=self.decoder_filters, **q)
 
     def forward(self, x_nhwc, training=False, taps=None):
         with torch.no_grad():

@@ -766,6 +766,10 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
     const int hv = halo_variant_for(p);
     if (hv >= 0) return stp_conv2d_halo(p, hv, stream);
     if (p && p->tile >= STP_TILE_HALO) return STP_E_BADARG;
+    // forms that ONLY the halo kernel implements: the space-to-depth data gradient (its KH = KW = 2 / Cout = 4 x C0 geometry means
+    // something else to the per-tap kernel) and a folded shortcut on a stride-1 launch - a plan / dispatcher mismatch (STP_HALO=0
+    // against a plan built without it) must fail, never run the generic kernel on these parameters
+    if (p && (p->s2d_dgrad || (p->fold_src && p->src0_mode != STP_SRC_ZEROINS2X))) return STP_E_BADARG;
   }
   ConvArgs a;
   bool c4;

@@ -948,7 +948,8 @@ class Plan(object):
                 fs = fold_shortcut
                 s2d = False
                 if (stride == 2 and k == 3 and pad == 1 and not transpose and src1 is None and x_ng and self.dtype != "fp32" and not stem
-                        and Cout == CoutB and C0 == Cin_master and (Hv, Wv) == (2 * Ho, 2 * Wo) and os.environ.get("STP_S2D", "1") != "0"):
+                        and Cout == CoutB and C0 == Cin_master and (Hv, Wv) == (2 * Ho, 2 * Wo) and os.environ.get("STP_S2D", "1") != "0"
+                        and os.environ.get("STP_HALO", "1") != "0"):      # (stp_conv2d_halo_variant ignores the A/B switch; the dispatcher honours it)
                     # SPACE-TO-DEPTH form (round 5, stp_conv_params.s2d_dgrad): the four output parity classes as ONE dense 2 x 2-tap
                     # convolution of dY into 4 x C0 class-major channels on the halo kernel, stored depth-to-space; the sibling 1x1 /
                     # stride-2 shortcut's dY rides along as a second source (its weights live at class 0 / tap 0 only)
@@ -976,7 +977,7 @@ class Plan(object):
                 folded1 = False
                 if (fs is not None and stride == 1 and k == 3 and pad == 1 and not transpose and not upsample and src1 is None and x_ng
                         and fs.needs_grad and fs.grad_ready and fs.meta.get("wb") is not None and (fs.H, fs.W) == (Ho, Wo)
-                        and fs.meta.get("w_master", (0, 0, 0, 0))[2:] == (C0, 1) and self.dtype != "fp32"):
+                        and fs.meta.get("w_master", (0, 0, 0, 0))[2:] == (C0, 1) and self.dtype != "fp32" and os.environ.get("STP_HALO", "1") != "0"):
                     # the sibling 1x1 / stride-1 shortcut (first unit of ResNet18 / 34's stage 1): its dY is a second source of this launch
                     # whose centre tap carries the shortcut's weights (conv_halo.hip, FOLD1) - no separate launch accumulates into dX
                     q.fold_src, q.fold_weight, q.fold_C = fs.grad.data_ptr(), fs.meta["wb"].data_ptr(), fs.gradC

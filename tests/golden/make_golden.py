@@ -10,6 +10,9 @@
   ``pspnet_resnet18_96.npz`` - outputs of the in-repo oracle (PARITY
   UNPINNED: the reference's Keras path is not runnable) on a seeded synthetic batch; they pin
   the oracle against drift of itself / of the torch build.
+* ``fpn_resnet50_128_fp16.npz`` / ``pspnet_resnet101_96_bf16.npz`` / ``linknet_resnet34_128_bf16.npz`` (``--storage-cases-only``) - the
+  STORAGE-QUANTISED oracle (rounds where the kernels round) on BASELINE.json configs[3] / [4]'s graphs and Linknet at their benchmarked
+  precision, at sizes the CPU finishes in seconds.
 """
 import json
 import os
@@ -139,7 +142,60 @@ def make_unet_fullsize_storage(storage="bf16", size=512, n=2, stride=4):
     print(fname, "loss", o1["loss"], "dice", o1["dice"], "logit range", lg.min(), lg.max())
 
 
+# BASELINE.json configs[3] / [4] (and Linknet) AT THEIR BENCHMARKED PRECISION, at sizes the oracle finishes in seconds:
+# (architecture, backbone, size, classes, storage, gradient scale of the stored gradients = the fp16 build's static loss scale)
+STORAGE_CASES = [("FPN", "resnet50", 128, 3, "fp16", 16384.0), ("PSPNet", "resnet101", 96, 20, "bf16", 1.0), ("Linknet", "resnet34", 128, 1, "bf16", 1.0)]
+
+
+def storage_case_inputs(size, classes, n=2):
+    """Seeded batch of a storage case: S1 images; the 1-class mask of S1, or a blocky class-index map for the softmax heads."""
+    from oracle import step
+    x, y = step.synthetic_batch(n, size, size, seed=1234)
+    if classes > 1:
+        yy, xx = np.mgrid[0:size, 0:size]
+        y = ((yy // 8 + 3 * (xx // 12)) % classes).astype(np.uint8)[None, :, :, None].repeat(n, axis=0)
+    return x, y
+
+
+def storage_case_spec(classes):
+    return ("sigmoid", "binary_crossentropy+1.0*dice_loss") if classes == 1 else ("softmax", "categorical_crossentropy+1.0*dice_loss")
+
+
+def make_storage_case(arch, backbone, size, classes, storage, grad_scale):
+    """One forward + backward of the STORAGE-QUANTISED oracle (``OracleTrainer(storage=...)``) for a non-U-Net graph, next to the fp32
+    oracle's logits of the same step (the test shows the device closer to the former): logits, scalars, every gradient norm, a few
+    gradients in full."""
+    from oracle import nets, step
+    init = {"Linknet": nets.init_linknet_resnet, "FPN": nets.init_fpn_resnet, "PSPNet": nets.init_pspnet_resnet}[arch]
+    P = init(backbone, classes=classes, seed=42)
+    x, y = storage_case_inputs(size, classes)
+    act, spec = storage_case_spec(classes)
+    kw = dict(backbone=backbone, loss=spec, optimizer="adam", lr=1e-3, architecture=arch, activation=act)
+    o = step.OracleTrainer(P, storage=storage, grad_scale=grad_scale, **kw).step(x.astype(np.float32), y.astype(np.float32), apply=False)
+    o32 = step.OracleTrainer(P, **kw).step(x.astype(np.float32), y.astype(np.float32), apply=False)
+    names = list(o["grads"].keys())
+    # gradients kept in full (cosine bars): the class convolution, the stem, and the small convolution kernels / BatchNormalization
+    # vectors spread over the depth of the graph (every kernel above 40 K elements is represented by its norm only: fixture size)
+    small = [k for k in names if o["grads"][k].size <= 40000 and (k.endswith("/kernel") or k.endswith("/gamma"))]
+    keep = ["final_conv/kernel", "conv0/kernel"] + [small[i * (len(small) - 1) // 7] for i in range(8)]
+    keep = list(dict.fromkeys(keep))
+    fname = "%s_%s_%d_%s.npz" % (arch.lower(), backbone, size, storage)
+    np.savez_compressed(
+        os.path.join(HERE, fname), seed=42, arch=arch, backbone=backbone, size=size, classes=classes, storage=storage, grad_scale=grad_scale,
+        x=x, y=y, logits1=o["logits"].astype(np.float32), logits1_fp32=o32["logits"].astype(np.float16),
+        scalars1=np.array([o[k] for k in ("loss", "bce", "dice_loss", "dice", "binary_accuracy")], np.float64),
+        grad_names=np.array(names),
+        grad_l2_step1=np.array([np.sqrt((o["grads"][k].astype(np.float64) ** 2).sum()) for k in names]),
+        full_grad_names=np.array(keep),
+        **{"grad_full_%d" % i: o["grads"][k].astype(np.float32) for i, k in enumerate(keep)})
+    print(fname, "loss", o["loss"], "(fp32 oracle %.5f)" % o32["loss"], "logit range", float(np.abs(o["logits"]).max()))
+
+
 if __name__ == "__main__":
+    if "--storage-cases-only" in sys.argv:
+        for c in STORAGE_CASES:
+            make_storage_case(*c)
+        sys.exit(0)
     if "--fullsize-only" in sys.argv:
         make_unet_fullsize()
         sys.exit(0)
@@ -154,3 +210,5 @@ if __name__ == "__main__":
     make_unet("resnet18", 96, 2, "pspnet_resnet18_96.npz", arch="PSPNet")
     make_unet_fullsize()
     make_unet_fullsize_storage("bf16")
+    for c in STORAGE_CASES:
+        make_storage_case(*c)

@@ -49,6 +49,55 @@ def test_oracle_matches_the_fullsize_golden(golden_dir):
     np.testing.assert_allclose(o1["logits"].astype(np.float64).sum(axis=(2, 3)), g["logits1_row_sums"], atol=2e-4 * size)
 
 
+@pytest.mark.parametrize("fname", ["fpn_resnet50_128_fp16.npz", "pspnet_resnet101_96_bf16.npz", "linknet_resnet34_128_bf16.npz"])
+def test_storage_quantised_oracle_matches_its_golden(golden_dir, fname):
+    """The storage-quantised oracle (nets._Ctx(storage=...)) on the non-U-Net graphs - BASELINE.json configs[3] / [4]'s networks and
+    Linknet at their benchmarked precision - reproduces the fixture it committed (tests/golden/make_golden.py --storage-cases-only):
+    every stored value IS a value of the storage format, the quantised step stays within the format's drift of the fp32 step, and the
+    tap-channel class head (nets._class_head) equals the direct 3x3 convolution when nothing is rounded."""
+    g = np.load(os.path.join(golden_dir, fname))
+    arch, backbone, classes, storage = str(g["arch"]), str(g["backbone"]), int(g["classes"]), str(g["storage"])
+    init = {"Linknet": nets.init_linknet_resnet, "FPN": nets.init_fpn_resnet, "PSPNet": nets.init_pspnet_resnet}[arch]
+    P = init(backbone, classes=classes, seed=int(g["seed"]))
+    act, spec = ("sigmoid", "binary_crossentropy+1.0*dice_loss") if classes == 1 else ("softmax", "categorical_crossentropy+1.0*dice_loss")
+    tr = step.OracleTrainer(P, backbone=backbone, loss=spec, optimizer="adam", lr=1e-3, architecture=arch, activation=act, storage=storage,
+                            grad_scale=float(g["grad_scale"]))
+    o = tr.step(g["x"].astype(np.float32), g["y"].astype(np.float32), apply=False)
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[storage]
+    lg = torch.from_numpy(o["logits"])
+    assert torch.equal(lg.to(dt).to(torch.float32), lg)              # the logits are a STORED tensor
+    ref = g["logits1"]
+    ulp = 2.0 ** (np.floor(np.log2(float(np.abs(ref).max()))) - (7 if storage == "bf16" else 10))
+    d = np.abs(o["logits"] - ref)
+    assert d.mean() <= 0.25 * ulp and d.max() <= 8 * ulp, (d.mean() / ulp, d.max() / ulp)       # (bit-identical on the host that wrote it)
+    np.testing.assert_allclose([o[k] for k in ("loss", "bce", "dice_loss", "dice", "binary_accuracy")], g["scalars1"], rtol=2e-3, atol=2e-4)
+    d32 = np.abs(o["logits"] - g["logits1_fp32"].astype(np.float32))
+    assert 0 < d32.mean() < 0.08 * float(np.abs(ref).max())          # quantised != fp32, and within the format's drift of it
+    names = [str(s) for s in g["grad_names"]]
+    l2 = np.array([np.sqrt((o["grads"][k].astype(np.float64) ** 2).sum()) for k in names])
+    np.testing.assert_allclose(l2, g["grad_l2_step1"], rtol=0.1, atol=1e-3 * float(g["grad_l2_step1"].max()))
+
+
+def test_tap_channel_class_head_equals_the_direct_convolution_without_rounding():
+    """nets._class_head's tap-channel restatement (what graph.Plan.conv3x3_taps computes) against F.conv2d in float64: the identity
+    W_t . shift_t(x) = shift_t(W_t . x) with zero padding, bias added once."""
+    rng = np.random.RandomState(3)
+    P = {"final_conv/kernel": torch.from_numpy(rng.randn(3, 3, 128, 5)).double(), "final_conv/bias": torch.from_numpy(rng.randn(5)).double()}
+    x = torch.from_numpy(rng.randn(2, 128, 7, 9)).double()
+
+    class _F64(nets._Ctx):          # storage "on" (the tap form is taken) with an identity rounding
+        def st(self, t):
+            return t
+
+        def wq(self, w):
+            return w
+    ctx = _F64(P, True, None, storage=torch.float64)
+    assert nets.class_head_uses_taps(128, 5)
+    got = nets._class_head(ctx, x)
+    want = F.conv2d(x, P["final_conv/kernel"].permute(3, 2, 0, 1), P["final_conv/bias"], padding=1)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-10)
+
+
 def test_rle_golden_vectors_from_reference(golden_dir):
     """The in-repo RLE restatement against vectors produced by the reference's own rle.py."""
     from segmentation_pipeline.impl import rle
