@@ -1,12 +1,17 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: U-Net/ResNet-34 training step, 512x512x3 -> 1 class, batch 16 per GPU,
-bf16 MFMA (BASELINE.json configs[1]; configs[2] with --gpus 8 under torch.distributed.run).
+"""Benchmark of the hot path: one training step on one MI355X (N ranks under torch.distributed.run).
 
-One "step" = on-device augmentation of the resident uint8 batch + weight compute copies + forward +
-sigmoid/BCE/Dice loss + backward + (RCCL gradient all-reduce when N > 1) + Adam.  Raw images and
-masks are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+DEFAULT (--config 1, what the driver runs) = BASELINE.json configs[1]: U-Net/ResNet-34, 512x512x3 -> 1 class, batch 16 per GPU, bf16
+MFMA; configs[2] = the same with --gpus 8.  --config 3 = configs[3]: FPN/ResNet-50 1024x1024 3-class batch 4, fp16 MFMA;
+--config 4 = configs[4]: PSPNet/ResNet-101 768x768 20-class batch 8, bf16, heavy augmentation.  Same JSON shape
+for every config (roofline, roofline_hbm, step_traffic_gb, kernel_time_us, cpu_baseline, box_calibration).
+
+One "step" = on-device augmentation of the resident uint8 batch + weight compute copies + forward + loss (sigmoid BCE + Dice, or
+softmax CCE + Dice) + backward + (RCCL gradient all-reduce when N > 1) + Adam.  Raw images and masks are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --config 4 --cpu-baseline short
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
         bench.py --gpus 8 --steps 20 --warmup 5
 """
@@ -23,13 +28,56 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H = W = 512
+H = W = 512          # config 1 (the module-level names are config 1's: dice_delta_vs_oracle, tests)
 BATCH = 16
 LOSS = "binary_crossentropy+1.0*dice_loss"
+LOSS_SOFTMAX = "categorical_crossentropy+1.0*dice_loss"
 # algorithmic work per trained image (BASELINE.md 3 / SURVEY 8d): conv MACs only, 2 FLOP/MAC, 3x forward
 FLOP_PER_IMAGE = 187.94e9
-PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
+
+# BASELINE.json configs by index: network, input, batch per GPU, classes, the precision BASELINE.json names,
+# augmentation pipeline ("S1": the README example + colour jitter = augment.BENCH_SPEC; "S4": heavy = Affine + blur + noise + CropAndPad)
+CONFIGS = {
+    1: dict(architecture="Unet", backbone="resnet34", size=512, batch=16, classes=1, dtype="bf16", augment="S1", pmc=""),
+    3: dict(architecture="FPN", backbone="resnet50", size=1024, batch=4, classes=3, dtype="fp16", augment="S1", pmc="_config3"),
+    4: dict(architecture="PSPNet", backbone="resnet101", size=768, batch=8, classes=20, dtype="bf16", augment="S4", pmc="_config4"),
+}
+_PMC = ""            # suffix of the counter files of the running config: profiles/*_pmc_traffic<_PMC>.json, *_pmc_sq<_PMC>.json
+
+
+def augment_spec(kind):
+    from segmentation_training_pipeline_amd import augment
+    if kind == "S1":
+        return augment.BENCH_SPEC
+    # S4: "heavy augment (Affine + blur + noise + CropAndPad)" on top of the flips and the colour jitter of S1
+    return [{"Fliplr": 0.5}, {"Flipud": 0.5}, {"CropAndPad": {"percent": [-0.1, 0.1]}},
+            {"Affine": {"scale": [0.8, 1.5], "translate_percent": {"x": [-0.2, 0.2], "y": [-0.2, 0.2]}, "rotate": [-16, 16], "shear": [-16, 16]}},
+            {"Add": [-20, 20]}, {"Multiply": [0.8, 1.2]}, {"AdditiveGaussianNoise": {"scale": [0, 12.75]}}, {"GaussianBlur": {"sigma": [0.5, 1.5]}}]
+
+
+def synthetic_data(rank, batch, size, classes):
+    """uniform uint8 images; 1 class: the union of 3 random discs per mask; softmax heads: a class-index map of
+    ``classes`` random regions (nearest random seed point).  Seed 1234 + rank."""
+    rng = np.random.RandomState(1234 + rank)
+    img = rng.randint(0, 256, size=(batch, size, size, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size]
+    msk = np.zeros((batch, size, size), np.uint8)
+    for i in range(batch):
+        if classes == 1:
+            for _ in range(3):
+                cy, cx, r = rng.uniform(0, size), rng.uniform(0, size), rng.uniform(0.08, 0.22) * size
+                msk[i] |= ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r).astype(np.uint8)
+        else:
+            best = np.full((size, size), np.inf)
+            for c in range(classes):
+                cy, cx = rng.uniform(0, size), rng.uniform(0, size)
+                d = (yy - cy) ** 2 + (xx - cx) ** 2
+                msk[i][d < best] = c
+                best = np.minimum(best, d)
+    return rng, img, msk
+
 
 CONV_TILES = {1: "128, 128, 2, 2", 2: "64, 256, 1, 4", 3: "32, 256, 1, 4", 4: "16, 256, 1, 4", 5: "64, 64, 2, 2", 6: "128, 64, 4, 1",
               7: "64, 128, 2, 2"}
@@ -56,6 +104,8 @@ def kernel_key(name, meta, dtype):
             return "conv_scn_stream_kernel<%s>" % t
         if tile == 736:   # 64 -> 64 channels with the weights in registers (conv_sc.hip: stp_conv2d_s64)
             return "conv_s64_stream_kernel<%s>" % t
+        if tile == 800:   # pointwise (1x1 / stride 1) pixel-streaming kernel (conv_pw.hip): <input channels, output channels, waves, tile pixels, ...>
+            return "conv_pw_kernel<%d, %d" % tuple(meta["pw"])
         if tile == 768:   # the stem: persistent form (conv_sc_lean.hip) unless switched off
             return "conv_stem_lean_kernel" if os.environ.get("STP_STEM_LEAN", "1") != "0" else "conv_stem_kernel"
         if tile >= 1024:  # halo-resident 3x3 kernel (conv_halo.hip): <rows of 16 pixels, channels, waves over channels x pixel rows> (the profiler's name carries the epilogue variant as a 5th argument)
@@ -221,7 +271,7 @@ def pmc_traffic(kernel):
     (FETCH_SIZE and WRITE_SIZE need separate passes and a profiler run, so they are not collected live); None if
     that kernel was not in the measured build.  Several instances of one key: dispatch-weighted mean."""
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    names = _pmc_files(pdir, "_pmc_traffic.json")
+    names = _pmc_files(pdir, "_pmc_traffic%s.json" % _PMC)
     for name in names:      # the measurement of THIS build first, then the newest that knows this kernel
         path = os.path.join(pdir, name)
         try:
@@ -240,7 +290,7 @@ def pmc_step_traffic():
     (profiles/*_pmc_traffic.json; the pass runs `steps` eager steps, 3 unless the file says otherwise): (bytes per step, file) or
     (None, None)."""
     pdir = os.path.join(ROOT, "profiles")
-    for name in _pmc_files(pdir, "_pmc_traffic.json"):
+    for name in _pmc_files(pdir, "_pmc_traffic%s.json" % _PMC):
         try:
             with open(os.path.join(pdir, name)) as f:
                 d = json.load(f)
@@ -257,7 +307,7 @@ def pmc_family_traffic(family):
     launches of its pass kernels per step, from the counter file of this build: (bytes per launch, file, kernels) or Nones."""
     pdir = os.path.join(ROOT, "profiles")
     fam = HBM_FAMILIES[family]
-    for name in _pmc_files(pdir, "_pmc_traffic.json"):
+    for name in _pmc_files(pdir, "_pmc_traffic%s.json" % _PMC):
         try:
             with open(os.path.join(pdir, name)) as f:
                 d = json.load(f)
@@ -277,7 +327,7 @@ def pmc_mfma_util(kernel):
     SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles); None when that kernel was not measured.  Several instances of one key:
     weighted by their total duration."""
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    names = _pmc_files(pdir, "_pmc_sq.json")
+    names = _pmc_files(pdir, "_pmc_sq%s.json" % _PMC)
     for name in names:
         try:
             with open(os.path.join(pdir, name)) as f:
@@ -290,27 +340,37 @@ def pmc_mfma_util(kernel):
     return None, None
 
 
-def cpu_baseline(full_protocol=False):
+def cpu_baseline(full_protocol=False, config=1):
     """The in-repo CPU oracle (a PORT: the reference's Keras-CPU fit() is not installable here) running the
-    same step - CPU augmentation (oracle/augment.py, the S1 pipeline of BASELINE.md 4) + forward + Dice/BCE + backward + Adam - on
-    a bounded sample of the workload: U-Net/ResNet-34, 512x512.  DEFAULT = BASELINE.md 4's protocol as written (batch 16, 3 warm-up
-    + 10 timed steps, median: ~5 minutes of host time on the GPU box's cores - the driver's budget for the bench is 30 minutes);
-    ``--cpu-baseline short`` runs batch 16 with 1 warm-up + 3 timed steps (~1.5 minutes) and says so in ``protocol``."""
+    same step - CPU augmentation (oracle/augment.py: warp + point operations + neighbourhood filters of the config's pipeline) +
+    forward + loss + backward + Adam - on a bounded sample of the workload.  Config 1 DEFAULT = BASELINE.md 4's protocol as written
+    (batch 16, 3 warm-up + 10 timed steps, median: ~5 minutes of host time on the GPU box's cores - the driver's budget for the bench
+    is 30 minutes); ``--cpu-baseline short`` runs 1 warm-up + 3 timed steps (~1.5 minutes) and says so in ``protocol``.  Configs 3 / 4:
+    the config's own batch, 1 warm-up + 2 timed steps (full: 1 + 4)."""
     from oracle import augment as oaug
     from oracle import nets as onets
     from oracle import step as ostep
     from segmentation_training_pipeline_amd import augment
-    n, warm, reps = (16, 3, 10) if full_protocol else (16, 1, 3)
-    P = onets.init_unet_resnet("resnet34", seed=42)
-    tr = ostep.OracleTrainer(P, backbone="resnet34", loss=LOSS, optimizer="adam", lr=1e-3)
-    x, y = ostep.synthetic_batch(n, H, W, seed=1234)
-    x8, y8 = x.astype(np.uint8), (y.reshape(n, H, W) > 0).astype(np.uint8)
+    cfg = CONFIGS[config]
+    n, size, classes = cfg["batch"], cfg["size"], cfg["classes"]
+    if config == 1:
+        warm, reps = (3, 10) if full_protocol else (1, 3)
+    else:
+        warm, reps = (1, 4) if full_protocol else (1, 2)
+    init = {"Unet": onets.init_unet_resnet, "FPN": onets.init_fpn_resnet, "PSPNet": onets.init_pspnet_resnet}[cfg["architecture"]]
+    P = init(cfg["backbone"], classes=classes, seed=42)
+    tr = ostep.OracleTrainer(P, backbone=cfg["backbone"], loss=LOSS if classes == 1 else LOSS_SOFTMAX, optimizer="adam", lr=1e-3,
+                             architecture=cfg["architecture"], activation="sigmoid" if classes == 1 else "softmax")
+    _, x8, y8 = synthetic_data(0, n, size, classes)
     rng = np.random.RandomState(1234)
+    spec = augment_spec(cfg["augment"])
 
     def one_step():
-        prm = augment.sample_batch(augment.BENCH_SPEC, rng, n, H, W, (H, W))
-        xa, ya = oaug.warp_u8(x8, y8, prm, (H, W))
-        tr.step(xa.astype(np.float32), ya.reshape(n, H, W, 1).astype(np.float32))
+        prm, filt = augment.sample_batch_ex(spec, rng, n, size, size, (size, size))
+        xa, ya = oaug.warp_u8(x8, y8, prm, (size, size))
+        for ps in range(0 if filt is None else filt.shape[0]):
+            xa = oaug.filter_u8(xa, filt[ps])
+        tr.step(xa.astype(np.float32), ya.reshape(n, size, size, 1).astype(np.float32))
 
     for _ in range(warm):
         one_step()
@@ -320,11 +380,64 @@ def cpu_baseline(full_protocol=False):
         one_step()
         times.append(time.time() - t0)
     med = float(np.median(times))
+    full_name = "BASELINE.md 4" if config == 1 else "configs[%d]: 1 warm-up + 4 timed" % config
     return {"value": round(n / med, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "protocol": "BASELINE.md 4" if full_protocol else "short (batch 16, 1 warm-up + 3 timed, median; BASELINE.md 4 asks 3 + 10)",
+            "protocol": full_name if full_protocol else "short (batch %d, %d warm-up + %d timed, median%s)" % (
+                n, warm, reps, "; BASELINE.md 4 asks 3 + 10" if config == 1 else ""),
             "protocol_detail": "batch %d, %d warm-up + %d timed steps, median" % (n, warm, reps),
-            "sample": "oracle (numpy augmentation + PyTorch-CPU fp32) training step incl. the S1 augmentation, U-Net/ResNet34 512x512x3, "
-                      "batch %d, median of %d timed steps after %d warm-up" % (n, len(times), warm)}
+            "sample": "oracle (numpy augmentation + PyTorch-CPU fp32) training step incl. the %s augmentation, %s/%s %dx%dx3 %d-class, "
+                      "batch %d, median of %d timed steps after %d warm-up" % (cfg["augment"], cfg["architecture"], cfg["backbone"], size, size,
+                                                                              classes, n, len(times), warm)}
+
+
+def box_calibration(dev, seconds=2.0):
+    """What THIS box sustains on two fixed loads, measured before the timed region: boxes of the pool differ by +-2.5 %,
+    more than a round's gain on the step, so a line is comparable with another line only next to these two numbers.
+    ``mfma_tflops``: every SIMD issuing back-to-back v_mfma_f32_32x32x16 on register operands (csrc/calib.hip) for ~``seconds`` -
+    the MFMA rate at the clocks the box holds under full matrix load (nominal 2516.6 at 2.4 GHz; ``sclk_mhz_from_mfma`` = that rate
+    expressed as a clock); ``copy_gbs``: read + write bytes per second of a 1 GiB device copy with 16-byte accesses."""
+    from segmentation_training_pipeline_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream()
+    blocks, iters = 256 * 4, 4096
+    out = torch.zeros(blocks * 512, dtype=torch.float32, device=dev)
+    fl = int(lib.stp_calib_mfma_flops(blocks, iters))
+
+    def mfma():
+        _lib.check(lib.stp_calib_mfma(out.data_ptr(), blocks, iters, st.cuda_stream), "stp_calib_mfma")
+
+    def timed_launches(fn, budget):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st); fn(); e1.record(st)
+        torch.cuda.synchronize()
+        reps = max(3, int(budget / max(e0.elapsed_time(e1) * 1e-3, 1e-6)))
+        evs = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st); fn(); b.record(st)
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+        return reps, ts
+    reps, ts = timed_launches(mfma, seconds)
+    last = ts[len(ts) // 2]                       # the median launch of the sustained region
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    src.zero_()
+
+    def copy():
+        _lib.check(lib.stp_calib_copy(dst.data_ptr(), src.data_ptr(), nbytes, st.cuda_stream), "stp_calib_copy")
+    creps, cts = timed_launches(copy, 0.5)
+    cmed = cts[len(cts) // 2]
+    tf = fl / last / 1e12
+    return {"mfma_tflops": round(tf, 1), "mfma_tflops_first_launch": round(fl / ts[-1] / 1e12, 1), "mfma_launches": reps,
+            "mfma_seconds": round(sum(ts), 2), "sclk_mhz_from_mfma": int(round(tf / 2516.6 * 2400.0)),
+            "copy_gbs": round(2.0 * nbytes / cmed / 1e9, 1), "copy_launches": creps,
+            "how": "csrc/calib.hip: 1024 workgroups x 8 waves x 65536 v_mfma_f32_32x32x16 per launch, median launch of ~%.0f s; 1 GiB device "
+                   "copy (read + write bytes), median of %d" % (seconds, creps)}
 
 
 def dice_delta_vs_oracle(device):
@@ -363,19 +476,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
-                    help="bf16 = the headline mode; fp16 = the IEEE-half build of the same kernels (libstp_hip_f16.so, loss scale 2^14); fp32 = the parity mode")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs index: 1 = U-Net/ResNet34 512x512 bs16 bf16 (the headline, default; configs[2] with --gpus 8); "
+                         "3 = FPN/ResNet50 1024x1024 3-class bs4 fp16; 4 = PSPNet/ResNet101 768x768 20-class bs8 bf16, heavy augmentation")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"],
+                    help="default: the precision BASELINE.json names for the config (bf16 / fp16 / bf16).  bf16 = libstp_hip.so; fp16 = the "
+                         "IEEE-half build of the same kernels (libstp_hip_f16.so, loss scale 2^14); fp32 = the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "short"],
-                    help="full = BASELINE.md 4 as written (batch 16, 3 warm-up + 10 timed steps: ~5 min of host time); short = 1 + 3")
+                    help="config 1: full = BASELINE.md 4 as written (batch 16, 3 warm-up + 10 timed steps: ~5 min of host time); short = 1 + 3.  "
+                         "configs 3 / 4: full = 1 + 4 steps of the config's batch, short = 1 + 2")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--architecture", default="Unet", choices=["Unet", "Linknet", "FPN"],
-                    help="Unet = BASELINE.json's headline workload; Linknet = SURVEY 8f N1 on the same kernels (not the headline metric)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the ~2.5 s box calibration (MFMA rate + copy bandwidth) before the timed region")
+    ap.add_argument("--architecture", default=None, choices=["Unet", "Linknet", "FPN"],
+                    help="config 1 only: Linknet / FPN over ResNet34 on the same shapes (SURVEY 8f N1 workloads, not the headline metric)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (for rocprofv3 kernel traces of the launches themselves)")
     ap.add_argument("--no-feed", action="store_true", help="skip the region fed from pinned host memory (profiler traces of the resident step only)")
     ap.add_argument("--sustain", type=float, default=8.0,
                     help="seconds of extra back-to-back steps after the counted ones, reported as `sustained` (0 = skip; 1-GPU runs only)")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.architecture and args.config != 1:
+        raise SystemExit("--architecture applies to --config 1")
+    arch = args.architecture or cfg["architecture"]
+    args.dtype = args.dtype or cfg["dtype"]
+    H = W = cfg["size"]
+    BATCH, classes = cfg["batch"], cfg["classes"]
+    global _PMC
+    _PMC = cfg["pmc"] if arch == cfg["architecture"] else "_" + arch.lower()
 
     from segmentation_training_pipeline_amd import augment, distributed, ops
     from segmentation_training_pipeline_amd.backend import HipSegModel
@@ -393,25 +521,35 @@ def main():
     distributed.init(os.environ.get("STP_DIST_BACKEND") or "nccl", force=force_dp)
     dev = torch.device("cuda", dev_index)
 
-    model = HipSegModel(args.architecture, "resnet34", (H, W, 3), 1, "sigmoid", batch=BATCH, dtype=args.dtype, loss=LOSS, optimizer="Adam",
-                        lr=1e-3, use_graph=not args.eager, device=str(dev))
+    # what this box sustains on two fixed loads (rank 0, before anything else runs on the device)
+    calib = box_calibration(dev) if (rank == 0 and not args.no_calibration) else None
+    if world > 1:
+        dist.barrier()
+
+    model = HipSegModel(arch, cfg["backbone"], (H, W, 3), classes, "sigmoid" if classes == 1 else "softmax", batch=BATCH, dtype=args.dtype,
+                        loss=LOSS if classes == 1 else LOSS_SOFTMAX, optimizer="Adam", lr=1e-3, use_graph=not args.eager, device=str(dev))
     if world > 1 or force_dp:
         ov = os.environ.get("STP_DP_OVERLAP", "auto")
         model.set_data_parallel(distributed.make_reducer(force=force_dp), overlap={"0": False, "1": True, "auto": True}.get(ov, "buckets"))
 
-    # synthetic data: uniform uint8 images, 3 random discs per mask, seed 1234 + rank
-    rng = np.random.RandomState(1234 + rank)
-    img = rng.randint(0, 256, size=(BATCH, H, W, 3)).astype(np.uint8)
-    yy, xx = np.mgrid[0:H, 0:W]
-    msk = np.zeros((BATCH, H, W), np.uint8)
-    for i in range(BATCH):
-        for _ in range(3):
-            cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(0.08, 0.22) * H
-            msk[i] |= ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r).astype(np.uint8)
+    # synthetic data, seed 1234 + rank
+    rng, img, msk = synthetic_data(rank, BATCH, H, classes)
     raw_img, raw_msk = torch.from_numpy(img).to(dev), torch.from_numpy(msk).to(dev)
     total = args.steps + args.warmup
-    prm = np.stack([augment.sample_batch(augment.BENCH_SPEC, rng, BATCH, H, W, (H, W)) for _ in range(total)])
-    prm = torch.from_numpy(prm).to(dev)
+    # the merged single-pass form of the config's pipeline: one stp_augment_u8 launch (warp + point operations, image and mask) and, for
+    # S4, one stp_filter_u8 launch per neighbourhood filter (the Gaussian blur) through two ping-pong buffers
+    spec = augment_spec(cfg["augment"])
+    sampled = [augment.sample_batch_ex(spec, rng, BATCH, H, W, (H, W)) for _ in range(total)]
+    prm = torch.from_numpy(np.stack([p for p, _ in sampled])).to(dev)
+    npass = max((0 if f is None else f.shape[0]) for _, f in sampled)
+    filt = None
+    if npass:
+        fr = np.zeros((total, npass, BATCH, augment.FILTER_RECORD), np.int32)       # (K = 0: a copy pass)
+        for i, (_, f) in enumerate(sampled):
+            if f is not None:
+                fr[i, :f.shape[0]] = f
+        filt = torch.from_numpy(fr).to(dev)
+        fbuf = [torch.empty_like(raw_img) for _ in range(2)]
     in_img, in_msk = model.plan.inputs["image"].buf, model.plan.inputs["mask"].buf
 
     # The schedules of pipeline.Trainer.run_epoch_sums.  Default: augmentation, then the step, on one stream.  STP_FEED_OVERLAP=1 (opt-in,
@@ -422,7 +560,12 @@ def main():
     aux = torch.cuda.Stream(device=dev)
 
     def augment_into_plan(src_img, src_msk, i):
-        ops.augment_u8(src_img, src_msk, in_img, in_msk, prm[i % total], BATCH, H, W, H, W, 3)
+        if filt is None:
+            ops.augment_u8(src_img, src_msk, in_img, in_msk, prm[i % total], BATCH, H, W, H, W, 3)
+            return
+        ops.augment_u8(src_img, src_msk, fbuf[0], in_msk, prm[i % total], BATCH, H, W, H, W, 3)
+        for ps in range(npass):
+            ops.filter_u8(fbuf[ps & 1], in_img if ps == npass - 1 else fbuf[1 - (ps & 1)], filt[i % total, ps], BATCH, H, W, 3)
 
     def step(i):
         if not overlap:
@@ -467,6 +610,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     elapsed = timed(step, args.warmup, args.steps)          # the contract's region: raw uint8 batch RESIDENT in HBM
+
+    # ---- the network alone (no augmentation launch): the part of the step the launch tables / floor tables describe.  Configs 3 / 4 only
+    # (config 1 keeps its established region list); the batch in the plan's input buffers is the last augmented one
+    elapsed_model = None
+    if args.config != 1 and not overlap:
+        elapsed_model = timed(lambda i: model.train_on_batch(None, None, fetch=False), 0, args.steps)
 
     # ---- the same step FED from pinned host memory (north_star: "fed by pinned hipMemcpyAsync"): NHOST distinct raw batches in pinned
     # memory, THREE device staging buffers, a copy stream.  The host stays at most two steps ahead of the GPU (it waits for step i - 2
@@ -538,19 +687,24 @@ def main():
     metrics = model.metrics()
     images_per_sec = world * BATCH * args.steps / elapsed
 
+    net_name = "%s/%s" % ("U-Net" if arch == "Unet" else arch, cfg["backbone"].replace("resnet", "ResNet"))
+    which = ("BASELINE.json configs[%d]" % args.config) if arch == cfg["architecture"] else "SURVEY 8f N1 workload, not the headline metric"
+    loss_name = "BCE+Dice" if classes == 1 else "softmax CCE+Dice"
     out = {
-        "metric": "images/sec %s/ResNet34 512x512 bs16 training step" % ("U-Net" if args.architecture == "Unet" else args.architecture), "value": round(images_per_sec, 2), "unit": "images/sec",
+        "metric": "images/sec %s %dx%d bs%d training step" % (net_name, H, W, BATCH), "value": round(images_per_sec, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("U-Net" if args.architecture == "Unet" else args.architecture) + "/ResNet34 512x512x3 1-class, batch 16 per GPU, BCE+Dice, Adam, on-device augment "
-                               "(%s%s)" % ("BASELINE.json configs[1]" if args.architecture == "Unet" else "SURVEY 8f N1 workload, not the headline metric",
-                                           "; configs[2] data-parallel" if world > 1 else ""),
+        "config": {"workload": "%s %dx%dx3 %d-class, batch %d per GPU, %s, Adam, on-device augment %s (%s%s)"
+                               % (net_name, H, W, classes, BATCH, loss_name, cfg["augment"], which,
+                                  "; configs[2] data-parallel" if (world > 1 and args.config == 1) else ""),
+                   "baseline_config_index": args.config,
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "hipgraph": not args.eager, "loss_after_run": round(metrics["loss"], 5), "dp_schedule": dp_schedule},
         # algorithmic FLOP per trained image = 3 x the forward conv FLOP the plan recorded (187.94 GFLOP for the U-Net)
         "step_mfma_frac": round(images_per_sec / world * flop_per_image(model) / (PEAK_BF16_TFLOPS * 1e12), 4),
         # the same K steps with every batch copied from pinned host memory (double-buffered hipMemcpyAsync on a copy stream)
         "ms_per_step_resident": round(1e3 * elapsed / args.steps, 3),
+        "ms_per_step_without_augmentation": round(1e3 * elapsed_model / args.steps, 3) if elapsed_model else None,
         "ms_per_step_with_feed": round(1e3 * elapsed_fed / args.steps, 3) if elapsed_fed else None,
         "value_with_feed": round(world * BATCH * args.steps / elapsed_fed, 2) if elapsed_fed else None,
     }
@@ -611,9 +765,12 @@ def main():
         out["gemm_time_us"] = round(1e6 * sum(v[1] for v in gemm.values()), 1)
         out["non_gemm_time_us"] = round(1e6 * (tot - sum(v[1] for v in gemm.values())), 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.dtype == "bf16" and args.architecture == "Unet":
+        if args.dtype == "bf16" and arch == "Unet" and args.config == 1:
             out["config"]["dice_delta_vs_oracle"] = dice_delta_vs_oracle(str(dev))
-        out["cpu_baseline"] = cpu_baseline(full_protocol=args.cpu_baseline == "full")
+        if arch == cfg["architecture"]:
+            out["cpu_baseline"] = cpu_baseline(full_protocol=args.cpu_baseline == "full", config=args.config)
+    if calib is not None:
+        out["box_calibration"] = calib
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():

@@ -652,6 +652,35 @@ int stp_background_replace_u8(const uint8_t* img, const uint8_t* mask, const uin
 int stp_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);
 int stp_cast_bf16_to_f32(const void* src, float* dst, int64_t count, float scale, void* stream);
 
+/* Batched reduce of lone weight gradients (round 6; the weight gradient of Keras' backward feeds only the optimizer, so its split-K
+ * reduction can wait): a layer whose stp_conv2d_wgrad_partial launch (variant 0) wrote plain [splits][Cout * KH * KW * C] slabs into a
+ * workspace OF ITS OWN adds a descriptor to a host table (stp_wgrad_reduce_desc_fill: returns the layer's element count, 0 = this layer
+ * keeps its own stp_conv2d_wgrad_reduce); the table, copied to the device, is reduced by ONE launch (n layers, max_count = the largest
+ * element count).  Deterministic (fixed walk, fixed tree). */
+size_t stp_wgrad_reduce_desc_bytes(void);
+int64_t stp_wgrad_reduce_desc_fill(void* host_table, int32_t index, const stp_wgrad_params* p, const void* workspace);
+int stp_wgrad_reduce_batched(const void* table_dev, int32_t n, int64_t max_count, void* stream);
+
+/* Conv2D(1x1, strides 1) of the bottleneck ResNets (classification_models residual_bottleneck_block conv1 / conv3 / the stride-1 shortcut,
+ * segmentation_models' FPN laterals; reached through segmentation.py:109-118) and its data gradient, 16-bit storage, 64 ... 512 channels
+ * (stp_conv2d_pw_eligible: the served (C0, Cout) pairs, N * Ho * Wo a multiple of the tile): a pixel-STREAMING kernel - persistent
+ * workgroups, the whole weight matrix as register-resident MFMA fragments, pixels double-buffered by LDS-DMA, epilogue (bias | statistics
+ * (+ residual) | BatchNormalization backward (+ accumulate)) from the accumulators with 16-byte accesses.  stp_conv2d dispatches to it
+ * (STP_PW=0 switches the automatic use off; tile = 800 forces it).  The [2][Cout][columns] table of fused sums has ONE column per
+ * workgroup: stp_conv2d_pw_cols (= stp_conv2d_stats_floats / (2 Cout)). */
+int stp_conv2d_pw_eligible(const stp_conv_params* p);
+int stp_conv2d_pw_cols(const stp_conv_params* p);
+int stp_conv2d_pw(const stp_conv_params* p, void* stream);
+
+/* Box calibration probes (bench.py `box_calibration`; no counterpart in the reference - the boxes of one MI355X pool differ by +-2.5 % in
+ * sustained clocks, more than one round's gain on the step, so the bench line states what the box it ran on sustains):
+ * stp_calib_mfma - `blocks` workgroups of 8 waves, each wave `iters` x 16 back-to-back v_mfma_f32_32x32x16 of the build's 16-bit
+ * format on register operands (stp_calib_mfma_flops(blocks, iters) = the FLOP of one launch); out: >= blocks * 512 floats of scratch.
+ * stp_calib_copy - device copy with 16-byte accesses (bytes a multiple of 16, both pointers 16-byte aligned). */
+int64_t stp_calib_mfma_flops(int32_t blocks, int32_t iters);
+int stp_calib_mfma(float* out, int32_t blocks, int32_t iters, void* stream);
+int stp_calib_copy(void* dst, const void* src, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -241,13 +241,13 @@ def _resize(x, f, interpolation):
 
 
 def fpn_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, dropout=None, step=1, interpolation="bilinear",
-                       storage=None, grad_scale=1.0):
+                       storage=None, grad_scale=1.0, accum64=False):
     """Pyramid over [encoder output, stage4/3/2 unit-1 relu1]: lateral Conv2D 1x1 (bias) + UpSampling2D(2) of the level above,
     two (Conv2D 3x3 no bias, BN, ReLU) per level; the maps resized to 1/4 resolution, concatenated finest first,
     Conv 3x3 + BN + ReLU (4 x 128 filters), Conv2D 3x3 to the classes, bilinear x4.  Returns (logits_nhwc, bn_updates).
     ``storage``: see _Ctx - stored on the device: the lateral convolution, the top-down sum (stp_upsample2x_add, in place), every
     resized slice of the concatenation, the class convolution (tap-channel form: _class_head) and the resized logits."""
-    ctx = _Ctx(P, training, taps, storage, grad_scale)
+    ctx = _Ctx(P, training, taps, storage, grad_scale, accum64)
     if backbone in VGG_BLOCKS:
         x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
         levels = (x, sk[0], sk[1], sk[2])
@@ -301,12 +301,12 @@ def init_pspnet_resnet(backbone="resnet34", in_ch=3, classes=1, seed=42, conv_fi
 
 
 def pspnet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, downsample_factor=8, dropout=None, step=1,
-                          final_interpolation="bilinear", psp_pooling_type="avg", storage=None, grad_scale=1.0):
+                          final_interpolation="bilinear", psp_pooling_type="avg", storage=None, grad_scale=1.0, accum64=False):
     """feature = stage3_unit1_relu1; for level in 1, 2, 3, 6: AveragePooling2D(size / level) -> Conv 1x1 (no bias) -> BN ->
     ReLU -> bilinear resize back; Concatenate([feature, l1, l2, l3, l6]); Conv 1x1 + BN + ReLU (512); Conv2D 3x3 to the
     classes; bilinear x8.  Returns (logits_nhwc, bn_updates).  ``storage``: see _Ctx - stored on the device: the pooled maps, every
     resized slice of the concatenation, the class convolution (tap-channel form: _class_head) and the resized logits."""
-    ctx = _Ctx(P, training, taps, storage, grad_scale)
+    ctx = _Ctx(P, training, taps, storage, grad_scale, accum64)
     if backbone in VGG_BLOCKS:
         f = _vgg_encoder(ctx, x_nhwc, backbone, stop_block=PSP_STAGE[int(downsample_factor)] + 1)
     else:
@@ -373,13 +373,17 @@ class _Ctx:
     training modes to a tight bar (tests/test_model_gpu.py); U-Net / Linknet / FPN / PSPNet over the ResNet (basic and bottleneck) and
     VGG encoders.  ``grad_scale``: the loss scale the stored GRADIENTS carry (fp16 build: 2^14 by default, backend.HipSegModel)."""
 
-    def __init__(self, P, training, taps, storage=None, grad_scale=1.0):
+    def __init__(self, P, training, taps, storage=None, grad_scale=1.0, accum64=False):
         self.P = P
         self.training = training
         self.taps = taps
         self.bn_updates = OrderedDict()
         self.storage = storage
         self.grad_scale = float(grad_scale)
+        # accum64: every convolution accumulates in float64 (then rounds to fp32, then to the storage format) - a SECOND, equally valid
+        # evaluation of the same rounding points: the distance between the two oracles is the noise floor of a 16-bit step (which way
+        # the rounding ties of ~10^6 stored values fall), the yardstick the device is held to (tests/test_model_gpu.py)
+        self.accum64 = bool(accum64)
 
     def st(self, t):
         return t if self.storage is None else _StoreRound.apply(t, self.storage, self.grad_scale)
@@ -400,7 +404,10 @@ def _conv(ctx, x, name, stride=1, pad=0, store=True):
     # Keras HWIO -> torch OIHW ; explicit symmetric ZeroPadding2D + 'valid'
     w = ctx.wq(ctx.P[name + "/kernel"].permute(3, 2, 0, 1))
     b = ctx.P.get(name + "/bias")
-    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if ctx.accum64:
+        y = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride, padding=pad).float()
+    else:
+        y = F.conv2d(x, w, b, stride=stride, padding=pad)
     return ctx.st(y) if store else y       # store=False: the epilogue adds a residual before the one rounding (caller stores)
 
 
@@ -430,7 +437,8 @@ def _class_head(ctx, y, name="final_conv"):
     acc = None
     for kh in range(3):
         for kw in range(3):
-            z = ctx.st(F.conv2d(y, wq[kh, kw].t().reshape(classes, -1, 1, 1)))           # tap channel (kh, kw): stored
+            wt = wq[kh, kw].t().reshape(classes, -1, 1, 1)
+            z = ctx.st(F.conv2d(y.double(), wt.double()).float() if ctx.accum64 else F.conv2d(y, wt))       # tap channel (kh, kw): stored
             zs = F.pad(z, (1, 1, 1, 1))[:, :, kh:kh + h, kw:kw + wd]                     # out[h, w] += z[h + kh - 1, w + kw - 1]
             acc = zs if acc is None else acc + zs
     return ctx.st(acc + ctx.P[name + "/bias"].view(1, -1, 1, 1))
@@ -505,10 +513,10 @@ def _resnet_encoder(ctx, x_nhwc, backbone, stop_at=None):
     return x, skips
 
 
-def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, storage=None, grad_scale=1.0):
+def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None, storage=None, grad_scale=1.0, accum64=False):
     """Linknet (see init_linknet_resnet).  Returns (logits_nhwc, bn_updates).  ``storage``: see _Ctx - the Add() with the encoder
     feature is a tensor op of its own on the device (stp_add_inplace): the sum is stored."""
-    ctx = _Ctx(P, training, taps, storage, grad_scale)
+    ctx = _Ctx(P, training, taps, storage, grad_scale, accum64)
     if backbone in VGG_BLOCKS:
         x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
         skips = {"s%d" % i: t for i, t in enumerate(sk)}
@@ -534,10 +542,10 @@ def linknet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=N
 
 
 def unet_resnet_forward(P, x_nhwc, backbone="resnet34", training=True, taps=None,
-                        decoder_filters=(256, 128, 64, 32, 16), storage=None, grad_scale=1.0):
+                        decoder_filters=(256, 128, 64, 32, 16), storage=None, grad_scale=1.0, accum64=False):
     """P: dict name -> torch tensor (Keras layouts).  x_nhwc: [N,H,W,C] float32 raw 0..255.
     Returns (logits_nhwc, bn_updates).  Probabilities = sigmoid(logits).  ``storage``: see _Ctx."""
-    ctx = _Ctx(P, training, taps, storage, grad_scale)
+    ctx = _Ctx(P, training, taps, storage, grad_scale, accum64)
     if backbone in VGG_BLOCKS:
         x, sk = _vgg_encoder(ctx, x_nhwc, backbone)
         skips = {"s%d" % i: t for i, t in enumerate(sk)}

@@ -32,7 +32,7 @@ class OracleTrainer:
     def __init__(self, params, backbone="resnet34", loss="binary_crossentropy+1.0*dice_loss",
                  optimizer="adam", lr=1e-3, freeze_encoder=False, clipnorm=None, clipvalue=None,
                  decoder_filters=(256, 128, 64, 32, 16), opt_kwargs=None, architecture="Unet", activation="sigmoid",
-                 net_kwargs=None, storage=None, grad_scale=None):
+                 net_kwargs=None, storage=None, grad_scale=None, accum64=False):
         self.P = OrderedDict((k, v.copy()) for k, v in params.items())
         self.backbone = backbone
         self.loss_spec = loss
@@ -48,6 +48,7 @@ class OracleTrainer:
         # grad_scale: the loss scale the device's stored gradients carry (None: 1 - the fp16 tests pass the build's 2^14)
         self.storage = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16}[storage]
         self.grad_scale = float(grad_scale or 1.0)
+        self.accum64 = bool(accum64)         # float64 accumulation inside the convolutions: the second evaluation of the same rounding points
         if self.storage is not None and architecture == "DeepLabV3":
             raise ValueError("the storage-quantised oracle covers the U-Net / Linknet / FPN / PSPNet graphs")
 
@@ -57,7 +58,7 @@ class OracleTrainer:
             if self.backbone == "xception":
                 return deeplab.deeplab_xception_forward(P, x, training=training, taps=taps, step=self.steps_done + 1, **self.net_kwargs)
             return deeplab.deeplab_forward(P, x, training=training, taps=taps, step=self.steps_done + 1)
-        q = dict(storage=self.storage, grad_scale=self.grad_scale)
+        q = dict(storage=self.storage, grad_scale=self.grad_scale, accum64=self.accum64)
         if self.architecture == "Linknet":
             return nets.linknet_resnet_forward(P, x, self.backbone, training=training, taps=taps, **q)
         if self.architecture == "PSPNet":

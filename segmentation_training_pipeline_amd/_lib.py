@@ -70,6 +70,9 @@ SIGNATURES = {
     "stp_conv2d_s64": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_s64_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_s64_stats_tiles": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_pw_eligible": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_pw_cols": (i32, [C.POINTER(ConvParams)]),
+    "stp_conv2d_pw": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_stem_eligible": (i32, [C.POINTER(ConvParams)]),
     "stp_conv2d_stem": (i32, [C.POINTER(ConvParams), vp]),
     "stp_conv2d_halo_variant": (i32, [C.POINTER(ConvParams)]),
@@ -79,6 +82,9 @@ SIGNATURES = {
     "stp_conv2d_wgrad": (i32, [C.POINTER(WgradParams), vp, sz, vp]),
     "stp_conv2d_wgrad_partial": (i32, [C.POINTER(WgradParams), vp, sz, i32, vp]),
     "stp_conv2d_wgrad_reduce": (i32, [C.POINTER(WgradParams), vp, i32, vp]),
+    "stp_wgrad_reduce_desc_bytes": (sz, []),
+    "stp_wgrad_reduce_desc_fill": (i64, [vp, i32, C.POINTER(WgradParams), vp]),
+    "stp_wgrad_reduce_batched": (i32, [vp, i32, i64, vp]),
     "stp_wgrad_sc_eligible": (i32, [C.POINTER(WgradParams)]),
     "stp_wgrad_sc_slabs": (i32, [C.POINTER(WgradParams)]),
     "stp_wgrad_sc_partial": (i32, [C.POINTER(WgradParams), vp, vp]),
@@ -176,6 +182,9 @@ SIGNATURES = {
     "stp_background_replace_u8": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "stp_cast_bf16_to_f32": (i32, [vp, vp, i64, f32, vp]),
+    "stp_calib_mfma_flops": (i64, [i32, i32]),
+    "stp_calib_mfma": (i32, [vp, i32, i32, vp]),
+    "stp_calib_copy": (i32, [vp, vp, i64, vp]),
 }
 
 _libs = {}          # storage format ("bf16" | "fp16") -> loaded library

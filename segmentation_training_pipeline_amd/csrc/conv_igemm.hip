@@ -591,6 +591,10 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
     // STP_DGRAD1X1_BNB_K=<largest K> for A/Bs)
     static const int k71 = getenv("STP_DGRAD1X1_BNB_K") ? atoi(getenv("STP_DGRAD1X1_BNB_K")) : 256;
     if (a.bnb.x && a.KH == 1 && a.KW == 1 && a.K <= k71 && mid >= 384) return 64 + 7;
+    // deep-K 1x1 GEMMs (PSPNet's psp_final: 2560 -> 512 and its data gradient at 8 x 96 x 96, 40 / 8 K steps of 64): STP_1X1_DEEPK_TILE
+    // = the tile id for 1x1 launches with K >= 512 (experiments: 97 / 129 = the 128 x 128 tile with a 3 / 4-stage ring)
+    static const int deepk = getenv("STP_1X1_DEEPK_TILE") ? atoi(getenv("STP_1X1_DEEPK_TILE")) : 0;
+    if (deepk > 0 && a.KH == 1 && a.KW == 1 && a.K >= 512 && big >= 384) return deepk;
     if (big >= 384) return 64 + 1;
     if (mid >= 384) return 64 + 6;
     return 128 + 5;
@@ -644,6 +648,10 @@ static int halo_variant_for(const stp_conv_params* p) {
 #define STP_TILE_SCW 640  // the wide-output (two-destination, 2x2-summed) data-gradient kernel of conv_sc.hip
 #define STP_TILE_SCN 704  // the narrow-output (upsample + concat -> 32 channels) forward kernel of conv_sc.hip
 #define STP_TILE_S64 736  // the 64 -> 64 channel weights-in-registers kernel of conv_sc.hip (opt-in: STP_S64=1, or this tile id)
+#define STP_TILE_PW 800   // the pointwise (1x1 / stride 1) pixel-streaming kernel of conv_pw.hip (round 6)
+extern "C" int stp_conv2d_pw_eligible(const stp_conv_params* p);
+extern "C" int stp_conv2d_pw_cols(const stp_conv_params* p);
+extern "C" int stp_conv2d_pw(const stp_conv_params* p, void* stream);
 static bool s64_auto() {
   static const bool on = getenv("STP_S64") && atoi(getenv("STP_S64")) == 1;
   return on;
@@ -656,6 +664,8 @@ extern "C" int stp_conv2d_tile_for(const stp_conv_params* p) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_SCN) && stp_conv2d_scn_eligible(p)) return STP_TILE_SCN;
   if (p && ((p->tile == 0 && s64_auto()) || p->tile == STP_TILE_S64) && stp_conv2d_s64_eligible(p)) return STP_TILE_S64;
   if (p && (p->tile == 0 || p->tile == STP_TILE_STEM) && stp_conv2d_stem_eligible(p)) return STP_TILE_STEM;
+  if (p && (p->tile == 0 || p->tile == STP_TILE_PW) && stp_conv2d_pw_eligible(p)) return STP_TILE_PW;
+  if (p && p->tile == STP_TILE_PW) return STP_E_BADARG;
   {
     const int hv = halo_variant_for(p);
     if (hv >= 0) return STP_TILE_HALO + hv;
@@ -679,6 +689,7 @@ extern "C" size_t stp_conv2d_stats_floats(const stp_conv_params* p) {
   if (tile == STP_TILE_SCN) return (size_t)stp_conv2d_scn_stats_tiles(p) * 2 * p->Cout;
   if (tile == STP_TILE_S64) return (size_t)stp_conv2d_s64_stats_tiles(p) * 2 * p->Cout;
   if (tile == STP_TILE_STEM) return (size_t)stp_conv2d_stem_stats_tiles(p) * 2 * p->Cout;
+  if (tile == STP_TILE_PW) return (size_t)stp_conv2d_pw_cols(p) * 2 * p->Cout;
   if (tile >= STP_TILE_HALO) return (size_t)stp_conv2d_halo_tiles(p, tile - STP_TILE_HALO) * 2 * (p->dst_sum2x2 ? p->Cd0 : p->Cout);
   return (size_t)ceil_div((int64_t)p->N * p->Ho * p->Wo, tile_pixels(tile)) * 2 * p->Cout;
 }
@@ -732,7 +743,7 @@ static bool fold_geometry_ok(const ConvArgs& a) { return a.KH == 3 && a.KW == 3 
 
 extern "C" int stp_conv2d_fold_ok(const stp_conv_params* p) {
   static const bool on = !(getenv("STP_FOLD_SHORTCUT") && atoi(getenv("STP_FOLD_SHORTCUT")) == 0);
-  if (!on || !p || p->tile != 0 || stp_conv2d_sc_eligible(p) || stp_conv2d_scw_eligible(p) || stp_conv2d_scn_eligible(p) || (s64_auto() && stp_conv2d_s64_eligible(p)) || stp_conv2d_stem_eligible(p) || halo_variant_for(p) >= 0) return 0;
+  if (!on || !p || p->tile != 0 || stp_conv2d_sc_eligible(p) || stp_conv2d_scw_eligible(p) || stp_conv2d_scn_eligible(p) || (s64_auto() && stp_conv2d_s64_eligible(p)) || stp_conv2d_stem_eligible(p) || stp_conv2d_pw_eligible(p) || halo_variant_for(p) >= 0) return 0;
   ConvArgs a;
   bool c4;
   int ut;
@@ -761,6 +772,10 @@ extern "C" int stp_conv2d(const stp_conv_params* p, void* stream) {
   if (p && (p->tile == 0 || p->tile == STP_TILE_STEM)) {
     if (stp_conv2d_stem_eligible(p)) return stp_conv2d_stem(p, stream);
     if (p->tile == STP_TILE_STEM) return STP_E_BADARG;
+  }
+  if (p && (p->tile == 0 || p->tile == STP_TILE_PW)) {
+    if (stp_conv2d_pw_eligible(p)) return stp_conv2d_pw(p, stream);
+    if (p->tile == STP_TILE_PW) return STP_E_BADARG;
   }
   {
     const int hv = halo_variant_for(p);

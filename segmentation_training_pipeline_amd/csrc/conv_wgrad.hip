@@ -2089,6 +2089,73 @@ extern "C" int stp_conv2d_wgrad_reduce(const stp_wgrad_params* p, const void* wo
   return STP_OK;
 }
 
+// ---- batched reduce of lone weight gradients (round 6) ---------------------------------------------------------------------------------
+// The bottleneck ResNets' 1x1 layers never neighbour a layer of their own class, so each ran partial launch + reduce launch: 59 reduces per
+// step on FPN/ResNet50, 30 on PSPNet/ResNet101 at ~9 us each (profiles/r06a_floor_config{3,4}.txt: 576 / 260 us = 3.7 % / 2.9 % of the
+// step) for 1 - 16 MB of slabs - launch latency, not bytes.  The weight gradient feeds nothing but the optimizer: a layer whose slabs are
+// the plain [splits][Cout * K] form keeps them in a workspace OF ITS OWN and its reduce joins a table; one launch (grid y = layer) reduces
+// up to STP_WGRAD_REDUCE_BATCH layers.  Same 16-lane walk + fixed-shape tree as wgrad_reduce_wide_kernel: deterministic.
+struct WgReduceDesc {
+  const float* slabs;
+  float* dw;
+  int64_t count;
+  int32_t splits, accumulate;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduceDesc* __restrict__ D) {
+  const WgReduceDesc d = D[blockIdx.y];
+  if ((int64_t)blockIdx.x * 64 >= d.count) return;                      // (workgroup-uniform: the grid is sized for the largest layer)
+  __shared__ f32x4 sh[16][16];
+  const int ev = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = ((int64_t)blockIdx.x * 16 + ev) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < d.count) {
+    int k = sl;
+    for (; k + 112 < d.splits; k += 128) {      // eight loads in flight per lane; same order of additions as the one-by-one loop
+      f32x4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(d.slabs + (size_t)(k + 16 * u) * d.count + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += a[u];
+    }
+    for (; k < d.splits; k += 16) s += *reinterpret_cast<const f32x4*>(d.slabs + (size_t)k * d.count + i);
+  }
+  sh[sl][ev] = s;
+  __syncthreads();
+  for (int w = 8; w > 0; w >>= 1) {
+    if (sl < w) sh[sl][ev] += sh[sl + w][ev];
+    __syncthreads();
+  }
+  if (sl == 0 && i < d.count) {
+    f32x4 r = sh[0][ev];
+    if (d.accumulate) r += *reinterpret_cast<const f32x4*>(d.dw + i);
+    *reinterpret_cast<f32x4*>(d.dw + i) = r;
+  }
+}
+
+extern "C" size_t stp_wgrad_reduce_desc_bytes() { return sizeof(WgReduceDesc); }
+
+// Fills descriptor `index` of a host table for the layer `p` whose partial launch (stp_conv2d_wgrad_partial, variant 0) wrote `workspace`.
+// Returns the element count of the layer (> 0), or 0 when its slabs are not the plain [splits][Cout * KH * KW * C] form (row-of-taps
+// kernels: fragment-major slabs) - such a layer keeps its own stp_conv2d_wgrad_reduce launch.
+extern "C" int64_t stp_wgrad_reduce_desc_fill(void* host_table, int32_t index, const stp_wgrad_params* p, const void* workspace) {
+  if (!host_table || index < 0 || !p || !p->dw || !workspace) return 0;
+  if (wgrad_row_auto(p) && !stp_wgrad_sc_eligible(p)) return 0;
+  const WgradPlan w = plan_wgrad(p);
+  const int64_t count = (int64_t)p->Cout * p->KH * p->KW * (p->C0 + p->C1);
+  if (w.splits < 1 || count <= 0 || (count & 3)) return 0;
+  WgReduceDesc& d = reinterpret_cast<WgReduceDesc*>(host_table)[index];
+  d.slabs = (const float*)workspace; d.dw = p->dw; d.count = count; d.splits = w.splits; d.accumulate = p->accumulate;
+  return count;
+}
+
+extern "C" int stp_wgrad_reduce_batched(const void* table_dev, int32_t n, int64_t max_count, void* stream) {
+  if (!table_dev || n <= 0 || max_count <= 0) return STP_E_BADARG;
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(ceil_div(max_count, 64), n), dim3(256), 0, (hipStream_t)stream, (const WgReduceDesc*)table_dev);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 extern "C" int stp_conv2d_wgrad(const stp_wgrad_params* p, void* workspace, size_t workspace_bytes, void* stream) {
   const int rc = stp_conv2d_wgrad_partial(p, workspace, workspace_bytes, 0, stream);
   if (rc != STP_OK) return rc;

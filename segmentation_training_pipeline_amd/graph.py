@@ -121,6 +121,17 @@ class Plan(object):
         # grouped weight gradients (stp_wgrad_group_*): the row-of-taps layers of a stage are collected and issued as ONE partial
         # + ONE reduce launch once their work reaches this many GFLOP (0: every layer is launched alone, as in round 2)
         self.wgrad_group_gflop = float(os.environ.get("STP_WGRAD_GROUP_GFLOP", "300"))
+        # a LONE row-of-taps layer of the 128-channel class this large runs as a one-layer group on the all-taps kernel (_flush_wgroup):
+        # FPN/ResNet50's `fpn_final` (512 -> 512 at 4 x 256 x 256, 1.24 TFLOP) 14.30 -> 14.04 and 14.62 -> 14.49 ms per step on two boxes
+        # (profiles/r06e_step_ab.txt); 0 = never
+        self.wgrad_lone_group_gflop = float(os.environ.get("STP_WGRAD_LONE_GROUP_GFLOP", "600"))
+        # lone weight gradients with plain slabs (the bottleneck ResNets' 1x1 layers, stride-2 layers): their reduces can wait in a table and
+        # run as ONE launch per STP_WGRAD_REDUCE_BATCH layers.  OPT-IN (default 0 = one reduce launch per layer): measured SLOWER on the
+        # step - FPN/ResNet50 14.62 -> 14.77 ms, PSPNet/ResNet101 8.06 -> 8.07, U-Net/ResNet34 6.350 -> 6.370 (same box, two interleaved
+        # repetitions, profiles/r06e_step_ab.txt): the 59 / 30 / 7 launches saved (~9 us each in the eager table, ~3 in the graph) cost less
+        # than reading 1 - 16 MB of slabs per layer back from HBM instead of from the cache the partial launch just wrote them through
+        self.reduce_batch = int(os.environ.get("STP_WGRAD_REDUCE_BATCH", "0")) if not self.side_stream_wgrad else 0
+        self._pending_reduces, self._pending_reduce_hi = [], 0
         self._wgroup, self._wgroup_cls, self._wgroup_flops, self._wgroup_hi = [], 0, 0.0, 0
         self._wgroup_reads = set()      # dY buffers of the pending layers: nothing may rewrite them before the group is issued
         self.wgroups = []               # (layer names, class) of every issued group (inspection / tests)
@@ -201,9 +212,11 @@ class Plan(object):
                     low = min(low, min(o for o, _ in self._goffs))
                 # a pending grouped weight gradient has asked for its addresses but not been launched: the arena is final only
                 # above the highest pending layer
-                self.bwd_marks.append((len(self.bwd), max(low, self._wgroup_hi)))
-            if self._wgroup:
+                # (... and below the highest layer whose reduce waits in the batched table)
+                self.bwd_marks.append((len(self.bwd), max(low, self._wgroup_hi, self._pending_reduce_hi)))
+            if self._wgroup or self._pending_reduces:
                 self._flush_wgroup()
+                self._flush_reduces()
                 self.bwd_marks.append((len(self.bwd), low))
         self._tape = []
         return self
@@ -462,17 +475,46 @@ class Plan(object):
         self._keep.append(p)
         if meta is not None and meta.get("tile") == 512:
             meta = dict(meta, sc=(int(p.C0), 1 if p.Cout <= 16 else 2))    # the small-channel kernel's instance <Cin, 16-channel tiles> (bench.py)
+        if meta is not None and meta.get("tile") == 800:
+            meta = dict(meta, pw=(int(p.C0), int(p.Cout)))                  # the pointwise streaming kernel's instance <Cin, Cout, ...> (bench.py)
         lst.append((self.lib.stp_conv2d, (C.byref(p),), "stp_conv2d", meta))
 
-    def _emit_wgrad(self, lst, p, meta=None):
+    def _emit_wgrad(self, lst, p, meta=None, defer_hi=0):
         """Weight gradient = split partial sums + fixed-order reduce: two launch records so that each
-        kernel can be timed on its own (bench.py) - same arithmetic as stp_conv2d_wgrad."""
+        kernel can be timed on its own (bench.py) - same arithmetic as stp_conv2d_wgrad.
+        ``defer_hi`` > 0 (the end of the layer's range in the gradient arena; only when nothing reads dW before the optimizer): a layer
+        with plain slabs writes them into a workspace of its own and its reduce joins the pending table (_flush_reduces)."""
         self._keep.append(p)
         meta = dict(meta or {}, stream=1)
+        if defer_hi > 0 and self.reduce_batch > 0 and lst is self.bwd:
+            db = int(self.lib.stp_wgrad_reduce_desc_bytes())
+            wsb = int(self.lib.stp_conv2d_wgrad_workspace_bytes(C.byref(p)))
+            ws = self._alloc((max(wsb // 4, 4) + 4,), torch.float32)
+            desc = (C.c_char * db)()
+            count = int(self.lib.stp_wgrad_reduce_desc_fill(C.addressof(desc), 0, C.byref(p), ws.data_ptr()))
+            if count > 0:
+                lst.append((self.lib.stp_conv2d_wgrad_partial, (C.byref(p), ws.data_ptr(), ws.numel() * 4, 0), "stp_conv2d_wgrad", meta))
+                self._pending_reduces.append((bytes(desc), count))
+                self._pending_reduce_hi = max(self._pending_reduce_hi, int(defer_hi))
+                if len(self._pending_reduces) >= self.reduce_batch:
+                    self._flush_reduces()
+                return
+            self._keep = [t for t in self._keep if t is not ws]          # (row-of-taps slabs: the layer keeps its own reduce launch)
         lst.append((self.lib.stp_conv2d_wgrad_partial, (C.byref(p), self.ws_wgrad.data_ptr(), self.ws_wgrad.numel() * 4, 0),
                     "stp_conv2d_wgrad", meta))
         lst.append((self.lib.stp_conv2d_wgrad_reduce, (C.byref(p), self.ws_wgrad.data_ptr(), 0), "stp_conv2d_wgrad_reduce",
                     {"stream": 1}))
+
+    def _flush_reduces(self):
+        """One stp_wgrad_reduce_batched launch for the pending lone-layer reduces (see _emit_wgrad)."""
+        if not self._pending_reduces:
+            return
+        table = b"".join(d for d, _ in self._pending_reduces)
+        dev = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(self.device)
+        self._keep.append(dev)
+        n, maxc = len(self._pending_reduces), max(c for _, c in self._pending_reduces)
+        self.bwd.append((self.lib.stp_wgrad_reduce_batched, (dev.data_ptr(), n, maxc), "stp_wgrad_reduce_batched", {"stream": 1, "layers": n}))
+        self._pending_reduces, self._pending_reduce_hi = [], 0
 
     def _flush_wgroup(self):
         """Issues the pending grouped weight gradient: descriptor table (built now - every pointer is final), one partial launch
@@ -483,7 +525,10 @@ class Plan(object):
         reads = self._wgroup_reads
         self._wgroup, self._wgroup_cls, self._wgroup_flops, self._wgroup_hi, self._wgroup_reads = [], 0, 0.0, 0, set()
         n = len(layers)
-        if n == 1 and cls != 32:
+        # (... unless the lone layer is large enough to fill the all-taps kernel by itself: FPN's 512 -> 512 3x3 `fpn_final` at 4 x 256 x 256,
+        #  1.24 TFLOP - 1284 us on the per-layer row-of-taps kernel at 963 TFLOP/s; STP_WGRAD_LONE_GROUP_GFLOP: the threshold, 0 = never)
+        lone_group = cls == 128 and 0 < self.wgrad_lone_group_gflop * 1e9 <= layers[0][2]
+        if n == 1 and cls != 32 and not lone_group:
             # a lone layer gains nothing from the work list (measured on the bottleneck ResNets, whose 3x3 layers never neighbour:
             # FPN/ResNet50 1024x1024 18.25 -> 17.85 ms, PSPNet/ResNet101 768x768 10.13 -> 10.03 ms with the per-layer launch and its
             # tuned split count); the 32-channel class exists only as a grouped kernel (the per-layer one pads it to 64)
@@ -876,7 +921,8 @@ class Plan(object):
                     self._side_reads.add(dy.data_ptr())     # see _gradbuf: the only buffer of the chain that is ever rewritten
                     self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
                                                     "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp))),
-                                                    "kernel_id": int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp)))})
+                                                    "kernel_id": int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp)))},
+                                     defer_hi=0 if padded else w.offset + int(np.prod(w.shape)))       # (a padded dW is unpadded right below)
                 if padded:
                     self._emit_side(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
                                     Cinp, 0)

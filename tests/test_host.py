@@ -530,6 +530,31 @@ def test_class_heads_of_fpn_and_pspnet_take_the_tap_channel_form():
     assert "final_conv_taps" not in plan.tensors
 
 
+def test_pointwise_kernel_sizing_queries_do_not_depend_on_the_table_pointer():
+    """stp_conv2d_stats_floats is asked BEFORE the table of fused sums is allocated (graph.Plan.conv) and again when the BatchNormalization
+    that reads it is planned: both answers - and the kernel the launch gets - must agree, with and without stats_partial (round 6: the
+    pointwise kernel writes one column per workgroup; a BatchNormalization-backward launch sized as the per-tap kernel's 16 tile columns
+    and run as 32 workgroups wrote past its table at 2 x 32 x 32 pixels).  Host logic only: runs without a GPU."""
+    import ctypes as C
+    from segmentation_training_pipeline_amd import _lib
+    lib = _lib.load()
+    for (cin, cout) in ((64, 64), (64, 256), (256, 64), (256, 128), (128, 256), (128, 512), (512, 128), (256, 256), (512, 256)):
+        for (n, h, w) in ((2, 32, 32), (1, 16, 64), (8, 192, 192)):
+            for bnb in (0, 1):
+                p = _lib.ConvParams()
+                p.src0 = p.weight = p.dst0 = 16
+                p.N, p.Hs0, p.Ws0, p.Hv, p.Wv, p.C0, p.C1 = n, h, w, h, w, cin, 0
+                p.src0_mode, p.KH, p.KW, p.stride, p.pad, p.Ho, p.Wo, p.Cout, p.Cd0, p.dtype = 0, 1, 1, 1, 0, h, w, cout, cout, _lib.BF16
+                if bnb:
+                    p.bnb_x = p.bnb_mean = p.bnb_rstd = 16
+                    p.bnb_relu = 1
+                t0, f0 = lib.stp_conv2d_tile_for(C.byref(p)), lib.stp_conv2d_stats_floats(C.byref(p))
+                p.stats_partial = 16
+                t1, f1 = lib.stp_conv2d_tile_for(C.byref(p)), lib.stp_conv2d_stats_floats(C.byref(p))
+                assert (t0, f0) == (t1, f1), ((cin, cout), (n, h, w), bnb, (t0, f0), (t1, f1))
+                assert t1 == 800 and f1 == 2 * cout * lib.stp_conv2d_pw_cols(C.byref(p)) and 0 < lib.stp_conv2d_pw_cols(C.byref(p)) <= 512
+
+
 def test_bench_names_every_launch_of_the_headline_plan():
     """bench.py's instrumented pass maps every launch of the step to the kernel the library runs for it (kernel_key): a launch kind
     it does not know (a new tile id) must fail here, on CPU, not in the driver's bench run."""

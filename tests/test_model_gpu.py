@@ -710,11 +710,18 @@ def test_16bit_step_matches_the_storage_quantised_oracle(dtype, monkeypatch):
 
 # (architecture, backbone, size, classes, storage) -> bars: logits max / mean error in storage ulps of the logit range, how many times
 # closer to the storage-quantised oracle than to the fp32 one, |loss difference|, worst gradient cosine, class-convolution cosine.
-# Set from the measurement on MI355X printed by the test (profiles/r06a_16bit_parity_other_graphs.txt), ~1.5-2x above it.
+# Measured on MI355X (profiles/r06a_16bit_parity_other_graphs.txt), device vs oracle | oracle (fp32 accumulation) vs oracle (fp64
+# accumulation: the SAME rounding points evaluated a second, equally valid way = the noise floor of the 16-bit step):
+#   PSPNet/ResNet101 bf16 : mean 1.13 ulp, max 6.8, cosine min 0.910 / median 0.953   |  1.09, 7.5, 0.946 / 0.962
+#   FPN/ResNet50 fp16     : mean 7.73 ulp, max 65,  cosine min 0.853 / median 0.916   |  7.68, 50,  0.838 / 0.896
+#   Linknet/ResNet34 bf16 : mean 4.20 ulp, max 44,  cosine min 0.339 / median 0.611   |  3.94, 43,  0.511 / 0.654
+# i.e. the device sits AT the noise floor in all three; the absolute bars are ~1.6x the measurement, and the test also holds the device
+# to 1.5x the floor it measures itself.  (Linknet's gradients decorrelate that fast in ANY bf16 evaluation: three BatchNormalizations
+# per decoder stage, the first over 32 values per channel.)
 STORAGE_CASE_BARS = {
-    ("FPN", "resnet50", 128, 3, "fp16"): dict(max_ulp=1e9, mean_ulp=1e9, closer=0.0, loss=1e9, cos_min=-1.0, cos_head=-1.0),
-    ("PSPNet", "resnet101", 96, 20, "bf16"): dict(max_ulp=1e9, mean_ulp=1e9, closer=0.0, loss=1e9, cos_min=-1.0, cos_head=-1.0),
-    ("Linknet", "resnet34", 128, 1, "bf16"): dict(max_ulp=1e9, mean_ulp=1e9, closer=0.0, loss=1e9, cos_min=-1.0, cos_head=-1.0),
+    ("FPN", "resnet50", 128, 3, "fp16"): dict(max_ulp=110.0, mean_ulp=12.0, closer=1.5, loss=5e-3, cos_min=0.75, cos_head=0.999),
+    ("PSPNet", "resnet101", 96, 20, "bf16"): dict(max_ulp=12.0, mean_ulp=2.0, closer=1.8, loss=5e-3, cos_min=0.85, cos_head=0.999),
+    ("Linknet", "resnet34", 128, 1, "bf16"): dict(max_ulp=80.0, mean_ulp=7.0, closer=1.3, loss=5e-3, cos_min=0.2, cos_head=0.9995),
 }
 
 
@@ -737,6 +744,8 @@ def test_16bit_step_of_the_other_graphs_matches_the_storage_quantised_oracle(cas
     P = init(backbone, classes=classes, seed=int(g["seed"]))
     kw = dict(backbone=backbone, loss=spec, optimizer="adam", lr=1e-3, architecture=arch, activation=act)
     o = ostep.OracleTrainer(P, storage=dtype, grad_scale=gs, **kw).step(x.astype(np.float32), y.astype(np.float32), apply=False)
+    # the noise floor: the same rounding points with float64 accumulation inside the convolutions
+    o64 = ostep.OracleTrainer(P, storage=dtype, grad_scale=gs, accum64=True, **kw).step(x.astype(np.float32), y.astype(np.float32), apply=False)
     # the live oracle against its committed fixture: the same arithmetic on another host CPU (oneDNN picks its kernels by ISA), so fp32
     # summation order may decide a few rounding ties differently - bit-identical on the build container, held to the device's bars elsewhere
     drift = np.abs(o["logits"] - g["logits1"])
@@ -759,16 +768,26 @@ def test_16bit_step_of_the_other_graphs_matches_the_storage_quantised_oracle(cas
     errg = np.abs(got - g["logits1"])
     print("device vs the committed fixture: max %.2f ulp, mean %.3f ulp" % (errg.max() / ulp, errg.mean() / ulp))
     print("loss %.5f (oracle %.5f)  dice_loss %.5f (%.5f)" % (met["loss"], o["loss"], met["dice_loss"], o["dice_loss"]))
+    floor = np.abs(o64["logits"] - ref)
     got_g = m.get_gradients()
-    cos = {}
-    for k, r in o["grads"].items():
-        if r.size > 64:
-            a, b = got_g[k].ravel().astype(np.float64), r.ravel().astype(np.float64)
-            cos[k] = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+
+    def cosines(ga):
+        out = {}
+        for k, r in o["grads"].items():
+            if r.size > 64:
+                a, b = ga[k].ravel().astype(np.float64), r.ravel().astype(np.float64)
+                out[k] = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        return out
+    cos, cos_floor = cosines(got_g), cosines(o64["grads"])
     worst = min(cos, key=cos.get)
-    srt = sorted(cos.values())
+    srt, srt_f = sorted(cos.values()), sorted(cos_floor.values())
     print("gradient cosine: min %.5f (%s), 5th percentile %.5f, median %.5f, head %.6f" % (cos[worst], worst, srt[len(srt) // 20], srt[len(srt) // 2],
                                                                                           cos["final_conv/kernel"]))
+    print("NOISE FLOOR (oracle with fp64 accumulation vs the oracle): logits max %.2f ulp, mean %.3f ulp; gradient cosine min %.5f, 5th percentile "
+          "%.5f, median %.5f" % (floor.max() / ulp, floor.mean() / ulp, srt_f[0], srt_f[len(srt_f) // 20], srt_f[len(srt_f) // 2]))
+    # the device against the floor it is compared with: within 1.5x of the distance between two CPU evaluations of the same rounding points
+    assert err.mean() <= 1.5 * floor.mean() + 0.25 * ulp, (err.mean() / ulp, floor.mean() / ulp)
+    assert 1.0 - srt[len(srt) // 2] <= 1.5 * (1.0 - srt_f[len(srt_f) // 2]) + 0.01, (srt[len(srt) // 2], srt_f[len(srt_f) // 2])
     assert err.max() <= bars["max_ulp"] * ulp and err.mean() <= bars["mean_ulp"] * ulp, (err.max() / ulp, err.mean() / ulp)
     assert errg.max() <= bars["max_ulp"] * ulp and errg.mean() <= bars["mean_ulp"] * ulp, (errg.max() / ulp, errg.mean() / ulp)
     assert drift.mean() <= bars["mean_ulp"] * ulp, drift.mean() / ulp

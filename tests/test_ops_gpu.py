@@ -930,6 +930,71 @@ def test_conv2d_weight_gradient(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_batched_reduce_of_lone_weight_gradients(ops, dtype):
+    """stp_wgrad_reduce_batched (round 6): the split-K reduces of several lone layers - the 1x1 convolutions of a bottleneck unit
+    (classification_models residual_bottleneck_block, reference graph through segmentation.py:109-118), a 1x1 / stride-2 shortcut and a
+    3x3 / stride-2 layer - as ONE launch over a descriptor table, each layer's slabs in a workspace of its own.  Against float64 numpy,
+    against the per-layer stp_conv2d_wgrad_reduce, with accumulate, and bit-identical on replay; a row-of-taps layer (fragment-major
+    slabs) is refused by the descriptor query and keeps its own reduce."""
+    lib = ops._lib.load()
+    # n, h, w, ci, co, k, stride, pad
+    layers = [(2, 24, 24, 64, 256, 1, 1, 0), (2, 24, 24, 256, 64, 1, 1, 0), (2, 24, 24, 64, 128, 1, 2, 0), (2, 24, 24, 64, 64, 3, 2, 1),
+              (1, 12, 12, 512, 128, 1, 1, 0)]
+    rng = np.random.RandomState(11)
+    db = int(lib.stp_wgrad_reduce_desc_bytes())
+    table = (ops.C.c_char * (db * len(layers)))()
+    Ws, refs, dws, wss, counts = [], [], [], [], []
+    for i, (n, h, w, ci, co, k, st_, pd) in enumerate(layers):
+        x = q(rng.randn(n, h, w, ci), dtype)
+        ho, wo = (h + 2 * pd - k) // st_ + 1, (w + 2 * pd - k) // st_ + 1
+        dy = q(rng.randn(n, ho, wo, co), dtype)
+        refs.append(np_ops.conv2d_wgrad(x, dy, (k, k), st_, pd))
+        dw = keep(torch.full((co, k, k, ci), float("nan"), dtype=torch.float32, device=DEV))
+        xd, dyd = dev(x, dtype), dev(dy, dtype)
+        W = ops.wgrad_params(xd, dyd, dw, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=k, KW=k, stride=st_, pad=pd, Ho=ho, Wo=wo, Cout=co,
+                             dtype=ops.dt(xd))
+        ws = keep(torch.empty(ops.wgrad_workspace_bytes(W) // 4 + 4, dtype=torch.float32, device=DEV))
+        c = int(lib.stp_wgrad_reduce_desc_fill(ops.C.addressof(table), i, ops.C.byref(W), ops.ptr(ws)))
+        assert c == co * k * k * ci, (i, c)
+        Ws.append(W); dws.append(dw); wss.append(ws); counts.append(c)
+    tdev = keep(torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(DEV))
+
+    def run():
+        for W, ws in zip(Ws, wss):
+            ops.conv2d_wgrad_partial(W, ws, 0)
+        ops._lib.check(lib.stp_wgrad_reduce_batched(ops.ptr(tdev), len(layers), max(counts), ops.stream()), "stp_wgrad_reduce_batched")
+    run()
+    first = [d.clone() for d in dws]
+    for d, ref in zip(dws, refs):
+        np.testing.assert_allclose(host(d).transpose(1, 2, 3, 0), ref, atol=tol(ref, dtype))
+    for d in dws:
+        d.fill_(float("nan"))
+    run()                                                      # replay: fixed walk, fixed tree
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(dws, first))
+    for W, ws, d, f_ in zip(Ws, wss, dws, first):             # the per-layer reduce of the same slabs: same sums up to the order
+        d.fill_(float("nan"))
+        ops.conv2d_wgrad_reduce(W, ws, 0)
+        np.testing.assert_allclose(host(d), host(f_), rtol=1e-5, atol=1e-5 * float(f_.abs().max()))
+    # accumulate: the table records the flag at fill time
+    for i, (W, ws) in enumerate(zip(Ws, wss)):
+        W.accumulate = 1
+        assert int(lib.stp_wgrad_reduce_desc_fill(ops.C.addressof(table), i, ops.C.byref(W), ops.ptr(ws))) == counts[i]
+    tdev2 = keep(torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(DEV))
+    for W, ws in zip(Ws, wss):
+        ops.conv2d_wgrad_partial(W, ws, 0)
+    ops._lib.check(lib.stp_wgrad_reduce_batched(ops.ptr(tdev2), len(layers), max(counts), ops.stream()), "stp_wgrad_reduce_batched")
+    for d, ref in zip(dws, refs):
+        np.testing.assert_allclose(host(d).transpose(1, 2, 3, 0), 2 * ref, atol=tol(ref, dtype, 2))
+    if dtype != "fp32":      # a row-of-taps layer writes fragment-major slabs: not for the table
+        n, h, w, c = 1, 16, 64, 64
+        xd, dyd = dev(q(rng.randn(n, h, w, c), dtype), dtype), dev(q(rng.randn(n, h, w, c), dtype), dtype)
+        dw = keep(torch.zeros((c, 3, 3, c), dtype=torch.float32, device=DEV))
+        W = ops.wgrad_params(xd, dyd, dw, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=c, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=c, dtype=ops.dt(xd))
+        if lib.stp_conv2d_wgrad_kernel_id(ops.C.byref(W)) in (2, 3):
+            assert int(lib.stp_wgrad_reduce_desc_fill(ops.C.addressof(table), 0, ops.C.byref(W), ops.ptr(wss[0]))) == 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("chans", [(32, 16, 64), (64, 64, 32), (32, 16, 16), (128, 64, 64, 8, 8), (64, 64, 128, 4, 32), (128, 128, 136, 8, 16),
                                    (64, 192, 72, 16, 64)])
 def test_conv2d_weight_gradient_upsample_concat(ops, dtype, chans):
@@ -1518,6 +1583,116 @@ def test_wide_output_data_gradient_of_upsample_concat(ops, dtype, mode, c_up):
     P.dst0 = ops.ptr(again)
     ops.conv2d(P)
     assert torch.equal(again, got_up) and torch.equal(st2[:2 * c_up * tiles], st[:2 * c_up * tiles])
+
+
+PW_SHAPES = [(64, 64), (64, 256), (256, 64), (256, 128), (128, 256), (128, 512), (512, 128), (256, 256), (512, 256), (256, 512)]
+
+
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("mode", ["plain", "bias", "accumulate", "residual", "stats", "residual_stats", "bn_backward", "bn_backward_accumulate",
+                                  "bn_backward_relu6", "bn_backward_linear"])
+@pytest.mark.parametrize("shape", PW_SHAPES, ids=lambda s_: "%dto%d" % s_)
+def test_pointwise_streaming_kernel(ops, dtype, mode, shape):
+    """stp_conv2d_pw (conv_pw.hip, round 6): the 1x1 / stride-1 convolutions of the bottleneck ResNets (classification_models
+    residual_bottleneck_block conv1 / conv3 / shortcut, FPN laterals: reference graph through segmentation.py:109-118) and their data
+    gradients as a pixel-streaming kernel, against a float64 matrix product of the same 16-bit operands: every served (Cin, Cout) pair x
+    every epilogue (bias | accumulate | residual | statistics (+ residual) | BatchNormalization backward (+ accumulate; ReLU / ReLU6 /
+    linear)).  33792 pixels = more tiles than workgroups for every tile size (32 / 64 / 128 pixels), so the persistent loop, the double
+    buffer and the cross-tile sums are exercised; the table of fused sums has one column per workgroup; a replay is bit-identical."""
+    from segmentation_training_pipeline_amd import _lib
+    lib = _lib.load()
+    cin, cout = shape
+    n, h, w = 2, 96, 176
+    P_ = n * h * w
+    rng = np.random.RandomState(7 + cin + 3 * cout)
+    x = q(rng.randn(n, h, w, cin), dtype)
+    wt = q(rng.randn(1, 1, cin, cout) / np.sqrt(cin), dtype)
+    _, fwd, _, _ = prep_weights(ops, wt, dtype)
+    xd = dev(x, dtype)
+    f = lambda a_: keep(torch.from_numpy(np.ascontiguousarray(a_, dtype=np.float32)).to(DEV))
+    bnb = mode.startswith("bn_backward")
+    relu = {"bn_backward_relu6": 2, "bn_backward_linear": 0}.get(mode, 1)
+    acc = mode in ("accumulate", "bn_backward_accumulate")
+    res_np = q(rng.randn(n, h, w, cout), dtype) if mode in ("residual", "residual_stats") else None
+    res = dev(res_np, dtype) if res_np is not None else None
+    bias_np = (rng.randn(cout) * 0.5).astype(np.float32) if mode == "bias" else None
+    bias = f(bias_np) if bias_np is not None else None
+    prev_np = q(rng.randn(n, h, w, cout), dtype) if acc else None
+    bx_np = q(rng.randn(n, h, w, cout) * 1.5 + 0.2, dtype) if bnb else None
+    bx = dev(bx_np, dtype) if bnb else None
+    gam, bet, mean, rstd = rng.rand(cout) + 0.5, rng.randn(cout) * 0.3, rng.randn(cout) * 0.1 + 0.2, rng.rand(cout) + 0.5
+    g_, b_, m_, r_ = f(gam), f(bet), f(mean), f(rstd)
+
+    def run(tile):
+        y = dev(prev_np, dtype).clone() if acc else torch.full((n, h, w, cout), float("nan"), dtype=TD[dtype], device=DEV)
+        keep(y)
+        P = ops.conv_params(xd, fwd, y, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=cin, KH=1, KW=1, stride=1, pad=0, Ho=h, Wo=w, Cout=cout, dtype=ops.dt(y),
+                            residual=res, bias=bias, accumulate0=int(acc), tile=tile)
+        st = None
+        if bnb or mode in ("stats", "residual_stats"):
+            if bnb:
+                P.bnb_x, P.bnb_mean, P.bnb_rstd, P.bnb_gamma, P.bnb_beta, P.bnb_relu = ops.ptr(bx), ops.ptr(m_), ops.ptr(r_), ops.ptr(g_), ops.ptr(b_), relu
+            P.stats_partial = 1          # (non-NULL: the sizing query keys on it)
+            nfl = ops.conv2d_stats_floats(P)
+            st = keep(torch.full((max(4, nfl),), float("nan"), dtype=torch.float32, device=DEV))
+            P.stats_partial = ops.ptr(st)
+        return y, st, P
+
+    y, st, P = run(0)
+    served = bool(lib.stp_conv2d_pw_eligible(ops.C.byref(P)))
+    level = 0 if (cin, cout) == (256, 512) else 1 if (cin, cout) in ((128, 512), (512, 128)) else 2
+    assert served == (not bnb or level >= (2 if acc else 1)), "eligibility of %s / %s" % (shape, mode)
+    assert (lib.stp_conv2d_tile_for(ops.C.byref(P)) == 800) == served
+    if not served:
+        P.tile = 800
+        assert lib.stp_conv2d(ops.C.byref(P), ops.stream()) == -1          # STP_E_BADARG: never a silent fallback under a forced tile id
+        return
+    ops.conv2d(P)
+    got = host(y).astype(np.float64)
+    ref = (x.reshape(P_, cin).astype(np.float64) @ wt.reshape(cin, cout).astype(np.float64)).reshape(n, h, w, cout)
+    if bias_np is not None:
+        ref = ref + bias_np
+    if res_np is not None:
+        ref = ref + res_np
+    if acc:
+        ref = ref + prev_np
+    cols = ops.conv2d_stats_floats(P) // (2 * cout) if st is not None else 0
+    if bnb:
+        sc = (rstd * gam).astype(np.float32)
+        sh = (bet.astype(np.float32) - mean.astype(np.float32) * sc).astype(np.float32)
+        tt = (bx_np.astype(np.float64) * sc.astype(np.float64) + sh.astype(np.float64)).astype(np.float32)        # the forward's fma, one rounding
+        on = np.ones_like(tt, bool) if relu == 0 else (tt > 0) if relu == 1 else ((tt > 0) & (tt < 6))
+        ref = np.where(on, ref, 0.0)
+        bad = np.abs(got - ref) > tol(ref, dtype)
+        assert bad.mean() < 1e-5, bad.mean()                        # (a mask decision within rounding of the activation's kink may differ)
+        assert np.array_equal(got == 0, ~on | (got == 0))           # masked positions are exact zeros
+        sums = host(st)[:2 * cout * cols].reshape(2, cout, cols).astype(np.float64).sum(-1)
+        xhat = (bx_np.astype(np.float64) - mean.astype(np.float32).astype(np.float64)) * rstd.astype(np.float32).astype(np.float64)
+        want0, want1 = got.reshape(P_, cout).sum(0), (got * xhat).reshape(P_, cout).sum(0)      # the sums take the values as STORED
+        np.testing.assert_allclose(sums[0], want0, rtol=1e-4, atol=2e-4 * np.abs(got).sum(axis=(0, 1, 2)).max())
+        np.testing.assert_allclose(sums[1], want1, rtol=1e-3, atol=1e-3 * np.abs(got * xhat).sum(axis=(0, 1, 2)).max())
+    else:
+        np.testing.assert_allclose(got, ref, atol=tol(ref, dtype))
+        if st is not None:
+            sums = host(st)[:2 * cout * cols].reshape(2, cout, cols).astype(np.float64).sum(-1)
+            np.testing.assert_allclose(sums[0], got.reshape(P_, cout).sum(0), rtol=1e-4, atol=2e-4 * np.abs(got).sum(axis=(0, 1, 2)).max())
+            np.testing.assert_allclose(sums[1], (got ** 2).reshape(P_, cout).sum(0), rtol=1e-4)
+    if st is not None:
+        assert P.stats_tiles == cols == lib.stp_conv2d_pw_cols(ops.C.byref(P)) and 0 < cols <= 512
+    # replay: static tile assignment, fixed order of every sum
+    y2, st2, P2 = run(0)
+    ops.conv2d(P2)
+    assert torch.equal(y2, y) and (st is None or torch.equal(st2[:2 * cout * cols], st[:2 * cout * cols]))
+    # against the per-tap kernel on the same operands (what served these launches before): same values up to the summation order
+    if not bnb:
+        y3, st3, P3 = run(0)
+        P3.tile = 65 if cin % 64 == 0 else 1
+        if lib.stp_conv2d_tile_for(ops.C.byref(P3)) == P3.tile:
+            if st3 is not None:
+                st3 = keep(torch.full((max(4, ops.conv2d_stats_floats(P3)),), float("nan"), dtype=torch.float32, device=DEV))
+                P3.stats_partial = ops.ptr(st3)
+            ops.conv2d(P3)
+            np.testing.assert_allclose(host(y3), host(y), atol=tol(ref, dtype))
 
 
 @pytest.mark.parametrize("dtype", H16)
