@@ -652,6 +652,17 @@ int stp_background_replace_u8(const uint8_t* img, const uint8_t* mask, const uin
 int stp_cast_f32_to_bf16(const float* src, void* dst, int64_t count, void* stream);
 int stp_cast_bf16_to_f32(const void* src, float* dst, int64_t count, float scale, void* stream);
 
+/* segmentation_models' PSPNet head (schemas/segmentation.raml:226-249: Conv2D(512, 1x1) over Concatenate([feature, the four resized
+ * pyramid levels])) WITHOUT the concatenation: a 1x1 convolution commutes with the bilinear resize, so the head is Conv2D(1x1) of the
+ * feature with its columns of the kernel + stp_upsample_sum of the 1x1 convolutions of the TINY level maps with theirs (the sum enters
+ * the feature convolution as its residual operand).  stp_upsample_sum: y[N][Ho][Wo][C] = sum over the non-NULL sources i of the TF-1.x
+ * bilinear resize (align_corners False) of x_i [N][h_i][h_i][C] by Ho / h_i (Ho == Wo, Ho % h_i == 0), one rounding; its gradient is
+ * stp_resize_bilinear_bwd per source.  stp_copy_cols_f32: dst[r][0..cols) (+)= src[r][0..cols), fp32 row-major with row pitches ld_* -
+ * the column range of the shared kernel as a dense matrix for stp_weight_prepare, and the weight gradient back into the range. */
+int stp_upsample_sum(const void* x0, const void* x1, const void* x2, const void* x3, int32_t h0, int32_t h1, int32_t h2, int32_t h3,
+                     void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, void* stream);
+int stp_copy_cols_f32(float* dst, int32_t ld_dst, const float* src, int32_t ld_src, int32_t rows, int32_t cols, int32_t accumulate, void* stream);
+
 /* Batched reduce of lone weight gradients (round 6; the weight gradient of Keras' backward feeds only the optimizer, so its split-K
  * reduction can wait): a layer whose stp_conv2d_wgrad_partial launch (variant 0) wrote plain [splits][Cout * KH * KW * C] slabs into a
  * workspace OF ITS OWN adds a descriptor to a host table (stp_wgrad_reduce_desc_fill: returns the layer's element count, 0 = this layer

@@ -137,6 +137,8 @@ SIGNATURES = {
     "stp_upsample2x_bwd_bn": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
     "stp_upsample2x_add": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "stp_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_upsample_sum": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "stp_copy_cols_f32": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "stp_resize_bilinear_bwd_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "stp_resize_bilinear_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "stp_resize_nearest": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -2603,6 +2603,93 @@ extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H,
   return STP_OK;
 }
 
+// ---- PSPNet head (round 6): Conv2D(1x1) over Concatenate([feature, resized pyramid levels]) = Conv2D(1x1) over the feature with ITS columns
+// of the kernel + the sum over the levels of resize(Conv2D(1x1) of the TINY level map with the level's columns) - a 1x1 convolution is a
+// per-pixel linear map, so it commutes with the (per-channel, linear) bilinear resize.  The 2560-channel concatenation (377 MB at 8 x 96 x
+// 96), its gradient and 80 % of the convolution's FLOP disappear.  This kernel is the sum of the resized level terms: up to four sources
+// [N][h_i][w_i][C], h_i * f_i = Ho, one fp32 sum, ONE rounding; same lerp order as resize_bilinear_vec_kernel (TF 1.x, align_corners False).
+struct UpSum4 { const void* x[4]; int h[4], w[4], f[4]; int n; };
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample_sum_kernel(const UpSum4 a, T* __restrict__ y, int Ho, int Wo, int C) {
+  const int cg = C / V;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cg) return;
+  const int xo = t / cg, c = (t - xo * cg) * V;
+  const int n = blockIdx.y / Ho, yo = blockIdx.y - n * Ho;
+  float o[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i >= a.n) break;
+    const int f = a.f[i], H = a.h[i], W = a.w[i];
+    const float inv = 1.f / (float)f;
+    const int x0 = xo / f, y0 = yo / f;
+    const float fx = (float)(xo - x0 * f) * inv, fy = (float)(yo - y0 * f) * inv;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const T* b = reinterpret_cast<const T*>(a.x[i]) + (int64_t)n * H * W * C + c;
+    float v00[V], v01[V], v10[V], v11[V];
+    ldv<T, V>(b + ((int64_t)y0 * W + x0) * C, v00);
+    ldv<T, V>(b + ((int64_t)y0 * W + x1) * C, v01);
+    ldv<T, V>(b + ((int64_t)y1 * W + x0) * C, v10);
+    ldv<T, V>(b + ((int64_t)y1 * W + x1) * C, v11);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float top = v00[e] + (v01[e] - v00[e]) * fx, bot = v10[e] + (v11[e] - v10[e]) * fx;
+      o[e] += top + (bot - top) * fy;
+    }
+  }
+  stv<T, V>(y + (((int64_t)n * Ho + yo) * Wo + xo) * C + c, o);
+}
+
+extern "C" int stp_upsample_sum(const void* x0, const void* x1, const void* x2, const void* x3, int32_t h0, int32_t h1, int32_t h2, int32_t h3,
+                                void* y, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, void* stream) {
+  if (!stp_dtype_ok(dtype) || !y || N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || Ho != Wo) return STP_E_BADARG;
+  const void* xs[4] = {x0, x1, x2, x3};
+  const int hs[4] = {h0, h1, h2, h3};
+  UpSum4 a;
+  a.n = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (!xs[i]) break;
+    if (hs[i] <= 0 || Ho % hs[i]) return STP_E_BADARG;
+    a.x[a.n] = xs[i]; a.h[a.n] = a.w[a.n] = hs[i]; a.f[a.n] = Ho / hs[i];
+    ++a.n;
+  }
+  for (int i = a.n; i < 4; ++i) { a.x[i] = nullptr; a.h[i] = a.w[i] = a.f[i] = 1; }
+  const int V = dtype == STP_H16 ? (C % 8 == 0 ? 8 : C % 4 == 0 ? 4 : 0) : (C % 4 == 0 ? 4 : 0);
+  if (!a.n || !V || (int64_t)N * Ho > 65535) return STP_E_BADARG;
+  const dim3 grid(ceil_div((int64_t)Wo * (C / V), 256), N * Ho);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == STP_H16 && V == 8) hipLaunchKernelGGL((upsample_sum_kernel<bf16_t, 8>), grid, dim3(256), 0, s, a, (bf16_t*)y, Ho, Wo, C);
+  else if (dtype == STP_H16) hipLaunchKernelGGL((upsample_sum_kernel<bf16_t, 4>), grid, dim3(256), 0, s, a, (bf16_t*)y, Ho, Wo, C);
+  else hipLaunchKernelGGL((upsample_sum_kernel<float, 4>), grid, dim3(256), 0, s, a, (float*)y, Ho, Wo, C);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// fp32 column slice of a row-major matrix: dst[r][0 .. cols) (+)= src[r][0 .. cols) with separate row pitches - the 1x1 convolutions
+// that multiply by a COLUMN RANGE of a shared kernel (stp_upsample_sum above) read their range as a dense matrix and hand their weight
+// gradient back into it.  cols, both pitches and both pointers multiples of 4 floats.
+__global__ __launch_bounds__(256) void copy_cols_f32_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int rows,
+                                                            int cols4, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols4) return;
+  const int r = (int)(i / cols4), c = (int)(i - (int64_t)r * cols4) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)r * lds + c);
+  float* d = dst + (int64_t)r * ldd + c;
+  if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
+  *reinterpret_cast<f32x4*>(d) = v;
+}
+extern "C" int stp_copy_cols_f32(float* dst, int32_t ld_dst, const float* src, int32_t ld_src, int32_t rows, int32_t cols, int32_t accumulate, void* stream) {
+  if (!dst || !src || rows <= 0 || cols <= 0 || (cols & 3) || (ld_dst & 3) || (ld_src & 3) || ld_dst < cols || ld_src < cols ||
+      (reinterpret_cast<uintptr_t>(dst) & 15) || (reinterpret_cast<uintptr_t>(src) & 15))
+    return STP_E_BADARG;
+  hipLaunchKernelGGL(copy_cols_f32_kernel, dim3(ceil_div((int64_t)rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src,
+                     rows, cols / 4, accumulate);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 extern "C" size_t stp_resize_bilinear_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t factor) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || factor < 2) return 0;
   const int64_t npix = (int64_t)N * H * W;

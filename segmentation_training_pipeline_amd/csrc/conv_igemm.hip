@@ -595,6 +595,10 @@ static int auto_tile(const ConvArgs& a, int ut_ok) {
     // = the tile id for 1x1 launches with K >= 512 (experiments: 97 / 129 = the 128 x 128 tile with a 3 / 4-stage ring)
     static const int deepk = getenv("STP_1X1_DEEPK_TILE") ? atoi(getenv("STP_1X1_DEEPK_TILE")) : 0;
     if (deepk > 0 && a.KH == 1 && a.KW == 1 && a.K >= 512 && big >= 384) return deepk;
+    // ... and for the small-M ones (the 1x1 layers of ResNet50's stages 3 - 4 at 4 x 64 x 64 / 4 x 32 x 32: 4 - 16 K pixels, K = 256 - 2048,
+    // 25 - 40 us at 3 - 7 x their floors): STP_1X1_SMALLM_TILE = the tile id when fewer than 384 128 x 128 tiles exist (experiments)
+    static const int smallm = getenv("STP_1X1_SMALLM_TILE") ? atoi(getenv("STP_1X1_SMALLM_TILE")) : 0;
+    if (smallm > 0 && a.KH == 1 && a.KW == 1 && a.K >= 256 && big < 384) return smallm;
     if (big >= 384) return 64 + 1;
     if (mid >= 384) return 64 + 6;
     return 128 + 5;

@@ -60,11 +60,12 @@ class DT(object):
 
 
 class ParamInfo(object):
-    __slots__ = ("name", "offset", "numel", "shape", "kind", "trainable")
+    __slots__ = ("name", "offset", "numel", "shape", "kind", "trainable", "pending_slices")
 
     def __init__(self, name, offset, shape, kind, trainable):
         self.name, self.offset, self.shape, self.kind, self.trainable = name, offset, tuple(shape), kind, trainable
         self.numel = int(np.prod(shape))
+        self.pending_slices = 0       # column ranges of a shared 1x1 kernel whose weight gradient has not been planned yet (Plan.conv param_cols)
 
 
 class Plan(object):
@@ -268,6 +269,8 @@ class Plan(object):
 
     # ------------------------------------------------------------------ parameters / state
     def param(self, name, shape, kind="weight"):
+        if self.dry and name in self.params and tuple(self.params[name].shape) == tuple(shape) and self.params[name].kind == kind:
+            return self.params[name]          # (a parameter several launches read: the column ranges of a shared 1x1 kernel, Plan.conv param_cols)
         if self.dry:
             off = _rup(self._poff, 4)
             trainable = not any(name.startswith(p) for p in self.frozen_prefixes)
@@ -744,12 +747,17 @@ class Plan(object):
         return out
 
     def conv(self, name, x, Cout, k, stride=1, pad=0, src1=None, upsample=False, bias=False, residual=None, bn_stats=False,
-             transpose=False, relu=False, same_tf=False, fold_shortcut=None, param_name=None, param_shape=None, cout_pad=None):
+             transpose=False, relu=False, same_tf=False, fold_shortcut=None, param_name=None, param_shape=None, cout_pad=None,
+             param_cols=None, flops_as=None):
         """Conv2D (explicit symmetric ZeroPadding + 'valid').  ``upsample`` folds UpSampling2D(2) of x,
         ``src1`` folds Concatenate([up(x), src1]) into the GEMM gather; ``residual`` folds Add().
 
         ``fold_shortcut``: the output tensor of the 1x1 / stride-2 projection shortcut that reads the same ``x`` as this 3x3 / stride-2
         convolution (ResNet basic block): its data gradient is folded into this layer's data-gradient launch (stp_conv_params.fold_*).
+
+        ``param_cols`` = (first column, total columns): this 1x1 convolution multiplies by the COLUMN RANGE [first, first + Cin) of the shared
+        kernel ``param_name/kernel`` of shape (Cout, 1, 1, total) - the PSPNet head without its concatenation (nets.pspnet_resnet): the range is
+        copied into a dense fp32 matrix in front of the weight preparation (stp_copy_cols_f32) and the weight gradient is copied back into it.
 
         ``transpose``: Keras ``Conv2DTranspose(Cout, k, strides=2, padding='same')`` (k even, 4 in segmentation_models'
         transpose decoder blocks).  TF pads the equivalent forward convolution by k/2-1 on each side, so the transposed
@@ -782,7 +790,13 @@ class Plan(object):
         Cin_master = real_c0 + C1
         Cinp = C0 + C1
         # (param_name / param_shape: conv3x3_taps - the 1x1 launch over the bytes of a 3x3 kernel registered under the layer's own name)
-        w = self.param((param_name or name) + "/kernel", param_shape or (Cout, k, k, Cin_master), "tkernel" if transpose else "kernel")
+        if param_cols is not None:
+            if k != 1 or stem or transpose or C1 or Cout % self.vec or Cin_master % 4 or param_cols[0] % 4 or param_cols[1] % 4 \
+                    or param_cols[0] + Cin_master > param_cols[1]:
+                raise StpShapeError("%s: a column range of a shared kernel serves a plain 1x1 convolution with aligned channel counts" % name)
+            param_shape = None
+        w = self.param((param_name or name) + "/kernel", (Cout, 1, 1, param_cols[1]) if param_cols is not None else (param_shape or (Cout, k, k, Cin_master)),
+                       "tkernel" if transpose else "kernel")
         if param_shape is not None and int(np.prod(param_shape)) != Cout * k * k * Cin_master:
             raise StpShapeError("%s: parameter view of %s does not match %d x %d x %d x %d" % (name, param_shape, Cout, k, k, Cin_master))
         b = self.param(name + "/bias", (Cout,), "bias") if bias else None
@@ -810,9 +824,16 @@ class Plan(object):
         need_dgrad = self.training and (x_ng or s_ng) and not stem
         wb = self._alloc((rows_b * k * k * CoutB,)) if need_dgrad else None
         out.meta["wb"] = wb
-        out.meta["w_master"] = (self._pptr(w), Cout, Cin_master, k)      # (the space-to-depth data gradient builds its weights from the masters)
+        wsrc = self._pptr(w)
+        if param_cols is not None:
+            w.pending_slices += 1      # (backward: the LAST range written makes the parameter's gradient final)
+            # the column range as a dense [Cout][Cin] fp32 matrix, refreshed every step in front of the batched weight preparation
+            wm = self._alloc((Cout * Cin_master,), torch.float32)
+            self._emit(self.prep, "stp_copy_cols_f32", wm.data_ptr(), Cin_master, wsrc + 4 * int(param_cols[0]), int(param_cols[1]), Cout, Cin_master, 0)
+            wsrc = wm.data_ptr()
+        out.meta["w_master"] = (wsrc, Cout, Cin_master, k)      # (the space-to-depth data gradient builds its weights from the masters)
         # collected here, issued as ONE batched launch per step (see _finish_prep)
-        self._prep_layers.append((self._pptr(w), wf.data_ptr(), wb.data_ptr() if wb is not None else None,
+        self._prep_layers.append((wsrc, wf.data_ptr(), wb.data_ptr() if wb is not None else None,
                                   Cout, k, k, Cin_master, KWp, Cinp, CoutB))
         p = ops.conv_params(x.buf, wf, out.buf, N=self.N, Hs0=x.H, Ws0=x.W, Hv=Hv, Wv=Wv, C0=C0, C1=C1,
                             src1=src1.buf if src1 is not None else None,
@@ -861,6 +882,10 @@ class Plan(object):
             out.meta["stats_table"] = self._group_stats(p, st, Cout)       # (table, columns) the BatchNormalization reads
         # algorithmic work of this layer: 2 * pixels * Cout * KH*KW*Cin with the REAL (unpadded) dims
         flops = 2.0 * self.N * Ho * Wo * Cout * k * k * Cin_master / (4.0 if transpose else 1.0)   # zero-inserted taps are not work
+        if flops_as is not None:
+            # (a launch of a RESTRUCTURED reference layer - the PSPNet head without its concatenation: the roofline bookkeeping keeps
+            #  counting the reference graph's convolution, SURVEY 8d's convention, not the cheaper form that is executed)
+            flops = float(flops_as)
         self._emit_conv(self.fwd, p, {"layer": name, "pass": "fwd", "flops": flops, "tile": int(self.lib.stp_conv2d_tile_for(C.byref(p))),
                                       "src2": bool(C1 or upsample)})
         if not self.training:
@@ -893,13 +918,17 @@ class Plan(object):
             # and at the end of the launch list
             if w.trainable:
                 padded = stem or CoutB != Cout
+                gcols = None
                 if padded:
                     dwp = self._alloc((CoutB * k * KWp * Cinp,), torch.float32)
                     wp.dw = dwp.data_ptr()
+                elif param_cols is not None:
+                    gcols = self._alloc((Cout * Cin_master,), torch.float32)       # dense gradient of the column range, copied back below
+                    wp.dw = gcols.data_ptr()
                 else:
                     wp.dw = self._gptr(w)
                 wp.src0, wp.src1, wp.dy = x.meta.get("src_override") or x.buf.data_ptr(), (src1.buf.data_ptr() if src1 is not None else None), dy.data_ptr()
-                cls = int(self.lib.stp_wgrad_group_class(C.byref(wp))) if (self.wgrad_group_gflop > 0 and not padded) else 0
+                cls = int(self.lib.stp_wgrad_group_class(C.byref(wp))) if (self.wgrad_group_gflop > 0 and not padded and gcols is None) else 0
                 if cls:
                     # row-of-taps layer: joins the pending group (one launch per stage instead of one per layer); dY stays untouched
                     # until the group is issued (_gradbuf / the BatchNormalization backward's out-of-place accumulate see to that)
@@ -922,7 +951,13 @@ class Plan(object):
                     self._emit_wgrad(self.bwd, wp, {"layer": name, "pass": "wgrad", "flops": flops, "cout": CoutB,
                                                     "sc": bool(self.lib.stp_wgrad_sc_eligible(C.byref(wp))),
                                                     "kernel_id": int(self.lib.stp_conv2d_wgrad_kernel_id(C.byref(wp)))},
-                                     defer_hi=0 if padded else w.offset + int(np.prod(w.shape)))       # (a padded dW is unpadded right below)
+                                     defer_hi=0 if (padded or gcols is not None) else w.offset + int(np.prod(w.shape)))       # (a padded dW is unpadded right below)
+                if gcols is not None:
+                    # (the arena range of the shared kernel is reported final - _gptr, bwd_marks - by the last of its ranges only)
+                    w.pending_slices -= 1
+                    gbase = self._gptr(w) if w.pending_slices == 0 else self.G.data_ptr() + 4 * w.offset
+                    self._emit_side(self.bwd, "stp_copy_cols_f32", gbase + 4 * int(param_cols[0]), int(param_cols[1]), gcols.data_ptr(), Cin_master,
+                                    Cout, Cin_master, 0)
                 if padded:
                     self._emit_side(self.bwd, "stp_weight_grad_unpad", dwp.data_ptr(), self._gptr(w), Cout, k, k, Cin_master, KWp,
                                     Cinp, 0)
@@ -1243,6 +1278,40 @@ class Plan(object):
                 m.grad_ready = True
             if x.needs_grad:
                 x.grad, x.grad_ready = dy, True
+
+        self._tape.append(back)
+        return out
+
+    def upsample_sum(self, name, parts):
+        """``sum_i ResizeImage(f_i, 'bilinear')(t_i)`` of up to four maps with equal channel counts (TF 1.x bilinear, integer factors; one fp32
+        sum, one rounding): the resized pyramid terms of the PSPNet head, computed behind their 1x1 convolutions (nets.pspnet_resnet).  The
+        gradient of each part is the bilinear-resize gradient of the sum's gradient."""
+        if not 1 <= len(parts) <= 4:
+            raise StpShapeError("%s: one to four parts" % name)
+        Ho, Wo, Cn = parts[0][0].H * parts[0][1], parts[0][0].W * parts[0][1], parts[0][0].C
+        if Ho != Wo or any((t.H * f, t.W * f, t.C) != (Ho, Wo, Cn) or t.H != t.W for t, f in parts):
+            raise StpShapeError("%s: the parts must be square maps of equal channel count that resize to one size" % name)
+        out = self._new(name, Ho, Wo, Cn, any(t.needs_grad for t, _ in parts))
+        self._use(*[t for t, _ in parts])
+        if self.dry:
+            return out
+        ptrs = [t.buf.data_ptr() for t, _ in parts] + [None] * (4 - len(parts))
+        hs = [t.H for t, _ in parts] + [0] * (4 - len(parts))
+        self._emit(self.fwd, "stp_upsample_sum", ptrs[0], ptrs[1], ptrs[2], ptrs[3], hs[0], hs[1], hs[2], hs[3], out.buf.data_ptr(), self.N, Ho, Wo, Cn,
+                   self.cdt)
+        if not self.training:
+            return out
+
+        def back():
+            if not out.needs_grad or not out.grad_ready:
+                return
+            for t, f in parts:
+                if not t.needs_grad:
+                    continue
+                wp, wb = self._scratch(self.lib.stp_resize_bilinear_bwd_workspace_bytes(self.N, t.H, t.W, t.C, f))
+                self._emit(self.bwd, "stp_resize_bilinear_bwd", out.grad.data_ptr(), self._gradbuf(t).data_ptr(), self.N, t.H, t.W, t.C, f, out.gradC, 0,
+                           self.cdt, int(t.grad_ready), wp, wb)
+                t.grad_ready = True
 
         self._tape.append(back)
         return out

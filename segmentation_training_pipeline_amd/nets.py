@@ -222,6 +222,7 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
         f = taps[stage]
     if f.H != f.W or f.H % 6:
         raise ValueError("PSPNet needs a square input whose 1/%d feature map is divisible by 6 (got %dx%d)" % (downsample_factor, f.H, f.W))
+    import os
     parts = [(f, 1)]
     for level in (1, 2, 3, 6):
         k = f.H // level
@@ -229,8 +230,24 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
         p = (plan.maxpool_k if psp_pooling_type == "max" else plan.avgpool)(pre + "pool", f, k)
         p = plan.bn(pre + "bn", plan.conv(pre + "conv", p, int(psp_conv_filters), 1, bn_stats=True), BN_EPS_DECODER, relu=True)
         parts.append((p, k))
-    cat = plan.concat_resize("psp_concat", parts)
-    y = plan.bn("psp_final_bn", plan.conv("psp_final", cat, 512, 1, bn_stats=True), BN_EPS_DECODER, relu=True)
+    F_ = int(psp_conv_filters)
+    if os.environ.get("STP_PSP_SPLIT", "1") != "0" and f.C % 8 == 0 and F_ % 8 == 0:
+        # Conv2D(512, 1x1)(Concatenate([f, resize(p1), resize(p2), resize(p3), resize(p6)])) WITHOUT the concatenation (round 6): a 1x1
+        # convolution is a per-pixel linear map and commutes with the bilinear resize, so
+        #     psp_final(cat) = W[:, :C] f  +  sum over the levels of resize(W[:, level's columns] p_level)
+        # - the level terms are 1x1 convolutions of 1x1 ... 6x6 maps, their resized sum (stp_upsample_sum) enters the feature convolution
+        # as its residual operand.  Same parameter (`psp_final/kernel`, Keras (1, 1, C + 4 F, 512)), same function; the 2560-channel tensor
+        # (377 MB at 8 x 96 x 96), its gradient and 80 % of the head's FLOP are gone.  STP_PSP_SPLIT=0: the concatenated form.
+        Ct = f.C + 4 * F_
+        zs = [(plan.conv("psp_final_level%d" % level, p, 512, 1, param_name="psp_final", param_cols=(f.C + i * F_, Ct), flops_as=0.0), k)
+              for i, (level, (p, k)) in enumerate(zip((1, 2, 3, 6), parts[1:]))]
+        r = plan.upsample_sum("psp_pyramid_sum", zs)
+        # (algorithmic FLOP = the reference layer's: Conv2D(512, 1x1) over the C + 4 F concatenated channels)
+        y = plan.conv("psp_final", f, 512, 1, residual=r, bn_stats=True, param_cols=(0, Ct), flops_as=2.0 * plan.N * f.H * f.W * 512 * Ct)
+    else:
+        cat = plan.concat_resize("psp_concat", parts)
+        y = plan.conv("psp_final", cat, 512, 1, bn_stats=True)
+    y = plan.bn("psp_final_bn", y, BN_EPS_DECODER, relu=True)
     if dropout:       # SpatialDropout2D between the final block and the class convolution (segmentation_models 0.2.1 psp builder)
         y = plan.dropout("psp_dropout", y, float(dropout), DECODER_DROPOUT_SALT, spatial=True)
     lo = _class_head(plan, y, classes)

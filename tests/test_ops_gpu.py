@@ -2190,6 +2190,58 @@ def test_upsample_gradient_with_fused_batchnorm_backward_sums(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 24, 64, (1, 2, 3, 6)), (1, 12, 40, (1, 2, 3, 6)), (3, 8, 16, (2, 4)), (2, 6, 8, (3,))])
+def test_sum_of_resized_pyramid_terms_and_column_ranges_of_a_shared_kernel(ops, dtype, case):
+    """The two pieces of the PSPNet head without its concatenation (segmentation_models PSPNet, schemas/segmentation.raml:226-249):
+    stp_upsample_sum = sum of the TF-1.x bilinear resizes of up to four square maps (against oracle.nets.resize_bilinear_tf1 in float64,
+    and against the per-level stp_resize_bilinear launches it replaces); stp_copy_cols_f32 = a column range of an fp32 matrix, copy and
+    accumulate.  And the identity the restructuring rests on: conv1x1(concat(resized maps)) == sum of resize(conv1x1 with the map's columns)."""
+    from oracle import nets as onets
+    lib = ops._lib.load()
+    n, ho, c, levels = case
+    rng = np.random.RandomState(ho + c)
+    maps = [q(rng.randn(n, l, l, c), dtype) for l in levels]
+    ref = sum(onets.resize_bilinear_tf1(torch.from_numpy(m.astype(np.float64)).permute(0, 3, 1, 2), ho // l).permute(0, 2, 3, 1).numpy() for m, l in zip(maps, levels))
+    md = [dev(m, dtype) for m in maps]
+    y = keep(torch.full((n, ho, ho, c), float("nan"), dtype=TD[dtype], device=DEV))
+    ptrs = [ops.ptr(t) for t in md] + [None] * (4 - len(md))
+    hs = list(levels) + [0] * (4 - len(levels))
+    ops._lib.check(lib.stp_upsample_sum(ptrs[0], ptrs[1], ptrs[2], ptrs[3], hs[0], hs[1], hs[2], hs[3], ops.ptr(y), n, ho, ho, c, ops.dt(y), ops.stream()),
+                   "stp_upsample_sum")
+    np.testing.assert_allclose(host(y), ref, atol=tol(ref, dtype))
+    # the per-level resize launches, summed on the host: equal up to the one rounding per level they carry
+    acc = np.zeros_like(ref)
+    for t, l in zip(md, levels):
+        z = keep(torch.empty((n, ho, ho, c), dtype=TD[dtype], device=DEV))
+        ops._lib.check(lib.stp_resize_bilinear(ops.ptr(t), ops.ptr(z), n, l, l, c, ho // l, c, 0, ops.dt(z), ops.stream()), "stp_resize_bilinear")
+        acc += host(z)
+    np.testing.assert_allclose(host(y), acc, atol=tol(ref, dtype, 1.0 + len(levels)))
+    # conv1x1(concat(resize(m_i))) == sum_i resize(conv1x1(m_i; the columns of part i)) in float64
+    co = 16
+    W = rng.randn(co, c * len(levels))
+    cat = np.concatenate([onets.resize_bilinear_tf1(torch.from_numpy(m.astype(np.float64)).permute(0, 3, 1, 2), ho // l).permute(0, 2, 3, 1).numpy()
+                          for m, l in zip(maps, levels)], axis=-1)
+    lhs = cat @ W.T
+    rhs = sum(onets.resize_bilinear_tf1(torch.from_numpy(m.astype(np.float64) @ W[:, i * c:(i + 1) * c].T).permute(0, 3, 1, 2), ho // l).permute(0, 2, 3, 1).numpy()
+              for i, (m, l) in enumerate(zip(maps, levels)))
+    np.testing.assert_allclose(lhs, rhs, atol=1e-9)
+    if dtype == "fp32":
+        rows, total, c0, cols = 24, 96, 32, 40
+        A = rng.randn(rows, total).astype(np.float32)
+        Ad = keep(torch.from_numpy(A).to(DEV))
+        D = keep(torch.full((rows, cols), float("nan"), dtype=torch.float32, device=DEV))
+        ops._lib.check(lib.stp_copy_cols_f32(ops.ptr(D), cols, ops.ptr(Ad) + 4 * c0, total, rows, cols, 0, ops.stream()), "stp_copy_cols_f32")
+        np.testing.assert_array_equal(host(D), A[:, c0:c0 + cols])
+        G = keep(torch.zeros((rows, total), dtype=torch.float32, device=DEV))
+        for _ in range(2):
+            ops._lib.check(lib.stp_copy_cols_f32(ops.ptr(G) + 4 * c0, total, ops.ptr(D), cols, rows, cols, 1, ops.stream()), "stp_copy_cols_f32")
+        want = np.zeros_like(A)
+        want[:, c0:c0 + cols] = 2 * A[:, c0:c0 + cols]
+        np.testing.assert_array_equal(host(G), want)
+        assert lib.stp_copy_cols_f32(ops.ptr(G) + 4, total, ops.ptr(D), cols, rows, cols, 0, ops.stream()) == -1      # misaligned: STP_E_BADARG
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("geom", [(1, 1, 24, 320), (2, 2, 12, 72), (3, 3, 8, 40), (6, 6, 4, 24), (5, 7, 8, 20), (3, 2, 6, 3), (12, 12, 8, 24), (16, 16, 4, 8),
                                   (5, 7, 2, 8), (9, 3, 3, 16)])
 def test_pyramid_pooling_geometry_resize_and_pool(ops, dtype, geom):
