@@ -2608,38 +2608,57 @@ extern "C" int stp_resize_bilinear(const void* x, void* y, int32_t N, int32_t H,
 // per-pixel linear map, so it commutes with the (per-channel, linear) bilinear resize.  The 2560-channel concatenation (377 MB at 8 x 96 x
 // 96), its gradient and 80 % of the convolution's FLOP disappear.  This kernel is the sum of the resized level terms: up to four sources
 // [N][h_i][w_i][C], h_i * f_i = Ho, one fp32 sum, ONE rounding; same lerp order as resize_bilinear_vec_kernel (TF 1.x, align_corners False).
-struct UpSum4 { const void* x[4]; int h[4], w[4], f[4]; int n; };
+struct UpSum4 { const void* x[4]; int h[4], w[4], f[4], col0[4]; FastDiv df[4], dcg; int n, cols; };
+// One workgroup per OUTPUT ROW (n, yo): the two source rows every level contributes to this row (sum of the widths <= 12 columns x 2 rows x C
+// channels, 16-bit: 24 KB for 512 channels) are staged in LDS once, then a thread walks (pixel, 16-byte channel group) items of the row.
+// (First form: one thread per output vector with sixteen 16-byte loads from the tiny maps in flight - 128 registers, three waves per SIMD,
+//  69-74 us for 75 MB = latency x occupancy, not bytes.)  Same lerp order as resize_bilinear_vec_kernel: along x first (top, bottom), then y.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample_sum_kernel(const UpSum4 a, T* __restrict__ y, int Ho, int Wo, int C) {
+  extern __shared__ __attribute__((aligned(16))) char ups_rows[];          // [2][cols][C] of T
+  T* rows = reinterpret_cast<T*>(ups_rows);
   const int cg = C / V;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= Wo * cg) return;
-  const int xo = t / cg, c = (t - xo * cg) * V;
-  const int n = blockIdx.y / Ho, yo = blockIdx.y - n * Ho;
-  float o[V];
-#pragma unroll
-  for (int e = 0; e < V; ++e) o[e] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i >= a.n) break;
-    const int f = a.f[i], H = a.h[i], W = a.w[i];
-    const float inv = 1.f / (float)f;
-    const int x0 = xo / f, y0 = yo / f;
-    const float fx = (float)(xo - x0 * f) * inv, fy = (float)(yo - y0 * f) * inv;
-    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-    const T* b = reinterpret_cast<const T*>(a.x[i]) + (int64_t)n * H * W * C + c;
-    float v00[V], v01[V], v10[V], v11[V];
-    ldv<T, V>(b + ((int64_t)y0 * W + x0) * C, v00);
-    ldv<T, V>(b + ((int64_t)y0 * W + x1) * C, v01);
-    ldv<T, V>(b + ((int64_t)y1 * W + x0) * C, v10);
-    ldv<T, V>(b + ((int64_t)y1 * W + x1) * C, v11);
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const float top = v00[e] + (v01[e] - v00[e]) * fx, bot = v10[e] + (v11[e] - v10[e]) * fx;
-      o[e] += top + (bot - top) * fy;
+  const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;                 // (workgroup-uniform)
+  float fy[4];
+  for (int i = 0; i < a.n; ++i) {
+    const int H = a.h[i], W = a.w[i], f = a.f[i];
+    const int y0 = (int)fdiv((uint32_t)yo, a.df[i]), y1 = min(y0 + 1, H - 1);
+    fy[i] = (float)(yo - y0 * f) * (1.f / (float)f);
+    const T* b = reinterpret_cast<const T*>(a.x[i]) + (int64_t)n * H * W * C;
+    for (int t = threadIdx.x; t < 2 * W * cg; t += 256) {
+      const int r = t / (W * cg), rem = t - r * (W * cg);                    // rem = w * cg + channel group: contiguous in the source row
+      float v[V];
+      ldv<T, V>(b + ((int64_t)(r ? y1 : y0) * W) * C + (int64_t)rem * V, v);
+      stv<T, V>(rows + ((size_t)(r * a.cols + a.col0[i]) * C) + (size_t)rem * V, v);
     }
   }
-  stv<T, V>(y + (((int64_t)n * Ho + yo) * Wo + xo) * C + c, o);
+  __syncthreads();
+  for (int t = threadIdx.x; t < Wo * cg; t += 256) {
+    const int xo = (int)fdiv((uint32_t)t, a.dcg), c = (t - xo * cg) * V;
+    float o[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= a.n) break;
+      const int f = a.f[i];
+      const int x0 = (int)fdiv((uint32_t)xo, a.df[i]), x1 = min(x0 + 1, a.w[i] - 1);
+      const float fx = (float)(xo - x0 * f) * (1.f / (float)f);
+      const T* r0 = rows + (size_t)a.col0[i] * C + c;
+      const T* r1 = r0 + (size_t)a.cols * C;
+      float v00[V], v01[V], v10[V], v11[V];
+      ldv<T, V>(r0 + (size_t)x0 * C, v00);
+      ldv<T, V>(r0 + (size_t)x1 * C, v01);
+      ldv<T, V>(r1 + (size_t)x0 * C, v10);
+      ldv<T, V>(r1 + (size_t)x1 * C, v11);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float top = v00[e] + (v01[e] - v00[e]) * fx, bot = v10[e] + (v11[e] - v10[e]) * fx;
+        o[e] += top + (bot - top) * fy[i];
+      }
+    }
+    stv<T, V>(y + (((int64_t)n * Ho + yo) * Wo + xo) * C + c, o);
+  }
 }
 
 extern "C" int stp_upsample_sum(const void* x0, const void* x1, const void* x2, const void* x3, int32_t h0, int32_t h1, int32_t h2, int32_t h3,
@@ -2648,21 +2667,24 @@ extern "C" int stp_upsample_sum(const void* x0, const void* x1, const void* x2, 
   const void* xs[4] = {x0, x1, x2, x3};
   const int hs[4] = {h0, h1, h2, h3};
   UpSum4 a;
-  a.n = 0;
+  a.n = 0; a.cols = 0;
   for (int i = 0; i < 4; ++i) {
     if (!xs[i]) break;
     if (hs[i] <= 0 || Ho % hs[i]) return STP_E_BADARG;
-    a.x[a.n] = xs[i]; a.h[a.n] = a.w[a.n] = hs[i]; a.f[a.n] = Ho / hs[i];
+    a.x[a.n] = xs[i]; a.h[a.n] = a.w[a.n] = hs[i]; a.f[a.n] = Ho / hs[i]; a.df[a.n] = make_fastdiv((uint32_t)(Ho / hs[i]));
+    a.col0[a.n] = a.cols; a.cols += hs[i];
     ++a.n;
   }
-  for (int i = a.n; i < 4; ++i) { a.x[i] = nullptr; a.h[i] = a.w[i] = a.f[i] = 1; }
+  for (int i = a.n; i < 4; ++i) { a.x[i] = nullptr; a.h[i] = a.w[i] = a.f[i] = 1; a.col0[i] = 0; a.df[i] = make_fastdiv(1u); }
   const int V = dtype == STP_H16 ? (C % 8 == 0 ? 8 : C % 4 == 0 ? 4 : 0) : (C % 4 == 0 ? 4 : 0);
-  if (!a.n || !V || (int64_t)N * Ho > 65535) return STP_E_BADARG;
-  const dim3 grid(ceil_div((int64_t)Wo * (C / V), 256), N * Ho);
+  const size_t lds = (size_t)2 * a.cols * C * (dtype == STP_H16 ? 2 : 4);
+  if (!a.n || !V || (int64_t)N * Ho >= (1ll << 31) || lds > 64 * 1024) return STP_E_BADARG;      // (PSPNet: 12 columns x 512 channels = 24 KB)
+  a.dcg = make_fastdiv((uint32_t)(C / V));
+  const dim3 grid((unsigned)(N * Ho));
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == STP_H16 && V == 8) hipLaunchKernelGGL((upsample_sum_kernel<bf16_t, 8>), grid, dim3(256), 0, s, a, (bf16_t*)y, Ho, Wo, C);
-  else if (dtype == STP_H16) hipLaunchKernelGGL((upsample_sum_kernel<bf16_t, 4>), grid, dim3(256), 0, s, a, (bf16_t*)y, Ho, Wo, C);
-  else hipLaunchKernelGGL((upsample_sum_kernel<float, 4>), grid, dim3(256), 0, s, a, (float*)y, Ho, Wo, C);
+  if (dtype == STP_H16 && V == 8) hipLaunchKernelGGL((upsample_sum_kernel<bf16_t, 8>), grid, dim3(256), lds, s, a, (bf16_t*)y, Ho, Wo, C);
+  else if (dtype == STP_H16) hipLaunchKernelGGL((upsample_sum_kernel<bf16_t, 4>), grid, dim3(256), lds, s, a, (bf16_t*)y, Ho, Wo, C);
+  else hipLaunchKernelGGL((upsample_sum_kernel<float, 4>), grid, dim3(256), lds, s, a, (float*)y, Ho, Wo, C);
   STP_LAUNCH_CHECK();
   return STP_OK;
 }

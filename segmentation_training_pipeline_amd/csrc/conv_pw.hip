@@ -288,6 +288,7 @@ constexpr int pw_bnb_level(int cin, int cout) { return (cin == 256 && cout == 51
 static const PwConfig PW_CONFIGS[] = {
     {64, 64, 4, 64},   {64, 256, 4, 64},  {256, 64, 4, 64},  {256, 128, 4, 64}, {128, 256, 8, 128},
     {128, 512, 8, 64}, {512, 128, 4, 32}, {256, 256, 8, 64}, {512, 256, 8, 32}, {256, 512, 8, 32},
+    {64, 512, 8, 64},      // (the data gradient of FPN's class head in its tap-channel form: 64 padded tap channels -> 512 at 4 x 256 x 256)
 };
 static const PwConfig* pw_config(int cin, int cout) {
   for (const PwConfig& c : PW_CONFIGS)
@@ -393,6 +394,7 @@ extern "C" int stp_conv2d_pw(const stp_conv_params* p, void* stream) {
   if (c->cin == CI && c->cout == CO) return pw_launch<CI, CO, NW_, TP_>(p, a, grid, s);
   PW_CASE(64, 64, 4, 64) PW_CASE(64, 256, 4, 64) PW_CASE(256, 64, 4, 64) PW_CASE(256, 128, 4, 64) PW_CASE(128, 256, 8, 128)
   PW_CASE(128, 512, 8, 64) PW_CASE(512, 128, 4, 32) PW_CASE(256, 256, 8, 64) PW_CASE(512, 256, 8, 32) PW_CASE(256, 512, 8, 32)
+  PW_CASE(64, 512, 8, 64)
 #undef PW_CASE
   return STP_E_BADARG;
 }

@@ -1639,7 +1639,10 @@ static int launch_wgrad_tile(WgradArgs& a, const WgradPlan& w, bool dma_ok, int 
   } else {
     const bool f32 = sizeof(T) == 4;
     int v = variant;
-    if (v == 0) v = dma_ok ? 2 : 1;
+    // (STP_WGRAD_DMA_STAGES=3: the 3-stage ring for the automatic choice - experiments on the lone 1x1 layers of the bottleneck ResNets,
+    //  whose 18-step workgroups wait for every 64-pixel step's LDS-DMA with only one other step in flight)
+    static const int dma_auto = (getenv("STP_WGRAD_DMA_STAGES") && atoi(getenv("STP_WGRAD_DMA_STAGES")) == 3) ? 3 : 2;
+    if (v == 0) v = dma_ok ? dma_auto : 1;
     if (v >= 2 && (!dma_ok || (f32 && w.tile >= 3))) v = 1;  // fp32 256-column tiles: swizzle key varies per pass
     if (v == 1) {
       switch (w.tile) {

@@ -964,11 +964,19 @@ class GenericTaskConfig(object):
         if world > 1:
             # replicas start the stage bit-identical: parameters, BatchNormalization statistics and optimizer state of rank 0
             impl.broadcast_state(src=0)
-            impl.set_data_parallel(distributed.make_reducer())
-            if os.environ.get("STP_DP_OVERLAP", "auto") not in ("0", "1", "buckets"):
-                # overlapped or serialised gradient all-reduce: measured on this node before the first epoch (state restored afterwards)
-                impl.calibrate_dp_schedule()
-            elif os.environ["STP_DP_OVERLAP"] == "0":
+            ov = os.environ.get("STP_DP_OVERLAP", "auto")
+            # ("buckets" = the per-bucket overlap, as bench.py passes it; "0" / "1" fix the serialised / two-phase schedule)
+            impl.set_data_parallel(distributed.make_reducer(), overlap={"0": False, "1": True, "auto": True}.get(ov, "buckets"))
+            if ov not in ("0", "1", "buckets"):
+                # overlapped or serialised gradient all-reduce: measured on this node ONCE per run, before the first epoch of the first
+                # stage (state restored afterwards); later stages and folds reuse the decision
+                choice = getattr(self, "_dp_schedule_choice", None)
+                if choice is None:
+                    rec = impl.calibrate_dp_schedule()
+                    self._dp_schedule_choice = choice = (rec or {}).get("chosen", "overlapped")
+                elif choice == "serialised":
+                    impl.dp_overlap, impl._segments, impl._graphs = False, None, None
+            elif ov == "0":
                 impl.dp_overlap, impl._segments, impl._graphs = False, None, None
         H, W = impl.H, impl.W                                  # = shape, or shape / crops
         feeder = DeviceFeeder(impl.device, (H, W), self._aug_spec(), seed=self.random_state * 7919 + fold * 101 + si,

@@ -538,7 +538,7 @@ def test_pointwise_kernel_sizing_queries_do_not_depend_on_the_table_pointer():
     import ctypes as C
     from segmentation_training_pipeline_amd import _lib
     lib = _lib.load()
-    for (cin, cout) in ((64, 64), (64, 256), (256, 64), (256, 128), (128, 256), (128, 512), (512, 128), (256, 256), (512, 256)):
+    for (cin, cout) in ((64, 64), (64, 256), (256, 64), (256, 128), (128, 256), (128, 512), (512, 128), (256, 256), (512, 256), (64, 512)):
         for (n, h, w) in ((2, 32, 32), (1, 16, 64), (8, 192, 192)):
             for bnb in (0, 1):
                 p = _lib.ConvParams()

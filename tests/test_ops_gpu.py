@@ -1585,7 +1585,7 @@ def test_wide_output_data_gradient_of_upsample_concat(ops, dtype, mode, c_up):
     assert torch.equal(again, got_up) and torch.equal(st2[:2 * c_up * tiles], st[:2 * c_up * tiles])
 
 
-PW_SHAPES = [(64, 64), (64, 256), (256, 64), (256, 128), (128, 256), (128, 512), (512, 128), (256, 256), (512, 256), (256, 512)]
+PW_SHAPES = [(64, 64), (64, 256), (256, 64), (256, 128), (128, 256), (128, 512), (512, 128), (256, 256), (512, 256), (256, 512), (64, 512)]
 
 
 @pytest.mark.parametrize("dtype", H16)
@@ -2066,6 +2066,51 @@ def test_class_head_as_tap_channels_plus_tap_sum(ops, dtype, case):
     lhs = float((want - bias) .reshape(-1, co).astype(np.float64).ravel() @ dy[..., :co].astype(np.float64).ravel())
     rhs = float(zh.astype(np.float64).ravel() @ dzh[..., :zc].astype(np.float64).ravel())
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("dtype", H16)
+def test_tap_channel_class_head_when_the_taps_cancel(ops, dtype):
+    """Advisor finding (round 5): the tap-channel form of the class convolution stores nine PARTIAL sums in 16 bits before they are added, the
+    direct 3x3 launch accumulates all taps in fp32 - the two differ most when the taps cancel.  Input: a constant map and a kernel whose
+    nine taps sum to zero per (class, channel) with taps ~60x larger than the interior result; the tap form must stay within the bound its
+    rounding points give - nine roundings of partials of size |z| (<= 9 x half a storage ulp of max |z|) plus the output rounding - and the
+    oracle's restatement of it (oracle.nets._class_head: the storage-quantised oracle models these roundings) must agree with the device
+    to one output rounding."""
+    from segmentation_training_pipeline_amd import _lib
+    from oracle import nets as onets
+    n, h, w, ci, co = 1, 12, 16, 128, 3
+    rng = np.random.RandomState(3)
+    x = q(1.0 + 0.01 * rng.randn(n, h, w, ci), dtype)                  # nearly constant: the interior response is the SUM of the taps
+    base = rng.randn(3, 3, ci, co)
+    wt = q((base - base.mean(axis=(0, 1), keepdims=True)) * 0.5, dtype)         # taps cancel per (channel, class)
+    bias = np.zeros(co, np.float32)
+    exact = np_ops.conv2d(x, wt, 1, 1)
+    w11 = np.ascontiguousarray(wt.transpose(3, 0, 1, 2).reshape(co * 9, ci).T.reshape(1, 1, ci, co * 9))
+    _, f11, _, _ = prep_weights(ops, w11, dtype)
+    _, f33, _, _ = prep_weights(ops, wt, dtype)
+    xd = dev(x, dtype)
+    zc = co * 9
+    z = keep(torch.full((n, h, w, zc), float("nan"), dtype=TD[dtype], device=DEV))
+    ops.conv2d(ops.conv_params(xd, f11, z, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=1, KW=1, stride=1, pad=0, Ho=h, Wo=w, Cout=zc, dtype=ops.dt(z)))
+    y = keep(torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV))
+    bd = keep(torch.from_numpy(bias).to(DEV))
+    _lib.call("stp_tapsum_fwd", ops.ptr(z), ops.ptr(y), ops.ptr(bd), n, h, w, co, zc, co, ops.dt(z), ops.stream())
+    yd = keep(torch.full((n, h, w, co), float("nan"), dtype=TD[dtype], device=DEV))
+    ops.conv2d(ops.conv_params(xd, f33, yd, N=n, Hs0=h, Ws0=w, Hv=h, Wv=w, C0=ci, KH=3, KW=3, stride=1, pad=1, Ho=h, Wo=w, Cout=co, dtype=ops.dt(yd)))
+    zmax = float(np.abs(host(z)).max())
+    half_ulp = 2.0 ** (np.floor(np.log2(zmax)) - (8 if dtype == "bf16" else 11))
+    inner = (slice(None), slice(1, -1), slice(1, -1))
+    assert np.abs(exact[inner]).max() < zmax / 20.0                     # the case is what it claims: partials >> result
+    err_taps, err_direct = np.abs(host(y) - exact), np.abs(host(yd) - exact)
+    print("taps cancel [%s]: max |partial| %.3g, interior |result| max %.3g; error tap form %.3g (bound %.3g), direct 3x3 %.3g"
+          % (dtype, zmax, np.abs(exact[inner]).max(), err_taps.max(), 9 * half_ulp + tol(exact, dtype), err_direct.max()))
+    assert err_taps.max() <= 9 * half_ulp + tol(exact, dtype)
+    np.testing.assert_allclose(host(yd), exact, atol=tol(exact, dtype))
+    # the oracle's tap-channel restatement (what the storage-quantised whole-step oracle uses for this layer)
+    P = {"final_conv/kernel": torch.from_numpy(wt.astype(np.float32)), "final_conv/bias": torch.from_numpy(bias)}
+    ctx = onets._Ctx(P, True, None, storage=TD[dtype])
+    got_o = onets._class_head(ctx, torch.from_numpy(x.astype(np.float32)).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(host(y), got_o, atol=tol(exact, dtype) + 2 * half_ulp)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
