@@ -390,6 +390,61 @@ def cpu_baseline(full_protocol=False, config=1):
                                                                               classes, n, len(times), warm)}
 
 
+class ClockSampler(object):
+    """Samples the GPU's shader clock and socket power from the amdgpu hwmon files while a region runs (a host thread, 50 ms period; no
+    subprocess, nothing on the device): the clocks a box HOLDS under the step's own load are what separates one box's step time from
+    another's (`box_calibration.mfma_tflops` is the same 2.48 PFLOP/s on every box met: the idle-fabric MFMA clock does not differ).
+    Everything is optional: unreadable files -> None."""
+
+    def __init__(self, index=0):
+        import glob
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        if cards:
+            hw = cards[min(index, len(cards) - 1)]
+            for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input"))):
+                for nm in names:
+                    if os.path.exists(os.path.join(hw, nm)):
+                        self.files[key] = os.path.join(hw, nm)
+                        break
+        self.samples = {k: [] for k in self.files}
+        self._stop = None
+        self._thread = None
+
+    def __enter__(self):
+        import threading
+        if self.files:
+            self._stop = threading.Event()
+
+            def run():
+                while not self._stop.is_set():
+                    for k, f in self.files.items():
+                        try:
+                            with open(f) as fh:
+                                self.samples[k].append(float(fh.read().strip()) * 1e-6)      # Hz -> MHz, microwatt -> W
+                        except (OSError, ValueError):
+                            pass
+                    self._stop.wait(0.05)
+            self._thread = threading.Thread(target=run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = round(float(np.mean(v)), 1)
+                out[k + "_min"] = round(float(np.min(v)), 1)
+                out[k + "_samples"] = len(v)
+        return out or None
+
+
 def box_calibration(dev, seconds=2.0):
     """What THIS box sustains on two fixed loads, measured before the timed region: boxes of the pool differ by +-2.5 %,
     more than a round's gain on the step, so a line is comparable with another line only next to these two numbers.
@@ -683,7 +738,9 @@ def main():
     sustained = None
     if world == 1 and args.sustain > 0:
         n_sus = max(200, int(args.sustain / max(elapsed / args.steps, 1e-4)))
-        sustained = (n_sus, timed(step, 0, n_sus))
+        with ClockSampler(dev_index) as clocks:
+            sustained = (n_sus, timed(step, 0, n_sus))
+        sustained_clocks = clocks.summary()
     metrics = model.metrics()
     images_per_sec = world * BATCH * args.steps / elapsed
 
@@ -710,7 +767,9 @@ def main():
     }
     if sustained is not None:
         out["sustained"] = {"steps": sustained[0], "seconds": round(sustained[1], 3), "ms_per_step": round(1e3 * sustained[1] / sustained[0], 3),
-                            "images_per_sec": round(BATCH * sustained[0] / sustained[1], 2)}
+                            "images_per_sec": round(BATCH * sustained[0] / sustained[1], 2),
+                            # shader clock / socket power the box held over this region (amdgpu hwmon, 50 ms samples; None: not readable)
+                            "clocks": sustained_clocks}
     if rank == 0 and not args.no_kernel_profile:
         prof = per_kernel_profile(model)
         tot = sum(v[1] for v in prof.values())
@@ -759,6 +818,9 @@ def main():
             out["step_traffic_stale"] = bool(_pmc_stale(os.path.join(ROOT, st_src)))
             out["step_hbm_floor_ms"] = round(st_bytes / (PEAK_HBM_GBS * 1e9) * 1e3, 3)       # that traffic at the 8 TB/s peak
             out["step_hbm_floor_ms_at_6300"] = round(st_bytes / 6.3e12 * 1e3, 3)             # ... at the rate a device copy reaches
+            # the whole step against the HBM roofline: L2-miss bytes of one step / the measured step time / 8 TB/s (next to step_mfma_frac:
+            # PSPNet/ResNet101 and FPN/ResNet50 are HBM-bound as whole steps, the U-Net is bound by neither)
+            out["step_hbm_frac"] = round(st_bytes / (elapsed / args.steps) / (PEAK_HBM_GBS * 1e9), 4)
         top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:16]
         out["kernel_time_us"] = {k: [round(v[0], 1), round(1e6 * v[1], 1), round(v[2] / v[1] / 1e12, 1) if v[2] else None] for k, v in top}
         out["kernel_time_total_us"] = round(1e6 * tot, 1)

@@ -530,6 +530,33 @@ def test_class_heads_of_fpn_and_pspnet_take_the_tap_channel_form():
     assert "final_conv_taps" not in plan.tensors
 
 
+def test_pspnet_head_without_its_concatenation_keeps_the_reference_parameters(monkeypatch):
+    """segmentation_models' PSPNet head (schemas/segmentation.raml:226-249) is planned WITHOUT its 2560-channel concatenation (round 6,
+    nets.pspnet_resnet): the parameters keep the reference's names and shapes (one `psp_final/kernel` over all C + 4 F input channels),
+    the roofline bookkeeping keeps the reference layer's FLOP, the gradient arena is still written in descending order (the data-parallel
+    overlap needs it), and STP_PSP_SPLIT=0 restores the concatenated plan.  Host logic only."""
+    from oracle import nets as onets
+
+    def plan_for(split):
+        monkeypatch.setenv("STP_PSP_SPLIT", split)
+        p = graph.Plan(2, "bf16", "cpu", training=True)
+        p.define(lambda q_: nets.pspnet_resnet(q_, "resnet50", 96, 96, classes=5))
+        return p
+    new, old = plan_for("1"), plan_for("0")
+    P = onets.init_pspnet_resnet("resnet50", classes=5, seed=1)
+    shapes = lambda pl: {k: tuple(v.shape) for k, v in pl.params.items()}
+    assert shapes(new) == shapes(old) and set(shapes(new)) == {k for k in P if not k.endswith(("moving_mean", "moving_variance"))}
+    assert shapes(new)["psp_final/kernel"] == (512, 1, 1, 512 + 4 * 512)              # OHWI of Keras' (1, 1, 2560, 512)
+    f = lambda pl, n: [x for x in pl.prep + pl.fwd + pl.bwd if x[2] == n]
+    assert len(f(new, "stp_upsample_sum")) == 1 and not f(old, "stp_upsample_sum")
+    assert len(f(new, "stp_resize_bilinear")) == 1 and len(f(old, "stp_resize_bilinear")) == 6        # only the logits are resized now
+    assert len(f(new, "stp_copy_cols_f32")) == 10 and new.prep[-1][2] == "stp_weight_prepare_batched"  # five ranges in, five gradients out
+    flops = lambda pl: sum(m["flops"] for _, _, _, m in pl.fwd if m and "flops" in m)
+    assert abs(flops(new) - flops(old)) < 1e-6 * flops(old)
+    assert new.bwd_monotone and old.bwd_monotone
+    assert "psp_concat" not in new.tensors and "psp_pyramid_sum" in new.tensors and new.tensors["psp_pyramid_sum"].C == 512
+
+
 def test_pointwise_kernel_sizing_queries_do_not_depend_on_the_table_pointer():
     """stp_conv2d_stats_floats is asked BEFORE the table of fused sums is allocated (graph.Plan.conv) and again when the BatchNormalization
     that reads it is planned: both answers - and the kernel the launch gets - must agree, with and without stats_partial (round 6: the
