@@ -400,8 +400,18 @@ class ClockSampler(object):
         import glob
         self.files = {}
         cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
-        if cards:
-            hw = cards[min(index, len(cards) - 1)]
+        # the card of THIS HIP device: a box may show the sysfs nodes of every GPU of its host while one is visible to the process -
+        # match the PCI address (domain:bus:device.function) of the device properties against the card's device link
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x." % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+        except Exception:
+            want = None
+        match = [c for c in cards if want and os.path.basename(os.path.realpath(os.path.join(c, "..", ".."))).startswith(want)]
+        self.card = match[0] if match else None
+        if match or len(cards) == 1:
+            hw = match[0] if match else cards[0]
             for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input"))):
                 for nm in names:
                     if os.path.exists(os.path.join(hw, nm)):

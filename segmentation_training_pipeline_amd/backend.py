@@ -199,8 +199,11 @@ class HipSegModel(object):
         saved = [t.clone() for t in self._mutable_state()]
         want = self.dp_overlap
         times = {}
+        two_phase = distributed.two_phase_bounds(self.plan.bwd_marks, self.plan.G.numel())
         for mode in (True, False):
             self.dp_overlap, self._segments, self._graphs, self._works = mode, None, None, []
+            # (each schedule with ITS bucket bounds: two ranges for the overlap, the uniform buckets for the serialised pass - advisor, round 5)
+            self.reducer.set_bounds(two_phase) if mode else self.reducer.reset_bounds()
             for _ in range(warm):
                 self.forward_backward(); self.apply_gradients()
             torch.cuda.synchronize(self.device)
@@ -215,6 +218,7 @@ class HipSegModel(object):
         t_ov, t_ser = float(t[0].item()), float(t[1].item())
         choice = bool(t_ov <= t_ser)
         self.dp_overlap, self._segments, self._graphs, self._works = choice, None, None, []
+        self.reducer.set_bounds(two_phase) if choice else self.reducer.reset_bounds()
         for d, sv in zip(self._mutable_state(), saved):
             d.copy_(sv)
         torch.cuda.synchronize(self.device)

@@ -145,6 +145,10 @@ class GradReducer(object):
         """Replaces the uniform buckets (e.g. with two_phase_bounds for the overlapped schedule)."""
         self._bounds = list(bounds)
 
+    def reset_bounds(self):
+        """Back to the uniform buckets (the serialised schedule: one pass of `bucket_mb` collectives after the backward)."""
+        self._bounds = None
+
     def allreduce_range(self, flat, s, e):
         """Asynchronous SUM-all-reduce of flat[s:e] ordered after the work already on the current stream; returns
         the work handle (``wait()`` orders the current stream after the collective) or None when inactive.  With the bf16 wire

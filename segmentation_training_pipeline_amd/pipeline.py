@@ -976,8 +976,10 @@ class GenericTaskConfig(object):
                     self._dp_schedule_choice = choice = (rec or {}).get("chosen", "overlapped")
                 elif choice == "serialised":
                     impl.dp_overlap, impl._segments, impl._graphs = False, None, None
+                    impl.reducer.reset_bounds()
             elif ov == "0":
                 impl.dp_overlap, impl._segments, impl._graphs = False, None, None
+                impl.reducer.reset_bounds()
         H, W = impl.H, impl.W                                  # = shape, or shape / crops
         feeder = DeviceFeeder(impl.device, (H, W), self._aug_spec(), seed=self.random_state * 7919 + fold * 101 + si,
                               classes=self.classes, channels=impl.in_ch)
