@@ -513,6 +513,21 @@ int stp_sigmoid(const void* logits, float* probs, int64_t count, int32_t dtype, 
 int stp_softmax_cce_dice(const void* logits, const uint8_t* target, int64_t pixels, int32_t classes, int32_t ldc,
                          int32_t dtype, float w_cce, float w_dice, float* scalars, void* dlogits, int32_t dl_channels,
                          float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The same loss on class logits the network produces at 1 / factor of the mask's resolution and resizes bilinearly (segmentation_models
+ * 0.2.1: PSPNet `final_interpolation: bilinear` x downsample_factor, schemas/segmentation.raml:225-249; FPN's last UpSampling2D(4,
+ * 'bilinear')) - replaces, in the training step, stp_resize_bilinear of the logits + stp_softmax_cce_dice + stp_scale_by_device +
+ * stp_resize_bilinear_bwd of their gradient WITHOUT the resized tensors: low [N][H][W][ldc], target [N][H factor][W factor] (4-byte
+ * aligned), dlow [N][H][W][dl_channels] = d loss / d low (classes gradients + zero padding; NULL: scalars only), rounded to the storage
+ * type where the unfused chain rounds (the resized logit, the per-pixel gradient).  dev_scale (may be NULL): device multiplier applied to
+ * dlow (the dynamic loss scale, stp_scale_by_device), recorded into dev_record[0].  factor 2 / 4 / 8 / 16; workspace >=
+ * stp_loss_workspace_bytes(); corners >= stp_softmax_cce_dice_up_corner_bytes() (16-byte aligned; only with dlow).  _ok: 1 if the
+ * fused form serves (factor, classes) (STP_UP_LOSS=0: never). */
+int stp_softmax_cce_dice_up_ok(int32_t factor, int32_t classes, int32_t dtype);
+size_t stp_softmax_cce_dice_up_corner_bytes(int32_t N, int32_t H, int32_t W, int32_t classes);
+int stp_softmax_cce_dice_up(const void* low, const uint8_t* target, int32_t N, int32_t H, int32_t W, int32_t factor, int32_t classes,
+                            int32_t ldc, int32_t dtype, float w_cce, float w_dice, float* scalars, void* dlow, int32_t dl_channels,
+                            float grad_scale, const float* dev_scale, float* dev_record, void* workspace, size_t workspace_bytes,
+                            void* corners, size_t corner_bytes, void* stream);
 /* probs [pixels][classes] fp32 = softmax of the first `classes` channels */
 int stp_softmax(const void* logits, float* probs, int64_t pixels, int32_t classes, int32_t ldc, int32_t dtype, void* stream);
 

@@ -153,6 +153,9 @@ SIGNATURES = {
     "stp_lovasz_hinge": (i32, [vp, vp, i32, i64, i32, f32, vp, vp, i32, vp, sz, vp]),
     "stp_sigmoid": (i32, [vp, vp, i64, i32, vp]),
     "stp_softmax_cce_dice": (i32, [vp, vp, i64, i32, i32, i32, f32, f32, vp, vp, i32, f32, vp, sz, vp]),
+    "stp_softmax_cce_dice_up_ok": (i32, [i32, i32, i32]),
+    "stp_softmax_cce_dice_up_corner_bytes": (sz, [i32, i32, i32, i32]),
+    "stp_softmax_cce_dice_up": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, i32, f32, vp, vp, vp, sz, vp, sz, vp]),
     "stp_softmax": (i32, [vp, vp, i64, i32, i32, i32, vp]),
     "stp_adam": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, vp, f32, vp]),
     "stp_sgd": (i32, [vp, vp, vp, i64, vp, f32, i32, vp, vp, f32, vp]),

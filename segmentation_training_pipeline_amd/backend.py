@@ -515,7 +515,7 @@ class HipSegModel(object):
 
     def logits(self):
         ts = self.plan.tensors                     # FPN / PSPNet / DeepLab: the head output is a resized tensor named "logits"
-        t = ts["logits"] if "logits" in ts else ts["final_conv"]
+        t = self.plan.tensor("logits" if "logits" in ts else "final_conv")      # (a resize fused into the loss is materialised here)
         return t.buf.to(torch.float32).cpu().numpy()
 
     def activation(self, name):

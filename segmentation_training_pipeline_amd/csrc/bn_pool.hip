@@ -2274,6 +2274,97 @@ __global__ __launch_bounds__(256) void resize_bilinear_vec_kernel(const T* __res
   stv<T, V>(y + (((int64_t)n * Ho + yo) * Wo + xo) * ldo + coff + c, o);
 }
 
+// gradient, ROW-PAIR TILE form for wide channel slices (round 6: FPN's pyramid levels resized x2 / x4 / x8 into the 512-channel
+// concatenation - 67 MB of dY per level; the gather kernel below re-reads every output pixel four times from L2 with a division per tap:
+// 84 us per level).  One workgroup = (image, two input rows, WS input columns, CC channels):
+//   phase 1 (vertical): the <= 3 f - 1 output rows that touch the two input rows are streamed ONCE; a thread owns <= K (column, 16-byte
+//            channel group) items of the tile's <= (WS + 1) f - 1 output columns and keeps two fp32 sums per element (one per input row,
+//            row weights are workgroup-uniform) - K independent 16-byte loads per row, no barrier in the loop;
+//   phase 2 (horizontal): the sums go to LDS once, then every (input row, input column, 4 channels) item adds its <= 2 f - 1 columns
+//            with the column weights, in a fixed order - deterministic.
+// Every dY byte is read (3 f - 1) / (2 f) x ((WS + 1) f - 1) / (WS f) ~ 1.6 times (from L2 where neighbouring workgroups overlap).
+#define RBT_K 3
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_tile_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int C, int f,
+                                                                       int ldo, int coff, int accumulate, int WS, int CC) {
+  extern __shared__ __attribute__((aligned(16))) float rbt_smem[];      // [2][cols][CC]
+  const int HP = (H + 1) >> 1;
+  const int n = blockIdx.y / HP, h0 = (blockIdx.y - n * HP) * 2, h1 = h0 + 1;
+  const int w0 = blockIdx.x * WS, w1 = min(w0 + WS, W);
+  const int c0 = blockIdx.z * CC;
+  const int Ho = H * f, Wo = W * f;
+  const int xlo = max((w0 - 1) * f + 1, 0), xhi = min(w1 * f, Wo), cols = xhi - xlo;
+  const int ylo = max((h0 - 1) * f + 1, 0), yhi = min((h1 + 1) * f, Ho);
+  const int cgc = CC >> 3, items = cols * cgc;
+  const float inv = 1.f / (float)f;
+  float a0[RBT_K][8], a1[RBT_K][8];
+  int64_t off[RBT_K];
+#pragma unroll
+  for (int k = 0; k < RBT_K; ++k) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[k][e] = a1[k][e] = 0.f;
+    const int it = threadIdx.x + k * 256;
+    const int col = it / cgc, cv = it - col * cgc;
+    off[k] = it < items ? (int64_t)(xlo + col) * ldo + coff + c0 + cv * 8 : -1;
+  }
+  const T* base = dy + (int64_t)n * Ho * Wo * ldo;
+#pragma unroll 2
+  for (int yo = ylo; yo < yhi; ++yo) {
+    const int y0 = yo / f, y1 = min(y0 + 1, H - 1);
+    const float fy = (float)(yo - y0 * f) * inv;
+    const float wa = (y0 == h0 ? 1.f - fy : 0.f) + (y1 == h0 ? fy : 0.f), wb = (y0 == h1 ? 1.f - fy : 0.f) + (y1 == h1 ? fy : 0.f);
+    const T* row = base + (int64_t)yo * Wo * ldo;
+    u32x4 v[RBT_K];
+#pragma unroll
+    for (int k = 0; k < RBT_K; ++k)
+      if (off[k] >= 0) v[k] = *reinterpret_cast<const u32x4*>(row + off[k]);
+#pragma unroll
+    for (int k = 0; k < RBT_K; ++k) {
+      if (off[k] < 0) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = h16lo_to_f32(v[k][e]), hi = h16hi_to_f32(v[k][e]);
+        a0[k][2 * e] += wa * lo; a0[k][2 * e + 1] += wa * hi;
+        a1[k][2 * e] += wb * lo; a1[k][2 * e + 1] += wb * hi;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RBT_K; ++k) {
+    const int it = threadIdx.x + k * 256;
+    if (it >= items) continue;
+    float* d0 = rbt_smem + (size_t)it * 8, *d1 = d0 + (size_t)cols * CC;      // item order = [col][channel group]: the [cols][CC] image
+    *reinterpret_cast<f32x4*>(d0) = f32x4{a0[k][0], a0[k][1], a0[k][2], a0[k][3]};
+    *reinterpret_cast<f32x4*>(d0 + 4) = f32x4{a0[k][4], a0[k][5], a0[k][6], a0[k][7]};
+    *reinterpret_cast<f32x4*>(d1) = f32x4{a1[k][0], a1[k][1], a1[k][2], a1[k][3]};
+    *reinterpret_cast<f32x4*>(d1 + 4) = f32x4{a1[k][4], a1[k][5], a1[k][6], a1[k][7]};
+  }
+  __syncthreads();
+  const int c4n = CC >> 2, per_row = (w1 - w0) * c4n;
+  for (int idx = threadIdx.x; idx < 2 * per_row; idx += 256) {
+    const int r = idx >= per_row ? 1 : 0, rem = idx - r * per_row;
+    const int wl = rem / c4n, c4 = rem - wl * c4n, w = w0 + wl;
+    const int h = r ? h1 : h0;
+    if (h >= H) continue;
+    const float* src = rbt_smem + (size_t)r * cols * CC + c4 * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    const int x_lo = max((w - 1) * f + 1, 0), x_hi = min((w + 1) * f, Wo);
+    for (int xo = x_lo; xo < x_hi; ++xo) {
+      const int x0 = xo / f, x1 = min(x0 + 1, W - 1);
+      const float fx = (float)(xo - x0 * f) * inv;
+      const float wx = (x0 == w ? 1.f - fx : 0.f) + (x1 == w ? fx : 0.f);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + (size_t)(xo - xlo) * CC);
+      sum.x += wx * t.x; sum.y += wx * t.y; sum.z += wx * t.z; sum.w += wx * t.w;
+    }
+    T* d = dx + (((int64_t)n * H + h) * W + w) * C + c0 + c4 * 4;
+    if (accumulate) {
+      const f32x4 o = load4(d);
+      sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+    }
+    store4(d, sum);
+  }
+}
+
 // gradient, one workgroup per (input pixel, channel chunk): the (2f)^2 outputs that may read the pixel are spread over TL tap
 // lanes (VL vector lanes each), tap-lane partials are combined through LDS in a fixed order - deterministic, and parallel
 // even when a whole 96x96 map is the gradient of a single pooled pixel (PSPNet level 1)
@@ -2777,6 +2868,28 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
       else
         hipLaunchKernelGGL(resize_bilinear_bwd_rows_kernel<float>, grid, dim3(256), (size_t)(2 * rowB), s, (const float*)dy, (float*)dx, H, W, C, factor, ldo, coff,
                            accumulate, nvec);
+      STP_LAUNCH_CHECK();
+      return STP_OK;
+    }
+  }
+  {
+    // wide 16-bit channel slices (FPN's pyramid levels): the row-pair tile kernel.  STP_RESIZE_BWD_TILE=0: the gather kernel.
+    static const bool tile_on = !(getenv("STP_RESIZE_BWD_TILE") && atoi(getenv("STP_RESIZE_BWD_TILE")) == 0);
+    const int WS = factor >= 64 ? 1 : 64 / (factor > 0 ? factor : 1), CC = C < 64 ? C : 64;
+    const int cols = (WS + 1) * factor - 1;
+    const size_t lds = (size_t)2 * cols * CC * sizeof(float);
+    if (tile_on && V == 8 && factor >= 2 && C >= 32 && C % CC == 0 && cols * (CC / 8) <= 256 * RBT_K && lds <= 96 * 1024 &&
+        (int64_t)N * ((H + 1) / 2) <= 65535 && C / CC <= 65535 && !(reinterpret_cast<uintptr_t>(dy) & 15) && !(reinterpret_cast<uintptr_t>(dx) & 7)) {
+      static bool attr_set = false;
+      if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resize_bilinear_bwd_tile_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                96 * 1024) != hipSuccess)
+          return STP_E_LAUNCH;
+        attr_set = true;
+      }
+      const dim3 grid((unsigned)ceil_div(W, WS), (unsigned)(N * ((H + 1) / 2)), (unsigned)(C / CC));
+      hipLaunchKernelGGL(resize_bilinear_bwd_tile_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, H, W, C,
+                         factor, ldo, coff, accumulate, WS, CC);
       STP_LAUNCH_CHECK();
       return STP_OK;
     }

@@ -428,7 +428,7 @@ extern "C" int stp_sigmoid_loss_ex(const void* logits, const uint8_t* target, in
 // Rows are held in registers: the class loops are unrolled to a compile-time bound CM (4, 8, 16, 24 or 32 >= classes) and
 // predicated, rows whose stride allows it are read / written as 16-byte vectors.
 template <typename T, int CM>
-__device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, float (&p)[CM], bool vec4 = false) {
+__device__ __forceinline__ void class_row_load(const T* z, int classes, bool vec, float (&p)[CM], bool vec4 = false) {
   constexpr int V = Elem<T>::VEC;
   if (vec) {
 #pragma unroll
@@ -459,6 +459,10 @@ __device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, f
 #pragma unroll
     for (int c = 0; c < CM; ++c) p[c] = c < classes ? Elem<T>::load(z + c) : 0.f;
   }
+}
+// logits in p[0 .. classes) -> probabilities (p[c] = 0 beyond `classes`)
+template <int CM>
+__device__ __forceinline__ void softmax_probs(float (&p)[CM], int classes) {
   float m = -3.4e38f;
 #pragma unroll
   for (int c = 0; c < CM; ++c) if (c < classes) m = fmaxf(m, p[c]);
@@ -471,6 +475,11 @@ __device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, f
   const float inv = 1.f / sum;
 #pragma unroll
   for (int c = 0; c < CM; ++c) p[c] *= inv;
+}
+template <typename T, int CM>
+__device__ __forceinline__ void softmax_row(const T* z, int classes, bool vec, float (&p)[CM], bool vec4 = false) {
+  class_row_load<T, CM>(z, classes, vec, p, vec4);
+  softmax_probs<CM>(p, classes);
 }
 
 template <typename T, int CM>
@@ -524,7 +533,17 @@ __global__ __launch_bounds__(256) void softmax_loss_finalize_kernel(const float*
   __shared__ double sh[32][LOSS_NSUM];
   const int e = threadIdx.x & 7, lane = threadIdx.x >> 3;
   double a = 0.0;
-  for (int b = lane; b < blocks; b += 32) a += (double)partial[(size_t)b * LOSS_NSUM + e];
+  {
+    int b = lane;
+    for (; b + 224 < blocks; b += 256) {      // eight partials in flight (a run-time trip count keeps one); same order of additions
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 32 * u) * LOSS_NSUM + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (double)v[u];
+    }
+    for (; b < blocks; b += 32) a += (double)partial[(size_t)b * LOSS_NSUM + e];
+  }
   sh[lane][e] = a;
   __syncthreads();
   for (int w = 16; w > 0; w >>= 1) {
@@ -653,6 +672,310 @@ extern "C" int stp_softmax_cce_dice(const void* logits, const uint8_t* target, i
                                  grad_scale, partial, blocks, s);
   else
     return STP_E_BADARG;
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the same loss on class logits that the network produces at 1 / f of the mask's resolution and resizes bilinearly (PSPNet's
+// `final_interpolation`, FPN's last upsampling) - WITHOUT the resized tensor.  The unfused chain writes the f^2-times larger logits,
+// reads them twice (value pass, gradient pass), writes their gradient and reads it back in the resize gradient: 1.0 GB and four launches
+// for PSPNet's 20 classes at 8 x 768 x 768 (468 us); here both passes interpolate from the low-resolution logits (cache-resident) and the
+// gradient pass reduces dL/dlogits straight into the low-resolution gradient.
+//   * one thread per (low-resolution cell (n, y0, x0), row jy of the cell): the f output pixels (y0 f + jy, x0 f .. x0 f + f - 1) read the
+//     cell's four corners (y0, x0), (y0, x1), (y1, x0), (y1, x1), x1 = min(x0 + 1, W - 1) - the lerp of resize_bilinear_vec_kernel, same
+//     order, and the SAME rounding points as the unfused chain: the interpolated logit is rounded to the storage type before the softmax,
+//     the per-pixel gradient is rounded to the storage type before it is weighted;
+//   * gradient: a thread sums (1 - fx) g and fx g over its f pixels, the f rows of a cell are combined by a DPP butterfly over the cell's f
+//     adjacent lanes (fixed order), the cell's four corner sums go to a [cells][4][CM] fp32 table, and a combine launch adds the (up to
+//     nine, border clamping included) cell corners that land on a low-resolution pixel in a fixed order - deterministic, no atomics.
+// rounds a pair of values to the storage type (one v_cvt_pk per pair)
+template <typename T> __device__ __forceinline__ void round_pair_to_storage(float& a, float& b) {
+  if constexpr (sizeof(T) == 2) {
+    const uint32_t w = pack_bf16x2(a, b);
+    a = h16lo_to_f32(w);
+    b = h16hi_to_f32(w);
+  }
+}
+// sum over the f = 2^lf adjacent lanes of a cell (every lane of the group gets the sum; groups are lane-aligned)
+__device__ __forceinline__ float cell_lanes_sum(float v, int lf) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));             // quad_perm [1,0,3,2]
+  if (lf >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+  if (lf >= 3) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)); // row_half_mirror
+  if (lf >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)); // row_mirror
+  return v;
+}
+
+struct UpGeo { int H, W, lf; FastDiv divW, divH; };
+
+// Row jy of cell (n, y0, x0): the logits of its f output pixels are L + D fx, fx = jx / f, with L / R the left / right corner columns
+// interpolated to the row FIRST (L = v00 + (v10 - v00) fy, R = v01 + (v11 - v01) fy, D = R - L): one multiply-add per class and pixel
+// instead of the three of the horizontal-first order of resize_bilinear_vec_kernel (the same number up to the rounding of fp32 sums,
+// i.e. the storage rounding that follows lands on the other neighbour for ~1 value in 10^4).  Also the f target bytes of the row.
+template <typename T, int CM>
+__device__ __forceinline__ void up_row_load(const T* __restrict__ low, const uint8_t* __restrict__ target, uint32_t item, const UpGeo& g, int classes,
+                                            int ldc, bool vec, bool vec4, float (&L)[CM], float (&D)[CM], uint32_t& tw0, uint32_t& tw1,
+                                            uint32_t& tw2, uint32_t& tw3, float& fy, int& jy, uint32_t& cell) {
+  const int f = 1 << g.lf;
+  jy = (int)(item & (uint32_t)(f - 1));
+  cell = item >> g.lf;
+  const uint32_t r = fdiv(cell, g.divW);
+  const int x0 = (int)(cell - r * (uint32_t)g.W);
+  const uint32_t n = fdiv(r, g.divH);
+  const int y0 = (int)(r - n * (uint32_t)g.H);
+  const int x1 = min(x0 + 1, g.W - 1), y1 = min(y0 + 1, g.H - 1);
+  fy = (float)jy * (1.f / (float)f);
+  const T* b = low + (int64_t)n * g.H * g.W * ldc;
+  float tmp[CM];
+  class_row_load<T, CM>(b + ((int64_t)y0 * g.W + x0) * ldc, classes, vec, L, vec4);
+  class_row_load<T, CM>(b + ((int64_t)y1 * g.W + x0) * ldc, classes, vec, tmp, vec4);
+#pragma unroll
+  for (int c = 0; c < CM; ++c) L[c] = L[c] + (tmp[c] - L[c]) * fy;
+  class_row_load<T, CM>(b + ((int64_t)y0 * g.W + x1) * ldc, classes, vec, D, vec4);
+  class_row_load<T, CM>(b + ((int64_t)y1 * g.W + x1) * ldc, classes, vec, tmp, vec4);
+#pragma unroll
+  for (int c = 0; c < CM; ++c) D[c] = (D[c] + (tmp[c] - D[c]) * fy) - L[c];
+  const uint8_t* trow = target + (((int64_t)n * g.H + y0) * f + jy) * ((int64_t)g.W * f) + (int64_t)x0 * f;
+  tw0 = tw1 = tw2 = tw3 = 0u;
+  if (f >= 4) {
+    const uint32_t* tq = reinterpret_cast<const uint32_t*>(trow);
+    tw0 = tq[0];
+    if (f >= 8) tw1 = tq[1];
+    if (f >= 16) { tw2 = tq[2]; tw3 = tq[3]; }
+  } else {
+    tw0 = *reinterpret_cast<const uint16_t*>(trow);
+  }
+}
+// output pixel jx of the row: e[c] = exp(logit_c - max) of the logits rounded to the storage type (0 beyond `classes`), their sum; returns the target class
+template <typename T, int CM>
+__device__ __forceinline__ int up_pixel_exp(const float (&L)[CM], const float (&D)[CM], uint32_t tw0, uint32_t tw1, uint32_t tw2, uint32_t tw3, int jx,
+                                            float inv_f, int classes, float (&e)[CM], float& esum) {
+  const float fx = (float)jx * inv_f;
+#pragma unroll
+  for (int c = 0; c < CM; c += 2) {
+    e[c] = L[c] + D[c] * fx;
+    e[c + 1] = L[c + 1] + D[c + 1] * fx;
+    round_pair_to_storage<T>(e[c], e[c + 1]);
+  }
+  float m = -3.4e38f;
+#pragma unroll
+  for (int c = 0; c < CM; ++c) if (c < classes) m = fmaxf(m, e[c]);
+  esum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CM; ++c) { e[c] = c < classes ? __expf(e[c] - m) : 0.f; esum += e[c]; }
+  const uint32_t w = jx < 4 ? tw0 : jx < 8 ? tw1 : jx < 12 ? tw2 : tw3;
+  const int t = (int)((w >> ((jx & 3) * 8)) & 255u);
+  return t < classes ? t : classes - 1;
+}
+
+template <typename T, int CM>
+__global__ __launch_bounds__(256) void softmax_up_partial_kernel(const T* __restrict__ low, const uint8_t* __restrict__ target, uint32_t items,
+                                                                 const UpGeo g, int classes, int ldc, float* partial) {
+  float a[LOSS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int f = 1 << g.lf;
+  const float inv_f = 1.f / (float)f;
+  const bool vec = (ldc % Elem<T>::VEC) == 0 && CM % Elem<T>::VEC == 0;
+  const bool vec4 = !vec && sizeof(T) == 2 && (ldc % 4) == 0 && (CM % 4) == 0 && !(reinterpret_cast<uintptr_t>(low) & 7);
+  for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += gridDim.x * 256u) {
+    float L[CM], D[CM], fy;
+    uint32_t tw0, tw1, tw2, tw3, cell;
+    int jy;
+    up_row_load<T, CM>(low, target, it, g, classes, ldc, vec, vec4, L, D, tw0, tw1, tw2, tw3, fy, jy, cell);
+    for (int jx = 0; jx < f; ++jx) {
+      float e[CM], esum;
+      const int t = up_pixel_exp<T, CM>(L, D, tw0, tw1, tw2, tw3, jx, inv_f, classes, e, esum);
+      float et = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) et = c == t ? e[c] : et;
+      // the closed forms of softmax_loss_partial_kernel with p_c = e_c / sum: the largest e is exp(0) = 1, so pmax = 1 / sum
+      const float inv = 1.f / esum, pt = et * inv, pmax = inv;
+      const float tt = pt > 0.5f ? 1.f : 0.f, tm = pmax > 0.5f ? 1.f : 0.f;
+      a[1] += esum * inv;
+      a[2] += 1.f;
+      a[3] += pt;
+      a[4] += tm;
+      a[5] += tt;
+      a[6] += (float)classes - (pt > 0.5f ? 0.f : 1.f + tm);
+      a[0] += -__logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+    }
+  }
+  __shared__ float red[4][LOSS_NSUM];
+#pragma unroll
+  for (int e = 0; e < LOSS_NSUM; ++e) a[e] = wave_sum(a[e]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < LOSS_NSUM; ++e) red[threadIdx.x >> 6][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < LOSS_NSUM)
+    partial[(size_t)blockIdx.x * LOSS_NSUM + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <typename T, int CM>
+__global__ __launch_bounds__(256) void softmax_up_grad_kernel(const T* __restrict__ low, const uint8_t* __restrict__ target, uint32_t items,
+                                                              const UpGeo g, int classes, int ldc, const float* __restrict__ scalars, float w_cce,
+                                                              float w_dice, float inv_pixels, float grad_scale, float* __restrict__ corners) {
+  const float sp = scalars[5], sy = scalars[6], spy = scalars[7];
+  const float den = sy + sp + 1.f;
+  const float inv_den2 = 1.f / (den * den);
+  const float num = 2.f * spy + 1.f;
+  const int f = 1 << g.lf;
+  const float inv_f = 1.f / (float)f;
+  const bool vec = (ldc % Elem<T>::VEC) == 0 && CM % Elem<T>::VEC == 0;
+  const bool vec4 = !vec && sizeof(T) == 2 && (ldc % 4) == 0 && (CM % 4) == 0 && !(reinterpret_cast<uintptr_t>(low) & 7);
+  // (items is a multiple of f and a cell's f lanes are lane-aligned: they enter and leave the loop together)
+  for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += gridDim.x * 256u) {
+    float L[CM], D[CM], fy;
+    uint32_t tw0, tw1, tw2, tw3, cell;
+    int jy;
+    up_row_load<T, CM>(low, target, it, g, classes, ldc, vec, vec4, L, D, tw0, tw1, tw2, tw3, fy, jy, cell);
+    float A[CM], B[CM];                           // sum over the row of (1 - fx) g and fx g
+#pragma unroll
+    for (int c = 0; c < CM; ++c) A[c] = B[c] = 0.f;
+    for (int jx = 0; jx < f; ++jx) {
+      float e[CM], esum;
+      const int t = up_pixel_exp<T, CM>(L, D, tw0, tw1, tw2, tw3, jx, inv_f, classes, e, esum);
+      float et = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) et = c == t ? e[c] : et;
+      const float inv = 1.f / esum, pt = et * inv, psum = esum * inv;
+      const bool inr = pt >= 1e-7f && pt <= 1.f - 1e-7f;      // the clip passes no gradient outside
+      // softmax_loss_grad_kernel's dz_c = w_cce (p_c - y_c) / pixels [inr] + w_dice p_c ((num - 2 y_c den) / den^2 - gp), p_c = e_c / sum:
+      // every class gets e_c Kq, the target class the two y terms on top
+      const float gp = (num * psum - 2.f * den * pt) * inv_den2;
+      const float k1 = inr ? w_cce * inv_pixels : 0.f;
+      const float kq = (k1 + w_dice * (num * inv_den2 - gp)) * inv * grad_scale;
+      const float corr = -(k1 + pt * w_dice * 2.f * den * inv_den2) * grad_scale;
+      const float fx = (float)jx * inv_f, gx = 1.f - fx;
+#pragma unroll
+      for (int c = 0; c < CM; c += 2) {
+        float g0 = e[c] * kq + (c == t ? corr : 0.f), g1 = e[c + 1] * kq + (c + 1 == t ? corr : 0.f);
+        round_pair_to_storage<T>(g0, g1);
+        A[c] += gx * g0; B[c] += fx * g0;
+        A[c + 1] += gx * g1; B[c + 1] += fx * g1;
+      }
+    }
+    // the cell's four corner sums over its f rows; corner k = (row a, column b), k = 2 a + b, is stored by lane k (f >= 4) / k & 1 (f = 2)
+    float* out = corners + (size_t)cell * (4 * CM);
+    const float wy0 = 1.f - fy, wy1 = fy;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float s[CM];
+#pragma unroll
+      for (int c = 0; c < CM; ++c) s[c] = cell_lanes_sum(((k & 2) ? wy1 : wy0) * ((k & 1) ? B[c] : A[c]), g.lf);
+      if (jy == (k & (f - 1))) {
+#pragma unroll
+        for (int c = 0; c < CM; c += 4) *reinterpret_cast<f32x4*>(out + k * CM + c) = f32x4{s[c], s[c + 1], s[c + 2], s[c + 3]};
+      }
+    }
+  }
+}
+
+// low-resolution gradient = the cell corners that land on each pixel: cell (y0, x0) corner (a, b) -> pixel (min(y0 + a, H - 1), min(x0 + b, W - 1))
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_up_combine_kernel(const float* __restrict__ corners, int64_t total, int H, int W, int CM, int classes,
+                                                                 T* __restrict__ dl, int dlc, const float* __restrict__ dev_scale,
+                                                                 float* dev_record) {
+  const float m = dev_scale ? dev_scale[0] : 1.f;
+  if (dev_record && blockIdx.x == 0 && threadIdx.x == 0) dev_record[0] = m;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % dlc);
+    const int64_t pix = i / dlc;
+    float sum = 0.f;
+    if (c < classes) {
+      const int w = (int)(pix % W);
+      const int64_t r = pix / W;
+      const int h = (int)(r % H);
+      const int64_t n = r / H;
+      const float* base = corners + n * H * W * (int64_t)(4 * CM) + c;
+      // rows of cells whose corner row a lands on h: a = 0: h; a = 1: h - 1, and H - 1 itself when h is the last row (clamped)
+      int ys[3], as[3], ny = 0;
+      ys[ny] = h; as[ny++] = 0;
+      if (h >= 1) { ys[ny] = h - 1; as[ny++] = 1; }
+      if (h == H - 1) { ys[ny] = h; as[ny++] = 1; }
+      int xs[3], bs[3], nx = 0;
+      xs[nx] = w; bs[nx++] = 0;
+      if (w >= 1) { xs[nx] = w - 1; bs[nx++] = 1; }
+      if (w == W - 1) { xs[nx] = w; bs[nx++] = 1; }
+      for (int iy = 0; iy < ny; ++iy)
+        for (int ix = 0; ix < nx; ++ix)
+          sum += base[(((int64_t)ys[iy] * W + xs[ix]) * 4 + as[iy] * 2 + bs[ix]) * CM];
+    }
+    Elem<T>::store(dl + i, sum * m);
+  }
+}
+
+template <typename T, int CM>
+static void launch_softmax_up(const T* low, const uint8_t* target, int N, int H, int W, int lf, int classes, int ldc, float w_cce, float w_dice,
+                              float* scalars, T* dl, int dlc, float grad_scale, const float* dev_scale, float* dev_record, float* partial,
+                              float* corners, hipStream_t s) {
+  const int64_t cells = (int64_t)N * H * W, items = cells << lf, pixels = items << lf;
+  UpGeo g;
+  g.H = H; g.W = W; g.lf = lf; g.divW = make_fastdiv((uint32_t)W); g.divH = make_fastdiv((uint32_t)H);
+  // value pass: at most 2048 partial rows (they fit the loss workspace), every thread the same number of rows where the count allows
+  // (PSPNet's 589 824 rows: 1152 workgroups x 2 rows, not 1024 x 2.25)
+  int64_t b = (items + 255) / 256;
+  const int64_t iters = (b + 2047) / 2048;
+  b = (b + iters - 1) / iters;
+  const int blocks = (int)b;
+  static_assert(2048 * LOSS_NSUM <= LOSS_GSUM_OFFSET + LOSS_GRAD_MAX_BLOCKS, "partial rows fit stp_loss_workspace_bytes()");
+  hipLaunchKernelGGL((softmax_up_partial_kernel<T, CM>), dim3(blocks), dim3(256), 0, s, low, target, (uint32_t)items, g, classes, ldc, partial);
+  hipLaunchKernelGGL(softmax_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, 1.0 / (double)pixels,
+                     1.0 / ((double)pixels * classes), w_cce, w_dice, scalars);
+  if (dl) {
+    int64_t gr = (items + 255) / 256;
+    if (gr > 16384) gr = 16384;
+    hipLaunchKernelGGL((softmax_up_grad_kernel<T, CM>), dim3((int)gr), dim3(256), 0, s, low, target, (uint32_t)items, g, classes, ldc, scalars, w_cce,
+                       w_dice, (float)(1.0 / (double)pixels), grad_scale, corners);
+    const int64_t total = cells * dlc;
+    int64_t g2 = (total + 255) / 256;
+    if (g2 > 8192) g2 = 8192;
+    hipLaunchKernelGGL(softmax_up_combine_kernel<T>, dim3((int)g2), dim3(256), 0, s, corners, total, H, W, CM, classes, dl, dlc, dev_scale, dev_record);
+  }
+}
+
+static int up_class_bucket(int classes) { return classes <= 4 ? 4 : classes <= 8 ? 8 : classes <= 16 ? 16 : classes <= 24 ? 24 : 32; }
+
+extern "C" int stp_softmax_cce_dice_up_ok(int32_t factor, int32_t classes, int32_t dtype) {
+  const bool on = !(getenv("STP_UP_LOSS") && atoi(getenv("STP_UP_LOSS")) == 0);      // (a plan-time query: read at every call)
+  return on && stp_dtype_ok(dtype) && (factor == 2 || factor == 4 || factor == 8 || factor == 16) && classes >= 2 && classes <= STP_MAX_CLASSES;
+}
+extern "C" size_t stp_softmax_cce_dice_up_corner_bytes(int32_t N, int32_t H, int32_t W, int32_t classes) {
+  if (N <= 0 || H <= 0 || W <= 0 || classes < 2 || classes > STP_MAX_CLASSES) return 0;
+  return (size_t)N * H * W * 4 * up_class_bucket(classes) * sizeof(float);
+}
+extern "C" int stp_softmax_cce_dice_up(const void* low, const uint8_t* target, int32_t N, int32_t H, int32_t W, int32_t factor, int32_t classes,
+                                       int32_t ldc, int32_t dtype, float w_cce, float w_dice, float* scalars, void* dlow, int32_t dl_channels,
+                                       float grad_scale, const float* dev_scale, float* dev_record, void* workspace, size_t workspace_bytes,
+                                       void* corners, size_t corner_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  if (!low || !target || !scalars || !workspace || N <= 0 || H <= 0 || W <= 0 || classes < 2 || classes > STP_MAX_CLASSES || ldc < classes)
+    return STP_E_BADARG;
+  if (factor != 2 && factor != 4 && factor != 8 && factor != 16) return STP_E_BADARG;
+  if ((int64_t)N * H * W * factor >= (1ll << 31)) return STP_E_BADARG;      // (work items are indexed in 32 bits)
+  if (workspace_bytes < stp_loss_workspace_bytes()) return STP_E_WORKSPACE;
+  if (dlow && (dl_channels < classes || !corners)) return STP_E_BADARG;
+  if (dlow && corner_bytes < stp_softmax_cce_dice_up_corner_bytes(N, H, W, classes)) return STP_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(target) & 3) || (dlow && (reinterpret_cast<uintptr_t>(corners) & 15))) return STP_E_BADARG;
+  const int lf = factor == 2 ? 1 : factor == 4 ? 2 : factor == 8 ? 3 : 4;
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+#define STP_UP(T, CM)                                                                                                                       \
+  launch_softmax_up<T, CM>((const T*)low, target, N, H, W, lf, classes, ldc, w_cce, w_dice, scalars, (T*)dlow, dl_channels, grad_scale, \
+                           dev_scale, dev_record, partial, (float*)corners, s)
+#define STP_UP_T(T)                                                                                                                         \
+  switch (up_class_bucket(classes)) {                                                                                                       \
+    case 4: STP_UP(T, 4); break;                                                                                                            \
+    case 8: STP_UP(T, 8); break;                                                                                                            \
+    case 16: STP_UP(T, 16); break;                                                                                                          \
+    case 24: STP_UP(T, 24); break;                                                                                                          \
+    default: STP_UP(T, 32); break;                                                                                                          \
+  }
+  if (dtype == STP_H16) { STP_UP_T(bf16_t) }
+  else if (dtype == STP_F32) { STP_UP_T(float) }
+  else return STP_E_BADARG;
+#undef STP_UP_T
+#undef STP_UP
   STP_LAUNCH_CHECK();
   return STP_OK;
 }

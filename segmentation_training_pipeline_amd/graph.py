@@ -1365,6 +1365,8 @@ class Plan(object):
                    x.C, factor, x.C, 0, self.cdt)
         if not self.training:
             return out
+        if not nearest:      # (softmax_loss may take this launch and its gradient over: stp_softmax_cce_dice_up)
+            out.meta["resize_rec"] = (len(self.fwd) - 1, x, int(factor))
 
         def back():
             if not (x.needs_grad and out.grad_ready):
@@ -1698,6 +1700,28 @@ class Plan(object):
         if self.dry:
             return
         self.loss_scalars = self._alloc((12,), torch.float32)
+        rec = logits.meta.get("resize_rec")
+        if (self.training and rec is not None and self.fwd[rec[0]][2] == "stp_resize_bilinear" and rec[1].needs_grad
+                and not rec[1].grad_ready and target.buf.data_ptr() % 4 == 0
+                and self.lib.stp_softmax_cce_dice_up_ok(rec[2], logits.C, self.cdt)):
+            # the logits are a bilinear resize of the class convolution's output (PSPNet, FPN) and only this loss reads them: both loss passes
+            # interpolate from the low-resolution tensor, the gradient pass reduces straight into its gradient - the resized logits, their
+            # gradient, the resize launch, stp_scale_by_device and stp_resize_bilinear_bwd leave the step (the launch record is kept for
+            # HipSegModel.logits(), which materialises the resized tensor on demand)
+            idx, lo, f = rec
+            logits.meta["deferred"] = (self.fwd[idx][0], self.fwd[idx][1], self.fwd[idx][2])
+            self.fwd[idx] = (None, (), "fused:resize->loss", None)
+            nb = int(self.lib.stp_softmax_cce_dice_up_corner_bytes(self.N, lo.H, lo.W, logits.C))
+            corners = self._alloc((nb // 4,), torch.float32)
+            dlow = self._gradbuf(lo)
+            dls = self.dls.data_ptr() if self.dls is not None else None
+            self._emit(self.fwd, "stp_softmax_cce_dice_up", lo.buf.data_ptr(), target.buf.data_ptr(), self.N, lo.H, lo.W, f, logits.C, lo.C,
+                       self.cdt, float(w_cce), float(w_dice), self.loss_scalars.data_ptr(), dlow.data_ptr(), lo.gradC, float(self.loss_scale),
+                       dls, (dls + 16) if dls is not None else None, self.ws_loss.data_ptr(), self.ws_loss.numel() * 4, corners.data_ptr(), nb)
+            lo.grad_ready = True
+            logits.grad_ready = False
+            logits.meta["fused_into_loss"] = True
+            return
         dl = self._gradbuf(logits) if self.training else None
         self._emit(self.fwd, "stp_softmax_cce_dice", logits.buf.data_ptr(), target.buf.data_ptr(), logits.rows, logits.C, logits.C,
                    self.cdt, float(w_cce), float(w_dice), self.loss_scalars.data_ptr(), dl.data_ptr() if dl is not None else None,

@@ -549,12 +549,42 @@ def test_pspnet_head_without_its_concatenation_keeps_the_reference_parameters(mo
     assert shapes(new)["psp_final/kernel"] == (512, 1, 1, 512 + 4 * 512)              # OHWI of Keras' (1, 1, 2560, 512)
     f = lambda pl, n: [x for x in pl.prep + pl.fwd + pl.bwd if x[2] == n]
     assert len(f(new, "stp_upsample_sum")) == 1 and not f(old, "stp_upsample_sum")
-    assert len(f(new, "stp_resize_bilinear")) == 1 and len(f(old, "stp_resize_bilinear")) == 6        # only the logits are resized now
+    # no resize launch is left: the pyramid levels enter through stp_upsample_sum, the logits' resize lives inside the loss (see below)
+    assert len(f(new, "stp_resize_bilinear")) == 0 and len(f(old, "stp_resize_bilinear")) == 5
+    assert len(f(new, "stp_softmax_cce_dice_up")) == 1 and len(f(old, "stp_softmax_cce_dice_up")) == 1
     assert len(f(new, "stp_copy_cols_f32")) == 10 and new.prep[-1][2] == "stp_weight_prepare_batched"  # five ranges in, five gradients out
     flops = lambda pl: sum(m["flops"] for _, _, _, m in pl.fwd if m and "flops" in m)
     assert abs(flops(new) - flops(old)) < 1e-6 * flops(old)
     assert new.bwd_monotone and old.bwd_monotone
     assert "psp_concat" not in new.tensors and "psp_pyramid_sum" in new.tensors and new.tensors["psp_pyramid_sum"].C == 512
+
+
+def test_loss_on_resized_logits_is_planned_without_the_resized_tensor(monkeypatch):
+    """PSPNet / FPN end in Conv -> bilinear resize -> softmax loss (segmentation_models 0.2.1: `final_interpolation`, FPN's last
+    UpSampling2D): a TRAINING plan replaces resize + loss + (dynamic loss scale) + resize gradient by stp_softmax_cce_dice_up, which reads
+    the low-resolution logits and writes their gradient; the resize launch is kept as the deferred record of the "logits" tensor.  The
+    1-class (sigmoid) heads, nearest interpolation, inference plans and STP_UP_LOSS=0 keep the unfused launches.  Host logic only."""
+    def plan_for(net, training=True, **kw):
+        p = graph.Plan(2, "bf16", "cpu", training=training)
+        p.define(lambda q_: net(q_, "resnet18", 96, 96, **kw))
+        return p
+    names = lambda pl, lst=None: [x[2] for x in (pl.prep + pl.fwd + pl.bwd if lst is None else lst)]
+    for net, f in ((nets.pspnet_resnet, 8), (nets.fpn_resnet, 4)):
+        p = plan_for(net, classes=4)
+        n = names(p)
+        assert n.count("stp_softmax_cce_dice_up") == 1 and "stp_softmax_cce_dice" not in n and "fused:resize->loss" in n
+        assert not [a for a in p.bwd if a[2] == "stp_resize_bilinear_bwd" and a[1][5] == 8 and a[1][6] == f]      # (the 8 padded class channels)
+        logits = p.tensors["logits"]
+        assert logits.meta.get("fused_into_loss") and logits.meta["deferred"][2] == "stp_resize_bilinear" and logits.grad is None
+        a = [x for x in p.fwd if x[2] == "stp_softmax_cce_dice_up"][0][1]
+        assert a[2:8] == (2, 96 // f, 96 // f, f, 4, 4) and a[13] == 8                   # N, H, W, factor, classes, row stride; padded gradient rows
+        # inference plan, 1-class head, nearest interpolation: nothing changes
+        assert "stp_softmax_cce_dice_up" not in names(plan_for(net, training=False, classes=4, with_loss=False))
+        assert "stp_softmax_cce_dice_up" not in names(plan_for(net, classes=1))
+    assert "stp_softmax_cce_dice_up" not in names(plan_for(nets.pspnet_resnet, classes=4, final_interpolation="nearest"))
+    monkeypatch.setenv("STP_UP_LOSS", "0")
+    n = names(plan_for(nets.pspnet_resnet, classes=4))
+    assert "stp_softmax_cce_dice_up" not in n and n.count("stp_softmax_cce_dice") == 1 and "stp_resize_bilinear" in n
 
 
 def test_pointwise_kernel_sizing_queries_do_not_depend_on_the_table_pointer():

@@ -1898,7 +1898,11 @@ def test_batchnorm_apply_fused_with_the_max_pooling_behind_it(ops, case, dtype):
 @pytest.mark.parametrize("case", [(2, 12, 24, 24, 24, 0, 8), (1, 16, 64, 8, 8, 0, 4), (2, 6, 10, 8, 24, 8, 2), (1, 9, 33, 16, 16, 0, 8),
                                   (2, 5, 7, 16, 48, 16, 1), (1, 8, 8, 128, 320, 64, 1),       # factor 1 = a channel slice copied / added back
                                   # tiny maps, large factors, a slice of a wide tensor (PSPNet's pyramid levels): the separable two-pass form
-                                  (2, 1, 1, 128, 320, 64, 32), (1, 2, 2, 512, 1024, 512, 16), (2, 3, 3, 64, 192, 128, 24), (1, 6, 6, 256, 256, 0, 8)])
+                                  (2, 1, 1, 128, 320, 64, 32), (1, 2, 2, 512, 1024, 512, 16), (2, 3, 3, 64, 192, 128, 24), (1, 6, 6, 256, 256, 0, 8),
+                                  # wide slices of a concatenation (FPN's pyramid levels: round 6, resize_bilinear_bwd_tile_kernel): two channel
+                                  # chunks, ragged column segments, an odd row count (a row pair with one row), factors 2 .. 16 and a factor of 3
+                                  (1, 18, 20, 128, 512, 128, 8), (2, 17, 33, 64, 192, 64, 4), (1, 40, 36, 128, 512, 384, 2), (1, 17, 3, 32, 32, 0, 16),
+                                  (1, 20, 20, 48, 48, 0, 3)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_bilinear_resize_gradient_of_class_logits_and_of_an_unresized_slice(ops, case, dtype):
     """Round 5: resize_bilinear_bwd_rows_kernel - the gradient of the x4 / x8 bilinear resize of class logits (channel count padded to
@@ -2605,6 +2609,79 @@ def test_softmax_categorical_crossentropy_dice_loss_and_gradient(ops, dtype, cla
     probs = torch.empty((pixels, classes), device=DEV)
     _lib.call("stp_softmax", ops.ptr(zd), ops.ptr(probs), pixels, classes, ldc, ops.dt(zd), ops.stream())
     np.testing.assert_allclose(host(probs), pd.numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 12, 12, 8, 20, 20, 24), (2, 16, 20, 4, 3, 3, 8), (1, 9, 7, 2, 5, 8, 8), (1, 3, 5, 16, 2, 4, 8),
+                                  (3, 1, 6, 4, 9, 12, 16), (1, 6, 1, 8, 30, 32, 32)])
+def test_softmax_loss_on_upsampled_logits_without_the_upsampled_tensor(ops, dtype, case):
+    """stp_softmax_cce_dice_up (the loss of PSPNet / FPN heads: bilinear resize of the class logits + softmax loss + the gradient of
+    both) against the chain it replaces - stp_resize_bilinear, stp_softmax_cce_dice, stp_scale_by_device, stp_resize_bilinear_bwd - run
+    on the device: same scalars, same low-resolution gradient up to the order of its fp32 sums (the fused form rounds where the chain
+    stores: the resized logit, the per-pixel gradient).  Cases cover every factor, every class bucket, padded rows, one-row / one-column
+    maps (both border clamps in one cell) and the device multiplier of the dynamic loss scale."""
+    from segmentation_training_pipeline_amd import _lib
+    n, h, w, f, classes, ldc, dlc = case
+    rng = np.random.RandomState(5 + f + classes)
+    ho, wo = h * f, w * f
+    z = q(rng.randn(n, h, w, ldc) * 2.5, dtype)
+    t = rng.randint(0, classes + 1, size=(n, ho, wo)).astype(np.uint8)      # (one value past the classes: clamped like the unfused kernel)
+    zd, td = dev(z, dtype), keep(torch.from_numpy(t).to(DEV))
+    gscale = 64.0 if dtype == "fp16" else 1.0
+    ws = torch.empty(ops.loss_workspace_bytes() // 4, dtype=torch.float32, device=DEV)
+    mult = keep(torch.tensor([4.0 if dtype == "fp16" else 1.0, 0, 0, 0, 0, 0, 0, 0], device=DEV))
+    # the chain
+    up = torch.empty((n, ho, wo, ldc), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_resize_bilinear", ops.ptr(zd), ops.ptr(up), n, h, w, ldc, f, ldc, 0, ops.dt(zd), ops.stream())
+    scal0 = torch.zeros(12, device=DEV)
+    dl = torch.full((n, ho, wo, dlc), float("nan"), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_softmax_cce_dice", ops.ptr(up), ops.ptr(td), n * ho * wo, classes, ldc, ops.dt(zd), 1.0, 0.5, ops.ptr(scal0), ops.ptr(dl), dlc,
+              gscale, ops.ptr(ws), ws.numel() * 4, ops.stream())
+    _lib.call("stp_scale_by_device", ops.ptr(dl), n * ho * wo * dlc, ops.dt(zd), ops.ptr(mult), None, ops.stream())
+    wsb = int(_lib.load().stp_resize_bilinear_bwd_workspace_bytes(n, h, w, dlc, f))
+    wsr = torch.empty(max(wsb, 16) // 4, dtype=torch.float32, device=DEV)
+    dlow0 = torch.full((n, h, w, dlc), float("nan"), dtype=TD[dtype], device=DEV)
+    _lib.call("stp_resize_bilinear_bwd", ops.ptr(dl), ops.ptr(dlow0), n, h, w, dlc, f, dlc, 0, ops.dt(zd), 0, ops.ptr(wsr) if wsb else None, wsb,
+              ops.stream())
+    # the fused launch
+    assert _lib.load().stp_softmax_cce_dice_up_ok(f, classes, ops.dt(zd)) == 1
+    nb = int(_lib.load().stp_softmax_cce_dice_up_corner_bytes(n, h, w, classes))
+    corners = torch.full((nb // 4,), float("nan"), dtype=torch.float32, device=DEV)
+    scal1 = torch.zeros(12, device=DEV)
+    dlow1 = torch.full((n, h, w, dlc), float("nan"), dtype=TD[dtype], device=DEV)
+    rec = keep(torch.zeros(4, device=DEV))
+    _lib.call("stp_softmax_cce_dice_up", ops.ptr(zd), ops.ptr(td), n, h, w, f, classes, ldc, ops.dt(zd), 1.0, 0.5, ops.ptr(scal1), ops.ptr(dlow1),
+              dlc, gscale, ops.ptr(mult), ops.ptr(rec), ops.ptr(ws), ws.numel() * 4, ops.ptr(corners), nb, ops.stream())
+    s0, s1 = host(scal0), host(scal1)
+    np.testing.assert_allclose(s1[:10], s0[:10], rtol=2e-6, atol=2e-6)       # (the partial sums are taken in another order)
+    assert host(rec)[0] == host(mult)[0]
+    g0, g1 = host(dlow0), host(dlow1)
+    assert np.isfinite(g1).all()
+    np.testing.assert_array_equal(g1[..., classes:], 0)
+    scale = np.abs(g0).max()
+    # fp32: the sums only differ in their order; 16-bit: one storage ulp of the result where a sum lands on a rounding boundary
+    np.testing.assert_allclose(g1[..., :classes], g0[..., :classes], atol={"fp32": 2e-6, "bf16": 8e-3, "fp16": 1e-3}[dtype] * scale)
+    if dtype != "fp32":
+        assert np.mean(g1 == g0) > 0.9, np.mean(g1 == g0)
+    # and the value against the oracle's loss on the resized logits (float64 lerp of the rounded inputs, rounded as the chain stores it)
+    if dtype == "fp32":
+        upz = host(up)[..., :classes].reshape(-1, classes)
+        zt = torch.from_numpy(upz.copy())
+        tt = np.minimum(t.reshape(-1), classes - 1).astype(np.int64)
+        yt = torch.nn.functional.one_hot(torch.from_numpy(tt), classes).to(torch.float32)
+        loss = olosses.composite_loss("categorical_crossentropy+0.5*dice_loss", yt, torch.softmax(zt, dim=-1))
+        assert abs(s1[0] - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
+    # scalars only (no gradient buffer)
+    scal2 = torch.zeros(12, device=DEV)
+    _lib.call("stp_softmax_cce_dice_up", ops.ptr(zd), ops.ptr(td), n, h, w, f, classes, ldc, ops.dt(zd), 1.0, 0.5, ops.ptr(scal2), None, 0, 1.0,
+              None, None, ops.ptr(ws), ws.numel() * 4, None, 0, ops.stream())
+    np.testing.assert_array_equal(host(scal2)[:10], s1[:10])
+    # argument checks: a factor the kernel does not serve, a corner table that is too small
+    lib = _lib.load()
+    assert lib.stp_softmax_cce_dice_up(ops.ptr(zd), ops.ptr(td), n, h, w, 3, classes, ldc, ops.dt(zd), 1.0, 0.5, ops.ptr(scal2), None, 0, 1.0, None,
+                                       None, ops.ptr(ws), ws.numel() * 4, None, 0, ops.stream()) != 0
+    assert lib.stp_softmax_cce_dice_up(ops.ptr(zd), ops.ptr(td), n, h, w, f, classes, ldc, ops.dt(zd), 1.0, 0.5, ops.ptr(scal2), ops.ptr(dlow1), dlc,
+                                       1.0, None, None, ops.ptr(ws), ws.numel() * 4, ops.ptr(corners), nb - 16, ops.stream()) != 0
 
 
 @pytest.mark.parametrize("bad", [float("inf"), float("nan")])
