@@ -412,6 +412,17 @@ int stp_avgpool(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t
                 size_t workspace_bytes, void* stream);
 int stp_avgpool_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
                     int32_t accumulate, void* stream);
+/* PSPNet's pyramid pooling (segmentation_models 0.2.1 psp builder: AveragePooling2D(size / level) of ONE feature map for levels 1, 2, 3, 6;
+ * schemas/segmentation.raml:225-249) in one pass over the feature map: up to four levels y_i [N][H / k_i][W / k_i][C], k0 the FINEST window
+ * (smallest k), every other k_i a multiple of k0 (k_i = 0: level unused) - the means are formed from the fp32 sums of the finest windows, one
+ * rounding per output as stp_avgpool.  _bwd: dx (+)= sum_i dy_i / k_i^2 in one pass.  _ok: 1 if the pyramid form serves the shape
+ * (STP_POOL_PYRAMID=0: never); workspace >= stp_avgpool_pyramid_workspace_bytes(). */
+int stp_avgpool_pyramid_ok(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k0, int32_t k1, int32_t k2, int32_t k3, int32_t dtype);
+size_t stp_avgpool_pyramid_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k0, int32_t dtype);
+int stp_avgpool_pyramid(const void* x, void* y0, void* y1, void* y2, void* y3, int32_t k0, int32_t k1, int32_t k2, int32_t k3, int32_t N,
+                        int32_t H, int32_t W, int32_t C, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+int stp_avgpool_pyramid_bwd(const void* dy0, const void* dy1, const void* dy2, const void* dy3, int32_t k0, int32_t k1, int32_t k2, int32_t k3,
+                            void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate, void* stream);
 /* MaxPooling2D(pool_size = strides = k), any k dividing H and W (PSPNet `psp_pooling_type: max`): idx[N,H/k,W/k,C] int32 = position of the
  * first maximum inside its window (NULL = not wanted); the gradient goes to that position. */
 int stp_maxpool_k(const void* x, void* y, int32_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* stream);

@@ -124,6 +124,10 @@ SIGNATURES = {
     "stp_avgpool_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "stp_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "stp_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "stp_avgpool_pyramid_ok": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32]),
+    "stp_avgpool_pyramid_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "stp_avgpool_pyramid": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "stp_avgpool_pyramid_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool_k": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stp_maxpool_k_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "stp_relu_bwd": (i32, [vp, vp, i64, i32, vp]),

@@ -2931,6 +2931,152 @@ extern "C" int stp_resize_bilinear_bwd(const void* dy, void* dx, int32_t N, int3
   return STP_OK;
 }
 
+// ---- PSPNet's pyramid pooling in ONE pass over the feature map (round 6).  AveragePooling2D at the four pyramid levels (windows 96 / 48 / 32 /
+// 16 pixels at 8 x 96 x 96 x 512) read the same 75 MB four times (4 x 20 us) and their gradients rewrite its gradient four times (108 us).
+// Every coarser window is a union of windows of the finest level, so: the fp32 sums of the FINEST windows (avgpool_win_kernel with its
+// partial-sum table), then one small launch that forms every level's mean from those sums in a fixed order (one rounding per output, as
+// the separate launches); backward: one pass over the feature gradient that adds the <= 4 levels' dY / k^2 of its pixel.
+struct PoolPyr { void* y[4]; int k[4]; int64_t first[5]; int64_t nwin; int levels; };
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_pyramid_combine_kernel(const float* __restrict__ part, int S, PoolPyr p, int H, int W, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.first[p.levels]) return;
+  int L = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q) if (q < p.levels && i >= p.first[q]) L = q;
+  const int64_t j = i - p.first[L];
+  const int k0 = p.k[0], k = p.k[L], r = k / k0, Ho = H / k, Wo = W / k, H0 = H / k0, W0 = W / k0;
+  const int c = (int)(j % C);
+  int64_t b = j / C;
+  const int wo = (int)(b % Wo); b /= Wo;
+  const int ho = (int)(b % Ho);
+  const int64_t n = b / Ho;
+  float sum = 0.f;
+  for (int a = 0; a < r; ++a)
+    for (int d = 0; d < r; ++d) {
+      const int64_t win = (n * H0 + (int64_t)ho * r + a) * W0 + (int64_t)wo * r + d;
+      for (int q = 0; q < S; ++q) sum += part[((int64_t)q * p.nwin + win) * C + c];
+    }
+  Elem<T>::store((T*)p.y[L] + j, sum / (float)(k * k));
+}
+
+struct PoolPyrB { const void* dy[4]; int k[4]; float inv[4]; int levels; };
+template <typename T, int V>
+__global__ __launch_bounds__(256) void avgpool_pyramid_bwd_kernel(PoolPyrB p, T* __restrict__ dx, int H, int W, int C, int accumulate) {
+  const int cg = C / V;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W * cg) return;
+  const int w = t / cg, c = (t - w * cg) * V;
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  float o[V], g[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int L = 0; L < 4; ++L) {
+    if (L < p.levels) {
+      const int k = p.k[L];
+      ldv<T, V>((const T*)p.dy[L] + (((int64_t)n * (H / k) + h / k) * (W / k) + w / k) * C + c, g);
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] += g[e] * p.inv[L];
+    }
+  }
+  T* d = dx + (((int64_t)n * H + h) * W + w) * C + c;
+  if (accumulate) {
+    ldv<T, V>(d, g);
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] += g[e];
+  }
+  stv<T, V>(d, o);
+}
+
+static int pool_pyramid_levels(const int* k) {
+  int levels = 0;
+  while (levels < 4 && k[levels] > 0) ++levels;
+  return levels;
+}
+static bool pool_pyramid_ok(int N, int H, int W, int C, const int* k, int levels, int dtype) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || levels < 1 || levels > 4 || (dtype != STP_H16 && dtype != STP_F32)) return false;
+  if (vec_for(dtype, C, 0, 0) <= 1 || (int64_t)N * H > 65535) return false;
+  for (int i = 0; i < levels; ++i)
+    if (k[i] < 1 || H % k[i] || W % k[i] || k[i] % k[0]) return false;
+  return k[0] * k[0] >= 32;      // (the window kernel serves the finest level)
+}
+// 1 if the four AveragePooling2D(k_i) of one tensor can run as a pyramid: k0 = the finest window, every other k a multiple of it (k = 0: level unused)
+extern "C" int stp_avgpool_pyramid_ok(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k0, int32_t k1, int32_t k2, int32_t k3, int32_t dtype) {
+  const bool on = !(getenv("STP_POOL_PYRAMID") && atoi(getenv("STP_POOL_PYRAMID")) == 0);      // (a plan-time query: read at every call)
+  const int k[4] = {k0, k1, k2, k3};
+  return on && stp_dtype_ok(dtype) && pool_pyramid_ok(N, H, W, C, k, pool_pyramid_levels(k), dtype) ? 1 : 0;
+}
+// rows-per-split of the finest level's window launch (the table of fp32 sums is always written, also with one split)
+static int pool_pyramid_rps(int N, int H, int W, int C, int k0, int dtype) {
+  const int V = vec_for(dtype, C, 0, 0), cg = C / V;
+  const int64_t nwin = (int64_t)N * (H / k0) * (W / k0);
+  return split_rows(nwin * ceil_div(cg, pool_vl(cg)), k0, k0);
+}
+extern "C" size_t stp_avgpool_pyramid_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t k0, int32_t dtype) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || k0 < 1 || H % k0 || W % k0 || (dtype != STP_H16 && dtype != STP_F32) || vec_for(dtype, C, 0, 0) <= 1) return 0;
+  const int S = ceil_div(k0, pool_pyramid_rps(N, H, W, C, k0, dtype));
+  return (size_t)S * N * (H / k0) * (W / k0) * C * sizeof(float);
+}
+extern "C" int stp_avgpool_pyramid(const void* x, void* y0, void* y1, void* y2, void* y3, int32_t k0, int32_t k1, int32_t k2, int32_t k3, int32_t N,
+                                   int32_t H, int32_t W, int32_t C, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  const int k[4] = {k0, k1, k2, k3};
+  void* y[4] = {y0, y1, y2, y3};
+  PoolPyr p;
+  p.levels = pool_pyramid_levels(k);
+  if (!x || !workspace || !pool_pyramid_ok(N, H, W, C, k, p.levels, dtype)) return STP_E_BADARG;
+  if (workspace_bytes < stp_avgpool_pyramid_workspace_bytes(N, H, W, C, k0, dtype)) return STP_E_WORKSPACE;
+  p.first[0] = 0;
+  for (int i = 0; i < 4; ++i) {
+    const bool on = i < p.levels;
+    if (on && !y[i]) return STP_E_BADARG;
+    p.y[i] = on ? y[i] : nullptr;
+    p.k[i] = on ? k[i] : 0;
+    p.first[i + 1] = p.first[i] + (on ? (int64_t)N * (H / k[i]) * (W / k[i]) * C : 0);
+  }
+  const int V = vec_for(dtype, C, 0, 0), cg = C / V, VL = pool_vl(cg);
+  p.nwin = (int64_t)N * (H / k0) * (W / k0);
+  const int rps = pool_pyramid_rps(N, H, W, C, k0, dtype), S = ceil_div(k0, rps);
+  float* part = (float*)workspace;
+  const dim3 grid((unsigned)p.nwin, ceil_div(cg, VL), S);
+  const size_t lds = (size_t)(256 / VL) * VL * V * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (V == 8) hipLaunchKernelGGL((avgpool_win_kernel<bf16_t, 8>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)nullptr, H, W, C, k0, VL, rps, part);
+  else if (dtype == STP_H16) hipLaunchKernelGGL((avgpool_win_kernel<bf16_t, 4>), grid, dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)nullptr, H, W, C, k0, VL, rps, part);
+  else hipLaunchKernelGGL((avgpool_win_kernel<float, 4>), grid, dim3(256), lds, s, (const float*)x, (float*)nullptr, H, W, C, k0, VL, rps, part);
+  STP_LAUNCH_CHECK();
+  const unsigned g = (unsigned)ceil_div(p.first[p.levels], (int64_t)256);
+  if (dtype == STP_H16) hipLaunchKernelGGL(avgpool_pyramid_combine_kernel<bf16_t>, dim3(g), dim3(256), 0, s, part, S, p, H, W, C);
+  else hipLaunchKernelGGL(avgpool_pyramid_combine_kernel<float>, dim3(g), dim3(256), 0, s, part, S, p, H, W, C);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+extern "C" int stp_avgpool_pyramid_bwd(const void* dy0, const void* dy1, const void* dy2, const void* dy3, int32_t k0, int32_t k1, int32_t k2, int32_t k3,
+                                       void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate, void* stream) {
+  if (!stp_dtype_ok(dtype)) return STP_E_BADARG;      // (the other build's 16-bit code, or garbage)
+  const int k[4] = {k0, k1, k2, k3};
+  const void* dy[4] = {dy0, dy1, dy2, dy3};
+  PoolPyrB p;
+  p.levels = pool_pyramid_levels(k);
+  if (!dx || !pool_pyramid_ok(N, H, W, C, k, p.levels, dtype)) return STP_E_BADARG;
+  for (int i = 0; i < 4; ++i) {
+    const bool on = i < p.levels;
+    if (on && !dy[i]) return STP_E_BADARG;
+    p.dy[i] = on ? dy[i] : nullptr;
+    p.k[i] = on ? k[i] : 1;
+    p.inv[i] = on ? 1.f / (float)(k[i] * k[i]) : 0.f;
+  }
+  const int V = vec_for(dtype, C, 0, 0);
+  const dim3 grid(ceil_div(W * (C / V), 256), N * H);
+  hipStream_t s = (hipStream_t)stream;
+  if (V == 8) hipLaunchKernelGGL((avgpool_pyramid_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, p, (bf16_t*)dx, H, W, C, accumulate);
+  else if (dtype == STP_H16) hipLaunchKernelGGL((avgpool_pyramid_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, p, (bf16_t*)dx, H, W, C, accumulate);
+  else hipLaunchKernelGGL((avgpool_pyramid_bwd_kernel<float, 4>), grid, dim3(256), 0, s, p, (float*)dx, H, W, C, accumulate);
+  STP_LAUNCH_CHECK();
+  return STP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // MaxPooling2D(pool_size = strides = k) for any k (PSPNet `psp_pooling_type: max`, schemas/segmentation.raml:233-236): one thread
 // per (output pixel, channel), channels fastest (coalesced); idx = position kh * k + kw of the FIRST maximum (int32, k up to the

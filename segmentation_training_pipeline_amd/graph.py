@@ -1560,6 +1560,47 @@ class Plan(object):
         self._tape.append(back)
         return out
 
+    def avgpool_pyramid(self, names, x, ks):
+        """The AveragePooling2D(k) of PSPNet's pyramid levels (one per name / window size) of ONE tensor: where the windows nest (every k a
+        multiple of the smallest one) a single pass over ``x`` (stp_avgpool_pyramid) and a single pass over its gradient instead of one per
+        level; otherwise the separate launches of ``avgpool``.  Returns the pooled tensors in the order of ``names``."""
+        order = sorted(range(len(ks)), key=lambda i: ks[i])
+        kk = [int(ks[i]) for i in order] + [0] * (4 - len(ks))
+        if (len(ks) < 2 or len(ks) > 4 or any(x.H % k or x.W % k for k in ks)
+                or not self.lib.stp_avgpool_pyramid_ok(self.N, x.H, x.W, x.C, kk[0], kk[1], kk[2], kk[3], self.cdt)):
+            return [self.avgpool(nm, x, k) for nm, k in zip(names, ks)]
+        outs = [self._new(nm, x.H // k, x.W // k, x.C, x.needs_grad) for nm, k in zip(names, ks)]
+        for _ in outs:
+            self._use(x)
+        if self.dry:
+            return outs
+        so = [outs[i] for i in order]
+        wp, wb = self._scratch(self.lib.stp_avgpool_pyramid_workspace_bytes(self.N, x.H, x.W, x.C, kk[0], self.cdt))
+        yp = [t.buf.data_ptr() for t in so] + [None] * (4 - len(so))
+        self._emit(self.fwd, "stp_avgpool_pyramid", x.buf.data_ptr(), yp[0], yp[1], yp[2], yp[3], kk[0], kk[1], kk[2], kk[3], self.N, x.H, x.W,
+                   x.C, self.cdt, wp, wb)
+        if not self.training:
+            return outs
+
+        def back():
+            if not x.needs_grad:
+                return
+            ready = [t for t in so if t.grad_ready]
+            if len(ready) == len(so):
+                gp = [t.grad.data_ptr() for t in so] + [None] * (4 - len(so))
+                self._emit(self.bwd, "stp_avgpool_pyramid_bwd", gp[0], gp[1], gp[2], gp[3], kk[0], kk[1], kk[2], kk[3], self._gradbuf(x).data_ptr(),
+                           self.N, x.H, x.W, x.C, self.cdt, int(x.grad_ready))
+                x.grad_ready = True
+                return
+            for t, k in zip(so, kk):      # (a level without a gradient: the separate launches for the others)
+                if t.grad_ready:
+                    self._emit(self.bwd, "stp_avgpool_bwd", t.grad.data_ptr(), self._gradbuf(x).data_ptr(), self.N, x.H, x.W, x.C, k, self.cdt,
+                               int(x.grad_ready))
+                    x.grad_ready = True
+
+        self._tape.append(back)
+        return outs
+
     def maxpool_k(self, name, x, k):
         """MaxPooling2D(pool_size = strides = k) (PSPNet ``psp_pooling_type: max``)."""
         if x.H % k or x.W % k:

@@ -224,10 +224,14 @@ def pspnet_resnet(plan, backbone, H, W, in_ch=3, classes=1, decoder_filters=None
         raise ValueError("PSPNet needs a square input whose 1/%d feature map is divisible by 6 (got %dx%d)" % (downsample_factor, f.H, f.W))
     import os
     parts = [(f, 1)]
-    for level in (1, 2, 3, 6):
+    levels = (1, 2, 3, 6)
+    if psp_pooling_type == "max":
+        pooled = [plan.maxpool_k("psp_level%d_pool" % level, f, f.H // level) for level in levels]
+    else:         # (the four average poolings of the feature map: one pass over it and one over its gradient where the windows nest)
+        pooled = plan.avgpool_pyramid(["psp_level%d_pool" % level for level in levels], f, [f.H // level for level in levels])
+    for level, p in zip(levels, pooled):
         k = f.H // level
         pre = "psp_level%d_" % level
-        p = (plan.maxpool_k if psp_pooling_type == "max" else plan.avgpool)(pre + "pool", f, k)
         p = plan.bn(pre + "bn", plan.conv(pre + "conv", p, int(psp_conv_filters), 1, bn_stats=True), BN_EPS_DECODER, relu=True)
         parts.append((p, k))
     F_ = int(psp_conv_filters)

@@ -587,6 +587,29 @@ def test_loss_on_resized_logits_is_planned_without_the_resized_tensor(monkeypatc
     assert "stp_softmax_cce_dice_up" not in n and n.count("stp_softmax_cce_dice") == 1 and "stp_resize_bilinear" in n
 
 
+def test_pyramid_pooling_is_planned_as_one_pass(monkeypatch):
+    """PSPNet's four AveragePooling2D of the feature map (levels 1, 2, 3, 6: windows that nest) are ONE stp_avgpool_pyramid launch and one
+    stp_avgpool_pyramid_bwd in a training plan, the pooled tensors keep their names and shapes; max pooling and STP_POOL_PYRAMID=0 keep the
+    separate launches.  Host logic only."""
+    def plan_for(**kw):
+        p = graph.Plan(1, "bf16", "cpu", training=True)
+        p.define(lambda q_: nets.pspnet_resnet(q_, "resnet18", 384, 384, classes=4, **kw))      # (1/8 feature 48 x 48: windows 48 / 24 / 16 / 8)
+        return p
+    count = lambda pl, n: len([x for x in pl.prep + pl.fwd + pl.bwd if x[2] == n])
+    p = plan_for()
+    assert count(p, "stp_avgpool_pyramid") == 1 and count(p, "stp_avgpool_pyramid_bwd") == 1 and count(p, "stp_avgpool") == 0 and count(p, "stp_avgpool_bwd") == 0
+    a = [x for x in p.fwd if x[2] == "stp_avgpool_pyramid"][0][1]
+    assert a[5:9] == (8, 16, 24, 48) and a[9:13] == (1, 48, 48, 128)                       # finest window first; N, H, W, C of the 1/8 feature
+    for level in (1, 2, 3, 6):
+        t = p.tensors["psp_level%d_pool" % level]
+        assert (t.H, t.W, t.C) == (level, level, 128)
+    pm = plan_for(psp_pooling_type="max")
+    assert count(pm, "stp_avgpool_pyramid") == 0 and count(pm, "stp_maxpool_k") == 4
+    monkeypatch.setenv("STP_POOL_PYRAMID", "0")
+    po = plan_for()
+    assert count(po, "stp_avgpool_pyramid") == 0 and count(po, "stp_avgpool") == 4 and count(po, "stp_avgpool_bwd") == 4
+
+
 def test_pointwise_kernel_sizing_queries_do_not_depend_on_the_table_pointer():
     """stp_conv2d_stats_floats is asked BEFORE the table of fused sums is allocated (graph.Plan.conv) and again when the BatchNormalization
     that reads it is planned: both answers - and the kernel the launch gets - must agree, with and without stats_partial (round 6: the

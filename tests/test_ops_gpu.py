@@ -2612,6 +2612,59 @@ def test_softmax_categorical_crossentropy_dice_loss_and_gradient(ops, dtype, cla
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 48, 48, 64, (8, 16, 24, 48)), (1, 36, 72, 24, (6, 12, 36)), (2, 24, 24, 20, (12, 24)), (1, 96, 96, 40, (16, 32, 48, 96))])
+def test_pyramid_pooling_in_one_pass_over_the_feature_map(ops, dtype, case):
+    """stp_avgpool_pyramid / _bwd (round 6: PSPNet's four AveragePooling2D of one feature map, windows that nest) against torch's
+    avg_pool2d per level and against the separate stp_avgpool / stp_avgpool_bwd launches: the means come from the fp32 sums of the finest
+    windows (one rounding per output), the gradient pass adds every level's dY / k^2 in one pass (with and without accumulation).  Channel
+    counts on the 16-byte and 8-byte vector paths, non-square maps, two to four levels; the shapes it does not serve are refused."""
+    from segmentation_training_pipeline_amd import _lib
+    lib = _lib.load()
+    n, h, w, c, ks = case
+    rng = np.random.RandomState(17 + c)
+    x = q(rng.randn(n, h, w, c), dtype)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    kk = list(ks) + [0] * (4 - len(ks))
+    assert lib.stp_avgpool_pyramid_ok(n, h, w, c, kk[0], kk[1], kk[2], kk[3], ops.dt(dev(x[:1, :1, :1], dtype))) == 1
+    xd = dev(x, dtype)
+    ys = [torch.full((n, h // k, w // k, c), 9.0, dtype=TD[dtype], device=DEV) for k in ks]
+    wsb = int(lib.stp_avgpool_pyramid_workspace_bytes(n, h, w, c, ks[0], ops.dt(xd)))
+    assert wsb > 0
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=DEV)
+    yp = [ops.ptr(t) for t in ys] + [None] * (4 - len(ks))
+    _lib.call("stp_avgpool_pyramid", ops.ptr(xd), yp[0], yp[1], yp[2], yp[3], kk[0], kk[1], kk[2], kk[3], n, h, w, c, ops.dt(xd), ops.ptr(ws), wsb,
+              ops.stream())
+    gys, loss = [], 0.0
+    for k, y in zip(ks, ys):
+        ref = torch.nn.functional.avg_pool2d(xt, k, k)
+        np.testing.assert_allclose(host(y), ref.detach().permute(0, 2, 3, 1).numpy(), atol=tol(x, dtype, 0.1))
+        # the separate launch: same sums in another order
+        y1 = torch.empty_like(y)
+        w1 = int(lib.stp_avgpool_workspace_bytes(n, h, w, c, k))
+        wb1 = torch.empty(max(w1, 4) // 4, dtype=torch.float32, device=DEV)
+        _lib.call("stp_avgpool", ops.ptr(xd), ops.ptr(y1), n, h, w, c, k, ops.dt(xd), ops.ptr(wb1) if w1 else None, w1, ops.stream())
+        d = np.abs(host(y) - host(y1))
+        assert d.max() <= tol(x, dtype, 0.02) and (dtype == "fp32" or np.mean(d == 0) > 0.95)      # (fp32: the order of the sums shows)
+        gy = q(rng.randn(n, h // k, w // k, c), dtype)
+        gys.append(gy)
+        loss = loss + (ref * torch.from_numpy(gy).permute(0, 3, 1, 2)).sum()
+    loss.backward()
+    gref = xt.grad.permute(0, 2, 3, 1).numpy()
+    gd = [dev(g, dtype) for g in gys]
+    gp = [ops.ptr(t) for t in gd] + [None] * (4 - len(ks))
+    for acc in (0, 1):
+        base = q(rng.randn(n, h, w, c), dtype)
+        dx = dev(base, dtype)
+        _lib.call("stp_avgpool_pyramid_bwd", gp[0], gp[1], gp[2], gp[3], kk[0], kk[1], kk[2], kk[3], ops.ptr(dx), n, h, w, c, ops.dt(xd), acc, ops.stream())
+        want = gref + (base if acc else 0)
+        np.testing.assert_allclose(host(dx), want, atol=tol(want, dtype, 1.0))
+    # refused: a window that is not a multiple of the finest one, a finest window below the window kernel's size, a missing output
+    assert lib.stp_avgpool_pyramid_ok(n, h, w, c, ks[0], ks[0] + 1, 0, 0, ops.dt(xd)) == 0
+    assert lib.stp_avgpool_pyramid_ok(n, h, w, c, 2, 4, 0, 0, ops.dt(xd)) == 0
+    assert lib.stp_avgpool_pyramid(ops.ptr(xd), yp[0], None, None, None, kk[0], kk[1], 0, 0, n, h, w, c, ops.dt(xd), ops.ptr(ws), wsb, ops.stream()) != 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 12, 12, 8, 20, 20, 24), (2, 16, 20, 4, 3, 3, 8), (1, 9, 7, 2, 5, 8, 8), (1, 3, 5, 16, 2, 4, 8),
                                   (3, 1, 6, 4, 9, 12, 16), (1, 6, 1, 8, 30, 32, 32)])
 def test_softmax_loss_on_upsampled_logits_without_the_upsampled_tensor(ops, dtype, case):
