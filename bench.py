@@ -193,6 +193,7 @@ def per_kernel_profile(model, reps=3):
     launches = [(l, "prep") for l in p.prep] + [(l, "fwd") for l in p.fwd] + [(l, "bwd") for l in p.bwd]
     acc = {}
     saved = [t.clone() for t in model._mutable_state()]
+    times, recs = [], None          # per pass: the duration of every launch; the launches' records (same in every pass)
     for rep in range(reps + 1):
         evs = []
         for (fn, args, name, meta), _ in launches:
@@ -208,16 +209,20 @@ def per_kernel_profile(model, reps=3):
         torch.cuda.synchronize()
         if rep == 0:
             continue  # first pass warms caches / clocks
-        for name, meta, e0, e1, byt in evs:
-            key = kernel_key(name, meta, model.dtype) if (meta and "flops" in meta) else name
-            a = acc.setdefault(key, [0, 0.0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += meta["flops"] if (meta and "flops" in meta) else 0.0
-            a[3] += byt or 0
+        times.append([e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1, _ in evs])
+        recs = [(name, meta, byt) for name, meta, _, _, byt in evs]
+    # the MEDIAN over the passes per launch: one pass in which a launch waited tens of milliseconds for something outside the step (seen
+    # once on the pool: 11 launches of one key 620 us each instead of 24) must not move a key to the top of the table
+    for i, (name, meta, byt) in enumerate(recs):
+        key = kernel_key(name, meta, model.dtype) if (meta and "flops" in meta) else name
+        a = acc.setdefault(key, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += float(np.median([t[i] for t in times]))
+        a[2] += meta["flops"] if (meta and "flops" in meta) else 0.0
+        a[3] += byt or 0
     for t, s in zip(model._mutable_state(), saved):
         t.copy_(s)
-    return {k: [v[0] / reps, v[1] / reps, v[2] / reps, v[3] / reps] for k, v in acc.items()}
+    return {k: [float(v[0]), v[1], v[2], float(v[3])] for k, v in acc.items()}
 
 
 def flop_per_image(model):

@@ -9,6 +9,7 @@
 // their Elementwise forms, AdditiveGaussianNoise, Dropout, Grayscale, Invert) follow on the uint8 result, saturating
 // like imgaug; crop / pad augmenters are part of the matrix.
 #include "common.h"
+#include <cstdlib>
 
 // Per-sample record, STP_AUG_RECORD = 24 floats (integers are stored as exactly representable floats):
 //   0-5   2x3 output->input matrix
@@ -291,6 +292,116 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i;
 }
 
+// one output element (image n, row y, column x, channel c) the direct way: K x K byte loads from global memory (median: 8 passes over them)
+__device__ __forceinline__ uint8_t filter_one(const uint8_t* __restrict__ src, const int32_t* __restrict__ r, int n, int y, int x, int c, int H, int W, int C) {
+  const int K = r[0];
+  const int rad = K >> 1;
+  const uint8_t* b = src + (int64_t)n * H * W * C + c;
+  if (r[1] == 0) {
+    int acc = 0;
+    for (int ky = 0; ky < K; ++ky) {
+      const int yy = reflect101(y + ky - rad, H);
+      for (int kx = 0; kx < K; ++kx) acc += r[4 + ky * K + kx] * (int)b[((int64_t)yy * W + reflect101(x + kx - rad, W)) * C];
+    }
+    return (uint8_t)min(max((acc + 8192) >> 14, 0), 255);
+  }
+  // median of K*K bytes by counting: the smallest value v with #(values <= v) > K*K/2
+  int lo = 0, hi = 255;
+  const int need = (K * K) / 2 + 1;
+  while (lo < hi) {            // binary search over the value range, one pass over the window per step
+    const int mid = (lo + hi) >> 1;
+    int cnt = 0;
+    for (int ky = 0; ky < K; ++ky) {
+      const int yy = reflect101(y + ky - rad, H);
+      for (int kx = 0; kx < K; ++kx) cnt += (int)b[((int64_t)yy * W + reflect101(x + kx - rad, W)) * C] <= mid;
+    }
+    if (cnt >= need) hi = mid; else lo = mid + 1;
+  }
+  return (uint8_t)lo;
+}
+
+// Round 6: the linear filters on a 64 x 16 pixel tile staged in LDS.  The element-per-thread kernel above was the largest non-GEMM launch
+// of configs[4]'s step (534 us for 8 x 768 x 768 x 3 with the S4 GaussianBlur, K = 5 .. 11: K^2 byte loads through reflect-101 index
+// arithmetic, a weight load and a quarter-rate 32-bit multiply per tap and element).  Here the tile's (16 + K - 1) x (64 + K - 1) patch
+// goes to LDS once as one plane per channel (border reflection paid once per patch byte); a thread owns FOUR adjacent pixels of a row: per
+// kernel row it reads 16 patch bytes as 4 aligned dwords and feeds every byte to the <= 4 outputs that use it with v_mad_i32_i24
+// (weights are wave-uniform: scalar loads; |weight| < 2^23 / 16384 = 512, far above every filter of the catalogue), K a compile-time
+// constant per image (uniform branch).  Same integers as the direct form: the sums are exact in any order.
+#define FT_W 64
+#define FT_H 16
+#define FT_PITCH 80      // bytes per patch row: 64 + 12 columns of the widest kernel, padded for the dword reads (col0 <= 60, 16 bytes)
+#define FT_ROWS 28       // 16 + 12
+template <int K>
+__device__ __forceinline__ void filter_tile_linear(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const int32_t* __restrict__ r, int n,
+                                                   int ty0, int tx0, int H, int W, int C, uint8_t* patch) {
+  constexpr int R = K / 2;
+  const int rows = min(FT_H, H - ty0) + K - 1, cols = min(FT_W, W - tx0) + K - 1;
+  const uint8_t* img = src + (int64_t)n * H * W * C;
+  // patch[c][row][col] = image(reflect(ty0 - R + row), reflect(tx0 - R + col), c); channel fastest in the loop = the order in memory
+  for (int i = threadIdx.x; i < rows * cols * C; i += 256) {
+    const int c = i % C, pc = i / C;
+    const int row = pc / cols, col = pc - row * cols;
+    patch[(c * FT_ROWS + row) * FT_PITCH + col] = img[((int64_t)reflect101(ty0 - R + row, H) * W + reflect101(tx0 - R + col, W)) * C + c];
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx0 = (threadIdx.x & 15) * 4;
+  const int y = ty0 + ly, x = tx0 + lx0;
+  if (y < H && x < W) {
+    const int32_t* w = r + 4;
+    for (int c = 0; c < C; ++c) {
+      int acc[4] = {0, 0, 0, 0};
+      const uint8_t* pl = patch + (c * FT_ROWS + ly) * FT_PITCH + lx0;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(pl + ky * FT_PITCH);
+        uint32_t d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (j * 4 < K + 3) ? q[j] : 0u;
+        int b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[j] = (int)__builtin_amdgcn_ubfe(d[j >> 2], 8 * (j & 3), 8);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int wt = w[ky * K + kx];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[p] += __mul24(wt, b[p + kx]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (x + p < W) dst[(((int64_t)n * H + y) * W + x + p) * C + c] = (uint8_t)min(max((acc[p] + 8192) >> 14, 0), 255);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void filter_u8_tile_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                             const int32_t* __restrict__ prm, int H, int W, int C) {
+  __shared__ __attribute__((aligned(16))) uint8_t patch[4 * FT_ROWS * FT_PITCH];
+  const int n = blockIdx.z, ty0 = blockIdx.y * FT_H, tx0 = blockIdx.x * FT_W;
+  const int32_t* r = prm + (size_t)n * STP_FILTER_RECORD;
+  const int K = r[0], mode = r[1];
+  if (K > 0 && mode == 0 && (K & 1) && K <= 13 && C <= 4) {
+    switch (K) {
+      case 1: filter_tile_linear<1>(src, dst, r, n, ty0, tx0, H, W, C, patch); break;
+      case 3: filter_tile_linear<3>(src, dst, r, n, ty0, tx0, H, W, C, patch); break;
+      case 5: filter_tile_linear<5>(src, dst, r, n, ty0, tx0, H, W, C, patch); break;
+      case 7: filter_tile_linear<7>(src, dst, r, n, ty0, tx0, H, W, C, patch); break;
+      case 9: filter_tile_linear<9>(src, dst, r, n, ty0, tx0, H, W, C, patch); break;
+      case 11: filter_tile_linear<11>(src, dst, r, n, ty0, tx0, H, W, C, patch); break;
+      default: filter_tile_linear<13>(src, dst, r, n, ty0, tx0, H, W, C, patch); break;
+    }
+    return;
+  }
+  // no filter (copy), the median, or a shape the tile form does not serve: element by element over the tile
+  const int th = min(FT_H, H - ty0), tw = min(FT_W, W - tx0);
+  for (int i = threadIdx.x; i < th * tw * C; i += 256) {
+    const int c = i % C, pc = i / C;
+    const int y = ty0 + pc / tw, x = tx0 + pc % tw;
+    const int64_t o = (((int64_t)n * H + y) * W + x) * C + c;
+    dst[o] = K <= 0 ? src[o] : filter_one(src, r, n, y, x, c, H, W, C);
+  }
+}
+
 __global__ __launch_bounds__(256) void filter_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         const int32_t* __restrict__ prm, int N, int H, int W, int C) {
   const int64_t total = (int64_t)N * H * W * C;
@@ -300,39 +411,20 @@ __global__ __launch_bounds__(256) void filter_u8_kernel(const uint8_t* __restric
     const int y = (int)((i / ((int64_t)C * W)) % H);
     const int n = (int)(i / ((int64_t)C * W * H));
     const int32_t* r = prm + (size_t)n * STP_FILTER_RECORD;
-    const int K = r[0];
-    if (K <= 0) { dst[i] = src[i]; continue; }
-    const int rad = K >> 1;
-    const uint8_t* b = src + (int64_t)n * H * W * C + c;
-    if (r[1] == 0) {
-      int acc = 0;
-      for (int ky = 0; ky < K; ++ky) {
-        const int yy = reflect101(y + ky - rad, H);
-        for (int kx = 0; kx < K; ++kx) acc += r[4 + ky * K + kx] * (int)b[((int64_t)yy * W + reflect101(x + kx - rad, W)) * C];
-      }
-      dst[i] = (uint8_t)min(max((acc + 8192) >> 14, 0), 255);
-    } else {
-      // median of K*K bytes by counting: the smallest value v with #(values <= v) > K*K/2
-      int hist_lo = 0, lo = 0, hi = 255;
-      const int need = (K * K) / 2 + 1;
-      while (lo < hi) {            // binary search over the value range, one pass over the window per step
-        const int mid = (lo + hi) >> 1;
-        int cnt = 0;
-        for (int ky = 0; ky < K; ++ky) {
-          const int yy = reflect101(y + ky - rad, H);
-          for (int kx = 0; kx < K; ++kx) cnt += (int)b[((int64_t)yy * W + reflect101(x + kx - rad, W)) * C] <= mid;
-        }
-        if (cnt >= need) hi = mid; else lo = mid + 1;
-      }
-      (void)hist_lo;
-      dst[i] = (uint8_t)lo;
-    }
+    dst[i] = r[0] <= 0 ? src[i] : filter_one(src, r, n, y, x, c, H, W, C);
   }
 }
 
 extern "C" int stp_filter_u8(const uint8_t* src, uint8_t* dst, const int32_t* params, int32_t N, int32_t H, int32_t W, int32_t C,
                              void* stream) {
   if (!src || !dst || !params || src == dst || N <= 0 || H <= 0 || W <= 0 || C <= 0) return STP_E_BADARG;
+  static const bool tile_on = !(getenv("STP_FILTER_TILE") && atoi(getenv("STP_FILTER_TILE")) == 0);
+  const int gx = (W + FT_W - 1) / FT_W, gy = (H + FT_H - 1) / FT_H;
+  if (tile_on && C <= 4 && N <= 65535 && gy <= 65535) {
+    hipLaunchKernelGGL(filter_u8_tile_kernel, dim3(gx, gy, N), dim3(256), 0, (hipStream_t)stream, src, dst, params, H, W, C);
+    STP_LAUNCH_CHECK();
+    return STP_OK;
+  }
   int64_t g = ((int64_t)N * H * W * C + 255) / 256;
   if (g > 16384) g = 16384;
   hipLaunchKernelGGL(filter_u8_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, src, dst, params, N, H, W, C);

@@ -2922,7 +2922,8 @@ def test_neighbourhood_filters_bit_exact(ops):
             recs[:f.shape[0], i] = f[:, 0]
     assert passes == 2 and recs[0, 0, 0] == 9 and recs[0, 7, 0] == 13 and recs[1, 7, 0] == 3 and recs[0, 8, 0] == 0
     assert recs[0, 0, 4:4 + 81].sum() == 16384 and recs[0, 2, 0] == 5 and recs[0, 3, 1] == 1     # unit DC gain; even box in odd window
-    for (h, w, c) in [(21, 30, 3), (5, 4, 1)]:
+    # (round 6: the linear filters run on 64 x 16 tiles staged in LDS - several tiles with ragged edges, four channels, maps smaller than the kernel)
+    for (h, w, c) in [(21, 30, 3), (5, 4, 1), (37, 150, 3), (18, 66, 4)]:
         img = rng.randint(0, 256, size=(len(specs), h, w, c)).astype(np.uint8)
         cur = keep(torch.from_numpy(img).to(DEV))
         ref = img
